@@ -1,0 +1,418 @@
+"""CPU oracle for the ConvBPDN hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a plain-NumPy restatement of the arithmetic performed by the
+reference (bwohlberg/sporco, mounted read-only at /root/reference) on the
+FFT-domain convolutional sparse coding path.  It exists so that the HIP
+kernels of ``sporco_amd`` can be checked on a GPU box where the reference
+itself is not present.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it; the product package never
+does (``sporco_amd`` fails loudly when its HIP library is missing).
+
+Pinning: ``oracle/make_golden.py`` runs the *unmodified* reference in the
+authoring container and stores its outputs under ``tests/golden/``;
+``tests/test_oracle_vs_golden.py`` checks every function here against those
+fixtures (so parity is pinned to the reference itself, to tolerance --
+the reference path is floating point and its own tests pin it to tolerance
+only).
+
+All arrays use the reference's internal 5-D layout
+``(H, W, C, N, K)`` = SPORCO ``(N0, N1, C, K, M)`` (``sporco/cnvrep.py:86-111``),
+filter index fastest.  Letters follow BASELINE.json: N images, K filters.
+
+Every function cites the reference lines it follows.
+"""
+
+import time
+
+import numpy as np
+
+AX_SPATIAL = (0, 1)   # cri.axisN for dimN = 2   (sporco/cnvrep.py:190)
+AX_C = 2              # cri.axisC                 (sporco/cnvrep.py:191)
+AX_N = 3              # cri.axisK (image index)   (sporco/cnvrep.py:192)
+AX_K = 4              # cri.axisM (filter index)  (sporco/cnvrep.py:193)
+
+
+# ---------------------------------------------------------------------------
+# dtype helpers (sporco/fft.py:44-101 complex_dtype / real_dtype)
+# ---------------------------------------------------------------------------
+
+def complex_dtype(dtype):
+    return (np.zeros(1, dtype=dtype) + 1j).dtype
+
+
+def real_dtype(dtype):
+    return np.zeros(1, dtype=dtype).real.dtype
+
+
+# ---------------------------------------------------------------------------
+# FFT primitives (sporco/fft.py:257-314; numpy fallback :631-639)
+# ---------------------------------------------------------------------------
+
+def rfftn2(a, s=None):
+    """Unnormalised 2-D real FFT over axes (0, 1), result cast to the complex
+    type matching ``a`` -- sporco/fft.py:631-634 (`_rfftn`)."""
+    return np.fft.rfftn(a, s, AX_SPATIAL).astype(complex_dtype(a.dtype))
+
+
+def irfftn2(af, s):
+    """Inverse of :func:`rfftn2`; ``s`` = (H, W) is mandatory because W may be
+    odd -- sporco/fft.py:636-639 (`_irfftn`)."""
+    return np.fft.irfftn(af, s, AX_SPATIAL).astype(real_dtype(af.dtype))
+
+
+def rfl2norm2(xf, xs):
+    """Squared l2 norm of the spatial-domain array whose rfftn2 is ``xf``
+    (half-spectrum Parseval with weights 1,2,...,2,(1)) -- sporco/fft.py:449-484.
+    ``xs`` is the spatial shape tuple (only xs[0], xs[1] are used)."""
+    scl = 1.0 / (xs[0] * xs[1])
+    w = xs[1]
+    n0 = np.linalg.norm(xf[:, 0])
+    idx1 = (w + 1) // 2
+    n1 = np.linalg.norm(xf[:, 1:idx1])
+    n2 = np.linalg.norm(xf[:, -1:]) if w % 2 == 0 else 0.0
+    return scl * (n0 ** 2 + 2.0 * n1 ** 2 + n2 ** 2)
+
+
+# ---------------------------------------------------------------------------
+# linalg primitives (sporco/linalg.py)
+# ---------------------------------------------------------------------------
+
+def inner(x, y, axis=-1):
+    """sum(x*y) over ``axis`` with keepdims, no conjugation --
+    sporco/linalg.py:41-88."""
+    return np.sum(x * y, axis=axis, keepdims=True)
+
+
+def solvedbi_sm_c(ah, a, rho, axis=AX_K):
+    """c = ah / (ah.a + rho) -- sporco/linalg.py:277-297."""
+    return ah / (inner(ah, a, axis=axis) + rho)
+
+
+def solvedbi_sm(ah, rho, b, c=None, axis=AX_K):
+    """Solve (rho I + a a^H) x = b per pixel by Sherman-Morrison --
+    sporco/linalg.py:232-273."""
+    a = np.conj(ah)
+    if c is None:
+        c = solvedbi_sm_c(ah, a, rho, axis)
+    return (b - (a * inner(c, b, axis=axis))) / rho
+
+
+def rrs(ax, b):
+    """Relative residual ||b - ax|| / max(||ax||, ||b||) --
+    sporco/linalg.py:883-910."""
+    nrm = max(np.linalg.norm(ax.ravel()), np.linalg.norm(b.ravel()))
+    if nrm == 0.0:
+        return 0.0
+    return np.linalg.norm((ax - b).ravel()) / nrm
+
+
+# ---------------------------------------------------------------------------
+# proximal operators (sporco/prox/_lp.py, sporco/prox/_l21.py, sporco/array.py)
+# ---------------------------------------------------------------------------
+
+def prox_l1(v, alpha):
+    """Soft threshold sign(v) * max(|v| - alpha, 0), real input --
+    sporco/prox/_lp.py:174-181."""
+    return np.sign(v) * np.clip(np.abs(v) - alpha, 0, float('Inf'))
+
+
+def zdivide(x, y):
+    """x / y with 0 where y == 0 -- sporco/array.py:119-137."""
+    return np.divide(x, y, out=np.zeros_like(x), where=(y != 0))
+
+
+def prox_l2(v, alpha, axis=None):
+    """Vector shrinkage v/||v|| * max(0, ||v|| - alpha) over ``axis`` --
+    sporco/prox/_lp.py:283-290."""
+    a = np.sqrt(np.sum(v ** 2, axis=axis, keepdims=True))
+    b = np.maximum(0, a - alpha)
+    b = zdivide(b, a)
+    return np.asarray(b * v, dtype=v.dtype)
+
+
+def prox_sl1l2(v, alpha, beta, axis=None):
+    """prox of alpha*l1 + beta*l2 = S_2,beta(S_1,alpha(v)) --
+    sporco/prox/_l21.py:51-88."""
+    return prox_l2(prox_l1(v, alpha), beta, axis)
+
+
+# ---------------------------------------------------------------------------
+# ADMM ConvBPDN / ConvBPDNJoint (sporco/admm/cbpdn.py + sporco/admm/admm.py)
+# ---------------------------------------------------------------------------
+
+def default_rho_xi(lmbda):
+    """rho_xi default -- sporco/admm/cbpdn.py:588-591."""
+    if lmbda != 0.0:
+        return float(1.0 + 18.3 ** (np.log10(lmbda) + 1.0))
+    return 1.0
+
+
+def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
+               rho=None, rlx=1.8, auto_rho=True, rho_period=1,
+               rho_tau=1000.0, rho_mu=1.2, rho_xi=None, auto_scaling=True,
+               std_residuals=False, abs_tol=0.0, rel_tol=1e-3,
+               nonneg=False, nobndry=False, wl1=1.0, wl21=1.0,
+               gevaly=False, fevalx=True, stats=True, Y0=None, U0=None,
+               time_budget=None):
+    """Run ADMM ConvBPDN (``mu is None``) or ConvBPDNJoint on 5-D arrays.
+
+    ``D``: (dH, dW, 1, 1, K);  ``S``: (H, W, C, N, 1).  Single-channel
+    dictionary only (Cd = 1), i.e. the ``solvedbi_sm`` branch of
+    sporco/admm/cbpdn.py:274-276.
+
+    Follows, per iteration, sporco/admm/admm.py:331-377:
+      Yprev=Y; xstep (cbpdn.py:267-281); relax_AX (admm.py:877-885);
+      ystep (cbpdn.py:614-620 / :785-794 then :297-311); ustep (admm.py:434-437);
+      compute_residuals (admm.py:462-486 with :959-983);
+      eval_objfn (cbpdn.py:325-344, :624-630, :798-807);
+      update_rho (admm.py:549-575); stop test (admm.py:375-377).
+
+    Returns a dict with final X, Y, U, Xf and the per-iteration traces.
+    """
+    dtype = np.dtype(dtype)
+    rdt = real_dtype(dtype).type
+    D = np.asarray(D, dtype=dtype)
+    S = np.asarray(S, dtype=dtype)
+    H, W = S.shape[0], S.shape[1]
+    K = D.shape[AX_K]
+    shpX = (H, W, S.shape[AX_C], S.shape[AX_N], K)
+    Nx = int(np.prod(shpX))
+
+    lmbda = rdt(lmbda)
+    joint = mu is not None
+    if joint:
+        mu = dtype.type(mu)
+    # penalty parameter default: cbpdn.py:584
+    rho = rdt(50.0 * lmbda + 1.0) if rho is None else rdt(rho)
+    if rho_xi is None:
+        rho_xi = default_rho_xi(lmbda)
+    rho_xi = rdt(rho_xi)
+    rho_tau = rdt(rho_tau)
+    rho_mu = rdt(rho_mu)
+    rlx = rdt(rlx)
+    wl1 = np.asarray(wl1, dtype=real_dtype(dtype))
+    wl21 = np.asarray(wl21, dtype=dtype)
+
+    # cbpdn.py:231, :247-249
+    Sf = rfftn2(S)
+    Df = rfftn2(D, (H, W))
+    DSf = np.conj(Df) * Sf
+
+    Y = np.zeros(shpX, dtype=dtype) if Y0 is None else \
+        np.asarray(Y0).astype(dtype, copy=True)
+    if U0 is not None:
+        U = np.asarray(U0).astype(dtype, copy=True)
+    elif Y0 is None:
+        U = np.zeros(shpX, dtype=dtype)
+    else:
+        U = (lmbda / rho) * np.sign(Y)           # cbpdn.py:601-610
+
+    tr = {k: [] for k in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl',
+                          'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho')}
+    X = None
+    Xf = None
+    t0 = time.perf_counter()
+    k = 0
+    for k in range(maxiter):
+        Yprev = Y.copy()
+        # -- xstep: cbpdn.py:267-281
+        YU = Y - U
+        b = DSf + rho * rfftn2(YU)
+        Xf = solvedbi_sm(Df, rho, b, None, AX_K).astype(b.dtype)
+        X = irfftn2(Xf, (H, W))
+        # -- relax_AX: admm.py:877-885
+        AXnr = X
+        AX = X if rlx == 1.0 else rlx * X + (1 - rlx) * Y
+        # -- ystep
+        if joint:
+            Y = prox_sl1l2(AX + U, (lmbda / rho) * wl1, (mu / rho) * wl21,
+                           axis=AX_C)
+        else:
+            Y = prox_l1(AX + U, (lmbda / rho) * wl1)
+        if nonneg:
+            Y[Y < 0.0] = 0.0
+        if nobndry:
+            Y[1 - D.shape[0]:] = 0.0
+            Y[:, 1 - D.shape[1]:] = 0.0
+        # -- ustep: admm.py:434-437
+        U = U + (AX - Y)
+        if stats or auto_rho:
+            # -- compute_residuals: admm.py:462-486
+            nAX, nY = np.linalg.norm(AXnr), np.linalg.norm(Y)
+            nr = np.linalg.norm(AXnr - Y)
+            ns = np.linalg.norm(rho * (Yprev - Y))
+            if std_residuals:
+                r, s = nr, ns
+                epri = np.sqrt(Nx) * abs_tol + max(nAX, nY) * rel_tol
+                edua = np.sqrt(Nx) * abs_tol + rho * np.linalg.norm(U) * rel_tol
+            else:
+                rn = max(nAX, nY)
+                rn = 1.0 if rn == 0.0 else rn
+                sn = rho * np.linalg.norm(U)
+                sn = 1.0 if sn == 0.0 else sn
+                r, s = nr / rn, ns / sn
+                epri = np.sqrt(Nx) * abs_tol / rn + rel_tol
+                edua = np.sqrt(Nx) * abs_tol / sn + rel_tol
+        if stats:
+            # -- eval_objfn: cbpdn.py:325-344
+            fvar = Xf if fevalx else rfftn2(Y)
+            Ef = inner(Df, fvar, axis=AX_K) - Sf
+            dfd = rfl2norm2(Ef, S.shape) / 2.0
+            gvar = Y if gevaly else X
+            rl1 = np.linalg.norm((wl1 * gvar).ravel(), 1)
+            if joint:
+                rl21 = np.sum(wl21 * np.sqrt(np.sum(gvar ** 2, axis=AX_C)))
+                obj = dfd + lmbda * rl1 + mu * rl21
+            else:
+                rl21 = 0.0
+                obj = dfd + lmbda * rl1
+            for key, val in (('ObjFun', obj), ('DFid', dfd), ('RegL1', rl1),
+                             ('RegL21', rl21), ('PrimalRsdl', r),
+                             ('DualRsdl', s), ('EpsPrimal', epri),
+                             ('EpsDual', edua), ('Rho', rho)):
+                tr[key].append(float(val))
+        # -- update_rho: admm.py:549-575
+        if auto_rho and k != 0 and (k + 1) % rho_period == 0:
+            if auto_scaling:
+                if s == 0.0 or r == 0.0:
+                    rhomlt = rho_tau
+                else:
+                    rhomlt = np.sqrt(r / (s * rho_xi) if r > s * rho_xi
+                                     else (s * rho_xi) / r)
+                    if rhomlt > rho_tau:
+                        rhomlt = rho_tau
+            else:
+                rhomlt = rho_tau
+            rsf = 1.0
+            if r > rho_xi * rho_mu * s:
+                rsf = rhomlt
+            elif s > (rho_mu / rho_xi) * r:
+                rsf = 1.0 / rhomlt
+            rho = rho * rdt(rsf)
+            U = U / rsf
+        if (stats or auto_rho) and r < epri and s < edua:
+            break
+        if time_budget is not None and time.perf_counter() - t0 > time_budget:
+            break
+    elapsed = time.perf_counter() - t0
+    out = {key: np.array(val) for key, val in tr.items()}
+    out.update(X=X, Y=Y, U=U, Xf=Xf, Df=Df, Sf=Sf, rho=rho, iters=k + 1,
+               seconds=elapsed)
+    return out
+
+
+def reconstruct(Df, X, s):
+    """irfftn(sum_k Df * rfftn(X)) -- sporco/admm/cbpdn.py:373-380."""
+    Xf = rfftn2(X)
+    return irfftn2(np.sum(Df * Xf, axis=AX_K), s)
+
+
+# ---------------------------------------------------------------------------
+# PGM (FISTA) ConvBPDN (sporco/pgm/cbpdn.py + sporco/pgm/pgm.py)
+# ---------------------------------------------------------------------------
+
+def pgm_cbpdn(D, S, lmbda, dtype=np.float32, maxiter=50, L=500.0,
+              rel_tol=1e-3, nonneg=False, nobndry=False, wl1=1.0,
+              stats=True, time_budget=None):
+    """FISTA ConvBPDN with Nesterov momentum, fixed L (no backtracking).
+
+    Follows sporco/pgm/pgm.py:328-370 with PGMDFT.xstep (:779-811),
+    PGMDFT.ystep (:815-831), MomentumNesterov.update
+    (sporco/pgm/momentum.py:65-70), grad_f/prox_g/rsdl/eval_objfn of
+    sporco/pgm/cbpdn.py:263-356.
+    """
+    dtype = np.dtype(dtype)
+    D = np.asarray(D, dtype=dtype)
+    S = np.asarray(S, dtype=dtype)
+    H, W = S.shape[0], S.shape[1]
+    K = D.shape[AX_K]
+    shpX = (H, W, S.shape[AX_C], S.shape[AX_N], K)
+    lmbda = dtype.type(lmbda)
+    L = dtype.type(L)
+    wl1 = np.asarray(wl1, dtype=dtype)
+
+    Sf = rfftn2(S)
+    Df = rfftn2(D, (H, W))
+    X = np.zeros(shpX, dtype=dtype)
+    Xf = rfftn2(X)
+    Yf = Xf.copy()
+    Yfprv = Yf.copy() + 1e5                        # pgm/cbpdn.py:233
+    t = 1.0
+    tr = {k: [] for k in ('ObjFun', 'DFid', 'RegL1', 'Rsdl')}
+    t0 = time.perf_counter()
+    k = 0
+    for k in range(maxiter):
+        Xfprv = Xf.copy()                           # pgm.py:835-846
+        if stats:
+            Yfprv = Yf.copy()
+        # xstep: pgm.py:779-811
+        gradf = np.conj(Df) * (inner(Df, Yf, axis=AX_K) - Sf)
+        Vf = Yf - (1.0 / L) * gradf
+        V = irfftn2(Vf.astype(complex_dtype(dtype)), (H, W))
+        X = prox_l1(V, (lmbda / L) * wl1)
+        if nonneg:
+            X[X < 0.0] = 0.0
+        if nobndry:
+            X[1 - D.shape[0]:] = 0.0
+            X[:, 1 - D.shape[1]:] = 0.0
+        Xf = rfftn2(X)
+        # ystep: pgm.py:815-831, momentum.py:65-70
+        tprv = t
+        t = 0.5 * float(1.0 + np.sqrt(1.0 + 4.0 * t ** 2))
+        Yf = Xf + ((tprv - 1.0) / t) * (Xf - Xfprv)
+        if stats:
+            rsdl = rfl2norm2(Xf - Yfprv, X.shape)   # pgm/cbpdn.py:314-320
+            Ef = inner(Df, Xf, axis=AX_K) - Sf
+            dfd = rfl2norm2(Ef, S.shape) / 2.0
+            rl1 = np.linalg.norm((wl1 * X).ravel(), 1)
+            tr['ObjFun'].append(float(dfd + lmbda * rl1))
+            tr['DFid'].append(float(dfd))
+            tr['RegL1'].append(float(rl1))
+            tr['Rsdl'].append(float(rsdl))
+            if rsdl < rel_tol:
+                break
+        if time_budget is not None and time.perf_counter() - t0 > time_budget:
+            break
+    elapsed = time.perf_counter() - t0
+    out = {key: np.array(val) for key, val in tr.items()}
+    out.update(X=X, Xf=Xf, Yf=Yf, Df=Df, Sf=Sf, iters=k + 1, seconds=elapsed)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Dictionary update pieces (sporco/cnvrep.py, sporco/pgm/ccmod.py)
+# ---------------------------------------------------------------------------
+
+def zpad(v, Nv):
+    """Zero-pad the spatial axes of v to Nv -- sporco/cnvrep.py:704-726."""
+    vp = np.zeros(tuple(Nv) + v.shape[len(Nv):], dtype=v.dtype)
+    vp[tuple(slice(0, x) for x in v.shape)] = v
+    return vp
+
+
+def bcrop(v, dsz):
+    """Crop to the filter support (single-size dictionaries only) --
+    sporco/cnvrep.py:729-795."""
+    return v[:dsz[0], :dsz[1]]
+
+
+def normalise(v, dimN=2):
+    """Unit l2 norm per filter over spatial+channel axes; zero filters are
+    left unchanged -- sporco/cnvrep.py:673-700."""
+    axisN = tuple(range(0, dimN))
+    vn = np.sqrt(np.sum(v ** 2, axisN, keepdims=True))
+    vn[vn == 0] = 1.0
+    return np.asarray(v / vn, dtype=v.dtype)
+
+
+def pcn(x, dsz, Nv, dimN=2, dimC=1, crp=False, zm=False):
+    """Constraint-set projection normalise(zpad(bcrop(x))) (optionally cropped
+    output, optional zero-mean) -- sporco/cnvrep.py:868-913 (Pcn), :953-1074 (_Pcn*).
+    zeromean (cnvrep.py:609-670) subtracts the mean over the filter support only,
+    which for a single-size dictionary equals subtracting it before zero-padding."""
+    v = bcrop(x, dsz)
+    if zm:
+        v = v - np.mean(v, axis=tuple(range(dimN)), keepdims=True)
+    if not crp:
+        v = zpad(v, Nv)
+    return normalise(v, dimN + dimC)

@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures under tests/golden/ from the UNMODIFIED reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs only in the authoring container, where the
+reference is mounted read-only at /root/reference (it does not exist on the
+GPU box, so nothing under tests/ -m gpu, smoke() or bench.py reads it).
+
+    python oracle/make_golden.py            # (re)writes tests/golden/*.npz
+
+The reference is pure Python; three of its import-time dependencies
+(`future`, `imageio`, `filetype`) are absent from this image and are
+replaced by the tiny stand-ins in oracle/_stubs.
+pyFFTW is absent too, so the reference runs on its own numpy.fft fallback
+(sporco/fft.py:593-639).
+
+Each fixture stores the seeded inputs, the option values and the reference
+outputs (final iterates plus per-iteration IterationStats traces).
+"""
+
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get('SPORCO_REFERENCE', '/root/reference')
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, '_stubs'))
+warnings.filterwarnings('ignore')
+
+from sporco.admm import cbpdn as ref_cbpdn            # noqa: E402
+from sporco.pgm import cbpdn as ref_pgm_cbpdn         # noqa: E402
+from sporco.pgm.backtrack import BacktrackStandard, BacktrackRobust  # noqa: E402
+from sporco.pgm.momentum import MomentumLinear, MomentumGenLinear    # noqa: E402
+from sporco.pgm.stepsize import StepSizePolicyBB, StepSizePolicyCauchy  # noqa: E402
+from sporco.dictlrn import cbpdndl as ref_cbpdndl     # noqa: E402
+from sporco.pgm import ccmod as ref_pgm_ccmod         # noqa: E402
+from sporco import linalg as ref_linalg               # noqa: E402
+from sporco import prox as ref_prox                   # noqa: E402
+from sporco import fft as ref_fft                     # noqa: E402
+from sporco import cnvrep as ref_cnvrep               # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('%-34s %8.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+def itstat_dict(b, prefix='it_'):
+    its = b.getitstat()
+    out = {}
+    for f in its._fields:
+        if f == 'Time':
+            continue
+        v = getattr(its, f)
+        if len(v) and v[0] is None:
+            continue
+        out[prefix + f] = np.asarray(v, dtype=np.float64)
+    return out
+
+
+# ---------------------------------------------------------------------------
+def admm_case(name, D, S, lmbda, optd, dimK=None, joint_mu=None):
+    if joint_mu is None:
+        opt = ref_cbpdn.ConvBPDN.Options(optd)
+        b = ref_cbpdn.ConvBPDN(D, S, lmbda, opt, dimK=dimK)
+    else:
+        opt = ref_cbpdn.ConvBPDNJoint.Options(optd)
+        b = ref_cbpdn.ConvBPDNJoint(D, S, lmbda, joint_mu, opt, dimK=dimK)
+    b.solve()
+    extra = {}
+    for key, val in optd.items():
+        if isinstance(val, np.ndarray):
+            extra['optarr_' + key] = val.copy()
+    save(name, D=D, S=S, lmbda=np.float64(lmbda),
+         mu=np.float64(-1.0 if joint_mu is None else joint_mu),
+         dimK=np.int64(-1 if dimK is None else dimK),
+         X=b.X, Y=b.Y, U=b.U, Xf=b.Xf, rho_final=np.float64(b.rho),
+         k_final=np.int64(b.k), recon=b.reconstruct(),
+         **extra, **itstat_dict(b))
+
+
+def gen_admm():
+    np.random.seed(12345)
+    D = np.random.randn(5, 5, 4)
+    S = np.random.randn(16, 16, 2)
+    # default options (AutoRho on, relaxation 1.8), both precisions
+    admm_case('admm_default_f64', D, S, 0.1, {'MaxMainIter': 30})
+    admm_case('admm_default_f32', D, S, 0.1,
+              {'MaxMainIter': 30, 'DataType': np.float32})
+    # LinSolveCheck + fixed rho + no relaxation
+    admm_case('admm_fixedrho_f64', D, S, 0.05,
+              {'MaxMainIter': 25, 'rho': 2.0, 'RelaxParam': 1.0,
+               'AutoRho': {'Enabled': False}, 'LinSolveCheck': True})
+    # non-default AutoRho: period 3, no autoscaling, std residuals
+    admm_case('admm_autorho_std_f64', D, S, 0.1,
+              {'MaxMainIter': 30, 'AutoRho': {'Period': 3, 'AutoScaling': False,
+                                             'Scaling': 2.0, 'RsdlRatio': 1.5,
+                                             'StdResiduals': True},
+               'AbsStopTol': 1e-6})
+    # odd sizes, single image (dimK inferred 0), NonNeg + NoBndryCross
+    S2 = np.random.randn(15, 17)
+    admm_case('admm_odd_nonneg_nobndry_f64', D, S2, 0.1,
+              {'MaxMainIter': 30, 'NonNegCoef': True, 'NoBndryCross': True})
+    # L1Weight per filter + AuxVarObj (objective from Y)
+    w = np.abs(np.random.randn(1, 1, 1, 1, 4)) + 0.5
+    admm_case('admm_l1weight_auxvar_f64', D, S, 0.1,
+              {'MaxMainIter': 25, 'L1Weight': w, 'AuxVarObj': True})
+    # spatially varying L1Weight, already in internal 5-D layout (H, W, 1, N, 1)
+    w2 = np.abs(np.random.randn(16, 16, 1, 2, 1)) + 0.5
+    admm_case('admm_l1weight_spatial_f64', D, S, 0.1,
+              {'MaxMainIter': 20, 'L1Weight': w2})
+    # multi-channel signal, single-channel dictionary, multiple images
+    S3 = np.random.randn(16, 12, 3, 2)
+    admm_case('admm_multichan_f64', D, S3, 0.1, {'MaxMainIter': 25})
+    # joint l2,1
+    admm_case('admm_joint_f64', D, S3, 0.1, {'MaxMainIter': 25}, joint_mu=0.05)
+    admm_case('admm_joint_f32', D, S3, 0.1,
+              {'MaxMainIter': 25, 'DataType': np.float32}, joint_mu=0.05)
+    # L21Weight must broadcast against both (H,W,1,N,K) (prox) and (H,W,N,K)
+    # (objective, no keepdims) in the reference => trailing (N, K) shape
+    wj = np.abs(np.random.randn(2, 4)) + 0.5
+    admm_case('admm_joint_l21weight_f64', D, S3, 0.1,
+              {'MaxMainIter': 20, 'L21Weight': wj, 'NonNegCoef': True},
+              joint_mu=0.1)
+    # warm start through Y0 and U0.  (Y0 alone raises AttributeError in the
+    # reference: ConvBPDN.uinit, cbpdn.py:601-610, reads self.lmbda before
+    # ConvBPDN.__init__ has set it.)
+    Y0 = np.random.randn(16, 16, 1, 2, 4) * (np.random.rand(16, 16, 1, 2, 4) > 0.8)
+    U0 = 0.1 * np.random.randn(16, 16, 1, 2, 4)
+    admm_case('admm_warmstart_f64', D, S, 0.1,
+              {'MaxMainIter': 15, 'Y0': Y0, 'U0': U0})
+    # default lambda (cbpdn.py:573-578)
+    b = ref_cbpdn.ConvBPDN(D, S, None, ref_cbpdn.ConvBPDN.Options({'MaxMainIter': 5}))
+    b.solve()
+    save('admm_default_lambda', D=D, S=S, lmbda=np.float64(b.lmbda),
+         rho0=np.float64(50.0 * b.lmbda + 1.0), Y=b.Y, **itstat_dict(b))
+
+
+def gen_known_answer():
+    """Recipe of tests/admm/test_cbpdn.py:156-176 (sparse synthesis, fixed rho)."""
+    np.random.seed(12345)
+    N, M, Nd = 64, 4, 8
+    D = np.random.randn(Nd, Nd, M)
+    X0 = np.zeros((N, N, M))
+    xr = np.random.randn(N, N, M)
+    xp = np.abs(xr) > 3
+    X0[xp] = np.random.randn(X0[xp].size)
+    S = np.sum(ref_fft.fftconv(D, X0, axes=(0, 1)), axis=2)
+    opt = ref_cbpdn.ConvBPDN.Options({'Verbose': False, 'MaxMainIter': 500,
+                                      'RelStopTol': 1e-3, 'rho': 1e-1,
+                                      'AutoRho': {'Enabled': False}})
+    b = ref_cbpdn.ConvBPDN(D, S, 1e-4, opt)
+    b.solve()
+    save('admm_known_answer_f64', D=D, S=S, X0=X0, lmbda=np.float64(1e-4),
+         Y=b.Y, k_final=np.int64(b.k), recon=b.reconstruct(), **itstat_dict(b))
+    # odd size variant: tests/admm/test_cbpdn.py:204-225
+    N = 63
+    X0 = np.zeros((N, N, M))
+    xr = np.random.randn(N, N, M)
+    xp = np.abs(xr) > 3
+    X0[xp] = np.random.randn(X0[xp].size)
+    S = np.sum(np.fft.ifftn(np.fft.fftn(D, (N, N), (0, 1)) *
+                            np.fft.fftn(X0, None, (0, 1)), None, (0, 1)).real,
+               axis=2)
+    b = ref_cbpdn.ConvBPDN(D, S, 1e-4, opt)
+    b.solve()
+    save('admm_known_answer_odd_f64', D=D, S=S, X0=X0, lmbda=np.float64(1e-4),
+         Y=b.Y, k_final=np.int64(b.k), **itstat_dict(b))
+
+
+def gen_config1():
+    """BASELINE config 1 shape: 256x256, K=32 8x8 filters, N=1, float32,
+    default options; stores traces, norms and a strided subsample of Y."""
+    rng = np.random.RandomState(12345)
+    D = rng.randn(8, 8, 32).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(256, 256).astype(np.float32)
+    opt = ref_cbpdn.ConvBPDN.Options({'MaxMainIter': 20, 'RelStopTol': 0.0})
+    b = ref_cbpdn.ConvBPDN(D, S, 0.05, opt, dimK=0)
+    b.solve()
+    Y = b.Y
+    save('admm_config1_f32', seed=np.int64(12345), lmbda=np.float64(0.05),
+         Y_sub=Y[::16, ::16].copy(), Y_l2=np.float64(np.linalg.norm(Y.astype(np.float64))),
+         Y_l1=np.float64(np.abs(Y.astype(np.float64)).sum()),
+         Y_nnz=np.int64(np.count_nonzero(Y)), **itstat_dict(b))
+    # float64 run of the same problem: the accuracy yardstick for fp32 kernels
+    opt = ref_cbpdn.ConvBPDN.Options({'MaxMainIter': 20, 'RelStopTol': 0.0,
+                                      'DataType': np.float64})
+    b = ref_cbpdn.ConvBPDN(D, S, 0.05, opt, dimK=0)
+    b.solve()
+    Y = b.Y
+    save('admm_config1_f64', seed=np.int64(12345), lmbda=np.float64(0.05),
+         Y_sub=Y[::16, ::16].copy(), Y_l2=np.float64(np.linalg.norm(Y)),
+         Y_l1=np.float64(np.abs(Y).sum()), Y_nnz=np.int64(np.count_nonzero(Y)),
+         **itstat_dict(b))
+
+
+# ---------------------------------------------------------------------------
+def pgm_case(name, D, S, lmbda, optd, tag_objs=None):
+    optd = dict(optd)
+    optd.setdefault('RelStopTol', 0.0)     # run all MaxMainIter iterations
+    opt = ref_pgm_cbpdn.ConvBPDN.Options(optd)
+    b = ref_pgm_cbpdn.ConvBPDN(D, S, lmbda, opt)
+    X = b.solve()
+    clean = {k: v for k, v in optd.items()
+             if isinstance(v, (int, float, bool))}
+    save(name, D=D, S=S, lmbda=np.float64(lmbda), X=X.copy(), Xf=b.Xf,
+         L_final=np.float64(b.L), k_final=np.int64(b.k),
+         recon=b.reconstruct(),
+         **{'opt_' + k: np.float64(v) for k, v in clean.items()},
+         **itstat_dict(b))
+
+
+def gen_pgm():
+    np.random.seed(12345)
+    D = np.random.randn(5, 5, 4)
+    S = np.random.randn(16, 16, 2)
+    pgm_case('pgm_default_f64', D, S, 0.1, {'MaxMainIter': 40, 'L': 500.0})
+    pgm_case('pgm_default_f32', D, S, 0.1,
+             {'MaxMainIter': 40, 'L': 500.0, 'DataType': np.float32})
+    pgm_case('pgm_nonneg_nobndry_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 500.0, 'NonNegCoef': True,
+              'NoBndryCross': True})
+    pgm_case('pgm_btstd_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 1.0, 'Backtrack': BacktrackStandard()})
+    pgm_case('pgm_btrobust_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 1.0, 'Backtrack': BacktrackRobust()})
+    pgm_case('pgm_momlinear_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 500.0, 'Momentum': MomentumLinear()})
+    pgm_case('pgm_momgenlinear_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 500.0, 'Momentum': MomentumGenLinear()})
+    pgm_case('pgm_stepbb_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 500.0, 'StepSizePolicy': StepSizePolicyBB()})
+    pgm_case('pgm_stepcauchy_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 500.0,
+              'StepSizePolicy': StepSizePolicyCauchy()})
+    pgm_case('pgm_monotone_f64', D, S, 0.1,
+             {'MaxMainIter': 30, 'L': 500.0, 'Monotone': True})
+    S3 = np.random.randn(16, 12, 3, 2)
+    pgm_case('pgm_multichan_f64', D, S3, 0.1, {'MaxMainIter': 30, 'L': 500.0})
+
+
+# ---------------------------------------------------------------------------
+def gen_primitives():
+    np.random.seed(12345)
+    # solvedbi_sm: shapes of tests/test_linalg.py:147-159
+    N, M, K = 16, 4, 2
+    ah = np.random.randn(N, N, 1, 1, M) + 1j * np.random.randn(N, N, 1, 1, M)
+    b = np.random.randn(N, N, 1, K, M) + 1j * np.random.randn(N, N, 1, K, M)
+    rho = 0.37
+    x = ref_linalg.solvedbi_sm(ah, rho, b, axis=4)
+    c = ref_linalg.solvedbi_sm_c(ah, np.conj(ah), rho, axis=4)
+    ip = ref_linalg.inner(ah, b, axis=4)
+    # real FFTs incl. odd sizes
+    a = np.random.randn(12, 9, 3, 2, 4)
+    af = ref_fft.rfftn(a, None, (0, 1))
+    ar = ref_fft.irfftn(af, (12, 9), (0, 1))
+    a2 = np.random.randn(16, 16, 1, 2, 4).astype(np.float32)
+    a2f = ref_fft.rfftn(a2, None, (0, 1))
+    # zero-padded dictionary transform (setdict, cbpdn.py:247)
+    d = np.random.randn(5, 5, 1, 1, 4)
+    df = ref_fft.rfftn(d, (12, 9), (0, 1))
+    # Parseval
+    nrm = ref_fft.rfl2norm2(af, a.shape, axis=(0, 1))
+    nrm_even = ref_fft.rfl2norm2(a2f, a2.shape, axis=(0, 1))
+    # prox
+    v = np.random.randn(12, 9, 3, 2, 4)
+    alpha = 0.3
+    wgt = np.abs(np.random.randn(1, 1, 1, 1, 4))
+    pl1 = ref_prox.prox_l1(v, alpha)
+    pl1w = ref_prox.prox_l1(v, alpha * wgt)
+    pl2 = ref_prox.prox_l2(v, 0.9, axis=2)
+    psl = ref_prox.prox_sl1l2(v, alpha, 0.9, axis=2)
+    vz = v.copy()
+    vz[:, :, :, 0, 0] = 0.0     # exercises the zdivide branch
+    pslz = ref_prox.prox_sl1l2(vz, alpha, 0.9, axis=2)
+    save('primitives', sm_ah=ah, sm_b=b, sm_rho=np.float64(rho), sm_x=x,
+         sm_c=c, inner_ab=ip, fft_a=a, fft_af=af, fft_ar=ar, fft_a2=a2,
+         fft_a2f=a2f, fft_d=d, fft_df=df, nrm_odd=np.float64(nrm),
+         nrm_even=np.float64(nrm_even), prox_v=v, prox_alpha=np.float64(alpha),
+         prox_w=wgt, prox_l1=pl1, prox_l1w=pl1w, prox_l2=pl2, prox_sl1l2=psl,
+         prox_vz=vz, prox_sl1l2_z=pslz)
+
+
+def gen_pcn():
+    np.random.seed(12345)
+    x = np.random.randn(16, 12, 1, 1, 6)
+    dsz = (5, 5, 6)
+    out = {}
+    for crp in (False, True):
+        for zm in (False, True):
+            y = ref_cnvrep.Pcn(x, dsz, (16, 12), dimN=2, dimC=1, crp=crp, zm=zm)
+            out['pcn_crp%d_zm%d' % (crp, zm)] = y
+    save('pcn', x=x, **out)
+
+
+def gen_dictlearn():
+    np.random.seed(12345)
+    N, M, Nd, K = 16, 4, 5, 3
+    D0 = np.random.randn(Nd, Nd, M)
+    S = np.random.randn(N, N, K)
+    lmbda = 0.1
+    for name, dt in (('cbpdndl_f64', np.float64), ('cbpdndl_f32', np.float32)):
+        opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+            {'MaxMainIter': 12, 'AccurateDFid': True},
+            xmethod='admm', dmethod='pgm')
+        b = ref_cbpdndl.ConvBPDNDictLearn(D0.astype(dt), S.astype(dt), lmbda,
+                                          opt, xmethod='admm', dmethod='pgm')
+        D1 = b.solve()
+        save(name, D0=D0, S=S, lmbda=np.float64(lmbda), D1=D1,
+             X=b.getcoef(), **itstat_dict(b))
+    # PGM D-step alone with known coefficients (pgm/ccmod.py)
+    X = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    opt = ref_pgm_ccmod.ConvCnstrMOD.Options({'MaxMainIter': 25, 'L': 800.0})
+    c = ref_pgm_ccmod.ConvCnstrMOD(X, S, (Nd, Nd, M), opt)
+    c.solve()
+    save('pgm_ccmod_f64', Z=X, S=S, dsz=np.array((Nd, Nd, M)),
+         D=c.getdict(), Xfull=c.X, **itstat_dict(c))
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
+                             'pcn', 'dictlearn']
+    table = {'primitives': gen_primitives, 'admm': gen_admm,
+             'known': gen_known_answer, 'config1': gen_config1,
+             'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
+    for w in which:
+        table[w]()

@@ -1,0 +1,143 @@
+"""Pin the NumPy oracle (oracle/cbpdn_oracle.py) to the reference itself.
+
+The fixtures in tests/golden/ were produced by oracle/make_golden.py from the
+unmodified reference (bwohlberg/sporco).  Every oracle function used by the
+GPU parity tests is checked here on CPU.  The path is floating point, so the
+pins are tolerances (float64 cases: 1e-10 or tighter; float32: 1e-4).
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+from oracle import cbpdn_oracle as orc
+
+
+def to5d(D, S, dimK=None):
+    """Internal 5-D layout for single-channel dictionaries (cnvrep.py:195-198)."""
+    D5 = D.reshape(D.shape[0], D.shape[1], 1, 1, D.shape[-1])
+    rdim = S.ndim - 2
+    if dimK is None:
+        dimC, dimKk = (0, 0) if rdim == 0 else ((0, 1) if rdim == 1 else (1, 1))
+    else:
+        dimKk, dimC = dimK, rdim - dimK
+    C = S.shape[2] if dimC else 1
+    N = S.shape[2 + dimC] if dimKk else 1
+    return D5, S.reshape(S.shape[0], S.shape[1], C, N, 1)
+
+
+def test_primitives():
+    g = load_golden('primitives')
+    x = orc.solvedbi_sm(g['sm_ah'], float(g['sm_rho']), g['sm_b'])
+    assert rel_l2(x, g['sm_x']) < 1e-13
+    assert rel_l2(orc.solvedbi_sm_c(g['sm_ah'], np.conj(g['sm_ah']),
+                                    float(g['sm_rho'])), g['sm_c']) < 1e-13
+    assert rel_l2(orc.inner(g['sm_ah'], g['sm_b'], axis=4), g['inner_ab']) < 1e-13
+    assert rel_l2(orc.rfftn2(g['fft_a']), g['fft_af']) < 1e-13
+    assert rel_l2(orc.irfftn2(g['fft_af'], (12, 9)), g['fft_ar']) < 1e-13
+    assert rel_l2(orc.rfftn2(g['fft_a2']), g['fft_a2f']) < 1e-6
+    assert orc.rfftn2(g['fft_a2']).dtype == np.complex64
+    assert rel_l2(orc.rfftn2(g['fft_d'], (12, 9)), g['fft_df']) < 1e-13
+    assert abs(orc.rfl2norm2(g['fft_af'], g['fft_a'].shape) - g['nrm_odd']) \
+        < 1e-12 * g['nrm_odd']
+    assert abs(orc.rfl2norm2(g['fft_a2f'], g['fft_a2'].shape) - g['nrm_even']) \
+        < 1e-6 * g['nrm_even']
+    a = float(g['prox_alpha'])
+    assert rel_l2(orc.prox_l1(g['prox_v'], a), g['prox_l1']) == 0.0
+    assert rel_l2(orc.prox_l1(g['prox_v'], a * g['prox_w']), g['prox_l1w']) == 0.0
+    assert rel_l2(orc.prox_l2(g['prox_v'], 0.9, axis=2), g['prox_l2']) < 1e-15
+    assert rel_l2(orc.prox_sl1l2(g['prox_v'], a, 0.9, axis=2),
+                  g['prox_sl1l2']) < 1e-15
+    assert rel_l2(orc.prox_sl1l2(g['prox_vz'], a, 0.9, axis=2),
+                  g['prox_sl1l2_z']) < 1e-15
+
+
+ADMM_CASES = {
+    'admm_default_f64': dict(maxiter=30),
+    'admm_default_f32': dict(maxiter=30, dtype=np.float32),
+    'admm_fixedrho_f64': dict(maxiter=25, rho=2.0, rlx=1.0, auto_rho=False),
+    'admm_autorho_std_f64': dict(maxiter=30, rho_period=3, auto_scaling=False,
+                                 rho_tau=2.0, rho_mu=1.5, std_residuals=True,
+                                 abs_tol=1e-6),
+    'admm_odd_nonneg_nobndry_f64': dict(maxiter=30, nonneg=True, nobndry=True),
+    'admm_l1weight_auxvar_f64': dict(maxiter=25, gevaly=True, fevalx=False,
+                                     _wl1='optarr_L1Weight'),
+    'admm_l1weight_spatial_f64': dict(maxiter=20, _wl1='optarr_L1Weight'),
+    'admm_multichan_f64': dict(maxiter=25),
+    'admm_joint_f64': dict(maxiter=25),
+    'admm_joint_f32': dict(maxiter=25, dtype=np.float32),
+    'admm_joint_l21weight_f64': dict(maxiter=20, nonneg=True,
+                                     _wl21='optarr_L21Weight'),
+    'admm_warmstart_f64': dict(maxiter=15, _y0='optarr_Y0', _u0='optarr_U0'),
+}
+
+
+@pytest.mark.parametrize('name', sorted(ADMM_CASES))
+def test_admm_traces(name):
+    g = load_golden(name)
+    kw = dict(ADMM_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    if '_wl1' in kw:
+        kw['wl1'] = g[kw.pop('_wl1')]
+    if '_wl21' in kw:
+        kw['wl21'] = g[kw.pop('_wl21')]
+    if '_y0' in kw:
+        kw['Y0'] = g[kw.pop('_y0')]
+        kw['U0'] = g[kw.pop('_u0')]
+    dimK = None if int(g['dimK']) < 0 else int(g['dimK'])
+    D5, S5 = to5d(g['D'], g['S'], dimK)
+    mu = None if float(g['mu']) < 0 else float(g['mu'])
+    r = orc.admm_cbpdn(D5, S5, float(g['lmbda']), mu=mu, dtype=dtype, **kw)
+    assert r['iters'] == int(g['k_final'])
+    assert rel_l2(r['Y'], g['Y']) < tol
+    assert rel_l2(r['U'], g['U']) < tol
+    assert rel_l2(r['X'], g['X']) < tol
+    for key in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl',
+                'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    if mu is not None:
+        assert rel_l2(r['RegL21'], g['it_RegL21']) < tol
+    assert rel_l2(orc.reconstruct(r['Df'], r['Y'], S5.shape[:2]),
+                  g['recon']) < tol
+
+
+def test_admm_known_answer():
+    g = load_golden('admm_known_answer_f64')
+    D5, S5 = to5d(g['D'], g['S'])
+    r = orc.admm_cbpdn(D5, S5, float(g['lmbda']), dtype=np.float64,
+                       maxiter=500, rho=1e-1, auto_rho=False)
+    assert r['iters'] == int(g['k_final'])
+    assert rel_l2(r['Y'], g['Y']) < 1e-9
+    # the reference's own assertion, tests/admm/test_cbpdn.py:173-176
+    assert orc.rrs(g['X0'], r['Y'].squeeze()) < 5e-5
+
+
+PGM_CASES = {
+    'pgm_default_f64': dict(maxiter=40, L=500.0),
+    'pgm_default_f32': dict(maxiter=40, L=500.0, dtype=np.float32),
+    'pgm_nonneg_nobndry_f64': dict(maxiter=30, L=500.0, nonneg=True, nobndry=True),
+    'pgm_multichan_f64': dict(maxiter=30, L=500.0),
+}
+
+
+@pytest.mark.parametrize('name', sorted(PGM_CASES))
+def test_pgm_traces(name):
+    g = load_golden(name)
+    kw = dict(PGM_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    D5, S5 = to5d(g['D'], g['S'])
+    r = orc.pgm_cbpdn(D5, S5, float(g['lmbda']), dtype=dtype, rel_tol=0.0, **kw)
+    assert r['iters'] == int(g['k_final'])
+    assert rel_l2(r['X'], g['X']) < tol
+    for key in ('ObjFun', 'DFid', 'RegL1', 'Rsdl'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+
+
+def test_pcn():
+    g = load_golden('pcn')
+    for crp in (0, 1):
+        for zm in (0, 1):
+            y = orc.pcn(g['x'], (5, 5, 6), (16, 12), crp=bool(crp), zm=bool(zm))
+            assert rel_l2(y, g['pcn_crp%d_zm%d' % (crp, zm)]) < 1e-14
