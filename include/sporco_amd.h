@@ -1,0 +1,248 @@
+/*
+ * sporco_amd.h -- C ABI of libsporco_amd.so, the MI355X (gfx950) backend for
+ * SPORCO's FFT-domain convolutional sparse coding path.
+ *
+ * The reference (bwohlberg/sporco) is pure Python and has no FFI of its own
+ * (SURVEY.md section 8(b)); its "operator API" is the Python class API.  This
+ * header is therefore the binding surface that a reference-side backend shim
+ * would load with ctypes (INTEGRATION.md shows that shim).  Every entry point
+ * cites the reference function(s) whose arithmetic it replaces, as
+ * `sporco/<file>:<lines>` relative to the reference root.
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers and sizes only, no C++/torch types;
+ *   - every function returns 0 on success, a negative code on failure; the
+ *     message is available from sporco_amd_last_error() (thread local);
+ *   - pointers are HOST pointers unless the parameter name ends in `_dev`;
+ *   - arrays use the reference's internal C-contiguous layout
+ *     (H, W, C, N, K), filter index K fastest (sporco/cnvrep.py:86-111;
+ *     BASELINE letters: N = images = SPORCO `K`, K = filters = SPORCO `M`);
+ *     frequency-domain arrays are (H, W/2+1, C, N, K) interleaved complex;
+ *   - `dtype` is SPORCO_AMD_F32 (float / complex64) or SPORCO_AMD_F64;
+ *   - a handle owns one HIP stream (or borrows the one passed at creation);
+ *     calls on one handle must not be issued concurrently from two threads.
+ */
+#ifndef SPORCO_AMD_H
+#define SPORCO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPORCO_AMD_F32 0
+#define SPORCO_AMD_F64 1
+
+/* error codes */
+#define SPORCO_AMD_OK 0
+#define SPORCO_AMD_EINVAL (-1)   /* bad argument / unsupported size        */
+#define SPORCO_AMD_EHIP (-2)     /* HIP runtime error (message has detail) */
+#define SPORCO_AMD_ENOMEM (-3)
+#define SPORCO_AMD_ESTATE (-4)   /* call order violated (e.g. no dictionary set) */
+
+/* ---- library-level ------------------------------------------------------ */
+
+const char *sporco_amd_version(void);
+const char *sporco_amd_last_error(void);
+/* Number of visible HIP devices (0 when none: product code must then fail). */
+int sporco_amd_device_count(int *count);
+/* Device name and compute-unit count of `device`. */
+int sporco_amd_device_info(int device, char *name, size_t name_len, int *cu_count,
+                           size_t *hbm_bytes);
+
+/* ---- solver handle ------------------------------------------------------ */
+
+typedef struct sporco_amd_csc *sporco_amd_csc_t;
+
+typedef struct {
+    int32_t H, W;   /* spatial size Nv (sporco/cnvrep.py:186)                  */
+    int32_t C;      /* channels of S and of X; dictionary is single channel   */
+    int32_t N;      /* images,  SPORCO cri.K (cnvrep.py:176-180)              */
+    int32_t K;      /* filters, SPORCO cri.M (cnvrep.py:183)                  */
+    int32_t dtype;  /* SPORCO_AMD_F32 | SPORCO_AMD_F64                        */
+} sporco_amd_dims;
+
+/* State arrays addressable through upload/download. */
+#define SPORCO_AMD_VAR_Y 0     /* real  (H,W,C,N,K)   ADMM auxiliary variable        */
+#define SPORCO_AMD_VAR_U 1     /* real  (H,W,C,N,K)   ADMM scaled dual variable       */
+#define SPORCO_AMD_VAR_X 2     /* real  (H,W,C,N,K)   primal variable                 */
+#define SPORCO_AMD_VAR_XF 3    /* cplx  (H,Wf,C,N,K)  rfftn(X)                        */
+#define SPORCO_AMD_VAR_DF 4    /* cplx  (H,Wf,1,1,K)  rfftn(D zero-padded)            */
+#define SPORCO_AMD_VAR_SF 5    /* cplx  (H,Wf,C,N,1)  rfftn(S)                        */
+#define SPORCO_AMD_VAR_YF 6    /* cplx  (H,Wf,C,N,K)  PGM auxiliary state Yf          */
+#define SPORCO_AMD_VAR_XFPRV 7 /* cplx  PGM previous Xf                               */
+#define SPORCO_AMD_VAR_YFPRV 8 /* cplx  PGM previous Yf                               */
+#define SPORCO_AMD_VAR_VF 9    /* cplx  PGM gradient-step buffer Vf / generic scratch */
+#define SPORCO_AMD_VAR_GF 10   /* cplx  PGM gradient buffer                           */
+#define SPORCO_AMD_VAR_AX 11   /* real  relaxed AX of the staged ADMM path            */
+#define SPORCO_AMD_VAR_YPREV 12 /* real Y of the previous iteration (staged ADMM path) */
+#define SPORCO_AMD_VAR_COUNT 13
+
+/* Create a solver on HIP device `device`.  `stream` is a hipStream_t to borrow
+ * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to own a new one.
+ * Replaces the allocation half of GenericConvBPDN.__init__
+ * (sporco/admm/cbpdn.py:224-236) and PGM ConvBPDN.__init__
+ * (sporco/pgm/cbpdn.py:216-233). */
+int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
+                          sporco_amd_csc_t *out);
+int sporco_amd_csc_destroy(sporco_amd_csc_t h);
+int sporco_amd_csc_sync(sporco_amd_csc_t h);
+
+/* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))
+ * on device -- sporco/admm/cbpdn.py:228-231, sporco/fft.py:257-286. */
+int sporco_amd_csc_set_signal(sporco_amd_csc_t h, const void *S);
+
+/* D: real (dH,dW,K) filters.  Zero-pads to (H,W), Df = rfftn, and caches the
+ * per-pixel Sherman-Morrison denominator sum_k |Df|^2 -- setdict,
+ * sporco/admm/cbpdn.py:242-256 (DSf is never materialised), and
+ * sporco/pgm/cbpdn.py:239-245. */
+int sporco_amd_csc_set_dict(sporco_amd_csc_t h, const void *D, int32_t dH, int32_t dW);
+
+/* l1 weight array (L1Weight option, sporco/admm/cbpdn.py:596-597 after
+ * cnvrep.l1Wshape, sporco/cnvrep.py:492-550).  shape[d] is 1 (broadcast) or the
+ * full extent of (H,W,C,N,K)[d]; w == NULL restores the scalar weight 1. */
+int sporco_amd_csc_set_l1_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]);
+/* l2,1 weight (L21Weight, sporco/admm/cbpdn.py:781): broadcastable against
+ * (H,W,1,N,K); shape[2] must be 1. */
+int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]);
+
+/* Host <-> device transfer of one state array in the reference layout. */
+int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src);
+int sporco_amd_csc_download(sporco_amd_csc_t h, int var, void *dst);
+/* Raw device pointer of a state array (plumbing for torch.distributed / tests). */
+int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
+
+/* ---- ADMM iteration (sporco/admm/admm.py:331-367 loop body) -------------- */
+
+#define SPORCO_AMD_FLAG_NONNEG (1u << 0)     /* NonNegCoef    cbpdn.py:306-307 */
+#define SPORCO_AMD_FLAG_NOBNDRY (1u << 1)    /* NoBndryCross  cbpdn.py:308-311 */
+#define SPORCO_AMD_FLAG_JOINT (1u << 2)      /* ConvBPDNJoint ystep cbpdn.py:785-794 */
+#define SPORCO_AMD_FLAG_RESID (1u << 3)      /* fill residual sums out[0..4]   */
+#define SPORCO_AMD_FLAG_OBJ (1u << 4)        /* fill objective sums out[5..7]  */
+#define SPORCO_AMD_FLAG_XRRS (1u << 5)       /* LinSolveCheck sums out[8..10]  */
+#define SPORCO_AMD_FLAG_GEVAL_Y (1u << 6)    /* regularisers evaluated at Y (gEvalY) */
+#define SPORCO_AMD_FLAG_FEVAL_Y (1u << 7)    /* data fidelity evaluated at Y (fEvalX False) */
+#define SPORCO_AMD_FLAG_KEEP_X (1u << 8)     /* keep X resident after the call */
+
+typedef struct {
+    double rho;      /* penalty parameter for this iteration                     */
+    double lmbda;    /* l1 weight lambda                                          */
+    double mu;       /* l2,1 weight (JOINT only)                                  */
+    double rlx;      /* RelaxParam alpha (sporco/admm/admm.py:877-885)            */
+    double u_scale;  /* pending `U /= rsf` of update_rho (admm.py:573), applied
+                        to U as it is read: U_true = u_scale * U_stored          */
+    uint32_t flags;
+    int32_t dH, dW;  /* filter support, for NOBNDRY                               */
+} sporco_amd_admm_params;
+
+/* Output slots of admm_iter (raw sums; the host forms r, s, eps exactly as
+ * sporco/admm/admm.py:462-486 with ADMMEqual.rsdl_* :959-983). */
+#define SPORCO_AMD_OUT_R2 0      /* sum (AXnr - Y)^2                               */
+#define SPORCO_AMD_OUT_S2 1      /* sum (Y - Yprev)^2   (rho applied by host)      */
+#define SPORCO_AMD_OUT_AX2 2     /* sum AXnr^2                                     */
+#define SPORCO_AMD_OUT_Y2 3      /* sum Y^2                                        */
+#define SPORCO_AMD_OUT_U2 4      /* sum U^2 (new U, before any rho rescale)        */
+#define SPORCO_AMD_OUT_DFID 5    /* half-spectrum Parseval sum of |Df.Xf - Sf|^2 / (H W)
+                                    (cbpdn.py:337-344, fft.py:449-484); host halves it */
+#define SPORCO_AMD_OUT_L1 6      /* sum |wl1 * g-variable|   (cbpdn.py:624-630)    */
+#define SPORCO_AMD_OUT_L21 7     /* sum wl21 * sqrt(sum_c g^2) (cbpdn.py:798-807)  */
+#define SPORCO_AMD_OUT_XRRS_D2 8 /* sum |ax - b|^2 of the X-step system            */
+#define SPORCO_AMD_OUT_XRRS_AX2 9
+#define SPORCO_AMD_OUT_XRRS_B2 10
+#define SPORCO_AMD_OUT_COUNT 16
+
+/* One full ADMM iteration on device: xstep (cbpdn.py:267-281: rfftn(Y-U),
+ * Sherman-Morrison solve linalg.py:232-297, irfftn), relax_AX, ystep
+ * (prox_l1 prox/_lp.py:144-183 or prox_sl1l2 prox/_l21.py:51-88, NonNeg,
+ * NoBndryCross), ustep (admm.py:434-437) and all reductions of
+ * compute_residuals / eval_objfn.  Blocks until `out` is valid. */
+int sporco_amd_csc_admm_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                             double out[SPORCO_AMD_OUT_COUNT]);
+/* Same, but leaves the sums in device memory at `out_dev` (double[16]) and does
+ * not synchronise: used to all-reduce them over RCCL before reading. */
+int sporco_amd_csc_admm_iter_dev(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                                 double *out_dev);
+
+/* Staged path, for callers that override individual ADMM steps
+ * (SURVEY.md section 8(b) "monkey-patch hazard").  Each mirrors one method. */
+int sporco_amd_csc_admm_xstep(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]); /* GenericConvBPDN.xstep */
+int sporco_amd_csc_admm_relax(sporco_amd_csc_t h, double rlx);   /* ADMMEqual.relax_AX    */
+int sporco_amd_csc_admm_ystep(sporco_amd_csc_t h, const sporco_amd_admm_params *p);
+int sporco_amd_csc_admm_ustep(sporco_amd_csc_t h, const sporco_amd_admm_params *p);
+int sporco_amd_csc_admm_stats(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]);
+/* U *= s (the eager form of update_rho's `U /= rsf`, admm.py:573). */
+int sporco_amd_csc_scale_u(sporco_amd_csc_t h, double s);
+
+/* irfftn(sum_k Df * rfftn(V)) for V = state `var` (Y or X): reconstruct,
+ * sporco/admm/cbpdn.py:373-380.  dst: real (H,W,C,N). */
+int sporco_amd_csc_reconstruct(sporco_amd_csc_t h, int var, void *dst);
+/* max |conj(Df) * Sf| for the default lambda rule, sporco/admm/cbpdn.py:573-578. */
+int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out);
+
+/* ---- PGM / FISTA steps (sporco/pgm/pgm.py:779-846, pgm/cbpdn.py:263-372) -- */
+
+#define SPORCO_AMD_PGM_F 0       /* 0.5 * sum |Df.Vf - Sf|^2 (unnormalised DFT domain) */
+#define SPORCO_AMD_PGM_DFID 1    /* Parseval-weighted version / (H W), not halved      */
+#define SPORCO_AMD_PGM_L1 2      /* sum |wl1 * X|                                       */
+#define SPORCO_AMD_PGM_RSDL 3    /* rfl2norm2(Xf - Yfprv)  (pgm/cbpdn.py:314-320)       */
+#define SPORCO_AMD_PGM_LIN 4     /* sum Re(conj(Xf - Yf) * gradf)  (pgm.py:886-894)     */
+#define SPORCO_AMD_PGM_DXY2 5    /* sum |Xf - Yf|^2                                     */
+#define SPORCO_AMD_PGM_GRAD2 6   /* sum |gradf|^2                                       */
+#define SPORCO_AMD_PGM_GHG 7     /* sum Re(conj(gradf) * hessian_f(gradf)) (Cauchy)     */
+
+/* GF = conj(Df) * (sum_k Df*src - Sf) for src = state `var` (grad_f,
+ * pgm/cbpdn.py:263-279); out[PGM_F] receives obfn_f(src) (:358-372). */
+int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
+/* Proximal step of PGMDFT.xstep (pgm.py:800-803): Vf = Yf - GF/L;
+ * X = prox_g(irfftn(Vf)) with prox_l1(., lmbda/L * wl1) + NonNeg/NoBndry
+ * (pgm/cbpdn.py:288-300); Xf = rfftn(X). */
+int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uint32_t flags,
+                                 int32_t dH, int32_t dW);
+/* Yf = Xf + beta*(Xf - Xfprv)  (+ gamma*(ZZf - Xf) when gamma != 0, Monotone
+ * variant; ZZf is held in VAR_VF) -- PGMDFT.ystep, pgm.py:815-831. */
+int sporco_amd_csc_pgm_momentum(sporco_amd_csc_t h, double beta, double gamma);
+/* dst = src (complex state copy: on_iteration_start, pgm.py:835-846). */
+int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var);
+/* Scalars of the PGM loop selected by `what` (bit i = slot i above). */
+int sporco_amd_csc_pgm_stats(sporco_amd_csc_t h, uint32_t what, double out[SPORCO_AMD_OUT_COUNT]);
+
+/* ---- per-kernel timing (HIP events on the handle's stream) ---------------- */
+
+int sporco_amd_csc_profile(sporco_amd_csc_t h, int enable);
+/* Reads and clears accumulated time of timing slot `slot`; returns its name. */
+int sporco_amd_csc_profile_read(sporco_amd_csc_t h, int slot, const char **name,
+                                double *total_ms, int64_t *launches);
+int sporco_amd_profile_slots(void);
+
+/* ---- stateless primitives on host arrays (parity entry points) ------------ */
+
+/* rfftn over axes (0,1) of real (H,W,P) -> complex (H,W/2+1,P); sporco/fft.py:257-286. */
+int sporco_amd_rfftn2(int dtype, int32_t H, int32_t W, int64_t P, const void *in, void *out);
+/* irfftn with s=(H,W): complex (H,W/2+1,P) -> real (H,W,P); sporco/fft.py:288-314. */
+int sporco_amd_irfftn2(int dtype, int32_t H, int32_t W, int64_t P, const void *in, void *out);
+/* solvedbi_sm (sporco/linalg.py:232-297) with ah: complex (npix,1,K),
+ * b, x: complex (npix,CN,K); solves (rho I + a a^H) x = b along K. */
+int sporco_amd_solvedbi_sm(int dtype, int64_t npix, int64_t CN, int32_t K, const void *ah,
+                           double rho, const void *b, void *x);
+/* inner(x, y, axis=K) (sporco/linalg.py:41-88): x complex (npix,1,K) broadcast
+ * over CN, y complex (npix,CN,K) -> out complex (npix,CN). */
+int sporco_amd_inner(int dtype, int64_t npix, int64_t CN, int32_t K, const void *x,
+                     const void *y, void *out);
+/* prox_l1 (sporco/prox/_lp.py:144-183), real v of n elements, scalar alpha. */
+int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *out);
+/* prox_sl1l2 (sporco/prox/_l21.py:51-88) with the l2 norm over the middle axis
+ * of real v shaped (outer, C, inner). */
+int sporco_amd_prox_sl1l2(int dtype, int64_t outer, int32_t C, int64_t inner, const void *v,
+                          double alpha, double beta, void *out);
+/* rfl2norm2 (sporco/fft.py:449-484) of complex xf (H,W/2+1,P) for spatial (H,W). */
+int sporco_amd_rfl2norm2(int dtype, int32_t H, int32_t W, int64_t P, const void *xf,
+                         double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPORCO_AMD_H */

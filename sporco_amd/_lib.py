@@ -1,0 +1,390 @@
+"""ctypes binding of libsporco_amd.so (the C ABI declared in include/sporco_amd.h).
+
+There is exactly one compute path: the HIP library built for gfx950.  If the
+shared object is missing, or no AMD GPU is visible, the functions here raise
+:class:`BackendError`; nothing falls back to NumPy.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+F32, F64 = 0, 1
+
+VAR_Y, VAR_U, VAR_X, VAR_XF, VAR_DF, VAR_SF = 0, 1, 2, 3, 4, 5
+VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_AX, VAR_YPREV = 6, 7, 8, 9, 10, 11, 12
+
+FLAG_NONNEG = 1 << 0
+FLAG_NOBNDRY = 1 << 1
+FLAG_JOINT = 1 << 2
+FLAG_RESID = 1 << 3
+FLAG_OBJ = 1 << 4
+FLAG_XRRS = 1 << 5
+FLAG_GEVAL_Y = 1 << 6
+FLAG_FEVAL_Y = 1 << 7
+FLAG_KEEP_X = 1 << 8
+
+OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
+OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
+OUT_XRRS_D2, OUT_XRRS_AX2, OUT_XRRS_B2 = 8, 9, 10
+OUT_COUNT = 16
+
+PGM_F, PGM_DFID, PGM_L1, PGM_RSDL, PGM_LIN, PGM_DXY2, PGM_GRAD2, PGM_GHG = range(8)
+
+EXPORTS = (
+    'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
+    'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_destroy',
+    'sporco_amd_csc_sync', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
+    'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
+    'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
+    'sporco_amd_csc_admm_iter', 'sporco_amd_csc_admm_iter_dev',
+    'sporco_amd_csc_admm_xstep', 'sporco_amd_csc_admm_relax',
+    'sporco_amd_csc_admm_ystep', 'sporco_amd_csc_admm_ustep',
+    'sporco_amd_csc_admm_stats', 'sporco_amd_csc_scale_u',
+    'sporco_amd_csc_reconstruct', 'sporco_amd_csc_dhs_absmax',
+    'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_prox_step',
+    'sporco_amd_csc_pgm_momentum', 'sporco_amd_csc_copy', 'sporco_amd_csc_pgm_stats',
+    'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
+    'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
+    'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_sl1l2',
+    'sporco_amd_rfl2norm2',
+)
+
+
+class BackendError(RuntimeError):
+    """The HIP backend is missing, failed to load, or reported an error."""
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('C', ctypes.c_int32),
+                ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('dtype', ctypes.c_int32)]
+
+
+class AdmmParams(ctypes.Structure):
+    _fields_ = [('rho', ctypes.c_double), ('lmbda', ctypes.c_double),
+                ('mu', ctypes.c_double), ('rlx', ctypes.c_double),
+                ('u_scale', ctypes.c_double), ('flags', ctypes.c_uint32),
+                ('dH', ctypes.c_int32), ('dW', ctypes.c_int32)]
+
+
+_DEFAULT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                             'libsporco_amd.so')
+_lib = None
+_lib_path = None
+
+
+def default_library_path():
+    return _DEFAULT_PATH
+
+
+def load(path=None):
+    """Load the backend shared library (default: the in-tree hipcc build).
+
+    ``path`` exists so that the test-suite can point the binding at the CPU
+    fiber simulator build of the same sources (tests/hostsim); product code
+    never passes it.
+    """
+    global _lib, _lib_path
+    path = os.path.abspath(path or _DEFAULT_PATH)
+    if not os.path.exists(path):
+        raise BackendError(
+            "sporco_amd: HIP library %s not found. Build it with "
+            "`make -C sporco_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
+            "g.build()'`). There is no CPU fallback." % path)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise BackendError("sporco_amd: cannot load %s: %s" % (path, e))
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise BackendError("sporco_amd: %s lacks symbols %s" % (path, missing))
+    lib.sporco_amd_version.restype = ctypes.c_char_p
+    lib.sporco_amd_last_error.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        if name not in ('sporco_amd_version', 'sporco_amd_last_error'):
+            getattr(lib, name).restype = ctypes.c_int
+    lib.sporco_amd_csc_create.argtypes = [ctypes.POINTER(Dims), ctypes.c_int,
+                                          ctypes.c_void_p,
+                                          ctypes.POINTER(ctypes.c_void_p)]
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+    dptr = ctypes.POINTER(ctypes.c_double)
+    pptr = ctypes.POINTER(AdmmParams)
+    sig = {
+        'sporco_amd_device_count': [ctypes.POINTER(ctypes.c_int)],
+        'sporco_amd_device_info': [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                   ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_size_t)],
+        'sporco_amd_csc_destroy': [vp], 'sporco_amd_csc_sync': [vp],
+        'sporco_amd_csc_set_signal': [vp, vp],
+        'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
+        'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
+        'sporco_amd_csc_set_l21_weight': [vp, vp, ctypes.POINTER(i64)],
+        'sporco_amd_csc_upload': [vp, ctypes.c_int, vp],
+        'sporco_amd_csc_download': [vp, ctypes.c_int, vp],
+        'sporco_amd_csc_device_ptr': [vp, ctypes.c_int, ctypes.POINTER(vp)],
+        'sporco_amd_csc_admm_iter': [vp, pptr, dptr],
+        'sporco_amd_csc_admm_iter_dev': [vp, pptr, vp],
+        'sporco_amd_csc_admm_xstep': [vp, pptr, dptr],
+        'sporco_amd_csc_admm_relax': [vp, dbl],
+        'sporco_amd_csc_admm_ystep': [vp, pptr],
+        'sporco_amd_csc_admm_ustep': [vp, pptr],
+        'sporco_amd_csc_admm_stats': [vp, pptr, dptr],
+        'sporco_amd_csc_scale_u': [vp, dbl],
+        'sporco_amd_csc_reconstruct': [vp, ctypes.c_int, vp],
+        'sporco_amd_csc_dhs_absmax': [vp, dptr],
+        'sporco_amd_csc_pgm_grad': [vp, ctypes.c_int, dptr],
+        'sporco_amd_csc_pgm_prox_step': [vp, dbl, dbl, ctypes.c_uint32, i32, i32],
+        'sporco_amd_csc_pgm_momentum': [vp, dbl, dbl],
+        'sporco_amd_csc_copy': [vp, ctypes.c_int, ctypes.c_int],
+        'sporco_amd_csc_pgm_stats': [vp, ctypes.c_uint32, dptr],
+        'sporco_amd_csc_profile': [vp, ctypes.c_int],
+        'sporco_amd_csc_profile_read': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                        dptr, ctypes.POINTER(i64)],
+        'sporco_amd_profile_slots': [],
+        'sporco_amd_rfftn2': [ctypes.c_int, i32, i32, i64, vp, vp],
+        'sporco_amd_irfftn2': [ctypes.c_int, i32, i32, i64, vp, vp],
+        'sporco_amd_solvedbi_sm': [ctypes.c_int, i64, i64, i32, vp, dbl, vp, vp],
+        'sporco_amd_inner': [ctypes.c_int, i64, i64, i32, vp, vp, vp],
+        'sporco_amd_prox_l1': [ctypes.c_int, i64, vp, dbl, vp],
+        'sporco_amd_prox_sl1l2': [ctypes.c_int, i64, i32, i64, vp, dbl, dbl, vp],
+        'sporco_amd_rfl2norm2': [ctypes.c_int, i32, i32, i64, vp, dptr],
+    }
+    for name, argtypes in sig.items():
+        getattr(lib, name).argtypes = argtypes
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def lib():
+    """Return the loaded library, loading the default one on first use."""
+    if _lib is None:
+        load()
+    return _lib
+
+
+def library_path():
+    return _lib_path
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().sporco_amd_last_error()
+        raise BackendError("sporco_amd backend error %d: %s" %
+                           (rc, msg.decode('utf-8', 'replace') if msg else '?'))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().sporco_amd_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def device_info(device=0):
+    name = ctypes.create_string_buffer(256)
+    cu = ctypes.c_int(0)
+    mem = ctypes.c_size_t(0)
+    check(lib().sporco_amd_device_info(device, name, 256, ctypes.byref(cu),
+                                       ctypes.byref(mem)))
+    return name.value.decode(), cu.value, mem.value
+
+
+def dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return F32
+    if dtype == np.float64:
+        return F64
+    raise TypeError("sporco_amd supports float32 and float64 data, not %s" % dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _carr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Solver(object):
+    """Owner of one device-side ConvBPDN problem (opaque C handle)."""
+
+    def __init__(self, H, W, C, N, K, dtype, device=0, stream=None):
+        self.dims = (int(H), int(W), int(C), int(N), int(K))
+        self.dtype = np.dtype(dtype)
+        self.cdtype = np.dtype(np.complex64 if self.dtype == np.float32
+                               else np.complex128)
+        d = Dims(*self.dims, dtype_code(dtype))
+        h = ctypes.c_void_p()
+        check(lib().sporco_amd_csc_create(ctypes.byref(d), int(device),
+                                          ctypes.c_void_p(stream or 0),
+                                          ctypes.byref(h)))
+        self._h = h
+        self._lib = lib()
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.sporco_amd_csc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- shapes -----------------------------------------------------------
+    @property
+    def shape_x(self):
+        return self.dims
+
+    @property
+    def shape_xf(self):
+        H, W, C, N, K = self.dims
+        return (H, W // 2 + 1, C, N, K)
+
+    def var_shape_dtype(self, var):
+        H, W, C, N, K = self.dims
+        Wf = W // 2 + 1
+        if var == VAR_DF:
+            return (H, Wf, 1, 1, K), self.cdtype
+        if var == VAR_SF:
+            return (H, Wf, C, N, 1), self.cdtype
+        if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF):
+            return (H, Wf, C, N, K), self.cdtype
+        return (H, W, C, N, K), self.dtype
+
+    # -- set-up -----------------------------------------------------------
+    def sync(self):
+        check(self._lib.sporco_amd_csc_sync(self._h))
+
+    def set_signal(self, S):
+        H, W, C, N, K = self.dims
+        S = _carr(S, self.dtype).reshape(H, W, C, N)
+        check(self._lib.sporco_amd_csc_set_signal(self._h, _ptr(S)))
+
+    def set_dict(self, D):
+        K = self.dims[4]
+        D = _carr(D, self.dtype)
+        dH, dW = D.shape[0], D.shape[1]
+        D = D.reshape(dH, dW, K)
+        check(self._lib.sporco_amd_csc_set_dict(self._h, _ptr(D), dH, dW))
+
+    def _set_weight(self, fn, w):
+        if w is None:
+            check(fn(self._h, None, None))
+            return
+        w = _carr(w, self.dtype)
+        shape = (ctypes.c_int64 * 5)(*w.shape)
+        check(fn(self._h, _ptr(w), shape))
+
+    def set_l1_weight(self, w):
+        self._set_weight(self._lib.sporco_amd_csc_set_l1_weight, w)
+
+    def set_l21_weight(self, w):
+        self._set_weight(self._lib.sporco_amd_csc_set_l21_weight, w)
+
+    # -- transfers --------------------------------------------------------
+    def upload(self, var, a):
+        shape, dt = self.var_shape_dtype(var)
+        a = _carr(a, dt)
+        if a.size != int(np.prod(shape)):
+            raise ValueError("array of shape %s cannot fill state of shape %s" %
+                             (a.shape, shape))
+        check(self._lib.sporco_amd_csc_upload(self._h, var, _ptr(a)))
+
+    def download(self, var):
+        shape, dt = self.var_shape_dtype(var)
+        out = np.empty(shape, dtype=dt)
+        check(self._lib.sporco_amd_csc_download(self._h, var, _ptr(out)))
+        return out
+
+    def device_ptr(self, var):
+        p = ctypes.c_void_p()
+        check(self._lib.sporco_amd_csc_device_ptr(self._h, var, ctypes.byref(p)))
+        return p.value
+
+    # -- ADMM ---------------------------------------------------------------
+    @staticmethod
+    def _out():
+        return (ctypes.c_double * OUT_COUNT)()
+
+    def admm_iter(self, params):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_admm_iter(self._h, ctypes.byref(params), out))
+        return list(out)
+
+    def admm_iter_dev(self, params, out_dev_ptr):
+        check(self._lib.sporco_amd_csc_admm_iter_dev(self._h, ctypes.byref(params),
+                                                     ctypes.c_void_p(out_dev_ptr)))
+
+    def admm_xstep(self, params):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_admm_xstep(self._h, ctypes.byref(params), out))
+        return list(out)
+
+    def admm_relax(self, rlx):
+        check(self._lib.sporco_amd_csc_admm_relax(self._h, float(rlx)))
+
+    def admm_ystep(self, params):
+        check(self._lib.sporco_amd_csc_admm_ystep(self._h, ctypes.byref(params)))
+
+    def admm_ustep(self, params):
+        check(self._lib.sporco_amd_csc_admm_ustep(self._h, ctypes.byref(params)))
+
+    def admm_stats(self, params):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_admm_stats(self._h, ctypes.byref(params), out))
+        return list(out)
+
+    def scale_u(self, s):
+        check(self._lib.sporco_amd_csc_scale_u(self._h, float(s)))
+
+    def reconstruct(self, var):
+        H, W, C, N, K = self.dims
+        out = np.empty((H, W, C, N, 1), dtype=self.dtype)
+        check(self._lib.sporco_amd_csc_reconstruct(self._h, var, _ptr(out)))
+        return out
+
+    def dhs_absmax(self):
+        v = ctypes.c_double(0.0)
+        check(self._lib.sporco_amd_csc_dhs_absmax(self._h, ctypes.byref(v)))
+        return v.value
+
+    # -- PGM ----------------------------------------------------------------
+    def pgm_grad(self, var):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pgm_grad(self._h, var, out))
+        return list(out)
+
+    def pgm_prox_step(self, L, lmbda, flags, dH, dW):
+        check(self._lib.sporco_amd_csc_pgm_prox_step(self._h, float(L), float(lmbda),
+                                                     int(flags), int(dH), int(dW)))
+
+    def pgm_momentum(self, beta, gamma=0.0):
+        check(self._lib.sporco_amd_csc_pgm_momentum(self._h, float(beta), float(gamma)))
+
+    def copy(self, dst, src):
+        check(self._lib.sporco_amd_csc_copy(self._h, dst, src))
+
+    def pgm_stats(self, what):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pgm_stats(self._h, int(what), out))
+        return list(out)
+
+    # -- timing -------------------------------------------------------------
+    def profile(self, enable):
+        check(self._lib.sporco_amd_csc_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """Return {kernel name: (total_ms, launches)} and reset the counters."""
+        res = {}
+        for slot in range(self._lib.sporco_amd_profile_slots()):
+            name = ctypes.c_char_p()
+            ms = ctypes.c_double(0.0)
+            cnt = ctypes.c_int64(0)
+            check(self._lib.sporco_amd_csc_profile_read(self._h, slot, ctypes.byref(name),
+                                                        ctypes.byref(ms), ctypes.byref(cnt)))
+            res[name.value.decode()] = (ms.value, cnt.value)
+        return res

@@ -1,0 +1,127 @@
+// common.h -- shared host/device helpers for libsporco_amd (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace sporco_amd {
+
+constexpr int kWave = 64;  // CDNA4 wavefront width
+
+// ---------------------------------------------------------------------------
+// error plumbing: C++ exceptions inside, codes + thread-local message at the ABI
+// ---------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define SA_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t sa_e_ = (expr);                                                     \
+        if (sa_e_ != hipSuccess)                                                       \
+            throw ::sporco_amd::Error(-2, std::string(#expr) + ": " +                  \
+                                              hipGetErrorString(sa_e_));               \
+    } while (0)
+
+#define SA_REQUIRE(cond, msg)                                                          \
+    do {                                                                               \
+        if (!(cond)) throw ::sporco_amd::Error(-1, std::string(msg));                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// complex numbers as plain 2-vectors (layout-compatible with numpy complex64/128)
+// ---------------------------------------------------------------------------
+template <typename T> struct cx {
+    T re, im;
+};
+
+template <typename T> __host__ __device__ __forceinline__ cx<T> mk(T a, T b) {
+    cx<T> r;
+    r.re = a;
+    r.im = b;
+    return r;
+}
+template <typename T> __host__ __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) {
+    return mk<T>(a.re + b.re, a.im + b.im);
+}
+template <typename T> __host__ __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) {
+    return mk<T>(a.re - b.re, a.im - b.im);
+}
+// a * b
+template <typename T> __host__ __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+    return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+}
+// conj(a) * b
+template <typename T> __host__ __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> b) {
+    return mk<T>(a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re);
+}
+template <typename T> __host__ __device__ __forceinline__ cx<T> cscale(cx<T> a, T s) {
+    return mk<T>(a.re * s, a.im * s);
+}
+template <typename T> __host__ __device__ __forceinline__ cx<T> cconj(cx<T> a) {
+    return mk<T>(a.re, -a.im);
+}
+template <typename T> __host__ __device__ __forceinline__ T cabs2(cx<T> a) {
+    return a.re * a.re + a.im * a.im;
+}
+// multiply by -i (forward quarter turn) / +i
+template <typename T> __host__ __device__ __forceinline__ cx<T> mul_mi(cx<T> a) {
+    return mk<T>(a.im, -a.re);
+}
+template <typename T> __host__ __device__ __forceinline__ cx<T> mul_pi(cx<T> a) {
+    return mk<T>(-a.im, a.re);
+}
+
+// ---------------------------------------------------------------------------
+// LDS: every kernel carves its scratch from the dynamic region (keeps the
+// base 16-byte aligned and leaves no static __shared__ objects around).
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T *dyn_lds() {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sporco_amd_lds_raw[];
+    return reinterpret_cast<T *>(sporco_amd_lds_raw);
+}
+
+// ---------------------------------------------------------------------------
+// deterministic reductions of double accumulators
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = kWave / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+// Sum `NV` per-thread doubles over the block; thread 0 writes them to
+// dst[0..NV).  `scratch` must hold NV * (blockDim.x / 64) doubles of LDS.
+template <int NV>
+__device__ __forceinline__ void block_sum_store(const double (&acc)[NV], double *scratch,
+                                                double *dst) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nwave = (blockDim.x + kWave - 1) / kWave;
+    double w[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) w[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = w[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < nwave; ++j) s += scratch[j * NV + i];
+            dst[i] = s;
+        }
+    }
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace sporco_amd

@@ -1,0 +1,1123 @@
+// csc_api.hip -- C ABI of libsporco_amd.so (see include/sporco_amd.h).
+//
+// The handle owns every device array of one ConvBPDN problem; the host side
+// (sporco_amd/*.py, which mirrors the reference classes) keeps only scalars and
+// the iteration loop.  Arrays stay resident in HBM for the life of the handle.
+#include "../../include/sporco_amd.h"
+
+#include <cmath>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "csc_kernels.h"
+#include "fft.h"
+
+namespace sporco_amd {
+
+static thread_local std::string g_last_error;
+
+enum ProfSlot {
+    PS_FFT_R2C = 0,
+    PS_FFT_C2C_FWD,
+    PS_SM_SOLVE,
+    PS_FFT_C2C_INV,
+    PS_FFT_C2R,
+    PS_ADMM_POST,
+    PS_FINALIZE,
+    PS_PGM,
+    PS_OTHER,
+    PS_COUNT
+};
+static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_solve",
+                                           "fft_c2c_cols_inv", "fft_c2r_rows",     "admm_post",
+                                           "finalize",         "pgm_elementwise",  "other"};
+
+struct Profiler {
+    bool on = false;
+    hipStream_t st = nullptr;
+    struct Rec {
+        int slot;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[PS_COUNT] = {0};
+    int64_t count[PS_COUNT] = {0};
+
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        SA_HIP(hipEventCreate(&e));
+        return e;
+    }
+    void drain() {
+        for (auto &r : pending) {
+            SA_HIP(hipEventSynchronize(r.b));
+            float ms = 0.f;
+            SA_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+            total_ms[r.slot] += ms;
+            count[r.slot] += 1;
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+    ~Profiler() {
+        for (auto &r : pending) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+// RAII timing scope around one kernel (group) on the handle's stream.
+struct ProfScope {
+    Profiler &p;
+    int slot;
+    hipEvent_t a = nullptr;
+    ProfScope(Profiler &p_, int slot_) : p(p_), slot(slot_) {
+        if (p.on) {
+            a = p.get();
+            SA_HIP(hipEventRecord(a, p.st));
+        }
+    }
+    ~ProfScope() {
+        if (p.on && a) {
+            hipEvent_t b = p.get();
+            (void)hipEventRecord(b, p.st);
+            p.pending.push_back({slot, a, b});
+            if (p.pending.size() > 4096) p.drain();
+        }
+    }
+};
+
+struct CscBase {
+    virtual ~CscBase() {}
+    virtual void sync() = 0;
+    virtual void set_signal(const void *S) = 0;
+    virtual void set_dict(const void *D, int dH, int dW) = 0;
+    virtual void set_weight(int which, const void *w, const int64_t shape[5]) = 0;
+    virtual void upload(int var, const void *src) = 0;
+    virtual void download(int var, void *dst) = 0;
+    virtual void *device_ptr(int var) = 0;
+    virtual void admm_iter(const sporco_amd_admm_params &p, double *out_dev) = 0;
+    virtual void admm_xstep(const sporco_amd_admm_params &p, double *out_dev) = 0;
+    virtual void admm_relax(double rlx) = 0;
+    virtual void admm_ystep(const sporco_amd_admm_params &p) = 0;
+    virtual void admm_ustep(const sporco_amd_admm_params &p) = 0;
+    virtual void admm_stats(const sporco_amd_admm_params &p, double *out_dev) = 0;
+    virtual void scale_u(double s) = 0;
+    virtual void reconstruct(int var, void *dst) = 0;
+    virtual void dhs_absmax(double *out_host) = 0;
+    virtual void pgm_grad(int var, double *out_dev) = 0;
+    virtual void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW) = 0;
+    virtual void pgm_momentum(double beta, double gamma) = 0;
+    virtual void copy(int dst, int src) = 0;
+    virtual void pgm_stats(uint32_t what, double *out_dev) = 0;
+    virtual void read_out(const double *out_dev, double *out_host) = 0;
+    double *out_dev_default = nullptr;
+    Profiler prof;
+};
+
+static bool var_is_complex(int var) {
+    switch (var) {
+    case SPORCO_AMD_VAR_XF:
+    case SPORCO_AMD_VAR_DF:
+    case SPORCO_AMD_VAR_SF:
+    case SPORCO_AMD_VAR_YF:
+    case SPORCO_AMD_VAR_XFPRV:
+    case SPORCO_AMD_VAR_YFPRV:
+    case SPORCO_AMD_VAR_VF:
+    case SPORCO_AMD_VAR_GF:
+        return true;
+    default:
+        return false;
+    }
+}
+
+template <typename T> struct Csc : CscBase {
+    sporco_amd_dims dm;
+    int device;
+    hipStream_t st = nullptr;
+    bool own_stream = false;
+    int H, W, Wf, C, N, K, CN;
+    int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
+    FftPlan planW, planH;
+    void *vars[SPORCO_AMD_VAR_COUNT] = {nullptr};
+    cx<T> *work = nullptr;    // column-pass scratch (EF complex)
+    cx<T> *innerb = nullptr;  // (npix, CN) complex
+    T *gram = nullptr;        // (npix)
+    T *dpad = nullptr;        // (H, W, K) real
+    T *sreal = nullptr;       // (H, W, CN) real staging / reconstruct output
+    T *wl1_buf = nullptr, *wl21_buf = nullptr;
+    Weight<T> wl1, wl21;
+    double *part_a = nullptr, *part_b = nullptr;  // block partials
+    double *out_dev_own = nullptr;
+    double *out_pinned = nullptr;
+    bool have_dict = false, have_signal = false;
+    int dH_ = 0, dW_ = 0;
+
+    Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
+        SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
+                   "all dimensions must be >= 1");
+        SA_HIP(hipSetDevice(device));
+        H = d.H;
+        W = d.W;
+        C = d.C;
+        N = d.N;
+        K = d.K;
+        Wf = W / 2 + 1;
+        CN = C * N;
+        P = (int64_t)C * N * K;
+        E = (int64_t)H * W * P;
+        npix = (int64_t)H * Wf;
+        EF = npix * P;
+        if (stream) {
+            st = (hipStream_t)stream;
+        } else {
+            SA_HIP(hipStreamCreate(&st));
+            own_stream = true;
+        }
+        prof.st = st;
+        planW.init(W);
+        planH.init(H);
+        SA_HIP(hipMalloc((void **)&part_a, sizeof(double) * kMaxPartialBlocks * 8));
+        SA_HIP(hipMalloc((void **)&part_b, sizeof(double) * kMaxPartialBlocks * 8));
+        SA_HIP(hipMalloc((void **)&out_dev_own, sizeof(double) * kOutSlots));
+        SA_HIP(hipMemset(out_dev_own, 0, sizeof(double) * kOutSlots));
+        SA_HIP(hipHostMalloc((void **)&out_pinned, sizeof(double) * kOutSlots, 0));
+        out_dev_default = out_dev_own;
+        SA_HIP(hipMalloc((void **)&gram, sizeof(T) * npix));
+        SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CN));
+        SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CN));
+        // the three ADMM state arrays start at zero (yinit/uinit, admm.py:279-289)
+        for (int v : {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U, SPORCO_AMD_VAR_X}) (void)var_ptr(v);
+    }
+
+    ~Csc() override {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(st);
+        for (auto &v : vars)
+            if (v) (void)hipFree(v);
+        for (void *p : {(void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
+                        (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
+                        (void *)out_dev_own})
+            if (p) (void)hipFree(p);
+        if (out_pinned) (void)hipHostFree(out_pinned);
+        planW.destroy();
+        planH.destroy();
+        if (own_stream) (void)hipStreamDestroy(st);
+    }
+
+    size_t var_bytes(int var) const {
+        switch (var) {
+        case SPORCO_AMD_VAR_DF:
+            return sizeof(cx<T>) * npix * K;
+        case SPORCO_AMD_VAR_SF:
+            return sizeof(cx<T>) * npix * CN;
+        default:
+            return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
+        }
+    }
+
+    void *var_ptr(int var) {
+        SA_REQUIRE(var >= 0 && var < SPORCO_AMD_VAR_COUNT, "unknown state variable id");
+        if (!vars[var]) {
+            SA_HIP(hipMalloc(&vars[var], var_bytes(var)));
+            SA_HIP(hipMemsetAsync(vars[var], 0, var_bytes(var), st));
+        }
+        return vars[var];
+    }
+    T *rv(int var) { return static_cast<T *>(var_ptr(var)); }
+    cx<T> *cv(int var) { return static_cast<cx<T> *>(var_ptr(var)); }
+    cx<T> *work_buf() {
+        if (!work) SA_HIP(hipMalloc((void **)&work, sizeof(cx<T>) * EF));
+        return work;
+    }
+    Dims5 d5() const { return Dims5{H, W, C, N, K}; }
+
+    void sync() override { SA_HIP(hipStreamSynchronize(st)); }
+
+    // ---- 2-D transforms with per-kernel timing -------------------------------
+    void fwd2(const T *in, const T *in2, T s2, cx<T> *out, int64_t cols) {
+        {
+            ProfScope ps(prof, PS_FFT_R2C);
+            fft_r2c<T>(st, planW, in, in2, s2, out, H, cols, (int64_t)W * cols, cols,
+                       (int64_t)Wf * cols, cols);
+        }
+        {
+            ProfScope ps(prof, PS_FFT_C2C_FWD);
+            fft_c2c<T>(st, planH, false, out, out, 1, (int64_t)Wf * cols, 0, (int64_t)Wf * cols, 0,
+                       (int64_t)Wf * cols, T(1));
+        }
+    }
+    void inv2(const cx<T> *in, cx<T> *tmp, T *out, int64_t cols) {
+        {
+            ProfScope ps(prof, PS_FFT_C2C_INV);
+            fft_c2c<T>(st, planH, true, in, tmp, 1, (int64_t)Wf * cols, 0, (int64_t)Wf * cols, 0,
+                       (int64_t)Wf * cols, T(1));
+        }
+        {
+            ProfScope ps(prof, PS_FFT_C2R);
+            fft_c2r<T>(st, planW, tmp, out, H, cols, (int64_t)Wf * cols, cols, (int64_t)W * cols,
+                       cols, T(1.0 / ((double)H * (double)W)));
+        }
+    }
+
+    void finalize(const double *part, int nblocks, int stride, int nvals, const int *slots,
+                  const double *scales, double *out_dev, bool is_max = false) {
+        ProfScope ps(prof, PS_FINALIZE);
+        launch_finalize(st, part, nblocks, stride, nvals, slots, scales, is_max, out_dev);
+    }
+
+    // ---- set-up ------------------------------------------------------------------
+    void set_signal(const void *S) override {
+        SA_HIP(hipMemcpyAsync(sreal, S, sizeof(T) * (int64_t)H * W * CN, hipMemcpyHostToDevice, st));
+        fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CN);
+        sync();  // the host buffer may be released after return
+        have_signal = true;
+    }
+
+    void set_dict(const void *D, int dH, int dW) override {
+        SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W,
+                   "filter support must fit inside the signal");
+        if (!dpad) SA_HIP(hipMalloc((void **)&dpad, sizeof(T) * (int64_t)H * W * K));
+        // stage the compact filters at the tail of dpad's own allocation? no: use `work`-free
+        // dedicated staging so set_dict is safe while iterates are live.
+        T *stage = nullptr;
+        SA_HIP(hipMalloc((void **)&stage, sizeof(T) * (int64_t)dH * dW * K));
+        SA_HIP(hipMemcpyAsync(stage, D, sizeof(T) * (int64_t)dH * dW * K, hipMemcpyHostToDevice, st));
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_pad_dict<T>(st, stage, dpad, H, W, K, dH, dW);
+        }
+        fwd2(dpad, nullptr, T(0), cv(SPORCO_AMD_VAR_DF), K);
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
+        }
+        sync();
+        SA_HIP(hipFree(stage));
+        dH_ = dH;
+        dW_ = dW;
+        have_dict = true;
+    }
+
+    void set_weight(int which, const void *w, const int64_t shape[5]) override {
+        Weight<T> &dst = which == 0 ? wl1 : wl21;
+        T *&buf = which == 0 ? wl1_buf : wl21_buf;
+        if (buf) {
+            sync();
+            SA_HIP(hipFree(buf));
+            buf = nullptr;
+        }
+        dst = Weight<T>();
+        if (!w) return;
+        const int64_t full[5] = {H, W, C, N, K};
+        int64_t n = 1;
+        for (int i = 0; i < 5; ++i) {
+            SA_REQUIRE(shape[i] == 1 || shape[i] == full[i],
+                       "weight shape must be 1 or the full extent on every axis");
+            n *= shape[i];
+        }
+        if (which == 1) SA_REQUIRE(shape[2] == 1, "L21Weight must not vary over the channel axis");
+        SA_HIP(hipMalloc((void **)&buf, sizeof(T) * n));
+        SA_HIP(hipMemcpyAsync(buf, w, sizeof(T) * n, hipMemcpyHostToDevice, st));
+        sync();
+        int64_t stride = 1;
+        for (int i = 4; i >= 0; --i) {
+            dst.stride[i] = shape[i] == 1 ? 0 : stride;
+            stride *= shape[i];
+        }
+        dst.ptr = buf;
+    }
+
+    void upload(int var, const void *src) override {
+        SA_HIP(hipMemcpyAsync(var_ptr(var), src, var_bytes(var), hipMemcpyHostToDevice, st));
+        sync();
+    }
+    void download(int var, void *dst) override {
+        SA_HIP(hipMemcpyAsync(dst, var_ptr(var), var_bytes(var), hipMemcpyDeviceToHost, st));
+        sync();
+    }
+    void *device_ptr(int var) override { return var_ptr(var); }
+
+    void read_out(const double *out_dev, double *out_host) override {
+        SA_HIP(hipMemcpyAsync(out_pinned, out_dev, sizeof(double) * kOutSlots, hipMemcpyDeviceToHost,
+                              st));
+        sync();
+        std::memcpy(out_host, out_pinned, sizeof(double) * kOutSlots);
+    }
+
+    void require_ready() const {
+        if (!have_dict || !have_signal)
+            throw Error(SPORCO_AMD_ESTATE, "set_signal and set_dict must be called first");
+    }
+
+    // ---- ADMM --------------------------------------------------------------------
+    // X-step: Xf = SM(rfftn(Y - s U)), X = irfftn(Xf); objective / check sums -> out_dev
+    void xstep_impl(const sporco_amd_admm_params &p, double *out_dev) {
+        require_ready();
+        T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
+        fwd2(Y, U, (T)p.u_scale, Xf, P);
+        const bool obj = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
+        const bool xr = p.flags & F_XRRS;
+        int nb;
+        {
+            ProfScope ps(prof, PS_SM_SOLVE);
+            nb = launch_sm_solve<T>(st, Xf, Xf, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF), gram,
+                                    (T)p.rho, npix, CN, K, W, obj, xr, part_a);
+        }
+        if (obj || xr) {
+            const int slots[4] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
+                                  SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
+            const double scales[4] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0};
+            finalize(part_a, nb, 4, 4, slots, scales, out_dev);
+        }
+        inv2(Xf, work_buf(), X, P);
+    }
+
+    // data fidelity evaluated at Y (fEvalX False / AuxVarObj, cbpdn.py:315-321)
+    void dfid_at(const T *V, double *out_dev) {
+        cx<T> *wk = work_buf();
+        fwd2(V, nullptr, T(0), wk, P);
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), wk, innerb, npix, CN, K);
+        }
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_rfl2norm2<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), npix, CN, W, part_a);
+        }
+        const int slots[1] = {SPORCO_AMD_OUT_DFID};
+        const double scales[1] = {1.0 / ((double)H * W)};
+        finalize(part_a, nb, 1, 1, slots, scales, out_dev);
+    }
+
+    void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        xstep_impl(p, out_dev);
+        PostParams<T> pp;
+        pp.x = rv(SPORCO_AMD_VAR_X);
+        pp.y = rv(SPORCO_AMD_VAR_Y);
+        pp.u = rv(SPORCO_AMD_VAR_U);
+        pp.rlx = (T)p.rlx;
+        pp.thr = (T)(p.lmbda / p.rho);
+        pp.thr21 = (T)(p.mu / p.rho);
+        pp.u_scale = (T)p.u_scale;
+        pp.flags = p.flags;
+        pp.d = d5();
+        pp.dH = p.dH;
+        pp.dW = p.dW;
+        pp.wl1 = wl1;
+        pp.wl21 = wl21;
+        int nb;
+        {
+            ProfScope ps(prof, PS_ADMM_POST);
+            nb = launch_admm_post<T>(st, pp, part_b);
+        }
+        const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                              SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
+                              SPORCO_AMD_OUT_L21};
+        const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
+        finalize(part_b, nb, 8, 7, slots, scales, out_dev);
+        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+    }
+
+    void admm_xstep(const sporco_amd_admm_params &p, double *out_dev) override {
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        xstep_impl(p, out_dev);
+    }
+
+    void admm_relax(double rlx) override {
+        ProfScope ps(prof, PS_OTHER);
+        launch_relax<T>(st, rv(SPORCO_AMD_VAR_X), rv(SPORCO_AMD_VAR_Y), rv(SPORCO_AMD_VAR_AX), (T)rlx,
+                        E);
+    }
+
+    void admm_ystep(const sporco_amd_admm_params &p) override {
+        ProfScope ps(prof, PS_OTHER);
+        launch_ystep<T>(st, rv(SPORCO_AMD_VAR_AX), rv(SPORCO_AMD_VAR_U), rv(SPORCO_AMD_VAR_Y),
+                        (T)(p.lmbda / p.rho), (T)(p.mu / p.rho), (T)p.u_scale, p.flags, d5(), p.dH,
+                        p.dW, wl1, wl21);
+    }
+
+    void admm_ustep(const sporco_amd_admm_params &p) override {
+        ProfScope ps(prof, PS_OTHER);
+        launch_ustep<T>(st, rv(SPORCO_AMD_VAR_AX), rv(SPORCO_AMD_VAR_Y), rv(SPORCO_AMD_VAR_U),
+                        (T)p.u_scale, E);
+    }
+
+    void admm_stats(const sporco_amd_admm_params &p, double *out_dev) override {
+        // keeps the xstep sums already in out_dev; fills the residual/regulariser slots
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_admm_stats<T>(st, rv(SPORCO_AMD_VAR_X), rv(SPORCO_AMD_VAR_Y),
+                                      rv(SPORCO_AMD_VAR_YPREV), rv(SPORCO_AMD_VAR_U), p.flags, d5(),
+                                      wl1, wl21, part_b);
+        }
+        const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                              SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
+                              SPORCO_AMD_OUT_L21};
+        const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
+        finalize(part_b, nb, 8, 7, slots, scales, out_dev);
+        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+    }
+
+    void scale_u(double s) override {
+        ProfScope ps(prof, PS_OTHER);
+        launch_scale<T>(st, rv(SPORCO_AMD_VAR_U), (T)s, E);
+    }
+
+    void reconstruct(int var, void *dst) override {
+        require_ready();
+        SA_REQUIRE(!var_is_complex(var), "reconstruct needs a real state variable");
+        cx<T> *wk = work_buf();
+        fwd2(rv(var), nullptr, T(0), wk, P);
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), wk, innerb, npix, CN, K);
+        }
+        inv2(innerb, innerb, sreal, CN);
+        SA_HIP(hipMemcpyAsync(dst, sreal, sizeof(T) * (int64_t)H * W * CN, hipMemcpyDeviceToHost, st));
+        sync();
+    }
+
+    void dhs_absmax(double *out_host) override {
+        require_ready();
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_dhs_absmax<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF), npix, CN, K,
+                                      part_a);
+        }
+        const int slots[1] = {0};
+        const double scales[1] = {1.0};
+        SA_HIP(hipMemsetAsync(out_dev_own, 0, sizeof(double) * kOutSlots, st));
+        finalize(part_a, nb, 1, 1, slots, scales, out_dev_own, true);
+        double tmp[kOutSlots];
+        read_out(out_dev_own, tmp);
+        *out_host = std::sqrt(tmp[0]);
+    }
+
+    // ---- PGM -----------------------------------------------------------------------
+    void pgm_grad(int var, double *out_dev) override {
+        require_ready();
+        SA_REQUIRE(var_is_complex(var), "pgm_grad needs a frequency-domain variable");
+        int nb;
+        {
+            ProfScope ps(prof, PS_PGM);
+            nb = launch_pgm_grad<T>(st, cv(var), cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF),
+                                    cv(SPORCO_AMD_VAR_GF), npix, CN, K, W, part_a);
+        }
+        const int slots[2] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID};
+        const double scales[2] = {0.5, 1.0 / ((double)H * W)};
+        finalize(part_a, nb, 2, 2, slots, scales, out_dev);
+    }
+
+    void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW) override {
+        require_ready();
+        cx<T> *Vf = cv(SPORCO_AMD_VAR_VF);
+        {
+            ProfScope ps(prof, PS_PGM);
+            launch_axpy_c<T>(st, cv(SPORCO_AMD_VAR_YF), cv(SPORCO_AMD_VAR_GF), Vf, (T)(-1.0 / L), EF);
+        }
+        T *X = rv(SPORCO_AMD_VAR_X);
+        inv2(Vf, work_buf(), X, P);
+        int nb;
+        {
+            ProfScope ps(prof, PS_PGM);
+            nb = launch_prox_l1<T>(st, X, X, (T)(lmbda / L), flags, d5(), dH, dW, wl1, part_b);
+        }
+        const int slots[1] = {SPORCO_AMD_PGM_L1};
+        const double scales[1] = {1.0};
+        finalize(part_b, nb, 1, 1, slots, scales, out_dev_own);
+        fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_XF), P);
+    }
+
+    void pgm_momentum(double beta, double gamma) override {
+        ProfScope ps(prof, PS_PGM);
+        launch_momentum<T>(st, cv(SPORCO_AMD_VAR_XF), cv(SPORCO_AMD_VAR_XFPRV),
+                           gamma != 0.0 ? cv(SPORCO_AMD_VAR_VF) : nullptr, cv(SPORCO_AMD_VAR_YF),
+                           (T)beta, (T)gamma, EF);
+    }
+
+    void copy(int dst, int src) override {
+        SA_REQUIRE(var_bytes(dst) == var_bytes(src), "copy between variables of different size");
+        ProfScope ps(prof, PS_OTHER);
+        SA_HIP(hipMemcpyAsync(var_ptr(dst), var_ptr(src), var_bytes(src), hipMemcpyDeviceToDevice, st));
+    }
+
+    void pgm_stats(uint32_t what, double *out_dev) override {
+        require_ready();
+        const double ihw = 1.0 / ((double)H * W);
+        if (what & ((1u << SPORCO_AMD_PGM_F) | (1u << SPORCO_AMD_PGM_DFID))) {
+            int nb;
+            {
+                ProfScope ps(prof, PS_PGM);
+                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_XF), innerb, npix, CN, K);
+                nb = launch_pair_stats<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), nullptr, npix, CN, W,
+                                          part_a);
+            }
+            const int slots[2] = {SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F};
+            const double scales[2] = {ihw, 0.5};
+            // partial layout: [0] weighted, [1] lin, [2] unweighted, [3] |g|^2
+            const int s0[1] = {slots[0]};
+            const double c0[1] = {scales[0]};
+            finalize(part_a, nb, 4, 1, s0, c0, out_dev);
+            const int s2[1] = {slots[1]};
+            const double c2[1] = {scales[1]};
+            finalize(part_a + 2, nb, 4, 1, s2, c2, out_dev);
+        }
+        if (what & (1u << SPORCO_AMD_PGM_RSDL)) {
+            int nb;
+            {
+                ProfScope ps(prof, PS_PGM);
+                nb = launch_pair_stats<T>(st, cv(SPORCO_AMD_VAR_XF), cv(SPORCO_AMD_VAR_YFPRV), nullptr,
+                                          npix, P, W, part_a);
+            }
+            const int s[1] = {SPORCO_AMD_PGM_RSDL};
+            const double c[1] = {ihw};
+            finalize(part_a, nb, 4, 1, s, c, out_dev);
+        }
+        if (what & ((1u << SPORCO_AMD_PGM_LIN) | (1u << SPORCO_AMD_PGM_DXY2) |
+                    (1u << SPORCO_AMD_PGM_GRAD2))) {
+            int nb;
+            {
+                ProfScope ps(prof, PS_PGM);
+                nb = launch_pair_stats<T>(st, cv(SPORCO_AMD_VAR_XF), cv(SPORCO_AMD_VAR_YF),
+                                          cv(SPORCO_AMD_VAR_GF), npix, P, W, part_a);
+            }
+            const int s[3] = {SPORCO_AMD_PGM_LIN, SPORCO_AMD_PGM_DXY2, SPORCO_AMD_PGM_GRAD2};
+            const double c[3] = {1.0, 1.0, 1.0};
+            finalize(part_a + 1, nb, 4, 3, s, c, out_dev);
+        }
+        if (what & (1u << SPORCO_AMD_PGM_GHG)) {
+            int nb;
+            {
+                ProfScope ps(prof, PS_PGM);
+                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_GF), innerb, npix, CN, K);
+                nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CN, W, part_a);
+            }
+            const int s[1] = {SPORCO_AMD_PGM_GHG};
+            const double c[1] = {1.0};
+            finalize(part_a + 2, nb, 4, 1, s, c, out_dev);
+        }
+        if (what & (1u << SPORCO_AMD_PGM_L1)) {
+            SA_HIP(hipMemcpyAsync(out_dev + SPORCO_AMD_PGM_L1, out_dev_own + SPORCO_AMD_PGM_L1,
+                                  sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+    }
+};
+
+}  // namespace sporco_amd
+
+using namespace sporco_amd;
+
+struct sporco_amd_csc {
+    std::unique_ptr<CscBase> impl;
+    int device;
+    double *stats_dev = nullptr;  // scratch for pgm_stats into a separate buffer
+    ~sporco_amd_csc() {
+        if (stats_dev) (void)hipFree(stats_dev);
+    }
+};
+
+#define SA_API_BEGIN try {
+#define SA_API_END                                                                     \
+    }                                                                                  \
+    catch (const sporco_amd::Error &e) {                                               \
+        g_last_error = e.what();                                                       \
+        return e.code;                                                                 \
+    }                                                                                  \
+    catch (const std::bad_alloc &) {                                                   \
+        g_last_error = "host allocation failed";                                       \
+        return SPORCO_AMD_ENOMEM;                                                      \
+    }                                                                                  \
+    catch (const std::exception &e) {                                                  \
+        g_last_error = e.what();                                                       \
+        return SPORCO_AMD_EINVAL;                                                      \
+    }                                                                                  \
+    return SPORCO_AMD_OK;
+
+#define SA_HANDLE(h)                                                                   \
+    SA_REQUIRE((h) != nullptr && (h)->impl, "null solver handle");                     \
+    SA_HIP(hipSetDevice((h)->device));
+
+extern "C" {
+
+const char *sporco_amd_version(void) { return "sporco_amd 0.1.0 (gfx950)"; }
+const char *sporco_amd_last_error(void) { return g_last_error.c_str(); }
+
+int sporco_amd_device_count(int *count) {
+    SA_API_BEGIN
+    SA_REQUIRE(count != nullptr, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        n = 0;
+        (void)hipGetLastError();
+    }
+    *count = n;
+    SA_API_END
+}
+
+int sporco_amd_device_info(int device, char *name, size_t name_len, int *cu_count,
+                           size_t *hbm_bytes) {
+    SA_API_BEGIN
+    hipDeviceProp_t prop;
+    SA_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len) {
+        std::strncpy(name, prop.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    SA_API_END
+}
+
+int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
+                          sporco_amd_csc_t *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(dims && out, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        throw Error(SPORCO_AMD_EHIP, "no HIP device visible: libsporco_amd needs an AMD GPU");
+    SA_REQUIRE(device >= 0 && device < n, "device index out of range");
+    std::unique_ptr<sporco_amd_csc> h(new sporco_amd_csc);
+    h->device = device;
+    if (dims->dtype == SPORCO_AMD_F32)
+        h->impl.reset(new Csc<float>(*dims, device, stream));
+    else if (dims->dtype == SPORCO_AMD_F64)
+        h->impl.reset(new Csc<double>(*dims, device, stream));
+    else
+        throw Error(SPORCO_AMD_EINVAL, "dtype must be SPORCO_AMD_F32 or SPORCO_AMD_F64");
+    *out = h.release();
+    SA_API_END
+}
+
+int sporco_amd_csc_destroy(sporco_amd_csc_t h) {
+    SA_API_BEGIN
+    if (h) {
+        (void)hipSetDevice(h->device);
+        delete h;
+    }
+    SA_API_END
+}
+
+int sporco_amd_csc_sync(sporco_amd_csc_t h) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->sync();
+    SA_API_END
+}
+
+int sporco_amd_csc_set_signal(sporco_amd_csc_t h, const void *S) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(S != nullptr, "S is null");
+    h->impl->set_signal(S);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_dict(sporco_amd_csc_t h, const void *D, int32_t dH, int32_t dW) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(D != nullptr, "D is null");
+    h->impl->set_dict(D, dH, dW);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_l1_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
+    h->impl->set_weight(0, w, shape);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
+    h->impl->set_weight(1, w, shape);
+    SA_API_END
+}
+
+int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(src != nullptr, "src is null");
+    h->impl->upload(var, src);
+    SA_API_END
+}
+
+int sporco_amd_csc_download(sporco_amd_csc_t h, int var, void *dst) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(dst != nullptr, "dst is null");
+    h->impl->download(var, dst);
+    SA_API_END
+}
+
+int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(ptr_dev != nullptr, "ptr_dev is null");
+    *ptr_dev = h->impl->device_ptr(var);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                             double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out, "null argument");
+    h->impl->admm_iter(*p, h->impl->out_dev_default);
+    h->impl->read_out(h->impl->out_dev_default, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_iter_dev(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                                 double *out_dev) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out_dev, "null argument");
+    h->impl->admm_iter(*p, out_dev);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_xstep(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out, "null argument");
+    h->impl->admm_xstep(*p, h->impl->out_dev_default);
+    h->impl->read_out(h->impl->out_dev_default, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_relax(sporco_amd_csc_t h, double rlx) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->admm_relax(rlx);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_ystep(sporco_amd_csc_t h, const sporco_amd_admm_params *p) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p, "null argument");
+    h->impl->admm_ystep(*p);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_ustep(sporco_amd_csc_t h, const sporco_amd_admm_params *p) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p, "null argument");
+    h->impl->admm_ustep(*p);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_stats(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out, "null argument");
+    h->impl->admm_stats(*p, h->impl->out_dev_default);
+    h->impl->read_out(h->impl->out_dev_default, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_scale_u(sporco_amd_csc_t h, double s) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->scale_u(s);
+    SA_API_END
+}
+
+int sporco_amd_csc_reconstruct(sporco_amd_csc_t h, int var, void *dst) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(dst != nullptr, "dst is null");
+    h->impl->reconstruct(var, dst);
+    SA_API_END
+}
+
+int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    h->impl->dhs_absmax(out);
+    SA_API_END
+}
+
+static double *stats_buf(sporco_amd_csc_t h) {
+    if (!h->stats_dev) {
+        SA_HIP(hipMalloc((void **)&h->stats_dev, sizeof(double) * kOutSlots));
+        SA_HIP(hipMemset(h->stats_dev, 0, sizeof(double) * kOutSlots));
+    }
+    return h->stats_dev;
+}
+
+int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->pgm_grad(var, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uint32_t flags,
+                                 int32_t dH, int32_t dW) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(L > 0.0, "L must be positive");
+    h->impl->pgm_prox_step(L, lmbda, flags, dH, dW);
+    SA_API_END
+}
+
+int sporco_amd_csc_pgm_momentum(sporco_amd_csc_t h, double beta, double gamma) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->pgm_momentum(beta, gamma);
+    SA_API_END
+}
+
+int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->copy(dst_var, src_var);
+    SA_API_END
+}
+
+int sporco_amd_csc_pgm_stats(sporco_amd_csc_t h, uint32_t what, double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->pgm_stats(what, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_profile(sporco_amd_csc_t h, int enable) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->sync();
+    h->impl->prof.drain();
+    h->impl->prof.on = enable != 0;
+    SA_API_END
+}
+
+int sporco_amd_profile_slots(void) { return PS_COUNT; }
+
+int sporco_amd_csc_profile_read(sporco_amd_csc_t h, int slot, const char **name, double *total_ms,
+                                int64_t *launches) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(slot >= 0 && slot < PS_COUNT, "timing slot out of range");
+    h->impl->prof.drain();
+    if (name) *name = kProfNames[slot];
+    if (total_ms) *total_ms = h->impl->prof.total_ms[slot];
+    if (launches) *launches = h->impl->prof.count[slot];
+    h->impl->prof.total_ms[slot] = 0.0;
+    h->impl->prof.count[slot] = 0;
+    SA_API_END
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// stateless primitives
+// ---------------------------------------------------------------------------
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) { SA_HIP(hipMalloc(&p, bytes ? bytes : 1)); }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    template <typename U> U *as() { return static_cast<U *>(p); }
+};
+
+void require_gpu() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        throw Error(SPORCO_AMD_EHIP, "no HIP device visible: libsporco_amd needs an AMD GPU");
+}
+
+template <typename T> void prim_rfftn2(int H, int W, int64_t P, const void *in, void *out) {
+    const int64_t Wf = W / 2 + 1;
+    DevBuf din(sizeof(T) * H * W * P), dout(sizeof(cx<T>) * H * Wf * P);
+    FftPlan pw, ph;
+    pw.init(W);
+    ph.init(H);
+    SA_HIP(hipMemcpy(din.p, in, sizeof(T) * H * W * P, hipMemcpyHostToDevice));
+    rfft2<T>(nullptr, pw, ph, din.as<T>(), nullptr, T(0), dout.as<cx<T>>(), H, W, P);
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dout.p, sizeof(cx<T>) * H * Wf * P, hipMemcpyDeviceToHost));
+    pw.destroy();
+    ph.destroy();
+}
+
+template <typename T> void prim_irfftn2(int H, int W, int64_t P, const void *in, void *out) {
+    const int64_t Wf = W / 2 + 1;
+    DevBuf din(sizeof(cx<T>) * H * Wf * P), dout(sizeof(T) * H * W * P);
+    FftPlan pw, ph;
+    pw.init(W);
+    ph.init(H);
+    SA_HIP(hipMemcpy(din.p, in, sizeof(cx<T>) * H * Wf * P, hipMemcpyHostToDevice));
+    irfft2<T>(nullptr, pw, ph, din.as<cx<T>>(), din.as<cx<T>>(), dout.as<T>(), H, W, P);
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dout.p, sizeof(T) * H * W * P, hipMemcpyDeviceToHost));
+    pw.destroy();
+    ph.destroy();
+}
+
+template <typename T>
+void prim_solvedbi_sm(int64_t npix, int64_t CN, int K, const void *ah, double rho, const void *b,
+                      void *x) {
+    // General right-hand side b: solve through the same kernel by passing
+    // yuf = b / rho and Sf = 0  (b = conj(Df)*0 + rho*yuf).
+    DevBuf dah(sizeof(cx<T>) * npix * K), db(sizeof(cx<T>) * npix * CN * K),
+        dsf(sizeof(cx<T>) * npix * CN), dg(sizeof(T) * npix),
+        dpart(sizeof(double) * kMaxPartialBlocks * 4);
+    SA_HIP(hipMemcpy(dah.p, ah, sizeof(cx<T>) * npix * K, hipMemcpyHostToDevice));
+    SA_HIP(hipMemcpy(db.p, b, sizeof(cx<T>) * npix * CN * K, hipMemcpyHostToDevice));
+    SA_HIP(hipMemset(dsf.p, 0, sizeof(cx<T>) * npix * CN));
+    launch_scale<T>(nullptr, db.as<T>(), (T)(1.0 / rho), 2 * npix * CN * K);
+    launch_gram<T>(nullptr, dah.as<cx<T>>(), dg.as<T>(), npix, K);
+    launch_sm_solve<T>(nullptr, db.as<cx<T>>(), db.as<cx<T>>(), dah.as<cx<T>>(), dsf.as<cx<T>>(),
+                       dg.as<T>(), (T)rho, npix, (int)CN, K, 2, false, false, dpart.as<double>());
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(x, db.p, sizeof(cx<T>) * npix * CN * K, hipMemcpyDeviceToHost));
+}
+
+template <typename T>
+void prim_inner(int64_t npix, int64_t CN, int K, const void *x, const void *y, void *out) {
+    DevBuf dx(sizeof(cx<T>) * npix * K), dy(sizeof(cx<T>) * npix * CN * K),
+        dout(sizeof(cx<T>) * npix * CN);
+    SA_HIP(hipMemcpy(dx.p, x, sizeof(cx<T>) * npix * K, hipMemcpyHostToDevice));
+    SA_HIP(hipMemcpy(dy.p, y, sizeof(cx<T>) * npix * CN * K, hipMemcpyHostToDevice));
+    launch_inner<T>(nullptr, dx.as<cx<T>>(), dy.as<cx<T>>(), dout.as<cx<T>>(), npix, (int)CN, K);
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dout.p, sizeof(cx<T>) * npix * CN, hipMemcpyDeviceToHost));
+}
+
+template <typename T> void prim_prox_l1(int64_t n, const void *v, double alpha, void *out) {
+    DevBuf dv(sizeof(T) * n), dpart(sizeof(double) * kMaxPartialBlocks);
+    SA_HIP(hipMemcpy(dv.p, v, sizeof(T) * n, hipMemcpyHostToDevice));
+    // view as (1, 1, 1, 1, n) when n fits an int, else split
+    SA_REQUIRE(n < (int64_t)1 << 31, "prox_l1 primitive: too many elements");
+    Dims5 d{1, 1, 1, 1, (int)n};
+    launch_prox_l1<T>(nullptr, dv.as<T>(), dv.as<T>(), (T)alpha, 0u, d, 1, 1, Weight<T>(),
+                      dpart.as<double>());
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dv.p, sizeof(T) * n, hipMemcpyDeviceToHost));
+}
+
+template <typename T>
+void prim_prox_sl1l2(int64_t outer, int C, int64_t inner, const void *v, double alpha, double beta,
+                     void *out) {
+    const int64_t n = outer * C * inner;
+    DevBuf dv(sizeof(T) * n), dout(sizeof(T) * n);
+    SA_HIP(hipMemcpy(dv.p, v, sizeof(T) * n, hipMemcpyHostToDevice));
+    launch_prox_sl1l2<T>(nullptr, dv.as<T>(), dout.as<T>(), (T)alpha, (T)beta, outer, C, inner);
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dout.p, sizeof(T) * n, hipMemcpyDeviceToHost));
+}
+
+template <typename T> void prim_rfl2norm2(int H, int W, int64_t P, const void *xf, double *out) {
+    const int64_t npix = (int64_t)H * (W / 2 + 1);
+    DevBuf dx(sizeof(cx<T>) * npix * P), dpart(sizeof(double) * kMaxPartialBlocks),
+        dout(sizeof(double) * kOutSlots);
+    SA_HIP(hipMemcpy(dx.p, xf, sizeof(cx<T>) * npix * P, hipMemcpyHostToDevice));
+    const int nb = launch_rfl2norm2<T>(nullptr, dx.as<cx<T>>(), nullptr, npix, P, W,
+                                       dpart.as<double>());
+    const int slots[1] = {0};
+    const double scales[1] = {1.0 / ((double)H * W)};
+    launch_finalize(nullptr, dpart.as<double>(), nb, 1, 1, slots, scales, false, dout.as<double>());
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dout.p, sizeof(double), hipMemcpyDeviceToHost));
+}
+
+}  // namespace
+
+extern "C" {
+
+#define SA_DISPATCH(dtype, fn, ...)                                                    \
+    require_gpu();                                                                     \
+    if ((dtype) == SPORCO_AMD_F32)                                                     \
+        fn<float>(__VA_ARGS__);                                                        \
+    else if ((dtype) == SPORCO_AMD_F64)                                                \
+        fn<double>(__VA_ARGS__);                                                       \
+    else                                                                               \
+        throw Error(SPORCO_AMD_EINVAL, "dtype must be SPORCO_AMD_F32 or SPORCO_AMD_F64");
+
+int sporco_amd_rfftn2(int dtype, int32_t H, int32_t W, int64_t P, const void *in, void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(in && out && H >= 1 && W >= 1 && P >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_rfftn2, H, W, P, in, out)
+    SA_API_END
+}
+
+int sporco_amd_irfftn2(int dtype, int32_t H, int32_t W, int64_t P, const void *in, void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(in && out && H >= 1 && W >= 1 && P >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_irfftn2, H, W, P, in, out)
+    SA_API_END
+}
+
+int sporco_amd_solvedbi_sm(int dtype, int64_t npix, int64_t CN, int32_t K, const void *ah,
+                           double rho, const void *b, void *x) {
+    SA_API_BEGIN
+    SA_REQUIRE(ah && b && x && npix >= 1 && CN >= 1 && K >= 1 && rho != 0.0, "bad argument");
+    SA_DISPATCH(dtype, prim_solvedbi_sm, npix, CN, K, ah, rho, b, x)
+    SA_API_END
+}
+
+int sporco_amd_inner(int dtype, int64_t npix, int64_t CN, int32_t K, const void *x, const void *y,
+                     void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(x && y && out && npix >= 1 && CN >= 1 && K >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_inner, npix, CN, K, x, y, out)
+    SA_API_END
+}
+
+int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(v && out && n >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_prox_l1, n, v, alpha, out)
+    SA_API_END
+}
+
+int sporco_amd_prox_sl1l2(int dtype, int64_t outer, int32_t C, int64_t inner, const void *v,
+                          double alpha, double beta, void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(v && out && outer >= 1 && C >= 1 && inner >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_prox_sl1l2, outer, C, inner, v, alpha, beta, out)
+    SA_API_END
+}
+
+int sporco_amd_rfl2norm2(int dtype, int32_t H, int32_t W, int64_t P, const void *xf, double *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(xf && out && H >= 1 && W >= 1 && P >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_rfl2norm2, H, W, P, xf, out)
+    SA_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// csc_kernels.h -- launchers of the non-FFT kernels of the ConvBPDN path.
+#pragma once
+
+#include "common.h"
+
+namespace sporco_amd {
+
+constexpr int kMaxPartialBlocks = 4096;  // upper bound on reduction-producing grids
+constexpr int kOutSlots = 16;            // == SPORCO_AMD_OUT_COUNT
+
+// Broadcastable weight array over (H, W, C, N, K): stride 0 on broadcast axes.
+template <typename T> struct Weight {
+    const T *ptr = nullptr;  // nullptr => scalar 1
+    int64_t stride[5] = {0, 0, 0, 0, 0};
+};
+
+struct Dims5 {
+    int H, W, C, N, K;
+};
+
+// Flags shared with the C ABI (SPORCO_AMD_FLAG_*).
+enum : uint32_t {
+    F_NONNEG = 1u << 0,
+    F_NOBNDRY = 1u << 1,
+    F_JOINT = 1u << 2,
+    F_RESID = 1u << 3,
+    F_OBJ = 1u << 4,
+    F_XRRS = 1u << 5,
+    F_GEVAL_Y = 1u << 6,
+    F_FEVAL_Y = 1u << 7,
+    F_KEEP_X = 1u << 8,
+};
+
+// dst(H, W, K) = zero-padded src(dH, dW, K)              (cnvrep.zpad, cnvrep.py:704-726)
+template <typename T>
+void launch_pad_dict(hipStream_t st, const T *src, T *dst, int H, int W, int K, int dH, int dW);
+
+// gram[pix] = sum_k |df[pix, k]|^2   (the a^H a term of linalg.solvedbi_sm_c, linalg.py:297)
+template <typename T>
+void launch_gram(hipStream_t st, const cx<T> *df, T *gram, int64_t npix, int K);
+
+// Sherman-Morrison X-step solve in the DFT domain (linalg.solvedbi_sm, linalg.py:232-297)
+// with b = conj(Df) Sf + rho * yuf formed on the fly (cbpdn.py:273):
+//     xf = yuf + conj(Df) * (Sf - sum_k Df*yuf) / (gram + rho)
+// partial sums (per block, 4 doubles): Parseval-weighted |Df.xf - Sf|^2, and the
+// LinSolveCheck triple |ax-b|^2, |ax|^2, |b|^2 (cbpdn.py:283-291).  Returns the
+// number of blocks that wrote partials.
+template <typename T>
+int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
+                    const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
+                    bool want_obj, bool want_xrrs, double *partials);
+
+// out[pix, cn] = sum_k df[pix, k] * v[pix, cn, k]   (linalg.inner over axisM, linalg.py:41-88)
+template <typename T>
+void launch_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
+                  int CN, int K);
+
+// partial[block][0] = sum wgt(wf) |ef - sf|^2 with half-spectrum weights
+// (fft.rfl2norm2, fft.py:449-484); sf may be null.  Returns #blocks.
+template <typename T>
+int launch_rfl2norm2(hipStream_t st, const cx<T> *ef, const cx<T> *sf, int64_t npix, int64_t cols,
+                     int W, double *partials);
+
+// ADMM epilogue: relax_AX + ystep + ustep + residual/objective sums in one pass
+// (admm.py:877-885, cbpdn.py:614-620 / :785-794, :297-311, admm.py:434-437, :462-486).
+// per-block partials (8 doubles): r2, s2, ax2, y2, u2, l1, l21, unused.
+template <typename T> struct PostParams {
+    const T *x;
+    T *y;
+    T *u;
+    T rlx, thr, thr21, u_scale;
+    uint32_t flags;
+    Dims5 d;
+    int dH, dW;
+    Weight<T> wl1, wl21;
+};
+template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials);
+
+// Staged pieces (each mirrors one overridable method of the reference class).
+template <typename T>
+void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t n);   // relax_AX
+template <typename T>
+void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
+                  uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21);
+template <typename T>
+void launch_ustep(hipStream_t st, const T *ax, const T *y, T *u, T u_scale, int64_t n);  // ustep
+// residual/objective sums of the staged path: x, ax unused for relaxed r (r uses x = AXnr)
+template <typename T>
+int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
+                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, double *partials);
+template <typename T> void launch_scale(hipStream_t st, T *v, T s, int64_t n);
+
+// out = soft(v, thr * w) (+ NonNeg / NoBndryCross), l1 partial = sum |w * out|
+// (prox_g of pgm/cbpdn.py:288-300; also the prox_l1 primitive).  Returns #blocks.
+template <typename T>
+int launch_prox_l1(hipStream_t st, const T *v, T *out, T thr, uint32_t flags, Dims5 d, int dH,
+                   int dW, Weight<T> wl1, double *partials);
+// prox_sl1l2 primitive on (outer, C, inner) (prox/_l21.py:51-88)
+template <typename T>
+void launch_prox_sl1l2(hipStream_t st, const T *v, T *out, T alpha, T beta, int64_t outer, int C,
+                       int64_t inner);
+
+// PGM gradient: gf = conj(df) * (sum_k df*v - sf)  (pgm/cbpdn.py:263-286);
+// partial[0] = sum |sum_k df*v - sf|^2 (unweighted), partial[1] = Parseval-weighted.
+template <typename T>
+int launch_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T> *sf, cx<T> *gf,
+                    int64_t npix, int CN, int K, int W, double *partials);
+// vf = yf - gf / L
+template <typename T>
+void launch_axpy_c(hipStream_t st, const cx<T> *y, const cx<T> *g, cx<T> *out, T a, int64_t n);
+// yf = xf + beta (xf - xfprv) + gamma (zz - xf)
+template <typename T>
+void launch_momentum(hipStream_t st, const cx<T> *xf, const cx<T> *xfprv, const cx<T> *zz,
+                     cx<T> *yf, T beta, T gamma, int64_t n);
+// complex pair statistics over (npix, cols) arrays with half-spectrum weights where noted:
+//   partial[0] = rfl2norm2-weighted sum |a - b|^2, partial[1] = sum Re(conj(a-b) g),
+//   partial[2] = sum |a-b|^2, partial[3] = sum |g|^2
+template <typename T>
+int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *g, int64_t npix,
+                      int64_t cols, int W, double *partials);
+
+// max |conj(df) * sf| over (npix, CN, K)   (cbpdn.py:573-578); partial[block][0] = block max
+template <typename T>
+int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int CN,
+                      int K, double *partials);
+
+// out[slot[i]] = scale[i] * sum_b partials[b*stride + i]  (or max when is_max)
+void launch_finalize(hipStream_t st, const double *partials, int nblocks, int stride, int nvals,
+                     const int *slots, const double *scales, bool is_max, double *out);
+
+}  // namespace sporco_amd

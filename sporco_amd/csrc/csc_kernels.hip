@@ -1,0 +1,1012 @@
+// csc_kernels.hip -- the non-FFT kernels of the ConvBPDN iteration for gfx950.
+//
+// All of them are HBM-bound streaming kernels over (pixel, C, N, K) arrays with
+// the filter index K fastest, so the mapping is always "consecutive lanes ->
+// consecutive K", 16 bytes per lane where the shape allows, wave64 shuffles for
+// the per-pixel K-length inner products, and double-precision block partials
+// (summed in a fixed order by finalize_kernel => run-to-run deterministic).
+#include "csc_kernels.h"
+
+namespace sporco_amd {
+
+constexpr int kThreads = 256;
+
+template <typename T, int V> struct alignas(sizeof(T) * V) Vec {
+    T v[V];
+};
+
+template <typename T> struct alignas(2 * sizeof(cx<T>)) cxpair {
+    cx<T> a, b;
+};
+
+static inline int grid_for(int64_t work_items, int threads = kThreads) {
+    int64_t g = ceil_div(work_items, threads);
+    if (g < 1) g = 1;
+    if (g > kMaxPartialBlocks) g = kMaxPartialBlocks;
+    return (int)g;
+}
+
+template <typename T>
+__device__ __forceinline__ T weight_at(const Weight<T> &w, int h, int x, int c, int n, int k) {
+    return w.ptr[h * w.stride[0] + x * w.stride[1] + c * w.stride[2] + n * w.stride[3] +
+                 k * w.stride[4]];
+}
+
+template <typename T> __device__ __forceinline__ T soft(T v, T thr) {
+    // sign(v) * max(|v| - thr, 0)            (prox/_lp.py:181)
+    T m = (v < T(0) ? -v : v) - thr;
+    m = m > T(0) ? m : T(0);
+    return v < T(0) ? -m : m;
+}
+
+// True when (h, x) lies in the band zeroed by NoBndryCross: Y[1-dH:, ...] = 0,
+// Y[:, 1-dW:, ...] = 0  (cbpdn.py:308-311; a size-1 filter gives slice(0, None),
+// i.e. the whole axis, which is mirrored here).
+__device__ __forceinline__ bool in_bndry(int h, int x, int H, int W, int dH, int dW) {
+    const int h0 = (dH > 1) ? H - (dH - 1) : 0;
+    const int x0 = (dW > 1) ? W - (dW - 1) : 0;
+    return h >= h0 || x >= x0;
+}
+
+// ---------------------------------------------------------------------------
+// dictionary set-up
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) pad_dict_kernel(const T *__restrict__ src,
+                                                            T *__restrict__ dst, int H, int W,
+                                                            int K, int dH, int dW) {
+    const int64_t n = (int64_t)H * W * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / K;
+        const int x = (int)(pix % W), h = (int)(pix / W);
+        dst[i] = (h < dH && x < dW) ? src[((int64_t)h * dW + x) * K + k] : T(0);
+    }
+}
+
+template <typename T>
+void launch_pad_dict(hipStream_t st, const T *src, T *dst, int H, int W, int K, int dH, int dW) {
+    const int64_t n = (int64_t)H * W * K;
+    hipLaunchKernelGGL((pad_dict_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, src, dst, H,
+                       W, K, dH, dW);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) gram_kernel(const cx<T> *__restrict__ df,
+                                                        T *__restrict__ gram, int64_t npix, int K) {
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < npix;
+         pix += (int64_t)gridDim.x * blockDim.x) {
+        T s = T(0);
+        for (int k = 0; k < K; ++k) s += cabs2(df[pix * K + k]);
+        gram[pix] = s;
+    }
+}
+
+template <typename T>
+void launch_gram(hipStream_t st, const cx<T> *df, T *gram, int64_t npix, int K) {
+    hipLaunchKernelGGL((gram_kernel<T>), dim3(grid_for(npix)), dim3(kThreads), 0, st, df, gram,
+                       npix, K);
+    SA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// Sherman-Morrison solve
+// ---------------------------------------------------------------------------
+template <typename T> struct SmArgs {
+    const cx<T> *yuf;
+    cx<T> *xf;
+    const cx<T> *df;
+    const cx<T> *sf;
+    const T *gram;
+    T rho;
+    int64_t npix;
+    int CN, K, Wf, W;
+    int want_obj, want_xrrs;
+    double *partials;
+};
+
+__device__ __forceinline__ double parseval_weight(int wf, int Wf, int W) {
+    // weights 1, 2, ..., 2, (1 if W even else 2) over the half spectrum (fft.py:476-484)
+    return (wf == 0 || ((W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+}
+
+// Fast path: K even and G = K/2 a power of two <= 64.  Each lane owns two
+// adjacent filters (one 16-byte access for f32), a group of G lanes owns one
+// (pixel, c, n) system, and the K-length inner product is a log2(G)-step
+// wave shuffle reduction.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T> a) {
+    const int G = a.K >> 1;
+    const int64_t total = a.npix * a.CN * G;
+    const int64_t total_pad = (total + kWave - 1) / kWave * kWave;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const T rho = a.rho;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_pad;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const bool valid = t < total;
+        const int64_t grp = t / G;
+        const int lg = (int)(t - grp * G);
+        const int64_t pix = grp / a.CN;
+        cxpair<T> yu, d;
+        cx<T> s = mk<T>(T(0), T(0));
+        T g = T(1);
+        yu.a = yu.b = d.a = d.b = s;
+        if (valid) {
+            yu = *reinterpret_cast<const cxpair<T> *>(a.yuf + 2 * t);
+            d = *reinterpret_cast<const cxpair<T> *>(a.df + pix * a.K + 2 * lg);
+            s = a.sf[grp];
+            g = a.gram[pix];
+        }
+        cx<T> q = cmul(d.a, yu.a) + cmul(d.b, yu.b);
+        for (int m = G >> 1; m > 0; m >>= 1) {
+            q.re += __shfl_xor(q.re, m, kWave);
+            q.im += __shfl_xor(q.im, m, kWave);
+        }
+        const T inv = T(1) / (g + rho);
+        const cx<T> coef = cscale(s - q, inv);
+        cxpair<T> x;
+        x.a = yu.a + cmulc(d.a, coef);
+        x.b = yu.b + cmulc(d.b, coef);
+        if (valid) *reinterpret_cast<cxpair<T> *>(a.xf + 2 * t) = x;
+        if (a.want_obj && valid && lg == 0) {
+            // Df.xf - Sf = rho (q - Sf) / (gram + rho)
+            const double e2 = (double)cabs2(coef) * (double)rho * (double)rho;
+            acc[0] += parseval_weight((int)(pix % a.Wf), a.Wf, a.W) * e2;
+        }
+        if (a.want_xrrs) {
+            cx<T> dx = cmul(d.a, x.a) + cmul(d.b, x.b);
+            for (int m = G >> 1; m > 0; m >>= 1) {
+                dx.re += __shfl_xor(dx.re, m, kWave);
+                dx.im += __shfl_xor(dx.im, m, kWave);
+            }
+            if (valid) {
+                const cx<T> axa = cmulc(d.a, dx) + cscale(x.a, rho);
+                const cx<T> axb = cmulc(d.b, dx) + cscale(x.b, rho);
+                const cx<T> ba = cmulc(d.a, s) + cscale(yu.a, rho);
+                const cx<T> bb = cmulc(d.b, s) + cscale(yu.b, rho);
+                acc[1] += (double)cabs2(axa - ba) + (double)cabs2(axb - bb);
+                acc[2] += (double)cabs2(axa) + (double)cabs2(axb);
+                acc[3] += (double)cabs2(ba) + (double)cabs2(bb);
+            }
+        }
+    }
+    block_sum_store<4>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * 4);
+}
+
+// Generic path (any K): one thread per (pixel, c, n) system.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs<T> a) {
+    const int64_t total = a.npix * a.CN;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const T rho = a.rho;
+    for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
+         grp += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = grp / a.CN;
+        const cx<T> *d = a.df + pix * a.K;
+        const cx<T> *yu = a.yuf + grp * a.K;
+        cx<T> *x = a.xf + grp * a.K;
+        const cx<T> s = a.sf[grp];
+        cx<T> q = mk<T>(T(0), T(0));
+        for (int k = 0; k < a.K; ++k) q = q + cmul(d[k], yu[k]);
+        const T inv = T(1) / (a.gram[pix] + rho);
+        const cx<T> coef = cscale(s - q, inv);
+        if (a.want_obj)
+            acc[0] += parseval_weight((int)(pix % a.Wf), a.Wf, a.W) * (double)cabs2(coef) *
+                      (double)rho * (double)rho;
+        cx<T> dx = mk<T>(T(0), T(0));
+        double b2 = 0.0;
+        for (int k = 0; k < a.K; ++k) {
+            const cx<T> yk = yu[k];
+            const cx<T> xk = yk + cmulc(d[k], coef);
+            if (a.want_xrrs) {
+                dx = dx + cmul(d[k], xk);
+                b2 += (double)cabs2(cmulc(d[k], s) + cscale(yk, rho));
+            }
+            x[k] = xk;
+        }
+        if (a.want_xrrs) {
+            // b = ax + (b - ax):  recompute b from x: yu = x - conj(d) coef
+            double d2 = 0.0, ax2 = 0.0;
+            for (int k = 0; k < a.K; ++k) {
+                const cx<T> xk = x[k];
+                const cx<T> yk = xk - cmulc(d[k], coef);
+                const cx<T> ax = cmulc(d[k], dx) + cscale(xk, rho);
+                const cx<T> b = cmulc(d[k], s) + cscale(yk, rho);
+                d2 += (double)cabs2(ax - b);
+                ax2 += (double)cabs2(ax);
+            }
+            acc[1] += d2;
+            acc[2] += ax2;
+            acc[3] += b2;
+        }
+    }
+    block_sum_store<4>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * 4);
+}
+
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <typename T>
+int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
+                    const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
+                    bool want_obj, bool want_xrrs, double *partials) {
+    SmArgs<T> a;
+    a.yuf = yuf;
+    a.xf = xf;
+    a.df = df;
+    a.sf = sf;
+    a.gram = gram;
+    a.rho = rho;
+    a.npix = npix;
+    a.CN = CN;
+    a.K = K;
+    a.W = W;
+    a.Wf = W / 2 + 1;
+    a.want_obj = want_obj;
+    a.want_xrrs = want_xrrs;
+    a.partials = partials;
+    const size_t lds = sizeof(double) * 4 * (kThreads / kWave);
+    int grid;
+    if (K % 2 == 0 && is_pow2(K / 2) && K / 2 <= kWave) {
+        grid = grid_for(npix * CN * (K / 2));
+        hipLaunchKernelGGL((sm_solve_wave_kernel<T>), dim3(grid), dim3(kThreads), lds, st, a);
+    } else {
+        grid = grid_for(npix * CN);
+        hipLaunchKernelGGL((sm_solve_generic_kernel<T>), dim3(grid), dim3(kThreads), lds, st, a);
+    }
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------
+// inner product over filters, half-spectrum norms
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) inner_kernel(const cx<T> *__restrict__ df,
+                                                         const cx<T> *__restrict__ v,
+                                                         cx<T> *__restrict__ out, int64_t npix,
+                                                         int CN, int K) {
+    const int64_t total = npix * CN;
+    for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
+         grp += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = grp / CN;
+        cx<T> q = mk<T>(T(0), T(0));
+        for (int k = 0; k < K; ++k) q = q + cmul(df[pix * K + k], v[grp * K + k]);
+        out[grp] = q;
+    }
+}
+
+template <typename T>
+void launch_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
+                  int CN, int K) {
+    hipLaunchKernelGGL((inner_kernel<T>), dim3(grid_for(npix * CN)), dim3(kThreads), 0, st, df, v,
+                       out, npix, CN, K);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) rfl2norm2_kernel(const cx<T> *__restrict__ ef,
+                                                             const cx<T> *__restrict__ sf,
+                                                             int64_t npix, int64_t cols, int Wf,
+                                                             int W, double *partials) {
+    const int64_t total = npix * cols;
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / cols;
+        cx<T> e = ef[i];
+        if (sf) e = e - sf[i];
+        acc[0] += parseval_weight((int)(pix % Wf), Wf, W) * (double)cabs2(e);
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T>
+int launch_rfl2norm2(hipStream_t st, const cx<T> *ef, const cx<T> *sf, int64_t npix, int64_t cols,
+                     int W, double *partials) {
+    const int grid = grid_for(npix * cols);
+    hipLaunchKernelGGL((rfl2norm2_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, ef, sf, npix, cols, W / 2 + 1, W,
+                       partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------
+// ADMM epilogue (single-pass relax + prox + dual update + all sums)
+// ---------------------------------------------------------------------------
+// GENERAL = weight arrays and/or NoBndryCross need the 5-D index of every element.
+template <typename T, int VEC, bool GENERAL>
+__global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T> p, int64_t nvec,
+                                                             double *partials) {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const T a = p.rlx, oma = T(1) - p.rlx;
+    const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY, gy = p.flags & F_GEVAL_Y;
+    const int64_t P = (int64_t)p.d.C * p.d.N * p.d.K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const Vec<T, VEC> xv = reinterpret_cast<const Vec<T, VEC> *>(p.x)[i];
+        Vec<T, VEC> yv = reinterpret_cast<const Vec<T, VEC> *>(p.y)[i];
+        Vec<T, VEC> uv = reinterpret_cast<const Vec<T, VEC> *>(p.u)[i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const T x = xv.v[e], yo = yv.v[e], uo = p.u_scale * uv.v[e];
+            const T ax = a * x + oma * yo;
+            T w = T(1);
+            bool kill = false;
+            if (GENERAL) {
+                const int64_t idx = i * VEC + e;
+                const int64_t pix = idx / P;
+                const int r = (int)(idx - pix * P);
+                const int k = r % p.d.K, n = (r / p.d.K) % p.d.N, c = r / (p.d.K * p.d.N);
+                const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
+                if (p.wl1.ptr) w = weight_at(p.wl1, h, xw, c, n, k);
+                kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
+            }
+            T yn = soft(ax + uo, p.thr * w);
+            if (nonneg && yn < T(0)) yn = T(0);
+            if (kill) yn = T(0);
+            const T un = uo + ax - yn;
+            yv.v[e] = yn;
+            uv.v[e] = un;
+            const double dr = (double)(x - yn), ds = (double)(yn - yo);
+            acc[0] += dr * dr;
+            acc[1] += ds * ds;
+            acc[2] += (double)x * (double)x;
+            acc[3] += (double)yn * (double)yn;
+            acc[4] += (double)un * (double)un;
+            const T gv = w * (gy ? yn : x);
+            acc[5] += (double)(gv < T(0) ? -gv : gv);
+        }
+        reinterpret_cast<Vec<T, VEC> *>(p.y)[i] = yv;
+        reinterpret_cast<Vec<T, VEC> *>(p.u)[i] = uv;
+    }
+    block_sum_store<8>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 8);
+}
+
+// Joint l1 + l2,1 epilogue: one thread per (pixel, n, k), looping over the C
+// channels that prox_l2 couples (prox/_lp.py:283-290 over axisC, cbpdn.py:790-793).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostParams<T> p,
+                                                                   double *partials) {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const T a = p.rlx, oma = T(1) - p.rlx;
+    const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY, gy = p.flags & F_GEVAL_Y;
+    const int C = p.d.C;
+    const int64_t NK = (int64_t)p.d.N * p.d.K;
+    const int64_t total = (int64_t)p.d.H * p.d.W * NK;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / NK;
+        const int nk = (int)(t - pix * NK);
+        const int k = nk % p.d.K, n = nk / p.d.K;
+        const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
+        const int64_t base = pix * C * NK + nk;
+        const bool kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
+        // pass 1: l2 norm over channels of the soft-thresholded values
+        T nrm2 = T(0);
+        for (int c = 0; c < C; ++c) {
+            const int64_t idx = base + c * NK;
+            const T w = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
+            const T ax = a * p.x[idx] + oma * p.y[idx];
+            const T sv = soft(ax + p.u_scale * p.u[idx], p.thr * w);
+            nrm2 += sv * sv;
+        }
+        const T nrm = sqrt(nrm2);
+        const T w21 = p.wl21.ptr ? weight_at(p.wl21, h, xw, 0, n, k) : T(1);
+        T shrink = nrm - p.thr21 * w21;
+        shrink = shrink > T(0) ? shrink : T(0);
+        const T fac = (nrm != T(0)) ? shrink / nrm : T(0);  // array.zdivide, array.py:119-137
+        // pass 2: outputs and sums
+        double g2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const int64_t idx = base + c * NK;
+            const T w = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
+            const T x = p.x[idx], yo = p.y[idx], uo = p.u_scale * p.u[idx];
+            const T ax = a * x + oma * yo;
+            T yn = fac * soft(ax + uo, p.thr * w);
+            if (nonneg && yn < T(0)) yn = T(0);
+            if (kill) yn = T(0);
+            const T un = uo + ax - yn;
+            p.y[idx] = yn;
+            p.u[idx] = un;
+            const double dr = (double)(x - yn), ds = (double)(yn - yo);
+            acc[0] += dr * dr;
+            acc[1] += ds * ds;
+            acc[2] += (double)x * (double)x;
+            acc[3] += (double)yn * (double)yn;
+            acc[4] += (double)un * (double)un;
+            const T gvar = gy ? yn : x;
+            const T gv = w * gvar;
+            acc[5] += (double)(gv < T(0) ? -gv : gv);
+            g2 += (double)gvar * (double)gvar;
+        }
+        acc[6] += (double)w21 * sqrt(g2);
+    }
+    block_sum_store<8>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 8);
+}
+
+template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials) {
+    const int64_t E = (int64_t)p.d.H * p.d.W * p.d.C * p.d.N * p.d.K;
+    const size_t lds = sizeof(double) * 8 * (kThreads / kWave);
+    int grid;
+    if (p.flags & F_JOINT) {
+        grid = grid_for(E / p.d.C);
+        hipLaunchKernelGGL((admm_post_joint_kernel<T>), dim3(grid), dim3(kThreads), lds, st, p,
+                           partials);
+    } else {
+        const bool general = p.wl1.ptr != nullptr || (p.flags & F_NOBNDRY);
+        constexpr int V = 16 / sizeof(T);
+        if (E % V == 0) {
+            grid = grid_for(E / V);
+            if (general)
+                hipLaunchKernelGGL((admm_post_kernel<T, V, true>), dim3(grid), dim3(kThreads), lds,
+                                   st, p, E / V, partials);
+            else
+                hipLaunchKernelGGL((admm_post_kernel<T, V, false>), dim3(grid), dim3(kThreads), lds,
+                                   st, p, E / V, partials);
+        } else {
+            grid = grid_for(E);
+            if (general)
+                hipLaunchKernelGGL((admm_post_kernel<T, 1, true>), dim3(grid), dim3(kThreads), lds,
+                                   st, p, E, partials);
+            else
+                hipLaunchKernelGGL((admm_post_kernel<T, 1, false>), dim3(grid), dim3(kThreads), lds,
+                                   st, p, E, partials);
+        }
+    }
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------
+// staged ADMM pieces
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) relax_kernel(const T *__restrict__ x,
+                                                         const T *__restrict__ y,
+                                                         T *__restrict__ ax, T rlx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        ax[i] = rlx * x[i] + (T(1) - rlx) * y[i];
+}
+
+template <typename T>
+void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t n) {
+    hipLaunchKernelGGL((relax_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, x, y, ax, rlx, n);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T> struct YstepArgs {
+    const T *ax;
+    const T *u;
+    T *y;
+    T thr, thr21, u_scale;
+    uint32_t flags;
+    Dims5 d;
+    int dH, dW;
+    Weight<T> wl1, wl21;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
+    const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY, joint = p.flags & F_JOINT;
+    const int C = p.d.C;
+    const int64_t NK = (int64_t)p.d.N * p.d.K;
+    const int64_t total = (int64_t)p.d.H * p.d.W * NK;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / NK;
+        const int nk = (int)(t - pix * NK);
+        const int k = nk % p.d.K, n = nk / p.d.K;
+        const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
+        const int64_t base = pix * C * NK + nk;
+        const bool kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
+        T fac = T(1);
+        if (joint) {
+            T nrm2 = T(0);
+            for (int c = 0; c < C; ++c) {
+                const int64_t idx = base + c * NK;
+                const T w = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
+                const T sv = soft(p.ax[idx] + p.u_scale * p.u[idx], p.thr * w);
+                nrm2 += sv * sv;
+            }
+            const T nrm = sqrt(nrm2);
+            const T w21 = p.wl21.ptr ? weight_at(p.wl21, h, xw, 0, n, k) : T(1);
+            T shrink = nrm - p.thr21 * w21;
+            shrink = shrink > T(0) ? shrink : T(0);
+            fac = (nrm != T(0)) ? shrink / nrm : T(0);
+        }
+        for (int c = 0; c < C; ++c) {
+            const int64_t idx = base + c * NK;
+            const T w = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
+            T yn = fac * soft(p.ax[idx] + p.u_scale * p.u[idx], p.thr * w);
+            if (nonneg && yn < T(0)) yn = T(0);
+            if (kill) yn = T(0);
+            p.y[idx] = yn;
+        }
+    }
+}
+
+template <typename T>
+void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
+                  uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21) {
+    YstepArgs<T> p;
+    p.ax = ax;
+    p.u = u;
+    p.y = y;
+    p.thr = thr;
+    p.thr21 = thr21;
+    p.u_scale = u_scale;
+    p.flags = flags;
+    p.d = d;
+    p.dH = dH;
+    p.dW = dW;
+    p.wl1 = wl1;
+    p.wl21 = wl21;
+    const int64_t total = (int64_t)d.H * d.W * d.N * d.K;
+    hipLaunchKernelGGL((ystep_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, p);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) ustep_kernel(const T *__restrict__ ax,
+                                                         const T *__restrict__ y,
+                                                         T *__restrict__ u, T u_scale, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        u[i] = u_scale * u[i] + ax[i] - y[i];
+}
+
+template <typename T>
+void launch_ustep(hipStream_t st, const T *ax, const T *y, T *u, T u_scale, int64_t n) {
+    hipLaunchKernelGGL((ustep_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, ax, y, u,
+                       u_scale, n);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T> struct StatsArgs {
+    const T *x;
+    const T *y;
+    const T *yprev;
+    const T *u;
+    uint32_t flags;
+    Dims5 d;
+    Weight<T> wl1, wl21;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T> p,
+                                                              double *partials) {
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const bool gy = p.flags & F_GEVAL_Y, joint = p.flags & F_JOINT;
+    const int C = p.d.C;
+    const int64_t NK = (int64_t)p.d.N * p.d.K;
+    const int64_t total = (int64_t)p.d.H * p.d.W * NK;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / NK;
+        const int nk = (int)(t - pix * NK);
+        const int k = nk % p.d.K, n = nk / p.d.K;
+        const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
+        const int64_t base = pix * C * NK + nk;
+        double g2 = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const int64_t idx = base + c * NK;
+            const T w = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
+            const T x = p.x[idx], y = p.y[idx], yo = p.yprev[idx], u = p.u[idx];
+            const double dr = (double)(x - y), ds = (double)(y - yo);
+            acc[0] += dr * dr;
+            acc[1] += ds * ds;
+            acc[2] += (double)x * (double)x;
+            acc[3] += (double)y * (double)y;
+            acc[4] += (double)u * (double)u;
+            const T gvar = gy ? y : x;
+            const T gv = w * gvar;
+            acc[5] += (double)(gv < T(0) ? -gv : gv);
+            g2 += (double)gvar * (double)gvar;
+        }
+        if (joint) {
+            const T w21 = p.wl21.ptr ? weight_at(p.wl21, h, xw, 0, n, k) : T(1);
+            acc[6] += (double)w21 * sqrt(g2);
+        }
+    }
+    block_sum_store<8>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 8);
+}
+
+template <typename T>
+int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
+                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, double *partials) {
+    StatsArgs<T> p;
+    p.x = x;
+    p.y = y;
+    p.yprev = yprev;
+    p.u = u;
+    p.flags = flags;
+    p.d = d;
+    p.wl1 = wl1;
+    p.wl21 = wl21;
+    const int grid = grid_for((int64_t)d.H * d.W * d.N * d.K);
+    hipLaunchKernelGGL((admm_stats_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 8 * (kThreads / kWave), st, p, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) scale_kernel(T *__restrict__ v, T s, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        v[i] *= s;
+}
+
+template <typename T> void launch_scale(hipStream_t st, T *v, T s, int64_t n) {
+    hipLaunchKernelGGL((scale_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, v, s, n);
+    SA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// proximal operators
+// ---------------------------------------------------------------------------
+template <typename T> struct ProxArgs {
+    const T *v;
+    T *out;
+    T thr;
+    uint32_t flags;
+    Dims5 d;
+    int dH, dW;
+    Weight<T> wl1;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) prox_l1_kernel(const ProxArgs<T> p, double *partials) {
+    double acc[1] = {0.0};
+    const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY;
+    const bool general = nob || p.wl1.ptr != nullptr;
+    const int64_t P = (int64_t)p.d.C * p.d.N * p.d.K;
+    const int64_t total = (int64_t)p.d.H * p.d.W * P;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        T w = T(1);
+        bool kill = false;
+        if (general) {
+            const int64_t pix = idx / P;
+            const int r = (int)(idx - pix * P);
+            const int k = r % p.d.K, n = (r / p.d.K) % p.d.N, c = r / (p.d.K * p.d.N);
+            const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
+            if (p.wl1.ptr) w = weight_at(p.wl1, h, xw, c, n, k);
+            kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
+        }
+        T o = soft(p.v[idx], p.thr * w);
+        if (nonneg && o < T(0)) o = T(0);
+        if (kill) o = T(0);
+        p.out[idx] = o;
+        const T gv = w * o;
+        acc[0] += (double)(gv < T(0) ? -gv : gv);
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T>
+int launch_prox_l1(hipStream_t st, const T *v, T *out, T thr, uint32_t flags, Dims5 d, int dH,
+                   int dW, Weight<T> wl1, double *partials) {
+    ProxArgs<T> p;
+    p.v = v;
+    p.out = out;
+    p.thr = thr;
+    p.flags = flags;
+    p.d = d;
+    p.dH = dH;
+    p.dW = dW;
+    p.wl1 = wl1;
+    const int grid = grid_for((int64_t)d.H * d.W * d.C * d.N * d.K);
+    hipLaunchKernelGGL((prox_l1_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, p, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) prox_sl1l2_kernel(const T *__restrict__ v,
+                                                              T *__restrict__ out, T alpha, T beta,
+                                                              int64_t outer, int C, int64_t inner) {
+    const int64_t total = outer * inner;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = t / inner, in = t - o * inner;
+        const int64_t base = o * C * inner + in;
+        T nrm2 = T(0);
+        for (int c = 0; c < C; ++c) {
+            const T sv = soft(v[base + c * inner], alpha);
+            nrm2 += sv * sv;
+        }
+        const T nrm = sqrt(nrm2);
+        T shrink = nrm - beta;
+        shrink = shrink > T(0) ? shrink : T(0);
+        const T fac = (nrm != T(0)) ? shrink / nrm : T(0);
+        for (int c = 0; c < C; ++c) out[base + c * inner] = fac * soft(v[base + c * inner], alpha);
+    }
+}
+
+template <typename T>
+void launch_prox_sl1l2(hipStream_t st, const T *v, T *out, T alpha, T beta, int64_t outer, int C,
+                       int64_t inner) {
+    hipLaunchKernelGGL((prox_sl1l2_kernel<T>), dim3(grid_for(outer * inner)), dim3(kThreads), 0, st,
+                       v, out, alpha, beta, outer, C, inner);
+    SA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// PGM kernels
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) pgm_grad_kernel(const cx<T> *__restrict__ v,
+                                                            const cx<T> *__restrict__ df,
+                                                            const cx<T> *__restrict__ sf,
+                                                            cx<T> *__restrict__ gf, int64_t npix,
+                                                            int CN, int K, int Wf, int W,
+                                                            double *partials) {
+    // wave-cooperative when K is a power of two <= 64 (lane = filter), else per-thread loop
+    double acc[2] = {0.0, 0.0};
+    const bool coop = K <= kWave && (K & (K - 1)) == 0;
+    if (coop) {
+        const int64_t total = npix * CN * K;
+        const int64_t total_pad = (total + kWave - 1) / kWave * kWave;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_pad;
+             t += (int64_t)gridDim.x * blockDim.x) {
+            const bool valid = t < total;
+            const int64_t grp = t / K;
+            const int k = (int)(t - grp * K);
+            const int64_t pix = grp / CN;
+            cx<T> d = mk<T>(T(0), T(0)), x = d, s = d;
+            if (valid) {
+                d = df[pix * K + k];
+                x = v[t];
+                s = sf[grp];
+            }
+            cx<T> q = cmul(d, x);
+            for (int m = K >> 1; m > 0; m >>= 1) {
+                q.re += __shfl_xor(q.re, m, kWave);
+                q.im += __shfl_xor(q.im, m, kWave);
+            }
+            const cx<T> r = q - s;
+            if (valid) {
+                gf[t] = cmulc(d, r);
+                if (k == 0) {
+                    const double r2 = (double)cabs2(r);
+                    acc[0] += r2;
+                    acc[1] += parseval_weight((int)(pix % Wf), Wf, W) * r2;
+                }
+            }
+        }
+    } else {
+        const int64_t total = npix * CN;
+        for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
+             grp += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t pix = grp / CN;
+            cx<T> q = mk<T>(T(0), T(0));
+            for (int k = 0; k < K; ++k) q = q + cmul(df[pix * K + k], v[grp * K + k]);
+            const cx<T> r = q - sf[grp];
+            for (int k = 0; k < K; ++k) gf[grp * K + k] = cmulc(df[pix * K + k], r);
+            const double r2 = (double)cabs2(r);
+            acc[0] += r2;
+            acc[1] += parseval_weight((int)(pix % Wf), Wf, W) * r2;
+        }
+    }
+    block_sum_store<2>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 2);
+}
+
+template <typename T>
+int launch_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T> *sf, cx<T> *gf,
+                    int64_t npix, int CN, int K, int W, double *partials) {
+    const bool coop = K <= kWave && (K & (K - 1)) == 0;
+    const int grid = grid_for(coop ? npix * CN * K : npix * CN);
+    hipLaunchKernelGGL((pgm_grad_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 2 * (kThreads / kWave), st, v, df, sf, gf, npix, CN, K,
+                       W / 2 + 1, W, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) axpy_c_kernel(const cx<T> *__restrict__ y,
+                                                          const cx<T> *__restrict__ g,
+                                                          cx<T> *__restrict__ out, T a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y[i] + cscale(g[i], a);
+}
+
+template <typename T>
+void launch_axpy_c(hipStream_t st, const cx<T> *y, const cx<T> *g, cx<T> *out, T a, int64_t n) {
+    hipLaunchKernelGGL((axpy_c_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, y, g, out, a, n);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) momentum_kernel(const cx<T> *__restrict__ xf,
+                                                            const cx<T> *__restrict__ xfprv,
+                                                            const cx<T> *__restrict__ zz,
+                                                            cx<T> *__restrict__ yf, T beta, T gamma,
+                                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const cx<T> x = xf[i];
+        cx<T> y = x + cscale(x - xfprv[i], beta);
+        if (zz) y = y + cscale(zz[i] - x, gamma);
+        yf[i] = y;
+    }
+}
+
+template <typename T>
+void launch_momentum(hipStream_t st, const cx<T> *xf, const cx<T> *xfprv, const cx<T> *zz,
+                     cx<T> *yf, T beta, T gamma, int64_t n) {
+    hipLaunchKernelGGL((momentum_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, xf, xfprv,
+                       zz, yf, beta, gamma, n);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) pair_stats_kernel(const cx<T> *__restrict__ a,
+                                                              const cx<T> *__restrict__ b,
+                                                              const cx<T> *__restrict__ g,
+                                                              int64_t npix, int64_t cols, int Wf,
+                                                              int W, double *partials) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t total = npix * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / cols;
+        cx<T> dlt = a[i];
+        if (b) dlt = dlt - b[i];
+        const double d2 = (double)cabs2(dlt);
+        acc[0] += parseval_weight((int)(pix % Wf), Wf, W) * d2;
+        acc[2] += d2;
+        if (g) {
+            const cx<T> gg = g[i];
+            acc[1] += (double)dlt.re * (double)gg.re + (double)dlt.im * (double)gg.im;
+            acc[3] += (double)cabs2(gg);
+        }
+    }
+    block_sum_store<4>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 4);
+}
+
+template <typename T>
+int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *g, int64_t npix,
+                      int64_t cols, int W, double *partials) {
+    const int grid = grid_for(npix * cols);
+    hipLaunchKernelGGL((pair_stats_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 4 * (kThreads / kWave), st, a, b, g, npix, cols, W / 2 + 1,
+                       W, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) dhs_absmax_kernel(const cx<T> *__restrict__ df,
+                                                              const cx<T> *__restrict__ sf,
+                                                              int64_t npix, int CN, int K,
+                                                              double *partials) {
+    double m = 0.0;
+    const int64_t total = npix * CN * K;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t grp = t / K;
+        const int k = (int)(t - grp * K);
+        const int64_t pix = grp / CN;
+        const double v = (double)cabs2(cmulc(df[pix * K + k], sf[grp]));
+        m = v > m ? v : m;
+    }
+    // block max through LDS
+    double *scratch = dyn_lds<double>();
+    for (int s = kWave / 2; s > 0; s >>= 1) {
+        const double o = __shfl_xor(m, s, kWave);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) scratch[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int j = 0; j < (int)(blockDim.x / kWave); ++j) r = scratch[j] > r ? scratch[j] : r;
+        partials[blockIdx.x] = r;
+    }
+}
+
+template <typename T>
+int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int CN,
+                      int K, double *partials) {
+    const int grid = grid_for(npix * CN * K);
+    hipLaunchKernelGGL((dhs_absmax_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, df, sf, npix, CN, K, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------
+// fixed-order final reduction of block partials
+// ---------------------------------------------------------------------------
+struct FinalizeArgs {
+    const double *partials;
+    int nblocks, stride, nvals, is_max;
+    int slots[8];
+    double scales[8];
+    double *out;
+};
+
+__global__ void __launch_bounds__(kThreads) finalize_kernel(const FinalizeArgs a) {
+    // thread t sums blocks t, t+256, ... of value i; then a fixed-shape LDS tree
+    double *scratch = dyn_lds<double>();
+    for (int i = 0; i < a.nvals; ++i) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < a.nblocks; b += blockDim.x) {
+            const double v = a.partials[(int64_t)b * a.stride + i];
+            s = a.is_max ? (v > s ? v : s) : s + v;
+        }
+        scratch[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) {
+                const double o = scratch[threadIdx.x + w];
+                scratch[threadIdx.x] = a.is_max ? (o > scratch[threadIdx.x] ? o : scratch[threadIdx.x])
+                                                : scratch[threadIdx.x] + o;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.out[a.slots[i]] = scratch[0] * a.scales[i];
+        __syncthreads();
+    }
+}
+
+void launch_finalize(hipStream_t st, const double *partials, int nblocks, int stride, int nvals,
+                     const int *slots, const double *scales, bool is_max, double *out) {
+    FinalizeArgs a;
+    a.partials = partials;
+    a.nblocks = nblocks;
+    a.stride = stride;
+    a.nvals = nvals;
+    a.is_max = is_max ? 1 : 0;
+    for (int i = 0; i < 8; ++i) {
+        a.slots[i] = i < nvals ? slots[i] : 0;
+        a.scales[i] = i < nvals ? scales[i] : 0.0;
+    }
+    a.out = out;
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), sizeof(double) * kThreads, st, a);
+    SA_HIP(hipGetLastError());
+}
+
+#define SA_INST(T)                                                                                 \
+    template void launch_pad_dict<T>(hipStream_t, const T *, T *, int, int, int, int, int);        \
+    template void launch_gram<T>(hipStream_t, const cx<T> *, T *, int64_t, int);                   \
+    template int launch_sm_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,            \
+                                    const cx<T> *, const T *, T, int64_t, int, int, int, bool,     \
+                                    bool, double *);                                               \
+    template void launch_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,     \
+                                  int, int);                                                       \
+    template int launch_rfl2norm2<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int64_t,  \
+                                     int, double *);                                               \
+    template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *);                \
+    template void launch_relax<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
+    template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \
+                                  Dims5, int, int, Weight<T>, Weight<T>);                          \
+    template void launch_ustep<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
+    template int launch_admm_stats<T>(hipStream_t, const T *, const T *, const T *, const T *,     \
+                                      uint32_t, Dims5, Weight<T>, Weight<T>, double *);            \
+    template void launch_scale<T>(hipStream_t, T *, T, int64_t);                                   \
+    template int launch_prox_l1<T>(hipStream_t, const T *, T *, T, uint32_t, Dims5, int, int,      \
+                                   Weight<T>, double *);                                           \
+    template void launch_prox_sl1l2<T>(hipStream_t, const T *, T *, T, T, int64_t, int, int64_t);  \
+    template int launch_pgm_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,      \
+                                    cx<T> *, int64_t, int, int, int, double *);                    \
+    template void launch_axpy_c<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, T,          \
+                                   int64_t);                                                       \
+    template void launch_momentum<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,     \
+                                     cx<T> *, T, T, int64_t);                                      \
+    template int launch_pair_stats<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
+                                      int64_t, int64_t, int, double *);                            \
+    template int launch_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,     \
+                                      int, double *);
+SA_INST(float)
+SA_INST(double)
+
+}  // namespace sporco_amd

@@ -1,0 +1,64 @@
+// fft.h -- batched strided line FFTs for the (H, W, P) layout (P = C*N*K fastest).
+//
+// Replaces the reference's sporco.fft.rfftn / irfftn over axes (0, 1)
+// (sporco/fft.py:257-314; numpy fallback :631-639).  The transform axes are
+// the SLOWEST axes of the array, so every kernel here works on "lines with a
+// contiguous batch": a workgroup owns all n points of `cols` adjacent batch
+// columns, which makes each global access a contiguous >=128-byte segment.
+#pragma once
+
+#include "common.h"
+
+namespace sporco_amd {
+
+constexpr int kMaxRadixPasses = 24;
+
+// Factorisation + twiddle tables of one transform length (host object).
+struct FftPlan {
+    int n = 0;
+    int nrad = 0;
+    int radix[kMaxRadixPasses] = {0};
+    cx<float> *tw32 = nullptr;   // device, W_n^t = exp(-2 pi i t / n), t in [0, n)
+    cx<double> *tw64 = nullptr;  // device
+    void init(int n_);
+    void destroy();
+    template <typename T> const cx<T> *tw() const;
+};
+
+// Complex -> complex lines.  Element (o, i, c) of the input lives at
+// in[o*in_outer + i*in_line + c] (units: complex elements), likewise for out.
+template <typename T>
+void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in, cx<T> *out,
+             int64_t n_outer, int64_t ncols, int64_t in_outer, int64_t in_line,
+             int64_t out_outer, int64_t out_line, T scale);
+
+// Real -> half-spectrum lines (forward).  Input element (o, i, p) at
+// in[o*in_outer + i*in_line + p] (units: reals), p in [0, P).  If in2 != null
+// the transformed signal is in - s2*in2 (fuses `YU = Y - U`,
+// sporco/admm/cbpdn.py:271).  Output (o, f, p), f in [0, n/2], at
+// out[o*out_outer + f*out_line + p] (units: complex).
+template <typename T>
+void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
+             int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
+             int64_t out_line);
+
+// Half-spectrum -> real lines (inverse, unnormalised times `scale`).  The
+// imaginary parts of the DC (and Nyquist, n even) bins are ignored, as
+// numpy.fft.irfft / FFTW c2r do.
+template <typename T>
+void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64_t n_outer,
+             int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer, int64_t out_line,
+             T scale);
+
+// out(H, W/2+1, P) = rfftn(in [- s2*in2], axes=(0,1)) for real in(H, W, P).
+template <typename T>
+void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
+           T s2, cx<T> *out, int H, int W, int64_t P);
+
+// out(H, W, P) = irfftn(in(H, W/2+1, P), s=(H, W)); `tmp` receives the
+// column-transformed spectrum (may alias `in` for an in-place column pass).
+template <typename T>
+void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx<T> *in,
+            cx<T> *tmp, T *out, int H, int W, int64_t P);
+
+}  // namespace sporco_amd

@@ -1,0 +1,483 @@
+// fft.hip -- generic-length batched line FFT kernels (Stockham autosort in LDS).
+//
+// One kernel template serves every transform on the path:
+//   MODE_C2C  complex lines (the H axis of rfftn/irfftn),
+//   MODE_R2C  real -> half spectrum (the W axis of rfftn, sporco/fft.py:257-286),
+//   MODE_C2R  half spectrum -> real (the W axis of irfftn, sporco/fft.py:288-314).
+// For real transforms two ADJACENT batch columns (p, p+1) are packed into one
+// complex line z = x_p + i x_{p+1}; with the filter-fastest layout that pair is a
+// single aligned 8-byte (f32) load, and the two half spectra are separated
+// ("untangled") on the way out.  Odd batch counts use one real column per
+// complex line.
+//
+// A workgroup holds `cols` adjacent columns x all n points in LDS
+// ([i][col], col fastest => conflict-free b64 accesses and 128-byte global
+// segments), runs the radix passes ping-pong between two LDS buffers and
+// streams the result out.  Radices 8/4/2 use in-register butterflies; any
+// other factor (3, 5, 7, 17, ...) goes through a direct O(R) per-output pass,
+// so every length that fits LDS is supported.
+#include "fft.h"
+
+#include <cmath>
+#include <vector>
+
+namespace sporco_amd {
+
+enum { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
+
+template <typename T> struct LineArgs {
+    const void *in;
+    const void *in2;
+    void *out;
+    const cx<T> *tw;
+    T s2, scale;
+    int n, nfreq, cols, inverse, nrad;
+    int radix[kMaxRadixPasses];
+    int64_t ncols;
+    int64_t in_outer, in_line, out_outer, out_line;
+};
+
+// two adjacent complex values moved as one vector access
+template <typename T> struct alignas(2 * sizeof(cx<T>)) cx2 {
+    cx<T> a, b;
+};
+
+// ---------------------------------------------------------------------------
+// in-register butterflies; INV selects exp(+2 pi i ...) kernels
+// ---------------------------------------------------------------------------
+template <typename T, bool INV> __device__ __forceinline__ cx<T> quarter(cx<T> a) {
+    // multiply by W4 = exp(-/+ i pi/2)
+    return INV ? mul_pi(a) : mul_mi(a);
+}
+
+template <typename T, bool INV>
+__device__ __forceinline__ void dft4(cx<T> &a0, cx<T> &a1, cx<T> &a2, cx<T> &a3) {
+    const cx<T> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = quarter<T, INV>(a1 - a3);
+    a0 = t0 + t2;
+    a1 = t1 + t3;
+    a2 = t0 - t2;
+    a3 = t1 - t3;
+}
+
+template <typename T, int R, bool INV> struct Butterfly;
+
+template <typename T, bool INV> struct Butterfly<T, 2, INV> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[2]) {
+        const cx<T> a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+};
+
+template <typename T, bool INV> struct Butterfly<T, 4, INV> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[4]) { dft4<T, INV>(v[0], v[1], v[2], v[3]); }
+};
+
+template <typename T, bool INV> struct Butterfly<T, 8, INV> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[8]) {
+        cx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+        cx<T> o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+        dft4<T, INV>(e0, e1, e2, e3);
+        dft4<T, INV>(o0, o1, o2, o3);
+        const T h = T(0.70710678118654752440);
+        // W8^1 = (1 -/+ i)/sqrt2, W8^2 = -/+ i, W8^3 = (-1 -/+ i)/sqrt2
+        const cx<T> w1 = INV ? mk<T>(h * (o1.re - o1.im), h * (o1.re + o1.im))
+                             : mk<T>(h * (o1.re + o1.im), h * (o1.im - o1.re));
+        const cx<T> w2 = quarter<T, INV>(o2);
+        const cx<T> w3 = INV ? mk<T>(-h * (o3.re + o3.im), h * (o3.re - o3.im))
+                             : mk<T>(h * (o3.im - o3.re), -h * (o3.re + o3.im));
+        v[0] = e0 + o0;
+        v[4] = e0 - o0;
+        v[1] = e1 + w1;
+        v[5] = e1 - w1;
+        v[2] = e2 + w2;
+        v[6] = e2 - w2;
+        v[3] = e3 + w3;
+        v[7] = e3 - w3;
+    }
+};
+
+// One Stockham pass of radix R over the `cols` columns held by the workgroup.
+//   read  src[j + r*n/R],  twiddle exp(-/+ 2 pi i k r /(Ns R)), k = j mod Ns,
+//   write dst[(j div Ns) Ns R + k + q Ns]
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void radix_pass(const cx<T> *__restrict__ src, cx<T> *__restrict__ dst,
+                                           const cx<T> *__restrict__ tw, int n, int Ns, int cols,
+                                           int col, int lane, int lpc) {
+    const int nb = n / R;
+    const int tmul = n / (Ns * R);
+    for (int j = lane; j < nb; j += lpc) {
+        const int k = j % Ns;
+        const int j0 = (j - k) * R + k;
+        const int ts = k * tmul;
+        cx<T> v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const cx<T> x = src[(j + r * nb) * cols + col];
+            v[r] = (r == 0 || Ns == 1) ? x : cmul(x, tw[r * ts]);
+        }
+        Butterfly<T, R, INV>::run(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) dst[(j0 + q * Ns) * cols + col] = v[q];
+    }
+}
+
+// Direct pass for an arbitrary radix R: every output is an R-term sum.
+template <typename T>
+__device__ __forceinline__ void direct_pass(const cx<T> *__restrict__ src, cx<T> *__restrict__ dst,
+                                            const cx<T> *__restrict__ tw, int n, int R, int Ns,
+                                            int cols, int col, int lane, int lpc) {
+    const int nb = n / R;
+    const int tmul = n / (Ns * R);
+    for (int item = lane; item < n; item += lpc) {
+        const int j = item % nb, q = item / nb;
+        const int k = j % Ns;
+        const int j0 = (j - k) * R + k;
+        int step = k * tmul + q * nb;
+        if (step >= n) step -= n;
+        int idx = 0;
+        cx<T> acc = mk<T>(T(0), T(0));
+        for (int r = 0; r < R; ++r) {
+            acc = acc + cmul(src[(j + r * nb) * cols + col], tw[idx]);
+            idx += step;
+            if (idx >= n) idx -= n;
+        }
+        dst[(j0 + q * Ns) * cols + col] = acc;
+    }
+}
+
+template <typename T, int MODE, bool PACK>
+__global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
+    const int n = a.n, cols = a.cols;
+    cx<T> *buf0 = dyn_lds<cx<T>>();
+    cx<T> *buf1 = buf0 + (size_t)n * cols;
+    cx<T> *tw = buf1 + (size_t)n * cols;
+
+    const int tid = threadIdx.x;
+    const int col = tid % cols, lane = tid / cols, lpc = blockDim.x / cols;
+    const int64_t c = (int64_t)blockIdx.x * cols + col;
+    const int64_t o = blockIdx.y;
+    const bool valid = c < a.ncols;
+    const cx<T> zero = mk<T>(T(0), T(0));
+
+    for (int t = tid; t < n; t += blockDim.x) {
+        cx<T> w = a.tw[t];
+        if (a.inverse) w.im = -w.im;
+        tw[t] = w;
+    }
+
+    // ---------------- load ----------------
+    if (MODE == MODE_C2C) {
+        const cx<T> *in = static_cast<const cx<T> *>(a.in) + o * a.in_outer + c;
+        for (int i = lane; i < n; i += lpc) buf0[i * cols + col] = valid ? in[i * a.in_line] : zero;
+    } else if (MODE == MODE_R2C) {
+        if (PACK) {
+            const cx<T> *in = static_cast<const cx<T> *>(a.in) + o * a.in_outer + c;
+            const cx<T> *in2 = a.in2 ? static_cast<const cx<T> *>(a.in2) + o * a.in_outer + c : nullptr;
+            for (int i = lane; i < n; i += lpc) {
+                cx<T> v = zero;
+                if (valid) {
+                    v = in[i * a.in_line];
+                    if (in2) {
+                        const cx<T> u = in2[i * a.in_line];
+                        v = mk<T>(v.re - a.s2 * u.re, v.im - a.s2 * u.im);
+                    }
+                }
+                buf0[i * cols + col] = v;
+            }
+        } else {
+            const T *in = static_cast<const T *>(a.in) + o * a.in_outer + c;
+            const T *in2 = a.in2 ? static_cast<const T *>(a.in2) + o * a.in_outer + c : nullptr;
+            for (int i = lane; i < n; i += lpc) {
+                T v = T(0);
+                if (valid) {
+                    v = in[i * a.in_line];
+                    if (in2) v -= a.s2 * in2[i * a.in_line];
+                }
+                buf0[i * cols + col] = mk<T>(v, T(0));
+            }
+        }
+    } else {  // MODE_C2R: rebuild the full spectrum of the packed line
+        const int nyq = (n % 2 == 0) ? n / 2 : -1;
+        for (int f = lane; f < a.nfreq; f += lpc) {
+            cx<T> A = zero, B = zero;
+            if (valid) {
+                if (PACK) {
+                    const cx2<T> ab = *reinterpret_cast<const cx2<T> *>(
+                        static_cast<const cx<T> *>(a.in) + o * a.in_outer + f * a.in_line + 2 * c);
+                    A = ab.a;
+                    B = ab.b;
+                } else {
+                    A = (static_cast<const cx<T> *>(a.in) + o * a.in_outer + c)[f * a.in_line];
+                }
+            }
+            if (f == 0 || f == nyq) {
+                buf0[f * cols + col] = mk<T>(A.re, B.re);
+            } else {
+                buf0[f * cols + col] = mk<T>(A.re - B.im, A.im + B.re);
+                buf0[(n - f) * cols + col] = mk<T>(A.re + B.im, B.re - A.im);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- radix passes ----------------
+    cx<T> *src = buf0, *dst = buf1;
+    int Ns = 1;
+    for (int p = 0; p < a.nrad; ++p) {
+        const int R = a.radix[p];
+        if (a.inverse) {
+            if (R == 8) radix_pass<T, 8, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 4) radix_pass<T, 4, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 2) radix_pass<T, 2, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc);
+        } else {
+            if (R == 8) radix_pass<T, 8, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 4) radix_pass<T, 4, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 2) radix_pass<T, 2, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc);
+        }
+        __syncthreads();
+        cx<T> *t = src;
+        src = dst;
+        dst = t;
+        Ns *= R;
+    }
+
+    // ---------------- store ----------------
+    if (!valid) return;
+    if (MODE == MODE_C2C) {
+        cx<T> *out = static_cast<cx<T> *>(a.out) + o * a.out_outer + c;
+        for (int i = lane; i < n; i += lpc) out[i * a.out_line] = cscale(src[i * cols + col], a.scale);
+    } else if (MODE == MODE_R2C) {
+        for (int f = lane; f < a.nfreq; f += lpc) {
+            const cx<T> zf = src[f * cols + col];
+            if (PACK) {
+                const cx<T> zn = src[(f == 0 ? 0 : n - f) * cols + col];
+                cx2<T> ab;
+                ab.a = mk<T>(T(0.5) * (zf.re + zn.re), T(0.5) * (zf.im - zn.im));
+                ab.b = mk<T>(T(0.5) * (zf.im + zn.im), T(0.5) * (zn.re - zf.re));
+                *reinterpret_cast<cx2<T> *>(static_cast<cx<T> *>(a.out) + o * a.out_outer +
+                                            f * a.out_line + 2 * c) = ab;
+            } else {
+                (static_cast<cx<T> *>(a.out) + o * a.out_outer + c)[f * a.out_line] = zf;
+            }
+        }
+    } else {
+        if (PACK) {
+            cx<T> *out = static_cast<cx<T> *>(a.out) + o * a.out_outer + c;
+            for (int i = lane; i < n; i += lpc) out[i * a.out_line] = cscale(src[i * cols + col], a.scale);
+        } else {
+            T *out = static_cast<T *>(a.out) + o * a.out_outer + c;
+            for (int i = lane; i < n; i += lpc) out[i * a.out_line] = src[i * cols + col].re * a.scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+void FftPlan::init(int n_) {
+    SA_REQUIRE(n_ >= 1, "FFT length must be >= 1");
+    destroy();
+    n = n_;
+    nrad = 0;
+    int m = n;
+    const int small[] = {8, 4, 2, 3, 5, 7};
+    for (int r : small)
+        while (m > 1 && m % r == 0) {
+            SA_REQUIRE(nrad < kMaxRadixPasses, "FFT length has too many factors");
+            radix[nrad++] = r;
+            m /= r;
+        }
+    for (int p = 11; m > 1; p += 2)
+        while (m % p == 0) {
+            SA_REQUIRE(nrad < kMaxRadixPasses, "FFT length has too many factors");
+            radix[nrad++] = p;
+            m /= p;
+        }
+    std::vector<cx<float>> t32(n);
+    std::vector<cx<double>> t64(n);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int t = 0; t < n; ++t) {
+        const double ang = -two_pi * (double)t / (double)n;
+        t64[t] = mk<double>(std::cos(ang), std::sin(ang));
+        t32[t] = mk<float>((float)t64[t].re, (float)t64[t].im);
+    }
+    SA_HIP(hipMalloc((void **)&tw32, sizeof(cx<float>) * n));
+    SA_HIP(hipMalloc((void **)&tw64, sizeof(cx<double>) * n));
+    SA_HIP(hipMemcpy(tw32, t32.data(), sizeof(cx<float>) * n, hipMemcpyHostToDevice));
+    SA_HIP(hipMemcpy(tw64, t64.data(), sizeof(cx<double>) * n, hipMemcpyHostToDevice));
+}
+
+void FftPlan::destroy() {
+    if (tw32) (void)hipFree(tw32);
+    if (tw64) (void)hipFree(tw64);
+    tw32 = nullptr;
+    tw64 = nullptr;
+    n = 0;
+    nrad = 0;
+}
+
+template <> const cx<float> *FftPlan::tw<float>() const { return tw32; }
+template <> const cx<double> *FftPlan::tw<double>() const { return tw64; }
+
+namespace {
+
+constexpr size_t kLdsBudget = 160 * 1024;  // one workgroup may own the whole CU LDS
+
+struct Cfg {
+    int cols, threads;
+    size_t lds;
+};
+
+template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
+    const size_t esz = sizeof(cx<T>);
+    int cols = (int)(128 / esz);  // 128-byte rows: 16 columns f32, 8 columns f64
+    while (cols > 1 && (2 * (size_t)n * cols + n) * esz > kLdsBudget) cols >>= 1;
+    SA_REQUIRE((2 * (size_t)n * cols + n) * esz <= kLdsBudget,
+               "transform length too large for the single-pass LDS FFT");
+    while (cols > 1 && cols / 2 >= ncols) cols >>= 1;
+    int lpc = 1;
+    while (lpc * 8 < n && lpc * 2 * cols <= 1024) lpc <<= 1;
+    int threads = cols * lpc;
+    if (threads < kWave) threads = kWave;
+    Cfg c;
+    c.cols = cols;
+    c.threads = threads;
+    c.lds = (2 * (size_t)n * cols + n) * esz;
+    return c;
+}
+
+template <typename T, int MODE, bool PACK>
+void launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n_outer) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    if (a.ncols <= 0 || n_outer <= 0) return;
+    const Cfg cfg = pick_cfg<T>(plan.n, a.ncols);
+    a.n = plan.n;
+    a.nfreq = plan.n / 2 + 1;
+    a.cols = cfg.cols;
+    a.nrad = plan.nrad;
+    for (int i = 0; i < plan.nrad; ++i) a.radix[i] = plan.radix[i];
+    a.tw = plan.tw<T>();
+    SA_REQUIRE(n_outer <= 65535, "too many outer slices for one launch");
+    const dim3 grid((unsigned)ceil_div(a.ncols, cfg.cols), (unsigned)n_outer, 1);
+    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK>), grid, dim3(cfg.threads), cfg.lds, st, a);
+    SA_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+template <typename T>
+void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in, cx<T> *out,
+             int64_t n_outer, int64_t ncols, int64_t in_outer, int64_t in_line,
+             int64_t out_outer, int64_t out_line, T scale) {
+    LineArgs<T> a{};
+    a.in = in;
+    a.in2 = nullptr;
+    a.out = out;
+    a.s2 = T(0);
+    a.scale = scale;
+    a.inverse = inverse ? 1 : 0;
+    a.ncols = ncols;
+    a.in_outer = in_outer;
+    a.in_line = in_line;
+    a.out_outer = out_outer;
+    a.out_line = out_line;
+    launch_lines<T, MODE_C2C, false>(st, plan, a, n_outer);
+}
+
+template <typename T>
+void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
+             int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
+             int64_t out_line) {
+    LineArgs<T> a{};
+    a.in = in;
+    a.in2 = in2;
+    a.out = out;
+    a.s2 = s2;
+    a.scale = T(1);
+    a.inverse = 0;
+    a.out_outer = out_outer;
+    a.out_line = out_line;
+    const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0) &&
+                      (out_outer % 2 == 0) && (out_line % 2 == 0);
+    if (pack) {
+        a.ncols = P / 2;
+        a.in_outer = in_outer / 2;
+        a.in_line = in_line / 2;
+        launch_lines<T, MODE_R2C, true>(st, plan, a, n_outer);
+    } else {
+        a.ncols = P;
+        a.in_outer = in_outer;
+        a.in_line = in_line;
+        launch_lines<T, MODE_R2C, false>(st, plan, a, n_outer);
+    }
+}
+
+template <typename T>
+void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64_t n_outer,
+             int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer, int64_t out_line,
+             T scale) {
+    LineArgs<T> a{};
+    a.in = in;
+    a.in2 = nullptr;
+    a.out = out;
+    a.s2 = T(0);
+    a.scale = scale;
+    a.inverse = 1;
+    a.in_outer = in_outer;
+    a.in_line = in_line;
+    const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0) &&
+                      (out_outer % 2 == 0) && (out_line % 2 == 0);
+    if (pack) {
+        a.ncols = P / 2;
+        a.out_outer = out_outer / 2;
+        a.out_line = out_line / 2;
+        launch_lines<T, MODE_C2R, true>(st, plan, a, n_outer);
+    } else {
+        a.ncols = P;
+        a.out_outer = out_outer;
+        a.out_line = out_line;
+        launch_lines<T, MODE_C2R, false>(st, plan, a, n_outer);
+    }
+}
+
+template <typename T>
+void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
+           T s2, cx<T> *out, int H, int W, int64_t P) {
+    const int64_t Wf = W / 2 + 1;
+    fft_r2c<T>(st, planW, in, in2, s2, out, H, P, (int64_t)W * P, P, Wf * P, P);
+    // columns: (wf, p) is one contiguous run of Wf*P complex columns per row h
+    fft_c2c<T>(st, planH, false, out, out, 1, Wf * P, 0, Wf * P, 0, Wf * P, T(1));
+}
+
+template <typename T>
+void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx<T> *in,
+            cx<T> *tmp, T *out, int H, int W, int64_t P) {
+    const int64_t Wf = W / 2 + 1;
+    fft_c2c<T>(st, planH, true, in, tmp, 1, Wf * P, 0, Wf * P, 0, Wf * P, T(1));
+    fft_c2r<T>(st, planW, tmp, out, H, P, Wf * P, P, (int64_t)W * P, P,
+               T(1.0 / ((double)H * (double)W)));
+}
+
+#define SA_INSTANTIATE(T)                                                                        \
+    template void fft_c2c<T>(hipStream_t, const FftPlan &, bool, const cx<T> *, cx<T> *, int64_t, \
+                             int64_t, int64_t, int64_t, int64_t, int64_t, T);                    \
+    template void fft_r2c<T>(hipStream_t, const FftPlan &, const T *, const T *, T, cx<T> *,     \
+                             int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);              \
+    template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
+                             int64_t, int64_t, int64_t, int64_t, T);                             \
+    template void rfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const T *, const T *,  \
+                           T, cx<T> *, int, int, int64_t);                                       \
+    template void irfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const cx<T> *,        \
+                            cx<T> *, T *, int, int, int64_t);
+SA_INSTANTIATE(float)
+SA_INSTANTIATE(double)
+
+}  // namespace sporco_amd

@@ -1,0 +1,79 @@
+"""Device FFT primitives with the call signatures of ``sporco.fft``.
+
+Mirrors ``rfftn`` / ``irfftn`` / ``rfl2norm2`` of the reference
+(sporco/fft.py:257-314, :449-484) for the case the convolutional solvers use:
+transform axes (0, 1) of an array whose remaining axes form the batch.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def complex_dtype(dtype):
+    """Complex dtype matching a real one (sporco/fft.py:44-71)."""
+    return np.dtype(np.complex64 if np.dtype(dtype) in (np.float32, np.complex64)
+                    else np.complex128)
+
+
+def real_dtype(dtype):
+    """Real dtype matching a complex one (sporco/fft.py:74-101)."""
+    return np.dtype(np.float32 if np.dtype(dtype) in (np.float32, np.complex64)
+                    else np.float64)
+
+
+def _check_axes(axes):
+    if axes is not None and tuple(axes) != (0, 1):
+        raise NotImplementedError("sporco_amd.fft transforms axes (0, 1) only")
+
+
+def rfftn(a, s=None, axes=(0, 1)):
+    """Unnormalised real FFT over axes (0, 1); ``s`` zero-pads (or crops) first."""
+    _check_axes(axes)
+    a = np.asarray(a)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    if s is not None and tuple(s) != a.shape[:2]:
+        pad = np.zeros(tuple(s) + a.shape[2:], dtype=a.dtype)
+        sl = tuple(slice(0, min(x, y)) for x, y in zip(s, a.shape[:2]))
+        pad[sl] = a[sl]
+        a = pad
+    a = np.ascontiguousarray(a)
+    H, W = a.shape[0], a.shape[1]
+    P = int(np.prod(a.shape[2:])) if a.ndim > 2 else 1
+    out = np.empty((H, W // 2 + 1) + a.shape[2:], dtype=complex_dtype(a.dtype))
+    _lib.check(_lib.lib().sporco_amd_rfftn2(_lib.dtype_code(a.dtype), H, W, P,
+                                            _lib._ptr(a), _lib._ptr(out)))
+    return out
+
+
+def irfftn(a, s, axes=(0, 1)):
+    """Inverse of :func:`rfftn`; ``s`` = (H, W) is required (W may be odd)."""
+    _check_axes(axes)
+    a = np.ascontiguousarray(a)
+    if a.dtype not in (np.complex64, np.complex128):
+        a = a.astype(np.complex128)
+    H, W = int(s[0]), int(s[1])
+    if a.shape[0] != H or a.shape[1] != W // 2 + 1:
+        raise ValueError("spectrum shape %s does not match s=%s" % (a.shape, (H, W)))
+    P = int(np.prod(a.shape[2:])) if a.ndim > 2 else 1
+    out = np.empty((H, W) + a.shape[2:], dtype=real_dtype(a.dtype))
+    _lib.check(_lib.lib().sporco_amd_irfftn2(_lib.dtype_code(out.dtype), H, W, P,
+                                             _lib._ptr(a), _lib._ptr(out)))
+    return out
+
+
+def rfl2norm2(xf, xs, axis=(0, 1)):
+    """Squared l2 norm of the array whose :func:`rfftn` is ``xf``."""
+    _check_axes(axis)
+    xf = np.ascontiguousarray(xf)
+    if xf.dtype not in (np.complex64, np.complex128):
+        xf = xf.astype(np.complex128)
+    H, W = int(xs[0]), int(xs[1])
+    P = int(np.prod(xf.shape[2:])) if xf.ndim > 2 else 1
+    out = ctypes.c_double(0.0)
+    _lib.check(_lib.lib().sporco_amd_rfl2norm2(_lib.dtype_code(real_dtype(xf.dtype)), H, W,
+                                               P, _lib._ptr(xf), ctypes.byref(out)))
+    return out.value

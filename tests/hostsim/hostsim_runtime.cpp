@@ -1,0 +1,210 @@
+// tests/hostsim/hostsim_runtime.cpp -- TEST INFRASTRUCTURE ONLY (see hip/hip_runtime.h).
+//
+// Fiber-based execution of one workgroup at a time: every GPU thread is a
+// ucontext fiber; __syncthreads / wave shuffles yield to a round-robin
+// scheduler and are released by arrival counters, so barrier semantics (and
+// barrier bugs: divergent barriers deadlock and are reported) match the GPU.
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace sporco_amd {
+// the dynamic-LDS region that sporco_amd::dyn_lds() declares `extern`
+alignas(16) unsigned char sporco_amd_lds_raw[160 * 1024];
+}  // namespace sporco_amd
+
+struct hostsim_event {
+    std::chrono::steady_clock::time_point t;
+};
+
+namespace hostsim {
+
+namespace {
+
+constexpr size_t kStack = 128 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    bool done = false;
+};
+
+std::vector<Fiber> fibers;
+ucontext_t sched_ctx;
+int cur = -1;
+int nthreads = 0;
+const std::function<void()> *body_fn = nullptr;
+
+int bar_arrived = 0, bar_gen = 0;
+int wave_arrived[32], wave_gen[32];
+unsigned long progress = 0;
+alignas(16) unsigned char slots[2048][16];
+
+void yield() { swapcontext(&fibers[cur].ctx, &sched_ctx); }
+
+void trampoline() {
+    (*body_fn)();
+    fibers[cur].done = true;
+    ++progress;
+    swapcontext(&fibers[cur].ctx, &sched_ctx);
+}
+
+}  // namespace
+
+int block_threads() { return nthreads; }
+void *shuffle_slot(int tid) { return slots[tid]; }
+
+void syncthreads() {
+    const int g = bar_gen;
+    if (++bar_arrived == nthreads) {
+        bar_arrived = 0;
+        ++bar_gen;
+        ++progress;
+    } else {
+        while (bar_gen == g) yield();
+    }
+}
+
+void wave_sync() {
+    const int w = (int)threadIdx.x / 64;
+    const int wsize = (nthreads - w * 64) < 64 ? (nthreads - w * 64) : 64;
+    const int g = wave_gen[w];
+    if (++wave_arrived[w] == wsize) {
+        wave_arrived[w] = 0;
+        ++wave_gen[w];
+        ++progress;
+    } else {
+        while (wave_gen[w] == g) yield();
+    }
+}
+
+void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
+    if (shmem > sizeof(sporco_amd::sporco_amd_lds_raw)) {
+        std::fprintf(stderr, "hostsim: dynamic LDS request %zu exceeds 160 KiB\n", shmem);
+        std::abort();
+    }
+    nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads > 1024 || block.y != 1 || block.z != 1) {
+        std::fprintf(stderr, "hostsim: unsupported block shape\n");
+        std::abort();
+    }
+    if ((int)fibers.size() < nthreads) {
+        const size_t old = fibers.size();
+        fibers.resize(nthreads);
+        for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char *)std::malloc(kStack);
+    }
+    body_fn = &body;
+    blockDim = block;
+    gridDim = grid;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx = dim3(bx, by, bz);
+                bar_arrived = 0;
+                for (int w = 0; w < 32; ++w) wave_arrived[w] = 0;
+                for (int t = 0; t < nthreads; ++t) {
+                    Fiber &f = fibers[t];
+                    f.done = false;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = f.stack;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = nullptr;
+                    makecontext(&f.ctx, trampoline, 0);
+                }
+                int live = nthreads;
+                while (live > 0) {
+                    const unsigned long before = progress;
+                    live = 0;
+                    for (int t = 0; t < nthreads; ++t) {
+                        if (fibers[t].done) continue;
+                        cur = t;
+                        threadIdx = dim3((unsigned)t, 0, 0);
+                        swapcontext(&sched_ctx, &fibers[t].ctx);
+                        if (!fibers[t].done) ++live;
+                    }
+                    if (live > 0 && progress == before) {
+                        std::fprintf(stderr,
+                                     "hostsim: deadlock -- %d threads wait at a barrier that the "
+                                     "others never reach (divergent __syncthreads/shuffle)\n",
+                                     live);
+                        std::abort();
+                    }
+                }
+            }
+    cur = -1;
+}
+
+}  // namespace hostsim
+
+// ---------------------------------------------------------------------------
+// runtime API: "device" memory is host memory, streams are synchronous
+// ---------------------------------------------------------------------------
+hipError_t hipMalloc(void **p, size_t n) {
+    void *q = nullptr;
+    if (posix_memalign(&q, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
+    std::memset(q, 0xCD, n);  // poison: catches reads of never-written device memory
+    *p = q;
+    return hipSuccess;
+}
+hipError_t hipFree(void *p) {
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void *p) { return hipFree(p); }
+hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
+    std::memmove(d, s, n);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) {
+    return hipMemcpy(d, s, n, k);
+}
+hipError_t hipMemset(void *d, int v, size_t n) {
+    std::memset(d, v, n);
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
+hipError_t hipStreamCreate(hipStream_t *st) {
+    *st = (hipStream_t)(uintptr_t)0x1;
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) {
+    *n = 1;
+    return hipSuccess;
+}
+hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    std::memset(p, 0, sizeof(*p));
+    std::strcpy(p->name, "hostsim (CPU fiber simulator, tests only)");
+    p->multiProcessorCount = 1;
+    p->totalGlobalMem = (size_t)1 << 34;
+    return hipSuccess;
+}
+hipError_t hipGetLastError() { return hipSuccess; }
+const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hostsim error"; }
+hipError_t hipEventCreate(hipEvent_t *e) {
+    *e = new hostsim_event;
+    return hipSuccess;
+}
+hipError_t hipEventDestroy(hipEvent_t e) {
+    delete e;
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    e->t = std::chrono::steady_clock::now();
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
