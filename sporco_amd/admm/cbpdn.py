@@ -1,0 +1,558 @@
+"""ADMM convolutional sparse coding on the GPU: ConvBPDN and ConvBPDNJoint.
+
+Drop-in for the first three classes of the reference's ``sporco.admm.cbpdn``
+(GenericConvBPDN sporco/admm/cbpdn.py:30-380, ConvBPDN :386-630,
+ConvBPDNJoint :636-807): same constructor signatures, Options trees,
+IterationStats fields, attributes (``X, Y, U, Xf, Df, Sf, D, S, rho, lmbda,
+cri, itstat, timer``) and overridable step methods.
+
+All X-sized arrays live in HBM inside a :class:`sporco_amd._lib.Solver`
+handle.  An iteration is one call into the C ABI that runs the HIP kernels
+
+    rfftn(Y - U)  ->  Sherman-Morrison solve  ->  irfftn
+    ->  relax + soft-threshold (+ l2,1 shrink) + dual update + all reductions
+
+and hands back the sums of squares from which the host forms the residuals,
+tolerances, objective and the next rho exactly as the reference does.  The
+attribute accessors download on demand (``b.Y`` is a NumPy array, as in the
+reference).  If a step method is overridden or monkey-patched, ``solve``
+falls back to the reference's step-by-step sequence with one device call per
+step, so hooks keep working.
+"""
+
+import copy
+
+import numpy as np
+
+from . import admm
+from .. import _lib
+from .. import cnvrep as cr
+from ..fft import complex_dtype, real_dtype
+
+__all__ = ['GenericConvBPDN', 'ConvBPDN', 'ConvBPDNJoint']
+
+
+class _DeviceArray(object):
+    """Attribute backed by a device-resident state array of the solver handle."""
+
+    def __init__(self, var):
+        self.var = var
+
+    def __get__(self, obj, cls):
+        if obj is None:
+            return self
+        return obj._fetch(self.var)
+
+    def __set__(self, obj, value):
+        obj._store(self.var, value)
+
+
+class GenericConvBPDN(admm.ADMMEqual):
+    r"""Base class: data fidelity (1/2)||sum_m d_m * x_m - s||^2 plus a
+    regulariser supplied by the derived class through ``ystep``/``obfn_reg``."""
+
+    class Options(admm.ADMMEqual.Options):
+        """Options of sporco/admm/cbpdn.py:119-164 (``AuxVarObj`` couples
+        ``fEvalX``/``gEvalY``).  ``HighMemSolve`` is accepted and has no effect:
+        the Sherman-Morrison denominator is always formed in-kernel with the
+        current rho."""
+
+        defaults = copy.deepcopy(admm.ADMMEqual.Options.defaults)
+        defaults.update({'AuxVarObj': False, 'fEvalX': True, 'gEvalY': False,
+                         'ReturnX': False, 'HighMemSolve': False,
+                         'LinSolveCheck': False, 'RelaxParam': 1.8,
+                         'NonNegCoef': False, 'NoBndryCross': False})
+        defaults['AutoRho'].update({'Enabled': True, 'Period': 1,
+                                    'AutoScaling': True, 'Scaling': 1000.0,
+                                    'RsdlRatio': 1.2})
+
+        def __init__(self, opt=None):
+            admm.ADMMEqual.Options.__init__(self, {} if opt is None else opt)
+
+        def __setitem__(self, key, value):
+            admm.ADMMEqual.Options.__setitem__(self, key, value)
+            if key == 'AuxVarObj':
+                self['fEvalX'] = value is not True
+                self['gEvalY'] = value is True
+
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'Reg')
+    itstat_fields_extra = ('XSlvRelRes',)
+    hdrtxt_objfn = ('Fnc', 'DFid', 'Reg')
+    hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', 'Reg': 'Reg'}
+
+    # device-resident arrays, fetched as NumPy arrays on access
+    Y = _DeviceArray(_lib.VAR_Y)
+    U = _DeviceArray(_lib.VAR_U)
+    X = _DeviceArray(_lib.VAR_X)
+    Xf = _DeviceArray(_lib.VAR_XF)
+    Df = _DeviceArray(_lib.VAR_DF)
+    Sf = _DeviceArray(_lib.VAR_SF)
+    Yprev = _DeviceArray(_lib.VAR_YPREV)
+    AX = _DeviceArray(_lib.VAR_AX)
+
+    # step methods whose identity decides between the fused and the staged path
+    _hook_names = ('xstep', 'relax_AX', 'ystep', 'ustep', 'save_yprev',
+                   'compute_residuals', 'residual_norms', 'eval_objfn', 'obfn_dfd',
+                   'obfn_reg', 'iteration_stats', 'itstat_extra', 'rescale_u')
+    _fused_base = None   # set after each fused-capable class definition
+
+    def __init__(self, D, S, opt=None, dimK=None, dimN=2, device=0, stream=None,
+                 reducer=None):
+        """``D``, ``S``, ``opt``, ``dimK``, ``dimN`` as in the reference
+        (sporco/admm/cbpdn.py:175-204).  Backend-only keyword arguments:
+        ``device`` (HIP device index), ``stream`` (a hipStream_t to share, e.g.
+        ``torch.cuda.current_stream().cuda_stream``) and ``reducer`` (sums the
+        per-iteration scalars over image shards held by other ranks, see
+        :mod:`sporco_amd.dist`)."""
+        if opt is None:
+            opt = GenericConvBPDN.Options()
+        if dimN != 2:
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        if not (np.isrealobj(D) and np.isrealobj(S)):
+            raise NotImplementedError("sporco_amd handles real-valued D and S")
+        self.real_dtype = True
+        if not hasattr(self, 'cri'):
+            self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
+        if self.cri.Cd > 1:
+            raise NotImplementedError(
+                "multi-channel dictionaries (linalg.solvemdbi_ism X-step) are not "
+                "part of the sporco_amd hot path yet")
+        self.set_dtype(opt, S.dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
+        self._device, self._stream, self._reducer = device, stream, reducer
+        self._new_handle()
+        super(GenericConvBPDN, self).__init__(self.cri.shpX, S.dtype, opt)
+        if reducer is not None:
+            # residual tolerances refer to the global problem size
+            self.Nx = self.Nx * reducer.world_size
+            self.Nc = self.Nc * reducer.world_size
+        self.D = np.asarray(D.reshape(self.cri.shpD), dtype=self.dtype)
+        self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
+        self._dev.set_signal(self.S)
+        self.setdict()
+
+    # -- device plumbing --------------------------------------------------------
+    def _new_handle(self):
+        H, W = self.cri.Nv
+        self._dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                                device=self._device, stream=self._stream)
+        self._cache = {}
+        self._u_scale = 1.0      # pending `U /= rsf` (admm.py:573), applied lazily
+        self._sums = [0.0] * _lib.OUT_COUNT
+        self._wl1_scalar = 1.0
+        self._wl21_scalar = 1.0
+
+    def _touch(self, *variables):
+        """Forget cached host copies of device arrays that were just rewritten."""
+        for v in variables:
+            self._cache.pop(v, None)
+
+    def _fetch(self, var):
+        if var not in self._cache:
+            a = self._dev.download(var)
+            if var == _lib.VAR_U and self._u_scale != 1.0:
+                a *= a.dtype.type(self._u_scale)
+            self._cache[var] = a
+        return self._cache[var]
+
+    def _store(self, var, value):
+        if value is None:      # ADMM.__init__ convention `self.X = None`
+            return
+        self._dev.upload(var, np.asarray(value))
+        if var == _lib.VAR_U:
+            self._u_scale = 1.0
+        self._touch(var)
+
+    def init_state(self, yshape, ushape):
+        """Y0 / U0 handling of sporco/admm/admm.py:262-272; device arrays start
+        at zero.  (A Y0 without U0 gets U0 = (lmbda/rho) sign(Y0) once lmbda is
+        known -- the intent documented at cbpdn.py:601-610.)"""
+        if self.opt['Y0'] is not None:
+            self.Y = np.asarray(self.opt['Y0']).astype(self.dtype, copy=True)
+        if self.opt['U0'] is not None:
+            self.U = np.asarray(self.opt['U0']).astype(self.dtype, copy=True)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for key in ('_dev', '_cache'):
+            state.pop(key, None)
+        # raw device contents: U is saved WITHOUT the pending scale (kept in
+        # _u_scale) so that a restored solver continues bit-identically
+        state['_saved_arrays'] = {v: self._dev.download(v)
+                                  for v in (_lib.VAR_Y, _lib.VAR_U, _lib.VAR_X)}
+        state['_stream'] = None
+        return state
+
+    def __setstate__(self, state):
+        saved = state.pop('_saved_arrays')
+        u_scale = state.get('_u_scale', 1.0)
+        self.__dict__.update(state)
+        self._new_handle()
+        self._dev.set_signal(self.S)
+        self.setdict()
+        self._upload_weights()
+        for v, a in saved.items():
+            self._store(v, a)
+        self._u_scale = u_scale
+
+    # -- dictionary ---------------------------------------------------------------
+    def setdict(self, D=None):
+        """Set the dictionary (internal layout, support (dH, dW) <= (H, W)):
+        Df and the Sherman-Morrison denominators are rebuilt on device."""
+        if D is not None:
+            self.D = np.asarray(D, dtype=self.dtype)
+        self._dev.set_dict(self.D)
+        self._touch(_lib.VAR_DF)
+        self.c = None
+
+    def getcoef(self):
+        return self.getmin()
+
+    # -- parameters handed to the device --------------------------------------------
+    def _flags(self):
+        f = 0
+        if self.opt['NonNegCoef']:
+            f |= _lib.FLAG_NONNEG
+        if self.opt['NoBndryCross']:
+            f |= _lib.FLAG_NOBNDRY
+        if self._needs_residuals():
+            f |= _lib.FLAG_RESID
+        if not self.opt['FastSolve']:
+            f |= _lib.FLAG_OBJ
+            if self.opt['gEvalY']:
+                f |= _lib.FLAG_GEVAL_Y
+            if not self.opt['fEvalX']:
+                f |= _lib.FLAG_FEVAL_Y
+        if self.opt['LinSolveCheck']:
+            f |= _lib.FLAG_XRRS
+        return f
+
+    def _lmbda_eff(self):
+        return 0.0
+
+    def _mu_eff(self):
+        return 0.0
+
+    def _params(self, extra_flags=0):
+        p = _lib.AdmmParams()
+        p.rho = float(self.rho)
+        p.lmbda = float(self._lmbda_eff())
+        p.mu = float(self._mu_eff())
+        p.rlx = float(self.rlx)
+        p.u_scale = float(self._u_scale)
+        p.flags = self._flags() | extra_flags
+        p.dH, p.dW = int(self.D.shape[0]), int(self.D.shape[1])
+        return p
+
+    def _upload_weights(self):
+        pass
+
+    # -- iteration: fused when nothing is overridden -----------------------------------
+    def _fused_ok(self):
+        base = type(self)._fused_base
+        if base is None:
+            return False
+        for name in self._hook_names:
+            if name in self.__dict__:
+                return False
+            if getattr(type(self), name) is not getattr(base, name):
+                return False
+        return True
+
+    def iteration(self):
+        if not self._fused_ok():
+            return super(GenericConvBPDN, self).iteration()
+        p = self._params()
+        if self._reducer is None:
+            self._sums = self._dev.admm_iter(p)
+        else:
+            self._sums = self._reducer.admm_iter(self._dev, p)
+        self._u_scale = 1.0
+        self._touch(_lib.VAR_X, _lib.VAR_Y, _lib.VAR_U, _lib.VAR_XF)
+        self._set_xrrs()
+        if not self._needs_residuals():
+            return None
+        self.timer.stop('solve_wo_rsdl')
+        res = self.compute_residuals()
+        self.timer.start('solve_wo_rsdl')
+        return res
+
+    def finish_solve(self):
+        self._dev.sync()
+
+    def _set_xrrs(self):
+        if self.opt['LinSolveCheck']:
+            s = self._sums
+            nrm = max(np.sqrt(s[_lib.OUT_XRRS_AX2]), np.sqrt(s[_lib.OUT_XRRS_B2]))
+            self.xrrs = 0.0 if nrm == 0.0 else np.sqrt(s[_lib.OUT_XRRS_D2]) / nrm
+        else:
+            self.xrrs = None
+
+    # -- staged steps (one device call each; same roles as the reference methods) ---------
+    def save_yprev(self):
+        self._dev.copy(_lib.VAR_YPREV, _lib.VAR_Y)
+        self._touch(_lib.VAR_YPREV)
+
+    def xstep(self):
+        """Y - U -> rfftn -> Sherman-Morrison -> irfftn (cbpdn.py:267-293)."""
+        out = self._dev.admm_xstep(self._params())
+        for slot in (_lib.OUT_DFID, _lib.OUT_XRRS_D2, _lib.OUT_XRRS_AX2, _lib.OUT_XRRS_B2):
+            self._sums[slot] = out[slot]
+        self._touch(_lib.VAR_X, _lib.VAR_XF)
+        self._set_xrrs()
+
+    def relax_AX(self):
+        """AX = alpha X + (1 - alpha) Y; AXnr is X itself (admm.py:877-885)."""
+        self._dev.admm_relax(self.rlx)
+        self._touch(_lib.VAR_AX)
+
+    @property
+    def AXnr(self):
+        return self.X
+
+    def ystep(self):
+        """NonNegCoef / NoBndryCross enforcement only (cbpdn.py:297-311): the
+        regulariser-specific shrinkage is added by derived classes."""
+        self._ystep_device(0.0, 0.0, 0)
+
+    def _ystep_device(self, lmbda, mu, extra_flags):
+        p = self._params(extra_flags)
+        p.lmbda, p.mu = float(lmbda), float(mu)
+        self._dev.admm_ystep(p)
+        self._touch(_lib.VAR_Y)
+
+    def ustep(self):
+        """U += AX - Y (admm.py:434-437)."""
+        self._dev.admm_ustep(self._params())
+        self._u_scale = 1.0
+        self._touch(_lib.VAR_U)
+
+    def residual_norms(self):
+        if not self._fused_ok():
+            out = self._dev.admm_stats(self._params(self._stats_flags()))
+            if self._reducer is not None:
+                out = self._reducer.sum(out)
+            for slot in (_lib.OUT_R2, _lib.OUT_S2, _lib.OUT_AX2, _lib.OUT_Y2, _lib.OUT_U2,
+                         _lib.OUT_L1, _lib.OUT_L21):
+                self._sums[slot] = out[slot]
+            if not self.opt['fEvalX']:
+                self._sums[_lib.OUT_DFID] = out[_lib.OUT_DFID]
+        s = self._sums
+        rho = float(self.rho)
+        nr = np.sqrt(s[_lib.OUT_R2])
+        ns = rho * np.sqrt(s[_lib.OUT_S2])
+        rn = max(np.sqrt(s[_lib.OUT_AX2]), np.sqrt(s[_lib.OUT_Y2]))
+        sn = rho * np.sqrt(s[_lib.OUT_U2])
+        return nr, ns, rn, sn
+
+    def _stats_flags(self):
+        return 0
+
+    def rescale_u(self, rsf):
+        """Defer ``U /= rsf`` (admm.py:573): the factor rides along as
+        ``u_scale`` and is applied by the next kernels that read U."""
+        self._u_scale = self._u_scale / float(rsf)
+        self._touch(_lib.VAR_U)
+
+    # -- objective --------------------------------------------------------------------------
+    def eval_objfn(self):
+        dfd = self.obfn_dfd()
+        reg = self.obfn_reg()
+        return (dfd + reg[0], dfd) + reg[1:]
+
+    def obfn_dfd(self):
+        """(1/2)||sum_m Df Xf - Sf||^2 by half-spectrum Parseval (cbpdn.py:337-344);
+        the sum comes out of the Sherman-Morrison kernel as a by-product."""
+        return self._sums[_lib.OUT_DFID] / 2.0
+
+    def obfn_reg(self):
+        raise NotImplementedError()
+
+    def itstat_extra(self):
+        return (self.xrrs,)
+
+    def rhochange(self):
+        pass
+
+    def reconstruct(self, X=None):
+        """irfftn(sum_m Df * rfftn(X)), X defaulting to Y (cbpdn.py:373-380)."""
+        if X is None:
+            var = _lib.VAR_Y
+        else:
+            self._dev.upload(_lib.VAR_AX, np.asarray(X, dtype=self.dtype))
+            self._touch(_lib.VAR_AX)
+            var = _lib.VAR_AX
+        return self._dev.reconstruct(var)[..., 0]
+
+    # -- per-kernel timing ---------------------------------------------------------------------
+    def profile(self, enable=True):
+        self._dev.profile(enable)
+
+    def profile_read(self):
+        return self._dev.profile_read()
+
+
+class ConvBPDN(GenericConvBPDN):
+    r"""Convolutional BPDN: minimise (1/2)||sum_m d_m * x_m - s||_2^2 +
+    lambda sum_m ||x_m||_1 by ADMM (reference class: sporco/admm/cbpdn.py:386-630).
+
+    IterationStats fields: ``Iter, ObjFun, DFid, RegL1, PrimalRsdl, DualRsdl,
+    EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
+    """
+
+    class Options(GenericConvBPDN.Options):
+        """Adds ``L1Weight`` (cbpdn.py:494-495)."""
+
+        defaults = copy.deepcopy(GenericConvBPDN.Options.defaults)
+        defaults.update({'L1Weight': 1.0})
+
+        def __init__(self, opt=None):
+            GenericConvBPDN.Options.__init__(self, {} if opt is None else opt)
+
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'RegL1')
+    hdrtxt_objfn = ('Fnc', 'DFid', u'Regℓ1')
+    hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', u'Regℓ1': 'RegL1'}
+
+    def __init__(self, D, S, lmbda=None, opt=None, dimK=None, dimN=2, **backend):
+        if opt is None:
+            opt = ConvBPDN.Options()
+        self.set_dtype(opt, S.dtype)
+        super(ConvBPDN, self).__init__(D, S, opt, dimK, dimN, **backend)
+        rdt = real_dtype(self.dtype).type
+        if lmbda is None:
+            # 0.1 * max |D^H s|  (cbpdn.py:573-578), evaluated on device
+            lmbda = 0.1 * self._dev.dhs_absmax()
+            if self._reducer is not None:
+                lmbda = self._reducer.max(lmbda)
+        self.lmbda = rdt(lmbda)
+        self.set_attr('rho', opt['rho'], dval=(50.0 * self.lmbda + 1.0), dtype=rdt,
+                      reset=True)
+        if self.lmbda != 0.0:
+            rho_xi = float(1.0 + (18.3) ** (np.log10(self.lmbda) + 1.0))
+        else:
+            rho_xi = 1.0
+        self.set_attr('rho_xi', opt['AutoRho', 'RsdlTarget'], dval=rho_xi, dtype=rdt,
+                      reset=True)
+        self.wl1 = np.asarray(opt['L1Weight'], dtype=real_dtype(self.dtype))
+        self.wl1 = self.wl1.reshape(cr.l1Wshape(self.wl1, self.cri))
+        self._upload_weights()
+        if opt['Y0'] is not None and opt['U0'] is None:
+            self.U = (self.lmbda / self.rho) * np.sign(self.Y)
+
+    def _upload_weights(self):
+        if self.wl1.size == 1:
+            self._wl1_scalar = float(self.wl1.ravel()[0])
+            self._dev.set_l1_weight(None)
+        else:
+            self._wl1_scalar = 1.0
+            self._dev.set_l1_weight(_broadcastable(self.wl1, self.cri.shpX))
+
+    def _lmbda_eff(self):
+        # a scalar L1Weight folds into the threshold: (lmbda/rho) * w
+        return float(self.lmbda) * self._wl1_scalar
+
+    def uinit(self, ushape):
+        if self.opt['Y0'] is None:
+            return np.zeros(ushape, dtype=self.dtype)
+        return (self.lmbda / self.rho) * np.sign(self.Y)
+
+    def ystep(self):
+        """Y = prox_l1(AX + U, (lmbda/rho) wl1), then NonNeg / NoBndryCross
+        (cbpdn.py:614-620)."""
+        self._ystep_device(self._lmbda_eff(), 0.0, 0)
+
+    def obfn_reg(self):
+        rl1 = abs(self._wl1_scalar) * self._sums[_lib.OUT_L1]
+        return (self.lmbda * rl1, rl1)
+
+
+class ConvBPDNJoint(ConvBPDN):
+    r"""ConvBPDN with an additional l2,1 term over the channel axis,
+    mu ||{x_c,m}||_{2,1} (reference class: sporco/admm/cbpdn.py:636-807).
+
+    IterationStats fields: ``Iter, ObjFun, DFid, RegL1, RegL21, PrimalRsdl,
+    DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
+    """
+
+    class Options(ConvBPDN.Options):
+        """Adds ``L21Weight`` (cbpdn.py:719-720)."""
+
+        defaults = copy.deepcopy(ConvBPDN.Options.defaults)
+        defaults.update({'L21Weight': 1.0})
+
+        def __init__(self, opt=None):
+            ConvBPDN.Options.__init__(self, {} if opt is None else opt)
+
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'RegL1', 'RegL21')
+    hdrtxt_objfn = ('Fnc', 'DFid', u'Regℓ1', u'Regℓ2,1')
+    hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', u'Regℓ1': 'RegL1',
+                     u'Regℓ2,1': 'RegL21'}
+
+    def __init__(self, D, S, lmbda=None, mu=0.0, opt=None, dimK=None, dimN=2, **backend):
+        if opt is None:
+            opt = ConvBPDN.Options()
+        self.mu = None
+        self.wl21 = np.asarray(opt['L21Weight'] if 'L21Weight' in opt else 1.0)
+        super(ConvBPDNJoint, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN,
+                                            **backend)
+        self.mu = self.dtype.type(mu)
+        self.wl21 = np.asarray(self.wl21, dtype=self.dtype)
+        self._upload_weights()
+
+    def _upload_weights(self):
+        super(ConvBPDNJoint, self)._upload_weights()
+        w = np.asarray(self.wl21)
+        if w.size == 1:
+            self._wl21_scalar = float(w.ravel()[0])
+            self._dev.set_l21_weight(None)
+        else:
+            self._wl21_scalar = 1.0
+            H, W_, C, N, K = self.cri.shpX
+            if w.ndim == 5:
+                w5 = w
+            elif w.ndim <= 4:
+                # the reference needs wl21 to broadcast against (H, W, N, K):
+                # align trailing axes, then insert the (singleton) channel axis
+                w4 = w.reshape((1,) * (4 - w.ndim) + w.shape)
+                w5 = w4[:, :, np.newaxis, :, :]
+            else:
+                raise ValueError("L21Weight has too many dimensions")
+            self._dev.set_l21_weight(_broadcastable(w5, (H, W_, 1, N, K)))
+
+    def _mu_eff(self):
+        return 0.0 if self.mu is None else float(self.mu) * self._wl21_scalar
+
+    def _flags(self):
+        return super(ConvBPDNJoint, self)._flags() | _lib.FLAG_JOINT
+
+    def _stats_flags(self):
+        return _lib.FLAG_JOINT
+
+    def ystep(self):
+        """Y = prox_sl1l2(AX + U, (lmbda/rho) wl1, (mu/rho) wl21, axis=C)
+        (cbpdn.py:785-794)."""
+        self._ystep_device(self._lmbda_eff(), self._mu_eff(), _lib.FLAG_JOINT)
+
+    def obfn_reg(self):
+        rl1 = abs(self._wl1_scalar) * self._sums[_lib.OUT_L1]
+        rl21 = self._wl21_scalar * self._sums[_lib.OUT_L21]
+        return (self.lmbda * rl1 + self.mu * rl21, rl1, rl21)
+
+
+def _broadcastable(w, full_shape):
+    """Return ``w`` as a 5-D array whose axes are each 1 or the full extent."""
+    w = np.asarray(w)
+    if w.ndim != 5:
+        raise ValueError("weight array must be 5-dimensional after reshaping")
+    tgt = tuple(full_shape)
+    for ws, ts in zip(w.shape, tgt):
+        if ws not in (1, ts):
+            raise ValueError("weight array of shape %s cannot broadcast to %s" %
+                             (w.shape, tgt))
+    return np.ascontiguousarray(w)
+
+
+GenericConvBPDN._fused_base = None
+ConvBPDN._fused_base = ConvBPDN
+ConvBPDNJoint._fused_base = ConvBPDNJoint

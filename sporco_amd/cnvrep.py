@@ -1,0 +1,195 @@
+"""Shape inference and dictionary constraint helpers (host side).
+
+Same inference rules as ``sporco.cnvrep`` (sporco/cnvrep.py:24-198 for sparse
+coding, :277-454 for dictionary update, :492-550 for weight shapes,
+:609-1074 for the constraint projection), restated compactly.  Internal
+layout: ``S(N0, N1, C, K, 1)``, ``D(N0, N1, Cd, 1, M)``, ``X(N0, N1, Cx, K, M)``.
+"""
+
+import pprint
+
+import numpy as np
+
+
+class CSC_ConvRepIndexing(object):
+    """Problem dimensions of a convolutional sparse coding problem."""
+
+    def __init__(self, D, S, dimK=None, dimN=2):
+        self.dimCd = D.ndim - (dimN + 1)
+        self.Cd = 1 if self.dimCd == 0 else D.shape[-2]
+        extra = S.ndim - dimN
+        if dimK is None:
+            if extra == 0:
+                dimC, dimK = 0, 0
+            elif extra == 1:
+                # a single extra axis follows the dictionary: channels if D has them
+                dimC = self.dimCd
+                dimK = 1 - dimC
+            else:
+                dimC, dimK = 1, 1
+        else:
+            dimC = extra - dimK
+        self.dimN, self.dimC, self.dimK = dimN, dimC, dimK
+        self.C = S.shape[dimN] if dimC == 1 else 1
+        if self.Cd > 1 and self.C != self.Cd:
+            raise ValueError("Multi-channel dictionary with signal with mismatched "
+                             "number of channels (Cd=%d, C=%d)" % (self.Cd, self.C))
+        self.K = S.shape[dimN + dimC] if dimK == 1 else 1
+        self.M = D.shape[-1]
+        self.Nv = S.shape[0:dimN]
+        self.N = int(np.prod(np.array(self.Nv)))
+        self.axisN = tuple(range(dimN))
+        self.axisC, self.axisK, self.axisM = dimN, dimN + 1, dimN + 2
+        Cx = self.C - self.Cd + 1
+        self.shpD = D.shape[0:dimN] + (self.Cd, 1, self.M)
+        self.shpS = self.Nv + (self.C, self.K, 1)
+        self.shpX = self.Nv + (Cx, self.K, self.M)
+
+    def __str__(self):
+        return pprint.pformat(vars(self))
+
+
+class DictionarySize(object):
+    """Parameters of a (single-scale) dictionary size tuple ``dsz``."""
+
+    def __init__(self, dsz, dimN=2):
+        if isinstance(dsz[0], tuple):
+            raise NotImplementedError("multi-scale dictionary specifications are "
+                                      "outside the sporco_amd hot path")
+        self.dsz = dsz
+        self.ndim = len(dsz)
+        self.mxsz = tuple(dsz[0:dimN])
+        self.nflt = dsz[-1]
+        self.nchn = 1 if self.ndim == dimN + 1 else dsz[-2]
+
+    def __str__(self):
+        return pprint.pformat(vars(self))
+
+
+class CDU_ConvRepIndexing(object):
+    """Problem dimensions of a convolutional dictionary update problem
+    (sporco/cnvrep.py:277-454)."""
+
+    def __init__(self, dsz, S, dimK=None, dimN=2):
+        ds = DictionarySize(dsz, dimN)
+        self.dimCd = ds.ndim - dimN - 1
+        self.Cd = ds.nchn
+        self.M = ds.nflt
+        self.dsz = dsz
+        if dimK is None:
+            rdim = S.ndim - dimN
+            if rdim == 0:
+                dimC, dimK = 0, 0
+            elif rdim == 1:
+                dimC = self.dimCd
+                dimK = S.ndim - dimN - dimC
+            else:
+                dimC, dimK = 1, 1
+        else:
+            dimC = S.ndim - dimN - dimK
+        self.dimN, self.dimC, self.dimK = dimN, dimC, dimK
+        self.C = S.shape[dimN] if dimC == 1 else 1
+        self.Cx = self.C - self.Cd + 1
+        if self.Cd > 1 and self.C != self.Cd:
+            raise ValueError("Multi-channel dictionary with signal with mismatched "
+                             "number of channels (Cd=%d, C=%d)" % (self.Cd, self.C))
+        self.K = S.shape[dimN + dimC] if dimK == 1 else 1
+        self.Nv = S.shape[0:dimN]
+        self.N = int(np.prod(np.array(self.Nv)))
+        self.axisN = tuple(range(dimN))
+        self.axisC, self.axisK, self.axisM = dimN, dimN + 1, dimN + 2
+        self.shpD = self.Nv + (self.Cd, 1, self.M)
+        self.shpS = self.Nv + (self.C, self.K, 1)
+        self.shpX = self.Nv + (self.Cx, self.K, self.M)
+
+    def __str__(self):
+        return pprint.pformat(vars(self))
+
+
+def stdformD(D, Cd, M, dimN=2):
+    """Reshape a dictionary to the internal (.., Cd, 1, M) layout."""
+    return D.reshape(D.shape[0:dimN] + (Cd, 1, M))
+
+
+def l1Wshape(W, cri):
+    """Internal shape of an ``L1Weight`` array (sporco/cnvrep.py:492-550)."""
+    sdim = cri.dimN + cri.dimC + cri.dimK
+    if W.ndim < sdim:
+        if W.size != 1:
+            raise ValueError('weight array must be scalar or have at least '
+                             'the same number of dimensions as input array')
+        return (1,) * (cri.dimN + 3)
+    if W.ndim == sdim:
+        return W.shape + (1,) * (3 - cri.dimC - cri.dimK)
+    if W.ndim == cri.dimN + 3:
+        return W.shape
+    # otherwise the last axis is taken to be the filter index
+    return W.shape[0:-1] + (1,) * (2 - cri.dimC - cri.dimK) + W.shape[-1:]
+
+
+def mskWshape(W, cri):
+    """Internal shape of a spatial mask array (sporco/cnvrep.py:554-605)."""
+    ckdim = W.ndim - cri.dimN
+    if ckdim >= 2:
+        shp = W.shape + (1,) if ckdim == 2 else W.shape
+    elif ckdim == 1:
+        if cri.C == 1 and cri.K > 1:
+            shp = W.shape[0:cri.dimN] + (1, W.shape[cri.dimN], 1)
+        elif cri.C > 1 and cri.K == 1:
+            shp = W.shape[0:cri.dimN] + (W.shape[cri.dimN], 1, 1)
+        else:
+            shp = W.shape[0:cri.dimN] + (W.shape[cri.dimN], 1, 1)
+    else:
+        shp = W.shape + (1,) * 3
+    return shp
+
+
+# -- dictionary constraint set -------------------------------------------------
+
+def zpad(v, Nv):
+    """Zero-pad the leading axes of ``v`` to ``Nv``."""
+    out = np.zeros(tuple(Nv) + v.shape[len(Nv):], dtype=v.dtype)
+    out[tuple(slice(0, n) for n in v.shape)] = v
+    return out
+
+
+def bcrop(v, dsz, dimN=2):
+    """Crop to the filter support (single-scale ``dsz``)."""
+    if isinstance(dsz[0], tuple):
+        raise NotImplementedError("multi-scale dictionaries are outside the hot path")
+    return v[tuple(slice(0, n) for n in dsz[0:dimN])]
+
+
+def zeromean(v, dsz, dimN=2):
+    """Subtract, per filter, the mean over the filter support."""
+    if isinstance(dsz[0], tuple):
+        raise NotImplementedError("multi-scale dictionaries are outside the hot path")
+    out = v.copy()
+    sup = tuple(slice(0, n) for n in dsz[0:dimN])
+    out[sup] -= np.mean(v[sup], tuple(range(dimN)))
+    return out
+
+
+def normalise(v, dimN=2):
+    """Unit l2 norm over the first ``dimN`` axes (zero vectors untouched)."""
+    nrm = np.sqrt(np.sum(np.abs(v) ** 2, tuple(range(dimN)), keepdims=True))
+    nrm[nrm == 0] = 1.0
+    return np.asarray(v / nrm, dtype=v.dtype)
+
+
+def Pcn(x, dsz, Nv, dimN=2, dimC=1, crp=False, zm=False):
+    """Projection onto the constraint set: crop, (zero-pad), (zero-mean), normalise
+    (sporco/cnvrep.py:868-913)."""
+    v = bcrop(x, dsz, dimN)
+    if not crp:
+        v = zpad(v, Nv)
+    if zm:
+        v = zeromean(v, dsz, dimN)
+    return normalise(v, dimN + dimC)
+
+
+def getPcn(dsz, Nv, dimN=2, dimC=1, crp=False, zm=False):
+    """Return ``x -> Pcn(x, ...)`` with the options bound."""
+    def proj(x):
+        return Pcn(x, dsz, Nv, dimN, dimC, crp, zm)
+    return proj

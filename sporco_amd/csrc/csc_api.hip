@@ -92,7 +92,7 @@ struct ProfScope {
             hipEvent_t b = p.get();
             (void)hipEventRecord(b, p.st);
             p.pending.push_back({slot, a, b});
-            if (p.pending.size() > 4096) p.drain();
+            if (p.pending.size() >= 200) p.drain();
         }
     }
 };
@@ -918,6 +918,16 @@ int sporco_amd_csc_profile(sporco_amd_csc_t h, int enable) {
     SA_HANDLE(h);
     h->impl->sync();
     h->impl->prof.drain();
+    if (enable) {
+        // create the event pool up front: hipEventCreate is slow enough to
+        // distort a timed region if it happens lazily inside it
+        Profiler &pr = h->impl->prof;
+        while (pr.pool.size() < 512) {
+            hipEvent_t e;
+            SA_HIP(hipEventCreate(&e));
+            pr.pool.push_back(e);
+        }
+    }
     h->impl->prof.on = enable != 0;
     SA_API_END
 }

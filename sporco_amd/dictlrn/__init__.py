@@ -1,0 +1,1 @@
+"""Solver classes mirroring the reference sub-package of the same name."""

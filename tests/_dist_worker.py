@@ -1,0 +1,38 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a 2-process image-sharded solve.
+
+Runs on CPU: gloo process group + the fiber-simulator build of the kernels."""
+
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+
+def main():
+    out_path = sys.argv[1]
+    import torch.distributed as dist
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import sporco_amd
+    from conftest import HOSTSIM_LIB, load_golden
+    sporco_amd.load_library(HOSTSIM_LIB)
+    from sporco_amd.admm import cbpdn
+    from sporco_amd.dist import TorchReducer, shard_images
+    g = load_golden('admm_multichan_f64')          # S: (16, 12, 3, 2): two images
+    S = shard_images(g['S'], rank, world, axis=-1)
+    opt = cbpdn.ConvBPDN.Options({'MaxMainIter': 25})
+    b = cbpdn.ConvBPDN(g['D'], S, float(g['lmbda']), opt, reducer=TorchReducer())
+    Y = b.solve()
+    its = b.getitstat()
+    np.savez(out_path + '.%d.npz' % rank, Y=Y, ObjFun=np.array(its.ObjFun),
+             Rho=np.array(its.Rho), PrimalRsdl=np.array(its.PrimalRsdl),
+             DualRsdl=np.array(its.DualRsdl), k=b.k)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

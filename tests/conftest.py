@@ -35,3 +35,42 @@ def rel_l2(a, b):
     if nb == 0.0:
         return float(np.linalg.norm(a.ravel()))
     return float(np.linalg.norm((a - b).ravel()) / nb)
+
+
+# ---------------------------------------------------------------------------
+# backends: the same parity tests run against
+#   'hostsim' -- the kernel sources compiled for the CPU fiber simulator
+#                (tests/hostsim; CPU-only runs, small sizes), and
+#   'gpu'     -- the real hipcc/gfx950 library on an MI355X (-m gpu).
+# ---------------------------------------------------------------------------
+HOSTSIM_DIR = os.path.join(REPO, 'tests', 'hostsim')
+HOSTSIM_LIB = os.path.join(HOSTSIM_DIR, 'libsporco_amd_hostsim.so')
+
+
+def build_hostsim():
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', HOSTSIM_DIR, '-j8'])
+    return HOSTSIM_LIB
+
+
+def use_backend(name):
+    import sporco_amd
+    from sporco_amd import _lib
+    if name == 'hostsim':
+        sporco_amd.load_library(build_hostsim())
+    else:
+        sporco_amd.load_library()      # in-tree libsporco_amd.so, hipcc build
+        assert _lib.library_path().endswith('libsporco_amd.so')
+        assert sporco_amd.device_count() > 0, "no AMD GPU visible"
+        assert 'hostsim' not in sporco_amd.device_info(0)[0]
+    return name
+
+
+@pytest.fixture(params=['hostsim', pytest.param('gpu', marks=pytest.mark.gpu)])
+def backend(request):
+    return use_backend(request.param)
+
+
+@pytest.fixture
+def gpu_backend():
+    return use_backend('gpu')

@@ -1,0 +1,32 @@
+"""N > 1 path on CPU: two gloo ranks, images sharded over ranks, the only
+communication being the all-reduce of the per-iteration scalars.  The sharded
+run must reproduce the single-process reference trace (same rho schedule,
+same iterates) -- SURVEY.md section 8(e)."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import REPO, build_hostsim, load_golden, rel_l2
+
+
+def test_two_rank_image_sharding(tmp_path):
+    build_hostsim()
+    out = str(tmp_path / 'shard')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', '29613',
+           os.path.join(REPO, 'tests', '_dist_worker.py'), out]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=REPO)
+    g = load_golden('admm_multichan_f64')
+    parts = [np.load(out + '.%d.npz' % r) for r in range(2)]
+    Y = np.concatenate([p['Y'] for p in parts], axis=3)      # axisK = image axis
+    assert int(parts[0]['k']) == int(g['k_final'])
+    assert rel_l2(Y, g['Y']) < 1e-9
+    for p in parts:                                             # identical on every rank
+        assert rel_l2(p['ObjFun'], g['it_ObjFun']) < 1e-9
+        assert rel_l2(p['Rho'], g['it_Rho']) < 1e-9
+        assert rel_l2(p['PrimalRsdl'], g['it_PrimalRsdl']) < 1e-9
+        assert rel_l2(p['DualRsdl'], g['it_DualRsdl']) < 1e-9
