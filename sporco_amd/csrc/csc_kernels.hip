@@ -825,25 +825,23 @@ void launch_axpy_c(hipStream_t st, const cx<T> *y, const cx<T> *g, cx<T> *out, T
 }
 
 template <typename T>
-__global__ void __launch_bounds__(kThreads) momentum_kernel(const cx<T> *__restrict__ xf,
-                                                            const cx<T> *__restrict__ xfprv,
-                                                            const cx<T> *__restrict__ zz,
-                                                            cx<T> *__restrict__ yf, T beta, T gamma,
-                                                            int64_t n) {
+__global__ void __launch_bounds__(kThreads) lincomb_kernel(cx<T> *__restrict__ dst, T a,
+                                                           const cx<T> *va, T b, const cx<T> *vb,
+                                                           T c, const cx<T> *vc, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const cx<T> x = xf[i];
-        cx<T> y = x + cscale(x - xfprv[i], beta);
-        if (zz) y = y + cscale(zz[i] - x, gamma);
-        yf[i] = y;
+        cx<T> r = cscale(va[i], a);
+        if (vb) r = r + cscale(vb[i], b);
+        if (vc) r = r + cscale(vc[i], c);
+        dst[i] = r;
     }
 }
 
 template <typename T>
-void launch_momentum(hipStream_t st, const cx<T> *xf, const cx<T> *xfprv, const cx<T> *zz,
-                     cx<T> *yf, T beta, T gamma, int64_t n) {
-    hipLaunchKernelGGL((momentum_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, xf, xfprv,
-                       zz, yf, beta, gamma, n);
+void launch_lincomb(hipStream_t st, cx<T> *dst, T a, const cx<T> *va, T b, const cx<T> *vb, T c,
+                    const cx<T> *vc, int64_t n) {
+    hipLaunchKernelGGL((lincomb_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, dst, a, va, b,
+                       vb, c, vc, n);
     SA_HIP(hipGetLastError());
 }
 
@@ -1000,8 +998,8 @@ void launch_finalize(hipStream_t st, const double *partials, int nblocks, int st
                                     cx<T> *, int64_t, int, int, int, double *);                    \
     template void launch_axpy_c<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, T,          \
                                    int64_t);                                                       \
-    template void launch_momentum<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,     \
-                                     cx<T> *, T, T, int64_t);                                      \
+    template void launch_lincomb<T>(hipStream_t, cx<T> *, T, const cx<T> *, T, const cx<T> *, T,   \
+                                    const cx<T> *, int64_t);                                       \
     template int launch_pair_stats<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
                                       int64_t, int64_t, int, double *);                            \
     template int launch_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,     \

@@ -1,0 +1,214 @@
+"""FISTA convolutional sparse coding on the GPU (PGM ConvBPDN).
+
+Drop-in for ``sporco.pgm.cbpdn.ConvBPDN`` (sporco/pgm/cbpdn.py:29-383): same
+constructor, Options, IterationStats fields (``Iter, ObjFun, DFid, RegL1,
+Rsdl, F_Btrack, Q_Btrack, IterBTrack, L, Time``) and attributes.  Per
+iteration the device runs
+
+    gradient   GF = conj(Df) (sum_m Df Yf - Sf)            (one fused kernel)
+    prox step  Vf = Yf - GF/L -> irfftn -> soft threshold -> rfftn
+    momentum   Yf = Xf + beta (Xf - Xfprv)                  (one kernel)
+
+with backtracking / step-size policies composed from device reductions.
+"""
+
+import copy
+
+import numpy as np
+
+from . import pgm
+from .. import _lib
+from .. import cnvrep as cr
+from ..admm.cbpdn import _DeviceArray, _broadcastable
+
+__all__ = ['ConvBPDN']
+
+
+class ConvBPDN(pgm.PGMDFT):
+    r"""Minimise (1/2)||sum_m d_m * x_m - s||_2^2 + lambda sum_m ||x_m||_1 by
+    accelerated proximal gradient."""
+
+    class Options(pgm.PGMDFT.Options):
+        """Adds ``NonNegCoef``, ``NoBndryCross``, ``L1Weight``; default ``L`` 500
+        (sporco/pgm/cbpdn.py:112-118)."""
+
+        defaults = copy.deepcopy(pgm.PGMDFT.Options.defaults)
+        defaults.update({'NonNegCoef': False, 'NoBndryCross': False})
+        defaults.update({'L1Weight': 1.0})
+        defaults.update({'L': 500.0})
+
+        def __init__(self, opt=None):
+            pgm.PGMDFT.Options.__init__(self, {} if opt is None else opt)
+
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'RegL1')
+    hdrtxt_objfn = ('Fnc', 'DFid', u'Regℓ1')
+    hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', u'Regℓ1': 'RegL1'}
+
+    X = _DeviceArray(_lib.VAR_X)
+    Xf = _DeviceArray(_lib.VAR_XF)
+    Yf = _DeviceArray(_lib.VAR_YF)
+    Xfprv = _DeviceArray(_lib.VAR_XFPRV)
+    Yfprv = _DeviceArray(_lib.VAR_YFPRV)
+    Vf = _DeviceArray(_lib.VAR_VF)
+    Df = _DeviceArray(_lib.VAR_DF)
+    Sf = _DeviceArray(_lib.VAR_SF)
+
+    def __init__(self, D, S, lmbda=None, opt=None, dimK=None, dimN=2, device=0, stream=None):
+        if opt is None:
+            opt = ConvBPDN.Options()
+        if dimN != 2:
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        if not (np.isrealobj(D) and np.isrealobj(S)):
+            raise NotImplementedError("sporco_amd handles real-valued D and S")
+        if not hasattr(self, 'cri'):
+            self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
+        if self.cri.Cd > 1:
+            raise NotImplementedError("multi-channel dictionaries are not part of the "
+                                      "sporco_amd hot path yet")
+        self.set_dtype(opt, S.dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
+        self._device, self._stream = device, stream
+        self._new_handle()
+        self.D = np.asarray(D.reshape(self.cri.shpD), dtype=self.dtype)
+        self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
+        self.dev.set_signal(self.S)
+        self.setdict()
+        if lmbda is None:
+            lmbda = 0.1 * self.dev.dhs_absmax()            # pgm/cbpdn.py:209-214
+        self.lmbda = self.dtype.type(lmbda)
+        self.wl1 = np.asarray(opt['L1Weight'], dtype=self.dtype)
+        self._upload_weights()
+        super(ConvBPDN, self).__init__(self.cri.shpX, self.cri.Nv, self.cri.axisN, S.dtype, opt)
+
+    # -- device plumbing ----------------------------------------------------------
+    def _new_handle(self):
+        H, W = self.cri.Nv
+        self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                               device=self._device, stream=self._stream)
+        self._cache = {}
+        self._fcache = {}
+        self._rl1 = 0.0
+        self._wl1_scalar = 1.0
+
+    def _fetch(self, var):
+        if var not in self._cache:
+            self._cache[var] = self.dev.download(var)
+        return self._cache[var]
+
+    def _store(self, var, value):
+        if value is None:
+            return
+        self.dev.upload(var, np.asarray(value))
+        self.invalidate(var)
+
+    def _upload_weights(self):
+        w = self.wl1
+        if w.size == 1:
+            self._wl1_scalar = float(w.ravel()[0])
+            self.dev.set_l1_weight(None)
+        else:
+            self._wl1_scalar = 1.0
+            w5 = w.reshape(cr.l1Wshape(w, self.cri)) if w.ndim != 5 else w
+            self.dev.set_l1_weight(_broadcastable(w5, self.cri.shpX))
+
+    def init_state(self, xshape):
+        """X = X0 or 0; Xf = rfftn(X); Yf = Xf (pgm/cbpdn.py:222-233)."""
+        if self.opt['X0'] is not None:
+            self.X = np.asarray(self.opt['X0']).astype(self.dtype, copy=True)
+            self.dev.fft_var(_lib.VAR_X, _lib.VAR_XF)
+            self.dev.copy(_lib.VAR_YF, _lib.VAR_XF)
+        self.Y = None
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for key in ('dev', '_cache', '_fcache'):
+            state.pop(key, None)
+        state['_saved_arrays'] = {v: self.dev.download(v) for v in
+                                  (_lib.VAR_X, _lib.VAR_XF, _lib.VAR_YF, _lib.VAR_XFPRV,
+                                   _lib.VAR_YFPRV)}
+        state['_stream'] = None
+        return state
+
+    def __setstate__(self, state):
+        saved = state.pop('_saved_arrays')
+        rl1 = state.get('_rl1', 0.0)
+        self.__dict__.update(state)
+        self._new_handle()
+        self.dev.set_signal(self.S)
+        self.setdict()
+        self._upload_weights()
+        for v, a in saved.items():
+            self._store(v, a)
+        self._rl1 = rl1
+
+    # -- dictionary / coefficients ------------------------------------------------------
+    def setdict(self, D=None):
+        if D is not None:
+            self.D = np.asarray(D, dtype=self.dtype)
+        self.dev.set_dict(self.D)
+        self._cache.pop(_lib.VAR_DF, None)
+        self._fcache.clear()
+
+    def getcoef(self):
+        return self.X
+
+    def _flags(self):
+        f = 0
+        if self.opt['NonNegCoef']:
+            f |= _lib.FLAG_NONNEG
+        if self.opt['NoBndryCross']:
+            f |= _lib.FLAG_NOBNDRY
+        return f
+
+    # -- smooth term ---------------------------------------------------------------------
+    def grad_f(self, V=None):
+        """GF = conj(Df)(sum_m Df V - Sf) at V (default Yf); returns the handle of
+        the gradient array (pgm/cbpdn.py:263-279).  f(V) comes back for free."""
+        if V is None:
+            V = _lib.VAR_YF
+        out = self.dev.pgm_grad(V)
+        self._fcache[V] = out[_lib.PGM_F]
+        self.invalidate(_lib.VAR_GF)
+        return _lib.VAR_GF
+
+    def obfn_f(self, Xf=None):
+        """(1/2)||sum_m Df Xf - Sf||^2 in the unnormalised DFT domain
+        (pgm/cbpdn.py:358-372)."""
+        if Xf is None:
+            Xf = _lib.VAR_XF
+        if Xf not in self._fcache:
+            self._fcache[Xf] = self.dev.pgm_eval(Xf)[_lib.PGM_F]
+        return self._fcache[Xf]
+
+    def prox_step(self, gradf):
+        if gradf != _lib.VAR_GF:
+            self.dev.copy(_lib.VAR_GF, gradf)
+        out = self.dev.pgm_prox_step(self.L, float(self.lmbda) * self._wl1_scalar, self._flags(),
+                                     self.D.shape[0], self.D.shape[1])
+        self._rl1 = abs(self._wl1_scalar) * out[_lib.PGM_L1]
+        self.invalidate(_lib.VAR_X, _lib.VAR_XF, _lib.VAR_VF)
+
+    def rsdl(self):
+        """rfl2norm2(Xf - Yfprv) (pgm/cbpdn.py:314-320)."""
+        return self.dev.pair_stats(_lib.VAR_XF, _lib.VAR_YFPRV)[0]
+
+    # -- objective ---------------------------------------------------------------------------
+    def eval_objfn(self):
+        dfd = self.obfn_dfd()
+        reg = self.obfn_reg()
+        return (dfd + reg[0], dfd) + reg[1:]
+
+    def obfn_dfd(self):
+        return self.dev.pgm_eval(_lib.VAR_XF)[_lib.PGM_DFID] / 2.0
+
+    def obfn_reg(self):
+        return (self.lmbda * self._rl1, self._rl1)
+
+    def reconstruct(self, X=None):
+        if X is None:
+            var = _lib.VAR_X
+        else:
+            self.dev.upload(_lib.VAR_AX, np.asarray(X, dtype=self.dtype))
+            var = _lib.VAR_AX
+        return self.dev.reconstruct(var)[..., 0]
