@@ -81,7 +81,20 @@ typedef struct {
 #define SPORCO_AMD_VAR_T0 13   /* cplx  scratch state for host-composed policies        */
 #define SPORCO_AMD_VAR_T1 14   /* cplx  (BB step size: previous x / gradient;           */
 #define SPORCO_AMD_VAR_T2 15   /* cplx   robust backtracking: Z; monotone FISTA: ZZ)    */
-#define SPORCO_AMD_VAR_COUNT 16
+#define SPORCO_AMD_VAR_ZF 16   /* cplx  (H,Wf,C,N,K) rfftn of the coefficient maps (D-step)   */
+/* Dictionary-sized state of the D-step (pgm.ccmod.ConvCnstrMOD): real (H,W,K) /
+ * complex (H,Wf,K).  Ids 17..31 are reserved. */
+#define SPORCO_AMD_VAR_DX 32      /* real  dictionary iterate X (zero-padded filters)    */
+#define SPORCO_AMD_VAR_DXF 33     /* cplx  rfftn(DX)                                     */
+#define SPORCO_AMD_VAR_DYF 34     /* cplx  auxiliary (momentum) state                    */
+#define SPORCO_AMD_VAR_DXFPRV 35  /* cplx  previous DXF                                  */
+#define SPORCO_AMD_VAR_DYFPRV 36  /* cplx  previous DYF                                  */
+#define SPORCO_AMD_VAR_DVF 37     /* cplx  gradient-step buffer                          */
+#define SPORCO_AMD_VAR_DGF 38     /* cplx  gradient                                      */
+#define SPORCO_AMD_VAR_DT0 39     /* cplx  scratch for host-composed policies            */
+#define SPORCO_AMD_VAR_DT1 40
+#define SPORCO_AMD_VAR_DT2 41
+#define SPORCO_AMD_VAR_COUNT 42
 
 /* Create a solver on HIP device `device`.  `stream` is a hipStream_t to borrow
  * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to own a new one.
@@ -222,6 +235,37 @@ int sporco_amd_csc_fft_var(sporco_amd_csc_t h, int real_var, int cplx_var);
 int sporco_amd_csc_ifft_var(sporco_amd_csc_t h, int cplx_var, int real_var);
 /* dst = src (state copy of equal size: on_iteration_start, pgm.py:835-846). */
 int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var);
+
+/* ---- dictionary update (pgm.ccmod.ConvCnstrMOD, sporco/pgm/ccmod.py:139-404) --- */
+
+/* ZF = rfftn(real state `var`): setcoef (pgm/ccmod.py:264-279).  With a handle
+ * shared between the X-step and the D-step, var = VAR_Y keeps the coefficient
+ * maps on the device (DictLearn.post_xstep, dictlrn/dictlrn.py:379-382). */
+int sporco_amd_csc_ccmod_setcoef(sporco_amd_csc_t h, int var);
+/* DGF = sum_n conj(Zf) (sum_k Zf*v - Sf) for the D-sized complex state `var`
+ * (grad_f, pgm/ccmod.py:295-309: inner over axisM then over axisK, channels of
+ * a single-channel dictionary folded into the image axis); out[PGM_F],
+ * out[PGM_DFID], out[PGM_HESS] as for pgm_grad. */
+int sporco_amd_csc_ccmod_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
+/* Same sums without writing the gradient (obfn_f / obfn_dfd, ccmod.py:340-372). */
+int sporco_amd_csc_ccmod_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
+/* DVF = DYF - DGF/L; DX = Pcn(irfftn(DVF)); DXF = rfftn(DX)  (PGMDFT.xstep with
+ * prox_g = Pcn, pgm/ccmod.py:320-323; cnvrep.Pcn, sporco/cnvrep.py:868-913:
+ * crop to (dH,dW), zero-pad, optional zero-mean, unit l2 norm per filter). */
+int sporco_amd_csc_ccmod_prox_step(sporco_amd_csc_t h, double L, int32_t dH, int32_t dW,
+                                   int32_t zero_mean);
+/* out[0] = ||Pcn(DX) - DX||_2  (obfn_cns, pgm/ccmod.py:350-355). */
+int sporco_amd_csc_ccmod_cnstr(sporco_amd_csc_t h, int32_t dH, int32_t dW, int32_t zero_mean,
+                               double out[SPORCO_AMD_OUT_COUNT]);
+/* dst(dH,dW,K) = DX[:dH,:dW,:]  (getdict(crop=True), pgm/ccmod.py:283-291). */
+int sporco_amd_csc_ccmod_getdict(sporco_amd_csc_t h, int32_t dH, int32_t dW, void *dst);
+/* Df = DXF and its Sherman-Morrison denominators, device to device: the
+ * X-step's setdict(dstep.getdict()) of DictLearn.post_dstep without PCIe
+ * (dictlrn/dictlrn.py:386-389, admm/cbpdn.py:242-256). */
+int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW);
+/* out[0] = sum |v| over the real state `var` (RegL1 of DictLearn.evaluate,
+ * dictlrn/cbpdndl.py:519). */
+int sporco_amd_csc_asum(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
 
 /* ---- per-kernel timing (HIP events on the handle's stream) ---------------- */
 

@@ -14,7 +14,9 @@ F32, F64 = 0, 1
 
 VAR_Y, VAR_U, VAR_X, VAR_XF, VAR_DF, VAR_SF = 0, 1, 2, 3, 4, 5
 VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_AX, VAR_YPREV = 6, 7, 8, 9, 10, 11, 12
-VAR_T0, VAR_T1, VAR_T2 = 13, 14, 15
+VAR_T0, VAR_T1, VAR_T2, VAR_ZF = 13, 14, 15, 16
+VAR_DX, VAR_DXF, VAR_DYF, VAR_DXFPRV, VAR_DYFPRV = 32, 33, 34, 35, 36
+VAR_DVF, VAR_DGF, VAR_DT0, VAR_DT1, VAR_DT2 = 37, 38, 39, 40, 41
 
 FLAG_NONNEG = 1 << 0
 FLAG_NOBNDRY = 1 << 1
@@ -47,6 +49,9 @@ EXPORTS = (
     'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_eval', 'sporco_amd_csc_pgm_prox_step',
     'sporco_amd_csc_lincomb', 'sporco_amd_csc_pair_stats', 'sporco_amd_csc_copy',
     'sporco_amd_csc_fft_var', 'sporco_amd_csc_ifft_var',
+    'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
+    'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
+    'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
     'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_sl1l2',
@@ -144,6 +149,14 @@ def load(path=None):
         'sporco_amd_csc_copy': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_fft_var': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_ifft_var': [vp, ctypes.c_int, ctypes.c_int],
+        'sporco_amd_csc_ccmod_setcoef': [vp, ctypes.c_int],
+        'sporco_amd_csc_ccmod_grad': [vp, ctypes.c_int, dptr],
+        'sporco_amd_csc_ccmod_eval': [vp, ctypes.c_int, dptr],
+        'sporco_amd_csc_ccmod_prox_step': [vp, dbl, i32, i32, i32],
+        'sporco_amd_csc_ccmod_cnstr': [vp, i32, i32, i32, dptr],
+        'sporco_amd_csc_ccmod_getdict': [vp, i32, i32, vp],
+        'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
+        'sporco_amd_csc_asum': [vp, ctypes.c_int, dptr],
         'sporco_amd_csc_profile': [vp, ctypes.c_int],
         'sporco_amd_csc_profile_read': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                         dptr, ctypes.POINTER(i64)],
@@ -257,8 +270,13 @@ class Solver(object):
             return (H, Wf, 1, 1, K), self.cdtype
         if var == VAR_SF:
             return (H, Wf, C, N, 1), self.cdtype
-        if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2):
+        if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2,
+                   VAR_ZF):
             return (H, Wf, C, N, K), self.cdtype
+        if var == VAR_DX:
+            return (H, W, 1, 1, K), self.dtype
+        if VAR_DXF <= var <= VAR_DT2:
+            return (H, Wf, 1, 1, K), self.cdtype
         return (H, W, C, N, K), self.dtype
 
     # -- set-up -----------------------------------------------------------
@@ -386,6 +404,44 @@ class Solver(object):
 
     def copy(self, dst, src):
         check(self._lib.sporco_amd_csc_copy(self._h, dst, src))
+
+    # -- dictionary update ---------------------------------------------------
+    def ccmod_setcoef(self, var):
+        check(self._lib.sporco_amd_csc_ccmod_setcoef(self._h, var))
+
+    def ccmod_grad(self, var):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_ccmod_grad(self._h, var, out))
+        return list(out)
+
+    def ccmod_eval(self, var):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_ccmod_eval(self._h, var, out))
+        return list(out)
+
+    def ccmod_prox_step(self, L, dH, dW, zero_mean):
+        check(self._lib.sporco_amd_csc_ccmod_prox_step(self._h, float(L), int(dH), int(dW),
+                                                       1 if zero_mean else 0))
+
+    def ccmod_cnstr(self, dH, dW, zero_mean):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_ccmod_cnstr(self._h, int(dH), int(dW),
+                                                   1 if zero_mean else 0, out))
+        return out[0]
+
+    def ccmod_getdict(self, dH, dW):
+        K = self.dims[4]
+        out = np.empty((dH, dW, 1, 1, K), dtype=self.dtype)
+        check(self._lib.sporco_amd_csc_ccmod_getdict(self._h, int(dH), int(dW), _ptr(out)))
+        return out
+
+    def setdict_from_dstep(self, dH, dW):
+        check(self._lib.sporco_amd_csc_setdict_from_dstep(self._h, int(dH), int(dW)))
+
+    def asum(self, var):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_asum(self._h, var, out))
+        return out[0]
 
     def fft_var(self, real_var, cplx_var):
         check(self._lib.sporco_amd_csc_fft_var(self._h, real_var, cplx_var))

@@ -122,6 +122,13 @@ struct CscBase {
     virtual void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) = 0;
     virtual void pair_stats(int va, int vb, int vg, double *out_dev) = 0;
     virtual void copy(int dst, int src) = 0;
+    virtual void ccmod_setcoef(int var) = 0;
+    virtual void ccmod_grad(int var, bool write_grad, double *out_dev) = 0;
+    virtual void ccmod_prox_step(double L, int dH, int dW, bool zm) = 0;
+    virtual void ccmod_cnstr(int dH, int dW, bool zm, double *out_dev) = 0;
+    virtual void ccmod_getdict(int dH, int dW, void *dst) = 0;
+    virtual void setdict_from_dstep(int dH, int dW) = 0;
+    virtual void asum(int var, double *out_dev) = 0;
     virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
     virtual void read_out(const double *out_dev, double *out_host) = 0;
     double *out_dev_default = nullptr;
@@ -141,10 +148,29 @@ static bool var_is_complex(int var) {
     case SPORCO_AMD_VAR_T0:
     case SPORCO_AMD_VAR_T1:
     case SPORCO_AMD_VAR_T2:
+    case SPORCO_AMD_VAR_ZF:
+    case SPORCO_AMD_VAR_DXF:
+    case SPORCO_AMD_VAR_DYF:
+    case SPORCO_AMD_VAR_DXFPRV:
+    case SPORCO_AMD_VAR_DYFPRV:
+    case SPORCO_AMD_VAR_DVF:
+    case SPORCO_AMD_VAR_DGF:
+    case SPORCO_AMD_VAR_DT0:
+    case SPORCO_AMD_VAR_DT1:
+    case SPORCO_AMD_VAR_DT2:
         return true;
     default:
         return false;
     }
+}
+
+static bool var_is_dict_sized(int var) {
+    return var == SPORCO_AMD_VAR_DF || (var >= SPORCO_AMD_VAR_DX && var <= SPORCO_AMD_VAR_DT2);
+}
+
+static bool var_is_valid(int var) {
+    return (var >= 0 && var <= SPORCO_AMD_VAR_ZF) ||
+           (var >= SPORCO_AMD_VAR_DX && var <= SPORCO_AMD_VAR_DT2);
 }
 
 template <typename T> struct Csc : CscBase {
@@ -157,6 +183,8 @@ template <typename T> struct Csc : CscBase {
     FftPlan planW, planH;
     void *vars[SPORCO_AMD_VAR_COUNT] = {nullptr};
     cx<T> *work = nullptr;    // column-pass scratch (EF complex)
+    cx<T> *dwork = nullptr;   // column-pass scratch of the D-step (npix*K complex)
+    T *pcn_stats = nullptr;   // per-filter mean and 1/norm of the constraint projection
     cx<T> *innerb = nullptr;  // (npix, CN) complex
     T *gram = nullptr;        // (npix)
     T *dpad = nullptr;        // (H, W, K) real
@@ -211,7 +239,7 @@ template <typename T> struct Csc : CscBase {
         (void)hipStreamSynchronize(st);
         for (auto &v : vars)
             if (v) (void)hipFree(v);
-        for (void *p : {(void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
+        for (void *p : {(void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
@@ -222,18 +250,14 @@ template <typename T> struct Csc : CscBase {
     }
 
     size_t var_bytes(int var) const {
-        switch (var) {
-        case SPORCO_AMD_VAR_DF:
-            return sizeof(cx<T>) * npix * K;
-        case SPORCO_AMD_VAR_SF:
-            return sizeof(cx<T>) * npix * CN;
-        default:
-            return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
-        }
+        if (var == SPORCO_AMD_VAR_SF) return sizeof(cx<T>) * npix * CN;
+        if (var_is_dict_sized(var))
+            return var_is_complex(var) ? sizeof(cx<T>) * npix * K : sizeof(T) * (int64_t)H * W * K;
+        return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
     }
 
     void *var_ptr(int var) {
-        SA_REQUIRE(var >= 0 && var < SPORCO_AMD_VAR_COUNT, "unknown state variable id");
+        SA_REQUIRE(var_is_valid(var), "unknown state variable id");
         if (!vars[var]) {
             SA_HIP(hipMalloc(&vars[var], var_bytes(var)));
             SA_HIP(hipMemsetAsync(vars[var], 0, var_bytes(var), st));
@@ -245,6 +269,14 @@ template <typename T> struct Csc : CscBase {
     cx<T> *work_buf() {
         if (!work) SA_HIP(hipMalloc((void **)&work, sizeof(cx<T>) * EF));
         return work;
+    }
+    cx<T> *dwork_buf() {
+        if (!dwork) SA_HIP(hipMalloc((void **)&dwork, sizeof(cx<T>) * npix * K));
+        return dwork;
+    }
+    T *pcn_stats_buf() {
+        if (!pcn_stats) SA_HIP(hipMalloc((void **)&pcn_stats, sizeof(T) * 2 * K));
+        return pcn_stats;
     }
     Dims5 d5() const { return Dims5{H, W, C, N, K}; }
 
@@ -577,27 +609,29 @@ template <typename T> struct Csc : CscBase {
     }
 
     void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) override {
-        SA_REQUIRE(var_is_complex(dst) && var_bytes(dst) == sizeof(cx<T>) * EF,
-                   "lincomb works on X-sized frequency-domain variables");
+        SA_REQUIRE(var_is_valid(dst) && var_is_complex(dst) && dst != SPORCO_AMD_VAR_SF,
+                   "lincomb works on frequency-domain state variables");
         for (int v : {va, vb, vc})
             SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(dst)),
                        "lincomb operand of the wrong kind");
         SA_REQUIRE(va >= 0, "lincomb needs a first operand");
         ProfScope ps(prof, PS_PGM);
         launch_lincomb<T>(st, cv(dst), (T)a, cv(va), (T)b, vb >= 0 ? cv(vb) : nullptr, (T)c,
-                          vc >= 0 ? cv(vc) : nullptr, EF);
+                          vc >= 0 ? cv(vc) : nullptr, (int64_t)(var_bytes(dst) / sizeof(cx<T>)));
     }
 
     void pair_stats(int va, int vb, int vg, double *out_dev) override {
-        for (int v : {va, vb, vg})
-            SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == sizeof(cx<T>) * EF),
-                       "pair_stats works on X-sized frequency-domain variables");
-        SA_REQUIRE(va >= 0, "pair_stats needs a first operand");
+        SA_REQUIRE(va >= 0 && var_is_valid(va) && var_is_complex(va) && va != SPORCO_AMD_VAR_SF,
+                   "pair_stats needs a frequency-domain first operand");
+        for (int v : {vb, vg})
+            SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(va)),
+                       "pair_stats operands must have the same shape");
+        const int64_t cols = var_is_dict_sized(va) ? K : P;
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
             nb = launch_pair_stats<T>(st, cv(va), vb >= 0 ? cv(vb) : nullptr,
-                                      vg >= 0 ? cv(vg) : nullptr, npix, P, W, part_a);
+                                      vg >= 0 ? cv(vg) : nullptr, npix, cols, W, part_a);
         }
         const int slots[4] = {0, 1, 2, 3};
         const double scales[4] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0};
@@ -605,13 +639,102 @@ template <typename T> struct Csc : CscBase {
     }
 
     void fft_var(int rvar, int cvar, bool inverse) override {
-        SA_REQUIRE(!var_is_complex(rvar) && var_is_complex(cvar) &&
-                       var_bytes(rvar) == sizeof(T) * E && var_bytes(cvar) == sizeof(cx<T>) * EF,
-                   "fft_var needs an X-sized real and an X-sized complex variable");
+        SA_REQUIRE(var_is_valid(rvar) && var_is_valid(cvar) && !var_is_complex(rvar) &&
+                       var_is_complex(cvar) && cvar != SPORCO_AMD_VAR_SF &&
+                       var_is_dict_sized(rvar) == var_is_dict_sized(cvar),
+                   "fft_var needs a real and a complex variable of matching shape");
+        const int64_t cols = var_is_dict_sized(rvar) ? K : P;
         if (inverse)
-            inv2(cv(cvar), work_buf(), rv(rvar), P);
+            inv2(cv(cvar), var_is_dict_sized(rvar) ? dwork_buf() : work_buf(), rv(rvar), cols);
         else
-            fwd2(rv(rvar), nullptr, T(0), cv(cvar), P);
+            fwd2(rv(rvar), nullptr, T(0), cv(cvar), cols);
+    }
+
+    // ---- dictionary update -------------------------------------------------------------
+    void ccmod_setcoef(int var) override {
+        SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
+                   "ccmod_setcoef needs an X-sized real variable");
+        fwd2(rv(var), nullptr, T(0), cv(SPORCO_AMD_VAR_ZF), P);
+    }
+
+    void ccmod_grad(int var, bool write_grad, double *out_dev) override {
+        if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
+        SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var),
+                   "ccmod_grad needs a dictionary-sized frequency-domain variable");
+        int nb;
+        {
+            ProfScope ps(prof, PS_PGM);
+            nb = launch_ccmod_grad<T>(st, cv(SPORCO_AMD_VAR_ZF), cv(var), cv(SPORCO_AMD_VAR_SF),
+                                      write_grad ? cv(SPORCO_AMD_VAR_DGF) : nullptr, npix, CN, K, W,
+                                      part_a);
+        }
+        const int slots[3] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_HESS};
+        const double scales[3] = {0.5, 1.0 / ((double)H * W), 1.0};
+        finalize(part_a, nb, 3, 3, slots, scales, out_dev);
+    }
+
+    void pcn_project(const T *v, T *out, int dH, int dW, bool zm, double *out_dev) {
+        SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W, "filter support out of range");
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_pcn_stats<T>(st, v, pcn_stats_buf(), H, W, K, dH, dW, zm);
+            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b);
+        }
+        if (out_dev) {
+            const int slots[1] = {0};
+            const double scales[1] = {1.0};
+            finalize(part_b, nb, 1, 1, slots, scales, out_dev);
+        }
+    }
+
+    void ccmod_prox_step(double L, int dH, int dW, bool zm) override {
+        cx<T> *Vf = cv(SPORCO_AMD_VAR_DVF);
+        {
+            ProfScope ps(prof, PS_PGM);
+            launch_axpy_c<T>(st, cv(SPORCO_AMD_VAR_DYF), cv(SPORCO_AMD_VAR_DGF), Vf, (T)(-1.0 / L),
+                             npix * K);
+        }
+        T *X = rv(SPORCO_AMD_VAR_DX);
+        inv2(Vf, dwork_buf(), X, K);
+        pcn_project(X, X, dH, dW, zm, nullptr);
+        fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+    }
+
+    void ccmod_cnstr(int dH, int dW, bool zm, double *out_dev) override {
+        pcn_project(rv(SPORCO_AMD_VAR_DX), nullptr, dH, dW, zm, out_dev);
+    }
+
+    void ccmod_getdict(int dH, int dW, void *dst) override {
+        SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W, "filter support out of range");
+        SA_HIP(hipMemcpy2DAsync(dst, sizeof(T) * (size_t)dW * K, rv(SPORCO_AMD_VAR_DX),
+                                sizeof(T) * (size_t)W * K, sizeof(T) * (size_t)dW * K, (size_t)dH,
+                                hipMemcpyDeviceToHost, st));
+        sync();
+    }
+
+    void setdict_from_dstep(int dH, int dW) override {
+        SA_HIP(hipMemcpyAsync(cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_DXF),
+                              sizeof(cx<T>) * npix * K, hipMemcpyDeviceToDevice, st));
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
+        }
+        dH_ = dH;
+        dW_ = dW;
+        have_dict = true;
+    }
+
+    void asum(int var, double *out_dev) override {
+        SA_REQUIRE(var_is_valid(var) && !var_is_complex(var), "asum needs a real variable");
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_asum<T>(st, rv(var), (int64_t)(var_bytes(var) / sizeof(T)), part_a);
+        }
+        const int slots[1] = {0};
+        const double scales[1] = {1.0};
+        finalize(part_a, nb, 1, 1, slots, scales, out_dev);
     }
 
     void copy(int dst, int src) override {
@@ -941,6 +1064,79 @@ int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->copy(dst_var, src_var);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_setcoef(sporco_amd_csc_t h, int var) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->ccmod_setcoef(var);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->ccmod_grad(var, true, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->ccmod_grad(var, false, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_prox_step(sporco_amd_csc_t h, double L, int32_t dH, int32_t dW,
+                                   int32_t zero_mean) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(L > 0.0, "L must be positive");
+    h->impl->ccmod_prox_step(L, dH, dW, zero_mean != 0);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_cnstr(sporco_amd_csc_t h, int32_t dH, int32_t dW, int32_t zero_mean,
+                               double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->ccmod_cnstr(dH, dW, zero_mean != 0, sb);
+    h->impl->read_out(sb, out);
+    out[0] = std::sqrt(out[0]);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_getdict(sporco_amd_csc_t h, int32_t dH, int32_t dW, void *dst) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(dst != nullptr, "dst is null");
+    h->impl->ccmod_getdict(dH, dW, dst);
+    SA_API_END
+}
+
+int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->setdict_from_dstep(dH, dW);
+    SA_API_END
+}
+
+int sporco_amd_csc_asum(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->asum(var, sb);
+    h->impl->read_out(sb, out);
     SA_API_END
 }
 

@@ -119,6 +119,29 @@ template <typename T>
 int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *g, int64_t npix,
                       int64_t cols, int W, double *partials);
 
+// Dictionary-update gradient (pgm/ccmod.py:295-317), both contractions in one pass
+// over the coefficient spectra zf(npix, CN, K):
+//     r[n]  = sum_k zf[n,k] d[k] - sf[n]           (inner over filters, axisM)
+//     gf[k] = sum_n conj(zf[n,k]) r[n]             (inner over images, axisK; C folded in)
+// gf may be null (evaluation only).  partials per block (3 doubles): sum |r|^2,
+// Parseval-weighted sum |r|^2, sum |r + sf|^2 (= <d, Hess d>).  Returns #blocks.
+template <typename T>
+int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
+                      int64_t npix, int CN, int K, int W, double *partials);
+
+// Constraint-set projection Pcn = normalise(zeromean(zpad(bcrop(v)))) of a
+// dictionary v(H, W, K) with filter support (dH, dW) (cnvrep.py:868-913).
+// stats[2k] = mean over support (0 unless zm), stats[2k+1] = 1/norm (1 if norm is 0).
+template <typename T>
+void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
+                      bool zm);
+// out = projected v (out may be null: measure only); partial[block] = sum (P(v) - v)^2
+template <typename T>
+int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
+                     int dH, int dW, double *partials);
+// partial[block] = sum |v|
+template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, double *partials);
+
 // max |conj(df) * sf| over (npix, CN, K)   (cbpdn.py:573-578); partial[block][0] = block max
 template <typename T>
 int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int CN,

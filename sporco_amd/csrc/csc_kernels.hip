@@ -922,6 +922,168 @@ int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t 
 }
 
 // ---------------------------------------------------------------------------
+// dictionary update (D-step) kernels
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ cx<T> wave_sum_cx(cx<T> v) {
+#pragma unroll
+    for (int m = kWave / 2; m > 0; m >>= 1) {
+        v.re += __shfl_xor(v.re, m, kWave);
+        v.im += __shfl_xor(v.im, m, kWave);
+    }
+    return v;
+}
+
+// One workgroup per pixel (grid-stride): phase 1 gives every wave whole rows of
+// zf[n, :] (lanes = filters, coalesced) and reduces them to r[n] in LDS; phase 2
+// re-walks the same rows (now L1/L2 resident) accumulating conj(zf) r per filter.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__restrict__ zf,
+                                                              const cx<T> *__restrict__ d,
+                                                              const cx<T> *__restrict__ sf,
+                                                              cx<T> *__restrict__ gf, int64_t npix,
+                                                              int CN, int K, int Wf, int W,
+                                                              double *partials) {
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int nwave = blockDim.x / kWave;
+    cx<T> *r = dyn_lds<cx<T>>();               // [CN]
+    cx<T> *gpart = r + CN;                     // [nwave][K]
+    double *red = reinterpret_cast<double *>(gpart + (size_t)nwave * K);  // [3 * nwave]
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+        const cx<T> *zp = zf + pix * CN * K;
+        const cx<T> *dp = d + pix * K;
+        for (int n = wave; n < CN; n += nwave) {
+            cx<T> q = mk<T>(T(0), T(0));
+            for (int k = lane; k < K; k += kWave) q = q + cmul(zp[(int64_t)n * K + k], dp[k]);
+            q = wave_sum_cx(q);
+            if (lane == 0) {
+                const cx<T> rr = q - sf[pix * CN + n];
+                r[n] = rr;
+                const double r2 = (double)cabs2(rr);
+                acc[0] += r2;
+                acc[1] += parseval_weight((int)(pix % Wf), Wf, W) * r2;
+                acc[2] += (double)cabs2(q);
+            }
+        }
+        __syncthreads();
+        if (gf) {
+            for (int k = lane; k < K; k += kWave) {
+                cx<T> g = mk<T>(T(0), T(0));
+                for (int n = wave; n < CN; n += nwave) g = g + cmulc(zp[(int64_t)n * K + k], r[n]);
+                gpart[wave * K + k] = g;
+            }
+            __syncthreads();
+            for (int k = threadIdx.x; k < K; k += blockDim.x) {
+                cx<T> g = gpart[k];
+                for (int w = 1; w < nwave; ++w) g = g + gpart[w * K + k];
+                gf[pix * K + k] = g;
+            }
+        }
+        __syncthreads();
+    }
+    block_sum_store<3>(acc, red, partials + (int64_t)blockIdx.x * 3);
+}
+
+template <typename T>
+int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
+                      int64_t npix, int CN, int K, int W, double *partials) {
+    int grid = (int)(npix < kMaxPartialBlocks ? npix : kMaxPartialBlocks);
+    const int nwave = kThreads / kWave;
+    size_t lds = sizeof(cx<T>) * ((size_t)CN + (size_t)nwave * K) + sizeof(double) * 3 * nwave;
+    lds = (lds + 15) / 16 * 16;
+    SA_REQUIRE(lds <= 64 * 1024, "too many images x filters for the D-step gradient kernel");
+    hipLaunchKernelGGL((ccmod_grad_kernel<T>), dim3(grid), dim3(kThreads), lds, st, zf, d, sf, gf,
+                       npix, CN, K, W / 2 + 1, W, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict__ v,
+                                                             T *__restrict__ stats, int H, int W,
+                                                             int K, int dH, int dW, int zm) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        T mean = T(0);
+        if (zm) {
+            T s = T(0);
+            for (int h = 0; h < dH; ++h)
+                for (int x = 0; x < dW; ++x) s += v[((int64_t)h * W + x) * K + k];
+            mean = s / (T)(dH * dW);
+        }
+        T n2 = T(0);
+        for (int h = 0; h < dH; ++h)
+            for (int x = 0; x < dW; ++x) {
+                const T c = v[((int64_t)h * W + x) * K + k] - mean;
+                n2 += c * c;
+            }
+        const T nrm = sqrt(n2);
+        stats[2 * k] = mean;
+        stats[2 * k + 1] = nrm == T(0) ? T(1) : T(1) / nrm;
+    }
+}
+
+template <typename T>
+void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
+                      bool zm) {
+    hipLaunchKernelGGL((pcn_stats_kernel<T>), dim3(grid_for(K)), dim3(kThreads), 0, st, v, stats, H,
+                       W, K, dH, dW, zm ? 1 : 0);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict__ v,
+                                                             const T *__restrict__ stats, T *out,
+                                                             int H, int W, int K, int dH, int dW,
+                                                             double *partials) {
+    double acc[1] = {0.0};
+    const int64_t n = (int64_t)H * W * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / K;
+        const int x = (int)(pix % W), h = (int)(pix / W);
+        const T vi = v[i];
+        // v / vn as in cnvrep.normalise (cnvrep.py:696-700): 1/norm is applied by division
+        const T o = (h < dH && x < dW) ? (vi - stats[2 * k]) * stats[2 * k + 1] : T(0);
+        if (out) out[i] = o;
+        const double df = (double)(o - vi);
+        acc[0] += df * df;
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T>
+int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
+                     int dH, int dW, double *partials) {
+    const int grid = grid_for((int64_t)H * W * K);
+    hipLaunchKernelGGL((pcn_apply_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, v, stats, out, H, W, K, dH, dW,
+                       partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) asum_kernel(const T *__restrict__ v, int64_t n,
+                                                        double *partials) {
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T x = v[i];
+        acc[0] += (double)(x < T(0) ? -x : x);
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, double *partials) {
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((asum_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, v, n, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------
 // fixed-order final reduction of block partials
 // ---------------------------------------------------------------------------
 struct FinalizeArgs {
@@ -1003,7 +1165,13 @@ void launch_finalize(hipStream_t st, const double *partials, int nblocks, int st
     template int launch_pair_stats<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
                                       int64_t, int64_t, int, double *);                            \
     template int launch_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,     \
-                                      int, double *);
+                                      int, double *);                                              \
+    template int launch_ccmod_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
+                                      cx<T> *, int64_t, int, int, int, double *);                  \
+    template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool); \
+    template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
+                                     int, double *);                                               \
+    template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);
 SA_INST(float)
 SA_INST(double)
 

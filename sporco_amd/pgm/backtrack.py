@@ -63,7 +63,7 @@ class BacktrackRobust(BacktrackBase):
 
     def update(self, solverobj):
         dev = solverobj.dev
-        Z = _lib.VAR_T2
+        Z = solverobj.scratch(2)
         if not self.have_z:
             dev.copy(Z, solverobj.var_x())
             self.have_z = True

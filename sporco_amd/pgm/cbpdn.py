@@ -189,9 +189,9 @@ class ConvBPDN(pgm.PGMDFT):
         self._rl1 = abs(self._wl1_scalar) * out[_lib.PGM_L1]
         self.invalidate(_lib.VAR_X, _lib.VAR_XF, _lib.VAR_VF)
 
-    def rsdl(self):
-        """rfl2norm2(Xf - Yfprv) (pgm/cbpdn.py:314-320)."""
-        return self.dev.pair_stats(_lib.VAR_XF, _lib.VAR_YFPRV)[0]
+    def hess_quad(self, V):
+        """<V, hessian_f(V)> = sum |sum_m Df V|^2 (pgm/cbpdn.py:302-312)."""
+        return self.dev.pgm_eval(V)[_lib.PGM_HESS]
 
     # -- objective ---------------------------------------------------------------------------
     def eval_objfn(self):

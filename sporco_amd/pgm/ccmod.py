@@ -1,0 +1,178 @@
+"""Constrained convolutional dictionary update by FISTA, on the GPU.
+
+Drop-in for ``sporco.pgm.ccmod.ConvCnstrMOD`` (sporco/pgm/ccmod.py:28-404):
+minimise (1/2) sum_k ||sum_m d_m * x_{k,m} - s_k||^2 over filters d_m of unit
+norm and support ``dsz``.  The PGM variable is the zero-padded dictionary;
+IterationStats fields are ``Iter, DFid, Cnstr, Rsdl, F_Btrack, Q_Btrack,
+IterBTrack, L, Time``.
+
+Device work per step: the gradient needs two contractions of the coefficient
+spectra Zf (over filters, then over images); one kernel does both per pixel
+while the slice of Zf is cache resident.  The proximal map is the constraint
+projection ``Pcn`` (crop, zero-pad, optional zero-mean, normalise).
+"""
+
+import copy
+
+import numpy as np
+
+from . import pgm
+from .. import _lib
+from .. import cnvrep as cr
+from ..admm.cbpdn import _DeviceArray
+
+__all__ = ['ConvCnstrMOD']
+
+
+class ConvCnstrMOD(pgm.PGMDFT):
+
+    class Options(pgm.PGMDFT.Options):
+        """Adds ``ZeroMean`` (sporco/pgm/ccmod.py:111-112)."""
+
+        defaults = copy.deepcopy(pgm.PGMDFT.Options.defaults)
+        defaults.update({'ZeroMean': False})
+
+        def __init__(self, opt=None):
+            pgm.PGMDFT.Options.__init__(self, {} if opt is None else opt)
+
+    itstat_fields_objfn = ('DFid', 'Cnstr')
+    hdrtxt_objfn = ('DFid', 'Cnstr')
+    hdrval_objfun = {'DFid': 'DFid', 'Cnstr': 'Cnstr'}
+
+    _v = {'x': _lib.VAR_DXF, 'y': _lib.VAR_DYF, 'xprv': _lib.VAR_DXFPRV,
+          'yprv': _lib.VAR_DYFPRV, 'g': _lib.VAR_DGF, 't0': _lib.VAR_DT0,
+          't1': _lib.VAR_DT1, 't2': _lib.VAR_DT2}
+
+    X = _DeviceArray(_lib.VAR_DX)
+    Xf = _DeviceArray(_lib.VAR_DXF)
+    Yf = _DeviceArray(_lib.VAR_DYF)
+    Zf = _DeviceArray(_lib.VAR_ZF)
+    Sf = _DeviceArray(_lib.VAR_SF)
+
+    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
+        """``Z, S, dsz, opt, dimK, dimN`` as in the reference (pgm/ccmod.py:139).
+        Backend keyword ``dev``: an existing :class:`sporco_amd._lib.Solver`
+        (that of the sparse-coding step) to share, so that coefficient maps and
+        dictionary never leave the GPU during dictionary learning."""
+        if opt is None:
+            opt = ConvCnstrMOD.Options()
+        if dimN != 2:
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        if self.cri.Cd > 1:
+            raise NotImplementedError("multi-channel dictionaries are not part of the "
+                                      "sporco_amd hot path yet")
+        self.set_dtype(opt, S.dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
+        self._cache = {}
+        self._fcache = {}
+        self._shared = dev is not None
+        H, W = self.cri.Nv
+        # channels of S fold into the image axis for a single-channel dictionary
+        # (pgm/ccmod.py:224-229); (H, W, C, K) and (H, W, 1, C*K) share their memory layout
+        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.cri.C * self.cri.K, 1)),
+                            dtype=self.dtype)
+        if dev is None:
+            self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                                   device=device, stream=stream)
+            self.dev.set_signal(self.S)
+        else:
+            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
+                raise ValueError("shared device solver has different dimensions")
+            self.dev = dev
+        super(ConvCnstrMOD, self).__init__(self.cri.shpD, self.cri.Nv, self.cri.axisN,
+                                           S.dtype, opt)
+        self.set_attr('L', opt['L'], dval=self.cri.K * 14.0, dtype=self.dtype)
+        self.Pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd,
+                             zm=opt['ZeroMean'])
+        if Z is not None:
+            self.setcoef(Z)
+
+    # -- state ---------------------------------------------------------------------
+    def _fetch(self, var):
+        if var not in self._cache:
+            self._cache[var] = self.dev.download(var)
+        return self._cache[var]
+
+    def _store(self, var, value):
+        if value is None:
+            return
+        self.dev.upload(var, np.asarray(value))
+        self.invalidate(var)
+
+    def init_state(self, xshape):
+        """X = X0 or zeros; Xf = rfftn(X); Yf = Xf (pgm/ccmod.py:241-252)."""
+        if self.opt['X0'] is None:
+            self.X = np.zeros(xshape, dtype=self.dtype)
+        else:
+            self.X = np.asarray(self.opt['X0']).astype(self.dtype, copy=True)
+        self.dev.fft_var(_lib.VAR_DX, _lib.VAR_DXF)
+        self.dev.copy(_lib.VAR_DYF, _lib.VAR_DXF)
+        self.invalidate(_lib.VAR_DXF, _lib.VAR_DYF)
+        self.Y = None
+
+    def setcoef(self, Z):
+        """Set the coefficient maps: Zf = rfftn(Z) (pgm/ccmod.py:264-279)."""
+        self.Z = np.asarray(Z, dtype=self.dtype)
+        self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
+        self.dev.ccmod_setcoef(_lib.VAR_AX)
+        self.invalidate(_lib.VAR_ZF)
+        self._fcache.clear()
+
+    def setcoef_from_device(self, var=_lib.VAR_Y):
+        """Zf = rfftn(<real state of the shared solver>), no host round trip."""
+        self.dev.ccmod_setcoef(var)
+        self.invalidate(_lib.VAR_ZF)
+        self._fcache.clear()
+
+    def getdict(self, crop=True):
+        """Current dictionary, cropped to the filter support by default
+        (pgm/ccmod.py:283-291)."""
+        if crop:
+            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
+        return self.X
+
+    # -- smooth term -------------------------------------------------------------------
+    def grad_f(self, V=None):
+        """sum_k conj(Zf) (sum_m Zf V - Sf) at V (default Yf) (pgm/ccmod.py:295-309)."""
+        if V is None:
+            V = _lib.VAR_DYF
+        out = self.dev.ccmod_grad(V)
+        self._fcache[V] = out[_lib.PGM_F]
+        self.invalidate(_lib.VAR_DGF)
+        return _lib.VAR_DGF
+
+    def obfn_f(self, Xf=None):
+        if Xf is None:
+            Xf = _lib.VAR_DXF
+        if Xf not in self._fcache:
+            self._fcache[Xf] = self.dev.ccmod_eval(Xf)[_lib.PGM_F]
+        return self._fcache[Xf]
+
+    def hess_quad(self, V):
+        return self.dev.ccmod_eval(V)[_lib.PGM_HESS]
+
+    def prox_step(self, gradf):
+        if gradf != _lib.VAR_DGF:
+            self.dev.copy(_lib.VAR_DGF, gradf)
+        self.dev.ccmod_prox_step(self.L, self.cri.dsz[0], self.cri.dsz[1], self.opt['ZeroMean'])
+        self.invalidate(_lib.VAR_DX, _lib.VAR_DXF, _lib.VAR_DVF)
+
+    # -- objective ------------------------------------------------------------------------
+    def eval_objfn(self):
+        return (self.obfn_dfd(), self.obfn_cns())
+
+    def obfn_dfd(self):
+        return self.dev.ccmod_eval(_lib.VAR_DXF)[_lib.PGM_DFID] / 2.0
+
+    def obfn_cns(self):
+        """||Pcn(X) - X||_2 (pgm/ccmod.py:350-355)."""
+        return self.dev.ccmod_cnstr(self.cri.dsz[0], self.cri.dsz[1], self.opt['ZeroMean'])
+
+    def reconstruct(self, D=None):
+        """irfftn(sum_m Zf * Df) (pgm/ccmod.py:374-383); host arithmetic on the
+        downloaded spectra (off the iteration path)."""
+        Df = self.Xf if D is None else np.fft.rfftn(np.asarray(D), axes=(0, 1))
+        Sf = np.sum(self.Zf * Df, axis=self.cri.axisM)
+        return np.fft.irfftn(Sf, self.cri.Nv, axes=(0, 1)).astype(self.dtype)

@@ -243,17 +243,26 @@ class PGMDFT(PGM):
         self.axisN = axisN
 
     # -- handles of the device-resident iterates ---------------------------------
+    # state-variable ids of the iterate family this solver works on
+    _v = {'x': _lib.VAR_XF, 'y': _lib.VAR_YF, 'xprv': _lib.VAR_XFPRV,
+          'yprv': _lib.VAR_YFPRV, 'g': _lib.VAR_GF, 't0': _lib.VAR_T0,
+          't1': _lib.VAR_T1, 't2': _lib.VAR_T2}
+
     def var_x(self):
-        return _lib.VAR_XF
+        return self._v['x']
 
     def var_y(self, y=None):
-        if y is not None and y != _lib.VAR_YF:
-            self.dev.copy(_lib.VAR_YF, y)
-            self.invalidate(_lib.VAR_YF)
-        return _lib.VAR_YF
+        if y is not None and y != self._v['y']:
+            self.dev.copy(self._v['y'], y)
+            self.invalidate(self._v['y'])
+        return self._v['y']
 
     def var_xprv(self):
-        return _lib.VAR_XFPRV
+        return self._v['xprv']
+
+    def scratch(self, i):
+        """Device scratch array i (0..2) of the same shape as the iterates."""
+        return self._v['t%d' % i]
 
     def invalidate(self, *variables):
         """Forget cached scalars / host copies of rewritten device arrays."""
@@ -274,12 +283,12 @@ class PGMDFT(PGM):
                 self.stepsizepolicy.store_prev_state(self, self.var_x(), gradf)
         self.prox_step(gradf)
         if self.opt['Monotone'] and self.k > 0:
-            self.dev.copy(_lib.VAR_T2, _lib.VAR_XF)          # ZZf = Xf.copy()
+            self.dev.copy(self._v['t2'], self._v['x'])          # ZZf = Xf.copy()
             self.objfn = self.eval_objfn()
             if self.objfn_prev[0] < self.objfn[0]:
                 # objective went up: fall back to the previous iterate
-                self.dev.copy(_lib.VAR_XF, _lib.VAR_XFPRV)
-                self.invalidate(_lib.VAR_XF)
+                self.dev.copy(self._v['x'], self._v['xprv'])
+                self.invalidate(self._v['x'])
                 self.objfn = self.objfn_prev
         return gradf
 
@@ -291,26 +300,30 @@ class PGMDFT(PGM):
         beta = (tprv - 1.) / self.t
         if self.opt['Monotone'] and self.k > 0:
             gamma = tprv / self.t
-            self.dev.lincomb(_lib.VAR_YF, 1.0 + beta - gamma, _lib.VAR_XF, -beta,
-                             _lib.VAR_XFPRV, gamma, _lib.VAR_T2)
+            self.dev.lincomb(self._v['y'], 1.0 + beta - gamma, self._v['x'], -beta,
+                             self._v['xprv'], gamma, self._v['t2'])
         else:
-            self.dev.lincomb(_lib.VAR_YF, 1.0 + beta, _lib.VAR_XF, -beta, _lib.VAR_XFPRV)
-        self.invalidate(_lib.VAR_YF)
+            self.dev.lincomb(self._v['y'], 1.0 + beta, self._v['x'], -beta, self._v['xprv'])
+        self.invalidate(self._v['y'])
 
     def on_iteration_start(self):
         """Xfprv = Xf, Yfprv = Yf (sporco/pgm/pgm.py:835-846)."""
-        self.dev.copy(_lib.VAR_XFPRV, _lib.VAR_XF)
-        self.invalidate(_lib.VAR_XFPRV)
+        self.dev.copy(self._v['xprv'], self._v['x'])
+        self.invalidate(self._v['xprv'])
         if not self.opt['FastSolve'] or isinstance(self.backtrack, BacktrackRobust):
-            self.dev.copy(_lib.VAR_YFPRV, _lib.VAR_YF)
-            self.invalidate(_lib.VAR_YFPRV)
+            self.dev.copy(self._v['yprv'], self._v['y'])
+            self.invalidate(self._v['yprv'])
         if self.opt['Monotone']:
             if self.k == 0:
                 self.objfn = self.eval_objfn()
             self.objfn_prev = self.objfn
 
     def eval_Dxy(self):
-        return (_lib.VAR_XF, _lib.VAR_YF)
+        return (self._v['x'], self._v['y'])
+
+    def rsdl(self):
+        """rfl2norm2(Xf - Yfprv) (pgm/cbpdn.py:314-320, pgm/ccmod.py:326-332)."""
+        return self.dev.pair_stats(self._v['x'], self._v['yprv'])[0]
 
     def eval_linear_approx(self, Dxy, gradY):
         return self.dev.pair_stats(Dxy[0], Dxy[1], gradY)[1]

@@ -24,7 +24,7 @@ class StepSizePolicyCauchy(StepSizePolicyBase):
         if grad is None:
             grad = solverobj.grad_f()
         den = solverobj.dev.pair_stats(grad)[2]                      # ||g||^2
-        num = solverobj.dev.pgm_eval(grad)[_lib.PGM_HESS]           # sum |Df.g|^2
+        num = solverobj.hess_quad(grad)                             # <g, Hess_f g>
         return num / den
 
 
@@ -36,8 +36,8 @@ class StepSizePolicyBB(StepSizePolicyBase):
         self.have_prev = False
 
     def store_prev_state(self, solverobj, xvar, gvar):
-        solverobj.dev.copy(_lib.VAR_T0, xvar)
-        solverobj.dev.copy(_lib.VAR_T1, gvar)
+        solverobj.dev.copy(solverobj.scratch(0), xvar)
+        solverobj.dev.copy(solverobj.scratch(1), gvar)
         self.have_prev = True
 
     def update(self, solverobj, grad=None):
@@ -45,8 +45,9 @@ class StepSizePolicyBB(StepSizePolicyBase):
             grad = solverobj.grad_f()
         dev = solverobj.dev
         if self.have_prev:
-            dev.lincomb(_lib.VAR_T2, 1.0, grad, -1.0, _lib.VAR_T1)          # dg
-            st = dev.pair_stats(solverobj.var_x(), _lib.VAR_T0, _lib.VAR_T2)
+            dg = solverobj.scratch(2)
+            dev.lincomb(dg, 1.0, grad, -1.0, solverobj.scratch(1))
+            st = dev.pair_stats(solverobj.var_x(), solverobj.scratch(0), dg)
         else:
             # reference initial state: xprv = gradprv = 0.0
             st = dev.pair_stats(solverobj.var_x(), -1, grad)

@@ -63,6 +63,8 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
 hipError_t hipHostFree(void *p);
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width,
+                            size_t height, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemset(void *d, int v, size_t n);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st);
 hipError_t hipStreamCreate(hipStream_t *st);

@@ -5,7 +5,6 @@
 // scheduler and are released by arrival counters, so barrier semantics (and
 // barrier bugs: divergent barriers deadlock and are reported) match the GPU.
 #include <hip/hip_runtime.h>
-#include <ucontext.h>
 
 #include <chrono>
 #include <cstdio>
@@ -28,14 +27,40 @@ namespace {
 
 constexpr size_t kStack = 128 * 1024;
 
+// Minimal x86-64 System V context switch (callee-saved registers + stack
+// pointer); ucontext's swapcontext costs two sigprocmask syscalls per switch.
+extern "C" void hostsim_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl hostsim_switch
+.type hostsim_switch,@function
+hostsim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hostsim_switch,.-hostsim_switch
+)");
+
 struct Fiber {
-    ucontext_t ctx;
+    void *sp = nullptr;
     char *stack = nullptr;
     bool done = false;
 };
 
 std::vector<Fiber> fibers;
-ucontext_t sched_ctx;
+void *sched_sp = nullptr;
 int cur = -1;
 int nthreads = 0;
 const std::function<void()> *body_fn = nullptr;
@@ -45,13 +70,27 @@ int wave_arrived[32], wave_gen[32];
 unsigned long progress = 0;
 alignas(16) unsigned char slots[2048][16];
 
-void yield() { swapcontext(&fibers[cur].ctx, &sched_ctx); }
+void yield() { hostsim_switch(&fibers[cur].sp, sched_sp); }
 
 void trampoline() {
     (*body_fn)();
     fibers[cur].done = true;
     ++progress;
-    swapcontext(&fibers[cur].ctx, &sched_ctx);
+    hostsim_switch(&fibers[cur].sp, sched_sp);
+    std::abort();  // a finished fiber is never resumed
+}
+
+void prepare(Fiber &f) {
+    // stack image consumed by hostsim_switch: r15 r14 r13 r12 rbx rbp, return
+    // address (trampoline), one pad word so that trampoline starts with the ABI's
+    // call-site alignment (rsp % 16 == 8)
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void **sp = (void **)top - 8;
+    for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+    sp[6] = (void *)&trampoline;
+    sp[7] = nullptr;
+    f.sp = sp;
+    f.done = false;
 }
 
 }  // namespace
@@ -108,13 +147,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &
                 bar_arrived = 0;
                 for (int w = 0; w < 32; ++w) wave_arrived[w] = 0;
                 for (int t = 0; t < nthreads; ++t) {
-                    Fiber &f = fibers[t];
-                    f.done = false;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, trampoline, 0);
+                    prepare(fibers[t]);
                 }
                 int live = nthreads;
                 while (live > 0) {
@@ -124,7 +157,7 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &
                         if (fibers[t].done) continue;
                         cur = t;
                         threadIdx = dim3((unsigned)t, 0, 0);
-                        swapcontext(&sched_ctx, &fibers[t].ctx);
+                        hostsim_switch(&sched_sp, fibers[t].sp);
                         if (!fibers[t].done) ++live;
                     }
                     if (live > 0 && progress == before) {
@@ -163,6 +196,12 @@ hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
 }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) {
     return hipMemcpy(d, s, n, k);
+}
+hipError_t hipMemcpy2DAsync(void *d, size_t dpitch, const void *s, size_t spitch, size_t width,
+                            size_t height, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < height; ++r)
+        std::memmove((char *)d + r * dpitch, (const char *)s + r * spitch, width);
+    return hipSuccess;
 }
 hipError_t hipMemset(void *d, int v, size_t n) {
     std::memset(d, v, n);
