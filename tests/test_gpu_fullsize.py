@@ -1,0 +1,113 @@
+"""GPU-only tests at BASELINE.json sizes.
+
+The oracle cannot run the full configurations in seconds, so these use
+(a) the golden traces the reference produced for config 1 (256x256, K=32, N=1),
+(b) the NumPy oracle at a size it finishes quickly (128x128, K=16, N=4), and
+(c) size-independent properties at config 2 (512x512, K=64, N=32):
+    the reference's own LinSolveCheck assertion (XSlvRelRes < 1e-5,
+    tests/admm/test_cbpdn.py:124-139), image independence under fixed rho
+    (an image solved inside the batch equals the same image solved alone),
+    Parseval consistency of the data-fidelity term, and determinism.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def normalised_dict(rng, K, dtype=np.float32):
+    D = rng.randn(8, 8, K).astype(dtype)
+    return D / np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+
+
+@pytest.mark.parametrize('name,dt', [('admm_config1_f32', np.float32),
+                                     ('admm_config1_f64', np.float64)])
+def test_config1_against_reference_traces(gpu_backend, name, dt):
+    from sporco_amd.admm import cbpdn
+    g = load_golden(name)
+    rng = np.random.RandomState(int(g['seed']))
+    D = normalised_dict(rng, 32)
+    S = rng.randn(256, 256).astype(np.float32)
+    opt = cbpdn.ConvBPDN.Options({'MaxMainIter': 20, 'RelStopTol': 0.0, 'DataType': dt})
+    b = cbpdn.ConvBPDN(D, S, float(g['lmbda']), opt, dimK=0)
+    Y = b.solve()
+    tol = 1e-9 if dt is np.float64 else 2e-4
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert rel_l2(Y[::16, ::16], g['Y_sub']) < (1e-8 if dt is np.float64 else 5e-4)
+    assert abs(np.linalg.norm(Y.astype(np.float64)) - float(g['Y_l2'])) < tol * float(g['Y_l2'])
+    if dt is np.float32:
+        # 1e-4 bar against the float64 reference run of the same problem
+        g64 = load_golden('admm_config1_f64')
+        assert rel_l2(Y[::16, ::16], g64['Y_sub']) < 1e-4
+
+
+def test_oracle_parity_midsize(gpu_backend):
+    from sporco_amd.admm import cbpdn
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(7)
+    D = normalised_dict(rng, 16)
+    S = rng.randn(128, 128, 4).astype(np.float32)
+    opt = cbpdn.ConvBPDN.Options({'MaxMainIter': 30, 'RelStopTol': 0.0})
+    b = cbpdn.ConvBPDN(D, S, 0.05, opt)
+    Y = b.solve()
+    ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, 16), S.reshape(128, 128, 1, 4, 1), 0.05,
+                         dtype=np.float64, maxiter=30, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 1e-4
+    its = b.getitstat()
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f
+
+
+def test_oracle_parity_joint_and_pgm_midsize(gpu_backend):
+    from sporco_amd.admm import cbpdn
+    from sporco_amd.pgm import cbpdn as pgm_cbpdn
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(11)
+    D = normalised_dict(rng, 16)
+    S = rng.randn(96, 80, 3, 2).astype(np.float32)          # C = 3, N = 2, non-square
+    opt = cbpdn.ConvBPDNJoint.Options({'MaxMainIter': 25, 'RelStopTol': 0.0})
+    b = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, opt)
+    Y = b.solve()
+    ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, 16), S.reshape(96, 80, 3, 2, 1), 0.05, mu=0.02,
+                         dtype=np.float64, maxiter=25, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 1e-4
+    assert rel_l2(b.getitstat().RegL21, ref['RegL21']) < 1e-3
+    opt = pgm_cbpdn.ConvBPDN.Options({'MaxMainIter': 25, 'RelStopTol': 0.0, 'L': 50.0})
+    p = pgm_cbpdn.ConvBPDN(D, S, 0.05, opt)
+    X = p.solve()
+    ref = orc.pgm_cbpdn(D.reshape(8, 8, 1, 1, 16), S.reshape(96, 80, 3, 2, 1), 0.05,
+                        dtype=np.float64, maxiter=25, L=50.0, rel_tol=0.0)
+    assert rel_l2(X, ref['X']) < 1e-4
+    assert rel_l2(p.getitstat().ObjFun, ref['ObjFun']) < 1e-4
+
+
+def test_config2_fullsize_properties(gpu_backend):
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(12345)
+    D = normalised_dict(rng, 64)
+    S = rng.randn(512, 512, 32).astype(np.float32)
+    optd = {'MaxMainIter': 4, 'RelStopTol': 0.0, 'rho': 3.5, 'AutoRho': {'Enabled': False},
+            'LinSolveCheck': True}
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    Y = b.solve()
+    its = b.getitstat()
+    # the reference's own check on the X-step linear solve
+    assert max(its.XSlvRelRes) < 1e-5
+    # image independence: image 5 of the batch == the same image solved alone
+    one = cbpdn.ConvBPDN(D, S[:, :, 5], 0.05, cbpdn.ConvBPDN.Options(optd), dimK=0)
+    Y1 = one.solve()
+    assert rel_l2(Y[:, :, 0, 5], Y1[:, :, 0, 0]) < 1e-6
+    # Parseval: DFid from the frequency-domain by-product == spatial-domain value
+    rec = b.reconstruct(b.X)
+    dfid_spatial = 0.5 * np.sum((rec[:, :, 0, :].astype(np.float64) - S) ** 2)
+    assert abs(its.DFid[-1] - dfid_spatial) < 1e-4 * dfid_spatial
+    # l1 term and sparsity sanity
+    assert abs(its.RegL1[-1] - np.abs(b.X.astype(np.float64)).sum()) < 1e-5 * its.RegL1[-1]
+    # determinism: a second solver object reproduces the iterates bit for bit
+    b2 = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    assert np.array_equal(b2.solve(), Y)
