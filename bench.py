@@ -54,6 +54,7 @@ def kernel_bytes(H, W, P, itemsize):
         'fft_r2c_rows': 2 * E + EF,          # read Y, U; write row spectra
         'fft_c2c_cols_fwd': 2 * EF,
         'sm_solve': 2 * EF,
+        'fused_cols_sm': 2 * EF,             # read row spectra, write solved column-IFFT (in place)
         'fft_c2c_cols_inv': 2 * EF,
         'fft_c2r_rows': EF + E,              # read spectra; write X
         'admm_post': 5 * E,                  # read X, Y, U; write Y, U

@@ -6,10 +6,12 @@
 #include "../../include/sporco_amd.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <vector>
 
 #include "common.h"
+#include "csc_fused.h"
 #include "csc_kernels.h"
 #include "fft.h"
 
@@ -24,6 +26,7 @@ enum ProfSlot {
     PS_FFT_C2C_INV,
     PS_FFT_C2R,
     PS_ADMM_POST,
+    PS_FUSED_COLS,
     PS_FINALIZE,
     PS_PGM,
     PS_OTHER,
@@ -31,7 +34,8 @@ enum ProfSlot {
 };
 static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_solve",
                                            "fft_c2c_cols_inv", "fft_c2r_rows",     "admm_post",
-                                           "finalize",         "pgm_elementwise",  "other"};
+                                           "fused_cols_sm",    "finalize",         "pgm_elementwise",
+                                           "other"};
 
 struct Profiler {
     bool on = false;
@@ -196,6 +200,12 @@ template <typename T> struct Csc : CscBase {
     double *out_pinned = nullptr;
     bool have_dict = false, have_signal = false;
     int dH_ = 0, dW_ = 0;
+    // fused X-step (csc_fused.h): tile-major copies of Df, Sf, gram, its twiddles and
+    // per-tile partials; xf_tiled marks VAR_XF as holding a tile-major intermediate
+    bool fused = false, xf_tiled = false;
+    cx<T> *dft = nullptr, *sft = nullptr, *twA = nullptr, *twB = nullptr;
+    T *gramt = nullptr;
+    double *part_f = nullptr;
 
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
@@ -230,6 +240,19 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMalloc((void **)&gram, sizeof(T) * npix));
         SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CN));
         SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CN));
+        fused = fused_cols_supported<T>(H, K) && K % 2 == 0 && !std::getenv("SPORCO_AMD_UNFUSED");
+        if (fused) {
+            SA_HIP(hipMalloc((void **)&dft, sizeof(cx<T>) * npix * K));
+            SA_HIP(hipMalloc((void **)&sft, sizeof(cx<T>) * npix * CN));
+            SA_HIP(hipMalloc((void **)&gramt, sizeof(T) * npix));
+            SA_HIP(hipMalloc((void **)&part_f, sizeof(double) * (int64_t)Wf * CN));
+            SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * H));
+            SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * H));
+            std::vector<cx<T>> ta(H), tb(H);
+            fused_twiddles<T>(H, K, ta.data(), tb.data());
+            SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
+        }
         // the three ADMM state arrays start at zero (yinit/uinit, admm.py:279-289)
         for (int v : {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U, SPORCO_AMD_VAR_X}) (void)var_ptr(v);
     }
@@ -239,7 +262,8 @@ template <typename T> struct Csc : CscBase {
         (void)hipStreamSynchronize(st);
         for (auto &v : vars)
             if (v) (void)hipFree(v);
-        for (void *p : {(void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
+        for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
+                        (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
@@ -314,10 +338,32 @@ template <typename T> struct Csc : CscBase {
         launch_finalize(st, part, nblocks, stride, nvals, slots, scales, is_max, out_dev);
     }
 
+    // ---- tile-major operands of the fused X-step -----------------------------------
+    void refresh_fused_dict() {
+        if (!fused) return;
+        ProfScope ps(prof, PS_OTHER);
+        launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_DF), dft, H, Wf, K);
+        launch_permute_ab<T>(st, gram, gramt, H, Wf, 1);
+    }
+    void refresh_fused_signal() {
+        if (!fused) return;
+        ProfScope ps(prof, PS_OTHER);
+        launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_SF), sft, H, (int64_t)Wf * CN, 1);
+    }
+    // VAR_XF as callers know it (natural layout): after a fused X-step the buffer
+    // holds a tile-major intermediate, and Xf = rfftn(X) is rebuilt on demand.
+    void need_natural(int var) {
+        if (var == SPORCO_AMD_VAR_XF && xf_tiled) {
+            xf_tiled = false;
+            fwd2(rv(SPORCO_AMD_VAR_X), nullptr, T(0), cv(SPORCO_AMD_VAR_XF), P);
+        }
+    }
+
     // ---- set-up ------------------------------------------------------------------
     void set_signal(const void *S) override {
         SA_HIP(hipMemcpyAsync(sreal, S, sizeof(T) * (int64_t)H * W * CN, hipMemcpyHostToDevice, st));
         fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CN);
+        refresh_fused_signal();
         sync();  // the host buffer may be released after return
         have_signal = true;
     }
@@ -340,6 +386,7 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
         }
+        refresh_fused_dict();
         sync();
         SA_HIP(hipFree(stage));
         dH_ = dH;
@@ -378,13 +425,23 @@ template <typename T> struct Csc : CscBase {
 
     void upload(int var, const void *src) override {
         SA_HIP(hipMemcpyAsync(var_ptr(var), src, var_bytes(var), hipMemcpyHostToDevice, st));
+        if (var == SPORCO_AMD_VAR_XF) xf_tiled = false;
+        if (var == SPORCO_AMD_VAR_DF) {
+            launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
+            refresh_fused_dict();
+        }
+        if (var == SPORCO_AMD_VAR_SF) refresh_fused_signal();
         sync();
     }
     void download(int var, void *dst) override {
+        need_natural(var);
         SA_HIP(hipMemcpyAsync(dst, var_ptr(var), var_bytes(var), hipMemcpyDeviceToHost, st));
         sync();
     }
-    void *device_ptr(int var) override { return var_ptr(var); }
+    void *device_ptr(int var) override {
+        need_natural(var);
+        return var_ptr(var);
+    }
 
     void read_out(const double *out_dev, double *out_host) override {
         SA_HIP(hipMemcpyAsync(out_pinned, out_dev, sizeof(double) * kOutSlots, hipMemcpyDeviceToHost,
@@ -404,6 +461,47 @@ template <typename T> struct Csc : CscBase {
         require_ready();
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
+        if (fused && !(p.flags & F_XRRS)) {
+            // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
+            // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
+            const int64_t tline = (int64_t)CN * H * K, tgrp = (int64_t)H * K;
+            {
+                ProfScope ps(prof, PS_FFT_R2C);
+                fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, Xf, H, P, (int64_t)W * P, P, K, tline, K,
+                           tgrp);
+            }
+            FusedColsArgs<T> fa;
+            fa.t = Xf;
+            fa.dft = dft;
+            fa.sft = sft;
+            fa.gramt = gramt;
+            fa.twA = twA;
+            fa.twB = twB;
+            fa.rho = (T)p.rho;
+            fa.H = H;
+            fa.W = W;
+            fa.CN = CN;
+            fa.K = K;
+            fa.partials = part_f;
+            int64_t ntiles;
+            {
+                ProfScope ps(prof, PS_FUSED_COLS);
+                ntiles = launch_fused_cols<T>(st, fa);
+            }
+            xf_tiled = true;
+            if ((p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
+                const int slots[1] = {SPORCO_AMD_OUT_DFID};
+                const double scales[1] = {1.0 / ((double)H * W)};
+                finalize(part_f, (int)ntiles, 1, 1, slots, scales, out_dev);
+            }
+            {
+                ProfScope ps(prof, PS_FFT_C2R);
+                fft_c2r<T>(st, planW, Xf, X, H, P, K, tline, (int64_t)W * P, P,
+                           T(1.0 / ((double)H * (double)W)), K, tgrp);
+            }
+            return;
+        }
+        xf_tiled = false;
         fwd2(Y, U, (T)p.u_scale, Xf, P);
         const bool obj = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
         const bool xr = p.flags & F_XRRS;
@@ -551,6 +649,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_grad(int var, double *out_dev) override {
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_grad needs a frequency-domain variable");
+        need_natural(var);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
@@ -565,6 +664,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_eval(int var, double *out_dev) override {
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_eval needs a frequency-domain variable");
+        need_natural(var);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
@@ -605,6 +705,7 @@ template <typename T> struct Csc : CscBase {
         const int slots[1] = {SPORCO_AMD_PGM_L1};
         const double scales[1] = {1.0};
         finalize(part_b, nb, 1, 1, slots, scales, out_dev);
+        xf_tiled = false;
         fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_XF), P);
     }
 
@@ -615,6 +716,9 @@ template <typename T> struct Csc : CscBase {
             SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(dst)),
                        "lincomb operand of the wrong kind");
         SA_REQUIRE(va >= 0, "lincomb needs a first operand");
+        for (int v : {va, vb, vc})
+            if (v >= 0) need_natural(v);
+        if (dst == SPORCO_AMD_VAR_XF) xf_tiled = false;
         ProfScope ps(prof, PS_PGM);
         launch_lincomb<T>(st, cv(dst), (T)a, cv(va), (T)b, vb >= 0 ? cv(vb) : nullptr, (T)c,
                           vc >= 0 ? cv(vc) : nullptr, (int64_t)(var_bytes(dst) / sizeof(cx<T>)));
@@ -627,6 +731,8 @@ template <typename T> struct Csc : CscBase {
             SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(va)),
                        "pair_stats operands must have the same shape");
         const int64_t cols = var_is_dict_sized(va) ? K : P;
+        for (int v : {va, vb, vg})
+            if (v >= 0) need_natural(v);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
@@ -644,6 +750,8 @@ template <typename T> struct Csc : CscBase {
                        var_is_dict_sized(rvar) == var_is_dict_sized(cvar),
                    "fft_var needs a real and a complex variable of matching shape");
         const int64_t cols = var_is_dict_sized(rvar) ? K : P;
+        if (inverse) need_natural(cvar);
+        if (!inverse && cvar == SPORCO_AMD_VAR_XF) xf_tiled = false;
         if (inverse)
             inv2(cv(cvar), var_is_dict_sized(rvar) ? dwork_buf() : work_buf(), rv(rvar), cols);
         else
@@ -720,6 +828,7 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
         }
+        refresh_fused_dict();
         dH_ = dH;
         dW_ = dW;
         have_dict = true;
@@ -739,6 +848,8 @@ template <typename T> struct Csc : CscBase {
 
     void copy(int dst, int src) override {
         SA_REQUIRE(var_bytes(dst) == var_bytes(src), "copy between variables of different size");
+        need_natural(src);
+        if (dst == SPORCO_AMD_VAR_XF) xf_tiled = false;
         ProfScope ps(prof, PS_OTHER);
         SA_HIP(hipMemcpyAsync(var_ptr(dst), var_ptr(src), var_bytes(src), hipMemcpyDeviceToDevice, st));
     }

@@ -1,0 +1,47 @@
+// csc_fused.h -- the fused fast path of the ADMM X-step for gfx950.
+//
+// The unfused path (fft.hip + csc_kernels.hip) runs the X-step of
+// sporco/admm/cbpdn.py:267-281 as five kernels and moves 16 float32 passes over
+// an X-sized array per iteration.  The kernels declared here bring that down to
+// the algorithmic 10 passes by keeping every intermediate of
+//     column FFT -> Sherman-Morrison solve (linalg.py:232-297) -> column IFFT
+// in the register file of one workgroup.  They work on a *tile-major* layout of
+// the half-spectrum intermediates that only these kernels see:
+//
+//     T[wf][cn][h][k]      (wf: row frequency 0..W/2, cn: (channel, image),
+//                           h: row / column frequency, k: filter, fastest)
+//
+// so that one (wf, cn) tile -- all H points of all K filters, the unit the
+// Sherman-Morrison inner product couples -- is one contiguous block of HBM.
+#pragma once
+
+#include "common.h"
+
+namespace sporco_amd {
+
+// out[(b*A + a)*C + c] = in[(a*B + b)*C + c]: (A, B, C) -> (B, A, C).  Used to
+// re-lay Df (H, Wf, K), the per-pixel gram (H, Wf) and Sf (H, Wf*CN) tile-major.
+template <typename E>
+void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B, int64_t C);
+
+template <typename T> struct FusedColsArgs {
+    cx<T> *t;          // in: row spectra of Y - sU, tile-major; out (in place): column-
+                       // inverse-transformed solution, unnormalised
+    const cx<T> *dft;  // Df   tile-major [Wf][H][K]
+    const cx<T> *sft;  // Sf   tile-major [Wf][CN][H]
+    const T *gramt;    // sum_k |Df|^2 [Wf][H]
+    const cx<T> *twA;  // H entries: exp(-2 pi i w brev(i) / H), the twiddles between the two
+    const cx<T> *twB;  // H entries: exp(-2 pi i (w + NW j) h2 / H)    FFT stages (fused_twiddles)
+    T rho;
+    int H, W, CN, K;
+    double *partials;  // one double per tile: Parseval-weighted sum |Df.xf - Sf|^2
+};
+
+// Host tables twA, twB (H entries each) for fused_cols_supported shapes.
+template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB);
+// True when the register-resident column kernel handles this shape.
+template <typename T> bool fused_cols_supported(int H, int K);
+// Number of tiles (= partials written).
+template <typename T> int64_t launch_fused_cols(hipStream_t st, const FusedColsArgs<T> &a);
+
+}  // namespace sporco_amd

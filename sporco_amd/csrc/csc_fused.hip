@@ -1,0 +1,462 @@
+// csc_fused.hip -- register-resident column FFT + Sherman-Morrison + column IFFT.
+//
+// One workgroup of 16 waves owns one (wf, cn) tile: all H = 16*N1 points of all
+// K <= 64 filters (N1 = 16 or 32, i.e. H = 256 or 512; 256 KiB of complex64 at
+// 512 x 64, which is why the tile lives in the 512 KiB vector register file and
+// not in the 160 KiB LDS).  Lane = filter k, so every global access of a wave
+// is one contiguous K*8-byte row and the K-length inner product of
+// linalg.solvedbi_sm (sporco/linalg.py:232-297) is a cross-lane reduction.
+//
+// The length-H transform is split H = N1 x 16 (Cooley-Tukey):
+//   forward   wave w holds rows h = 16*h1 + w:   DIF FFT-N1 over h1 in registers,
+//             twiddle W_H^(w*f1), exchange through LDS so that wave w' holds
+//             f1 in {w', w'+16} x all 16 h2, DIF FFT-16 over h2  ->  X[f1 + N1*f2]
+//   solve     per frequency f: q = sum_k Df*yuf (transposing wave reduction),
+//             xf = yuf + conj(Df) * (Sf - q) / (sum_k |Df|^2 + rho)
+//   inverse   the mirror image (DIT FFT-16, conj twiddle, LDS exchange, DIT FFT-N1),
+//             landing on the rows the wave loaded, stored in place.
+// LDS is used only for the two exchanges (128 KiB, real and imaginary halves in
+// turn when N1 = 32).  Forward FFTs are decimation-in-frequency (natural in,
+// bit-reversed out), inverse ones decimation-in-time (bit-reversed in, natural
+// out), so no reordering pass exists anywhere.
+#include "csc_fused.h"
+
+#include <gfx950_intrin.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+namespace sporco_amd {
+
+namespace {
+
+typedef cx<float> cf;
+
+struct alignas(8) f2 {
+    float x, y;
+};
+
+// cos(2 pi t / 64), t = 0..16
+__host__ __device__ constexpr double cos64_q(int t) {
+    constexpr double c[17] = {1.0,
+                              0.99518472667219688624,
+                              0.98078528040323044913,
+                              0.95694033573220886494,
+                              0.92387953251128675613,
+                              0.88192126434835502971,
+                              0.83146961230254523708,
+                              0.77301045336273696081,
+                              0.70710678118654752440,
+                              0.63439328416364549822,
+                              0.55557023301960222474,
+                              0.47139673682599764856,
+                              0.38268343236508977173,
+                              0.29028467725446236764,
+                              0.19509032201612826785,
+                              0.09801714032956060199,
+                              0.0};
+    return c[t];
+}
+__host__ __device__ constexpr double cos64(int t) {
+    t = ((t % 64) + 64) % 64;
+    if (t > 32) t = 64 - t;
+    return t <= 16 ? cos64_q(t) : -cos64_q(32 - t);
+}
+__host__ __device__ constexpr double sin64(int t) { return cos64(t - 16); }
+
+__host__ __device__ constexpr int brev(int x, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+__host__ __device__ constexpr int ilog2(int n) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+
+// d * exp(-/+ 2 pi i t / 64), t in [0, 32), t known at compile time after unrolling
+template <bool INV> __device__ __forceinline__ cf tw64_mul(cf d, int t) {
+    const float h = 0.70710678118654752440f;
+    if (t == 0) return d;
+    if (t == 16) return INV ? mul_pi(d) : mul_mi(d);
+    if (t == 8)
+        return INV ? mk<float>(h * (d.re - d.im), h * (d.re + d.im))
+                   : mk<float>(h * (d.re + d.im), h * (d.im - d.re));
+    if (t == 24)
+        return INV ? mk<float>(-h * (d.re + d.im), h * (d.re - d.im))
+                   : mk<float>(h * (d.im - d.re), -h * (d.re + d.im));
+    const float c = (float)cos64(t), s = (float)sin64(t);
+    return INV ? mk<float>(d.re * c - d.im * s, d.im * c + d.re * s)
+               : mk<float>(d.re * c + d.im * s, d.im * c - d.re * s);
+}
+
+// Decimation in frequency: natural-order input v[off .. off+N), output X[brev(i)] at v[off+i].
+template <int N, bool INV, int TOT> __device__ __forceinline__ void dif(cf (&v)[TOT], int off) {
+#pragma unroll
+    for (int len = N; len >= 2; len >>= 1) {
+#pragma unroll
+        for (int blk = 0; blk < N; blk += len) {
+#pragma unroll
+            for (int j = 0; j < len / 2; ++j) {
+                const cf x = v[off + blk + j], y = v[off + blk + j + len / 2];
+                v[off + blk + j] = x + y;
+                v[off + blk + j + len / 2] = tw64_mul<INV>(x - y, j * (64 / len));
+            }
+        }
+    }
+}
+
+// Decimation in time: input x[brev(i)] at v[off+i], natural-order output.
+template <int N, bool INV, int TOT> __device__ __forceinline__ void dit(cf (&v)[TOT], int off) {
+#pragma unroll
+    for (int len = 2; len <= N; len <<= 1) {
+#pragma unroll
+        for (int blk = 0; blk < N; blk += len) {
+#pragma unroll
+            for (int j = 0; j < len / 2; ++j) {
+                const cf x = v[off + blk + j];
+                const cf y = tw64_mul<INV>(v[off + blk + j + len / 2], j * (64 / len));
+                v[off + blk + j] = x + y;
+                v[off + blk + j + len / 2] = x - y;
+            }
+        }
+    }
+}
+
+// Sum r[i] over the 64 lanes of the wave for all 8 i at once ("transposing"
+// reduction: each of the first three exchanges halves the number of live
+// values); lane l returns the total of r[l >> 3].  10 shuffles instead of 48.
+__device__ __forceinline__ float reduce8_across_lanes(const float (&r)[8], int lane) {
+    float a4[4], a2[2];
+    {
+        const bool up = lane & 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float keep = up ? r[i + 4] : r[i], send = up ? r[i] : r[i + 4];
+            a4[i] = keep + __shfl_xor(send, 32, kWave);
+        }
+    }
+    {
+        const bool up = lane & 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float keep = up ? a4[i + 2] : a4[i], send = up ? a4[i] : a4[i + 2];
+            a2[i] = keep + __shfl_xor(send, 16, kWave);
+        }
+    }
+    float a1;
+    {
+        const bool up = lane & 8;
+        const float keep = up ? a2[1] : a2[0], send = up ? a2[0] : a2[1];
+        a1 = keep + __shfl_xor(send, 8, kWave);
+    }
+    a1 += __shfl_xor(a1, 4, kWave);
+    a1 += __shfl_xor(a1, 2, kWave);
+    a1 += __shfl_xor(a1, 1, kWave);
+    return a1;
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef SaBuf BufRsrc;
+__device__ __forceinline__ BufRsrc make_rsrc(const void *base, uint32_t bytes) {
+    return sa_make_buf(base, bytes);
+}
+__device__ __forceinline__ cf buf_load_cf(BufRsrc r, int voff, int soff) {
+    cf x;
+    sa_buf_load2(r, voff, soff, x.re, x.im);
+    return x;
+}
+__device__ __forceinline__ void buf_store_cf(BufRsrc r, int voff, int soff, cf x) {
+    sa_buf_store2(r, voff, soff, x.re, x.im);
+}
+
+// Register fence: every element passes through an (empty) volatile asm, and a
+// token chained through all of them and back makes everything after the fence
+// depend on everything before it.  No instruction is emitted; it only stops the
+// scheduler from overlapping two stages of the unrolled transform, which is what
+// drives its register demand far above the tile itself.
+template <int N, int TOT> __device__ __forceinline__ void reg_fence(cf (&v)[TOT], int off, int &token) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) SA_VGPR_FENCE3(v[off + i].re, v[off + i].im, token);
+#pragma unroll
+    for (int i = 0; i < N; ++i) SA_VGPR_FENCE3(v[off + i].re, v[off + i].im, token);
+}
+
+constexpr int kExchUnitsMax = 16384;  // f2 units of the exchange buffer (128 KiB)
+constexpr size_t kFusedLds = sizeof(f2) * kExchUnitsMax + sizeof(double) * 16;
+
+// N1 x NW = H; NW waves; KC: compile-time filter count (64), or 0 for a run-time K <= 64.
+template <int N1, int NW, int LPARAM, int KC>
+__global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
+    constexpr int H = N1 * NW;
+    constexpr int J = N1 / NW;   // stage-2 lines per thread (each NW points)
+    constexpr int LB1 = ilog2(N1), LBW = ilog2(NW);
+    // The two LDS exchanges and the solve between them are pipelined over groups
+    // of LP lines (FP = LP*NW values of f1): a group leaves the register tile,
+    // is transformed / solved / transformed back by the waves that own its
+    // lines, and returns to the same registers; the rest of the tile stays put.
+    constexpr int LP = LPARAM;
+    constexpr int FP = LP * NW, Q = J / LP;
+    static_assert(J % LP == 0, "lines per group must divide the lines per thread");
+    static_assert(FP * NW * 64 <= kExchUnitsMax, "exchange group too large");
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KC ? KC : a.K;
+    const bool kv = KC == 64 ? true : k < K;
+    const int tile = blockIdx.x;
+    const int wf = tile / a.CN;
+    // buffer addressing: wave-uniform descriptors of this tile / this Df slice, one
+    // shared 32-bit lane offset and scalar row offsets, so the 3*N1 row addresses
+    // cost no vector registers (the tile itself needs 2*N1 of them)
+    const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
+    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, (uint32_t)(H * K * sizeof(cf)));
+    const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
+    const cf *S = a.sft + (int64_t)tile * H + w;
+    const float *G = a.gramt + (int64_t)wf * H + w;
+    const cf *twA = a.twA + w * N1;                           // W_H^(w * brev(i)),      i < N1
+    const cf *twB = a.twB + w * N1;                           // W_H^((w + NW j) * h2), [j][h2]
+    // One buffer serves both exchanges: a unit is written and read back by the
+    // same thread on either side, so only the two hand-overs need a barrier.
+    f2 *LA = dyn_lds<f2>();
+    f2 *LB = LA;
+    double *scratch = reinterpret_cast<double *>(LA + kExchUnitsMax);
+    const cf zero = mk<float>(0.f, 0.f);
+    int token = 0;
+
+    // ---- load rows h = NW*h1 + w, forward FFT over h1, twiddle -----------------------
+    cf v[N1];
+#pragma unroll
+    for (int h1 = 0; h1 < N1; ++h1)
+        v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
+    dif<N1, false>(v, 0);
+    reg_fence<N1>(v, 0, token);
+#pragma unroll
+    for (int i = 1; i < N1; ++i) v[i] = cmul(v[i], twA[i]);
+    reg_fence<N1>(v, 0, token);
+
+    const float rho = a.rho;
+    float obj = 0.f;
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        // ---- exchange A: (w = h2; f1 in regs) -> (w = f1 mod NW; h2 in regs) ---------
+#pragma unroll
+        for (int fl = 0; fl < FP; ++fl) {
+            const cf x = v[brev(q * FP + fl, LB1)];
+            f2 t;
+            t.x = x.re;
+            t.y = x.im;
+            LA[(fl * NW + w) * 64 + k] = t;
+        }
+        __syncthreads();
+        cf u[FP];   // u[NW*jl + h2] = A[h2][f1 = w + NW*(q*LP + jl)]
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int h2 = 0; h2 < NW; ++h2) {
+                const f2 t = LA[((w + NW * jl) * NW + h2) * 64 + k];
+                u[NW * jl + h2] = mk<float>(t.x, t.y);
+            }
+        }
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+            const int j = q * LP + jl;
+            // forward FFT over h2: u[NW jl + i] = X[f1 + N1 * brev(i)], f1 = w + NW j
+            dif<NW, false>(u, NW * jl);
+            // Sherman-Morrison solve, 4 frequencies at a time
+#pragma unroll
+            for (int c = 0; c < NW / 4; ++c) {
+                cf d[4];
+                float red[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);  // f - w
+                    d[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                    const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                    red[2 * e] = p.re;
+                    red[2 * e + 1] = p.im;
+                }
+                const float tot = reduce8_across_lanes(red, k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                    const cf qq = mk<float>(sa_readlane(tot, 16 * e), sa_readlane(tot, 16 * e + 8));
+                    const cf sv = S[fo];
+                    const float inv = sa_rcp(G[fo] + rho);
+                    const cf coef = cscale(sv - qq, inv);
+                    // Df.xf - Sf = rho (q - Sf) / (gram + rho)
+                    obj += cabs2(coef);
+                    u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
+                }
+            }
+            // inverse FFT over f2, conj twiddle
+            dit<NW, true>(u, NW * jl);
+#pragma unroll
+            for (int h2 = 1; h2 < NW; ++h2)
+                u[NW * jl + h2] = cmulc(twB[NW * j + h2], u[NW * jl + h2]);
+        }
+        SA_VGPR_FENCE3(obj, token, token);
+        // ---- exchange B: back to (w = h2; f1 in regs), placed in DIT input order -----
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int h2 = 0; h2 < NW; ++h2) {
+                f2 t;
+                t.x = u[NW * jl + h2].re;
+                t.y = u[NW * jl + h2].im;
+                LB[((w + NW * jl) * NW + h2) * 64 + k] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int fl = 0; fl < FP; ++fl) {
+            const f2 t = LB[(fl * NW + w) * 64 + k];
+            v[brev(q * FP + fl, LB1)] = mk<float>(t.x, t.y);
+        }
+    });
+    reg_fence<N1>(v, 0, token);
+
+    // ---- inverse FFT over f1, store the rows this wave loaded ------------------------
+    dit<N1, true>(v, 0);
+    if (kv) {
+#pragma unroll
+        for (int h1 = 0; h1 < N1; ++h1)
+            buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
+    }
+
+    // (always written: a conditional here makes the compiler sink the whole |coef|^2
+    // chain into the branch and keep every coef alive until the end of the kernel)
+    const int Wf = a.W / 2 + 1;
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
+    block_sum_store<1>(acc, scratch, a.partials + tile);
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256) permute_ab_kernel(const E *__restrict__ in,
+                                                         E *__restrict__ out, int64_t A, int64_t B,
+                                                         int64_t C) {
+    const int64_t n = A * B * C;
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n;
+         o += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = o % C, ba = o / C;
+        const int64_t aa = ba % A, bb = ba / A;
+        out[o] = in[(aa * B + bb) * C + c];
+    }
+}
+
+}  // namespace
+
+template <typename E>
+void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B, int64_t C) {
+    const int64_t n = A * B * C;
+    if (n <= 0) return;
+    int64_t g = ceil_div(n, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL((permute_ab_kernel<E>), dim3((unsigned)g), dim3(256), 0, st, in, out, A, B, C);
+    SA_HIP(hipGetLastError());
+}
+
+// Split of a supported shape into N1 (in-register FFT length) x NW (waves), and
+// the number LP of stage-2 lines per exchange group.  H = 512 has two layouts:
+// 16 waves x 32 points (108 VGPRs, 4 waves/SIMD) and 8 waves x 64 points (~200
+// VGPRs, 2 waves/SIMD); SPORCO_AMD_FUSED_VARIANT picks one for A/B runs.
+struct FusedSplit {
+    int N1, NW, LP;
+};
+static FusedSplit fused_split(int H, int K) {
+    if (H == 256) return {32, 8, 2};
+    static const int variant = [] {
+        const char *e = std::getenv("SPORCO_AMD_FUSED_VARIANT");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (variant == 1) return {64, 8, 2};
+    if (variant == 2) return {64, 8, 4};
+    return {32, 16, 1};
+}
+
+template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB) {
+    const FusedSplit sp = fused_split(H, K);
+    const int N1 = sp.N1, NW = sp.NW;
+    const int LB = ilog2(N1), J = N1 / NW;
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int w = 0; w < NW; ++w) {
+        for (int i = 0; i < N1; ++i) {
+            const double ang = -two_pi * (double)(w * brev(i, LB)) / (double)H;
+            twA[w * N1 + i] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
+        }
+        for (int j = 0; j < J; ++j)
+            for (int h2 = 0; h2 < NW; ++h2) {
+                const double ang = -two_pi * (double)((w + NW * j) * h2) / (double)H;
+                twB[w * N1 + NW * j + h2] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
+            }
+    }
+}
+template void fused_twiddles<float>(int, int, cx<float> *, cx<float> *);
+template void fused_twiddles<double>(int, int, cx<double> *, cx<double> *);
+
+template <> bool fused_cols_supported<float>(int H, int K) {
+    return (H == 256 || H == 512) && K >= 1 && K <= 64;
+}
+template <> bool fused_cols_supported<double>(int, int) { return false; }
+
+template <int N1, int NW, int LP, int KC>
+static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC>), dim3((unsigned)ntiles), dim3(NW * 64),
+                       kFusedLds, st, a);
+}
+
+template <int N1, int NW, int LP>
+static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
+    if (a.K == 64)
+        launch_fused_inst<N1, NW, LP, 64>(st, a, ntiles);
+    else
+        launch_fused_inst<N1, NW, LP, 0>(st, a, ntiles);
+}
+
+template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs<float> &a) {
+    SA_REQUIRE(fused_cols_supported<float>(a.H, a.K), "shape not handled by the fused column kernel");
+    const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
+    const FusedSplit sp = fused_split(a.H, a.K);
+    if (sp.N1 == 32 && sp.NW == 8)
+        launch_fused_k<32, 8, 2>(st, a, ntiles);
+    else if (sp.N1 == 32 && sp.NW == 16)
+        launch_fused_k<32, 16, 1>(st, a, ntiles);
+    else if (sp.LP == 2)
+        launch_fused_k<64, 8, 2>(st, a, ntiles);
+    else
+        launch_fused_k<64, 8, 4>(st, a, ntiles);
+    SA_HIP(hipGetLastError());
+    return ntiles;
+}
+template <> int64_t launch_fused_cols<double>(hipStream_t, const FusedColsArgs<double> &) {
+    throw Error(-1, "the fused column kernel is float32 only");
+}
+
+template void launch_permute_ab<float>(hipStream_t, const float *, float *, int64_t, int64_t, int64_t);
+template void launch_permute_ab<double>(hipStream_t, const double *, double *, int64_t, int64_t,
+                                        int64_t);
+template void launch_permute_ab<cx<float>>(hipStream_t, const cx<float> *, cx<float> *, int64_t,
+                                           int64_t, int64_t);
+template void launch_permute_ab<cx<double>>(hipStream_t, const cx<double> *, cx<double> *, int64_t,
+                                            int64_t, int64_t);
+
+}  // namespace sporco_amd

@@ -32,6 +32,8 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
              int64_t n_outer, int64_t ncols, int64_t in_outer, int64_t in_line,
              int64_t out_outer, int64_t out_line, T scale);
 
+// For both real transforms: with grp > 0 the complex-side column p is addressed as
+// (p / grp) * grp_stride + p % grp (the tile-major layout of csc_fused.h).
 // Real -> half-spectrum lines (forward).  Input element (o, i, p) at
 // in[o*in_outer + i*in_line + p] (units: reals), p in [0, P).  If in2 != null
 // the transformed signal is in - s2*in2 (fuses `YU = Y - U`,
@@ -40,7 +42,7 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
 template <typename T>
 void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
              int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
-             int64_t out_line);
+             int64_t out_line, int64_t grp = 0, int64_t grp_stride = 0);
 
 // Half-spectrum -> real lines (inverse, unnormalised times `scale`).  The
 // imaginary parts of the DC (and Nyquist, n even) bins are ignored, as
@@ -48,7 +50,7 @@ void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s
 template <typename T>
 void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64_t n_outer,
              int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer, int64_t out_line,
-             T scale);
+             T scale, int64_t grp = 0, int64_t grp_stride = 0);
 
 // out(H, W/2+1, P) = rfftn(in [- s2*in2], axes=(0,1)) for real in(H, W, P).
 template <typename T>

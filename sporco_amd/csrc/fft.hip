@@ -35,7 +35,15 @@ template <typename T> struct LineArgs {
     int radix[kMaxRadixPasses];
     int64_t ncols;
     int64_t in_outer, in_line, out_outer, out_line;
+    // Column groups on the complex side of a real transform (0 = plain): column p
+    // lives at (p / grp) * grp_stride + p % grp instead of p.  This is how the row
+    // transforms write / read the tile-major layout of csc_fused.h.
+    int64_t grp, grp_stride;
 };
+
+template <typename T> __device__ __forceinline__ int64_t col_off(const LineArgs<T> &a, int64_t p) {
+    return a.grp ? (p / a.grp) * a.grp_stride + p % a.grp : p;
+}
 
 // two adjacent complex values moved as one vector access
 template <typename T> struct alignas(2 * sizeof(cx<T>)) cx2 {
@@ -204,11 +212,12 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
             if (valid) {
                 if (PACK) {
                     const cx2<T> ab = *reinterpret_cast<const cx2<T> *>(
-                        static_cast<const cx<T> *>(a.in) + o * a.in_outer + f * a.in_line + 2 * c);
+                        static_cast<const cx<T> *>(a.in) + o * a.in_outer + f * a.in_line +
+                        col_off(a, 2 * c));
                     A = ab.a;
                     B = ab.b;
                 } else {
-                    A = (static_cast<const cx<T> *>(a.in) + o * a.in_outer + c)[f * a.in_line];
+                    A = (static_cast<const cx<T> *>(a.in) + o * a.in_outer + col_off(a, c))[f * a.in_line];
                 }
             }
             if (f == 0 || f == nyq) {
@@ -258,9 +267,9 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
                 ab.a = mk<T>(T(0.5) * (zf.re + zn.re), T(0.5) * (zf.im - zn.im));
                 ab.b = mk<T>(T(0.5) * (zf.im + zn.im), T(0.5) * (zn.re - zf.re));
                 *reinterpret_cast<cx2<T> *>(static_cast<cx<T> *>(a.out) + o * a.out_outer +
-                                            f * a.out_line + 2 * c) = ab;
+                                            f * a.out_line + col_off(a, 2 * c)) = ab;
             } else {
-                (static_cast<cx<T> *>(a.out) + o * a.out_outer + c)[f * a.out_line] = zf;
+                (static_cast<cx<T> *>(a.out) + o * a.out_outer + col_off(a, c))[f * a.out_line] = zf;
             }
         }
     } else {
@@ -395,8 +404,10 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
 template <typename T>
 void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
              int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
-             int64_t out_line) {
+             int64_t out_line, int64_t grp, int64_t grp_stride) {
     LineArgs<T> a{};
+    a.grp = grp;
+    a.grp_stride = grp_stride;
     a.in = in;
     a.in2 = in2;
     a.out = out;
@@ -406,7 +417,8 @@ void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s
     a.out_outer = out_outer;
     a.out_line = out_line;
     const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0) &&
-                      (out_outer % 2 == 0) && (out_line % 2 == 0);
+                      (out_outer % 2 == 0) && (out_line % 2 == 0) && (grp % 2 == 0) &&
+                      (grp_stride % 2 == 0);
     if (pack) {
         a.ncols = P / 2;
         a.in_outer = in_outer / 2;
@@ -423,8 +435,10 @@ void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s
 template <typename T>
 void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64_t n_outer,
              int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer, int64_t out_line,
-             T scale) {
+             T scale, int64_t grp, int64_t grp_stride) {
     LineArgs<T> a{};
+    a.grp = grp;
+    a.grp_stride = grp_stride;
     a.in = in;
     a.in2 = nullptr;
     a.out = out;
@@ -434,7 +448,8 @@ void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64
     a.in_outer = in_outer;
     a.in_line = in_line;
     const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0) &&
-                      (out_outer % 2 == 0) && (out_line % 2 == 0);
+                      (out_outer % 2 == 0) && (out_line % 2 == 0) && (grp % 2 == 0) &&
+                      (grp_stride % 2 == 0);
     if (pack) {
         a.ncols = P / 2;
         a.out_outer = out_outer / 2;
@@ -452,7 +467,7 @@ template <typename T>
 void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
            T s2, cx<T> *out, int H, int W, int64_t P) {
     const int64_t Wf = W / 2 + 1;
-    fft_r2c<T>(st, planW, in, in2, s2, out, H, P, (int64_t)W * P, P, Wf * P, P);
+    fft_r2c<T>(st, planW, in, in2, s2, out, H, P, (int64_t)W * P, P, Wf * P, P, 0, 0);
     // columns: (wf, p) is one contiguous run of Wf*P complex columns per row h
     fft_c2c<T>(st, planH, false, out, out, 1, Wf * P, 0, Wf * P, 0, Wf * P, T(1));
 }
@@ -463,16 +478,17 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
     const int64_t Wf = W / 2 + 1;
     fft_c2c<T>(st, planH, true, in, tmp, 1, Wf * P, 0, Wf * P, 0, Wf * P, T(1));
     fft_c2r<T>(st, planW, tmp, out, H, P, Wf * P, P, (int64_t)W * P, P,
-               T(1.0 / ((double)H * (double)W)));
+               T(1.0 / ((double)H * (double)W)), 0, 0);
 }
 
 #define SA_INSTANTIATE(T)                                                                        \
     template void fft_c2c<T>(hipStream_t, const FftPlan &, bool, const cx<T> *, cx<T> *, int64_t, \
                              int64_t, int64_t, int64_t, int64_t, int64_t, T);                    \
     template void fft_r2c<T>(hipStream_t, const FftPlan &, const T *, const T *, T, cx<T> *,     \
-                             int64_t, int64_t, int64_t, int64_t, int64_t, int64_t);              \
+                             int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,      \
+                             int64_t);                                                           \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
-                             int64_t, int64_t, int64_t, int64_t, T);                             \
+                             int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
     template void rfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const T *, const T *,  \
                            T, cx<T> *, int, int, int64_t);                                       \
     template void irfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const cx<T> *,        \
