@@ -483,6 +483,7 @@ template <typename T> struct Csc : CscBase {
             fa.CN = CN;
             fa.K = K;
             fa.partials = part_f;
+            fa.ablate = 0;
             int64_t ntiles;
             {
                 ProfScope ps(prof, PS_FUSED_COLS);

@@ -128,35 +128,31 @@ template <int N, bool INV, int TOT> __device__ __forceinline__ void dit(cf (&v)[
 
 // Sum r[i] over the 64 lanes of the wave for all 8 i at once ("transposing"
 // reduction: each of the first three exchanges halves the number of live
-// values); lane l returns the total of r[l >> 3].  10 shuffles instead of 48.
+// values); lane l returns the total of r[l >> 3].  Everything stays on the VALU:
+// permlane swaps across the 32- and 16-lane halves, DPP inside a 16-lane row
+// (row_mirror pairs l with l^15, row_half_mirror with l^7: any pairing that
+// flips the selecting bit works, and {15, 7, 2, 1} generate all 16 lanes).
 __device__ __forceinline__ float reduce8_across_lanes(const float (&r)[8], int lane) {
-    float a4[4], a2[2];
-    {
-        const bool up = lane & 32;
+    float a[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float keep = up ? r[i + 4] : r[i], send = up ? r[i] : r[i + 4];
-            a4[i] = keep + __shfl_xor(send, 32, kWave);
-        }
-    }
-    {
-        const bool up = lane & 16;
+    for (int i = 0; i < 8; ++i) a[i] = r[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float keep = up ? a4[i + 2] : a4[i], send = up ? a4[i] : a4[i + 2];
-            a2[i] = keep + __shfl_xor(send, 16, kWave);
-        }
+    for (int i = 0; i < 4; ++i) {
+        sa_swap32(a[i], a[i + 4]);
+        a[i] += a[i + 4];          // lanes < 32: sum of r[i]; lanes >= 32: sum of r[i + 4]
     }
-    float a1;
-    {
-        const bool up = lane & 8;
-        const float keep = up ? a2[1] : a2[0], send = up ? a2[0] : a2[1];
-        a1 = keep + __shfl_xor(send, 8, kWave);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        sa_swap16(a[i], a[i + 2]);
+        a[i] += a[i + 2];          // even rows: r[i] (or r[i+4]); odd rows: r[i+2] (or r[i+6])
     }
-    a1 += __shfl_xor(a1, 4, kWave);
-    a1 += __shfl_xor(a1, 2, kWave);
-    a1 += __shfl_xor(a1, 1, kWave);
-    return a1;
+    const bool up = lane & 8;
+    const float keep = up ? a[1] : a[0], send = up ? a[0] : a[1];
+    float t = keep + sa_lane_xor15(send);
+    t += sa_lane_xor7(t);
+    t += sa_lane_xor2(t);
+    t += sa_lane_xor1(t);
+    return t;
 }
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
@@ -240,14 +236,18 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 #pragma unroll
     for (int h1 = 0; h1 < N1; ++h1)
         v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
+    if (!(a.ablate & 8)) {
     dif<N1, false>(v, 0);
     reg_fence<N1>(v, 0, token);
 #pragma unroll
     for (int i = 1; i < N1; ++i) v[i] = cmul(v[i], twA[i]);
+    }
     reg_fence<N1>(v, 0, token);
 
     const float rho = a.rho;
     float obj = 0.f;
+    const int abl = a.ablate;
+    if (!(abl & 4))
     static_for<Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         // ---- exchange A: (w = h2; f1 in regs) -> (w = f1 mod NW; h2 in regs) ---------
@@ -259,6 +259,25 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
             t.y = x.im;
             LA[(fl * NW + w) * 64 + k] = t;
         }
+        // The Df values of chunk g+1 (4 frequencies) and the Sf / gram scalars of
+        // chunk g are requested one chunk ahead of their use; chunk 0's before the
+        // barrier, so that their latency hides behind the exchange and the FFT.
+        constexpr int CPL = NW / 4, NCH = LP * CPL;   // chunks per line, per group
+        cf dn[4];
+        cf sn[4];
+        float gn[4];
+        auto prefetch = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);  // f - w
+                dn[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                sa_uload2(reinterpret_cast<const float *>(S + fo), sn[e].re, sn[e].im);
+                gn[e] = sa_uload(G + fo);
+            }
+        };
+        prefetch(std::integral_constant<int, 0>{});
         __syncthreads();
         cf u[FP];   // u[NW*jl + h2] = A[h2][f1 = w + NW*(q*LP + jl)]
 #pragma unroll
@@ -269,43 +288,52 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 u[NW * jl + h2] = mk<float>(t.x, t.y);
             }
         }
-#pragma unroll
-        for (int jl = 0; jl < LP; ++jl) {
-            const int j = q * LP + jl;
+        if (!(abl & 2))
+        static_for<NCH>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL;
             // forward FFT over h2: u[NW jl + i] = X[f1 + N1 * brev(i)], f1 = w + NW j
-            dif<NW, false>(u, NW * jl);
-            // Sherman-Morrison solve, 4 frequencies at a time
+            if constexpr (c == 0) dif<NW, false>(u, NW * jl);
+            // Sherman-Morrison solve of 4 frequencies
+            cf d[4], sv[4];
+            float gv[4], red[8];
 #pragma unroll
-            for (int c = 0; c < NW / 4; ++c) {
-                cf d[4];
-                float red[8];
+            for (int e = 0; e < 4; ++e) {
+                d[e] = dn[e];
+                sv[e] = sn[e];
+                gv[e] = gn[e];
+            }
+            if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
+            if (!(abl & 1)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);  // f - w
-                    d[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
-                    const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
-                    red[2 * e] = p.re;
-                    red[2 * e + 1] = p.im;
-                }
-                const float tot = reduce8_across_lanes(red, k);
+            for (int e = 0; e < 4; ++e) {
+                const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                red[2 * e] = p.re;
+                red[2 * e + 1] = p.im;
+            }
+            const float tot = reduce8_across_lanes(red, k);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                    const cf qq = mk<float>(sa_readlane(tot, 16 * e), sa_readlane(tot, 16 * e + 8));
-                    const cf sv = S[fo];
-                    const float inv = sa_rcp(G[fo] + rho);
-                    const cf coef = cscale(sv - qq, inv);
-                    // Df.xf - Sf = rho (q - Sf) / (gram + rho)
-                    obj += cabs2(coef);
-                    u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const cf qq = mk<float>(sa_readlane(tot, 16 * e), sa_readlane(tot, 16 * e + 8));
+                const float inv = sa_rcp(gv[e] + rho);
+                const cf coef = cscale(sv[e] - qq, inv);
+                // Df.xf - Sf = rho (q - Sf) / (gram + rho)
+                obj += cabs2(coef);
+                u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
+            }
             }
             // inverse FFT over f2, conj twiddle
-            dit<NW, true>(u, NW * jl);
+            if constexpr (c == CPL - 1) {
+                constexpr int j = q * LP + jl;
+                dit<NW, true>(u, NW * jl);
 #pragma unroll
-            for (int h2 = 1; h2 < NW; ++h2)
-                u[NW * jl + h2] = cmulc(twB[NW * j + h2], u[NW * jl + h2]);
-        }
+                for (int h2 = 1; h2 < NW; ++h2) {
+                    cf tw;
+                    sa_uload2(reinterpret_cast<const float *>(twB + NW * j + h2), tw.re, tw.im);
+                    u[NW * jl + h2] = cmulc(tw, u[NW * jl + h2]);
+                }
+            }
+        });
         SA_VGPR_FENCE3(obj, token, token);
         // ---- exchange B: back to (w = h2; f1 in regs), placed in DIT input order -----
 #pragma unroll
@@ -328,7 +356,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     reg_fence<N1>(v, 0, token);
 
     // ---- inverse FFT over f1, store the rows this wave loaded ------------------------
-    dit<N1, true>(v, 0);
+    if (!(abl & 8)) dit<N1, true>(v, 0);
     if (kv) {
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1)
@@ -432,10 +460,16 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
         launch_fused_inst<N1, NW, LP, 0>(st, a, ntiles);
 }
 
-template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs<float> &a) {
-    SA_REQUIRE(fused_cols_supported<float>(a.H, a.K), "shape not handled by the fused column kernel");
-    const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
-    const FusedSplit sp = fused_split(a.H, a.K);
+template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs<float> &a_in) {
+    SA_REQUIRE(fused_cols_supported<float>(a_in.H, a_in.K), "shape not handled by the fused column kernel");
+    const int64_t ntiles = (int64_t)(a_in.W / 2 + 1) * a_in.CN;
+    const FusedSplit sp = fused_split(a_in.H, a_in.K);
+    static const int ablate = [] {
+        const char *e = std::getenv("SPORCO_AMD_FUSED_ABLATE");
+        return e ? std::atoi(e) : 0;
+    }();
+    FusedColsArgs<float> a = a_in;
+    a.ablate = ablate;
     if (sp.N1 == 32 && sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);
     else if (sp.N1 == 32 && sp.NW == 16)

@@ -40,6 +40,50 @@ __device__ __forceinline__ void sa_buf_store2(SaBuf r, int voff, int soff, float
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sa_b64, t), r, voff, soff, 0);
 }
 
+// Wave-uniform loads of read-only data through the scalar cache (s_load_dword[x2]):
+// the pointer is re-typed to the constant address space, which is what lets the
+// compiler keep them scalar after barriers/fences (a plain global load of a uniform
+// address turns into a vector load as soon as anything before it may write memory).
+__device__ __forceinline__ float sa_uload(const float *p) {
+    return *(const float __attribute__((address_space(4))) *)p;
+}
+__device__ __forceinline__ void sa_uload2(const float *p, float &a, float &b) {
+    const sa_floatx2 t = *(const sa_floatx2 __attribute__((address_space(4))) *)p;
+    a = t.x;
+    b = t.y;
+}
+
+// Cross-lane moves on the VALU (no LDS traffic, unlike ds_bpermute).
+//   sa_swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b      (v_permlane32_swap)
+//   sa_swap16(a, b): odd 16-lane rows of a <-> even rows of b     (v_permlane16_swap)
+// (element access through named unsigned temporaries: subscripting the builtin's
+// result directly as `const auto r; r[1]` is folded to r[0] by this clang)
+typedef unsigned sa_uintx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sa_swap32(float &a, float &b) {
+    sa_uintx2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a),
+                                                   __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned x = r.x, y = r.y;
+    a = __builtin_bit_cast(float, x);
+    b = __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ void sa_swap16(float &a, float &b) {
+    sa_uintx2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a),
+                                                   __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned x = r.x, y = r.y;
+    a = __builtin_bit_cast(float, x);
+    b = __builtin_bit_cast(float, y);
+}
+// DPP reads: the value of `v` in lane l^1 / l^2 (quad_perm), l^7 (row_half_mirror),
+// l^15 (row_mirror).
+template <int CTRL> __device__ __forceinline__ float sa_dpp(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sa_lane_xor1(float v) { return sa_dpp<0xB1>(v); }
+__device__ __forceinline__ float sa_lane_xor2(float v) { return sa_dpp<0x4E>(v); }
+__device__ __forceinline__ float sa_lane_xor7(float v) { return sa_dpp<0x141>(v); }
+__device__ __forceinline__ float sa_lane_xor15(float v) { return sa_dpp<0x140>(v); }
+
 // Empty volatile asm that ties three values to vector registers at this point of
 // the instruction stream (see reg_fence in csc_fused.hip): no instruction is
 // emitted, it only orders the scheduler.

@@ -56,6 +56,47 @@ inline void sa_buf_store2(SaBuf r, int voff, int soff, float a, float b) {
     }
 }
 
+inline float sa_uload(const float *p) { return *p; }
+inline void sa_uload2(const float *p, float &a, float &b) {
+    a = p[0];
+    b = p[1];
+}
+
+// value of `v` held by lane `src` of the calling thread's wave (src may differ per lane)
+inline float hostsim_gather(float v, int src) {
+    const int tid = (int)threadIdx.x;
+    const int base = tid - (tid & 63);
+    std::memcpy(hostsim::shuffle_slot(tid), &v, sizeof(float));
+    hostsim::wave_sync();
+    float r;
+    std::memcpy(&r, hostsim::shuffle_slot(base + src), sizeof(float));
+    hostsim::wave_sync();
+    return r;
+}
+inline void sa_swap32(float &a, float &b) {
+    const int lane = (int)threadIdx.x & 63;
+    const float b_lo = hostsim_gather(b, lane & 31);         // b[lane - 32] for the upper half
+    const float a_hi = hostsim_gather(a, (lane & 31) + 32);  // a[lane + 32] for the lower half
+    if (lane < 32)
+        b = a_hi;
+    else
+        a = b_lo;
+}
+inline void sa_swap16(float &a, float &b) {
+    const int lane = (int)threadIdx.x & 63;
+    const bool odd_row = (lane >> 4) & 1;
+    const float b_even = hostsim_gather(b, lane & ~16);  // b[lane - 16] for odd rows
+    const float a_odd = hostsim_gather(a, lane | 16);    // a[lane + 16] for even rows
+    if (odd_row)
+        a = b_even;
+    else
+        b = a_odd;
+}
+inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }
+inline float sa_lane_xor2(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 2); }
+inline float sa_lane_xor7(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 7); }
+inline float sa_lane_xor15(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 15); }
+
 #define SA_VGPR_FENCE3(a, b, c) ((void)0)
 
 }  // namespace sporco_amd
