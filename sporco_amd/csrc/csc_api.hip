@@ -13,6 +13,7 @@
 #include "common.h"
 #include "csc_fused.h"
 #include "csc_kernels.h"
+#include "csc_rows.h"
 #include "fft.h"
 
 namespace sporco_amd {
@@ -27,6 +28,8 @@ enum ProfSlot {
     PS_FFT_C2R,
     PS_ADMM_POST,
     PS_FUSED_COLS,
+    PS_ROWS_FWD,
+    PS_ROWS_INV_POST,
     PS_FINALIZE,
     PS_PGM,
     PS_OTHER,
@@ -34,8 +37,8 @@ enum ProfSlot {
 };
 static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_solve",
                                            "fft_c2c_cols_inv", "fft_c2r_rows",     "admm_post",
-                                           "fused_cols_sm",    "finalize",         "pgm_elementwise",
-                                           "other"};
+                                           "fused_cols_sm",    "rows_fwd",         "rows_inv_post",
+                                           "finalize",         "pgm_elementwise",  "other"};
 
 struct Profiler {
     bool on = false;
@@ -206,6 +209,10 @@ template <typename T> struct Csc : CscBase {
     cx<T> *dft = nullptr, *sft = nullptr, *twA = nullptr, *twB = nullptr;
     T *gramt = nullptr;
     double *part_f = nullptr;
+    // fused row passes (csc_rows.h)
+    bool rows_ok = false;
+    cx<T> *twRows = nullptr;
+    double *part_rows = nullptr;
 
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
@@ -253,6 +260,14 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
             SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
         }
+        rows_ok = fused && rows_supported<T>(W, K) && !std::getenv("SPORCO_AMD_OLD_ROWS");
+        if (rows_ok) {
+            SA_HIP(hipMalloc((void **)&twRows, sizeof(cx<T>) * W));
+            std::vector<cx<T>> ta(W);
+            rows_twiddles<T>(W, ta.data());
+            SA_HIP(hipMemcpy(twRows, ta.data(), sizeof(cx<T>) * W, hipMemcpyHostToDevice));
+            SA_HIP(hipMalloc((void **)&part_rows, sizeof(double) * 8 * (int64_t)H * ceil_div(P, 128)));
+        }
         // the three ADMM state arrays start at zero (yinit/uinit, admm.py:279-289)
         for (int v : {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U, SPORCO_AMD_VAR_X}) (void)var_ptr(v);
     }
@@ -263,6 +278,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
+                        (void *)twRows, (void *)part_rows,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -455,6 +471,91 @@ template <typename T> struct Csc : CscBase {
             throw Error(SPORCO_AMD_ESTATE, "set_signal and set_dict must be called first");
     }
 
+    // column FFT + Sherman-Morrison + column IFFT on the tile-major spectrum in the
+    // Xf buffer (csc_fused.h); the data-fidelity sum goes to out_dev when wanted
+    void run_fused_cols(const sporco_amd_admm_params &p, double *out_dev) {
+        FusedColsArgs<T> fa;
+        fa.t = cv(SPORCO_AMD_VAR_XF);
+        fa.dft = dft;
+        fa.sft = sft;
+        fa.gramt = gramt;
+        fa.twA = twA;
+        fa.twB = twB;
+        fa.rho = (T)p.rho;
+        fa.H = H;
+        fa.W = W;
+        fa.CN = CN;
+        fa.K = K;
+        fa.partials = part_f;
+        fa.ablate = 0;
+        int64_t ntiles;
+        {
+            ProfScope ps(prof, PS_FUSED_COLS);
+            ntiles = launch_fused_cols<T>(st, fa);
+        }
+        xf_tiled = true;
+        if ((p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
+            const int slots[1] = {SPORCO_AMD_OUT_DFID};
+            const double scales[1] = {1.0 / ((double)H * W)};
+            finalize(part_f, (int)ntiles, 1, 1, slots, scales, out_dev);
+        }
+    }
+
+    // One whole ADMM iteration in three launches (csc_rows.h): rows_fwd, fused_cols,
+    // rows_inv_post.  X is written only on request (F_KEEP_X).
+    void admm_iter_fused(const sporco_amd_admm_params &p, double *out_dev) {
+        require_ready();
+        T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U);
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
+        RowsFwdArgs<T> ra;
+        ra.y = Y;
+        ra.u = U;
+        ra.s2 = (T)p.u_scale;
+        ra.t = Xf;
+        ra.twA = twRows;
+        ra.H = H;
+        ra.W = W;
+        ra.CN = CN;
+        ra.K = K;
+        ra.P = P;
+        {
+            ProfScope ps(prof, PS_ROWS_FWD);
+            launch_rows_fwd<T>(st, ra);
+        }
+        run_fused_cols(p, out_dev);
+        RowsPostArgs<T> pa;
+        pa.t = Xf;
+        pa.twW = planW.tw<T>();
+        pa.y = Y;
+        pa.u = U;
+        pa.x = rv(SPORCO_AMD_VAR_X);
+        pa.scale = T(1.0 / ((double)H * (double)W));
+        pa.rlx = (T)p.rlx;
+        pa.thr = (T)(p.lmbda / p.rho);
+        pa.u_scale = (T)p.u_scale;
+        pa.flags = p.flags;
+        pa.H = H;
+        pa.W = W;
+        pa.C = C;
+        pa.N = N;
+        pa.K = K;
+        pa.dH = p.dH;
+        pa.dW = p.dW;
+        pa.P = P;
+        pa.wl1 = wl1;
+        pa.partials = part_rows;
+        int64_t nt;
+        {
+            ProfScope ps(prof, PS_ROWS_INV_POST);
+            nt = launch_rows_inv_post<T>(st, pa);
+        }
+        const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                              SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
+        const double scales[6] = {1, 1, 1, 1, 1, 1};
+        finalize(part_rows, (int)nt, 8, 6, slots, scales, out_dev);
+        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+    }
+
     // ---- ADMM --------------------------------------------------------------------
     // X-step: Xf = SM(rfftn(Y - s U)), X = irfftn(Xf); objective / check sums -> out_dev
     void xstep_impl(const sporco_amd_admm_params &p, double *out_dev) {
@@ -470,31 +571,7 @@ template <typename T> struct Csc : CscBase {
                 fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, Xf, H, P, (int64_t)W * P, P, K, tline, K,
                            tgrp);
             }
-            FusedColsArgs<T> fa;
-            fa.t = Xf;
-            fa.dft = dft;
-            fa.sft = sft;
-            fa.gramt = gramt;
-            fa.twA = twA;
-            fa.twB = twB;
-            fa.rho = (T)p.rho;
-            fa.H = H;
-            fa.W = W;
-            fa.CN = CN;
-            fa.K = K;
-            fa.partials = part_f;
-            fa.ablate = 0;
-            int64_t ntiles;
-            {
-                ProfScope ps(prof, PS_FUSED_COLS);
-                ntiles = launch_fused_cols<T>(st, fa);
-            }
-            xf_tiled = true;
-            if ((p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
-                const int slots[1] = {SPORCO_AMD_OUT_DFID};
-                const double scales[1] = {1.0 / ((double)H * W)};
-                finalize(part_f, (int)ntiles, 1, 1, slots, scales, out_dev);
-            }
+            run_fused_cols(p, out_dev);
             {
                 ProfScope ps(prof, PS_FFT_C2R);
                 fft_c2r<T>(st, planW, Xf, X, H, P, K, tline, (int64_t)W * P, P,
@@ -541,6 +618,10 @@ template <typename T> struct Csc : CscBase {
 
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT))) {
+            admm_iter_fused(p, out_dev);
+            return;
+        }
         xstep_impl(p, out_dev);
         PostParams<T> pp;
         pp.x = rv(SPORCO_AMD_VAR_X);

@@ -1,0 +1,58 @@
+// csc_rows.h -- the row (W axis) passes of the fused ADMM iteration.
+//
+// Together with the column kernel of csc_fused.h they bring one iteration of
+// sporco/admm/admm.py:331-367 for ConvBPDN down to three launches and the
+// algorithmic ten float32 passes of SURVEY.md 8(d):
+//
+//   rows_fwd       Y, U                 -> T   rfft along W of Y - s U     (3 passes)
+//   fused_cols     T                    -> T   csc_fused.h                 (2 passes)
+//   rows_inv_post  T, Y, U [, X]        -> Y, U [, X] + reduction partials (5 passes)
+//
+// rows_inv_post fuses irfft along W (the second half of irfftn in
+// GenericConvBPDN.xstep, cbpdn.py:281) with relax_AX (admm.py:877-885), the
+// l1 shrinkage ystep (cbpdn.py:614-620, :297-311), ustep (admm.py:434-437) and
+// the sums of compute_residuals / obfn_reg (admm.py:462-486, cbpdn.py:624-630),
+// so X exists only in registers unless the caller asks for it.
+//
+// Both kernels are register-resident real FFTs of two adjacent filters packed
+// into one complex line (lane = filter pair); T is the tile-major half spectrum
+// T[wf][cn][h][k] of csc_fused.h.
+#pragma once
+
+#include "common.h"
+#include "csc_kernels.h"
+
+namespace sporco_amd {
+
+template <typename T> struct RowsFwdArgs {
+    const T *y, *u;    // real (H, W, P)
+    T s2;              // transform Y - s2 * U
+    cx<T> *t;          // out: tile-major (Wf, CN, H, K)
+    const cx<T> *twA;  // [NW][32]: exp(-2 pi i w brev5(i) / W)   (rows_twiddles)
+    int H, W, CN, K;
+    int64_t P;
+};
+
+template <typename T> struct RowsPostArgs {
+    const cx<T> *t;    // in: tile-major column-inverse-transformed solution, unnormalised
+    const cx<T> *twW;  // exp(-2 pi i t / W), t in [0, W)
+    T *y, *u;          // in/out real (H, W, P)
+    T *x;              // out (optional, may be null): X = irfftn(Xf)
+    T scale;           // 1 / (H W)
+    T rlx, thr, u_scale;
+    uint32_t flags;    // F_NONNEG | F_NOBNDRY | F_GEVAL_Y
+    int H, W, C, N, K, dH, dW;
+    int64_t P;
+    Weight<T> wl1;
+    double *partials;  // per tile 8 doubles: r2, s2, ax2, y2, u2, l1, 0, 0
+};
+
+// Shapes the register-resident row kernels handle (float32, W in {256, 512}, K even).
+template <typename T> bool rows_supported(int W, int K);
+// Host table for RowsFwdArgs::twA ((W/32) * 32 entries).
+template <typename T> void rows_twiddles(int W, cx<T> *twA);
+template <typename T> void launch_rows_fwd(hipStream_t st, const RowsFwdArgs<T> &a);
+// Returns the number of tiles (= rows of `partials` written).
+template <typename T> int64_t launch_rows_inv_post(hipStream_t st, const RowsPostArgs<T> &a);
+
+}  // namespace sporco_amd

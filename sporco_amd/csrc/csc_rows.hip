@@ -1,0 +1,441 @@
+// csc_rows.hip -- register-resident row transforms of the fused ADMM iteration
+// (see csc_rows.h for what they fuse and the reference lines they replace).
+//
+// Layout of the work.  A workgroup of NW waves owns one image row h and 128
+// consecutive columns p = (c, n, k) of it: lane l holds the filter pair
+// (p, p+1) = 128*tile + 2l packed into one complex line z = x_p + i x_{p+1}, so
+// every access to Y / U / X is a 512-byte row of float2 and every access to the
+// tile-major spectrum T[wf][cn][h][k] is 16 bytes per lane.  The length-W
+// transform is split W = 32 x NW as in csc_fused.hip:
+//   spatial side   wave w holds the pixels x = NW*n1 + w, n1 = 0..31;
+//   spectral side  wave w holds whole lines k1 of the intermediate
+//                  C[k1][n2] (k1 = 0..31: index of the 32-point transform,
+//                  n2 = 0..NW-1), namely the lines {w, 32-w} (and {16-w, 16+w}
+//                  when NW = 8).  Those sets are closed under k1 -> -k1, which
+//                  is what makes the real-transform "untangling"
+//                      A[f] = (Z[f] + conj Z[W-f]) / 2,  B[f] = (Z[f] - conj Z[W-f]) / 2i
+//                  (and its inverse) a purely per-thread operation: the bins f
+//                  and W-f always live in the same thread.  Wave 0 owns the
+//                  self-paired lines 0 and 16 (plus 8, 24 for NW = 8).
+// One LDS exchange (128 KiB, two halves when W = 512) moves the data between
+// the two sides; nothing else touches LDS.
+#include "csc_rows.h"
+
+#include <cmath>
+#include <cstdlib>
+
+#include "regfft.h"
+
+namespace sporco_amd {
+
+namespace {
+
+using namespace regfft;
+
+struct alignas(16) cf2 {
+    cf a, b;
+};
+
+constexpr int kN1 = 32;
+constexpr size_t kRowsLds = sizeof(f2) * 16384 + sizeof(double) * 8 * 16;
+
+// line k1 held in slot j of spectral-side wave w (see the file header)
+__device__ __forceinline__ int line_of(int w, int j) {
+    if (j == 0) return w;
+    if (j == 1) return w == 0 ? 16 : 32 - w;
+    if (j == 2) return w == 0 ? 8 : 16 - w;
+    return w == 0 ? 24 : 16 + w;
+}
+
+__device__ __forceinline__ float soft1(float v, float thr) {
+    // sign(v) * max(|v| - thr, 0)            (prox/_lp.py:181)
+    float m = fabsf(v) - thr;
+    m = m > 0.f ? m : 0.f;
+    return v < 0.f ? -m : m;
+}
+
+// ---------------------------------------------------------------------------
+// rows_fwd: T = rfft_W(Y - s2 U), tile-major
+// ---------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a) {
+    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
+    constexpr int NG = (NW == 16) ? 2 : 1;   // exchange halves
+    constexpr int LPG = J / NG, KPG = N1 / NG;
+    constexpr int LBW = ilog2(NW);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const bool pv = p < a.P;
+    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
+    f2 *L = dyn_lds<f2>();
+    int token = 0;
+
+    // ---- spatial side: z[n1] = (Y - s2 U)(h, x = NW n1 + w, p..p+1) -------------------
+    const int64_t rowoff = (int64_t)h * W * a.P;
+    const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
+    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes), Ub = make_rsrc(a.u + rowoff, rowbytes);
+    const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;  // masked lanes read 0
+    const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
+    const float s2 = a.s2;
+    cf v[N1];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        cf yv[N1 / 2], uv[N1 / 2];
+#pragma unroll
+        for (int i = 0; i < N1 / 2; ++i) {
+            const int n1 = half * (N1 / 2) + i;
+            const int soff = (NW * n1 + w) * pixbytes;
+            yv[i] = buf_load_cf(Yb, voff, soff);
+            uv[i] = buf_load_cf(Ub, voff, soff);
+        }
+#pragma unroll
+        for (int i = 0; i < N1 / 2; ++i)
+            v[half * (N1 / 2) + i] = mk<float>(yv[i].re - s2 * uv[i].re, yv[i].im - s2 * uv[i].im);
+        reg_fence<N1 / 2>(v, half * (N1 / 2), token);
+    }
+    dif<N1, false>(v, 0);
+#pragma unroll
+    for (int i = 1; i < N1; ++i) {
+        cf tw;
+        sa_uload2(reinterpret_cast<const float *>(a.twA + w * N1 + i), tw.re, tw.im);
+        v[i] = cmul(v[i], tw);
+    }
+    reg_fence<N1>(v, 0, token);
+
+    // ---- exchange to the spectral side: z[NW j + n2] = C[line_of(w, j)][n2] ------------
+    cf z[N1];
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int kk = 0; kk < KPG; ++kk) {
+            const cf x = v[brev(g * KPG + kk, 5)];   // C[k1 = g KPG + kk][n2 = w]
+            f2 t;
+            t.x = x.re;
+            t.y = x.im;
+            L[(kk * NW + w) * 64 + lane] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jl = 0; jl < LPG; ++jl) {
+            const int j = g * LPG + jl;
+            const int kl = line_of(w, j) & (KPG - 1);
+#pragma unroll
+            for (int n2 = 0; n2 < NW; ++n2) {
+                const f2 t = L[(kl * NW + n2) * 64 + lane];
+                z[NW * j + n2] = mk<float>(t.x, t.y);
+            }
+        }
+        if (g + 1 < NG) __syncthreads();
+    });
+
+    // ---- transform over n2: z[NW j + i] = Z[k1 + 32 brev(i)] -----------------------------
+#pragma unroll
+    for (int j = 0; j < J; ++j) dif<NW, false>(z, NW * j);
+
+    // ---- untangle the two real spectra and store the bins f <= W/2 ------------------------
+    const int64_t tline = (int64_t)a.CN * a.H * a.K;
+    cf *Tl = a.t + (int64_t)cn * a.H * a.K + (int64_t)h * a.K + k;
+    auto store_unit = [&](int f, cf zf, cf zp) {
+        // A = (Zf + conj Zp) / 2,  B = (Zf - conj Zp) / (2i)
+        cf2 ab;
+        ab.a = mk<float>(0.5f * (zf.re + zp.re), 0.5f * (zf.im - zp.im));
+        ab.b = mk<float>(0.5f * (zf.im + zp.im), 0.5f * (zp.re - zf.re));
+        if (pv) *reinterpret_cast<cf2 *>(Tl + (int64_t)f * tline) = ab;
+    };
+#pragma unroll
+    for (int pr = 0; pr < J / 2; ++pr) {
+        const int ja = 2 * pr, jb = 2 * pr + 1;
+        const int k1a = line_of(w, ja), k1b = line_of(w, jb);
+        if (pr == 0 && w == 0) {
+            // self-paired lines 0 and 16: f and W - f sit in the same line
+#pragma unroll
+            for (int k2 = 0; k2 <= NW / 2; ++k2) {
+                const cf zf = z[NW * ja + brev(k2 % NW, LBW)];
+                const cf zp = z[NW * ja + brev((NW - k2) % NW, LBW)];
+                store_unit(N1 * k2, zf, zp);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < NW / 2; ++k2) {
+                const cf zf = z[NW * jb + brev(k2, LBW)];
+                const cf zp = z[NW * jb + brev(NW - 1 - k2, LBW)];
+                store_unit(N1 / 2 + N1 * k2, zf, zp);
+            }
+        } else {
+            // W - (k1a + 32 k2) = k1b + 32 (NW - 1 - k2)
+#pragma unroll
+            for (int k2 = 0; k2 < NW / 2; ++k2) {
+                store_unit(k1a + N1 * k2, z[NW * ja + brev(k2, LBW)],
+                           z[NW * jb + brev(NW - 1 - k2, LBW)]);
+                store_unit(k1b + N1 * k2, z[NW * jb + brev(k2, LBW)],
+                           z[NW * ja + brev(NW - 1 - k2, LBW)]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// rows_inv_post: X = irfft_W(T) / (H W); relax, shrink, dual update, sums
+// ---------------------------------------------------------------------------
+template <int NW, bool WRITE_X, bool GENERAL>
+__global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
+    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
+    constexpr int NG = (NW == 16) ? 2 : 1;
+    constexpr int LPG = J / NG, KPG = N1 / NG;
+    constexpr int LBW = ilog2(NW);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const bool pv = p < a.P;
+    const int CN = a.C * a.N;
+    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + 16384);
+    const cf zero = mk<float>(0.f, 0.f);
+    int token = 0;
+
+    // ---- spectral side: load the bins f <= W/2 of this thread's lines, rebuild Z -------
+    const int64_t tline = (int64_t)CN * a.H * a.K;
+    const cf *Tl = a.t + (int64_t)cn * a.H * a.K + (int64_t)h * a.K + k;
+    auto load_unit = [&](int f) {
+        cf2 ab;
+        ab.a = zero;
+        ab.b = zero;
+        if (pv) ab = *reinterpret_cast<const cf2 *>(Tl + (int64_t)f * tline);
+        return ab;
+    };
+    cf z[N1];   // z[NW j + i] = Z[line_of(w, j) + 32 brev(i)]
+#pragma unroll
+    for (int pr = 0; pr < J / 2; ++pr) {
+        const int ja = 2 * pr, jb = 2 * pr + 1;
+        const int k1a = line_of(w, ja), k1b = line_of(w, jb);
+        if (pr == 0 && w == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 <= NW / 2; ++k2) {
+                const cf2 ab = load_unit(N1 * k2);
+                if (k2 == 0 || k2 == NW / 2) {
+                    // DC / Nyquist: imaginary parts ignored, as numpy.fft.irfft does
+                    z[NW * ja + brev(k2, LBW)] = mk<float>(ab.a.re, ab.b.re);
+                } else {
+                    z[NW * ja + brev(k2, LBW)] = mk<float>(ab.a.re - ab.b.im, ab.a.im + ab.b.re);
+                    z[NW * ja + brev(NW - k2, LBW)] = mk<float>(ab.a.re + ab.b.im, ab.b.re - ab.a.im);
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < NW / 2; ++k2) {
+                const cf2 ab = load_unit(N1 / 2 + N1 * k2);
+                z[NW * jb + brev(k2, LBW)] = mk<float>(ab.a.re - ab.b.im, ab.a.im + ab.b.re);
+                z[NW * jb + brev(NW - 1 - k2, LBW)] = mk<float>(ab.a.re + ab.b.im, ab.b.re - ab.a.im);
+            }
+        } else {
+#pragma unroll
+            for (int k2 = 0; k2 < NW / 2; ++k2) {
+                const cf2 ua = load_unit(k1a + N1 * k2);
+                z[NW * ja + brev(k2, LBW)] = mk<float>(ua.a.re - ua.b.im, ua.a.im + ua.b.re);
+                z[NW * jb + brev(NW - 1 - k2, LBW)] = mk<float>(ua.a.re + ua.b.im, ua.b.re - ua.a.im);
+                const cf2 ub = load_unit(k1b + N1 * k2);
+                z[NW * jb + brev(k2, LBW)] = mk<float>(ub.a.re - ub.b.im, ub.a.im + ub.b.re);
+                z[NW * ja + brev(NW - 1 - k2, LBW)] = mk<float>(ub.a.re + ub.b.im, ub.b.re - ub.a.im);
+            }
+        }
+    }
+    reg_fence<N1>(z, 0, token);
+
+    // ---- inverse transform over k2, conj twiddle, exchange to the spatial side --------------
+    cf v[N1];
+    static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int jl = 0; jl < LPG; ++jl) {
+            const int j = g * LPG + jl;
+            const int k1 = line_of(w, j);
+            const int kl = k1 & (KPG - 1);
+            dit<NW, true>(z, NW * j);
+#pragma unroll
+            for (int n2 = 0; n2 < NW; ++n2) {
+                cf x = z[NW * j + n2];
+                if (n2 > 0) {
+                    cf tw;
+                    sa_uload2(reinterpret_cast<const float *>(a.twW + ((n2 * k1) & (W - 1))), tw.re,
+                              tw.im);
+                    x = cmulc(tw, x);
+                }
+                f2 t;
+                t.x = x.re;
+                t.y = x.im;
+                L[(kl * NW + n2) * 64 + lane] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < KPG; ++kk) {
+            const f2 t = L[(kk * NW + w) * 64 + lane];
+            v[brev(g * KPG + kk, 5)] = mk<float>(t.x, t.y);
+        }
+        if (g + 1 < NG) __syncthreads();
+    });
+    reg_fence<N1>(v, 0, token);
+    dit<N1, true>(v, 0);   // v[n1] = (X_p, X_{p+1}) at x = NW n1 + w, unnormalised
+
+    // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
+    const int64_t rowoff = (int64_t)h * W * a.P;
+    const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
+    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes), Ub = make_rsrc(a.u + rowoff, rowbytes);
+    const BufRsrc Xb = make_rsrc(WRITE_X ? a.x + rowoff : a.y + rowoff, rowbytes);
+    const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;
+    const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
+    const float al = a.rlx, oma = 1.f - a.rlx, usc = a.u_scale, scale = a.scale;
+    const bool nonneg = a.flags & F_NONNEG, nob = a.flags & F_NOBNDRY, gy = a.flags & F_GEVAL_Y;
+    int64_t wbase = 0;
+    if (GENERAL && a.wl1.ptr) {
+        const int c = cn / a.N, n = cn % a.N;
+        wbase = h * a.wl1.stride[0] + c * a.wl1.stride[2] + n * a.wl1.stride[3] + k * a.wl1.stride[4];
+    }
+    const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
+    const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
+    float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f;
+    constexpr int B = 4;   // pixels per batch (Y, U of the next batch are in flight)
+    cf yb[2][B], ub[2][B];
+    auto fetch = [&](int slot, int b) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int soff = (NW * (b * B + i) + w) * pixbytes;
+            yb[slot][i] = buf_load_cf(Yb, voff, soff);
+            ub[slot][i] = buf_load_cf(Ub, voff, soff);
+        }
+    };
+    fetch(0, 0);
+    static_for<N1 / B>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if constexpr (b + 1 < N1 / B) fetch((b + 1) & 1, b + 1);
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const int n1 = b * B + i;
+            const int xw = NW * n1 + w;
+            const int soff = xw * pixbytes;
+            const float xs[2] = {v[n1].re * scale, v[n1].im * scale};
+            const float yo[2] = {yb[b & 1][i].re, yb[b & 1][i].im};
+            const float uo[2] = {usc * ub[b & 1][i].re, usc * ub[b & 1][i].im};
+            float yn[2], un[2];
+            const bool kill = GENERAL && (hkill || (nob && xw >= x0kill));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float ax = al * xs[e] + oma * yo[e];
+                float wt = 1.f;
+                if (GENERAL && a.wl1.ptr)
+                    wt = a.wl1.ptr[wbase + xw * a.wl1.stride[1] + e * a.wl1.stride[4]];
+                float y1 = soft1(ax + uo[e], a.thr * wt);
+                if (nonneg && y1 < 0.f) y1 = 0.f;
+                if (kill) y1 = 0.f;
+                const float u1 = uo[e] + ax - y1;
+                yn[e] = y1;
+                un[e] = u1;
+                const float dr = xs[e] - y1, ds = y1 - yo[e];
+                s_r2 += dr * dr;
+                s_s2 += ds * ds;
+                s_x2 += xs[e] * xs[e];
+                s_y2 += y1 * y1;
+                s_u2 += u1 * u1;
+                s_l1 += fabsf(wt * (gy ? y1 : xs[e]));
+            }
+            buf_store_cf(Yb, voff, soff, mk<float>(yn[0], yn[1]));
+            buf_store_cf(Ub, voff, soff, mk<float>(un[0], un[1]));
+            if (WRITE_X) buf_store_cf(Xb, voff, soff, mk<float>(xs[0], xs[1]));
+        }
+    });
+
+    // masked lanes contributed zeros everywhere except possibly the threshold of 0: their
+    // inputs are all zero, so every term above is exactly 0
+    double acc[8] = {(double)s_r2, (double)s_s2, (double)s_x2, (double)s_y2,
+                     (double)s_u2, (double)s_l1, 0.0,          0.0};
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    block_sum_store<8>(acc, scratch, a.partials + tile * 8);
+}
+
+template <int NW, typename K>
+void set_lds_attr(K kernel) {
+    SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLds));
+}
+
+}  // namespace
+
+template <> bool rows_supported<float>(int W, int K) {
+    return (W == 256 || W == 512) && K >= 2 && K % 2 == 0;
+}
+template <> bool rows_supported<double>(int, int) { return false; }
+
+template <typename T> void rows_twiddles(int W, cx<T> *twA) {
+    const int NW = W / kN1;
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int w = 0; w < NW; ++w)
+        for (int i = 0; i < kN1; ++i) {
+            const double ang = -two_pi * (double)(w * regfft::brev(i, 5)) / (double)W;
+            twA[w * kN1 + i] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
+        }
+}
+template void rows_twiddles<float>(int, cx<float> *);
+template void rows_twiddles<double>(int, cx<double> *);
+
+template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float> &a) {
+    SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
+    SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds_attr<8>(&rows_fwd_kernel<8>);
+        set_lds_attr<16>(&rows_fwd_kernel<16>);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
+    if (a.W == 256)
+        hipLaunchKernelGGL((rows_fwd_kernel<8>), grid, dim3(8 * 64), kRowsLds, st, a);
+    else
+        hipLaunchKernelGGL((rows_fwd_kernel<16>), grid, dim3(16 * 64), kRowsLds, st, a);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_rows_fwd<double>(hipStream_t, const RowsFwdArgs<double> &) {
+    throw Error(-1, "the fused row kernels are float32 only");
+}
+
+template <int NW>
+static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, false>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, false>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, true>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, true>);
+        attr_set = true;
+    }
+    const bool general = a.wl1.ptr != nullptr || (a.flags & F_NOBNDRY);
+    const dim3 block(NW * 64);
+    if (a.x && general)
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true>), grid, block, kRowsLds, st, a);
+    else if (a.x)
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, false>), grid, block, kRowsLds, st, a);
+    else if (general)
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, true>), grid, block, kRowsLds, st, a);
+    else
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, false>), grid, block, kRowsLds, st, a);
+}
+
+template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostArgs<float> &a) {
+    SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
+    SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
+    const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
+    if (a.W == 256)
+        launch_post_nw<8>(st, a, grid);
+    else
+        launch_post_nw<16>(st, a, grid);
+    SA_HIP(hipGetLastError());
+    return (int64_t)grid.x * grid.y;
+}
+template <> int64_t launch_rows_inv_post<double>(hipStream_t, const RowsPostArgs<double> &) {
+    throw Error(-1, "the fused row kernels are float32 only");
+}
+
+}  // namespace sporco_amd
