@@ -59,7 +59,7 @@ def kernel_bytes(H, W, P, itemsize):
         'fft_c2r_rows': EF + E,              # read spectra; write X
         'admm_post': 5 * E,                  # read X, Y, U; write Y, U
         'rows_fwd': 2 * E + EF,              # read Y, U; write tile-major row spectra
-        'rows_inv_post': EF + 5 * E,         # read spectra, Y, U; write Y, U, X
+        'rows_inv_post': EF + 4 * E,         # read spectra, Y, U; write Y, U (X stays in registers)
     }
 
 

@@ -105,6 +105,11 @@ int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
                           sporco_amd_csc_t *out);
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
 int sporco_amd_csc_sync(sporco_amd_csc_t h);
+/* Which kernels serve this handle's shape: *out = 1 when the fused path named by
+ * `what` is active (float32, H and/or W in {256, 512}, even K <= 64), else 0. */
+#define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
+#define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
+int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))
  * on device -- sporco/admm/cbpdn.py:228-231, sporco/fft.py:257-286. */
@@ -140,7 +145,12 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
 #define SPORCO_AMD_FLAG_XRRS (1u << 5)       /* LinSolveCheck sums out[8..10]  */
 #define SPORCO_AMD_FLAG_GEVAL_Y (1u << 6)    /* regularisers evaluated at Y (gEvalY) */
 #define SPORCO_AMD_FLAG_FEVAL_Y (1u << 7)    /* data fidelity evaluated at Y (fEvalX False) */
-#define SPORCO_AMD_FLAG_KEEP_X (1u << 8)     /* keep X resident after the call */
+#define SPORCO_AMD_FLAG_KEEP_X (1u << 8)     /* write X during the call (default: X, Xf are rebuilt
+                                                on demand from the previous iterate, which
+                                                the fused path keeps) */
+#define SPORCO_AMD_FLAG_NO_X (1u << 9)       /* caller will not read X / Xf of this iteration:
+                                                they are neither written nor recoverable, and
+                                                reading them fails with SPORCO_AMD_ESTATE */
 
 typedef struct {
     double rho;      /* penalty parameter for this iteration                     */

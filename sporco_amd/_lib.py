@@ -27,6 +27,7 @@ FLAG_XRRS = 1 << 5
 FLAG_GEVAL_Y = 1 << 6
 FLAG_FEVAL_Y = 1 << 7
 FLAG_KEEP_X = 1 << 8
+FLAG_NO_X = 1 << 9
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
@@ -38,7 +39,7 @@ PGM_F, PGM_DFID, PGM_L1, PGM_HESS = range(4)
 EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_destroy',
-    'sporco_amd_csc_sync', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
+    'sporco_amd_csc_sync', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
     'sporco_amd_csc_admm_iter', 'sporco_amd_csc_admm_iter_dev',
@@ -123,6 +124,7 @@ def load(path=None):
                                    ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_size_t)],
         'sporco_amd_csc_destroy': [vp], 'sporco_amd_csc_sync': [vp],
+        'sporco_amd_csc_query': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         'sporco_amd_csc_set_signal': [vp, vp],
         'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
         'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
@@ -282,6 +284,19 @@ class Solver(object):
     # -- set-up -----------------------------------------------------------
     def sync(self):
         check(self._lib.sporco_amd_csc_sync(self._h))
+
+    def _query(self, what):
+        out = ctypes.c_int(0)
+        check(self._lib.sporco_amd_csc_query(self._h, int(what), ctypes.byref(out)))
+        return bool(out.value)
+
+    def uses_fused_cols(self):
+        """True when the register-resident column kernel serves this shape."""
+        return self._query(0)
+
+    def uses_fused_rows(self):
+        """True when an ADMM iteration runs as the three fused launches."""
+        return self._query(1)
 
     def set_signal(self, S):
         H, W, C, N, K = self.dims

@@ -138,6 +138,7 @@ class GenericConvBPDN(admm.ADMMEqual):
         self._dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
                                 device=self._device, stream=self._stream)
         self._cache = {}
+        self._no_x = getattr(self, '_no_x', False)   # promise that X / Xf will not be read
         self._u_scale = 1.0      # pending `U /= rsf` (admm.py:573), applied lazily
         self._sums = [0.0] * _lib.OUT_COUNT
         self._wl1_scalar = 1.0
@@ -226,6 +227,8 @@ class GenericConvBPDN(admm.ADMMEqual):
                 f |= _lib.FLAG_FEVAL_Y
         if self.opt['LinSolveCheck']:
             f |= _lib.FLAG_XRRS
+        if self._no_x:
+            f |= _lib.FLAG_NO_X
         return f
 
     def _lmbda_eff(self):

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -107,6 +108,7 @@ struct ProfScope {
 struct CscBase {
     virtual ~CscBase() {}
     virtual void sync() = 0;
+    virtual int query(int what) = 0;
     virtual void set_signal(const void *S) = 0;
     virtual void set_dict(const void *D, int dH, int dW) = 0;
     virtual void set_weight(int which, const void *w, const int64_t shape[5]) = 0;
@@ -213,6 +215,13 @@ template <typename T> struct Csc : CscBase {
     bool rows_ok = false;
     cx<T> *twRows = nullptr;
     double *part_rows = nullptr;
+    // The three-launch iteration writes the new (Y, U) into a second pair of
+    // buffers and swaps: the previous iterate stays intact, so X (which that path
+    // keeps in registers only) can be rebuilt exactly, on demand, by re-running the
+    // X-step on it with the parameters of the iteration (`last_p`).
+    T *y_alt = nullptr, *u_alt = nullptr;
+    bool x_stale = false, x_invalid = false;
+    sporco_amd_admm_params last_p;
 
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
@@ -278,7 +287,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
-                        (void *)twRows, (void *)part_rows,
+                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -321,6 +330,11 @@ template <typename T> struct Csc : CscBase {
     Dims5 d5() const { return Dims5{H, W, C, N, K}; }
 
     void sync() override { SA_HIP(hipStreamSynchronize(st)); }
+    int query(int what) override {
+        if (what == SPORCO_AMD_QUERY_FUSED_COLS) return fused ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
+        throw Error(SPORCO_AMD_EINVAL, "unknown query");
+    }
 
     // ---- 2-D transforms with per-kernel timing -------------------------------
     void fwd2(const T *in, const T *in2, T s2, cx<T> *out, int64_t cols) {
@@ -366,6 +380,35 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_SF), sft, H, (int64_t)Wf * CN, 1);
     }
+    // X of the last three-launch iteration, rebuilt from the previous iterate.
+    void materialize_x() {
+        if (x_invalid)
+            throw Error(SPORCO_AMD_ESTATE,
+                        "X / Xf of an iteration run with SPORCO_AMD_FLAG_NO_X were requested");
+        if (!x_stale) return;
+        x_stale = false;
+        sporco_amd_admm_params q = last_p;
+        q.flags = 0;
+        launch_rows_fwd_on(y_alt, u_alt, (T)q.u_scale);
+        run_fused_cols(q, nullptr);
+        ProfScope ps(prof, PS_FFT_C2R);
+        fft_c2r<T>(st, planW, cv(SPORCO_AMD_VAR_XF), rv(SPORCO_AMD_VAR_X), H, P, K,
+                   (int64_t)CN * H * K, (int64_t)W * P, P, T(1.0 / ((double)H * (double)W)), K,
+                   (int64_t)H * K);
+    }
+    // call before reading `var` / before changing anything X depends on
+    void before_read(int var) {
+        if (var == SPORCO_AMD_VAR_X || var == SPORCO_AMD_VAR_XF) materialize_x();
+        need_natural(var);
+    }
+    void before_state_change() {
+        if (x_stale && !x_invalid) materialize_x();
+    }
+    void x_written() {
+        x_stale = false;
+        x_invalid = false;
+    }
+
     // VAR_XF as callers know it (natural layout): after a fused X-step the buffer
     // holds a tile-major intermediate, and Xf = rfftn(X) is rebuilt on demand.
     void need_natural(int var) {
@@ -377,6 +420,7 @@ template <typename T> struct Csc : CscBase {
 
     // ---- set-up ------------------------------------------------------------------
     void set_signal(const void *S) override {
+        before_state_change();
         SA_HIP(hipMemcpyAsync(sreal, S, sizeof(T) * (int64_t)H * W * CN, hipMemcpyHostToDevice, st));
         fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CN);
         refresh_fused_signal();
@@ -387,6 +431,7 @@ template <typename T> struct Csc : CscBase {
     void set_dict(const void *D, int dH, int dW) override {
         SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W,
                    "filter support must fit inside the signal");
+        before_state_change();
         if (!dpad) SA_HIP(hipMalloc((void **)&dpad, sizeof(T) * (int64_t)H * W * K));
         // stage the compact filters at the tail of dpad's own allocation? no: use `work`-free
         // dedicated staging so set_dict is safe while iterates are live.
@@ -440,6 +485,14 @@ template <typename T> struct Csc : CscBase {
     }
 
     void upload(int var, const void *src) override {
+        if (var == SPORCO_AMD_VAR_X) {
+            x_written();
+        } else if (var == SPORCO_AMD_VAR_XF) {
+            if (x_stale && !x_invalid) materialize_x();   // keep X; Xf is replaced below
+        } else if (var == SPORCO_AMD_VAR_Y || var == SPORCO_AMD_VAR_U || var == SPORCO_AMD_VAR_DF ||
+                   var == SPORCO_AMD_VAR_SF) {
+            before_state_change();
+        }
         SA_HIP(hipMemcpyAsync(var_ptr(var), src, var_bytes(var), hipMemcpyHostToDevice, st));
         if (var == SPORCO_AMD_VAR_XF) xf_tiled = false;
         if (var == SPORCO_AMD_VAR_DF) {
@@ -450,12 +503,12 @@ template <typename T> struct Csc : CscBase {
         sync();
     }
     void download(int var, void *dst) override {
-        need_natural(var);
+        before_read(var);
         SA_HIP(hipMemcpyAsync(dst, var_ptr(var), var_bytes(var), hipMemcpyDeviceToHost, st));
         sync();
     }
     void *device_ptr(int var) override {
-        need_natural(var);
+        before_read(var);
         return var_ptr(var);
     }
 
@@ -494,7 +547,7 @@ template <typename T> struct Csc : CscBase {
             ntiles = launch_fused_cols<T>(st, fa);
         }
         xf_tiled = true;
-        if ((p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
+        if (out_dev && (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
             const double scales[1] = {1.0 / ((double)H * W)};
             finalize(part_f, (int)ntiles, 1, 1, slots, scales, out_dev);
@@ -507,28 +560,21 @@ template <typename T> struct Csc : CscBase {
         require_ready();
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
-        RowsFwdArgs<T> ra;
-        ra.y = Y;
-        ra.u = U;
-        ra.s2 = (T)p.u_scale;
-        ra.t = Xf;
-        ra.twA = twRows;
-        ra.H = H;
-        ra.W = W;
-        ra.CN = CN;
-        ra.K = K;
-        ra.P = P;
-        {
-            ProfScope ps(prof, PS_ROWS_FWD);
-            launch_rows_fwd<T>(st, ra);
+        const bool keep_x = p.flags & F_KEEP_X;
+        if (!keep_x && !y_alt) {
+            SA_HIP(hipMalloc((void **)&y_alt, sizeof(T) * E));
+            SA_HIP(hipMalloc((void **)&u_alt, sizeof(T) * E));
         }
+        launch_rows_fwd_on(Y, U, (T)p.u_scale);
         run_fused_cols(p, out_dev);
         RowsPostArgs<T> pa;
         pa.t = Xf;
         pa.twW = planW.tw<T>();
         pa.y = Y;
         pa.u = U;
-        pa.x = rv(SPORCO_AMD_VAR_X);
+        pa.y_out = keep_x ? Y : y_alt;
+        pa.u_out = keep_x ? U : u_alt;
+        pa.x = keep_x ? rv(SPORCO_AMD_VAR_X) : nullptr;
         pa.scale = T(1.0 / ((double)H * (double)W));
         pa.rlx = (T)p.rlx;
         pa.thr = (T)(p.lmbda / p.rho);
@@ -553,13 +599,40 @@ template <typename T> struct Csc : CscBase {
                               SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
         const double scales[6] = {1, 1, 1, 1, 1, 1};
         finalize(part_rows, (int)nt, 8, 6, slots, scales, out_dev);
+        if (keep_x) {
+            x_written();
+        } else {
+            // the new iterate lives in the alternate buffers: swap roles
+            std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
+            std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
+            last_p = p;
+            x_stale = true;
+            x_invalid = p.flags & F_NO_X;
+        }
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+    }
+
+    void launch_rows_fwd_on(const T *Yin, const T *Uin, T s2) {
+        RowsFwdArgs<T> ra;
+        ra.y = Yin;
+        ra.u = Uin;
+        ra.s2 = s2;
+        ra.t = cv(SPORCO_AMD_VAR_XF);
+        ra.twA = twRows;
+        ra.H = H;
+        ra.W = W;
+        ra.CN = CN;
+        ra.K = K;
+        ra.P = P;
+        ProfScope ps(prof, PS_ROWS_FWD);
+        launch_rows_fwd<T>(st, ra);
     }
 
     // ---- ADMM --------------------------------------------------------------------
     // X-step: Xf = SM(rfftn(Y - s U)), X = irfftn(Xf); objective / check sums -> out_dev
     void xstep_impl(const sporco_amd_admm_params &p, double *out_dev) {
         require_ready();
+        x_written();
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         if (fused && !(p.flags & F_XRRS)) {
@@ -622,6 +695,7 @@ template <typename T> struct Csc : CscBase {
             admm_iter_fused(p, out_dev);
             return;
         }
+        before_state_change();
         xstep_impl(p, out_dev);
         PostParams<T> pp;
         pp.x = rv(SPORCO_AMD_VAR_X);
@@ -651,11 +725,13 @@ template <typename T> struct Csc : CscBase {
     }
 
     void admm_xstep(const sporco_amd_admm_params &p, double *out_dev) override {
+        before_state_change();
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         xstep_impl(p, out_dev);
     }
 
     void admm_relax(double rlx) override {
+        before_read(SPORCO_AMD_VAR_X);
         ProfScope ps(prof, PS_OTHER);
         launch_relax<T>(st, rv(SPORCO_AMD_VAR_X), rv(SPORCO_AMD_VAR_Y), rv(SPORCO_AMD_VAR_AX), (T)rlx,
                         E);
@@ -675,6 +751,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void admm_stats(const sporco_amd_admm_params &p, double *out_dev) override {
+        before_read(SPORCO_AMD_VAR_X);
         // keeps the xstep sums already in out_dev; fills the residual/regulariser slots
         int nb;
         {
@@ -699,6 +776,7 @@ template <typename T> struct Csc : CscBase {
     void reconstruct(int var, void *dst) override {
         require_ready();
         SA_REQUIRE(!var_is_complex(var), "reconstruct needs a real state variable");
+        before_read(var);
         cx<T> *wk = work_buf();
         fwd2(rv(var), nullptr, T(0), wk, P);
         {
@@ -731,7 +809,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_grad(int var, double *out_dev) override {
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_grad needs a frequency-domain variable");
-        need_natural(var);
+        before_read(var);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
@@ -746,7 +824,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_eval(int var, double *out_dev) override {
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_eval needs a frequency-domain variable");
-        need_natural(var);
+        before_read(var);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
@@ -772,6 +850,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW,
                        double *out_dev) override {
         require_ready();
+        x_written();
         cx<T> *Vf = cv(SPORCO_AMD_VAR_VF);
         {
             ProfScope ps(prof, PS_PGM);
@@ -799,7 +878,7 @@ template <typename T> struct Csc : CscBase {
                        "lincomb operand of the wrong kind");
         SA_REQUIRE(va >= 0, "lincomb needs a first operand");
         for (int v : {va, vb, vc})
-            if (v >= 0) need_natural(v);
+            if (v >= 0) before_read(v);
         if (dst == SPORCO_AMD_VAR_XF) xf_tiled = false;
         ProfScope ps(prof, PS_PGM);
         launch_lincomb<T>(st, cv(dst), (T)a, cv(va), (T)b, vb >= 0 ? cv(vb) : nullptr, (T)c,
@@ -814,7 +893,7 @@ template <typename T> struct Csc : CscBase {
                        "pair_stats operands must have the same shape");
         const int64_t cols = var_is_dict_sized(va) ? K : P;
         for (int v : {va, vb, vg})
-            if (v >= 0) need_natural(v);
+            if (v >= 0) before_read(v);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
@@ -832,8 +911,13 @@ template <typename T> struct Csc : CscBase {
                        var_is_dict_sized(rvar) == var_is_dict_sized(cvar),
                    "fft_var needs a real and a complex variable of matching shape");
         const int64_t cols = var_is_dict_sized(rvar) ? K : P;
-        if (inverse) need_natural(cvar);
-        if (!inverse && cvar == SPORCO_AMD_VAR_XF) xf_tiled = false;
+        if (inverse) {
+            before_read(cvar);
+            if (rvar == SPORCO_AMD_VAR_X) x_written();
+        } else {
+            before_read(rvar);
+            if (cvar == SPORCO_AMD_VAR_XF) xf_tiled = false;
+        }
         if (inverse)
             inv2(cv(cvar), var_is_dict_sized(rvar) ? dwork_buf() : work_buf(), rv(rvar), cols);
         else
@@ -844,6 +928,7 @@ template <typename T> struct Csc : CscBase {
     void ccmod_setcoef(int var) override {
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
+        before_read(var);
         fwd2(rv(var), nullptr, T(0), cv(SPORCO_AMD_VAR_ZF), P);
     }
 
@@ -904,6 +989,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void setdict_from_dstep(int dH, int dW) override {
+        before_state_change();
         SA_HIP(hipMemcpyAsync(cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_DXF),
                               sizeof(cx<T>) * npix * K, hipMemcpyDeviceToDevice, st));
         {
@@ -918,6 +1004,7 @@ template <typename T> struct Csc : CscBase {
 
     void asum(int var, double *out_dev) override {
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var), "asum needs a real variable");
+        before_read(var);
         int nb;
         {
             ProfScope ps(prof, PS_OTHER);
@@ -930,8 +1017,9 @@ template <typename T> struct Csc : CscBase {
 
     void copy(int dst, int src) override {
         SA_REQUIRE(var_bytes(dst) == var_bytes(src), "copy between variables of different size");
-        need_natural(src);
+        before_read(src);
         if (dst == SPORCO_AMD_VAR_XF) xf_tiled = false;
+        if (dst == SPORCO_AMD_VAR_X) x_written();
         ProfScope ps(prof, PS_OTHER);
         SA_HIP(hipMemcpyAsync(var_ptr(dst), var_ptr(src), var_bytes(src), hipMemcpyDeviceToDevice, st));
     }
@@ -1036,6 +1124,14 @@ int sporco_amd_csc_sync(sporco_amd_csc_t h) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->sync();
+    SA_API_END
+}
+
+int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "null output pointer");
+    *out = h->impl->query(what);
     SA_API_END
 }
 

@@ -29,6 +29,7 @@ enum : uint32_t {
     F_GEVAL_Y = 1u << 6,
     F_FEVAL_Y = 1u << 7,
     F_KEEP_X = 1u << 8,
+    F_NO_X = 1u << 9,
 };
 
 // dst(H, W, K) = zero-padded src(dH, dW, K)              (cnvrep.zpad, cnvrep.py:704-726)

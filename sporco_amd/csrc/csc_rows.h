@@ -36,7 +36,8 @@ template <typename T> struct RowsFwdArgs {
 template <typename T> struct RowsPostArgs {
     const cx<T> *t;    // in: tile-major column-inverse-transformed solution, unnormalised
     const cx<T> *twW;  // exp(-2 pi i t / W), t in [0, W)
-    T *y, *u;          // in/out real (H, W, P)
+    const T *y, *u;    // in: real (H, W, P)
+    T *y_out, *u_out;  // out (may alias y, u: every element is read and written by one thread)
     T *x;              // out (optional, may be null): X = irfftn(Xf)
     T scale;           // 1 / (H W)
     T rlx, thr, u_scale;

@@ -285,7 +285,8 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const int64_t rowoff = (int64_t)h * W * a.P;
     const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
     const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes), Ub = make_rsrc(a.u + rowoff, rowbytes);
-    const BufRsrc Xb = make_rsrc(WRITE_X ? a.x + rowoff : a.y + rowoff, rowbytes);
+    const BufRsrc Yo = make_rsrc(a.y_out + rowoff, rowbytes), Uo = make_rsrc(a.u_out + rowoff, rowbytes);
+    const BufRsrc Xb = make_rsrc(WRITE_X ? a.x + rowoff : a.y_out + rowoff, rowbytes);
     const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;
     const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
     const float al = a.rlx, oma = 1.f - a.rlx, usc = a.u_scale, scale = a.scale;
@@ -342,8 +343,8 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
                 s_u2 += u1 * u1;
                 s_l1 += fabsf(wt * (gy ? y1 : xs[e]));
             }
-            buf_store_cf(Yb, voff, soff, mk<float>(yn[0], yn[1]));
-            buf_store_cf(Ub, voff, soff, mk<float>(un[0], un[1]));
+            buf_store_cf(Yo, voff, soff, mk<float>(yn[0], yn[1]));
+            buf_store_cf(Uo, voff, soff, mk<float>(un[0], un[1]));
             if (WRITE_X) buf_store_cf(Xb, voff, soff, mk<float>(xs[0], xs[1]));
         }
     });

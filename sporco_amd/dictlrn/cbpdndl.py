@@ -149,6 +149,10 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
         xstep = ConvBPDN(D0, S, lmbda, opt['CBPDN'], method=xmethod, dimK=dimK, dimN=dimN,
                          device=device, stream=stream)
+        if xmethod == 'admm':
+            # the alternation only ever consumes Y (var_y) of the X-step: tell the
+            # device that X / Xf of the inner iterations are never read
+            xstep._no_x = True
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
         dstep = ConvCnstrMOD(None, S, dsz, opt['CCMOD'], method=dmethod, dimK=dimK, dimN=dimN,
                              dev=xdev)
