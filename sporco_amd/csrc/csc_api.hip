@@ -540,7 +540,6 @@ template <typename T> struct Csc : CscBase {
         fa.CN = CN;
         fa.K = K;
         fa.partials = part_f;
-        fa.ablate = 0;
         int64_t ntiles;
         {
             ProfScope ps(prof, PS_FUSED_COLS);
@@ -566,7 +565,7 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMalloc((void **)&u_alt, sizeof(T) * E));
         }
         launch_rows_fwd_on(Y, U, (T)p.u_scale);
-        run_fused_cols(p, out_dev);
+        run_fused_cols(p, nullptr);
         RowsPostArgs<T> pa;
         pa.t = Xf;
         pa.twW = planW.tw<T>();
@@ -595,10 +594,19 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_ROWS_INV_POST);
             nt = launch_rows_inv_post<T>(st, pa);
         }
-        const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
-                              SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
-        const double scales[6] = {1, 1, 1, 1, 1, 1};
-        finalize(part_rows, (int)nt, 8, 6, slots, scales, out_dev);
+        if (p.flags & (F_RESID | F_OBJ)) {
+            // one launch sums both partial arrays: the six epilogue sums and the
+            // data-fidelity term of the column kernel
+            const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                                  SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
+            const double scales[6] = {1, 1, 1, 1, 1, 1};
+            const int fslots[1] = {SPORCO_AMD_OUT_DFID};
+            const double fscales[1] = {1.0 / ((double)H * W)};
+            const bool dfid = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
+            ProfScope ps(prof, PS_FINALIZE);
+            launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, (int)(Wf * CN), 1,
+                             dfid ? 1 : 0, fslots, fscales, out_dev);
+        }
         if (keep_x) {
             x_written();
         } else {

@@ -34,7 +34,6 @@ template <typename T> struct FusedColsArgs {
     const cx<T> *twB;  // H entries: exp(-2 pi i (w + NW j) h2 / H)    FFT stages (fused_twiddles)
     T rho;
     int H, W, CN, K;
-    int ablate;        // diagnostics only (SPORCO_AMD_FUSED_ABLATE): skip parts of the kernel
     double *partials;  // one double per tile: Parseval-weighted sum |Df.xf - Sf|^2
 };
 

@@ -56,8 +56,14 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     const int w = sa_readfirstlane(tid >> 6);
     const int K = KC ? KC : a.K;
     const bool kv = KC == 64 ? true : k < K;
-    const int tile = blockIdx.x;
-    const int wf = tile / a.CN;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).
+    // All C*N tiles of one row frequency wf share the same 256 KiB slice of Df, so
+    // they are given to one XCD, back to back: its L2 then serves the re-reads.
+    const int Wf = a.W / 2 + 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wf = (slot / a.CN) * 8 + xcd;
+    if (wf >= Wf) return;
+    const int tile = wf * a.CN + slot % a.CN;
     // buffer addressing: wave-uniform descriptors of this tile / this Df slice, one
     // shared 32-bit lane offset and scalar row offsets, so the 3*N1 row addresses
     // cost no vector registers (the tile itself needs 2*N1 of them)
@@ -81,18 +87,14 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 #pragma unroll
     for (int h1 = 0; h1 < N1; ++h1)
         v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
-    if (!(a.ablate & 8)) {
     dif<N1, false>(v, 0);
     reg_fence<N1>(v, 0, token);
 #pragma unroll
     for (int i = 1; i < N1; ++i) v[i] = cmul(v[i], twA[i]);
-    }
     reg_fence<N1>(v, 0, token);
 
     const float rho = a.rho;
     float obj = 0.f;
-    const int abl = a.ablate;
-    if (!(abl & 4))
     static_for<Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         // ---- exchange A: (w = h2; f1 in regs) -> (w = f1 mod NW; h2 in regs) ---------
@@ -133,7 +135,6 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 u[NW * jl + h2] = mk<float>(t.x, t.y);
             }
         }
-        if (!(abl & 2))
         static_for<NCH>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int jl = g / CPL, c = g % CPL;
@@ -149,7 +150,6 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 gv[e] = gn[e];
             }
             if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
-            if (!(abl & 1)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
@@ -165,7 +165,6 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 // Df.xf - Sf = rho (q - Sf) / (gram + rho)
                 obj += cabs2(coef);
                 u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
-            }
             }
             // inverse FFT over f2, conj twiddle
             if constexpr (c == CPL - 1) {
@@ -201,7 +200,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     reg_fence<N1>(v, 0, token);
 
     // ---- inverse FFT over f1, store the rows this wave loaded ------------------------
-    if (!(abl & 8)) dit<N1, true>(v, 0);
+    dit<N1, true>(v, 0);
     if (kv) {
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1)
@@ -210,7 +209,6 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 
     // (always written: a conditional here makes the compiler sink the whole |coef|^2
     // chain into the branch and keep every coef alive until the end of the kernel)
-    const int Wf = a.W / 2 + 1;
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
     double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
     block_sum_store<1>(acc, scratch, a.partials + tile);
@@ -293,8 +291,9 @@ static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC>), dim3((unsigned)ntiles), dim3(NW * 64),
-                       kFusedLds, st, a);
+    const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
+    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC>), dim3((unsigned)(wf_groups * 8 * a.CN)),
+                       dim3(NW * 64), kFusedLds, st, a);
 }
 
 template <int N1, int NW, int LP>
@@ -309,12 +308,7 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     SA_REQUIRE(fused_cols_supported<float>(a_in.H, a_in.K), "shape not handled by the fused column kernel");
     const int64_t ntiles = (int64_t)(a_in.W / 2 + 1) * a_in.CN;
     const FusedSplit sp = fused_split(a_in.H, a_in.K);
-    static const int ablate = [] {
-        const char *e = std::getenv("SPORCO_AMD_FUSED_ABLATE");
-        return e ? std::atoi(e) : 0;
-    }();
-    FusedColsArgs<float> a = a_in;
-    a.ablate = ablate;
+    const FusedColsArgs<float> &a = a_in;
     if (sp.N1 == 32 && sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);
     else if (sp.N1 == 32 && sp.NW == 16)

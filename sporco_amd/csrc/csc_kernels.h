@@ -151,5 +151,10 @@ int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t 
 // out[slot[i]] = scale[i] * sum_b partials[b*stride + i]  (or max when is_max)
 void launch_finalize(hipStream_t st, const double *partials, int nblocks, int stride, int nvals,
                      const int *slots, const double *scales, bool is_max, double *out);
+// the same for two partial arrays in one launch (sums only)
+void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int stride_a, int nvals_a,
+                      const int *slots_a, const double *scales_a, const double *pb, int nblocks_b,
+                      int stride_b, int nvals_b, const int *slots_b, const double *scales_b,
+                      double *out);
 
 }  // namespace sporco_amd

@@ -1086,52 +1086,85 @@ template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, dou
 // ---------------------------------------------------------------------------
 // fixed-order final reduction of block partials
 // ---------------------------------------------------------------------------
-struct FinalizeArgs {
+struct FinalizeGroup {
     const double *partials;
-    int nblocks, stride, nvals, is_max;
+    int nblocks, stride, nvals;
     int slots[8];
     double scales[8];
+};
+struct FinalizeArgs {
+    FinalizeGroup g[2];
+    int ngroups, is_max;
     double *out;
 };
 
+// One workgroup per output value: thread t sums blocks t, t+256, ... of its value,
+// then a fixed-shape LDS tree (same order on every run).
 __global__ void __launch_bounds__(kThreads) finalize_kernel(const FinalizeArgs a) {
-    // thread t sums blocks t, t+256, ... of value i; then a fixed-shape LDS tree
     double *scratch = dyn_lds<double>();
-    for (int i = 0; i < a.nvals; ++i) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < a.nblocks; b += blockDim.x) {
-            const double v = a.partials[(int64_t)b * a.stride + i];
-            s = a.is_max ? (v > s ? v : s) : s + v;
+    int i = blockIdx.x;
+    const FinalizeGroup *gp = &a.g[0];
+    if (i >= a.g[0].nvals) {
+        i -= a.g[0].nvals;
+        gp = &a.g[1];
+    }
+    const FinalizeGroup &g = *gp;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < g.nblocks; b += blockDim.x) {
+        const double v = g.partials[(int64_t)b * g.stride + i];
+        s = a.is_max ? (v > s ? v : s) : s + v;
+    }
+    scratch[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const double o = scratch[threadIdx.x + w];
+            scratch[threadIdx.x] = a.is_max ? (o > scratch[threadIdx.x] ? o : scratch[threadIdx.x])
+                                            : scratch[threadIdx.x] + o;
         }
-        scratch[threadIdx.x] = s;
         __syncthreads();
-        for (int w = blockDim.x / 2; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) {
-                const double o = scratch[threadIdx.x + w];
-                scratch[threadIdx.x] = a.is_max ? (o > scratch[threadIdx.x] ? o : scratch[threadIdx.x])
-                                                : scratch[threadIdx.x] + o;
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) a.out[a.slots[i]] = scratch[0] * a.scales[i];
-        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.out[g.slots[i]] = scratch[0] * g.scales[i];
+}
+
+static void fill_group(FinalizeGroup &g, const double *partials, int nblocks, int stride, int nvals,
+                       const int *slots, const double *scales) {
+    g.partials = partials;
+    g.nblocks = nblocks;
+    g.stride = stride;
+    g.nvals = nvals;
+    for (int i = 0; i < 8; ++i) {
+        g.slots[i] = i < nvals ? slots[i] : 0;
+        g.scales[i] = i < nvals ? scales[i] : 0.0;
     }
 }
 
 void launch_finalize(hipStream_t st, const double *partials, int nblocks, int stride, int nvals,
                      const int *slots, const double *scales, bool is_max, double *out) {
     FinalizeArgs a;
-    a.partials = partials;
-    a.nblocks = nblocks;
-    a.stride = stride;
-    a.nvals = nvals;
+    fill_group(a.g[0], partials, nblocks, stride, nvals, slots, scales);
+    fill_group(a.g[1], partials, 0, 1, 0, slots, scales);
+    a.ngroups = 1;
     a.is_max = is_max ? 1 : 0;
-    for (int i = 0; i < 8; ++i) {
-        a.slots[i] = i < nvals ? slots[i] : 0;
-        a.scales[i] = i < nvals ? scales[i] : 0.0;
-    }
     a.out = out;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kThreads), sizeof(double) * kThreads, st, a);
+    if (nvals <= 0) return;
+    hipLaunchKernelGGL(finalize_kernel, dim3(nvals), dim3(kThreads), sizeof(double) * kThreads, st, a);
+    SA_HIP(hipGetLastError());
+}
+
+void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int stride_a, int nvals_a,
+                      const int *slots_a, const double *scales_a, const double *pb, int nblocks_b,
+                      int stride_b, int nvals_b, const int *slots_b, const double *scales_b,
+                      double *out) {
+    FinalizeArgs a;
+    fill_group(a.g[0], pa, nblocks_a, stride_a, nvals_a, slots_a, scales_a);
+    fill_group(a.g[1], pb, nblocks_b, stride_b, nvals_b, slots_b, scales_b);
+    a.ngroups = 2;
+    a.is_max = 0;
+    a.out = out;
+    if (nvals_a + nvals_b <= 0) return;
+    hipLaunchKernelGGL(finalize_kernel, dim3(nvals_a + nvals_b), dim3(kThreads),
+                       sizeof(double) * kThreads, st, a);
     SA_HIP(hipGetLastError());
 }
 
