@@ -34,8 +34,11 @@ namespace {
 
 using namespace regfft;
 
-constexpr int kExchUnitsMax = 16384;  // f2 units of the exchange buffer (128 KiB)
-constexpr size_t kFusedLds = sizeof(f2) * kExchUnitsMax + sizeof(double) * 16;
+constexpr int kExchUnitsMax = 16384;  // f2 units of the largest exchange buffer (128 KiB)
+// LDS of one instantiation: its exchange group (LP lines of NW points for every wave) + scratch
+constexpr size_t fused_lds_bytes(int NW, int LP) {
+    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * 16;
+}
 
 // N1 x NW = H; NW waves; KC: compile-time filter count (64), or 0 for a run-time K <= 64.
 template <int N1, int NW, int LPARAM, int KC>
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     // same thread on either side, so only the two hand-overs need a barrier.
     f2 *LA = dyn_lds<f2>();
     f2 *LB = LA;
-    double *scratch = reinterpret_cast<double *>(LA + kExchUnitsMax);
+    double *scratch = reinterpret_cast<double *>(LA + FP * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
     int token = 0;
 
@@ -288,12 +291,12 @@ static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds));
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
     hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC>), dim3((unsigned)(wf_groups * 8 * a.CN)),
-                       dim3(NW * 64), kFusedLds, st, a);
+                       dim3(NW * 64), fused_lds_bytes(NW, LP), st, a);
 }
 
 template <int N1, int NW, int LP>

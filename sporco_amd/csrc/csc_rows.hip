@@ -17,7 +17,8 @@
 //                  (and its inverse) a purely per-thread operation: the bins f
 //                  and W-f always live in the same thread.  Wave 0 owns the
 //                  self-paired lines 0 and 16 (plus 8, 24 for NW = 8).
-// One LDS exchange (128 KiB, two halves when W = 512) moves the data between
+// One LDS exchange, in two halves of 16 lines (64 KiB each for W = 256, which
+// lets two workgroups share a CU; 128 KiB for W = 512), moves the data between
 // the two sides; nothing else touches LDS.
 #include "csc_rows.h"
 
@@ -37,7 +38,9 @@ struct alignas(16) cf2 {
 };
 
 constexpr int kN1 = 32;
-constexpr size_t kRowsLds = sizeof(f2) * 16384 + sizeof(double) * 8 * 16;
+constexpr size_t rows_lds_bytes(int NW) {
+    return sizeof(f2) * 16 * NW * 64 + sizeof(double) * 8 * 16;
+}
 
 // line k1 held in slot j of spectral-side wave w (see the file header)
 __device__ __forceinline__ int line_of(int w, int j) {
@@ -45,6 +48,18 @@ __device__ __forceinline__ int line_of(int w, int j) {
     if (j == 1) return w == 0 ? 16 : 32 - w;
     if (j == 2) return w == 0 ? 8 : 16 - w;
     return w == 0 ? 24 : 16 + w;
+}
+
+// The exchange moves 16 lines at a time (64 KiB for NW = 8, 128 KiB for NW = 16):
+// group_of / kl_of give the half a line travels in and its slot there.  Each
+// half holds whole {k1, 32 - k1} pairs, i.e. slots (0, 1) or (2, 3) of a wave.
+__host__ __device__ constexpr int group_of(int NW, int k1) {
+    return NW == 16 ? (k1 >> 4) : ((k1 < 8 || k1 == 16 || k1 > 24) ? 0 : 1);
+}
+__host__ __device__ constexpr int kl_of(int NW, int k1) {
+    if (NW == 16) return k1 & 15;
+    if (group_of(NW, k1) == 0) return k1 < 8 ? k1 : (k1 == 16 ? 8 : k1 - 16);
+    return k1 < 16 ? k1 - 8 : k1 - 9;
 }
 
 __device__ __forceinline__ float soft1(float v, float thr) {
@@ -60,8 +75,8 @@ __device__ __forceinline__ float soft1(float v, float thr) {
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
-    constexpr int NG = (NW == 16) ? 2 : 1;   // exchange halves
-    constexpr int LPG = J / NG, KPG = N1 / NG;
+    constexpr int NG = 2;                    // exchange halves
+    constexpr int LPG = J / NG;
     constexpr int LBW = ilog2(NW);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,18 +125,19 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
 #pragma unroll
-        for (int kk = 0; kk < KPG; ++kk) {
-            const cf x = v[brev(g * KPG + kk, 5)];   // C[k1 = g KPG + kk][n2 = w]
+        for (int k1 = 0; k1 < N1; ++k1) {
+            if (group_of(NW, k1) != g) continue;
+            const cf x = v[brev(k1, 5)];   // C[k1][n2 = w]
             f2 t;
             t.x = x.re;
             t.y = x.im;
-            L[(kk * NW + w) * 64 + lane] = t;
+            L[(kl_of(NW, k1) * NW + w) * 64 + lane] = t;
         }
         __syncthreads();
 #pragma unroll
         for (int jl = 0; jl < LPG; ++jl) {
             const int j = g * LPG + jl;
-            const int kl = line_of(w, j) & (KPG - 1);
+            const int kl = kl_of(NW, line_of(w, j));
 #pragma unroll
             for (int n2 = 0; n2 < NW; ++n2) {
                 const f2 t = L[(kl * NW + n2) * 64 + lane];
@@ -182,8 +198,8 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 template <int NW, bool WRITE_X, bool GENERAL>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
-    constexpr int NG = (NW == 16) ? 2 : 1;
-    constexpr int LPG = J / NG, KPG = N1 / NG;
+    constexpr int NG = 2;
+    constexpr int LPG = J / NG;
     constexpr int LBW = ilog2(NW);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -194,7 +210,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const int CN = a.C * a.N;
     const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
     f2 *L = dyn_lds<f2>();
-    double *scratch = reinterpret_cast<double *>(L + 16384);
+    double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
     int token = 0;
 
@@ -253,7 +269,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
         for (int jl = 0; jl < LPG; ++jl) {
             const int j = g * LPG + jl;
             const int k1 = line_of(w, j);
-            const int kl = k1 & (KPG - 1);
+            const int kl = kl_of(NW, k1);
             dit<NW, true>(z, NW * j);
 #pragma unroll
             for (int n2 = 0; n2 < NW; ++n2) {
@@ -272,9 +288,10 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < KPG; ++kk) {
-            const f2 t = L[(kk * NW + w) * 64 + lane];
-            v[brev(g * KPG + kk, 5)] = mk<float>(t.x, t.y);
+        for (int k1 = 0; k1 < N1; ++k1) {
+            if (group_of(NW, k1) != g) continue;
+            const f2 t = L[(kl_of(NW, k1) * NW + w) * 64 + lane];
+            v[brev(k1, 5)] = mk<float>(t.x, t.y);
         }
         if (g + 1 < NG) __syncthreads();
     });
@@ -360,7 +377,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
 template <int NW, typename K>
 void set_lds_attr(K kernel) {
     SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLds));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds_bytes(NW)));
 }
 
 }  // namespace
@@ -393,9 +410,9 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
     }
     const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
     if (a.W == 256)
-        hipLaunchKernelGGL((rows_fwd_kernel<8>), grid, dim3(8 * 64), kRowsLds, st, a);
+        hipLaunchKernelGGL((rows_fwd_kernel<8>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
     else
-        hipLaunchKernelGGL((rows_fwd_kernel<16>), grid, dim3(16 * 64), kRowsLds, st, a);
+        hipLaunchKernelGGL((rows_fwd_kernel<16>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
     SA_HIP(hipGetLastError());
 }
 template <> void launch_rows_fwd<double>(hipStream_t, const RowsFwdArgs<double> &) {
@@ -415,13 +432,13 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 gr
     const bool general = a.wl1.ptr != nullptr || (a.flags & F_NOBNDRY);
     const dim3 block(NW * 64);
     if (a.x && general)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true>), grid, block, kRowsLds, st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true>), grid, block, rows_lds_bytes(NW), st, a);
     else if (a.x)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, false>), grid, block, kRowsLds, st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, false>), grid, block, rows_lds_bytes(NW), st, a);
     else if (general)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, true>), grid, block, kRowsLds, st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, true>), grid, block, rows_lds_bytes(NW), st, a);
     else
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, false>), grid, block, kRowsLds, st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, false>), grid, block, rows_lds_bytes(NW), st, a);
 }
 
 template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostArgs<float> &a) {
