@@ -156,6 +156,10 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
         dstep = ConvCnstrMOD(None, S, dsz, opt['CCMOD'], method=dmethod, dimK=dimK, dimN=dimN,
                              dev=xdev)
+        # dictlrn.DictLearn.solve ignores what the inner solve() calls return
+        # (dictlrn.py:333,338): do not copy the iterates to the host every outer iteration
+        xstep._return_min = False
+        dstep._return_min = False
         isc = dictlrn.IterStatsConfig(
             isfld=dc.isfld(xmethod, dmethod, opt), isxmap=dc.isxmap(xmethod, opt),
             isdmap=dc.isdmap(dmethod), evlmap=dc.evlmap(opt['AccurateDFid']),

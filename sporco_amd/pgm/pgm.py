@@ -119,7 +119,9 @@ class PGM(common.IterativeSolver):
         self.finish_solve()
         self.timer.stop(labels)
         self.display_end(nsep)
-        return self.getmin()
+        # (solvers driven by an outer loop that never looks at the return value set
+        # `_return_min = False`: for a device-resident solver it is a device-to-host copy)
+        return self.getmin() if getattr(self, '_return_min', True) else None
 
     def finish_solve(self):
         pass
