@@ -218,6 +218,29 @@ int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out);
 #define SPORCO_AMD_PGM_L1 2      /* sum |wl1 * X| of the last prox step (obfn_reg :347-356) */
 #define SPORCO_AMD_PGM_HESS 3    /* sum |sum_k Df v|^2 = Re <v, hessian_f(v)> (:302-312)  */
 
+#define SPORCO_AMD_PGM_RSDL 4    /* rfl2norm2(Xf - Yfprv) of pgm_iter (rsdl, pgm/cbpdn.py:314-320) */
+#define SPORCO_AMD_PGM_FY 5      /* f at the Yf the step started from (pgm_iter)             */
+
+/* One whole default-option FISTA iteration on device (float32, H and W in {256, 512},
+ * even K <= 64; SPORCO_AMD_EINVAL otherwise -- compose the calls below instead):
+ * on_iteration_start (Xfprv = Xf, Yfprv = Yf, by buffer rotation), PGMDFT.xstep
+ * (grad_f at Yf, Vf = Yf - grad/L, X = prox_g(irfftn(Vf)), Xf = rfftn(X);
+ * sporco/pgm/pgm.py:779-811) and PGMDFT.ystep with the caller's momentum factor
+ * Yf = Xf + beta (Xf - Xfprv) (pgm.py:815-831).  out[PGM_F], out[PGM_DFID] (at the
+ * new Xf; only with `want_stats`), out[PGM_L1], out[PGM_RSDL], out[PGM_FY].
+ * The spectral iterates stay in an internal tile-major layout between such calls
+ * and X is rebuilt on demand; any other entry point sees the reference layout. */
+typedef struct {
+    double L;        /* inverse step size                                   */
+    double lmbda;    /* l1 weight (times a scalar L1Weight)                 */
+    double beta;     /* momentum factor (t_prev - 1) / t                    */
+    uint32_t flags;  /* SPORCO_AMD_FLAG_NONNEG | SPORCO_AMD_FLAG_NOBNDRY     */
+    int32_t dH, dW;  /* filter support, for NOBNDRY                         */
+    int32_t want_stats; /* evaluate the objective at the new Xf             */
+} sporco_amd_pgm_params;
+int sporco_amd_csc_pgm_iter(sporco_amd_csc_t h, const sporco_amd_pgm_params *p,
+                            double out[SPORCO_AMD_OUT_COUNT]);
+
 /* GF = conj(Df) * (sum_k Df*v - Sf) for v = complex state `var` (grad_f,
  * pgm/cbpdn.py:263-279); out[PGM_F], out[PGM_DFID] receive f(v). */
 int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);

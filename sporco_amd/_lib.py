@@ -34,7 +34,7 @@ OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
 OUT_XRRS_D2, OUT_XRRS_AX2, OUT_XRRS_B2 = 8, 9, 10
 OUT_COUNT = 16
 
-PGM_F, PGM_DFID, PGM_L1, PGM_HESS = range(4)
+PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY = range(6)
 
 EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
@@ -48,6 +48,7 @@ EXPORTS = (
     'sporco_amd_csc_admm_stats', 'sporco_amd_csc_scale_u',
     'sporco_amd_csc_reconstruct', 'sporco_amd_csc_dhs_absmax',
     'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_eval', 'sporco_amd_csc_pgm_prox_step',
+    'sporco_amd_csc_pgm_iter',
     'sporco_amd_csc_lincomb', 'sporco_amd_csc_pair_stats', 'sporco_amd_csc_copy',
     'sporco_amd_csc_fft_var', 'sporco_amd_csc_ifft_var',
     'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
@@ -67,6 +68,12 @@ class BackendError(RuntimeError):
 class Dims(ctypes.Structure):
     _fields_ = [('H', ctypes.c_int32), ('W', ctypes.c_int32), ('C', ctypes.c_int32),
                 ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('dtype', ctypes.c_int32)]
+
+
+class PgmParams(ctypes.Structure):
+    _fields_ = [('L', ctypes.c_double), ('lmbda', ctypes.c_double), ('beta', ctypes.c_double),
+                ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32), ('dW', ctypes.c_int32),
+                ('want_stats', ctypes.c_int32)]
 
 
 class AdmmParams(ctypes.Structure):
@@ -144,6 +151,7 @@ def load(path=None):
         'sporco_amd_csc_dhs_absmax': [vp, dptr],
         'sporco_amd_csc_pgm_grad': [vp, ctypes.c_int, dptr],
         'sporco_amd_csc_pgm_eval': [vp, ctypes.c_int, dptr],
+        'sporco_amd_csc_pgm_iter': [vp, ctypes.POINTER(PgmParams), dptr],
         'sporco_amd_csc_pgm_prox_step': [vp, dbl, dbl, ctypes.c_uint32, i32, i32, dptr],
         'sporco_amd_csc_lincomb': [vp, ctypes.c_int, dbl, ctypes.c_int, dbl, ctypes.c_int, dbl,
                                    ctypes.c_int],
@@ -395,6 +403,14 @@ class Solver(object):
     def pgm_grad(self, var):
         out = self._out()
         check(self._lib.sporco_amd_csc_pgm_grad(self._h, var, out))
+        return list(out)
+
+    def pgm_iter(self, L, lmbda, beta, flags, dH, dW, want_stats):
+        """One fused default-option FISTA iteration (sporco_amd_csc_pgm_iter)."""
+        p = PgmParams(float(L), float(lmbda), float(beta), int(flags), int(dH), int(dW),
+                      1 if want_stats else 0)
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pgm_iter(self._h, ctypes.byref(p), out))
         return list(out)
 
     def pgm_eval(self, var):

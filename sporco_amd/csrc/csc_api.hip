@@ -14,6 +14,7 @@
 #include "common.h"
 #include "csc_fused.h"
 #include "csc_kernels.h"
+#include "csc_pgm.h"
 #include "csc_rows.h"
 #include "fft.h"
 
@@ -31,6 +32,9 @@ enum ProfSlot {
     PS_FUSED_COLS,
     PS_ROWS_FWD,
     PS_ROWS_INV_POST,
+    PS_PGM_GRAD_IFFT,
+    PS_PGM_ROWS_PROX,
+    PS_PGM_FFT_MOM,
     PS_FINALIZE,
     PS_PGM,
     PS_OTHER,
@@ -39,6 +43,7 @@ enum ProfSlot {
 static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_solve",
                                            "fft_c2c_cols_inv", "fft_c2r_rows",     "admm_post",
                                            "fused_cols_sm",    "rows_fwd",         "rows_inv_post",
+                                           "pgm_grad_ifft",    "pgm_rows_prox",    "pgm_fft_momentum",
                                            "finalize",         "pgm_elementwise",  "other"};
 
 struct Profiler {
@@ -126,6 +131,7 @@ struct CscBase {
     virtual void dhs_absmax(double *out_host) = 0;
     virtual void pgm_grad(int var, double *out_dev) = 0;
     virtual void pgm_eval(int var, double *out_dev) = 0;
+    virtual void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) = 0;
     virtual void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW,
                                double *out_dev) = 0;
     virtual void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) = 0;
@@ -222,6 +228,11 @@ template <typename T> struct Csc : CscBase {
     T *y_alt = nullptr, *u_alt = nullptr;
     bool x_stale = false, x_invalid = false;
     sporco_amd_admm_params last_p;
+    // fused PGM iteration (csc_pgm.h): Xf, Yf, Xfprv, Yfprv tile-major; X of the last
+    // iteration is prox(irfft_W(work)) and is rebuilt on demand with `last_pgm`
+    bool pgm_tiled = false, pgm_x_stale = false;
+    sporco_amd_pgm_params last_pgm;
+    double *part_pgm = nullptr;
 
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
@@ -287,7 +298,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
-                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt,
+                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -385,6 +396,10 @@ template <typename T> struct Csc : CscBase {
         if (x_invalid)
             throw Error(SPORCO_AMD_ESTATE,
                         "X / Xf of an iteration run with SPORCO_AMD_FLAG_NO_X were requested");
+        if (pgm_x_stale) {
+            pgm_x_stale = false;
+            pgm_rows_prox(last_pgm, work_buf(), nullptr, rv(SPORCO_AMD_VAR_X), nullptr);
+        }
         if (!x_stale) return;
         x_stale = false;
         sporco_amd_admm_params q = last_p;
@@ -402,16 +417,44 @@ template <typename T> struct Csc : CscBase {
         need_natural(var);
     }
     void before_state_change() {
-        if (x_stale && !x_invalid) materialize_x();
+        if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
     }
     void x_written() {
         x_stale = false;
         x_invalid = false;
+        pgm_x_stale = false;
+    }
+    static bool is_pgm_iterate(int var) {
+        return var == SPORCO_AMD_VAR_XF || var == SPORCO_AMD_VAR_YF ||
+               var == SPORCO_AMD_VAR_XFPRV || var == SPORCO_AMD_VAR_YFPRV;
+    }
+    // natural (H, Wf*CN, K) <-> tile-major (Wf*CN, H, K) of one X-sized spectrum, through
+    // the column-pass scratch buffer (pointer swap, no second copy)
+    void relayout(int var, bool to_tiled) {
+        cx<T> *src = cv(var), *dst = work_buf();
+        {
+            ProfScope ps(prof, PS_OTHER);
+            if (to_tiled)
+                launch_permute_ab<cx<T>>(st, src, dst, H, (int64_t)Wf * CN, K);
+            else
+                launch_permute_ab<cx<T>>(st, src, dst, (int64_t)Wf * CN, H, K);
+        }
+        vars[var] = dst;
+        work = src;
+    }
+    void pgm_leave_tiled() {
+        if (!pgm_tiled) return;
+        if (pgm_x_stale) materialize_x();   // needs `work` before it is reused as scratch
+        pgm_tiled = false;
+        for (int v : {SPORCO_AMD_VAR_XF, SPORCO_AMD_VAR_YF, SPORCO_AMD_VAR_XFPRV,
+                      SPORCO_AMD_VAR_YFPRV})
+            relayout(v, false);
     }
 
     // VAR_XF as callers know it (natural layout): after a fused X-step the buffer
     // holds a tile-major intermediate, and Xf = rfftn(X) is rebuilt on demand.
     void need_natural(int var) {
+        if (pgm_tiled && is_pgm_iterate(var)) pgm_leave_tiled();
         if (var == SPORCO_AMD_VAR_XF && xf_tiled) {
             xf_tiled = false;
             fwd2(rv(SPORCO_AMD_VAR_X), nullptr, T(0), cv(SPORCO_AMD_VAR_XF), P);
@@ -485,6 +528,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void upload(int var, const void *src) override {
+        if (is_pgm_iterate(var)) pgm_leave_tiled();
         if (var == SPORCO_AMD_VAR_X) {
             x_written();
         } else if (var == SPORCO_AMD_VAR_XF) {
@@ -814,6 +858,119 @@ template <typename T> struct Csc : CscBase {
     }
 
     // ---- PGM -----------------------------------------------------------------------
+    // rows pass of the fused iteration: X = prox(irfft_W(t_in)), t_out = rfft_W(X)
+    void pgm_rows_prox(const sporco_amd_pgm_params &p, const cx<T> *t_in, cx<T> *t_out, T *x,
+                       double *out_dev) {
+        RowsProxArgs<T> ra;
+        ra.t_in = t_in;
+        ra.t_out = t_out;
+        ra.x = x;
+        ra.twA = twRows;
+        ra.twW = planW.tw<T>();
+        ra.scale = T(1.0 / ((double)H * (double)W));
+        ra.thr = (T)(p.lmbda / p.L);
+        ra.flags = p.flags;
+        ra.H = H;
+        ra.W = W;
+        ra.C = C;
+        ra.N = N;
+        ra.K = K;
+        ra.dH = p.dH;
+        ra.dW = p.dW;
+        ra.P = P;
+        ra.wl1 = wl1;
+        ra.partials = part_rows;
+        int64_t nt;
+        {
+            ProfScope ps(prof, PS_PGM_ROWS_PROX);
+            nt = launch_rows_inv_prox_fwd<T>(st, ra);
+        }
+        if (out_dev) {
+            const int slots[1] = {SPORCO_AMD_PGM_L1};
+            const double scales[1] = {1.0};
+            finalize(part_rows, (int)nt, 1, 1, slots, scales, out_dev);
+        }
+    }
+
+    void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
+        require_ready();
+        if (!rows_ok) throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        if (!part_pgm) SA_HIP(hipMalloc((void **)&part_pgm, sizeof(double) * 4 * (int64_t)Wf * CN));
+        if (!pgm_tiled) {
+            // enter the tile-major regime: the two live iterates are re-laid out once
+            need_natural(SPORCO_AMD_VAR_XF);   // (an ADMM leftover in the Xf buffer is resolved first)
+            need_natural(SPORCO_AMD_VAR_YF);
+            relayout(SPORCO_AMD_VAR_XF, true);
+            relayout(SPORCO_AMD_VAR_YF, true);
+            (void)cv(SPORCO_AMD_VAR_XFPRV);
+            (void)cv(SPORCO_AMD_VAR_YFPRV);
+            (void)cv(SPORCO_AMD_VAR_VF);
+            pgm_tiled = true;
+        }
+        if (pgm_x_stale) pgm_x_stale = false;   // X of the previous iteration is superseded
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF), *Yf = cv(SPORCO_AMD_VAR_YF);
+        cx<T> *Xprv = cv(SPORCO_AMD_VAR_XFPRV), *Yprv = cv(SPORCO_AMD_VAR_YFPRV);
+        cx<T> *spare = cv(SPORCO_AMD_VAR_VF), *Tm = work_buf();
+        PgmColsArgs<T> ca;
+        ca.dft = dft;
+        ca.sft = sft;
+        ca.twA = twA;
+        ca.twB = twB;
+        ca.inv_L = (T)(1.0 / p.L);
+        ca.beta = (T)p.beta;
+        ca.H = H;
+        ca.W = W;
+        ca.CN = CN;
+        ca.K = K;
+        ca.want_stats = p.want_stats;
+        // 1. gradient step at Yf, inverse transform along H
+        ca.yf = Yf;
+        ca.xf_old = nullptr;
+        ca.t = Tm;
+        ca.yf_new = nullptr;
+        ca.partials = part_f;
+        int64_t ntile;
+        {
+            ProfScope ps(prof, PS_PGM_GRAD_IFFT);
+            ntile = launch_pgm_grad_ifft<T>(st, ca);
+        }
+        {
+            const int slots[1] = {SPORCO_AMD_PGM_FY};
+            const double scales[1] = {0.5};
+            finalize(part_f, (int)ntile, 1, 1, slots, scales, out_dev);
+        }
+        // 2. inverse along W, proximal map, forward along W
+        pgm_rows_prox(p, Tm, spare, nullptr, out_dev);
+        // 3. forward along H (in place: `spare` becomes the new Xf), momentum into the old
+        //    Yfprv buffer, residual and objective sums
+        ca.yf = Yf;
+        ca.xf_old = Xf;
+        ca.t = spare;
+        ca.yf_new = Yprv;
+        ca.partials = part_pgm;
+        {
+            ProfScope ps(prof, PS_PGM_FFT_MOM);
+            launch_pgm_fft_momentum<T>(st, ca);
+        }
+        {
+            const int slots[3] = {SPORCO_AMD_PGM_RSDL, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F};
+            const double scales[3] = {1.0 / ((double)H * W), 1.0 / ((double)H * W), 0.5};
+            finalize(part_pgm, (int)ntile, 4, p.want_stats ? 3 : 1, slots, scales, out_dev);
+        }
+        // on_iteration_start's copies as a rotation of buffers (pgm.py:835-846)
+        vars[SPORCO_AMD_VAR_XF] = spare;
+        vars[SPORCO_AMD_VAR_XFPRV] = Xf;
+        vars[SPORCO_AMD_VAR_VF] = Xprv;
+        vars[SPORCO_AMD_VAR_YF] = Yprv;
+        vars[SPORCO_AMD_VAR_YFPRV] = Yf;
+        xf_tiled = false;
+        x_stale = false;
+        x_invalid = false;
+        pgm_x_stale = true;
+        last_pgm = p;
+    }
+
     void pgm_grad(int var, double *out_dev) override {
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_grad needs a frequency-domain variable");
@@ -858,6 +1015,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW,
                        double *out_dev) override {
         require_ready();
+        pgm_leave_tiled();
         x_written();
         cx<T> *Vf = cv(SPORCO_AMD_VAR_VF);
         {
@@ -885,6 +1043,7 @@ template <typename T> struct Csc : CscBase {
             SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(dst)),
                        "lincomb operand of the wrong kind");
         SA_REQUIRE(va >= 0, "lincomb needs a first operand");
+        if (is_pgm_iterate(dst)) pgm_leave_tiled();
         for (int v : {va, vb, vc})
             if (v >= 0) before_read(v);
         if (dst == SPORCO_AMD_VAR_XF) xf_tiled = false;
@@ -919,6 +1078,7 @@ template <typename T> struct Csc : CscBase {
                        var_is_dict_sized(rvar) == var_is_dict_sized(cvar),
                    "fft_var needs a real and a complex variable of matching shape");
         const int64_t cols = var_is_dict_sized(rvar) ? K : P;
+        if (is_pgm_iterate(cvar)) pgm_leave_tiled();
         if (inverse) {
             before_read(cvar);
             if (rvar == SPORCO_AMD_VAR_X) x_written();
@@ -1026,6 +1186,7 @@ template <typename T> struct Csc : CscBase {
     void copy(int dst, int src) override {
         SA_REQUIRE(var_bytes(dst) == var_bytes(src), "copy between variables of different size");
         before_read(src);
+        if (is_pgm_iterate(dst)) pgm_leave_tiled();
         if (dst == SPORCO_AMD_VAR_XF) xf_tiled = false;
         if (dst == SPORCO_AMD_VAR_X) x_written();
         ProfScope ps(prof, PS_OTHER);
@@ -1299,6 +1460,16 @@ int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_O
     double *sb = stats_buf(h);
     h->impl->pgm_grad(var, sb);
     h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_pgm_iter(sporco_amd_csc_t h, const sporco_amd_pgm_params *p,
+                            double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p != nullptr && out != nullptr, "null argument");
+    h->impl->pgm_iter(*p, stats_buf(h));
+    h->impl->read_out(stats_buf(h), out);
     SA_API_END
 }
 

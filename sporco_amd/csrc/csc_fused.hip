@@ -242,21 +242,15 @@ void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B
     SA_HIP(hipGetLastError());
 }
 
-// Split of a supported shape into N1 (in-register FFT length) x NW (waves), and
-// the number LP of stage-2 lines per exchange group.  H = 512 has two layouts:
-// 16 waves x 32 points (108 VGPRs, 4 waves/SIMD) and 8 waves x 64 points (~200
-// VGPRs, 2 waves/SIMD); SPORCO_AMD_FUSED_VARIANT picks one for A/B runs.
+// Split of a supported shape into N1 = 32 (in-register FFT length) x NW = H/32 waves,
+// and the number LP of stage-2 lines per exchange group.  (An 8-wave x 64-point
+// layout of H = 512 was measured too: ~200 VGPRs, 2 waves/SIMD, 1.4x slower.)
 struct FusedSplit {
     int N1, NW, LP;
 };
 static FusedSplit fused_split(int H, int K) {
+    (void)K;
     if (H == 256) return {32, 8, 2};
-    static const int variant = [] {
-        const char *e = std::getenv("SPORCO_AMD_FUSED_VARIANT");
-        return e ? std::atoi(e) : 0;
-    }();
-    if (variant == 1) return {64, 8, 2};
-    if (variant == 2) return {64, 8, 4};
     return {32, 16, 1};
 }
 
@@ -312,14 +306,10 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     const int64_t ntiles = (int64_t)(a_in.W / 2 + 1) * a_in.CN;
     const FusedSplit sp = fused_split(a_in.H, a_in.K);
     const FusedColsArgs<float> &a = a_in;
-    if (sp.N1 == 32 && sp.NW == 8)
+    if (sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);
-    else if (sp.N1 == 32 && sp.NW == 16)
-        launch_fused_k<32, 16, 1>(st, a, ntiles);
-    else if (sp.LP == 2)
-        launch_fused_k<64, 8, 2>(st, a, ntiles);
     else
-        launch_fused_k<64, 8, 4>(st, a, ntiles);
+        launch_fused_k<32, 16, 1>(st, a, ntiles);
     SA_HIP(hipGetLastError());
     return ntiles;
 }

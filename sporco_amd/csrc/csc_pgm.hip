@@ -1,0 +1,350 @@
+// csc_pgm.hip -- column passes of the fused PGM iteration (see csc_pgm.h).
+//
+// Same decomposition as csc_fused.hip (H = 32 x NW, lane = filter, one (wf, cn)
+// tile per workgroup, XCD-aware tile order), but each kernel needs only one of
+// the two LDS exchanges: the iterates live in the frequency domain, so
+//   pgm_grad_ifft     starts on the spectral side (wave w owns the frequencies
+//                     f = w + NW j + 32 brev(i), exactly the order the inverse
+//                     DIT transform wants), and ends with rows of T;
+//   pgm_fft_momentum  starts with rows of T' and ends on the spectral side, where
+//                     the momentum update and the sums are element-wise.
+#include "csc_pgm.h"
+
+#include "regfft.h"
+
+namespace sporco_amd {
+
+namespace {
+
+using namespace regfft;
+
+constexpr size_t pgm_lds_bytes(int NW, int LP) {
+    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * 4 * 16;
+}
+
+// sum over the K filters of d[e] * x[e] for 4 frequencies e at once (wave reduction);
+// returns the 4 complex totals as wave-uniform values
+__device__ __forceinline__ void inner4(const cf (&d)[4], const cf *x, int lane, cf (&q)[4]) {
+    float red[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const cf p = cmul(d[e], x[e]);
+        red[2 * e] = p.re;
+        red[2 * e + 1] = p.im;
+    }
+    const float tot = reduce8_across_lanes(red, lane);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        q[e] = mk<float>(sa_readlane(tot, 16 * e), sa_readlane(tot, 16 * e + 8));
+}
+
+// ---------------------------------------------------------------------------
+// Vf = Yf - conj(Df) (sum_k Df Yf - Sf) / L;  T = IFFT_H(Vf)      (grad_f + the step,
+// sporco/pgm/cbpdn.py:263-279, sporco/pgm/pgm.py:800)
+// ---------------------------------------------------------------------------
+template <int NW, int LP, int KC>
+__global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArgs<float> a) {
+    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr int LBW = ilog2(NW);
+    constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KC ? KC : a.K;
+    const bool kv = KC == 64 ? true : k < K;
+    const int Wf = a.W / 2 + 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wf = (slot / a.CN) * 8 + xcd;   // see fused_cols_kernel for the tile order
+    if (wf >= Wf) return;
+    const int tile = wf * a.CN + slot % a.CN;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Yb = make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Ob = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
+    const int ko = (w * K + k) * (int)sizeof(cf);   // row w, filter k
+    const cf *S = a.sft + (int64_t)tile * H + w;
+    const cf *twB = a.twB + w * N1;
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
+    const cf zero = mk<float>(0.f, 0.f);
+    const float inv_L = a.inv_L;
+    int token = 0;
+    float fsum = 0.f;
+
+    cf v[N1];
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        // this group's lines of Yf and the matching rows of Df
+        cf u[FP];
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int fo = NW * (q * LP + jl) + N1 * brev(i, LBW);   // f - w
+                u[NW * jl + i] = kv ? buf_load_cf(Yb, ko, fo * K * (int)sizeof(cf)) : zero;
+            }
+        }
+        static_for<NCH>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+            cf dd[4], sv[4], qq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                dd[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                sa_uload2(reinterpret_cast<const float *>(S + fo), sv[e].re, sv[e].im);
+            }
+            inner4(dd, &u[NW * jl + 4 * c], k, qq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const cf r = qq[e] - sv[e];   // sum_k Df Yf - Sf
+                fsum += cabs2(r);
+                u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] - cscale(cmulc(dd[e], r), inv_L);
+            }
+            if constexpr (c == CPL - 1) {
+                // inverse FFT over f2, conj twiddle
+                dit<NW, true>(u, NW * jl);
+#pragma unroll
+                for (int h2 = 1; h2 < NW; ++h2) {
+                    cf tw;
+                    sa_uload2(reinterpret_cast<const float *>(twB + NW * j + h2), tw.re, tw.im);
+                    u[NW * jl + h2] = cmulc(tw, u[NW * jl + h2]);
+                }
+            }
+        });
+        {
+            float &fs_ = fsum;
+            int &tk_ = token;
+            SA_VGPR_FENCE3(fs_, tk_, tk_);
+        }
+        // exchange: (wave = f1 mod NW; h2 in registers) -> (wave = h2; f1 in registers)
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int h2 = 0; h2 < NW; ++h2) {
+                f2 t;
+                t.x = u[NW * jl + h2].re;
+                t.y = u[NW * jl + h2].im;
+                L[((w + NW * jl) * NW + h2) * 64 + k] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int fl = 0; fl < FP; ++fl) {
+            const f2 t = L[(fl * NW + w) * 64 + k];
+            v[brev(q * FP + fl, 5)] = mk<float>(t.x, t.y);
+        }
+        if (q + 1 < Q) __syncthreads();
+    });
+    reg_fence<N1>(v, 0, token);
+    dit<N1, true>(v, 0);
+    if (kv) {
+#pragma unroll
+        for (int h1 = 0; h1 < N1; ++h1) buf_store_cf(Ob, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
+    }
+    double acc[1] = {k == 0 ? (double)fsum : 0.0};
+    block_sum_store<1>(acc, scratch, a.partials + tile);
+}
+
+// ---------------------------------------------------------------------------
+// Xf' = FFT_H(T');  Yf' = Xf' + beta (Xf' - Xf);  sums of |Xf' - Yf|^2 and f(Xf')
+// (sporco/pgm/pgm.py:803, :815-831; sporco/pgm/cbpdn.py:314-345)
+// ---------------------------------------------------------------------------
+template <int NW, int LP, int KC, bool STATS>
+__global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmColsArgs<float> a) {
+    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr int LBW = ilog2(NW);
+    constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KC ? KC : a.K;
+    const bool kv = KC == 64 ? true : k < K;
+    const int Wf = a.W / 2 + 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wf = (slot / a.CN) * 8 + xcd;
+    if (wf >= Wf) return;
+    const int tile = wf * a.CN + slot % a.CN;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Xo = make_rsrc(a.xf_old + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Yo = make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Yn = make_rsrc(a.yf_new + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
+    const int ko = (w * K + k) * (int)sizeof(cf);
+    const cf *S = a.sft + (int64_t)tile * H + w;
+    const cf *twA = a.twA + w * N1;
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
+    const cf zero = mk<float>(0.f, 0.f);
+    const float beta = a.beta;
+    int token = 0;
+    float rs = 0.f, fsum = 0.f;
+
+    // rows h = NW h1 + w of T', forward FFT over h1, twiddle
+    cf v[N1];
+#pragma unroll
+    for (int h1 = 0; h1 < N1; ++h1)
+        v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
+    dif<N1, false>(v, 0);
+    reg_fence<N1>(v, 0, token);
+#pragma unroll
+    for (int i = 1; i < N1; ++i) {
+        cf tw;
+        sa_uload2(reinterpret_cast<const float *>(twA + i), tw.re, tw.im);
+        v[i] = cmul(v[i], tw);
+    }
+    reg_fence<N1>(v, 0, token);
+
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+#pragma unroll
+        for (int fl = 0; fl < FP; ++fl) {
+            const cf x = v[brev(q * FP + fl, 5)];
+            f2 t;
+            t.x = x.re;
+            t.y = x.im;
+            L[(fl * NW + w) * 64 + k] = t;
+        }
+        // previous iterates (and Df / Sf for the objective) of chunk g+1 are requested while
+        // chunk g is processed; chunk 0's before the barrier
+        cf xn4[4], yn4[4];
+        auto prefetch = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                xn4[e] = kv ? buf_load_cf(Xo, ko, fo * K * (int)sizeof(cf)) : zero;
+                yn4[e] = kv ? buf_load_cf(Yo, ko, fo * K * (int)sizeof(cf)) : zero;
+            }
+        };
+        prefetch(std::integral_constant<int, 0>{});
+        __syncthreads();
+        cf u[FP];
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int h2 = 0; h2 < NW; ++h2) {
+                const f2 t = L[((w + NW * jl) * NW + h2) * 64 + k];
+                u[NW * jl + h2] = mk<float>(t.x, t.y);
+            }
+        }
+        if (q + 1 < Q) __syncthreads();
+        static_for<NCH>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+            if constexpr (c == 0) dif<NW, false>(u, NW * jl);   // u[NW jl + i] = Xf'[f]
+            cf xo[4], yo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xo[e] = xn4[e];
+                yo[e] = yn4[e];
+            }
+            if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
+            if constexpr (STATS) {
+                // f(Xf') = 0.5 sum |sum_k Df Xf' - Sf|^2: Df (L2-resident) loaded at use
+                cf dd[4], sv[4], qq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                    dd[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                    sa_uload2(reinterpret_cast<const float *>(S + fo), sv[e].re, sv[e].im);
+                }
+                inner4(dd, &u[NW * jl + 4 * c], k, qq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fsum += cabs2(qq[e] - sv[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                const cf xn = u[NW * jl + 4 * c + e];
+                const cf yn = xn + cscale(xn - xo[e], beta);
+                if (kv) {
+                    buf_store_cf(Tb, ko, fo * K * (int)sizeof(cf), xn);
+                    buf_store_cf(Yn, ko, fo * K * (int)sizeof(cf), yn);
+                    rs += cabs2(xn - yo[e]);
+                }
+            }
+        });
+        {
+            float &rs_ = rs, &fs_ = fsum;   // (named references: asm operands alone do not capture)
+            int &tk_ = token;
+            SA_VGPR_FENCE3(rs_, fs_, tk_);
+        }
+    });
+
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    const double rsw = wave_sum((double)rs);   // rs is per lane (all filters); fsum is wave-uniform
+    double acc[4] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
+                     k == 0 ? (double)fsum : 0.0, 0.0};
+    block_sum_store<4>(acc, scratch, a.partials + (int64_t)tile * 4);
+}
+
+template <typename F> void set_lds(F kernel, size_t bytes) {
+    SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+}
+
+template <int NW, int LP, int KC> void launch_grad(hipStream_t st, const PgmColsArgs<float> &a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds(&pgm_grad_ifft_kernel<NW, LP, KC>, pgm_lds_bytes(NW, LP));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
+    hipLaunchKernelGGL((pgm_grad_ifft_kernel<NW, LP, KC>), dim3(grid), dim3(NW * 64),
+                       pgm_lds_bytes(NW, LP), st, a);
+}
+
+template <int NW, int LP, int KC, bool STATS>
+void launch_mom(hipStream_t st, const PgmColsArgs<float> &a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, STATS>, pgm_lds_bytes(NW, LP));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
+    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS>), dim3(grid), dim3(NW * 64),
+                       pgm_lds_bytes(NW, LP), st, a);
+}
+
+}  // namespace
+
+template <> int64_t launch_pgm_grad_ifft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
+    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
+               "shape not handled by the fused PGM kernels");
+    if (a.H == 256) {
+        if (a.K == 64) launch_grad<8, 2, 64>(st, a);
+        else launch_grad<8, 2, 0>(st, a);
+    } else {
+        if (a.K == 64) launch_grad<16, 1, 64>(st, a);
+        else launch_grad<16, 1, 0>(st, a);
+    }
+    SA_HIP(hipGetLastError());
+    return (int64_t)(a.W / 2 + 1) * a.CN;
+}
+
+template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmColsArgs<float> &a) {
+    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
+               "shape not handled by the fused PGM kernels");
+    const bool k64 = a.K == 64, st8 = a.H == 256, stats = a.want_stats != 0;
+    if (st8) {
+        if (k64) { if (stats) launch_mom<8, 2, 64, true>(st, a); else launch_mom<8, 2, 64, false>(st, a); }
+        else { if (stats) launch_mom<8, 2, 0, true>(st, a); else launch_mom<8, 2, 0, false>(st, a); }
+    } else {
+        if (k64) { if (stats) launch_mom<16, 1, 64, true>(st, a); else launch_mom<16, 1, 64, false>(st, a); }
+        else { if (stats) launch_mom<16, 1, 0, true>(st, a); else launch_mom<16, 1, 0, false>(st, a); }
+    }
+    SA_HIP(hipGetLastError());
+    return (int64_t)(a.W / 2 + 1) * a.CN;
+}
+
+template <> int64_t launch_pgm_grad_ifft<double>(hipStream_t, const PgmColsArgs<double> &) {
+    throw Error(-1, "the fused PGM kernels are float32 only");
+}
+template <> int64_t launch_pgm_fft_momentum<double>(hipStream_t, const PgmColsArgs<double> &) {
+    throw Error(-1, "the fused PGM kernels are float32 only");
+}
+
+}  // namespace sporco_amd

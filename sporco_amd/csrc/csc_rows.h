@@ -48,6 +48,24 @@ template <typename T> struct RowsPostArgs {
     double *partials;  // per tile 8 doubles: r2, s2, ax2, y2, u2, l1, 0, 0
 };
 
+// The row pass of the fused PGM (FISTA) iteration, sporco/pgm/pgm.py:800-803 with
+// prox_g of sporco/pgm/cbpdn.py:288-300:  X = prox_l1(irfft_W(t_in) / (H W), thr * wl1)
+// (+ NonNeg / NoBndryCross), then t_out = rfft_W(X), tile-major.  t_out == null stops
+// after writing X (used to materialise X on demand); x may be null.
+template <typename T> struct RowsProxArgs {
+    const cx<T> *t_in;
+    cx<T> *t_out;
+    T *x;
+    const cx<T> *twA, *twW;
+    T scale, thr;
+    uint32_t flags;    // F_NONNEG | F_NOBNDRY
+    int H, W, C, N, K, dH, dW;
+    int64_t P;
+    Weight<T> wl1;
+    double *partials;  // per tile 1 double: sum |wl1 * X|
+};
+template <typename T> int64_t launch_rows_inv_prox_fwd(hipStream_t st, const RowsProxArgs<T> &a);
+
 // Shapes the register-resident row kernels handle (float32, W in {256, 512}, K even).
 template <typename T> bool rows_supported(int W, int K);
 // Host table for RowsFwdArgs::twA ((W/32) * 32 entries).

@@ -69,53 +69,22 @@ __device__ __forceinline__ float soft1(float v, float thr) {
     return v < 0.f ? -m : m;
 }
 
-// ---------------------------------------------------------------------------
-// rows_fwd: T = rfft_W(Y - s2 U), tile-major
-// ---------------------------------------------------------------------------
+// Spatial side -> spectral side: v[n1] = z(x = NW n1 + w) (destroyed) is transformed
+// along W, untangled into the spectra of the two packed real lines, and the bins
+// f <= W/2 are stored tile-major at t[f][cn][h][k..k+1].
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a) {
-    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
+__device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA, cf *t, int CN, int H,
+                                                    int K, int cn, int k, int h, bool pv, int w,
+                                                    int lane, f2 *L, int &token) {
+    constexpr int N1 = kN1, J = N1 / NW;
     constexpr int NG = 2;                    // exchange halves
     constexpr int LPG = J / NG;
     constexpr int LBW = ilog2(NW);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = sa_readfirstlane(tid >> 6);
-    const int h = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
-    const bool pv = p < a.P;
-    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
-    f2 *L = dyn_lds<f2>();
-    int token = 0;
-
-    // ---- spatial side: z[n1] = (Y - s2 U)(h, x = NW n1 + w, p..p+1) -------------------
-    const int64_t rowoff = (int64_t)h * W * a.P;
-    const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
-    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes), Ub = make_rsrc(a.u + rowoff, rowbytes);
-    const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;  // masked lanes read 0
-    const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
-    const float s2 = a.s2;
-    cf v[N1];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        cf yv[N1 / 2], uv[N1 / 2];
-#pragma unroll
-        for (int i = 0; i < N1 / 2; ++i) {
-            const int n1 = half * (N1 / 2) + i;
-            const int soff = (NW * n1 + w) * pixbytes;
-            yv[i] = buf_load_cf(Yb, voff, soff);
-            uv[i] = buf_load_cf(Ub, voff, soff);
-        }
-#pragma unroll
-        for (int i = 0; i < N1 / 2; ++i)
-            v[half * (N1 / 2) + i] = mk<float>(yv[i].re - s2 * uv[i].re, yv[i].im - s2 * uv[i].im);
-        reg_fence<N1 / 2>(v, half * (N1 / 2), token);
-    }
     dif<N1, false>(v, 0);
 #pragma unroll
     for (int i = 1; i < N1; ++i) {
         cf tw;
-        sa_uload2(reinterpret_cast<const float *>(a.twA + w * N1 + i), tw.re, tw.im);
+        sa_uload2(reinterpret_cast<const float *>(twA + w * N1 + i), tw.re, tw.im);
         v[i] = cmul(v[i], tw);
     }
     reg_fence<N1>(v, 0, token);
@@ -152,8 +121,8 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     for (int j = 0; j < J; ++j) dif<NW, false>(z, NW * j);
 
     // ---- untangle the two real spectra and store the bins f <= W/2 ------------------------
-    const int64_t tline = (int64_t)a.CN * a.H * a.K;
-    cf *Tl = a.t + (int64_t)cn * a.H * a.K + (int64_t)h * a.K + k;
+    const int64_t tline = (int64_t)CN * H * K;
+    cf *Tl = t + (int64_t)cn * H * K + (int64_t)h * K + k;
     auto store_unit = [&](int f, cf zf, cf zp) {
         // A = (Zf + conj Zp) / 2,  B = (Zf - conj Zp) / (2i)
         cf2 ab;
@@ -192,31 +161,21 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     }
 }
 
-// ---------------------------------------------------------------------------
-// rows_inv_post: X = irfft_W(T) / (H W); relax, shrink, dual update, sums
-// ---------------------------------------------------------------------------
-template <int NW, bool WRITE_X, bool GENERAL>
-__global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
+// Spectral side -> spatial side: the bins f <= W/2 of t[f][cn][h][k..k+1] are loaded,
+// the packed spectrum Z is rebuilt, and v[n1] receives the unnormalised inverse
+// transform at x = NW n1 + w: (re, im) = (filter k, filter k+1).
+template <int NW>
+__device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW, const cf *t, int CN,
+                                                    int H, int K, int cn, int k, int h, bool pv, int w,
+                                                    int lane, f2 *L, int &token) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
     constexpr int NG = 2;
     constexpr int LPG = J / NG;
     constexpr int LBW = ilog2(NW);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = sa_readfirstlane(tid >> 6);
-    const int h = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
-    const bool pv = p < a.P;
-    const int CN = a.C * a.N;
-    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
-    f2 *L = dyn_lds<f2>();
-    double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
-    int token = 0;
-
     // ---- spectral side: load the bins f <= W/2 of this thread's lines, rebuild Z -------
-    const int64_t tline = (int64_t)CN * a.H * a.K;
-    const cf *Tl = a.t + (int64_t)cn * a.H * a.K + (int64_t)h * a.K + k;
+    const int64_t tline = (int64_t)CN * H * K;
+    const cf *Tl = t + (int64_t)cn * H * K + (int64_t)h * K + k;
     auto load_unit = [&](int f) {
         cf2 ab;
         ab.a = zero;
@@ -262,7 +221,6 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     reg_fence<N1>(z, 0, token);
 
     // ---- inverse transform over k2, conj twiddle, exchange to the spatial side --------------
-    cf v[N1];
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
 #pragma unroll
@@ -276,7 +234,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
                 cf x = z[NW * j + n2];
                 if (n2 > 0) {
                     cf tw;
-                    sa_uload2(reinterpret_cast<const float *>(a.twW + ((n2 * k1) & (W - 1))), tw.re,
+                    sa_uload2(reinterpret_cast<const float *>(twW + ((n2 * k1) & (W - 1))), tw.re,
                               tw.im);
                     x = cmulc(tw, x);
                 }
@@ -297,6 +255,77 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     });
     reg_fence<N1>(v, 0, token);
     dit<N1, true>(v, 0);   // v[n1] = (X_p, X_{p+1}) at x = NW n1 + w, unnormalised
+}
+
+// ---------------------------------------------------------------------------
+// rows_fwd: T = rfft_W(Y - s2 U), tile-major
+// ---------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a) {
+    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
+    constexpr int NG = 2;                    // exchange halves
+    constexpr int LPG = J / NG;
+    constexpr int LBW = ilog2(NW);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const bool pv = p < a.P;
+    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
+    f2 *L = dyn_lds<f2>();
+    int token = 0;
+
+    // ---- spatial side: z[n1] = (Y - s2 U)(h, x = NW n1 + w, p..p+1) -------------------
+    const int64_t rowoff = (int64_t)h * W * a.P;
+    const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
+    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes), Ub = make_rsrc(a.u + rowoff, rowbytes);
+    const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;  // masked lanes read 0
+    const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
+    const float s2 = a.s2;
+    cf v[N1];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        cf yv[N1 / 2], uv[N1 / 2];
+#pragma unroll
+        for (int i = 0; i < N1 / 2; ++i) {
+            const int n1 = half * (N1 / 2) + i;
+            const int soff = (NW * n1 + w) * pixbytes;
+            yv[i] = buf_load_cf(Yb, voff, soff);
+            uv[i] = buf_load_cf(Ub, voff, soff);
+        }
+#pragma unroll
+        for (int i = 0; i < N1 / 2; ++i)
+            v[half * (N1 / 2) + i] = mk<float>(yv[i].re - s2 * uv[i].re, yv[i].im - s2 * uv[i].im);
+        reg_fence<N1 / 2>(v, half * (N1 / 2), token);
+    }
+    spatial_to_spectral<NW>(v, a.twA, a.t, a.CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+}
+
+// ---------------------------------------------------------------------------
+// rows_inv_post: X = irfft_W(T) / (H W); relax, shrink, dual update, sums
+// ---------------------------------------------------------------------------
+template <int NW, bool WRITE_X, bool GENERAL>
+__global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
+    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
+    constexpr int NG = 2;
+    constexpr int LPG = J / NG;
+    constexpr int LBW = ilog2(NW);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const bool pv = p < a.P;
+    const int CN = a.C * a.N;
+    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
+    const cf zero = mk<float>(0.f, 0.f);
+    int token = 0;
+
+    cf v[N1];
+    spectral_to_spatial<NW>(v, a.twW, a.t, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a.P;
@@ -308,10 +337,12 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
     const float al = a.rlx, oma = 1.f - a.rlx, usc = a.u_scale, scale = a.scale;
     const bool nonneg = a.flags & F_NONNEG, nob = a.flags & F_NOBNDRY, gy = a.flags & F_GEVAL_Y;
-    int64_t wbase = 0;
-    if (GENERAL && a.wl1.ptr) {
+    // weight of element (h, x, c, n, k): wave-uniform row pointer + 32-bit lane offset
+    int wlane = 0;
+    const int ws4 = (int)a.wl1.stride[4];
+    if (GENERAL) {   // (the launcher substitutes a constant 1 with zero strides for "no weights")
         const int c = cn / a.N, n = cn % a.N;
-        wbase = h * a.wl1.stride[0] + c * a.wl1.stride[2] + n * a.wl1.stride[3] + k * a.wl1.stride[4];
+        wlane = (int)(c * a.wl1.stride[2] + n * a.wl1.stride[3] + k * a.wl1.stride[4]);
     }
     const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
     const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
@@ -339,16 +370,21 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
             const float yo[2] = {yb[b & 1][i].re, yb[b & 1][i].im};
             const float uo[2] = {usc * ub[b & 1][i].re, usc * ub[b & 1][i].im};
             float yn[2], un[2];
-            const bool kill = GENERAL && (hkill || (nob && xw >= x0kill));
+            // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
+            // epilogue into dozens of blocks and the register allocator spills the tile)
+            const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float ax = al * xs[e] + oma * yo[e];
                 float wt = 1.f;
-                if (GENERAL && a.wl1.ptr)
-                    wt = a.wl1.ptr[wbase + xw * a.wl1.stride[1] + e * a.wl1.stride[4]];
+                if (GENERAL) {
+                    const float *wrow = a.wl1.ptr + (int64_t)h * a.wl1.stride[0] +
+                                        (int64_t)xw * a.wl1.stride[1];
+                    wt = wrow[wlane + e * ws4];
+                }
                 float y1 = soft1(ax + uo[e], a.thr * wt);
                 if (nonneg && y1 < 0.f) y1 = 0.f;
-                if (kill) y1 = 0.f;
+                if (GENERAL) y1 *= keep;
                 const float u1 = uo[e] + ax - y1;
                 yn[e] = y1;
                 un[e] = u1;
@@ -372,6 +408,76 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
                      (double)s_u2, (double)s_l1, 0.0,          0.0};
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     block_sum_store<8>(acc, scratch, a.partials + tile * 8);
+}
+
+// ---------------------------------------------------------------------------
+// rows_inv_prox_fwd: X = prox_l1(irfft_W(T_in) / (H W)); T_out = rfft_W(X)
+// ---------------------------------------------------------------------------
+template <int NW, bool GENERAL>
+__global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsProxArgs<float> a) {
+    constexpr int N1 = kN1, W = N1 * NW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const bool pv = p < a.P;
+    const int CN = a.C * a.N;
+    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
+    int token = 0;
+
+    cf v[N1];
+    spectral_to_spatial<NW>(v, a.twW, a.t_in, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+
+    // ---- proximal step on the 32 pixels of this thread -----------------------------------------
+    const int64_t rowoff = (int64_t)h * W * a.P;
+    const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
+    // no X requested: a zero-length buffer drops every store
+    const BufRsrc Xb = a.x ? make_rsrc(a.x + rowoff, rowbytes) : make_rsrc(a.t_in, 0u);
+    const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;
+    const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
+    const float scale = a.scale;
+    const bool nonneg = a.flags & F_NONNEG, nob = a.flags & F_NOBNDRY;
+    int wlane = 0;
+    const int ws4 = (int)a.wl1.stride[4];
+    if (GENERAL) {
+        const int c = cn / a.N, n = cn % a.N;
+        wlane = (int)(c * a.wl1.stride[2] + n * a.wl1.stride[3] + k * a.wl1.stride[4]);
+    }
+    const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
+    const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
+    float s_l1 = 0.f;
+#pragma unroll
+    for (int n1 = 0; n1 < N1; ++n1) {
+        const int xw = NW * n1 + w;
+        const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
+        float y[2] = {v[n1].re * scale, v[n1].im * scale};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float wt = 1.f;
+            if (GENERAL) {
+                const float *wrow = a.wl1.ptr + (int64_t)h * a.wl1.stride[0] +
+                                    (int64_t)xw * a.wl1.stride[1];
+                wt = wrow[wlane + e * ws4];
+            }
+            float y1 = soft1(y[e], a.thr * wt);
+            if (nonneg && y1 < 0.f) y1 = 0.f;
+            if (GENERAL) y1 *= keep;
+            s_l1 += fabsf(wt * y1);
+            y[e] = y1;
+        }
+        v[n1] = mk<float>(y[0], y[1]);
+        buf_store_cf(Xb, voff, xw * pixbytes, v[n1]);
+    }
+    double acc[1] = {(double)s_l1};
+    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    block_sum_store<1>(acc, scratch, a.partials + tile);
+    if (!a.t_out) return;
+    reg_fence<N1>(v, 0, token);
+
+    spatial_to_spectral<NW>(v, a.twA, a.t_out, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
 }
 
 template <int NW, typename K>
@@ -419,8 +525,19 @@ template <> void launch_rows_fwd<double>(hipStream_t, const RowsFwdArgs<double> 
     throw Error(-1, "the fused row kernels are float32 only");
 }
 
+// a device-resident 1.0f: the weight array of the GENERAL epilogue when none is set
+static const float *device_one() {
+    static float *one = nullptr;
+    if (!one) {
+        const float v = 1.0f;
+        SA_HIP(hipMalloc((void **)&one, sizeof(float)));
+        SA_HIP(hipMemcpy(one, &v, sizeof(float), hipMemcpyHostToDevice));
+    }
+    return one;
+}
+
 template <int NW>
-static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
+static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a_in, dim3 grid) {
     static bool attr_set = false;
     if (!attr_set) {
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, false>);
@@ -429,7 +546,9 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 gr
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, true>);
         attr_set = true;
     }
-    const bool general = a.wl1.ptr != nullptr || (a.flags & F_NOBNDRY);
+    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY);
+    RowsPostArgs<float> a = a_in;
+    if (general && !a.wl1.ptr) a.wl1.ptr = device_one();   // strides are already all zero
     const dim3 block(NW * 64);
     if (a.x && general)
         hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true>), grid, block, rows_lds_bytes(NW), st, a);
@@ -452,6 +571,39 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
     SA_HIP(hipGetLastError());
     return (int64_t)grid.x * grid.y;
 }
+template <int NW>
+static void launch_prox_nw(hipStream_t st, const RowsProxArgs<float> &a_in, dim3 grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds_attr<NW>(&rows_inv_prox_fwd_kernel<NW, false>);
+        set_lds_attr<NW>(&rows_inv_prox_fwd_kernel<NW, true>);
+        attr_set = true;
+    }
+    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY);
+    RowsProxArgs<float> a = a_in;
+    if (general && !a.wl1.ptr) a.wl1.ptr = device_one();
+    const dim3 block(NW * 64);
+    if (general)
+        hipLaunchKernelGGL((rows_inv_prox_fwd_kernel<NW, true>), grid, block, rows_lds_bytes(NW), st, a);
+    else
+        hipLaunchKernelGGL((rows_inv_prox_fwd_kernel<NW, false>), grid, block, rows_lds_bytes(NW), st, a);
+}
+
+template <> int64_t launch_rows_inv_prox_fwd<float>(hipStream_t st, const RowsProxArgs<float> &a) {
+    SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
+    SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
+    const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
+    if (a.W == 256)
+        launch_prox_nw<8>(st, a, grid);
+    else
+        launch_prox_nw<16>(st, a, grid);
+    SA_HIP(hipGetLastError());
+    return (int64_t)grid.x * grid.y;
+}
+template <> int64_t launch_rows_inv_prox_fwd<double>(hipStream_t, const RowsProxArgs<double> &) {
+    throw Error(-1, "the fused row kernels are float32 only");
+}
+
 template <> int64_t launch_rows_inv_post<double>(hipStream_t, const RowsPostArgs<double> &) {
     throw Error(-1, "the fused row kernels are float32 only");
 }

@@ -161,6 +161,46 @@ class ConvBPDN(pgm.PGMDFT):
             f |= _lib.FLAG_NOBNDRY
         return f
 
+    # -- whole iteration in three launches when nothing is customised -----------------
+    _hook_names = ('on_iteration_start', 'xstep', 'ystep', 'grad_f', 'prox_step', 'rsdl',
+                   'compute_residuals', 'eval_objfn', 'obfn_dfd', 'obfn_reg', 'obfn_f',
+                   'eval_linear_approx', 'hess_quad')
+
+    def _fused_ok(self):
+        if self.opt['Backtrack'] is not None or self.stepsizepolicy is not None \
+                or self.opt['Monotone'] or not self.dev.uses_fused_rows():
+            return False
+        for name in self._hook_names:
+            if name in self.__dict__ or getattr(type(self), name) is not getattr(ConvBPDN, name):
+                return False
+        return True
+
+    def fused_iteration(self):
+        """on_iteration_start, xstep and ystep (pgm.py:835-846, :779-831) as one
+        device call (csc_pgm.h); the sums it returns serve rsdl and eval_objfn."""
+        if not self._fused_ok():
+            self._fused_sums = None
+            return False
+        tprv = self.t
+        self.t = self.momentum.update(self.var_momentum())
+        beta = (tprv - 1.) / self.t
+        stats = not self.opt['FastSolve']
+        out = self.dev.pgm_iter(self.L, float(self.lmbda) * self._wl1_scalar, beta, self._flags(),
+                                self.D.shape[0], self.D.shape[1], stats)
+        self._fused_sums = out
+        self._rl1 = abs(self._wl1_scalar) * out[_lib.PGM_L1]
+        self._cache.clear()
+        self._fcache.clear()
+        self._fcache[_lib.VAR_YFPRV] = out[_lib.PGM_FY]
+        if stats:
+            self._fcache[_lib.VAR_XF] = out[_lib.PGM_F]
+        return True
+
+    def rsdl(self):
+        if getattr(self, '_fused_sums', None) is not None:
+            return self._fused_sums[_lib.PGM_RSDL]
+        return super(ConvBPDN, self).rsdl()
+
     # -- smooth term ---------------------------------------------------------------------
     def grad_f(self, V=None):
         """GF = conj(Df)(sum_m Df V - Sf) at V (default Yf); returns the handle of
@@ -200,6 +240,8 @@ class ConvBPDN(pgm.PGMDFT):
         return (dfd + reg[0], dfd) + reg[1:]
 
     def obfn_dfd(self):
+        if getattr(self, '_fused_sums', None) is not None:
+            return self._fused_sums[_lib.PGM_DFID] / 2.0
         return self.dev.pgm_eval(_lib.VAR_XF)[_lib.PGM_DFID] / 2.0
 
     def obfn_reg(self):

@@ -91,12 +91,15 @@ class PGM(common.IterativeSolver):
         labels = ['solve', 'solve_wo_func', 'solve_wo_rsdl', 'solve_wo_btrack']
         self.timer.start(labels)
         for self.k in range(self.k, self.k + self.opt['MaxMainIter']):
-            self.on_iteration_start()
-            if self.opt['Backtrack'] is not None and self.k >= 0:
+            if self.fused_iteration():
+                pass
+            elif self.opt['Backtrack'] is not None and self.k >= 0:
+                self.on_iteration_start()
                 self.timer.stop('solve_wo_btrack')
                 self.backtrack.update(self)
                 self.timer.start('solve_wo_btrack')
             else:
+                self.on_iteration_start()
                 self.xstep()
                 self.ystep()
             self.timer.stop(['solve_wo_rsdl', 'solve_wo_btrack'])
@@ -125,6 +128,11 @@ class PGM(common.IterativeSolver):
 
     def finish_solve(self):
         pass
+
+    def fused_iteration(self):
+        """Run on_iteration_start + xstep + ystep as one device call when the
+        problem class can; return False to have the loop compose them."""
+        return False
 
     def getmin(self):
         return self.X

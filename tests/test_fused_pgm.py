@@ -1,0 +1,99 @@
+"""The fused FISTA iteration (csc_pgm.hip + csc_rows.hip: three launches, tile-major
+spectral iterates, X rebuilt on demand) against the NumPy oracle and against the
+generic composition of the same library.  Engages for float32, H and W in
+{256, 512}, even K <= 64 and default policies (no backtracking / step-size policy /
+monotone restart); anything else composes the staged calls.
+
+Tolerance: 1e-5 relative l2 against the float64 oracle after 4 iterations (observed
+5e-7); the generic float32 path agrees with the fused one to the same level.
+"""
+
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from test_fused_xstep import problem
+
+
+def make(D, S, optd, generic=False):
+    from sporco_amd.pgm import cbpdn as pc
+    if generic:
+        os.environ['SPORCO_AMD_OLD_ROWS'] = '1'
+    try:
+        return pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(optd))
+    finally:
+        os.environ.pop('SPORCO_AMD_OLD_ROWS', None)
+
+
+@pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1)])
+def test_fused_pgm_matches_oracle(backend, H, W, K, N):
+    from oracle import cbpdn_oracle as orc
+    if backend == 'hostsim' and W == 512:
+        pytest.skip("W = 512 row kernels run under the simulator in test_fused_xstep; here GPU only")
+    D, S = problem(H, W, K, N, seed=H + W)
+    optd = {'MaxMainIter': 4, 'RelStopTol': 0.0, 'L': 50.0}
+    b = make(D, S, optd)
+    assert b.dev.uses_fused_rows() and b._fused_ok()
+    X = b.solve()
+    ref = orc.pgm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
+                        dtype=np.float64, maxiter=4, L=50.0, rel_tol=0.0)
+    assert rel_l2(X, ref['X']) < 1e-5
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
+    # the spectral iterates come back in the reference layout
+    assert rel_l2(b.Xf, np.fft.rfftn(ref['X'], axes=(0, 1))) < 1e-5
+    b0 = make(D, S, optd, generic=True)
+    assert not b0.dev.uses_fused_rows()
+    b0.solve()
+    for name in ('Yf', 'Xfprv', 'Yfprv'):
+        assert rel_l2(getattr(b, name), getattr(b0, name)) < 1e-5, name
+    # X is exactly sparse (it is the prox output, not a transform of Xf)
+    assert np.count_nonzero(X) == np.count_nonzero(b0.X)
+    # continue after the layout round trip
+    b.solve()
+    b0.solve()
+    assert rel_l2(b.X, b0.X) < 1e-5
+
+
+def test_fused_pgm_options_and_pickle(backend):
+    """Linear momentum, NonNegCoef + L1Weight array (GENERAL prox), FastSolve, pickling."""
+    from sporco_amd.pgm.momentum import MomentumLinear
+    H, W, K, N = 256, 256, 4, (1 if backend == 'hostsim' else 2)
+    D, S = problem(H, W, K, N, seed=77)
+    rng = np.random.RandomState(5)
+    wl1 = (0.5 + rng.rand(H, W, 1, 1, K)).astype(np.float32)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L': 60.0, 'NonNegCoef': True, 'L1Weight': wl1,
+            'Momentum': MomentumLinear()}
+    b, b0 = make(D, S, optd), make(D, S, optd, generic=True)
+    X, X0 = b.solve(), b0.solve()
+    assert b._fused_ok() and rel_l2(X, X0) < 1e-5 and np.all(X >= 0)
+    for f in ('ObjFun', 'RegL1', 'Rsdl'):
+        assert rel_l2(getattr(b.getitstat(), f), getattr(b0.getitstat(), f)) < 1e-5, f
+    b2 = pickle.loads(pickle.dumps(b))
+    b.solve()
+    b2.solve()
+    assert np.array_equal(b.X, b2.X)
+    if backend == 'hostsim':
+        return       # (keeps the CPU suite short; the rest runs on the GPU)
+    # FastSolve: no statistics are read back
+    optf = dict(optd, FastSolve=True)
+    bf, bf0 = make(D, S, optf), make(D, S, optf, generic=True)
+    assert rel_l2(bf.solve(), bf0.solve()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_backtracking_still_composes(gpu_backend):
+    """A policy the fused call does not cover falls back to the staged composition."""
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    H, W, K, N = 256, 256, 4, 1
+    D, S = problem(H, W, K, N, seed=8)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L': 1.0, 'Backtrack': BacktrackStandard()}
+    b = make(D, S, optd)
+    assert not b._fused_ok()
+    b0 = make(D, S, optd, generic=True)
+    assert rel_l2(b.solve(), b0.solve()) < 1e-5
+    assert rel_l2(b.getitstat().L, b0.getitstat().L) < 1e-6

@@ -114,6 +114,8 @@ def test_three_launch_iteration_matches_oracle(backend, H, W, K, N):
     # the previous iterate, and Xf from X
     assert rel_l2(b.X, ref['X']) < 1e-5
     assert rel_l2(b.Xf, np.fft.rfftn(ref['X'], axes=(0, 1))) < 1e-5
+    if backend == 'hostsim' and W == 512:
+        return       # (keeps the CPU suite short)
     # the solver keeps going from where it stopped (admm.py:331)
     b.solve()
     ref8 = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
