@@ -230,6 +230,9 @@ template <typename T> struct Csc : CscBase {
     sporco_amd_admm_params last_p;
     // fused PGM iteration (csc_pgm.h): Xf, Yf, Xfprv, Yfprv tile-major; X of the last
     // iteration is prox(irfft_W(work)) and is rebuilt on demand with `last_pgm`
+    bool zf_tiled = false;          // VAR_ZF holds the tile-major spectrum (fused D-step)
+    cx<T> *gpart = nullptr;         // group partials of the tiled D-step gradient
+    int ccmod_groups = 1;
     bool pgm_tiled = false, pgm_x_stale = false;
     sporco_amd_pgm_params last_pgm;
     double *part_pgm = nullptr;
@@ -298,7 +301,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
-                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm,
+                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -455,6 +458,11 @@ template <typename T> struct Csc : CscBase {
     // holds a tile-major intermediate, and Xf = rfftn(X) is rebuilt on demand.
     void need_natural(int var) {
         if (pgm_tiled && is_pgm_iterate(var)) pgm_leave_tiled();
+        if (var == SPORCO_AMD_VAR_ZF && zf_tiled) {
+            if (pgm_x_stale) materialize_x();   // `work` is about to be used as scratch
+            zf_tiled = false;
+            relayout(SPORCO_AMD_VAR_ZF, false);
+        }
         if (var == SPORCO_AMD_VAR_XF && xf_tiled) {
             xf_tiled = false;
             fwd2(rv(SPORCO_AMD_VAR_X), nullptr, T(0), cv(SPORCO_AMD_VAR_XF), P);
@@ -499,6 +507,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void set_weight(int which, const void *w, const int64_t shape[5]) override {
+        before_state_change();   // a pending X of the fused PGM step depends on the weights
         Weight<T> &dst = which == 0 ? wl1 : wl21;
         T *&buf = which == 0 ? wl1_buf : wl21_buf;
         if (buf) {
@@ -529,6 +538,7 @@ template <typename T> struct Csc : CscBase {
 
     void upload(int var, const void *src) override {
         if (is_pgm_iterate(var)) pgm_leave_tiled();
+        if (var == SPORCO_AMD_VAR_ZF) zf_tiled = false;
         if (var == SPORCO_AMD_VAR_X) {
             x_written();
         } else if (var == SPORCO_AMD_VAR_XF) {
@@ -1097,6 +1107,48 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
+        if (rows_ok) {
+            // rows then columns, register-resident, straight into the tile-major layout
+            RowsFwdArgs<T> ra;
+            ra.y = rv(var);
+            ra.u = nullptr;
+            ra.s2 = T(0);
+            ra.t = cv(SPORCO_AMD_VAR_ZF);
+            ra.twA = twRows;
+            ra.H = H;
+            ra.W = W;
+            ra.CN = CN;
+            ra.K = K;
+            ra.P = P;
+            {
+                ProfScope ps(prof, PS_ROWS_FWD);
+                launch_rows_fwd<T>(st, ra);
+            }
+            PgmColsArgs<T> ca;
+            ca.yf = nullptr;
+            ca.xf_old = nullptr;
+            ca.t = cv(SPORCO_AMD_VAR_ZF);
+            ca.yf_new = nullptr;
+            ca.dft = nullptr;
+            ca.sft = nullptr;
+            ca.twA = twA;
+            ca.twB = twB;
+            ca.inv_L = T(0);
+            ca.beta = T(0);
+            ca.H = H;
+            ca.W = W;
+            ca.CN = CN;
+            ca.K = K;
+            ca.want_stats = 0;
+            ca.partials = nullptr;
+            {
+                ProfScope ps(prof, PS_PGM_FFT_MOM);
+                launch_cols_fft<T>(st, ca);
+            }
+            zf_tiled = true;
+            return;
+        }
+        zf_tiled = false;
         fwd2(rv(var), nullptr, T(0), cv(SPORCO_AMD_VAR_ZF), P);
     }
 
@@ -1104,6 +1156,37 @@ template <typename T> struct Csc : CscBase {
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var),
                    "ccmod_grad needs a dictionary-sized frequency-domain variable");
+        if (zf_tiled) {
+            // fixed groups of tiles per workgroup; enough groups to fill the chip
+            if (!gpart) {
+                ccmod_groups = (int)ceil_div(768, Wf);
+                if (ccmod_groups > CN) ccmod_groups = CN;
+                if (ccmod_groups > 8) ccmod_groups = 8;
+                SA_HIP(hipMalloc((void **)&gpart, sizeof(cx<T>) * npix * K * ccmod_groups));
+            }
+            CcmodTiledArgs<T> ga;
+            ga.zf = cv(SPORCO_AMD_VAR_ZF);
+            ga.d = cv(var);
+            ga.sft = sft;
+            ga.gpart = write_grad ? gpart : nullptr;
+            ga.H = H;
+            ga.W = W;
+            ga.CN = CN;
+            ga.K = K;
+            ga.G = ccmod_groups;
+            ga.partials = part_a;
+            int64_t nwg;
+            {
+                ProfScope ps(prof, PS_PGM);
+                nwg = launch_ccmod_grad_tiled<T>(st, ga);
+                if (write_grad)
+                    launch_sum_groups<T>(st, gpart, cv(SPORCO_AMD_VAR_DGF), npix * K, ccmod_groups);
+            }
+            const int slots[3] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_HESS};
+            const double scales[3] = {0.5, 1.0 / ((double)H * W), 1.0};
+            finalize(part_a, (int)nwg, 4, 3, slots, scales, out_dev);
+            return;
+        }
         int nb;
         {
             ProfScope ps(prof, PS_PGM);

@@ -34,6 +34,29 @@ template <typename T> struct PgmColsArgs {
 };
 
 template <typename T> int64_t launch_pgm_grad_ifft(hipStream_t st, const PgmColsArgs<T> &a);
+// t <- FFT_H(t) only (row spectra -> full tile-major spectrum, in place): uses t, twA, H, W, CN, K
+template <typename T> int64_t launch_cols_fft(hipStream_t st, const PgmColsArgs<T> &a);
+
+// Dictionary-update gradient on a tile-major coefficient spectrum (pgm/ccmod.py:295-317):
+//     r[n, f]  = sum_k zf[n, f, k] d[f, k] - sf[n, f]
+//     g[f, k]  = sum_n conj(zf[n, f, k]) r[n, f]
+// One workgroup owns a row frequency wf and a fixed group of the C*N tiles, so the sum
+// over images is accumulated in registers in a fixed order; the G group partials are
+// added by launch_sum_groups.  d and the gradient are in the reference layout (H, Wf, K).
+template <typename T> struct CcmodTiledArgs {
+    const cx<T> *zf;     // tile-major (Wf, CN, H, K)
+    const cx<T> *d;      // (H, Wf, K)
+    const cx<T> *sft;    // tile-major (Wf, CN, H)
+    cx<T> *gpart;        // (G, H, Wf, K), or null: sums only
+    int H, W, CN, K, G;
+    double *partials;    // per workgroup 4 doubles: |r|^2, pw |r|^2, |r + sf|^2, 0
+};
+template <typename T> bool ccmod_tiled_supported(int H, int K);
+// returns the number of workgroups (rows of `partials`)
+template <typename T> int64_t launch_ccmod_grad_tiled(hipStream_t st, const CcmodTiledArgs<T> &a);
+// out[i] = sum_g part[g * n + i]
+template <typename T>
+void launch_sum_groups(hipStream_t st, const cx<T> *part, cx<T> *out, int64_t n, int G);
 template <typename T> int64_t launch_pgm_fft_momentum(hipStream_t st, const PgmColsArgs<T> &a);
 
 }  // namespace sporco_amd

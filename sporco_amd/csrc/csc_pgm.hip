@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
 // Xf' = FFT_H(T');  Yf' = Xf' + beta (Xf' - Xf);  sums of |Xf' - Yf|^2 and f(Xf')
 // (sporco/pgm/pgm.py:803, :815-831; sporco/pgm/cbpdn.py:314-345)
 // ---------------------------------------------------------------------------
-template <int NW, int LP, int KC, bool STATS>
+// PLAIN: forward transform only (no momentum, no sums): t <- FFT_H(t)
+template <int NW, int LP, int KC, bool STATS, bool PLAIN = false>
 __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmColsArgs<float> a) {
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
@@ -167,9 +168,9 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     const int tile = wf * a.CN + slot % a.CN;
     const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
     const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Xo = make_rsrc(a.xf_old + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Yo = make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Yn = make_rsrc(a.yf_new + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Xo = PLAIN ? Tb : make_rsrc(a.xf_old + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Yo = PLAIN ? Tb : make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Yn = PLAIN ? Tb : make_rsrc(a.yf_new + (int64_t)tile * H * K, tbytes);
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
     const int ko = (w * K + k) * (int)sizeof(cf);
     const cf *S = a.sft + (int64_t)tile * H + w;
@@ -215,8 +216,13 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                xn4[e] = kv ? buf_load_cf(Xo, ko, fo * K * (int)sizeof(cf)) : zero;
-                yn4[e] = kv ? buf_load_cf(Yo, ko, fo * K * (int)sizeof(cf)) : zero;
+                if constexpr (!PLAIN) {
+                    xn4[e] = kv ? buf_load_cf(Xo, ko, fo * K * (int)sizeof(cf)) : zero;
+                    yn4[e] = kv ? buf_load_cf(Yo, ko, fo * K * (int)sizeof(cf)) : zero;
+                } else {
+                    xn4[e] = zero;
+                    yn4[e] = zero;
+                }
             }
         };
         prefetch(std::integral_constant<int, 0>{});
@@ -262,8 +268,10 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                 const cf yn = xn + cscale(xn - xo[e], beta);
                 if (kv) {
                     buf_store_cf(Tb, ko, fo * K * (int)sizeof(cf), xn);
-                    buf_store_cf(Yn, ko, fo * K * (int)sizeof(cf), yn);
-                    rs += cabs2(xn - yo[e]);
+                    if constexpr (!PLAIN) {
+                        buf_store_cf(Yn, ko, fo * K * (int)sizeof(cf), yn);
+                        rs += cabs2(xn - yo[e]);
+                    }
                 }
             }
         });
@@ -274,11 +282,112 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
         }
     });
 
+    if constexpr (PLAIN) return;
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
     const double rsw = wave_sum((double)rs);   // rs is per lane (all filters); fsum is wave-uniform
     double acc[4] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
                      k == 0 ? (double)fsum : 0.0, 0.0};
     block_sum_store<4>(acc, scratch, a.partials + (int64_t)tile * 4);
+}
+
+// ---------------------------------------------------------------------------
+// dictionary-update gradient on tile-major coefficient spectra (see csc_pgm.h)
+// ---------------------------------------------------------------------------
+template <int NW, int KC>
+__global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTiledArgs<float> a) {
+    constexpr int N1 = 32, H = N1 * NW;
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KC ? KC : a.K;
+    const bool kv = KC == 64 ? true : k < K;
+    const int Wf = a.W / 2 + 1;
+    const int g = blockIdx.x % a.G, wf = blockIdx.x / a.G;
+    const int cng = (a.CN + a.G - 1) / a.G;
+    const int cn0 = g * cng, cn1 = (cn0 + cng < a.CN) ? cn0 + cng : a.CN;
+    const cf zero = mk<float>(0.f, 0.f);
+    double *scratch = dyn_lds<double>();
+    // rows f = NW i + w of this thread; d(f, wf, k) is re-read per tile (L2-resident)
+    const uint32_t dbytes = (uint32_t)((int64_t)H * Wf * K * sizeof(cf));
+    const BufRsrc Db = make_rsrc(a.d, dbytes);
+    const int dko = ((w * Wf + wf) * K + k) * (int)sizeof(cf);
+    const int drow = NW * Wf * K * (int)sizeof(cf);   // from row f to row f + NW
+    const int ko = (w * K + k) * (int)sizeof(cf);
+    cf acc[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) acc[i] = zero;
+    float s_r2 = 0.f, s_q2 = 0.f;
+    int kov = ko, dkov = dko, token = 0;   // offsets routed through the register fences below
+    for (int cn = cn0; cn < cn1; ++cn) {
+        const int tile = wf * a.CN + cn;
+        const BufRsrc Zb = make_rsrc(a.zf + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
+        const cf *S = a.sft + (int64_t)tile * H + w;
+        // 4 rows at a time; the next 4 rows of Zf and d are in flight meanwhile.  The
+        // offsets of prefetch c+1 are tied (empty asm) to a result of chunk c-1, which
+        // keeps the compiler from hoisting all 64 loads above the arithmetic.
+        cf zn[4], dn[4];
+        auto prefetch = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * c + e;
+                zn[e] = kv ? buf_load_cf(Zb, kov, NW * i * K * (int)sizeof(cf)) : zero;
+                dn[e] = kv ? buf_load_cf(Db, dkov, i * drow) : zero;
+            }
+        };
+        prefetch(std::integral_constant<int, 0>{});
+        static_for<N1 / 4>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            cf z[4], d[4], q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z[e] = zn[e];
+                d[e] = dn[e];
+            }
+            if constexpr (c + 1 < N1 / 4) {
+                if constexpr (c > 0) {
+                    float &dep = acc[4 * c - 1].re;
+                    int &ko_ = kov, &dko_ = dkov;
+                    SA_VGPR_FENCE3(dep, ko_, dko_);
+                }
+                prefetch(std::integral_constant<int, c + 1>{});
+            }
+            inner4(d, z, k, q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * c + e;
+                cf sv;
+                sa_uload2(reinterpret_cast<const float *>(S + NW * i), sv.re, sv.im);
+                const cf r = q[e] - sv;
+                s_r2 += cabs2(r);
+                s_q2 += cabs2(q[e]);
+                acc[i] = acc[i] + cmulc(z[e], r);
+            }
+        });
+        {
+            float &dep = acc[N1 - 1].re;
+            SA_VGPR_FENCE3(dep, kov, token);
+        }
+    }
+    if (a.gpart && kv) {
+        cf *gp = a.gpart + (int64_t)g * H * Wf * K;
+#pragma unroll
+        for (int i = 0; i < N1; ++i) gp[((int64_t)(NW * i + w) * Wf + wf) * K + k] = acc[i];
+    }
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    double accd[4] = {k == 0 ? (double)s_r2 : 0.0, k == 0 ? (double)s_r2 * pw : 0.0,
+                      k == 0 ? (double)s_q2 : 0.0, 0.0};
+    block_sum_store<4>(accd, scratch, a.partials + (int64_t)blockIdx.x * 4);
+}
+
+__global__ void __launch_bounds__(256) sum_groups_kernel(const cf *__restrict__ part,
+                                                         cf *__restrict__ out, int64_t n, int G) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        cf s = part[i];
+        for (int g = 1; g < G; ++g) s = s + part[(int64_t)g * n + i];
+        out[i] = s;
+    }
 }
 
 template <typename F> void set_lds(F kernel, size_t bytes) {
@@ -338,6 +447,69 @@ template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmCols
     }
     SA_HIP(hipGetLastError());
     return (int64_t)(a.W / 2 + 1) * a.CN;
+}
+
+template <int NW, int LP, int KC> static void launch_plain(hipStream_t st, const PgmColsArgs<float> &a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, false, true>, pgm_lds_bytes(NW, LP));
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
+    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, false, true>), dim3(grid), dim3(NW * 64),
+                       pgm_lds_bytes(NW, LP), st, a);
+}
+
+template <> int64_t launch_cols_fft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
+    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
+               "shape not handled by the fused column kernels");
+    if (a.H == 256) {
+        if (a.K == 64) launch_plain<8, 2, 64>(st, a);
+        else launch_plain<8, 2, 0>(st, a);
+    } else {
+        if (a.K == 64) launch_plain<16, 1, 64>(st, a);
+        else launch_plain<16, 1, 0>(st, a);
+    }
+    SA_HIP(hipGetLastError());
+    return (int64_t)(a.W / 2 + 1) * a.CN;
+}
+template <> int64_t launch_cols_fft<double>(hipStream_t, const PgmColsArgs<double> &) {
+    throw Error(-1, "the fused column kernels are float32 only");
+}
+
+template <> bool ccmod_tiled_supported<float>(int H, int K) {
+    return (H == 256 || H == 512) && K >= 1 && K <= 64;
+}
+template <> bool ccmod_tiled_supported<double>(int, int) { return false; }
+
+template <> int64_t launch_ccmod_grad_tiled<float>(hipStream_t st, const CcmodTiledArgs<float> &a) {
+    SA_REQUIRE(ccmod_tiled_supported<float>(a.H, a.K), "shape not handled by the tiled D-step kernel");
+    const unsigned grid = (unsigned)((a.W / 2 + 1) * a.G);
+    const size_t lds = sizeof(double) * 4 * 16;
+    if (a.H == 256) {
+        if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 64>), dim3(grid), dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0>), dim3(grid), dim3(512), lds, st, a);
+    } else {
+        if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 64>), dim3(grid), dim3(1024), lds, st, a);
+        else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 0>), dim3(grid), dim3(1024), lds, st, a);
+    }
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+template <> int64_t launch_ccmod_grad_tiled<double>(hipStream_t, const CcmodTiledArgs<double> &) {
+    throw Error(-1, "the tiled D-step kernel is float32 only");
+}
+
+template <>
+void launch_sum_groups<float>(hipStream_t st, const cx<float> *part, cx<float> *out, int64_t n, int G) {
+    int64_t grid = ceil_div(n, 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(sum_groups_kernel, dim3((unsigned)grid), dim3(256), 0, st, part, out, n, G);
+    SA_HIP(hipGetLastError());
+}
+template <>
+void launch_sum_groups<double>(hipStream_t, const cx<double> *, cx<double> *, int64_t, int) {
+    throw Error(-1, "float32 only");
 }
 
 template <> int64_t launch_pgm_grad_ifft<double>(hipStream_t, const PgmColsArgs<double> &) {

@@ -279,7 +279,9 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     // ---- spatial side: z[n1] = (Y - s2 U)(h, x = NW n1 + w, p..p+1) -------------------
     const int64_t rowoff = (int64_t)h * W * a.P;
     const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
-    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes), Ub = make_rsrc(a.u + rowoff, rowbytes);
+    // (u may be null: a zero-length buffer then reads as zeros)
+    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes);
+    const BufRsrc Ub = a.u ? make_rsrc(a.u + rowoff, rowbytes) : make_rsrc(a.y, 0u);
     const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;  // masked lanes read 0
     const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
     const float s2 = a.s2;
