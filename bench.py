@@ -60,6 +60,7 @@ def kernel_bytes(H, W, P, itemsize):
         'admm_post': 5 * E,                  # read X, Y, U; write Y, U
         'rows_fwd': 2 * E + EF,              # read Y, U; write tile-major row spectra
         'rows_inv_post': EF + 4 * E,         # read spectra, Y, U; write Y, U (X stays in registers)
+        'rows_inv_post_emit': 2 * EF + 4 * E,  # ... and write the next iteration's row spectra
     }
 
 

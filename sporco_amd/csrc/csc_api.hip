@@ -32,6 +32,7 @@ enum ProfSlot {
     PS_FUSED_COLS,
     PS_ROWS_FWD,
     PS_ROWS_INV_POST,
+    PS_ROWS_INV_POST_EMIT,
     PS_PGM_GRAD_IFFT,
     PS_PGM_ROWS_PROX,
     PS_PGM_FFT_MOM,
@@ -43,6 +44,7 @@ enum ProfSlot {
 static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_solve",
                                            "fft_c2c_cols_inv", "fft_c2r_rows",     "admm_post",
                                            "fused_cols_sm",    "rows_fwd",         "rows_inv_post",
+                                           "rows_inv_post_emit",
                                            "pgm_grad_ifft",    "pgm_rows_prox",    "pgm_fft_momentum",
                                            "finalize",         "pgm_elementwise",  "other"};
 
@@ -227,6 +229,10 @@ template <typename T> struct Csc : CscBase {
     // X-step on it with the parameters of the iteration (`last_p`).
     T *y_alt = nullptr, *u_alt = nullptr;
     bool x_stale = false, x_invalid = false;
+    // t_ready: the Xf buffer already holds rows_fwd(Y, U, s = 1) of the current
+    // iterate, emitted by the previous rows_inv_post on the bet that rho stays put
+    bool t_ready = false;
+    int stable_run = 0;   // consecutive fused iterations entered with an unchanged rho
     sporco_amd_admm_params last_p;
     // fused PGM iteration (csc_pgm.h): Xf, Yf, Xfprv, Yfprv tile-major; X of the last
     // iteration is prox(irfft_W(work)) and is rebuilt on demand with `last_pgm`
@@ -405,6 +411,7 @@ template <typename T> struct Csc : CscBase {
         }
         if (!x_stale) return;
         x_stale = false;
+        t_ready = false;   // the Xf buffer is about to be reused
         sporco_amd_admm_params q = last_p;
         q.flags = 0;
         launch_rows_fwd_on(y_alt, u_alt, (T)q.u_scale);
@@ -421,6 +428,7 @@ template <typename T> struct Csc : CscBase {
     }
     void before_state_change() {
         if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
+        t_ready = false;
     }
     void x_written() {
         x_stale = false;
@@ -457,6 +465,7 @@ template <typename T> struct Csc : CscBase {
     // VAR_XF as callers know it (natural layout): after a fused X-step the buffer
     // holds a tile-major intermediate, and Xf = rfftn(X) is rebuilt on demand.
     void need_natural(int var) {
+        if (var == SPORCO_AMD_VAR_XF) t_ready = false;
         if (pgm_tiled && is_pgm_iterate(var)) pgm_leave_tiled();
         if (var == SPORCO_AMD_VAR_ZF && zf_tiled) {
             if (pgm_x_stale) materialize_x();   // `work` is about to be used as scratch
@@ -618,9 +627,18 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMalloc((void **)&y_alt, sizeof(T) * E));
             SA_HIP(hipMalloc((void **)&u_alt, sizeof(T) * E));
         }
-        launch_rows_fwd_on(Y, U, (T)p.u_scale);
+        // rows_fwd, unless the previous iteration already left its result behind
+        if (!(t_ready && p.u_scale == 1.0)) launch_rows_fwd_on(Y, U, (T)p.u_scale);
+        t_ready = false;
         run_fused_cols(p, nullptr);
+        // Bet on an unchanged rho only once it has stayed put for two updates in a row:
+        // while AutoRho is still moving it almost every iteration a lost bet costs one
+        // extra pass, a won one saves three (rows_fwd of the next iteration).
+        stable_run = p.u_scale == 1.0 ? stable_run + 1 : 0;
+        const bool emit = stable_run >= 2 && !std::getenv("SPORCO_AMD_NO_SPECULATION");
         RowsPostArgs<T> pa;
+        pa.twA = twRows;
+        pa.t_next = emit ? Xf : nullptr;
         pa.t = Xf;
         pa.twW = planW.tw<T>();
         pa.y = Y;
@@ -645,7 +663,7 @@ template <typename T> struct Csc : CscBase {
         pa.partials = part_rows;
         int64_t nt;
         {
-            ProfScope ps(prof, PS_ROWS_INV_POST);
+            ProfScope ps(prof, emit ? PS_ROWS_INV_POST_EMIT : PS_ROWS_INV_POST);
             nt = launch_rows_inv_post<T>(st, pa);
         }
         if (p.flags & (F_RESID | F_OBJ)) {
@@ -671,6 +689,7 @@ template <typename T> struct Csc : CscBase {
             x_stale = true;
             x_invalid = p.flags & F_NO_X;
         }
+        t_ready = emit;
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
     }
 
@@ -695,6 +714,7 @@ template <typename T> struct Csc : CscBase {
     void xstep_impl(const sporco_amd_admm_params &p, double *out_dev) {
         require_ready();
         x_written();
+        t_ready = false;
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         if (fused && !(p.flags & F_XRRS)) {
@@ -905,6 +925,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
         require_ready();
         if (!rows_ok) throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
+        t_ready = false;
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         if (!part_pgm) SA_HIP(hipMalloc((void **)&part_pgm, sizeof(double) * 4 * (int64_t)Wf * CN));
         if (!pgm_tiled) {

@@ -36,6 +36,9 @@ template <typename T> struct RowsFwdArgs {
 template <typename T> struct RowsPostArgs {
     const cx<T> *t;    // in: tile-major column-inverse-transformed solution, unnormalised
     const cx<T> *twW;  // exp(-2 pi i t / W), t in [0, W)
+    const cx<T> *twA;  // rows_twiddles table (only read when t_next is set)
+    cx<T> *t_next;     // optional: also emit rfft_W(Y' - U') tile-major, i.e. the next
+                       // iteration's rows_fwd for an unchanged rho; may alias t
     const T *y, *u;    // in: real (H, W, P)
     T *y_out, *u_out;  // out (may alias y, u: every element is read and written by one thread)
     T *x;              // out (optional, may be null): X = irfftn(Xf)

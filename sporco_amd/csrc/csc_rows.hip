@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // ---------------------------------------------------------------------------
 // rows_inv_post: X = irfft_W(T) / (H W); relax, shrink, dual update, sums
 // ---------------------------------------------------------------------------
-template <int NW, bool WRITE_X, bool GENERAL>
+template <int NW, bool WRITE_X, bool GENERAL, bool EMIT_T>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
     constexpr int NG = 2;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
     const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
     float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f;
-    constexpr int B = 4;   // pixels per batch (Y, U of the next batch are in flight)
+    constexpr int B = EMIT_T ? 2 : 4;   // pixels per batch (Y, U of the next batch are in flight)
     cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll
@@ -401,8 +401,22 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
             buf_store_cf(Yo, voff, soff, mk<float>(yn[0], yn[1]));
             buf_store_cf(Uo, voff, soff, mk<float>(un[0], un[1]));
             if (WRITE_X) buf_store_cf(Xb, voff, soff, mk<float>(xs[0], xs[1]));
+            if (EMIT_T) v[n1] = mk<float>(yn[0] - un[0], yn[1] - un[1]);
         }
     });
+
+    // (pin the six sums here: left alone, the compiler sinks their accumulation below the
+    // transform that follows and keeps every per-element term alive until then)
+    SA_VGPR_FENCE3(s_r2, s_s2, s_x2);
+    SA_VGPR_FENCE3(s_y2, s_u2, s_l1);
+    if (EMIT_T) {
+        // Speculation on an unchanged rho: the row spectra of Y' - U' that the next
+        // iteration's rows_fwd would compute from these very values, stored over the
+        // units this thread consumed (same spectral-side ownership: in place is safe).
+        reg_fence<N1>(v, 0, token);
+        spatial_to_spectral<NW>(v, a.twA, a.t_next, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+        __syncthreads();   // the reduction scratch below sits next to the exchange buffer
+    }
 
     // masked lanes contributed zeros everywhere except possibly the threshold of 0: their
     // inputs are all zero, so every term above is exactly 0
@@ -538,14 +552,14 @@ static const float *device_one() {
     return one;
 }
 
-template <int NW>
+template <int NW, bool EMIT>
 static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a_in, dim3 grid) {
     static bool attr_set = false;
     if (!attr_set) {
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, false>);
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, false>);
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, true>);
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, true>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, false, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, false, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, true, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, true, EMIT>);
         attr_set = true;
     }
     const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY);
@@ -553,26 +567,30 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a_in, dim3
     if (general && !a.wl1.ptr) a.wl1.ptr = device_one();   // strides are already all zero
     const dim3 block(NW * 64);
     if (a.x && general)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true>), grid, block, rows_lds_bytes(NW), st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
     else if (a.x)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, false>), grid, block, rows_lds_bytes(NW), st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, false, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
     else if (general)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, true>), grid, block, rows_lds_bytes(NW), st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, true, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
     else
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, false>), grid, block, rows_lds_bytes(NW), st, a);
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, false, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
 }
 
 template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostArgs<float> &a) {
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
-    if (a.W == 256)
-        launch_post_nw<8>(st, a, grid);
-    else
-        launch_post_nw<16>(st, a, grid);
+    if (a.W == 256) {
+        if (a.t_next) launch_post_nw<8, true>(st, a, grid);
+        else launch_post_nw<8, false>(st, a, grid);
+    } else {
+        if (a.t_next) launch_post_nw<16, true>(st, a, grid);
+        else launch_post_nw<16, false>(st, a, grid);
+    }
     SA_HIP(hipGetLastError());
     return (int64_t)grid.x * grid.y;
 }
+
 template <int NW>
 static void launch_prox_nw(hipStream_t st, const RowsProxArgs<float> &a_in, dim3 grid) {
     static bool attr_set = false;

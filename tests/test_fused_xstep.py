@@ -157,3 +157,25 @@ def test_no_x_hint_and_pickle(backend):
     with pytest.raises(_lib.BackendError):
         b.X
     assert np.all(np.isfinite(b.Y)) and np.any(b.Y != 0)     # Y stays available
+
+
+def test_speculative_rows_fwd_is_bit_identical(backend):
+    """With rho unchanged, rows_inv_post also emits the next iteration's rows_fwd output
+    (two passes fewer per iteration); the iterates must not change by a single bit."""
+    H, W, K, N = 256, 256, 4, 1
+    D, S = problem(H, W, K, N, seed=91)
+    optd = {'MaxMainIter': 4, 'RelStopTol': 0.0, 'rho': 1.5, 'AutoRho': {'Enabled': False}}
+    b, Y = solve(D, S, optd)
+    os.environ['SPORCO_AMD_NO_SPECULATION'] = '1'
+    try:
+        b0, Y0 = solve(D, S, optd)
+    finally:
+        os.environ.pop('SPORCO_AMD_NO_SPECULATION', None)
+    assert np.array_equal(Y, Y0) and np.array_equal(b.U, b0.U) and np.array_equal(b.X, b0.X)
+    assert np.array_equal(np.asarray(b.getitstat().ObjFun), np.asarray(b0.getitstat().ObjFun))
+    # a dictionary change invalidates the speculated spectra
+    D2 = D[..., ::-1].copy()
+    for s in (b, b0):
+        s.setdict(D2.reshape(s.cri.shpD))
+        s.solve()
+    assert np.array_equal(b.Y, b0.Y)
