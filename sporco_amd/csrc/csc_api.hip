@@ -416,10 +416,7 @@ template <typename T> struct Csc : CscBase {
         q.flags = 0;
         launch_rows_fwd_on(y_alt, u_alt, (T)q.u_scale);
         run_fused_cols(q, nullptr);
-        ProfScope ps(prof, PS_FFT_C2R);
-        fft_c2r<T>(st, planW, cv(SPORCO_AMD_VAR_XF), rv(SPORCO_AMD_VAR_X), H, P, K,
-                   (int64_t)CN * H * K, (int64_t)W * P, P, T(1.0 / ((double)H * (double)W)), K,
-                   (int64_t)H * K);
+        rows_inverse_to(rv(SPORCO_AMD_VAR_X));
     }
     // call before reading `var` / before changing anything X depends on
     void before_read(int var) {
@@ -693,6 +690,32 @@ template <typename T> struct Csc : CscBase {
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
     }
 
+    // X = irfft_W(tile-major spectrum in the Xf buffer) / (H W): the row pass of
+    // rows_inv_prox_fwd with a zero threshold (soft(v, 0) = v) and no forward half
+    void rows_inverse_to(T *Xout) {
+        RowsProxArgs<T> ra;
+        ra.t_in = cv(SPORCO_AMD_VAR_XF);
+        ra.t_out = nullptr;
+        ra.x = Xout;
+        ra.twA = twRows;
+        ra.twW = planW.tw<T>();
+        ra.scale = T(1.0 / ((double)H * (double)W));
+        ra.thr = T(0);
+        ra.flags = 0;
+        ra.H = H;
+        ra.W = W;
+        ra.C = C;
+        ra.N = N;
+        ra.K = K;
+        ra.dH = 1;
+        ra.dW = 1;
+        ra.P = P;
+        ra.wl1 = Weight<T>();
+        ra.partials = part_rows;
+        ProfScope ps(prof, PS_FFT_C2R);
+        launch_rows_inv_prox_fwd<T>(st, ra);
+    }
+
     void launch_rows_fwd_on(const T *Yin, const T *Uin, T s2) {
         RowsFwdArgs<T> ra;
         ra.y = Yin;
@@ -721,6 +744,13 @@ template <typename T> struct Csc : CscBase {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
             const int64_t tline = (int64_t)CN * H * K, tgrp = (int64_t)H * K;
+            if (rows_ok) {
+                // register-resident row passes around it (ConvBPDNJoint, staged callers)
+                launch_rows_fwd_on(Y, U, (T)p.u_scale);
+                run_fused_cols(p, out_dev);
+                rows_inverse_to(X);
+                return;
+            }
             {
                 ProfScope ps(prof, PS_FFT_R2C);
                 fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, Xf, H, P, (int64_t)W * P, P, K, tline, K,

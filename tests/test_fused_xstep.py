@@ -179,3 +179,19 @@ def test_speculative_rows_fwd_is_bit_identical(backend):
         s.setdict(D2.reshape(s.cri.shpD))
         s.solve()
     assert np.array_equal(b.Y, b0.Y)
+
+
+def test_joint_at_fused_row_sizes(backend):
+    """ConvBPDNJoint where the row kernels engage too (X-step through rows_fwd / fused
+    columns / row inverse, l2,1 epilogue generic)."""
+    from oracle import cbpdn_oracle as orc
+    H, W, K, N, C = 256, 256, 4, 1, 3
+    D, S = problem(H, W, K, N, seed=15, C=C)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0}
+    b, Y = solve(D, S, optd, joint=True)
+    assert b._dev.uses_fused_rows()
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, C, N, 1), 0.05, mu=0.02,
+                         dtype=np.float64, maxiter=3, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 1e-5
+    assert rel_l2(b.X, ref['X']) < 1e-5
+    assert rel_l2(b.getitstat().ObjFun, ref['ObjFun']) < 1e-5
