@@ -101,7 +101,8 @@ def load(path=None):
     never passes it.
     """
     global _lib, _lib_path
-    path = os.path.abspath(path or _DEFAULT_PATH)
+    # (SPORCO_AMD_LIBRARY: an alternative hipcc build of the same sources, for A/B timing)
+    path = os.path.abspath(path or os.environ.get('SPORCO_AMD_LIBRARY') or _DEFAULT_PATH)
     if not os.path.exists(path):
         raise BackendError(
             "sporco_amd: HIP library %s not found. Build it with "

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);  // f - w
-                dn[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                 sa_uload2(reinterpret_cast<const float *>(S + fo), sn[e].re, sn[e].im);
                 gn[e] = sa_uload(G + fo);
             }

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                dd[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                dd[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                 sa_uload2(reinterpret_cast<const float *>(S + fo), sv[e].re, sv[e].im);
             }
             inner4(dd, &u[NW * jl + 4 * c], k, qq);
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                    dd[e] = kv ? buf_load_cf(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                    dd[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                     sa_uload2(reinterpret_cast<const float *>(S + fo), sv[e].re, sv[e].im);
                 }
                 inner4(dd, &u[NW * jl + 4 * c], k, qq);
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * c + e;
                 zn[e] = kv ? buf_load_cf(Zb, kov, NW * i * K * (int)sizeof(cf)) : zero;
-                dn[e] = kv ? buf_load_cf(Db, dkov, i * drow) : zero;
+                dn[e] = kv ? buf_load_cf_cached(Db, dkov, i * drow) : zero;
             }
         };
         prefetch(std::integral_constant<int, 0>{});

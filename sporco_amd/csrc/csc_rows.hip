@@ -128,7 +128,10 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
         cf2 ab;
         ab.a = mk<float>(0.5f * (zf.re + zp.re), 0.5f * (zf.im - zp.im));
         ab.b = mk<float>(0.5f * (zf.im + zp.im), 0.5f * (zp.re - zf.re));
-        if (pv) *reinterpret_cast<cf2 *>(Tl + (int64_t)f * tline) = ab;
+        if (pv) {
+            const float q[4] = {ab.a.re, ab.a.im, ab.b.re, ab.b.im};
+            sa_stream_store4(reinterpret_cast<float *>(Tl + (int64_t)f * tline), q);
+        }
     };
 #pragma unroll
     for (int pr = 0; pr < J / 2; ++pr) {
@@ -180,7 +183,12 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
         cf2 ab;
         ab.a = zero;
         ab.b = zero;
-        if (pv) ab = *reinterpret_cast<const cf2 *>(Tl + (int64_t)f * tline);
+        if (pv) {
+            float q[4];
+            sa_stream_load4(reinterpret_cast<const float *>(Tl + (int64_t)f * tline), q);
+            ab.a = mk<float>(q[0], q[1]);
+            ab.b = mk<float>(q[2], q[3]);
+        }
         return ab;
     };
     cf z[N1];   // z[NW j + i] = Z[line_of(w, j) + 32 brev(i)]

@@ -157,6 +157,12 @@ __device__ __forceinline__ cf buf_load_cf(BufRsrc r, int voff, int soff) {
     sa_buf_load2(r, voff, soff, x.re, x.im);
     return x;
 }
+// for operands that are re-read by other workgroups (Df): default cache policy
+__device__ __forceinline__ cf buf_load_cf_cached(BufRsrc r, int voff, int soff) {
+    cf x;
+    sa_buf_load2_cached(r, voff, soff, x.re, x.im);
+    return x;
+}
 __device__ __forceinline__ void buf_store_cf(BufRsrc r, int voff, int soff, cf x) {
     sa_buf_store2(r, voff, soff, x.re, x.im);
 }

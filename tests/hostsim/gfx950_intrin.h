@@ -48,6 +48,15 @@ inline void sa_buf_load2(SaBuf r, int voff, int soff, float &a, float &b) {
         std::memcpy(&b, r.base + off + 4, 4);
     }
 }
+inline void sa_buf_load2_cached(SaBuf r, int voff, int soff, float &a, float &b) {
+    sa_buf_load2(r, voff, soff, a, b);
+}
+inline void sa_stream_load4(const float *p, float (&v)[4]) {
+    for (int i = 0; i < 4; ++i) v[i] = p[i];
+}
+inline void sa_stream_store4(float *p, const float (&v)[4]) {
+    for (int i = 0; i < 4; ++i) p[i] = v[i];
+}
 inline void sa_buf_store2(SaBuf r, int voff, int soff, float a, float b) {
     const uint32_t off = (uint32_t)voff + (uint32_t)soff;
     if ((uint64_t)off + 8 <= r.bytes) {
