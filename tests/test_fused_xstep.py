@@ -195,3 +195,56 @@ def test_joint_at_fused_row_sizes(backend):
     assert rel_l2(Y, ref['Y']) < 1e-5
     assert rel_l2(b.X, ref['X']) < 1e-5
     assert rel_l2(b.getitstat().ObjFun, ref['ObjFun']) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_state_machine_random_walk(gpu_backend, seed):
+    """Random sequences of solves, reads, writes and dictionary changes drive the fused
+    path's lazy state (ping-pong iterates, on-demand X / Xf, speculated row spectra)
+    through its transitions; a solver on the generic chain must stay in step."""
+    import pickle
+    H, W, K, N = 256, 256, 6, 2
+    D, S = problem(H, W, K, N, seed=100 + seed)
+    rng = np.random.RandomState(seed)
+    fixed = seed == 1
+    optd = {'MaxMainIter': 2, 'RelStopTol': 0.0}
+    if fixed:
+        optd.update({'rho': 2.0, 'AutoRho': {'Enabled': False}})
+    b, _ = solve(D, S, optd)
+    g, _ = solve(D, S, optd, unfused=True)
+    assert b._dev.uses_fused_rows() and not g._dev.uses_fused_cols()
+    tol = 2e-5
+    for step in range(14):
+        op = rng.randint(8)
+        if op == 0:
+            n = int(rng.randint(1, 4))
+            for s in (b, g):
+                s.opt['MaxMainIter'] = n
+                s.solve()
+        elif op == 1:
+            assert rel_l2(b.X, g.X) < tol, (step, 'X')
+        elif op == 2:
+            assert rel_l2(b.Xf, g.Xf) < tol, (step, 'Xf')
+        elif op == 3:
+            D2 = (D * (1.0 + 0.1 * rng.randn(1, 1, K))).astype(np.float32)
+            for s in (b, g):
+                s.setdict(D2.reshape(s.cri.shpD))
+        elif op == 4:
+            Ynew = (b.Y * np.float32(0.9)).copy()
+            for s in (b, g):
+                s.Y = Ynew
+        elif op == 5:
+            assert rel_l2(b.reconstruct(), g.reconstruct()) < tol, (step, 'recon')
+        elif op == 6:
+            b = pickle.loads(pickle.dumps(b))
+        else:
+            assert rel_l2(b.U, g.U) < tol, (step, 'U')
+        assert rel_l2(b.Y, g.Y) < tol, (step, op, 'Y')
+    for s in (b, g):
+        s.opt['MaxMainIter'] = 3
+        s.solve()
+    assert rel_l2(b.Y, g.Y) < tol and rel_l2(b.X, g.X) < tol
+    its, itg = b.getitstat(), g.getitstat()
+    assert len(its.ObjFun) == len(itg.ObjFun)
+    assert rel_l2(its.ObjFun, itg.ObjFun) < 1e-4 and rel_l2(its.Rho, itg.Rho) < 1e-4
