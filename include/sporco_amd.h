@@ -106,9 +106,11 @@ int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
 int sporco_amd_csc_sync(sporco_amd_csc_t h);
 /* Which kernels serve this handle's shape: *out = 1 when the fused path named by
- * `what` is active (float32, H and/or W in {256, 512}, even K <= 64), else 0. */
+ * `what` is active (float32, H and/or W in {256, 512}, even K <= 64 -- or K = 128,
+ * 192, 256 for the ADMM column pass, which then runs as two kernels), else 0. */
 #define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
 #define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
+#define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step (K <= 64) */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))

@@ -307,6 +307,10 @@ class Solver(object):
         """True when an ADMM iteration runs as the three fused launches."""
         return self._query(1)
 
+    def uses_fused_pgm(self):
+        """True when pgm_iter / the tile-major D-step serve this shape."""
+        return self._query(2)
+
     def set_signal(self, S):
         H, W, C, N, K = self.dims
         S = _carr(S, self.dtype).reshape(H, W, C, N)

@@ -216,6 +216,8 @@ template <typename T> struct Csc : CscBase {
     // fused X-step (csc_fused.h): tile-major copies of Df, Sf, gram, its twiddles and
     // per-tile partials; xf_tiled marks VAR_XF as holding a tile-major intermediate
     bool fused = false, xf_tiled = false;
+    bool fused_slabs = false;       // K = 64*NH: column pass as two slab kernels (csc_fused.h)
+    cx<T> *qpart = nullptr;
     cx<T> *dft = nullptr, *sft = nullptr, *twA = nullptr, *twB = nullptr;
     T *gramt = nullptr;
     double *part_f = nullptr;
@@ -277,7 +279,10 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CN));
         SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CN));
         fused = fused_cols_supported<T>(H, K) && K % 2 == 0 && !std::getenv("SPORCO_AMD_UNFUSED");
-        if (fused) {
+        fused_slabs = fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
+        if (fused_slabs)
+            SA_HIP(hipMalloc((void **)&qpart, sizeof(cx<T>) * (int64_t)Wf * CN * (K / 64) * H));
+        if (fused || fused_slabs) {
             SA_HIP(hipMalloc((void **)&dft, sizeof(cx<T>) * npix * K));
             SA_HIP(hipMalloc((void **)&sft, sizeof(cx<T>) * npix * CN));
             SA_HIP(hipMalloc((void **)&gramt, sizeof(T) * npix));
@@ -289,7 +294,8 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
             SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
         }
-        rows_ok = fused && rows_supported<T>(W, K) && !std::getenv("SPORCO_AMD_OLD_ROWS");
+        rows_ok = (fused || fused_slabs) && rows_supported<T>(W, K) &&
+                  !std::getenv("SPORCO_AMD_OLD_ROWS");
         if (rows_ok) {
             SA_HIP(hipMalloc((void **)&twRows, sizeof(cx<T>) * W));
             std::vector<cx<T>> ta(W);
@@ -308,6 +314,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
+                        (void *)qpart,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -351,8 +358,9 @@ template <typename T> struct Csc : CscBase {
 
     void sync() override { SA_HIP(hipStreamSynchronize(st)); }
     int query(int what) override {
-        if (what == SPORCO_AMD_QUERY_FUSED_COLS) return fused ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && fused) ? 1 : 0;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
 
@@ -390,13 +398,13 @@ template <typename T> struct Csc : CscBase {
 
     // ---- tile-major operands of the fused X-step -----------------------------------
     void refresh_fused_dict() {
-        if (!fused) return;
+        if (!fused && !fused_slabs) return;
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_DF), dft, H, Wf, K);
         launch_permute_ab<T>(st, gram, gramt, H, Wf, 1);
     }
     void refresh_fused_signal() {
-        if (!fused) return;
+        if (!fused && !fused_slabs) return;
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_SF), sft, H, (int64_t)Wf * CN, 1);
     }
@@ -601,7 +609,14 @@ template <typename T> struct Csc : CscBase {
         fa.K = K;
         fa.partials = part_f;
         int64_t ntiles;
-        {
+        if (fused_slabs) {
+            FusedSlabArgs<T> sa;
+            sa.c = fa;
+            sa.qpart = qpart;
+            ProfScope ps(prof, PS_FUSED_COLS);
+            launch_cols_fwd_partial<T>(st, sa);
+            ntiles = launch_cols_sm_apply_inv<T>(st, sa);
+        } else {
             ProfScope ps(prof, PS_FUSED_COLS);
             ntiles = launch_fused_cols<T>(st, fa);
         }
@@ -740,7 +755,7 @@ template <typename T> struct Csc : CscBase {
         t_ready = false;
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
-        if (fused && !(p.flags & F_XRRS)) {
+        if ((fused || (fused_slabs && rows_ok)) && !(p.flags & F_XRRS)) {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
             const int64_t tline = (int64_t)CN * H * K, tgrp = (int64_t)H * K;
@@ -954,7 +969,8 @@ template <typename T> struct Csc : CscBase {
 
     void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
         require_ready();
-        if (!rows_ok) throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
+        if (!(rows_ok && fused))
+            throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
         t_ready = false;
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         if (!part_pgm) SA_HIP(hipMalloc((void **)&part_pgm, sizeof(double) * 4 * (int64_t)Wf * CN));
@@ -1158,7 +1174,7 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
-        if (rows_ok) {
+        if (rows_ok && fused) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;
             ra.y = rv(var);

@@ -37,6 +37,21 @@ template <typename T> struct FusedColsArgs {
     double *partials;  // one double per tile: Parseval-weighted sum |Df.xf - Sf|^2
 };
 
+// K = 64 * NH filters (NH = 2..4): a tile of all K filters does not fit the register file
+// of one workgroup, so the X-step column pass runs as two kernels over (tile, 64-filter
+// slab) pairs and exchanges only the partial inner products sum_k Df yuf through `qpart`:
+//   cols_fwd_partial    t <- FFT_H(t);            qpart[tile][slab][f] = sum_{k in slab} Df yuf
+//   cols_sm_apply_inv   q = sum_slab qpart;  xf = yuf + conj(Df)(Sf - q)/(gram + rho);
+//                       t <- IFFT_H(xf);  data-fidelity partials (slab 0 only)
+// (12 float32 passes per ADMM iteration instead of 10.)  Uses the FusedColsArgs fields plus:
+template <typename T> struct FusedSlabArgs {
+    FusedColsArgs<T> c;
+    cx<T> *qpart;   // (Wf*CN, NH, H) complex
+};
+template <typename T> bool fused_slabs_supported(int H, int K);
+template <typename T> void launch_cols_fwd_partial(hipStream_t st, const FusedSlabArgs<T> &a);
+template <typename T> int64_t launch_cols_sm_apply_inv(hipStream_t st, const FusedSlabArgs<T> &a);
+
 // Host tables twA, twB (H entries each) for fused_cols_supported shapes.
 template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB);
 // True when the register-resident column kernel handles this shape.

@@ -217,6 +217,213 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     block_sum_store<1>(acc, scratch, a.partials + tile);
 }
 
+// ---------------------------------------------------------------------------
+// K = 64 * NH: the column pass in two kernels over 64-filter slabs (see csc_fused.h)
+// ---------------------------------------------------------------------------
+// KS: compile-time row stride in filters (128), or 0 for a run-time a.c.K.
+template <int NW, int LP, int KS>
+__global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSlabArgs<float> aa) {
+    const FusedColsArgs<float> &a = aa.c;
+    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr int LBW = ilog2(NW);
+    constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KS ? KS : a.K;
+    const int NH = K / 64, slab = blockIdx.y;
+    const int Wf = a.W / 2 + 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wf = (slot / a.CN) * 8 + xcd;
+    if (wf >= Wf) return;
+    const int tile = wf * a.CN + slot % a.CN;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
+    const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
+    const cf *twA = a.twA + w * N1;
+    cf *qp = aa.qpart + ((int64_t)tile * NH + slab) * H + w;
+    f2 *L = dyn_lds<f2>();
+    int token = 0;
+
+    cf v[N1];
+#pragma unroll
+    for (int h1 = 0; h1 < N1; ++h1) v[h1] = buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf));
+    dif<N1, false>(v, 0);
+    reg_fence<N1>(v, 0, token);
+#pragma unroll
+    for (int i = 1; i < N1; ++i) {
+        cf tw;
+        sa_uload2(reinterpret_cast<const float *>(twA + i), tw.re, tw.im);
+        v[i] = cmul(v[i], tw);
+    }
+    reg_fence<N1>(v, 0, token);
+
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+#pragma unroll
+        for (int fl = 0; fl < FP; ++fl) {
+            const cf x = v[brev(q * FP + fl, 5)];
+            f2 t;
+            t.x = x.re;
+            t.y = x.im;
+            L[(fl * NW + w) * 64 + k] = t;
+        }
+        cf dn[4];
+        auto prefetch = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                dn[e] = buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf));
+            }
+        };
+        prefetch(std::integral_constant<int, 0>{});
+        __syncthreads();
+        cf u[FP];
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int h2 = 0; h2 < NW; ++h2) {
+                const f2 t = L[((w + NW * jl) * NW + h2) * 64 + k];
+                u[NW * jl + h2] = mk<float>(t.x, t.y);
+            }
+        }
+        if (q + 1 < Q) __syncthreads();
+        static_for<NCH>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+            if constexpr (c == 0) dif<NW, false>(u, NW * jl);
+            cf d[4];
+            float red[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = dn[e];
+            if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                red[2 * e] = p.re;
+                red[2 * e + 1] = p.im;
+            }
+            const float tot = reduce8_across_lanes(red, k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                buf_store_cf(Tb, ko, fo * K * (int)sizeof(cf), u[NW * jl + 4 * c + e]);
+                // lane 16 e holds Re, lane 16 e + 8 holds Im of the slab's partial sum
+                if (k == 16 * e) qp[fo].re = tot;
+                if (k == 16 * e + 8) qp[fo].im = tot;
+            }
+        });
+    });
+}
+
+template <int NW, int LP, int KS>
+__global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedSlabArgs<float> aa) {
+    const FusedColsArgs<float> &a = aa.c;
+    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr int LBW = ilog2(NW);
+    constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KS ? KS : a.K;
+    const int NH = K / 64, slab = blockIdx.y;
+    const int Wf = a.W / 2 + 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int wf = (slot / a.CN) * 8 + xcd;
+    if (wf >= Wf) return;
+    const int tile = wf * a.CN + slot % a.CN;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
+    const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
+    const cf *S = a.sft + (int64_t)tile * H + w;
+    const float *G = a.gramt + (int64_t)wf * H + w;
+    const cf *twB = a.twB + w * N1;
+    const cf *qp = aa.qpart + (int64_t)tile * NH * H + w;
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
+    const float rho = a.rho;
+    int token = 0;
+    float obj = 0.f;
+
+    cf v[N1];
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        cf u[FP];
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int fo = NW * (q * LP + jl) + N1 * brev(i, LBW);
+                u[NW * jl + i] = buf_load_cf(Tb, ko, fo * K * (int)sizeof(cf));
+            }
+        }
+        static_for<NCH>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                const cf d = buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf));
+                cf qq = mk<float>(0.f, 0.f), sv;
+                for (int sl = 0; sl < NH; ++sl) {
+                    cf t;
+                    sa_uload2(reinterpret_cast<const float *>(qp + (int64_t)sl * H + fo), t.re, t.im);
+                    qq = qq + t;
+                }
+                sa_uload2(reinterpret_cast<const float *>(S + fo), sv.re, sv.im);
+                const float inv = sa_rcp(sa_uload(G + fo) + rho);
+                const cf coef = cscale(sv - qq, inv);
+                obj += cabs2(coef);
+                u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d, coef);
+            }
+            if constexpr (c == CPL - 1) {
+                dit<NW, true>(u, NW * jl);
+#pragma unroll
+                for (int h2 = 1; h2 < NW; ++h2) {
+                    cf tw;
+                    sa_uload2(reinterpret_cast<const float *>(twB + NW * j + h2), tw.re, tw.im);
+                    u[NW * jl + h2] = cmulc(tw, u[NW * jl + h2]);
+                }
+            }
+        });
+        {
+            float &ob_ = obj;
+            int &tk_ = token;
+            SA_VGPR_FENCE3(ob_, tk_, tk_);
+        }
+#pragma unroll
+        for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+            for (int h2 = 0; h2 < NW; ++h2) {
+                f2 t;
+                t.x = u[NW * jl + h2].re;
+                t.y = u[NW * jl + h2].im;
+                L[((w + NW * jl) * NW + h2) * 64 + k] = t;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int fl = 0; fl < FP; ++fl) {
+            const f2 t = L[(fl * NW + w) * 64 + k];
+            v[brev(q * FP + fl, 5)] = mk<float>(t.x, t.y);
+        }
+        if (q + 1 < Q) __syncthreads();
+    });
+    reg_fence<N1>(v, 0, token);
+    dit<N1, true>(v, 0);
+#pragma unroll
+    for (int h1 = 0; h1 < N1; ++h1) buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
+
+    // every slab computes the same |coef|^2: slab 0 reports it
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    double acc[1] = {(k == 0 && slab == 0) ? (double)obj * pw * (double)rho * (double)rho : 0.0};
+    if (slab == 0) block_sum_store<1>(acc, scratch, a.partials + tile);
+}
+
 template <typename E>
 __global__ void __launch_bounds__(256) permute_ab_kernel(const E *__restrict__ in,
                                                          E *__restrict__ out, int64_t A, int64_t B,
@@ -313,6 +520,55 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     SA_HIP(hipGetLastError());
     return ntiles;
 }
+template <> bool fused_slabs_supported<float>(int H, int K) {
+    return (H == 256 || H == 512) && K > 64 && K <= 256 && K % 64 == 0;
+}
+template <> bool fused_slabs_supported<double>(int, int) { return false; }
+
+template <int NW, int LP, int KS>
+static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (const void *f : {reinterpret_cast<const void *>(&cols_fwd_partial_kernel<NW, LP, KS>),
+                              reinterpret_cast<const void *>(&cols_sm_apply_inv_kernel<NW, LP, KS>)})
+            SA_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)fused_lds_bytes(NW, LP)));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(ceil_div(a.c.W / 2 + 1, 8) * 8 * a.c.CN), (unsigned)(a.c.K / 64));
+    if (!second)
+        hipLaunchKernelGGL((cols_fwd_partial_kernel<NW, LP, KS>), grid, dim3(NW * 64),
+                           fused_lds_bytes(NW, LP), st, a);
+    else
+        hipLaunchKernelGGL((cols_sm_apply_inv_kernel<NW, LP, KS>), grid, dim3(NW * 64),
+                           fused_lds_bytes(NW, LP), st, a);
+    SA_HIP(hipGetLastError());
+}
+
+static void launch_slabs_any(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
+    SA_REQUIRE(fused_slabs_supported<float>(a.c.H, a.c.K), "shape not handled by the slab column kernels");
+    if (a.c.H == 256) {
+        if (a.c.K == 128) launch_slabs<8, 2, 128>(st, a, second);
+        else launch_slabs<8, 2, 0>(st, a, second);
+    } else {
+        if (a.c.K == 128) launch_slabs<16, 1, 128>(st, a, second);
+        else launch_slabs<16, 1, 0>(st, a, second);
+    }
+}
+template <> void launch_cols_fwd_partial<float>(hipStream_t st, const FusedSlabArgs<float> &a) {
+    launch_slabs_any(st, a, false);
+}
+template <> int64_t launch_cols_sm_apply_inv<float>(hipStream_t st, const FusedSlabArgs<float> &a) {
+    launch_slabs_any(st, a, true);
+    return (int64_t)(a.c.W / 2 + 1) * a.c.CN;
+}
+template <> void launch_cols_fwd_partial<double>(hipStream_t, const FusedSlabArgs<double> &) {
+    throw Error(-1, "the fused column kernels are float32 only");
+}
+template <> int64_t launch_cols_sm_apply_inv<double>(hipStream_t, const FusedSlabArgs<double> &) {
+    throw Error(-1, "the fused column kernels are float32 only");
+}
+
 template <> int64_t launch_fused_cols<double>(hipStream_t, const FusedColsArgs<double> &) {
     throw Error(-1, "the fused column kernel is float32 only");
 }

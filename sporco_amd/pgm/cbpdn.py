@@ -168,7 +168,7 @@ class ConvBPDN(pgm.PGMDFT):
 
     def _fused_ok(self):
         if self.opt['Backtrack'] is not None or self.stepsizepolicy is not None \
-                or self.opt['Monotone'] or not self.dev.uses_fused_rows():
+                or self.opt['Monotone'] or not self.dev.uses_fused_pgm():
             return False
         for name in self._hook_names:
             if name in self.__dict__ or getattr(type(self), name) is not getattr(ConvBPDN, name):

@@ -248,3 +248,26 @@ def test_state_machine_random_walk(gpu_backend, seed):
     its, itg = b.getitstat(), g.getitstat()
     assert len(its.ObjFun) == len(itg.ObjFun)
     assert rel_l2(its.ObjFun, itg.ObjFun) < 1e-4 and rel_l2(its.Rho, itg.Rho) < 1e-4
+
+
+# ---------------------------------------------------------------------------
+# K = 64 * NH filters: the column pass runs as two kernels over 64-filter slabs
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('H,W,K,N,C', [(256, 256, 128, 1, None),
+                                       pytest.param(512, 512, 128, 1, None, marks=pytest.mark.gpu),
+                                       pytest.param(256, 512, 192, 1, None, marks=pytest.mark.gpu),
+                                       pytest.param(256, 256, 128, 1, 3, marks=pytest.mark.gpu)])
+def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
+    from oracle import cbpdn_oracle as orc
+    D, S = problem(H, W, K, N, seed=H + K, C=C)
+    iters = 2 if backend == 'hostsim' else 3
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
+    b, Y = solve(D, S, optd, joint=C is not None)
+    assert b._dev.uses_fused_rows() and not b._dev.uses_fused_pgm()
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, C or 1, N, 1), 0.05,
+                         mu=(0.02 if C else None), dtype=np.float64, maxiter=iters, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 1e-5
+    assert rel_l2(b.X, ref['X']) < 1e-5
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
