@@ -281,7 +281,7 @@ template <typename T> struct Csc : CscBase {
         fused = fused_cols_supported<T>(H, K) && K % 2 == 0 && !std::getenv("SPORCO_AMD_UNFUSED");
         fused_slabs = fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
         if (fused_slabs)
-            SA_HIP(hipMalloc((void **)&qpart, sizeof(cx<T>) * (int64_t)Wf * CN * (K / 64) * H));
+            SA_HIP(hipMalloc((void **)&qpart, sizeof(cx<T>) * (int64_t)Wf * CN * ((K + 63) / 64) * H));
         if (fused || fused_slabs) {
             SA_HIP(hipMalloc((void **)&dft, sizeof(cx<T>) * npix * K));
             SA_HIP(hipMalloc((void **)&sft, sizeof(cx<T>) * npix * CN));

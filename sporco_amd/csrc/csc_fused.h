@@ -37,7 +37,7 @@ template <typename T> struct FusedColsArgs {
     double *partials;  // one double per tile: Parseval-weighted sum |Df.xf - Sf|^2
 };
 
-// K = 64 * NH filters (NH = 2..4): a tile of all K filters does not fit the register file
+// 64 < K <= 256 filters (NH = ceil(K/64) slabs, the last one possibly partial): a tile of all K filters does not fit the register file
 // of one workgroup, so the X-step column pass runs as two kernels over (tile, 64-filter
 // slab) pairs and exchanges only the partial inner products sum_k Df yuf through `qpart`:
 //   cols_fwd_partial    t <- FFT_H(t);            qpart[tile][slab][f] = sum_{k in slab} Df yuf

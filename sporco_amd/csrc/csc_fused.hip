@@ -231,7 +231,9 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int K = KS ? KS : a.K;
-    const int NH = K / 64, slab = blockIdx.y;
+    const int NH = (K + 63) / 64, slab = blockIdx.y;
+    const bool kv = KS == 128 ? true : slab * 64 + k < K;   // the last slab may be partial
+    const cf zero = mk<float>(0.f, 0.f);
     const int Wf = a.W / 2 + 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int wf = (slot / a.CN) * 8 + xcd;
@@ -248,7 +250,7 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
 
     cf v[N1];
 #pragma unroll
-    for (int h1 = 0; h1 < N1; ++h1) v[h1] = buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf));
+    for (int h1 = 0; h1 < N1; ++h1) v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
     dif<N1, false>(v, 0);
     reg_fence<N1>(v, 0, token);
 #pragma unroll
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                dn[e] = buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf));
+                dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
             }
         };
         prefetch(std::integral_constant<int, 0>{});
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                buf_store_cf(Tb, ko, fo * K * (int)sizeof(cf), u[NW * jl + 4 * c + e]);
+                if (kv) buf_store_cf(Tb, ko, fo * K * (int)sizeof(cf), u[NW * jl + 4 * c + e]);
                 // lane 16 e holds Re, lane 16 e + 8 holds Im of the slab's partial sum
                 if (k == 16 * e) qp[fo].re = tot;
                 if (k == 16 * e + 8) qp[fo].im = tot;
@@ -329,7 +331,9 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int K = KS ? KS : a.K;
-    const int NH = K / 64, slab = blockIdx.y;
+    const int NH = (K + 63) / 64, slab = blockIdx.y;
+    const bool kv = KS == 128 ? true : slab * 64 + k < K;   // the last slab may be partial
+    const cf zero = mk<float>(0.f, 0.f);
     const int Wf = a.W / 2 + 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int wf = (slot / a.CN) * 8 + xcd;
@@ -358,7 +362,7 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
                 const int fo = NW * (q * LP + jl) + N1 * brev(i, LBW);
-                u[NW * jl + i] = buf_load_cf(Tb, ko, fo * K * (int)sizeof(cf));
+                u[NW * jl + i] = kv ? buf_load_cf(Tb, ko, fo * K * (int)sizeof(cf)) : zero;
             }
         }
         static_for<NCH>([&](auto gc) {
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                const cf d = buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf));
+                const cf d = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                 cf qq = mk<float>(0.f, 0.f), sv;
                 for (int sl = 0; sl < NH; ++sl) {
                     cf t;
@@ -416,7 +420,8 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
     reg_fence<N1>(v, 0, token);
     dit<N1, true>(v, 0);
 #pragma unroll
-    for (int h1 = 0; h1 < N1; ++h1) buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
+    for (int h1 = 0; h1 < N1; ++h1)
+        if (kv) buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
 
     // every slab computes the same |coef|^2: slab 0 reports it
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
@@ -521,7 +526,7 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     return ntiles;
 }
 template <> bool fused_slabs_supported<float>(int H, int K) {
-    return (H == 256 || H == 512) && K > 64 && K <= 256 && K % 64 == 0;
+    return (H == 256 || H == 512) && K > 64 && K <= 256 && K % 2 == 0;
 }
 template <> bool fused_slabs_supported<double>(int, int) { return false; }
 
@@ -535,7 +540,7 @@ static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool sec
                                        (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
-    const dim3 grid((unsigned)(ceil_div(a.c.W / 2 + 1, 8) * 8 * a.c.CN), (unsigned)(a.c.K / 64));
+    const dim3 grid((unsigned)(ceil_div(a.c.W / 2 + 1, 8) * 8 * a.c.CN), (unsigned)ceil_div(a.c.K, 64));
     if (!second)
         hipLaunchKernelGGL((cols_fwd_partial_kernel<NW, LP, KS>), grid, dim3(NW * 64),
                            fused_lds_bytes(NW, LP), st, a);
