@@ -39,6 +39,10 @@ class TorchReducer(object):
     def admm_iter(self, solver, params):
         if self.on_gpu:
             solver.admm_iter_dev(params, self.buf.data_ptr())
+            # The sums are produced on the solver's stream and consumed by RCCL on a stream
+            # of its own: make the hand-over explicit instead of relying on the implicit
+            # ordering of the legacy default stream (one host sync of ~10 us per iteration).
+            solver.sync()
             self.dist.all_reduce(self.buf, group=self.group)
             return self.buf.cpu().tolist()
         return self.sum(solver.admm_iter(params))
