@@ -120,8 +120,12 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # (SPORCO_AMD_BENCH_BACKEND=gloo lets the multi-rank flow be exercised on a box with
+        # fewer GPUs than ranks: ranks then share devices and reduce through host memory)
+        backend = os.environ.get('SPORCO_AMD_BENCH_BACKEND', 'nccl')
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')
+        dist.init_process_group(backend)
         from sporco_amd.dist import TorchReducer
         reducer = TorchReducer()
         stream = reducer.stream_handle()
@@ -174,7 +178,8 @@ def main():
     download_ms = 1e3 * (time.perf_counter() - t1)
     del y_host
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
 
@@ -194,7 +199,8 @@ def main():
     achieved = kb[dom] / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(REPO, 'profiles', 'hbm_traffic_bytes.json')
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and (H, W, K, N) == (512, 512, 64, 32):
+        # measured for exactly this workload (rocprofv3 PMC passes, see the file)
         with open(tpath) as f:
             traffic = json.load(f).get(dom)
     E = H * W * P

@@ -93,6 +93,28 @@ def default_library_path():
     return _DEFAULT_PATH
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and
+    link it by file name, so a process that loads this library (which needs the SONAME
+    from /opt/rocm) *and* torch ends up with two HIP runtimes, and the second one to
+    initialise finds no GPU.  torch.distributed is how the multi-GPU path talks to
+    RCCL, so when torch is installed its copy is loaded first: the dynamic linker then
+    resolves our dependency to it by SONAME and a later ``import torch`` reuses the
+    same object.  SPORCO_AMD_SHARE_TORCH_RUNTIME=0 disables this."""
+    if os.environ.get('SPORCO_AMD_SHARE_TORCH_RUNTIME', '1') == '0':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass     # fall back to the system runtime
+
+
 def load(path=None):
     """Load the backend shared library (default: the in-tree hipcc build).
 
@@ -108,6 +130,7 @@ def load(path=None):
             "sporco_amd: HIP library %s not found. Build it with "
             "`make -C sporco_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
             "g.build()'`). There is no CPU fallback." % path)
+    _share_torch_hip_runtime()
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:
