@@ -1,0 +1,45 @@
+"""Worker of tests/test_dist_nccl.py: a one-rank RCCL ('nccl') process group on the GPU.
+
+Exercises what the multi-GPU bench relies on and a single-GPU run never touches:
+torch and libsporco_amd.so in one process (one shared HIP runtime), the reducer's
+device buffer written by the solver's stream and reduced by RCCL, the shared stream."""
+
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+
+def main():
+    import sporco_amd
+    from sporco_amd import _lib
+    _lib.load()                          # before torch on purpose: the harder order
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from sporco_amd.admm import cbpdn
+    from sporco_amd.dist import TorchReducer
+    from test_fused_xstep import problem
+    from conftest import rel_l2
+    D, S = problem(256, 256, 8, 2, seed=4)
+    optd = {'MaxMainIter': 8, 'RelStopTol': 0.0}
+    red = TorchReducer()
+    assert red.on_gpu
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd), stream=red.stream_handle(),
+                       reducer=red)
+    Y = b.solve()
+    b0 = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    Y0 = b0.solve()
+    assert np.array_equal(Y, Y0), rel_l2(Y, Y0)
+    assert np.array_equal(np.asarray(b.getitstat().Rho), np.asarray(b0.getitstat().Rho))
+    dist.destroy_process_group()
+    print('NCCL_WORKER_OK')
+
+
+if __name__ == '__main__':
+    main()
