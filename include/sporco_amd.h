@@ -130,6 +130,10 @@ int sporco_amd_csc_set_l1_weight(sporco_amd_csc_t h, const void *w, const int64_
 /* l2,1 weight (L21Weight, sporco/admm/cbpdn.py:781): broadcastable against
  * (H,W,1,N,K); shape[2] must be 1. */
 int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]);
+/* Per-filter weights of the gradient penalty (GradWeight option of ConvBPDNGradReg,
+ * sporco/admm/cbpdn.py:1063-1071, :1134-1139): K values of the handle's dtype;
+ * w == NULL restores the scalar weight 1. */
+int sporco_amd_csc_set_grad_weight(sporco_amd_csc_t h, const void *w);
 
 /* Host <-> device transfer of one state array in the reference layout. */
 int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src);
@@ -153,11 +157,14 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
 #define SPORCO_AMD_FLAG_NO_X (1u << 9)       /* caller will not read X / Xf of this iteration:
                                                 they are neither written nor recoverable, and
                                                 reading them fails with SPORCO_AMD_ESTATE */
+#define SPORCO_AMD_FLAG_GRADREG (1u << 10)   /* ConvBPDNGradReg xstep / objective
+                                                (cbpdn.py:1163-1214): diagonal mu*GradWeight*GHGf
+                                                + rho, params.mu = gradient weight mu */
 
 typedef struct {
     double rho;      /* penalty parameter for this iteration                     */
     double lmbda;    /* l1 weight lambda                                          */
-    double mu;       /* l2,1 weight (JOINT only)                                  */
+    double mu;       /* l2,1 weight (JOINT) / gradient penalty weight (GRADREG)   */
     double rlx;      /* RelaxParam alpha (sporco/admm/admm.py:877-885)            */
     double u_scale;  /* pending `U /= rsf` of update_rho (admm.py:573), applied
                         to U as it is read: U_true = u_scale * U_stored          */
@@ -179,6 +186,8 @@ typedef struct {
 #define SPORCO_AMD_OUT_XRRS_D2 8 /* sum |ax - b|^2 of the X-step system            */
 #define SPORCO_AMD_OUT_XRRS_AX2 9
 #define SPORCO_AMD_OUT_XRRS_B2 10
+#define SPORCO_AMD_OUT_RGR 11    /* Parseval sum of GradWeight GHGf |Xf|^2 / (H W)  (twice RegGrad,
+                                  * cbpdn.py:1204-1214; FLAG_GRADREG only)         */
 #define SPORCO_AMD_OUT_COUNT 16
 
 /* One full ADMM iteration on device: xstep (cbpdn.py:267-281: rfftn(Y-U),

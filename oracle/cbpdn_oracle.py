@@ -97,6 +97,32 @@ def solvedbi_sm(ah, rho, b, c=None, axis=AX_K):
     return (b - (a * inner(c, b, axis=axis))) / rho
 
 
+def solvedbd_sm_c(ah, a, d, axis=AX_K):
+    """(ah/d) / (<ah, a/d> + 1) -- sporco/linalg.py:346-366."""
+    return (ah / d) / (inner(ah, a / d, axis=axis) + 1.0)
+
+
+def solvedbd_sm(ah, d, b, c=None, axis=AX_K):
+    """Solve (diag(d) + a a^H) x = b per frequency -- sporco/linalg.py:300-342."""
+    a = np.conj(ah)
+    if c is None:
+        c = solvedbd_sm_c(ah, a, d, axis)
+    return (b - a * inner(c, b, axis=axis)) / d
+
+
+def gradient_filters_ghg(shp, dtype):
+    """sum_i |G_i|^2 on the half spectrum, shape (H, W//2+1, 1, 1, 1), for the
+    two-tap difference filters [1, -1] along each spatial axis --
+    sporco/signal.py:204-240 (the Gf themselves are only used by the
+    reference through this sum, sporco/admm/cbpdn.py:1141-1143)."""
+    H, W = shp
+    g = np.zeros((2, 2, 1, 1, 1, 2), dtype=dtype)
+    g[:, 0, 0, 0, 0, 0] = (1, -1)
+    g[0, :, 0, 0, 0, 1] = (1, -1)
+    Gf = np.fft.rfftn(g, (H, W), axes=(0, 1))
+    return np.sum(np.conj(Gf) * Gf, axis=-1).real
+
+
 def rrs(ax, b):
     """Relative residual ||b - ax|| / max(||ax||, ||b||) --
     sporco/linalg.py:883-910."""
@@ -153,7 +179,7 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
                std_residuals=False, abs_tol=0.0, rel_tol=1e-3,
                nonneg=False, nobndry=False, wl1=1.0, wl21=1.0,
                gevaly=False, fevalx=True, stats=True, Y0=None, U0=None,
-               time_budget=None):
+               time_budget=None, grad_mu=None, grad_weight=1.0):
     """Run ADMM ConvBPDN (``mu is None``) or ConvBPDNJoint on 5-D arrays.
 
     ``D``: (dH, dW, 1, 1, K);  ``S``: (H, W, C, N, 1).  Single-channel
@@ -166,6 +192,11 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
       compute_residuals (admm.py:462-486 with :959-983);
       eval_objfn (cbpdn.py:325-344, :624-630, :798-807);
       update_rho (admm.py:549-575); stop test (admm.py:375-377).
+
+    ``grad_mu`` (with ``mu is None``) selects ConvBPDNGradReg
+    (cbpdn.py:992-1214): the x step solves with diagonal
+    ``grad_mu * grad_weight[k] * GHGf + rho`` (:1167-1175) and the objective
+    gains ``grad_mu * RegGrad`` (:1204-1214).
 
     Returns a dict with final X, Y, U, Xf and the per-iteration traces.
     """
@@ -197,6 +228,14 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
     Sf = rfftn2(S)
     Df = rfftn2(D, (H, W))
     DSf = np.conj(Df) * Sf
+    gradreg = grad_mu is not None
+    if gradreg:
+        assert not joint
+        grad_mu = dtype.type(grad_mu)                      # cbpdn.py:1133
+        wg = np.asarray(grad_weight, dtype=dtype)
+        if wg.ndim:
+            wg = wg.reshape((1, 1, 1, 1) + wg.shape)       # cbpdn.py:1134-1139
+        GHGf = wg * gradient_filters_ghg((H, W), dtype)    # cbpdn.py:1141-1143
 
     Y = np.zeros(shpX, dtype=dtype) if Y0 is None else \
         np.asarray(Y0).astype(dtype, copy=True)
@@ -207,7 +246,7 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
     else:
         U = (lmbda / rho) * np.sign(Y)           # cbpdn.py:601-610
 
-    tr = {k: [] for k in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl',
+    tr = {k: [] for k in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'RegGrad', 'PrimalRsdl',
                           'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho')}
     X = None
     Xf = None
@@ -218,7 +257,11 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
         # -- xstep: cbpdn.py:267-281
         YU = Y - U
         b = DSf + rho * rfftn2(YU)
-        Xf = solvedbi_sm(Df, rho, b, None, AX_K).astype(b.dtype)
+        if gradreg:
+            Xf = solvedbd_sm(Df, grad_mu * GHGf + rho, b, None,
+                             AX_K).astype(b.dtype)
+        else:
+            Xf = solvedbi_sm(Df, rho, b, None, AX_K).astype(b.dtype)
         X = irfftn2(Xf, (H, W))
         # -- relax_AX: admm.py:877-885
         AXnr = X
@@ -263,11 +306,18 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
             if joint:
                 rl21 = np.sum(wl21 * np.sqrt(np.sum(gvar ** 2, axis=AX_C)))
                 obj = dfd + lmbda * rl1 + mu * rl21
+            elif gradreg:
+                rl21 = 0.0
+                rgr = rfl2norm2(np.sqrt(GHGf * np.conj(fvar) * fvar),
+                                S.shape) / 2.0
+                obj = dfd + lmbda * rl1 + grad_mu * rgr
             else:
                 rl21 = 0.0
                 obj = dfd + lmbda * rl1
             for key, val in (('ObjFun', obj), ('DFid', dfd), ('RegL1', rl1),
-                             ('RegL21', rl21), ('PrimalRsdl', r),
+                             ('RegL21', rl21),
+                             ('RegGrad', rgr if gradreg else 0.0),
+                             ('PrimalRsdl', r),
                              ('DualRsdl', s), ('EpsPrimal', epri),
                              ('EpsDual', edua), ('Rho', rho)):
                 tr[key].append(float(val))

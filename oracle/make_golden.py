@@ -324,11 +324,47 @@ def gen_dictlearn():
          D=c.getdict(), Xfull=c.X, **itstat_dict(c))
 
 
+def gradreg_case(name, D, S, lmbda, mu, optd, dimK=None):
+    opt = ref_cbpdn.ConvBPDNGradReg.Options(optd)
+    b = ref_cbpdn.ConvBPDNGradReg(D, S, lmbda, mu, opt, dimK=dimK)
+    b.solve()
+    extra = {}
+    for key, val in optd.items():
+        if isinstance(val, np.ndarray):
+            extra['optarr_' + key] = val.copy()
+    save(name, D=D, S=S, lmbda=np.float64(lmbda), mu=np.float64(mu),
+         dimK=np.int64(-1 if dimK is None else dimK),
+         X=b.X, Y=b.Y, U=b.U, Xf=b.Xf, rho_final=np.float64(b.rho),
+         k_final=np.int64(b.k), recon=b.reconstruct(), GHGf=b.GHGf,
+         **extra, **itstat_dict(b))
+
+
+def gen_gradreg():
+    """ConvBPDNGradReg (sporco/admm/cbpdn.py:992-1214): SURVEY.md 8(f) rank 1."""
+    np.random.seed(2468)
+    D = np.random.randn(5, 5, 4)
+    S = np.random.randn(16, 16, 2)
+    gradreg_case('admm_gradreg_f64', D, S, 0.1, 0.2, {'MaxMainIter': 30})
+    gradreg_case('admm_gradreg_f32', D, S, 0.1, 0.2,
+                 {'MaxMainIter': 30, 'DataType': np.float32})
+    # per-filter gradient weights (the usual use: penalise only a low-pass filter),
+    # LinSolveCheck, fixed rho, odd size, single image
+    wg = np.array([0.0, 0.0, 1.0, 0.5])
+    S2 = np.random.randn(15, 17)
+    gradreg_case('admm_gradreg_weights_f64', D, S2, 0.05, 0.5,
+                 {'MaxMainIter': 25, 'GradWeight': wg, 'rho': 1.5,
+                  'AutoRho': {'Enabled': False}, 'LinSolveCheck': True,
+                  'NonNegCoef': True})
+    # objective evaluated at the auxiliary variable: RegGrad then uses rfftn(Y)
+    gradreg_case('admm_gradreg_auxvar_f64', D, S, 0.1, 0.3,
+                 {'MaxMainIter': 20, 'AuxVarObj': True, 'GradWeight': wg})
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn']
-    table = {'primitives': gen_primitives, 'admm': gen_admm,
+                             'pcn', 'dictlearn', 'gradreg']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

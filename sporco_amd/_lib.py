@@ -28,10 +28,12 @@ FLAG_GEVAL_Y = 1 << 6
 FLAG_FEVAL_Y = 1 << 7
 FLAG_KEEP_X = 1 << 8
 FLAG_NO_X = 1 << 9
+FLAG_GRADREG = 1 << 10
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
 OUT_XRRS_D2, OUT_XRRS_AX2, OUT_XRRS_B2 = 8, 9, 10
+OUT_RGR = 11
 OUT_COUNT = 16
 
 PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY = range(6)
@@ -41,6 +43,7 @@ EXPORTS = (
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_destroy',
     'sporco_amd_csc_sync', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
+    'sporco_amd_csc_set_grad_weight',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
     'sporco_amd_csc_admm_iter', 'sporco_amd_csc_admm_iter_dev',
     'sporco_amd_csc_admm_xstep', 'sporco_amd_csc_admm_relax',
@@ -160,6 +163,7 @@ def load(path=None):
         'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
         'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_l21_weight': [vp, vp, ctypes.POINTER(i64)],
+        'sporco_amd_csc_set_grad_weight': [vp, vp],
         'sporco_amd_csc_upload': [vp, ctypes.c_int, vp],
         'sporco_amd_csc_download': [vp, ctypes.c_int, vp],
         'sporco_amd_csc_device_ptr': [vp, ctypes.c_int, ctypes.POINTER(vp)],
@@ -359,6 +363,16 @@ class Solver(object):
 
     def set_l21_weight(self, w):
         self._set_weight(self._lib.sporco_amd_csc_set_l21_weight, w)
+
+    def set_grad_weight(self, w):
+        """K per-filter weights of the gradient penalty, or None for 1."""
+        if w is None:
+            check(self._lib.sporco_amd_csc_set_grad_weight(self._h, None))
+            return
+        w = _carr(w, self.dtype).ravel()
+        if w.size != self.dims[4]:
+            raise ValueError("GradWeight must hold one value per filter")
+        check(self._lib.sporco_amd_csc_set_grad_weight(self._h, _ptr(w)))
 
     # -- transfers --------------------------------------------------------
     def upload(self, var, a):

@@ -29,7 +29,7 @@ from .. import _lib
 from .. import cnvrep as cr
 from ..fft import complex_dtype, real_dtype
 
-__all__ = ['GenericConvBPDN', 'ConvBPDN', 'ConvBPDNJoint']
+__all__ = ['GenericConvBPDN', 'ConvBPDN', 'ConvBPDNJoint', 'ConvBPDNGradReg']
 
 
 class _DeviceArray(object):
@@ -300,7 +300,8 @@ class GenericConvBPDN(admm.ADMMEqual):
     def xstep(self):
         """Y - U -> rfftn -> Sherman-Morrison -> irfftn (cbpdn.py:267-293)."""
         out = self._dev.admm_xstep(self._params())
-        for slot in (_lib.OUT_DFID, _lib.OUT_XRRS_D2, _lib.OUT_XRRS_AX2, _lib.OUT_XRRS_B2):
+        for slot in (_lib.OUT_DFID, _lib.OUT_XRRS_D2, _lib.OUT_XRRS_AX2, _lib.OUT_XRRS_B2,
+                     _lib.OUT_RGR):
             self._sums[slot] = out[slot]
         self._touch(_lib.VAR_X, _lib.VAR_XF)
         self._set_xrrs()
@@ -341,6 +342,7 @@ class GenericConvBPDN(admm.ADMMEqual):
                 self._sums[slot] = out[slot]
             if not self.opt['fEvalX']:
                 self._sums[_lib.OUT_DFID] = out[_lib.OUT_DFID]
+                self._sums[_lib.OUT_RGR] = out[_lib.OUT_RGR]
         s = self._sums
         rho = float(self.rho)
         nr = np.sqrt(s[_lib.OUT_R2])
@@ -543,6 +545,82 @@ class ConvBPDNJoint(ConvBPDN):
         return (self.lmbda * rl1 + self.mu * rl21, rl1, rl21)
 
 
+class ConvBPDNGradReg(ConvBPDN):
+    r"""ConvBPDN with an l2 penalty on the gradient of the coefficient maps,
+    (mu/2) sum_i sum_m w_m ||G_i x_m||_2^2 (reference class:
+    sporco/admm/cbpdn.py:992-1214).  The gradient term enters the X step only:
+    the per-frequency system becomes (diag(mu w_m GHGf + rho) + a a^H) x = b and is
+    solved by the diagonal Sherman-Morrison form of ``linalg.solvedbd_sm``
+    (sporco/linalg.py:300-366) inside the same kernel.
+
+    IterationStats fields: ``Iter, ObjFun, DFid, RegL1, RegGrad, PrimalRsdl,
+    DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
+    """
+
+    class Options(ConvBPDN.Options):
+        """Adds ``GradWeight``: scalar, or one weight per filter (cbpdn.py:1059-1073)."""
+
+        defaults = copy.deepcopy(ConvBPDN.Options.defaults)
+        defaults.update({'GradWeight': 1.0})
+
+        def __init__(self, opt=None):
+            ConvBPDN.Options.__init__(self, {} if opt is None else opt)
+
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'RegL1', 'RegGrad')
+    hdrtxt_objfn = ('Fnc', 'DFid', u'Regℓ1', u'Regℓ2∇')
+    hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', u'Regℓ1': 'RegL1',
+                     u'Regℓ2∇': 'RegGrad'}
+
+    def __init__(self, D, S, lmbda=None, mu=0.0, opt=None, dimK=None, dimN=2, **backend):
+        if opt is None:
+            opt = ConvBPDNGradReg.Options()
+        self.set_dtype(opt, S.dtype)
+        self.mu = self.dtype.type(mu)
+        gw = opt['GradWeight']
+        if hasattr(gw, 'ndim') and np.ndim(gw) > 0:
+            # one weight per filter, broadcast along the filter axis (cbpdn.py:1134-1137)
+            self.Wgrd = np.asarray(np.asarray(gw).reshape((1,) * (dimN + 2) + np.shape(gw)),
+                                   dtype=self.dtype)
+        else:
+            self.Wgrd = np.asarray(gw, dtype=self.dtype)
+        super(ConvBPDNGradReg, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN,
+                                              **backend)
+
+    @property
+    def GHGf(self):
+        """Wgrd * sum_i |G_i|^2 on the half spectrum (cbpdn.py:1141-1143); host-side
+        convenience, the kernels evaluate it from two separable tables."""
+        H, W = self.cri.Nv
+        gh = (2.0 - 2.0 * np.cos(2.0 * np.pi * np.arange(H) / H)) if H > 1 else np.ones(1)
+        gw = (2.0 - 2.0 * np.cos(2.0 * np.pi * np.arange(W // 2 + 1) / W)) if W > 1 \
+            else np.ones(1)
+        g = (gh[:, np.newaxis] + gw[np.newaxis, :]).reshape(H, W // 2 + 1, 1, 1, 1)
+        return self.Wgrd * g.astype(self.dtype)
+
+    def _upload_weights(self):
+        super(ConvBPDNGradReg, self)._upload_weights()
+        if self.Wgrd.size == 1:
+            self._wg_scalar = float(self.Wgrd.ravel()[0])
+            self._dev.set_grad_weight(None)
+        else:
+            if self.Wgrd.size != self.cri.M:
+                raise ValueError("GradWeight must be a scalar or hold one weight per filter")
+            self._wg_scalar = 1.0
+            self._dev.set_grad_weight(self.Wgrd.ravel())
+
+    def _mu_eff(self):
+        # a scalar GradWeight folds into mu: mu * (w GHGf)
+        return float(self.mu) * self._wg_scalar
+
+    def _flags(self):
+        return super(ConvBPDNGradReg, self)._flags() | _lib.FLAG_GRADREG
+
+    def obfn_reg(self):
+        rl1 = abs(self._wl1_scalar) * self._sums[_lib.OUT_L1]
+        rgr = self._wg_scalar * self._sums[_lib.OUT_RGR] / 2.0
+        return (self.lmbda * rl1 + self.mu * rgr, rl1, rgr)
+
+
 def _broadcastable(w, full_shape):
     """Return ``w`` as a 5-D array whose axes are each 1 or the full extent."""
     w = np.asarray(w)
@@ -559,3 +637,4 @@ def _broadcastable(w, full_shape):
 GenericConvBPDN._fused_base = None
 ConvBPDN._fused_base = ConvBPDN
 ConvBPDNJoint._fused_base = ConvBPDNJoint
+ConvBPDNGradReg._fused_base = ConvBPDNGradReg

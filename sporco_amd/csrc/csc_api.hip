@@ -119,6 +119,7 @@ struct CscBase {
     virtual void set_signal(const void *S) = 0;
     virtual void set_dict(const void *D, int dH, int dW) = 0;
     virtual void set_weight(int which, const void *w, const int64_t shape[5]) = 0;
+    virtual void set_grad_weight(const void *w) = 0;
     virtual void upload(int var, const void *src) = 0;
     virtual void download(int var, void *dst) = 0;
     virtual void *device_ptr(int var) = 0;
@@ -244,6 +245,9 @@ template <typename T> struct Csc : CscBase {
     bool pgm_tiled = false, pgm_x_stale = false;
     sporco_amd_pgm_params last_pgm;
     double *part_pgm = nullptr;
+    // ConvBPDNGradReg (F_GRADREG): separable gradient spectrum tables and filter weights
+    T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
+    bool have_wg = false;
 
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
@@ -314,7 +318,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -550,6 +554,40 @@ template <typename T> struct Csc : CscBase {
         dst.ptr = buf;
     }
 
+    // GradWeight (cbpdn.py:1063-1071, :1134-1139): K per-filter weights, NULL => scalar 1
+    void set_grad_weight(const void *w) override {
+        before_state_change();
+        have_wg = w != nullptr;
+        if (!w) return;
+        if (!wg) SA_HIP(hipMalloc((void **)&wg, sizeof(T) * K));
+        SA_HIP(hipMemcpyAsync(wg, w, sizeof(T) * K, hipMemcpyHostToDevice, st));
+        SA_HIP(hipStreamSynchronize(st));
+    }
+
+    // sum_i |G_i|^2 of the difference filters [1, -1] along each axis is separable:
+    // |1 - e^{-i t}|^2 = 2 - 2 cos t  (signal.gradient_filters, signal.py:230-239)
+    GradTerm<T> grad_term(double mu) {
+        if (!ghh) {
+            std::vector<T> th(H), tw(Wf);
+            const double tau = 6.283185307179586476925286766559;
+            for (int h = 0; h < H; ++h) th[h] = (T)(2.0 - 2.0 * std::cos(tau * h / H));
+            for (int f = 0; f < Wf; ++f) tw[f] = (T)(2.0 - 2.0 * std::cos(tau * f / W));
+            // a singleton axis crops the 2-tap filter to its first tap (numpy's fft `s` rule)
+            if (H == 1) th[0] = T(1);
+            if (W == 1) tw[0] = T(1);
+            SA_HIP(hipMalloc((void **)&ghh, sizeof(T) * H));
+            SA_HIP(hipMalloc((void **)&ghw, sizeof(T) * Wf));
+            SA_HIP(hipMemcpy(ghh, th.data(), sizeof(T) * H, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(ghw, tw.data(), sizeof(T) * Wf, hipMemcpyHostToDevice));
+        }
+        GradTerm<T> g;
+        g.ghh = ghh;
+        g.ghw = ghw;
+        g.wg = have_wg ? wg : nullptr;
+        g.mu = (T)mu;
+        return g;
+    }
+
     void upload(int var, const void *src) override {
         if (is_pgm_iterate(var)) pgm_leave_tiled();
         if (var == SPORCO_AMD_VAR_ZF) zf_tiled = false;
@@ -702,7 +740,7 @@ template <typename T> struct Csc : CscBase {
             x_invalid = p.flags & F_NO_X;
         }
         t_ready = emit;
-        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
     }
 
     // X = irfft_W(tile-major spectrum in the Xf buffer) / (H W): the row pass of
@@ -755,7 +793,8 @@ template <typename T> struct Csc : CscBase {
         t_ready = false;
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
-        if ((fused || (fused_slabs && rows_ok)) && !(p.flags & F_XRRS)) {
+        const bool gradreg = p.flags & F_GRADREG;
+        if ((fused || (fused_slabs && rows_ok)) && !(p.flags & F_XRRS) && !gradreg) {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
             const int64_t tline = (int64_t)CN * H * K, tgrp = (int64_t)H * K;
@@ -784,24 +823,40 @@ template <typename T> struct Csc : CscBase {
         const bool obj = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
         const bool xr = p.flags & F_XRRS;
         int nb;
+        GradTerm<T> gt;
+        if (gradreg) gt = grad_term(p.mu);
         {
             ProfScope ps(prof, PS_SM_SOLVE);
             nb = launch_sm_solve<T>(st, Xf, Xf, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF), gram,
-                                    (T)p.rho, npix, CN, K, W, obj, xr, part_a);
+                                    (T)p.rho, npix, CN, K, W, obj, xr, part_a,
+                                    gradreg ? &gt : nullptr);
         }
         if (obj || xr) {
-            const int slots[4] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
-                                  SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
-            const double scales[4] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0};
-            finalize(part_a, nb, 4, 4, slots, scales, out_dev);
+            const int slots[5] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
+                                  SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2,
+                                  SPORCO_AMD_OUT_RGR};
+            const double scales[5] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0, 1.0 / ((double)H * W)};
+            const int nv = gradreg ? 5 : 4;
+            finalize(part_a, nb, nv, nv, slots, scales, out_dev);
         }
         inv2(Xf, work_buf(), X, P);
     }
 
     // data fidelity evaluated at Y (fEvalX False / AuxVarObj, cbpdn.py:315-321)
-    void dfid_at(const T *V, double *out_dev) {
+    void dfid_at(const T *V, double *out_dev, const sporco_amd_admm_params *gp = nullptr) {
         cx<T> *wk = work_buf();
         fwd2(V, nullptr, T(0), wk, P);
+        if (gp && (gp->flags & F_GRADREG)) {
+            // the gradient term follows the data-fidelity variable (cbpdn.py:1209-1213)
+            int nbg;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nbg = launch_grad_norm<T>(st, wk, grad_term(gp->mu), npix, CN, K, W, part_a);
+            }
+            const int gslots[1] = {SPORCO_AMD_OUT_RGR};
+            const double gscales[1] = {1.0 / ((double)H * W)};
+            finalize(part_a, nbg, 1, 1, gslots, gscales, out_dev);
+        }
         {
             ProfScope ps(prof, PS_OTHER);
             launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), wk, innerb, npix, CN, K);
@@ -818,7 +873,7 @@ template <typename T> struct Csc : CscBase {
 
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT))) {
+        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT | F_GRADREG))) {
             admm_iter_fused(p, out_dev);
             return;
         }
@@ -848,7 +903,7 @@ template <typename T> struct Csc : CscBase {
                               SPORCO_AMD_OUT_L21};
         const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
         finalize(part_b, nb, 8, 7, slots, scales, out_dev);
-        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
     }
 
     void admm_xstep(const sporco_amd_admm_params &p, double *out_dev) override {
@@ -892,7 +947,7 @@ template <typename T> struct Csc : CscBase {
                               SPORCO_AMD_OUT_L21};
         const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
         finalize(part_b, nb, 8, 7, slots, scales, out_dev);
-        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev);
+        if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
     }
 
     void scale_u(double s) override {
@@ -1483,6 +1538,13 @@ int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64
     SA_HANDLE(h);
     SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
     h->impl->set_weight(1, w, shape);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_grad_weight(sporco_amd_csc_t h, const void *w) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->set_grad_weight(w);
     SA_API_END
 }
 

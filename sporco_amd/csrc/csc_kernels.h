@@ -30,6 +30,17 @@ enum : uint32_t {
     F_FEVAL_Y = 1u << 7,
     F_KEEP_X = 1u << 8,
     F_NO_X = 1u << 9,
+    F_GRADREG = 1u << 10,
+};
+
+// Gradient penalty of ConvBPDNGradReg (cbpdn.py:1133-1143): GHGf[h, wf] = ghh[h] + ghw[wf]
+// (signal.gradient_filters, signal.py:204-240, is separable), per-filter weights wg
+// (GradWeight; nullptr => 1) and the regularisation parameter mu.
+template <typename T> struct GradTerm {
+    const T *ghh = nullptr;  // H values   2 - 2 cos(2 pi h / H)
+    const T *ghw = nullptr;  // Wf values  2 - 2 cos(2 pi wf / W)
+    const T *wg = nullptr;   // K values or nullptr
+    T mu = T(0);
 };
 
 // dst(H, W, K) = zero-padded src(dH, dW, K)              (cnvrep.zpad, cnvrep.py:704-726)
@@ -46,10 +57,18 @@ void launch_gram(hipStream_t st, const cx<T> *df, T *gram, int64_t npix, int K);
 // partial sums (per block, 4 doubles): Parseval-weighted |Df.xf - Sf|^2, and the
 // LinSolveCheck triple |ax-b|^2, |ax|^2, |b|^2 (cbpdn.py:283-291).  Returns the
 // number of blocks that wrote partials.
+// With `grad` the system diagonal is mu wg GHGf + rho (linalg.solvedbd_sm, linalg.py:300-366,
+// as called by ConvBPDNGradReg.xstep, cbpdn.py:1163-1175); partials are then 5 doubles per
+// block, the fifth being the Parseval-weighted sum of wg GHGf |xf|^2 (cbpdn.py:1204-1214).
 template <typename T>
 int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                     const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
-                    bool want_obj, bool want_xrrs, double *partials);
+                    bool want_obj, bool want_xrrs, double *partials,
+                    const GradTerm<T> *grad = nullptr);
+// partial[block] = Parseval-weighted sum of wg GHGf |vf|^2 (RegGrad at an arbitrary spectrum)
+template <typename T>
+int launch_grad_norm(hipStream_t st, const cx<T> *vf, const GradTerm<T> &g, int64_t npix, int CN,
+                     int K, int W, double *partials);
 
 // out[pix, cn] = sum_k df[pix, k] * v[pix, cn, k]   (linalg.inner over axisM, linalg.py:41-88)
 template <typename T>

@@ -105,6 +105,7 @@ template <typename T> struct SmArgs {
     int CN, K, Wf, W;
     int want_obj, want_xrrs;
     double *partials;
+    GradTerm<T> g;
 };
 
 __device__ __forceinline__ double parseval_weight(int wf, int Wf, int W) {
@@ -112,16 +113,32 @@ __device__ __forceinline__ double parseval_weight(int wf, int Wf, int W) {
     return (wf == 0 || ((W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
 }
 
+// Weighted gradient spectrum w_k * sum_i |G_i|^2 at (pixel, filter): GHGf of cbpdn.py:1141-1143
+template <typename T>
+__device__ __forceinline__ T grad_gh(const GradTerm<T> &g, int64_t pix, int Wf) {
+    return g.ghh[pix / Wf] + g.ghw[pix % Wf];
+}
+template <typename T> __device__ __forceinline__ T grad_w(const GradTerm<T> &g, int k) {
+    return g.wg ? g.wg[k] : T(1);
+}
+
 // Fast path: K even and G = K/2 a power of two <= 64.  Each lane owns two
 // adjacent filters (one 16-byte access for f32), a group of G lanes owns one
 // (pixel, c, n) system, and the K-length inner product is a log2(G)-step
 // wave shuffle reduction.
-template <typename T>
+//
+// GRAD (ConvBPDNGradReg, cbpdn.py:1163-1175): the system diagonal is
+// dd_k = mu w_k GHGf + rho instead of rho (linalg.solvedbd_sm, linalg.py:300-366):
+//     coef = (Sf - rho sum_k Df yuf / dd) / (1 + sum_k |Df|^2 / dd)
+//     xf   = (rho yuf + conj(Df) coef) / dd,        Df.xf - Sf = -coef
+// and partial 4 is the Parseval-weighted sum of w_k GHGf |xf|^2 (obfn_reg, :1204-1214).
+template <typename T, bool GRAD>
 __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T> a) {
+    constexpr int NA = GRAD ? 5 : 4;
     const int G = a.K >> 1;
     const int64_t total = a.npix * a.CN * G;
     const int64_t total_pad = (total + kWave - 1) / kWave * kWave;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[NA] = {};
     const T rho = a.rho;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_pad;
          t += (int64_t)gridDim.x * blockDim.x) {
@@ -133,27 +150,55 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
         cx<T> s = mk<T>(T(0), T(0));
         T g = T(1);
         yu.a = yu.b = d.a = d.b = s;
+        T gwa = T(0), gwb = T(0);
         if (valid) {
             yu = *reinterpret_cast<const cxpair<T> *>(a.yuf + 2 * t);
             d = *reinterpret_cast<const cxpair<T> *>(a.df + pix * a.K + 2 * lg);
             s = a.sf[grp];
-            g = a.gram[pix];
+            if constexpr (GRAD) {
+                const T gh = grad_gh(a.g, pix, a.Wf);
+                gwa = grad_w(a.g, 2 * lg) * gh;
+                gwb = grad_w(a.g, 2 * lg + 1) * gh;
+            } else {
+                g = a.gram[pix];
+            }
         }
-        cx<T> q = cmul(d.a, yu.a) + cmul(d.b, yu.b);
+        const T dda = GRAD ? a.g.mu * gwa + rho : rho, ddb = GRAD ? a.g.mu * gwb + rho : rho;
+        const T ia = T(1) / dda, ib = T(1) / ddb;
+        cx<T> q;
+        T gs = T(0);
+        if constexpr (GRAD) {
+            q = cscale(cmul(d.a, yu.a), ia) + cscale(cmul(d.b, yu.b), ib);
+            gs = cabs2(d.a) * ia + cabs2(d.b) * ib;
+        } else {
+            q = cmul(d.a, yu.a) + cmul(d.b, yu.b);
+        }
         for (int m = G >> 1; m > 0; m >>= 1) {
             q.re += __shfl_xor(q.re, m, kWave);
             q.im += __shfl_xor(q.im, m, kWave);
+            if constexpr (GRAD) gs += __shfl_xor(gs, m, kWave);
         }
-        const T inv = T(1) / (g + rho);
-        const cx<T> coef = cscale(s - q, inv);
+        cx<T> coef;
         cxpair<T> x;
-        x.a = yu.a + cmulc(d.a, coef);
-        x.b = yu.b + cmulc(d.b, coef);
+        if constexpr (GRAD) {
+            coef = cscale(s - cscale(q, rho), T(1) / (T(1) + gs));
+            x.a = cscale(cscale(yu.a, rho) + cmulc(d.a, coef), ia);
+            x.b = cscale(cscale(yu.b, rho) + cmulc(d.b, coef), ib);
+        } else {
+            coef = cscale(s - q, T(1) / (g + rho));
+            x.a = yu.a + cmulc(d.a, coef);
+            x.b = yu.b + cmulc(d.b, coef);
+        }
         if (valid) *reinterpret_cast<cxpair<T> *>(a.xf + 2 * t) = x;
+        const double pw = parseval_weight((int)(pix % a.Wf), a.Wf, a.W);
         if (a.want_obj && valid && lg == 0) {
-            // Df.xf - Sf = rho (q - Sf) / (gram + rho)
-            const double e2 = (double)cabs2(coef) * (double)rho * (double)rho;
-            acc[0] += parseval_weight((int)(pix % a.Wf), a.Wf, a.W) * e2;
+            // Df.xf - Sf = rho (q - Sf) / (gram + rho)   [GRAD: -coef]
+            const double e2 = (double)cabs2(coef) * (GRAD ? 1.0 : (double)rho * (double)rho);
+            acc[0] += pw * e2;
+        }
+        if constexpr (GRAD) {
+            if (a.want_obj && valid)
+                acc[4] += pw * ((double)gwa * (double)cabs2(x.a) + (double)gwb * (double)cabs2(x.b));
         }
         if (a.want_xrrs) {
             cx<T> dx = cmul(d.a, x.a) + cmul(d.b, x.b);
@@ -162,8 +207,8 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
                 dx.im += __shfl_xor(dx.im, m, kWave);
             }
             if (valid) {
-                const cx<T> axa = cmulc(d.a, dx) + cscale(x.a, rho);
-                const cx<T> axb = cmulc(d.b, dx) + cscale(x.b, rho);
+                const cx<T> axa = cmulc(d.a, dx) + cscale(x.a, dda);
+                const cx<T> axb = cmulc(d.b, dx) + cscale(x.b, ddb);
                 const cx<T> ba = cmulc(d.a, s) + cscale(yu.a, rho);
                 const cx<T> bb = cmulc(d.b, s) + cscale(yu.b, rho);
                 acc[1] += (double)cabs2(axa - ba) + (double)cabs2(axb - bb);
@@ -172,14 +217,15 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
             }
         }
     }
-    block_sum_store<4>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * 4);
+    block_sum_store<NA>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * NA);
 }
 
 // Generic path (any K): one thread per (pixel, c, n) system.
-template <typename T>
+template <typename T, bool GRAD>
 __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs<T> a) {
+    constexpr int NA = GRAD ? 5 : 4;
     const int64_t total = a.npix * a.CN;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[NA] = {};
     const T rho = a.rho;
     for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
          grp += (int64_t)gridDim.x * blockDim.x) {
@@ -188,32 +234,49 @@ __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs
         const cx<T> *yu = a.yuf + grp * a.K;
         cx<T> *x = a.xf + grp * a.K;
         const cx<T> s = a.sf[grp];
+        const T gh = GRAD ? grad_gh(a.g, pix, a.Wf) : T(0);
+        auto diag = [&](int k) -> T { return GRAD ? a.g.mu * (grad_w(a.g, k) * gh) + rho : rho; };
         cx<T> q = mk<T>(T(0), T(0));
-        for (int k = 0; k < a.K; ++k) q = q + cmul(d[k], yu[k]);
-        const T inv = T(1) / (a.gram[pix] + rho);
-        const cx<T> coef = cscale(s - q, inv);
+        T gs = T(0);
+        for (int k = 0; k < a.K; ++k) {
+            if constexpr (GRAD) {
+                const T inv = T(1) / diag(k);
+                q = q + cscale(cmul(d[k], yu[k]), inv);
+                gs += cabs2(d[k]) * inv;
+            } else {
+                q = q + cmul(d[k], yu[k]);
+            }
+        }
+        const cx<T> coef = GRAD ? cscale(s - cscale(q, rho), T(1) / (T(1) + gs))
+                                : cscale(s - q, T(1) / (a.gram[pix] + rho));
+        const double pw = parseval_weight((int)(pix % a.Wf), a.Wf, a.W);
         if (a.want_obj)
-            acc[0] += parseval_weight((int)(pix % a.Wf), a.Wf, a.W) * (double)cabs2(coef) *
-                      (double)rho * (double)rho;
+            acc[0] += pw * (double)cabs2(coef) * (GRAD ? 1.0 : (double)rho * (double)rho);
         cx<T> dx = mk<T>(T(0), T(0));
-        double b2 = 0.0;
+        double b2 = 0.0, rg = 0.0;
         for (int k = 0; k < a.K; ++k) {
             const cx<T> yk = yu[k];
-            const cx<T> xk = yk + cmulc(d[k], coef);
+            const cx<T> xk = GRAD ? cscale(cscale(yk, rho) + cmulc(d[k], coef), T(1) / diag(k))
+                                  : yk + cmulc(d[k], coef);
             if (a.want_xrrs) {
                 dx = dx + cmul(d[k], xk);
                 b2 += (double)cabs2(cmulc(d[k], s) + cscale(yk, rho));
             }
+            if constexpr (GRAD) rg += (double)(grad_w(a.g, k) * gh) * (double)cabs2(xk);
             x[k] = xk;
         }
+        if constexpr (GRAD) {
+            if (a.want_obj) acc[4] += pw * rg;
+        }
         if (a.want_xrrs) {
-            // b = ax + (b - ax):  recompute b from x: yu = x - conj(d) coef
+            // b = ax + (b - ax):  recompute b from x: rho yu = dd x - conj(d) coef
             double d2 = 0.0, ax2 = 0.0;
             for (int k = 0; k < a.K; ++k) {
                 const cx<T> xk = x[k];
-                const cx<T> yk = xk - cmulc(d[k], coef);
-                const cx<T> ax = cmulc(d[k], dx) + cscale(xk, rho);
-                const cx<T> b = cmulc(d[k], s) + cscale(yk, rho);
+                const cx<T> ry = GRAD ? cscale(xk, diag(k)) - cmulc(d[k], coef)
+                                      : cscale(xk - cmulc(d[k], coef), rho);
+                const cx<T> ax = cmulc(d[k], dx) + cscale(xk, diag(k));
+                const cx<T> b = cmulc(d[k], s) + ry;
                 d2 += (double)cabs2(ax - b);
                 ax2 += (double)cabs2(ax);
             }
@@ -222,7 +285,7 @@ __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs
             acc[3] += b2;
         }
     }
-    block_sum_store<4>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * 4);
+    block_sum_store<NA>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * NA);
 }
 
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -230,7 +293,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 template <typename T>
 int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                     const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
-                    bool want_obj, bool want_xrrs, double *partials) {
+                    bool want_obj, bool want_xrrs, double *partials, const GradTerm<T> *grad) {
     SmArgs<T> a;
     a.yuf = yuf;
     a.xf = xf;
@@ -246,15 +309,53 @@ int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df
     a.want_obj = want_obj;
     a.want_xrrs = want_xrrs;
     a.partials = partials;
-    const size_t lds = sizeof(double) * 4 * (kThreads / kWave);
+    a.g = grad ? *grad : GradTerm<T>();
+    const size_t lds = sizeof(double) * 5 * (kThreads / kWave);
     int grid;
     if (K % 2 == 0 && is_pow2(K / 2) && K / 2 <= kWave) {
         grid = grid_for(npix * CN * (K / 2));
-        hipLaunchKernelGGL((sm_solve_wave_kernel<T>), dim3(grid), dim3(kThreads), lds, st, a);
+        if (grad)
+            hipLaunchKernelGGL((sm_solve_wave_kernel<T, true>), dim3(grid), dim3(kThreads), lds, st, a);
+        else
+            hipLaunchKernelGGL((sm_solve_wave_kernel<T, false>), dim3(grid), dim3(kThreads), lds, st, a);
     } else {
         grid = grid_for(npix * CN);
-        hipLaunchKernelGGL((sm_solve_generic_kernel<T>), dim3(grid), dim3(kThreads), lds, st, a);
+        if (grad)
+            hipLaunchKernelGGL((sm_solve_generic_kernel<T, true>), dim3(grid), dim3(kThreads), lds, st, a);
+        else
+            hipLaunchKernelGGL((sm_solve_generic_kernel<T, false>), dim3(grid), dim3(kThreads), lds, st, a);
     }
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// partial[block] = Parseval-weighted sum of w_k GHGf |vf|^2 over (npix, CN, K): the
+// gradient regulariser evaluated at an arbitrary spectrum (cbpdn.py:1204-1214 with
+// fEvalX False)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) grad_norm_kernel(const cx<T> *__restrict__ vf,
+                                                             const GradTerm<T> g, int64_t npix,
+                                                             int CN, int K, int W,
+                                                             double *__restrict__ partials) {
+    const int Wf = W / 2 + 1;
+    const int64_t total = npix * CN * K;
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / ((int64_t)K * CN);
+        acc[0] += parseval_weight((int)(pix % Wf), Wf, W) *
+                  (double)(grad_w(g, k) * grad_gh(g, pix, Wf)) * (double)cabs2(vf[i]);
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T>
+int launch_grad_norm(hipStream_t st, const cx<T> *vf, const GradTerm<T> &g, int64_t npix, int CN,
+                     int K, int W, double *partials) {
+    const int grid = grid_for(npix * CN * K);
+    hipLaunchKernelGGL((grad_norm_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, vf, g, npix, CN, K, W, partials);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -1171,9 +1272,11 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
 #define SA_INST(T)                                                                                 \
     template void launch_pad_dict<T>(hipStream_t, const T *, T *, int, int, int, int, int);        \
     template void launch_gram<T>(hipStream_t, const cx<T> *, T *, int64_t, int);                   \
+    template int launch_grad_norm<T>(hipStream_t, const cx<T> *, const GradTerm<T> &, int64_t, int, \
+                                     int, int, double *);                                          \
     template int launch_sm_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,            \
                                     const cx<T> *, const T *, T, int64_t, int, int, int, bool,     \
-                                    bool, double *);                                               \
+                                    bool, double *, const GradTerm<T> *);                          \
     template void launch_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,     \
                                   int, int);                                                       \
     template int launch_rfl2norm2<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int64_t,  \

@@ -39,6 +39,16 @@ CASES = {
     'admm_joint_l21weight_f64': dict(opt={'MaxMainIter': 20, 'NonNegCoef': True},
                                      joint=True),
     'admm_warmstart_f64': dict(opt={'MaxMainIter': 15}),
+    # ConvBPDNGradReg
+    'admm_gradreg_f64': dict(opt={'MaxMainIter': 30}, gradreg=True),
+    'admm_gradreg_f32': dict(opt={'MaxMainIter': 30, 'DataType': np.float32},
+                             gradreg=True),
+    'admm_gradreg_weights_f64': dict(opt={'MaxMainIter': 25, 'rho': 1.5,
+                                          'AutoRho': {'Enabled': False},
+                                          'LinSolveCheck': True, 'NonNegCoef': True},
+                                     gradreg=True),
+    'admm_gradreg_auxvar_f64': dict(opt={'MaxMainIter': 20, 'AuxVarObj': True},
+                                    gradreg=True),
 }
 
 
@@ -53,7 +63,10 @@ def build(name, extra_opt=None):
     if extra_opt:
         optd.update(extra_opt)
     dimK = None if int(g['dimK']) < 0 else int(g['dimK'])
-    if case.get('joint'):
+    if case.get('gradreg'):
+        b = cbpdn.ConvBPDNGradReg(g['D'], g['S'], float(g['lmbda']), float(g['mu']),
+                                  cbpdn.ConvBPDNGradReg.Options(optd), dimK=dimK)
+    elif case.get('joint'):
         b = cbpdn.ConvBPDNJoint(g['D'], g['S'], float(g['lmbda']), float(g['mu']),
                                 cbpdn.ConvBPDNJoint.Options(optd), dimK=dimK)
     else:
@@ -90,7 +103,8 @@ def test_golden_traces(backend, name):
 
 @pytest.mark.parametrize('name', ['admm_default_f64', 'admm_joint_f64',
                                   'admm_odd_nonneg_nobndry_f64',
-                                  'admm_l1weight_auxvar_f64'])
+                                  'admm_l1weight_auxvar_f64',
+                                  'admm_gradreg_f64', 'admm_gradreg_auxvar_f64'])
 def test_staged_path_matches_fused(backend, name):
     """Overriding a step method switches solve() to one device call per
     reference step; the iterates must not change."""

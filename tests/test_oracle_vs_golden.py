@@ -102,6 +102,38 @@ def test_admm_traces(name):
                   g['recon']) < tol
 
 
+GRADREG_CASES = {
+    'admm_gradreg_f64': dict(maxiter=30),
+    'admm_gradreg_f32': dict(maxiter=30, dtype=np.float32),
+    'admm_gradreg_weights_f64': dict(maxiter=25, rho=1.5, auto_rho=False,
+                                     nonneg=True, _wg='optarr_GradWeight'),
+    'admm_gradreg_auxvar_f64': dict(maxiter=20, gevaly=True, fevalx=False,
+                                    _wg='optarr_GradWeight'),
+}
+
+
+@pytest.mark.parametrize('name', sorted(GRADREG_CASES))
+def test_gradreg_traces(name):
+    """ConvBPDNGradReg restatement (solvedbd_sm, gradient filters, RegGrad)."""
+    g = load_golden(name)
+    kw = dict(GRADREG_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    if '_wg' in kw:
+        kw['grad_weight'] = g[kw.pop('_wg')]
+    D5, S5 = to5d(g['D'], g['S'])
+    r = orc.admm_cbpdn(D5, S5, float(g['lmbda']), grad_mu=float(g['mu']),
+                       dtype=dtype, **kw)
+    assert rel_l2(orc.gradient_filters_ghg(S5.shape[:2], np.float64)
+                  * (kw.get('grad_weight', 1.0)), g['GHGf']) < 1e-6
+    assert r['iters'] == int(g['k_final'])
+    for key in ('Y', 'U', 'X', 'Xf'):
+        assert rel_l2(r[key], g[key]) < tol, key
+    for key in ('ObjFun', 'DFid', 'RegL1', 'RegGrad', 'PrimalRsdl', 'DualRsdl',
+                'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+
+
 def test_admm_known_answer():
     g = load_golden('admm_known_answer_f64')
     D5, S5 = to5d(g['D'], g['S'])
