@@ -248,6 +248,9 @@ template <typename T> struct Csc : CscBase {
     // ConvBPDNGradReg (F_GRADREG): separable gradient spectrum tables and filter weights
     T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
     bool have_wg = false;
+    T *g1t = nullptr;               // fused path: 1 + sum_k |Df|^2 / diagonal, tile-major
+    bool g1_valid = false;
+    double g1_rho = 0.0, g1_mu = 0.0;
 
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
@@ -290,7 +293,7 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMalloc((void **)&dft, sizeof(cx<T>) * npix * K));
             SA_HIP(hipMalloc((void **)&sft, sizeof(cx<T>) * npix * CN));
             SA_HIP(hipMalloc((void **)&gramt, sizeof(T) * npix));
-            SA_HIP(hipMalloc((void **)&part_f, sizeof(double) * (int64_t)Wf * CN));
+            SA_HIP(hipMalloc((void **)&part_f, sizeof(double) * 2 * (int64_t)Wf * CN));
             SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * H));
             SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * H));
             std::vector<cx<T>> ta(H), tb(H);
@@ -318,7 +321,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -406,6 +409,7 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_DF), dft, H, Wf, K);
         launch_permute_ab<T>(st, gram, gramt, H, Wf, 1);
+        g1_valid = false;
     }
     void refresh_fused_signal() {
         if (!fused && !fused_slabs) return;
@@ -425,7 +429,7 @@ template <typename T> struct Csc : CscBase {
         x_stale = false;
         t_ready = false;   // the Xf buffer is about to be reused
         sporco_amd_admm_params q = last_p;
-        q.flags = 0;
+        q.flags = last_p.flags & F_GRADREG;   // (the system solved, not the sums wanted)
         launch_rows_fwd_on(y_alt, u_alt, (T)q.u_scale);
         run_fused_cols(q, nullptr);
         rows_inverse_to(rv(SPORCO_AMD_VAR_X));
@@ -558,6 +562,7 @@ template <typename T> struct Csc : CscBase {
     void set_grad_weight(const void *w) override {
         before_state_change();
         have_wg = w != nullptr;
+        g1_valid = false;
         if (!w) return;
         if (!wg) SA_HIP(hipMalloc((void **)&wg, sizeof(T) * K));
         SA_HIP(hipMemcpyAsync(wg, w, sizeof(T) * K, hipMemcpyHostToDevice, st));
@@ -646,6 +651,25 @@ template <typename T> struct Csc : CscBase {
         fa.CN = CN;
         fa.K = K;
         fa.partials = part_f;
+        const bool gradreg = p.flags & F_GRADREG;
+        if (gradreg) {
+            SA_REQUIRE(fused, "the gradient-regularised column pass needs the K <= 64 kernel");
+            const GradTerm<T> gt = grad_term(p.mu);
+            if (!g1t) SA_HIP(hipMalloc((void **)&g1t, sizeof(T) * npix));
+            fa.ghh = gt.ghh;
+            fa.ghw = gt.ghw;
+            fa.wg = gt.wg;
+            fa.mu = gt.mu;
+            fa.g1t_out = g1t;
+            if (!g1_valid || g1_rho != p.rho || g1_mu != p.mu) {
+                ProfScope ps(prof, PS_OTHER);
+                launch_grad_g1<T>(st, fa);
+                g1_valid = true;
+                g1_rho = p.rho;
+                g1_mu = p.mu;
+            }
+            fa.g1t = g1t;
+        }
         int64_t ntiles;
         if (fused_slabs) {
             FusedSlabArgs<T> sa;
@@ -660,9 +684,10 @@ template <typename T> struct Csc : CscBase {
         }
         xf_tiled = true;
         if (out_dev && (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
-            const int slots[1] = {SPORCO_AMD_OUT_DFID};
-            const double scales[1] = {1.0 / ((double)H * W)};
-            finalize(part_f, (int)ntiles, 1, 1, slots, scales, out_dev);
+            const int slots[2] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_RGR};
+            const double scales[2] = {1.0 / ((double)H * W), 1.0 / ((double)H * W)};
+            const int nv = gradreg ? 2 : 1;
+            finalize(part_f, (int)ntiles, nv, nv, slots, scales, out_dev);
         }
     }
 
@@ -722,12 +747,13 @@ template <typename T> struct Csc : CscBase {
             const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
                                   SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
             const double scales[6] = {1, 1, 1, 1, 1, 1};
-            const int fslots[1] = {SPORCO_AMD_OUT_DFID};
-            const double fscales[1] = {1.0 / ((double)H * W)};
+            const int fslots[2] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_RGR};
+            const double fscales[2] = {1.0 / ((double)H * W), 1.0 / ((double)H * W)};
             const bool dfid = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
+            const int fnv = (p.flags & F_GRADREG) ? 2 : 1;
             ProfScope ps(prof, PS_FINALIZE);
-            launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, (int)(Wf * CN), 1,
-                             dfid ? 1 : 0, fslots, fscales, out_dev);
+            launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, (int)(Wf * CN), fnv,
+                             dfid ? fnv : 0, fslots, fscales, out_dev);
         }
         if (keep_x) {
             x_written();
@@ -794,7 +820,7 @@ template <typename T> struct Csc : CscBase {
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         const bool gradreg = p.flags & F_GRADREG;
-        if ((fused || (fused_slabs && rows_ok)) && !(p.flags & F_XRRS) && !gradreg) {
+        if ((fused || (fused_slabs && rows_ok && !gradreg)) && !(p.flags & F_XRRS)) {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
             const int64_t tline = (int64_t)CN * H * K, tgrp = (int64_t)H * K;
@@ -873,7 +899,7 @@ template <typename T> struct Csc : CscBase {
 
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT | F_GRADREG))) {
+        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT)) && (fused || !(p.flags & F_GRADREG))) {
             admm_iter_fused(p, out_dev);
             return;
         }

@@ -35,7 +35,17 @@ template <typename T> struct FusedColsArgs {
     T rho;
     int H, W, CN, K;
     double *partials;  // one double per tile: Parseval-weighted sum |Df.xf - Sf|^2
+    // ConvBPDNGradReg (g1t != nullptr; K <= 64 kernel only): the system diagonal is
+    // mu wg[k] (ghh[f] + ghw[wf]) + rho, g1t[wf][f] = 1 + sum_k |Df|^2 / diagonal
+    // (launch_grad_g1 fills it), and partials holds two doubles per tile, the second the
+    // Parseval-weighted sum of wg GHGf |xf|^2.
+    const T *g1t = nullptr;
+    T *g1t_out = nullptr;
+    const T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
+    T mu = T(0);
 };
+// g1t_out[wf][h] from dft, ghh, ghw, wg, mu, rho.
+template <typename T> void launch_grad_g1(hipStream_t st, const FusedColsArgs<T> &a);
 
 // 64 < K <= 256 filters (NH = ceil(K/64) slabs, the last one possibly partial): a tile of all K filters does not fit the register file
 // of one workgroup, so the X-step column pass runs as two kernels over (tile, 64-filter

@@ -41,7 +41,12 @@ constexpr size_t fused_lds_bytes(int NW, int LP) {
 }
 
 // N1 x NW = H; NW waves; KC: compile-time filter count (64), or 0 for a run-time K <= 64.
-template <int N1, int NW, int LPARAM, int KC>
+// GRAD: the diagonal Sherman-Morrison form of ConvBPDNGradReg (cbpdn.py:1163-1175,
+// linalg.py:300-366) with dd = mu wg_k (ghh[f] + ghw[wf]) + rho per element:
+//     coef = (Sf - rho sum_k Df yuf / dd) / g1,    g1 = 1 + sum_k |Df|^2 / dd  (table)
+//     xf = (rho yuf + conj(Df) coef) / dd,         Df.xf - Sf = -coef
+// and a second partial per tile, the weighted sum of wg GHGf |xf|^2 (cbpdn.py:1204-1214).
+template <int N1, int NW, int LPARAM, int KC, bool GRAD>
 __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
     constexpr int H = N1 * NW;
     constexpr int J = N1 / NW;   // stage-2 lines per thread (each NW points)
@@ -74,7 +79,8 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, (uint32_t)(H * K * sizeof(cf)));
     const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
     const cf *S = a.sft + (int64_t)tile * H + w;
-    const float *G = a.gramt + (int64_t)wf * H + w;
+    const float *G = (GRAD ? a.g1t : a.gramt) + (int64_t)wf * H + w;
+    const float *GH = a.ghh + w;
     const cf *twA = a.twA + w * N1;                           // W_H^(w * brev(i)),      i < N1
     const cf *twB = a.twB + w * N1;                           // W_H^((w + NW j) * h2), [j][h2]
     // One buffer serves both exchanges: a unit is written and read back by the
@@ -98,6 +104,13 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 
     const float rho = a.rho;
     float obj = 0.f;
+    // GRAD: dd = ak * ghh[f] + bk, with the row-frequency part folded into bk
+    float ak = 0.f, bk = 0.f, gw = 0.f, rg = 0.f;
+    if constexpr (GRAD) {
+        gw = sa_uload(a.ghw + wf);
+        ak = a.mu * ((a.wg && kv) ? a.wg[k] : 1.f);
+        bk = ak * gw + rho;
+    }
     static_for<Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         // ---- exchange A: (w = h2; f1 in regs) -> (w = f1 mod NW; h2 in regs) ---------
@@ -115,7 +128,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
         constexpr int CPL = NW / 4, NCH = LP * CPL;   // chunks per line, per group
         cf dn[4];
         cf sn[4];
-        float gn[4];
+        float gn[4], hn[4];
         auto prefetch = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
@@ -125,6 +138,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                 sa_uload2(reinterpret_cast<const float *>(S + fo), sn[e].re, sn[e].im);
                 gn[e] = sa_uload(G + fo);
+                if constexpr (GRAD) hn[e] = sa_uload(GH + fo);
             }
         };
         prefetch(std::integral_constant<int, 0>{});
@@ -145,17 +159,22 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
             if constexpr (c == 0) dif<NW, false>(u, NW * jl);
             // Sherman-Morrison solve of 4 frequencies
             cf d[4], sv[4];
-            float gv[4], red[8];
+            float gv[4], hv[4], idd[4], red[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 d[e] = dn[e];
                 sv[e] = sn[e];
                 gv[e] = gn[e];
+                if constexpr (GRAD) hv[e] = hn[e];
             }
             if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                if constexpr (GRAD) {
+                    idd[e] = sa_rcp(ak * hv[e] + bk);
+                    p = cscale(p, idd[e]);
+                }
                 red[2 * e] = p.re;
                 red[2 * e + 1] = p.im;
             }
@@ -163,11 +182,20 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const cf qq = mk<float>(sa_readlane(tot, 16 * e), sa_readlane(tot, 16 * e + 8));
-                const float inv = sa_rcp(gv[e] + rho);
-                const cf coef = cscale(sv[e] - qq, inv);
-                // Df.xf - Sf = rho (q - Sf) / (gram + rho)
-                obj += cabs2(coef);
-                u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
+                if constexpr (GRAD) {
+                    const cf coef = cscale(sv[e] - cscale(qq, rho), sa_rcp(gv[e]));
+                    obj += cabs2(coef);
+                    const cf xn = cscale(cscale(u[NW * jl + 4 * c + e], rho) + cmulc(d[e], coef),
+                                         idd[e]);
+                    rg += (hv[e] + gw) * cabs2(xn);
+                    u[NW * jl + 4 * c + e] = xn;
+                } else {
+                    const float inv = sa_rcp(gv[e] + rho);
+                    const cf coef = cscale(sv[e] - qq, inv);
+                    // Df.xf - Sf = rho (q - Sf) / (gram + rho)
+                    obj += cabs2(coef);
+                    u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
+                }
             }
             // inverse FFT over f2, conj twiddle
             if constexpr (c == CPL - 1) {
@@ -181,7 +209,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 }
             }
         });
-        SA_VGPR_FENCE3(obj, token, token);
+        SA_VGPR_FENCE3(obj, rg, token);
         // ---- exchange B: back to (w = h2; f1 in regs), placed in DIT input order -----
 #pragma unroll
         for (int jl = 0; jl < LP; ++jl) {
@@ -213,8 +241,34 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     // (always written: a conditional here makes the compiler sink the whole |coef|^2
     // chain into the branch and keep every coef alive until the end of the kernel)
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
-    double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
-    block_sum_store<1>(acc, scratch, a.partials + tile);
+    if constexpr (GRAD) {
+        const float wk = (a.wg && kv) ? a.wg[k] : 1.f;
+        double acc[2] = {k == 0 ? (double)obj * pw : 0.0, kv ? (double)(rg * wk) * pw : 0.0};
+        block_sum_store<2>(acc, scratch, a.partials + 2 * tile);
+    } else {
+        double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
+        block_sum_store<1>(acc, scratch, a.partials + tile);
+    }
+}
+
+// g1t[wf][h] = 1 + sum_k |Df|^2 / (mu wg_k (ghh[h] + ghw[wf]) + rho): the Sherman-Morrison
+// denominator of linalg.solvedbd_sm_c (linalg.py:346-366), refreshed when rho changes.
+// One wave per (wf, h) row of the tile-major Df, lane = filter.
+__global__ void __launch_bounds__(256) grad_g1_kernel(const FusedColsArgs<float> a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nrows = (int64_t)(a.W / 2 + 1) * a.H;
+    if (row >= nrows) return;
+    const int wf = (int)(row / a.H), h = (int)(row % a.H);
+    const float gh = a.ghh[h], gw = a.ghw[wf];
+    float s = 0.f;
+    for (int k = lane; k < a.K; k += 64) {
+        const float ak = a.mu * (a.wg ? a.wg[k] : 1.f);
+        const float dd = ak * gh + (ak * gw + a.rho);
+        s += cabs2(a.dft[row * a.K + k]) / dd;
+    }
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) a.g1t_out[row] = 1.f + s;
 }
 
 // ---------------------------------------------------------------------------
@@ -491,26 +545,31 @@ template <> bool fused_cols_supported<float>(int H, int K) {
 }
 template <> bool fused_cols_supported<double>(int, int) { return false; }
 
-template <int N1, int NW, int LP, int KC>
+template <int N1, int NW, int LP, int KC, bool GRAD>
 static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
     static bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC>),
+            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC, GRAD>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
-    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC>), dim3((unsigned)(wf_groups * 8 * a.CN)),
-                       dim3(NW * 64), fused_lds_bytes(NW, LP), st, a);
+    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD>),
+                       dim3((unsigned)(wf_groups * 8 * a.CN)), dim3(NW * 64),
+                       fused_lds_bytes(NW, LP), st, a);
 }
 
 template <int N1, int NW, int LP>
 static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
-    if (a.K == 64)
-        launch_fused_inst<N1, NW, LP, 64>(st, a, ntiles);
-    else
-        launch_fused_inst<N1, NW, LP, 0>(st, a, ntiles);
+    const bool grad = a.g1t != nullptr;
+    if (a.K == 64) {
+        if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
+        else launch_fused_inst<N1, NW, LP, 64, false>(st, a, ntiles);
+    } else {
+        if (grad) launch_fused_inst<N1, NW, LP, 0, true>(st, a, ntiles);
+        else launch_fused_inst<N1, NW, LP, 0, false>(st, a, ntiles);
+    }
 }
 
 template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs<float> &a_in) {
@@ -524,6 +583,14 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
         launch_fused_k<32, 16, 1>(st, a, ntiles);
     SA_HIP(hipGetLastError());
     return ntiles;
+}
+template <> void launch_grad_g1<float>(hipStream_t st, const FusedColsArgs<float> &a) {
+    const int64_t nrows = (int64_t)(a.W / 2 + 1) * a.H;
+    hipLaunchKernelGGL(grad_g1_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, st, a);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_grad_g1<double>(hipStream_t, const FusedColsArgs<double> &) {
+    throw Error(-1, "the fused column kernel is float32 only");
 }
 template <> bool fused_slabs_supported<float>(int H, int K) {
     return (H == 256 || H == 512) && K > 64 && K <= 256 && K % 2 == 0;

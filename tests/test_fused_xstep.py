@@ -284,3 +284,49 @@ def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
     its = b.getitstat()
     for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
+
+
+# ---------------------------------------------------------------------------
+# ConvBPDNGradReg on the fused kernels (GRAD variant of the column kernel)
+# ---------------------------------------------------------------------------
+def solve_gradreg(D, S, optd, mu=0.3, unfused=False):
+    from sporco_amd.admm import cbpdn
+    if unfused:
+        os.environ['SPORCO_AMD_UNFUSED'] = '1'
+    try:
+        b = cbpdn.ConvBPDNGradReg(D, S, 0.05, mu, cbpdn.ConvBPDNGradReg.Options(optd))
+    finally:
+        os.environ.pop('SPORCO_AMD_UNFUSED', None)
+    return b, b.solve()
+
+
+@pytest.mark.parametrize('H,W,K,N,weights', [
+    (256, 12, 8, 2, False), (512, 8, 6, 1, True),
+    pytest.param(256, 256, 4, 1, True),
+    pytest.param(512, 512, 64, 2, True, marks=pytest.mark.gpu)])
+def test_fused_gradreg_matches_oracle_and_unfused(backend, H, W, K, N, weights):
+    from oracle import cbpdn_oracle as orc
+    D, S = problem(H, W, K, N, seed=H + K + 1)
+    iters = 4 if W >= 256 else 10
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
+    wg = None
+    if weights:
+        wg = np.linspace(0.0, 2.0, K).astype(np.float32)
+        optd['GradWeight'] = wg
+    b, Y = solve_gradreg(D, S, optd)
+    assert b._dev.uses_fused_cols()
+    b0, Y0 = solve_gradreg(D, S, optd, unfused=True)
+    assert rel_l2(Y, Y0) < 2e-5
+    its, its0 = b.getitstat(), b0.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'RegGrad', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), getattr(its0, f)) < 1e-4, f
+    assert rel_l2(b.X, b0.X) < 2e-5
+    if W * K * N > 512 * 64:
+        return           # (the float64 oracle would take minutes at this size)
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
+                         dtype=np.float64, maxiter=iters, rel_tol=0.0, grad_mu=0.3,
+                         grad_weight=1.0 if wg is None else wg.astype(np.float64))
+    assert rel_l2(Y, ref['Y']) < 1e-4
+    assert rel_l2(b.X, ref['X']) < 1e-4
+    for f in ('ObjFun', 'DFid', 'RegL1', 'RegGrad', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f
