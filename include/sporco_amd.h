@@ -134,6 +134,12 @@ int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64
  * sporco/admm/cbpdn.py:1063-1071, :1134-1139): K values of the handle's dtype;
  * w == NULL restores the scalar weight 1. */
 int sporco_amd_csc_set_grad_weight(sporco_amd_csc_t h, const void *w);
+/* Mask of the additive-mask-simulation wrapper (AddMaskSim, sporco/admm/cbpdn.py:2287-2485):
+ * broadcastable against (H,W,C,N,1), shape[4] must be 1.  With SPORCO_AMD_FLAG_AMS the last
+ * filter of the dictionary is taken to be the appended impulse (:2345-2353); its slice of Y
+ * is AX + U zeroed where the mask is nonzero (:2378-2394) and is left out of the l1 / l2,1
+ * sums (:2398-2412).  w == NULL removes the mask. */
+int sporco_amd_csc_set_ams_mask(sporco_amd_csc_t h, const void *w, const int64_t shape[5]);
 
 /* Host <-> device transfer of one state array in the reference layout. */
 int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src);
@@ -160,6 +166,8 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
 #define SPORCO_AMD_FLAG_GRADREG (1u << 10)   /* ConvBPDNGradReg xstep / objective
                                                 (cbpdn.py:1163-1214): diagonal mu*GradWeight*GHGf
                                                 + rho, params.mu = gradient weight mu */
+#define SPORCO_AMD_FLAG_AMS (1u << 11)       /* AddMaskSim y step / regulariser sums on the
+                                                last filter slice (set_ams_mask) */
 
 typedef struct {
     double rho;      /* penalty parameter for this iteration                     */

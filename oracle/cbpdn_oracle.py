@@ -179,7 +179,7 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
                std_residuals=False, abs_tol=0.0, rel_tol=1e-3,
                nonneg=False, nobndry=False, wl1=1.0, wl21=1.0,
                gevaly=False, fevalx=True, stats=True, Y0=None, U0=None,
-               time_budget=None, grad_mu=None, grad_weight=1.0):
+               time_budget=None, grad_mu=None, grad_weight=1.0, ams_mask=None):
     """Run ADMM ConvBPDN (``mu is None``) or ConvBPDNJoint on 5-D arrays.
 
     ``D``: (dH, dW, 1, 1, K);  ``S``: (H, W, C, N, 1).  Single-channel
@@ -197,6 +197,13 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
     (cbpdn.py:992-1214): the x step solves with diagonal
     ``grad_mu * grad_weight[k] * GHGf + rho`` (:1167-1175) and the objective
     gains ``grad_mu * RegGrad`` (:1204-1214).
+
+    ``ams_mask`` selects the additive-mask-simulation wrapper AddMaskSim
+    (cbpdn.py:2287-2485) around the chosen class: ``D`` must already carry the
+    appended impulse filter as its last filter (:2345-2353), ``ams_mask`` is the
+    mask W in its internal 5-D shape (cnvrep.mskWshape); the y step leaves the
+    impulse slice unshrunk and zeroes it where W is nonzero (:2378-2394) and the
+    regularisers ignore that slice (:2398-2412).
 
     Returns a dict with final X, Y, U, Xf and the per-iteration traces.
     """
@@ -267,6 +274,8 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
         AXnr = X
         AX = X if rlx == 1.0 else rlx * X + (1 - rlx) * Y
         # -- ystep
+        if ams_mask is not None:
+            Yi = (AX + U)[..., -1:].copy()               # cbpdn.py:2386-2387
         if joint:
             Y = prox_sl1l2(AX + U, (lmbda / rho) * wl1, (mu / rho) * wl21,
                            axis=AX_C)
@@ -277,6 +286,11 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
         if nobndry:
             Y[1 - D.shape[0]:] = 0.0
             Y[:, 1 - D.shape[1]:] = 0.0
+        if ams_mask is not None:
+            # (index semantics of the reference kept as they are: np.where on W's own
+            # shape, so a broadcast axis of W addresses index 0 only)
+            Yi[np.where(np.asarray(ams_mask).astype(bool))] = 0.0   # cbpdn.py:2393
+            Y[..., -1:] = Yi
         # -- ustep: admm.py:434-437
         U = U + (AX - Y)
         if stats or auto_rho:
@@ -302,6 +316,9 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
             Ef = inner(Df, fvar, axis=AX_K) - Sf
             dfd = rfl2norm2(Ef, S.shape) / 2.0
             gvar = Y if gevaly else X
+            if ams_mask is not None:
+                gvar = gvar.copy()
+                gvar[..., -1:] = 0                       # cbpdn.py:2404-2411
             rl1 = np.linalg.norm((wl1 * gvar).ravel(), 1)
             if joint:
                 rl21 = np.sum(wl21 * np.sqrt(np.sum(gvar ** 2, axis=AX_C)))

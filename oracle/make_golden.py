@@ -360,11 +360,50 @@ def gen_gradreg():
                  {'MaxMainIter': 20, 'AuxVarObj': True, 'GradWeight': wg})
 
 
+def ams_case(name, cls, D, S, W, args, optd, dimK=None):
+    opt = cls.Options(optd)
+    b = ref_cbpdn.AddMaskSim(cls, D, S, W, *args, opt=opt, dimK=dimK)
+    Xret = b.solve()
+    c = b.cbpdn
+    extra = {}
+    for key, val in optd.items():
+        if isinstance(val, np.ndarray):
+            extra['optarr_' + key] = val.copy()
+    save(name, D=D, S=S, W=W, lmbda=np.float64(args[0]),
+         mu=np.float64(args[1] if len(args) > 1 else -1.0),
+         dimK=np.int64(-1 if dimK is None else dimK),
+         Wint=b.W, Xret=Xret, X=c.X, Y=c.Y, U=c.U, rho_final=np.float64(c.rho),
+         k_final=np.int64(c.k), recon=b.reconstruct(), coef=b.getcoef(),
+         **extra, **itstat_dict(c))
+
+
+def gen_ams():
+    """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
+    ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
+    np.random.seed(97531)
+    D = np.random.randn(5, 5, 3)
+    S = np.random.randn(16, 16, 2)
+    W2 = (np.random.rand(16, 16) > 0.3).astype(np.float64)      # broadcast over images
+    W3 = (np.random.rand(16, 16, 2) > 0.3).astype(np.float64)   # one mask per image
+    ams_case('ams_cbpdn_f64', ref_cbpdn.ConvBPDN, D, S, W3, (0.1,), {'MaxMainIter': 25})
+    ams_case('ams_cbpdn_f32', ref_cbpdn.ConvBPDN, D, S, W3, (0.1,),
+             {'MaxMainIter': 25, 'DataType': np.float32})
+    ams_case('ams_cbpdn_bcast_nonneg_f64', ref_cbpdn.ConvBPDN, D, S, W2, (0.1,),
+             {'MaxMainIter': 20, 'NonNegCoef': True, 'NoBndryCross': True,
+              'AuxVarObj': True})
+    ams_case('ams_gradreg_f64', ref_cbpdn.ConvBPDNGradReg, D, S, W3, (0.1, 0.2),
+             {'MaxMainIter': 20, 'GradWeight': np.array([0.0, 1.0, 0.5, 1.0])})
+    Sc = np.random.randn(16, 16, 3, 2)
+    Wc = (np.random.rand(16, 16, 3, 2) > 0.3).astype(np.float64)
+    ams_case('ams_joint_f64', ref_cbpdn.ConvBPDNJoint, D, Sc, Wc, (0.1, 0.05),
+             {'MaxMainIter': 20})
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg,
+                             'pcn', 'dictlearn', 'gradreg', 'ams']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -29,6 +29,7 @@ FLAG_FEVAL_Y = 1 << 7
 FLAG_KEEP_X = 1 << 8
 FLAG_NO_X = 1 << 9
 FLAG_GRADREG = 1 << 10
+FLAG_AMS = 1 << 11
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
@@ -43,7 +44,7 @@ EXPORTS = (
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_destroy',
     'sporco_amd_csc_sync', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
-    'sporco_amd_csc_set_grad_weight',
+    'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
     'sporco_amd_csc_admm_iter', 'sporco_amd_csc_admm_iter_dev',
     'sporco_amd_csc_admm_xstep', 'sporco_amd_csc_admm_relax',
@@ -164,6 +165,7 @@ def load(path=None):
         'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_l21_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_grad_weight': [vp, vp],
+        'sporco_amd_csc_set_ams_mask': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_upload': [vp, ctypes.c_int, vp],
         'sporco_amd_csc_download': [vp, ctypes.c_int, vp],
         'sporco_amd_csc_device_ptr': [vp, ctypes.c_int, ctypes.POINTER(vp)],
@@ -363,6 +365,10 @@ class Solver(object):
 
     def set_l21_weight(self, w):
         self._set_weight(self._lib.sporco_amd_csc_set_l21_weight, w)
+
+    def set_ams_mask(self, w):
+        """AddMaskSim mask, 5-D with every axis 1 or full and a singleton filter axis."""
+        self._set_weight(self._lib.sporco_amd_csc_set_ams_mask, w)
 
     def set_grad_weight(self, w):
         """K per-filter weights of the gradient penalty, or None for 1."""

@@ -29,7 +29,8 @@ from .. import _lib
 from .. import cnvrep as cr
 from ..fft import complex_dtype, real_dtype
 
-__all__ = ['GenericConvBPDN', 'ConvBPDN', 'ConvBPDNJoint', 'ConvBPDNGradReg']
+__all__ = ['GenericConvBPDN', 'ConvBPDN', 'ConvBPDNJoint', 'ConvBPDNGradReg',
+           'AddMaskSim']
 
 
 class _DeviceArray(object):
@@ -229,6 +230,8 @@ class GenericConvBPDN(admm.ADMMEqual):
             f |= _lib.FLAG_XRRS
         if self._no_x:
             f |= _lib.FLAG_NO_X
+        if self._ams_mask is not None:
+            f |= _lib.FLAG_AMS
         return f
 
     def _lmbda_eff(self):
@@ -249,7 +252,27 @@ class GenericConvBPDN(admm.ADMMEqual):
         return p
 
     def _upload_weights(self):
-        pass
+        self._upload_ams()
+
+    _ams_mask = None
+
+    def _set_ams(self, W):
+        """Switch on the additive-mask-simulation treatment of the last filter
+        (the impulse appended by :class:`AddMaskSim`) with mask ``W`` in its internal
+        5-D shape (cnvrep.mskWshape)."""
+        self._ams_mask = np.asarray(W)
+        self._upload_ams()
+
+    def _upload_ams(self):
+        if self._ams_mask is None:
+            return
+        H, W_, C, N, _ = self.cri.shpX
+        # the reference zeroes `Yi[np.where(W.astype(bool))]` (cbpdn.py:2393): fancy
+        # indexing with W's own index tuples, so an axis that W merely broadcasts over
+        # addresses index 0 only; expanding the mask the same way keeps that behaviour
+        full = np.zeros((H, W_, C, N, 1), dtype=self.dtype)
+        full[np.where(self._ams_mask.astype(bool))] = 1.0
+        self._dev.set_ams_mask(full)
 
     # -- iteration: fused when nothing is overridden -----------------------------------
     def _fused_ok(self):
@@ -446,6 +469,7 @@ class ConvBPDN(GenericConvBPDN):
             self.U = (self.lmbda / self.rho) * np.sign(self.Y)
 
     def _upload_weights(self):
+        super(ConvBPDN, self)._upload_weights()
         if self.wl1.size == 1:
             self._wl1_scalar = float(self.wl1.ravel()[0])
             self._dev.set_l1_weight(None)
@@ -619,6 +643,71 @@ class ConvBPDNGradReg(ConvBPDN):
         rl1 = abs(self._wl1_scalar) * self._sums[_lib.OUT_L1]
         rgr = self._wg_scalar * self._sums[_lib.OUT_RGR] / 2.0
         return (self.lmbda * rl1 + self.mu * rgr, rl1, rgr)
+
+
+class AddMaskSim(object):
+    """Boundary / missing-data masking by additive mask simulation: wrapper about a
+    ConvBPDN-family object of this module with an impulse filter appended to the
+    dictionary (reference class: sporco/admm/cbpdn.py:2287-2485, same constructor,
+    methods and attributes; ``b.cbpdn`` is the inner solver).
+
+    The reference installs Python replacements for the inner object's ``ystep`` and
+    ``obfn_gvar``.  Here the inner solver is told about the mask instead
+    (``SPORCO_AMD_FLAG_AMS``): its y step and regulariser sums treat the impulse slice
+    on the device, so the iteration stays one fused call.
+    """
+
+    def __init__(self, cbpdnclass, D, S, W, *args, **kwargs):
+        dimK = kwargs.get('dimK', None)
+        dimN = kwargs.get('dimN', 2)
+        self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
+        if self.cri.Cd != 1:
+            raise NotImplementedError(
+                "multi-channel dictionaries are not part of the sporco_amd hot path yet")
+        if not hasattr(cbpdnclass, '_set_ams'):
+            raise TypeError("AddMaskSim wraps the solver classes of sporco_amd.admm.cbpdn")
+        # impulse filter appended to the dictionary (cbpdn.py:2345-2353)
+        self.imp = np.zeros(D.shape[0:dimN] + (1,))
+        self.imp[(0,) * dimN] = 1.0
+        Di = np.concatenate((D, self.imp), axis=D.ndim - 1)
+        self.cbpdn = cbpdnclass(Di, S, *args, **kwargs)
+        self.IterationStats = self.cbpdn.IterationStats
+        self.W = np.asarray(W.reshape(cr.mskWshape(W, self.cri)), dtype=self.cbpdn.dtype)
+        self.cbpdn._set_ams(self.W)
+
+    def solve(self):
+        """Solve with the inner object; the AMS component is stripped from the result."""
+        Xi = self.cbpdn.solve()
+        self.timer = self.cbpdn.timer
+        self.itstat = self.cbpdn.itstat
+        return Xi[self.index_primary()]
+
+    def setdict(self, D=None):
+        imp = self.imp.reshape(self.imp.shape[:-1] + (1,) * (D.ndim - self.imp.ndim) +
+                               self.imp.shape[-1:])
+        self.cbpdn.setdict(np.concatenate((D, imp), axis=D.ndim - 1))
+
+    def getcoef(self):
+        return self.cbpdn.getcoef()[self.index_primary()]
+
+    def index_primary(self):
+        return np.s_[..., 0:-self.cri.Cd]
+
+    def index_addmsk(self):
+        return np.s_[..., -self.cri.Cd:]
+
+    def reconstruct(self, X=None):
+        """Reconstruction from the primary component only (cbpdn.py:2457-2477)."""
+        if X is None:
+            X = self.cbpdn.Y[self.index_primary()]
+        X = np.asarray(X).reshape(self.cri.shpX[:-1] + (-1,))
+        # a zero impulse slice: the inner reconstruction then sums the primary filters only
+        Xi = np.concatenate((X, np.zeros(X.shape[:-1] + (self.cri.Cd,), dtype=X.dtype)),
+                            axis=-1)
+        return self.cbpdn.reconstruct(Xi)
+
+    def getitstat(self):
+        return self.cbpdn.getitstat()
 
 
 def _broadcastable(w, full_shape):

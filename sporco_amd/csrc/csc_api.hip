@@ -207,8 +207,8 @@ template <typename T> struct Csc : CscBase {
     T *gram = nullptr;        // (npix)
     T *dpad = nullptr;        // (H, W, K) real
     T *sreal = nullptr;       // (H, W, CN) real staging / reconstruct output
-    T *wl1_buf = nullptr, *wl21_buf = nullptr;
-    Weight<T> wl1, wl21;
+    T *wl1_buf = nullptr, *wl21_buf = nullptr, *wams_buf = nullptr;
+    Weight<T> wl1, wl21, wams;   // wams: AddMaskSim mask (F_AMS)
     double *part_a = nullptr, *part_b = nullptr;  // block partials
     double *out_dev_own = nullptr;
     double *out_pinned = nullptr;
@@ -323,7 +323,7 @@ template <typename T> struct Csc : CscBase {
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
                         (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
-                        (void *)wl1_buf, (void *)wl21_buf, (void *)part_a, (void *)part_b,
+                        (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
         if (out_pinned) (void)hipHostFree(out_pinned);
@@ -530,8 +530,8 @@ template <typename T> struct Csc : CscBase {
 
     void set_weight(int which, const void *w, const int64_t shape[5]) override {
         before_state_change();   // a pending X of the fused PGM step depends on the weights
-        Weight<T> &dst = which == 0 ? wl1 : wl21;
-        T *&buf = which == 0 ? wl1_buf : wl21_buf;
+        Weight<T> &dst = which == 0 ? wl1 : (which == 1 ? wl21 : wams);
+        T *&buf = which == 0 ? wl1_buf : (which == 1 ? wl21_buf : wams_buf);
         if (buf) {
             sync();
             SA_HIP(hipFree(buf));
@@ -547,6 +547,7 @@ template <typename T> struct Csc : CscBase {
             n *= shape[i];
         }
         if (which == 1) SA_REQUIRE(shape[2] == 1, "L21Weight must not vary over the channel axis");
+        if (which == 2) SA_REQUIRE(shape[4] == 1, "the mask must not vary over the filter axis");
         SA_HIP(hipMalloc((void **)&buf, sizeof(T) * n));
         SA_HIP(hipMemcpyAsync(buf, w, sizeof(T) * n, hipMemcpyHostToDevice, st));
         sync();
@@ -735,6 +736,7 @@ template <typename T> struct Csc : CscBase {
         pa.dW = p.dW;
         pa.P = P;
         pa.wl1 = wl1;
+        pa.ams = ams_of(p);
         pa.partials = part_rows;
         int64_t nt;
         {
@@ -897,6 +899,13 @@ template <typename T> struct Csc : CscBase {
         finalize(part_a, nb, 1, 1, slots, scales, out_dev);
     }
 
+    // the AddMaskSim mask, when the call asks for it (F_AMS)
+    Weight<T> ams_of(const sporco_amd_admm_params &p) const {
+        if (!(p.flags & F_AMS)) return Weight<T>();
+        if (!wams.ptr) throw Error(SPORCO_AMD_ESTATE, "FLAG_AMS without a mask (set_ams_mask)");
+        return wams;
+    }
+
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         if (rows_ok && !(p.flags & (F_XRRS | F_JOINT)) && (fused || !(p.flags & F_GRADREG))) {
@@ -919,6 +928,7 @@ template <typename T> struct Csc : CscBase {
         pp.dW = p.dW;
         pp.wl1 = wl1;
         pp.wl21 = wl21;
+        pp.ams = ams_of(p);
         int nb;
         {
             ProfScope ps(prof, PS_ADMM_POST);
@@ -949,7 +959,7 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_OTHER);
         launch_ystep<T>(st, rv(SPORCO_AMD_VAR_AX), rv(SPORCO_AMD_VAR_U), rv(SPORCO_AMD_VAR_Y),
                         (T)(p.lmbda / p.rho), (T)(p.mu / p.rho), (T)p.u_scale, p.flags, d5(), p.dH,
-                        p.dW, wl1, wl21);
+                        p.dW, wl1, wl21, ams_of(p));
     }
 
     void admm_ustep(const sporco_amd_admm_params &p) override {
@@ -966,7 +976,7 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             nb = launch_admm_stats<T>(st, rv(SPORCO_AMD_VAR_X), rv(SPORCO_AMD_VAR_Y),
                                       rv(SPORCO_AMD_VAR_YPREV), rv(SPORCO_AMD_VAR_U), p.flags, d5(),
-                                      wl1, wl21, part_b);
+                                      wl1, wl21, (p.flags & F_AMS) != 0, part_b);
         }
         const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
                               SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
@@ -1564,6 +1574,14 @@ int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64
     SA_HANDLE(h);
     SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
     h->impl->set_weight(1, w, shape);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_ams_mask(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
+    h->impl->set_weight(2, w, shape);
     SA_API_END
 }
 

@@ -31,6 +31,7 @@ enum : uint32_t {
     F_KEEP_X = 1u << 8,
     F_NO_X = 1u << 9,
     F_GRADREG = 1u << 10,
+    F_AMS = 1u << 11,
 };
 
 // Gradient penalty of ConvBPDNGradReg (cbpdn.py:1133-1143): GHGf[h, wf] = ghh[h] + ghw[wf]
@@ -93,6 +94,10 @@ template <typename T> struct PostParams {
     Dims5 d;
     int dH, dW;
     Weight<T> wl1, wl21;
+    // AddMaskSim (cbpdn.py:2287-2485): when ams.ptr is set, the last filter is the appended
+    // impulse; its slice of Y is (AX + U) zeroed where the mask (H, W, C, N, 1) is nonzero,
+    // and it does not enter the l1 / l2,1 sums.
+    Weight<T> ams;
 };
 template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials);
 
@@ -101,13 +106,15 @@ template <typename T>
 void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t n);   // relax_AX
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
-                  uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21);
+                  uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
+                  Weight<T> ams = Weight<T>());
 template <typename T>
 void launch_ustep(hipStream_t st, const T *ax, const T *y, T *u, T u_scale, int64_t n);  // ustep
 // residual/objective sums of the staged path: x, ax unused for relaxed r (r uses x = AXnr)
 template <typename T>
 int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
-                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, double *partials);
+                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, bool ams,
+                      double *partials);
 template <typename T> void launch_scale(hipStream_t st, T *v, T s, int64_t n);
 
 // out = soft(v, thr * w) (+ NonNeg / NoBndryCross), l1 partial = sum |w * out|

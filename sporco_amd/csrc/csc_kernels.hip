@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T>
             const T x = xv.v[e], yo = yv.v[e], uo = p.u_scale * uv.v[e];
             const T ax = a * x + oma * yo;
             T w = T(1);
-            bool kill = false;
+            bool kill = false, ams = false;
             if (GENERAL) {
                 const int64_t idx = i * VEC + e;
                 const int64_t pix = idx / P;
@@ -444,9 +444,17 @@ __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T>
                 const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
                 if (p.wl1.ptr) w = weight_at(p.wl1, h, xw, c, n, k);
                 kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
+                if (p.ams.ptr && k == p.d.K - 1) {
+                    // AddMaskSim impulse slice (cbpdn.py:2378-2394): no shrinkage, no
+                    // NonNeg / NoBndryCross, zero where the mask is set; invisible to
+                    // the regulariser (:2398-2412)
+                    ams = true;
+                    w = T(0);
+                    kill = weight_at(p.ams, h, xw, c, n, 0) != T(0);
+                }
             }
             T yn = soft(ax + uo, p.thr * w);
-            if (nonneg && yn < T(0)) yn = T(0);
+            if (nonneg && !ams && yn < T(0)) yn = T(0);
             if (kill) yn = T(0);
             const T un = uo + ax - yn;
             yv.v[e] = yn;
@@ -485,6 +493,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostPar
         const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
         const int64_t base = pix * C * NK + nk;
         const bool kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
+        const bool ams = p.ams.ptr && k == p.d.K - 1;   // AddMaskSim slice, see admm_post_kernel
         // pass 1: l2 norm over channels of the soft-thresholded values
         T nrm2 = T(0);
         for (int c = 0; c < C; ++c) {
@@ -509,6 +518,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostPar
             T yn = fac * soft(ax + uo, p.thr * w);
             if (nonneg && yn < T(0)) yn = T(0);
             if (kill) yn = T(0);
+            if (ams) yn = weight_at(p.ams, h, xw, c, n, 0) != T(0) ? T(0) : ax + uo;
             const T un = uo + ax - yn;
             p.y[idx] = yn;
             p.u[idx] = un;
@@ -518,7 +528,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostPar
             acc[2] += (double)x * (double)x;
             acc[3] += (double)yn * (double)yn;
             acc[4] += (double)un * (double)un;
-            const T gvar = gy ? yn : x;
+            const T gvar = ams ? T(0) : (gy ? yn : x);
             const T gv = w * gvar;
             acc[5] += (double)(gv < T(0) ? -gv : gv);
             g2 += (double)gvar * (double)gvar;
@@ -537,7 +547,7 @@ template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &
         hipLaunchKernelGGL((admm_post_joint_kernel<T>), dim3(grid), dim3(kThreads), lds, st, p,
                            partials);
     } else {
-        const bool general = p.wl1.ptr != nullptr || (p.flags & F_NOBNDRY);
+        const bool general = p.wl1.ptr != nullptr || (p.flags & F_NOBNDRY) || p.ams.ptr;
         constexpr int V = 16 / sizeof(T);
         if (E % V == 0) {
             grid = grid_for(E / V);
@@ -587,7 +597,7 @@ template <typename T> struct YstepArgs {
     uint32_t flags;
     Dims5 d;
     int dH, dW;
-    Weight<T> wl1, wl21;
+    Weight<T> wl1, wl21, ams;
 };
 
 template <typename T>
@@ -622,9 +632,12 @@ __global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
         for (int c = 0; c < C; ++c) {
             const int64_t idx = base + c * NK;
             const T w = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
-            T yn = fac * soft(p.ax[idx] + p.u_scale * p.u[idx], p.thr * w);
+            const T v = p.ax[idx] + p.u_scale * p.u[idx];
+            T yn = fac * soft(v, p.thr * w);
             if (nonneg && yn < T(0)) yn = T(0);
             if (kill) yn = T(0);
+            if (p.ams.ptr && k == p.d.K - 1)   // AddMaskSim slice (cbpdn.py:2378-2394)
+                yn = weight_at(p.ams, h, xw, c, n, 0) != T(0) ? T(0) : v;
             p.y[idx] = yn;
         }
     }
@@ -632,8 +645,10 @@ __global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
 
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
-                  uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21) {
+                  uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
+                  Weight<T> ams) {
     YstepArgs<T> p;
+    p.ams = ams;
     p.ax = ax;
     p.u = u;
     p.y = y;
@@ -675,6 +690,7 @@ template <typename T> struct StatsArgs {
     uint32_t flags;
     Dims5 d;
     Weight<T> wl1, wl21;
+    bool ams;
 };
 
 template <typename T>
@@ -703,7 +719,8 @@ __global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T>
             acc[2] += (double)x * (double)x;
             acc[3] += (double)y * (double)y;
             acc[4] += (double)u * (double)u;
-            const T gvar = gy ? y : x;
+            // (the regularisers do not see the AddMaskSim slice, cbpdn.py:2398-2412)
+            const T gvar = (p.ams && k == p.d.K - 1) ? T(0) : (gy ? y : x);
             const T gv = w * gvar;
             acc[5] += (double)(gv < T(0) ? -gv : gv);
             g2 += (double)gvar * (double)gvar;
@@ -718,8 +735,10 @@ __global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T>
 
 template <typename T>
 int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
-                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, double *partials) {
+                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, bool ams,
+                      double *partials) {
     StatsArgs<T> p;
+    p.ams = ams;
     p.x = x;
     p.y = y;
     p.yprev = yprev;
@@ -1284,10 +1303,10 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *);                \
     template void launch_relax<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \
-                                  Dims5, int, int, Weight<T>, Weight<T>);                          \
+                                  Dims5, int, int, Weight<T>, Weight<T>, Weight<T>);               \
     template void launch_ustep<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template int launch_admm_stats<T>(hipStream_t, const T *, const T *, const T *, const T *,     \
-                                      uint32_t, Dims5, Weight<T>, Weight<T>, double *);            \
+                                      uint32_t, Dims5, Weight<T>, Weight<T>, bool, double *);      \
     template void launch_scale<T>(hipStream_t, T *, T, int64_t);                                   \
     template int launch_prox_l1<T>(hipStream_t, const T *, T *, T, uint32_t, Dims5, int, int,      \
                                    Weight<T>, double *);                                           \

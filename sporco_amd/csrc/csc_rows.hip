@@ -315,6 +315,15 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // ---------------------------------------------------------------------------
 // rows_inv_post: X = irfft_W(T) / (H W); relax, shrink, dual update, sums
 // ---------------------------------------------------------------------------
+// extent of the AddMaskSim mask in bytes (0 when there is none: every access is then
+// out of range and reads 0)
+__device__ __forceinline__ uint32_t am1_bytes(const RowsPostArgs<float> &a) {
+    if (!a.ams.ptr) return 0u;
+    const int64_t n = 1 + (a.H - 1) * a.ams.stride[0] + (a.W - 1) * a.ams.stride[1] +
+                      (a.C - 1) * a.ams.stride[2] + (a.N - 1) * a.ams.stride[3];
+    return (uint32_t)(n * (int64_t)sizeof(float));
+}
+
 template <int NW, bool WRITE_X, bool GENERAL, bool EMIT_T>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
@@ -356,6 +365,17 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     }
     const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
     const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
+    // AddMaskSim (cbpdn.py:2378-2412): K is even here, so the impulse slice K - 1 is the
+    // second element of the lanes with k = K - 2.  Those lanes read the mask of their
+    // (c, n); every other lane (and every lane without a mask) sends an out-of-range
+    // offset, which costs no memory traffic and returns 0.
+    const bool am1 = GENERAL && a.ams.ptr != nullptr && pv && k + 2 == a.K;
+    const BufRsrc Mb = make_rsrc(a.ams.ptr, am1_bytes(a));
+    const int mvoff = am1 ? (int)(((cn / a.N) * a.ams.stride[2] + (cn % a.N) * a.ams.stride[3]) *
+                                  (int64_t)sizeof(float))
+                          : (int)0x80000000;
+    const int mrow = (int)(h * a.ams.stride[0] * (int64_t)sizeof(float));
+    const int mpix = (int)(a.ams.stride[1] * (int64_t)sizeof(float));
     float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f;
     constexpr int B = EMIT_T ? 2 : 4;   // pixels per batch (Y, U of the next batch are in flight)
     cf yb[2][B], ub[2][B];
@@ -383,18 +403,22 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
             // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
             // epilogue into dozens of blocks and the register allocator spills the tile)
             const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
+            float mkeep = 1.f;
+            if (GENERAL) mkeep = sa_buf_load1(Mb, mvoff, mrow + xw * mpix) != 0.f ? 0.f : 1.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float ax = al * xs[e] + oma * yo[e];
+                const bool am = GENERAL && e == 1 && am1;
                 float wt = 1.f;
                 if (GENERAL) {
                     const float *wrow = a.wl1.ptr + (int64_t)h * a.wl1.stride[0] +
                                         (int64_t)xw * a.wl1.stride[1];
                     wt = wrow[wlane + e * ws4];
+                    if (e == 1) wt = am ? 0.f : wt;
                 }
                 float y1 = soft1(ax + uo[e], a.thr * wt);
-                if (nonneg && y1 < 0.f) y1 = 0.f;
-                if (GENERAL) y1 *= keep;
+                if (nonneg && !am && y1 < 0.f) y1 = 0.f;
+                if (GENERAL) y1 *= (e == 1 && am) ? mkeep : keep;
                 const float u1 = uo[e] + ax - y1;
                 yn[e] = y1;
                 un[e] = u1;
@@ -570,7 +594,7 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a_in, dim3
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, true, EMIT>);
         attr_set = true;
     }
-    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY);
+    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY) || a_in.ams.ptr;
     RowsPostArgs<float> a = a_in;
     if (general && !a.wl1.ptr) a.wl1.ptr = device_one();   // strides are already all zero
     const dim3 block(NW * 64);

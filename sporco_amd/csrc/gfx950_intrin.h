@@ -46,6 +46,10 @@ __device__ __forceinline__ void sa_buf_load2(SaBuf r, int voff, int soff, float 
 __device__ __forceinline__ void sa_buf_load2_cached(SaBuf r, int voff, int soff, float &a, float &b) {
     sa_buf_load2_aux<0>(r, voff, soff, a, b);
 }
+// one float, default cache policy (small re-read operands such as masks)
+__device__ __forceinline__ float sa_buf_load1(SaBuf r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
 __device__ __forceinline__ void sa_buf_store2(SaBuf r, int voff, int soff, float a, float b) {
     sa_floatx2 t;
     t.x = a;

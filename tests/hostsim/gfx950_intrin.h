@@ -48,6 +48,12 @@ inline void sa_buf_load2(SaBuf r, int voff, int soff, float &a, float &b) {
         std::memcpy(&b, r.base + off + 4, 4);
     }
 }
+inline float sa_buf_load1(SaBuf r, int voff, int soff) {
+    const uint32_t off = (uint32_t)voff + (uint32_t)soff;
+    float a = 0.f;
+    if ((uint64_t)off + 4 <= r.bytes) std::memcpy(&a, r.base + off, 4);
+    return a;
+}
 inline void sa_buf_load2_cached(SaBuf r, int voff, int soff, float &a, float &b) {
     sa_buf_load2(r, voff, soff, a, b);
 }

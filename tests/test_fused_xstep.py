@@ -330,3 +330,56 @@ def test_fused_gradreg_matches_oracle_and_unfused(backend, H, W, K, N, weights):
     assert rel_l2(b.X, ref['X']) < 1e-4
     for f in ('ObjFun', 'DFid', 'RegL1', 'RegGrad', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f
+
+
+# ---------------------------------------------------------------------------
+# AddMaskSim on the three-launch iteration (mask handling inside rows_inv_post)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('H,W,K,N,gradreg', [
+    (256, 256, 3, 2, False),
+    pytest.param(256, 256, 5, 1, True, marks=pytest.mark.gpu),
+    pytest.param(512, 512, 63, 3, False, marks=pytest.mark.gpu)])
+def test_fused_ams_matches_oracle_and_unfused(backend, H, W, K, N, gradreg):
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    D, S = problem(H, W, K, N, seed=H + K + 7)
+    rng = np.random.RandomState(3)
+    Wm = (rng.rand(H, W, N) > 0.25).astype(np.float32)
+    iters = 4
+    cls = cbpdn.ConvBPDNGradReg if gradreg else cbpdn.ConvBPDN
+    args = (0.05, 0.3) if gradreg else (0.05,)
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'NonNegCoef': True}
+
+    def run(unfused):
+        if unfused:
+            os.environ['SPORCO_AMD_UNFUSED'] = '1'
+        try:
+            b = cbpdn.AddMaskSim(cls, D, S, Wm, *args, opt=cls.Options(optd))
+        finally:
+            os.environ.pop('SPORCO_AMD_UNFUSED', None)
+        b.solve()
+        return b
+
+    b, b0 = run(False), run(True)
+    assert b.cbpdn._dev.uses_fused_rows() and not b0.cbpdn._dev.uses_fused_rows()
+    assert rel_l2(b.cbpdn.Y, b0.cbpdn.Y) < 2e-5
+    assert rel_l2(b.cbpdn.U, b0.cbpdn.U) < 2e-5
+    its, its0 = b.getitstat(), b0.getitstat()
+    fields = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho')
+    for f in fields:
+        assert rel_l2(getattr(its, f), getattr(its0, f)) < 1e-4, f
+    # the impulse slice is zero exactly where the mask is set, and only there shrunk
+    Yi = b.cbpdn.Y[..., -1]
+    assert np.all(Yi[Wm.reshape(Yi.shape) != 0] == 0)
+    if K * N > 16:
+        return           # (the float64 oracle would take minutes at this size)
+    imp = np.zeros((4, 4, 1), np.float32)
+    imp[0, 0] = 1
+    Di = np.concatenate((D, imp), axis=2)
+    kw = dict(grad_mu=0.3) if gradreg else {}
+    ref = orc.admm_cbpdn(Di.reshape(4, 4, 1, 1, K + 1), S.reshape(H, W, 1, N, 1), 0.05,
+                         dtype=np.float64, maxiter=iters, rel_tol=0.0, nonneg=True,
+                         ams_mask=Wm.reshape(H, W, 1, N, 1), **kw)
+    assert rel_l2(b.cbpdn.Y, ref['Y']) < 1e-4
+    for f in fields:
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f

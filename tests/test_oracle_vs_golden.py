@@ -134,6 +134,55 @@ def test_gradreg_traces(name):
         assert rel_l2(r[key], g['it_' + key]) < tol, key
 
 
+AMS_CASES = {
+    'ams_cbpdn_f64': dict(maxiter=25),
+    'ams_cbpdn_f32': dict(maxiter=25, dtype=np.float32),
+    'ams_cbpdn_bcast_nonneg_f64': dict(maxiter=20, nonneg=True, nobndry=True,
+                                       gevaly=True, fevalx=False),
+    'ams_gradreg_f64': dict(maxiter=20, _wg='optarr_GradWeight', _gradreg=True),
+    'ams_joint_f64': dict(maxiter=20, _joint=True),
+}
+
+
+def ams_inputs(g):
+    """Dictionary with the impulse filter appended (cbpdn.py:2345-2353) and the
+    internal 5-D arrays."""
+    D = g['D']
+    imp = np.zeros(D.shape[:2] + (1,))
+    imp[0, 0] = 1.0
+    D5, S5 = to5d(np.concatenate((D, imp), axis=2), g['S'])
+    return D5, S5
+
+
+@pytest.mark.parametrize('name', sorted(AMS_CASES))
+def test_ams_traces(name):
+    """AddMaskSim restatement (masked impulse slice in the y step, regularisers
+    blind to it)."""
+    g = load_golden(name)
+    kw = dict(AMS_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    D5, S5 = ams_inputs(g)
+    if kw.pop('_gradreg', False):
+        kw['grad_mu'] = float(g['mu'])
+        kw['grad_weight'] = g[kw.pop('_wg')]
+    if kw.pop('_joint', False):
+        kw['mu'] = float(g['mu'])
+    r = orc.admm_cbpdn(D5, S5, float(g['lmbda']), dtype=dtype, ams_mask=g['Wint'], **kw)
+    assert r['iters'] == int(g['k_final'])
+    for key in ('Y', 'U', 'X'):
+        assert rel_l2(r[key], g[key]) < tol, key
+    fields = ['ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal',
+              'EpsDual', 'Rho']
+    fields += ['RegGrad'] if 'grad_mu' in kw else []
+    fields += ['RegL21'] if 'mu' in kw else []
+    for key in fields:
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    # AddMaskSim.reconstruct / getcoef drop the impulse slice (cbpdn.py:2431-2477)
+    assert rel_l2(orc.reconstruct(r['Df'][..., :-1], r['Y'][..., :-1], S5.shape[:2]),
+                  g['recon']) < tol
+
+
 def test_admm_known_answer():
     g = load_golden('admm_known_answer_f64')
     D5, S5 = to5d(g['D'], g['S'])
