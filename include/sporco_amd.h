@@ -111,6 +111,11 @@ int sporco_amd_csc_sync(sporco_amd_csc_t h);
 #define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
 #define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
 #define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step (K <= 64) */
+#define SPORCO_AMD_QUERY_DEVICE_FILTERS 3 /* filter count of the device-resident arrays: K, or
+                                            K + 1 when an odd K was padded with one all-zero
+                                            filter to reach the fused kernels (host arrays
+                                            always have K; only sporco_amd_csc_device_ptr
+                                            exposes the padded layout) */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))

@@ -30,6 +30,7 @@ FLAG_KEEP_X = 1 << 8
 FLAG_NO_X = 1 << 9
 FLAG_GRADREG = 1 << 10
 FLAG_AMS = 1 << 11
+QUERY_FUSED_COLS, QUERY_FUSED_ROWS, QUERY_FUSED_PGM, QUERY_DEVICE_FILTERS = 0, 1, 2, 3
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
@@ -323,10 +324,13 @@ class Solver(object):
     def sync(self):
         check(self._lib.sporco_amd_csc_sync(self._h))
 
-    def _query(self, what):
+    def query(self, what):
         out = ctypes.c_int(0)
         check(self._lib.sporco_amd_csc_query(self._h, int(what), ctypes.byref(out)))
-        return bool(out.value)
+        return out.value
+
+    def _query(self, what):
+        return bool(self.query(what))
 
     def uses_fused_cols(self):
         """True when the register-resident column kernel serves this shape."""

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <memory>
 #include <utility>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -197,6 +198,15 @@ template <typename T> struct Csc : CscBase {
     hipStream_t st = nullptr;
     bool own_stream = false;
     int H, W, Wf, C, N, K, CN;
+    // Ku: the caller's filter count.  K (what every kernel sees) is Ku, or Ku + 1 when Ku is
+    // odd and one all-zero filter buys the register-resident kernels (which pair filters):
+    // a zero filter's coefficient map stays zero through every iteration of every solver here
+    // (x_k = yuf_k, prox(0) = 0, zero gradient) up to the rounding-level cross-talk of the
+    // row FFTs, which transform two filters as one complex line; the shrinkage removes that
+    // again, and the dictionary projection (the one place that would normalise noise up to
+    // unit norm) keeps padding filters at zero.  Host arrays always have Ku filters; the
+    // copies in and out are strided.
+    int Ku;
     int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
     FftPlan planW, planH;
     void *vars[SPORCO_AMD_VAR_COUNT] = {nullptr};
@@ -252,6 +262,13 @@ template <typename T> struct Csc : CscBase {
     bool g1_valid = false;
     double g1_rho = 0.0, g1_mu = 0.0;
 
+    static int padded_filters(int H_, int W_, int K_) {
+        if (K_ % 2 == 0 || std::getenv("SPORCO_AMD_UNFUSED") || std::getenv("SPORCO_AMD_NO_PAD"))
+            return K_;
+        const bool cols = fused_cols_supported<T>(H_, K_ + 1) || fused_slabs_supported<T>(H_, K_ + 1);
+        return (cols && rows_supported<T>(W_, K_ + 1)) ? K_ + 1 : K_;
+    }
+
     Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
                    "all dimensions must be >= 1");
@@ -260,7 +277,8 @@ template <typename T> struct Csc : CscBase {
         W = d.W;
         C = d.C;
         N = d.N;
-        K = d.K;
+        Ku = d.K;
+        K = padded_filters(d.H, d.W, d.K);
         Wf = W / 2 + 1;
         CN = C * N;
         P = (int64_t)C * N * K;
@@ -368,6 +386,7 @@ template <typename T> struct Csc : CscBase {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && fused) ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
 
@@ -509,11 +528,11 @@ template <typename T> struct Csc : CscBase {
         // stage the compact filters at the tail of dpad's own allocation? no: use `work`-free
         // dedicated staging so set_dict is safe while iterates are live.
         T *stage = nullptr;
-        SA_HIP(hipMalloc((void **)&stage, sizeof(T) * (int64_t)dH * dW * K));
-        SA_HIP(hipMemcpyAsync(stage, D, sizeof(T) * (int64_t)dH * dW * K, hipMemcpyHostToDevice, st));
+        SA_HIP(hipMalloc((void **)&stage, sizeof(T) * (int64_t)dH * dW * Ku));
+        SA_HIP(hipMemcpyAsync(stage, D, sizeof(T) * (int64_t)dH * dW * Ku, hipMemcpyHostToDevice, st));
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_pad_dict<T>(st, stage, dpad, H, W, K, dH, dW);
+            launch_pad_dict<T>(st, stage, dpad, H, W, K, dH, dW, Ku);
         }
         fwd2(dpad, nullptr, T(0), cv(SPORCO_AMD_VAR_DF), K);
         {
@@ -539,7 +558,7 @@ template <typename T> struct Csc : CscBase {
         }
         dst = Weight<T>();
         if (!w) return;
-        const int64_t full[5] = {H, W, C, N, K};
+        const int64_t full[5] = {H, W, C, N, Ku};
         int64_t n = 1;
         for (int i = 0; i < 5; ++i) {
             SA_REQUIRE(shape[i] == 1 || shape[i] == full[i],
@@ -548,13 +567,27 @@ template <typename T> struct Csc : CscBase {
         }
         if (which == 1) SA_REQUIRE(shape[2] == 1, "L21Weight must not vary over the channel axis");
         if (which == 2) SA_REQUIRE(shape[4] == 1, "the mask must not vary over the filter axis");
+        int64_t dshape[5] = {shape[0], shape[1], shape[2], shape[3], shape[4]};
+        std::vector<T> padded;
+        const void *srcp = w;
+        if (K != Ku && shape[4] == Ku) {
+            // weight 1 on the padding filter (its coefficients are zero whatever the weight)
+            dshape[4] = K;
+            const int64_t rows = n / Ku;
+            padded.assign((size_t)(rows * K), T(1));
+            const T *wt = static_cast<const T *>(w);
+            for (int64_t r = 0; r < rows; ++r)
+                for (int k = 0; k < Ku; ++k) padded[(size_t)(r * K + k)] = wt[r * Ku + k];
+            srcp = padded.data();
+            n = rows * K;
+        }
         SA_HIP(hipMalloc((void **)&buf, sizeof(T) * n));
-        SA_HIP(hipMemcpyAsync(buf, w, sizeof(T) * n, hipMemcpyHostToDevice, st));
+        SA_HIP(hipMemcpyAsync(buf, srcp, sizeof(T) * n, hipMemcpyHostToDevice, st));
         sync();
         int64_t stride = 1;
         for (int i = 4; i >= 0; --i) {
-            dst.stride[i] = shape[i] == 1 ? 0 : stride;
-            stride *= shape[i];
+            dst.stride[i] = dshape[i] == 1 ? 0 : stride;
+            stride *= dshape[i];
         }
         dst.ptr = buf;
     }
@@ -566,7 +599,9 @@ template <typename T> struct Csc : CscBase {
         g1_valid = false;
         if (!w) return;
         if (!wg) SA_HIP(hipMalloc((void **)&wg, sizeof(T) * K));
-        SA_HIP(hipMemcpyAsync(wg, w, sizeof(T) * K, hipMemcpyHostToDevice, st));
+        std::vector<T> tmp((size_t)K, T(1));
+        std::memcpy(tmp.data(), w, sizeof(T) * Ku);
+        SA_HIP(hipMemcpyAsync(wg, tmp.data(), sizeof(T) * K, hipMemcpyHostToDevice, st));
         SA_HIP(hipStreamSynchronize(st));
     }
 
@@ -594,6 +629,25 @@ template <typename T> struct Csc : CscBase {
         return g;
     }
 
+    // Host <-> device copy of one state array; the host side has Ku filters on its last axis.
+    void host_copy(int var, void *host, bool to_device) {
+        void *dev = var_ptr(var);
+        const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+        if (K == Ku || var == SPORCO_AMD_VAR_SF) {
+            if (to_device) SA_HIP(hipMemcpyAsync(dev, host, var_bytes(var), kind, st));
+            else SA_HIP(hipMemcpyAsync(host, dev, var_bytes(var), kind, st));
+            return;
+        }
+        const size_t es = var_is_complex(var) ? sizeof(cx<T>) : sizeof(T);
+        const size_t rows = var_bytes(var) / (es * K);
+        if (to_device) {
+            SA_HIP(hipMemsetAsync(dev, 0, var_bytes(var), st));
+            SA_HIP(hipMemcpy2DAsync(dev, es * K, host, es * Ku, es * Ku, rows, kind, st));
+        } else {
+            SA_HIP(hipMemcpy2DAsync(host, es * Ku, dev, es * K, es * Ku, rows, kind, st));
+        }
+    }
+
     void upload(int var, const void *src) override {
         if (is_pgm_iterate(var)) pgm_leave_tiled();
         if (var == SPORCO_AMD_VAR_ZF) zf_tiled = false;
@@ -605,7 +659,7 @@ template <typename T> struct Csc : CscBase {
                    var == SPORCO_AMD_VAR_SF) {
             before_state_change();
         }
-        SA_HIP(hipMemcpyAsync(var_ptr(var), src, var_bytes(var), hipMemcpyHostToDevice, st));
+        host_copy(var, const_cast<void *>(src), true);
         if (var == SPORCO_AMD_VAR_XF) xf_tiled = false;
         if (var == SPORCO_AMD_VAR_DF) {
             launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
@@ -616,7 +670,7 @@ template <typename T> struct Csc : CscBase {
     }
     void download(int var, void *dst) override {
         before_read(var);
-        SA_HIP(hipMemcpyAsync(dst, var_ptr(var), var_bytes(var), hipMemcpyDeviceToHost, st));
+        host_copy(var, dst, false);
         sync();
     }
     void *device_ptr(int var) override {
@@ -737,6 +791,7 @@ template <typename T> struct Csc : CscBase {
         pa.P = P;
         pa.wl1 = wl1;
         pa.ams = ams_of(p);
+        pa.ams_k = Ku - 1;
         pa.partials = part_rows;
         int64_t nt;
         {
@@ -929,6 +984,7 @@ template <typename T> struct Csc : CscBase {
         pp.wl1 = wl1;
         pp.wl21 = wl21;
         pp.ams = ams_of(p);
+        pp.ams_k = Ku - 1;
         int nb;
         {
             ProfScope ps(prof, PS_ADMM_POST);
@@ -959,7 +1015,7 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_OTHER);
         launch_ystep<T>(st, rv(SPORCO_AMD_VAR_AX), rv(SPORCO_AMD_VAR_U), rv(SPORCO_AMD_VAR_Y),
                         (T)(p.lmbda / p.rho), (T)(p.mu / p.rho), (T)p.u_scale, p.flags, d5(), p.dH,
-                        p.dW, wl1, wl21, ams_of(p));
+                        p.dW, wl1, wl21, ams_of(p), Ku - 1);
     }
 
     void admm_ustep(const sporco_amd_admm_params &p) override {
@@ -976,7 +1032,7 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             nb = launch_admm_stats<T>(st, rv(SPORCO_AMD_VAR_X), rv(SPORCO_AMD_VAR_Y),
                                       rv(SPORCO_AMD_VAR_YPREV), rv(SPORCO_AMD_VAR_U), p.flags, d5(),
-                                      wl1, wl21, (p.flags & F_AMS) != 0, part_b);
+                                      wl1, wl21, (p.flags & F_AMS) ? Ku - 1 : -1, part_b);
         }
         const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
                               SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
@@ -1363,7 +1419,7 @@ template <typename T> struct Csc : CscBase {
         {
             ProfScope ps(prof, PS_OTHER);
             launch_pcn_stats<T>(st, v, pcn_stats_buf(), H, W, K, dH, dW, zm);
-            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b);
+            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b, Ku);
         }
         if (out_dev) {
             const int slots[1] = {0};
@@ -1391,10 +1447,21 @@ template <typename T> struct Csc : CscBase {
 
     void ccmod_getdict(int dH, int dW, void *dst) override {
         SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W, "filter support out of range");
-        SA_HIP(hipMemcpy2DAsync(dst, sizeof(T) * (size_t)dW * K, rv(SPORCO_AMD_VAR_DX),
+        std::vector<T> tmp;
+        void *out = dst;
+        if (K != Ku) {
+            tmp.resize((size_t)dH * dW * K);
+            out = tmp.data();
+        }
+        SA_HIP(hipMemcpy2DAsync(out, sizeof(T) * (size_t)dW * K, rv(SPORCO_AMD_VAR_DX),
                                 sizeof(T) * (size_t)W * K, sizeof(T) * (size_t)dW * K, (size_t)dH,
                                 hipMemcpyDeviceToHost, st));
         sync();
+        if (K != Ku) {   // drop the padding filter
+            T *o = static_cast<T *>(dst);
+            for (int64_t r = 0; r < (int64_t)dH * dW; ++r)
+                for (int k = 0; k < Ku; ++k) o[r * Ku + k] = tmp[(size_t)(r * K + k)];
+        }
     }
 
     void setdict_from_dstep(int dH, int dW) override {

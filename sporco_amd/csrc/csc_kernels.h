@@ -46,7 +46,8 @@ template <typename T> struct GradTerm {
 
 // dst(H, W, K) = zero-padded src(dH, dW, K)              (cnvrep.zpad, cnvrep.py:704-726)
 template <typename T>
-void launch_pad_dict(hipStream_t st, const T *src, T *dst, int H, int W, int K, int dH, int dW);
+void launch_pad_dict(hipStream_t st, const T *src, T *dst, int H, int W, int K, int dH, int dW,
+                     int Ksrc = -1);   // Ksrc < K: src holds Ksrc filters, the rest are zero
 
 // gram[pix] = sum_k |df[pix, k]|^2   (the a^H a term of linalg.solvedbi_sm_c, linalg.py:297)
 template <typename T>
@@ -98,6 +99,7 @@ template <typename T> struct PostParams {
     // impulse; its slice of Y is (AX + U) zeroed where the mask (H, W, C, N, 1) is nonzero,
     // and it does not enter the l1 / l2,1 sums.
     Weight<T> ams;
+    int ams_k = -1;   // index of that filter (K - 1 unless the handle pads the filter axis)
 };
 template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials);
 
@@ -107,13 +109,13 @@ void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t 
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
                   uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
-                  Weight<T> ams = Weight<T>());
+                  Weight<T> ams = Weight<T>(), int ams_k = -1);
 template <typename T>
 void launch_ustep(hipStream_t st, const T *ax, const T *y, T *u, T u_scale, int64_t n);  // ustep
 // residual/objective sums of the staged path: x, ax unused for relaxed r (r uses x = AXnr)
 template <typename T>
 int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
-                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, bool ams,
+                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, int ams_k,
                       double *partials);
 template <typename T> void launch_scale(hipStream_t st, T *v, T s, int64_t n);
 
@@ -165,7 +167,7 @@ void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K,
 // out = projected v (out may be null: measure only); partial[block] = sum (P(v) - v)^2
 template <typename T>
 int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
-                     int dH, int dW, double *partials);
+                     int dH, int dW, double *partials, int Kvalid = -1);   // k >= Kvalid -> 0
 // partial[block] = sum |v|
 template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, double *partials);
 

@@ -54,22 +54,23 @@ __device__ __forceinline__ bool in_bndry(int h, int x, int H, int W, int dH, int
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pad_dict_kernel(const T *__restrict__ src,
                                                             T *__restrict__ dst, int H, int W,
-                                                            int K, int dH, int dW) {
+                                                            int K, int dH, int dW, int Ksrc) {
     const int64_t n = (int64_t)H * W * K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % K);
         const int64_t pix = i / K;
         const int x = (int)(pix % W), h = (int)(pix / W);
-        dst[i] = (h < dH && x < dW) ? src[((int64_t)h * dW + x) * K + k] : T(0);
+        dst[i] = (h < dH && x < dW && k < Ksrc) ? src[((int64_t)h * dW + x) * Ksrc + k] : T(0);
     }
 }
 
 template <typename T>
-void launch_pad_dict(hipStream_t st, const T *src, T *dst, int H, int W, int K, int dH, int dW) {
+void launch_pad_dict(hipStream_t st, const T *src, T *dst, int H, int W, int K, int dH, int dW,
+                     int Ksrc) {
     const int64_t n = (int64_t)H * W * K;
     hipLaunchKernelGGL((pad_dict_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, src, dst, H,
-                       W, K, dH, dW);
+                       W, K, dH, dW, Ksrc < 0 ? K : Ksrc);
     SA_HIP(hipGetLastError());
 }
 
@@ -444,7 +445,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T>
                 const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
                 if (p.wl1.ptr) w = weight_at(p.wl1, h, xw, c, n, k);
                 kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
-                if (p.ams.ptr && k == p.d.K - 1) {
+                if (p.ams.ptr && k == p.ams_k) {
                     // AddMaskSim impulse slice (cbpdn.py:2378-2394): no shrinkage, no
                     // NonNeg / NoBndryCross, zero where the mask is set; invisible to
                     // the regulariser (:2398-2412)
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostPar
         const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
         const int64_t base = pix * C * NK + nk;
         const bool kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
-        const bool ams = p.ams.ptr && k == p.d.K - 1;   // AddMaskSim slice, see admm_post_kernel
+        const bool ams = p.ams.ptr && k == p.ams_k;   // AddMaskSim slice, see admm_post_kernel
         // pass 1: l2 norm over channels of the soft-thresholded values
         T nrm2 = T(0);
         for (int c = 0; c < C; ++c) {
@@ -598,6 +599,7 @@ template <typename T> struct YstepArgs {
     Dims5 d;
     int dH, dW;
     Weight<T> wl1, wl21, ams;
+    int ams_k;
 };
 
 template <typename T>
@@ -636,7 +638,7 @@ __global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
             T yn = fac * soft(v, p.thr * w);
             if (nonneg && yn < T(0)) yn = T(0);
             if (kill) yn = T(0);
-            if (p.ams.ptr && k == p.d.K - 1)   // AddMaskSim slice (cbpdn.py:2378-2394)
+            if (p.ams.ptr && k == p.ams_k)   // AddMaskSim slice (cbpdn.py:2378-2394)
                 yn = weight_at(p.ams, h, xw, c, n, 0) != T(0) ? T(0) : v;
             p.y[idx] = yn;
         }
@@ -646,9 +648,10 @@ __global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
                   uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
-                  Weight<T> ams) {
+                  Weight<T> ams, int ams_k) {
     YstepArgs<T> p;
     p.ams = ams;
+    p.ams_k = ams_k;
     p.ax = ax;
     p.u = u;
     p.y = y;
@@ -690,7 +693,7 @@ template <typename T> struct StatsArgs {
     uint32_t flags;
     Dims5 d;
     Weight<T> wl1, wl21;
-    bool ams;
+    int ams_k;   // filter index of the AddMaskSim slice, or -1
 };
 
 template <typename T>
@@ -720,7 +723,7 @@ __global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T>
             acc[3] += (double)y * (double)y;
             acc[4] += (double)u * (double)u;
             // (the regularisers do not see the AddMaskSim slice, cbpdn.py:2398-2412)
-            const T gvar = (p.ams && k == p.d.K - 1) ? T(0) : (gy ? y : x);
+            const T gvar = (k == p.ams_k) ? T(0) : (gy ? y : x);
             const T gv = w * gvar;
             acc[5] += (double)(gv < T(0) ? -gv : gv);
             g2 += (double)gvar * (double)gvar;
@@ -735,10 +738,10 @@ __global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T>
 
 template <typename T>
 int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
-                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, bool ams,
+                      uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, int ams_k,
                       double *partials) {
     StatsArgs<T> p;
-    p.ams = ams;
+    p.ams_k = ams_k;
     p.x = x;
     p.y = y;
     p.yprev = yprev;
@@ -1154,7 +1157,7 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict__ v,
                                                              const T *__restrict__ stats, T *out,
                                                              int H, int W, int K, int dH, int dW,
-                                                             double *partials) {
+                                                             int Kvalid, double *partials) {
     double acc[1] = {0.0};
     const int64_t n = (int64_t)H * W * K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -1164,7 +1167,9 @@ __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict
         const int x = (int)(pix % W), h = (int)(pix / W);
         const T vi = v[i];
         // v / vn as in cnvrep.normalise (cnvrep.py:696-700): 1/norm is applied by division
-        const T o = (h < dH && x < dW) ? (vi - stats[2 * k]) * stats[2 * k + 1] : T(0);
+        // (filters >= Kvalid are the handle's zero padding: rounding noise must not be
+        // normalised up to a unit-norm filter)
+        const T o = (h < dH && x < dW && k < Kvalid) ? (vi - stats[2 * k]) * stats[2 * k + 1] : T(0);
         if (out) out[i] = o;
         const double df = (double)(o - vi);
         acc[0] += df * df;
@@ -1174,11 +1179,11 @@ __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict
 
 template <typename T>
 int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
-                     int dH, int dW, double *partials) {
+                     int dH, int dW, double *partials, int Kvalid) {
     const int grid = grid_for((int64_t)H * W * K);
     hipLaunchKernelGGL((pcn_apply_kernel<T>), dim3(grid), dim3(kThreads),
                        sizeof(double) * (kThreads / kWave), st, v, stats, out, H, W, K, dH, dW,
-                       partials);
+                       Kvalid < 0 ? K : Kvalid, partials);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -1289,7 +1294,7 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
 }
 
 #define SA_INST(T)                                                                                 \
-    template void launch_pad_dict<T>(hipStream_t, const T *, T *, int, int, int, int, int);        \
+    template void launch_pad_dict<T>(hipStream_t, const T *, T *, int, int, int, int, int, int);        \
     template void launch_gram<T>(hipStream_t, const cx<T> *, T *, int64_t, int);                   \
     template int launch_grad_norm<T>(hipStream_t, const cx<T> *, const GradTerm<T> &, int64_t, int, \
                                      int, int, double *);                                          \
@@ -1303,10 +1308,10 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *);                \
     template void launch_relax<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \
-                                  Dims5, int, int, Weight<T>, Weight<T>, Weight<T>);               \
+                                  Dims5, int, int, Weight<T>, Weight<T>, Weight<T>, int);          \
     template void launch_ustep<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template int launch_admm_stats<T>(hipStream_t, const T *, const T *, const T *, const T *,     \
-                                      uint32_t, Dims5, Weight<T>, Weight<T>, bool, double *);      \
+                                      uint32_t, Dims5, Weight<T>, Weight<T>, int, double *);       \
     template void launch_scale<T>(hipStream_t, T *, T, int64_t);                                   \
     template int launch_prox_l1<T>(hipStream_t, const T *, T *, T, uint32_t, Dims5, int, int,      \
                                    Weight<T>, double *);                                           \
@@ -1325,7 +1330,7 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
                                       cx<T> *, int64_t, int, int, int, double *);                  \
     template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool); \
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
-                                     int, double *);                                               \
+                                     int, double *, int);                                               \
     template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);
 SA_INST(float)
 SA_INST(double)

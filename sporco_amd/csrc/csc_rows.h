@@ -49,6 +49,7 @@ template <typename T> struct RowsPostArgs {
     int64_t P;
     Weight<T> wl1;
     Weight<T> ams;     // AddMaskSim mask (H, W, C, N, 1) or null, as PostParams::ams
+    int ams_k = -1;    // filter index of the impulse slice
     double *partials;  // per tile 8 doubles: r2, s2, ax2, y2, u2, l1, 0, 0
 };
 

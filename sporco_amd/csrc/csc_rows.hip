@@ -365,13 +365,13 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     }
     const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
     const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
-    // AddMaskSim (cbpdn.py:2378-2412): K is even here, so the impulse slice K - 1 is the
-    // second element of the lanes with k = K - 2.  Those lanes read the mask of their
-    // (c, n); every other lane (and every lane without a mask) sends an out-of-range
-    // offset, which costs no memory traffic and returns 0.
-    const bool am1 = GENERAL && a.ams.ptr != nullptr && pv && k + 2 == a.K;
+    // AddMaskSim (cbpdn.py:2378-2412): the lanes whose filter pair holds the impulse slice
+    // ams_k read the mask of their (c, n); every other lane (and every lane without a mask)
+    // sends an out-of-range offset, which costs no memory traffic and returns 0.
+    const bool aml = GENERAL && a.ams.ptr != nullptr && pv && (k | 1) == (a.ams_k | 1);
+    const bool am_e[2] = {aml && !(a.ams_k & 1), aml && (a.ams_k & 1)};
     const BufRsrc Mb = make_rsrc(a.ams.ptr, am1_bytes(a));
-    const int mvoff = am1 ? (int)(((cn / a.N) * a.ams.stride[2] + (cn % a.N) * a.ams.stride[3]) *
+    const int mvoff = aml ? (int)(((cn / a.N) * a.ams.stride[2] + (cn % a.N) * a.ams.stride[3]) *
                                   (int64_t)sizeof(float))
                           : (int)0x80000000;
     const int mrow = (int)(h * a.ams.stride[0] * (int64_t)sizeof(float));
@@ -408,17 +408,17 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float ax = al * xs[e] + oma * yo[e];
-                const bool am = GENERAL && e == 1 && am1;
+                const bool am = GENERAL && am_e[e];
                 float wt = 1.f;
                 if (GENERAL) {
                     const float *wrow = a.wl1.ptr + (int64_t)h * a.wl1.stride[0] +
                                         (int64_t)xw * a.wl1.stride[1];
                     wt = wrow[wlane + e * ws4];
-                    if (e == 1) wt = am ? 0.f : wt;
+                    wt = am ? 0.f : wt;
                 }
                 float y1 = soft1(ax + uo[e], a.thr * wt);
                 if (nonneg && !am && y1 < 0.f) y1 = 0.f;
-                if (GENERAL) y1 *= (e == 1 && am) ? mkeep : keep;
+                if (GENERAL) y1 *= am ? mkeep : keep;
                 const float u1 = uo[e] + ax - y1;
                 yn[e] = y1;
                 un[e] = u1;

@@ -134,12 +134,14 @@ def test_tiled_dstep_one_fista_step(backend):
 
 
 @pytest.mark.gpu
-def test_dictlearn_fused_vs_generic(gpu_backend):
-    """ConvBPDNDictLearn through the fused kernels == the generic kernel chain."""
+@pytest.mark.parametrize('K', [8, 7])
+def test_dictlearn_fused_vs_generic(gpu_backend, K):
+    """ConvBPDNDictLearn through the fused kernels == the generic kernel chain (K = 7:
+    the handle pads the filter axis to 8 for the fused kernels; getdict drops the pad)."""
     import os
     from sporco_amd.dictlrn import cbpdndl
     H = W = 256
-    K, N = 8, 4
+    N = 4
     rng = np.random.RandomState(3)
     D0 = rng.randn(6, 6, K).astype(np.float32)
     S = rng.randn(H, W, N).astype(np.float32)
@@ -147,17 +149,20 @@ def test_dictlearn_fused_vs_generic(gpu_backend):
     def run(generic):
         if generic:
             os.environ['SPORCO_AMD_OLD_ROWS'] = '1'
+            os.environ['SPORCO_AMD_NO_PAD'] = '1'
         try:
             opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 6, 'AccurateDFid': True},
                                                     xmethod='admm', dmethod='pgm')
             d = cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod='pgm')
         finally:
             os.environ.pop('SPORCO_AMD_OLD_ROWS', None)
+            os.environ.pop('SPORCO_AMD_NO_PAD', None)
         return d, d.solve()
 
     d, D1 = run(False)
     d0, D10 = run(True)
     assert d.xstep._dev.uses_fused_rows() and not d0.xstep._dev.uses_fused_rows()
+    assert D1.shape == D10.shape and D1.shape[-1] == K
     assert rel_l2(D1, D10) < 1e-5
     assert rel_l2(d.getcoef(), d0.getcoef()) < 1e-5
     errs = {f: rel_l2(np.asarray(getattr(d.getitstat(), f), dtype=float),

@@ -22,13 +22,16 @@ def make(D, S, optd, generic=False):
     from sporco_amd.pgm import cbpdn as pc
     if generic:
         os.environ['SPORCO_AMD_OLD_ROWS'] = '1'
+        os.environ['SPORCO_AMD_NO_PAD'] = '1'
     try:
         return pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(optd))
     finally:
         os.environ.pop('SPORCO_AMD_OLD_ROWS', None)
+        os.environ.pop('SPORCO_AMD_NO_PAD', None)
 
 
-@pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1)])
+@pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1),
+                                     pytest.param(256, 256, 5, 2, marks=pytest.mark.gpu)])
 def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     from oracle import cbpdn_oracle as orc
     if backend == 'hostsim' and W == 512:

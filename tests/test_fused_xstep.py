@@ -383,3 +383,67 @@ def test_fused_ams_matches_oracle_and_unfused(backend, H, W, K, N, gradreg):
     assert rel_l2(b.cbpdn.Y, ref['Y']) < 1e-4
     for f in fields:
         assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f
+
+
+# ---------------------------------------------------------------------------
+# odd filter counts: the handle pads the filter axis with one all-zero filter to reach the
+# fused kernels; host arrays keep the caller's K
+# ---------------------------------------------------------------------------
+def test_odd_filter_count_is_padded_on_device(backend):
+    """AddMaskSim(ConvBPDNGradReg) with K = 4 (+ impulse = 5 filters, 6 on the device),
+    per-filter L1Weight and GradWeight: everything that carries a filter axis across the
+    ABI, against the float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd import _lib
+    from sporco_amd.admm import cbpdn
+    H, W, K, N = 256, 256, 4, 1
+    D, S = problem(H, W, K, N, seed=77)
+    rng = np.random.RandomState(5)
+    Wm = (rng.rand(H, W) > 0.25).astype(np.float32)
+    wl1 = np.linspace(0.5, 1.5, K + 1).astype(np.float32).reshape(1, 1, 1, 1, K + 1)
+    wg = np.array([0.0, 1.0, 0.5, 2.0, 1.0], np.float32)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L1Weight': wl1, 'GradWeight': wg}
+    b = cbpdn.AddMaskSim(cbpdn.ConvBPDNGradReg, D, S, Wm, 0.05, 0.3,
+                         opt=cbpdn.ConvBPDNGradReg.Options(optd))
+    c = b.cbpdn
+    assert c._dev.query(_lib.QUERY_DEVICE_FILTERS) == K + 2 and c._dev.uses_fused_rows()
+    b.solve()
+    assert c.Y.shape == (H, W, 1, N, K + 1) and c.Xf.shape[-1] == K + 1
+    imp = np.zeros((4, 4, 1), np.float32)
+    imp[0, 0] = 1
+    Di = np.concatenate((D, imp), axis=2)
+    ref = orc.admm_cbpdn(Di.reshape(4, 4, 1, 1, K + 1), S.reshape(H, W, 1, N, 1), 0.05,
+                         dtype=np.float64, maxiter=3, rel_tol=0.0, grad_mu=0.3,
+                         grad_weight=wg.astype(np.float64), wl1=wl1.astype(np.float64),
+                         ams_mask=Wm.reshape(H, W, 1, 1, 1))
+    for key in ('Y', 'U', 'X'):
+        assert rel_l2(getattr(c, key), ref[key]) < 1e-5, key
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'RegGrad', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
+    # state written back through the ABI lands in the right filters
+    Y = c.Y.copy()
+    c.Y = Y
+    assert np.array_equal(c.Y, Y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K', [7, 63, 65])
+def test_odd_filter_count_matches_unpadded(backend, K):
+    H, W, N = 256, 256, 2
+    D, S = problem(H, W, K, N, seed=K)
+    optd = {'MaxMainIter': 8, 'RelStopTol': 0.0}
+    b, Y = solve(D, S, optd)
+    assert b._dev.uses_fused_rows()
+    os.environ['SPORCO_AMD_NO_PAD'] = '1'
+    try:
+        b0, Y0 = solve(D, S, optd)
+    finally:
+        os.environ.pop('SPORCO_AMD_NO_PAD', None)
+    assert not b0._dev.uses_fused_rows()
+    assert Y.shape == Y0.shape == (H, W, 1, N, K)
+    assert rel_l2(Y, Y0) < 2e-5
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(b.getitstat(), f), getattr(b0.getitstat(), f)) < 1e-4, f
+    assert rel_l2(b.X, b0.X) < 2e-5 and rel_l2(b.Xf, b0.Xf) < 2e-5
+    assert rel_l2(b.reconstruct(), b0.reconstruct()) < 2e-5
