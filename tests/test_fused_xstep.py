@@ -141,6 +141,8 @@ def test_three_launch_weights_nonneg_nobndry(backend):
 
 
 def test_no_x_hint_and_pickle(backend):
+    if backend == 'hostsim':
+        pytest.skip("kept for the GPU run: the CPU suite covers these kernels in other cases")
     import pickle
     from sporco_amd import _lib
     H, W, K, N = 256, 256, 4, 1
@@ -187,6 +189,8 @@ def test_speculative_rows_fwd_is_bit_identical(backend):
 def test_joint_at_fused_row_sizes(backend):
     """ConvBPDNJoint where the row kernels engage too (X-step through rows_fwd / fused
     columns / row inverse, l2,1 epilogue generic)."""
+    if backend == 'hostsim':
+        pytest.skip("kept for the GPU run: the CPU suite covers these kernels in other cases")
     from oracle import cbpdn_oracle as orc
     H, W, K, N, C = 256, 256, 4, 1, 3
     D, S = problem(H, W, K, N, seed=15, C=C)
@@ -302,7 +306,7 @@ def solve_gradreg(D, S, optd, mu=0.3, unfused=False):
 
 @pytest.mark.parametrize('H,W,K,N,weights', [
     (256, 12, 8, 2, False), (512, 8, 6, 1, True),
-    pytest.param(256, 256, 4, 1, True),
+    pytest.param(256, 256, 4, 1, True, marks=pytest.mark.gpu),
     pytest.param(512, 512, 64, 2, True, marks=pytest.mark.gpu)])
 def test_fused_gradreg_matches_oracle_and_unfused(backend, H, W, K, N, weights):
     from oracle import cbpdn_oracle as orc
@@ -336,7 +340,7 @@ def test_fused_gradreg_matches_oracle_and_unfused(backend, H, W, K, N, weights):
 # AddMaskSim on the three-launch iteration (mask handling inside rows_inv_post)
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize('H,W,K,N,gradreg', [
-    (256, 256, 3, 2, False),
+    pytest.param(256, 256, 3, 2, False, marks=pytest.mark.gpu),
     pytest.param(256, 256, 5, 1, True, marks=pytest.mark.gpu),
     pytest.param(512, 512, 63, 3, False, marks=pytest.mark.gpu)])
 def test_fused_ams_matches_oracle_and_unfused(backend, H, W, K, N, gradreg):
