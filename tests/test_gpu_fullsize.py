@@ -111,3 +111,41 @@ def test_config2_fullsize_properties(gpu_backend):
     # determinism: a second solver object reproduces the iterates bit for bit
     b2 = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
     assert np.array_equal(b2.solve(), Y)
+
+
+def test_config3_shard_fullsize(gpu_backend):
+    """Config 3 as one of its 8 GPUs sees it: ConvBPDNJoint, 512x512 RGB, K = 128, 32 of
+    the 256 images -- 3.2e9 elements (12.9 GB) per X-sized array, i.e. past 2^31 elements.
+    The slab column kernels + fused row passes against the generic kernel chain."""
+    import os
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(3)
+    H, C, N, K = 512, 3, 32, 128
+    D = rng.randn(8, 8, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, H, C, N).astype(np.float32)
+
+    def run(unfused):
+        if unfused:
+            os.environ['SPORCO_AMD_UNFUSED'] = '1'
+        try:
+            opt = cbpdn.ConvBPDNJoint.Options({'MaxMainIter': 4, 'RelStopTol': 0.0})
+            b = cbpdn.ConvBPDNJoint(D, S, 0.1, 0.02, opt)
+        finally:
+            os.environ.pop('SPORCO_AMD_UNFUSED', None)
+        Y = b.solve()
+        return Y, b.getitstat(), bool(b._dev.uses_fused_cols())
+
+    Y, its, fused = run(False)
+    Y0, its0, fused0 = run(True)
+    assert fused and not fused0
+    num = den = 0.0
+    for h in range(0, H, 32):         # blockwise: no 26 GB float64 temporaries
+        d = Y[h:h + 32].astype(np.float64) - Y0[h:h + 32]
+        num += float(np.sum(d * d))
+        den += float(np.sum(Y0[h:h + 32].astype(np.float64) ** 2))
+    assert np.sqrt(num / den) < 2e-5
+    for f in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(np.asarray(getattr(its, f), float), np.asarray(getattr(its0, f), float)) < 1e-5, f
+    # every image's last filter was reached (the far end of the 12.9 GB arrays is not zero)
+    assert np.count_nonzero(Y[-1, -8:, :, -1, -1]) + np.count_nonzero(Y[0, :8, :, -1, -1]) > 0

@@ -1,0 +1,52 @@
+"""Config 3 of BASELINE.json as one GPU sees it under 8-way image sharding:
+ConvBPDNJoint, 512x512 RGB (C = 3), K = 128, N = 256 / 8 = 32 images (12.9 GB per X-sized array).
+Prints it/s and the fused-vs-generic agreement after a few fixed-rho iterations."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sporco_amd.admm import cbpdn
+
+rng = np.random.RandomState(3)
+H, C, N, K = 512, 3, int(os.environ.get('N', 32)), 128
+D = rng.randn(8, 8, K).astype(np.float32); D /= np.sqrt(np.sum(D**2, axis=(0, 1), keepdims=True))
+S = rng.randn(H, H, C, N).astype(np.float32)
+
+
+def run(unfused, iters, timed):
+    if unfused:
+        os.environ['SPORCO_AMD_UNFUSED'] = '1'
+    try:
+        opt = cbpdn.ConvBPDNJoint.Options({'MaxMainIter': iters, 'RelStopTol': 0.0, 'rho': 6.0,
+                                           'AutoRho': {'Enabled': False}})
+        b = cbpdn.ConvBPDNJoint(D, S, 0.1, 0.02, opt)
+    finally:
+        os.environ.pop('SPORCO_AMD_UNFUSED', None)
+    b._return_min = False
+    b.solve(); b._dev.sync()
+    out = {}
+    if timed:
+        b.opt['MaxMainIter'] = timed          # (solve() runs MaxMainIter more iterations)
+        b.profile(True)
+        t0 = time.perf_counter(); b.solve(); b._dev.sync(); t = time.perf_counter() - t0
+        out = {'it_per_s': timed / t, 'ms_per_it': 1e3 * t / timed,
+               'kernel_ms': {k: round(v[0] / v[1], 3) for k, v in b.profile_read().items() if v[1]}}
+    its = b.getitstat()
+    return b, its, out
+
+
+b, its, perf = run(False, 3, 10)
+print(json.dumps({'config': 'ConvBPDNJoint 512x512x3 K=128 N=%d f32 (config 3, one of 8 shards)' % N,
+                  'fused_cols': bool(b._dev.uses_fused_cols()), **perf}))
+obj = np.asarray(its.ObjFun, dtype=float)
+print('ObjFun', obj[:4], 'monotone' if np.all(np.diff(obj[1:]) < 0) else 'NOT monotone')
+Y = b.Y
+b_k = b.k
+del b
+b0, its0, _ = run(True, b_k, 0)
+Y0 = b0.Y
+num = 0.0; den = 0.0
+for h in range(0, H, 64):     # blockwise: a 12.9 GB float64 temporary would not be welcome
+    d = Y[h:h + 64].astype(np.float64) - Y0[h:h + 64]
+    num += float(np.sum(d * d)); den += float(np.sum(Y0[h:h + 64].astype(np.float64) ** 2))
+print('rel_l2(Y fused, Y generic) after %d iterations:' % b_k, np.sqrt(num / den))
+o0 = np.asarray(its0.ObjFun, float); print('ObjFun fused  ', obj[:13]); print('ObjFun generic', o0[:13])
