@@ -103,6 +103,14 @@ typedef struct {
  * (sporco/pgm/cbpdn.py:216-233). */
 int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
                           sporco_amd_csc_t *out);
+/* The same for a multi-channel dictionary (SPORCO cri.Cd > 1, sporco/cnvrep.py:186-194):
+ * dict_channels == dims->C channels in D (host layout (dH,dW,Cd,K)) and in S; the coefficient
+ * arrays then have a single channel, (H,W,1,N,K), Df is (H,Wf,Cd,1,K), and the X-step is the
+ * iterated Sherman-Morrison solve linalg.solvemdbi_ism (sporco/linalg.py:370-444, call site
+ * sporco/admm/cbpdn.py:277-279).  ADMM ConvBPDN only; dict_channels == 1 is
+ * sporco_amd_csc_create. */
+int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels, int device,
+                             void *stream, sporco_amd_csc_t *out);
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
 int sporco_amd_csc_sync(sporco_amd_csc_t h);
 /* Which kernels serve this handle's shape: *out = 1 when the fused path named by

@@ -110,6 +110,28 @@ def solvedbd_sm(ah, d, b, c=None, axis=AX_K):
     return (b - a * inner(c, b, axis=axis)) / d
 
 
+def solvemdbi_ism(ah, rho, b, axisM=AX_K, axisK=AX_C):
+    """Solve (rho I + sum_c a_c a_c^H) x = b per frequency by iterated
+    Sherman-Morrison over the C rank-one terms -- sporco/linalg.py:370-444
+    (``axisK`` is the reference's name for the axis indexing the terms: here the
+    dictionary channel axis)."""
+    C = ah.shape[axisK]
+    a = np.conj(ah)
+    take = lambda v, c: np.take(v, [c], axisK)
+    gamma, delta = [], []
+    alpha = take(a, 0) / rho
+    beta = b / rho
+    for c in range(C):
+        gamma.append(alpha.copy())
+        delta.append(1.0 + inner(take(ah, c), gamma[c], axis=axisM))
+        beta = beta - gamma[c] * inner(take(ah, c), beta, axis=axisM) / delta[c]
+        if c < C - 1:
+            alpha = take(a, c + 1) / rho
+            for l in range(c + 1):
+                alpha = alpha - gamma[l] * inner(take(ah, l), alpha, axis=axisM) / delta[l]
+    return beta
+
+
 def gradient_filters_ghg(shp, dtype):
     """sum_i |G_i|^2 on the half spectrum, shape (H, W//2+1, 1, 1, 1), for the
     two-tap difference filters [1, -1] along each spatial axis --
@@ -182,9 +204,10 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
                time_budget=None, grad_mu=None, grad_weight=1.0, ams_mask=None):
     """Run ADMM ConvBPDN (``mu is None``) or ConvBPDNJoint on 5-D arrays.
 
-    ``D``: (dH, dW, 1, 1, K);  ``S``: (H, W, C, N, 1).  Single-channel
-    dictionary only (Cd = 1), i.e. the ``solvedbi_sm`` branch of
-    sporco/admm/cbpdn.py:274-276.
+    ``D``: (dH, dW, Cd, 1, K);  ``S``: (H, W, C, N, 1).  Cd = 1 is the
+    ``solvedbi_sm`` branch of sporco/admm/cbpdn.py:274-276; Cd = C > 1 (a
+    multi-channel dictionary, one coefficient map set shared by the channels:
+    X is (H, W, 1, N, K)) the ``solvemdbi_ism`` branch (:250-251, :277-279).
 
     Follows, per iteration, sporco/admm/admm.py:331-377:
       Yprev=Y; xstep (cbpdn.py:267-281); relax_AX (admm.py:877-885);
@@ -213,7 +236,8 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
     S = np.asarray(S, dtype=dtype)
     H, W = S.shape[0], S.shape[1]
     K = D.shape[AX_K]
-    shpX = (H, W, S.shape[AX_C], S.shape[AX_N], K)
+    mcd = D.shape[AX_C] > 1
+    shpX = (H, W, 1 if mcd else S.shape[AX_C], S.shape[AX_N], K)
     Nx = int(np.prod(shpX))
 
     lmbda = rdt(lmbda)
@@ -235,6 +259,8 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
     Sf = rfftn2(S)
     Df = rfftn2(D, (H, W))
     DSf = np.conj(Df) * Sf
+    if mcd:
+        DSf = np.sum(DSf, axis=AX_C, keepdims=True)        # cbpdn.py:250-251
     gradreg = grad_mu is not None
     if gradreg:
         assert not joint
@@ -267,6 +293,8 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
         if gradreg:
             Xf = solvedbd_sm(Df, grad_mu * GHGf + rho, b, None,
                              AX_K).astype(b.dtype)
+        elif mcd:
+            Xf = solvemdbi_ism(Df, rho, b, AX_K, AX_C).astype(b.dtype)
         else:
             Xf = solvedbi_sm(Df, rho, b, None, AX_K).astype(b.dtype)
         X = irfftn2(Xf, (H, W))

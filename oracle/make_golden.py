@@ -377,6 +377,26 @@ def ams_case(name, cls, D, S, W, args, optd, dimK=None):
          **extra, **itstat_dict(c))
 
 
+def gen_mcdict():
+    """Multi-channel dictionary (Cd = C > 1): the solvemdbi_ism X-step branch,
+    sporco/admm/cbpdn.py:277-279, sporco/linalg.py:370-444.  SURVEY.md 8(f) rank 2."""
+    np.random.seed(8642)
+    D = np.random.randn(5, 5, 3, 4)
+    S = np.random.randn(16, 16, 3, 2)
+    admm_case('admm_mcdict_f64', D, S, 0.1, {'MaxMainIter': 25, 'LinSolveCheck': True})
+    admm_case('admm_mcdict_f32', D, S, 0.1, {'MaxMainIter': 25, 'DataType': np.float32})
+    S1 = np.random.randn(15, 18, 3)
+    admm_case('admm_mcdict_single_nonneg_f64', D, S1, 0.05,
+              {'MaxMainIter': 20, 'NonNegCoef': True, 'AuxVarObj': True,
+               'rho': 2.0, 'AutoRho': {'Enabled': False}})
+    g = {}
+    # the primitive itself, on random data (4 channels, 6 filters)
+    ah = np.random.randn(7, 5, 4, 1, 6) + 1j * np.random.randn(7, 5, 4, 1, 6)
+    b = np.random.randn(7, 5, 1, 3, 6) + 1j * np.random.randn(7, 5, 1, 3, 6)
+    x = ref_linalg.solvemdbi_ism(ah, 1.7, b.copy(), 4, 2)
+    save('solvemdbi_ism', ah=ah, b=b, rho=np.float64(1.7), x=x)
+
+
 def gen_ams():
     """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
     ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
@@ -402,8 +422,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

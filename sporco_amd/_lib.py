@@ -42,7 +42,8 @@ PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY = range(6)
 
 EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
-    'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_destroy',
+    'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc',
+    'sporco_amd_csc_destroy',
     'sporco_amd_csc_sync', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
@@ -151,6 +152,9 @@ def load(path=None):
     lib.sporco_amd_csc_create.argtypes = [ctypes.POINTER(Dims), ctypes.c_int,
                                           ctypes.c_void_p,
                                           ctypes.POINTER(ctypes.c_void_p)]
+    lib.sporco_amd_csc_create_mc.argtypes = [ctypes.POINTER(Dims), ctypes.c_int32, ctypes.c_int,
+                                             ctypes.c_void_p,
+                                             ctypes.POINTER(ctypes.c_void_p)]
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
     dptr = ctypes.POINTER(ctypes.c_double)
     pptr = ctypes.POINTER(AdmmParams)
@@ -269,16 +273,20 @@ def _carr(a, dtype):
 class Solver(object):
     """Owner of one device-side ConvBPDN problem (opaque C handle)."""
 
-    def __init__(self, H, W, C, N, K, dtype, device=0, stream=None):
-        self.dims = (int(H), int(W), int(C), int(N), int(K))
+    def __init__(self, H, W, C, N, K, dtype, device=0, stream=None, Cd=1):
+        """``C``: channels of the signal.  ``Cd`` > 1 (== C): multi-channel dictionary, the
+        coefficient arrays then have a single channel (cnvrep.py:186-194)."""
+        self.Cd = int(Cd)
+        self.Cs = int(C)
+        self.dims = (int(H), int(W), 1 if self.Cd > 1 else int(C), int(N), int(K))
         self.dtype = np.dtype(dtype)
         self.cdtype = np.dtype(np.complex64 if self.dtype == np.float32
                                else np.complex128)
-        d = Dims(*self.dims, dtype_code(dtype))
+        d = Dims(int(H), int(W), int(C), int(N), int(K), dtype_code(dtype))
         h = ctypes.c_void_p()
-        check(lib().sporco_amd_csc_create(ctypes.byref(d), int(device),
-                                          ctypes.c_void_p(stream or 0),
-                                          ctypes.byref(h)))
+        check(lib().sporco_amd_csc_create_mc(ctypes.byref(d), self.Cd, int(device),
+                                             ctypes.c_void_p(stream or 0),
+                                             ctypes.byref(h)))
         self._h = h
         self._lib = lib()
 
@@ -308,9 +316,9 @@ class Solver(object):
         H, W, C, N, K = self.dims
         Wf = W // 2 + 1
         if var == VAR_DF:
-            return (H, Wf, 1, 1, K), self.cdtype
+            return (H, Wf, self.Cd, 1, K), self.cdtype
         if var == VAR_SF:
-            return (H, Wf, C, N, 1), self.cdtype
+            return (H, Wf, self.Cs, N, 1), self.cdtype
         if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2,
                    VAR_ZF):
             return (H, Wf, C, N, K), self.cdtype
@@ -346,14 +354,14 @@ class Solver(object):
 
     def set_signal(self, S):
         H, W, C, N, K = self.dims
-        S = _carr(S, self.dtype).reshape(H, W, C, N)
+        S = _carr(S, self.dtype).reshape(H, W, self.Cs, N)
         check(self._lib.sporco_amd_csc_set_signal(self._h, _ptr(S)))
 
     def set_dict(self, D):
         K = self.dims[4]
         D = _carr(D, self.dtype)
         dH, dW = D.shape[0], D.shape[1]
-        D = D.reshape(dH, dW, K)
+        D = D.reshape(dH, dW, self.Cd * K)      # (dH, dW, Cd, 1, K) is contiguous as (.., Cd K)
         check(self._lib.sporco_amd_csc_set_dict(self._h, _ptr(D), dH, dW))
 
     def _set_weight(self, fn, w):
@@ -442,7 +450,7 @@ class Solver(object):
 
     def reconstruct(self, var):
         H, W, C, N, K = self.dims
-        out = np.empty((H, W, C, N, 1), dtype=self.dtype)
+        out = np.empty((H, W, self.Cs, N, 1), dtype=self.dtype)
         check(self._lib.sporco_amd_csc_reconstruct(self._h, var, _ptr(out)))
         return out
 

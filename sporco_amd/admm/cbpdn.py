@@ -96,6 +96,10 @@ class GenericConvBPDN(admm.ADMMEqual):
                    'compute_residuals', 'residual_norms', 'eval_objfn', 'obfn_dfd',
                    'obfn_reg', 'iteration_stats', 'itstat_extra', 'rescale_u')
     _fused_base = None   # set after each fused-capable class definition
+    # multi-channel dictionaries (cri.Cd > 1): X-step by iterated Sherman-Morrison
+    # (linalg.solvemdbi_ism, cbpdn.py:277-279); the variants below that need a different
+    # system matrix switch this off
+    _multichannel_dict_ok = True
 
     def __init__(self, D, S, opt=None, dimK=None, dimN=2, device=0, stream=None,
                  reducer=None):
@@ -114,10 +118,10 @@ class GenericConvBPDN(admm.ADMMEqual):
         self.real_dtype = True
         if not hasattr(self, 'cri'):
             self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd > 1:
+        if self.cri.Cd > 1 and not self._multichannel_dict_ok:
             raise NotImplementedError(
-                "multi-channel dictionaries (linalg.solvemdbi_ism X-step) are not "
-                "part of the sporco_amd hot path yet")
+                "%s with a multi-channel dictionary is not part of the sporco_amd hot path "
+                "(ConvBPDN is: linalg.solvemdbi_ism X-step)" % type(self).__name__)
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
@@ -137,7 +141,7 @@ class GenericConvBPDN(admm.ADMMEqual):
     def _new_handle(self):
         H, W = self.cri.Nv
         self._dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                device=self._device, stream=self._stream)
+                                device=self._device, stream=self._stream, Cd=self.cri.Cd)
         self._cache = {}
         self._no_x = getattr(self, '_no_x', False)   # promise that X / Xf will not be read
         self._u_scale = 1.0      # pending `U /= rsf` (admm.py:573), applied lazily
@@ -504,6 +508,8 @@ class ConvBPDNJoint(ConvBPDN):
     DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
     """
 
+    _multichannel_dict_ok = False
+
     class Options(ConvBPDN.Options):
         """Adds ``L21Weight`` (cbpdn.py:719-720)."""
 
@@ -580,6 +586,8 @@ class ConvBPDNGradReg(ConvBPDN):
     IterationStats fields: ``Iter, ObjFun, DFid, RegL1, RegGrad, PrimalRsdl,
     DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
     """
+
+    _multichannel_dict_ok = False
 
     class Options(ConvBPDN.Options):
         """Adds ``GradWeight``: scalar, or one weight per filter (cbpdn.py:1059-1073)."""

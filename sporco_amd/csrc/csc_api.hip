@@ -207,6 +207,12 @@ template <typename T> struct Csc : CscBase {
     // unit norm) keeps padding filters at zero.  Host arrays always have Ku filters; the
     // copies in and out are strided.
     int Ku;
+    // Multi-channel dictionary (Cd > 1, cnvrep.py:186-194): D and S have Cd = Cs channels,
+    // the coefficient maps one (C = 1); X-step by iterated Sherman-Morrison (ism_*).
+    int Cd = 1, Cs, CNs;
+    cx<T> *ism_gam = nullptr, *ism_del = nullptr, *ism_mm = nullptr;
+    bool ism_valid = false;
+    double ism_rho = 0.0;
     int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
     FftPlan planW, planH;
     void *vars[SPORCO_AMD_VAR_COUNT] = {nullptr};
@@ -269,18 +275,23 @@ template <typename T> struct Csc : CscBase {
         return (cols && rows_supported<T>(W_, K_ + 1)) ? K_ + 1 : K_;
     }
 
-    Csc(const sporco_amd_dims &d, int dev, void *stream) : dm(d), device(dev) {
+    Csc(const sporco_amd_dims &d, int dev, void *stream, int cd) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
                    "all dimensions must be >= 1");
+        SA_REQUIRE(cd == 1 || cd == d.C,
+                   "a multi-channel dictionary needs as many channels as the signal");
         SA_HIP(hipSetDevice(device));
         H = d.H;
         W = d.W;
-        C = d.C;
+        Cd = cd;
+        Cs = d.C;
+        C = cd > 1 ? 1 : d.C;   // channels of the coefficient maps
         N = d.N;
         Ku = d.K;
-        K = padded_filters(d.H, d.W, d.K);
+        K = cd > 1 ? d.K : padded_filters(d.H, d.W, d.K);
         Wf = W / 2 + 1;
         CN = C * N;
+        CNs = Cs * N;
         P = (int64_t)C * N * K;
         E = (int64_t)H * W * P;
         npix = (int64_t)H * Wf;
@@ -301,10 +312,11 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipHostMalloc((void **)&out_pinned, sizeof(double) * kOutSlots, 0));
         out_dev_default = out_dev_own;
         SA_HIP(hipMalloc((void **)&gram, sizeof(T) * npix));
-        SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CN));
-        SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CN));
-        fused = fused_cols_supported<T>(H, K) && K % 2 == 0 && !std::getenv("SPORCO_AMD_UNFUSED");
-        fused_slabs = fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
+        SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CNs));
+        SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CNs));
+        fused = Cd == 1 && fused_cols_supported<T>(H, K) && K % 2 == 0 &&
+                !std::getenv("SPORCO_AMD_UNFUSED");
+        fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
         if (fused_slabs)
             SA_HIP(hipMalloc((void **)&qpart, sizeof(cx<T>) * (int64_t)Wf * CN * ((K + 63) / 64) * H));
         if (fused || fused_slabs) {
@@ -339,7 +351,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -351,7 +363,8 @@ template <typename T> struct Csc : CscBase {
     }
 
     size_t var_bytes(int var) const {
-        if (var == SPORCO_AMD_VAR_SF) return sizeof(cx<T>) * npix * CN;
+        if (var == SPORCO_AMD_VAR_SF) return sizeof(cx<T>) * npix * CNs;
+        if (var == SPORCO_AMD_VAR_DF) return sizeof(cx<T>) * npix * Cd * K;
         if (var_is_dict_sized(var))
             return var_is_complex(var) ? sizeof(cx<T>) * npix * K : sizeof(T) * (int64_t)H * W * K;
         return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
@@ -513,8 +526,8 @@ template <typename T> struct Csc : CscBase {
     // ---- set-up ------------------------------------------------------------------
     void set_signal(const void *S) override {
         before_state_change();
-        SA_HIP(hipMemcpyAsync(sreal, S, sizeof(T) * (int64_t)H * W * CN, hipMemcpyHostToDevice, st));
-        fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CN);
+        SA_HIP(hipMemcpyAsync(sreal, S, sizeof(T) * (int64_t)H * W * CNs, hipMemcpyHostToDevice, st));
+        fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CNs);
         refresh_fused_signal();
         sync();  // the host buffer may be released after return
         have_signal = true;
@@ -524,18 +537,20 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W,
                    "filter support must fit inside the signal");
         before_state_change();
-        if (!dpad) SA_HIP(hipMalloc((void **)&dpad, sizeof(T) * (int64_t)H * W * K));
+        if (!dpad) SA_HIP(hipMalloc((void **)&dpad, sizeof(T) * (int64_t)H * W * Cd * K));
         // stage the compact filters at the tail of dpad's own allocation? no: use `work`-free
         // dedicated staging so set_dict is safe while iterates are live.
         T *stage = nullptr;
-        SA_HIP(hipMalloc((void **)&stage, sizeof(T) * (int64_t)dH * dW * Ku));
-        SA_HIP(hipMemcpyAsync(stage, D, sizeof(T) * (int64_t)dH * dW * Ku, hipMemcpyHostToDevice, st));
-        {
+        SA_HIP(hipMalloc((void **)&stage, sizeof(T) * (int64_t)dH * dW * Cd * Ku));
+        SA_HIP(hipMemcpyAsync(stage, D, sizeof(T) * (int64_t)dH * dW * Cd * Ku, hipMemcpyHostToDevice,
+                              st));
+        {   // (Cd > 1: host layout (dH, dW, Cd, K), never padded)
             ProfScope ps(prof, PS_OTHER);
-            launch_pad_dict<T>(st, stage, dpad, H, W, K, dH, dW, Ku);
+            launch_pad_dict<T>(st, stage, dpad, H, W, Cd * K, dH, dW, Cd * Ku);
         }
-        fwd2(dpad, nullptr, T(0), cv(SPORCO_AMD_VAR_DF), K);
-        {
+        fwd2(dpad, nullptr, T(0), cv(SPORCO_AMD_VAR_DF), (int64_t)Cd * K);
+        ism_valid = false;
+        if (Cd == 1) {
             ProfScope ps(prof, PS_OTHER);
             launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
         }
@@ -662,7 +677,8 @@ template <typename T> struct Csc : CscBase {
         host_copy(var, const_cast<void *>(src), true);
         if (var == SPORCO_AMD_VAR_XF) xf_tiled = false;
         if (var == SPORCO_AMD_VAR_DF) {
-            launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
+            ism_valid = false;
+            if (Cd == 1) launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
             refresh_fused_dict();
         }
         if (var == SPORCO_AMD_VAR_SF) refresh_fused_signal();
@@ -685,6 +701,11 @@ template <typename T> struct Csc : CscBase {
         std::memcpy(out_host, out_pinned, sizeof(double) * kOutSlots);
     }
 
+    void require_single_channel_dict() const {
+        if (Cd > 1)
+            throw Error(SPORCO_AMD_EINVAL,
+                        "multi-channel dictionaries are handled by the ADMM ConvBPDN calls only");
+    }
     void require_ready() const {
         if (!have_dict || !have_signal)
             throw Error(SPORCO_AMD_ESTATE, "set_signal and set_dict must be called first");
@@ -905,6 +926,38 @@ template <typename T> struct Csc : CscBase {
         fwd2(Y, U, (T)p.u_scale, Xf, P);
         const bool obj = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
         const bool xr = p.flags & F_XRRS;
+        if (Cd > 1) {
+            // multi-channel dictionary: iterated Sherman-Morrison (cbpdn.py:277-279)
+            SA_REQUIRE(!(p.flags & (F_GRADREG | F_AMS | F_JOINT)),
+                       "this solver variant needs a single-channel dictionary");
+            if (!ism_gam) {
+                SA_HIP(hipMalloc((void **)&ism_gam, sizeof(cx<T>) * npix * Cd * K));
+                SA_HIP(hipMalloc((void **)&ism_del, sizeof(cx<T>) * npix * Cd));
+                SA_HIP(hipMalloc((void **)&ism_mm, sizeof(cx<T>) * npix * Cd * Cd));
+            }
+            if (!ism_valid || ism_rho != p.rho) {
+                ProfScope ps(prof, PS_OTHER);
+                launch_ism_setup<T>(st, cv(SPORCO_AMD_VAR_DF), ism_gam, ism_del, ism_mm, npix, Cd, K,
+                                    (T)p.rho);
+                ism_valid = true;
+                ism_rho = p.rho;
+            }
+            int nbm;
+            {
+                ProfScope ps(prof, PS_SM_SOLVE);
+                nbm = launch_ism_solve<T>(st, Xf, Xf, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF),
+                                          ism_gam, ism_del, ism_mm, (T)p.rho, npix, Cd, N, K, W, obj, xr,
+                                          part_a);
+            }
+            if (obj || xr) {
+                const int slots[4] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
+                                      SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
+                const double scales[4] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0};
+                finalize(part_a, nbm, 4, 4, slots, scales, out_dev);
+            }
+            inv2(Xf, work_buf(), X, P);
+            return;
+        }
         int nb;
         GradTerm<T> gt;
         if (gradreg) gt = grad_term(p.mu);
@@ -926,6 +979,14 @@ template <typename T> struct Csc : CscBase {
     }
 
     // data fidelity evaluated at Y (fEvalX False / AuxVarObj, cbpdn.py:315-321)
+    // innerb(npix, Cs, N) = sum_k Df * vf   (linalg.inner over the filter axis)
+    void inner_df(const cx<T> *vf) {
+        if (Cd > 1)
+            launch_mc_inner<T>(st, cv(SPORCO_AMD_VAR_DF), vf, innerb, npix, Cd, N, K);
+        else
+            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), vf, innerb, npix, CN, K);
+    }
+
     void dfid_at(const T *V, double *out_dev, const sporco_amd_admm_params *gp = nullptr) {
         cx<T> *wk = work_buf();
         fwd2(V, nullptr, T(0), wk, P);
@@ -942,12 +1003,12 @@ template <typename T> struct Csc : CscBase {
         }
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), wk, innerb, npix, CN, K);
+            inner_df(wk);
         }
         int nb;
         {
             ProfScope ps(prof, PS_OTHER);
-            nb = launch_rfl2norm2<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), npix, CN, W, part_a);
+            nb = launch_rfl2norm2<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), npix, CNs, W, part_a);
         }
         const int slots[1] = {SPORCO_AMD_OUT_DFID};
         const double scales[1] = {1.0 / ((double)H * W)};
@@ -1055,10 +1116,10 @@ template <typename T> struct Csc : CscBase {
         fwd2(rv(var), nullptr, T(0), wk, P);
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), wk, innerb, npix, CN, K);
+            inner_df(wk);
         }
-        inv2(innerb, innerb, sreal, CN);
-        SA_HIP(hipMemcpyAsync(dst, sreal, sizeof(T) * (int64_t)H * W * CN, hipMemcpyDeviceToHost, st));
+        inv2(innerb, innerb, sreal, CNs);
+        SA_HIP(hipMemcpyAsync(dst, sreal, sizeof(T) * (int64_t)H * W * CNs, hipMemcpyDeviceToHost, st));
         sync();
     }
 
@@ -1067,8 +1128,10 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_OTHER);
-            nb = launch_dhs_absmax<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF), npix, CN, K,
-                                      part_a);
+            nb = Cd > 1 ? launch_mc_dhs_absmax<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF),
+                                                   npix, Cd, N, K, part_a)
+                        : launch_dhs_absmax<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF), npix,
+                                               CN, K, part_a);
         }
         const int slots[1] = {0};
         const double scales[1] = {1.0};
@@ -1115,6 +1178,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
+        require_single_channel_dict();
         require_ready();
         if (!(rows_ok && fused))
             throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
@@ -1196,6 +1260,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void pgm_grad(int var, double *out_dev) override {
+        require_single_channel_dict();
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_grad needs a frequency-domain variable");
         before_read(var);
@@ -1211,6 +1276,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void pgm_eval(int var, double *out_dev) override {
+        require_single_channel_dict();
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_eval needs a frequency-domain variable");
         before_read(var);
@@ -1318,6 +1384,7 @@ template <typename T> struct Csc : CscBase {
 
     // ---- dictionary update -------------------------------------------------------------
     void ccmod_setcoef(int var) override {
+        require_single_channel_dict();
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
@@ -1367,6 +1434,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void ccmod_grad(int var, bool write_grad, double *out_dev) override {
+        require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var),
                    "ccmod_grad needs a dictionary-sized frequency-domain variable");
@@ -1465,6 +1533,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void setdict_from_dstep(int dH, int dW) override {
+        require_single_channel_dict();
         before_state_change();
         SA_HIP(hipMemcpyAsync(cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_DXF),
                               sizeof(cx<T>) * npix * K, hipMemcpyDeviceToDevice, st));
@@ -1570,8 +1639,14 @@ int sporco_amd_device_info(int device, char *name, size_t name_len, int *cu_coun
 
 int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
                           sporco_amd_csc_t *out) {
+    return sporco_amd_csc_create_mc(dims, 1, device, stream, out);
+}
+
+int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels, int device,
+                             void *stream, sporco_amd_csc_t *out) {
     SA_API_BEGIN
     SA_REQUIRE(dims && out, "null argument");
+    SA_REQUIRE(dict_channels >= 1, "dict_channels must be >= 1");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
         throw Error(SPORCO_AMD_EHIP, "no HIP device visible: libsporco_amd needs an AMD GPU");
@@ -1579,9 +1654,9 @@ int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
     std::unique_ptr<sporco_amd_csc> h(new sporco_amd_csc);
     h->device = device;
     if (dims->dtype == SPORCO_AMD_F32)
-        h->impl.reset(new Csc<float>(*dims, device, stream));
+        h->impl.reset(new Csc<float>(*dims, device, stream, dict_channels));
     else if (dims->dtype == SPORCO_AMD_F64)
-        h->impl.reset(new Csc<double>(*dims, device, stream));
+        h->impl.reset(new Csc<double>(*dims, device, stream, dict_channels));
     else
         throw Error(SPORCO_AMD_EINVAL, "dtype must be SPORCO_AMD_F32 or SPORCO_AMD_F64");
     *out = h.release();

@@ -176,6 +176,28 @@ template <typename T>
 int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int CN,
                       int K, double *partials);
 
+// Multi-channel dictionary (Cd > 1) X-step, linalg.solvemdbi_ism (linalg.py:370-444):
+// gam(npix, Cd, K), del(npix, Cd), mm(npix, Cd, Cd) hold the recursion's gamma / delta and the
+// products <ah_c, gamma_l> (functions of Df and rho);
+// the solve forms b = sum_c conj(Df) Sf + rho yuf on the fly.  Layouts: df (npix, Cd, K),
+// sf (npix, Cd, N), yuf / xf (npix, N, K).  K <= 256, Cd <= 8.  Partials as launch_sm_solve.
+template <typename T>
+void launch_ism_setup(hipStream_t st, const cx<T> *df, cx<T> *gam, cx<T> *del, cx<T> *mm,
+                      int64_t npix, int Cd, int K, T rho);
+template <typename T>
+int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
+                     const cx<T> *sf, const cx<T> *gam, const cx<T> *del, const cx<T> *mm, T rho,
+                     int64_t npix, int Cd, int N, int K, int W, bool want_obj, bool want_xrrs,
+                     double *partials);
+// out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]
+template <typename T>
+void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
+                     int Cd, int N, int K);
+// max |conj(df[pix, c, k]) sf[pix, c, n]|^2; partial[block] = block max
+template <typename T>
+int launch_mc_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int Cd,
+                         int N, int K, double *partials);
+
 // out[slot[i]] = scale[i] * sum_b partials[b*stride + i]  (or max when is_max)
 void launch_finalize(hipStream_t st, const double *partials, int nblocks, int stride, int nvals,
                      const int *slots, const double *scales, bool is_max, double *out);

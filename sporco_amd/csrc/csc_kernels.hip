@@ -1221,6 +1221,335 @@ int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<
     return grid;
 }
 
+// ---------------------------------------------------------------------------
+// multi-channel dictionaries (Cd > 1): iterated Sherman-Morrison, linalg.solvemdbi_ism
+// (linalg.py:370-444) as called by GenericConvBPDN.xstep (cbpdn.py:277-279)
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ cx<T> cdivide(cx<T> a, cx<T> b) {
+    const T s = T(1) / cabs2(b);
+    return cscale(cmulc(b, a), s);   // a conj(b) / |b|^2
+}
+
+// gam[pix, c, :], del[pix, c] and mm[pix, c, l]: the vectors gamma_c and scalars delta_c of
+// the recursion (linalg.py:418-441) and the products M_cl = <ah_c, gamma_l>; they depend on
+// Df and rho only.  One wave per frequency, lane = filter (KR chunks of 64: K <= 64 KR).
+template <typename T, int KR>
+__global__ void __launch_bounds__(kThreads) ism_setup_kernel(const cx<T> *__restrict__ df,
+                                                             cx<T> *__restrict__ gam,
+                                                             cx<T> *__restrict__ del,
+                                                             cx<T> *__restrict__ mm, int64_t npix,
+                                                             int Cd, int K, T rho) {
+    constexpr int CMAX = 8;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    const T irho = T(1) / rho;
+    for (int64_t pix = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+         pix < npix; pix += nwaves) {
+        const cx<T> *d = df + pix * Cd * K;
+        cx<T> *g = gam + pix * Cd * K;
+        cx<T> dl[CMAX];
+        for (int c = 0; c < Cd; ++c) {
+            cx<T> al[KR];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                al[j] = k < K ? cscale(cconj(d[c * K + k]), irho) : mk<T>(T(0), T(0));
+            }
+            for (int l = 0; l < c; ++l) {
+                cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    if (k < K) t = t + cmul(d[l * K + k], al[j]);
+                }
+                const cx<T> f = cdivide(wave_sum_cx(t), dl[l]);
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    if (k < K) al[j] = al[j] - cmul(g[l * K + k], f);
+                }
+            }
+            cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) {
+                    g[c * K + k] = al[j];
+                    t = t + cmul(d[c * K + k], al[j]);
+                }
+            }
+            t = wave_sum_cx(t);
+            dl[c] = mk<T>(T(1) + t.re, t.im);
+            if (lane == 0) del[pix * Cd + c] = dl[c];
+        }
+        // M_cl = sum_k d_c[k] gamma_l[k] for every pair (the solve kernel then needs only the
+        // Cd inner products with b / rho, taken together)
+        for (int c = 0; c < Cd; ++c)
+            for (int l = 0; l < Cd; ++l) {
+                cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    if (k < K) t = t + cmul(d[c * K + k], g[l * K + k]);
+                }
+                t = wave_sum_cx(t);
+                if (lane == 0) mm[(pix * Cd + c) * Cd + l] = t;
+            }
+    }
+}
+
+template <typename T> struct IsmArgs {
+    const cx<T> *yuf;   // (npix, N, K): rfftn(Y - U)
+    cx<T> *xf;          // out (may alias yuf)
+    const cx<T> *df;    // (npix, Cd, K)
+    const cx<T> *sf;    // (npix, Cd, N)
+    const cx<T> *gam;   // (npix, Cd, K)
+    const cx<T> *del;   // (npix, Cd)
+    const cx<T> *mm;    // (npix, Cd, Cd)
+    T rho;
+    int64_t npix;
+    int Cd, N, K, W;
+    int want_obj, want_xrrs;
+    double *partials;   // 4 doubles per block, as launch_sm_solve
+};
+
+// xf = solvemdbi_ism(Df, rho, sum_c conj(Df) Sf + rho yuf): one workgroup per frequency, its
+// waves take the images in turn, lane = filter.  With beta0 = b / rho and t_c = <ah_c, beta0> (the only reductions,
+// taken together), the recursion of linalg.py:425-441 unrolls to
+//     f_c = (t_c - sum_{l<c} M_cl f_l) / delta_c,     x = beta0 - sum_c gamma_c f_c,
+//     (D x)_c = t_c - sum_l M_cl f_l.
+// CC: compile-time channel count (2..4), or 0 for a run-time Cd <= 8.
+template <typename T, int KR, int CC>
+__global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a) {
+    constexpr int CM = CC ? CC : 8;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    const int Wf = a.W / 2 + 1, K = a.K, Cd = CC ? CC : a.Cd;
+    const T rho = a.rho, irho = T(1) / a.rho;
+    // The kThreads / kWave waves of a workgroup share one frequency and take its images in
+    // turn: Df, gamma, M and delta of the frequency are loaded once per wave, into registers.
+    constexpr int WPB = kThreads / kWave;
+    const int wv = threadIdx.x / kWave;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t pix = blockIdx.x; pix < a.npix; pix += gridDim.x) {
+        const cx<T> *dp = a.df + pix * Cd * K;
+        const cx<T> *gp = a.gam + pix * Cd * K;
+        const cx<T> *M = a.mm + pix * Cd * Cd;
+        const double pw = parseval_weight((int)(pix % Wf), Wf, a.W);
+        cx<T> d[CM][KR], g[CM][KR], dl[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < Cd) {
+                dl[c] = a.del[pix * Cd + c];
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    d[c][j] = g[c][j] = mk<T>(T(0), T(0));
+                    if (k < K) {
+                        d[c][j] = dp[c * K + k];
+                        g[c][j] = gp[c * K + k];
+                    }
+                }
+            }
+        for (int n = wv; n < a.N; n += WPB) {
+            const int64_t sys = pix * a.N + n;
+            cx<T> sc[CM], t[CM], f[CM], dx[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                t[c] = mk<T>(T(0), T(0));
+                if (c < Cd) sc[c] = a.sf[(pix * Cd + c) * a.N + n];
+            }
+            cx<T> be[KR];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                be[j] = mk<T>(T(0), T(0));
+                if (k < K) {
+                    cx<T> v = a.yuf[sys * K + k];
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < Cd) v = v + cscale(cmulc(d[c][j], sc[c]), irho);
+                    be[j] = v;                                   // beta0 = b / rho
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < Cd) t[c] = t[c] + cmul(d[c][j], v);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < Cd) t[c] = wave_sum_cx(t[c]);
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < Cd) {
+                    cx<T> r = t[c];
+#pragma unroll
+                    for (int l = 0; l < CM; ++l)
+                        if (l < c) r = r - cmul(M[c * Cd + l], f[l]);
+                    f[c] = cdivide(r, dl[c]);
+                }
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < Cd) {
+                    cx<T> r = t[c];
+#pragma unroll
+                    for (int l = 0; l < CM; ++l)
+                        if (l < Cd) r = r - cmul(M[c * Cd + l], f[l]);
+                    dx[c] = r;                                   // (D x)_c
+                    if (a.want_obj && lane == 0) acc[0] += pw * (double)cabs2(r - sc[c]);
+                }
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) {
+                    cx<T> x = be[j];
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < Cd) x = x - cmul(g[c][j], f[c]);
+                    a.xf[sys * K + k] = x;
+                    if (a.want_xrrs) {
+                        cx<T> ax = cscale(x, rho);
+#pragma unroll
+                        for (int c = 0; c < CM; ++c)
+                            if (c < Cd) ax = ax + cmulc(d[c][j], dx[c]);
+                        const cx<T> b = cscale(be[j], rho);
+                        acc[1] += (double)cabs2(ax - b);
+                        acc[2] += (double)cabs2(ax);
+                        acc[3] += (double)cabs2(b);
+                    }
+                }
+            }
+        }
+    }
+    block_sum_store<4>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * 4);
+}
+
+template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
+    if (K <= 64) f(std::integral_constant<int, 1>{});
+    else if (K <= 128) f(std::integral_constant<int, 2>{});
+    else if (K <= 256) f(std::integral_constant<int, 4>{});
+    else throw Error(-1, "multi-channel dictionaries are handled for K <= 256 filters");
+}
+
+template <typename T>
+void launch_ism_setup(hipStream_t st, const cx<T> *df, cx<T> *gam, cx<T> *del, cx<T> *mm,
+                      int64_t npix, int Cd, int K, T rho) {
+    if (Cd > 8) throw Error(-1, "multi-channel dictionaries are handled for up to 8 channels");
+    const int grid = grid_for(npix * kWave);
+    ism_dispatch_kr<T>(K, [&](auto kr) {
+        constexpr int KR = decltype(kr)::value;
+        hipLaunchKernelGGL((ism_setup_kernel<T, KR>), dim3(grid), dim3(kThreads), 0, st, df, gam,
+                           del, mm, npix, Cd, K, rho);
+    });
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
+                     const cx<T> *sf, const cx<T> *gam, const cx<T> *del, const cx<T> *mm, T rho,
+                     int64_t npix, int Cd, int N, int K, int W, bool want_obj, bool want_xrrs,
+                     double *partials) {
+    IsmArgs<T> a;
+    a.yuf = yuf;
+    a.xf = xf;
+    a.df = df;
+    a.sf = sf;
+    a.gam = gam;
+    a.del = del;
+    a.mm = mm;
+    a.rho = rho;
+    a.npix = npix;
+    a.Cd = Cd;
+    a.N = N;
+    a.K = K;
+    a.W = W;
+    a.want_obj = want_obj;
+    a.want_xrrs = want_xrrs;
+    a.partials = partials;
+    const int grid = (int)std::min<int64_t>(npix, kMaxPartialBlocks);
+    const size_t lds = sizeof(double) * 4 * (kThreads / kWave);
+    ism_dispatch_kr<T>(K, [&](auto kr) {
+        constexpr int KR = decltype(kr)::value;
+        switch (Cd) {
+        case 2: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 2>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        case 3: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 3>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 4>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        default: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 0>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        }
+    });
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]: linalg.inner over the filter axis for a
+// multi-channel dictionary (the Cd = 1 case is launch_inner)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mc_inner_kernel(const cx<T> *__restrict__ df,
+                                                            const cx<T> *__restrict__ v,
+                                                            cx<T> *__restrict__ out, int64_t npix,
+                                                            int Cd, int N, int K) {
+    const int64_t total = npix * Cd * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const int c = (int)((i / N) % Cd);
+        const int64_t pix = i / ((int64_t)N * Cd);
+        const cx<T> *d = df + (pix * Cd + c) * K;
+        const cx<T> *x = v + (pix * N + n) * K;
+        cx<T> q = mk<T>(T(0), T(0));
+        for (int k = 0; k < K; ++k) q = q + cmul(d[k], x[k]);
+        out[i] = q;
+    }
+}
+
+template <typename T>
+void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
+                     int Cd, int N, int K) {
+    hipLaunchKernelGGL((mc_inner_kernel<T>), dim3(grid_for(npix * Cd * N)), dim3(kThreads), 0, st,
+                       df, v, out, npix, Cd, N, K);
+    SA_HIP(hipGetLastError());
+}
+
+// max |conj(df[pix, c, k]) sf[pix, c, n]| (cbpdn.py:573-578 without the channel sum)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mc_dhs_absmax_kernel(const cx<T> *__restrict__ df,
+                                                                 const cx<T> *__restrict__ sf,
+                                                                 int64_t npix, int Cd, int N,
+                                                                 int K, double *partials) {
+    double m = 0.0;
+    const int64_t total = npix * Cd * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pc = i / N;   // (pix, c)
+        const double s2 = (double)cabs2(sf[i]);
+        for (int k = 0; k < K; ++k) {
+            const double v = (double)cabs2(df[pc * K + k]) * s2;
+            m = v > m ? v : m;
+        }
+    }
+    double *scratch = dyn_lds<double>();
+    for (int s = kWave / 2; s > 0; s >>= 1) {
+        const double o = __shfl_xor(m, s, kWave);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) scratch[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int j = 0; j < (int)(blockDim.x / kWave); ++j) r = scratch[j] > r ? scratch[j] : r;
+        partials[blockIdx.x] = r;
+    }
+}
+
+template <typename T>
+int launch_mc_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int Cd,
+                         int N, int K, double *partials) {
+    const int grid = grid_for(npix * Cd * N);
+    hipLaunchKernelGGL((mc_dhs_absmax_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, df, sf, npix, Cd, N, K, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict__ v,
                                                              T *__restrict__ stats, int H, int W,
@@ -1431,7 +1760,16 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool); \
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
                                      int, double *, int);                                               \
-    template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);
+    template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);                        \
+    template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
+                                      int64_t, int, int, T);                                       \
+    template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \
+                                     const cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *,   \
+                                     T, int64_t, int, int, int, int, bool, bool, double *);        \
+    template void launch_mc_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,  \
+                                     int, int, int);                                               \
+    template int launch_mc_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,  \
+                                         int, int, double *);
 SA_INST(float)
 SA_INST(double)
 

@@ -183,6 +183,54 @@ def test_ams_traces(name):
                   g['recon']) < tol
 
 
+MCDICT_CASES = {
+    'admm_mcdict_f64': dict(maxiter=25),
+    'admm_mcdict_f32': dict(maxiter=25, dtype=np.float32),
+    'admm_mcdict_single_nonneg_f64': dict(maxiter=20, nonneg=True, gevaly=True, fevalx=False,
+                                          rho=2.0, auto_rho=False),
+}
+
+
+def mcdict_inputs(g):
+    """Internal layout for a multi-channel dictionary (cnvrep.py:186-194): D
+    (dH, dW, C, 1, K), S (H, W, C, N, 1), coefficient maps (H, W, 1, N, K)."""
+    D, S = g['D'], g['S']
+    D5 = D.reshape(D.shape[0], D.shape[1], D.shape[2], 1, D.shape[3])
+    N = S.shape[3] if S.ndim == 4 else 1
+    return D5, S.reshape(S.shape[0], S.shape[1], S.shape[2], N, 1)
+
+
+def test_solvemdbi_ism():
+    g = load_golden('solvemdbi_ism')
+    x = orc.solvemdbi_ism(g['ah'], float(g['rho']), g['b'], 4, 2)
+    assert rel_l2(x, g['x']) < 1e-13
+    # it solves the system it claims to solve
+    a = np.conj(g['ah'])
+    ax = float(g['rho']) * x + np.sum(a * orc.inner(g['ah'], x, axis=4), axis=2, keepdims=True)
+    assert rel_l2(ax, g['b']) < 1e-12
+
+
+@pytest.mark.parametrize('name', sorted(MCDICT_CASES))
+def test_mcdict_traces(name):
+    g = load_golden(name)
+    kw = dict(MCDICT_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    # (float32: two float32 evaluations of 25 adaptive-rho iterations of the C-term
+    # iterated solve; observed 2.0e-4)
+    tol = 1e-9 if dtype == np.float64 else 5e-4
+    D5, S5 = mcdict_inputs(g)
+    r = orc.admm_cbpdn(D5, S5, float(g['lmbda']), dtype=dtype, **kw)
+    assert r['iters'] == int(g['k_final'])
+    for key in ('Y', 'U', 'X', 'Xf'):
+        assert r[key].shape == g[key].shape
+        assert rel_l2(r[key], g[key]) < tol, key
+    for key in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal',
+                'EpsDual', 'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    assert rel_l2(orc.reconstruct(r['Df'], r['Y'], S5.shape[:2]).squeeze(),
+                  g['recon'].squeeze()) < tol
+
+
 def test_admm_known_answer():
     g = load_golden('admm_known_answer_f64')
     D5, S5 = to5d(g['D'], g['S'])
