@@ -82,8 +82,10 @@ typedef struct {
 #define SPORCO_AMD_VAR_T1 14   /* cplx  (BB step size: previous x / gradient;           */
 #define SPORCO_AMD_VAR_T2 15   /* cplx   robust backtracking: Z; monotone FISTA: ZZ)    */
 #define SPORCO_AMD_VAR_ZF 16   /* cplx  (H,Wf,C,N,K) rfftn of the coefficient maps (D-step)   */
-/* Dictionary-sized state of the D-step (pgm.ccmod.ConvCnstrMOD): real (H,W,K) /
- * complex (H,Wf,K).  Ids 17..31 are reserved. */
+#define SPORCO_AMD_VAR_CX 17   /* real  (H,W,C,N,K) consensus D-step: dictionary copy per image */
+#define SPORCO_AMD_VAR_CU 18   /* real  (H,W,C,N,K) consensus D-step: scaled dual per image     */
+/* Dictionary-sized state of the D-step (pgm.ccmod.ConvCnstrMOD, admm.ccmod consensus Y =
+ * DX): real (H,W,K) / complex (H,Wf,K).  Ids 19..31 are reserved. */
 #define SPORCO_AMD_VAR_DX 32      /* real  dictionary iterate X (zero-padded filters)    */
 #define SPORCO_AMD_VAR_DXF 33     /* cplx  rfftn(DX)                                     */
 #define SPORCO_AMD_VAR_DYF 34     /* cplx  auxiliary (momentum) state                    */
@@ -209,6 +211,7 @@ typedef struct {
 #define SPORCO_AMD_OUT_XRRS_B2 10
 #define SPORCO_AMD_OUT_RGR 11    /* Parseval sum of GradWeight GHGf |Xf|^2 / (H W)  (twice RegGrad,
                                   * cbpdn.py:1204-1214; FLAG_GRADREG only)         */
+#define SPORCO_AMD_OUT_CNSTR 12  /* sum (Pcn(Y) - Y)^2 of the consensus D-step (ccmod.py:888-894) */
 #define SPORCO_AMD_OUT_COUNT 16
 
 /* One full ADMM iteration on device: xstep (cbpdn.py:267-281: rfftn(Y-U),
@@ -330,6 +333,31 @@ int sporco_amd_csc_ccmod_getdict(sporco_amd_csc_t h, int32_t dH, int32_t dW, voi
 int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW);
 /* out[0] = sum |v| over the real state `var` (RegL1 of DictLearn.evaluate,
  * dictlrn/cbpdndl.py:519). */
+/* ---- ADMM consensus dictionary update (admm.ccmod.ConvCnstrMOD_Consensus, -----------
+ * sporco/admm/ccmod.py:605-908 on admm.ADMMConsensus, sporco/admm/admm.py:1441-1707) ----
+ * One dictionary copy X_n and dual U_n per image (VAR_CX, VAR_CU), consensus variable
+ * Y = VAR_DX (its spectrum VAR_DXF is kept current, so sporco_amd_csc_ccmod_getdict and
+ * sporco_amd_csc_setdict_from_dstep serve this D-step too).  Coefficient maps come from
+ * sporco_amd_csc_ccmod_setcoef.  Single-channel dictionaries. */
+/* Y = Y0 (real (H,W,K), zero-padded filters) or 0; U_n = Y0 / rho or 0 (uinit, ccmod.py:734-742). */
+int sporco_amd_csc_cns_init(sporco_amd_csc_t h, const void *Y0, double rho);
+typedef struct {
+    double rho;      /* penalty parameter                                               */
+    double rlx;      /* RelaxParam                                                      */
+    double u_scale;  /* pending U /= rsf, as in sporco_amd_admm_params                  */
+    uint32_t flags;  /* SPORCO_AMD_FLAG_RESID | SPORCO_AMD_FLAG_OBJ                     */
+    int32_t dH, dW;  /* filter support of the constraint set                            */
+    int32_t zero_mean;
+} sporco_amd_cns_params;
+/* One iteration: xstep per image by Sherman-Morrison (ccmod.py:766-778), relax_AX
+ * (admm.py:1608-1616), ystep Y = Pcn(mean_n(AX_n + U_n)) (admm.py:1585-1591, ccmod.py:832-835),
+ * ustep.  out: R2 = sum_n |X_n - Y|^2, S2 = |Y - Yprev|^2, AX2 = sum_n |X_n|^2, Y2 = |Y|^2,
+ * U2 = sum_n |U_n|^2 (the host applies the sqrt(Nb) and rho factors of admm.py:1673-1707),
+ * DFID = Parseval sum of |sum_m Zf Yf - Sf|^2 / (H W) and CNSTR, both evaluated at Y
+ * (fEvalX False, gEvalY True: the class defaults, ccmod.py:853-894). */
+int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
+                            double out[SPORCO_AMD_OUT_COUNT]);
+
 int sporco_amd_csc_asum(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
 
 /* ---- per-kernel timing (HIP events on the handle's stream) ---------------- */

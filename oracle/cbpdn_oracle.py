@@ -511,3 +511,99 @@ def pcn(x, dsz, Nv, dimN=2, dimC=1, crp=False, zm=False):
     if not crp:
         v = zpad(v, Nv)
     return normalise(v, dimN + dimC)
+
+
+# ---------------------------------------------------------------------------
+# ADMM consensus dictionary update (sporco/admm/ccmod.py:605-908 on the
+# ADMMConsensus base, sporco/admm/admm.py:1441-1707)
+# ---------------------------------------------------------------------------
+
+def admm_ccmod_cns(Z, S, dsz, dtype=np.float64, maxiter=20, rho=None, rlx=1.8,
+                   auto_rho=False, rho_period=10, rho_tau=2.0, rho_mu=10.0,
+                   rho_xi=1.0, auto_scaling=False, zero_mean=False, Y0=None,
+                   abs_tol=0.0, rel_tol=1e-3):
+    """ConvCnstrMOD_Consensus for a single-channel dictionary.
+
+    ``Z``: (H, W, 1, Nb, M) coefficient maps, ``S``: (H, W, 1, Nb, 1), ``dsz`` =
+    (dH, dW, M).  One dictionary copy X_i per image (the blocks of the consensus
+    problem, stacked on a new last axis), consensus variable Y (H, W, 1, 1, M):
+
+      xstep  (ccmod.py:766-778): X_i = irfftn(solvedbi_sm(Zf_i, rho,
+             conj(Zf_i) Sf_i + rho rfftn(Y - U_i)))
+      relax  (admm.py:1608-1616), ystep (admm.py:1585-1591 with prox_g = Pcn,
+             ccmod.py:832-835), ustep (admm.py:434-437 with rsdl_r :1673-1676)
+      residuals (admm.py:1673-1707), objective at Y (fEvalX False, gEvalY True:
+             ccmod.py:853-894), update_rho (admm.py:549-575).
+    The default rho is 1.0: the constructor's ``dval=cri.K`` (ccmod.py:700) comes
+    after the base class has already set the attribute.
+    """
+    dtype = np.dtype(dtype)
+    rdt = real_dtype(dtype).type
+    Z = np.asarray(Z, dtype=dtype)
+    S = np.asarray(S, dtype=dtype)
+    H, W = S.shape[0], S.shape[1]
+    Nb, M = Z.shape[AX_N], Z.shape[AX_K]
+    rho = rdt(1.0 if rho is None else rho)
+    rlx = rdt(rlx)
+    Sf = rfftn2(S)
+    Zf = rfftn2(Z)
+    ZSf = np.conj(Zf) * Sf
+    P = lambda v: pcn(v, dsz, (H, W), 2, 1, crp=False, zm=zero_mean)
+    yshape = (H, W, 1, 1, M)
+    if Y0 is None:
+        Y = np.zeros(yshape, dtype=dtype)
+        U = np.zeros(yshape + (Nb,), dtype=dtype)
+    else:
+        Y = np.asarray(Y0).astype(dtype, copy=True)
+        U = (np.repeat(Y[..., np.newaxis], Nb, axis=-1) / rho).astype(dtype)
+    Nx = Nb * int(np.prod(yshape))
+    tr = {k: [] for k in ('DFid', 'Cnstr', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal',
+                          'EpsDual', 'Rho')}
+    X = None
+    for k in range(maxiter):
+        Yprev = Y.copy()
+        YU = Y[..., np.newaxis] - U
+        b = np.swapaxes(ZSf[..., np.newaxis], AX_N, -1) + rho * rfftn2(YU)
+        Xf = np.empty_like(b)
+        for i in range(Nb):
+            Xf[..., i] = solvedbi_sm(Zf[..., [i], :], rho, b[..., i], None, AX_K)
+        X = irfftn2(Xf, (H, W))
+        AX = X if rlx == 1.0 else rlx * X + (1 - rlx) * Y[..., np.newaxis]
+        Y = P(np.mean(AX + U, axis=-1)).astype(dtype)
+        U = U + (AX - Y[..., np.newaxis])
+        nr = np.linalg.norm(X - Y[..., np.newaxis])
+        ns = np.linalg.norm(np.sqrt(Nb) * rho * (Yprev - Y))
+        rn = max(np.linalg.norm(X), np.sqrt(Nb) * np.linalg.norm(Y))
+        sn = rho * np.linalg.norm(U)
+        rn = 1.0 if rn == 0.0 else rn
+        sn = 1.0 if sn == 0.0 else sn
+        r, s = nr / rn, ns / sn
+        epri = np.sqrt(Nx) * abs_tol / rn + rel_tol
+        edua = np.sqrt(Nx) * abs_tol / sn + rel_tol
+        Ef = inner(Zf, rfftn2(Y), axis=AX_K) - Sf
+        dfd = rfl2norm2(Ef, S.shape) / 2.0
+        cns = np.linalg.norm(P(Y) - Y)
+        for key, val in (('DFid', dfd), ('Cnstr', cns), ('PrimalRsdl', r), ('DualRsdl', s),
+                         ('EpsPrimal', epri), ('EpsDual', edua), ('Rho', rho)):
+            tr[key].append(float(val))
+        if auto_rho and k != 0 and (k + 1) % rho_period == 0:
+            if auto_scaling:
+                if s == 0.0 or r == 0.0:
+                    rhomlt = rho_tau
+                else:
+                    rhomlt = min(np.sqrt(r / (s * rho_xi) if r > s * rho_xi
+                                         else (s * rho_xi) / r), rho_tau)
+            else:
+                rhomlt = rho_tau
+            rsf = 1.0
+            if r > rho_xi * rho_mu * s:
+                rsf = rhomlt
+            elif s > (rho_mu / rho_xi) * r:
+                rsf = 1.0 / rhomlt
+            rho = rho * rdt(rsf)
+            U = U / rsf
+        if r < epri and s < edua:
+            break
+    out = {key: np.array(val) for key, val in tr.items()}
+    out.update(X=X, Y=Y, U=U, rho=rho, iters=k + 1, D=bcrop(Y, dsz))
+    return out

@@ -37,6 +37,7 @@ from sporco.pgm.momentum import MomentumLinear, MomentumGenLinear    # noqa: E40
 from sporco.pgm.stepsize import StepSizePolicyBB, StepSizePolicyCauchy  # noqa: E402
 from sporco.dictlrn import cbpdndl as ref_cbpdndl     # noqa: E402
 from sporco.pgm import ccmod as ref_pgm_ccmod         # noqa: E402
+from sporco.admm import ccmod as ref_admm_ccmod       # noqa: E402
 from sporco import linalg as ref_linalg               # noqa: E402
 from sporco import prox as ref_prox                   # noqa: E402
 from sporco import fft as ref_fft                     # noqa: E402
@@ -397,6 +398,46 @@ def gen_mcdict():
     save('solvemdbi_ism', ah=ah, b=b, rho=np.float64(1.7), x=x)
 
 
+def gen_cns():
+    """ADMM consensus dictionary update ConvCnstrMOD_Consensus (sporco/admm/ccmod.py:605-908,
+    sporco/admm/admm.py:1441-1707) alone and inside ConvBPDNDictLearn(dmethod='cns').
+    SURVEY.md 8(f) rank 3."""
+    np.random.seed(13579)
+    N, M, Nd, K = 16, 4, 5, 3
+    S = np.random.randn(N, N, K)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    for name, optd in (
+            ('ccmod_cns_f64', {'MaxMainIter': 20}),
+            ('ccmod_cns_f32', {'MaxMainIter': 20, 'DataType': np.float32}),
+            ('ccmod_cns_autorho_zm_f64',
+             {'MaxMainIter': 25, 'ZeroMean': True, 'LinSolveCheck': True, 'rho': 2.0,
+              'RelaxParam': 1.5,
+              'AutoRho': {'Enabled': True, 'Period': 2, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+                          'AutoScaling': True, 'RsdlTarget': 1.0}})):
+        opt = ref_admm_ccmod.ConvCnstrMOD_Consensus.Options(optd)
+        c = ref_admm_ccmod.ConvCnstrMOD_Consensus(Z, S, (Nd, Nd, M), opt)
+        c.solve()
+        save(name, Z=Z, S=S, dsz=np.array((Nd, Nd, M)), D=c.getdict(), Y=c.Y, X=c.X, U=c.U,
+             rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+    # warm start from a dictionary (the Y0 path used by dictionary learning, uinit :734-742)
+    D0 = np.random.randn(Nd, Nd, M)
+    Y0 = ref_cnvrep.zpad(ref_cnvrep.stdformD(
+        ref_cnvrep.Pcn(D0, (Nd, Nd, M), (N, N), 2, 0, crp=True), 1, M, 2), (N, N))
+    opt = ref_admm_ccmod.ConvCnstrMOD_Consensus.Options({'MaxMainIter': 10, 'Y0': Y0})
+    c = ref_admm_ccmod.ConvCnstrMOD_Consensus(Z, S, (Nd, Nd, M), opt)
+    c.solve()
+    save('ccmod_cns_y0_f64', Z=Z, S=S, dsz=np.array((Nd, Nd, M)), Y0=Y0, D=c.getdict(),
+         Y=c.Y, U=c.U, **itstat_dict(c))
+    # dictionary learning with the consensus D-step
+    for name, dt in (('cbpdndl_cns_f64', np.float64), ('cbpdndl_cns_f32', np.float32)):
+        opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+            {'MaxMainIter': 10, 'AccurateDFid': True}, xmethod='admm', dmethod='cns')
+        b = ref_cbpdndl.ConvBPDNDictLearn(D0.astype(dt), S.astype(dt), 0.1, opt,
+                                          xmethod='admm', dmethod='cns')
+        D1 = b.solve()
+        save(name, D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(), **itstat_dict(b))
+
+
 def gen_ams():
     """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
     ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
@@ -422,8 +463,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -15,6 +15,7 @@ F32, F64 = 0, 1
 VAR_Y, VAR_U, VAR_X, VAR_XF, VAR_DF, VAR_SF = 0, 1, 2, 3, 4, 5
 VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_AX, VAR_YPREV = 6, 7, 8, 9, 10, 11, 12
 VAR_T0, VAR_T1, VAR_T2, VAR_ZF = 13, 14, 15, 16
+VAR_CX, VAR_CU = 17, 18
 VAR_DX, VAR_DXF, VAR_DYF, VAR_DXFPRV, VAR_DYFPRV = 32, 33, 34, 35, 36
 VAR_DVF, VAR_DGF, VAR_DT0, VAR_DT1, VAR_DT2 = 37, 38, 39, 40, 41
 
@@ -36,6 +37,7 @@ OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
 OUT_XRRS_D2, OUT_XRRS_AX2, OUT_XRRS_B2 = 8, 9, 10
 OUT_RGR = 11
+OUT_CNSTR = 12
 OUT_COUNT = 16
 
 PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY = range(6)
@@ -60,6 +62,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
+    'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
     'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_sl1l2',
@@ -80,6 +83,12 @@ class PgmParams(ctypes.Structure):
     _fields_ = [('L', ctypes.c_double), ('lmbda', ctypes.c_double), ('beta', ctypes.c_double),
                 ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32), ('dW', ctypes.c_int32),
                 ('want_stats', ctypes.c_int32)]
+
+
+class CnsParams(ctypes.Structure):
+    _fields_ = [('rho', ctypes.c_double), ('rlx', ctypes.c_double), ('u_scale', ctypes.c_double),
+                ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32), ('dW', ctypes.c_int32),
+                ('zero_mean', ctypes.c_int32)]
 
 
 class AdmmParams(ctypes.Structure):
@@ -200,6 +209,8 @@ def load(path=None):
         'sporco_amd_csc_ccmod_prox_step': [vp, dbl, i32, i32, i32],
         'sporco_amd_csc_ccmod_cnstr': [vp, i32, i32, i32, dptr],
         'sporco_amd_csc_ccmod_getdict': [vp, i32, i32, vp],
+        'sporco_amd_csc_cns_init': [vp, vp, dbl],
+        'sporco_amd_csc_cns_iter': [vp, ctypes.POINTER(CnsParams), dptr],
         'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
         'sporco_amd_csc_asum': [vp, ctypes.c_int, dptr],
         'sporco_amd_csc_profile': [vp, ctypes.c_int],
@@ -471,6 +482,23 @@ class Solver(object):
                       1 if want_stats else 0)
         out = self._out()
         check(self._lib.sporco_amd_csc_pgm_iter(self._h, ctypes.byref(p), out))
+        return list(out)
+
+    def cns_init(self, Y0, rho):
+        """Consensus D-step state: Y = Y0 (H, W, 1, 1, K) or zero, U_n = Y0 / rho or zero."""
+        if Y0 is None:
+            check(self._lib.sporco_amd_csc_cns_init(self._h, None, float(rho)))
+            return
+        H, W, C, N, K = self.dims
+        Y0 = _carr(Y0, self.dtype).reshape(H, W, K)
+        check(self._lib.sporco_amd_csc_cns_init(self._h, _ptr(Y0), float(rho)))
+
+    def cns_iter(self, rho, rlx, u_scale, flags, dH, dW, zero_mean):
+        """One consensus D-step iteration (sporco_amd_csc_cns_iter)."""
+        p = CnsParams(float(rho), float(rlx), float(u_scale), int(flags), int(dH), int(dW),
+                      1 if zero_mean else 0)
+        out = self._out()
+        check(self._lib.sporco_amd_csc_cns_iter(self._h, ctypes.byref(p), out))
         return list(out)
 
     def pgm_eval(self, var):

@@ -1,0 +1,265 @@
+"""ADMM dictionary update on the GPU: the consensus form of convolutional constrained MOD.
+
+Drop-in for ``sporco.admm.ccmod.ConvCnstrMOD_Consensus`` (sporco/admm/ccmod.py:605-908, on
+``admm.ADMMConsensus``, sporco/admm/admm.py:1441-1707): same constructor, Options tree,
+IterationStats fields and methods (``setcoef / getdict / solve / getitstat``).  The other two
+ADMM dictionary updates of the reference (``ConvCnstrMOD_IterSM``, ``ConvCnstrMOD_CG``) are
+not part of the hot path and raise ``NotImplementedError`` through :func:`ConvCnstrMOD`.
+
+Each image keeps its own copy X_n of the (zero-padded) dictionary and a dual U_n, both
+resident on the device; the consensus variable Y is the dictionary.  One iteration is one call
+into the C ABI (``sporco_amd_csc_cns_iter``): the per-image X-step is the Sherman-Morrison
+solve of the sparse coding path with the roles of dictionary and coefficients swapped
+(ccmod.py:766-778), followed by the mean over images + constraint projection and the dual
+update; the host forms residuals, tolerances and the rho schedule from the returned sums.
+"""
+
+import copy
+
+import numpy as np
+
+from . import admm
+from .. import _lib
+from .. import cnvrep as cr
+from ..fft import real_dtype
+
+__all__ = ['ConvCnstrMOD_Consensus', 'ConvCnstrMOD', 'ConvCnstrMODOptions']
+
+
+class ConvCnstrMOD_Consensus(admm.ADMM):
+    r"""Minimise (1/2) sum_k ||sum_m d_m * x_{k,m} - s_k||_2^2 over filters d_m of unit norm
+    and constrained support, as an ADMM consensus problem over the images.
+
+    IterationStats fields: ``Iter, DFid, Cnstr, PrimalRsdl, DualRsdl, EpsPrimal, EpsDual,
+    Rho, XSlvRelRes, Time``.
+    """
+
+    class Options(admm.ADMM.Options):
+        """Options of sporco/admm/ccmod.py:623-648: those of ConvCnstrMODBase
+        (``AuxVarObj, fEvalX, gEvalY, ReturnX, ZeroMean, LinSolveCheck``; :129-136) overlaid with
+        the ADMMConsensus defaults (admm.py:1495-1497), i.e. the objective is evaluated at the
+        consensus variable and AutoRho is off unless enabled; ``RelaxParam`` 1.8."""
+
+        defaults = copy.deepcopy(admm.ADMM.Options.defaults)
+        defaults.update({'AuxVarObj': True, 'fEvalX': False, 'gEvalY': True, 'ReturnX': False,
+                         'ZeroMean': False, 'LinSolveCheck': False, 'RelaxParam': 1.8})
+
+        def __init__(self, opt=None):
+            admm.ADMM.Options.__init__(self, {} if opt is None else opt)
+            if self['AutoRho', 'RsdlTarget'] is None:
+                self['AutoRho', 'RsdlTarget'] = 1.0
+
+        def __setitem__(self, key, value):
+            admm.ADMM.Options.__setitem__(self, key, value)
+            if key == 'AuxVarObj':
+                self['fEvalX'] = value is not True
+                self['gEvalY'] = value is True
+
+    itstat_fields_objfn = ('DFid', 'Cnstr')
+    itstat_fields_extra = ('XSlvRelRes',)
+    hdrtxt_objfn = ('DFid', 'Cnstr')
+    hdrval_objfun = {'DFid': 'DFid', 'Cnstr': 'Cnstr'}
+
+    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
+        """``Z, S, dsz, opt, dimK, dimN`` as in the reference (ccmod.py:653-712).  Backend
+        keyword ``dev``: a :class:`sporco_amd._lib.Solver` to share with the sparse coding
+        step, so that coefficient maps and dictionary stay on the GPU."""
+        if opt is None:
+            opt = ConvCnstrMOD_Consensus.Options()
+        if dimN != 2:
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        if self.cri.Cd > 1:
+            raise NotImplementedError("multi-channel dictionaries are not part of the "
+                                      "sporco_amd dictionary update")
+        if not opt['gEvalY'] or opt['fEvalX']:
+            raise NotImplementedError("the consensus D-step evaluates its objective at the "
+                                      "consensus variable (AuxVarObj True, the class default)")
+        if opt['LinSolveCheck']:
+            raise NotImplementedError("LinSolveCheck is not offered by the device consensus "
+                                      "D-step")
+        self.set_dtype(opt, S.dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
+        H, W = self.cri.Nv
+        # one consensus block per (channel, image): channels fold into the image axis for a
+        # single-channel dictionary (ccmod.py:695-699, :702-706)
+        self.Nb = self.cri.C * self.cri.K
+        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
+        self._shared = dev is not None
+        if dev is None:
+            self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                                   device=device, stream=stream)
+            self.dev.set_signal(self.S)
+        else:
+            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
+                raise ValueError("shared device solver has different dimensions")
+            self.dev = dev
+        self._cache = {}
+        self._u_scale = 1.0
+        self._sums = [0.0] * _lib.OUT_COUNT
+        self.yshape = self.cri.shpD
+        self.xshape = self.cri.shpD + (self.Nb,)
+        Nx = self.Nb * int(np.prod(self.yshape))
+        super(ConvCnstrMOD_Consensus, self).__init__(Nx, self.yshape, self.xshape, S.dtype, opt)
+        # (the reference's `dval=cri.K` at ccmod.py:700 never takes effect: the base class has
+        # already set rho, default 1.0)
+        self.xrrs = None
+        if Z is not None:
+            self.setcoef(Z)
+
+    # -- state ---------------------------------------------------------------------------
+    def init_state(self, yshape, ushape):
+        """Y = Y0 or zeros, U_n = Y0 / rho or zeros (admm.py:262-272 with uinit of
+        ccmod.py:734-742), on the device."""
+        self.dev.cns_init(self.opt['Y0'], float(self.rho))
+        if self.opt['U0'] is not None:
+            self.U = self.opt['U0']
+
+    def _from_blocks(self, a):
+        """Device layout (H, W, 1, Nb, M) -> the reference's (H, W, 1, 1, M, Nb)."""
+        return np.ascontiguousarray(np.moveaxis(a, 3, -1)[:, :, :, np.newaxis])
+
+    def _to_blocks(self, a):
+        return np.ascontiguousarray(np.moveaxis(np.asarray(a)[:, :, :, 0], -1, 3))
+
+    @property
+    def Y(self):
+        if _lib.VAR_DX not in self._cache:
+            self._cache[_lib.VAR_DX] = self.dev.download(_lib.VAR_DX)
+        return self._cache[_lib.VAR_DX]
+
+    @Y.setter
+    def Y(self, value):
+        if value is None:
+            return
+        self.dev.upload(_lib.VAR_DX, np.asarray(value, dtype=self.dtype))
+        self.dev.fft_var(_lib.VAR_DX, _lib.VAR_DXF)
+        self._cache.pop(_lib.VAR_DX, None)
+
+    @property
+    def X(self):
+        return self._from_blocks(self.dev.download(_lib.VAR_CX))
+
+    @X.setter
+    def X(self, value):
+        if value is not None:
+            self.dev.upload(_lib.VAR_CX, self._to_blocks(np.asarray(value, dtype=self.dtype)))
+
+    @property
+    def U(self):
+        u = self._from_blocks(self.dev.download(_lib.VAR_CU))
+        return u * u.dtype.type(self._u_scale) if self._u_scale != 1.0 else u
+
+    @U.setter
+    def U(self, value):
+        if value is not None:
+            self.dev.upload(_lib.VAR_CU, self._to_blocks(np.asarray(value, dtype=self.dtype)))
+            self._u_scale = 1.0
+
+    def getmin(self):
+        return self.Y
+
+    def setcoef(self, Z):
+        """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:746-755)."""
+        self.Z = np.asarray(np.asarray(Z).reshape(self.cri.Nv + (1, self.Nb, self.cri.M)),
+                            dtype=self.dtype)
+        self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
+        self.dev.ccmod_setcoef(_lib.VAR_AX)
+
+    def setcoef_from_device(self, var=_lib.VAR_Y):
+        """Zf = rfftn(<real state of the shared solver>), no host round trip."""
+        self.dev.ccmod_setcoef(var)
+
+    def getdict(self, crop=True):
+        """The consensus variable, cropped to the filter support by default
+        (ccmod.py:839-848)."""
+        if crop:
+            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
+        return self.Y
+
+    # -- iteration --------------------------------------------------------------------------
+    def iteration(self):
+        flags = 0
+        if self._needs_residuals():
+            flags |= _lib.FLAG_RESID
+        if not self.opt['FastSolve']:
+            flags |= _lib.FLAG_OBJ
+        self._sums = self.dev.cns_iter(self.rho, self.rlx, self._u_scale, flags,
+                                       self.cri.dsz[0], self.cri.dsz[1], self.opt['ZeroMean'])
+        self._u_scale = 1.0
+        self._cache.clear()
+        if not self._needs_residuals():
+            return None
+        self.timer.stop('solve_wo_rsdl')
+        res = self.compute_residuals()
+        self.timer.start('solve_wo_rsdl')
+        return res
+
+    def finish_solve(self):
+        self.dev.sync()
+
+    def residual_norms(self):
+        """Consensus residuals and normalisations (admm.py:1673-1707)."""
+        s = self._sums
+        rho, nb = float(self.rho), float(self.Nb)
+        nr = np.sqrt(s[_lib.OUT_R2])
+        ns = np.sqrt(nb) * rho * np.sqrt(s[_lib.OUT_S2])
+        rn = max(np.sqrt(s[_lib.OUT_AX2]), np.sqrt(nb) * np.sqrt(s[_lib.OUT_Y2]))
+        sn = rho * np.sqrt(s[_lib.OUT_U2])
+        return nr, ns, rn, sn
+
+    def rescale_u(self, rsf):
+        self._u_scale = self._u_scale / float(rsf)
+
+    # -- objective ----------------------------------------------------------------------------
+    def eval_objfn(self):
+        return (self.obfn_dfd(), self.obfn_cns())
+
+    def obfn_dfd(self):
+        """(1/2) ||sum_m Zf Yf - Sf||^2 (ccmod.py:871-878 with fEvalX False)."""
+        return self._sums[_lib.OUT_DFID] / 2.0
+
+    def obfn_cns(self):
+        """||Pcn(Y) - Y||_2 (ccmod.py:882-889)."""
+        return np.sqrt(self._sums[_lib.OUT_CNSTR])
+
+    def itstat_extra(self):
+        return (self.xrrs,)
+
+    def reconstruct(self, D=None):
+        """irfftn(sum_m Zf * Df) (ccmod.py:897-907); host arithmetic, off the iteration path."""
+        Df = self.dev.download(_lib.VAR_DXF) if D is None else \
+            np.fft.rfftn(np.asarray(D), axes=(0, 1))
+        Zf = self.dev.download(_lib.VAR_ZF)
+        return np.fft.irfftn(np.sum(Zf * Df, axis=self.cri.axisM), self.cri.Nv,
+                             axes=(0, 1)).astype(self.dtype)
+
+    def profile(self, enable=True):
+        self.dev.profile(enable)
+
+    def profile_read(self):
+        return self.dev.profile_read()
+
+
+_METHODS = {'cns': ConvCnstrMOD_Consensus}
+
+
+def _lookup(method):
+    if method in _METHODS:
+        return _METHODS[method]
+    if method in ('ism', 'cg'):
+        raise NotImplementedError("ADMM dictionary update %r is not part of the sporco_amd hot "
+                                  "path; 'cns' (consensus) is" % method)
+    raise ValueError('Unknown ConvCnstrMOD solver method %s' % method)
+
+
+def ConvCnstrMODOptions(opt=None, method='cns'):
+    """Options object of the selected ADMM dictionary update (ccmod.py:953-990)."""
+    return _lookup(method).Options(opt)
+
+
+def ConvCnstrMOD(*args, **kwargs):
+    """Construct the ADMM dictionary update selected by ``method`` (ccmod.py:911-950)."""
+    method = kwargs.pop('method', 'cns')
+    return _lookup(method)(*args, **kwargs)

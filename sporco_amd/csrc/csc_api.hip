@@ -148,6 +148,8 @@ struct CscBase {
     virtual void ccmod_getdict(int dH, int dW, void *dst) = 0;
     virtual void setdict_from_dstep(int dH, int dW) = 0;
     virtual void asum(int var, double *out_dev) = 0;
+    virtual void cns_init(const void *Y0, double rho) = 0;
+    virtual void cns_iter(const sporco_amd_cns_params &p, double *out_dev) = 0;
     virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
     virtual void read_out(const double *out_dev, double *out_host) = 0;
     double *out_dev_default = nullptr;
@@ -188,7 +190,7 @@ static bool var_is_dict_sized(int var) {
 }
 
 static bool var_is_valid(int var) {
-    return (var >= 0 && var <= SPORCO_AMD_VAR_ZF) ||
+    return (var >= 0 && var <= SPORCO_AMD_VAR_CU) ||
            (var >= SPORCO_AMD_VAR_DX && var <= SPORCO_AMD_VAR_DT2);
 }
 
@@ -211,6 +213,11 @@ template <typename T> struct Csc : CscBase {
     // the coefficient maps one (C = 1); X-step by iterated Sherman-Morrison (ism_*).
     int Cd = 1, Cs, CNs;
     cx<T> *ism_gam = nullptr, *ism_del = nullptr, *ism_mm = nullptr;
+    // consensus D-step scratch: spectrum of the per-image copies, per-(pixel, image) gram of
+    // the coefficient spectra, mean / previous-Y buffers (dictionary sized)
+    cx<T> *cns_f = nullptr;
+    T *cns_m = nullptr, *cns_yold = nullptr;
+    bool cns_active = false;   // setcoef then keeps Zf in the natural layout this D-step reads
     bool ism_valid = false;
     double ism_rho = 0.0;
     int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
@@ -351,7 +358,8 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m,
+                        (void *)cns_yold,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -1388,7 +1396,7 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
-        if (rows_ok && fused) {
+        if (rows_ok && fused && !cns_active) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;
             ra.y = rv(var);
@@ -1545,6 +1553,110 @@ template <typename T> struct Csc : CscBase {
         dH_ = dH;
         dW_ = dW;
         have_dict = true;
+    }
+
+    // ---- ADMM consensus dictionary update -------------------------------------------------
+    void cns_init(const void *Y0, double rho) override {
+        require_single_channel_dict();
+        SA_REQUIRE(rho != 0.0, "rho must be nonzero");
+        cns_active = true;
+        T *Y = rv(SPORCO_AMD_VAR_DX), *U = rv(SPORCO_AMD_VAR_CU);
+        (void)rv(SPORCO_AMD_VAR_CX);
+        SA_HIP(hipMemsetAsync(U, 0, sizeof(T) * E, st));
+        if (Y0) {
+            host_copy(SPORCO_AMD_VAR_DX, const_cast<void *>(Y0), true);
+            // U_n = Y0 / rho for every image: 0 - (-1/rho) * Y through the Y - s U kernel
+            ProfScope ps(prof, PS_OTHER);
+            launch_cns_yu<T>(st, Y, U, U, T(0), (int64_t)H * W, CN, K);
+            launch_scale<T>(st, U, (T)(1.0 / rho), E);
+        } else {
+            SA_HIP(hipMemsetAsync(Y, 0, var_bytes(SPORCO_AMD_VAR_DX), st));
+        }
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        sync();
+    }
+
+    void cns_iter(const sporco_amd_cns_params &p, double *out_dev) override {
+        require_single_channel_dict();
+        if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        need_natural(SPORCO_AMD_VAR_ZF);
+        const int64_t npixr = (int64_t)H * W;
+        T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_CX), *U = rv(SPORCO_AMD_VAR_CU);
+        cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF);
+        if (!cns_f) {
+            SA_HIP(hipMalloc((void **)&cns_f, sizeof(cx<T>) * EF));
+            SA_HIP(hipMalloc((void **)&cns_m, sizeof(T) * npixr * K));
+            SA_HIP(hipMalloc((void **)&cns_yold, sizeof(T) * npixr * K));
+        }
+        // xstep (ccmod.py:766-778): X_n = irfftn(SM(Zf_n, rho, conj(Zf_n) Sf_n + rho rfftn(Y - U_n)));
+        // Y is broadcast over the images by the row transform itself
+        {
+            ProfScope ps(prof, PS_FFT_R2C);
+            fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, cns_f, H, P, (int64_t)W * P, P,
+                       (int64_t)Wf * P, P, 0, 0, K);
+        }
+        {
+            ProfScope ps(prof, PS_FFT_C2C_FWD);
+            fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * P, 0, (int64_t)Wf * P, 0,
+                       (int64_t)Wf * P, T(1));
+        }
+        {   // (the per-image gram sum_k |Zf|^2 is formed inside the kernel)
+            ProfScope ps(prof, PS_SM_SOLVE);
+            launch_sm_solve<T>(st, cns_f, cns_f, Zf, cv(SPORCO_AMD_VAR_SF), nullptr, (T)p.rho, npix,
+                               CN, K, W, false, false, part_a, nullptr, true);
+        }
+        inv2(cns_f, work_buf(), X, P);
+        // relax + ystep: Y = Pcn(mean_n(alpha X_n + (1 - alpha) Y + U_n))
+        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * K, hipMemcpyDeviceToDevice, st));
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, (T)p.u_scale, npixr, CN, K);
+        }
+        pcn_project(cns_m, Y, p.dH, p.dW, p.zero_mean != 0, nullptr);
+        // ustep + the X-sized sums
+        int nb;
+        {
+            ProfScope ps(prof, PS_ADMM_POST);
+            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, (T)p.u_scale, npixr, CN, K,
+                                     part_b);
+        }
+        {
+            const int slots[3] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_AX2, SPORCO_AMD_OUT_U2};
+            const double scales[3] = {1, 1, 1};
+            finalize(part_b, nb, 4, 3, slots, scales, out_dev);
+        }
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * K, part_a);
+        }
+        {
+            const int slots[2] = {SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_Y2};
+            const double scales[2] = {1, 1};
+            finalize(part_a, nb, 2, 2, slots, scales, out_dev);
+        }
+        // the consensus dictionary's spectrum (for the objective, getdict / setdict_from_dstep)
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        if (p.flags & F_OBJ) {
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nb = launch_ccmod_grad<T>(st, Zf, cv(SPORCO_AMD_VAR_DXF), cv(SPORCO_AMD_VAR_SF),
+                                          nullptr, npix, CN, K, W, part_a);
+            }
+            const int slots[1] = {SPORCO_AMD_OUT_DFID};
+            const double scales[1] = {1.0 / ((double)H * W)};
+            finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
+            int nbc;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_pcn_stats<T>(st, Y, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                nbc = launch_pcn_apply<T>(st, Y, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
+                                          Ku);
+            }
+            const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
+            const double cscales[1] = {1.0};
+            finalize(part_b, nbc, 1, 1, cslots, cscales, out_dev);
+        }
     }
 
     void asum(int var, double *out_dev) override {
@@ -1993,6 +2105,24 @@ int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->setdict_from_dstep(dH, dW);
+    SA_API_END
+}
+
+int sporco_amd_csc_cns_init(sporco_amd_csc_t h, const void *Y0, double rho) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->cns_init(Y0, rho);
+    SA_API_END
+}
+
+int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
+                            double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out, "null argument");
+    double *dev = stats_buf(h);
+    h->impl->cns_iter(*p, dev);
+    h->impl->read_out(dev, out);
     SA_API_END
 }
 

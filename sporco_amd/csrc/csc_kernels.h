@@ -66,7 +66,9 @@ template <typename T>
 int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                     const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
                     bool want_obj, bool want_xrrs, double *partials,
-                    const GradTerm<T> *grad = nullptr);
+                    const GradTerm<T> *grad = nullptr, bool per_grp = false);
+// (per_grp: df is (npix, CN, K) and gram (npix, CN) -- one rank-one term per (pixel, cn), the
+// consensus dictionary update's per-image systems, admm/ccmod.py:766-778)
 // partial[block] = Parseval-weighted sum of wg GHGf |vf|^2 (RegGrad at an arbitrary spectrum)
 template <typename T>
 int launch_grad_norm(hipStream_t st, const cx<T> *vf, const GradTerm<T> &g, int64_t npix, int CN,
@@ -175,6 +177,20 @@ template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, dou
 template <typename T>
 int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int CN,
                       int K, double *partials);
+
+// ADMM consensus dictionary update (admm/ccmod.py:605-908, admm/admm.py:1441-1707): per-image
+// dictionary copies x, duals u (npixr, CN, K) with npixr = H * W, consensus y (npixr, K).
+template <typename T>   // out = y - s u
+void launch_cns_yu(hipStream_t st, const T *y, const T *u, T *out, T s, int64_t npixr, int CN,
+                   int K);
+template <typename T>   // m = mean_n(a x + (1 - a) y + s u)
+void launch_cns_mean(hipStream_t st, const T *x, const T *u, const T *y, T *m, T a, T s,
+                     int64_t npixr, int CN, int K);
+template <typename T>   // u = s u + a x + (1 - a) yold - ynew; partials (4): |x - ynew|^2, |x|^2, |u|^2
+int launch_cns_ustep(hipStream_t st, const T *x, T *u, const T *yold, const T *ynew, T a, T s,
+                     int64_t npixr, int CN, int K, double *partials);
+template <typename T>   // partials (2): |ynew - yold|^2, |ynew|^2
+int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, double *partials);
 
 // Multi-channel dictionary (Cd > 1) X-step, linalg.solvemdbi_ism (linalg.py:370-444):
 // gam(npix, Cd, K), del(npix, Cd), mm(npix, Cd, Cd) hold the recursion's gamma / delta and the

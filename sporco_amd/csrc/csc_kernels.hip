@@ -107,6 +107,7 @@ template <typename T> struct SmArgs {
     int want_obj, want_xrrs;
     double *partials;
     GradTerm<T> g;
+    int per_grp;   // df is (npix, CN, K) and gram (npix, CN): one system matrix per (pixel, cn)
 };
 
 __device__ __forceinline__ double parseval_weight(int wf, int Wf, int W) {
@@ -154,13 +155,13 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
         T gwa = T(0), gwb = T(0);
         if (valid) {
             yu = *reinterpret_cast<const cxpair<T> *>(a.yuf + 2 * t);
-            d = *reinterpret_cast<const cxpair<T> *>(a.df + pix * a.K + 2 * lg);
+            d = *reinterpret_cast<const cxpair<T> *>(a.df + (a.per_grp ? grp : pix) * a.K + 2 * lg);
             s = a.sf[grp];
             if constexpr (GRAD) {
                 const T gh = grad_gh(a.g, pix, a.Wf);
                 gwa = grad_w(a.g, 2 * lg) * gh;
                 gwb = grad_w(a.g, 2 * lg + 1) * gh;
-            } else {
+            } else if (!a.per_grp) {
                 g = a.gram[pix];
             }
         }
@@ -173,12 +174,16 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
             gs = cabs2(d.a) * ia + cabs2(d.b) * ib;
         } else {
             q = cmul(d.a, yu.a) + cmul(d.b, yu.b);
+            // one system matrix per (pixel, cn): its gram is formed here, from the values
+            // already loaded (a.gram may be null)
+            if (a.per_grp) gs = cabs2(d.a) + cabs2(d.b);
         }
         for (int m = G >> 1; m > 0; m >>= 1) {
             q.re += __shfl_xor(q.re, m, kWave);
             q.im += __shfl_xor(q.im, m, kWave);
-            if constexpr (GRAD) gs += __shfl_xor(gs, m, kWave);
+            if (GRAD || a.per_grp) gs += __shfl_xor(gs, m, kWave);
         }
+        if (!GRAD && a.per_grp) g = gs;
         cx<T> coef;
         cxpair<T> x;
         if constexpr (GRAD) {
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs
     for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
          grp += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = grp / a.CN;
-        const cx<T> *d = a.df + pix * a.K;
+        const cx<T> *d = a.df + (a.per_grp ? grp : pix) * a.K;
         const cx<T> *yu = a.yuf + grp * a.K;
         cx<T> *x = a.xf + grp * a.K;
         const cx<T> s = a.sf[grp];
@@ -246,10 +251,11 @@ __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs
                 gs += cabs2(d[k]) * inv;
             } else {
                 q = q + cmul(d[k], yu[k]);
+                if (a.per_grp) gs += cabs2(d[k]);
             }
         }
         const cx<T> coef = GRAD ? cscale(s - cscale(q, rho), T(1) / (T(1) + gs))
-                                : cscale(s - q, T(1) / (a.gram[pix] + rho));
+                                : cscale(s - q, T(1) / ((a.per_grp ? gs : a.gram[pix]) + rho));
         const double pw = parseval_weight((int)(pix % a.Wf), a.Wf, a.W);
         if (a.want_obj)
             acc[0] += pw * (double)cabs2(coef) * (GRAD ? 1.0 : (double)rho * (double)rho);
@@ -294,8 +300,10 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 template <typename T>
 int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                     const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
-                    bool want_obj, bool want_xrrs, double *partials, const GradTerm<T> *grad) {
+                    bool want_obj, bool want_xrrs, double *partials, const GradTerm<T> *grad,
+                    bool per_grp) {
     SmArgs<T> a;
+    a.per_grp = per_grp ? 1 : 0;
     a.yuf = yuf;
     a.xf = xf;
     a.df = df;
@@ -1222,6 +1230,122 @@ int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<
 }
 
 // ---------------------------------------------------------------------------
+// ADMM consensus dictionary update (admm/ccmod.py:605-908 on admm/admm.py:1441-1707):
+// one dictionary copy X_n (and dual U_n) per image, consensus variable Y (H, W, K)
+// ---------------------------------------------------------------------------
+// out[pix, n, k] = y[pix, k] - s * u[pix, n, k]        (ccmod.py:768: Y[..., newaxis] - U)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cns_yu_kernel(const T *__restrict__ y,
+                                                          const T *__restrict__ u,
+                                                          T *__restrict__ out, T s, int64_t npixr,
+                                                          int CN, int K) {
+    const int64_t total = npixr * CN * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / ((int64_t)K * CN);
+        out[i] = y[pix * K + k] - s * u[i];
+    }
+}
+
+// m[pix, k] = mean_n (a x + (1 - a) y + s u)    (relax_AX admm.py:1608-1616, ystep :1585-1591)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cns_mean_kernel(const T *__restrict__ x,
+                                                            const T *__restrict__ u,
+                                                            const T *__restrict__ y,
+                                                            T *__restrict__ m, T a, T s,
+                                                            int64_t npixr, int CN, int K) {
+    const int64_t total = npixr * K;
+    const T inv = T(1) / (T)CN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / K;
+        const T yo = (T(1) - a) * y[i];
+        T acc = T(0);
+        for (int n = 0; n < CN; ++n) {
+            const int64_t j = (pix * CN + n) * K + k;
+            acc += a * x[j] + yo + s * u[j];
+        }
+        m[i] = acc * inv;
+    }
+}
+
+// u = s u + (a x + (1 - a) yold) - ynew   (ustep, admm.py:434-437 with rsdl_r :1673-1676);
+// partials per block (4): sum (x - ynew)^2, sum x^2, sum u_new^2, unused
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cns_ustep_kernel(const T *__restrict__ x,
+                                                             T *__restrict__ u,
+                                                             const T *__restrict__ yold,
+                                                             const T *__restrict__ ynew, T a, T s,
+                                                             int64_t npixr, int CN, int K,
+                                                             double *partials) {
+    const int64_t total = npixr * CN * K;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / ((int64_t)K * CN);
+        const T xv = x[i], yn = ynew[pix * K + k];
+        const T un = s * u[i] + (a * xv + (T(1) - a) * yold[pix * K + k]) - yn;
+        u[i] = un;
+        const double dr = (double)(xv - yn);
+        acc[0] += dr * dr;
+        acc[1] += (double)xv * (double)xv;
+        acc[2] += (double)un * (double)un;
+    }
+    block_sum_store<4>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 4);
+}
+
+// partials per block (2): sum (ynew - yold)^2, sum ynew^2
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cns_ystats_kernel(const T *__restrict__ yold,
+                                                              const T *__restrict__ ynew,
+                                                              int64_t n, double *partials) {
+    double acc[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double d = (double)(ynew[i] - yold[i]);
+        acc[0] += d * d;
+        acc[1] += (double)ynew[i] * (double)ynew[i];
+    }
+    block_sum_store<2>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 2);
+}
+
+template <typename T>
+void launch_cns_yu(hipStream_t st, const T *y, const T *u, T *out, T s, int64_t npixr, int CN,
+                   int K) {
+    hipLaunchKernelGGL((cns_yu_kernel<T>), dim3(grid_for(npixr * CN * K)), dim3(kThreads), 0, st, y,
+                       u, out, s, npixr, CN, K);
+    SA_HIP(hipGetLastError());
+}
+template <typename T>
+void launch_cns_mean(hipStream_t st, const T *x, const T *u, const T *y, T *m, T a, T s,
+                     int64_t npixr, int CN, int K) {
+    hipLaunchKernelGGL((cns_mean_kernel<T>), dim3(grid_for(npixr * K)), dim3(kThreads), 0, st, x, u,
+                       y, m, a, s, npixr, CN, K);
+    SA_HIP(hipGetLastError());
+}
+template <typename T>
+int launch_cns_ustep(hipStream_t st, const T *x, T *u, const T *yold, const T *ynew, T a, T s,
+                     int64_t npixr, int CN, int K, double *partials) {
+    const int grid = grid_for(npixr * CN * K);
+    hipLaunchKernelGGL((cns_ustep_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 4 * (kThreads / kWave), st, x, u, yold, ynew, a, s, npixr,
+                       CN, K, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+template <typename T>
+int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, double *partials) {
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((cns_ystats_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 2 * (kThreads / kWave), st, yold, ynew, n, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// ---------------------------------------------------------------------------
 // multi-channel dictionaries (Cd > 1): iterated Sherman-Morrison, linalg.solvemdbi_ism
 // (linalg.py:370-444) as called by GenericConvBPDN.xstep (cbpdn.py:277-279)
 // ---------------------------------------------------------------------------
@@ -1729,7 +1853,7 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
                                      int, int, double *);                                          \
     template int launch_sm_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,            \
                                     const cx<T> *, const T *, T, int64_t, int, int, int, bool,     \
-                                    bool, double *, const GradTerm<T> *);                          \
+                                    bool, double *, const GradTerm<T> *, bool);                    \
     template void launch_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,     \
                                   int, int);                                                       \
     template int launch_rfl2norm2<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int64_t,  \
@@ -1761,6 +1885,12 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
                                      int, double *, int);                                               \
     template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);                        \
+    template void launch_cns_yu<T>(hipStream_t, const T *, const T *, T *, T, int64_t, int, int);  \
+    template void launch_cns_mean<T>(hipStream_t, const T *, const T *, const T *, T *, T, T,      \
+                                     int64_t, int, int);                                           \
+    template int launch_cns_ustep<T>(hipStream_t, const T *, T *, const T *, const T *, T, T,      \
+                                     int64_t, int, int, double *);                                 \
+    template int launch_cns_ystats<T>(hipStream_t, const T *, const T *, int64_t, double *);       \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
                                       int64_t, int, int, T);                                       \
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \

@@ -42,7 +42,8 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
 template <typename T>
 void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
              int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
-             int64_t out_line, int64_t grp = 0, int64_t grp_stride = 0);
+             int64_t out_line, int64_t grp = 0, int64_t grp_stride = 0, int64_t bc_mod = 0);
+// (bc_mod > 0: `in` is (n_outer, n, bc_mod) and is broadcast over the P / bc_mod column blocks)
 
 // Half-spectrum -> real lines (inverse, unnormalised times `scale`).  The
 // imaginary parts of the DC (and Nyquist, n even) bins are ignored, as

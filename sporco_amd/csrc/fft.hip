@@ -35,6 +35,10 @@ template <typename T> struct LineArgs {
     int radix[kMaxRadixPasses];
     int64_t ncols;
     int64_t in_outer, in_line, out_outer, out_line;
+    // R2C only: `in` is broadcast over column blocks of bc_mod columns (column c reads
+    // in[o * bc_outer + i * bc_line + c % bc_mod]); 0 = plain.  The consensus dictionary
+    // update transforms Y[.., k] - s U[.., n, k] this way (admm/ccmod.py:768).
+    int64_t bc_mod, bc_outer, bc_line;
     // Column groups on the complex side of a real transform (0 = plain): column p
     // lives at (p / grp) * grp_stride + p % grp instead of p.  This is how the row
     // transforms write / read the tile-major layout of csc_fused.h.
@@ -180,12 +184,15 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
         for (int i = lane; i < n; i += lpc) buf0[i * cols + col] = valid ? in[i * a.in_line] : zero;
     } else if (MODE == MODE_R2C) {
         if (PACK) {
-            const cx<T> *in = static_cast<const cx<T> *>(a.in) + o * a.in_outer + c;
+            const cx<T> *in = a.bc_mod
+                                  ? static_cast<const cx<T> *>(a.in) + o * a.bc_outer + c % a.bc_mod
+                                  : static_cast<const cx<T> *>(a.in) + o * a.in_outer + c;
+            const int64_t in_ln = a.bc_mod ? a.bc_line : a.in_line;
             const cx<T> *in2 = a.in2 ? static_cast<const cx<T> *>(a.in2) + o * a.in_outer + c : nullptr;
             for (int i = lane; i < n; i += lpc) {
                 cx<T> v = zero;
                 if (valid) {
-                    v = in[i * a.in_line];
+                    v = in[i * in_ln];
                     if (in2) {
                         const cx<T> u = in2[i * a.in_line];
                         v = mk<T>(v.re - a.s2 * u.re, v.im - a.s2 * u.im);
@@ -194,12 +201,14 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
                 buf0[i * cols + col] = v;
             }
         } else {
-            const T *in = static_cast<const T *>(a.in) + o * a.in_outer + c;
+            const T *in = a.bc_mod ? static_cast<const T *>(a.in) + o * a.bc_outer + c % a.bc_mod
+                                   : static_cast<const T *>(a.in) + o * a.in_outer + c;
+            const int64_t in_ln = a.bc_mod ? a.bc_line : a.in_line;
             const T *in2 = a.in2 ? static_cast<const T *>(a.in2) + o * a.in_outer + c : nullptr;
             for (int i = lane; i < n; i += lpc) {
                 T v = T(0);
                 if (valid) {
-                    v = in[i * a.in_line];
+                    v = in[i * in_ln];
                     if (in2) v -= a.s2 * in2[i * a.in_line];
                 }
                 buf0[i * cols + col] = mk<T>(v, T(0));
@@ -404,8 +413,12 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
 template <typename T>
 void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
              int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
-             int64_t out_line, int64_t grp, int64_t grp_stride) {
+             int64_t out_line, int64_t grp, int64_t grp_stride, int64_t bc_mod) {
     LineArgs<T> a{};
+    // broadcast `in`: (n_outer, n, bc_mod) contiguous, i.e. line stride bc_mod
+    a.bc_mod = bc_mod;
+    a.bc_line = bc_mod;
+    a.bc_outer = (int64_t)plan.n * bc_mod;
     a.grp = grp;
     a.grp_stride = grp_stride;
     a.in = in;
@@ -418,8 +431,11 @@ void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s
     a.out_line = out_line;
     const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0) &&
                       (out_outer % 2 == 0) && (out_line % 2 == 0) && (grp % 2 == 0) &&
-                      (grp_stride % 2 == 0);
+                      (grp_stride % 2 == 0) && (bc_mod % 2 == 0);
     if (pack) {
+        a.bc_mod /= 2;
+        a.bc_line /= 2;
+        a.bc_outer /= 2;
         a.ncols = P / 2;
         a.in_outer = in_outer / 2;
         a.in_line = in_line / 2;
@@ -467,7 +483,7 @@ template <typename T>
 void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
            T s2, cx<T> *out, int H, int W, int64_t P) {
     const int64_t Wf = W / 2 + 1;
-    fft_r2c<T>(st, planW, in, in2, s2, out, H, P, (int64_t)W * P, P, Wf * P, P, 0, 0);
+    fft_r2c<T>(st, planW, in, in2, s2, out, H, P, (int64_t)W * P, P, Wf * P, P, 0, 0, 0);
     // columns: (wf, p) is one contiguous run of Wf*P complex columns per row h
     fft_c2c<T>(st, planH, false, out, out, 1, Wf * P, 0, Wf * P, 0, Wf * P, T(1));
 }
@@ -486,7 +502,7 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
                              int64_t, int64_t, int64_t, int64_t, int64_t, T);                    \
     template void fft_r2c<T>(hipStream_t, const FftPlan &, const T *, const T *, T, cx<T> *,     \
                              int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,      \
-                             int64_t);                                                           \
+                             int64_t, int64_t);                                                  \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
                              int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
     template void rfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const T *, const T *,  \

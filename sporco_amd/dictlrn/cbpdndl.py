@@ -4,8 +4,9 @@ Drop-in for ``sporco.dictlrn.cbpdndl`` (sporco/dictlrn/cbpdndl.py:31-524):
 ``ConvBPDNDictLearn(D0, S, lmbda, opt, xmethod, dmethod, dimK, dimN)`` with the
 same Options tree (``CBPDN`` / ``CCMOD`` sub-options built from the selected
 inner solver classes) and IterationStats.  ``xmethod`` is ``'admm'`` or
-``'pgm'``; ``dmethod`` is ``'pgm'`` (the reference default).  The ADMM D-step
-variants (``'ism'``, ``'cg'``, ``'cns'``) are outside this backend's hot path.
+``'pgm'``; ``dmethod`` is ``'pgm'`` (the reference default) or ``'cns'`` (the ADMM
+consensus update, sporco_amd.admm.ccmod).  The other two ADMM D-steps (``'ism'``,
+``'cg'``) are outside this backend's hot path.
 
 Both inner solvers share ONE device handle: after the X-step the coefficient
 maps are transformed in place on the GPU for the D-step (``setcoef``), and after
@@ -22,6 +23,7 @@ from . import dictlrn
 from .. import _lib
 from .. import cnvrep as cr
 from ..admm import cbpdn as admm_cbpdn
+from ..admm import ccmod as admm_ccmod
 from ..pgm import cbpdn as pgm_cbpdn
 from ..pgm import ccmod as pgm_ccmod
 
@@ -30,8 +32,8 @@ __all__ = ['cbpdn_class_label_lookup', 'ConvBPDNOptionsDefaults', 'ConvBPDNOptio
            'ConvCnstrMODOptions', 'ConvCnstrMOD', 'ConvBPDNDictLearn']
 
 _XCLS = {'admm': admm_cbpdn.ConvBPDN, 'pgm': pgm_cbpdn.ConvBPDN}
-_DCLS = {'pgm': pgm_ccmod.ConvCnstrMOD}
-_D_UNPORTED = ('ism', 'cg', 'cns')
+_DCLS = {'pgm': pgm_ccmod.ConvCnstrMOD, 'cns': admm_ccmod.ConvCnstrMOD_Consensus}
+_D_UNPORTED = ('ism', 'cg')
 _dyn = {}
 
 
@@ -46,7 +48,7 @@ def ccmod_class_label_lookup(label):
         return _DCLS[label]
     if label in _D_UNPORTED:
         raise NotImplementedError("dictionary update method '%s' (sporco.admm.ccmod) is "
-                                  "not part of the sporco_amd hot path; use 'pgm'" % label)
+                                  "not part of the sporco_amd hot path; use 'pgm' or 'cns'" % label)
     raise ValueError('Unknown ConvCnstrMOD solver method %s' % label)
 
 
@@ -64,6 +66,9 @@ def ConvCnstrMODOptionsDefaults(method='pgm'):
     """Inner D-step defaults inside dictionary learning (cbpdndl.py:139-152)."""
     dflt = copy.deepcopy(ccmod_class_label_lookup(method).Options.defaults)
     dflt.update({'MaxMainIter': 1})
+    if method != 'pgm':
+        dflt['AutoRho'].update({'Period': 10, 'AutoScaling': False, 'RsdlRatio': 10.0,
+                                'Scaling': 2.0, 'RsdlTarget': 1.0})
     return dflt
 
 
@@ -146,7 +151,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)
         # normalise the initial dictionary and hand it (zero-padded) to the D-step
         D0 = cr.Pcn(D0, dsz, cri.Nv, dimN, cri.dimCd, crp=True, zm=opt['CCMOD', 'ZeroMean'])
-        opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
+        optname = 'X0' if dmethod == 'pgm' else 'Y0'        # (cbpdndl.py:443-445)
+        opt['CCMOD'].update({optname: cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
         xstep = ConvBPDN(D0, S, lmbda, opt['CBPDN'], method=xmethod, dimK=dimK, dimN=dimN,
                          device=device, stream=stream)
         if xmethod == 'admm':

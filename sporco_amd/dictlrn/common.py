@@ -26,6 +26,11 @@ _D = {
                 hdr=({'L_D': 'D_L'},
                      {'F_D': 'D_F_Btrack', 'Q_D': 'D_Q_Btrack', 'It_D': 'D_ItBt',
                       'L_D': 'D_L'})),
+    'cns': dict(map={'Cnstr': 'Cnstr', 'DPrRsdl': 'PrimalRsdl', 'DDlRsdl': 'DualRsdl',
+                     'DRho': 'Rho'},
+                fld=(['DPrRsdl', 'DDlRsdl', 'DRho'],) * 2,
+                txt=(['r_D', 's_D', u'ρ_D'],) * 2,
+                hdr=({'r_D': 'DPrRsdl', 's_D': 'DDlRsdl', u'ρ_D': 'DRho'},) * 2),
 }
 
 

@@ -1,0 +1,87 @@
+"""ADMM consensus dictionary update (sporco_amd.admm.ccmod.ConvCnstrMOD_Consensus) and
+ConvBPDNDictLearn(dmethod='cns') against fixtures produced by the unmodified reference
+(oracle/make_golden.py gen_cns).  float64 1e-9; float32 against the reference's own float32
+run 3e-4 (iterates), as in test_admm_cbpdn.py."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+CASES = {
+    'ccmod_cns_f64': dict(opt={'MaxMainIter': 20}),
+    'ccmod_cns_f32': dict(opt={'MaxMainIter': 20, 'DataType': np.float32}),
+    'ccmod_cns_autorho_zm_f64': dict(opt={
+        'MaxMainIter': 25, 'ZeroMean': True, 'rho': 2.0, 'RelaxParam': 1.5,
+        'AutoRho': {'Enabled': True, 'Period': 2, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+                    'AutoScaling': True, 'RsdlTarget': 1.0}}),
+    'ccmod_cns_y0_f64': dict(opt={'MaxMainIter': 10}, y0=True),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_consensus_golden_traces(backend, name):
+    from sporco_amd.admm import ccmod
+    g = load_golden(name)
+    optd = dict(CASES[name]['opt'])
+    if CASES[name].get('y0'):
+        optd['Y0'] = g['Y0']
+    f32 = optd.get('DataType') is np.float32
+    tol = 3e-4 if f32 else 1e-9
+    c = ccmod.ConvCnstrMOD_Consensus(g['Z'], g['S'], tuple(int(v) for v in g['dsz']),
+                                     ccmod.ConvCnstrMOD_Consensus.Options(optd))
+    Y = c.solve()
+    if 'k_final' in g:
+        assert c.k == int(g['k_final'])
+    assert Y.shape == g['Y'].shape and rel_l2(Y, g['Y']) < tol
+    assert rel_l2(c.getdict(), g['D']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    if 'X' in g:
+        assert rel_l2(c.X, g['X']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < (1e-5 if f32 else 1e-12)
+    assert c.Y.dtype == (np.float32 if f32 else np.float64)
+
+
+def test_consensus_surface(backend):
+    from sporco_amd.admm import ccmod
+    g = load_golden('ccmod_cns_f64')
+    dsz = tuple(int(v) for v in g['dsz'])
+    # factory functions of the reference module; the other two ADMM D-steps are not offered
+    c = ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz,
+                           ccmod.ConvCnstrMODOptions({'MaxMainIter': 3}, method='cns'),
+                           method='cns')
+    c.solve()
+    c.solve()                      # continues (admm.py:331)
+    assert c.k == 6
+    c2 = ccmod.ConvCnstrMOD_Consensus(g['Z'], g['S'], dsz,
+                                      ccmod.ConvCnstrMOD_Consensus.Options({'MaxMainIter': 6}))
+    c2.solve()
+    assert rel_l2(c.Y, c2.Y) < 1e-12
+    assert c.reconstruct().shape[:2] == g['S'].shape[:2]
+    for m in ('ism', 'cg'):
+        with pytest.raises(NotImplementedError):
+            ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz, method=m)
+    with pytest.raises(NotImplementedError):
+        ccmod.ConvCnstrMOD_Consensus(
+            g['Z'], g['S'], dsz, ccmod.ConvCnstrMOD_Consensus.Options({'AuxVarObj': False}))
+
+
+@pytest.mark.parametrize('name,dt,tol', [('cbpdndl_cns_f64', np.float64, 1e-9),
+                                         ('cbpdndl_cns_f32', np.float32, 1e-3)])
+def test_dictlearn_consensus_trace(backend, name, dt, tol):
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden(name)
+    opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                            xmethod='admm', dmethod='cns')
+    d = cbpdndl.ConvBPDNDictLearn(g['D0'].astype(dt), g['S'].astype(dt), float(g['lmbda']),
+                                  opt, xmethod='admm', dmethod='cns')
+    D1 = d.solve()
+    assert rel_l2(D1, g['D1']) < tol
+    assert rel_l2(d.getcoef(), g['X']) < tol
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'DPrRsdl', 'DDlRsdl',
+              'DRho'):
+        assert rel_l2(np.asarray(getattr(its, f), dtype=float), g['it_' + f]) < tol, f

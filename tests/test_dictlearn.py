@@ -97,7 +97,7 @@ def test_dictlearn_variants_run(backend):
     with pytest.raises(ValueError):
         cbpdndl.ConvBPDN(D0, S, 0.1, method='nonsense')
     with pytest.raises(NotImplementedError):
-        cbpdndl.ConvBPDNDictLearn.Options(dmethod='cns')
+        cbpdndl.ConvBPDNDictLearn.Options(dmethod='ism')
 
 
 # ---------------------------------------------------------------------------

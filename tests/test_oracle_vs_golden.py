@@ -231,6 +231,39 @@ def test_mcdict_traces(name):
                   g['recon'].squeeze()) < tol
 
 
+CNS_CASES = {
+    'ccmod_cns_f64': dict(maxiter=20),
+    'ccmod_cns_f32': dict(maxiter=20, dtype=np.float32),
+    'ccmod_cns_autorho_zm_f64': dict(maxiter=25, zero_mean=True, rho=2.0, rlx=1.5,
+                                     auto_rho=True, rho_period=2, rho_tau=2.0, rho_mu=1.2,
+                                     auto_scaling=True, rho_xi=1.0),
+    'ccmod_cns_y0_f64': dict(maxiter=10, _y0=True),
+}
+
+
+@pytest.mark.parametrize('name', sorted(CNS_CASES))
+def test_ccmod_consensus_traces(name):
+    """ConvCnstrMOD_Consensus restatement (per-image Sherman-Morrison, mean + Pcn, consensus
+    residuals)."""
+    g = load_golden(name)
+    kw = dict(CNS_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-9 if dtype == np.float64 else 2e-4
+    if kw.pop('_y0', False):
+        kw['Y0'] = g['Y0']
+    S = g['S']
+    r = orc.admm_ccmod_cns(g['Z'], S.reshape(S.shape[0], S.shape[1], 1, S.shape[2], 1),
+                           tuple(int(v) for v in g['dsz']), dtype=dtype, **kw)
+    if 'k_final' in g:
+        assert r['iters'] == int(g['k_final'])
+    assert rel_l2(r['Y'], g['Y']) < tol
+    assert rel_l2(r['U'], g['U']) < tol
+    assert rel_l2(r['D'], g['D']) < tol
+    for key in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    assert np.max(np.abs(r['Cnstr'] - g['it_Cnstr'])) < 1e-6
+
+
 def test_admm_known_answer():
     g = load_golden('admm_known_answer_f64')
     D5, S5 = to5d(g['D'], g['S'])
