@@ -216,6 +216,10 @@ template <typename T> struct Csc : CscBase {
     // consensus D-step scratch: spectrum of the per-image copies, per-(pixel, image) gram of
     // the coefficient spectra, mean / previous-Y buffers (dictionary sized)
     cx<T> *cns_f = nullptr;
+    // 64 < K <= 64 + kTailMax filters: single column kernel on the first 64, the tail through
+    // the generic column FFT (run_fused_cols)
+    static constexpr int kTailMax = 8;
+    cx<T> *sft_eff = nullptr, *coef_t = nullptr;
     T *cns_m = nullptr, *cns_yold = nullptr;
     bool cns_active = false;   // setcoef then keeps Zf in the natural layout this D-step reads
     bool ism_valid = false;
@@ -358,7 +362,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t,
                         (void *)cns_yold,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
@@ -755,7 +759,27 @@ template <typename T> struct Csc : CscBase {
             fa.g1t = g1t;
         }
         int64_t ntiles;
-        if (fused_slabs) {
+        if (fused_slabs && K - 64 <= kTailMax && !gradreg && !std::getenv("SPORCO_AMD_NO_TAIL")) {
+            // A handful of filters past 64 (the AddMaskSim impulse on a 64-filter dictionary):
+            // they go through the generic column FFT, their inner products are folded into
+            // Sf, and the register-resident kernel runs on the first 64 as if alone.
+            if (!sft_eff) {
+                SA_HIP(hipMalloc((void **)&sft_eff, sizeof(cx<T>) * npix * CN));
+                SA_HIP(hipMalloc((void **)&coef_t, sizeof(cx<T>) * npix * CN));
+            }
+            const int Kt = K - 64;
+            const int64_t nt = (int64_t)Wf * CN, tstride = (int64_t)H * K;
+            cx<T> *tail = fa.t + 64;
+            fa.Kv = 64;
+            fa.coef_out = coef_t;
+            ProfScope ps(prof, PS_FUSED_COLS);
+            fft_c2c<T>(st, planH, false, tail, tail, nt, Kt, tstride, K, tstride, K, T(1));
+            launch_tail_inner<T>(st, fa, sft, sft_eff);
+            fa.sft = sft_eff;
+            ntiles = launch_fused_cols<T>(st, fa);
+            launch_tail_update<T>(st, fa);
+            fft_c2c<T>(st, planH, true, tail, tail, nt, Kt, tstride, K, tstride, K, T(1));
+        } else if (fused_slabs) {
             FusedSlabArgs<T> sa;
             sa.c = fa;
             sa.qpart = qpart;

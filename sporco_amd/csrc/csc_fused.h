@@ -39,11 +39,24 @@ template <typename T> struct FusedColsArgs {
     // mu wg[k] (ghh[f] + ghw[wf]) + rho, g1t[wf][f] = 1 + sum_k |Df|^2 / diagonal
     // (launch_grad_g1 fills it), and partials holds two doubles per tile, the second the
     // Parseval-weighted sum of wg GHGf |xf|^2.
+    // A few more than 64 filters (Kv = 64 < K): the kernel owns the first 64 of the K filters
+    // of a row; the caller has already folded the inner products of the others
+    // into sft (sft = Sf - sum_{k >= Kv} Df yuf) and gramt covers all K, so the multiplier
+    // coef = (Sf - sum_k Df yuf) / (gram + rho) the kernel forms is that of the whole system;
+    // it is stored to coef_out[tile][f] for the update of the remaining filters.
+    int Kv = 0;
+    cx<T> *coef_out = nullptr;
     const T *g1t = nullptr;
     T *g1t_out = nullptr;
     const T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
     T mu = T(0);
 };
+// The two small kernels around the column kernel when it owns only the first Kv filters:
+// sft_eff = sft - sum_{k >= Kv} dft t (t column-transformed on those filters), and afterwards
+// t[.., k >= Kv] += conj(dft) coef_out.
+template <typename T>
+void launch_tail_inner(hipStream_t st, const FusedColsArgs<T> &a, const cx<T> *sft, cx<T> *sft_eff);
+template <typename T> void launch_tail_update(hipStream_t st, const FusedColsArgs<T> &a);
 // g1t_out[wf][h] from dft, ghh, ghw, wg, mu, rho.
 template <typename T> void launch_grad_g1(hipStream_t st, const FusedColsArgs<T> &a);
 

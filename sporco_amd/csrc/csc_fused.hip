@@ -46,7 +46,9 @@ constexpr size_t fused_lds_bytes(int NW, int LP) {
 //     coef = (Sf - rho sum_k Df yuf / dd) / g1,    g1 = 1 + sum_k |Df|^2 / dd  (table)
 //     xf = (rho yuf + conj(Df) coef) / dd,         Df.xf - Sf = -coef
 // and a second partial per tile, the weighted sum of wg GHGf |xf|^2 (cbpdn.py:1204-1214).
-template <int N1, int NW, int LPARAM, int KC, bool GRAD>
+// KRT (with KC = 64): the kernel owns 64 filters of rows that are a.K > 64 filters long
+// (FusedColsArgs::Kv): run-time row stride, all lanes valid, multipliers stored.
+template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false>
 __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
     constexpr int H = N1 * NW;
     constexpr int J = N1 / NW;   // stage-2 lines per thread (each NW points)
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
-    const int K = KC ? KC : a.K;
+    const int K = (KC && !KRT) ? KC : a.K;             // row stride of the tile, in filters
     const bool kv = KC == 64 ? true : k < K;
     // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).
     // All C*N tiles of one row frequency wf share the same 256 KiB slice of Df, so
@@ -77,6 +79,9 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     // cost no vector registers (the tile itself needs 2*N1 of them)
     const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, (uint32_t)(H * K * sizeof(cf)));
+    const BufRsrc Cb = make_rsrc((KRT && a.coef_out) ? a.coef_out + (int64_t)tile * H : nullptr,
+                                 (KRT && a.coef_out) ? (uint32_t)(H * sizeof(cf)) : 0u);
+    const int cvoff = k == 0 ? 0 : (int)0x80000000;
     const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
     const cf *S = a.sft + (int64_t)tile * H + w;
     const float *G = (GRAD ? a.g1t : a.gramt) + (int64_t)wf * H + w;
@@ -195,6 +200,13 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                     // Df.xf - Sf = rho (q - Sf) / (gram + rho)
                     obj += cabs2(coef);
                     u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
+                    if constexpr (KRT) {
+                        // the multiplier of this frequency, for the filters held elsewhere
+                        // (lane 0 only; a null coef_out makes every lane out of range)
+                        constexpr int j = q * LP + jl;
+                        const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                        buf_store_cf(Cb, cvoff, (w + fo) * (int)sizeof(cf), coef);
+                    }
                 }
             }
             // inverse FFT over f2, conj twiddle
@@ -545,17 +557,17 @@ template <> bool fused_cols_supported<float>(int H, int K) {
 }
 template <> bool fused_cols_supported<double>(int, int) { return false; }
 
-template <int N1, int NW, int LP, int KC, bool GRAD>
+template <int N1, int NW, int LP, int KC, bool GRAD, bool KRT = false>
 static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
     static bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC, GRAD>),
+            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
-    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD>),
+    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT>),
                        dim3((unsigned)(wf_groups * 8 * a.CN)), dim3(NW * 64),
                        fused_lds_bytes(NW, LP), st, a);
 }
@@ -563,7 +575,9 @@ static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int
 template <int N1, int NW, int LP>
 static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
     const bool grad = a.g1t != nullptr;
-    if (a.K == 64) {
+    if (a.Kv == 64 && a.K > 64 && !grad) {
+        launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
+    } else if (a.K == 64) {
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false>(st, a, ntiles);
     } else {
@@ -573,9 +587,10 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
 }
 
 template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs<float> &a_in) {
-    SA_REQUIRE(fused_cols_supported<float>(a_in.H, a_in.K), "shape not handled by the fused column kernel");
+    SA_REQUIRE(fused_cols_supported<float>(a_in.H, a_in.Kv ? a_in.Kv : a_in.K),
+               "shape not handled by the fused column kernel");
     const int64_t ntiles = (int64_t)(a_in.W / 2 + 1) * a_in.CN;
-    const FusedSplit sp = fused_split(a_in.H, a_in.K);
+    const FusedSplit sp = fused_split(a_in.H, a_in.Kv ? a_in.Kv : a_in.K);
     const FusedColsArgs<float> &a = a_in;
     if (sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);
@@ -592,6 +607,71 @@ template <> void launch_grad_g1<float>(hipStream_t st, const FusedColsArgs<float
 template <> void launch_grad_g1<double>(hipStream_t, const FusedColsArgs<double> &) {
     throw Error(-1, "the fused column kernel is float32 only");
 }
+// ---------------------------------------------------------------------------
+// a few more than 64 filters: the column pass of the filters >= Kv (csc_fused.h)
+// ---------------------------------------------------------------------------
+// sft_eff[tile][f] = sft[tile][f] - sum_{k >= Kv} dft[wf][f][k] t[tile][f][k]
+__global__ void __launch_bounds__(256) tail_inner_kernel(const cf *__restrict__ t,
+                                                         const cf *__restrict__ dft,
+                                                         const cf *__restrict__ sft,
+                                                         cf *__restrict__ sft_eff, int64_t ntiles,
+                                                         int CN, int H, int K, int Kv) {
+    const int64_t total = ntiles * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tile = i / H;
+        const int f = (int)(i - tile * H);
+        const int64_t wf = tile / CN;
+        const cf *d = dft + (wf * H + f) * K, *x = t + i * K;
+        cf q = mk<float>(0.f, 0.f);
+        for (int k = Kv; k < K; ++k) q = q + cmul(d[k], x[k]);
+        sft_eff[i] = sft[i] - q;
+    }
+}
+
+// t[tile][f][k] += conj(dft[wf][f][k]) coef[tile][f] for k >= Kv
+__global__ void __launch_bounds__(256) tail_update_kernel(cf *__restrict__ t,
+                                                          const cf *__restrict__ dft,
+                                                          const cf *__restrict__ coef,
+                                                          int64_t ntiles, int CN, int H, int K,
+                                                          int Kv) {
+    const int Kt = K - Kv;
+    const int64_t total = ntiles * H * Kt;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = Kv + (int)(i % Kt);
+        const int64_t row = i / Kt;          // tile * H + f
+        const int64_t tile = row / H;
+        const int f = (int)(row - tile * H);
+        const int64_t wf = tile / CN;
+        t[row * K + k] = t[row * K + k] + cmulc(dft[(wf * H + f) * K + k], coef[row]);
+    }
+}
+
+template <> void launch_tail_inner<float>(hipStream_t st, const FusedColsArgs<float> &a,
+                                          const cx<float> *sft, cx<float> *sft_eff) {
+    const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(ntiles * a.H, 256), 65535);
+    hipLaunchKernelGGL(tail_inner_kernel, dim3(grid), dim3(256), 0, st, a.t, a.dft, sft, sft_eff,
+                       ntiles, a.CN, a.H, a.K, a.Kv);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_tail_update<float>(hipStream_t st, const FusedColsArgs<float> &a) {
+    const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
+    const unsigned grid =
+        (unsigned)std::min<int64_t>(ceil_div(ntiles * a.H * (a.K - a.Kv), 256), 65535);
+    hipLaunchKernelGGL(tail_update_kernel, dim3(grid), dim3(256), 0, st, a.t, a.dft, a.coef_out,
+                       ntiles, a.CN, a.H, a.K, a.Kv);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_tail_inner<double>(hipStream_t, const FusedColsArgs<double> &,
+                                           const cx<double> *, cx<double> *) {
+    throw Error(-1, "the fused column kernel is float32 only");
+}
+template <> void launch_tail_update<double>(hipStream_t, const FusedColsArgs<double> &) {
+    throw Error(-1, "the fused column kernel is float32 only");
+}
+
 template <> bool fused_slabs_supported<float>(int H, int K) {
     return (H == 256 || H == 512) && K > 64 && K <= 256 && K % 2 == 0;
 }

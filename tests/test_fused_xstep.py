@@ -261,6 +261,11 @@ def test_state_machine_random_walk(gpu_backend, seed):
 # K = 64 * NH filters: the column pass runs as two kernels over 64-filter slabs
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize('H,W,K,N,C', [(256, 256, 128, 1, None),
+                                       # 64 < K <= 72: one column kernel on the first 64
+                                       # filters, the tail through the generic column FFT
+                                       (256, 256, 70, 1, None),
+                                       pytest.param(512, 512, 66, 2, None, marks=pytest.mark.gpu),
+                                       pytest.param(256, 256, 72, 1, 3, marks=pytest.mark.gpu),
                                        pytest.param(512, 512, 128, 1, None, marks=pytest.mark.gpu),
                                        pytest.param(256, 512, 192, 1, None, marks=pytest.mark.gpu),
                                        pytest.param(256, 256, 96, 2, None, marks=pytest.mark.gpu),
@@ -272,7 +277,7 @@ def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
     optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
     b, Y = solve(D, S, optd, joint=C is not None)
     assert b._dev.uses_fused_rows() and not b._dev.uses_fused_pgm()
-    if H * W * K * N > 2 ** 24:
+    if H * W * K * N * (C or 1) > 2 ** 23:
         # large case: the generic kernel chain of the same library is the reference
         # (the float64 NumPy oracle would take a minute here)
         b0, Y0 = solve(D, S, optd, unfused=True, joint=C is not None)

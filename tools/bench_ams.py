@@ -26,5 +26,5 @@ def run(K, steps=30):
                       'it_per_s': steps / t, 'ms_per_it': 1e3 * t / steps, 'kernel_ms': prof}))
 
 
-run(63)
-run(64)
+for K in [int(v) for v in os.environ.get('KS', '63,64').split(',')]:
+    run(K)
