@@ -438,6 +438,24 @@ def gen_cns():
         save(name, D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_signal():
+    """Pre/post-processing around the solver: signal.tikhonov_filter
+    (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
+    from sporco import signal as ref_signal
+    np.random.seed(24680)
+    s2 = np.random.randn(20, 17)
+    s3 = np.random.randn(16, 16, 3).astype(np.float32)
+    sl2, sh2 = ref_signal.tikhonov_filter(s2, 5.0, 16)
+    sl3, sh3 = ref_signal.tikhonov_filter(s3, 2.0, 4)
+    d = np.random.randn(5, 5, 4)
+    x = np.random.randn(16, 12, 4)
+    cv = ref_fft.fftconv(d, x, axes=(0, 1), origin=(2, 2))
+    cv1 = ref_fft.fftconv(np.random.RandomState(1).randn(3, 3), s2)
+    Gf, GHGf = ref_signal.gradient_filters(5, (0, 1), (12, 9), dtype=np.dtype(np.float64))
+    save('signal_prims', s2=s2, s3=s3, sl2=sl2, sh2=sh2, sl3=sl3, sh3=sh3, d=d, x=x, cv=cv,
+         k3=np.random.RandomState(1).randn(3, 3), cv1=cv1, Gf=Gf, GHGf=GHGf)
+
+
 def gen_ams():
     """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
     ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
@@ -463,8 +481,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'signal']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'signal': gen_signal,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

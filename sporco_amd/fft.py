@@ -77,3 +77,23 @@ def rfl2norm2(xf, xs, axis=(0, 1)):
     _lib.check(_lib.lib().sporco_amd_rfl2norm2(_lib.dtype_code(real_dtype(xf.dtype)), H, W,
                                                P, _lib._ptr(xf), ctypes.byref(out)))
     return out.value
+
+
+def fftconv(a, b, axes=(0, 1), origin=None):
+    """Circular convolution of real arrays over axes (0, 1) by multiplication in the DFT
+    domain, ``origin`` shifting the result (sporco/fft.py:376-417).  The remaining axes of
+    ``a`` and ``b`` broadcast against each other."""
+    _check_axes(axes)
+    a, b = np.asarray(a), np.asarray(b)
+    if np.iscomplexobj(a) or np.iscomplexobj(b):
+        raise NotImplementedError("sporco_amd.fft handles real-valued arrays")
+    nd = max(a.ndim, b.ndim)
+    a = a.reshape(a.shape + (1,) * (nd - a.ndim))
+    b = b.reshape(b.shape + (1,) * (nd - b.ndim))
+    dims = tuple(int(max(x, y)) for x, y in zip(a.shape[:2], b.shape[:2]))
+    af = rfftn(a, dims, axes)
+    bf = rfftn(b, dims, axes)
+    ab = irfftn(np.ascontiguousarray(af * bf), dims, axes)
+    if origin is not None:
+        ab = np.roll(ab, -np.array(origin), axis=axes)
+    return ab
