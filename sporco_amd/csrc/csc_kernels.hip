@@ -1447,7 +1447,6 @@ template <typename T, int KR, int CC>
 __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a) {
     constexpr int CM = CC ? CC : 8;
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
     const int Wf = a.W / 2 + 1, K = a.K, Cd = CC ? CC : a.Cd;
     const T rho = a.rho, irho = T(1) / a.rho;
     // The kThreads / kWave waves of a workgroup share one frequency and take its images in

@@ -270,10 +270,7 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // ---------------------------------------------------------------------------
 template <int NW>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a) {
-    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
-    constexpr int NG = 2;                    // exchange halves
-    constexpr int LPG = J / NG;
-    constexpr int LBW = ilog2(NW);
+    constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -326,10 +323,7 @@ __device__ __forceinline__ uint32_t am1_bytes(const RowsPostArgs<float> &a) {
 
 template <int NW, bool WRITE_X, bool GENERAL, bool EMIT_T>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
-    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
-    constexpr int NG = 2;
-    constexpr int LPG = J / NG;
-    constexpr int LBW = ilog2(NW);
+    constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -340,7 +334,6 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
-    const cf zero = mk<float>(0.f, 0.f);
     int token = 0;
 
     cf v[N1];
