@@ -17,6 +17,22 @@ def pytest_configure(config):
         'markers', 'gpu: needs a real MI355X (run with -m gpu through gpurun)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """A case marked ``gpu`` through its parameters is meant for the real device only: drop
+    its 'hostsim' twin (it would otherwise run the CPU simulator at GPU sizes under -m gpu)."""
+    keep, drop = [], []
+    for item in items:
+        cs = getattr(item, 'callspec', None)
+        if cs is not None and cs.params.get('backend') == 'hostsim' and \
+                item.get_closest_marker('gpu') is not None:
+            drop.append(item)
+        else:
+            keep.append(item)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
