@@ -220,6 +220,8 @@ template <typename T> struct Csc : CscBase {
     // the generic column FFT (run_fused_cols)
     static constexpr int kTailMax = 8;
     cx<T> *sft_eff = nullptr, *coef_t = nullptr;
+    uint32_t *ams_bits = nullptr;   // AddMaskSim mask, one bit per pixel (csc_rows.h)
+    bool ams_bits_valid = false;
     T *cns_m = nullptr, *cns_yold = nullptr;
     bool cns_active = false;   // setcoef then keeps Zf in the natural layout this D-step reads
     bool ism_valid = false;
@@ -362,7 +364,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits,
                         (void *)cns_yold,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
@@ -576,6 +578,7 @@ template <typename T> struct Csc : CscBase {
 
     void set_weight(int which, const void *w, const int64_t shape[5]) override {
         before_state_change();   // a pending X of the fused PGM step depends on the weights
+        if (which == 2) ams_bits_valid = false;
         Weight<T> &dst = which == 0 ? wl1 : (which == 1 ? wl21 : wams);
         T *&buf = which == 0 ? wl1_buf : (which == 1 ? wl21_buf : wams_buf);
         if (buf) {
@@ -843,7 +846,7 @@ template <typename T> struct Csc : CscBase {
         pa.dW = p.dW;
         pa.P = P;
         pa.wl1 = wl1;
-        pa.ams = ams_of(p);
+        pa.ams_bits = ams_bits_of(p);
         pa.ams_k = Ku - 1;
         pa.partials = part_rows;
         int64_t nt;
@@ -1052,6 +1055,19 @@ template <typename T> struct Csc : CscBase {
         if (!(p.flags & F_AMS)) return Weight<T>();
         if (!wams.ptr) throw Error(SPORCO_AMD_ESTATE, "FLAG_AMS without a mask (set_ams_mask)");
         return wams;
+    }
+
+    // the same mask, one bit per pixel in the row kernel's order (built on first use)
+    const uint32_t *ams_bits_of(const sporco_amd_admm_params &p) {
+        if (!(p.flags & F_AMS)) return nullptr;
+        const Weight<T> m = ams_of(p);
+        if (!ams_bits_valid) {
+            if (!ams_bits) SA_HIP(hipMalloc((void **)&ams_bits, sizeof(uint32_t) * (int64_t)H * CN * (W / 32)));
+            ProfScope ps(prof, PS_OTHER);
+            launch_ams_pack<T>(st, m, ams_bits, H, W, C, N);
+            ams_bits_valid = true;
+        }
+        return ams_bits;
     }
 
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {

@@ -48,10 +48,17 @@ template <typename T> struct RowsPostArgs {
     int H, W, C, N, K, dH, dW;
     int64_t P;
     Weight<T> wl1;
-    Weight<T> ams;     // AddMaskSim mask (H, W, C, N, 1) or null, as PostParams::ams
+    const uint32_t *ams_bits = nullptr;   // AddMaskSim mask packed by launch_ams_pack, or null
     int ams_k = -1;    // filter index of the impulse slice
     double *partials;  // per tile 8 doubles: r2, s2, ax2, y2, u2, l1, 0, 0
 };
+
+// Pack an AddMaskSim mask (as PostParams::ams: broadcastable (H, W, C, N, 1), nonzero = masked)
+// into one bit per pixel in the order the row kernel reads it: bits[(h * C N + cn) * NW + w],
+// bit n1 <-> pixel x = NW n1 + w, NW = W / 32.  H * C * N * NW words.
+template <typename T>
+void launch_ams_pack(hipStream_t st, const Weight<T> &mask, uint32_t *bits, int H, int W, int C,
+                     int N);
 
 // The row pass of the fused PGM (FISTA) iteration, sporco/pgm/pgm.py:800-803 with
 // prox_g of sporco/pgm/cbpdn.py:288-300:  X = prox_l1(irfft_W(t_in) / (H W), thr * wl1)

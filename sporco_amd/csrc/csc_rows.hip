@@ -312,17 +312,11 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // ---------------------------------------------------------------------------
 // rows_inv_post: X = irfft_W(T) / (H W); relax, shrink, dual update, sums
 // ---------------------------------------------------------------------------
-// extent of the AddMaskSim mask in bytes (0 when there is none: every access is then
-// out of range and reads 0)
-__device__ __forceinline__ uint32_t am1_bytes(const RowsPostArgs<float> &a) {
-    if (!a.ams.ptr) return 0u;
-    const int64_t n = 1 + (a.H - 1) * a.ams.stride[0] + (a.W - 1) * a.ams.stride[1] +
-                      (a.C - 1) * a.ams.stride[2] + (a.N - 1) * a.ams.stride[3];
-    return (uint32_t)(n * (int64_t)sizeof(float));
-}
-
-template <int NW, bool WRITE_X, bool GENERAL, bool EMIT_T>
+// MODE: 0 = plain epilogue; 1 = L1Weight array (+ NoBndryCross, AddMaskSim); 2 = NoBndryCross
+// and / or AddMaskSim without a weight array (no weight loads).
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
+    constexpr bool GENERAL = MODE != 0;
     constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -352,23 +346,25 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     // weight of element (h, x, c, n, k): wave-uniform row pointer + 32-bit lane offset
     int wlane = 0;
     const int ws4 = (int)a.wl1.stride[4];
-    if (GENERAL) {   // (the launcher substitutes a constant 1 with zero strides for "no weights")
+    if (MODE == 1) {
         const int c = cn / a.N, n = cn % a.N;
         wlane = (int)(c * a.wl1.stride[2] + n * a.wl1.stride[3] + k * a.wl1.stride[4]);
     }
     const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
     const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
     // AddMaskSim (cbpdn.py:2378-2412): the lanes whose filter pair holds the impulse slice
-    // ams_k read the mask of their (c, n); every other lane (and every lane without a mask)
-    // sends an out-of-range offset, which costs no memory traffic and returns 0.
-    const bool aml = GENERAL && a.ams.ptr != nullptr && pv && (k | 1) == (a.ams_k | 1);
+    // ams_k read the mask of their (c, n) and row: one 32-bit word per thread, bit n1 for the
+    // pixel x = NW n1 + w (ams_bits, packed by launch_ams_pack); every other lane (and every
+    // lane without a mask) sends an out-of-range offset, which costs no memory traffic and
+    // returns 0.
+    const bool aml = GENERAL && a.ams_bits != nullptr && pv && (k | 1) == (a.ams_k | 1);
     const bool am_e[2] = {aml && !(a.ams_k & 1), aml && (a.ams_k & 1)};
-    const BufRsrc Mb = make_rsrc(a.ams.ptr, am1_bytes(a));
-    const int mvoff = aml ? (int)(((cn / a.N) * a.ams.stride[2] + (cn % a.N) * a.ams.stride[3]) *
-                                  (int64_t)sizeof(float))
-                          : (int)0x80000000;
-    const int mrow = (int)(h * a.ams.stride[0] * (int64_t)sizeof(float));
-    const int mpix = (int)(a.ams.stride[1] * (int64_t)sizeof(float));
+    uint32_t mbits = 0u;
+    if (GENERAL) {
+        const BufRsrc Mb = make_rsrc(a.ams_bits, a.ams_bits ? (uint32_t)((int64_t)a.H * CN * NW * 4) : 0u);
+        const int mvoff = aml ? cn * NW * 4 : (int)0x80000000;
+        mbits = __builtin_bit_cast(uint32_t, sa_buf_load1(Mb, mvoff, (h * CN * NW + w) * 4));
+    }
     float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f;
     constexpr int B = EMIT_T ? 2 : 4;   // pixels per batch (Y, U of the next batch are in flight)
     cf yb[2][B], ub[2][B];
@@ -396,19 +392,18 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
             // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
             // epilogue into dozens of blocks and the register allocator spills the tile)
             const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
-            float mkeep = 1.f;
-            if (GENERAL) mkeep = sa_buf_load1(Mb, mvoff, mrow + xw * mpix) != 0.f ? 0.f : 1.f;
+            const float mkeep = (GENERAL && ((mbits >> n1) & 1u)) ? 0.f : 1.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float ax = al * xs[e] + oma * yo[e];
                 const bool am = GENERAL && am_e[e];
                 float wt = 1.f;
-                if (GENERAL) {
+                if (MODE == 1) {
                     const float *wrow = a.wl1.ptr + (int64_t)h * a.wl1.stride[0] +
                                         (int64_t)xw * a.wl1.stride[1];
                     wt = wrow[wlane + e * ws4];
-                    wt = am ? 0.f : wt;
                 }
+                if (GENERAL) wt = am ? 0.f : wt;
                 float y1 = soft1(ax + uo[e], a.thr * wt);
                 if (nonneg && !am && y1 < 0.f) y1 = 0.f;
                 if (GENERAL) y1 *= am ? mkeep : keep;
@@ -578,27 +573,62 @@ static const float *device_one() {
 }
 
 template <int NW, bool EMIT>
-static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a_in, dim3 grid) {
+static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
     static bool attr_set = false;
     if (!attr_set) {
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, false, EMIT>);
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, false, EMIT>);
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, true, EMIT>);
-        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, true, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 0, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 1, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 1, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 2, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 2, EMIT>);
         attr_set = true;
     }
-    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY) || a_in.ams.ptr;
-    RowsPostArgs<float> a = a_in;
-    if (general && !a.wl1.ptr) a.wl1.ptr = device_one();   // strides are already all zero
+    const int mode = a.wl1.ptr != nullptr ? 1 : (((a.flags & F_NOBNDRY) || a.ams_bits) ? 2 : 0);
     const dim3 block(NW * 64);
-    if (a.x && general)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, true, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
-    else if (a.x)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, false, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
-    else if (general)
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, true, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
-    else
-        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, false, EMIT>), grid, block, rows_lds_bytes(NW), st, a);
+    const size_t lds = rows_lds_bytes(NW);
+    if (a.x) {
+        if (mode == 1) hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, 1, EMIT>), grid, block, lds, st, a);
+        else if (mode == 2) hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, 2, EMIT>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, 0, EMIT>), grid, block, lds, st, a);
+    } else {
+        if (mode == 1) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 1, EMIT>), grid, block, lds, st, a);
+        else if (mode == 2) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 2, EMIT>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT>), grid, block, lds, st, a);
+    }
+}
+
+// ams_bits[(h * CN + cn) * NW + w], bit n1 = (mask(h, NW n1 + w, c, n) != 0)
+__global__ void __launch_bounds__(256) ams_pack_kernel(Weight<float> m, uint32_t *bits, int H, int W,
+                                                       int C, int N, int NW) {
+    const int64_t total = (int64_t)H * C * N * NW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % NW);
+        const int cn = (int)((i / NW) % (C * N));
+        const int h = (int)(i / ((int64_t)NW * C * N));
+        const int c = cn / N, n = cn % N;
+        uint32_t b = 0u;
+        for (int n1 = 0; n1 < W / NW; ++n1) {
+            const int x = NW * n1 + w;
+            const float v = m.ptr[h * m.stride[0] + x * m.stride[1] + c * m.stride[2] + n * m.stride[3]];
+            if (v != 0.f) b |= 1u << n1;
+        }
+        bits[i] = b;
+    }
+}
+
+template <> void launch_ams_pack<float>(hipStream_t st, const Weight<float> &mask, uint32_t *bits,
+                                        int H, int W, int C, int N) {
+    const int NW = W / kN1;
+    const int64_t total = (int64_t)H * C * N * NW;
+    hipLaunchKernelGGL(ams_pack_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 65535)),
+                       dim3(256), 0, st, mask, bits, H, W, C, N, NW);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_ams_pack<double>(hipStream_t, const Weight<double> &, uint32_t *, int, int,
+                                         int, int) {
+    throw Error(-1, "the fused row kernels are float32 only");
 }
 
 template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostArgs<float> &a) {
