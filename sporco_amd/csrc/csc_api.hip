@@ -223,7 +223,12 @@ template <typename T> struct Csc : CscBase {
     uint32_t *ams_bits = nullptr;   // AddMaskSim mask, one bit per pixel (csc_rows.h)
     bool ams_bits_valid = false;
     T *cns_m = nullptr, *cns_yold = nullptr;
-    bool cns_active = false;   // setcoef then keeps Zf in the natural layout this D-step reads
+    bool cns_active = false;   // a consensus D-step lives on this handle
+    T *gramz_t = nullptr;      // its fused path: sum_k |Zf|^2 per row of the tile-major Zf
+    bool gramz_valid = false;
+    bool cns_fused() const {
+        return rows_ok && fused && !std::getenv("SPORCO_AMD_CNS_GENERIC");
+    }
     bool ism_valid = false;
     double ism_rho = 0.0;
     int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
@@ -364,7 +369,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
@@ -680,7 +685,10 @@ template <typename T> struct Csc : CscBase {
 
     void upload(int var, const void *src) override {
         if (is_pgm_iterate(var)) pgm_leave_tiled();
-        if (var == SPORCO_AMD_VAR_ZF) zf_tiled = false;
+        if (var == SPORCO_AMD_VAR_ZF) {
+            zf_tiled = false;
+            gramz_valid = false;
+        }
         if (var == SPORCO_AMD_VAR_X) {
             x_written();
         } else if (var == SPORCO_AMD_VAR_XF) {
@@ -884,9 +892,9 @@ template <typename T> struct Csc : CscBase {
 
     // X = irfft_W(tile-major spectrum in the Xf buffer) / (H W): the row pass of
     // rows_inv_prox_fwd with a zero threshold (soft(v, 0) = v) and no forward half
-    void rows_inverse_to(T *Xout) {
+    void rows_inverse_to(T *Xout, const cx<T> *t_in = nullptr) {
         RowsProxArgs<T> ra;
-        ra.t_in = cv(SPORCO_AMD_VAR_XF);
+        ra.t_in = t_in ? t_in : cv(SPORCO_AMD_VAR_XF);
         ra.t_out = nullptr;
         ra.x = Xout;
         ra.twA = twRows;
@@ -1436,7 +1444,9 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
-        if (rows_ok && fused && !cns_active) {
+        gramz_valid = false;
+        // (the generic consensus D-step reads Zf in the natural layout)
+        if (rows_ok && fused && !(cns_active && !cns_fused())) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;
             ra.y = rv(var);
@@ -1620,7 +1630,12 @@ template <typename T> struct Csc : CscBase {
         require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        need_natural(SPORCO_AMD_VAR_ZF);
+        const bool fusedx = cns_fused();
+        if (fusedx) {
+            if (!zf_tiled) relayout(SPORCO_AMD_VAR_ZF, true), zf_tiled = true;
+        } else {
+            need_natural(SPORCO_AMD_VAR_ZF);
+        }
         const int64_t npixr = (int64_t)H * W;
         T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_CX), *U = rv(SPORCO_AMD_VAR_CU);
         cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF);
@@ -1631,6 +1646,51 @@ template <typename T> struct Csc : CscBase {
         }
         // xstep (ccmod.py:766-778): X_n = irfftn(SM(Zf_n, rho, conj(Zf_n) Sf_n + rho rfftn(Y - U_n)));
         // Y is broadcast over the images by the row transform itself
+        if (fusedx) {
+            // the three register-resident kernels of the sparse coding step, with the
+            // coefficient spectra of each (frequency, image) tile in the dictionary's place
+            if (!gramz_t) SA_HIP(hipMalloc((void **)&gramz_t, sizeof(T) * npix * CN));
+            if (!gramz_valid) {
+                ProfScope ps(prof, PS_OTHER);
+                launch_gram_rows<T>(st, Zf, gramz_t, npix * CN, K);
+                gramz_valid = true;
+            }
+            RowsFwdArgs<T> ra;
+            ra.y = Y;
+            ra.u = U;
+            ra.s2 = (T)p.u_scale;
+            ra.t = cns_f;
+            ra.twA = twRows;
+            ra.H = H;
+            ra.W = W;
+            ra.CN = CN;
+            ra.K = K;
+            ra.P = P;
+            ra.y_bcast = 1;
+            {
+                ProfScope ps(prof, PS_ROWS_FWD);
+                launch_rows_fwd<T>(st, ra);
+            }
+            FusedColsArgs<T> fa;
+            fa.t = cns_f;
+            fa.dft = Zf;
+            fa.sft = sft;
+            fa.gramt = gramz_t;
+            fa.twA = twA;
+            fa.twB = twB;
+            fa.rho = (T)p.rho;
+            fa.H = H;
+            fa.W = W;
+            fa.CN = CN;
+            fa.K = K;
+            fa.partials = part_f;
+            fa.per_tile = 1;
+            {
+                ProfScope ps(prof, PS_FUSED_COLS);
+                launch_fused_cols<T>(st, fa);
+            }
+            rows_inverse_to(X, cns_f);
+        } else {
         {
             ProfScope ps(prof, PS_FFT_R2C);
             fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, cns_f, H, P, (int64_t)W * P, P,
@@ -1647,6 +1707,7 @@ template <typename T> struct Csc : CscBase {
                                CN, K, W, false, false, part_a, nullptr, true);
         }
         inv2(cns_f, work_buf(), X, P);
+        }
         // relax + ystep: Y = Pcn(mean_n(alpha X_n + (1 - alpha) Y + U_n))
         SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * K, hipMemcpyDeviceToDevice, st));
         {
@@ -1678,14 +1739,40 @@ template <typename T> struct Csc : CscBase {
         // the consensus dictionary's spectrum (for the objective, getdict / setdict_from_dstep)
         fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
         if (p.flags & F_OBJ) {
-            {
-                ProfScope ps(prof, PS_OTHER);
-                nb = launch_ccmod_grad<T>(st, Zf, cv(SPORCO_AMD_VAR_DXF), cv(SPORCO_AMD_VAR_SF),
-                                          nullptr, npix, CN, K, W, part_a);
-            }
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
             const double scales[1] = {1.0 / ((double)H * W)};
-            finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
+            if (zf_tiled) {
+                if (!gpart) {
+                    ccmod_groups = (int)ceil_div(768, Wf);
+                    if (ccmod_groups > CN) ccmod_groups = CN;
+                    if (ccmod_groups > 8) ccmod_groups = 8;
+                    SA_HIP(hipMalloc((void **)&gpart, sizeof(cx<T>) * npix * K * ccmod_groups));
+                }
+                CcmodTiledArgs<T> ga;
+                ga.zf = Zf;
+                ga.d = cv(SPORCO_AMD_VAR_DXF);
+                ga.sft = sft;
+                ga.gpart = nullptr;
+                ga.H = H;
+                ga.W = W;
+                ga.CN = CN;
+                ga.K = K;
+                ga.G = ccmod_groups;
+                ga.partials = part_a;
+                int64_t nwg;
+                {
+                    ProfScope ps(prof, PS_PGM);
+                    nwg = launch_ccmod_grad_tiled<T>(st, ga);
+                }
+                finalize(part_a + 1, (int)nwg, 4, 1, slots, scales, out_dev);
+            } else {
+                {
+                    ProfScope ps(prof, PS_OTHER);
+                    nb = launch_ccmod_grad<T>(st, Zf, cv(SPORCO_AMD_VAR_DXF), cv(SPORCO_AMD_VAR_SF),
+                                              nullptr, npix, CN, K, W, part_a);
+                }
+                finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
+            }
             int nbc;
             {
                 ProfScope ps(prof, PS_OTHER);

@@ -46,6 +46,10 @@ template <typename T> struct FusedColsArgs {
     // it is stored to coef_out[tile][f] for the update of the remaining filters.
     int Kv = 0;
     cx<T> *coef_out = nullptr;
+    // per_tile: dft is tile-major like t ([Wf][CN][H][K]) and gramt is [Wf][CN][H] -- one rank-one
+    // term per (frequency, image), the X-step of the consensus dictionary update
+    // (admm/ccmod.py:766-778) with the coefficient spectra in the role of the dictionary.
+    int per_tile = 0;
     const T *g1t = nullptr;
     T *g1t_out = nullptr;
     const T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
@@ -57,6 +61,9 @@ template <typename T> struct FusedColsArgs {
 template <typename T>
 void launch_tail_inner(hipStream_t st, const FusedColsArgs<T> &a, const cx<T> *sft, cx<T> *sft_eff);
 template <typename T> void launch_tail_update(hipStream_t st, const FusedColsArgs<T> &a);
+// out[row] = sum_k |z[row, k]|^2 over rows of K contiguous filters (one wave per row): the
+// per_tile gram of a tile-major spectrum.
+template <typename T> void launch_gram_rows(hipStream_t st, const cx<T> *z, T *out, int64_t nrows, int K);
 // g1t_out[wf][h] from dft, ghh, ghw, wg, mu, rho.
 template <typename T> void launch_grad_g1(hipStream_t st, const FusedColsArgs<T> &a);
 

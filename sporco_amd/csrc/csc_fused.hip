@@ -48,7 +48,9 @@ constexpr size_t fused_lds_bytes(int NW, int LP) {
 // and a second partial per tile, the weighted sum of wg GHGf |xf|^2 (cbpdn.py:1204-1214).
 // KRT (with KC = 64): the kernel owns 64 filters of rows that are a.K > 64 filters long
 // (FusedColsArgs::Kv): run-time row stride, all lanes valid, multipliers stored.
-template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false>
+// PER_TILE (with KC = 64): the D-side operands (dft, gramt) are those of the tile, not of its
+// row frequency (FusedColsArgs::per_tile).
+template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false>
 __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
     constexpr int H = N1 * NW;
     constexpr int J = N1 / NW;   // stage-2 lines per thread (each NW points)
@@ -78,13 +80,14 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     // shared 32-bit lane offset and scalar row offsets, so the 3*N1 row addresses
     // cost no vector registers (the tile itself needs 2*N1 of them)
     const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
-    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, (uint32_t)(H * K * sizeof(cf)));
+    const int dsel = PER_TILE ? tile : wf;
+    const BufRsrc Db = make_rsrc(a.dft + (int64_t)dsel * H * K, (uint32_t)(H * K * sizeof(cf)));
     const BufRsrc Cb = make_rsrc((KRT && a.coef_out) ? a.coef_out + (int64_t)tile * H : nullptr,
                                  (KRT && a.coef_out) ? (uint32_t)(H * sizeof(cf)) : 0u);
     const int cvoff = k == 0 ? 0 : (int)0x80000000;
     const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
     const cf *S = a.sft + (int64_t)tile * H + w;
-    const float *G = (GRAD ? a.g1t : a.gramt) + (int64_t)wf * H + w;
+    const float *G = (GRAD ? a.g1t : a.gramt) + (int64_t)dsel * H + w;
     const float *GH = a.ghh + w;
     const cf *twA = a.twA + w * N1;                           // W_H^(w * brev(i)),      i < N1
     const cf *twB = a.twB + w * N1;                           // W_H^((w + NW j) * h2), [j][h2]
@@ -557,17 +560,17 @@ template <> bool fused_cols_supported<float>(int H, int K) {
 }
 template <> bool fused_cols_supported<double>(int, int) { return false; }
 
-template <int N1, int NW, int LP, int KC, bool GRAD, bool KRT = false>
+template <int N1, int NW, int LP, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false>
 static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
     static bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT>),
+            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
-    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT>),
+    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE>),
                        dim3((unsigned)(wf_groups * 8 * a.CN)), dim3(NW * 64),
                        fused_lds_bytes(NW, LP), st, a);
 }
@@ -575,7 +578,11 @@ static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int
 template <int N1, int NW, int LP>
 static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
     const bool grad = a.g1t != nullptr;
-    if (a.Kv == 64 && a.K > 64 && !grad) {
+    if (a.per_tile) {
+        SA_REQUIRE(!grad, "per-tile operands do not combine with the gradient term");
+        if (a.K == 64) launch_fused_inst<N1, NW, LP, 64, false, false, true>(st, a, ntiles);
+        else launch_fused_inst<N1, NW, LP, 0, false, false, true>(st, a, ntiles);
+    } else if (a.Kv == 64 && a.K > 64 && !grad) {
         launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
     } else if (a.K == 64) {
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
@@ -598,6 +605,26 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
         launch_fused_k<32, 16, 1>(st, a, ntiles);
     SA_HIP(hipGetLastError());
     return ntiles;
+}
+__global__ void __launch_bounds__(256) gram_rows_kernel(const cf *__restrict__ z,
+                                                        float *__restrict__ out, int64_t nrows,
+                                                        int K) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += cabs2(z[row * K + k]);
+    for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) out[row] = s;
+}
+template <> void launch_gram_rows<float>(hipStream_t st, const cx<float> *z, float *out,
+                                         int64_t nrows, int K) {
+    hipLaunchKernelGGL(gram_rows_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), 0, st, z, out,
+                       nrows, K);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_gram_rows<double>(hipStream_t, const cx<double> *, double *, int64_t, int) {
+    throw Error(-1, "the fused column kernel is float32 only");
 }
 template <> void launch_grad_g1<float>(hipStream_t st, const FusedColsArgs<float> &a) {
     const int64_t nrows = (int64_t)(a.W / 2 + 1) * a.H;

@@ -31,6 +31,7 @@ template <typename T> struct RowsFwdArgs {
     const cx<T> *twA;  // [NW][32]: exp(-2 pi i w brev5(i) / W)   (rows_twiddles)
     int H, W, CN, K;
     int64_t P;
+    int y_bcast = 0;   // y is (H, W, K), broadcast over the CN blocks (consensus D-step)
 };
 
 template <typename T> struct RowsPostArgs {

@@ -268,7 +268,7 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // ---------------------------------------------------------------------------
 // rows_fwd: T = rfft_W(Y - s2 U), tile-major
 // ---------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool BCAST>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a) {
     constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
@@ -285,10 +285,16 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     const int64_t rowoff = (int64_t)h * W * a.P;
     const uint32_t rowbytes = (uint32_t)((int64_t)W * a.P * sizeof(float));
     // (u may be null: a zero-length buffer then reads as zeros)
-    const BufRsrc Yb = make_rsrc(a.y + rowoff, rowbytes);
+    // BCAST: y is (H, W, K) and is broadcast over the (c, n) blocks of K filters -- the
+    // consensus dictionary update transforms Y[.., k] - s U[.., n, k] (admm/ccmod.py:768)
+    const BufRsrc Yb = BCAST ? make_rsrc(a.y + (int64_t)h * W * a.K,
+                                         (uint32_t)((int64_t)W * a.K * sizeof(float)))
+                             : make_rsrc(a.y + rowoff, rowbytes);
     const BufRsrc Ub = a.u ? make_rsrc(a.u + rowoff, rowbytes) : make_rsrc(a.y, 0u);
     const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;  // masked lanes read 0
     const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
+    const int yvoff = BCAST ? (pv ? k * (int)sizeof(float) : (int)0x80000000) : voff;
+    const int ypixbytes = BCAST ? a.K * (int)sizeof(float) : pixbytes;
     const float s2 = a.s2;
     cf v[N1];
 #pragma unroll
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
         for (int i = 0; i < N1 / 2; ++i) {
             const int n1 = half * (N1 / 2) + i;
             const int soff = (NW * n1 + w) * pixbytes;
-            yv[i] = buf_load_cf(Yb, voff, soff);
+            yv[i] = buf_load_cf(Yb, yvoff, (NW * n1 + w) * ypixbytes);
             uv[i] = buf_load_cf(Ub, voff, soff);
         }
 #pragma unroll
@@ -546,15 +552,20 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     static bool attr_set = false;
     if (!attr_set) {
-        set_lds_attr<8>(&rows_fwd_kernel<8>);
-        set_lds_attr<16>(&rows_fwd_kernel<16>);
+        set_lds_attr<8>(&rows_fwd_kernel<8, false>);
+        set_lds_attr<16>(&rows_fwd_kernel<16, false>);
+        set_lds_attr<8>(&rows_fwd_kernel<8, true>);
+        set_lds_attr<16>(&rows_fwd_kernel<16, true>);
         attr_set = true;
     }
     const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
-    if (a.W == 256)
-        hipLaunchKernelGGL((rows_fwd_kernel<8>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
-    else
-        hipLaunchKernelGGL((rows_fwd_kernel<16>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+    if (a.W == 256) {
+        if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<8, true>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
+        else hipLaunchKernelGGL((rows_fwd_kernel<8, false>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
+    } else {
+        if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<16, true>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+        else hipLaunchKernelGGL((rows_fwd_kernel<16, false>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+    }
     SA_HIP(hipGetLastError());
 }
 template <> void launch_rows_fwd<double>(hipStream_t, const RowsFwdArgs<double> &) {

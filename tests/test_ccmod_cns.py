@@ -85,3 +85,49 @@ def test_dictlearn_consensus_trace(backend, name, dt, tol):
     for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'DPrRsdl', 'DDlRsdl',
               'DRho'):
         assert rel_l2(np.asarray(getattr(its, f), dtype=float), g['it_' + f]) < tol, f
+
+
+@pytest.mark.parametrize('H,K,N', [(256, 4, 1), pytest.param(256, 4, 3, marks=pytest.mark.gpu),
+                                   pytest.param(256, 64, 8, marks=pytest.mark.gpu)])
+def test_consensus_on_fused_kernels(backend, H, K, N):
+    """The consensus X-step through rows_fwd (broadcast Y) / the register-resident column
+    kernel with per-image rank-one terms / the row inverse, against the float64 oracle and
+    against the generic kernel chain of the same library."""
+    import os
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import ccmod
+    rng = np.random.RandomState(H + K)
+    Z = (rng.randn(H, H, 1, N, K) * (rng.rand(H, H, 1, N, K) > 0.8)).astype(np.float32)
+    S = rng.randn(H, H, N).astype(np.float32)
+    dsz = (6, 6, K)
+    optd = {'MaxMainIter': 4, 'RelStopTol': 0.0, 'rho': 5.0}
+
+    def run(generic):
+        if generic:
+            os.environ['SPORCO_AMD_CNS_GENERIC'] = '1'
+        try:
+            c = ccmod.ConvCnstrMOD_Consensus(Z, S, dsz, ccmod.ConvCnstrMOD_Consensus.Options(optd))
+            c.solve()
+        finally:
+            os.environ.pop('SPORCO_AMD_CNS_GENERIC', None)
+        return c
+
+    c = run(False)
+    assert c.dev.uses_fused_rows()
+    if K * N <= 16:
+        ref = orc.admm_ccmod_cns(Z, S.reshape(H, H, 1, N, 1), dsz, dtype=np.float64, maxiter=4,
+                                 rho=5.0, rel_tol=0.0)
+        assert rel_l2(c.Y, ref['Y']) < 1e-5
+        assert rel_l2(c.U, ref['U']) < 1e-5
+        its = c.getitstat()
+        for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
+            assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
+    if backend == 'hostsim':
+        return
+    c0 = run(True)
+    assert rel_l2(c.Y, c0.Y) < 1e-5 and rel_l2(c.U, c0.U) < 1e-5 and rel_l2(c.X, c0.X) < 1e-5
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
+        assert rel_l2(np.asarray(getattr(c.getitstat(), f), float),
+                      np.asarray(getattr(c0.getitstat(), f), float)) < 1e-5, f
+    # (Y is a projected point: the constraint violation is float32 rounding noise)
+    assert max(c.getitstat().Cnstr) < 1e-5 and max(c0.getitstat().Cnstr) < 1e-5
