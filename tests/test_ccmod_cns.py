@@ -100,7 +100,7 @@ def test_consensus_on_fused_kernels(backend, H, K, N):
     Z = (rng.randn(H, H, 1, N, K) * (rng.rand(H, H, 1, N, K) > 0.8)).astype(np.float32)
     S = rng.randn(H, H, N).astype(np.float32)
     dsz = (6, 6, K)
-    optd = {'MaxMainIter': 4, 'RelStopTol': 0.0, 'rho': 5.0}
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'rho': 5.0}
 
     def run(generic):
         if generic:
@@ -115,7 +115,7 @@ def test_consensus_on_fused_kernels(backend, H, K, N):
     c = run(False)
     assert c.dev.uses_fused_rows()
     if K * N <= 16:
-        ref = orc.admm_ccmod_cns(Z, S.reshape(H, H, 1, N, 1), dsz, dtype=np.float64, maxiter=4,
+        ref = orc.admm_ccmod_cns(Z, S.reshape(H, H, 1, N, 1), dsz, dtype=np.float64, maxiter=3,
                                  rho=5.0, rel_tol=0.0)
         assert rel_l2(c.Y, ref['Y']) < 1e-5
         assert rel_l2(c.U, ref['U']) < 1e-5

@@ -37,12 +37,12 @@ def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     if backend == 'hostsim' and W == 512:
         pytest.skip("W = 512 row kernels run under the simulator in test_fused_xstep; here GPU only")
     D, S = problem(H, W, K, N, seed=H + W)
-    optd = {'MaxMainIter': 4, 'RelStopTol': 0.0, 'L': 50.0}
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L': 50.0}
     b = make(D, S, optd)
     assert b.dev.uses_fused_rows() and b._fused_ok()
     X = b.solve()
     ref = orc.pgm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
-                        dtype=np.float64, maxiter=4, L=50.0, rel_tol=0.0)
+                        dtype=np.float64, maxiter=3, L=50.0, rel_tol=0.0)
     assert rel_l2(X, ref['X']) < 1e-5
     its = b.getitstat()
     for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl'):
@@ -53,7 +53,7 @@ def test_fused_pgm_matches_oracle(backend, H, W, K, N):
         # after the layout round trip the solver continues in step with the oracle
         b.solve()
         ref8 = orc.pgm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
-                             dtype=np.float64, maxiter=8, L=50.0, rel_tol=0.0)
+                             dtype=np.float64, maxiter=6, L=50.0, rel_tol=0.0)
         assert rel_l2(b.X, ref8['X']) < 1e-5
         return       # (the comparison with the generic composition runs on the GPU)
     b0 = make(D, S, optd, generic=True)
