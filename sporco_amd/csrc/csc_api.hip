@@ -213,6 +213,12 @@ template <typename T> struct Csc : CscBase {
     // the coefficient maps one (C = 1); X-step by iterated Sherman-Morrison (ism_*).
     int Cd = 1, Cs, CNs;
     cx<T> *ism_gam = nullptr, *ism_del = nullptr, *ism_mm = nullptr;
+    // ... and on the fast-path shapes the register-resident column kernel of csc_fused_mc.hip
+    bool fused_mc = false;
+    cx<T> *dft_mc = nullptr, *sft_mc = nullptr;
+    T *bt_mc = nullptr;
+    bool binv_valid = false;
+    double binv_rho = 0.0;
     // consensus D-step scratch: spectrum of the per-image copies, per-(pixel, image) gram of
     // the coefficient spectra, mean / previous-Y buffers (dictionary sized)
     cx<T> *cns_f = nullptr;
@@ -335,6 +341,20 @@ template <typename T> struct Csc : CscBase {
         fused = Cd == 1 && fused_cols_supported<T>(H, K) && K % 2 == 0 &&
                 !std::getenv("SPORCO_AMD_UNFUSED");
         fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
+        fused_mc = Cd > 1 && fused_mc_supported<T>(H, K, Cd) && K % 2 == 0 &&
+                   !std::getenv("SPORCO_AMD_UNFUSED");
+        if (fused_mc) {
+            SA_HIP(hipMalloc((void **)&dft_mc, sizeof(cx<T>) * npix * Cd * K));
+            SA_HIP(hipMalloc((void **)&sft_mc, sizeof(cx<T>) * npix * CNs));
+            SA_HIP(hipMalloc((void **)&bt_mc, sizeof(T) * npix * 2 * Cd * Cd));
+            SA_HIP(hipMalloc((void **)&part_f, sizeof(double) * 2 * (int64_t)Wf * CN));
+            SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * H));
+            SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * H));
+            std::vector<cx<T>> ta(H), tb(H);
+            fused_twiddles<T>(H, K, ta.data(), tb.data());
+            SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
+        }
         if (fused_slabs)
             SA_HIP(hipMalloc((void **)&qpart, sizeof(cx<T>) * (int64_t)Wf * CN * ((K + 63) / 64) * H));
         if (fused || fused_slabs) {
@@ -349,7 +369,7 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
             SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
         }
-        rows_ok = (fused || fused_slabs) && rows_supported<T>(W, K) &&
+        rows_ok = (fused || fused_slabs || fused_mc) && rows_supported<T>(W, K) &&
                   !std::getenv("SPORCO_AMD_OLD_ROWS");
         if (rows_ok) {
             SA_HIP(hipMalloc((void **)&twRows, sizeof(cx<T>) * W));
@@ -369,7 +389,7 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
+                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
@@ -415,7 +435,7 @@ template <typename T> struct Csc : CscBase {
 
     void sync() override { SA_HIP(hipStreamSynchronize(st)); }
     int query(int what) override {
-        if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs) ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && fused) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
@@ -456,6 +476,12 @@ template <typename T> struct Csc : CscBase {
 
     // ---- tile-major operands of the fused X-step -----------------------------------
     void refresh_fused_dict() {
+        if (fused_mc) {
+            ProfScope ps(prof, PS_OTHER);
+            launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_DF), dft_mc, H, Wf, (int64_t)Cd * K);
+            binv_valid = false;
+            return;
+        }
         if (!fused && !fused_slabs) return;
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_DF), dft, H, Wf, K);
@@ -463,6 +489,11 @@ template <typename T> struct Csc : CscBase {
         g1_valid = false;
     }
     void refresh_fused_signal() {
+        if (fused_mc) {
+            ProfScope ps(prof, PS_OTHER);
+            launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_SF), sft_mc, H, Wf, (int64_t)CNs);
+            return;
+        }
         if (!fused && !fused_slabs) return;
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_SF), sft, H, (int64_t)Wf * CN, 1);
@@ -737,6 +768,42 @@ template <typename T> struct Csc : CscBase {
     // column FFT + Sherman-Morrison + column IFFT on the tile-major spectrum in the
     // Xf buffer (csc_fused.h); the data-fidelity sum goes to out_dev when wanted
     void run_fused_cols(const sporco_amd_admm_params &p, double *out_dev) {
+        if (fused_mc) {
+            SA_REQUIRE(!(p.flags & (F_GRADREG | F_AMS | F_JOINT)),
+                       "this solver variant needs a single-channel dictionary");
+            if (!binv_valid || binv_rho != p.rho) {
+                ProfScope ps(prof, PS_OTHER);
+                launch_mc_binv<T>(st, dft_mc, bt_mc, npix, Cd, K, (T)p.rho);
+                binv_valid = true;
+                binv_rho = p.rho;
+            }
+            FusedMcArgs<T> ma;
+            ma.t = cv(SPORCO_AMD_VAR_XF);
+            ma.dft = dft_mc;
+            ma.sft = sft_mc;
+            ma.bt = bt_mc;
+            ma.twA = twA;
+            ma.twB = twB;
+            ma.rho = (T)p.rho;
+            ma.H = H;
+            ma.W = W;
+            ma.N = N;
+            ma.K = K;
+            ma.Cd = Cd;
+            ma.partials = part_f;
+            int64_t nt;
+            {
+                ProfScope ps(prof, PS_FUSED_COLS);
+                nt = launch_fused_cols_mc<T>(st, ma);
+            }
+            xf_tiled = true;
+            if (out_dev && (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
+                const int slots[1] = {SPORCO_AMD_OUT_DFID};
+                const double scales[1] = {1.0 / ((double)H * W)};
+                finalize(part_f, (int)nt, 1, 1, slots, scales, out_dev);
+            }
+            return;
+        }
         FusedColsArgs<T> fa;
         fa.t = cv(SPORCO_AMD_VAR_XF);
         fa.dft = dft;
@@ -941,7 +1008,8 @@ template <typename T> struct Csc : CscBase {
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         const bool gradreg = p.flags & F_GRADREG;
-        if ((fused || (fused_slabs && rows_ok && !gradreg)) && !(p.flags & F_XRRS)) {
+        if ((fused || (fused_slabs && rows_ok && !gradreg) || (fused_mc && rows_ok)) &&
+            !(p.flags & F_XRRS)) {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
             const int64_t tline = (int64_t)CN * H * K, tgrp = (int64_t)H * K;

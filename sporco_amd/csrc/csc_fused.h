@@ -82,6 +82,25 @@ template <typename T> bool fused_slabs_supported(int H, int K);
 template <typename T> void launch_cols_fwd_partial(hipStream_t st, const FusedSlabArgs<T> &a);
 template <typename T> int64_t launch_cols_sm_apply_inv(hipStream_t st, const FusedSlabArgs<T> &a);
 
+// Multi-channel dictionary (Cd = 2..4 channels in D and S, one coefficient channel): the
+// column pass with the Cd rank-one terms in registers (csc_fused_mc.hip).  Woodbury form of the
+// system of sporco/admm/cbpdn.py:277-279: x = yuf + Df^H B (Sf - Df yuf), B = (rho I + Df Df^H)^-1.
+template <typename T> struct FusedMcArgs {
+    cx<T> *t;            // in/out as FusedColsArgs::t, tile-major [Wf][N][H][K]
+    const cx<T> *dft;    // Df tile-major [Wf][H][Cd][K]
+    const cx<T> *sft;    // Sf tile-major [Wf][H][Cd][N]
+    const T *bt;         // B  [Wf][H][Cd][Cd] complex (row-major), from launch_mc_binv
+    const cx<T> *twA, *twB;   // fused_twiddles
+    T rho;
+    int H, W, N, K, Cd;
+    double *partials;    // one double per tile: Parseval-weighted sum_c |Df.xf - Sf|^2
+};
+template <typename T> bool fused_mc_supported(int H, int K, int Cd);
+template <typename T> int64_t launch_fused_cols_mc(hipStream_t st, const FusedMcArgs<T> &a);
+// bt[row] = (rho I + Df Df^H)^-1 for the nrows = Wf * H frequency rows of dft
+template <typename T>
+void launch_mc_binv(hipStream_t st, const cx<T> *dft, T *bt, int64_t nrows, int Cd, int K, T rho);
+
 // Host tables twA, twB (H entries each) for fused_cols_supported shapes.
 template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB);
 // True when the register-resident column kernel handles this shape.

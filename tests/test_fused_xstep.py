@@ -456,3 +456,56 @@ def test_odd_filter_count_matches_unpadded(backend, K):
         assert rel_l2(getattr(b.getitstat(), f), getattr(b0.getitstat(), f)) < 1e-4, f
     assert rel_l2(b.X, b0.X) < 2e-5 and rel_l2(b.Xf, b0.Xf) < 2e-5
     assert rel_l2(b.reconstruct(), b0.reconstruct()) < 2e-5
+
+
+# ---------------------------------------------------------------------------
+# multi-channel dictionaries on the three-launch iteration (csc_fused_mc.hip)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('H,W,C,K,N', [(256, 256, 3, 4, 1),
+                                       pytest.param(256, 256, 2, 6, 2, marks=pytest.mark.gpu),
+                                       pytest.param(512, 256, 4, 8, 1, marks=pytest.mark.gpu),
+                                       pytest.param(512, 512, 3, 64, 3, marks=pytest.mark.gpu)])
+def test_fused_multichannel_dictionary(backend, H, W, C, K, N):
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(H + C + K)
+    D = rng.randn(4, 4, C, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1, 2), keepdims=True))
+    S = rng.randn(H, W, C, N).astype(np.float32)
+    iters = 2 if backend == 'hostsim' else 3
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
+    kw = {}
+    if backend == 'hostsim':
+        # (one rho: the wave-level reductions of the B-matrix kernel are slow to simulate)
+        optd.update({'rho': 4.0, 'AutoRho': {'Enabled': False}})
+        kw = dict(rho=4.0, auto_rho=False)
+
+    def run(unfused):
+        if unfused:
+            os.environ['SPORCO_AMD_UNFUSED'] = '1'
+        try:
+            b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+        finally:
+            os.environ.pop('SPORCO_AMD_UNFUSED', None)
+        b.solve()
+        return b
+
+    b = run(False)
+    assert b._dev.uses_fused_rows()
+    fields = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho')
+    if K * N * C <= 16:
+        ref = orc.admm_cbpdn(D.reshape(4, 4, C, 1, K), S.reshape(H, W, C, N, 1), 0.05,
+                             dtype=np.float64, maxiter=iters, rel_tol=0.0, **kw)
+        assert rel_l2(b.Y, ref['Y']) < 1e-5 and rel_l2(b.U, ref['U']) < 1e-5
+        assert rel_l2(b.X, ref['X']) < 1e-5
+        for f in fields:
+            assert rel_l2(getattr(b.getitstat(), f), ref[f]) < 1e-5, f
+    if backend == 'hostsim':
+        return
+    b0 = run(True)
+    assert not b0._dev.uses_fused_rows()
+    assert rel_l2(b.Y, b0.Y) < 1e-5 and rel_l2(b.X, b0.X) < 1e-5
+    assert rel_l2(b.Xf, b0.Xf) < 1e-5
+    assert rel_l2(b.reconstruct(), b0.reconstruct()) < 1e-5
+    for f in fields:
+        assert rel_l2(getattr(b.getitstat(), f), getattr(b0.getitstat(), f)) < 1e-5, f
