@@ -818,8 +818,10 @@ template <typename T> struct Csc : CscBase {
         fa.K = K;
         fa.partials = part_f;
         const bool gradreg = p.flags & F_GRADREG;
+        const bool tail_ok = fused_slabs && K - 64 <= kTailMax && !std::getenv("SPORCO_AMD_NO_TAIL");
         if (gradreg) {
-            SA_REQUIRE(fused, "the gradient-regularised column pass needs the K <= 64 kernel");
+            SA_REQUIRE(fused || tail_ok,
+                       "the gradient-regularised column pass needs the K <= 64 kernel");
             const GradTerm<T> gt = grad_term(p.mu);
             if (!g1t) SA_HIP(hipMalloc((void **)&g1t, sizeof(T) * npix));
             fa.ghh = gt.ghh;
@@ -837,7 +839,7 @@ template <typename T> struct Csc : CscBase {
             fa.g1t = g1t;
         }
         int64_t ntiles;
-        if (fused_slabs && K - 64 <= kTailMax && !gradreg && !std::getenv("SPORCO_AMD_NO_TAIL")) {
+        if (tail_ok) {
             // A handful of filters past 64 (the AddMaskSim impulse on a 64-filter dictionary):
             // they go through the generic column FFT, their inner products are folded into
             // Sf, and the register-resident kernel runs on the first 64 as if alone.
@@ -1008,7 +1010,8 @@ template <typename T> struct Csc : CscBase {
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         const bool gradreg = p.flags & F_GRADREG;
-        if ((fused || (fused_slabs && rows_ok && !gradreg) || (fused_mc && rows_ok)) &&
+        if ((fused || (fused_slabs && rows_ok && (!gradreg || grad_tail_ok())) ||
+             (fused_mc && rows_ok)) &&
             !(p.flags & F_XRRS)) {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
@@ -1126,6 +1129,11 @@ template <typename T> struct Csc : CscBase {
         finalize(part_a, nb, 1, 1, slots, scales, out_dev);
     }
 
+    // 64 < K <= 64 + kTailMax: the gradient-regularised column pass is available too
+    bool grad_tail_ok() const {
+        return fused_slabs && K - 64 <= kTailMax && !std::getenv("SPORCO_AMD_NO_TAIL");
+    }
+
     // the AddMaskSim mask, when the call asks for it (F_AMS)
     Weight<T> ams_of(const sporco_amd_admm_params &p) const {
         if (!(p.flags & F_AMS)) return Weight<T>();
@@ -1148,7 +1156,8 @@ template <typename T> struct Csc : CscBase {
 
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT)) && (fused || !(p.flags & F_GRADREG))) {
+        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT)) &&
+            (fused || grad_tail_ok() || !(p.flags & F_GRADREG))) {
             admm_iter_fused(p, out_dev);
             return;
         }

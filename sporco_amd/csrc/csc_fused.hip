@@ -193,6 +193,11 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
                 if constexpr (GRAD) {
                     const cf coef = cscale(sv[e] - cscale(qq, rho), sa_rcp(gv[e]));
                     obj += cabs2(coef);
+                    if constexpr (KRT) {
+                        constexpr int j = q * LP + jl;
+                        const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                        buf_store_cf(Cb, cvoff, (w + fo) * (int)sizeof(cf), coef);
+                    }
                     const cf xn = cscale(cscale(u[NW * jl + 4 * c + e], rho) + cmulc(d[e], coef),
                                          idd[e]);
                     rg += (hv[e] + gw) * cabs2(xn);
@@ -582,8 +587,9 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
         SA_REQUIRE(!grad, "per-tile operands do not combine with the gradient term");
         if (a.K == 64) launch_fused_inst<N1, NW, LP, 64, false, false, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 0, false, false, true>(st, a, ntiles);
-    } else if (a.Kv == 64 && a.K > 64 && !grad) {
-        launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
+    } else if (a.Kv == 64 && a.K > 64) {
+        if (grad) launch_fused_inst<N1, NW, LP, 64, true, true>(st, a, ntiles);
+        else launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
     } else if (a.K == 64) {
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false>(st, a, ntiles);
@@ -638,40 +644,66 @@ template <> void launch_grad_g1<double>(hipStream_t, const FusedColsArgs<double>
 // a few more than 64 filters: the column pass of the filters >= Kv (csc_fused.h)
 // ---------------------------------------------------------------------------
 // sft_eff[tile][f] = sft[tile][f] - sum_{k >= Kv} dft[wf][f][k] t[tile][f][k]
-__global__ void __launch_bounds__(256) tail_inner_kernel(const cf *__restrict__ t,
-                                                         const cf *__restrict__ dft,
+// (gradient-regularised system, a.g1t set: - rho sum_{k >= Kv} dft t / dd_k, with
+// dd_k = mu wg_k (ghh[f] + ghw[wf]) + rho as in the column kernel)
+__global__ void __launch_bounds__(256) tail_inner_kernel(const FusedColsArgs<float> a,
                                                          const cf *__restrict__ sft,
-                                                         cf *__restrict__ sft_eff, int64_t ntiles,
-                                                         int CN, int H, int K, int Kv) {
+                                                         cf *__restrict__ sft_eff, int64_t ntiles) {
+    const int H = a.H, K = a.K, Kv = a.Kv;
+    const bool grad = a.g1t != nullptr;
     const int64_t total = ntiles * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t tile = i / H;
         const int f = (int)(i - tile * H);
-        const int64_t wf = tile / CN;
-        const cf *d = dft + (wf * H + f) * K, *x = t + i * K;
+        const int64_t wf = tile / a.CN;
+        const cf *d = a.dft + (wf * H + f) * K, *x = a.t + i * K;
+        const float gh = grad ? a.ghh[f] + a.ghw[wf] : 0.f;
         cf q = mk<float>(0.f, 0.f);
-        for (int k = Kv; k < K; ++k) q = q + cmul(d[k], x[k]);
+        for (int k = Kv; k < K; ++k) {
+            cf p = cmul(d[k], x[k]);
+            if (grad) p = cscale(p, a.rho / (a.mu * (a.wg ? a.wg[k] : 1.f) * gh + a.rho));
+            q = q + p;
+        }
         sft_eff[i] = sft[i] - q;
     }
 }
 
-// t[tile][f][k] += conj(dft[wf][f][k]) coef[tile][f] for k >= Kv
-__global__ void __launch_bounds__(256) tail_update_kernel(cf *__restrict__ t,
-                                                          const cf *__restrict__ dft,
-                                                          const cf *__restrict__ coef,
-                                                          int64_t ntiles, int CN, int H, int K,
-                                                          int Kv) {
-    const int Kt = K - Kv;
-    const int64_t total = ntiles * H * Kt;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = Kv + (int)(i % Kt);
-        const int64_t row = i / Kt;          // tile * H + f
-        const int64_t tile = row / H;
-        const int f = (int)(row - tile * H);
-        const int64_t wf = tile / CN;
-        t[row * K + k] = t[row * K + k] + cmulc(dft[(wf * H + f) * K + k], coef[row]);
+// t[tile][f][k] += conj(dft[wf][f][k]) coef[tile][f] for k >= Kv; one workgroup per tile,
+// thread = column frequency.  Gradient-regularised system: t = (rho t + conj(dft) coef) / dd_k,
+// and the tail's share of the gradient term is added to the tile's second partial.
+__global__ void __launch_bounds__(512) tail_update_kernel(const FusedColsArgs<float> a) {
+    const int H = a.H, K = a.K, Kv = a.Kv;
+    const bool grad = a.g1t != nullptr;
+    const int64_t tile = blockIdx.x;
+    const int64_t wf = tile / a.CN;
+    const int Wf = a.W / 2 + 1;
+    double acc[1] = {0.0};
+    for (int f = threadIdx.x; f < H; f += blockDim.x) {
+        const int64_t row = tile * H + f;
+        const cf cf_ = a.coef_out[row];
+        const cf *d = a.dft + (wf * H + f) * K;
+        cf *x = a.t + row * K;
+        const float gh = grad ? a.ghh[f] + a.ghw[wf] : 0.f;
+        for (int k = Kv; k < K; ++k) {
+            if (grad) {
+                const float wk = a.wg ? a.wg[k] : 1.f;
+                const cf xn = cscale(cscale(x[k], a.rho) + cmulc(d[k], cf_),
+                                     1.f / (a.mu * wk * gh + a.rho));
+                x[k] = xn;
+                acc[0] += (double)(gh * wk * cabs2(xn));
+            } else {
+                x[k] = x[k] + cmulc(d[k], cf_);
+            }
+        }
+    }
+    if (grad) {
+        double *scratch = dyn_lds<double>();
+        block_sum_store<1>(acc, scratch, scratch + 12);   // (thread 0 writes, thread 0 reads)
+        if (threadIdx.x == 0) {
+            const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+            a.partials[2 * tile + 1] += scratch[12] * pw;
+        }
     }
 }
 
@@ -679,16 +711,12 @@ template <> void launch_tail_inner<float>(hipStream_t st, const FusedColsArgs<fl
                                           const cx<float> *sft, cx<float> *sft_eff) {
     const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(ntiles * a.H, 256), 65535);
-    hipLaunchKernelGGL(tail_inner_kernel, dim3(grid), dim3(256), 0, st, a.t, a.dft, sft, sft_eff,
-                       ntiles, a.CN, a.H, a.K, a.Kv);
+    hipLaunchKernelGGL(tail_inner_kernel, dim3(grid), dim3(256), 0, st, a, sft, sft_eff, ntiles);
     SA_HIP(hipGetLastError());
 }
 template <> void launch_tail_update<float>(hipStream_t st, const FusedColsArgs<float> &a) {
     const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
-    const unsigned grid =
-        (unsigned)std::min<int64_t>(ceil_div(ntiles * a.H * (a.K - a.Kv), 256), 65535);
-    hipLaunchKernelGGL(tail_update_kernel, dim3(grid), dim3(256), 0, st, a.t, a.dft, a.coef_out,
-                       ntiles, a.CN, a.H, a.K, a.Kv);
+    hipLaunchKernelGGL(tail_update_kernel, dim3((unsigned)ntiles), dim3(a.H), sizeof(double) * 16, st, a);
     SA_HIP(hipGetLastError());
 }
 template <> void launch_tail_inner<double>(hipStream_t, const FusedColsArgs<double> &,
