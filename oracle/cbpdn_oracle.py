@@ -421,7 +421,8 @@ def pgm_cbpdn(D, S, lmbda, dtype=np.float32, maxiter=50, L=500.0,
     S = np.asarray(S, dtype=dtype)
     H, W = S.shape[0], S.shape[1]
     K = D.shape[AX_K]
-    shpX = (H, W, S.shape[AX_C], S.shape[AX_N], K)
+    mcd = D.shape[AX_C] > 1        # multi-channel dictionary: one coefficient channel
+    shpX = (H, W, 1 if mcd else S.shape[AX_C], S.shape[AX_N], K)
     lmbda = dtype.type(lmbda)
     L = dtype.type(L)
     wl1 = np.asarray(wl1, dtype=dtype)
@@ -442,6 +443,8 @@ def pgm_cbpdn(D, S, lmbda, dtype=np.float32, maxiter=50, L=500.0,
             Yfprv = Yf.copy()
         # xstep: pgm.py:779-811
         gradf = np.conj(Df) * (inner(Df, Yf, axis=AX_K) - Sf)
+        if mcd:
+            gradf = np.sum(gradf, axis=AX_C, keepdims=True)   # pgm/cbpdn.py:277-279
         Vf = Yf - (1.0 / L) * gradf
         V = irfftn2(Vf.astype(complex_dtype(dtype)), (H, W))
         X = prox_l1(V, (lmbda / L) * wl1)

@@ -390,6 +390,8 @@ def gen_mcdict():
     admm_case('admm_mcdict_single_nonneg_f64', D, S1, 0.05,
               {'MaxMainIter': 20, 'NonNegCoef': True, 'AuxVarObj': True,
                'rho': 2.0, 'AutoRho': {'Enabled': False}})
+    # the FISTA solver with the same kind of dictionary (pgm/cbpdn.py:263-286, sum over channels)
+    pgm_case('pgm_mcdict_f64', D, S, 0.1, {'MaxMainIter': 30, 'L': 500.0})
     g = {}
     # the primitive itself, on random data (4 channels, 6 filters)
     ah = np.random.randn(7, 5, 4, 1, 6) + 1j * np.random.randn(7, 5, 4, 1, 6)

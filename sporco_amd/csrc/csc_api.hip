@@ -1393,15 +1393,18 @@ template <typename T> struct Csc : CscBase {
     }
 
     void pgm_grad(int var, double *out_dev) override {
-        require_single_channel_dict();
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_grad needs a frequency-domain variable");
         before_read(var);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
-            nb = launch_pgm_grad<T>(st, cv(var), cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF),
-                                    cv(SPORCO_AMD_VAR_GF), npix, CN, K, W, part_a);
+            nb = Cd > 1 ? launch_mc_pgm_grad<T>(st, cv(var), cv(SPORCO_AMD_VAR_DF),
+                                                cv(SPORCO_AMD_VAR_SF), cv(SPORCO_AMD_VAR_GF), npix,
+                                                Cd, N, K, W, part_a)
+                        : launch_pgm_grad<T>(st, cv(var), cv(SPORCO_AMD_VAR_DF),
+                                             cv(SPORCO_AMD_VAR_SF), cv(SPORCO_AMD_VAR_GF), npix, CN,
+                                             K, W, part_a);
         }
         const int slots[2] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID};
         const double scales[2] = {0.5, 1.0 / ((double)H * W)};
@@ -1409,15 +1412,14 @@ template <typename T> struct Csc : CscBase {
     }
 
     void pgm_eval(int var, double *out_dev) override {
-        require_single_channel_dict();
         require_ready();
         SA_REQUIRE(var_is_complex(var), "pgm_eval needs a frequency-domain variable");
         before_read(var);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
-            launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(var), innerb, npix, CN, K);
-            nb = launch_pair_stats<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), nullptr, npix, CN, W, part_a);
+            inner_df(cv(var));
+            nb = launch_pair_stats<T>(st, innerb, cv(SPORCO_AMD_VAR_SF), nullptr, npix, CNs, W, part_a);
         }
         // partial layout per block: [0] weighted |d|^2, [1] Re<d,g>, [2] |d|^2, [3] |g|^2
         const int s0[1] = {SPORCO_AMD_PGM_DFID};
@@ -1428,7 +1430,7 @@ template <typename T> struct Csc : CscBase {
         finalize(part_a + 2, nb, 4, 1, s2, c2, out_dev);
         {
             ProfScope ps(prof, PS_PGM);
-            nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CN, W, part_b);
+            nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CNs, W, part_b);
         }
         const int s3[1] = {SPORCO_AMD_PGM_HESS};
         const double c3[1] = {1.0};

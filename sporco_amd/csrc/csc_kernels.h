@@ -205,6 +205,10 @@ int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *d
                      const cx<T> *sf, const cx<T> *gam, const cx<T> *del, const cx<T> *mm, T rho,
                      int64_t npix, int Cd, int N, int K, int W, bool want_obj, bool want_xrrs,
                      double *partials);
+// PGM gradient for a multi-channel dictionary (pgm/cbpdn.py:263-279); partials as launch_pgm_grad
+template <typename T>
+int launch_mc_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T> *sf, cx<T> *gf,
+                       int64_t npix, int Cd, int N, int K, int W, double *partials);
 // out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]
 template <typename T>
 void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,

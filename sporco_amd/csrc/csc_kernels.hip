@@ -1603,6 +1603,76 @@ int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *d
     return grid;
 }
 
+// PGM gradient for a multi-channel dictionary (pgm/cbpdn.py:263-279):
+// gf[pix, n, k] = sum_c conj(df[pix, c, k]) (sum_m df[pix, c, m] v[pix, n, m] - sf[pix, c, n]);
+// one wave per (pix, n) system, lane = filter.  Partials (2): sum_c |r_c|^2 unweighted and
+// Parseval-weighted.
+template <typename T, int KR>
+__global__ void __launch_bounds__(kThreads) mc_pgm_grad_kernel(const cx<T> *__restrict__ v,
+                                                               const cx<T> *__restrict__ df,
+                                                               const cx<T> *__restrict__ sf,
+                                                               cx<T> *__restrict__ gf, int64_t npix,
+                                                               int Cd, int N, int K, int W,
+                                                               double *partials) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    const int Wf = W / 2 + 1;
+    const int64_t nsys = npix * N;
+    double acc[2] = {0.0, 0.0};
+    for (int64_t sys = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+         sys < nsys; sys += nwaves) {
+        const int64_t pix = sys / N;
+        const int n = (int)(sys - pix * N);
+        const cx<T> *d = df + pix * Cd * K;
+        cx<T> x[KR], g[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            x[j] = k < K ? v[sys * K + k] : mk<T>(T(0), T(0));
+            g[j] = mk<T>(T(0), T(0));
+        }
+        for (int c = 0; c < Cd; ++c) {
+            cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) t = t + cmul(d[c * K + k], x[j]);
+            }
+            const cx<T> r = wave_sum_cx(t) - sf[(pix * Cd + c) * N + n];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) g[j] = g[j] + cmulc(d[c * K + k], r);
+            }
+            if (lane == 0) {
+                const double r2 = (double)cabs2(r);
+                acc[0] += r2;
+                acc[1] += parseval_weight((int)(pix % Wf), Wf, W) * r2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            if (k < K) gf[sys * K + k] = g[j];
+        }
+    }
+    block_sum_store<2>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 2);
+}
+
+template <typename T>
+int launch_mc_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T> *sf, cx<T> *gf,
+                       int64_t npix, int Cd, int N, int K, int W, double *partials) {
+    const int grid = grid_for(npix * N * kWave);
+    const size_t lds = sizeof(double) * 2 * (kThreads / kWave);
+    ism_dispatch_kr<T>(K, [&](auto kr) {
+        constexpr int KR = decltype(kr)::value;
+        hipLaunchKernelGGL((mc_pgm_grad_kernel<T, KR>), dim3(grid), dim3(kThreads), lds, st, v, df, sf,
+                           gf, npix, Cd, N, K, W, partials);
+    });
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
 // out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]: linalg.inner over the filter axis for a
 // multi-channel dictionary (the Cd = 1 case is launch_inner)
 template <typename T>
@@ -1895,6 +1965,8 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \
                                      const cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *,   \
                                      T, int64_t, int, int, int, int, bool, bool, double *);        \
+    template int launch_mc_pgm_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,   \
+                                       cx<T> *, int64_t, int, int, int, int, double *);            \
     template void launch_mc_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,  \
                                      int, int, int);                                               \
     template int launch_mc_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,  \

@@ -62,9 +62,6 @@ class ConvBPDN(pgm.PGMDFT):
             raise NotImplementedError("sporco_amd handles real-valued D and S")
         if not hasattr(self, 'cri'):
             self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd > 1:
-            raise NotImplementedError("multi-channel dictionaries are not part of the "
-                                      "sporco_amd hot path yet")
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
@@ -85,7 +82,7 @@ class ConvBPDN(pgm.PGMDFT):
     def _new_handle(self):
         H, W = self.cri.Nv
         self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                               device=self._device, stream=self._stream)
+                               device=self._device, stream=self._stream, Cd=self.cri.Cd)
         self._cache = {}
         self._fcache = {}
         self._rl1 = 0.0

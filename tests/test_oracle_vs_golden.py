@@ -264,6 +264,19 @@ def test_ccmod_consensus_traces(name):
     assert np.max(np.abs(r['Cnstr'] - g['it_Cnstr'])) < 1e-6
 
 
+def test_pgm_mcdict_traces():
+    """FISTA with a multi-channel dictionary: gradient summed over the channels
+    (pgm/cbpdn.py:263-279)."""
+    g = load_golden('pgm_mcdict_f64')
+    D5, S5 = mcdict_inputs(g)
+    r = orc.pgm_cbpdn(D5, S5, float(g['lmbda']), dtype=np.float64, maxiter=30, L=500.0,
+                      rel_tol=0.0)
+    assert r['iters'] == int(g['k_final'])
+    assert r['X'].shape == g['X'].shape and rel_l2(r['X'], g['X']) < 1e-9
+    for key in ('ObjFun', 'DFid', 'RegL1', 'Rsdl'):
+        assert rel_l2(r[key], g['it_' + key]) < 1e-9, key
+
+
 def test_admm_known_answer():
     g = load_golden('admm_known_answer_f64')
     D5, S5 = to5d(g['D'], g['S'])

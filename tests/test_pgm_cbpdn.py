@@ -34,12 +34,14 @@ def policies():
                                'StepSizePolicy': StepSizePolicyCauchy()},
         'pgm_monotone_f64': {'MaxMainIter': 30, 'L': 500.0, 'Monotone': True},
         'pgm_multichan_f64': {'MaxMainIter': 30, 'L': 500.0},
+        # multi-channel dictionary: gradient summed over the channels (pgm/cbpdn.py:277-279)
+        'pgm_mcdict_f64': {'MaxMainIter': 30, 'L': 500.0},
     }
 
 
 NAMES = ['pgm_default_f64', 'pgm_default_f32', 'pgm_nonneg_nobndry_f64', 'pgm_btstd_f64',
          'pgm_btrobust_f64', 'pgm_momlinear_f64', 'pgm_momgenlinear_f64', 'pgm_stepbb_f64',
-         'pgm_stepcauchy_f64', 'pgm_monotone_f64', 'pgm_multichan_f64']
+         'pgm_stepcauchy_f64', 'pgm_monotone_f64', 'pgm_multichan_f64', 'pgm_mcdict_f64']
 
 
 @pytest.mark.parametrize('name', NAMES)
