@@ -392,6 +392,24 @@ def gen_mcdict():
                'rho': 2.0, 'AutoRho': {'Enabled': False}})
     # the FISTA solver with the same kind of dictionary (pgm/cbpdn.py:263-286, sum over channels)
     pgm_case('pgm_mcdict_f64', D, S, 0.1, {'MaxMainIter': 30, 'L': 500.0})
+    # dictionary update and dictionary learning with a multi-channel dictionary
+    # (pgm/ccmod.py:139-404 with Cd > 1: channel-joint normalisation, cnvrep.py:868-913)
+    N_, M_, Nd_, K_ = 16, 4, 5, 3
+    Sc = np.random.randn(N_, N_, 3, K_)
+    Zc = np.random.randn(N_, N_, 1, K_, M_) * (np.random.rand(N_, N_, 1, K_, M_) > 0.7)
+    opt = ref_pgm_ccmod.ConvCnstrMOD.Options({'MaxMainIter': 20, 'L': 800.0, 'ZeroMean': True})
+    c = ref_pgm_ccmod.ConvCnstrMOD(Zc, Sc, (Nd_, Nd_, 3, M_), opt)
+    c.solve()
+    save('pgm_ccmod_mcdict_f64', Z=Zc, S=Sc, dsz=np.array((Nd_, Nd_, 3, M_)), D=c.getdict(),
+         Xfull=c.X, **itstat_dict(c))
+    D0c = np.random.randn(Nd_, Nd_, 3, M_)
+    for name, dt in (('cbpdndl_mcdict_f64', np.float64), ('cbpdndl_mcdict_f32', np.float32)):
+        opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+            {'MaxMainIter': 10, 'AccurateDFid': True}, xmethod='admm', dmethod='pgm')
+        b = ref_cbpdndl.ConvBPDNDictLearn(D0c.astype(dt), Sc.astype(dt), 0.1, opt,
+                                          xmethod='admm', dmethod='pgm')
+        D1 = b.solve()
+        save(name, D0=D0c, S=Sc, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(), **itstat_dict(b))
     g = {}
     # the primitive itself, on random data (4 channels, 6 filters)
     ah = np.random.randn(7, 5, 4, 1, 6) + 1j * np.random.randn(7, 5, 4, 1, 6)

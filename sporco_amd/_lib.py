@@ -334,9 +334,9 @@ class Solver(object):
                    VAR_ZF):
             return (H, Wf, C, N, K), self.cdtype
         if var == VAR_DX:
-            return (H, W, 1, 1, K), self.dtype
+            return (H, W, self.Cd, 1, K), self.dtype
         if VAR_DXF <= var <= VAR_DT2:
-            return (H, Wf, 1, 1, K), self.cdtype
+            return (H, Wf, self.Cd, 1, K), self.cdtype
         return (H, W, C, N, K), self.dtype
 
     # -- set-up -----------------------------------------------------------
@@ -550,7 +550,7 @@ class Solver(object):
 
     def ccmod_getdict(self, dH, dW):
         K = self.dims[4]
-        out = np.empty((dH, dW, 1, 1, K), dtype=self.dtype)
+        out = np.empty((dH, dW, self.Cd, 1, K), dtype=self.dtype)
         check(self._lib.sporco_amd_csc_ccmod_getdict(self._h, int(dH), int(dW), _ptr(out)))
         return out
 

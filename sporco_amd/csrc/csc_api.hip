@@ -401,11 +401,12 @@ template <typename T> struct Csc : CscBase {
         if (own_stream) (void)hipStreamDestroy(st);
     }
 
+    int64_t KD() const { return (int64_t)Cd * K; }   // dictionary entries per pixel
     size_t var_bytes(int var) const {
         if (var == SPORCO_AMD_VAR_SF) return sizeof(cx<T>) * npix * CNs;
-        if (var == SPORCO_AMD_VAR_DF) return sizeof(cx<T>) * npix * Cd * K;
         if (var_is_dict_sized(var))
-            return var_is_complex(var) ? sizeof(cx<T>) * npix * K : sizeof(T) * (int64_t)H * W * K;
+            return var_is_complex(var) ? sizeof(cx<T>) * npix * KD()
+                                       : sizeof(T) * (int64_t)H * W * KD();
         return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
     }
 
@@ -424,11 +425,11 @@ template <typename T> struct Csc : CscBase {
         return work;
     }
     cx<T> *dwork_buf() {
-        if (!dwork) SA_HIP(hipMalloc((void **)&dwork, sizeof(cx<T>) * npix * K));
+        if (!dwork) SA_HIP(hipMalloc((void **)&dwork, sizeof(cx<T>) * npix * KD()));
         return dwork;
     }
     T *pcn_stats_buf() {
-        if (!pcn_stats) SA_HIP(hipMalloc((void **)&pcn_stats, sizeof(T) * 2 * K));
+        if (!pcn_stats) SA_HIP(hipMalloc((void **)&pcn_stats, sizeof(T) * 2 * KD()));
         return pcn_stats;
     }
     Dims5 d5() const { return Dims5{H, W, C, N, K}; }
@@ -1483,7 +1484,7 @@ template <typename T> struct Csc : CscBase {
         for (int v : {vb, vg})
             SA_REQUIRE(v < 0 || (var_is_complex(v) && var_bytes(v) == var_bytes(va)),
                        "pair_stats operands must have the same shape");
-        const int64_t cols = var_is_dict_sized(va) ? K : P;
+        const int64_t cols = var_is_dict_sized(va) ? KD() : P;
         for (int v : {va, vb, vg})
             if (v >= 0) before_read(v);
         int nb;
@@ -1502,7 +1503,7 @@ template <typename T> struct Csc : CscBase {
                        var_is_complex(cvar) && cvar != SPORCO_AMD_VAR_SF &&
                        var_is_dict_sized(rvar) == var_is_dict_sized(cvar),
                    "fft_var needs a real and a complex variable of matching shape");
-        const int64_t cols = var_is_dict_sized(rvar) ? K : P;
+        const int64_t cols = var_is_dict_sized(rvar) ? KD() : P;
         if (is_pgm_iterate(cvar)) pgm_leave_tiled();
         if (inverse) {
             before_read(cvar);
@@ -1519,7 +1520,6 @@ template <typename T> struct Csc : CscBase {
 
     // ---- dictionary update -------------------------------------------------------------
     void ccmod_setcoef(int var) override {
-        require_single_channel_dict();
         SA_REQUIRE(var_is_valid(var) && !var_is_complex(var) && !var_is_dict_sized(var),
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
@@ -1571,7 +1571,6 @@ template <typename T> struct Csc : CscBase {
     }
 
     void ccmod_grad(int var, bool write_grad, double *out_dev) override {
-        require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var),
                    "ccmod_grad needs a dictionary-sized frequency-domain variable");
@@ -1611,7 +1610,7 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_PGM);
             nb = launch_ccmod_grad<T>(st, cv(SPORCO_AMD_VAR_ZF), cv(var), cv(SPORCO_AMD_VAR_SF),
                                       write_grad ? cv(SPORCO_AMD_VAR_DGF) : nullptr, npix, CN, K, W,
-                                      part_a);
+                                      part_a, Cd);
         }
         const int slots[3] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_HESS};
         const double scales[3] = {0.5, 1.0 / ((double)H * W), 1.0};
@@ -1623,8 +1622,8 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_pcn_stats<T>(st, v, pcn_stats_buf(), H, W, K, dH, dW, zm);
-            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b, Ku);
+            launch_pcn_stats<T>(st, v, pcn_stats_buf(), H, W, K, dH, dW, zm, Cd);
+            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b, Ku, Cd);
         }
         if (out_dev) {
             const int slots[1] = {0};
@@ -1638,12 +1637,12 @@ template <typename T> struct Csc : CscBase {
         {
             ProfScope ps(prof, PS_PGM);
             launch_axpy_c<T>(st, cv(SPORCO_AMD_VAR_DYF), cv(SPORCO_AMD_VAR_DGF), Vf, (T)(-1.0 / L),
-                             npix * K);
+                             npix * KD());
         }
         T *X = rv(SPORCO_AMD_VAR_DX);
-        inv2(Vf, dwork_buf(), X, K);
+        inv2(Vf, dwork_buf(), X, KD());
         pcn_project(X, X, dH, dW, zm, nullptr);
-        fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), KD());
     }
 
     void ccmod_cnstr(int dH, int dW, bool zm, double *out_dev) override {
@@ -1658,9 +1657,10 @@ template <typename T> struct Csc : CscBase {
             tmp.resize((size_t)dH * dW * K);
             out = tmp.data();
         }
-        SA_HIP(hipMemcpy2DAsync(out, sizeof(T) * (size_t)dW * K, rv(SPORCO_AMD_VAR_DX),
-                                sizeof(T) * (size_t)W * K, sizeof(T) * (size_t)dW * K, (size_t)dH,
-                                hipMemcpyDeviceToHost, st));
+        // (rows of dW pixels x Cd channels x K filters; Cd > 1 is never padded)
+        SA_HIP(hipMemcpy2DAsync(out, sizeof(T) * (size_t)dW * KD(), rv(SPORCO_AMD_VAR_DX),
+                                sizeof(T) * (size_t)W * KD(), sizeof(T) * (size_t)dW * KD(),
+                                (size_t)dH, hipMemcpyDeviceToHost, st));
         sync();
         if (K != Ku) {   // drop the padding filter
             T *o = static_cast<T *>(dst);
@@ -1670,11 +1670,11 @@ template <typename T> struct Csc : CscBase {
     }
 
     void setdict_from_dstep(int dH, int dW) override {
-        require_single_channel_dict();
         before_state_change();
         SA_HIP(hipMemcpyAsync(cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_DXF),
-                              sizeof(cx<T>) * npix * K, hipMemcpyDeviceToDevice, st));
-        {
+                              sizeof(cx<T>) * npix * KD(), hipMemcpyDeviceToDevice, st));
+        ism_valid = false;
+        if (Cd == 1) {
             ProfScope ps(prof, PS_OTHER);
             launch_gram<T>(st, cv(SPORCO_AMD_VAR_DF), gram, npix, K);
         }

@@ -158,18 +158,20 @@ int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T
 // Parseval-weighted sum |r|^2, sum |r + sf|^2 (= <d, Hess d>).  Returns #blocks.
 template <typename T>
 int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
-                      int64_t npix, int CN, int K, int W, double *partials);
+                      int64_t npix, int CN, int K, int W, double *partials, int Cd = 1);
+// (Cd > 1: d, gf (npix, Cd, K), sf (npix, Cd, CN): one least-squares problem per channel)
 
 // Constraint-set projection Pcn = normalise(zeromean(zpad(bcrop(v)))) of a
 // dictionary v(H, W, K) with filter support (dH, dW) (cnvrep.py:868-913).
 // stats[2k] = mean over support (0 unless zm), stats[2k+1] = 1/norm (1 if norm is 0).
 template <typename T>
 void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
-                      bool zm);
+                      bool zm, int Cd = 1);   // Cd > 1: v (H, W, Cd, K), stats sized 2 Cd K
 // out = projected v (out may be null: measure only); partial[block] = sum (P(v) - v)^2
 template <typename T>
 int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
-                     int dH, int dW, double *partials, int Kvalid = -1);   // k >= Kvalid -> 0
+                     int dH, int dW, double *partials, int Kvalid = -1,   // k >= Kvalid -> 0
+                     int Cd = 1);
 // partial[block] = sum |v|
 template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, double *partials);
 

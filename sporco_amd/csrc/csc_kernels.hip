@@ -1172,23 +1172,26 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
                                                               const cx<T> *__restrict__ d,
                                                               const cx<T> *__restrict__ sf,
                                                               cx<T> *__restrict__ gf, int64_t npix,
-                                                              int CN, int K, int Wf, int W,
+                                                              int CN, int K, int Wf, int W, int Cd,
                                                               double *partials) {
+    // Cd > 1 (multi-channel dictionary): d, gf are (npix, Cd, K), sf is (npix, Cd, CN); the
+    // channels are independent least-squares problems sharing zf (pgm/ccmod.py:295-317)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int nwave = blockDim.x / kWave;
     cx<T> *r = dyn_lds<cx<T>>();               // [CN]
     cx<T> *gpart = r + CN;                     // [nwave][K]
     double *red = reinterpret_cast<double *>(gpart + (size_t)nwave * K);  // [3 * nwave]
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int64_t pix = blockIdx.x; pix < npix; pix += gridDim.x) {
+    for (int64_t pc = blockIdx.x; pc < npix * Cd; pc += gridDim.x) {
+        const int64_t pix = pc / Cd;
         const cx<T> *zp = zf + pix * CN * K;
-        const cx<T> *dp = d + pix * K;
+        const cx<T> *dp = d + pc * K;
         for (int n = wave; n < CN; n += nwave) {
             cx<T> q = mk<T>(T(0), T(0));
             for (int k = lane; k < K; k += kWave) q = q + cmul(zp[(int64_t)n * K + k], dp[k]);
             q = wave_sum_cx(q);
             if (lane == 0) {
-                const cx<T> rr = q - sf[pix * CN + n];
+                const cx<T> rr = q - sf[pc * CN + n];
                 r[n] = rr;
                 const double r2 = (double)cabs2(rr);
                 acc[0] += r2;
@@ -1207,7 +1210,7 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
             for (int k = threadIdx.x; k < K; k += blockDim.x) {
                 cx<T> g = gpart[k];
                 for (int w = 1; w < nwave; ++w) g = g + gpart[w * K + k];
-                gf[pix * K + k] = g;
+                gf[pc * K + k] = g;
             }
         }
         __syncthreads();
@@ -1217,14 +1220,14 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
 
 template <typename T>
 int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
-                      int64_t npix, int CN, int K, int W, double *partials) {
-    int grid = (int)(npix < kMaxPartialBlocks ? npix : kMaxPartialBlocks);
+                      int64_t npix, int CN, int K, int W, double *partials, int Cd) {
+    int grid = (int)(npix * Cd < kMaxPartialBlocks ? npix * Cd : kMaxPartialBlocks);
     const int nwave = kThreads / kWave;
     size_t lds = sizeof(cx<T>) * ((size_t)CN + (size_t)nwave * K) + sizeof(double) * 3 * nwave;
     lds = (lds + 15) / 16 * 16;
     SA_REQUIRE(lds <= 64 * 1024, "too many images x filters for the D-step gradient kernel");
     hipLaunchKernelGGL((ccmod_grad_kernel<T>), dim3(grid), dim3(kThreads), lds, st, zf, d, sf, gf,
-                       npix, CN, K, W / 2 + 1, W, partials);
+                       npix, CN, K, W / 2 + 1, W, Cd, partials);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -1746,32 +1749,37 @@ int launch_mc_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict__ v,
                                                              T *__restrict__ stats, int H, int W,
-                                                             int K, int dH, int dW, int zm) {
+                                                             int K, int dH, int dW, int zm, int Cd) {
+    // v is (H, W, Cd, K); mean per (channel, filter) over the support (cnvrep.zeromean,
+    // cnvrep.py:609-670), norm per filter over support and channels (cnvrep.normalise with
+    // dimN + dimC axes, cnvrep.py:696-700).  stats[2 (c K + k)] = mean, stats[2k + 1] = 1/norm.
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        T mean = T(0);
-        if (zm) {
-            T s = T(0);
-            for (int h = 0; h < dH; ++h)
-                for (int x = 0; x < dW; ++x) s += v[((int64_t)h * W + x) * K + k];
-            mean = s / (T)(dH * dW);
-        }
         T n2 = T(0);
-        for (int h = 0; h < dH; ++h)
-            for (int x = 0; x < dW; ++x) {
-                const T c = v[((int64_t)h * W + x) * K + k] - mean;
-                n2 += c * c;
+        for (int c = 0; c < Cd; ++c) {
+            T mean = T(0);
+            if (zm) {
+                T s = T(0);
+                for (int h = 0; h < dH; ++h)
+                    for (int x = 0; x < dW; ++x) s += v[(((int64_t)h * W + x) * Cd + c) * K + k];
+                mean = s / (T)(dH * dW);
             }
+            for (int h = 0; h < dH; ++h)
+                for (int x = 0; x < dW; ++x) {
+                    const T e = v[(((int64_t)h * W + x) * Cd + c) * K + k] - mean;
+                    n2 += e * e;
+                }
+            stats[2 * (c * K + k)] = mean;
+        }
         const T nrm = sqrt(n2);
-        stats[2 * k] = mean;
         stats[2 * k + 1] = nrm == T(0) ? T(1) : T(1) / nrm;
     }
 }
 
 template <typename T>
 void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
-                      bool zm) {
+                      bool zm, int Cd) {
     hipLaunchKernelGGL((pcn_stats_kernel<T>), dim3(grid_for(K)), dim3(kThreads), 0, st, v, stats, H,
-                       W, K, dH, dW, zm ? 1 : 0);
+                       W, K, dH, dW, zm ? 1 : 0, Cd);
     SA_HIP(hipGetLastError());
 }
 
@@ -1779,19 +1787,21 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict__ v,
                                                              const T *__restrict__ stats, T *out,
                                                              int H, int W, int K, int dH, int dW,
-                                                             int Kvalid, double *partials) {
+                                                             int Kvalid, int Cd, double *partials) {
     double acc[1] = {0.0};
-    const int64_t n = (int64_t)H * W * K;
+    const int64_t KD = (int64_t)Cd * K;
+    const int64_t n = (int64_t)H * W * KD;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % K);
-        const int64_t pix = i / K;
+        const int ck = (int)(i % KD);
+        const int k = ck % K;
+        const int64_t pix = i / KD;
         const int x = (int)(pix % W), h = (int)(pix / W);
         const T vi = v[i];
         // v / vn as in cnvrep.normalise (cnvrep.py:696-700): 1/norm is applied by division
         // (filters >= Kvalid are the handle's zero padding: rounding noise must not be
         // normalised up to a unit-norm filter)
-        const T o = (h < dH && x < dW && k < Kvalid) ? (vi - stats[2 * k]) * stats[2 * k + 1] : T(0);
+        const T o = (h < dH && x < dW && k < Kvalid) ? (vi - stats[2 * ck]) * stats[2 * k + 1] : T(0);
         if (out) out[i] = o;
         const double df = (double)(o - vi);
         acc[0] += df * df;
@@ -1801,11 +1811,11 @@ __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict
 
 template <typename T>
 int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
-                     int dH, int dW, double *partials, int Kvalid) {
-    const int grid = grid_for((int64_t)H * W * K);
+                     int dH, int dW, double *partials, int Kvalid, int Cd) {
+    const int grid = grid_for((int64_t)H * W * Cd * K);
     hipLaunchKernelGGL((pcn_apply_kernel<T>), dim3(grid), dim3(kThreads),
                        sizeof(double) * (kThreads / kWave), st, v, stats, out, H, W, K, dH, dW,
-                       Kvalid < 0 ? K : Kvalid, partials);
+                       Kvalid < 0 ? K : Kvalid, Cd, partials);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -1949,10 +1959,11 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,     \
                                       int, double *);                                              \
     template int launch_ccmod_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
-                                      cx<T> *, int64_t, int, int, int, double *);                  \
-    template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool); \
+                                      cx<T> *, int64_t, int, int, int, double *, int);             \
+    template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool,  \
+                                      int);                                                        \
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
-                                     int, double *, int);                                               \
+                                     int, double *, int, int);                                               \
     template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);                        \
     template void launch_cns_yu<T>(hipStream_t, const T *, const T *, T *, T, int64_t, int, int);  \
     template void launch_cns_mean<T>(hipStream_t, const T *, const T *, const T *, T *, T, T,      \

@@ -59,9 +59,6 @@ class ConvCnstrMOD(pgm.PGMDFT):
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd > 1:
-            raise NotImplementedError("multi-channel dictionaries are not part of the "
-                                      "sporco_amd hot path yet")
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
@@ -70,15 +67,22 @@ class ConvCnstrMOD(pgm.PGMDFT):
         self._shared = dev is not None
         H, W = self.cri.Nv
         # channels of S fold into the image axis for a single-channel dictionary
-        # (pgm/ccmod.py:224-229); (H, W, C, K) and (H, W, 1, C*K) share their memory layout
-        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.cri.C * self.cri.K, 1)),
-                            dtype=self.dtype)
+        # (pgm/ccmod.py:224-229); (H, W, C, K) and (H, W, 1, C*K) share their memory layout.
+        # With a multi-channel dictionary S keeps its channel axis and the coefficient maps
+        # have one channel.
+        if self.cri.Cd == 1:
+            self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.cri.C * self.cri.K, 1)),
+                                dtype=self.dtype)
+        else:
+            self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
         if dev is None:
             self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                   device=device, stream=stream)
+                                   device=device, stream=stream, Cd=self.cri.Cd)
             self.dev.set_signal(self.S)
         else:
-            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
+            if (dev.dims[:2] + (dev.Cs,) + dev.dims[3:]) != (H, W, self.cri.C, self.cri.K,
+                                                              self.cri.M) \
+                    or dev.Cd != self.cri.Cd or dev.dtype != self.dtype:
                 raise ValueError("shared device solver has different dimensions")
             self.dev = dev
         super(ConvCnstrMOD, self).__init__(self.cri.shpD, self.cri.Nv, self.cri.axisN,

@@ -169,3 +169,39 @@ def test_dictlearn_fused_vs_generic(gpu_backend, K):
                       np.asarray(getattr(d0.getitstat(), f), dtype=float))
             for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'D_Rsdl')}
     assert max(errs.values()) < 1e-5, errs
+
+
+# ---------------------------------------------------------------------------
+# multi-channel dictionaries (Cd > 1): D-step and dictionary learning
+# ---------------------------------------------------------------------------
+def test_ccmod_pgm_multichannel_dictionary(backend):
+    from sporco_amd.pgm import ccmod
+    g = load_golden('pgm_ccmod_mcdict_f64')
+    opt = ccmod.ConvCnstrMOD.Options({'MaxMainIter': 20, 'L': 800.0, 'ZeroMean': True})
+    c = ccmod.ConvCnstrMOD(g['Z'], g['S'], tuple(int(v) for v in g['dsz']), opt)
+    c.solve()
+    D = c.getdict()
+    assert D.shape == g['D'].shape and rel_l2(D, g['D']) < 1e-9
+    assert rel_l2(c.getdict(crop=False), g['Xfull']) < 1e-9
+    errs = trace_errors(c.getitstat(), g)
+    assert errs and max(errs.values()) < 1e-9, errs
+    # filters have unit norm over support and channels, zero mean per channel
+    assert np.allclose(np.sum(D ** 2, axis=(0, 1, 2)).ravel(), 1.0)
+    assert np.max(np.abs(np.mean(D, axis=(0, 1)))) < 1e-12
+
+
+@pytest.mark.parametrize('name,dt,tol', [('cbpdndl_mcdict_f64', np.float64, 1e-9),
+                                         ('cbpdndl_mcdict_f32', np.float32, 1e-3)])
+def test_dictlearn_multichannel_dictionary(backend, name, dt, tol):
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden(name)
+    opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                            xmethod='admm', dmethod='pgm')
+    b = cbpdndl.ConvBPDNDictLearn(g['D0'].astype(dt), g['S'].astype(dt), float(g['lmbda']),
+                                  opt, xmethod='admm', dmethod='pgm')
+    D1 = b.solve()
+    assert D1.squeeze().shape == g['D1'].squeeze().shape
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < tol
+    assert rel_l2(b.getcoef(), g['X']) < tol
+    errs = trace_errors(b.getitstat(), g)
+    assert max(errs.values()) < tol, errs
