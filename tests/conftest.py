@@ -15,6 +15,30 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 def pytest_configure(config):
     config.addinivalue_line(
         'markers', 'gpu: needs a real MI355X (run with -m gpu through gpurun)')
+    _parallel_cpu_run(config)
+
+
+def _parallel_cpu_run(config):
+    """The CPU suite spends its time in the fiber simulator, one test at a time: for the
+    plain `-m "not gpu"` run, spread the tests over a few worker processes (pytest-xdist,
+    when installed).  GPU runs stay in one process.  SPORCO_AMD_TEST_WORKERS=0 disables it,
+    an explicit -n wins."""
+    if os.environ.get('PYTEST_XDIST_WORKER') or not config.pluginmanager.hasplugin('xdist'):
+        return
+    if (config.option.markexpr or '').strip() != 'not gpu':
+        return
+    if getattr(config.option, 'numprocesses', None) or getattr(config.option, 'collectonly', False):
+        return
+    try:
+        n = int(os.environ.get('SPORCO_AMD_TEST_WORKERS', min(4, os.cpu_count() or 1)))
+    except ValueError:
+        n = 0
+    if n < 2:
+        return
+    build_hostsim()          # once, before the workers race for it
+    config.option.numprocesses = n
+    config.option.dist = 'load'
+    config.option.tx = ['popen'] * n
 
 
 def pytest_collection_modifyitems(config, items):

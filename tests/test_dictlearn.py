@@ -190,8 +190,9 @@ def test_ccmod_pgm_multichannel_dictionary(backend):
     assert np.max(np.abs(np.mean(D, axis=(0, 1)))) < 1e-12
 
 
-@pytest.mark.parametrize('name,dt,tol', [('cbpdndl_mcdict_f64', np.float64, 1e-9),
-                                         ('cbpdndl_mcdict_f32', np.float32, 1e-3)])
+@pytest.mark.parametrize('name,dt,tol', [
+    ('cbpdndl_mcdict_f64', np.float64, 1e-9),
+    pytest.param('cbpdndl_mcdict_f32', np.float32, 1e-3, marks=pytest.mark.gpu)])
 def test_dictlearn_multichannel_dictionary(backend, name, dt, tol):
     from sporco_amd.dictlrn import cbpdndl
     g = load_golden(name)
