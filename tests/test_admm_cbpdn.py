@@ -322,3 +322,39 @@ def test_multichannel_dictionary_surface(backend):
         cbpdn.ConvBPDNJoint(D, S, 0.1, 0.1)
     with pytest.raises(NotImplementedError):
         cbpdn.ConvBPDNGradReg(D, S, 0.1, 0.1)
+
+
+def test_abi_error_paths_of_the_widened_calls(backend):
+    """The C ABI refuses, with an error code and message, what it cannot do: no silent
+    fallbacks (include/sporco_amd.h)."""
+    from sporco_amd import _lib
+    rng = np.random.RandomState(0)
+    dev = _lib.Solver(16, 16, 1, 2, 4, np.float64)
+    # a mask that varies over the filter axis, and FLAG_AMS without any mask
+    with pytest.raises(_lib.BackendError):
+        dev.set_ams_mask(np.ones((16, 16, 1, 2, 4)))
+    dev.set_signal(rng.randn(16, 16, 1, 2))
+    dev.set_dict(rng.randn(5, 5, 4))
+    p = _lib.AdmmParams()
+    p.rho, p.lmbda, p.mu, p.rlx, p.u_scale = 1.0, 0.1, 0.0, 1.8, 1.0
+    p.flags = _lib.FLAG_AMS | _lib.FLAG_RESID
+    p.dH = p.dW = 5
+    with pytest.raises(_lib.BackendError):
+        dev.admm_iter(p)
+    with pytest.raises(ValueError):
+        dev.set_grad_weight(np.ones(3))            # one weight per filter
+    # a multi-channel dictionary needs the signal's channel count
+    with pytest.raises(_lib.BackendError):
+        _lib.Solver(16, 16, 2, 1, 4, np.float64, Cd=3)
+    # ... and serves ADMM ConvBPDN / PGM only: no consensus D-step, no fused PGM iteration
+    mc = _lib.Solver(16, 16, 3, 1, 4, np.float64, Cd=3)
+    mc.set_signal(rng.randn(16, 16, 3, 1))
+    with pytest.raises(_lib.BackendError):
+        mc.cns_init(None, 1.0)
+    with pytest.raises(_lib.BackendError):
+        mc.pgm_iter(500.0, 0.1, 0.0, 0, 5, 5, True)
+    # the consensus D-step needs a signal before it can iterate
+    fresh = _lib.Solver(16, 16, 1, 2, 4, np.float64)
+    fresh.cns_init(None, 1.0)
+    with pytest.raises(_lib.BackendError):
+        fresh.cns_iter(1.0, 1.8, 1.0, _lib.FLAG_RESID, 5, 5, False)
