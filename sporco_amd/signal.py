@@ -13,17 +13,28 @@ __all__ = ['gradient_filters', 'tikhonov_filter']
 def gradient_filters(ndim, axes, axshp, dtype=None):
     """Frequency-domain gradient operators ``Gf`` and ``GHGf = sum_i |Gf_i|^2`` for the
     two-tap difference filters along ``axes`` (sporco/signal.py:204-240).  Real dtypes and
-    axes (0, 1) (the half-spectrum layout of the solvers)."""
+    axes (0, 1) (the half-spectrum layout of the solvers).
+
+    The DFT of the filter (1, -1) along an axis of length n is 1 - exp(-2 pi i f / n); it is
+    written down directly, on the half spectrum of the last transformed axis."""
     if dtype is None:
         dtype = np.float32
-    if np.dtype(dtype).kind == 'c':
+    dtype = np.dtype(dtype)
+    if dtype.kind == 'c':
         raise NotImplementedError("sporco_amd handles real-valued signals")
     axes = tuple(axes)
-    g = np.zeros([2 if k in axes else 1 for k in range(ndim)] + [len(axes)], dtype)
-    for k in axes:
-        g[(0,) * k + (slice(None),) + (0,) * (g.ndim - 2 - k) + (k,)] = np.array([1, -1])
-    Gf = sfft.rfftn(g, axshp, axes=axes)
-    GHGf = np.sum(np.conj(Gf) * Gf, axis=-1).real
+    if axes != (0, 1):
+        raise NotImplementedError("sporco_amd.signal handles axes (0, 1)")
+    cdt = sfft.complex_dtype(dtype)
+    n0, n1 = int(axshp[0]), int(axshp[1])
+    shape = (n0, n1 // 2 + 1) + (1,) * (ndim - 2)
+    Gf = np.zeros(shape + (2,), dtype=cdt)
+    f0 = np.arange(n0).reshape((n0, 1) + (1,) * (ndim - 2))
+    f1 = np.arange(n1 // 2 + 1).reshape((1, n1 // 2 + 1) + (1,) * (ndim - 2))
+    # (a length-1 axis crops the filter to its first tap: the transform is then 1)
+    Gf[..., 0] = (1.0 - np.exp(-2j * np.pi * f0 / n0)) if n0 > 1 else 1.0
+    Gf[..., 1] = (1.0 - np.exp(-2j * np.pi * f1 / n1)) if n1 > 1 else 1.0
+    GHGf = np.sum(Gf.real ** 2 + Gf.imag ** 2, axis=-1).astype(dtype)
     return Gf, GHGf
 
 
