@@ -21,8 +21,10 @@ namespace sporco_amd {
 
 // out[(b*A + a)*C + c] = in[(a*B + b)*C + c]: (A, B, C) -> (B, A, C).  Used to
 // re-lay Df (H, Wf, K), the per-pixel gram (H, Wf) and Sf (H, Wf*CN) tile-major.
+// (in_stride / out_stride: elements between consecutive C-runs when they are padded; 0 = C)
 template <typename E>
-void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B, int64_t C);
+void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B, int64_t C,
+                       int64_t in_stride = 0, int64_t out_stride = 0);
 
 template <typename T> struct FusedColsArgs {
     cx<T> *t;          // in: row spectra of Y - sU, tile-major; out (in place): column-
@@ -46,6 +48,9 @@ template <typename T> struct FusedColsArgs {
     // it is stored to coef_out[tile][f] for the update of the remaining filters.
     int Kv = 0;
     cx<T> *coef_out = nullptr;
+    // ... and in that mode the rows of t and dft may be Ks > K filters apart (0: K), so that
+    // every row starts on a cache line although K * 8 bytes is not a multiple of one
+    int Ks = 0;
     // per_tile: dft is tile-major like t ([Wf][CN][H][K]) and gramt is [Wf][CN][H] -- one rank-one
     // term per (frequency, image), the X-step of the consensus dictionary update
     // (admm/ccmod.py:766-778) with the coefficient spectra in the role of the dictionary.

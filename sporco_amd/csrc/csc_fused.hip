@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
-    const int K = (KC && !KRT) ? KC : a.K;             // row stride of the tile, in filters
+    const int K = (KC && !KRT) ? KC : ((KRT && a.Ks) ? a.Ks : a.K);   // row stride, in filters
     const bool kv = KC == 64 ? true : k < K;
     // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).
     // All C*N tiles of one row frequency wf share the same 256 KiB slice of Df, so
@@ -282,10 +282,11 @@ __global__ void __launch_bounds__(256) grad_g1_kernel(const FusedColsArgs<float>
     const int wf = (int)(row / a.H), h = (int)(row % a.H);
     const float gh = a.ghh[h], gw = a.ghw[wf];
     float s = 0.f;
+    const int Ks = a.Ks ? a.Ks : a.K;
     for (int k = lane; k < a.K; k += 64) {
         const float ak = a.mu * (a.wg ? a.wg[k] : 1.f);
         const float dd = ak * gh + (ak * gw + a.rho);
-        s += cabs2(a.dft[row * a.K + k]) / dd;
+        s += cabs2(a.dft[row * Ks + k]) / dd;
     }
     for (int m = 32; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
     if (lane == 0) a.g1t_out[row] = 1.f + s;
@@ -506,25 +507,27 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
 template <typename E>
 __global__ void __launch_bounds__(256) permute_ab_kernel(const E *__restrict__ in,
                                                          E *__restrict__ out, int64_t A, int64_t B,
-                                                         int64_t C) {
+                                                         int64_t C, int64_t Cin, int64_t Cout) {
     const int64_t n = A * B * C;
     for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n;
          o += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = o % C, ba = o / C;
         const int64_t aa = ba % A, bb = ba / A;
-        out[o] = in[(aa * B + bb) * C + c];
+        out[ba * Cout + c] = in[(aa * B + bb) * Cin + c];
     }
 }
 
 }  // namespace
 
 template <typename E>
-void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B, int64_t C) {
+void launch_permute_ab(hipStream_t st, const E *in, E *out, int64_t A, int64_t B, int64_t C,
+                       int64_t in_stride, int64_t out_stride) {
     const int64_t n = A * B * C;
     if (n <= 0) return;
     int64_t g = ceil_div(n, 256);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL((permute_ab_kernel<E>), dim3((unsigned)g), dim3(256), 0, st, in, out, A, B, C);
+    hipLaunchKernelGGL((permute_ab_kernel<E>), dim3((unsigned)g), dim3(256), 0, st, in, out, A, B, C,
+                       in_stride ? in_stride : C, out_stride ? out_stride : C);
     SA_HIP(hipGetLastError());
 }
 
@@ -649,7 +652,7 @@ template <> void launch_grad_g1<double>(hipStream_t, const FusedColsArgs<double>
 __global__ void __launch_bounds__(256) tail_inner_kernel(const FusedColsArgs<float> a,
                                                          const cf *__restrict__ sft,
                                                          cf *__restrict__ sft_eff, int64_t ntiles) {
-    const int H = a.H, K = a.K, Kv = a.Kv;
+    const int H = a.H, K = a.K, Kv = a.Kv, Ks = a.Ks ? a.Ks : a.K;
     const bool grad = a.g1t != nullptr;
     const int64_t total = ntiles * H;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -657,7 +660,7 @@ __global__ void __launch_bounds__(256) tail_inner_kernel(const FusedColsArgs<flo
         const int64_t tile = i / H;
         const int f = (int)(i - tile * H);
         const int64_t wf = tile / a.CN;
-        const cf *d = a.dft + (wf * H + f) * K, *x = a.t + i * K;
+        const cf *d = a.dft + (wf * H + f) * Ks, *x = a.t + i * Ks;
         const float gh = grad ? a.ghh[f] + a.ghw[wf] : 0.f;
         cf q = mk<float>(0.f, 0.f);
         for (int k = Kv; k < K; ++k) {
@@ -673,7 +676,7 @@ __global__ void __launch_bounds__(256) tail_inner_kernel(const FusedColsArgs<flo
 // thread = column frequency.  Gradient-regularised system: t = (rho t + conj(dft) coef) / dd_k,
 // and the tail's share of the gradient term is added to the tile's second partial.
 __global__ void __launch_bounds__(512) tail_update_kernel(const FusedColsArgs<float> a) {
-    const int H = a.H, K = a.K, Kv = a.Kv;
+    const int H = a.H, K = a.K, Kv = a.Kv, Ks = a.Ks ? a.Ks : a.K;
     const bool grad = a.g1t != nullptr;
     const int64_t tile = blockIdx.x;
     const int64_t wf = tile / a.CN;
@@ -682,8 +685,8 @@ __global__ void __launch_bounds__(512) tail_update_kernel(const FusedColsArgs<fl
     for (int f = threadIdx.x; f < H; f += blockDim.x) {
         const int64_t row = tile * H + f;
         const cf cf_ = a.coef_out[row];
-        const cf *d = a.dft + (wf * H + f) * K;
-        cf *x = a.t + row * K;
+        const cf *d = a.dft + (wf * H + f) * Ks;
+        cf *x = a.t + row * Ks;
         const float gh = grad ? a.ghh[f] + a.ghw[wf] : 0.f;
         for (int k = Kv; k < K; ++k) {
             if (grad) {
@@ -780,12 +783,13 @@ template <> int64_t launch_fused_cols<double>(hipStream_t, const FusedColsArgs<d
     throw Error(-1, "the fused column kernel is float32 only");
 }
 
-template void launch_permute_ab<float>(hipStream_t, const float *, float *, int64_t, int64_t, int64_t);
+template void launch_permute_ab<float>(hipStream_t, const float *, float *, int64_t, int64_t, int64_t,
+                                       int64_t, int64_t);
 template void launch_permute_ab<double>(hipStream_t, const double *, double *, int64_t, int64_t,
-                                        int64_t);
+                                        int64_t, int64_t, int64_t);
 template void launch_permute_ab<cx<float>>(hipStream_t, const cx<float> *, cx<float> *, int64_t,
-                                           int64_t, int64_t);
+                                           int64_t, int64_t, int64_t, int64_t);
 template void launch_permute_ab<cx<double>>(hipStream_t, const cx<double> *, cx<double> *, int64_t,
-                                            int64_t, int64_t);
+                                            int64_t, int64_t, int64_t, int64_t);
 
 }  // namespace sporco_amd

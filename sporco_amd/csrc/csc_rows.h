@@ -32,6 +32,7 @@ template <typename T> struct RowsFwdArgs {
     int H, W, CN, K;
     int64_t P;
     int y_bcast = 0;   // y is (H, W, K), broadcast over the CN blocks (consensus D-step)
+    int Ks = 0;        // row stride of t in filters when it is not K (0: K), see csc_fused.h
 };
 
 template <typename T> struct RowsPostArgs {
@@ -49,6 +50,7 @@ template <typename T> struct RowsPostArgs {
     int H, W, C, N, K, dH, dW;
     int64_t P;
     Weight<T> wl1;
+    int Ks = 0;        // row stride of t / t_next in filters when it is not K (0: K)
     const uint32_t *ams_bits = nullptr;   // AddMaskSim mask packed by launch_ams_pack, or null
     int ams_k = -1;    // filter index of the impulse slice
     double *partials;  // per tile 8 doubles: r2, s2, ax2, y2, u2, l1, 0, 0
@@ -74,6 +76,7 @@ template <typename T> struct RowsProxArgs {
     uint32_t flags;    // F_NONNEG | F_NOBNDRY
     int H, W, C, N, K, dH, dW;
     int64_t P;
+    int Ks = 0;        // row stride of t_in / t_out in filters when it is not K (0: K)
     Weight<T> wl1;
     double *partials;  // per tile 1 double: sum |wl1 * X|
 };

@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
             v[half * (N1 / 2) + i] = mk<float>(yv[i].re - s2 * uv[i].re, yv[i].im - s2 * uv[i].im);
         reg_fence<N1 / 2>(v, half * (N1 / 2), token);
     }
-    spatial_to_spectral<NW>(v, a.twA, a.t, a.CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+    spatial_to_spectral<NW>(v, a.twA, a.t, a.CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
+                            token);
 }
 
 // ---------------------------------------------------------------------------
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     int token = 0;
 
     cf v[N1];
-    spectral_to_spatial<NW>(v, a.twW, a.t, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+    spectral_to_spatial<NW>(v, a.twW, a.t, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L, token);
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a.P;
@@ -440,7 +441,8 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
         // iteration's rows_fwd would compute from these very values, stored over the
         // units this thread consumed (same spectral-side ownership: in place is safe).
         reg_fence<N1>(v, 0, token);
-        spatial_to_spectral<NW>(v, a.twA, a.t_next, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+        spatial_to_spectral<NW>(v, a.twA, a.t_next, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane,
+                                L, token);
         __syncthreads();   // the reduction scratch below sits next to the exchange buffer
     }
 
@@ -471,7 +473,8 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsPr
     int token = 0;
 
     cf v[N1];
-    spectral_to_spatial<NW>(v, a.twW, a.t_in, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+    spectral_to_spatial<NW>(v, a.twW, a.t_in, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
+                            token);
 
     // ---- proximal step on the 32 pixels of this thread -----------------------------------------
     const int64_t rowoff = (int64_t)h * W * a.P;
@@ -519,7 +522,8 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsPr
     if (!a.t_out) return;
     reg_fence<N1>(v, 0, token);
 
-    spatial_to_spectral<NW>(v, a.twA, a.t_out, CN, a.H, a.K, cn, k, h, pv, w, lane, L, token);
+    spatial_to_spectral<NW>(v, a.twA, a.t_out, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
+                            token);
 }
 
 template <int NW, typename K>
