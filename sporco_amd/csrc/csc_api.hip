@@ -269,6 +269,7 @@ template <typename T> struct Csc : CscBase {
     cx<T> *dft = nullptr, *sft = nullptr, *twA = nullptr, *twB = nullptr;
     T *gramt = nullptr;
     double *part_f = nullptr;
+    int part_f_rows = 0;   // rows of part_f the last column pass wrote (tiles, or tiles x slabs)
     // fused row passes (csc_rows.h)
     bool rows_ok = false;
     cx<T> *twRows = nullptr;
@@ -368,7 +369,9 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMalloc((void **)&dft, sizeof(cx<T>) * npix * K));
             SA_HIP(hipMalloc((void **)&sft, sizeof(cx<T>) * npix * CN));
             SA_HIP(hipMalloc((void **)&gramt, sizeof(T) * npix));
-            SA_HIP(hipMalloc((void **)&part_f, sizeof(double) * 2 * (int64_t)Wf * CN));
+            // (two per tile, and per 64-filter slab for the gradient-regularised slab pass)
+            SA_HIP(hipMalloc((void **)&part_f,
+                             sizeof(double) * 2 * (int64_t)Wf * CN * ((K + 63) / 64)));
             SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * H));
             SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * H));
             std::vector<cx<T>> ta(H), tb(H);
@@ -815,6 +818,7 @@ template <typename T> struct Csc : CscBase {
                 ProfScope ps(prof, PS_FUSED_COLS);
                 nt = launch_fused_cols_mc<T>(st, ma);
             }
+            part_f_rows = (int)nt;
             xf_tiled = true;
             if (out_dev && (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
                 const int slots[1] = {SPORCO_AMD_OUT_DFID};
@@ -840,8 +844,7 @@ template <typename T> struct Csc : CscBase {
         const bool gradreg = p.flags & F_GRADREG;
         const bool tail_ok = tail_mode;
         if (gradreg) {
-            SA_REQUIRE(fused || tail_ok,
-                       "the gradient-regularised column pass needs the K <= 64 kernel");
+            SA_REQUIRE(fused || fused_slabs, "no gradient-regularised column pass for this shape");
             const GradTerm<T> gt = grad_term(p.mu);
             if (!g1t) SA_HIP(hipMalloc((void **)&g1t, sizeof(T) * npix));
             fa.ghh = gt.ghh;
@@ -887,10 +890,12 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_FUSED_COLS);
             launch_cols_fwd_partial<T>(st, sa);
             ntiles = launch_cols_sm_apply_inv<T>(st, sa);
+            if (gradreg) ntiles *= (K + 63) / 64;   // (one row of partials per tile and slab)
         } else {
             ProfScope ps(prof, PS_FUSED_COLS);
             ntiles = launch_fused_cols<T>(st, fa);
         }
+        part_f_rows = (int)ntiles;
         xf_tiled = true;
         if (out_dev && (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y)) {
             const int slots[2] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_RGR};
@@ -964,7 +969,7 @@ template <typename T> struct Csc : CscBase {
             const bool dfid = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
             const int fnv = (p.flags & F_GRADREG) ? 2 : 1;
             ProfScope ps(prof, PS_FINALIZE);
-            launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, (int)(Wf * CN), fnv,
+            launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, part_f_rows, fnv,
                              dfid ? fnv : 0, fslots, fscales, out_dev);
         }
         if (keep_x) {
@@ -1034,8 +1039,7 @@ template <typename T> struct Csc : CscBase {
         T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         const bool gradreg = p.flags & F_GRADREG;
-        if ((fused || (fused_slabs && rows_ok && (!gradreg || grad_tail_ok())) ||
-             (fused_mc && rows_ok)) &&
+        if ((fused || (fused_slabs && rows_ok) || (fused_mc && rows_ok)) &&
             !(p.flags & F_XRRS)) {
             // rows -> [column FFT, Sherman-Morrison, column IFFT] in registers -> rows,
             // through the tile-major intermediate T[wf][cn][h][k] held in the Xf buffer
@@ -1179,7 +1183,7 @@ template <typename T> struct Csc : CscBase {
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         if (rows_ok && !(p.flags & (F_XRRS | F_JOINT)) &&
-            (fused || grad_tail_ok() || !(p.flags & F_GRADREG))) {
+            (fused || fused_slabs || !(p.flags & F_GRADREG))) {
             admm_iter_fused(p, out_dev);
             return;
         }

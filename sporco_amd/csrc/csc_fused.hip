@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) grad_g1_kernel(const FusedColsArgs<float>
 // K = 64 * NH: the column pass in two kernels over 64-filter slabs (see csc_fused.h)
 // ---------------------------------------------------------------------------
 // KS: compile-time row stride in filters (128), or 0 for a run-time a.c.K.
-template <int NW, int LP, int KS>
+template <int NW, int LP, int KS, bool GRAD>
 __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSlabArgs<float> aa) {
     const FusedColsArgs<float> &a = aa.c;
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
@@ -322,6 +322,13 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
     cf *qp = aa.qpart + ((int64_t)tile * NH + slab) * H + w;
     f2 *L = dyn_lds<f2>();
     int token = 0;
+    // GRAD (ConvBPDNGradReg): the partial sums are of Df yuf / dd, dd = ak ghh[f] + bk
+    float ak = 0.f, bk = 0.f;
+    const float *GH = a.ghh + w;
+    if constexpr (GRAD) {
+        ak = a.mu * ((a.wg && kv) ? a.wg[slab * 64 + k] : 1.f);
+        bk = ak * sa_uload(a.ghw + wf) + a.rho;
+    }
 
     cf v[N1];
 #pragma unroll
@@ -379,7 +386,11 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
             if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
+                if constexpr (GRAD) {
+                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                    p = cscale(p, sa_rcp(ak * sa_uload(GH + fo) + bk));
+                }
                 red[2 * e] = p.re;
                 red[2 * e + 1] = p.im;
             }
@@ -396,7 +407,7 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
     });
 }
 
-template <int NW, int LP, int KS>
+template <int NW, int LP, int KS, bool GRAD>
 __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedSlabArgs<float> aa) {
     const FusedColsArgs<float> &a = aa.c;
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
@@ -419,14 +430,20 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
     const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
     const cf *S = a.sft + (int64_t)tile * H + w;
-    const float *G = a.gramt + (int64_t)wf * H + w;
+    const float *G = (GRAD ? a.g1t : a.gramt) + (int64_t)wf * H + w;
+    const float *GH = a.ghh + w;
     const cf *twB = a.twB + w * N1;
     const cf *qp = aa.qpart + (int64_t)tile * NH * H + w;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
     const float rho = a.rho;
     int token = 0;
-    float obj = 0.f;
+    float obj = 0.f, rg = 0.f, ak = 0.f, bk = 0.f, gw = 0.f;
+    if constexpr (GRAD) {
+        gw = sa_uload(a.ghw + wf);
+        ak = a.mu * ((a.wg && kv) ? a.wg[slab * 64 + k] : 1.f);
+        bk = ak * gw + rho;
+    }
 
     cf v[N1];
     static_for<Q>([&](auto qc) {
@@ -454,10 +471,20 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
                     qq = qq + t;
                 }
                 sa_uload2(reinterpret_cast<const float *>(S + fo), sv.re, sv.im);
-                const float inv = sa_rcp(sa_uload(G + fo) + rho);
-                const cf coef = cscale(sv - qq, inv);
-                obj += cabs2(coef);
-                u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d, coef);
+                if constexpr (GRAD) {
+                    const float gh = sa_uload(GH + fo);
+                    const cf coef = cscale(sv - cscale(qq, rho), sa_rcp(sa_uload(G + fo)));
+                    obj += cabs2(coef);
+                    const cf xn = cscale(cscale(u[NW * jl + 4 * c + e], rho) + cmulc(d, coef),
+                                         sa_rcp(ak * gh + bk));
+                    rg += (gh + gw) * cabs2(xn);
+                    u[NW * jl + 4 * c + e] = xn;
+                } else {
+                    const float inv = sa_rcp(sa_uload(G + fo) + rho);
+                    const cf coef = cscale(sv - qq, inv);
+                    obj += cabs2(coef);
+                    u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d, coef);
+                }
             }
             if constexpr (c == CPL - 1) {
                 dit<NW, true>(u, NW * jl);
@@ -470,9 +497,9 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
             }
         });
         {
-            float &ob_ = obj;
+            float &ob_ = obj, &rg_ = rg;
             int &tk_ = token;
-            SA_VGPR_FENCE3(ob_, tk_, tk_);
+            SA_VGPR_FENCE3(ob_, rg_, tk_);
         }
 #pragma unroll
         for (int jl = 0; jl < LP; ++jl) {
@@ -500,8 +527,17 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
 
     // every slab computes the same |coef|^2: slab 0 reports it
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
-    double acc[1] = {(k == 0 && slab == 0) ? (double)obj * pw * (double)rho * (double)rho : 0.0};
-    if (slab == 0) block_sum_store<1>(acc, scratch, a.partials + tile);
+    if constexpr (GRAD) {
+        // per (tile, slab): the data-fidelity sum (slab 0) and this slab's share of the
+        // gradient term
+        const float wk = (a.wg && kv) ? a.wg[slab * 64 + k] : 1.f;
+        double acc[2] = {(k == 0 && slab == 0) ? (double)obj * pw : 0.0,
+                         kv ? (double)(rg * wk) * pw : 0.0};
+        block_sum_store<2>(acc, scratch, a.partials + 2 * ((int64_t)tile * NH + slab));
+    } else {
+        double acc[1] = {(k == 0 && slab == 0) ? (double)obj * pw * (double)rho * (double)rho : 0.0};
+        if (slab == 0) block_sum_store<1>(acc, scratch, a.partials + tile);
+    }
 }
 
 template <typename E>
@@ -735,34 +771,41 @@ template <> bool fused_slabs_supported<float>(int H, int K) {
 }
 template <> bool fused_slabs_supported<double>(int, int) { return false; }
 
-template <int NW, int LP, int KS>
+template <int NW, int LP, int KS, bool GRAD>
 static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
     static bool attr_set = false;
     if (!attr_set) {
-        for (const void *f : {reinterpret_cast<const void *>(&cols_fwd_partial_kernel<NW, LP, KS>),
-                              reinterpret_cast<const void *>(&cols_sm_apply_inv_kernel<NW, LP, KS>)})
+        for (const void *f :
+             {reinterpret_cast<const void *>(&cols_fwd_partial_kernel<NW, LP, KS, GRAD>),
+              reinterpret_cast<const void *>(&cols_sm_apply_inv_kernel<NW, LP, KS, GRAD>)})
             SA_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
     const dim3 grid((unsigned)(ceil_div(a.c.W / 2 + 1, 8) * 8 * a.c.CN), (unsigned)ceil_div(a.c.K, 64));
     if (!second)
-        hipLaunchKernelGGL((cols_fwd_partial_kernel<NW, LP, KS>), grid, dim3(NW * 64),
+        hipLaunchKernelGGL((cols_fwd_partial_kernel<NW, LP, KS, GRAD>), grid, dim3(NW * 64),
                            fused_lds_bytes(NW, LP), st, a);
     else
-        hipLaunchKernelGGL((cols_sm_apply_inv_kernel<NW, LP, KS>), grid, dim3(NW * 64),
+        hipLaunchKernelGGL((cols_sm_apply_inv_kernel<NW, LP, KS, GRAD>), grid, dim3(NW * 64),
                            fused_lds_bytes(NW, LP), st, a);
     SA_HIP(hipGetLastError());
+}
+
+template <int NW, int LP, int KS>
+static void launch_slabs_g(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
+    if (a.c.g1t) launch_slabs<NW, LP, KS, true>(st, a, second);
+    else launch_slabs<NW, LP, KS, false>(st, a, second);
 }
 
 static void launch_slabs_any(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
     SA_REQUIRE(fused_slabs_supported<float>(a.c.H, a.c.K), "shape not handled by the slab column kernels");
     if (a.c.H == 256) {
-        if (a.c.K == 128) launch_slabs<8, 2, 128>(st, a, second);
-        else launch_slabs<8, 2, 0>(st, a, second);
+        if (a.c.K == 128) launch_slabs_g<8, 2, 128>(st, a, second);
+        else launch_slabs_g<8, 2, 0>(st, a, second);
     } else {
-        if (a.c.K == 128) launch_slabs<16, 1, 128>(st, a, second);
-        else launch_slabs<16, 1, 0>(st, a, second);
+        if (a.c.K == 128) launch_slabs_g<16, 1, 128>(st, a, second);
+        else launch_slabs_g<16, 1, 0>(st, a, second);
     }
 }
 template <> void launch_cols_fwd_partial<float>(hipStream_t st, const FusedSlabArgs<float> &a) {

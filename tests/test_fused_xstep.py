@@ -314,6 +314,9 @@ def solve_gradreg(D, S, optd, mu=0.3, unfused=False):
     # 64 < K <= 72: the gradient-regularised column kernel on the first 64 filters + tail
     pytest.param(256, 256, 66, 1, True, marks=pytest.mark.gpu),
     pytest.param(512, 512, 70, 2, True, marks=pytest.mark.gpu),
+    # more filters: the gradient-regularised slab kernels
+    pytest.param(256, 256, 128, 1, True, marks=pytest.mark.gpu),
+    pytest.param(512, 256, 96, 2, False, marks=pytest.mark.gpu),
     pytest.param(256, 256, 4, 1, True, marks=pytest.mark.gpu),
     pytest.param(512, 512, 64, 2, True, marks=pytest.mark.gpu)])
 def test_fused_gradreg_matches_oracle_and_unfused(backend, H, W, K, N, weights):
