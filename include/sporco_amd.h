@@ -333,6 +333,21 @@ int sporco_amd_csc_ccmod_getdict(sporco_amd_csc_t h, int32_t dH, int32_t dW, voi
 int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW);
 /* out[0] = sum |v| over the real state `var` (RegL1 of DictLearn.evaluate,
  * dictlrn/cbpdndl.py:519). */
+/* ---- masked data fidelity (pgm.cbpdn.ConvBPDNMask, sporco/pgm/cbpdn.py:387-506; ----------
+ * pgm.ccmod.ConvCnstrMODMask, sporco/pgm/ccmod.py:408-604) --------------------------------
+ * W (cnvrep.mskWshape layout, broadcastable against (H,W,C,N,1)); NULL removes it. */
+int sporco_amd_csc_set_data_mask(sporco_amd_csc_t h, const void *w, const int64_t shape[5]);
+/* Gradient of (1/2)||W (sum_m d_m * x_m - s)||^2: residual -> irfftn -> W^2 -> rfftn -> adjoint.
+ * dstep == 0: `var` is a coefficient spectrum, the gradient goes to SPORCO_AMD_VAR_GF
+ * (conj(Df) .), pgm/cbpdn.py:454-477; dstep != 0: `var` is a dictionary spectrum, the gradient
+ * goes to SPORCO_AMD_VAR_DGF (sum over images of conj(Zf) .), pgm/ccmod.py:552-575.
+ * write_grad == 0: evaluation only -- out[SPORCO_AMD_PGM_DFID] = sum (W R)^2 (spatial domain,
+ * twice the data fidelity term) and out[SPORCO_AMD_PGM_F] = (1/2) sum |rfftn(W R)|^2 over the
+ * half spectrum (the value backtracking compares, :493-506).  With write_grad != 0 only
+ * out[SPORCO_AMD_PGM_DFID] is filled. */
+int sporco_amd_csc_masked_grad(sporco_amd_csc_t h, int var, int32_t dstep, int32_t write_grad,
+                               double out[SPORCO_AMD_OUT_COUNT]);
+
 /* ---- ADMM consensus dictionary update (admm.ccmod.ConvCnstrMOD_Consensus, -----------
  * sporco/admm/ccmod.py:605-908 on admm.ADMMConsensus, sporco/admm/admm.py:1441-1707) ----
  * One dictionary copy X_n and dual U_n per image (VAR_CX, VAR_CU), consensus variable

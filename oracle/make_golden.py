@@ -476,6 +476,44 @@ def gen_signal():
          k3=np.random.RandomState(1).randn(3, 3), cv1=cv1, Gf=Gf, GHGf=GHGf)
 
 
+def gen_mask():
+    """Masked data fidelity by PGM: pgm.cbpdn.ConvBPDNMask (sporco/pgm/cbpdn.py:387-506) and
+    pgm.ccmod.ConvCnstrMODMask (sporco/pgm/ccmod.py:408-604).  SURVEY.md 8(f) rank 3."""
+    np.random.seed(86420)
+    N, M, Nd, K = 16, 4, 5, 3
+    D = np.random.randn(Nd, Nd, M)
+    S = np.random.randn(N, N, K)
+    W = (np.random.rand(N, N, K) > 0.3).astype(np.float64)
+    W1 = (np.random.rand(N, N) > 0.3).astype(np.float64)
+    for name, Wm, optd in (('pgm_mask_f64', W, {'MaxMainIter': 30, 'L': 500.0}),
+                           ('pgm_mask_f32', W, {'MaxMainIter': 30, 'L': 500.0,
+                                                'DataType': np.float32}),
+                           ('pgm_mask_bcast_bt_f64', W1.reshape(N, N, 1),
+                            {'MaxMainIter': 25, 'L': 1.0, 'Backtrack': BacktrackStandard()})):
+        optd = dict(optd, RelStopTol=0.0)
+        opt = ref_pgm_cbpdn.ConvBPDNMask.Options(optd)
+        b = ref_pgm_cbpdn.ConvBPDNMask(D, S, 0.1, Wm, opt)
+        b.solve()
+        save(name, D=D, S=S, W=Wm, lmbda=np.float64(0.1), X=b.X, Xf=b.Xf,
+             L_final=np.float64(b.L), k_final=np.int64(b.k), **itstat_dict(b))
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    opt = ref_pgm_ccmod.ConvCnstrMODMask.Options({'MaxMainIter': 20, 'L': 800.0})
+    Wi = W.reshape(N, N, 1, K, 1)      # internal layout of S (pgm/ccmod.py:480-486)
+    c = ref_pgm_ccmod.ConvCnstrMODMask(Z, S, Wi, (Nd, Nd, M), opt)
+    c.solve()
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    D0 = np.random.randn(Nd, Nd, M)
+    Wd = W.reshape(N, N, 1, K)
+    opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                               xmethod='pgm', dmethod='pgm')
+    b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, Wd, opt, xmethod='pgm', dmethod='pgm')
+    D1 = b.solve()
+    save('cbpdndlmd_pgm_f64', D0=D0, S=S, W=Wd, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(),
+         **itstat_dict(b))
+    save('pgm_ccmod_mask_f64', Z=Z, S=S, W=Wi, dsz=np.array((Nd, Nd, M)), D=c.getdict(),
+         Xfull=c.X, **itstat_dict(c))
+
+
 def gen_ams():
     """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
     ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
@@ -501,8 +539,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'signal']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'signal': gen_signal,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

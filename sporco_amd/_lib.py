@@ -63,6 +63,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
     'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
+    'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
     'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_sl1l2',
@@ -210,6 +211,8 @@ def load(path=None):
         'sporco_amd_csc_ccmod_cnstr': [vp, i32, i32, i32, dptr],
         'sporco_amd_csc_ccmod_getdict': [vp, i32, i32, vp],
         'sporco_amd_csc_cns_init': [vp, vp, dbl],
+        'sporco_amd_csc_set_data_mask': [vp, vp, ctypes.POINTER(i64)],
+        'sporco_amd_csc_masked_grad': [vp, ctypes.c_int, i32, i32, dptr],
         'sporco_amd_csc_cns_iter': [vp, ctypes.POINTER(CnsParams), dptr],
         'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
         'sporco_amd_csc_asum': [vp, ctypes.c_int, dptr],
@@ -392,6 +395,17 @@ class Solver(object):
     def set_ams_mask(self, w):
         """AddMaskSim mask, 5-D with every axis 1 or full and a singleton filter axis."""
         self._set_weight(self._lib.sporco_amd_csc_set_ams_mask, w)
+
+    def set_data_mask(self, w):
+        """Data-fidelity mask of the *Mask PGM classes, 5-D, singleton filter axis."""
+        self._set_weight(self._lib.sporco_amd_csc_set_data_mask, w)
+
+    def masked_grad(self, var, dstep, write_grad):
+        """Masked data-fidelity gradient / evaluation (sporco_amd_csc_masked_grad)."""
+        out = self._out()
+        check(self._lib.sporco_amd_csc_masked_grad(self._h, int(var), 1 if dstep else 0,
+                                                   1 if write_grad else 0, out))
+        return list(out)
 
     def set_grad_weight(self, w):
         """K per-filter weights of the gradient penalty, or None for 1."""

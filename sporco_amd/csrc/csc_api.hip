@@ -148,6 +148,7 @@ struct CscBase {
     virtual void ccmod_getdict(int dH, int dW, void *dst) = 0;
     virtual void setdict_from_dstep(int dH, int dW) = 0;
     virtual void asum(int var, double *out_dev) = 0;
+    virtual void masked_grad(int var, bool dstep, bool write_grad, double *out_dev) = 0;
     virtual void cns_init(const void *Y0, double rho) = 0;
     virtual void cns_iter(const sporco_amd_cns_params &p, double *out_dev) = 0;
     virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
@@ -254,8 +255,10 @@ template <typename T> struct Csc : CscBase {
     T *gram = nullptr;        // (npix)
     T *dpad = nullptr;        // (H, W, K) real
     T *sreal = nullptr;       // (H, W, CN) real staging / reconstruct output
-    T *wl1_buf = nullptr, *wl21_buf = nullptr, *wams_buf = nullptr;
+    T *wl1_buf = nullptr, *wl21_buf = nullptr, *wams_buf = nullptr, *wdat_buf = nullptr;
     Weight<T> wl1, wl21, wams;   // wams: AddMaskSim mask (F_AMS)
+    Weight<T> wdat;              // data-fidelity mask of the *Mask PGM classes
+    bool have_wdat = false;
     double *part_a = nullptr, *part_b = nullptr;  // block partials
     double *out_dev_own = nullptr;
     double *out_pinned = nullptr;
@@ -409,7 +412,7 @@ template <typename T> struct Csc : CscBase {
                         (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
-                        (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)part_a, (void *)part_b,
+                        (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)wdat_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
         if (out_pinned) (void)hipHostFree(out_pinned);
@@ -637,8 +640,9 @@ template <typename T> struct Csc : CscBase {
     void set_weight(int which, const void *w, const int64_t shape[5]) override {
         before_state_change();   // a pending X of the fused PGM step depends on the weights
         if (which == 2) ams_bits_valid = false;
-        Weight<T> &dst = which == 0 ? wl1 : (which == 1 ? wl21 : wams);
-        T *&buf = which == 0 ? wl1_buf : (which == 1 ? wl21_buf : wams_buf);
+        if (which == 3) have_wdat = w != nullptr;
+        Weight<T> &dst = which == 0 ? wl1 : (which == 1 ? wl21 : (which == 2 ? wams : wdat));
+        T *&buf = which == 0 ? wl1_buf : (which == 1 ? wl21_buf : (which == 2 ? wams_buf : wdat_buf));
         if (buf) {
             sync();
             SA_HIP(hipFree(buf));
@@ -654,7 +658,7 @@ template <typename T> struct Csc : CscBase {
             n *= shape[i];
         }
         if (which == 1) SA_REQUIRE(shape[2] == 1, "L21Weight must not vary over the channel axis");
-        if (which == 2) SA_REQUIRE(shape[4] == 1, "the mask must not vary over the filter axis");
+        if (which >= 2) SA_REQUIRE(shape[4] == 1, "the mask must not vary over the filter axis");
         int64_t dshape[5] = {shape[0], shape[1], shape[2], shape[3], shape[4]};
         std::vector<T> padded;
         const void *srcp = w;
@@ -1709,6 +1713,64 @@ template <typename T> struct Csc : CscBase {
         have_dict = true;
     }
 
+    // ---- masked data fidelity (pgm ConvBPDNMask / ConvCnstrMODMask) -------------------------
+    // Gradient of (1/2) ||W (sum_m d_m * x_m - s)||^2 with respect to the coefficient spectra
+    // (dstep false: `var` is X-sized, result in VAR_GF; pgm/cbpdn.py:454-477) or to the
+    // dictionary (dstep true: `var` is dictionary sized, result in VAR_DGF; pgm/ccmod.py:552-575):
+    // residual -> irfftn -> W^2 -> rfftn -> adjoint.  With write_grad false the residual is
+    // weighted by W only and nothing is written back: out[PGM_DFID] = sum (W R)^2 (twice the
+    // data fidelity term, :481-489) and out[PGM_F] = (1/2) sum_half |rfftn(W R)|^2 (the
+    // unnormalised DFT-domain value backtracking compares, :493-506).
+    void masked_grad(int var, bool dstep, bool write_grad, double *out_dev) override {
+        require_single_channel_dict();
+        if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
+        SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var) == dstep &&
+                       var != SPORCO_AMD_VAR_SF && var != SPORCO_AMD_VAR_DF,
+                   "masked_grad: variable of the wrong kind");
+        before_read(var);
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        cx<T> *Sf = cv(SPORCO_AMD_VAR_SF);
+        {   // residual spectrum R = sum_m Df Xf - Sf, signal sized (npix, C N)
+            ProfScope ps(prof, PS_PGM);
+            if (dstep) {
+                need_natural(SPORCO_AMD_VAR_ZF);
+                launch_inner<T>(st, cv(var), cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
+            } else {
+                require_ready();
+                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(var), innerb, npix, CN, K);
+            }
+            launch_lincomb<T>(st, innerb, T(1), innerb, T(-1), Sf, T(0), nullptr, npix * CN);
+        }
+        inv2(innerb, innerb, sreal, CN);
+        int nb;
+        {
+            ProfScope ps(prof, PS_PGM);
+            nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), write_grad, H, W, C, N,
+                                      part_a);
+        }
+        {
+            const int slots[1] = {SPORCO_AMD_PGM_DFID};
+            const double scales[1] = {1.0};
+            finalize(part_a, nb, 1, 1, slots, scales, out_dev);
+        }
+        fwd2(sreal, nullptr, T(0), innerb, CN);
+        if (!write_grad) {
+            {
+                ProfScope ps(prof, PS_PGM);
+                nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CN, W, part_b);
+            }
+            const int slots[1] = {SPORCO_AMD_PGM_F};
+            const double scales[1] = {0.5};
+            finalize(part_b + 2, nb, 4, 1, slots, scales, out_dev);
+            return;
+        }
+        ProfScope ps(prof, PS_PGM);
+        if (dstep)
+            launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, cv(SPORCO_AMD_VAR_DGF), npix, CN, K);
+        else
+            launch_conj_outer<T>(st, cv(SPORCO_AMD_VAR_DF), innerb, cv(SPORCO_AMD_VAR_GF), npix, CN, K);
+    }
+
     // ---- ADMM consensus dictionary update -------------------------------------------------
     void cns_init(const void *Y0, double rho) override {
         require_single_channel_dict();
@@ -2336,6 +2398,25 @@ int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->setdict_from_dstep(dH, dW);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_data_mask(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
+    h->impl->set_weight(3, w, shape);
+    SA_API_END
+}
+
+int sporco_amd_csc_masked_grad(sporco_amd_csc_t h, int var, int32_t dstep, int32_t write_grad,
+                               double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->masked_grad(var, dstep != 0, write_grad != 0, sb);
+    h->impl->read_out(sb, out);
     SA_API_END
 }
 

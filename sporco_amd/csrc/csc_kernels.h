@@ -180,6 +180,20 @@ template <typename T>
 int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int CN,
                       int K, double *partials);
 
+// Masked data fidelity (pgm.cbpdn.ConvBPDNMask, pgm.ccmod.ConvCnstrMODMask): r (H, W, C, N) real
+// <- w r or w^2 r in place, partial[block] = sum (w r)^2 of the incoming r.  Returns #blocks.
+template <typename T>
+int launch_mask_apply(hipStream_t st, T *r, const Weight<T> &w, bool squared, int H, int W, int C,
+                      int N, double *partials);
+// gf[pix, cn, k] = conj(df[pix, k]) r[pix, cn]
+template <typename T>
+void launch_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *gf, int64_t npix,
+                       int CN, int K);
+// gf[pix, k] = sum_n conj(zf[pix, n, k]) r[pix, n]
+template <typename T>
+void launch_zf_adjoint(hipStream_t st, const cx<T> *zf, const cx<T> *r, cx<T> *gf, int64_t npix,
+                       int CN, int K);
+
 // ADMM consensus dictionary update (admm/ccmod.py:605-908, admm/admm.py:1441-1707): per-image
 // dictionary copies x, duals u (npixr, CN, K) with npixr = H * W, consensus y (npixr, K).
 template <typename T>   // out = y - s u

@@ -1233,6 +1233,91 @@ int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<
 }
 
 // ---------------------------------------------------------------------------
+// masked data fidelity (pgm.cbpdn.ConvBPDNMask, pgm/cbpdn.py:387-506; pgm.ccmod.ConvCnstrMODMask,
+// pgm/ccmod.py:408-604): the residual goes to the spatial domain, is weighted, and comes back
+// ---------------------------------------------------------------------------
+// r(H, W, C, N) <- w^p r (p = 1 or 2), w broadcastable (H, W, C, N, 1); partial[block] = sum (w r)^2
+// of the INPUT r (so that both powers report the weighted residual energy)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mask_apply_kernel(T *__restrict__ r, const Weight<T> w,
+                                                              int squared, int W_, int C, int N,
+                                                              int64_t n, double *partials) {
+    double acc[1] = {0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int nn = (int)(i % N);
+        const int c = (int)((i / N) % C);
+        const int64_t pix = i / ((int64_t)N * C);
+        const int x = (int)(pix % W_), h = (int)(pix / W_);
+        const T wv = w.ptr ? weight_at(w, h, x, c, nn, 0) : T(1);
+        const T v = r[i], wr = wv * v;
+        acc[0] += (double)wr * (double)wr;
+        r[i] = squared ? wv * wr : wr;
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T>
+int launch_mask_apply(hipStream_t st, T *r, const Weight<T> &w, bool squared, int H, int W, int C,
+                      int N, double *partials) {
+    const int64_t n = (int64_t)H * W * C * N;
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((mask_apply_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, r, w, squared ? 1 : 0, W, C, N, n,
+                       partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// gf[pix, cn, k] = conj(df[pix, k]) r[pix, cn]      (D^H applied to a signal-sized spectrum)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) conj_outer_kernel(const cx<T> *__restrict__ df,
+                                                              const cx<T> *__restrict__ r,
+                                                              cx<T> *__restrict__ gf, int64_t npix,
+                                                              int CN, int K) {
+    const int64_t total = npix * CN * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t grp = i / K;
+        gf[i] = cmulc(df[(grp / CN) * K + k], r[grp]);
+    }
+}
+
+template <typename T>
+void launch_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *gf, int64_t npix,
+                       int CN, int K) {
+    hipLaunchKernelGGL((conj_outer_kernel<T>), dim3(grid_for(npix * CN * K)), dim3(kThreads), 0, st,
+                       df, r, gf, npix, CN, K);
+    SA_HIP(hipGetLastError());
+}
+
+// gf[pix, k] = sum_n conj(zf[pix, n, k]) r[pix, n]   (inner over the image axis, pgm/ccmod.py:570)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) zf_adjoint_kernel(const cx<T> *__restrict__ zf,
+                                                              const cx<T> *__restrict__ r,
+                                                              cx<T> *__restrict__ gf, int64_t npix,
+                                                              int CN, int K) {
+    const int64_t total = npix * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int64_t pix = i / K;
+        cx<T> g = mk<T>(T(0), T(0));
+        for (int n = 0; n < CN; ++n) g = g + cmulc(zf[(pix * CN + n) * K + k], r[pix * CN + n]);
+        gf[i] = g;
+    }
+}
+
+template <typename T>
+void launch_zf_adjoint(hipStream_t st, const cx<T> *zf, const cx<T> *r, cx<T> *gf, int64_t npix,
+                       int CN, int K) {
+    hipLaunchKernelGGL((zf_adjoint_kernel<T>), dim3(grid_for(npix * K)), dim3(kThreads), 0, st, zf,
+                       r, gf, npix, CN, K);
+    SA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
 // ADMM consensus dictionary update (admm/ccmod.py:605-908 on admm/admm.py:1441-1707):
 // one dictionary copy X_n (and dual U_n) per image, consensus variable Y (H, W, K)
 // ---------------------------------------------------------------------------
@@ -1965,6 +2050,12 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
                                      int, double *, int, int);                                               \
     template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);                        \
+    template int launch_mask_apply<T>(hipStream_t, T *, const Weight<T> &, bool, int, int, int,    \
+                                      int, double *);                                              \
+    template void launch_conj_outer<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,         \
+                                       int64_t, int, int);                                         \
+    template void launch_zf_adjoint<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,         \
+                                       int64_t, int, int);                                         \
     template void launch_cns_yu<T>(hipStream_t, const T *, const T *, T *, T, int64_t, int, int);  \
     template void launch_cns_mean<T>(hipStream_t, const T *, const T *, const T *, T *, T, T,      \
                                      int64_t, int, int);                                           \

@@ -1,0 +1,106 @@
+"""Convolutional dictionary learning with a spatial mask in the data fidelity term.
+
+Drop-in for ``sporco.dictlrn.cbpdndlmd.ConvBPDNMaskDictLearn`` (sporco/dictlrn/cbpdndlmd.py:
+219-543) with the PGM inner solvers: ``xmethod='pgm'`` (:class:`sporco_amd.pgm.cbpdn.ConvBPDNMask`)
+and ``dmethod='pgm'`` (:class:`sporco_amd.pgm.ccmod.ConvCnstrMODMask`).  The reference's ADMM
+variants (``ConvBPDNMaskDcpl``, ``ConvCnstrMODMaskDcpl_*``) are not part of this backend.
+Both steps share one device handle, as in :mod:`sporco_amd.dictlrn.cbpdndl`.
+"""
+
+import copy
+
+import numpy as np
+
+from . import cbpdndl
+from . import common as dc
+from . import dictlrn
+from .. import _lib
+from .. import cnvrep as cr
+from ..pgm import cbpdn as pgm_cbpdn
+from ..pgm import ccmod as pgm_ccmod
+
+__all__ = ['ConvBPDNMaskDictLearn']
+
+
+def _x_class(method):
+    if method == 'pgm':
+        return pgm_cbpdn.ConvBPDNMask
+    if method == 'admm':
+        raise NotImplementedError("ConvBPDNMaskDcpl (xmethod='admm') is not part of the "
+                                  "sporco_amd hot path; use xmethod='pgm'")
+    raise ValueError('Unknown ConvBPDNMask solver method %s' % method)
+
+
+def _d_class(method):
+    if method == 'pgm':
+        return pgm_ccmod.ConvCnstrMODMask
+    if method in ('ism', 'cg', 'cns'):
+        raise NotImplementedError("ConvCnstrMODMaskDcpl_* (dmethod='%s') is not part of the "
+                                  "sporco_amd hot path; use dmethod='pgm'" % method)
+    raise ValueError('Unknown ConvCnstrMODMask solver method %s' % method)
+
+
+class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
+    r"""Minimise (1/2) sum_k ||W (sum_m d_m * x_{k,m} - s_k)||^2 + lambda sum ||x_{k,m}||_1
+    over coefficient maps and constrained filters by alternating one masked sparse coding step
+    and one masked dictionary update per outer iteration."""
+
+    class Options(dictlrn.DictLearn.Options):
+        """``AccurateDFid``, ``DictSize``, ``CBPDN``, ``CCMOD`` (cbpdndlmd.py:331-380)."""
+
+        defaults = copy.deepcopy(dictlrn.DictLearn.Options.defaults)
+        defaults.update({'DictSize': None, 'AccurateDFid': False})
+
+        def __init__(self, opt=None, xmethod=None, dmethod=None):
+            self.xmethod = 'pgm' if xmethod is None else xmethod
+            self.dmethod = 'pgm' if dmethod is None else dmethod
+            xcls, dcls = _x_class(self.xmethod), _d_class(self.dmethod)
+            xd = copy.deepcopy(xcls.Options.defaults)
+            xd.update({'MaxMainIter': 1})
+            dd = copy.deepcopy(dcls.Options.defaults)
+            dd.update({'MaxMainIter': 1})
+            self.defaults.update({'CBPDN': xd, 'CCMOD': dd})
+            dictlrn.DictLearn.Options.__init__(self, {'CBPDN': xcls.Options(xd),
+                                                      'CCMOD': dcls.Options(dd)})
+            self.update({} if opt is None else opt)
+
+    def __init__(self, D0, S, lmbda, W, opt=None, xmethod=None, dmethod=None, dimK=1, dimN=2,
+                 device=0, stream=None):
+        """``W``: mask compatible with the *internal* layout of ``S`` (cbpdndlmd.py:383-395),
+        e.g. (H, W, 1, K) for K greyscale images.  The reference's default ``xmethod`` is
+        'admm'; this backend offers the PGM pair, so that is the default here."""
+        if opt is None:
+            opt = ConvBPDNMaskDictLearn.Options(xmethod=xmethod, dmethod=dmethod)
+        if xmethod is None:
+            xmethod = opt.xmethod
+        if dmethod is None:
+            dmethod = opt.dmethod
+        if opt.xmethod != xmethod or opt.dmethod != dmethod:
+            raise ValueError('Parameters xmethod and dmethod must have the same values used '
+                             'to initialise the Options object')
+        xcls, dcls = _x_class(xmethod), _d_class(dmethod)
+        self.opt, self.xmethod, self.dmethod = opt, xmethod, dmethod
+        dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
+        cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)
+        D0 = cr.Pcn(D0, dsz, cri.Nv, dimN, cri.dimCd, crp=True, zm=opt['CCMOD', 'ZeroMean'])
+        opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
+        xstep = xcls(D0, S, lmbda, W, opt['CBPDN'], dimK=dimK, dimN=dimN, device=device,
+                     stream=stream)
+        dstep = dcls(None, S, W, dsz, opt['CCMOD'], dimK=dimK, dimN=dimN, dev=xstep.dev)
+        xstep._return_min = False
+        dstep._return_min = False
+        isc = dictlrn.IterStatsConfig(
+            isfld=dc.isfld(xmethod, dmethod, opt), isxmap=dc.isxmap(xmethod, opt),
+            isdmap=dc.isdmap(dmethod), evlmap=dc.evlmap(opt['AccurateDFid']),
+            hdrtxt=dc.hdrtxt(xmethod, dmethod, opt), hdrmap=dc.hdrmap(xmethod, dmethod, opt),
+            fmtmap={'It_X': '%4d', 'It_D': '%4d'})
+        dictlrn.DictLearn.__init__(self, xstep, dstep, opt, isc)
+
+    def evaluate(self):
+        """Objective after the D update with the mask applied (cbpdndlmd.py:522-543)."""
+        if not self.opt['AccurateDFid']:
+            return None
+        dev = self.dstep.dev
+        dfd = dev.masked_grad(_lib.VAR_DXF, True, False)[_lib.PGM_DFID] / 2.0
+        rl1 = dev.asum(self._coef_var())
+        return dict(DFid=dfd, RegL1=rl1, ObjFun=dfd + self.xstep.lmbda * rl1)

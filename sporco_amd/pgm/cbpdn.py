@@ -21,7 +21,7 @@ from .. import _lib
 from .. import cnvrep as cr
 from ..admm.cbpdn import _DeviceArray, _broadcastable
 
-__all__ = ['ConvBPDN']
+__all__ = ['ConvBPDN', 'ConvBPDNMask']
 
 
 class ConvBPDN(pgm.PGMDFT):
@@ -251,3 +251,49 @@ class ConvBPDN(pgm.PGMDFT):
             self.dev.upload(_lib.VAR_AX, np.asarray(X, dtype=self.dtype))
             var = _lib.VAR_AX
         return self.dev.reconstruct(var)[..., 0]
+
+
+class ConvBPDNMask(ConvBPDN):
+    r"""FISTA for convolutional BPDN with a spatial mask in the data fidelity term,
+    (1/2) ||W (sum_m d_m * x_m - s)||_2^2 + lambda sum_m ||x_m||_1 (reference class:
+    sporco/pgm/cbpdn.py:387-506).  The gradient takes the residual to the spatial domain,
+    weights it by W^2 and brings it back (``sporco_amd_csc_masked_grad``); everything else is
+    the unmasked solver.  Single-channel dictionaries."""
+
+    def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
+        super(ConvBPDNMask, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
+        if self.cri.Cd > 1:
+            raise NotImplementedError("ConvBPDNMask with a multi-channel dictionary is not "
+                                      "part of the sporco_amd hot path")
+        if W is None:
+            W = np.array([1.0], dtype=self.dtype)
+        W = np.asarray(W)
+        shp = (1,) * 5 if W.size == 1 else cr.mskWshape(W, self.cri)
+        self.W = np.asarray(W.reshape(shp), dtype=self.dtype)
+        self._upload_mask()
+
+    def _upload_mask(self):
+        H, Wd = self.cri.Nv
+        self.dev.set_data_mask(_broadcastable(self.W, (H, Wd, self.cri.C, self.cri.K, 1)))
+
+    def _upload_weights(self):
+        super(ConvBPDNMask, self)._upload_weights()
+        if hasattr(self, 'W'):
+            self._upload_mask()
+
+    def grad_f(self, V=None):
+        """conj(Df) rfftn(W^2 irfftn(sum_m Df V - Sf)) (pgm/cbpdn.py:454-477)."""
+        if V is None:
+            V = _lib.VAR_YF
+        self.dev.masked_grad(V, False, True)
+        self.invalidate(_lib.VAR_GF)
+        return _lib.VAR_GF
+
+    def obfn_dfd(self):
+        """(1/2) ||W irfftn(sum_m Df Xf - Sf)||^2 (pgm/cbpdn.py:481-489)."""
+        return self.dev.masked_grad(_lib.VAR_XF, False, False)[_lib.PGM_DFID] / 2.0
+
+    def obfn_f(self, Xf=None):
+        """(1/2) ||rfftn(W irfftn(sum_m Df Xf - Sf))||^2, DFT scaling kept
+        (pgm/cbpdn.py:493-506)."""
+        return self.dev.masked_grad(_lib.VAR_XF if Xf is None else Xf, False, False)[_lib.PGM_F]

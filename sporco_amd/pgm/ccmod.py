@@ -21,7 +21,7 @@ from .. import _lib
 from .. import cnvrep as cr
 from ..admm.cbpdn import _DeviceArray
 
-__all__ = ['ConvCnstrMOD']
+__all__ = ['ConvCnstrMOD', 'ConvCnstrMODMask']
 
 
 class ConvCnstrMOD(pgm.PGMDFT):
@@ -180,3 +180,64 @@ class ConvCnstrMOD(pgm.PGMDFT):
         Df = self.Xf if D is None else np.fft.rfftn(np.asarray(D), axes=(0, 1))
         Sf = np.sum(self.Zf * Df, axis=self.cri.axisM)
         return np.fft.irfftn(Sf, self.cri.Nv, axes=(0, 1)).astype(self.dtype)
+
+
+class ConvCnstrMODMask(ConvCnstrMOD):
+    r"""PGM dictionary update with a spatial mask in the data fidelity term,
+    (1/2) sum_k ||W (sum_m d_m * x_{k,m} - s_k)||_2^2 over constrained filters (reference
+    class: sporco/pgm/ccmod.py:408-604).  ``W`` must be compatible with the *internal* layout
+    of ``S``, (H, W, C, K, 1) (single-channel dictionaries: (H, W, 1, C K, 1) works too)."""
+
+    def __init__(self, Z, S, W, dsz, opt=None, dimK=None, dimN=2, **backend):
+        if opt is None:
+            opt = ConvCnstrMODMask.Options()
+        if dimK is None:
+            dimK = 1 if np.asarray(S).ndim > dimN else 0
+        cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        if cri.Cd > 1:
+            raise NotImplementedError("ConvCnstrMODMask with a multi-channel dictionary is not "
+                                      "part of the sporco_amd hot path")
+        W = np.asarray(W)
+        if W.ndim < dimN + 3:
+            W = W.reshape(W.shape + (1,) * (dimN + 3 - W.ndim))
+        if cri.C > 1:
+            # channels fold into the image axis, as S does (pgm/ccmod.py:514-528)
+            shp = list(W.shape)
+            if 1 < shp[cri.axisC] * shp[cri.axisK] < cri.C * cri.K:
+                if shp[cri.axisK] == 1 and cri.K > 1:
+                    shp[cri.axisK] = cri.K
+                else:
+                    shp[cri.axisC] = cri.C
+                W = np.broadcast_to(W, shp)
+            W = W.reshape(W.shape[0:dimN] + (1, W.shape[cri.axisC] * W.shape[cri.axisK], 1))
+        self.W = W
+        super(ConvCnstrMODMask, self).__init__(Z, S, dsz, opt, dimK=dimK, dimN=dimN, **backend)
+        self.W = np.asarray(self.W, dtype=self.dtype)
+        H, Wd = self.cri.Nv
+        w = self.W.reshape(self.W.shape[0:2] + (1,) * (5 - self.W.ndim) + self.W.shape[2:]) \
+            if self.W.ndim < 5 else self.W
+        # device layout of the folded image axis: (C, K) row-major == (1, C K)
+        full = (H, Wd, self.cri.C, self.cri.K, 1)
+        if w.shape[2] == 1 and w.shape[3] == self.cri.C * self.cri.K and self.cri.C > 1:
+            w = w.reshape(w.shape[0], w.shape[1], self.cri.C, self.cri.K, 1)
+        for ws, fs in zip(w.shape, full):
+            if ws not in (1, fs):
+                raise ValueError("mask of shape %s cannot broadcast to %s" % (w.shape, full))
+        self.dev.set_data_mask(np.ascontiguousarray(w))
+
+    def grad_f(self, V=None):
+        """sum_k conj(Zf) rfftn(W^2 irfftn(sum_m Zf V - Sf)) (pgm/ccmod.py:552-575)."""
+        if V is None:
+            V = _lib.VAR_DYF
+        self.dev.masked_grad(V, True, True)
+        self._fcache.pop(V, None)
+        self.invalidate(_lib.VAR_DGF)
+        return _lib.VAR_DGF
+
+    def obfn_dfd(self):
+        """(1/2) ||W irfftn(sum_m Zf Xf - Sf)||^2 (pgm/ccmod.py:579-587)."""
+        return self.dev.masked_grad(_lib.VAR_DXF, True, False)[_lib.PGM_DFID] / 2.0
+
+    def obfn_f(self, Xf=None):
+        """(1/2) ||rfftn(W irfftn(sum_m Zf Xf - Sf))||^2 (pgm/ccmod.py:591-604)."""
+        return self.dev.masked_grad(_lib.VAR_DXF if Xf is None else Xf, True, False)[_lib.PGM_F]

@@ -27,7 +27,8 @@ def _parallel_cpu_run(config):
         return
     if (config.option.markexpr or '').strip() != 'not gpu':
         return
-    if getattr(config.option, 'numprocesses', None) or getattr(config.option, 'collectonly', False):
+    if getattr(config.option, 'numprocesses', None) is not None or \
+            getattr(config.option, 'collectonly', False):
         return
     try:
         n = int(os.environ.get('SPORCO_AMD_TEST_WORKERS', min(4, os.cpu_count() or 1)))

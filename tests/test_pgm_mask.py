@@ -1,0 +1,75 @@
+"""Masked data fidelity by PGM: sporco_amd.pgm.cbpdn.ConvBPDNMask and
+sporco_amd.pgm.ccmod.ConvCnstrMODMask against fixtures produced by the unmodified reference
+(oracle/make_golden.py gen_mask).  float64 1e-9, float32 1e-4."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+
+def policies():
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    return {
+        'pgm_mask_f64': {'MaxMainIter': 30, 'L': 500.0},
+        'pgm_mask_f32': {'MaxMainIter': 30, 'L': 500.0, 'DataType': np.float32},
+        'pgm_mask_bcast_bt_f64': {'MaxMainIter': 25, 'L': 1.0, 'Backtrack': BacktrackStandard()},
+    }
+
+
+@pytest.mark.parametrize('name', ['pgm_mask_f64', 'pgm_mask_f32', 'pgm_mask_bcast_bt_f64'])
+def test_convbpdnmask_traces(backend, name):
+    from sporco_amd.pgm import cbpdn
+    g = load_golden(name)
+    optd = dict(policies()[name], RelStopTol=0.0)
+    tol = 1e-4 if optd.get('DataType') is np.float32 else 1e-9
+    b = cbpdn.ConvBPDNMask(g['D'], g['S'], float(g['lmbda']), g['W'],
+                           cbpdn.ConvBPDNMask.Options(optd))
+    X = b.solve()
+    assert b.k == int(g['k_final'])
+    assert X.shape == g['X'].shape and rel_l2(X, g['X']) < tol
+    assert abs(float(b.L) - float(g['L_final'])) < 1e-6 * float(g['L_final'])
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < tol, f
+    # a mask of ones is the unmasked solver
+    b1 = cbpdn.ConvBPDNMask(g['D'], g['S'], float(g['lmbda']), None,
+                            cbpdn.ConvBPDNMask.Options({'MaxMainIter': 5, 'L': 500.0}))
+    b0 = cbpdn.ConvBPDN(g['D'], g['S'], float(g['lmbda']),
+                        cbpdn.ConvBPDN.Options({'MaxMainIter': 5, 'L': 500.0}))
+    assert rel_l2(b1.solve(), b0.solve()) < (1e-5 if tol > 1e-6 else 1e-12)
+
+
+def test_convcnstrmodmask_trace(backend):
+    from sporco_amd.pgm import ccmod
+    g = load_golden('pgm_ccmod_mask_f64')
+    opt = ccmod.ConvCnstrMODMask.Options({'MaxMainIter': 20, 'L': 800.0})
+    c = ccmod.ConvCnstrMODMask(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']), opt)
+    c.solve()
+    assert rel_l2(c.getdict(), g['D']) < 1e-9
+    assert rel_l2(c.getdict(crop=False), g['Xfull']) < 1e-9
+    its = c.getitstat()
+    for f in ('DFid', 'Rsdl', 'L'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+    assert max(its.Cnstr) < 1e-12
+
+
+def test_masked_dictionary_learning_trace(backend):
+    """ConvBPDNMaskDictLearn with the PGM inner solvers (cbpdndlmd.py:219-543)."""
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_pgm_f64')
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                                  xmethod='pgm', dmethod='pgm')
+    d = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod='pgm', dmethod='pgm')
+    D1 = d.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(d.getcoef(), g['X']) < 1e-9
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'Cnstr', 'X_L', 'X_Rsdl', 'D_L', 'D_Rsdl'):
+        if f == 'Cnstr':
+            assert max(getattr(its, f)) < 1e-10
+        else:
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+    with pytest.raises(NotImplementedError):
+        cbpdndlmd.ConvBPDNMaskDictLearn.Options(xmethod='admm')
