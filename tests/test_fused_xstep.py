@@ -353,7 +353,11 @@ def test_fused_gradreg_matches_oracle_and_unfused(backend, H, W, K, N, weights):
 @pytest.mark.parametrize('H,W,K,N,gradreg', [
     pytest.param(256, 256, 3, 2, False, marks=pytest.mark.gpu),
     pytest.param(256, 256, 5, 1, True, marks=pytest.mark.gpu),
-    pytest.param(512, 512, 63, 3, False, marks=pytest.mark.gpu)])
+    pytest.param(512, 512, 63, 3, False, marks=pytest.mark.gpu),
+    # a 64-filter dictionary: 65 filters, padded to 66, column pass in tail mode, the impulse
+    # in the first half of the last filter pair
+    pytest.param(256, 256, 64, 2, False, marks=pytest.mark.gpu),
+    pytest.param(512, 256, 64, 1, True, marks=pytest.mark.gpu)])
 def test_fused_ams_matches_oracle_and_unfused(backend, H, W, K, N, gradreg):
     from oracle import cbpdn_oracle as orc
     from sporco_amd.admm import cbpdn
