@@ -96,7 +96,9 @@ typedef struct {
 #define SPORCO_AMD_VAR_DT0 39     /* cplx  scratch for host-composed policies            */
 #define SPORCO_AMD_VAR_DT1 40
 #define SPORCO_AMD_VAR_DT2 41
-#define SPORCO_AMD_VAR_COUNT 42
+#define SPORCO_AMD_VAR_DSX 42     /* real  X of the single-copy ADMM D-step (dstep_iter)   */
+#define SPORCO_AMD_VAR_DSU 43     /* real  its scaled dual variable U                      */
+#define SPORCO_AMD_VAR_COUNT 44
 
 /* Create a solver on HIP device `device`.  `stream` is a hipStream_t to borrow
  * (e.g. torch.cuda.current_stream().cuda_stream) or NULL to own a new one.
@@ -212,6 +214,9 @@ typedef struct {
 #define SPORCO_AMD_OUT_RGR 11    /* Parseval sum of GradWeight GHGf |Xf|^2 / (H W)  (twice RegGrad,
                                   * cbpdn.py:1204-1214; FLAG_GRADREG only)         */
 #define SPORCO_AMD_OUT_CNSTR 12  /* sum (Pcn(Y) - Y)^2 of the consensus D-step (ccmod.py:888-894) */
+#define SPORCO_AMD_OUT_CGIT 13   /* CG D-step: scipy's cg() status, 0 = converged, else MaxIter
+                                    (what the reference records as XSlvCGIt, linalg.py:578) */
+#define SPORCO_AMD_OUT_CGN 14    /* CG D-step: iterations actually run                     */
 #define SPORCO_AMD_OUT_COUNT 16
 
 /* One full ADMM iteration on device: xstep (cbpdn.py:267-281: rfftn(Y-U),
@@ -372,6 +377,37 @@ typedef struct {
  * (fEvalX False, gEvalY True: the class defaults, ccmod.py:853-894). */
 int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]);
+
+/* ---- ADMM dictionary update with one dictionary copy ---------------------------------------
+ * sporco.admm.ccmod.ConvCnstrMOD_IterSM / ConvCnstrMOD_CG (ccmod.py:433-601) on ConvCnstrMODBase
+ * (:103-429) and ADMMEqual (admm.py:808-983).  X = VAR_DSX, Y = VAR_DX (spectrum VAR_DXF kept
+ * current, as for the consensus update), U = VAR_DSU, all (H,W,K) real; Xf = VAR_DYF persists
+ * between calls (the CG warm start, ccmod.py:583,594-597).  Coefficient maps come from
+ * sporco_amd_csc_ccmod_setcoef.  Single-channel dictionaries. */
+#define SPORCO_AMD_DSTEP_ISM 0   /* X-step by linalg.solvemdbi_ism over the images (<= 8 images
+                                    times channels), ccmod.py:496-505                        */
+#define SPORCO_AMD_DSTEP_CG 1    /* X-step by linalg.solvemdbi_cg (scipy cg semantics: stop at
+                                    ||r|| < tol ||b|| at the top of an iteration), :587-601   */
+/* Y = U = Y0 (uinit, ccmod.py:298-307) or 0; Xf = 0. */
+int sporco_amd_csc_dstep_init(sporco_amd_csc_t h, const void *Y0);
+typedef struct {
+    double rho;      /* penalty parameter                                               */
+    double rlx;      /* RelaxParam                                                      */
+    double u_scale;  /* pending U /= rsf, as in sporco_amd_admm_params                  */
+    double cg_tol;   /* CG StopTol                                                      */
+    uint32_t flags;  /* SPORCO_AMD_FLAG_OBJ | _XRRS | _FEVAL_Y | _GEVAL_Y               */
+    int32_t dH, dW;  /* filter support of the constraint set                            */
+    int32_t zero_mean;
+    int32_t method;  /* SPORCO_AMD_DSTEP_ISM / SPORCO_AMD_DSTEP_CG                      */
+    int32_t cg_maxiter;
+} sporco_amd_dstep_params;
+/* One iteration: xstep (b = sum_n conj(Zf_n) Sf_n + rho rfftn(Y - U); Xf = (Z^H Z + rho I)^-1 b),
+ * relax_AX (admm.py:877-885), ystep Y = Pcn(AX + U) (ccmod.py:363-368), ustep.  out: R2 = |X - Y|^2,
+ * S2 = |Y - Yprev|^2, AX2 = |X|^2, Y2, U2; with FLAG_OBJ: DFID (at Xf, or at rfftn(Y) with
+ * FLAG_FEVAL_Y) and CNSTR (at X, or at Y with FLAG_GEVAL_Y), ccmod.py:372-410; with FLAG_XRRS the
+ * sums of xstep_check (:343-357); CGIT / CGN for the CG method. */
+int sporco_amd_csc_dstep_iter(sporco_amd_csc_t h, const sporco_amd_dstep_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]);
 
 int sporco_amd_csc_asum(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]);
 

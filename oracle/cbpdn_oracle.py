@@ -610,3 +610,135 @@ def admm_ccmod_cns(Z, S, dsz, dtype=np.float64, maxiter=20, rho=None, rlx=1.8,
     out = {key: np.array(val) for key, val in tr.items()}
     out.update(X=X, Y=Y, U=U, rho=rho, iters=k + 1, D=bcrop(Y, dsz))
     return out
+
+
+# ---------------------------------------------------------------------------
+# ADMM dictionary updates with a single dictionary copy: ConvCnstrMOD_IterSM and
+# ConvCnstrMOD_CG (sporco/admm/ccmod.py:433-601) on ConvCnstrMODBase (:103-429)
+# and ADMMEqual (sporco/admm/admm.py:808-983)
+# ---------------------------------------------------------------------------
+
+def cg_solve(matvec, b, x0, rtol, maxiter):
+    """Conjugate gradients as scipy.sparse.linalg.cg (1.15) runs it for
+    linalg.solvemdbi_cg (sporco/linalg.py:515-579): no preconditioner, stop when
+    ||r|| < rtol ||b|| at the top of an iteration.  Returns (x, info) with scipy's
+    ``info``: 0 on convergence, ``maxiter`` otherwise -- that flag is what the
+    reference records as 'XSlvCGIt'."""
+    x = x0.copy()
+    bn = np.linalg.norm(b.ravel())
+    if bn == 0:
+        return b.copy(), 0
+    atol = rtol * bn
+    r = b - matvec(x) if x.any() else b.copy()
+    p, rho_prev = None, None
+    for it in range(maxiter):
+        if np.linalg.norm(r.ravel()) < atol:
+            return x, 0
+        rho_cur = np.vdot(r.ravel(), r.ravel())
+        p = r.copy() if it == 0 else r + (rho_cur / rho_prev) * p
+        q = matvec(p)
+        alpha = rho_cur / np.vdot(p.ravel(), q.ravel())
+        x = x + alpha * p
+        r = r - alpha * q
+        rho_prev = rho_cur
+    return x, maxiter
+
+
+def admm_ccmod_eq(Z, S, dsz, method='ism', dtype=np.float64, maxiter=20, rho=None,
+                  rlx=1.8, auto_rho=True, rho_period=1, rho_tau=1000.0, rho_mu=1.2,
+                  rho_xi=1.0, auto_scaling=True, zero_mean=False, Y0=None,
+                  aux_var_obj=False, lin_solve_check=False, cg_tol=1e-3,
+                  cg_maxiter=1000, abs_tol=0.0, rel_tol=1e-3):
+    """ConvCnstrMOD_IterSM (``method='ism'``) / ConvCnstrMOD_CG (``'cg'``) for a
+    single-channel dictionary.
+
+    ``Z``: (H, W, 1, Nb, M), ``S``: (H, W, 1, Nb, 1), ``dsz`` = (dH, dW, M); X, Y, U
+    are (H, W, 1, 1, M).
+      xstep  b = sum_n conj(Zf_n) Sf_n + rho rfftn(Y - U); Xf = (Z^H Z + rho I)^-1 b
+             by iterated Sherman-Morrison (ccmod.py:496-505) or CG warm-started from
+             the previous Xf (:587-601; Xf starts at 0, :583)
+      relax  admm.py:877-885, ystep Y = Pcn(AX + U) (ccmod.py:363-368), ustep
+             admm.py:434-437, residuals admm.py:462-486 with :959-983
+      objective (ccmod.py:372-410): DFid at Xf (or rfftn(Y) with AuxVarObj), Cnstr =
+             ||Pcn(v) - v|| at X (or Y)
+    Default rho is 1.0 (the ``dval=cri.K`` of ccmod.py:264 comes after the base class
+    has set the attribute); uinit (:298-307): U0 = Y0.
+    """
+    dtype = np.dtype(dtype)
+    rdt = real_dtype(dtype).type
+    Z = np.asarray(Z, dtype=dtype)
+    S = np.asarray(S, dtype=dtype)
+    H, W = S.shape[0], S.shape[1]
+    M = Z.shape[AX_K]
+    rho = rdt(1.0 if rho is None else rho)
+    rlx = rdt(rlx)
+    Sf = rfftn2(S)
+    Zf = rfftn2(Z)
+    ZSf = inner(np.conj(Zf), Sf, axis=AX_N)
+    P = lambda v: pcn(v, dsz, (H, W), 2, 1, crp=False, zm=zero_mean)
+    yshape = (H, W, 1, 1, M)
+    if Y0 is None:
+        Y = np.zeros(yshape, dtype=dtype)
+        U = np.zeros(yshape, dtype=dtype)
+    else:
+        Y = np.asarray(Y0).astype(dtype, copy=True)
+        U = Y.copy()
+    Xf = np.zeros((H, W // 2 + 1, 1, 1, M), dtype=complex_dtype(dtype))
+    Nx = int(np.prod(yshape))
+    AHA = lambda x: inner(np.conj(Zf), inner(Zf, x, axis=AX_K), axis=AX_N)
+    keys = ('DFid', 'Cnstr', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho',
+            'XSlvRelRes') + (('XSlvCGIt',) if method == 'cg' else ())
+    tr = {k: [] for k in keys}
+    X = None
+    for k in range(maxiter):
+        Yprev = Y.copy()
+        b = ZSf + rho * rfftn2(Y - U)
+        if method == 'ism':
+            Xf = solvemdbi_ism(Zf, rho, b, AX_K, AX_N)
+            cgit = None
+        else:
+            Xf, cgit = cg_solve(lambda x: AHA(x) + rho * x, b, Xf, cg_tol, cg_maxiter)
+        Xf = Xf.astype(complex_dtype(dtype))
+        X = irfftn2(Xf, (H, W))
+        xrrs = rrs(AHA(Xf) + rho * Xf, b) if lin_solve_check else np.nan
+        AX = X if rlx == 1.0 else rlx * X + (1 - rlx) * Y
+        Y = P(AX + U).astype(dtype)
+        U = U + (AX - Y)
+        nr = np.linalg.norm(X - Y)
+        ns = rho * np.linalg.norm(Yprev - Y)
+        rn = max(np.linalg.norm(X), np.linalg.norm(Y))
+        sn = rho * np.linalg.norm(U)
+        rn = 1.0 if rn == 0.0 else rn
+        sn = 1.0 if sn == 0.0 else sn
+        r, s = nr / rn, ns / sn
+        epri = np.sqrt(Nx) * abs_tol / rn + rel_tol
+        edua = np.sqrt(Nx) * abs_tol / sn + rel_tol
+        fv = rfftn2(Y) if aux_var_obj else Xf
+        gv = Y if aux_var_obj else X
+        dfd = rfl2norm2(inner(Zf, fv, axis=AX_K) - Sf, S.shape) / 2.0
+        cns = np.linalg.norm(P(gv) - gv)
+        vals = dict(DFid=dfd, Cnstr=cns, PrimalRsdl=r, DualRsdl=s, EpsPrimal=epri,
+                    EpsDual=edua, Rho=rho, XSlvRelRes=xrrs, XSlvCGIt=cgit)
+        for key in keys:
+            tr[key].append(float(vals[key]))
+        if auto_rho and k != 0 and (k + 1) % rho_period == 0:
+            if auto_scaling:
+                if s == 0.0 or r == 0.0:
+                    rhomlt = rho_tau
+                else:
+                    rhomlt = min(np.sqrt(r / (s * rho_xi) if r > s * rho_xi
+                                         else (s * rho_xi) / r), rho_tau)
+            else:
+                rhomlt = rho_tau
+            rsf = 1.0
+            if r > rho_xi * rho_mu * s:
+                rsf = rhomlt
+            elif s > (rho_mu / rho_xi) * r:
+                rsf = 1.0 / rhomlt
+            rho = rho * rdt(rsf)
+            U = U / rsf
+        if r < epri and s < edua:
+            break
+    out = {key: np.array(val) for key, val in tr.items()}
+    out.update(X=X, Y=Y, U=U, rho=rho, iters=k + 1, D=bcrop(Y, dsz))
+    return out

@@ -458,6 +458,47 @@ def gen_cns():
         save(name, D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_ccmod_eq():
+    """Single-copy ADMM dictionary updates ConvCnstrMOD_IterSM and ConvCnstrMOD_CG
+    (sporco/admm/ccmod.py:433-601 on ConvCnstrMODBase :103-429) alone and inside
+    ConvBPDNDictLearn(dmethod='ism' / 'cg').  SURVEY.md 8(f) rank 3."""
+    np.random.seed(86420)
+    N, M, Nd, K = 16, 4, 5, 3
+    S = np.random.randn(N, N, K)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    D0 = np.random.randn(Nd, Nd, M)
+    Y0 = ref_cnvrep.zpad(ref_cnvrep.stdformD(
+        ref_cnvrep.Pcn(D0, (Nd, Nd, M), (N, N), 2, 0, crp=True), 1, M, 2), (N, N))
+    fixed = {'rho': 5.0, 'AutoRho': {'Enabled': False}}
+    for meth, cls in (('ism', ref_admm_ccmod.ConvCnstrMOD_IterSM),
+                      ('cg', ref_admm_ccmod.ConvCnstrMOD_CG)):
+        for name, optd in (
+                ('f64', {'MaxMainIter': 20}),
+                ('f32', {'MaxMainIter': 20, 'DataType': np.float32}),
+                ('fixedrho_zm_chk_f64', dict(fixed, MaxMainIter=20, ZeroMean=True,
+                                             LinSolveCheck=True, RelaxParam=1.5)),
+                ('auxobj_y0_f64', {'MaxMainIter': 12, 'AuxVarObj': True, 'Y0': Y0,
+                                   'AutoRho': {'Period': 3, 'Scaling': 2.0,
+                                               'AutoScaling': False, 'RsdlRatio': 1.5}})):
+            if meth == 'cg' and 'fixedrho' in name:
+                optd = dict(optd, CG={'MaxIter': 500, 'StopTol': 1e-9})
+            opt = cls.Options(optd)
+            c = cls(Z, S, (Nd, Nd, M), opt)
+            c.solve()
+            extra = {'Y0': Y0} if 'Y0' in optd else {}
+            save('ccmod_%s_%s' % (meth, name), Z=Z, S=S, dsz=np.array((Nd, Nd, M)),
+                 D=c.getdict(), Y=c.Y, X=c.X, U=c.U, rho_final=np.float64(c.rho),
+                 k_final=np.int64(c.k), **extra, **itstat_dict(c))
+        for dt, tag in ((np.float64, 'f64'), (np.float32, 'f32')):
+            opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+                {'MaxMainIter': 10, 'AccurateDFid': True}, xmethod='admm', dmethod=meth)
+            b = ref_cbpdndl.ConvBPDNDictLearn(D0.astype(dt), S.astype(dt), 0.1, opt,
+                                              xmethod='admm', dmethod=meth)
+            D1 = b.solve()
+            save('cbpdndl_%s_%s' % (meth, tag), D0=D0, S=S, lmbda=np.float64(0.1), D1=D1,
+                 X=b.getcoef(), **itstat_dict(b))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -539,8 +580,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -18,6 +18,8 @@ VAR_T0, VAR_T1, VAR_T2, VAR_ZF = 13, 14, 15, 16
 VAR_CX, VAR_CU = 17, 18
 VAR_DX, VAR_DXF, VAR_DYF, VAR_DXFPRV, VAR_DYFPRV = 32, 33, 34, 35, 36
 VAR_DVF, VAR_DGF, VAR_DT0, VAR_DT1, VAR_DT2 = 37, 38, 39, 40, 41
+VAR_DSX, VAR_DSU = 42, 43
+DSTEP_ISM, DSTEP_CG = 0, 1
 
 FLAG_NONNEG = 1 << 0
 FLAG_NOBNDRY = 1 << 1
@@ -38,6 +40,7 @@ OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
 OUT_XRRS_D2, OUT_XRRS_AX2, OUT_XRRS_B2 = 8, 9, 10
 OUT_RGR = 11
 OUT_CNSTR = 12
+OUT_CGIT, OUT_CGN = 13, 14
 OUT_COUNT = 16
 
 PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY = range(6)
@@ -63,6 +66,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
     'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
+    'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
@@ -90,6 +94,13 @@ class CnsParams(ctypes.Structure):
     _fields_ = [('rho', ctypes.c_double), ('rlx', ctypes.c_double), ('u_scale', ctypes.c_double),
                 ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32), ('dW', ctypes.c_int32),
                 ('zero_mean', ctypes.c_int32)]
+
+
+class DstepParams(ctypes.Structure):
+    _fields_ = [('rho', ctypes.c_double), ('rlx', ctypes.c_double), ('u_scale', ctypes.c_double),
+                ('cg_tol', ctypes.c_double), ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32),
+                ('dW', ctypes.c_int32), ('zero_mean', ctypes.c_int32), ('method', ctypes.c_int32),
+                ('cg_maxiter', ctypes.c_int32)]
 
 
 class AdmmParams(ctypes.Structure):
@@ -214,6 +225,8 @@ def load(path=None):
         'sporco_amd_csc_set_data_mask': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_masked_grad': [vp, ctypes.c_int, i32, i32, dptr],
         'sporco_amd_csc_cns_iter': [vp, ctypes.POINTER(CnsParams), dptr],
+        'sporco_amd_csc_dstep_init': [vp, vp],
+        'sporco_amd_csc_dstep_iter': [vp, ctypes.POINTER(DstepParams), dptr],
         'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
         'sporco_amd_csc_asum': [vp, ctypes.c_int, dptr],
         'sporco_amd_csc_profile': [vp, ctypes.c_int],
@@ -336,7 +349,7 @@ class Solver(object):
         if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2,
                    VAR_ZF):
             return (H, Wf, C, N, K), self.cdtype
-        if var == VAR_DX:
+        if var in (VAR_DX, VAR_DSX, VAR_DSU):
             return (H, W, self.Cd, 1, K), self.dtype
         if VAR_DXF <= var <= VAR_DT2:
             return (H, Wf, self.Cd, 1, K), self.cdtype
@@ -513,6 +526,24 @@ class Solver(object):
                       1 if zero_mean else 0)
         out = self._out()
         check(self._lib.sporco_amd_csc_cns_iter(self._h, ctypes.byref(p), out))
+        return list(out)
+
+    def dstep_init(self, Y0):
+        """Single-copy ADMM D-step state: Y = U = Y0 (H, W, 1, 1, K) or zero, Xf = 0."""
+        if Y0 is None:
+            check(self._lib.sporco_amd_csc_dstep_init(self._h, None))
+            return
+        H, W, C, N, K = self.dims
+        Y0 = _carr(Y0, self.dtype).reshape(H, W, K)
+        check(self._lib.sporco_amd_csc_dstep_init(self._h, _ptr(Y0)))
+
+    def dstep_iter(self, method, rho, rlx, u_scale, flags, dH, dW, zero_mean, cg_tol=1e-3,
+                   cg_maxiter=1000):
+        """One IterSM / CG D-step iteration (sporco_amd_csc_dstep_iter)."""
+        p = DstepParams(float(rho), float(rlx), float(u_scale), float(cg_tol), int(flags), int(dH),
+                        int(dW), 1 if zero_mean else 0, int(method), int(cg_maxiter))
+        out = self._out()
+        check(self._lib.sporco_amd_csc_dstep_iter(self._h, ctypes.byref(p), out))
         return list(out)
 
     def pgm_eval(self, var):

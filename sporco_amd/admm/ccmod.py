@@ -1,10 +1,10 @@
-"""ADMM dictionary update on the GPU: the consensus form of convolutional constrained MOD.
+"""ADMM dictionary updates on the GPU: convolutional constrained MOD in its consensus form
+and with a single dictionary copy (iterated Sherman-Morrison / conjugate gradient X-steps).
 
-Drop-in for ``sporco.admm.ccmod.ConvCnstrMOD_Consensus`` (sporco/admm/ccmod.py:605-908, on
-``admm.ADMMConsensus``, sporco/admm/admm.py:1441-1707): same constructor, Options tree,
-IterationStats fields and methods (``setcoef / getdict / solve / getitstat``).  The other two
-ADMM dictionary updates of the reference (``ConvCnstrMOD_IterSM``, ``ConvCnstrMOD_CG``) are
-not part of the hot path and raise ``NotImplementedError`` through :func:`ConvCnstrMOD`.
+Drop-ins for ``sporco.admm.ccmod.ConvCnstrMOD_Consensus`` (sporco/admm/ccmod.py:605-908, on
+``admm.ADMMConsensus``, sporco/admm/admm.py:1441-1707), ``ConvCnstrMOD_IterSM`` (:433-505) and
+``ConvCnstrMOD_CG`` (:511-601, both on ``ConvCnstrMODBase`` :103-429): same constructors,
+Options trees, IterationStats fields and methods (``setcoef / getdict / solve / getitstat``).
 
 Each image keeps its own copy X_n of the (zero-padded) dictionary and a dual U_n, both
 resident on the device; the consensus variable Y is the dictionary.  One iteration is one call
@@ -23,7 +23,8 @@ from .. import _lib
 from .. import cnvrep as cr
 from ..fft import real_dtype
 
-__all__ = ['ConvCnstrMOD_Consensus', 'ConvCnstrMOD', 'ConvCnstrMODOptions']
+__all__ = ['ConvCnstrMOD_Consensus', 'ConvCnstrMOD_IterSM', 'ConvCnstrMOD_CG', 'ConvCnstrMOD',
+           'ConvCnstrMODOptions']
 
 
 class ConvCnstrMOD_Consensus(admm.ADMM):
@@ -242,15 +243,209 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
         return self.dev.profile_read()
 
 
-_METHODS = {'cns': ConvCnstrMOD_Consensus}
+class ConvCnstrMODBase(ConvCnstrMOD_Consensus):
+    r"""Shared part of the single-copy ADMM dictionary updates (ConvCnstrMODBase,
+    sporco/admm/ccmod.py:103-429, on ADMMEqual): X, Y and U are all one zero-padded dictionary
+    (H, W, 1, 1, M); one iteration is one call of ``sporco_amd_csc_dstep_iter``.
+
+    Derived from the consensus class for the parts that do not depend on the splitting (device
+    handle, coefficient maps, dictionary read-back, objective terms); state, iteration and
+    residuals are those of ADMMEqual (admm.py:808-983).
+    """
+
+    class Options(admm.ADMM.Options):
+        """ConvCnstrMODBase.Options (ccmod.py:109-177): ADMMEqual options plus ``AuxVarObj,
+        ZeroMean, LinSolveCheck``; AutoRho on with period 1."""
+
+        defaults = copy.deepcopy(admm.ADMM.Options.defaults)
+        defaults.update({'AuxVarObj': False, 'fEvalX': True, 'gEvalY': False, 'ReturnX': False,
+                         'RelaxParam': 1.8, 'ZeroMean': False, 'LinSolveCheck': False})
+        defaults['AutoRho'].update({'Enabled': True, 'Period': 1, 'AutoScaling': True,
+                                    'Scaling': 1000.0, 'RsdlRatio': 1.2})
+
+        def __init__(self, opt=None):
+            admm.ADMM.Options.__init__(self, {} if opt is None else opt)
+            if self['AutoRho', 'RsdlTarget'] is None:
+                self['AutoRho', 'RsdlTarget'] = 1.0
+
+        def __setitem__(self, key, value):
+            admm.ADMM.Options.__setitem__(self, key, value)
+            if key == 'AuxVarObj':
+                self['fEvalX'] = value is not True
+                self['gEvalY'] = value is True
+
+    _method = None
+
+    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
+        if opt is None:
+            opt = type(self).Options()
+        if dimN != 2:
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        if self.cri.Cd > 1:
+            raise NotImplementedError("multi-channel dictionaries are not part of the "
+                                      "sporco_amd dictionary update")
+        if opt['ReturnX']:
+            raise NotImplementedError("the device D-step returns the constrained variable Y "
+                                      "(ReturnX False, the class default)")
+        self.set_dtype(opt, S.dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
+        H, W = self.cri.Nv
+        self.Nb = self.cri.C * self.cri.K
+        if self._method == _lib.DSTEP_ISM and self.Nb > 8:
+            raise NotImplementedError(
+                "the iterated Sherman-Morrison D-step handles up to 8 images (times channels) on "
+                "the device, %d given; use 'cns' or 'cg' (the reference's own advice for larger "
+                "training sets)" % self.Nb)
+        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
+        self._shared = dev is not None
+        if dev is None:
+            self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                                   device=device, stream=stream)
+            self.dev.set_signal(self.S)
+        else:
+            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
+                raise ValueError("shared device solver has different dimensions")
+            self.dev = dev
+        self._cache = {}
+        self._u_scale = 1.0
+        self._sums = [0.0] * _lib.OUT_COUNT
+        Nx = int(np.prod(self.cri.shpD))
+        admm.ADMM.__init__(self, Nx, self.cri.shpD, self.cri.shpD, S.dtype, opt)
+        # (as for the consensus class, the `dval=cri.K` of ccmod.py:264 never takes effect)
+        self.xrrs = None
+        self.cgit = None
+        if Z is not None:
+            self.setcoef(Z)
+
+    # -- state ---------------------------------------------------------------------------
+    def init_state(self, yshape, ushape):
+        """Y = Y0 or zeros, U = Y0 or zeros (uinit, ccmod.py:298-307), Xf = 0."""
+        self.dev.dstep_init(self.opt['Y0'])
+        if self.opt['U0'] is not None:
+            self.U = self.opt['U0']
+
+    @property
+    def X(self):
+        return self.dev.download(_lib.VAR_DSX)
+
+    @X.setter
+    def X(self, value):
+        if value is not None:
+            self.dev.upload(_lib.VAR_DSX, np.asarray(value, dtype=self.dtype))
+
+    @property
+    def Xf(self):
+        return self.dev.download(_lib.VAR_DYF)
+
+    @property
+    def U(self):
+        u = self.dev.download(_lib.VAR_DSU)
+        return u * u.dtype.type(self._u_scale) if self._u_scale != 1.0 else u
+
+    @U.setter
+    def U(self, value):
+        if value is not None:
+            self.dev.upload(_lib.VAR_DSU, np.asarray(value, dtype=self.dtype))
+            self._u_scale = 1.0
+
+    # -- iteration --------------------------------------------------------------------------
+    def _cg_options(self):
+        return 1e-3, 1000
+
+    def iteration(self):
+        flags = 0
+        if not self.opt['FastSolve']:
+            flags |= _lib.FLAG_OBJ
+        if not self.opt['fEvalX']:
+            flags |= _lib.FLAG_FEVAL_Y
+        if self.opt['gEvalY']:
+            flags |= _lib.FLAG_GEVAL_Y
+        if self.opt['LinSolveCheck']:
+            flags |= _lib.FLAG_XRRS
+        tol, mit = self._cg_options()
+        s = self._sums = self.dev.dstep_iter(
+            self._method, self.rho, self.rlx, self._u_scale, flags, self.cri.dsz[0],
+            self.cri.dsz[1], self.opt['ZeroMean'], tol, mit)
+        self._u_scale = 1.0
+        self._cache.clear()
+        if self.opt['LinSolveCheck']:
+            nrm = max(np.sqrt(s[_lib.OUT_XRRS_AX2]), np.sqrt(s[_lib.OUT_XRRS_B2]))
+            self.xrrs = np.sqrt(s[_lib.OUT_XRRS_D2]) / nrm if nrm > 0.0 else 0.0
+        if self._method == _lib.DSTEP_CG:
+            self.cgit = int(s[_lib.OUT_CGIT])
+            self.cg_iterations = int(s[_lib.OUT_CGN])
+        if not self._needs_residuals():
+            return None
+        self.timer.stop('solve_wo_rsdl')
+        res = self.compute_residuals()
+        self.timer.start('solve_wo_rsdl')
+        return res
+
+    def residual_norms(self):
+        """ADMMEqual residuals and normalisations (admm.py:959-983)."""
+        s = self._sums
+        rho = float(self.rho)
+        return (np.sqrt(s[_lib.OUT_R2]), rho * np.sqrt(s[_lib.OUT_S2]),
+                max(np.sqrt(s[_lib.OUT_AX2]), np.sqrt(s[_lib.OUT_Y2])),
+                rho * np.sqrt(s[_lib.OUT_U2]))
+
+    def reconstruct(self, D=None):
+        """irfftn(sum_m Zf * Xf) (ccmod.py:418-427); host arithmetic, off the iteration path."""
+        Df = self.Xf if D is None else np.fft.rfftn(np.asarray(D), axes=(0, 1))
+        Zf = self.dev.download(_lib.VAR_ZF)
+        return np.fft.irfftn(np.sum(Zf * Df, axis=self.cri.axisM), self.cri.Nv,
+                             axes=(0, 1)).astype(self.dtype)
+
+
+class ConvCnstrMOD_IterSM(ConvCnstrMODBase):
+    r"""ADMM dictionary update with the X-step solved by iterated Sherman-Morrison over the
+    images (sporco/admm/ccmod.py:433-505; linalg.solvemdbi_ism).  On the device the rank-one
+    terms of one frequency live in registers, which bounds the training set at 8 images
+    (times channels); the reference recommends this method for small training sets only.
+
+    IterationStats fields: ``Iter, DFid, Cnstr, PrimalRsdl, DualRsdl, EpsPrimal, EpsDual,
+    Rho, XSlvRelRes, Time``.
+    """
+
+    class Options(ConvCnstrMODBase.Options):
+        defaults = copy.deepcopy(ConvCnstrMODBase.Options.defaults)
+
+    _method = _lib.DSTEP_ISM
+
+
+class ConvCnstrMOD_CG(ConvCnstrMODBase):
+    r"""ADMM dictionary update with the X-step solved by conjugate gradients, warm-started from
+    the previous solution (sporco/admm/ccmod.py:511-601; linalg.solvemdbi_cg with scipy's cg
+    stopping rule).  ``XSlvCGIt`` carries scipy's status flag as in the reference (0 when the
+    tolerance was met, ``MaxIter`` otherwise); the attribute ``cg_iterations`` has the count.
+
+    IterationStats fields: ``Iter, DFid, Cnstr, PrimalRsdl, DualRsdl, EpsPrimal, EpsDual,
+    Rho, XSlvRelRes, XSlvCGIt, Time``.
+    """
+
+    class Options(ConvCnstrMODBase.Options):
+        """Adds ``CG``: ``MaxIter`` (1000), ``StopTol`` (1e-3) (ccmod.py:530-545)."""
+        defaults = copy.deepcopy(ConvCnstrMODBase.Options.defaults)
+        defaults.update({'CG': {'MaxIter': 1000, 'StopTol': 1e-3}})
+
+    itstat_fields_extra = ('XSlvRelRes', 'XSlvCGIt')
+    _method = _lib.DSTEP_CG
+
+    def _cg_options(self):
+        return self.opt['CG', 'StopTol'], self.opt['CG', 'MaxIter']
+
+    def itstat_extra(self):
+        return (self.xrrs, self.cgit)
+
+
+_METHODS = {'cns': ConvCnstrMOD_Consensus, 'ism': ConvCnstrMOD_IterSM, 'cg': ConvCnstrMOD_CG}
 
 
 def _lookup(method):
     if method in _METHODS:
         return _METHODS[method]
-    if method in ('ism', 'cg'):
-        raise NotImplementedError("ADMM dictionary update %r is not part of the sporco_amd hot "
-                                  "path; 'cns' (consensus) is" % method)
     raise ValueError('Unknown ConvCnstrMOD solver method %s' % method)
 
 

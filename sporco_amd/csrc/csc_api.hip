@@ -151,6 +151,8 @@ struct CscBase {
     virtual void masked_grad(int var, bool dstep, bool write_grad, double *out_dev) = 0;
     virtual void cns_init(const void *Y0, double rho) = 0;
     virtual void cns_iter(const sporco_amd_cns_params &p, double *out_dev) = 0;
+    virtual void dstep_init(const void *Y0) = 0;
+    virtual void dstep_iter(const sporco_amd_dstep_params &p, double *out_dev) = 0;
     virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
     virtual void read_out(const double *out_dev, double *out_host) = 0;
     double *out_dev_default = nullptr;
@@ -187,12 +189,12 @@ static bool var_is_complex(int var) {
 }
 
 static bool var_is_dict_sized(int var) {
-    return var == SPORCO_AMD_VAR_DF || (var >= SPORCO_AMD_VAR_DX && var <= SPORCO_AMD_VAR_DT2);
+    return var == SPORCO_AMD_VAR_DF || (var >= SPORCO_AMD_VAR_DX && var < SPORCO_AMD_VAR_COUNT);
 }
 
 static bool var_is_valid(int var) {
     return (var >= 0 && var <= SPORCO_AMD_VAR_CU) ||
-           (var >= SPORCO_AMD_VAR_DX && var <= SPORCO_AMD_VAR_DT2);
+           (var >= SPORCO_AMD_VAR_DX && var < SPORCO_AMD_VAR_COUNT);
 }
 
 template <typename T> struct Csc : CscBase {
@@ -238,6 +240,12 @@ template <typename T> struct Csc : CscBase {
     bool ams_bits_valid = false;
     T *cns_m = nullptr, *cns_yold = nullptr;
     bool cns_active = false;   // a consensus D-step lives on this handle
+    // single-copy ADMM D-step (dstep_iter): Zf stays in the natural layout; ZSf cache and the
+    // iterated Sherman-Morrison tables over the images
+    bool eq_active = false;
+    bool zsf_valid = false, dism_valid = false;
+    double dism_rho = 0.0;
+    cx<T> *dism_gam = nullptr, *dism_del = nullptr, *dism_mm = nullptr;
     T *gramz_t = nullptr;      // its fused path: sum_k |Zf|^2 per row of the tile-major Zf
     bool gramz_valid = false;
     bool cns_fused() const {
@@ -410,7 +418,7 @@ template <typename T> struct Csc : CscBase {
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
                         (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
-                        (void *)cns_yold,
+                        (void *)cns_yold, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)wdat_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -745,6 +753,7 @@ template <typename T> struct Csc : CscBase {
         if (var == SPORCO_AMD_VAR_ZF) {
             zf_tiled = false;
             gramz_valid = false;
+            zsf_valid = dism_valid = false;
         }
         if (var == SPORCO_AMD_VAR_X) {
             x_written();
@@ -1553,8 +1562,10 @@ template <typename T> struct Csc : CscBase {
                    "ccmod_setcoef needs an X-sized real variable");
         before_read(var);
         gramz_valid = false;
-        // (the generic consensus D-step reads Zf in the natural layout)
-        if (rows_ok && fused && !(cns_active && !cns_fused())) {
+        zsf_valid = dism_valid = false;
+        // (the generic consensus D-step and the single-copy ADMM D-step read Zf in the natural
+        // layout)
+        if (rows_ok && fused && !(cns_active && !cns_fused()) && !eq_active) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;
             ra.y = rv(var);
@@ -1945,6 +1956,223 @@ template <typename T> struct Csc : CscBase {
                 launch_pcn_stats<T>(st, Y, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
                 nbc = launch_pcn_apply<T>(st, Y, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
                                           Ku);
+            }
+            const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
+            const double cscales[1] = {1.0};
+            finalize(part_b, nbc, 1, 1, cslots, cscales, out_dev);
+        }
+    }
+
+    // ---- ADMM dictionary update with one dictionary copy (IterSM / CG) ----------------------
+    void dstep_init(const void *Y0) override {
+        require_single_channel_dict();
+        eq_active = true;
+        T *Y = rv(SPORCO_AMD_VAR_DX), *U = rv(SPORCO_AMD_VAR_DSU);
+        const size_t nbytes = var_bytes(SPORCO_AMD_VAR_DX);
+        if (Y0) {
+            host_copy(SPORCO_AMD_VAR_DX, const_cast<void *>(Y0), true);
+            SA_HIP(hipMemcpyAsync(U, Y, nbytes, hipMemcpyDeviceToDevice, st));
+        } else {
+            SA_HIP(hipMemsetAsync(Y, 0, nbytes, st));
+            SA_HIP(hipMemsetAsync(U, 0, nbytes, st));
+        }
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_DSX), 0, nbytes, st));
+        SA_HIP(hipMemsetAsync(cv(SPORCO_AMD_VAR_DYF), 0, var_bytes(SPORCO_AMD_VAR_DYF), st));
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        sync();
+    }
+
+    // two of the sums of launch_pair_stats over dictionary-sized spectra, read back:
+    // sum |a|^2 and sum Re(conj(a) g)   (the vdot's of scipy's cg on the half spectrum)
+    void cdots(const cx<T> *a, const cx<T> *g, double &a2, double &ag) {
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_pair_stats<T>(st, a, nullptr, g, npix, K, W, part_a);
+        }
+        SA_HIP(hipMemsetAsync(out_dev_own, 0, sizeof(double) * kOutSlots, st));
+        const int slots[2] = {0, 1};
+        const double scales[2] = {1.0, 1.0};
+        finalize(part_a + 1, nb, 4, 2, slots, scales, out_dev_own);
+        double tmp[kOutSlots];
+        read_out(out_dev_own, tmp);
+        ag = tmp[0];
+        a2 = tmp[1];
+    }
+
+    // q = (Z^H Z + rho I) v on dictionary-sized spectra
+    void dstep_op(const cx<T> *v, cx<T> *q, T rho) {
+        ProfScope ps(prof, PS_SM_SOLVE);
+        launch_inner<T>(st, v, cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
+        launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, q, npix, CN, K);
+        launch_lincomb<T>(st, q, T(1), q, rho, v, T(0), nullptr, npix * K);
+    }
+
+    void dstep_iter(const sporco_amd_dstep_params &p, double *out_dev) override {
+        require_single_channel_dict();
+        if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
+        SA_REQUIRE(eq_active, "dstep_init must be called first");
+        SA_REQUIRE(p.rho > 0.0, "rho must be positive");
+        SA_REQUIRE(p.method == SPORCO_AMD_DSTEP_ISM || p.method == SPORCO_AMD_DSTEP_CG,
+                   "unknown D-step method");
+        if (p.method == SPORCO_AMD_DSTEP_ISM && CN > 8)
+            throw Error(SPORCO_AMD_EINVAL,
+                        "the iterated Sherman-Morrison D-step handles up to 8 images (times "
+                        "channels); use the consensus or conjugate gradient update");
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        need_natural(SPORCO_AMD_VAR_ZF);
+        const int64_t npixr = (int64_t)H * W, nd = npix * K;
+        const T rho = (T)p.rho;
+        T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_DSX), *U = rv(SPORCO_AMD_VAR_DSU);
+        cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF), *Sf = cv(SPORCO_AMD_VAR_SF);
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_DYF), *bf = cv(SPORCO_AMD_VAR_DVF);
+        cx<T> *yuf = cv(SPORCO_AMD_VAR_DT2), *zsf = cv(SPORCO_AMD_VAR_DXFPRV);
+        if (!cns_m) {
+            SA_HIP(hipMalloc((void **)&cns_m, sizeof(T) * npixr * K));
+            SA_HIP(hipMalloc((void **)&cns_yold, sizeof(T) * npixr * K));
+        }
+        if (!zsf_valid) {   // ZSf = sum_n conj(Zf_n) Sf_n  (setcoef, ccmod.py:327)
+            ProfScope ps(prof, PS_OTHER);
+            launch_zf_adjoint<T>(st, Zf, Sf, zsf, npix, CN, K);
+            zsf_valid = true;
+        }
+        // xstep: b = ZSf + rho rfftn(Y - U)
+        fwd2(Y, U, (T)p.u_scale, yuf, K);
+        const bool need_b = p.method == SPORCO_AMD_DSTEP_CG || (p.flags & F_XRRS);
+        if (need_b) {
+            ProfScope ps(prof, PS_OTHER);
+            launch_lincomb<T>(st, bf, T(1), zsf, rho, yuf, T(0), nullptr, nd);
+        }
+        if (p.method == SPORCO_AMD_DSTEP_ISM) {
+            if (!dism_gam) {
+                SA_HIP(hipMalloc((void **)&dism_gam, sizeof(cx<T>) * npix * CN * K));
+                SA_HIP(hipMalloc((void **)&dism_del, sizeof(cx<T>) * npix * CN));
+                SA_HIP(hipMalloc((void **)&dism_mm, sizeof(cx<T>) * npix * CN * CN));
+            }
+            ProfScope ps(prof, PS_SM_SOLVE);
+            if (!dism_valid || dism_rho != p.rho) {
+                launch_ism_setup<T>(st, Zf, dism_gam, dism_del, dism_mm, npix, CN, K, rho);
+                dism_valid = true;
+                dism_rho = p.rho;
+            }
+            // the images are the rank-one terms, the dictionary the one right-hand side
+            launch_ism_solve<T>(st, yuf, Xf, Zf, Sf, dism_gam, dism_del, dism_mm, rho, npix, CN, 1,
+                                K, W, false, false, part_a);
+        } else {
+            // scipy.sparse.linalg.cg as linalg.solvemdbi_cg calls it (linalg.py:570-579), warm
+            // started from the previous Xf
+            cx<T> *r = cv(SPORCO_AMD_VAR_DT0), *pv = cv(SPORCO_AMD_VAR_DT1), *q = cv(SPORCO_AMD_VAR_DGF);
+            double b2, x2, dummy, rr, rr_prev = 0.0, pq;
+            cdots(bf, nullptr, b2, dummy);
+            cdots(Xf, nullptr, x2, dummy);
+            int info = 0, it = 0;
+            if (b2 == 0.0) {
+                SA_HIP(hipMemsetAsync(Xf, 0, sizeof(cx<T>) * nd, st));
+            } else {
+                const double atol = p.cg_tol * std::sqrt(b2);
+                if (x2 != 0.0) {
+                    dstep_op(Xf, q, rho);
+                    ProfScope ps(prof, PS_OTHER);
+                    launch_lincomb<T>(st, r, T(1), bf, T(-1), q, T(0), nullptr, nd);
+                } else {
+                    SA_HIP(hipMemcpyAsync(r, bf, sizeof(cx<T>) * nd, hipMemcpyDeviceToDevice, st));
+                }
+                info = p.cg_maxiter;
+                for (it = 0; it < p.cg_maxiter; ++it) {
+                    cdots(r, nullptr, rr, dummy);
+                    if (std::sqrt(rr) < atol) {
+                        info = 0;
+                        break;
+                    }
+                    {
+                        ProfScope ps(prof, PS_OTHER);
+                        if (it == 0)
+                            SA_HIP(hipMemcpyAsync(pv, r, sizeof(cx<T>) * nd, hipMemcpyDeviceToDevice,
+                                                  st));
+                        else
+                            launch_lincomb<T>(st, pv, T(1), r, (T)(rr / rr_prev), pv, T(0), nullptr,
+                                              nd);
+                    }
+                    dstep_op(pv, q, rho);
+                    cdots(pv, q, dummy, pq);
+                    const T alpha = (T)(rr / pq);
+                    {
+                        ProfScope ps(prof, PS_OTHER);
+                        launch_lincomb<T>(st, Xf, T(1), Xf, alpha, pv, T(0), nullptr, nd);
+                        launch_lincomb<T>(st, r, T(1), r, -alpha, q, T(0), nullptr, nd);
+                    }
+                    rr_prev = rr;
+                }
+            }
+            const double cgv[2] = {(double)info, (double)it};
+            SA_HIP(hipMemcpyAsync(out_dev + SPORCO_AMD_OUT_CGIT, cgv, sizeof(cgv),
+                                  hipMemcpyHostToDevice, st));
+            sync();   // cgv is a stack array
+        }
+        inv2(Xf, dwork_buf(), X, K);
+        if (p.flags & F_XRRS) {   // xstep_check (ccmod.py:343-357): rrs(Z^H Z Xf + rho Xf, b)
+            cx<T> *q = cv(SPORCO_AMD_VAR_DGF);
+            dstep_op(Xf, q, rho);
+            int nb;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nb = launch_pair_stats<T>(st, q, bf, bf, npix, K, W, part_a);
+            }
+            const int sl1[2] = {SPORCO_AMD_OUT_XRRS_D2, SPORCO_AMD_OUT_XRRS_B2};
+            const double sc1[2] = {1.0, 1.0};
+            finalize(part_a + 2, nb, 4, 2, sl1, sc1, out_dev);
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nb = launch_pair_stats<T>(st, q, nullptr, nullptr, npix, K, W, part_b);
+            }
+            const int sl2[1] = {SPORCO_AMD_OUT_XRRS_AX2};
+            finalize(part_b + 2, nb, 4, 1, sl2, sc1, out_dev);
+        }
+        // relax + ystep: Y = Pcn(alpha X + (1 - alpha) Y + U); ustep and the sums
+        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * K, hipMemcpyDeviceToDevice, st));
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, (T)p.u_scale, npixr, 1, K);
+        }
+        pcn_project(cns_m, Y, p.dH, p.dW, p.zero_mean != 0, nullptr);
+        int nb;
+        {
+            ProfScope ps(prof, PS_ADMM_POST);
+            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, (T)p.u_scale, npixr, 1, K,
+                                     part_b);
+        }
+        {
+            const int slots[3] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_AX2, SPORCO_AMD_OUT_U2};
+            const double scales[3] = {1, 1, 1};
+            finalize(part_b, nb, 4, 3, slots, scales, out_dev);
+        }
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * K, part_a);
+        }
+        {
+            const int slots[2] = {SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_Y2};
+            const double scales[2] = {1, 1};
+            finalize(part_a, nb, 2, 2, slots, scales, out_dev);
+        }
+        // the dictionary's spectrum (getdict / setdict_from_dstep / objective at Y)
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        if (p.flags & F_OBJ) {
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nb = launch_ccmod_grad<T>(st, Zf, (p.flags & F_FEVAL_Y) ? cv(SPORCO_AMD_VAR_DXF) : Xf,
+                                          Sf, nullptr, npix, CN, K, W, part_a);
+            }
+            const int slots[1] = {SPORCO_AMD_OUT_DFID};
+            const double scales[1] = {1.0 / ((double)H * W)};
+            finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
+            const T *gv = (p.flags & F_GEVAL_Y) ? Y : X;
+            int nbc;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                nbc = launch_pcn_apply<T>(st, gv, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW,
+                                          part_b, Ku);
             }
             const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
             const double cscales[1] = {1.0};
@@ -2434,6 +2662,24 @@ int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
     SA_REQUIRE(p && out, "null argument");
     double *dev = stats_buf(h);
     h->impl->cns_iter(*p, dev);
+    h->impl->read_out(dev, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_dstep_init(sporco_amd_csc_t h, const void *Y0) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->dstep_init(Y0);
+    SA_API_END
+}
+
+int sporco_amd_csc_dstep_iter(sporco_amd_csc_t h, const sporco_amd_dstep_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out, "null argument");
+    double *dev = stats_buf(h);
+    h->impl->dstep_iter(*p, dev);
     h->impl->read_out(dev, out);
     SA_API_END
 }

@@ -4,9 +4,9 @@ Drop-in for ``sporco.dictlrn.cbpdndl`` (sporco/dictlrn/cbpdndl.py:31-524):
 ``ConvBPDNDictLearn(D0, S, lmbda, opt, xmethod, dmethod, dimK, dimN)`` with the
 same Options tree (``CBPDN`` / ``CCMOD`` sub-options built from the selected
 inner solver classes) and IterationStats.  ``xmethod`` is ``'admm'`` or
-``'pgm'``; ``dmethod`` is ``'pgm'`` (the reference default) or ``'cns'`` (the ADMM
-consensus update, sporco_amd.admm.ccmod).  The other two ADMM D-steps (``'ism'``,
-``'cg'``) are outside this backend's hot path.
+``'pgm'``; ``dmethod`` is ``'pgm'`` (the reference default) or one of the ADMM updates of
+sporco_amd.admm.ccmod: ``'cns'`` (consensus), ``'ism'`` (iterated Sherman-Morrison, up to 8
+training images) or ``'cg'`` (conjugate gradients).
 
 Both inner solvers share ONE device handle: after the X-step the coefficient
 maps are transformed in place on the GPU for the D-step (``setcoef``), and after
@@ -32,8 +32,8 @@ __all__ = ['cbpdn_class_label_lookup', 'ConvBPDNOptionsDefaults', 'ConvBPDNOptio
            'ConvCnstrMODOptions', 'ConvCnstrMOD', 'ConvBPDNDictLearn']
 
 _XCLS = {'admm': admm_cbpdn.ConvBPDN, 'pgm': pgm_cbpdn.ConvBPDN}
-_DCLS = {'pgm': pgm_ccmod.ConvCnstrMOD, 'cns': admm_ccmod.ConvCnstrMOD_Consensus}
-_D_UNPORTED = ('ism', 'cg')
+_DCLS = {'pgm': pgm_ccmod.ConvCnstrMOD, 'cns': admm_ccmod.ConvCnstrMOD_Consensus,
+         'ism': admm_ccmod.ConvCnstrMOD_IterSM, 'cg': admm_ccmod.ConvCnstrMOD_CG}
 _dyn = {}
 
 
@@ -46,9 +46,6 @@ def cbpdn_class_label_lookup(label):
 def ccmod_class_label_lookup(label):
     if label in _DCLS:
         return _DCLS[label]
-    if label in _D_UNPORTED:
-        raise NotImplementedError("dictionary update method '%s' (sporco.admm.ccmod) is "
-                                  "not part of the sporco_amd hot path; use 'pgm' or 'cns'" % label)
     raise ValueError('Unknown ConvCnstrMOD solver method %s' % label)
 
 

@@ -32,6 +32,7 @@ _D = {
                 txt=(['r_D', 's_D', u'ρ_D'],) * 2,
                 hdr=({'r_D': 'DPrRsdl', 's_D': 'DDlRsdl', u'ρ_D': 'DRho'},) * 2),
 }
+_D['ism'] = _D['cg'] = _D['cns']      # the ADMM D-steps report the same fields
 
 
 def _bt(opt, node, method):

@@ -49,7 +49,7 @@ def test_consensus_surface(backend):
     from sporco_amd.admm import ccmod
     g = load_golden('ccmod_cns_f64')
     dsz = tuple(int(v) for v in g['dsz'])
-    # factory functions of the reference module; the other two ADMM D-steps are not offered
+    # factory functions of the reference module
     c = ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz,
                            ccmod.ConvCnstrMODOptions({'MaxMainIter': 3}, method='cns'),
                            method='cns')
@@ -61,9 +61,8 @@ def test_consensus_surface(backend):
     c2.solve()
     assert rel_l2(c.Y, c2.Y) < 1e-12
     assert c.reconstruct().shape[:2] == g['S'].shape[:2]
-    for m in ('ism', 'cg'):
-        with pytest.raises(NotImplementedError):
-            ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz, method=m)
+    with pytest.raises(ValueError):
+        ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz, method='nosuch')
     with pytest.raises(NotImplementedError):
         ccmod.ConvCnstrMOD_Consensus(
             g['Z'], g['S'], dsz, ccmod.ConvCnstrMOD_Consensus.Options({'AuxVarObj': False}))

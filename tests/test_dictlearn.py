@@ -96,8 +96,10 @@ def test_dictlearn_variants_run(backend):
         cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='pgm')
     with pytest.raises(ValueError):
         cbpdndl.ConvBPDN(D0, S, 0.1, method='nonsense')
-    with pytest.raises(NotImplementedError):
-        cbpdndl.ConvBPDNDictLearn.Options(dmethod='ism')
+    with pytest.raises(ValueError):
+        cbpdndl.ConvBPDNDictLearn.Options(dmethod='nonsense')
+    for m in ('ism', 'cg', 'cns'):                # all three ADMM D-steps are offered
+        assert cbpdndl.ConvBPDNDictLearn.Options(dmethod=m)['CCMOD', 'AutoRho', 'Period'] == 10
 
 
 # ---------------------------------------------------------------------------

@@ -264,6 +264,50 @@ def test_ccmod_consensus_traces(name):
     assert np.max(np.abs(r['Cnstr'] - g['it_Cnstr'])) < 1e-6
 
 
+EQ_CASES = {
+    'f64': dict(maxiter=20),
+    'f32': dict(maxiter=20, dtype=np.float32),
+    'fixedrho_zm_chk_f64': dict(maxiter=20, rho=5.0, auto_rho=False, zero_mean=True,
+                                lin_solve_check=True, rlx=1.5),
+    'auxobj_y0_f64': dict(maxiter=12, aux_var_obj=True, _y0=True, rho_period=3, rho_tau=2.0,
+                          auto_scaling=False, rho_mu=1.5),
+}
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+@pytest.mark.parametrize('case', sorted(EQ_CASES))
+def test_ccmod_ism_cg_traces(method, case):
+    """ConvCnstrMOD_IterSM / ConvCnstrMOD_CG restatement (one dictionary copy, X-step by
+    iterated Sherman-Morrison over the images or warm-started conjugate gradients)."""
+    g = load_golden('ccmod_%s_%s' % (method, case))
+    kw = dict(EQ_CASES[case])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-8 if dtype == np.float64 else 5e-4
+    if kw.pop('_y0', False):
+        kw['Y0'] = g['Y0']
+    if method == 'cg' and 'fixedrho' in case:
+        kw.update(cg_tol=1e-9, cg_maxiter=500)
+        tol = 1e-7
+    elif method == 'cg':
+        # CG run to the default 1e-3 stopping tolerance amplifies the rounding of the operator
+        # (einsum against broadcast-multiply-sum) to ~1e-5 in the iterate: same stopping rule
+        # and iteration flags, looser comparison of the values
+        tol = 1e-4 if dtype == np.float64 else 2e-3
+    S = g['S']
+    r = orc.admm_ccmod_eq(g['Z'], S.reshape(S.shape[0], S.shape[1], 1, S.shape[2], 1),
+                          tuple(int(v) for v in g['dsz']), method=method, dtype=dtype, **kw)
+    assert r['iters'] == int(g['k_final'])
+    for key in ('Y', 'U', 'X', 'D'):
+        assert rel_l2(r[key], g[key]) < tol, key
+    for key in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    assert np.max(np.abs(r['Cnstr'] - g['it_Cnstr'])) < max(10 * tol, 1e-6)
+    if 'chk' in case:
+        assert np.max(np.abs(r['XSlvRelRes'] - g['it_XSlvRelRes'])) < 1e-6
+    if method == 'cg':
+        assert np.array_equal(r['XSlvCGIt'], g['it_XSlvCGIt'])
+
+
 def test_pgm_mcdict_traces():
     """FISTA with a multi-channel dictionary: gradient summed over the channels
     (pgm/cbpdn.py:263-279)."""
