@@ -378,6 +378,15 @@ typedef struct {
 int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]);
 
+/* ---- online dictionary learning (sporco.dictlrn.onlinecdl.OnlineConvBPDNDictLearn.dstep,
+ * onlinecdl.py:310-333) -------------------------------------------------------------------
+ * After sporco_amd_csc_ccmod_setcoef and sporco_amd_csc_ccmod_grad(h, SPORCO_AMD_VAR_DF) (the
+ * gradient at the current dictionary, left in VAR_DGF): G = irfftn(Df - eta * gradient),
+ * D = Pcn(G) -> VAR_DX (and its spectrum VAR_DXF; read with sporco_amd_csc_ccmod_getdict).
+ * out[SPORCO_AMD_OUT_CNSTR] = sum (Pcn(G) - G)^2, the square of the reference's Cnstr (:398). */
+int sporco_amd_csc_ccmod_sgd_step(sporco_amd_csc_t h, double eta, int32_t dH, int32_t dW,
+                                  int32_t zero_mean, double out[SPORCO_AMD_OUT_COUNT]);
+
 /* ---- ADMM dictionary update with one dictionary copy ---------------------------------------
  * sporco.admm.ccmod.ConvCnstrMOD_IterSM / ConvCnstrMOD_CG (ccmod.py:433-601) on ConvCnstrMODBase
  * (:103-429) and ADMMEqual (admm.py:808-983).  X = VAR_DSX, Y = VAR_DX (spectrum VAR_DXF kept

@@ -742,3 +742,51 @@ def admm_ccmod_eq(Z, S, dsz, method='ism', dtype=np.float64, maxiter=20, rho=Non
     out = {key: np.array(val) for key, val in tr.items()}
     out.update(X=X, Y=Y, U=U, rho=rho, iters=k + 1, D=bcrop(Y, dsz))
     return out
+
+
+# ---------------------------------------------------------------------------
+# online dictionary learning (sporco/dictlrn/onlinecdl.py:33-460)
+# ---------------------------------------------------------------------------
+
+def online_cdl(D0, batches, lmbda, dtype=np.float64, eta_a=10.0, eta_b=5.0,
+               zero_mean=False, xstep_iter=100):
+    """OnlineConvBPDNDictLearn: for training batch j (5-D ``(H, W, 1, N, 1)``):
+      xstep  ADMM ConvBPDN with the current dictionary, cold start, ``xstep_iter``
+             iterations at the class's X-step defaults (AutoRho period 10, fixed
+             scaling 2, ratio 10; onlinecdl.py:89-101, :267-287)
+      dstep  gradf = sum_n conj(Zf_n) (sum_m Zf_nm Df_m - Sf_n); eta = a / (j + b);
+             G = irfftn(Df - eta gradf); D = Pcn(G) cropped (:310-333)
+      stats  Cnstr = ||zpad(D) - G||, DeltaD = ||D - Dprv|| (:398-399).
+    ``D0``: (dH, dW, M)."""
+    dtype = np.dtype(dtype)
+    dsz = D0.shape
+    M = dsz[-1]
+    D = pcn(np.asarray(D0, dtype=dtype).reshape(dsz[0], dsz[1], 1, 1, M), dsz, (), 2, 1,
+            crp=True, zm=zero_mean)
+    tr = {k: [] for k in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho', 'Cnstr',
+                          'DeltaD', 'Eta')}
+    Ds = []
+    for j, S in enumerate(batches):
+        S = np.asarray(S, dtype=dtype)
+        H, W = S.shape[:2]
+        r = admm_cbpdn(D, S, lmbda, dtype=dtype, maxiter=xstep_iter, rho_period=10,
+                       rho_tau=2.0, rho_mu=10.0, rho_xi=1.0, auto_scaling=False)
+        Zf = rfftn2(r['Y'])
+        Sf = rfftn2(S)
+        Df = rfftn2(D, (H, W))
+        Ryf = inner(Zf, Df, axis=AX_K) - Sf
+        gradf = inner(np.conj(Zf), Ryf, axis=AX_N)
+        eta = eta_a / (j + eta_b)
+        G = irfftn2(Df - eta * gradf, (H, W))
+        Dprv = D
+        D = pcn(G, dsz, (H, W), 2, 1, crp=True, zm=zero_mean).astype(dtype)
+        vals = dict(ObjFun=r['ObjFun'][-1], DFid=r['DFid'][-1], RegL1=r['RegL1'][-1],
+                    PrimalRsdl=r['PrimalRsdl'][-1], DualRsdl=r['DualRsdl'][-1],
+                    Rho=r['Rho'][-1], Cnstr=np.linalg.norm(zpad(D, (H, W)) - G),
+                    DeltaD=np.linalg.norm(D - Dprv), Eta=eta)
+        for k, v in vals.items():
+            tr[k].append(float(v))
+        Ds.append(D)
+    out = {k: np.array(v) for k, v in tr.items()}
+    out['Ds'] = np.stack(Ds)
+    return out

@@ -499,6 +499,35 @@ def gen_ccmod_eq():
                  X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_online():
+    """Online dictionary learning dictlrn.onlinecdl.OnlineConvBPDNDictLearn
+    (sporco/dictlrn/onlinecdl.py:33-460): one solve() per training image.  SURVEY.md 8(f)
+    rank 4."""
+    from sporco.dictlrn import onlinecdl as ref_online
+    np.random.seed(75319)
+    N, M, Nd = 16, 4, 5
+    D0 = np.random.randn(Nd, Nd, M)
+    imgs = np.random.randn(N, N, 5)
+    for tag, dt in (('f64', np.float64), ('f32', np.float32)):
+        opt = ref_online.OnlineConvBPDNDictLearn.Options(
+            {'eta_a': 8.0, 'eta_b': 4.0, 'ZeroMean': tag == 'f64', 'DataType': dt,
+             'CBPDN': {'MaxMainIter': 30}})
+        b = ref_online.OnlineConvBPDNDictLearn(D0, 0.1, opt, dimK=0)
+        Ds = []
+        for i in range(imgs.shape[-1]):
+            Ds.append(b.solve(imgs[..., i].astype(dt)).copy())
+        save('onlinecdl_' + tag, D0=D0, S=imgs, lmbda=np.float64(0.1), Ds=np.stack(Ds),
+             **itstat_dict(b))
+    # mini-batches of two images (a multi-channel signal with a single-channel dictionary
+    # fails inside the reference's own dstep: Sf keeps its channel axis, onlinecdl.py:316)
+    Sc = np.random.randn(N, N, 2, 3)
+    opt = ref_online.OnlineConvBPDNDictLearn.Options({'CBPDN': {'MaxMainIter': 20}})
+    b = ref_online.OnlineConvBPDNDictLearn(D0, 0.1, opt, dimK=1)
+    Ds = [b.solve(Sc[..., i]).copy() for i in range(Sc.shape[-1])]
+    save('onlinecdl_batch_f64', D0=D0, S=Sc, lmbda=np.float64(0.1), Ds=np.stack(Ds),
+         **itstat_dict(b))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -580,8 +609,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -66,7 +66,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
     'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
-    'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter',
+    'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter', 'sporco_amd_csc_ccmod_sgd_step',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
@@ -225,6 +225,7 @@ def load(path=None):
         'sporco_amd_csc_set_data_mask': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_masked_grad': [vp, ctypes.c_int, i32, i32, dptr],
         'sporco_amd_csc_cns_iter': [vp, ctypes.POINTER(CnsParams), dptr],
+        'sporco_amd_csc_ccmod_sgd_step': [vp, dbl, i32, i32, i32, dptr],
         'sporco_amd_csc_dstep_init': [vp, vp],
         'sporco_amd_csc_dstep_iter': [vp, ctypes.POINTER(DstepParams), dptr],
         'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
@@ -526,6 +527,13 @@ class Solver(object):
                       1 if zero_mean else 0)
         out = self._out()
         check(self._lib.sporco_amd_csc_cns_iter(self._h, ctypes.byref(p), out))
+        return list(out)
+
+    def ccmod_sgd_step(self, eta, dH, dW, zero_mean):
+        """Projected SGD step on the X-step dictionary (sporco_amd_csc_ccmod_sgd_step)."""
+        out = self._out()
+        check(self._lib.sporco_amd_csc_ccmod_sgd_step(self._h, float(eta), int(dH), int(dW),
+                                                      1 if zero_mean else 0, out))
         return list(out)
 
     def dstep_init(self, Y0):

@@ -144,6 +144,7 @@ struct CscBase {
     virtual void ccmod_setcoef(int var) = 0;
     virtual void ccmod_grad(int var, bool write_grad, double *out_dev) = 0;
     virtual void ccmod_prox_step(double L, int dH, int dW, bool zm) = 0;
+    virtual void ccmod_sgd_step(double eta, int dH, int dW, bool zm, double *out_dev) = 0;
     virtual void ccmod_cnstr(int dH, int dW, bool zm, double *out_dev) = 0;
     virtual void ccmod_getdict(int dH, int dW, void *dst) = 0;
     virtual void setdict_from_dstep(int dH, int dW) = 0;
@@ -1685,6 +1686,32 @@ template <typename T> struct Csc : CscBase {
         fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), KD());
     }
 
+    // One projected stochastic gradient step on the X-step's dictionary (onlinecdl.py:310-333):
+    // G = irfftn(Df - eta * gradient), D = Pcn(G); out[CNSTR] = sum (Pcn(G) - G)^2 (:398).
+    void ccmod_sgd_step(double eta, int dH, int dW, bool zm, double *out_dev) override {
+        if (!have_dict) throw Error(SPORCO_AMD_ESTATE, "set_dict must be called first");
+        SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W, "filter support out of range");
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        cx<T> *Vf = cv(SPORCO_AMD_VAR_DVF);
+        {
+            ProfScope ps(prof, PS_PGM);
+            launch_axpy_c<T>(st, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_DGF), Vf, (T)(-eta),
+                             npix * KD());
+        }
+        T *X = rv(SPORCO_AMD_VAR_DX);
+        inv2(Vf, dwork_buf(), X, KD());
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_pcn_stats<T>(st, X, pcn_stats_buf(), H, W, K, dH, dW, zm, Cd);
+            nb = launch_pcn_apply<T>(st, X, pcn_stats_buf(), X, H, W, K, dH, dW, part_b, Ku, Cd);
+        }
+        const int slots[1] = {SPORCO_AMD_OUT_CNSTR};
+        const double scales[1] = {1.0};
+        finalize(part_b, nb, 1, 1, slots, scales, out_dev);
+        fwd2(X, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), KD());
+    }
+
     void ccmod_cnstr(int dH, int dW, bool zm, double *out_dev) override {
         pcn_project(rv(SPORCO_AMD_VAR_DX), nullptr, dH, dW, zm, out_dev);
     }
@@ -2663,6 +2690,17 @@ int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
     double *dev = stats_buf(h);
     h->impl->cns_iter(*p, dev);
     h->impl->read_out(dev, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_ccmod_sgd_step(sporco_amd_csc_t h, double eta, int32_t dH, int32_t dW,
+                                  int32_t zero_mean, double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->ccmod_sgd_step(eta, dH, dW, zero_mean != 0, sb);
+    h->impl->read_out(sb, out);
     SA_API_END
 }
 

@@ -1,0 +1,215 @@
+"""Online convolutional dictionary learning by stochastic gradient descent, on the GPU.
+
+Drop-in for ``sporco.dictlrn.onlinecdl.OnlineConvBPDNDictLearn``
+(sporco/dictlrn/onlinecdl.py:33-460): same constructor, Options tree, ``solve(S)`` per
+training image (or mini-batch) and IterationStats fields.  Each ``solve`` call runs the ADMM
+ConvBPDN X-step of this package for the new data with the current dictionary, then takes one
+projected gradient step on the dictionary with step size ``eta_a / (j + eta_b)``.
+
+The two steps share the X-step's device handle: the coefficient maps are transformed in place
+for the gradient (``ccmod_setcoef`` / ``ccmod_grad`` at the current dictionary spectrum), the
+step, inverse transform and constraint projection run on the device
+(``sporco_amd_csc_ccmod_sgd_step``), and only the cropped dictionary (a few KB) returns to the
+host.  The masked variant (``OnlineConvBPDNMaskDictLearn``, onlinecdl.py:464-600) is not part
+of this backend.
+"""
+
+import copy
+
+import numpy as np
+
+from .. import _lib
+from .. import cdict
+from .. import common
+from .. import cnvrep as cr
+from .. import util
+from ..admm import cbpdn
+
+__all__ = ['OnlineConvBPDNDictLearn']
+
+
+class OnlineConvBPDNDictLearn(common.IterativeSolver):
+    r"""Stochastic-gradient online convolutional dictionary learning (onlinecdl.py:33-460).
+
+    IterationStats fields: ``Iter, ObjFun, DFid, RegL1, PrimalRsdl, DualRsdl, Rho, Cnstr,
+    DeltaD, Eta, Time``.
+    """
+
+    class Options(cdict.ConstrainedDict):
+        """``Verbose, StatusHeader, IterTimer, DictSize, DataType, ZeroMean, eta_a, eta_b,
+        CBPDN`` as onlinecdl.py:45-102 (X-step default: 100 iterations, AutoRho period 10).
+        ``CUDA_CBPDN`` is accepted for compatibility and must stay False: the X-step always
+        runs on the GPU here."""
+
+        defaults = {'Verbose': False, 'StatusHeader': True, 'IterTimer': 'solve',
+                    'DictSize': None, 'DataType': None, 'ZeroMean': False, 'eta_a': 10.0,
+                    'eta_b': 5.0, 'CUDA_CBPDN': False,
+                    'CBPDN': copy.deepcopy(cbpdn.ConvBPDN.Options.defaults)}
+
+        def __init__(self, opt=None):
+            cdict.ConstrainedDict.__init__(self, {
+                'CBPDN': cbpdn.ConvBPDN.Options({
+                    'MaxMainIter': 100,
+                    'AutoRho': {'Period': 10, 'AutoScaling': False, 'RsdlRatio': 10.0,
+                                'Scaling': 2.0, 'RsdlTarget': 1.0}})})
+            self.update({} if opt is None else opt)
+
+    fwiter = 4
+    fpothr = 2
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'RegL1')
+    itstat_fields_alg = ('PrimalRsdl', 'DualRsdl', 'Rho', 'Cnstr', 'DeltaD', 'Eta')
+    itstat_fields_extra = ()
+
+    def __new__(cls, *args, **kwargs):
+        obj = super(OnlineConvBPDNDictLearn, cls).__new__(cls)
+        obj.timer = util.Timer(['init', 'solve', 'solve_wo_eval'])
+        obj.timer.start('init')
+        return obj
+
+    def __init__(self, D0, lmbda=None, opt=None, dimK=None, dimN=2, device=0, stream=None):
+        """``D0, lmbda, opt, dimK, dimN`` as in the reference (onlinecdl.py:135-207); ``device``
+        / ``stream`` select the GPU and HIP stream of the X-step handles."""
+        if opt is None:
+            opt = OnlineConvBPDNDictLearn.Options()
+        if not isinstance(opt, OnlineConvBPDNDictLearn.Options):
+            raise TypeError('Parameter opt must be an instance of '
+                            'OnlineConvBPDNDictLearn.Options')
+        if opt['CUDA_CBPDN']:
+            raise ValueError('CUDA_CBPDN selects the sporco_cuda extension; this backend runs '
+                             'the X-step on the AMD GPU already')
+        if dimN != 2:
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        self.opt = opt
+        self.dimK, self.dimN = dimK, dimN
+        self._device, self._stream = device, stream
+        self.set_dtype(opt, D0.dtype)
+        if self.dtype not in (np.float32, np.float64):
+            raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
+        self.lmbda = lmbda
+        self.eta_a, self.eta_b = opt['eta_a'], opt['eta_b']
+        self.set_attr('eta', opt['eta_a'] / opt['eta_b'], dval=2.0, dtype=self.dtype)
+        self.dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
+        self.cri = None
+        ds = cr.DictionarySize(self.dsz, dimN)
+        self._dimCd = ds.ndim - dimN - 1
+        D0 = cr.stdformD(D0, ds.nchn, ds.nflt, dimN).astype(self.dtype)
+        self.D = cr.Pcn(D0, self.dsz, (), dimN, self._dimCd, crp=True, zm=opt['ZeroMean'])
+        self.Dprv = self.D.copy()
+        self.itstat = []
+        self.j = 0
+        self.display_config()
+
+    def solve(self, S, dimK=None):
+        """Sparse coding and dictionary update for training data ``S``
+        (onlinecdl.py:211-240); returns the updated dictionary."""
+        if dimK is None and self.dimK is not None:
+            dimK = self.dimK
+        if self.j == 0:
+            self.display_start()
+        self.timer.start(['solve', 'solve_wo_eval'])
+        self.init_vars(S, dimK)
+        self.xstep(S, self.lmbda, dimK)
+        self.dstep()
+        self.timer.stop('solve_wo_eval')
+        self.manage_itstat()
+        self.j += 1
+        self.timer.stop('solve')
+        return self.getdict()
+
+    def init_vars(self, S, dimK):
+        Nv = S.shape[0:self.dimN]
+        if self.cri is None or Nv != self.cri.Nv:
+            self.cri = cr.CDU_ConvRepIndexing(self.dsz, S, dimK, self.dimN)
+
+    def xstep(self, S, lmbda, dimK):
+        """ConvBPDN for the new data with the current dictionary (onlinecdl.py:267-287); the
+        solver object (and with it the device handle holding the coefficient maps) is kept
+        for the dictionary step."""
+        x = cbpdn.ConvBPDN(self.D.squeeze(), S, lmbda, self.opt['CBPDN'], dimK=dimK,
+                           dimN=self.cri.dimN, device=self._device, stream=self._stream)
+        x._return_min = False          # the coefficient maps stay on the device
+        x.solve()
+        self._xstep = x
+        self.xstep_itstat = x.itstat[-1] if x.itstat else None
+
+    def dstep(self):
+        """One projected SGD step (onlinecdl.py:310-333): gradient of the data fidelity term at
+        the current dictionary, summed over images (and channels for a single-channel
+        dictionary), step ``eta``, ``D = Pcn(G)``."""
+        dev = self._xstep._dev
+        dev.ccmod_setcoef(_lib.VAR_Y)            # Zf = rfftn(getcoef())
+        dev.ccmod_grad(_lib.VAR_DF)
+        self.eta = self.eta_a / (self.j + self.eta_b)
+        sums = dev.ccmod_sgd_step(self.eta, self.dsz[0], self.dsz[1], self.opt['ZeroMean'])
+        self._cnstr = np.sqrt(sums[_lib.OUT_CNSTR])
+        self.Dprv[:] = self.D
+        self.D[:] = dev.ccmod_getdict(self.dsz[0], self.dsz[1]).reshape(self.D.shape)
+
+    @property
+    def G(self):
+        """The unprojected gradient-step result is not kept (its only use, the ``Cnstr``
+        statistic, is computed on the device)."""
+        raise AttributeError("G is not kept by the device D-step")
+
+    def getcoef(self):
+        """Coefficient maps of the last ``solve`` call."""
+        return self._xstep.getcoef()
+
+    def manage_itstat(self):
+        itst = self.iteration_stats()
+        self.itstat.append(itst)
+        self.display_status(self.fmtstr, itst)
+
+    def getdict(self):
+        return self.D
+
+    def itstat_extra(self):
+        return ()
+
+    @classmethod
+    def hdrtxt(cls):
+        return ('Itn', 'X r', 'X s', u'X ρ', 'D cnstr', 'D dlt', u'D η')
+
+    @classmethod
+    def hdrval(cls):
+        return {'Itn': 'Iter', 'X r': 'PrimalRsdl', 'X s': 'DualRsdl', u'X ρ': 'Rho',
+                'D cnstr': 'Cnstr', 'D dlt': 'DeltaD', u'D η': 'Eta'}
+
+    def iteration_stats(self):
+        """onlinecdl.py:382-402."""
+        tk = self.timer.elapsed(self.opt['IterTimer'])
+        xi = self.xstep_itstat
+        if xi is None:
+            objfn, rsdl, rho = (0.0,) * 3, (0.0,) * 2, (0.0,)
+        else:
+            objfn = (xi.ObjFun, xi.DFid, xi.RegL1)
+            rsdl = (xi.PrimalRsdl, xi.DualRsdl)
+            rho = (xi.Rho,)
+        dltd = np.linalg.norm(self.D - self.Dprv)
+        tpl = (self.j,) + objfn + rsdl + rho + (self._cnstr, dltd, self.eta) + \
+            self.itstat_extra() + (tk,)
+        return type(self).IterationStats(*tpl)
+
+    def getitstat(self):
+        return util.transpose_ntpl_list(self.itstat)
+
+    def display_config(self):
+        if self.opt['Verbose']:
+            self.hdrstr, self.fmtstr, self.nsep = common.solve_status_str(
+                type(self).hdrtxt(), fwdth0=type(self).fwiter, fprec=type(self).fpothr)
+        else:
+            self.hdrstr, self.fmtstr, self.nsep = '', '', 0
+
+    def display_start(self):
+        if self.opt['Verbose'] and self.opt['StatusHeader']:
+            print(self.hdrstr)
+            print("-" * self.nsep)
+
+    def display_status(self, fmtstr, itst):
+        if self.opt['Verbose']:
+            hdrval = type(self).hdrval()
+            print(fmtstr % tuple(getattr(itst, hdrval[col]) for col in type(self).hdrtxt()))
+
+    def display_end(self):
+        if self.opt['Verbose'] and self.opt['StatusHeader']:
+            print("-" * self.nsep)

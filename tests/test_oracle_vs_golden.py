@@ -308,6 +308,29 @@ def test_ccmod_ism_cg_traces(method, case):
         assert np.array_equal(r['XSlvCGIt'], g['it_XSlvCGIt'])
 
 
+@pytest.mark.parametrize('name,dtype,tol', [('onlinecdl_f64', np.float64, 1e-9),
+                                            ('onlinecdl_f32', np.float32, 1e-3),
+                                            ('onlinecdl_batch_f64', np.float64, 1e-9)])
+def test_online_cdl_traces(name, dtype, tol):
+    """OnlineConvBPDNDictLearn restatement: cold-started X-step per batch, one projected SGD
+    step on the dictionary."""
+    g = load_golden(name)
+    S = g['S']
+    if 'batch' in name:
+        batches = [S[..., i].reshape(S.shape[0], S.shape[1], 1, S.shape[2], 1)
+                   for i in range(S.shape[-1])]
+        kw = dict(xstep_iter=20)
+    else:
+        batches = [S[..., i].reshape(S.shape[0], S.shape[1], 1, 1, 1)
+                   for i in range(S.shape[-1])]
+        kw = dict(xstep_iter=30, eta_a=8.0, eta_b=4.0, zero_mean=dtype == np.float64)
+    r = orc.online_cdl(g['D0'], batches, float(g['lmbda']), dtype=dtype, **kw)
+    assert rel_l2(r['Ds'], g['Ds']) < tol
+    for key in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho', 'Cnstr', 'DeltaD',
+                'Eta'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+
+
 def test_pgm_mcdict_traces():
     """FISTA with a multi-channel dictionary: gradient summed over the channels
     (pgm/cbpdn.py:263-279)."""
