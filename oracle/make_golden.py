@@ -528,6 +528,22 @@ def gen_online():
          **itstat_dict(b))
 
 
+def gen_shard():
+    """Dictionary learning on four images in ONE process: what the two-rank image-sharded run
+    of tests/test_dist_gloo.py must reproduce."""
+    np.random.seed(4242)
+    N, M, Nd, K = 16, 4, 5, 4
+    D0 = np.random.randn(Nd, Nd, M)
+    S = np.random.randn(N, N, K)
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+        {'MaxMainIter': 10, 'AccurateDFid': True, 'CCMOD': {'ZeroMean': True}},
+        xmethod='admm', dmethod='pgm')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod='pgm')
+    D1 = b.solve()
+    save('cbpdndl_shard_f64', D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(),
+         **itstat_dict(b))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -609,8 +625,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

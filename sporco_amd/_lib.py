@@ -446,6 +446,17 @@ class Solver(object):
         check(self._lib.sporco_amd_csc_download(self._h, var, _ptr(out)))
         return out
 
+    def device_reals(self, var):
+        """(number of real scalars, torch dtype) of the device array behind ``var`` -- the
+        device layout, i.e. with the padding filter of an odd dictionary."""
+        import torch
+        shape, dt = self.var_shape_dtype(var)
+        kdev = self.query(QUERY_DEVICE_FILTERS)
+        n = int(np.prod(shape[:-1])) * (kdev if shape[-1] == self.dims[4] else shape[-1])
+        if np.dtype(dt).kind == 'c':
+            n *= 2
+        return n, (torch.float32 if self.dtype == np.float32 else torch.float64)
+
     def device_ptr(self, var):
         p = ctypes.c_void_p()
         check(self._lib.sporco_amd_csc_device_ptr(self._h, var, ctypes.byref(p)))

@@ -133,13 +133,22 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             self.update({} if opt is None else opt)
 
     def __init__(self, D0, S, lmbda=None, opt=None, xmethod=None, dmethod=None, dimK=1,
-                 dimN=2, device=0, stream=None):
+                 dimN=2, device=0, stream=None, reducer=None):
+        """Arguments as in the reference (cbpdndl.py:385-423).  Backend keywords: ``device``,
+        ``stream``, and ``reducer`` (:class:`sporco_amd.dist.TorchReducer`) for one process per
+        GPU with ``S`` holding this rank's block of the training images: the
+        X-step exchanges its 16 per-iteration sums, the D-step all-reduces its gradient; every
+        rank ends with the same dictionary.  Offered for ``xmethod='admm'``, ``dmethod='pgm'``."""
+        self._reducer = reducer
         if opt is None:
             opt = ConvBPDNDictLearn.Options(xmethod=xmethod, dmethod=dmethod)
         if xmethod is None:
             xmethod = opt.xmethod
         if dmethod is None:
             dmethod = opt.dmethod
+        if reducer is not None and (xmethod != 'admm' or dmethod != 'pgm'):
+            raise NotImplementedError("image sharding is offered for xmethod='admm', "
+                                      "dmethod='pgm'")
         if opt.xmethod != xmethod or opt.dmethod != dmethod:
             raise ValueError('Parameters xmethod and dmethod must have the same values used '
                              'to initialise the Options object')
@@ -150,15 +159,16 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         D0 = cr.Pcn(D0, dsz, cri.Nv, dimN, cri.dimCd, crp=True, zm=opt['CCMOD', 'ZeroMean'])
         optname = 'X0' if dmethod == 'pgm' else 'Y0'        # (cbpdndl.py:443-445)
         opt['CCMOD'].update({optname: cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
+        bk = {} if reducer is None else {'reducer': reducer}
         xstep = ConvBPDN(D0, S, lmbda, opt['CBPDN'], method=xmethod, dimK=dimK, dimN=dimN,
-                         device=device, stream=stream)
+                         device=device, stream=stream, **bk)
         if xmethod == 'admm':
             # the alternation only ever consumes Y (var_y) of the X-step: tell the
             # device that X / Xf of the inner iterations are never read
             xstep._no_x = True
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
         dstep = ConvCnstrMOD(None, S, dsz, opt['CCMOD'], method=dmethod, dimK=dimK, dimN=dimN,
-                             dev=xdev)
+                             dev=xdev, **bk)
         # dictlrn.DictLearn.solve ignores what the inner solve() calls return
         # (dictlrn.py:333,338): do not copy the iterates to the host every outer iteration
         xstep._return_min = False
@@ -218,4 +228,6 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         dev = self.dstep.dev
         dfd = dev.ccmod_eval(_lib.VAR_DXF)[_lib.PGM_DFID] / 2.0
         rl1 = dev.asum(self._coef_var())
+        if self._reducer is not None:
+            dfd, rl1 = self._reducer.sum([dfd, rl1])
         return dict(DFid=dfd, RegL1=rl1, ObjFun=dfd + self.xstep.lmbda * rl1)

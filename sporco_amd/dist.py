@@ -9,9 +9,25 @@ exchange nothing but one all-reduce of the 16 per-iteration sums -- over RCCL
 CPU test-suite.  This mirrors the reference's per-image split in
 ``sporco/dictlrn/prlcnscdl.py:241,508`` (there: multiprocessing + shared memory).
 
+Dictionary learning shards the same way: the sparse coding step as
+above, and in the dictionary step the gradient -- a sum over images of a dictionary-sized
+spectrum, 17 MB at config 5 -- is all-reduced in place on the device
+(:meth:`TorchReducer.all_reduce_array`); the constraint projection is replicated.
+
 ``torch`` is used here for the process group only; it is not imported by the
 single-GPU path.
 """
+
+import ctypes
+
+
+class _DeviceView(object):
+    """Flat float view of library-owned device memory for ``torch.as_tensor`` (CUDA array
+    interface v2; ROCm builds of torch implement the same protocol)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {'shape': (int(count),), 'typestr': typestr,
+                                         'data': (int(ptr), False), 'version': 2}
 
 
 class TorchReducer(object):
@@ -46,6 +62,38 @@ class TorchReducer(object):
             self.dist.all_reduce(self.buf, group=self.group)
             return self.buf.cpu().tolist()
         return self.sum(solver.admm_iter(params))
+
+    def all_reduce_array(self, solver, var):
+        """Sum state array ``var`` of ``solver`` over the ranks, in place, in device memory."""
+        ptr = solver.device_ptr(var)
+        count, real = solver.device_reals(var)
+        solver.sync()                      # produced on the solver's stream
+        if self.on_gpu:
+            typestr = '<f4' if real == self.torch.float32 else '<f8'
+            try:
+                t = self.torch.as_tensor(_DeviceView(ptr, count, typestr),
+                                         device=self.buf.device)
+                self.array_transport = 'device'
+            except (TypeError, RuntimeError, ValueError) as exc:
+                # a torch build without the array-interface import: stage through the host
+                # (correct, slow -- said once, loudly)
+                if getattr(self, 'array_transport', None) != 'host-staged':
+                    import warnings
+                    warnings.warn("sporco_amd.dist: torch cannot alias library device memory "
+                                  "(%s); all-reducing arrays through host staging" % exc)
+                self.array_transport = 'host-staged'
+                a = solver.download(var)
+                t = self.torch.from_numpy(a).to(self.buf.device)
+                self.dist.all_reduce(t, group=self.group)
+                solver.upload(var, t.cpu().numpy())
+                return
+            self.dist.all_reduce(t, group=self.group)
+            self.torch.cuda.current_stream().synchronize()   # consumed on the solver's stream
+        else:
+            import numpy as np
+            ct = ctypes.c_float if real == self.torch.float32 else ctypes.c_double
+            a = np.ctypeslib.as_array((ct * count).from_address(ptr))
+            self.dist.all_reduce(self.torch.from_numpy(a), group=self.group)
 
     def sum(self, values):
         t = self.torch.tensor(list(values), dtype=self.torch.float64)

@@ -49,11 +49,16 @@ class ConvCnstrMOD(pgm.PGMDFT):
     Zf = _DeviceArray(_lib.VAR_ZF)
     Sf = _DeviceArray(_lib.VAR_SF)
 
-    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
+    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None,
+                 reducer=None):
         """``Z, S, dsz, opt, dimK, dimN`` as in the reference (pgm/ccmod.py:139).
         Backend keyword ``dev``: an existing :class:`sporco_amd._lib.Solver`
         (that of the sparse-coding step) to share, so that coefficient maps and
-        dictionary never leave the GPU during dictionary learning."""
+        dictionary never leave the GPU during dictionary learning.  ``reducer``
+        (:class:`sporco_amd.dist.TorchReducer`): ``S`` / ``Z`` are this rank's block of the
+        images; the gradient and the data-fidelity sums are all-reduced, the dictionary and
+        its projection are replicated."""
+        self._reducer = reducer
         if opt is None:
             opt = ConvCnstrMOD.Options()
         if dimN != 2:
@@ -87,7 +92,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
             self.dev = dev
         super(ConvCnstrMOD, self).__init__(self.cri.shpD, self.cri.Nv, self.cri.axisN,
                                            S.dtype, opt)
-        self.set_attr('L', opt['L'], dval=self.cri.K * 14.0, dtype=self.dtype)
+        nimg = self.cri.K * (1 if reducer is None else reducer.world_size)
+        self.set_attr('L', opt['L'], dval=nimg * 14.0, dtype=self.dtype)
         self.Pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd,
                              zm=opt['ZeroMean'])
         if Z is not None:
@@ -143,19 +149,27 @@ class ConvCnstrMOD(pgm.PGMDFT):
         if V is None:
             V = _lib.VAR_DYF
         out = self.dev.ccmod_grad(V)
+        if self._reducer is not None:
+            self._reducer.all_reduce_array(self.dev, _lib.VAR_DGF)
+            out = self._reducer.sum(out)
         self._fcache[V] = out[_lib.PGM_F]
         self.invalidate(_lib.VAR_DGF)
         return _lib.VAR_DGF
+
+    def _eval(self, var):
+        """Data-fidelity sums at a dictionary spectrum, over all ranks' images."""
+        out = self.dev.ccmod_eval(var)
+        return out if self._reducer is None else self._reducer.sum(out)
 
     def obfn_f(self, Xf=None):
         if Xf is None:
             Xf = _lib.VAR_DXF
         if Xf not in self._fcache:
-            self._fcache[Xf] = self.dev.ccmod_eval(Xf)[_lib.PGM_F]
+            self._fcache[Xf] = self._eval(Xf)[_lib.PGM_F]
         return self._fcache[Xf]
 
     def hess_quad(self, V):
-        return self.dev.ccmod_eval(V)[_lib.PGM_HESS]
+        return self._eval(V)[_lib.PGM_HESS]
 
     def prox_step(self, gradf):
         if gradf != _lib.VAR_DGF:
@@ -168,7 +182,7 @@ class ConvCnstrMOD(pgm.PGMDFT):
         return (self.obfn_dfd(), self.obfn_cns())
 
     def obfn_dfd(self):
-        return self.dev.ccmod_eval(_lib.VAR_DXF)[_lib.PGM_DFID] / 2.0
+        return self._eval(_lib.VAR_DXF)[_lib.PGM_DFID] / 2.0
 
     def obfn_cns(self):
         """||Pcn(X) - X||_2 (pgm/ccmod.py:350-355)."""
@@ -211,6 +225,9 @@ class ConvCnstrMODMask(ConvCnstrMOD):
                 W = np.broadcast_to(W, shp)
             W = W.reshape(W.shape[0:dimN] + (1, W.shape[cri.axisC] * W.shape[cri.axisK], 1))
         self.W = W
+        if backend.get('reducer') is not None:
+            raise NotImplementedError("image sharding is offered for the unmasked dictionary "
+                                      "update")
         super(ConvCnstrMODMask, self).__init__(Z, S, dsz, opt, dimK=dimK, dimN=dimN, **backend)
         self.W = np.asarray(self.W, dtype=self.dtype)
         H, Wd = self.cri.Nv

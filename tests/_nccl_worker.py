@@ -37,8 +37,23 @@ def main():
     Y0 = b0.solve()
     assert np.array_equal(Y, Y0), rel_l2(Y, Y0)
     assert np.array_equal(np.asarray(b.getitstat().Rho), np.asarray(b0.getitstat().Rho))
+    # dictionary learning with the reducer: the D-step gradient is all-reduced in place in the
+    # library's device memory (one rank: the sum is the identity, the plumbing is what runs)
+    from sporco_amd.dictlrn import cbpdndl
+    rng = np.random.RandomState(9)
+    D0, Sd = rng.randn(6, 6, 8), rng.randn(256, 256, 2).astype(np.float32)
+    outs = []
+    for r in (red, None):
+        opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 4, 'AccurateDFid': True},
+                                                xmethod='admm', dmethod='pgm')
+        kw = {} if r is None else {'reducer': r, 'stream': r.stream_handle()}
+        d = cbpdndl.ConvBPDNDictLearn(D0.astype(np.float32), Sd, 0.1, opt, xmethod='admm',
+                                      dmethod='pgm', **kw)
+        outs.append((d.solve(), np.asarray(d.getitstat().ObjFun, dtype=float)))
+    assert np.array_equal(outs[0][0], outs[1][0]), rel_l2(outs[0][0], outs[1][0])
+    assert rel_l2(outs[0][1], outs[1][1]) < 1e-12
     dist.destroy_process_group()
-    print('NCCL_WORKER_OK')
+    print('NCCL_WORKER_OK transport=%s' % getattr(red, 'array_transport', None))
 
 
 if __name__ == '__main__':

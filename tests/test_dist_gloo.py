@@ -30,3 +30,15 @@ def test_two_rank_image_sharding(tmp_path):
         assert rel_l2(p['Rho'], g['it_Rho']) < 1e-9
         assert rel_l2(p['PrimalRsdl'], g['it_PrimalRsdl']) < 1e-9
         assert rel_l2(p['DualRsdl'], g['it_DualRsdl']) < 1e-9
+    # dictionary learning: both ranks hold the dictionary of the single-process run, each its
+    # own images' coefficient maps; every statistic is the global one
+    g = load_golden('cbpdndl_shard_f64')
+    parts = [np.load(out + '.dl.%d.npz' % r) for r in range(2)]
+    assert rel_l2(np.concatenate([p['X'] for p in parts], axis=3), g['X']) < 1e-9
+    for p in parts:
+        assert rel_l2(p['D1'], g['D1']) < 1e-9
+        for f in ('ObjFun', 'DFid', 'RegL1', 'Cnstr', 'XPrRsdl', 'XDlRsdl', 'XRho', 'D_L',
+                  'D_Rsdl'):
+            assert rel_l2(p[f], g['it_' + f]) < 1e-9 or \
+                np.max(np.abs(p[f] - g['it_' + f])) < 1e-12, f
+    assert np.array_equal(parts[0]['D1'], parts[1]['D1'])
