@@ -84,6 +84,8 @@ typedef struct {
 #define SPORCO_AMD_VAR_ZF 16   /* cplx  (H,Wf,C,N,K) rfftn of the coefficient maps (D-step)   */
 #define SPORCO_AMD_VAR_CX 17   /* real  (H,W,C,N,K) consensus D-step: dictionary copy per image */
 #define SPORCO_AMD_VAR_CU 18   /* real  (H,W,C,N,K) consensus D-step: scaled dual per image     */
+#define SPORCO_AMD_VAR_MY0 19  /* real  (H,W,C,N,1) ConvBPDNMaskDcpl: block 0 of Y (masked residual) */
+#define SPORCO_AMD_VAR_MU0 20  /* real  (H,W,C,N,1) ConvBPDNMaskDcpl: block 0 of U                 */
 /* Dictionary-sized state of the D-step (pgm.ccmod.ConvCnstrMOD, admm.ccmod consensus Y =
  * DX): real (H,W,K) / complex (H,Wf,K).  Ids 19..31 are reserved. */
 #define SPORCO_AMD_VAR_DX 32      /* real  dictionary iterate X (zero-padded filters)    */
@@ -377,6 +379,22 @@ typedef struct {
  * (fEvalX False, gEvalY True: the class defaults, ccmod.py:853-894). */
 int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]);
+
+/* ---- ADMM with mask decoupling: sporco.admm.cbpdn.ConvBPDNMaskDcpl (cbpdn.py:2066-2283) on
+ * ConvTwoBlockCnstrnt (:1401-1826) / ADMMTwoBlockCnstrnt (admm.py:989-1437) ------------------
+ * Constraint [D; I] x - [y0; y1] = [s; 0].  Block 1 (coefficient sized) lives in the ADMM state
+ * VAR_Y / VAR_U, block 0 (signal sized) in VAR_MY0 / VAR_MU0; X / Xf as for ConvBPDN.  The mask W
+ * is the data mask of sporco_amd_csc_set_weights(which = 3); single-channel dictionaries. */
+/* S: the real signal (H,W,C,N) (the handle otherwise keeps only its spectrum); zeroes Y, U. */
+int sporco_amd_csc_mdcpl_init(sporco_amd_csc_t h, const void *S);
+/* One iteration.  params: rho, lmbda, rlx, u_scale, flags (NONNEG | NOBNDRY | OBJ | XRRS |
+ * GEVAL_Y = AuxVarObj), dH, dW.  xstep (:1610-1643, rho-free), relax_AX (:1664-1677), ystep
+ * (:2236-2247, :1647-1660), ustep.  out, block 1 sums in the ADMM slots and block 0 sums beside
+ * them (the host adds the pairs): R2 / L21 = |AXnr - y - c|^2, AX2 / RGR = |AXnr|^2, Y2 / CNSTR
+ * = |y|^2, U2 / CGIT = |u|^2; S2 = |A^T u|^2 = |irfftn(conj(Df) rfftn(u0)) + u1|^2 (:1814-1818);
+ * DFID = |W g0|^2 (twice the data fidelity, :2262-2268), L1 = |wl1 g1|_1; XRRS sums. */
+int sporco_amd_csc_mdcpl_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]);
 
 /* ---- online dictionary learning (sporco.dictlrn.onlinecdl.OnlineConvBPDNDictLearn.dstep,
  * onlinecdl.py:310-333) -------------------------------------------------------------------

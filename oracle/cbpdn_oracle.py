@@ -790,3 +790,114 @@ def online_cdl(D0, batches, lmbda, dtype=np.float64, eta_a=10.0, eta_b=5.0,
     out = {k: np.array(v) for k, v in tr.items()}
     out['Ds'] = np.stack(Ds)
     return out
+
+
+# ---------------------------------------------------------------------------
+# ConvBPDNMaskDcpl (sporco/admm/cbpdn.py:2066-2283) on ConvTwoBlockCnstrnt
+# (:1401-1826) and ADMMTwoBlockCnstrnt (sporco/admm/admm.py:989-1437)
+# ---------------------------------------------------------------------------
+
+def admm_cbpdn_maskdcpl(D, S, lmbda, W, dtype=np.float64, maxiter=50, rho=1.0, rlx=1.8,
+                        auto_rho=False, rho_period=10, rho_tau=2.0, rho_mu=10.0,
+                        rho_xi=1.0, auto_scaling=False, abs_tol=0.0, rel_tol=1e-3,
+                        nonneg=False, nobndry=False, wl1=1.0, aux_var_obj=False,
+                        lin_solve_check=False):
+    """Mask decoupling: minimise (1/2)||W(sum_m d_m * x_m - s)||^2 + lmbda ||x||_1 with
+    the constraint [D; I] x - [y0; y1] = [s; 0], single-channel dictionary.
+
+    ``D``: (dH, dW, 1, 1, K); ``S``: (H, W, C, N, 1); ``W`` broadcastable to S.
+      xstep  (cbpdn.py:1610-1643): b = conj(Df) rfftn(y0 - u0 + s) + rfftn(y1 - u1);
+             Xf = solvedbi_sm(Df, 1.0, b) -- rho does not enter
+      relax  (:1664-1677): AXnr = [D x; x], AX = a AXnr + (1 - a) [y0 + s; y1]
+      ystep  (:2236-2247, :1647-1660): y0 = rho (AX0 + u0 - s) / (W^2 + rho),
+             y1 = prox_l1(AX1 + u1, (lmbda / rho) wl1) (+ NonNegCoef / NoBndryCross)
+      ustep  (admm.py:434-437 with rsdl_r :1404-1414): u += AX - [y0 + s; y1]
+      residuals (admm.py:462-486): r = ||AXnr - [y0 + s; y1]||, s = rho ||A^T u|| with
+             A^T u = irfftn(conj(Df) rfftn(u0)) + u1 (cbpdn.py:1814-1818, the NEW u),
+             rn = max(||AXnr||, ||y||, ||s||) (admm.py:1423-1431), sn = rho ||u||
+             (cbpdn.py:1821-1824); Nx = K H W N, Nc = size of y (cbpdn.py:1568-1574)
+      objective (cbpdn.py:2251-2275): DFid = (1/2)||W g0||^2, g0 = y0 (AuxVarObj) or
+             D x - s; RegL1 = ||wl1 g1||_1, g1 = y1 or x.
+    Returns Y1 as the coefficient maps (ReturnVar 'Y1', :1487)."""
+    dtype = np.dtype(dtype)
+    rdt = real_dtype(dtype).type
+    D = np.asarray(D, dtype=dtype)
+    S = np.asarray(S, dtype=dtype)
+    W = np.asarray(W, dtype=dtype)
+    H, Wd = S.shape[0], S.shape[1]
+    K = D.shape[AX_K]
+    shpX = (H, Wd, S.shape[AX_C], S.shape[AX_N], K)
+    Nx = K * H * Wd * S.shape[AX_N]
+    Nc = int(np.prod(shpX)) + int(np.prod(S.shape))
+    lmbda, rho, rlx = rdt(lmbda), rdt(rho), rdt(rlx)
+    wl1 = np.asarray(wl1, dtype=real_dtype(dtype))
+    Df = rfftn2(D, (H, Wd))
+    A0 = lambda xf: irfftn2(inner(Df, xf, axis=AX_K), (H, Wd))
+    A0T = lambda y0: irfftn2(np.conj(Df) * rfftn2(y0), (H, Wd))
+    Y0 = np.zeros(S.shape, dtype=dtype)
+    Y1 = np.zeros(shpX, dtype=dtype)
+    U0, U1 = Y0.copy(), Y1.copy()
+    nrm_c = np.linalg.norm(S)
+    nrm2 = lambda a, b: np.sqrt(np.linalg.norm(a) ** 2 + np.linalg.norm(b) ** 2)
+    tr = {k: [] for k in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal',
+                          'EpsDual', 'Rho', 'XSlvRelRes')}
+    X = None
+    for k in range(maxiter):
+        b = np.conj(Df) * rfftn2(Y0 - U0 + S) + rfftn2(Y1 - U1)
+        Xf = solvedbi_sm(Df, 1.0, b, None, AX_K).astype(b.dtype)
+        X = irfftn2(Xf, (H, Wd))
+        xrrs = rrs(np.conj(Df) * inner(Df, Xf, axis=AX_K) + Xf, b) if lin_solve_check \
+            else np.nan
+        AX0nr, AX1nr = A0(Xf), X
+        if rlx == 1.0:
+            AX0, AX1 = AX0nr, AX1nr
+        else:
+            AX0 = rlx * AX0nr + (1 - rlx) * (Y0 + S)
+            AX1 = rlx * AX1nr + (1 - rlx) * Y1
+        Y0 = ((rho * (AX0 + U0 - S)) / (W ** 2 + rho)).astype(dtype)
+        Y1 = prox_l1(AX1 + U1, (lmbda / rho) * wl1).astype(dtype)
+        if nonneg:
+            Y1[Y1 < 0.0] = 0.0
+        if nobndry:
+            Y1[1 - D.shape[0]:] = 0.0
+            Y1[:, 1 - D.shape[1]:] = 0.0
+        U0 = U0 + (AX0 - (Y0 + S))
+        U1 = U1 + (AX1 - Y1)
+        nr = nrm2(AX0nr - (Y0 + S), AX1nr - Y1)
+        ns = rho * np.linalg.norm(A0T(U0) + U1)
+        rn = max(nrm2(AX0nr, AX1nr), nrm2(Y0, Y1), nrm_c)
+        sn = rho * nrm2(U0, U1)
+        rn = 1.0 if rn == 0.0 else rn
+        sn = 1.0 if sn == 0.0 else sn
+        r, s = nr / rn, ns / sn
+        epri = np.sqrt(Nc) * abs_tol / rn + rel_tol
+        edua = np.sqrt(Nx) * abs_tol / sn + rel_tol
+        g0 = Y0 if aux_var_obj else AX0nr - S
+        g1 = Y1 if aux_var_obj else X
+        dfd = np.linalg.norm(W * g0) ** 2 / 2.0
+        rl1 = np.sum(np.abs(wl1 * g1))
+        vals = dict(ObjFun=dfd + lmbda * rl1, DFid=dfd, RegL1=rl1, PrimalRsdl=r, DualRsdl=s,
+                    EpsPrimal=epri, EpsDual=edua, Rho=rho, XSlvRelRes=xrrs)
+        for key, val in vals.items():
+            tr[key].append(float(val))
+        if auto_rho and k != 0 and (k + 1) % rho_period == 0:
+            if auto_scaling:
+                if s == 0.0 or r == 0.0:
+                    rhomlt = rho_tau
+                else:
+                    rhomlt = min(np.sqrt(r / (s * rho_xi) if r > s * rho_xi
+                                         else (s * rho_xi) / r), rho_tau)
+            else:
+                rhomlt = rho_tau
+            rsf = 1.0
+            if r > rho_xi * rho_mu * s:
+                rsf = rhomlt
+            elif s > (rho_mu / rho_xi) * r:
+                rsf = 1.0 / rhomlt
+            rho = rho * rdt(rsf)
+            U0, U1 = U0 / rsf, U1 / rsf
+        if r < epri and s < edua:
+            break
+    out = {key: np.array(val) for key, val in tr.items()}
+    out.update(X=X, Y0=Y0, Y1=Y1, U0=U0, U1=U1, rho=rho, iters=k + 1)
+    return out

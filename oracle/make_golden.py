@@ -544,6 +544,35 @@ def gen_shard():
          **itstat_dict(b))
 
 
+def gen_maskdcpl():
+    """admm.cbpdn.ConvBPDNMaskDcpl (sporco/admm/cbpdn.py:2066-2283): mask decoupling, the ADMM
+    X-step of masked dictionary learning.  SURVEY.md 8(f) rank 3."""
+    np.random.seed(31415)
+    D = np.random.randn(5, 5, 4)
+    S = np.random.randn(16, 16, 2)
+    W = (np.random.rand(16, 16, 2) > 0.3).astype(np.float64)
+    Wb = (np.random.rand(16, 16) > 0.3).astype(np.float64)       # one mask for all images
+    wl1 = 0.5 + np.random.rand(1, 1, 1, 1, 4)
+    Sc = np.random.randn(16, 16, 3, 2)
+    Wc = (np.random.rand(16, 16, 3, 2) > 0.3).astype(np.float64)
+    for name, SS, WW, optd in (
+            ('maskdcpl_f64', S, W, {'MaxMainIter': 30}),
+            ('maskdcpl_f32', S, W, {'MaxMainIter': 30, 'DataType': np.float32}),
+            ('maskdcpl_autorho_opts_f64', S, Wb,
+             {'MaxMainIter': 30, 'rho': 2.0, 'RelaxParam': 1.5, 'NonNegCoef': True,
+              'NoBndryCross': True, 'L1Weight': wl1, 'AuxVarObj': True, 'LinSolveCheck': True,
+              'AutoRho': {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+                          'AutoScaling': True, 'RsdlTarget': 1.0}}),
+            ('maskdcpl_multichan_f64', Sc, Wc, {'MaxMainIter': 20})):
+        opt = ref_cbpdn.ConvBPDNMaskDcpl.Options(optd)
+        b = ref_cbpdn.ConvBPDNMaskDcpl(D, SS, 0.1, WW, opt)
+        Y1 = b.solve()
+        extra = {'wl1': wl1} if 'L1Weight' in optd else {}
+        save(name, D=D, S=SS, W=WW, lmbda=np.float64(0.1), Y1=Y1, X=b.X, Y=b.Y, U=b.U,
+             recon=b.reconstruct(), rho_final=np.float64(b.rho), k_final=np.int64(b.k),
+             **extra, **itstat_dict(b))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -625,8 +654,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -16,6 +16,7 @@ VAR_Y, VAR_U, VAR_X, VAR_XF, VAR_DF, VAR_SF = 0, 1, 2, 3, 4, 5
 VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_AX, VAR_YPREV = 6, 7, 8, 9, 10, 11, 12
 VAR_T0, VAR_T1, VAR_T2, VAR_ZF = 13, 14, 15, 16
 VAR_CX, VAR_CU = 17, 18
+VAR_MY0, VAR_MU0 = 19, 20
 VAR_DX, VAR_DXF, VAR_DYF, VAR_DXFPRV, VAR_DYFPRV = 32, 33, 34, 35, 36
 VAR_DVF, VAR_DGF, VAR_DT0, VAR_DT1, VAR_DT2 = 37, 38, 39, 40, 41
 VAR_DSX, VAR_DSU = 42, 43
@@ -67,6 +68,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
     'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
     'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter', 'sporco_amd_csc_ccmod_sgd_step',
+    'sporco_amd_csc_mdcpl_init', 'sporco_amd_csc_mdcpl_iter',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
@@ -226,6 +228,8 @@ def load(path=None):
         'sporco_amd_csc_masked_grad': [vp, ctypes.c_int, i32, i32, dptr],
         'sporco_amd_csc_cns_iter': [vp, ctypes.POINTER(CnsParams), dptr],
         'sporco_amd_csc_ccmod_sgd_step': [vp, dbl, i32, i32, i32, dptr],
+        'sporco_amd_csc_mdcpl_init': [vp, vp],
+        'sporco_amd_csc_mdcpl_iter': [vp, ctypes.POINTER(AdmmParams), dptr],
         'sporco_amd_csc_dstep_init': [vp, vp],
         'sporco_amd_csc_dstep_iter': [vp, ctypes.POINTER(DstepParams), dptr],
         'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
@@ -347,6 +351,8 @@ class Solver(object):
             return (H, Wf, self.Cd, 1, K), self.cdtype
         if var == VAR_SF:
             return (H, Wf, self.Cs, N, 1), self.cdtype
+        if var in (VAR_MY0, VAR_MU0):
+            return (H, W, self.Cs, N, 1), self.dtype
         if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2,
                    VAR_ZF):
             return (H, Wf, C, N, K), self.cdtype
@@ -470,6 +476,19 @@ class Solver(object):
     def admm_iter(self, params):
         out = self._out()
         check(self._lib.sporco_amd_csc_admm_iter(self._h, ctypes.byref(params), out))
+        return list(out)
+
+    def mdcpl_init(self, S):
+        """ConvBPDNMaskDcpl state: keeps the real signal on the device, zeroes Y and U."""
+        H, W, C, N, K = self.dims
+        S = _carr(S, self.dtype)
+        if S.size != H * W * self.Cs * N:
+            raise ValueError("signal of shape %s does not match the solver" % (S.shape,))
+        check(self._lib.sporco_amd_csc_mdcpl_init(self._h, _ptr(S)))
+
+    def mdcpl_iter(self, params):
+        out = self._out()
+        check(self._lib.sporco_amd_csc_mdcpl_iter(self._h, ctypes.byref(params), out))
         return list(out)
 
     def admm_iter_dev(self, params, out_dev_ptr):

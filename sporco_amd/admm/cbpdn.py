@@ -30,7 +30,7 @@ from .. import cnvrep as cr
 from ..fft import complex_dtype, real_dtype
 
 __all__ = ['GenericConvBPDN', 'ConvBPDN', 'ConvBPDNJoint', 'ConvBPDNGradReg',
-           'AddMaskSim']
+           'ConvBPDNMaskDcpl', 'AddMaskSim']
 
 
 class _DeviceArray(object):
@@ -651,6 +651,174 @@ class ConvBPDNGradReg(ConvBPDN):
         rl1 = abs(self._wl1_scalar) * self._sums[_lib.OUT_L1]
         rgr = self._wg_scalar * self._sums[_lib.OUT_RGR] / 2.0
         return (self.lmbda * rl1 + self.mu * rgr, rl1, rgr)
+
+
+class ConvBPDNMaskDcpl(ConvBPDN):
+    r"""ConvBPDN with a spatial mask in the data fidelity term, by mask decoupling: minimise
+    (1/2)||W(sum_m d_m * x_m - s)||_2^2 + lambda sum_m ||x_m||_1 through the two-block
+    constraint [D; I] x - [y0; y1] = [s; 0] (reference class: sporco/admm/cbpdn.py:2066-2283 on
+    ConvTwoBlockCnstrnt :1401-1826 and admm.ADMMTwoBlockCnstrnt, sporco/admm/admm.py:989-1437).
+
+    One iteration is one call of ``sporco_amd_csc_mdcpl_iter``: the X-step is the
+    Sherman-Morrison solve of ConvBPDN with rho = 1 and the block-0 spectrum in the signal's
+    place, block 1 (``y1``, ``u1``: coefficient sized) runs through the ConvBPDN epilogue
+    kernel, block 0 (``y0``, ``u0``: signal sized) through its own small kernel; the host forms
+    residuals, objective and the rho schedule from the returned sums.
+
+    IterationStats fields: ``Iter, ObjFun, DFid, RegL1, PrimalRsdl, DualRsdl, EpsPrimal,
+    EpsDual, Rho, XSlvRelRes, Time``.  Single-channel dictionaries; ``Y0`` / ``U0`` warm starts
+    are not offered.
+    """
+
+    _multichannel_dict_ok = False
+    _fused_base = None
+
+    class Options(admm.ADMMEqual.Options):
+        """ConvTwoBlockCnstrnt.Options (cbpdn.py:1428-1519) + ``L1Weight`` (:2123-2128): the
+        ADMM base defaults (AutoRho off) with ``rho`` 1.0, ``RelaxParam`` 1.8, ``ReturnVar``
+        'Y1'.  ``HighMemSolve`` is accepted and has no effect."""
+
+        defaults = copy.deepcopy(admm.ADMMEqual.Options.defaults)
+        defaults.update({'AuxVarObj': False, 'fEvalX': True, 'gEvalY': False,
+                         'HighMemSolve': False, 'LinSolveCheck': False, 'NonNegCoef': False,
+                         'NoBndryCross': False, 'RelaxParam': 1.8, 'rho': 1.0,
+                         'ReturnVar': 'Y1', 'L1Weight': 1.0})
+
+        def __init__(self, opt=None):
+            admm.ADMMEqual.Options.__init__(self, {} if opt is None else opt)
+
+    itstat_fields_objfn = ('ObjFun', 'DFid', 'RegL1')
+    itstat_fields_extra = ('XSlvRelRes',)
+    hdrtxt_objfn = ('Fnc', 'DFid', u'Regℓ1')
+    hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', u'Regℓ1': 'RegL1'}
+
+    def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
+        if opt is None:
+            opt = ConvBPDNMaskDcpl.Options()
+        if opt['Y0'] is not None or opt['U0'] is not None:
+            raise NotImplementedError("ConvBPDNMaskDcpl on the device starts from zero")
+        if opt['ReturnVar'] not in ('X', 'Y0', 'Y1'):
+            raise ValueError(str(opt['ReturnVar']) + ' is not a valid value for option ReturnVar')
+        if backend.get('reducer') is not None:
+            raise NotImplementedError("image sharding is offered for ConvBPDN / ConvBPDNJoint")
+        super(ConvBPDNMaskDcpl, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
+        rdt = real_dtype(self.dtype).type
+        # ADMM base values, not ConvBPDN's lambda-dependent ones (admm.py:245-253)
+        self.set_attr('rho', opt['rho'], dval=1.0, dtype=rdt, reset=True)
+        self.set_attr('rho_xi', opt['AutoRho', 'RsdlTarget'], dval=1.0, dtype=rdt, reset=True)
+        # problem sizes of the two-block constraint (cbpdn.py:1568-1574)
+        self.Nx = self.cri.M * self.cri.N * self.cri.K
+        self.Nc = int(np.prod(self.cri.shpX)) + int(np.prod(self.cri.shpS))
+        if W is None:
+            W = np.array([1.0], dtype=self.dtype)
+        W = np.asarray(W)
+        shp = (1,) * 5 if W.size == 1 else cr.mskWshape(W, self.cri)
+        self.W = np.asarray(W.reshape(shp), dtype=self.dtype)
+        self._upload_weights()
+        self._dev.mdcpl_init(self.S)
+        self._nrm_c = float(np.linalg.norm(self.S))
+
+    def _upload_weights(self):
+        super(ConvBPDNMaskDcpl, self)._upload_weights()
+        if hasattr(self, 'W'):
+            H, Wd = self.cri.Nv
+            self._dev.set_data_mask(_broadcastable(self.W, (H, Wd, self.cri.C, self.cri.K, 1)))
+
+    def __getstate__(self):
+        raise NotImplementedError("ConvBPDNMaskDcpl objects are not picklable in this backend")
+
+    # -- the two blocks -----------------------------------------------------------------------
+    def var_y0(self):
+        return self._dev.download(_lib.VAR_MY0)
+
+    def var_y1(self):
+        return self._fetch(_lib.VAR_Y)
+
+    def block_sep0(self, Y):
+        return Y[..., :self.cri.Cd]
+
+    def block_sep1(self, Y):
+        return Y[..., self.cri.Cd:]
+
+    def block_cat(self, Y0, Y1):
+        return np.concatenate((Y0, Y1), axis=self.cri.axisM)
+
+    @property
+    def Y(self):
+        """[y0; y1] concatenated on the filter axis, as the reference keeps it."""
+        return self.block_cat(self.var_y0(), self.var_y1())
+
+    @Y.setter
+    def Y(self, value):
+        if value is not None:
+            raise NotImplementedError("the blocks of Y are device state; use var_y0 / var_y1")
+
+    @property
+    def U(self):
+        u0 = self._dev.download(_lib.VAR_MU0)
+        if self._u_scale != 1.0:
+            u0 *= u0.dtype.type(self._u_scale)
+        return self.block_cat(u0, self._fetch(_lib.VAR_U))
+
+    @U.setter
+    def U(self, value):
+        if value is not None:
+            raise NotImplementedError("the blocks of U are device state")
+
+    def getmin(self):
+        rv = self.opt['ReturnVar']
+        return self.X if rv == 'X' else (self.var_y0() if rv == 'Y0' else self.var_y1())
+
+    # -- iteration ----------------------------------------------------------------------------
+    def iteration(self):
+        p = self._params()
+        flags = 0
+        if self.opt['NonNegCoef']:
+            flags |= _lib.FLAG_NONNEG
+        if self.opt['NoBndryCross']:
+            flags |= _lib.FLAG_NOBNDRY
+        if self._needs_residuals():
+            flags |= _lib.FLAG_RESID
+        if not self.opt['FastSolve']:
+            flags |= _lib.FLAG_OBJ
+        if self.opt['AuxVarObj']:
+            flags |= _lib.FLAG_GEVAL_Y
+        if self.opt['LinSolveCheck']:
+            flags |= _lib.FLAG_XRRS
+        p.flags = flags
+        self._sums = self._dev.mdcpl_iter(p)
+        self._u_scale = 1.0
+        self._touch(_lib.VAR_X, _lib.VAR_Y, _lib.VAR_U, _lib.VAR_XF)
+        self._set_xrrs()
+        if not self._needs_residuals():
+            return None
+        self.timer.stop('solve_wo_rsdl')
+        res = self.compute_residuals()
+        self.timer.start('solve_wo_rsdl')
+        return res
+
+    def residual_norms(self):
+        """admm.py:1404-1437 with the dual residual of cbpdn.py:1814-1824."""
+        s = self._sums
+        rho = float(self.rho)
+        nr = np.sqrt(s[_lib.OUT_R2] + s[_lib.OUT_L21])
+        ns = rho * np.sqrt(s[_lib.OUT_S2])
+        rn = max(np.sqrt(s[_lib.OUT_AX2] + s[_lib.OUT_RGR]),
+                 np.sqrt(s[_lib.OUT_Y2] + s[_lib.OUT_CNSTR]), self._nrm_c)
+        sn = rho * np.sqrt(s[_lib.OUT_U2] + s[_lib.OUT_CGIT])
+        return nr, ns, rn, sn
+
+    def eval_objfn(self):
+        """(1/2)||W g0||^2 + lmbda ||wl1 g1||_1 (cbpdn.py:2251-2275)."""
+        g0v = self._sums[_lib.OUT_DFID] / 2.0
+        g1v = abs(self._wl1_scalar) * self._sums[_lib.OUT_L1]
+        return (g0v + self.lmbda * g1v, g0v, g1v)
+
+    def reconstruct(self, X=None):
+        """irfftn(sum_m Df * rfftn(X)), X defaulting to the X variable (cbpdn.py:1801-1810)."""
+        if X is None:
+            return self._dev.reconstruct(_lib.VAR_X)[..., 0]
+        return super(ConvBPDNMaskDcpl, self).reconstruct(X)
 
 
 class AddMaskSim(object):

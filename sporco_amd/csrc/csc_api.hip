@@ -152,6 +152,8 @@ struct CscBase {
     virtual void masked_grad(int var, bool dstep, bool write_grad, double *out_dev) = 0;
     virtual void cns_init(const void *Y0, double rho) = 0;
     virtual void cns_iter(const sporco_amd_cns_params &p, double *out_dev) = 0;
+    virtual void mdcpl_init(const void *S) = 0;
+    virtual void mdcpl_iter(const sporco_amd_admm_params &p, double *out_dev) = 0;
     virtual void dstep_init(const void *Y0) = 0;
     virtual void dstep_iter(const sporco_amd_dstep_params &p, double *out_dev) = 0;
     virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
@@ -194,7 +196,7 @@ static bool var_is_dict_sized(int var) {
 }
 
 static bool var_is_valid(int var) {
-    return (var >= 0 && var <= SPORCO_AMD_VAR_CU) ||
+    return (var >= 0 && var <= SPORCO_AMD_VAR_MU0) ||
            (var >= SPORCO_AMD_VAR_DX && var < SPORCO_AMD_VAR_COUNT);
 }
 
@@ -243,6 +245,7 @@ template <typename T> struct Csc : CscBase {
     bool cns_active = false;   // a consensus D-step lives on this handle
     // single-copy ADMM D-step (dstep_iter): Zf stays in the natural layout; ZSf cache and the
     // iterated Sherman-Morrison tables over the images
+    T *md_s = nullptr;         // ConvBPDNMaskDcpl: the real signal
     bool eq_active = false;
     bool zsf_valid = false, dism_valid = false;
     double dism_rho = 0.0;
@@ -419,7 +422,7 @@ template <typename T> struct Csc : CscBase {
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
                         (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
-                        (void *)cns_yold, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
+                        (void *)cns_yold, (void *)md_s, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)wdat_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
@@ -431,8 +434,12 @@ template <typename T> struct Csc : CscBase {
     }
 
     int64_t KD() const { return (int64_t)Cd * K; }   // dictionary entries per pixel
+    static bool var_is_signal_real(int var) {
+        return var == SPORCO_AMD_VAR_MY0 || var == SPORCO_AMD_VAR_MU0;
+    }
     size_t var_bytes(int var) const {
         if (var == SPORCO_AMD_VAR_SF) return sizeof(cx<T>) * npix * CNs;
+        if (var_is_signal_real(var)) return sizeof(T) * (int64_t)H * W * CNs;
         if (var_is_dict_sized(var))
             return var_is_complex(var) ? sizeof(cx<T>) * npix * KD()
                                        : sizeof(T) * (int64_t)H * W * KD();
@@ -734,7 +741,7 @@ template <typename T> struct Csc : CscBase {
     void host_copy(int var, void *host, bool to_device) {
         void *dev = var_ptr(var);
         const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
-        if (K == Ku || var == SPORCO_AMD_VAR_SF) {
+        if (K == Ku || var == SPORCO_AMD_VAR_SF || var_is_signal_real(var)) {
             if (to_device) SA_HIP(hipMemcpyAsync(dev, host, var_bytes(var), kind, st));
             else SA_HIP(hipMemcpyAsync(host, dev, var_bytes(var), kind, st));
             return;
@@ -1990,6 +1997,131 @@ template <typename T> struct Csc : CscBase {
         }
     }
 
+    // ---- ADMM with mask decoupling (ConvBPDNMaskDcpl) ---------------------------------------
+    void mdcpl_init(const void *S) override {
+        require_single_channel_dict();
+        SA_REQUIRE(S != nullptr, "S is null");
+        const size_t nb = sizeof(T) * (int64_t)H * W * CN;
+        if (!md_s) SA_HIP(hipMalloc((void **)&md_s, nb));
+        SA_HIP(hipMemcpyAsync(md_s, S, nb, hipMemcpyHostToDevice, st));
+        before_state_change();
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_Y), 0, sizeof(T) * E, st));
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_U), 0, sizeof(T) * E, st));
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_MY0), 0, nb, st));
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_MU0), 0, nb, st));
+        sync();
+    }
+
+    void mdcpl_iter(const sporco_amd_admm_params &p, double *out_dev) override {
+        require_single_channel_dict();
+        require_ready();
+        SA_REQUIRE(md_s != nullptr, "mdcpl_init must be called first");
+        SA_REQUIRE(p.rho > 0.0, "rho must be positive");
+        SA_REQUIRE(!(p.flags & (F_JOINT | F_GRADREG | F_AMS)), "flag not valid for mask decoupling");
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        before_state_change();
+        x_written();
+        xf_tiled = false;
+        const int64_t ns = (int64_t)H * W * CN;
+        const T us = (T)p.u_scale;
+        T *Y1 = rv(SPORCO_AMD_VAR_Y), *U1 = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
+        T *Y0 = rv(SPORCO_AMD_VAR_MY0), *U0 = rv(SPORCO_AMD_VAR_MU0);
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF), *Df = cv(SPORCO_AMD_VAR_DF);
+        cx<T> *Vf = cv(SPORCO_AMD_VAR_VF), *Gf = cv(SPORCO_AMD_VAR_GF);
+        // xstep: b = conj(Df) rfftn(y0 - u0 + s) + rfftn(y1 - u1); (D^H D + I) Xf = b
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_md_pre<T>(st, Y0, U0, md_s, sreal, us, ns);
+        }
+        fwd2(sreal, nullptr, T(0), innerb, CN);
+        fwd2(Y1, U1, us, Vf, P);
+        const bool xr = p.flags & F_XRRS;
+        int nb;
+        {
+            ProfScope ps(prof, PS_SM_SOLVE);
+            nb = launch_sm_solve<T>(st, Vf, Xf, Df, innerb, gram, T(1), npix, CN, K, W, false, xr,
+                                    part_a);
+        }
+        if (xr) {
+            const int slots[4] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
+                                  SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
+            const double scales[4] = {0.0, 1.0, 1.0, 1.0};
+            finalize(part_a, nb, 4, 4, slots, scales, out_dev);
+        }
+        inv2(Xf, work_buf(), X, P);
+        // block 0: AXnr = D x, relax, y0, u0
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_inner<T>(st, Df, Xf, innerb, npix, CN, K);
+        }
+        inv2(innerb, innerb, sreal, CN);
+        // block 1: relax, y1 = prox_l1 (+ NonNegCoef / NoBndryCross), u1 and the sums
+        PostParams<T> pp;
+        pp.x = X;
+        pp.y = Y1;
+        pp.u = U1;
+        pp.rlx = (T)p.rlx;
+        pp.thr = (T)(p.lmbda / p.rho);
+        pp.thr21 = T(0);
+        pp.u_scale = us;
+        pp.flags = p.flags;
+        pp.d = d5();
+        pp.dH = p.dH;
+        pp.dW = p.dW;
+        pp.wl1 = wl1;
+        pp.wl21 = wl21;
+        pp.ams_k = Ku - 1;
+        {
+            ProfScope ps(prof, PS_ADMM_POST);
+            nb = launch_admm_post<T>(st, pp, part_b);
+        }
+        {
+            const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                                  SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
+            const double scales[6] = {1, 0, 1, 1, 1, 1};
+            finalize(part_b, nb, 8, 6, slots, scales, out_dev);
+        }
+        MdY0Args<T> ya;
+        ya.ax0nr = sreal;
+        ya.y0 = Y0;
+        ya.u0 = U0;
+        ya.s = md_s;
+        ya.w = have_wdat ? wdat : Weight<T>();
+        ya.rho = (T)p.rho;
+        ya.rlx = (T)p.rlx;
+        ya.us = us;
+        ya.geval_y = (p.flags & F_GEVAL_Y) ? 1 : 0;
+        ya.H = H;
+        ya.W = W;
+        ya.C = C;
+        ya.N = N;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_md_y0step<T>(st, ya, part_a);
+        }
+        {
+            const int slots[5] = {SPORCO_AMD_OUT_L21, SPORCO_AMD_OUT_RGR, SPORCO_AMD_OUT_CNSTR,
+                                  SPORCO_AMD_OUT_CGIT, SPORCO_AMD_OUT_DFID};
+            const double scales[5] = {1, 1, 1, 1, 1};
+            finalize(part_a, nb, 5, 5, slots, scales, out_dev);
+        }
+        if (p.flags & F_RESID) {
+            // dual residual (cbpdn.py:1814-1818): A^T u = irfftn(conj(Df) rfftn(u0)) + u1, its
+            // norm through the half-spectrum Parseval sum
+            fwd2(U0, nullptr, T(0), innerb, CN);
+            fwd2(U1, nullptr, T(0), Vf, P);
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_conj_outer<T>(st, Df, innerb, Gf, npix, CN, K);
+                launch_lincomb<T>(st, Gf, T(1), Gf, T(1), Vf, T(0), nullptr, EF);
+                nb = launch_pair_stats<T>(st, Gf, nullptr, nullptr, npix, P, W, part_b);
+            }
+            const int slots[1] = {SPORCO_AMD_OUT_S2};
+            const double scales[1] = {1.0 / ((double)H * W)};
+            finalize(part_b, nb, 4, 1, slots, scales, out_dev);
+        }
+    }
+
     // ---- ADMM dictionary update with one dictionary copy (IterSM / CG) ----------------------
     void dstep_init(const void *Y0) override {
         require_single_channel_dict();
@@ -2701,6 +2833,24 @@ int sporco_amd_csc_ccmod_sgd_step(sporco_amd_csc_t h, double eta, int32_t dH, in
     double *sb = stats_buf(h);
     h->impl->ccmod_sgd_step(eta, dH, dW, zero_mean != 0, sb);
     h->impl->read_out(sb, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_mdcpl_init(sporco_amd_csc_t h, const void *S) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->mdcpl_init(S);
+    SA_API_END
+}
+
+int sporco_amd_csc_mdcpl_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                              double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && out, "null argument");
+    double *dev = stats_buf(h);
+    h->impl->mdcpl_iter(*p, dev);
+    h->impl->read_out(dev, out);
     SA_API_END
 }
 

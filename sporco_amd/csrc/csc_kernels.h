@@ -185,6 +185,24 @@ int launch_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t 
 template <typename T>
 int launch_mask_apply(hipStream_t st, T *r, const Weight<T> &w, bool squared, int H, int W, int C,
                       int N, double *partials);
+// ConvBPDNMaskDcpl (cbpdn.py:2066-2283), the signal-sized block of the two-block constraint:
+// out = y0 - us u0 + s   (the block-0 part of the X-step right-hand side, :1615-1616)
+template <typename T>
+void launch_md_pre(hipStream_t st, const T *y0, const T *u0, const T *s, T *out, T us, int64_t n);
+// relax_AX / ystep / ustep of block 0 (:1664-1677, :2236-2241, admm.py:434-437) given
+// ax0nr = D x.  partials (5): |ax0nr - y0 - s|^2, |ax0nr|^2, |y0|^2, |u0|^2 (all new values) and
+// |w g0|^2 with g0 = y0 (geval_y) or ax0nr - s (:2251-2270).
+template <typename T> struct MdY0Args {
+    const T *ax0nr;
+    T *y0;
+    T *u0;
+    const T *s;
+    Weight<T> w;
+    T rho, rlx, us;
+    int geval_y;
+    int H, W, C, N;
+};
+template <typename T> int launch_md_y0step(hipStream_t st, const MdY0Args<T> &a, double *partials);
 // gf[pix, cn, k] = conj(df[pix, k]) r[pix, cn]
 template <typename T>
 void launch_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *gf, int64_t npix,

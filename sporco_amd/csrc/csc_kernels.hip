@@ -1269,6 +1269,64 @@ int launch_mask_apply(hipStream_t st, T *r, const Weight<T> &w, bool squared, in
     return grid;
 }
 
+// ---------------------------------------------------------------------------
+// ConvBPDNMaskDcpl: the signal-sized block (Y0, U0) of the two-block constraint
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) md_pre_kernel(const T *__restrict__ y0,
+                                                          const T *__restrict__ u0,
+                                                          const T *__restrict__ s,
+                                                          T *__restrict__ out, T us, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y0[i] - us * u0[i] + s[i];
+}
+
+template <typename T>
+void launch_md_pre(hipStream_t st, const T *y0, const T *u0, const T *s, T *out, T us, int64_t n) {
+    hipLaunchKernelGGL((md_pre_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, y0, u0, s, out,
+                       us, n);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) md_y0step_kernel(const MdY0Args<T> a, int64_t n,
+                                                             double *partials) {
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int nn = (int)(i % a.N);
+        const int c = (int)((i / a.N) % a.C);
+        const int64_t pix = i / ((int64_t)a.N * a.C);
+        const int x = (int)(pix % a.W), h = (int)(pix / a.W);
+        const T wv = a.w.ptr ? weight_at(a.w, h, x, c, nn, 0) : T(1);
+        const T axnr = a.ax0nr[i], sv = a.s[i], yo = a.y0[i], uo = a.us * a.u0[i];
+        const T ax = a.rlx == T(1) ? axnr : a.rlx * axnr + (T(1) - a.rlx) * (yo + sv);
+        const T yn = (a.rho * (ax + uo - sv)) / (wv * wv + a.rho);
+        const T un = uo + (ax - (yn + sv));
+        a.y0[i] = yn;
+        a.u0[i] = un;
+        const double r = (double)(axnr - (yn + sv));
+        const double g = (double)(wv * (a.geval_y ? yn : axnr - sv));
+        acc[0] += r * r;
+        acc[1] += (double)axnr * (double)axnr;
+        acc[2] += (double)yn * (double)yn;
+        acc[3] += (double)un * (double)un;
+        acc[4] += g * g;
+    }
+    block_sum_store<5>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 5);
+}
+
+template <typename T>
+int launch_md_y0step(hipStream_t st, const MdY0Args<T> &a, double *partials) {
+    const int64_t n = (int64_t)a.H * a.W * a.C * a.N;
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((md_y0step_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 5 * (kThreads / kWave), st, a, n, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
 // gf[pix, cn, k] = conj(df[pix, k]) r[pix, cn]      (D^H applied to a signal-sized spectrum)
 template <typename T>
 __global__ void __launch_bounds__(kThreads) conj_outer_kernel(const cx<T> *__restrict__ df,
@@ -2052,6 +2110,8 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);                        \
     template int launch_mask_apply<T>(hipStream_t, T *, const Weight<T> &, bool, int, int, int,    \
                                       int, double *);                                              \
+    template void launch_md_pre<T>(hipStream_t, const T *, const T *, const T *, T *, T, int64_t);    \
+    template int launch_md_y0step<T>(hipStream_t, const MdY0Args<T> &, double *);                  \
     template void launch_conj_outer<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,         \
                                        int64_t, int, int);                                         \
     template void launch_zf_adjoint<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,         \

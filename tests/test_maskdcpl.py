@@ -1,0 +1,77 @@
+"""ADMM ConvBPDN with mask decoupling (sporco_amd.admm.cbpdn.ConvBPDNMaskDcpl) against fixtures
+produced by the unmodified reference (oracle/make_golden.py gen_maskdcpl): both blocks of Y and
+U, X, and the IterationStats traces.  float64 1e-9; float32 against the reference's own float32
+run 5e-4, as in test_admm_cbpdn.py."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+AUTORHO = {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2, 'AutoScaling': True,
+           'RsdlTarget': 1.0}
+CASES = {
+    'maskdcpl_f64': {'MaxMainIter': 30},
+    'maskdcpl_f32': {'MaxMainIter': 30, 'DataType': np.float32},
+    'maskdcpl_autorho_opts_f64': {'MaxMainIter': 30, 'rho': 2.0, 'RelaxParam': 1.5,
+                                  'NonNegCoef': True, 'NoBndryCross': True, 'AuxVarObj': True,
+                                  'LinSolveCheck': True, 'AutoRho': AUTORHO},
+    'maskdcpl_multichan_f64': {'MaxMainIter': 20},
+}
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_golden_traces(backend, name):
+    from sporco_amd.admm import cbpdn
+    g = load_golden(name)
+    optd = dict(CASES[name])
+    if 'wl1' in g:
+        optd['L1Weight'] = g['wl1']
+    f32 = optd.get('DataType') is np.float32
+    tol = 5e-4 if f32 else 1e-9
+    b = cbpdn.ConvBPDNMaskDcpl(g['D'], g['S'], float(g['lmbda']), g['W'],
+                               cbpdn.ConvBPDNMaskDcpl.Options(optd))
+    Y1 = b.solve()
+    assert b.k == int(g['k_final'])
+    assert Y1.shape == g['Y1'].shape and rel_l2(Y1, g['Y1']) < tol
+    assert Y1.dtype == (np.float32 if f32 else np.float64)
+    assert rel_l2(b.X, g['X']) < tol
+    assert b.Y.shape == g['Y'].shape and rel_l2(b.Y, g['Y']) < tol
+    assert rel_l2(b.var_y0(), g['Y'][..., :1]) < tol
+    assert b.U.shape == g['U'].shape and rel_l2(b.U, g['U']) < tol
+    assert rel_l2(b.reconstruct().squeeze(), g['recon'].squeeze()) < tol
+    assert rel_l2(float(b.rho), float(g['rho_final'])) < tol
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    if optd.get('LinSolveCheck'):
+        assert np.max(np.abs(np.asarray(its.XSlvRelRes) - g['it_XSlvRelRes'])) < 1e-12
+        assert max(its.XSlvRelRes) < 1e-12
+    else:
+        assert all(v is None for v in its.XSlvRelRes)
+
+
+def test_surface(backend):
+    from sporco_amd.admm import cbpdn
+    g = load_golden('maskdcpl_f64')
+    cls = cbpdn.ConvBPDNMaskDcpl
+    opt = cls.Options()
+    assert opt['rho'] == 1.0 and opt['RelaxParam'] == 1.8 and opt['ReturnVar'] == 'Y1'
+    assert not opt['AutoRho', 'Enabled']
+    # no mask = all ones; ReturnVar selects what solve() returns; solve() continues
+    b = cls(g['D'], g['S'], 0.1, None, cls.Options({'MaxMainIter': 3, 'ReturnVar': 'X'}))
+    X = b.solve()
+    assert np.array_equal(X, b.X) and b.k == 3
+    b.solve()
+    assert b.k == 6
+    b1 = cls(g['D'], g['S'], 0.1, np.ones(g['S'].shape), cls.Options({'MaxMainIter': 6}))
+    assert rel_l2(b1.solve(), b.var_y1()) < 1e-12
+    b0 = cls(g['D'], g['S'], 0.1, g['W'], cls.Options({'MaxMainIter': 2, 'ReturnVar': 'Y0'}))
+    assert b0.solve().shape == b0.cri.shpS
+    with pytest.raises(ValueError):
+        cls(g['D'], g['S'], 0.1, None, cls.Options({'ReturnVar': 'Z'}))
+    with pytest.raises(NotImplementedError):
+        cls(g['D'], g['S'], 0.1, None, cls.Options({'Y0': np.zeros((16, 16, 1, 2, 5))}))
+    with pytest.raises(NotImplementedError):      # multi-channel dictionary
+        cls(np.zeros((5, 5, 3, 4)), np.zeros((16, 16, 3, 2)), 0.1)
+

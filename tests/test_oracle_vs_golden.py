@@ -331,6 +331,53 @@ def test_online_cdl_traces(name, dtype, tol):
         assert rel_l2(r[key], g['it_' + key]) < tol, key
 
 
+MDCPL_CASES = {
+    'maskdcpl_f64': dict(maxiter=30),
+    'maskdcpl_f32': dict(maxiter=30, dtype=np.float32),
+    'maskdcpl_autorho_opts_f64': dict(maxiter=30, rho=2.0, rlx=1.5, nonneg=True, nobndry=True,
+                                      aux_var_obj=True, lin_solve_check=True, auto_rho=True,
+                                      rho_period=3, rho_tau=2.0, rho_mu=1.2, auto_scaling=True,
+                                      _wl1=True),
+    'maskdcpl_multichan_f64': dict(maxiter=20),
+}
+
+
+def maskdcpl_inputs(g):
+    """5-D D, S and mask (cnvrep.mskWshape: a mask of the signal's shape, or one image-shaped
+    mask broadcast over channels and images)."""
+    S = g['S']
+    D5 = g['D'].reshape(g['D'].shape[:2] + (1, 1, g['D'].shape[2]))
+    S5 = S.reshape(S.shape[:2] + ((1, S.shape[2], 1) if S.ndim == 3 else S.shape[2:] + (1,)))
+    Wm = g['W']
+    W5 = Wm.reshape(S5.shape) if Wm.ndim == S.ndim else Wm.reshape(Wm.shape + (1, 1, 1))
+    return D5, S5, W5
+
+
+@pytest.mark.parametrize('name', sorted(MDCPL_CASES))
+def test_maskdcpl_traces(name):
+    """ConvBPDNMaskDcpl restatement: two-block constraint, rho-free X-step, dual residual from
+    the dual variable."""
+    g = load_golden(name)
+    kw = dict(MDCPL_CASES[name])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-9 if dtype == np.float64 else 5e-4
+    if kw.pop('_wl1', False):
+        kw['wl1'] = g['wl1']
+    D5, S5, W5 = maskdcpl_inputs(g)
+    r = orc.admm_cbpdn_maskdcpl(D5, S5, float(g['lmbda']), W5, dtype=dtype, **kw)
+    assert r['iters'] == int(g['k_final'])
+    K = D5.shape[-1]
+    assert rel_l2(r['Y1'], g['Y1']) < tol and rel_l2(r['X'], g['X']) < tol
+    assert rel_l2(r['Y0'], g['Y'][..., :1]) < tol and rel_l2(r['Y1'], g['Y'][..., 1:]) < tol
+    assert rel_l2(r['U0'], g['U'][..., :1]) < tol and rel_l2(r['U1'], g['U'][..., 1:]) < tol
+    assert g['Y'].shape[-1] == K + 1
+    for key in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual',
+                'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    if 'lin_solve_check' in kw:
+        assert np.max(np.abs(r['XSlvRelRes'] - g['it_XSlvRelRes'])) < 1e-12
+
+
 def test_pgm_mcdict_traces():
     """FISTA with a multi-channel dictionary: gradient summed over the channels
     (pgm/cbpdn.py:263-279)."""
