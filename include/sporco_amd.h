@@ -351,7 +351,9 @@ int sporco_amd_csc_set_data_mask(sporco_amd_csc_t h, const void *w, const int64_
  * write_grad == 0: evaluation only -- out[SPORCO_AMD_PGM_DFID] = sum (W R)^2 (spatial domain,
  * twice the data fidelity term) and out[SPORCO_AMD_PGM_F] = (1/2) sum |rfftn(W R)|^2 over the
  * half spectrum (the value backtracking compares, :493-506).  With write_grad != 0 only
- * out[SPORCO_AMD_PGM_DFID] is filled. */
+ * out[SPORCO_AMD_PGM_DFID] is filled.
+ * write_grad == 2 (dstep only in practice): as 1 with the residual weighted by W once instead of
+ * W^2 -- the gradient of OnlineConvBPDNMaskDictLearn.dstep (onlinecdl.py:574-590). */
 int sporco_amd_csc_masked_grad(sporco_amd_csc_t h, int var, int32_t dstep, int32_t write_grad,
                                double out[SPORCO_AMD_OUT_COUNT]);
 

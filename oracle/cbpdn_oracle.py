@@ -749,7 +749,7 @@ def admm_ccmod_eq(Z, S, dsz, method='ism', dtype=np.float64, maxiter=20, rho=Non
 # ---------------------------------------------------------------------------
 
 def online_cdl(D0, batches, lmbda, dtype=np.float64, eta_a=10.0, eta_b=5.0,
-               zero_mean=False, xstep_iter=100):
+               zero_mean=False, xstep_iter=100, masks=None):
     """OnlineConvBPDNDictLearn: for training batch j (5-D ``(H, W, 1, N, 1)``):
       xstep  ADMM ConvBPDN with the current dictionary, cold start, ``xstep_iter``
              iterations at the class's X-step defaults (AutoRho period 10, fixed
@@ -757,6 +757,9 @@ def online_cdl(D0, batches, lmbda, dtype=np.float64, eta_a=10.0, eta_b=5.0,
       dstep  gradf = sum_n conj(Zf_n) (sum_m Zf_nm Df_m - Sf_n); eta = a / (j + b);
              G = irfftn(Df - eta gradf); D = Pcn(G) cropped (:310-333)
       stats  Cnstr = ||zpad(D) - G||, DeltaD = ||D - Dprv|| (:398-399).
+    With ``masks`` (one per batch, broadcastable to the batch): OnlineConvBPDNMaskDictLearn
+    (:464-600) -- X-step ConvBPDNMaskDcpl at its defaults (rho 1, AutoRho off), residual of
+    the dictionary gradient weighted by W ONCE in the spatial domain (:578-580).
     ``D0``: (dH, dW, M)."""
     dtype = np.dtype(dtype)
     dsz = D0.shape
@@ -769,12 +772,19 @@ def online_cdl(D0, batches, lmbda, dtype=np.float64, eta_a=10.0, eta_b=5.0,
     for j, S in enumerate(batches):
         S = np.asarray(S, dtype=dtype)
         H, W = S.shape[:2]
-        r = admm_cbpdn(D, S, lmbda, dtype=dtype, maxiter=xstep_iter, rho_period=10,
-                       rho_tau=2.0, rho_mu=10.0, rho_xi=1.0, auto_scaling=False)
-        Zf = rfftn2(r['Y'])
+        if masks is None:
+            r = admm_cbpdn(D, S, lmbda, dtype=dtype, maxiter=xstep_iter, rho_period=10,
+                           rho_tau=2.0, rho_mu=10.0, rho_xi=1.0, auto_scaling=False)
+            Zf = rfftn2(r['Y'])
+        else:
+            Wm = np.asarray(masks[j], dtype=dtype)
+            r = admm_cbpdn_maskdcpl(D, S, lmbda, Wm, dtype=dtype, maxiter=xstep_iter)
+            Zf = rfftn2(r['Y1'])
         Sf = rfftn2(S)
         Df = rfftn2(D, (H, W))
         Ryf = inner(Zf, Df, axis=AX_K) - Sf
+        if masks is not None:
+            Ryf = rfftn2(Wm * irfftn2(Ryf, (H, W)))
         gradf = inner(np.conj(Zf), Ryf, axis=AX_N)
         eta = eta_a / (j + eta_b)
         G = irfftn2(Df - eta * gradf, (H, W))

@@ -573,6 +573,34 @@ def gen_maskdcpl():
              **extra, **itstat_dict(b))
 
 
+def gen_maskdl():
+    """Masked dictionary learning on the ADMM mask-decoupling X-step: ConvBPDNMaskDictLearn
+    (xmethod='admm', dmethod='pgm'; sporco/dictlrn/cbpdndlmd.py:219-543) and the online
+    learner OnlineConvBPDNMaskDictLearn (sporco/dictlrn/onlinecdl.py:464-600)."""
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    from sporco.dictlrn import onlinecdl as ref_online
+    np.random.seed(27182)
+    N, M, Nd, K = 16, 4, 5, 3
+    D0 = np.random.randn(Nd, Nd, M)
+    S = np.random.randn(N, N, K)
+    Wd = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                               xmethod='admm', dmethod='pgm')
+    b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, Wd, opt, xmethod='admm', dmethod='pgm')
+    D1 = b.solve()
+    save('cbpdndlmd_admm_pgm_f64', D0=D0, S=S, W=Wd, lmbda=np.float64(0.1), D1=D1,
+         X=b.getcoef(), **itstat_dict(b))
+    imgs = np.random.randn(N, N, 4)
+    Wi = (np.random.rand(N, N, 4) > 0.3).astype(np.float64)
+    Wi[..., 3] = 0.25 + 0.75 * np.random.rand(N, N)          # a non-binary weighting
+    opt = ref_online.OnlineConvBPDNMaskDictLearn.Options(
+        {'eta_a': 8.0, 'eta_b': 4.0, 'CBPDN': {'MaxMainIter': 30}})
+    o = ref_online.OnlineConvBPDNMaskDictLearn(D0, 0.1, opt, dimK=0)
+    Ds = [o.solve(imgs[..., i], Wi[..., i]).copy() for i in range(imgs.shape[-1])]
+    save('onlinecdl_mask_f64', D0=D0, S=imgs, W=Wi, lmbda=np.float64(0.1), Ds=np.stack(Ds),
+         **itstat_dict(o))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -654,8 +682,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -424,7 +424,7 @@ class Solver(object):
         """Masked data-fidelity gradient / evaluation (sporco_amd_csc_masked_grad)."""
         out = self._out()
         check(self._lib.sporco_amd_csc_masked_grad(self._h, int(var), 1 if dstep else 0,
-                                                   1 if write_grad else 0, out))
+                                                   int(write_grad), out))
         return list(out)
 
     def set_grad_weight(self, w):

@@ -149,7 +149,7 @@ struct CscBase {
     virtual void ccmod_getdict(int dH, int dW, void *dst) = 0;
     virtual void setdict_from_dstep(int dH, int dW) = 0;
     virtual void asum(int var, double *out_dev) = 0;
-    virtual void masked_grad(int var, bool dstep, bool write_grad, double *out_dev) = 0;
+    virtual void masked_grad(int var, bool dstep, int mode, double *out_dev) = 0;
     virtual void cns_init(const void *Y0, double rho) = 0;
     virtual void cns_iter(const sporco_amd_cns_params &p, double *out_dev) = 0;
     virtual void mdcpl_init(const void *S) = 0;
@@ -1766,7 +1766,10 @@ template <typename T> struct Csc : CscBase {
     // weighted by W only and nothing is written back: out[PGM_DFID] = sum (W R)^2 (twice the
     // data fidelity term, :481-489) and out[PGM_F] = (1/2) sum_half |rfftn(W R)|^2 (the
     // unnormalised DFT-domain value backtracking compares, :493-506).
-    void masked_grad(int var, bool dstep, bool write_grad, double *out_dev) override {
+    // (mode 0: evaluation, 1: gradient with W^2, 2: gradient with the residual weighted by W
+    // once -- the form of the online learner's dictionary step, onlinecdl.py:578-580)
+    void masked_grad(int var, bool dstep, int mode, double *out_dev) override {
+        const bool write_grad = mode != 0;
         require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var) == dstep &&
@@ -1790,7 +1793,7 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
-            nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), write_grad, H, W, C, N,
+            nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), mode == 1, H, W, C, N,
                                       part_a);
         }
         {
@@ -2802,7 +2805,7 @@ int sporco_amd_csc_masked_grad(sporco_amd_csc_t h, int var, int32_t dstep, int32
     SA_HANDLE(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
-    h->impl->masked_grad(var, dstep != 0, write_grad != 0, sb);
+    h->impl->masked_grad(var, dstep != 0, write_grad, sb);
     h->impl->read_out(sb, out);
     SA_API_END
 }

@@ -1,9 +1,11 @@
 """Convolutional dictionary learning with a spatial mask in the data fidelity term.
 
 Drop-in for ``sporco.dictlrn.cbpdndlmd.ConvBPDNMaskDictLearn`` (sporco/dictlrn/cbpdndlmd.py:
-219-543) with the PGM inner solvers: ``xmethod='pgm'`` (:class:`sporco_amd.pgm.cbpdn.ConvBPDNMask`)
-and ``dmethod='pgm'`` (:class:`sporco_amd.pgm.ccmod.ConvCnstrMODMask`).  The reference's ADMM
-variants (``ConvBPDNMaskDcpl``, ``ConvCnstrMODMaskDcpl_*``) are not part of this backend.
+219-543): ``xmethod='admm'`` (the default, mask decoupling:
+:class:`sporco_amd.admm.cbpdn.ConvBPDNMaskDcpl`) or ``'pgm'``
+(:class:`sporco_amd.pgm.cbpdn.ConvBPDNMask`), with ``dmethod='pgm'``
+(:class:`sporco_amd.pgm.ccmod.ConvCnstrMODMask`).  The reference's ADMM dictionary updates with
+mask decoupling (``ConvCnstrMODMaskDcpl_*``) are not part of this backend.
 Both steps share one device handle, as in :mod:`sporco_amd.dictlrn.cbpdndl`.
 """
 
@@ -16,6 +18,7 @@ from . import common as dc
 from . import dictlrn
 from .. import _lib
 from .. import cnvrep as cr
+from ..admm import cbpdn as admm_cbpdn
 from ..pgm import cbpdn as pgm_cbpdn
 from ..pgm import ccmod as pgm_ccmod
 
@@ -26,8 +29,7 @@ def _x_class(method):
     if method == 'pgm':
         return pgm_cbpdn.ConvBPDNMask
     if method == 'admm':
-        raise NotImplementedError("ConvBPDNMaskDcpl (xmethod='admm') is not part of the "
-                                  "sporco_amd hot path; use xmethod='pgm'")
+        return admm_cbpdn.ConvBPDNMaskDcpl
     raise ValueError('Unknown ConvBPDNMask solver method %s' % method)
 
 
@@ -52,11 +54,14 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
         defaults.update({'DictSize': None, 'AccurateDFid': False})
 
         def __init__(self, opt=None, xmethod=None, dmethod=None):
-            self.xmethod = 'pgm' if xmethod is None else xmethod
+            self.xmethod = 'admm' if xmethod is None else xmethod
             self.dmethod = 'pgm' if dmethod is None else dmethod
             xcls, dcls = _x_class(self.xmethod), _d_class(self.dmethod)
             xd = copy.deepcopy(xcls.Options.defaults)
             xd.update({'MaxMainIter': 1})
+            if self.xmethod == 'admm':                         # (cbpdndlmd.py:51-55)
+                xd['AutoRho'].update({'Period': 10, 'AutoScaling': False, 'RsdlRatio': 10.0,
+                                      'Scaling': 2.0, 'RsdlTarget': 1.0})
             dd = copy.deepcopy(dcls.Options.defaults)
             dd.update({'MaxMainIter': 1})
             self.defaults.update({'CBPDN': xd, 'CCMOD': dd})
@@ -67,8 +72,7 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
     def __init__(self, D0, S, lmbda, W, opt=None, xmethod=None, dmethod=None, dimK=1, dimN=2,
                  device=0, stream=None):
         """``W``: mask compatible with the *internal* layout of ``S`` (cbpdndlmd.py:383-395),
-        e.g. (H, W, 1, K) for K greyscale images.  The reference's default ``xmethod`` is
-        'admm'; this backend offers the PGM pair, so that is the default here."""
+        e.g. (H, W, 1, K) for K greyscale images."""
         if opt is None:
             opt = ConvBPDNMaskDictLearn.Options(xmethod=xmethod, dmethod=dmethod)
         if xmethod is None:
@@ -86,7 +90,8 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
         opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
         xstep = xcls(D0, S, lmbda, W, opt['CBPDN'], dimK=dimK, dimN=dimN, device=device,
                      stream=stream)
-        dstep = dcls(None, S, W, dsz, opt['CCMOD'], dimK=dimK, dimN=dimN, dev=xstep.dev)
+        xdev = xstep._dev if xmethod == 'admm' else xstep.dev
+        dstep = dcls(None, S, W, dsz, opt['CCMOD'], dimK=dimK, dimN=dimN, dev=xdev)
         xstep._return_min = False
         dstep._return_min = False
         isc = dictlrn.IterStatsConfig(

@@ -10,8 +10,9 @@ The two steps share the X-step's device handle: the coefficient maps are transfo
 for the gradient (``ccmod_setcoef`` / ``ccmod_grad`` at the current dictionary spectrum), the
 step, inverse transform and constraint projection run on the device
 (``sporco_amd_csc_ccmod_sgd_step``), and only the cropped dictionary (a few KB) returns to the
-host.  The masked variant (``OnlineConvBPDNMaskDictLearn``, onlinecdl.py:464-600) is not part
-of this backend.
+host.  ``OnlineConvBPDNMaskDictLearn`` (onlinecdl.py:464-600) does the same with a spatial mask:
+X-step by mask decoupling (:class:`sporco_amd.admm.cbpdn.ConvBPDNMaskDcpl`), gradient through
+``sporco_amd_csc_masked_grad``.
 """
 
 import copy
@@ -25,7 +26,7 @@ from .. import cnvrep as cr
 from .. import util
 from ..admm import cbpdn
 
-__all__ = ['OnlineConvBPDNDictLearn']
+__all__ = ['OnlineConvBPDNDictLearn', 'OnlineConvBPDNMaskDictLearn']
 
 
 class OnlineConvBPDNDictLearn(common.IterativeSolver):
@@ -213,3 +214,65 @@ class OnlineConvBPDNDictLearn(common.IterativeSolver):
     def display_end(self):
         if self.opt['Verbose'] and self.opt['StatusHeader']:
             print("-" * self.nsep)
+
+
+class OnlineConvBPDNMaskDictLearn(OnlineConvBPDNDictLearn):
+    r"""Online convolutional dictionary learning with a spatial mask in the data fidelity term
+    (onlinecdl.py:464-600): ``solve(S, W)`` per training image with its mask."""
+
+    class Options(OnlineConvBPDNDictLearn.Options):
+        """As :class:`OnlineConvBPDNDictLearn.Options` with ``CBPDN`` the options of
+        :class:`sporco_amd.admm.cbpdn.ConvBPDNMaskDcpl` (onlinecdl.py:477-509; note that this
+        leaves the X-step at that class's ``MaxMainIter`` of 1000 unless set)."""
+
+        defaults = copy.deepcopy(OnlineConvBPDNDictLearn.Options.defaults)
+        defaults.update({'CBPDN': copy.deepcopy(cbpdn.ConvBPDNMaskDcpl.Options.defaults)})
+
+        def __init__(self, opt=None):
+            OnlineConvBPDNDictLearn.Options.__init__(self, {
+                'CBPDN': cbpdn.ConvBPDNMaskDcpl.Options({
+                    'AutoRho': {'Period': 10, 'AutoScaling': False, 'RsdlRatio': 10.0,
+                                'Scaling': 2.0, 'RsdlTarget': 1.0}})})
+            self.update({} if opt is None else opt)
+
+    def solve(self, S, W=None, dimK=None):
+        """Sparse coding and dictionary update for training data ``S`` with mask ``W``
+        (onlinecdl.py:513-545)."""
+        if dimK is None and self.dimK is not None:
+            dimK = self.dimK
+        if self.j == 0:
+            self.display_start()
+        self.timer.start(['solve', 'solve_wo_eval'])
+        self.init_vars(S, dimK)
+        if W is None:
+            W = np.array([1.0], dtype=self.dtype)
+        self.xstep(S, W, self.lmbda, dimK)
+        self.dstep(W)
+        self.timer.stop('solve_wo_eval')
+        self.manage_itstat()
+        self.j += 1
+        self.timer.stop('solve')
+        return self.getdict()
+
+    def xstep(self, S, W, lmbda, dimK):
+        """ConvBPDNMaskDcpl for the new data with the current dictionary (:549-570)."""
+        x = cbpdn.ConvBPDNMaskDcpl(self.D.squeeze(), S, lmbda, np.asarray(W), self.opt['CBPDN'],
+                                   dimK=dimK, dimN=self.cri.dimN, device=self._device,
+                                   stream=self._stream)
+        x._return_min = False
+        x.solve()
+        self._xstep = x
+        self.xstep_itstat = x.itstat[-1] if x.itstat else None
+
+    def dstep(self, W):
+        """Projected SGD step with the residual weighted by the mask (once, in the spatial
+        domain) before the adjoint (:574-590); the mask is the one the X-step uploaded."""
+        dev = self._xstep._dev
+        dev.ccmod_setcoef(_lib.VAR_Y)                     # Zf = rfftn(y1), the coefficient maps
+        dev.copy(_lib.VAR_DYF, _lib.VAR_DF)
+        dev.masked_grad(_lib.VAR_DYF, True, 2)
+        self.eta = self.eta_a / (self.j + self.eta_b)
+        sums = dev.ccmod_sgd_step(self.eta, self.dsz[0], self.dsz[1], self.opt['ZeroMean'])
+        self._cnstr = np.sqrt(sums[_lib.OUT_CNSTR])
+        self.Dprv[:] = self.D
+        self.D[:] = dev.ccmod_getdict(self.dsz[0], self.dsz[1]).reshape(self.D.shape)

@@ -75,3 +75,22 @@ def test_surface(backend):
     with pytest.raises(NotImplementedError):      # multi-channel dictionary
         cls(np.zeros((5, 5, 3, 4)), np.zeros((16, 16, 3, 2)), 0.1)
 
+
+
+def test_masked_dictionary_learning_admm_xstep(backend):
+    """ConvBPDNMaskDictLearn with the mask-decoupling X-step and the PGM D-step
+    (cbpdndlmd.py:219-543; the reference's default xmethod)."""
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_admm_pgm_f64')
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                                  dmethod='pgm')
+    assert opt.xmethod == 'admm' and opt['CBPDN', 'AutoRho', 'Period'] == 10
+    d = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod='admm', dmethod='pgm')
+    D1 = d.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(d.getcoef(), g['X']) < 1e-9
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'D_L', 'D_Rsdl'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+    assert max(its.Cnstr) < 1e-10

@@ -38,6 +38,23 @@ def test_golden_traces(backend, name, dt, tol):
     assert b.getcoef().shape[:2] == S.shape[:2]
 
 
+def test_masked_golden_traces(backend):
+    """OnlineConvBPDNMaskDictLearn (onlinecdl.py:464-600): binary masks and a non-binary
+    weighting (the gradient weights the residual by W once, not W^2)."""
+    from sporco_amd.dictlrn import onlinecdl
+    g = load_golden('onlinecdl_mask_f64')
+    cls = onlinecdl.OnlineConvBPDNMaskDictLearn
+    assert cls.Options()['CBPDN', 'MaxMainIter'] == 1000 and cls.Options()['CBPDN', 'rho'] == 1.0
+    b = cls(g['D0'], float(g['lmbda']),
+            cls.Options({'eta_a': 8.0, 'eta_b': 4.0, 'CBPDN': {'MaxMainIter': 30}}), dimK=0)
+    for i in range(g['S'].shape[-1]):
+        D = b.solve(g['S'][..., i], g['W'][..., i])
+        assert rel_l2(D, g['Ds'][i]) < 1e-9, i
+    its = b.getitstat()
+    for f in FIELDS:
+        assert rel_l2(np.asarray(getattr(its, f), dtype=float), g['it_' + f]) < 1e-9, f
+
+
 def test_surface(backend):
     from sporco_amd.dictlrn import onlinecdl
     cls = onlinecdl.OnlineConvBPDNDictLearn

@@ -378,6 +378,22 @@ def test_maskdcpl_traces(name):
         assert np.max(np.abs(r['XSlvRelRes'] - g['it_XSlvRelRes'])) < 1e-12
 
 
+def test_online_masked_cdl_traces():
+    """OnlineConvBPDNMaskDictLearn restatement: mask-decoupling X-step, gradient residual
+    weighted by the mask once."""
+    g = load_golden('onlinecdl_mask_f64')
+    S, Wm = g['S'], g['W']
+    sh = (S.shape[0], S.shape[1], 1, 1, 1)
+    n = S.shape[-1]
+    r = orc.online_cdl(g['D0'], [S[..., i].reshape(sh) for i in range(n)], float(g['lmbda']),
+                       dtype=np.float64, eta_a=8.0, eta_b=4.0, xstep_iter=30,
+                       masks=[Wm[..., i].reshape(sh) for i in range(n)])
+    assert rel_l2(r['Ds'], g['Ds']) < 1e-9
+    for key in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho', 'Cnstr', 'DeltaD',
+                'Eta'):
+        assert rel_l2(r[key], g['it_' + key]) < 1e-9, key
+
+
 def test_pgm_mcdict_traces():
     """FISTA with a multi-channel dictionary: gradient summed over the channels
     (pgm/cbpdn.py:263-279)."""

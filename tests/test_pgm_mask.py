@@ -72,4 +72,4 @@ def test_masked_dictionary_learning_trace(backend):
         else:
             assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
     with pytest.raises(NotImplementedError):
-        cbpdndlmd.ConvBPDNMaskDictLearn.Options(xmethod='admm')
+        cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')
