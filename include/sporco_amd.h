@@ -86,6 +86,8 @@ typedef struct {
 #define SPORCO_AMD_VAR_CU 18   /* real  (H,W,C,N,K) consensus D-step: scaled dual per image     */
 #define SPORCO_AMD_VAR_MY0 19  /* real  (H,W,C,N,1) ConvBPDNMaskDcpl: block 0 of Y (masked residual) */
 #define SPORCO_AMD_VAR_MU0 20  /* real  (H,W,C,N,1) ConvBPDNMaskDcpl: block 0 of U                 */
+#define SPORCO_AMD_VAR_DMY0 21 /* real  (H,W,C,N,1) mask-decoupling D-step: block 0 of Y           */
+#define SPORCO_AMD_VAR_DMU0 22 /* real  (H,W,C,N,1) mask-decoupling D-step: block 0 of U           */
 /* Dictionary-sized state of the D-step (pgm.ccmod.ConvCnstrMOD, admm.ccmod consensus Y =
  * DX): real (H,W,K) / complex (H,Wf,K).  Ids 19..31 are reserved. */
 #define SPORCO_AMD_VAR_DX 32      /* real  dictionary iterate X (zero-padded filters)    */
@@ -429,12 +431,23 @@ typedef struct {
     int32_t zero_mean;
     int32_t method;  /* SPORCO_AMD_DSTEP_ISM / SPORCO_AMD_DSTEP_CG                      */
     int32_t cg_maxiter;
+    int32_t mask_dcpl; /* != 0: ConvCnstrMODMaskDcpl_IterSM / _CG (sporco/admm/ccmodmd.py:27-762):
+                        constraint [Z; I] d - [y0; y1] = [s; 0] with block 0 in VAR_DMY0 / _DMU0,
+                        mask = the data mask (set_data_mask), X-step system Z^H Z + I (rho-free),
+                        y0 = rho (AX0 + u0 - s) / (W^2 + rho).  out then carries the block-0 sums
+                        beside the block-1 ones -- L1 / R2 = |AXnr - y - c|^2, L21 / AX2 = |AXnr|^2,
+                        RGR / Y2 = |y|^2, slot 15 / U2 = |u|^2 --, S2 = |A^T u|^2 (:557-561),
+                        DFID = |W g0|^2 with g0 = y0 (FLAG_GEVAL_Y) or Z d - s (:508-524).     */
 } sporco_amd_dstep_params;
 /* One iteration: xstep (b = sum_n conj(Zf_n) Sf_n + rho rfftn(Y - U); Xf = (Z^H Z + rho I)^-1 b),
  * relax_AX (admm.py:877-885), ystep Y = Pcn(AX + U) (ccmod.py:363-368), ustep.  out: R2 = |X - Y|^2,
  * S2 = |Y - Yprev|^2, AX2 = |X|^2, Y2, U2; with FLAG_OBJ: DFID (at Xf, or at rfftn(Y) with
  * FLAG_FEVAL_Y) and CNSTR (at X, or at Y with FLAG_GEVAL_Y), ccmod.py:372-410; with FLAG_XRRS the
  * sums of xstep_check (:343-357); CGIT / CGN for the CG method. */
+/* State of the mask-decoupling variant: as sporco_amd_csc_dstep_init plus block 0 zeroed and the
+ * real signal S (H,W,C,N) kept on the device (NULL: keep the one a previous
+ * sporco_amd_csc_mdcpl_init / dstep_md_init call stored). */
+int sporco_amd_csc_dstep_md_init(sporco_amd_csc_t h, const void *Y0, const void *S);
 int sporco_amd_csc_dstep_iter(sporco_amd_csc_t h, const sporco_amd_dstep_params *p,
                               double out[SPORCO_AMD_OUT_COUNT]);
 

@@ -911,3 +911,120 @@ def admm_cbpdn_maskdcpl(D, S, lmbda, W, dtype=np.float64, maxiter=50, rho=1.0, r
     out = {key: np.array(val) for key, val in tr.items()}
     out.update(X=X, Y0=Y0, Y1=Y1, U0=U0, U1=U1, rho=rho, iters=k + 1)
     return out
+
+
+# ---------------------------------------------------------------------------
+# Dictionary updates with mask decoupling: ConvCnstrMODMaskDcpl_IterSM / _CG
+# (sporco/admm/ccmodmd.py:27-762) on ADMMTwoBlockCnstrnt
+# ---------------------------------------------------------------------------
+
+def admm_ccmod_maskdcpl(Z, S, W, dsz, method='ism', dtype=np.float64, maxiter=20, rho=1.0,
+                        rlx=1.8, auto_rho=False, rho_period=10, rho_tau=2.0, rho_mu=10.0,
+                        rho_xi=1.0, auto_scaling=False, zero_mean=False, Y0=None,
+                        aux_var_obj=False, lin_solve_check=False, cg_tol=1e-3,
+                        cg_maxiter=1000, abs_tol=0.0, rel_tol=1e-3):
+    """Constraint [Z; I] d - [y0; y1] = [s; 0], single-channel dictionary.
+
+    ``Z``: (H, W, 1, Nb, M), ``S``: (H, W, 1, Nb, 1), ``W`` broadcastable to S, ``dsz`` =
+    (dH, dW, M); d, y1, u1 are (H, W, 1, 1, M), y0, u0 have the shape of S.
+      xstep  (ccmodmd.py:638-654 / :735-753): b = sum_n conj(Zf_n) rfftn(y0 - u0 + s)_n +
+             rfftn(y1 - u1); (Z^H Z + I) Xf = b by iterated Sherman-Morrison or CG warm
+             started from the previous Xf -- rho does not enter
+      relax  (:387-396), ystep (:374-383): y0 = rho (AX0 + u0 - s) / (W^2 + rho),
+             y1 = Pcn(AX1 + u1); ustep admm.py:434-437 with rsdl_r :1404-1414
+      residuals: r = ||AXnr - [y0 + s; y1]||, s = rho ||A^T u|| with
+             A^T u = irfftn(sum_n conj(Zf_n) rfftn(u0)_n) + u1 (:557-561), rn =
+             max(||AXnr||, ||y||, ||s||), sn = rho ||u|| (:564-567); Nx = size of d,
+             Nc = size of y (:262-270)
+      objective (:508-532): DFid = (1/2)||W g0||^2, g0 = y0 (AuxVarObj) or Z d - s;
+             Cnstr = ||Pcn(g1) - g1||, g1 = y1 or d.
+    ``Y0`` (block 1 only, block 0 zero, as dictionary learning passes it,
+    cbpdndlmd.py:436-444): y1 = u1 = Y0 (uinit :311-322)."""
+    dtype = np.dtype(dtype)
+    rdt = real_dtype(dtype).type
+    Z = np.asarray(Z, dtype=dtype)
+    S = np.asarray(S, dtype=dtype)
+    W = np.asarray(W, dtype=dtype)
+    H, Wd = S.shape[0], S.shape[1]
+    M = Z.shape[AX_K]
+    rho, rlx = rdt(rho), rdt(rlx)
+    Zf = rfftn2(Z)
+    P = lambda v: pcn(v, dsz, (H, Wd), 2, 1, crp=False, zm=zero_mean)
+    A0 = lambda xf: irfftn2(inner(Zf, xf, axis=AX_K), (H, Wd))
+    A0T = lambda y0: irfftn2(inner(np.conj(Zf), rfftn2(y0), axis=AX_N), (H, Wd))
+    AHA = lambda x: inner(np.conj(Zf), inner(Zf, x, axis=AX_K), axis=AX_N)
+    yshape = (H, Wd, 1, 1, M)
+    Y0b = np.zeros(S.shape, dtype=dtype)
+    U0b = Y0b.copy()
+    if Y0 is None:
+        Y1 = np.zeros(yshape, dtype=dtype)
+        U1 = Y1.copy()
+    else:
+        Y1 = np.asarray(Y0).astype(dtype, copy=True)
+        U1 = Y1.copy()
+    Xf = np.zeros((H, Wd // 2 + 1, 1, 1, M), dtype=complex_dtype(dtype))
+    Nx = int(np.prod(yshape))
+    Nc = Nx + int(np.prod(S.shape))
+    nrm_c = np.linalg.norm(S)
+    nrm2 = lambda a, b: np.sqrt(np.linalg.norm(a) ** 2 + np.linalg.norm(b) ** 2)
+    keys = ('DFid', 'Cnstr', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho',
+            'XSlvRelRes') + (('XSlvCGIt',) if method == 'cg' else ())
+    tr = {k: [] for k in keys}
+    X = None
+    for k in range(maxiter):
+        b = inner(np.conj(Zf), rfftn2(Y0b - U0b + S), axis=AX_N) + rfftn2(Y1 - U1)
+        if method == 'ism':
+            Xf = solvemdbi_ism(Zf, 1.0, b, AX_K, AX_N)
+            cgit = None
+        else:
+            Xf, cgit = cg_solve(lambda x: AHA(x) + x, b, Xf, cg_tol, cg_maxiter)
+        Xf = Xf.astype(complex_dtype(dtype))
+        X = irfftn2(Xf, (H, Wd))
+        xrrs = rrs(AHA(Xf) + Xf, b) if lin_solve_check else np.nan
+        AX0nr, AX1nr = A0(Xf), X
+        if rlx == 1.0:
+            AX0, AX1 = AX0nr, AX1nr
+        else:
+            AX0 = rlx * AX0nr + (1 - rlx) * (Y0b + S)
+            AX1 = rlx * AX1nr + (1 - rlx) * Y1
+        Y0b = ((rho * (AX0 + U0b - S)) / (W ** 2 + rho)).astype(dtype)
+        Y1 = P(AX1 + U1).astype(dtype)
+        U0b = U0b + (AX0 - (Y0b + S))
+        U1 = U1 + (AX1 - Y1)
+        nr = nrm2(AX0nr - (Y0b + S), AX1nr - Y1)
+        ns = rho * np.linalg.norm(A0T(U0b) + U1)
+        rn = max(nrm2(AX0nr, AX1nr), nrm2(Y0b, Y1), nrm_c)
+        sn = rho * nrm2(U0b, U1)
+        rn = 1.0 if rn == 0.0 else rn
+        sn = 1.0 if sn == 0.0 else sn
+        r, s = nr / rn, ns / sn
+        epri = np.sqrt(Nc) * abs_tol / rn + rel_tol
+        edua = np.sqrt(Nx) * abs_tol / sn + rel_tol
+        g0 = Y0b if aux_var_obj else AX0nr - S
+        g1 = Y1 if aux_var_obj else X
+        vals = dict(DFid=np.linalg.norm(W * g0) ** 2 / 2.0, Cnstr=np.linalg.norm(P(g1) - g1),
+                    PrimalRsdl=r, DualRsdl=s, EpsPrimal=epri, EpsDual=edua, Rho=rho,
+                    XSlvRelRes=xrrs, XSlvCGIt=cgit)
+        for key in keys:
+            tr[key].append(float(vals[key]))
+        if auto_rho and k != 0 and (k + 1) % rho_period == 0:
+            if auto_scaling:
+                if s == 0.0 or r == 0.0:
+                    rhomlt = rho_tau
+                else:
+                    rhomlt = min(np.sqrt(r / (s * rho_xi) if r > s * rho_xi
+                                         else (s * rho_xi) / r), rho_tau)
+            else:
+                rhomlt = rho_tau
+            rsf = 1.0
+            if r > rho_xi * rho_mu * s:
+                rsf = rhomlt
+            elif s > (rho_mu / rho_xi) * r:
+                rsf = 1.0 / rhomlt
+            rho = rho * rdt(rsf)
+            U0b, U1 = U0b / rsf, U1 / rsf
+        if r < epri and s < edua:
+            break
+    out = {key: np.array(val) for key, val in tr.items()}
+    out.update(X=X, Y0=Y0b, Y1=Y1, U0=U0b, U1=U1, rho=rho, iters=k + 1, D=bcrop(Y1, dsz))
+    return out

@@ -601,6 +601,47 @@ def gen_maskdl():
          **itstat_dict(o))
 
 
+def gen_ccmodmd():
+    """ADMM dictionary updates with mask decoupling, ConvCnstrMODMaskDcpl_IterSM / _CG
+    (sporco/admm/ccmodmd.py:27-762), alone and inside ConvBPDNMaskDictLearn with the
+    mask-decoupling X-step (dmethod='ism' / 'cg').  SURVEY.md 8(f) rank 3."""
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    np.random.seed(16180)
+    N, M, Nd, K = 16, 4, 5, 3
+    S = np.random.randn(N, N, K)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    W = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    D0 = np.random.randn(Nd, Nd, M)
+    autorho = {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+               'AutoScaling': True, 'RsdlTarget': 1.0}
+    for meth, cls in (('ism', ref_ccmodmd.ConvCnstrMODMaskDcpl_IterSM),
+                      ('cg', ref_ccmodmd.ConvCnstrMODMaskDcpl_CG)):
+        for name, optd in (
+                ('f64', {'MaxMainIter': 20}),
+                ('f32', {'MaxMainIter': 20, 'DataType': np.float32}),
+                ('opts_f64', {'MaxMainIter': 20, 'rho': 3.0, 'RelaxParam': 1.5,
+                              'ZeroMean': True, 'LinSolveCheck': True, 'AuxVarObj': True,
+                              'AutoRho': autorho})):
+            if meth == 'cg':      # run CG tight: its result is then a function of its inputs
+                optd = dict(optd, CG={'MaxIter': 500,
+                                      'StopTol': 1e-5 if 'DataType' in optd else 1e-9})
+            opt = cls.Options(optd)
+            c = cls(Z, S, W, (Nd, Nd, M), opt)
+            c.solve()
+            save('ccmodmd_%s_%s' % (meth, name), Z=Z, S=S, W=W, dsz=np.array((Nd, Nd, M)),
+                 D=c.getdict(), Y=c.Y, X=c.X, U=c.U, rho_final=np.float64(c.rho),
+                 k_final=np.int64(c.k), **itstat_dict(c))
+        optd = {'MaxMainIter': 10, 'AccurateDFid': True}
+        if meth == 'cg':
+            optd['CCMOD'] = {'CG': {'MaxIter': 500, 'StopTol': 1e-9}}
+        opt = ref_md.ConvBPDNMaskDictLearn.Options(optd, xmethod='admm', dmethod=meth)
+        b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, W, opt, xmethod='admm', dmethod=meth)
+        D1 = b.solve()
+        save('cbpdndlmd_admm_%s_f64' % meth, D0=D0, S=S, W=W, lmbda=np.float64(0.1), D1=D1,
+             X=b.getcoef(), **itstat_dict(b))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -682,8 +723,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

@@ -17,6 +17,7 @@ VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_AX, VAR_YPREV = 6, 7, 8, 9, 10
 VAR_T0, VAR_T1, VAR_T2, VAR_ZF = 13, 14, 15, 16
 VAR_CX, VAR_CU = 17, 18
 VAR_MY0, VAR_MU0 = 19, 20
+VAR_DMY0, VAR_DMU0 = 21, 22
 VAR_DX, VAR_DXF, VAR_DYF, VAR_DXFPRV, VAR_DYFPRV = 32, 33, 34, 35, 36
 VAR_DVF, VAR_DGF, VAR_DT0, VAR_DT1, VAR_DT2 = 37, 38, 39, 40, 41
 VAR_DSX, VAR_DSU = 42, 43
@@ -68,7 +69,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
     'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
     'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter', 'sporco_amd_csc_ccmod_sgd_step',
-    'sporco_amd_csc_mdcpl_init', 'sporco_amd_csc_mdcpl_iter',
+    'sporco_amd_csc_mdcpl_init', 'sporco_amd_csc_mdcpl_iter', 'sporco_amd_csc_dstep_md_init',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
@@ -102,7 +103,7 @@ class DstepParams(ctypes.Structure):
     _fields_ = [('rho', ctypes.c_double), ('rlx', ctypes.c_double), ('u_scale', ctypes.c_double),
                 ('cg_tol', ctypes.c_double), ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32),
                 ('dW', ctypes.c_int32), ('zero_mean', ctypes.c_int32), ('method', ctypes.c_int32),
-                ('cg_maxiter', ctypes.c_int32)]
+                ('cg_maxiter', ctypes.c_int32), ('mask_dcpl', ctypes.c_int32)]
 
 
 class AdmmParams(ctypes.Structure):
@@ -231,6 +232,7 @@ def load(path=None):
         'sporco_amd_csc_mdcpl_init': [vp, vp],
         'sporco_amd_csc_mdcpl_iter': [vp, ctypes.POINTER(AdmmParams), dptr],
         'sporco_amd_csc_dstep_init': [vp, vp],
+        'sporco_amd_csc_dstep_md_init': [vp, vp, vp],
         'sporco_amd_csc_dstep_iter': [vp, ctypes.POINTER(DstepParams), dptr],
         'sporco_amd_csc_setdict_from_dstep': [vp, i32, i32],
         'sporco_amd_csc_asum': [vp, ctypes.c_int, dptr],
@@ -351,7 +353,7 @@ class Solver(object):
             return (H, Wf, self.Cd, 1, K), self.cdtype
         if var == VAR_SF:
             return (H, Wf, self.Cs, N, 1), self.cdtype
-        if var in (VAR_MY0, VAR_MU0):
+        if var in (VAR_MY0, VAR_MU0, VAR_DMY0, VAR_DMU0):
             return (H, W, self.Cs, N, 1), self.dtype
         if var in (VAR_XF, VAR_YF, VAR_XFPRV, VAR_YFPRV, VAR_VF, VAR_GF, VAR_T0, VAR_T1, VAR_T2,
                    VAR_ZF):
@@ -575,11 +577,20 @@ class Solver(object):
         Y0 = _carr(Y0, self.dtype).reshape(H, W, K)
         check(self._lib.sporco_amd_csc_dstep_init(self._h, _ptr(Y0)))
 
+    def dstep_md_init(self, Y0, S):
+        """Mask-decoupling D-step state: dstep_init(Y0), block 0 zeroed, real signal kept."""
+        H, W, C, N, K = self.dims
+        y0 = None if Y0 is None else _carr(Y0, self.dtype).reshape(H, W, K)
+        s = None if S is None else _carr(S, self.dtype)
+        check(self._lib.sporco_amd_csc_dstep_md_init(self._h, None if y0 is None else _ptr(y0),
+                                                     None if s is None else _ptr(s)))
+
     def dstep_iter(self, method, rho, rlx, u_scale, flags, dH, dW, zero_mean, cg_tol=1e-3,
-                   cg_maxiter=1000):
+                   cg_maxiter=1000, mask_dcpl=False):
         """One IterSM / CG D-step iteration (sporco_amd_csc_dstep_iter)."""
         p = DstepParams(float(rho), float(rlx), float(u_scale), float(cg_tol), int(flags), int(dH),
-                        int(dW), 1 if zero_mean else 0, int(method), int(cg_maxiter))
+                        int(dW), 1 if zero_mean else 0, int(method), int(cg_maxiter),
+                        1 if mask_dcpl else 0)
         out = self._out()
         check(self._lib.sporco_amd_csc_dstep_iter(self._h, ctypes.byref(p), out))
         return list(out)

@@ -155,6 +155,7 @@ struct CscBase {
     virtual void mdcpl_init(const void *S) = 0;
     virtual void mdcpl_iter(const sporco_amd_admm_params &p, double *out_dev) = 0;
     virtual void dstep_init(const void *Y0) = 0;
+    virtual void dstep_md_init(const void *Y0, const void *S) = 0;
     virtual void dstep_iter(const sporco_amd_dstep_params &p, double *out_dev) = 0;
     virtual void fft_var(int rvar, int cvar, bool inverse) = 0;
     virtual void read_out(const double *out_dev, double *out_host) = 0;
@@ -196,7 +197,7 @@ static bool var_is_dict_sized(int var) {
 }
 
 static bool var_is_valid(int var) {
-    return (var >= 0 && var <= SPORCO_AMD_VAR_MU0) ||
+    return (var >= 0 && var <= SPORCO_AMD_VAR_DMU0) ||
            (var >= SPORCO_AMD_VAR_DX && var < SPORCO_AMD_VAR_COUNT);
 }
 
@@ -435,7 +436,7 @@ template <typename T> struct Csc : CscBase {
 
     int64_t KD() const { return (int64_t)Cd * K; }   // dictionary entries per pixel
     static bool var_is_signal_real(int var) {
-        return var == SPORCO_AMD_VAR_MY0 || var == SPORCO_AMD_VAR_MU0;
+        return var >= SPORCO_AMD_VAR_MY0 && var <= SPORCO_AMD_VAR_DMU0;
     }
     size_t var_bytes(int var) const {
         if (var == SPORCO_AMD_VAR_SF) return sizeof(cx<T>) * npix * CNs;
@@ -2144,6 +2145,19 @@ template <typename T> struct Csc : CscBase {
         sync();
     }
 
+    void dstep_md_init(const void *Y0, const void *S) override {
+        dstep_init(Y0);
+        const size_t nb = sizeof(T) * (int64_t)H * W * CN;
+        if (S) {
+            if (!md_s) SA_HIP(hipMalloc((void **)&md_s, nb));
+            SA_HIP(hipMemcpyAsync(md_s, S, nb, hipMemcpyHostToDevice, st));
+        }
+        SA_REQUIRE(md_s != nullptr, "the real signal has not been set");
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_DMY0), 0, nb, st));
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_DMU0), 0, nb, st));
+        sync();
+    }
+
     // two of the sums of launch_pair_stats over dictionary-sized spectra, read back:
     // sum |a|^2 and sum Re(conj(a) g)   (the vdot's of scipy's cg on the half spectrum)
     void cdots(const cx<T> *a, const cx<T> *g, double &a2, double &ag) {
@@ -2184,9 +2198,23 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         need_natural(SPORCO_AMD_VAR_ZF);
         const int64_t npixr = (int64_t)H * W, nd = npix * K;
-        const T rho = (T)p.rho;
+        // mask decoupling: the X-step system is Z^H Z + I whatever rho is, and the signal's
+        // place in the right-hand side is taken by block 0 of y - u + c
+        const bool md = p.mask_dcpl != 0;
+        const T rho = md ? T(1) : (T)p.rho;
+        if (md) SA_REQUIRE(md_s != nullptr, "dstep_md_init must be called first");
         T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_DSX), *U = rv(SPORCO_AMD_VAR_DSU);
+        T *Y0 = md ? rv(SPORCO_AMD_VAR_DMY0) : nullptr, *U0 = md ? rv(SPORCO_AMD_VAR_DMU0) : nullptr;
         cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF), *Sf = cv(SPORCO_AMD_VAR_SF);
+        if (md) {
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_md_pre<T>(st, Y0, U0, md_s, sreal, (T)p.u_scale, (int64_t)H * W * CN);
+            }
+            fwd2(sreal, nullptr, T(0), innerb, CN);
+            Sf = innerb;
+            zsf_valid = false;
+        }
         cx<T> *Xf = cv(SPORCO_AMD_VAR_DYF), *bf = cv(SPORCO_AMD_VAR_DVF);
         cx<T> *yuf = cv(SPORCO_AMD_VAR_DT2), *zsf = cv(SPORCO_AMD_VAR_DXFPRV);
         if (!cns_m) {
@@ -2196,7 +2224,7 @@ template <typename T> struct Csc : CscBase {
         if (!zsf_valid) {   // ZSf = sum_n conj(Zf_n) Sf_n  (setcoef, ccmod.py:327)
             ProfScope ps(prof, PS_OTHER);
             launch_zf_adjoint<T>(st, Zf, Sf, zsf, npix, CN, K);
-            zsf_valid = true;
+            zsf_valid = !md;      // (block 0 changes every iteration)
         }
         // xstep: b = ZSf + rho rfftn(Y - U)
         fwd2(Y, U, (T)p.u_scale, yuf, K);
@@ -2212,10 +2240,10 @@ template <typename T> struct Csc : CscBase {
                 SA_HIP(hipMalloc((void **)&dism_mm, sizeof(cx<T>) * npix * CN * CN));
             }
             ProfScope ps(prof, PS_SM_SOLVE);
-            if (!dism_valid || dism_rho != p.rho) {
+            if (!dism_valid || dism_rho != (double)rho) {
                 launch_ism_setup<T>(st, Zf, dism_gam, dism_del, dism_mm, npix, CN, K, rho);
                 dism_valid = true;
-                dism_rho = p.rho;
+                dism_rho = (double)rho;
             }
             // the images are the rank-one terms, the dictionary the one right-hand side
             launch_ism_solve<T>(st, yuf, Xf, Zf, Sf, dism_gam, dism_del, dism_mm, rho, npix, CN, 1,
@@ -2319,15 +2347,63 @@ template <typename T> struct Csc : CscBase {
         }
         // the dictionary's spectrum (getdict / setdict_from_dstep / objective at Y)
         fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
-        if (p.flags & F_OBJ) {
+        if (md) {
+            // block 0: AXnr = Z d, relax, y0, u0 and its sums; then the dual residual
+            // rho ||A^T u|| with the new u (ccmodmd.py:557-561) as a Parseval sum
             {
                 ProfScope ps(prof, PS_OTHER);
-                nb = launch_ccmod_grad<T>(st, Zf, (p.flags & F_FEVAL_Y) ? cv(SPORCO_AMD_VAR_DXF) : Xf,
-                                          Sf, nullptr, npix, CN, K, W, part_a);
+                launch_inner<T>(st, Xf, Zf, innerb, npix, CN, K);
             }
-            const int slots[1] = {SPORCO_AMD_OUT_DFID};
+            inv2(innerb, innerb, sreal, CN);
+            MdY0Args<T> ya;
+            ya.ax0nr = sreal;
+            ya.y0 = Y0;
+            ya.u0 = U0;
+            ya.s = md_s;
+            ya.w = have_wdat ? wdat : Weight<T>();
+            ya.rho = (T)p.rho;
+            ya.rlx = (T)p.rlx;
+            ya.us = (T)p.u_scale;
+            ya.geval_y = (p.flags & F_GEVAL_Y) ? 1 : 0;
+            ya.H = H;
+            ya.W = W;
+            ya.C = C;
+            ya.N = N;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nb = launch_md_y0step<T>(st, ya, part_a);
+            }
+            {
+                const int slots[5] = {SPORCO_AMD_OUT_L1, SPORCO_AMD_OUT_L21, SPORCO_AMD_OUT_RGR, 15,
+                                      SPORCO_AMD_OUT_DFID};
+                const double scales[5] = {1, 1, 1, 1, 1};
+                finalize(part_a, nb, 5, 5, slots, scales, out_dev);
+            }
+            cx<T> *q = cv(SPORCO_AMD_VAR_DGF);
+            fwd2(U0, nullptr, T(0), innerb, CN);
+            fwd2(U, nullptr, T(0), yuf, K);
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_zf_adjoint<T>(st, Zf, innerb, q, npix, CN, K);
+                launch_lincomb<T>(st, q, T(1), q, T(1), yuf, T(0), nullptr, nd);
+                nb = launch_pair_stats<T>(st, q, nullptr, nullptr, npix, K, W, part_b);
+            }
+            const int slots[1] = {SPORCO_AMD_OUT_S2};
             const double scales[1] = {1.0 / ((double)H * W)};
-            finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
+            finalize(part_b, nb, 4, 1, slots, scales, out_dev);
+        }
+        if (p.flags & F_OBJ) {
+            if (!md) {
+                {
+                    ProfScope ps(prof, PS_OTHER);
+                    nb = launch_ccmod_grad<T>(st, Zf,
+                                              (p.flags & F_FEVAL_Y) ? cv(SPORCO_AMD_VAR_DXF) : Xf, Sf,
+                                              nullptr, npix, CN, K, W, part_a);
+                }
+                const int slots[1] = {SPORCO_AMD_OUT_DFID};
+                const double scales[1] = {1.0 / ((double)H * W)};
+                finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
+            }
             const T *gv = (p.flags & F_GEVAL_Y) ? Y : X;
             int nbc;
             {
@@ -2861,6 +2937,13 @@ int sporco_amd_csc_dstep_init(sporco_amd_csc_t h, const void *Y0) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->dstep_init(Y0);
+    SA_API_END
+}
+
+int sporco_amd_csc_dstep_md_init(sporco_amd_csc_t h, const void *Y0, const void *S) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->dstep_md_init(Y0, S);
     SA_API_END
 }
 

@@ -3,9 +3,9 @@
 Drop-in for ``sporco.dictlrn.cbpdndlmd.ConvBPDNMaskDictLearn`` (sporco/dictlrn/cbpdndlmd.py:
 219-543): ``xmethod='admm'`` (the default, mask decoupling:
 :class:`sporco_amd.admm.cbpdn.ConvBPDNMaskDcpl`) or ``'pgm'``
-(:class:`sporco_amd.pgm.cbpdn.ConvBPDNMask`), with ``dmethod='pgm'``
-(:class:`sporco_amd.pgm.ccmod.ConvCnstrMODMask`).  The reference's ADMM dictionary updates with
-mask decoupling (``ConvCnstrMODMaskDcpl_*``) are not part of this backend.
+(:class:`sporco_amd.pgm.cbpdn.ConvBPDNMask`); ``dmethod='pgm'``
+(:class:`sporco_amd.pgm.ccmod.ConvCnstrMODMask`), ``'ism'`` or ``'cg'`` (mask decoupling:
+:mod:`sporco_amd.admm.ccmodmd`; the consensus variant ``'cns'`` is not part of this backend).
 Both steps share one device handle, as in :mod:`sporco_amd.dictlrn.cbpdndl`.
 """
 
@@ -19,6 +19,7 @@ from . import dictlrn
 from .. import _lib
 from .. import cnvrep as cr
 from ..admm import cbpdn as admm_cbpdn
+from ..admm import ccmodmd as admm_ccmodmd
 from ..pgm import cbpdn as pgm_cbpdn
 from ..pgm import ccmod as pgm_ccmod
 
@@ -36,9 +37,13 @@ def _x_class(method):
 def _d_class(method):
     if method == 'pgm':
         return pgm_ccmod.ConvCnstrMODMask
-    if method in ('ism', 'cg', 'cns'):
-        raise NotImplementedError("ConvCnstrMODMaskDcpl_* (dmethod='%s') is not part of the "
-                                  "sporco_amd hot path; use dmethod='pgm'" % method)
+    if method == 'ism':
+        return admm_ccmodmd.ConvCnstrMODMaskDcpl_IterSM
+    if method == 'cg':
+        return admm_ccmodmd.ConvCnstrMODMaskDcpl_CG
+    if method == 'cns':
+        raise NotImplementedError("ConvCnstrMODMaskDcpl_Consensus (dmethod='cns') is not part of "
+                                  "the sporco_amd backend; use 'pgm', 'ism' or 'cg'")
     raise ValueError('Unknown ConvCnstrMODMask solver method %s' % method)
 
 
@@ -64,6 +69,9 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
                                       'Scaling': 2.0, 'RsdlTarget': 1.0})
             dd = copy.deepcopy(dcls.Options.defaults)
             dd.update({'MaxMainIter': 1})
+            if self.dmethod != 'pgm':                          # (cbpdndlmd.py:147-151)
+                dd['AutoRho'].update({'Period': 10, 'AutoScaling': False, 'RsdlRatio': 10.0,
+                                      'Scaling': 2.0, 'RsdlTarget': 1.0})
             self.defaults.update({'CBPDN': xd, 'CCMOD': dd})
             dictlrn.DictLearn.Options.__init__(self, {'CBPDN': xcls.Options(xd),
                                                       'CCMOD': dcls.Options(dd)})
@@ -87,7 +95,9 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
         dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
         cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)
         D0 = cr.Pcn(D0, dsz, cri.Nv, dimN, cri.dimCd, crp=True, zm=opt['CCMOD', 'ZeroMean'])
-        opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
+        # PGM: X0; ADMM: block 1 of Y0, block 0 zero (cbpdndlmd.py:433-444)
+        optname = 'X0' if dmethod == 'pgm' else 'Y0'
+        opt['CCMOD'].update({optname: cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
         xstep = xcls(D0, S, lmbda, W, opt['CBPDN'], dimK=dimK, dimN=dimN, device=device,
                      stream=stream)
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev

@@ -1,0 +1,95 @@
+"""ADMM dictionary updates with mask decoupling (sporco_amd.admm.ccmodmd.ConvCnstrMODMaskDcpl_IterSM
+/ _CG) and ConvBPDNMaskDictLearn(xmethod='admm', dmethod='ism' / 'cg') against fixtures produced
+by the unmodified reference (oracle/make_golden.py gen_ccmodmd).  IterSM: float64 1e-9, float32
+1e-3; CG is run tight in the fixtures (StopTol 1e-9, float32 1e-5) so that its result is a
+function of its inputs: 1e-7 / 1e-3 (see tests/test_ccmod_ism_cg.py on CG at loose tolerances)."""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+AUTORHO = {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2, 'AutoScaling': True,
+           'RsdlTarget': 1.0}
+CASES = {
+    'f64': {'MaxMainIter': 20},
+    'f32': {'MaxMainIter': 20, 'DataType': np.float32},
+    'opts_f64': {'MaxMainIter': 20, 'rho': 3.0, 'RelaxParam': 1.5, 'ZeroMean': True,
+                 'LinSolveCheck': True, 'AuxVarObj': True, 'AutoRho': AUTORHO},
+}
+
+
+def dstep_class(method):
+    from sporco_amd.admm import ccmodmd
+    return {'ism': ccmodmd.ConvCnstrMODMaskDcpl_IterSM, 'cg': ccmodmd.ConvCnstrMODMaskDcpl_CG}[method]
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_golden_traces(backend, method, case):
+    g = load_golden('ccmodmd_%s_%s' % (method, case))
+    optd = dict(CASES[case])
+    f32 = optd.get('DataType') is np.float32
+    tol = 1e-3 if f32 else 1e-9
+    if method == 'cg':
+        optd['CG'] = {'MaxIter': 500, 'StopTol': 1e-5 if f32 else 1e-9}
+        tol = 1e-3 if f32 else 1e-7
+    cls = dstep_class(method)
+    c = cls(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']), cls.Options(optd))
+    Y1 = c.solve()
+    assert c.k == int(g['k_final'])
+    Nb = g['S'].shape[2]
+    assert Y1.shape == g['Y'][..., Nb:].shape and rel_l2(Y1, g['Y'][..., Nb:]) < tol
+    assert c.Y.shape == g['Y'].shape and rel_l2(c.Y, g['Y']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    assert rel_l2(c.X, g['X']) < tol and rel_l2(c.getdict(), g['D']) < tol
+    assert rel_l2(float(c.rho), float(g['rho_final'])) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < max(10 * tol, 1e-9)
+    if optd.get('LinSolveCheck'):
+        assert np.max(np.abs(np.asarray(its.XSlvRelRes) - g['it_XSlvRelRes'])) < 1e-8
+    if method == 'cg':
+        assert np.array_equal(np.asarray(its.XSlvCGIt), g['it_XSlvCGIt'])
+
+
+def test_surface(backend):
+    from sporco_amd.admm import ccmodmd
+    g = load_golden('ccmodmd_ism_f64')
+    dsz = tuple(int(v) for v in g['dsz'])
+    opt = ccmodmd.ConvCnstrMODMaskDcplOptions({'MaxMainIter': 3}, method='ism')
+    assert opt['rho'] == 1.0 and not opt['AutoRho', 'Enabled'] and opt['ReturnVar'] == 'Y1'
+    c = ccmodmd.ConvCnstrMODMaskDcpl(g['Z'], g['S'], g['W'], dsz, opt, method='ism')
+    c.solve()
+    c.solve()
+    assert c.k == 6 and c.reconstruct().shape[:2] == g['S'].shape[:2]
+    with pytest.raises(NotImplementedError):
+        ccmodmd.ConvCnstrMODMaskDcpl(g['Z'], g['S'], g['W'], dsz, method='cns')
+    with pytest.raises(ValueError):
+        ccmodmd.ConvCnstrMODMaskDcpl(g['Z'], g['S'], g['W'], dsz, method='nosuch')
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+def test_masked_dictionary_learning(backend, method):
+    """ConvBPDNMaskDictLearn with both steps by mask decoupling (cbpdndlmd.py:219-543)."""
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_admm_%s_f64' % method)
+    optd = {'MaxMainIter': 10, 'AccurateDFid': True}
+    tol = 1e-9
+    if method == 'cg':
+        optd['CCMOD'] = {'CG': {'MaxIter': 500, 'StopTol': 1e-9}}
+        tol = 1e-7
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options(optd, xmethod='admm', dmethod=method)
+    assert opt['CCMOD', 'AutoRho', 'Period'] == 10
+    d = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod='admm', dmethod=method)
+    D1 = d.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < tol
+    assert rel_l2(d.getcoef(), g['X']) < tol
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'DPrRsdl', 'DDlRsdl',
+              'DRho'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < tol, f
+    with pytest.raises(NotImplementedError):
+        cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')

@@ -394,6 +394,46 @@ def test_online_masked_cdl_traces():
         assert rel_l2(r[key], g['it_' + key]) < 1e-9, key
 
 
+CCMODMD_CASES = {
+    'f64': dict(maxiter=20),
+    'f32': dict(maxiter=20, dtype=np.float32),
+    'opts_f64': dict(maxiter=20, rho=3.0, rlx=1.5, zero_mean=True, lin_solve_check=True,
+                     aux_var_obj=True, auto_rho=True, rho_period=3, rho_tau=2.0, rho_mu=1.2,
+                     auto_scaling=True),
+}
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+@pytest.mark.parametrize('case', sorted(CCMODMD_CASES))
+def test_ccmod_maskdcpl_traces(method, case):
+    """ConvCnstrMODMaskDcpl_IterSM / _CG restatement (two-block constraint, rho-free X-step
+    over the images, dual residual from the dual variable)."""
+    g = load_golden('ccmodmd_%s_%s' % (method, case))
+    kw = dict(CCMODMD_CASES[case])
+    dtype = kw.pop('dtype', np.float64)
+    tol = 1e-8 if dtype == np.float64 else 1e-3
+    if method == 'cg':
+        kw.update(cg_tol=1e-9 if dtype == np.float64 else 1e-5, cg_maxiter=500)
+        tol = 1e-7 if dtype == np.float64 else 1e-3
+    S, Wm = g['S'], g['W']
+    S5 = S.reshape(S.shape[0], S.shape[1], 1, S.shape[2], 1)
+    r = orc.admm_ccmod_maskdcpl(g['Z'], S5, Wm.reshape(S5.shape), tuple(int(v) for v in g['dsz']),
+                                method=method, dtype=dtype, **kw)
+    assert r['iters'] == int(g['k_final'])
+    Nb = S.shape[2]
+    # the reference keeps y0 on the filter axis of Y: (H, W, 1, 1, Nb + M)
+    y0 = np.moveaxis(r['Y0'], 3, 4)
+    u0 = np.moveaxis(r['U0'], 3, 4)
+    assert rel_l2(y0, g['Y'][..., :Nb]) < tol and rel_l2(r['Y1'], g['Y'][..., Nb:]) < tol
+    assert rel_l2(u0, g['U'][..., :Nb]) < tol and rel_l2(r['U1'], g['U'][..., Nb:]) < tol
+    assert rel_l2(r['X'], g['X']) < tol and rel_l2(r['D'], g['D']) < tol
+    for key in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(r[key], g['it_' + key]) < tol, key
+    assert np.max(np.abs(r['Cnstr'] - g['it_Cnstr'])) < max(10 * tol, 1e-6)
+    if method == 'cg':
+        assert np.array_equal(r['XSlvCGIt'], g['it_XSlvCGIt'])
+
+
 def test_pgm_mcdict_traces():
     """FISTA with a multi-channel dictionary: gradient summed over the channels
     (pgm/cbpdn.py:263-279)."""
