@@ -137,8 +137,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         """Arguments as in the reference (cbpdndl.py:385-423).  Backend keywords: ``device``,
         ``stream``, and ``reducer`` (:class:`sporco_amd.dist.TorchReducer`) for one process per
         GPU with ``S`` holding this rank's block of the training images: the
-        X-step exchanges its 16 per-iteration sums, the D-step all-reduces its gradient; every
-        rank ends with the same dictionary.  Offered for ``xmethod='admm'``, ``dmethod='pgm'``."""
+        X-step exchanges its per-iteration sums, the D-step all-reduces its gradient; every
+        rank ends with the same dictionary.  Offered for ``dmethod='pgm'`` with either X-step."""
         self._reducer = reducer
         if opt is None:
             opt = ConvBPDNDictLearn.Options(xmethod=xmethod, dmethod=dmethod)
@@ -146,9 +146,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             xmethod = opt.xmethod
         if dmethod is None:
             dmethod = opt.dmethod
-        if reducer is not None and (xmethod != 'admm' or dmethod != 'pgm'):
-            raise NotImplementedError("image sharding is offered for xmethod='admm', "
-                                      "dmethod='pgm'")
+        if reducer is not None and dmethod != 'pgm':
+            raise NotImplementedError("image sharding is offered for dmethod='pgm'")
         if opt.xmethod != xmethod or opt.dmethod != dmethod:
             raise ValueError('Parameters xmethod and dmethod must have the same values used '
                              'to initialise the Options object')
@@ -167,6 +166,7 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             # device that X / Xf of the inner iterations are never read
             xstep._no_x = True
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
+        xdev = getattr(xdev, '_raw', xdev)     # (the D-step's own sums are reduced explicitly)
         dstep = ConvCnstrMOD(None, S, dsz, opt['CCMOD'], method=dmethod, dimK=dimK, dimN=dimN,
                              dev=xdev, **bk)
         # dictlrn.DictLearn.solve ignores what the inner solve() calls return

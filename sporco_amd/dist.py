@@ -110,6 +110,34 @@ class TorchReducer(object):
         return float(t.cpu()[0])
 
 
+class ReducingSolver(object):
+    """Stand-in for a :class:`sporco_amd._lib.Solver` holding one rank's images: every call
+    that returns sums over the coefficient arrays (objective terms, residuals, the inner
+    products of the step-size and backtracking policies) returns them summed over the ranks,
+    everything else goes straight to the device handle (``_raw``).  Used by the FISTA sparse
+    coding step, whose host logic asks the device for such sums in many places."""
+
+    _SUMS = ('pgm_iter', 'pgm_grad', 'pgm_eval', 'pgm_prox_step', 'pair_stats')
+
+    def __init__(self, raw, reducer):
+        self.__dict__['_raw'] = raw
+        self.__dict__['_reducer'] = reducer
+
+    def __getattr__(self, name):
+        attr = getattr(self._raw, name)
+        red = self._reducer
+        if name in self._SUMS:
+            return lambda *a, **k: red.sum(attr(*a, **k))
+        if name == 'asum':
+            return lambda *a, **k: red.sum([attr(*a, **k)])[0]
+        if name == 'dhs_absmax':
+            return lambda *a, **k: red.max(attr(*a, **k))
+        return attr
+
+    def __setattr__(self, name, value):
+        setattr(self._raw, name, value)
+
+
 def shard_images(S, rank, world_size, axis=-1):
     """Contiguous block of the image axis owned by ``rank``."""
     import numpy as np

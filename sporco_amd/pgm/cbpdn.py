@@ -53,7 +53,14 @@ class ConvBPDN(pgm.PGMDFT):
     Df = _DeviceArray(_lib.VAR_DF)
     Sf = _DeviceArray(_lib.VAR_SF)
 
-    def __init__(self, D, S, lmbda=None, opt=None, dimK=None, dimN=2, device=0, stream=None):
+    def __init__(self, D, S, lmbda=None, opt=None, dimK=None, dimN=2, device=0, stream=None,
+                 reducer=None):
+        """``D, S, lmbda, opt, dimK, dimN`` as in the reference (pgm/cbpdn.py:147-218).  Backend
+        keywords: ``device``, ``stream``, and ``reducer`` (:class:`sporco_amd.dist.TorchReducer`)
+        when ``S`` is this rank's block of the images: every sum the iteration takes over the
+        coefficient arrays is then all-reduced (:class:`sporco_amd.dist.ReducingSolver`), so all
+        ranks follow the single-process step-size, backtracking and stopping decisions."""
+        self._reducer = reducer
         if opt is None:
             opt = ConvBPDN.Options()
         if dimN != 2:
@@ -83,6 +90,9 @@ class ConvBPDN(pgm.PGMDFT):
         H, W = self.cri.Nv
         self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
                                device=self._device, stream=self._stream, Cd=self.cri.Cd)
+        if getattr(self, '_reducer', None) is not None:
+            from ..dist import ReducingSolver
+            self.dev = ReducingSolver(self.dev, self._reducer)
         self._cache = {}
         self._fcache = {}
         self._rl1 = 0.0
@@ -125,6 +135,7 @@ class ConvBPDN(pgm.PGMDFT):
                                   (_lib.VAR_X, _lib.VAR_XF, _lib.VAR_YF, _lib.VAR_XFPRV,
                                    _lib.VAR_YFPRV)}
         state['_stream'] = None
+        state['_reducer'] = None          # a process group does not pickle
         return state
 
     def __setstate__(self, state):
@@ -261,6 +272,8 @@ class ConvBPDNMask(ConvBPDN):
     the unmasked solver.  Single-channel dictionaries."""
 
     def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
+        if backend.get('reducer') is not None:
+            raise NotImplementedError("image sharding is offered for the unmasked solver")
         super(ConvBPDNMask, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
         if self.cri.Cd > 1:
             raise NotImplementedError("ConvBPDNMask with a multi-channel dictionary is not "

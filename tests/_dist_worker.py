@@ -46,6 +46,34 @@ def main():
     np.savez(out_path + '.dl.%d.npz' % rank, D1=D1, X=d.getcoef(),
              **{f: np.asarray(getattr(its, f), dtype=float) for f in its._fields
                 if f not in ('Iter', 'Time')})
+    # FISTA sparse coding with one image per rank: backtracking and Barzilai-Borwein step sizes
+    # take their inner products over all images
+    from sporco_amd.pgm import cbpdn as pgm_cbpdn
+    from test_pgm_cbpdn import policies
+    for name in ('pgm_btstd_f64', 'pgm_stepbb_f64'):
+        g = load_golden(name)
+        optd = dict(policies()[name])
+        optd['RelStopTol'] = 0.0
+        S = shard_images(g['S'], rank, world, axis=-1)
+        b = pgm_cbpdn.ConvBPDN(g['D'], S, float(g['lmbda']), pgm_cbpdn.ConvBPDN.Options(optd),
+                               reducer=TorchReducer())
+        X = b.solve()
+        its = b.getitstat()
+        np.savez(out_path + '.%s.%d.npz' % (name, rank), X=X, k=b.k,
+                 **{f: np.asarray(getattr(its, f), dtype=float) for f in ('ObjFun', 'Rsdl', 'L')})
+    # ... and dictionary learning with that X-step
+    g = load_golden('cbpdndl_shard_f64')
+    S = shard_images(g['S'], rank, world, axis=-1)
+    outs = []
+    for red in (TorchReducer(), None):
+        opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 4, 'AccurateDFid': True},
+                                                xmethod='pgm', dmethod='pgm')
+        kw = {'reducer': red} if red is not None else {}
+        d = cbpdndl.ConvBPDNDictLearn(g['D0'], S if red is not None else g['S'],
+                                      float(g['lmbda']), opt, xmethod='pgm', dmethod='pgm', **kw)
+        outs.append((d.solve(), np.asarray(d.getitstat().ObjFun, dtype=float)))
+    np.savez(out_path + '.dlpgm.%d.npz' % rank, D1=outs[0][0], D1_single=outs[1][0],
+             ObjFun=outs[0][1], ObjFun_single=outs[1][1])
     dist.destroy_process_group()
 
 

@@ -42,3 +42,18 @@ def test_two_rank_image_sharding(tmp_path):
             assert rel_l2(p[f], g['it_' + f]) < 1e-9 or \
                 np.max(np.abs(p[f] - g['it_' + f])) < 1e-12, f
     assert np.array_equal(parts[0]['D1'], parts[1]['D1'])
+    # FISTA sparse coding sharded over the two images
+    for name in ('pgm_btstd_f64', 'pgm_stepbb_f64'):
+        g = load_golden(name)
+        parts = [np.load(out + '.%s.%d.npz' % (name, r)) for r in range(2)]
+        assert rel_l2(np.concatenate([p['X'] for p in parts], axis=3), g['X']) < 1e-9
+        for p in parts:
+            assert int(p['k']) == int(g['k_final'])
+            for f in ('ObjFun', 'Rsdl', 'L'):
+                assert rel_l2(p[f], g['it_' + f]) < 1e-9, (name, f)
+    # dictionary learning on the sharded FISTA X-step against the single-process run of the
+    # same classes (rank-local, all four images)
+    for r in range(2):
+        p = np.load(out + '.dlpgm.%d.npz' % r)
+        assert rel_l2(p['D1'], p['D1_single']) < 1e-9
+        assert rel_l2(p['ObjFun'], p['ObjFun_single']) < 1e-9
