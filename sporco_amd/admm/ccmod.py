@@ -27,7 +27,101 @@ __all__ = ['ConvCnstrMOD_Consensus', 'ConvCnstrMOD_IterSM', 'ConvCnstrMOD_CG', '
            'ConvCnstrMODOptions']
 
 
-class ConvCnstrMOD_Consensus(admm.ADMM):
+class _DeviceDStep(object):
+    """What the ADMM dictionary updates of this module share whatever their splitting: the
+    device handle (own or the sparse coding step's), coefficient maps, the dictionary Y =
+    ``SPORCO_AMD_VAR_DX`` with its read-back, the two objective terms from the sums of the last
+    device call, the deferred ``U /= rsf``."""
+
+    itstat_fields_objfn = ('DFid', 'Cnstr')
+    itstat_fields_extra = ('XSlvRelRes',)
+    hdrtxt_objfn = ('DFid', 'Cnstr')
+    hdrval_objfun = {'DFid': 'DFid', 'Cnstr': 'Cnstr'}
+
+    def _attach_device(self, S, dev, device, stream):
+        """``self.S`` in the internal layout (one block per (channel, image): channels fold
+        into the image axis for a single-channel dictionary, ccmod.py:695-699, :702-706) and
+        ``self.dev``."""
+        H, W = self.cri.Nv
+        self.Nb = self.cri.C * self.cri.K
+        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
+        self._shared = dev is not None
+        if dev is None:
+            self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                                   device=device, stream=stream)
+            self.dev.set_signal(self.S)
+        else:
+            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
+                raise ValueError("shared device solver has different dimensions")
+            self.dev = dev
+        self._cache = {}
+        self._u_scale = 1.0
+        self._sums = [0.0] * _lib.OUT_COUNT
+
+    @property
+    def Y(self):
+        if _lib.VAR_DX not in self._cache:
+            self._cache[_lib.VAR_DX] = self.dev.download(_lib.VAR_DX)
+        return self._cache[_lib.VAR_DX]
+
+    @Y.setter
+    def Y(self, value):
+        if value is None:
+            return
+        self.dev.upload(_lib.VAR_DX, np.asarray(value, dtype=self.dtype))
+        self.dev.fft_var(_lib.VAR_DX, _lib.VAR_DXF)
+        self._cache.pop(_lib.VAR_DX, None)
+
+    def getmin(self):
+        return self.Y
+
+    def setcoef(self, Z):
+        """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:311-327, :746-755)."""
+        self.Z = np.asarray(np.asarray(Z).reshape(self.cri.Nv + (1, self.Nb, self.cri.M)),
+                            dtype=self.dtype)
+        self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
+        self.dev.ccmod_setcoef(_lib.VAR_AX)
+
+    def setcoef_from_device(self, var=_lib.VAR_Y):
+        """Zf = rfftn(<real state of the shared solver>), no host round trip."""
+        self.dev.ccmod_setcoef(var)
+
+    def getdict(self, crop=True):
+        """The dictionary, cropped to the filter support by default (ccmod.py:331-339,
+        :839-848)."""
+        if crop:
+            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
+        return self.Y
+
+    def finish_solve(self):
+        self.dev.sync()
+
+    def rescale_u(self, rsf):
+        self._u_scale = self._u_scale / float(rsf)
+
+    def eval_objfn(self):
+        return (self.obfn_dfd(), self.obfn_cns())
+
+    def obfn_dfd(self):
+        """(1/2) ||sum_m Zf Df - Sf||^2 at the variable the options select (ccmod.py:396-403,
+        :871-878)."""
+        return self._sums[_lib.OUT_DFID] / 2.0
+
+    def obfn_cns(self):
+        """||Pcn(v) - v||_2 (ccmod.py:407-410, :882-889)."""
+        return np.sqrt(self._sums[_lib.OUT_CNSTR])
+
+    def itstat_extra(self):
+        return (self.xrrs,)
+
+    def profile(self, enable=True):
+        self.dev.profile(enable)
+
+    def profile_read(self):
+        return self.dev.profile_read()
+
+
+class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
     r"""Minimise (1/2) sum_k ||sum_m d_m * x_{k,m} - s_k||_2^2 over filters d_m of unit norm
     and constrained support, as an ADMM consensus problem over the images.
 
@@ -56,11 +150,6 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
                 self['fEvalX'] = value is not True
                 self['gEvalY'] = value is True
 
-    itstat_fields_objfn = ('DFid', 'Cnstr')
-    itstat_fields_extra = ('XSlvRelRes',)
-    hdrtxt_objfn = ('DFid', 'Cnstr')
-    hdrval_objfun = {'DFid': 'DFid', 'Cnstr': 'Cnstr'}
-
     def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
         """``Z, S, dsz, opt, dimK, dimN`` as in the reference (ccmod.py:653-712).  Backend
         keyword ``dev``: a :class:`sporco_amd._lib.Solver` to share with the sparse coding
@@ -82,23 +171,7 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
-        H, W = self.cri.Nv
-        # one consensus block per (channel, image): channels fold into the image axis for a
-        # single-channel dictionary (ccmod.py:695-699, :702-706)
-        self.Nb = self.cri.C * self.cri.K
-        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
-        self._shared = dev is not None
-        if dev is None:
-            self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                   device=device, stream=stream)
-            self.dev.set_signal(self.S)
-        else:
-            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
-                raise ValueError("shared device solver has different dimensions")
-            self.dev = dev
-        self._cache = {}
-        self._u_scale = 1.0
-        self._sums = [0.0] * _lib.OUT_COUNT
+        self._attach_device(S, dev, device, stream)     # one consensus block per image
         self.yshape = self.cri.shpD
         self.xshape = self.cri.shpD + (self.Nb,)
         Nx = self.Nb * int(np.prod(self.yshape))
@@ -125,20 +198,6 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
         return np.ascontiguousarray(np.moveaxis(np.asarray(a)[:, :, :, 0], -1, 3))
 
     @property
-    def Y(self):
-        if _lib.VAR_DX not in self._cache:
-            self._cache[_lib.VAR_DX] = self.dev.download(_lib.VAR_DX)
-        return self._cache[_lib.VAR_DX]
-
-    @Y.setter
-    def Y(self, value):
-        if value is None:
-            return
-        self.dev.upload(_lib.VAR_DX, np.asarray(value, dtype=self.dtype))
-        self.dev.fft_var(_lib.VAR_DX, _lib.VAR_DXF)
-        self._cache.pop(_lib.VAR_DX, None)
-
-    @property
     def X(self):
         return self._from_blocks(self.dev.download(_lib.VAR_CX))
 
@@ -158,27 +217,6 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
             self.dev.upload(_lib.VAR_CU, self._to_blocks(np.asarray(value, dtype=self.dtype)))
             self._u_scale = 1.0
 
-    def getmin(self):
-        return self.Y
-
-    def setcoef(self, Z):
-        """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:746-755)."""
-        self.Z = np.asarray(np.asarray(Z).reshape(self.cri.Nv + (1, self.Nb, self.cri.M)),
-                            dtype=self.dtype)
-        self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
-        self.dev.ccmod_setcoef(_lib.VAR_AX)
-
-    def setcoef_from_device(self, var=_lib.VAR_Y):
-        """Zf = rfftn(<real state of the shared solver>), no host round trip."""
-        self.dev.ccmod_setcoef(var)
-
-    def getdict(self, crop=True):
-        """The consensus variable, cropped to the filter support by default
-        (ccmod.py:839-848)."""
-        if crop:
-            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
-        return self.Y
-
     # -- iteration --------------------------------------------------------------------------
     def iteration(self):
         flags = 0
@@ -197,9 +235,6 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
         self.timer.start('solve_wo_rsdl')
         return res
 
-    def finish_solve(self):
-        self.dev.sync()
-
     def residual_norms(self):
         """Consensus residuals and normalisations (admm.py:1673-1707)."""
         s = self._sums
@@ -210,24 +245,6 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
         sn = rho * np.sqrt(s[_lib.OUT_U2])
         return nr, ns, rn, sn
 
-    def rescale_u(self, rsf):
-        self._u_scale = self._u_scale / float(rsf)
-
-    # -- objective ----------------------------------------------------------------------------
-    def eval_objfn(self):
-        return (self.obfn_dfd(), self.obfn_cns())
-
-    def obfn_dfd(self):
-        """(1/2) ||sum_m Zf Yf - Sf||^2 (ccmod.py:871-878 with fEvalX False)."""
-        return self._sums[_lib.OUT_DFID] / 2.0
-
-    def obfn_cns(self):
-        """||Pcn(Y) - Y||_2 (ccmod.py:882-889)."""
-        return np.sqrt(self._sums[_lib.OUT_CNSTR])
-
-    def itstat_extra(self):
-        return (self.xrrs,)
-
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Df) (ccmod.py:897-907); host arithmetic, off the iteration path."""
         Df = self.dev.download(_lib.VAR_DXF) if D is None else \
@@ -236,21 +253,14 @@ class ConvCnstrMOD_Consensus(admm.ADMM):
         return np.fft.irfftn(np.sum(Zf * Df, axis=self.cri.axisM), self.cri.Nv,
                              axes=(0, 1)).astype(self.dtype)
 
-    def profile(self, enable=True):
-        self.dev.profile(enable)
 
-    def profile_read(self):
-        return self.dev.profile_read()
-
-
-class ConvCnstrMODBase(ConvCnstrMOD_Consensus):
+class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
     r"""Shared part of the single-copy ADMM dictionary updates (ConvCnstrMODBase,
     sporco/admm/ccmod.py:103-429, on ADMMEqual): X, Y and U are all one zero-padded dictionary
     (H, W, 1, 1, M); one iteration is one call of ``sporco_amd_csc_dstep_iter``.
 
-    Derived from the consensus class for the parts that do not depend on the splitting (device
-    handle, coefficient maps, dictionary read-back, objective terms); state, iteration and
-    residuals are those of ADMMEqual (admm.py:808-983).
+    State, iteration and residuals are those of ADMMEqual (admm.py:808-983); the parts that do
+    not depend on the splitting come from :class:`_DeviceDStep`.
     """
 
     class Options(admm.ADMM.Options):
@@ -291,26 +301,13 @@ class ConvCnstrMODBase(ConvCnstrMOD_Consensus):
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
-        H, W = self.cri.Nv
         self.Nb = self.cri.C * self.cri.K
         if self._method == _lib.DSTEP_ISM and self.Nb > 8:
             raise NotImplementedError(
                 "the iterated Sherman-Morrison D-step handles up to 8 images (times channels) on "
                 "the device, %d given; use 'cns' or 'cg' (the reference's own advice for larger "
                 "training sets)" % self.Nb)
-        self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
-        self._shared = dev is not None
-        if dev is None:
-            self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                   device=device, stream=stream)
-            self.dev.set_signal(self.S)
-        else:
-            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
-                raise ValueError("shared device solver has different dimensions")
-            self.dev = dev
-        self._cache = {}
-        self._u_scale = 1.0
-        self._sums = [0.0] * _lib.OUT_COUNT
+        self._attach_device(S, dev, device, stream)
         Nx = int(np.prod(self.cri.shpD))
         admm.ADMM.__init__(self, Nx, self.cri.shpD, self.cri.shpD, S.dtype, opt)
         # (as for the consensus class, the `dval=cri.K` of ccmod.py:264 never takes effect)
