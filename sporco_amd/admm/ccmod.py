@@ -21,7 +21,6 @@ import numpy as np
 from . import admm
 from .. import _lib
 from .. import cnvrep as cr
-from ..fft import real_dtype
 
 __all__ = ['ConvCnstrMOD_Consensus', 'ConvCnstrMOD_IterSM', 'ConvCnstrMOD_CG', 'ConvCnstrMOD',
            'ConvCnstrMODOptions']
