@@ -11,7 +11,6 @@ Both steps share one device handle, as in :mod:`sporco_amd.dictlrn.cbpdndl`.
 
 import copy
 
-
 from . import cbpdndl
 from . import common as dc
 from . import dictlrn
