@@ -542,6 +542,16 @@ def gen_shard():
     D1 = b.solve()
     save('cbpdndl_shard_f64', D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(),
          **itstat_dict(b))
+    # ... and masked learning, with the mask-decoupling and the FISTA X-step
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    Wd = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    for xm in ('admm', 'pgm'):
+        opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                                   xmethod=xm, dmethod='pgm')
+        b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, Wd, opt, xmethod=xm, dmethod='pgm')
+        D1 = b.solve()
+        save('cbpdndlmd_shard_%s_f64' % xm, D0=D0, S=S, W=Wd, lmbda=np.float64(0.1), D1=D1,
+             X=b.getcoef(), **itstat_dict(b))
 
 
 def gen_maskdcpl():

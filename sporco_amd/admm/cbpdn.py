@@ -699,8 +699,6 @@ class ConvBPDNMaskDcpl(ConvBPDN):
             raise NotImplementedError("ConvBPDNMaskDcpl on the device starts from zero")
         if opt['ReturnVar'] not in ('X', 'Y0', 'Y1'):
             raise ValueError(str(opt['ReturnVar']) + ' is not a valid value for option ReturnVar')
-        if backend.get('reducer') is not None:
-            raise NotImplementedError("image sharding is offered for ConvBPDN / ConvBPDNJoint")
         super(ConvBPDNMaskDcpl, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
         rdt = real_dtype(self.dtype).type
         # ADMM base values, not ConvBPDN's lambda-dependent ones (admm.py:245-253)
@@ -709,6 +707,9 @@ class ConvBPDNMaskDcpl(ConvBPDN):
         # problem sizes of the two-block constraint (cbpdn.py:1568-1574)
         self.Nx = self.cri.M * self.cri.N * self.cri.K
         self.Nc = int(np.prod(self.cri.shpX)) + int(np.prod(self.cri.shpS))
+        if self._reducer is not None:       # image shards: the global problem's sizes
+            self.Nx *= self._reducer.world_size
+            self.Nc *= self._reducer.world_size
         if W is None:
             W = np.array([1.0], dtype=self.dtype)
         W = np.asarray(W)
@@ -716,7 +717,10 @@ class ConvBPDNMaskDcpl(ConvBPDN):
         self.W = np.asarray(W.reshape(shp), dtype=self.dtype)
         self._upload_weights()
         self._dev.mdcpl_init(self.S)
-        self._nrm_c = float(np.linalg.norm(self.S))
+        s2 = float(np.linalg.norm(self.S)) ** 2
+        if self._reducer is not None:
+            s2 = self._reducer.sum([s2])[0]
+        self._nrm_c = float(np.sqrt(s2))
 
     def _upload_weights(self):
         super(ConvBPDNMaskDcpl, self)._upload_weights()
@@ -787,6 +791,8 @@ class ConvBPDNMaskDcpl(ConvBPDN):
             flags |= _lib.FLAG_XRRS
         p.flags = flags
         self._sums = self._dev.mdcpl_iter(p)
+        if self._reducer is not None:
+            self._sums = self._reducer.sum(self._sums)
         self._u_scale = 1.0
         self._touch(_lib.VAR_X, _lib.VAR_Y, _lib.VAR_U, _lib.VAR_XF)
         self._set_xrrs()

@@ -76,9 +76,11 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
             self.update({} if opt is None else opt)
 
     def __init__(self, D0, S, lmbda, W, opt=None, xmethod=None, dmethod=None, dimK=1, dimN=2,
-                 device=0, stream=None):
+                 device=0, stream=None, reducer=None):
         """``W``: mask compatible with the *internal* layout of ``S`` (cbpdndlmd.py:383-395),
-        e.g. (H, W, 1, K) for K greyscale images."""
+        e.g. (H, W, 1, K) for K greyscale images.  ``reducer``: as for
+        :class:`sporco_amd.dictlrn.cbpdndl.ConvBPDNDictLearn` (``S`` and ``W`` hold this rank's
+        images; ``dmethod='pgm'``)."""
         if opt is None:
             opt = ConvBPDNMaskDictLearn.Options(xmethod=xmethod, dmethod=dmethod)
         if xmethod is None:
@@ -89,6 +91,10 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
             raise ValueError('Parameters xmethod and dmethod must have the same values used '
                              'to initialise the Options object')
         xcls, dcls = _x_class(xmethod), _d_class(dmethod)
+        if reducer is not None and dmethod != 'pgm':
+            raise NotImplementedError("image sharding is offered for dmethod='pgm'")
+        self._reducer = reducer
+        bk = {} if reducer is None else {'reducer': reducer}
         self.opt, self.xmethod, self.dmethod = opt, xmethod, dmethod
         dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
         cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)
@@ -97,9 +103,10 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
         optname = 'X0' if dmethod == 'pgm' else 'Y0'
         opt['CCMOD'].update({optname: cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
         xstep = xcls(D0, S, lmbda, W, opt['CBPDN'], dimK=dimK, dimN=dimN, device=device,
-                     stream=stream)
+                     stream=stream, **bk)
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
-        dstep = dcls(None, S, W, dsz, opt['CCMOD'], dimK=dimK, dimN=dimN, dev=xdev)
+        xdev = getattr(xdev, '_raw', xdev)
+        dstep = dcls(None, S, W, dsz, opt['CCMOD'], dimK=dimK, dimN=dimN, dev=xdev, **bk)
         xstep._return_min = False
         dstep._return_min = False
         isc = dictlrn.IterStatsConfig(
@@ -116,4 +123,6 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
         dev = self.dstep.dev
         dfd = dev.masked_grad(_lib.VAR_DXF, True, False)[_lib.PGM_DFID] / 2.0
         rl1 = dev.asum(self._coef_var())
+        if self._reducer is not None:
+            dfd, rl1 = self._reducer.sum([dfd, rl1])
         return dict(DFid=dfd, RegL1=rl1, ObjFun=dfd + self.xstep.lmbda * rl1)

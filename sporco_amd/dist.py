@@ -117,7 +117,7 @@ class ReducingSolver(object):
     everything else goes straight to the device handle (``_raw``).  Used by the FISTA sparse
     coding step, whose host logic asks the device for such sums in many places."""
 
-    _SUMS = ('pgm_iter', 'pgm_grad', 'pgm_eval', 'pgm_prox_step', 'pair_stats')
+    _SUMS = ('pgm_iter', 'pgm_grad', 'pgm_eval', 'pgm_prox_step', 'pair_stats', 'masked_grad')
 
     def __init__(self, raw, reducer):
         self.__dict__['_raw'] = raw

@@ -272,8 +272,6 @@ class ConvBPDNMask(ConvBPDN):
     the unmasked solver.  Single-channel dictionaries."""
 
     def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
-        if backend.get('reducer') is not None:
-            raise NotImplementedError("image sharding is offered for the unmasked solver")
         super(ConvBPDNMask, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
         if self.cri.Cd > 1:
             raise NotImplementedError("ConvBPDNMask with a multi-channel dictionary is not "

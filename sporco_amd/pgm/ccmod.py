@@ -225,9 +225,6 @@ class ConvCnstrMODMask(ConvCnstrMOD):
                 W = np.broadcast_to(W, shp)
             W = W.reshape(W.shape[0:dimN] + (1, W.shape[cri.axisC] * W.shape[cri.axisK], 1))
         self.W = W
-        if backend.get('reducer') is not None:
-            raise NotImplementedError("image sharding is offered for the unmasked dictionary "
-                                      "update")
         super(ConvCnstrMODMask, self).__init__(Z, S, dsz, opt, dimK=dimK, dimN=dimN, **backend)
         self.W = np.asarray(self.W, dtype=self.dtype)
         H, Wd = self.cri.Nv
@@ -247,14 +244,20 @@ class ConvCnstrMODMask(ConvCnstrMOD):
         if V is None:
             V = _lib.VAR_DYF
         self.dev.masked_grad(V, True, True)
+        if self._reducer is not None:
+            self._reducer.all_reduce_array(self.dev, _lib.VAR_DGF)
         self._fcache.pop(V, None)
         self.invalidate(_lib.VAR_DGF)
         return _lib.VAR_DGF
 
+    def _masked_eval(self, var):
+        out = self.dev.masked_grad(var, True, False)
+        return out if self._reducer is None else self._reducer.sum(out)
+
     def obfn_dfd(self):
         """(1/2) ||W irfftn(sum_m Zf Xf - Sf)||^2 (pgm/ccmod.py:579-587)."""
-        return self.dev.masked_grad(_lib.VAR_DXF, True, False)[_lib.PGM_DFID] / 2.0
+        return self._masked_eval(_lib.VAR_DXF)[_lib.PGM_DFID] / 2.0
 
     def obfn_f(self, Xf=None):
         """(1/2) ||rfftn(W irfftn(sum_m Zf Xf - Sf))||^2 (pgm/ccmod.py:591-604)."""
-        return self.dev.masked_grad(_lib.VAR_DXF if Xf is None else Xf, True, False)[_lib.PGM_F]
+        return self._masked_eval(_lib.VAR_DXF if Xf is None else Xf)[_lib.PGM_F]

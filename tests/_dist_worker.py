@@ -74,6 +74,32 @@ def main():
         outs.append((d.solve(), np.asarray(d.getitstat().ObjFun, dtype=float)))
     np.savez(out_path + '.dlpgm.%d.npz' % rank, D1=outs[0][0], D1_single=outs[1][0],
              ObjFun=outs[0][1], ObjFun_single=outs[1][1])
+    # mask decoupling: the X-step alone (one image and its mask per rank), then masked dictionary
+    # learning with either X-step and the masked PGM D-step
+    g = load_golden('maskdcpl_f64')
+    b = cbpdn.ConvBPDNMaskDcpl(g['D'], shard_images(g['S'], rank, world),
+                               float(g['lmbda']), shard_images(g['W'], rank, world),
+                               cbpdn.ConvBPDNMaskDcpl.Options({'MaxMainIter': 30}),
+                               reducer=TorchReducer())
+    Y1 = b.solve()
+    its = b.getitstat()
+    np.savez(out_path + '.mdcpl.%d.npz' % rank, Y1=Y1, k=b.k,
+             **{f: np.asarray(getattr(its, f), dtype=float)
+                for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual')})
+    from sporco_amd.dictlrn import cbpdndlmd
+    for xm in ('admm', 'pgm'):
+        g = load_golden('cbpdndlmd_shard_%s_f64' % xm)
+        opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                                      xmethod=xm, dmethod='pgm')
+        d = cbpdndlmd.ConvBPDNMaskDictLearn(
+            g['D0'], shard_images(g['S'], rank, world), float(g['lmbda']),
+            shard_images(g['W'], rank, world), opt, xmethod=xm, dmethod='pgm',
+            reducer=TorchReducer())
+        D1 = d.solve()
+        its = d.getitstat()
+        np.savez(out_path + '.dlmd_%s.%d.npz' % (xm, rank), D1=D1, X=d.getcoef(),
+                 **{f: np.asarray(getattr(its, f), dtype=float)
+                    for f in ('ObjFun', 'DFid', 'RegL1')})
     dist.destroy_process_group()
 
 

@@ -57,3 +57,19 @@ def test_two_rank_image_sharding(tmp_path):
         p = np.load(out + '.dlpgm.%d.npz' % r)
         assert rel_l2(p['D1'], p['D1_single']) < 1e-9
         assert rel_l2(p['ObjFun'], p['ObjFun_single']) < 1e-9
+    # mask decoupling, sharded
+    g = load_golden('maskdcpl_f64')
+    parts = [np.load(out + '.mdcpl.%d.npz' % r) for r in range(2)]
+    assert rel_l2(np.concatenate([p['Y1'] for p in parts], axis=3), g['Y1']) < 1e-9
+    for p in parts:
+        assert int(p['k']) == int(g['k_final'])
+        for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual'):
+            assert rel_l2(p[f], g['it_' + f]) < 1e-9, f
+    for xm in ('admm', 'pgm'):
+        g = load_golden('cbpdndlmd_shard_%s_f64' % xm)
+        parts = [np.load(out + '.dlmd_%s.%d.npz' % (xm, r)) for r in range(2)]
+        assert rel_l2(np.concatenate([p['X'] for p in parts], axis=3), g['X']) < 1e-9
+        for p in parts:
+            assert rel_l2(p['D1'].squeeze(), g['D1'].squeeze()) < 1e-9
+            for f in ('ObjFun', 'DFid', 'RegL1'):
+                assert rel_l2(p[f], g['it_' + f]) < 1e-9, (xm, f)
