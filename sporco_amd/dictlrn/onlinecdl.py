@@ -156,10 +156,20 @@ class OnlineConvBPDNDictLearn(common.IterativeSolver):
         """Coefficient maps of the last ``solve`` call."""
         return self._xstep.getcoef()
 
-    def manage_itstat(self):
-        itst = self.iteration_stats()
-        self.itstat.append(itst)
-        self.display_status(self.fmtstr, itst)
+    # -- statistics and status table ------------------------------------------------------------
+    # (display column, IterationStats field) pairs of the Verbose table (onlinecdl.py:362-378)
+    _COLUMNS = (('Itn', 'Iter'), ('X r', 'PrimalRsdl'), ('X s', 'DualRsdl'), (u'X ρ', 'Rho'),
+                ('D cnstr', 'Cnstr'), ('D dlt', 'DeltaD'), (u'D η', 'Eta'))
+    # fields copied from the last row of the X-step's statistics (zero when it kept none)
+    _FROM_XSTEP = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho')
+
+    @classmethod
+    def hdrtxt(cls):
+        return tuple(col for col, _ in cls._COLUMNS)
+
+    @classmethod
+    def hdrval(cls):
+        return dict(cls._COLUMNS)
 
     def getdict(self):
         return self.D
@@ -167,52 +177,44 @@ class OnlineConvBPDNDictLearn(common.IterativeSolver):
     def itstat_extra(self):
         return ()
 
-    @classmethod
-    def hdrtxt(cls):
-        return ('Itn', 'X r', 'X s', u'X ρ', 'D cnstr', 'D dlt', u'D η')
-
-    @classmethod
-    def hdrval(cls):
-        return {'Itn': 'Iter', 'X r': 'PrimalRsdl', 'X s': 'DualRsdl', u'X ρ': 'Rho',
-                'D cnstr': 'Cnstr', 'D dlt': 'DeltaD', u'D η': 'Eta'}
-
     def iteration_stats(self):
-        """onlinecdl.py:382-402."""
-        tk = self.timer.elapsed(self.opt['IterTimer'])
-        xi = self.xstep_itstat
-        if xi is None:
-            objfn, rsdl, rho = (0.0,) * 3, (0.0,) * 2, (0.0,)
-        else:
-            objfn = (xi.ObjFun, xi.DFid, xi.RegL1)
-            rsdl = (xi.PrimalRsdl, xi.DualRsdl)
-            rho = (xi.Rho,)
-        dltd = np.linalg.norm(self.D - self.Dprv)
-        tpl = (self.j,) + objfn + rsdl + rho + (self._cnstr, dltd, self.eta) + \
-            self.itstat_extra() + (tk,)
-        return type(self).IterationStats(*tpl)
+        """One IterationStats row (onlinecdl.py:382-402): the X-step's last objective /
+        residual values, the dictionary step's constraint distance, change and step size."""
+        row = {f: 0.0 if self.xstep_itstat is None else getattr(self.xstep_itstat, f)
+               for f in self._FROM_XSTEP}
+        row.update(Iter=self.j, Cnstr=self._cnstr, DeltaD=np.linalg.norm(self.D - self.Dprv),
+                   Eta=self.eta, Time=self.timer.elapsed(self.opt['IterTimer']))
+        cls = type(self).IterationStats
+        extra = dict(zip(type(self).itstat_fields_extra, self.itstat_extra()))
+        return cls(**dict(row, **extra))
+
+    def manage_itstat(self):
+        itst = self.iteration_stats()
+        self.itstat.append(itst)
+        self.display_status(self.fmtstr, itst)
 
     def getitstat(self):
         return util.transpose_ntpl_list(self.itstat)
 
+    def _verbose(self, header=False):
+        return self.opt['Verbose'] and (self.opt['StatusHeader'] or not header)
+
     def display_config(self):
-        if self.opt['Verbose']:
+        self.hdrstr, self.fmtstr, self.nsep = '', '', 0
+        if self._verbose():
             self.hdrstr, self.fmtstr, self.nsep = common.solve_status_str(
-                type(self).hdrtxt(), fwdth0=type(self).fwiter, fprec=type(self).fpothr)
-        else:
-            self.hdrstr, self.fmtstr, self.nsep = '', '', 0
+                self.hdrtxt(), fwdth0=self.fwiter, fprec=self.fpothr)
 
     def display_start(self):
-        if self.opt['Verbose'] and self.opt['StatusHeader']:
-            print(self.hdrstr)
-            print("-" * self.nsep)
+        if self._verbose(header=True):
+            print(self.hdrstr + "\n" + "-" * self.nsep)
 
     def display_status(self, fmtstr, itst):
-        if self.opt['Verbose']:
-            hdrval = type(self).hdrval()
-            print(fmtstr % tuple(getattr(itst, hdrval[col]) for col in type(self).hdrtxt()))
+        if self._verbose():
+            print(fmtstr % tuple(getattr(itst, field) for _, field in self._COLUMNS))
 
     def display_end(self):
-        if self.opt['Verbose'] and self.opt['StatusHeader']:
+        if self._verbose(header=True):
             print("-" * self.nsep)
 
 
