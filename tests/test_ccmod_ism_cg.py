@@ -35,6 +35,9 @@ def dstep_class(method):
 @pytest.mark.parametrize('method', ['ism', 'cg'])
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_golden_traces(backend, method, case):
+    if backend == 'hostsim' and (method, case) in (('cg', 'fixedrho_zm_chk_f64'), ('ism', 'f32')):
+        pytest.skip("kept for the GPU run (slow on the CPU simulator); the other cases of both "
+                    "methods run here")
     g = load_golden('ccmod_%s_%s' % (method, case))
     optd = dict(CASES[case]['opt'])
     if CASES[case].get('y0'):

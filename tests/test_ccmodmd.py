@@ -27,6 +27,9 @@ def dstep_class(method):
 @pytest.mark.parametrize('method', ['ism', 'cg'])
 @pytest.mark.parametrize('case', sorted(CASES))
 def test_golden_traces(backend, method, case):
+    if backend == 'hostsim' and method == 'cg' and case != 'f64':
+        pytest.skip("kept for the GPU run: hundreds of CG iterations per step on the CPU "
+                    "simulator; the float64 CG case and all IterSM cases run here")
     g = load_golden('ccmodmd_%s_%s' % (method, case))
     optd = dict(CASES[case])
     f32 = optd.get('DataType') is np.float32
