@@ -126,12 +126,21 @@ class OnlineConvBPDNDictLearn(common.IterativeSolver):
         """ConvBPDN for the new data with the current dictionary (onlinecdl.py:267-287); the
         solver object (and with it the device handle holding the coefficient maps) is kept
         for the dictionary step."""
+        self._release_xstep()
         x = cbpdn.ConvBPDN(self.D.squeeze(), S, lmbda, self.opt['CBPDN'], dimK=dimK,
                            dimN=self.cri.dimN, device=self._device, stream=self._stream)
         x._return_min = False          # the coefficient maps stay on the device
         x.solve()
         self._xstep = x
         self.xstep_itstat = x.itstat[-1] if x.itstat else None
+
+    def _release_xstep(self):
+        """Free the previous call's device arrays before the next X-step allocates its own
+        (a handle holds a few times the coefficient arrays)."""
+        old = getattr(self, '_xstep', None)
+        if old is not None:
+            old._dev.close()
+            self._xstep = None
 
     def dstep(self):
         """One projected SGD step (onlinecdl.py:310-333): gradient of the data fidelity term at
@@ -258,6 +267,7 @@ class OnlineConvBPDNMaskDictLearn(OnlineConvBPDNDictLearn):
 
     def xstep(self, S, W, lmbda, dimK):
         """ConvBPDNMaskDcpl for the new data with the current dictionary (:549-570)."""
+        self._release_xstep()
         x = cbpdn.ConvBPDNMaskDcpl(self.D.squeeze(), S, lmbda, np.asarray(W), self.opt['CBPDN'],
                                    dimK=dimK, dimN=self.cri.dimN, device=self._device,
                                    stream=self._stream)
