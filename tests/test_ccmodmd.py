@@ -96,3 +96,25 @@ def test_masked_dictionary_learning(backend, method):
         assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < tol, f
     with pytest.raises(NotImplementedError):
         cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+def test_odd_filter_count_against_oracle(backend, method):
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(3)
+    H, K, N = 32, 5, 2
+    S = rng.randn(H, H, N)
+    W = (rng.rand(H, H, 1, N) > 0.3).astype(float)
+    Z = rng.randn(H, H, 1, N, K) * (rng.rand(H, H, 1, N, K) > 0.8)
+    cls = dstep_class(method)
+    optd, kw = {'MaxMainIter': 5}, {}
+    if method == 'cg':
+        optd['CG'] = {'MaxIter': 300, 'StopTol': 1e-10}
+        kw = dict(cg_tol=1e-10, cg_maxiter=300)
+    d = cls(Z, S, W, (6, 6, K), cls.Options(optd))
+    d.solve()
+    r = orc.admm_ccmod_maskdcpl(Z, S.reshape(H, H, 1, N, 1), W.reshape(H, H, 1, N, 1), (6, 6, K),
+                                method=method, maxiter=5, **kw)
+    assert rel_l2(d.var_y1(), r['Y1']) < 1e-8
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
+        assert rel_l2(getattr(d.getitstat(), f), r[f]) < 1e-8, f

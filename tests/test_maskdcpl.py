@@ -94,3 +94,23 @@ def test_masked_dictionary_learning_admm_xstep(backend):
     for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'D_L', 'D_Rsdl'):
         assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
     assert max(its.Cnstr) < 1e-10
+
+
+def test_odd_filter_count_against_oracle(backend):
+    """Five filters, NoBndryCross, AutoRho: the X-step against the float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(3)
+    H, K, N = 32, 5, 2
+    D, S = rng.randn(6, 6, K), rng.randn(H, H, N)
+    W = (rng.rand(H, H, N) > 0.3).astype(float)
+    cls = cbpdn.ConvBPDNMaskDcpl
+    b = cls(D, S, 0.1, W, cls.Options({'MaxMainIter': 8, 'NoBndryCross': True,
+                                      'AutoRho': {'Enabled': True, 'Period': 2}}))
+    Y1 = b.solve()
+    r = orc.admm_cbpdn_maskdcpl(D.reshape(6, 6, 1, 1, K), S.reshape(H, H, 1, N, 1), 0.1,
+                                W.reshape(H, H, 1, N, 1), maxiter=8, nobndry=True, auto_rho=True,
+                                rho_period=2)
+    assert rel_l2(Y1, r['Y1']) < 1e-9 and rel_l2(b.var_y0(), r['Y0']) < 1e-9
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(b.getitstat(), f), r[f]) < 1e-9, f
