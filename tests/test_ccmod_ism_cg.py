@@ -164,3 +164,20 @@ def test_against_oracle_f32(backend, method, H, K, N):
     for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Cnstr'):
         assert rel_l2(getattr(its, f), ref[f]) < bar, f
     assert max(its.XSlvRelRes) < bar
+
+
+def test_multichannel_signal_against_oracle(backend):
+    """A two-channel signal with a single-channel dictionary: six rank-one terms for IterSM."""
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(5)
+    H, M, C, K = 16, 4, 2, 3
+    S = rng.randn(H, H, C, K)
+    Z = rng.randn(H, H, C, K, M) * (rng.rand(H, H, C, K, M) > 0.7)
+    cls = dstep_class('ism')
+    d = cls(Z, S, (5, 5, M), cls.Options({'MaxMainIter': 6}))
+    d.solve()
+    r = orc.admm_ccmod_eq(Z.reshape(H, H, 1, C * K, M), S.reshape(H, H, 1, C * K, 1), (5, 5, M),
+                          method='ism', maxiter=6)
+    assert rel_l2(d.Y, r['Y']) < 1e-9
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(d.getitstat(), f), r[f]) < 1e-9, f

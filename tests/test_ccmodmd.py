@@ -118,3 +118,24 @@ def test_odd_filter_count_against_oracle(backend, method):
     assert rel_l2(d.var_y1(), r['Y1']) < 1e-8
     for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
         assert rel_l2(getattr(d.getitstat(), f), r[f]) < 1e-8, f
+
+
+@pytest.mark.parametrize('bcast', [False, True])
+def test_multichannel_signal_against_oracle(backend, bcast):
+    """A two-channel signal with a single-channel dictionary: channels fold into the image axis
+    (ccmodmd.py:243-259, :272-276), with a full mask and with one broadcast over the channels."""
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(5)
+    H, M, C, K = 16, 4, 2, 3
+    S = rng.randn(H, H, C, K)
+    W = (rng.rand(H, H, 1 if bcast else C, K) > 0.3).astype(float)
+    Z = rng.randn(H, H, C, K, M) * (rng.rand(H, H, C, K, M) > 0.7)
+    cls = dstep_class('ism')
+    d = cls(Z, S, W, (5, 5, M), cls.Options({'MaxMainIter': 6}))
+    d.solve()
+    Wf = np.ascontiguousarray(np.broadcast_to(W, (H, H, C, K)))
+    r = orc.admm_ccmod_maskdcpl(Z.reshape(H, H, 1, C * K, M), S.reshape(H, H, 1, C * K, 1),
+                                Wf.reshape(H, H, 1, C * K, 1), (5, 5, M), method='ism', maxiter=6)
+    assert rel_l2(d.var_y1(), r['Y1']) < 1e-9
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
+        assert rel_l2(getattr(d.getitstat(), f), r[f]) < 1e-9, f
