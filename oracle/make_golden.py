@@ -650,6 +650,16 @@ def gen_ccmodmd():
         D1 = b.solve()
         save('cbpdndlmd_admm_%s_f64' % meth, D0=D0, S=S, W=W, lmbda=np.float64(0.1), D1=D1,
              X=b.getcoef(), **itstat_dict(b))
+    # two-channel signal, single-channel dictionary: channels fold into the image axis in the
+    # D-step and stay an axis of their own in the X-step
+    Sc = np.random.randn(N, N, 2, 2)
+    Wc = (np.random.rand(N, N, 2, 2) > 0.3).astype(np.float64)
+    opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 6, 'AccurateDFid': True},
+                                               xmethod='admm', dmethod='ism')
+    b = ref_md.ConvBPDNMaskDictLearn(D0, Sc, 0.1, Wc, opt, xmethod='admm', dmethod='ism')
+    D1 = b.solve()
+    save('cbpdndlmd_chan_admm_ism_f64', D0=D0, S=Sc, W=Wc, lmbda=np.float64(0.1), D1=D1,
+         X=b.getcoef(), **itstat_dict(b))
 
 
 def gen_signal():

@@ -139,3 +139,18 @@ def test_multichannel_signal_against_oracle(backend, bcast):
     assert rel_l2(d.var_y1(), r['Y1']) < 1e-9
     for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
         assert rel_l2(getattr(d.getitstat(), f), r[f]) < 1e-9, f
+
+
+def test_masked_dictionary_learning_multichannel_signal(backend):
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_chan_admm_ism_f64')
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 6, 'AccurateDFid': True},
+                                                  xmethod='admm', dmethod='ism')
+    d = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod='admm', dmethod='ism')
+    D1 = d.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(d.getcoef(), g['X']) < 1e-9
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'DPrRsdl', 'DDlRsdl'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
