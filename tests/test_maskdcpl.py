@@ -114,3 +114,24 @@ def test_odd_filter_count_against_oracle(backend):
     assert rel_l2(Y1, r['Y1']) < 1e-9 and rel_l2(b.var_y0(), r['Y0']) < 1e-9
     for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(getattr(b.getitstat(), f), r[f]) < 1e-9, f
+
+
+def test_image_size_float32_against_oracle(backend):
+    """256 x 256 float32 -- a shape whose handle also carries the register-resident ConvBPDN
+    kernels; mask decoupling runs the generic chain on it -- against the float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(11)
+    H, K = 256, 4
+    D = rng.randn(8, 8, K).astype(np.float32)
+    S = rng.randn(H, H, 1).astype(np.float32)
+    W = (rng.rand(H, H, 1) > 0.3).astype(np.float32)
+    cls = cbpdn.ConvBPDNMaskDcpl
+    b = cls(D, S, 0.1, W, cls.Options({'MaxMainIter': 3}))
+    Y1 = b.solve()
+    r = orc.admm_cbpdn_maskdcpl(D.reshape(8, 8, 1, 1, K).astype(np.float64),
+                                S.reshape(H, H, 1, 1, 1).astype(np.float64), 0.1,
+                                W.reshape(H, H, 1, 1, 1).astype(np.float64), maxiter=3)
+    assert rel_l2(Y1, r['Y1']) < 1e-5
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl'):
+        assert rel_l2(getattr(b.getitstat(), f), r[f]) < 1e-5, f

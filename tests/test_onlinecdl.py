@@ -55,6 +55,27 @@ def test_masked_golden_traces(backend):
         assert rel_l2(np.asarray(getattr(its, f), dtype=float), g['it_' + f]) < 1e-9, f
 
 
+def test_masked_step_at_image_size_float32(backend):
+    """One masked online step at 256 x 256 in float32 (X-step on the generic chain, coefficient
+    spectra through the tile-major transform and back for the masked gradient) against the
+    float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.dictlrn import onlinecdl
+    rng = np.random.RandomState(11)
+    H, K = 256, 4
+    D0 = rng.randn(8, 8, K)
+    S = rng.randn(H, H).astype(np.float32)
+    W = (rng.rand(H, H) > 0.3).astype(np.float32)
+    cls = onlinecdl.OnlineConvBPDNMaskDictLearn
+    o = cls(D0, 0.1, cls.Options({'DataType': np.float32, 'CBPDN': {'MaxMainIter': 3}}), dimK=0)
+    D1 = o.solve(S, W)
+    sh = (H, H, 1, 1, 1)
+    ref = orc.online_cdl(D0, [S.reshape(sh).astype(np.float64)], 0.1, xstep_iter=3,
+                         masks=[W.reshape(sh).astype(np.float64)])
+    assert rel_l2(D1, ref['Ds'][0]) < 1e-5
+    assert rel_l2(o.getitstat().Cnstr, ref['Cnstr']) < 1e-5
+
+
 def test_surface(backend):
     from sporco_amd.dictlrn import onlinecdl
     cls = onlinecdl.OnlineConvBPDNDictLearn
