@@ -2,6 +2,7 @@
 """bench.py -- ConvBPDN ADMM iterations/s on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 ...      (starts its own ranks through torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -45,6 +46,26 @@ def make_problem(H, W, K, N, rank, dtype=np.float32):
     return D, S
 
 
+def make_structured_problem(H, W, K, N, rank, dtype=np.float32, density=0.0027):
+    """Sparse-synthesis input for the time-to-tolerance measurement (the recipe of the
+    reference's known-answer test, tests/admm/test_cbpdn.py:160-165, at image size):
+    S_n = sum_k d_k * x0_{n,k} with x0 sparse (P(|randn| > 3) = 0.27 % of the entries nonzero,
+    standard normal values), circular convolution evaluated in float64."""
+    import scipy.fft as sfft
+    rng = np.random.RandomState(54321 + rank)
+    D = rng.randn(8, 8, K)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    Df = sfft.rfft2(D, (H, W), axes=(0, 1), workers=-1)
+    S = np.empty((H, W, N), dtype=dtype)
+    for n in range(N):
+        m = rng.rand(H, W, K) < density
+        X0 = np.zeros((H, W, K))
+        X0[m] = rng.randn(int(m.sum()))
+        S[:, :, n] = sfft.irfft2(np.sum(Df * sfft.rfft2(X0, axes=(0, 1), workers=-1), axis=2),
+                                 (H, W), axes=(0, 1), workers=-1)
+    return D.astype(dtype), S
+
+
 def kernel_bytes(H, W, P, itemsize):
     """Compulsory HBM bytes (inputs + outputs once) of each kernel of one ADMM
     iteration; P = C*N*K.  See DESIGN.md section 5."""
@@ -65,24 +86,121 @@ def kernel_bytes(H, W, P, itemsize):
 
 
 def cpu_baseline(H, W, K, n_full, seconds):
-    """Time the NumPy oracle (a port of the reference's arithmetic; the
-    reference itself is not present on the GPU box) on ONE image of the same
-    workload and scale by 1/n_full (images are independent and the arrays are
-    far larger than cache)."""
+    """Time the NumPy oracle (a port of the reference's arithmetic; the reference itself is
+    Python and is not present on the GPU box) on ONE and on TWO images of the same workload
+    (to show that the cost is linear in the number of images: they are independent and the
+    arrays are far larger than cache) and scale the two-image rate by
+    2/n_full.  `reference_here` quotes the unmodified reference timed on the same sample in
+    the authoring container (tools/time_reference_cpu.py -> profiles/r02_reference_cpu.json),
+    when that file is present."""
     from oracle import cbpdn_oracle as orc
-    D, S = make_problem(H, W, K, 1, 0)
-    r = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, 1, 1), 0.05,
-                       dtype=np.float32, maxiter=1000, rel_tol=0.0, time_budget=seconds)
-    its_per_s_one = r['iters'] / r['seconds']
-    return {
-        'value': its_per_s_one / n_full,
+    rates = {}
+    for n, budget in ((1, seconds / 3.0), (2, 2.0 * seconds / 3.0)):
+        D, S = make_problem(H, W, K, n, 0)
+        r = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, n, 1), 0.05,
+                           dtype=np.float32, maxiter=1000, rel_tol=0.0, time_budget=budget)
+        rates[n] = (r['iters'], r['seconds'])
+    one = rates[1][0] / rates[1][1]
+    two = rates[2][0] / rates[2][1]
+    out = {
+        'value': two * 2.0 / n_full,
         'unit': 'iterations/s',
         'cores': 1,
         'kind': 'port',
-        'sample': ('NumPy oracle (numpy.fft, single thread), %dx%d K=%d on 1 of %d images, '
-                   '%d iterations in %.1f s, rate divided by %d'
-                   % (H, W, K, n_full, r['iters'], r['seconds'], n_full)),
+        'sample': ('NumPy oracle (numpy.fft, single thread), %dx%d K=%d: 1 image %d iterations in '
+                   '%.1f s, 2 images %d iterations in %.1f s (image-iterations/s %.3f vs %.3f: '
+                   'linear in N); value = 2-image rate x 2/%d'
+                   % (H, W, K, rates[1][0], rates[1][1], rates[2][0], rates[2][1], one, 2 * two,
+                      n_full)),
+        'why_faster_than_BASELINE_md_2': (
+            'the port forms the Sherman-Morrison solve without the X-sized conj(Df)*Sf array, '
+            'works in place and skips the reference\'s per-call dtype conversions and Yprev/AX '
+            'copies; the unmodified reference is slower per image (see reference_here)'),
     }
+    rpath = os.path.join(REPO, 'profiles', 'r02_reference_cpu.json')
+    if os.path.exists(rpath) and (H, W, K) == (512, 512, 64):
+        with open(rpath) as f:
+            out['reference_here'] = json.load(f)
+    return out
+
+
+def parity_gate(cbpdn, H, W, K, iters, device):
+    """before any timing is quoted, the kernels of this workload
+    (same H, W, K, dtype, options => same kernel instantiations; two of the images) against
+    the float64 oracle: rel-l2 of Y and of the Rho / residual traces."""
+    from oracle import cbpdn_oracle as orc
+    D, S = make_problem(H, W, K, 2, 0)
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options({'MaxMainIter': iters,
+                                                           'RelStopTol': 0.0}), device=device)
+    fused = bool(b._dev.uses_fused_rows() and b._fused_ok())
+    Y = b.solve().astype(np.float64)
+    ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, 2, 1), 0.05,
+                         dtype=np.float64, maxiter=iters, rel_tol=0.0)
+    rel = float(np.linalg.norm(Y - ref['Y']) / np.linalg.norm(ref['Y']))
+    its = b.getitstat()
+    tr = {}
+    for f in ('Rho', 'PrimalRsdl', 'DualRsdl', 'ObjFun'):
+        a, r = np.asarray(getattr(its, f), float), np.asarray(ref[f], float)
+        tr[f] = float(np.linalg.norm(a - r) / np.linalg.norm(r))
+    del b
+    return {'rel_l2_vs_oracle': rel, 'images_checked': 2, 'iters': iters,
+            'oracle': 'float64 NumPy restatement (oracle/cbpdn_oracle.py)',
+            'trace_rel_err': tr, 'three_launch_path': fused,
+            'pass': bool(rel <= 1e-4 and max(tr.values()) <= 1e-3)}
+
+
+def time_to_tol(cbpdn, H, W, K, N, device, lmbda=0.01):
+    """Wall-clock and iterations to RelStopTol = 1e-3 (default options) on the
+    sparse-synthesis input, N images; the same stop measured with the float64 generic chain of
+    this library (pinned to the reference's traces at 1e-9 by the fixtures) as the reference
+    count for this input; and the N = 2 instance whose count the unmodified reference
+    produced (tests/golden/admm_tol_config2_n2_f32.npz)."""
+    def run(D, S, dt):
+        optd = {'MaxMainIter': 1000, 'RelStopTol': 1e-3}
+        if dt is not None:
+            optd['DataType'] = dt
+
+        class Resident(cbpdn.ConvBPDN):
+            def getmin(self):
+                return None
+        b = Resident(D, S, lmbda, cbpdn.ConvBPDN.Options(optd), device=device)
+        b._dev.sync()
+        t0 = time.perf_counter()
+        b.solve()
+        b._dev.sync()
+        return b.k, time.perf_counter() - t0, bool(b._dev.uses_fused_rows() and b._fused_ok())
+
+    D, S = make_structured_problem(H, W, K, N, 0)
+    k32, t32, fused = run(D, S, None)
+    k64, t64, _ = run(D, S, np.float64)
+    out = {'input': 'sparse synthesis (bench.make_structured_problem), %dx%d K=%d N=%d, '
+                    'lambda=%g, RelStopTol=1e-3, default options' % (H, W, K, N, lmbda),
+           'iterations': k32, 'seconds': t32, 'three_launch_path': fused,
+           'iterations_float64_generic_chain': k64, 'seconds_float64_generic_chain': t64}
+    gpath = os.path.join(REPO, 'tests', 'golden', 'admm_tol_config2_n2_f32.npz')
+    if os.path.exists(gpath) and (H, W, K) == (512, 512, 64):
+        with np.load(gpath) as g:
+            kref = int(g['k_final'])
+        D2, S2 = make_structured_problem(H, W, K, 2, 0)
+        k2, t2, _ = run(D2, S2, None)
+        out['n2_case'] = {'iterations': k2, 'seconds': t2, 'reference_iterations': kref,
+                          'within_one': bool(abs(k2 - kref) <= 1)}
+    return out
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: start the N ranks ourselves."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -94,18 +212,22 @@ def main():
     ap.add_argument('--filters', type=int, default=64)
     ap.add_argument('--images', type=int, default=32, help='images per GPU')
     ap.add_argument('--fastsolve', action='store_true',
-                    help='FastSolve + AutoRho off (pure iteration cost, no stats)')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+                    help='FastSolve + AutoRho off as the headline run (pure iteration cost)')
+    ap.add_argument('--cpu-seconds', type=float, default=21.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-time-to-tol', action='store_true')
+    ap.add_argument('--parity-iters', type=int, default=6)
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch through "
-                  "torch.distributed.run for N > 1" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
 
     import sporco_amd
@@ -132,10 +254,13 @@ def main():
 
     H = W = args.size
     K, N = args.filters, args.images
+
+    # parity gate first, rank 0, on the kernels this workload runs
+    parity = None
+    if rank == 0 and not args.no_parity:
+        parity = parity_gate(cbpdn, H, W, K, args.parity_iters, local_rank)
+
     D, S = make_problem(H, W, K, N, rank)
-    optd = {'MaxMainIter': max(args.warmup, 1), 'RelStopTol': 0.0}
-    if args.fastsolve:
-        optd.update({'FastSolve': True, 'AutoRho': {'Enabled': False}})
 
     class ResidentConvBPDN(cbpdn.ConvBPDN):
         """solve() normally returns the coefficient array, i.e. ends with a
@@ -146,42 +271,52 @@ def main():
         def getmin(self):
             return None
 
-    b = ResidentConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd), device=local_rank,
-                         stream=stream, reducer=reducer)
-
-    def sync_all():
+    def sync_all(b):
         b._dev.sync()
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier()
 
-    if args.warmup > 0:
+    def timed_run(fast):
+        optd = {'MaxMainIter': max(args.warmup, 1), 'RelStopTol': 0.0}
+        if fast:
+            optd.update({'FastSolve': True, 'AutoRho': {'Enabled': False}})
+        b = ResidentConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd), device=local_rank,
+                             stream=stream, reducer=reducer)
+        if args.warmup > 0:
+            b.solve()
+        # timed region: exactly `steps` iterations, no instrumentation
+        b.opt['MaxMainIter'] = args.steps
+        sync_all(b)
+        t0 = time.perf_counter()
         b.solve()
-    # timed region: exactly `steps` iterations, no instrumentation
-    b.opt['MaxMainIter'] = args.steps
-    sync_all()
-    t0 = time.perf_counter()
-    b.solve()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+        sync_all(b)
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64,
+                             device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.cpu()[0])
+        return b, elapsed
+
+    b, elapsed = timed_run(args.fastsolve)
     # per-kernel durations: HIP events recorded by the library on its own stream
     # around every launch, over a second run of the same iterations
     prof_steps = min(args.steps, 10)
     b.opt['MaxMainIter'] = prof_steps
     b.profile(True)
     b.solve()
-    sync_all()
+    sync_all(b)
     prof = b.profile_read()
     b.profile(False)
     t1 = time.perf_counter()
     y_host = cbpdn.ConvBPDN.getmin(b)          # what solve() would hand back to the caller
     download_ms = 1e3 * (time.perf_counter() - t1)
     del y_host
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.cpu()[0])
+    del b
+    # the other option set as a secondary figure (both are reported)
+    b2, elapsed2 = timed_run(not args.fastsolve)
+    del b2
 
     if rank != 0:
         if world > 1:
@@ -197,18 +332,29 @@ def main():
     dom = max((k for k in timed if k in kb), key=lambda k: timed[k][0])
     dom_ms = timed[dom][0] / timed[dom][1]
     achieved = kb[dom] / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(REPO, 'profiles', 'hbm_traffic_bytes.json')
     if os.path.exists(tpath) and (H, W, K, N) == (512, 512, 64, 32):
         # measured for exactly this workload (rocprofv3 PMC passes, see the file)
         with open(tpath) as f:
             traffic = json.load(f).get(dom)
+        traffic_source = ('profiles/hbm_traffic_bytes.json (rocprofv3 --pmc FETCH_SIZE / '
+                          'WRITE_SIZE passes of this command; not re-measured in this run)')
     E = H * W * P
     iter_alg_bytes = 40 * E                    # 10 float32 passes
+    per_kernel = {}
+    for k, v in timed.items():
+        if k in kb:
+            ms = v[0] / v[1]
+            per_kernel[k] = {'avg_ms': round(ms, 4), 'launches': v[1],
+                             'algorithmic_GBps': round(kb[k] / (ms * 1e-3) / 1e9, 1),
+                             'frac': round(kb[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    names = {False: 'default options (AutoRho, stats every iteration)',
+             True: 'FastSolve, AutoRho off'}
     line = {
         'metric': 'ConvBPDN ADMM iterations/s',
         'value': its_per_s * world,
-        'unit': 'iterations/s (512x512, K=64, N=32 per GPU; summed over GPUs)',
+        'unit': 'iterations/s (%dx%d, K=%d, N=%d per GPU; summed over GPUs)' % (H, W, K, N),
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
@@ -220,20 +366,26 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'admm.cbpdn.ConvBPDN %dx%d greyscale, K=%d 8x8 filters, '
                                'N=%d images per GPU, lambda=0.05, %s'
-                               % (H, W, K, N, 'FastSolve, AutoRho off' if args.fastsolve else
-                                  'default options (AutoRho, stats every iteration)'),
+                               % (H, W, K, N, names[bool(args.fastsolve)]),
                    'global_images': N * world, 'parallelism': 'image-shard x%d' % world},
         'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
                      'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                     'traffic': traffic, 'avg_kernel_ms': dom_ms,
-                     'algorithmic_bytes_per_launch': kb[dom]},
+                     'traffic': traffic, 'traffic_source': traffic_source,
+                     'avg_kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': kb[dom]},
         'iteration_roofline': {'algorithmic_bytes_per_iter': iter_alg_bytes,
                                'achieved': iter_alg_bytes * its_per_s / 1e9,
                                'unit': 'GB/s',
                                'frac': iter_alg_bytes * its_per_s / 1e9 / HBM_PEAK_GBPS},
+        'other_options': {'options': names[not args.fastsolve],
+                          'value': args.steps / elapsed2 * world,
+                          'ms_per_step': 1e3 * elapsed2 / args.steps},
+        'parity': parity,
         'result_download_ms': download_ms,
         'kernels_ms_per_iter': {k: round(v[0] / prof_steps, 4) for k, v in timed.items()},
+        'kernel_roofline': per_kernel,
     }
+    if world == 1 and not args.no_time_to_tol:
+        line['time_to_tol'] = time_to_tol(cbpdn, H, W, K, N, local_rank)
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(H, W, K, N, args.cpu_seconds)
     print(json.dumps(line))

@@ -202,6 +202,68 @@ def gen_config1():
          **itstat_dict(b))
 
 
+def _strided(Y):
+    return Y[::16, ::16].copy()
+
+
+def gen_config2():
+    """BASELINE config 2 shape (512x512, K=64 8x8 filters, float32, default options) on
+    N = 2 of the bench's own images (bench.make_problem, rank 0): per-iteration traces, a
+    strided subsample of Y and its norms, from the float32 and the float64 reference run."""
+    sys.path.insert(0, REPO)
+    import bench
+    D, S = bench.make_problem(512, 512, 64, 2, 0)
+    for tag, dt, extra in (('f32', np.float32, {}), ('f64', np.float64, {'DataType': np.float64})):
+        optd = {'MaxMainIter': 10, 'RelStopTol': 0.0}
+        optd.update(extra)
+        b = ref_cbpdn.ConvBPDN(D, S, 0.05, ref_cbpdn.ConvBPDN.Options(optd))
+        b.solve()
+        Y = b.Y
+        save('admm_config2_n2_' + tag, lmbda=np.float64(0.05), Y_sub=_strided(Y),
+             Y_l2=np.float64(np.linalg.norm(Y.astype(np.float64))),
+             Y_l1=np.float64(np.abs(Y.astype(np.float64)).sum()),
+             Y_nnz=np.int64(np.count_nonzero(Y)), **itstat_dict(b))
+
+
+def gen_config5():
+    """BASELINE config 5 kernels end to end: ConvBPDNDictLearn (xmethod admm, dmethod pgm),
+    256x256, K=64 8x8 filters, N=4 images, 4 outer iterations, from the float64 reference run
+    of the float32 inputs (seeded: RandomState(515))."""
+    rng = np.random.RandomState(515)
+    D0 = rng.randn(8, 8, 64).astype(np.float32)
+    S = rng.randn(256, 256, 4).astype(np.float32)
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 4, 'AccurateDFid': True},
+                                                xmethod='admm', dmethod='pgm')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0.astype(np.float64), S.astype(np.float64), 0.1, opt,
+                                      xmethod='admm', dmethod='pgm')
+    D1 = b.solve()
+    X = b.getcoef()
+    save('cbpdndl_config5_n4_f64', lmbda=np.float64(0.1), D1=D1, X_sub=_strided(X),
+         X_l2=np.float64(np.linalg.norm(X)), **itstat_dict(b))
+
+
+def gen_tol():
+    """Time-to-tolerance known answer at the config 2 shape: the sparse-synthesis input of
+    bench.make_structured_problem (512x512, K=64, N=2), lambda 0.01, default options,
+    RelStopTol 1e-3: the iteration count at which the reference stops (a
+    backend must stop within +-1 of it), its traces and a subsample of the final Y."""
+    sys.path.insert(0, REPO)
+    import bench
+    which = os.environ.get('GOLDEN_TOL_CASES', 'f32,f64').split(',')
+    D, S = bench.make_structured_problem(512, 512, 64, 2, 0)
+    for tag, extra in (('f32', {}), ('f64', {'DataType': np.float64})):
+        if tag not in which:
+            continue
+        optd = {'MaxMainIter': 1000, 'RelStopTol': 1e-3}
+        optd.update(extra)
+        b = ref_cbpdn.ConvBPDN(D, S, 0.01, ref_cbpdn.ConvBPDN.Options(optd))
+        b.solve()
+        Y = b.Y
+        save('admm_tol_config2_n2_' + tag, lmbda=np.float64(0.01), k_final=np.int64(b.k),
+             Y_sub=_strided(Y), Y_l2=np.float64(np.linalg.norm(Y.astype(np.float64))),
+             **itstat_dict(b))
+
+
 # ---------------------------------------------------------------------------
 def pgm_case(name, D, S, lmbda, optd, tag_objs=None):
     optd = dict(optd)
@@ -746,6 +808,7 @@ if __name__ == '__main__':
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'signal', 'mask']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
+             'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

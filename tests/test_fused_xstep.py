@@ -277,9 +277,9 @@ def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
     optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
     b, Y = solve(D, S, optd, joint=C is not None)
     assert b._dev.uses_fused_rows() and not b._dev.uses_fused_pgm()
-    if H * W * K * N * (C or 1) > 2 ** 23:
-        # large case: the generic kernel chain of the same library is the reference
-        # (the float64 NumPy oracle would take a minute here)
+    if H * W * K * N * (C or 1) > 2 ** 25:
+        # (not reached by the cases above: every one of them, including ConvBPDNJoint with
+        # K = 128, C = 3 -- 25 M elements -- is checked against the float64 oracle)
         b0, Y0 = solve(D, S, optd, unfused=True, joint=C is not None)
         ref = {'Y': Y0, 'X': b0.X}
         ref.update({f: getattr(b0.getitstat(), f)
