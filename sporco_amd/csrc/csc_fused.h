@@ -55,6 +55,9 @@ template <typename T> struct FusedColsArgs {
     // term per (frequency, image), the X-step of the consensus dictionary update
     // (admm/ccmod.py:766-778) with the coefficient spectra in the role of the dictionary.
     int per_tile = 0;
+    // persistent launch: workgroup slot s starts (s % stagger_groups) * stagger_sleeps * 8128
+    // cycles late, so that the workgroups' memory and arithmetic phases interleave across CUs
+    int stagger_groups = 1, stagger_sleeps = 0;
     const T *g1t = nullptr;
     T *g1t_out = nullptr;
     const T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;

@@ -37,7 +37,7 @@ using namespace regfft;
 constexpr int kExchUnitsMax = 16384;  // f2 units of the largest exchange buffer (128 KiB)
 // LDS of one instantiation: its exchange group (LP lines of NW points for every wave) + scratch
 constexpr size_t fused_lds_bytes(int NW, int LP) {
-    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * 16;
+    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * 2 * 16;   // + block_sum scratch
 }
 
 // N1 x NW = H; NW waves; KC: compile-time filter count (64), or 0 for a run-time K <= 64.
@@ -50,7 +50,20 @@ constexpr size_t fused_lds_bytes(int NW, int LP) {
 // (FusedColsArgs::Kv): run-time row stride, all lanes valid, multipliers stored.
 // PER_TILE (with KC = 64): the D-side operands (dft, gramt) are those of the tile, not of its
 // row frequency (FusedColsArgs::per_tile).
-template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false>
+#ifdef SPORCO_AMD_HOSTSIM
+#define SA_TS(i)
+#else
+#define SA_TS(i)                                                                  \
+    if constexpr (DBG >= 3) {                                                      \
+        unsigned long long t_;                                                     \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_));            \
+        ts[i] = t_;                                                                \
+    }
+#endif
+// DBG (measurement builds only, SPORCO_AMD_COLS_DEBUG): 1 = loads and stores only, 2 = no tile
+// loads / stores (arithmetic, exchanges and operand loads only).
+template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false,
+          int DBG = 0>
 __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
     constexpr int H = N1 * NW;
     constexpr int J = N1 / NW;   // stage-2 lines per thread (each NW points)
@@ -71,52 +84,89 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).
     // All C*N tiles of one row frequency wf share the same 256 KiB slice of Df, so
     // they are given to one XCD, back to back: its L2 then serves the re-reads.
-    const int Wf = a.W / 2 + 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int wf = (slot / a.CN) * 8 + xcd;
-    if (wf >= Wf) return;
-    const int tile = wf * a.CN + slot % a.CN;
-    // buffer addressing: wave-uniform descriptors of this tile / this Df slice, one
-    // shared 32-bit lane offset and scalar row offsets, so the 3*N1 row addresses
-    // cost no vector registers (the tile itself needs 2*N1 of them)
-    const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
-    const int dsel = PER_TILE ? tile : wf;
-    const BufRsrc Db = make_rsrc(a.dft + (int64_t)dsel * H * K, (uint32_t)(H * K * sizeof(cf)));
-    const BufRsrc Cb = make_rsrc((KRT && a.coef_out) ? a.coef_out + (int64_t)tile * H : nullptr,
-                                 (KRT && a.coef_out) ? (uint32_t)(H * sizeof(cf)) : 0u);
-    const int cvoff = k == 0 ? 0 : (int)0x80000000;
-    const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
-    const cf *S = a.sft + (int64_t)tile * H + w;
-    const float *G = (GRAD ? a.g1t : a.gramt) + (int64_t)dsel * H + w;
-    const float *GH = a.ghh + w;
-    const cf *twA = a.twA + w * N1;                           // W_H^(w * brev(i)),      i < N1
-    const cf *twB = a.twB + w * N1;                           // W_H^((w + NW j) * h2), [j][h2]
-    // One buffer serves both exchanges: a unit is written and read back by the
-    // same thread on either side, so only the two hand-overs need a barrier.
+    // With 16 waves (H = 512) the kernel is persistent: the launch holds one workgroup per
+    // CU (a multiple of 8 of them, launch_fused_inst) and workgroup (xcd, s) walks the slots
+    // s, s + G/8, ... of its XCD's list, so that the stores of one tile are still draining
+    // while the loads of the next are in flight -- the only overlap of memory and arithmetic
+    // a CU that holds a single 16-wave workgroup can have.  All workgroups of an XCD are on
+    // the same row frequency at about the same time (CN >= G/8 tiles share it), which keeps
+    // the Df slice in that XCD's L2 as before.  With 8 waves (H = 256) two workgroups share a
+    // CU and overlap each other; the tile loop would cost them the registers for that, so
+    // there it runs once.
+    constexpr bool PERSIST = NW == 16 && KC == 64;   // (run-time K: scalar registers are short)
+    const int xcd = blockIdx.x & 7;
     f2 *LA = dyn_lds<f2>();
     f2 *LB = LA;
     double *scratch = reinterpret_cast<double *>(LA + FP * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
+    const int cvoff = k == 0 ? 0 : (int)0x80000000;
+    const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
     int token = 0;
+    if constexpr (PERSIST) {
+        const int ph = (int)(blockIdx.x >> 3) % a.stagger_groups;
+        for (int i = 0; i < ph * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    for (int slot = blockIdx.x >> 3;; slot += gridDim.x >> 3) {
+    // (the argument block is re-read per tile through an opaque pointer: neither its fields
+    // nor the operand tables' loads may be hoisted out of the tile loop, where they would
+    // hold scalar registers throughout)
+    SA_ARGS_PTR_T(FusedColsArgs<float>) ap = sa_args_reload<PERSIST>(a);
+    const int Wf = ap->W / 2 + 1, CN = ap->CN;
+    if (slot >= ((Wf + 7) / 8) * CN) break;
+    const int wf = (slot / CN) * 8 + xcd;
+    if (wf >= Wf) break;
+    const int tile = wf * CN + slot % CN;
+    const float rho = ap->rho;
+    const float *GH = ap->ghh + w;
+    const cf *twA = ap->twA + w * N1;                         // W_H^(w * brev(i)),      i < N1
+    const cf *twB = ap->twB + w * N1;                         // W_H^((w + NW j) * h2), [j][h2]
+    // buffer addressing: wave-uniform descriptors of this tile / this Df slice, one
+    // shared 32-bit lane offset and scalar row offsets, so the 3*N1 row addresses
+    // cost no vector registers (the tile itself needs 2*N1 of them)
+    const BufRsrc Tb = make_rsrc(ap->t + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
+    const int dsel = PER_TILE ? tile : wf;
+    const BufRsrc Db = make_rsrc(ap->dft + (int64_t)dsel * H * K, (uint32_t)(H * K * sizeof(cf)));
+    cf *const coef_out = KRT ? ap->coef_out : nullptr;
+    const BufRsrc Cb = make_rsrc(coef_out ? coef_out + (int64_t)tile * H : nullptr,
+                                 coef_out ? (uint32_t)(H * sizeof(cf)) : 0u);
+    const cf *S = ap->sft + (int64_t)tile * H + w;
+    const float *G = (GRAD ? ap->g1t : ap->gramt) + (int64_t)dsel * H + w;
+    // One buffer (LA == LB) serves both exchanges: a unit is written and read back by the
+    // same thread on either side, so only the two hand-overs need a barrier -- also from
+    // one tile to the next.
 
     // ---- load rows h = NW*h1 + w, forward FFT over h1, twiddle -----------------------
+    unsigned long long ts[16] = {0};
+    SA_TS(0)
     cf v[N1];
 #pragma unroll
     for (int h1 = 0; h1 < N1; ++h1)
-        v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
+        v[h1] = (kv && DBG != 2 && DBG != 4) ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf))
+                                 : mk<float>((float)(k + h1), (float)(w - h1));
+    if constexpr (DBG != 1) {
     dif<N1, false>(v, 0);
     reg_fence<N1>(v, 0, token);
 #pragma unroll
-    for (int i = 1; i < N1; ++i) v[i] = cmul(v[i], twA[i]);
+    for (int i = 1; i < N1; ++i) {
+        // (scalar-cache load where the scalar registers allow it: a vector load here waits
+        // out a full L2 round trip)
+        cf tw;
+        if constexpr (KC == 64 && !GRAD) sa_uload2(reinterpret_cast<const float *>(twA + i), tw.re, tw.im);
+        else tw = twA[i];
+        v[i] = cmul(v[i], tw);
+    }
     reg_fence<N1>(v, 0, token);
+    }
+    SA_TS(1)
 
-    const float rho = a.rho;
     float obj = 0.f;
+    if constexpr (DBG != 1) {
     // GRAD: dd = ak * ghh[f] + bk, with the row-frequency part folded into bk
     float ak = 0.f, bk = 0.f, gw = 0.f, rg = 0.f;
     if constexpr (GRAD) {
-        gw = sa_uload(a.ghw + wf);
-        ak = a.mu * ((a.wg && kv) ? a.wg[k] : 1.f);
+        const float *wgp = ap->wg;
+        gw = sa_uload(ap->ghw + wf);
+        ak = ap->mu * ((wgp && kv) ? wgp[k] : 1.f);
         bk = ak * gw + rho;
     }
     static_for<Q>([&](auto qc) {
@@ -150,7 +200,9 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
             }
         };
         prefetch(std::integral_constant<int, 0>{});
+        SA_TS(2 + 4 * q)
         __syncthreads();
+        SA_TS(3 + 4 * q)
         cf u[FP];   // u[NW*jl + h2] = A[h2][f1 = w + NW*(q*LP + jl)]
 #pragma unroll
         for (int jl = 0; jl < LP; ++jl) {
@@ -230,6 +282,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
             }
         });
         SA_VGPR_FENCE3(obj, rg, token);
+        SA_TS(4 + 4 * q)
         // ---- exchange B: back to (w = h2; f1 in regs), placed in DIT input order -----
 #pragma unroll
         for (int jl = 0; jl < LP; ++jl) {
@@ -242,6 +295,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
             }
         }
         __syncthreads();
+        SA_TS(5 + 4 * q)
 #pragma unroll
         for (int fl = 0; fl < FP; ++fl) {
             const f2 t = LB[(fl * NW + w) * 64 + k];
@@ -249,26 +303,46 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
         }
     });
     reg_fence<N1>(v, 0, token);
+    SA_TS(10)
 
+    // The tile's sums go out before the last transform, so that the stores below are the
+    // last thing a wave does for this tile and the next tile's loads follow them directly.
+    // (always written: a conditional here makes the compiler sink the whole |coef|^2
+    // chain into the branch and keep every coef alive until the end of the kernel)
+    const double pw = (wf == 0 || ((ap->W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    if constexpr (GRAD) {
+        const float *wgp = ap->wg;
+        const float wk = (wgp && kv) ? wgp[k] : 1.f;
+        double acc[2] = {k == 0 ? (double)obj * pw : 0.0, kv ? (double)(rg * wk) * pw : 0.0};
+        block_sum_store<2>(acc, scratch, ap->partials + 2 * tile);
+    } else {
+        double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
+        block_sum_store<1>(acc, scratch, ap->partials + tile);
+    }
+    SA_VGPR_FENCE3(v[0].re, v[0].im, token);
+
+    }   // DBG != 1
     // ---- inverse FFT over f1, store the rows this wave loaded ------------------------
-    dit<N1, true>(v, 0);
-    if (kv) {
+    if constexpr (DBG != 1) dit<N1, true>(v, 0);
+    if ((DBG == 2 || DBG == 4) ? v[3].re == 1234.5678f : kv) {
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1)
             buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
     }
-
-    // (always written: a conditional here makes the compiler sink the whole |coef|^2
-    // chain into the branch and keep every coef alive until the end of the kernel)
-    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
-    if constexpr (GRAD) {
-        const float wk = (a.wg && kv) ? a.wg[k] : 1.f;
-        double acc[2] = {k == 0 ? (double)obj * pw : 0.0, kv ? (double)(rg * wk) * pw : 0.0};
-        block_sum_store<2>(acc, scratch, a.partials + 2 * tile);
-    } else {
-        double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
-        block_sum_store<1>(acc, scratch, a.partials + tile);
+    if constexpr (DBG >= 3) {
+        SA_VGPR_FENCE3(v[0].re, v[1].im, token);
+        SA_TS(12)
+        if (blockIdx.x == 17 && slot == (int)(blockIdx.x >> 3) + 5 * (int)(gridDim.x >> 3) && k == 0 &&
+            (w == 0 || w == 15)) {
+            printf("w%d load+fft32 %llu | q0: wrA %llu bar %llu sm %llu wrB+bar %llu | q1: rdB+wrA %llu bar %llu sm %llu "
+                   "wrB+bar %llu | rdB %llu sums %llu ifft32 %llu | total %llu\n",
+                   w, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5],
+                   ts[7] - ts[6], ts[8] - ts[7], ts[9] - ts[8], ts[10] - ts[9], ts[11] - ts[10], ts[12] - ts[11],
+                   ts[12] - ts[0]);
+        }
     }
+    if constexpr (!PERSIST) break;
+    }   // persistent loop over this workgroup's tiles
 }
 
 // g1t[wf][h] = 1 + sum_k |Df|^2 / (mu wg_k (ghh[h] + ghw[wf]) + rho): the Sherman-Morrison
@@ -604,18 +678,42 @@ template <> bool fused_cols_supported<float>(int H, int K) {
 }
 template <> bool fused_cols_supported<double>(int, int) { return false; }
 
-template <int N1, int NW, int LP, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false>
+// Workgroups of a persistent launch: as many as the device holds at once (16-wave
+// workgroups: one per CU; 8-wave ones: two), a multiple of 8 so that the XCD of a workgroup
+// is blockIdx % 8 for every slot it walks.  SPORCO_AMD_COLS_PERSIST=0: one workgroup per tile.
+static int64_t persistent_grid(int NW) {
+    static int cus = 0;
+    static bool off = false;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        SA_HIP(hipGetDevice(&dev));
+        SA_HIP(hipGetDeviceProperties(&pr, dev));
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        const char *e = std::getenv("SPORCO_AMD_COLS_PERSIST");
+        off = e && e[0] == '0';
+    }
+    if (off) return INT64_MAX;
+    if (NW != 16) return INT64_MAX;      // (the 8-wave kernel takes one tile per workgroup)
+    return std::max<int64_t>(8, cus / 8 * 8);
+}
+
+template <int N1, int NW, int LP, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false,
+          int DBG = 0>
 static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
     static bool attr_set = false;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE>),
+            reinterpret_cast<const void *>(
+                &fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE, DBG>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
         attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
-    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE>),
-                       dim3((unsigned)(wf_groups * 8 * a.CN)), dim3(NW * 64),
+    const int64_t all = wf_groups * 8 * a.CN;
+    hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE, DBG>),
+                       dim3((unsigned)std::min<int64_t>(all, persistent_grid(KC == 64 ? NW : 0))),
+                       dim3(NW * 64),
                        fused_lds_bytes(NW, LP), st, a);
 }
 
@@ -630,7 +728,12 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
         if (grad) launch_fused_inst<N1, NW, LP, 64, true, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
     } else if (a.K == 64) {
+        static const int dbg = std::getenv("SPORCO_AMD_COLS_DEBUG") ? std::atoi(std::getenv("SPORCO_AMD_COLS_DEBUG")) : 0;
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
+        else if (NW == 16 && dbg == 1) launch_fused_inst<N1, NW, LP, 64, false, false, false, 1>(st, a, ntiles);
+        else if (NW == 16 && dbg == 2) launch_fused_inst<N1, NW, LP, 64, false, false, false, 2>(st, a, ntiles);
+        else if (NW == 16 && dbg == 3) launch_fused_inst<N1, NW, LP, 64, false, false, false, 3>(st, a, ntiles);
+        else if (NW == 16 && dbg == 4) launch_fused_inst<N1, NW, LP, 64, false, false, false, 4>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false>(st, a, ntiles);
     } else {
         if (grad) launch_fused_inst<N1, NW, LP, 0, true>(st, a, ntiles);
@@ -643,7 +746,13 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
                "shape not handled by the fused column kernel");
     const int64_t ntiles = (int64_t)(a_in.W / 2 + 1) * a_in.CN;
     const FusedSplit sp = fused_split(a_in.H, a_in.Kv ? a_in.Kv : a_in.K);
-    const FusedColsArgs<float> &a = a_in;
+    FusedColsArgs<float> a = a_in;
+    static const int sg = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS")) : 1;
+    static const int ss = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS")) : 0;
+    // default: 4 phase groups 2 x 8128 cycles apart (about a fifth of a tile's time each):
+    // measured 1.13 -> 1.06 ms at 512 x 512, K = 64, N = 32 (profiles/r02_fused_cols_notes.md)
+    a.stagger_groups = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? (sg > 0 ? sg : 1) : 4;
+    a.stagger_sleeps = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? ss : 2;
     if (sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);
     else

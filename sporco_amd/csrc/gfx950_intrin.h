@@ -127,4 +127,23 @@ __device__ __forceinline__ float sa_lane_xor15(float v) { return sa_dpp<0x140>(v
 // emitted, it only orders the scheduler.
 #define SA_VGPR_FENCE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 
+// A wave-uniform pointer made opaque to the optimiser (no instruction emitted): inside a
+// persistent tile loop this keeps loop-invariant operand loads (twiddle tables, ...) where
+// they are used instead of being hoisted in front of the loop, where they would occupy
+// scalar registers for the whole kernel.
+template <typename P> __device__ __forceinline__ P *sa_opaque_sptr(P *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+// The kernel's (single, by-value) argument struct re-read from the kernarg segment through
+// an opaque pointer: fields used late in a long tile loop are then loaded (s_load) where
+// they are used, every iteration, instead of living in scalar registers throughout.
+#define SA_ARGS_PTR_T(A) const A __attribute__((address_space(4))) *
+template <bool OPAQUE = true, typename A>
+__device__ __forceinline__ SA_ARGS_PTR_T(A) sa_args_reload(const A &) {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();
+    if constexpr (OPAQUE) asm volatile("" : "+s"(p));
+    return (SA_ARGS_PTR_T(A))p;
+}
+
 }  // namespace sporco_amd

@@ -114,4 +114,9 @@ inline float sa_lane_xor15(float v) { return hostsim_gather(v, ((int)threadIdx.x
 
 #define SA_VGPR_FENCE3(a, b, c) ((void)0)
 
+template <typename P> inline P *sa_opaque_sptr(P *p) { return p; }
+inline void __builtin_amdgcn_s_sleep(int) {}
+#define SA_ARGS_PTR_T(A) const A *
+template <bool OPAQUE = true, typename A> inline const A *sa_args_reload(const A &a) { return &a; }
+
 }  // namespace sporco_amd

@@ -24,6 +24,7 @@
 #include <type_traits>
 #include <utility>
 
+#define SPORCO_AMD_HOSTSIM 1
 #define __global__
 #define __device__
 #define __host__
@@ -72,6 +73,7 @@ hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamSynchronize(hipStream_t st);
 hipError_t hipDeviceSynchronize();
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int *d);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 hipError_t hipGetLastError();

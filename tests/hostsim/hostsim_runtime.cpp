@@ -216,6 +216,10 @@ hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDevice(int *d) {
+    *d = 0;
+    return hipSuccess;
+}
 hipError_t hipGetDeviceCount(int *n) {
     *n = 1;
     return hipSuccess;
