@@ -235,6 +235,43 @@ int sporco_amd_csc_admm_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p
 int sporco_amd_csc_admm_iter_dev(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
                                  double *out_dev);
 
+/* ---- Device-driven solve: the whole loop of ADMM.solve (sporco/admm/admm.py:331-377) ----
+ * The residuals and tolerances (:462-486), the adaptive penalty parameter (:549-575) and the
+ * stopping test (:375-377) are evaluated on the device at the end of every iteration, in the
+ * precisions of the host code, and the next iteration's kernels read rho, lambda/rho and the
+ * pending U scale from device memory: the host only enqueues launches (a few iterations
+ * ahead) and reads the per-iteration records back when the run ends.  Iterates and statistics
+ * are identical to those of the same number of sporco_amd_csc_admm_iter calls driven by the
+ * host rule.  Available for the three-launch float32 path (query FUSED_ROWS, K <= 64,
+ * single-channel dictionary) without FLAG_XRRS / JOINT / GRADREG / KEEP_X / FEVAL_Y;
+ * otherwise the call returns SPORCO_AMD_EUNSUPPORTED and changes nothing. */
+#define SPORCO_AMD_EUNSUPPORTED (-5)
+typedef struct {
+    double abs_tol, rel_tol;        /* AbsStopTol, RelStopTol                                */
+    double sqrt_nc, sqrt_nx;        /* sqrt of the constraint / primal sizes (admm.py:478-485) */
+    double rho_tau, rho_mu, rho_xi; /* AutoRho Scaling, RsdlRatio, RsdlTarget (solver precision) */
+    int32_t auto_rho, period, auto_scaling, std_residuals;
+    int32_t need_residuals;         /* AutoRho enabled or not FastSolve                      */
+    int32_t k0;                     /* iteration counter at entry (the solver's k)           */
+    int32_t max_iter;               /* MaxMainIter                                            */
+    int32_t lookahead;              /* iterations enqueued ahead of the last finished one; 0 = 3 */
+} sporco_amd_admm_ctrl;
+typedef struct {
+    double sums[SPORCO_AMD_OUT_COUNT];
+    double r, s, epri, edua;        /* residuals and tolerances of the iteration              */
+    double rho, u_scale;            /* the values the iteration ran with                      */
+    double seconds;                 /* device clock at the end of the iteration, from the start of the run */
+    int32_t k, stop;
+} sporco_amd_admm_record;
+/* Optional hook between the local sums and the control update of every iteration: sum the 16
+ * doubles at sums_dev over the ranks that hold the other images, in stream order (RCCL on the
+ * handle's stream) or synchronously.  NULL for a single rank. */
+typedef void (*sporco_amd_reduce_fn)(void *user, double *sums_dev);
+int sporco_amd_csc_admm_run(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                            const sporco_amd_admm_ctrl *c, sporco_amd_admm_record *records,
+                            int32_t *n_done, double *rho_out, double *u_scale_out,
+                            sporco_amd_reduce_fn reduce, void *user);
+
 /* Staged path, for callers that override individual ADMM steps
  * (SURVEY.md section 8(b) "monkey-patch hazard").  Each mirrors one method. */
 int sporco_amd_csc_admm_xstep(sporco_amd_csc_t h, const sporco_amd_admm_params *p,

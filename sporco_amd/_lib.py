@@ -55,7 +55,7 @@ EXPORTS = (
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
-    'sporco_amd_csc_admm_iter', 'sporco_amd_csc_admm_iter_dev',
+    'sporco_amd_csc_admm_iter', 'sporco_amd_csc_admm_iter_dev', 'sporco_amd_csc_admm_run',
     'sporco_amd_csc_admm_xstep', 'sporco_amd_csc_admm_relax',
     'sporco_amd_csc_admm_ystep', 'sporco_amd_csc_admm_ustep',
     'sporco_amd_csc_admm_stats', 'sporco_amd_csc_scale_u',
@@ -104,6 +104,30 @@ class DstepParams(ctypes.Structure):
                 ('cg_tol', ctypes.c_double), ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32),
                 ('dW', ctypes.c_int32), ('zero_mean', ctypes.c_int32), ('method', ctypes.c_int32),
                 ('cg_maxiter', ctypes.c_int32), ('mask_dcpl', ctypes.c_int32)]
+
+
+class AdmmCtrl(ctypes.Structure):
+    """sporco_amd_admm_ctrl (include/sporco_amd.h): constants of a device-driven solve."""
+    _fields_ = [('abs_tol', ctypes.c_double), ('rel_tol', ctypes.c_double),
+                ('sqrt_nc', ctypes.c_double), ('sqrt_nx', ctypes.c_double),
+                ('rho_tau', ctypes.c_double), ('rho_mu', ctypes.c_double),
+                ('rho_xi', ctypes.c_double),
+                ('auto_rho', ctypes.c_int32), ('period', ctypes.c_int32),
+                ('auto_scaling', ctypes.c_int32), ('std_residuals', ctypes.c_int32),
+                ('need_residuals', ctypes.c_int32), ('k0', ctypes.c_int32),
+                ('max_iter', ctypes.c_int32), ('lookahead', ctypes.c_int32)]
+
+
+class AdmmRecord(ctypes.Structure):
+    """sporco_amd_admm_record: what one iteration of a device-driven solve leaves behind."""
+    _fields_ = [('sums', ctypes.c_double * 16), ('r', ctypes.c_double), ('s', ctypes.c_double),
+                ('epri', ctypes.c_double), ('edua', ctypes.c_double), ('rho', ctypes.c_double),
+                ('u_scale', ctypes.c_double), ('seconds', ctypes.c_double),
+                ('k', ctypes.c_int32), ('stop', ctypes.c_int32)]
+
+
+REDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p)
+EUNSUPPORTED = -5
 
 
 class AdmmParams(ctypes.Structure):
@@ -200,6 +224,9 @@ def load(path=None):
         'sporco_amd_csc_device_ptr': [vp, ctypes.c_int, ctypes.POINTER(vp)],
         'sporco_amd_csc_admm_iter': [vp, pptr, dptr],
         'sporco_amd_csc_admm_iter_dev': [vp, pptr, vp],
+        'sporco_amd_csc_admm_run': [vp, pptr, ctypes.POINTER(AdmmCtrl), ctypes.POINTER(AdmmRecord),
+                                    ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(dbl),
+                                    ctypes.POINTER(dbl), REDUCE_FN, vp],
         'sporco_amd_csc_admm_xstep': [vp, pptr, dptr],
         'sporco_amd_csc_admm_relax': [vp, dbl],
         'sporco_amd_csc_admm_ystep': [vp, pptr],
@@ -479,6 +506,24 @@ class Solver(object):
         out = self._out()
         check(self._lib.sporco_amd_csc_admm_iter(self._h, ctypes.byref(params), out))
         return list(out)
+
+    def admm_run(self, params, ctrl, reduce=None):
+        """Device-driven solve (sporco_amd_csc_admm_run): up to ``ctrl.max_iter`` iterations,
+        stopping on the tolerance test evaluated on the device.  ``reduce(sums_dev_ptr)``, when
+        given, sums the 16 doubles at that device address over the ranks.  Returns ``(records,
+        rho, u_scale)``, or None when this configuration has to be driven from the host."""
+        n = ctypes.c_int32(0)
+        rho, usc = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        recs = (AdmmRecord * max(int(ctrl.max_iter), 1))()
+        cb = REDUCE_FN(lambda user, ptr: reduce(ptr)) if reduce is not None else \
+            ctypes.cast(None, REDUCE_FN)
+        rc = self._lib.sporco_amd_csc_admm_run(self._h, ctypes.byref(params), ctypes.byref(ctrl),
+                                               recs, ctypes.byref(n), ctypes.byref(rho),
+                                               ctypes.byref(usc), cb, None)
+        if rc == EUNSUPPORTED:
+            return None
+        check(rc)
+        return [recs[i] for i in range(n.value)], rho.value, usc.value
 
     def mdcpl_init(self, S):
         """ConvBPDNMaskDcpl state: keeps the real signal on the device, zeroes Y and U."""

@@ -311,6 +311,73 @@ class GenericConvBPDN(admm.ADMMEqual):
     def finish_solve(self):
         self._dev.sync()
 
+    # -- the whole loop on the device, when nothing on the host needs to see the iterations --
+    def _device_loop_ok(self):
+        """The device-driven solve (``sporco_amd_csc_admm_run``) replaces the loop of
+        :meth:`ADMM.solve` when no callback, status display or overridden step has to run on
+        the host between iterations; anything else keeps the per-iteration loop."""
+        o = self.opt
+        return (self._fused_ok() and o['Callback'] is None and not o['Verbose'] and
+                o['IterTimer'] == 'solve' and type(self).solve is GenericConvBPDN.solve and
+                type(self).update_rho is admm.ADMM.update_rho and
+                type(self).rho_scale_factor is admm.ADMM.rho_scale_factor and
+                'update_rho' not in self.__dict__ and o['MaxMainIter'] > 0)
+
+    def solve(self):
+        """:meth:`ADMM.solve` (sporco/admm/admm.py:293-389).  When the iterations need no host
+        involvement they run as one device-driven call: the residuals, the rho schedule and the
+        stopping test are evaluated on the device after every iteration and the statistics are
+        assembled from the per-iteration records afterwards (identical values; ``Time`` from
+        the device clock; the ``solve_wo_func`` / ``solve_wo_rsdl`` timers then equal
+        ``solve``)."""
+        if not self._device_loop_ok():
+            return super(GenericConvBPDN, self).solve()
+        o = self.opt
+        ctrl = _lib.AdmmCtrl()
+        ctrl.abs_tol, ctrl.rel_tol = float(o['AbsStopTol']), float(o['RelStopTol'])
+        ctrl.sqrt_nc, ctrl.sqrt_nx = float(np.sqrt(self.Nc)), float(np.sqrt(self.Nx))
+        ctrl.rho_tau, ctrl.rho_mu, ctrl.rho_xi = \
+            float(self.rho_tau), float(self.rho_mu), float(self.rho_xi)
+        ctrl.auto_rho = int(bool(o['AutoRho', 'Enabled']))
+        ctrl.period = int(o['AutoRho', 'Period'])
+        ctrl.auto_scaling = int(bool(o['AutoRho', 'AutoScaling']))
+        ctrl.std_residuals = int(bool(o['AutoRho', 'StdResiduals']))
+        ctrl.need_residuals = int(self._needs_residuals())
+        ctrl.k0, ctrl.max_iter, ctrl.lookahead = int(self.k), int(o['MaxMainIter']), 0
+        all_timers = ['solve', 'solve_wo_func', 'solve_wo_rsdl']
+        t_before = self.timer.elapsed('solve')
+        self.timer.start(all_timers)
+        reduce = None
+        if self._reducer is not None:
+            reduce = self._reducer.device_sum_hook(self._dev)
+        res = None
+        if self._reducer is None or reduce is not None:
+            res = self._dev.admm_run(self._params(), ctrl, reduce)
+        if res is None:
+            self.timer.stop(all_timers)
+            return super(GenericConvBPDN, self).solve()
+        recs, rho, u_scale = res
+        self.timer.stop(all_timers)
+        rdt = real_dtype(self.dtype).type
+        fast = bool(o['FastSolve'])
+        for rec in recs:
+            self.k = int(rec.k)
+            if not fast:
+                self._sums = list(rec.sums)
+                self.rho = rdt(rec.rho)
+                self._set_xrrs()
+                tk = t_before + rec.seconds
+                tpl = (self.k,) + self.eval_objfn() + (rec.r, rec.s, rec.epri, rec.edua, self.rho) \
+                    + self.itstat_extra() + (tk,)
+                self.itstat.append(type(self).IterationStats(*tpl))
+        if recs:
+            self._sums = list(recs[-1].sums)
+        self.rho = rdt(rho)
+        self._u_scale = float(u_scale)
+        self._touch(_lib.VAR_X, _lib.VAR_Y, _lib.VAR_U, _lib.VAR_XF)
+        self.k += 1
+        return self.getmin() if getattr(self, '_return_min', True) else None
+
     def _set_xrrs(self):
         if self.opt['LinSolveCheck']:
             s = self._sums

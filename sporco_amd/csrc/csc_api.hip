@@ -125,6 +125,9 @@ struct CscBase {
     virtual void download(int var, void *dst) = 0;
     virtual void *device_ptr(int var) = 0;
     virtual void admm_iter(const sporco_amd_admm_params &p, double *out_dev) = 0;
+    virtual int admm_run(const sporco_amd_admm_params &p, const sporco_amd_admm_ctrl &c,
+                         sporco_amd_admm_record *records, double *rho_out, double *u_scale_out,
+                         sporco_amd_reduce_fn reduce, void *user) = 0;
     virtual void admm_xstep(const sporco_amd_admm_params &p, double *out_dev) = 0;
     virtual void admm_relax(double rlx) = 0;
     virtual void admm_ystep(const sporco_amd_admm_params &p) = 0;
@@ -300,6 +303,10 @@ template <typename T> struct Csc : CscBase {
     // iterate, emitted by the previous rows_inv_post on the bet that rho stays put
     bool t_ready = false;
     int stable_run = 0;   // consecutive fused iterations entered with an unchanged rho
+    // device-driven solve (admm_run): control block in device memory, records in pinned memory
+    AdmmCtl *ctl_dev = nullptr;
+    AdmmRecord *rec_ring = nullptr;
+    int rec_cap = 0;
     sporco_amd_admm_params last_p;
     // fused PGM iteration (csc_pgm.h): Xf, Yf, Xfprv, Yfprv tile-major; X of the last
     // iteration is prox(irfft_W(work)) and is rebuilt on demand with `last_pgm`
@@ -429,6 +436,8 @@ template <typename T> struct Csc : CscBase {
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
         if (out_pinned) (void)hipHostFree(out_pinned);
+        if (rec_ring) (void)hipHostFree(rec_ring);
+        if (ctl_dev) (void)hipFree(ctl_dev);
         planW.destroy();
         planH.destroy();
         if (own_stream) (void)hipStreamDestroy(st);
@@ -1006,6 +1015,221 @@ template <typename T> struct Csc : CscBase {
         }
         t_ready = emit;
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
+    }
+
+    // ---- device-driven solve (include/sporco_amd.h: sporco_amd_csc_admm_run) -----------------
+    bool admm_run_supported(const sporco_amd_admm_params &p) const {
+        return std::is_same<T, float>::value && rows_ok && fused && !fused_mc && !fused_slabs &&
+               !tail_mode &&
+               !(p.flags & (F_XRRS | F_JOINT | F_GRADREG | F_KEEP_X | F_FEVAL_Y)) &&
+               !std::getenv("SPORCO_AMD_HOST_LOOP");
+    }
+
+    // one iteration of admm_iter_fused with every iteration-dependent scalar taken from ctl_dev
+    int64_t enqueue_iter_ctl(const sporco_amd_admm_params &p) {
+        T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U);
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
+        {
+            RowsFwdArgs<T> ra;
+            ra.y = Y;
+            ra.u = U;
+            ra.s2 = T(1);
+            ra.t = Xf;
+            ra.Ks = Ks;
+            ra.twA = twRows;
+            ra.H = H;
+            ra.W = W;
+            ra.CN = CN;
+            ra.K = K;
+            ra.P = P;
+            ra.ctl = ctl_dev;
+            ProfScope ps(prof, PS_ROWS_FWD);
+            launch_rows_fwd<T>(st, ra);
+        }
+        {
+            FusedColsArgs<T> fa;
+            fa.t = Xf;
+            fa.dft = dft;
+            fa.sft = sft;
+            fa.gramt = gramt;
+            fa.twA = twA;
+            fa.twB = twB;
+            fa.rho = (T)p.rho;
+            fa.H = H;
+            fa.W = W;
+            fa.CN = CN;
+            fa.K = K;
+            fa.partials = part_f;
+            fa.Ks = Ks;
+            fa.ctl = ctl_dev;
+            ProfScope ps(prof, PS_FUSED_COLS);
+            part_f_rows = (int)launch_fused_cols<T>(st, fa);
+            xf_tiled = true;
+        }
+        RowsPostArgs<T> pa;
+        pa.twA = twRows;
+        pa.t_next = Xf;          // the emitting variant; ctl->emit decides per iteration
+        pa.t = Xf;
+        pa.twW = planW.tw<T>();
+        pa.y = Y;
+        pa.u = U;
+        pa.y_out = y_alt;
+        pa.u_out = u_alt;
+        pa.x = nullptr;
+        pa.scale = T(1.0 / ((double)H * (double)W));
+        pa.rlx = (T)p.rlx;
+        pa.thr = T(0);
+        pa.u_scale = T(1);
+        pa.flags = p.flags;
+        pa.H = H;
+        pa.W = W;
+        pa.C = C;
+        pa.N = N;
+        pa.K = K;
+        pa.dH = p.dH;
+        pa.dW = p.dW;
+        pa.P = P;
+        pa.wl1 = wl1;
+        pa.Ks = Ks;
+        pa.ams_bits = ams_bits_of(p);
+        pa.ams_k = Ku - 1;
+        pa.partials = part_rows;
+        pa.ctl = ctl_dev;
+        int64_t nt;
+        {
+            ProfScope ps(prof, PS_ROWS_INV_POST_EMIT);
+            nt = launch_rows_inv_post<T>(st, pa);
+        }
+        std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
+        std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
+        return nt;
+    }
+
+    int admm_run(const sporco_amd_admm_params &p, const sporco_amd_admm_ctrl &c,
+                 sporco_amd_admm_record *records, double *rho_out, double *u_scale_out,
+                 sporco_amd_reduce_fn reduce, void *user) override {
+        require_ready();
+        if (!admm_run_supported(p)) return -1;
+        SA_REQUIRE(c.max_iter >= 0, "max_iter must not be negative");
+        if (c.max_iter == 0) {
+            *rho_out = p.rho;
+            *u_scale_out = p.u_scale;
+            return 0;
+        }
+        if (!y_alt) {
+            SA_HIP(hipMalloc((void **)&y_alt, sizeof(T) * E));
+            SA_HIP(hipMalloc((void **)&u_alt, sizeof(T) * E));
+        }
+        if (!ctl_dev) SA_HIP(hipMalloc((void **)&ctl_dev, sizeof(AdmmCtl)));
+        if (rec_cap < c.max_iter) {
+            if (rec_ring) SA_HIP(hipHostFree(rec_ring));
+            rec_cap = std::max(c.max_iter, 256);
+            SA_HIP(hipHostMalloc((void **)&rec_ring, sizeof(AdmmRecord) * rec_cap, 0));
+        }
+        std::memset((void *)rec_ring, 0, sizeof(AdmmRecord) * c.max_iter);
+        double *out_dev = out_dev_default;
+        const bool want_sums = p.flags & (F_RESID | F_OBJ);
+        AdmmCtlInit in;
+        in.rho = p.rho;
+        in.u_scale = p.u_scale;
+        in.lmbda = p.lmbda;
+        in.abstol = c.abs_tol;
+        in.reltol = c.rel_tol;
+        in.sqrt_nc = c.sqrt_nc;
+        in.sqrt_nx = c.sqrt_nx;
+        in.tau = c.rho_tau;
+        in.mu = c.rho_mu;
+        in.xi = c.rho_xi;
+        in.k = c.k0;
+        in.stable_run = stable_run;
+        in.emitted = t_ready ? 1 : 0;
+        in.is_f32 = 1;
+        in.autorho = c.auto_rho;
+        in.period = c.period > 0 ? c.period : 1;
+        in.autoscaling = c.auto_scaling;
+        in.stdres = c.std_residuals;
+        in.need_resid = c.need_residuals;
+        in.no_speculation = std::getenv("SPORCO_AMD_NO_SPECULATION") ? 1 : 0;
+        launch_admm_ctl_init(st, ctl_dev, in);
+        SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        const int ahead = c.lookahead > 0 ? c.lookahead : 3;
+        int enq = 0, done = 0, stop_at = -1;
+        // (test knob: pretend the newest `lag` records are not visible yet, so that launches
+        // enqueued past the stopping iteration -- which must do nothing -- occur on any device)
+        int lag = std::getenv("SPORCO_AMD_RUN_LAG") ? std::atoi(std::getenv("SPORCO_AMD_RUN_LAG")) : 0;
+        auto poll = [&](bool block) {
+            // advance over finished iterations; returns at the first unfinished one
+            while (done < enq - lag && stop_at < 0) {
+                if (rec_ring[done].seq != done + 1) {
+                    if (!block) return;
+                    if (hipStreamQuery(st) == hipSuccess && rec_ring[done].seq != done + 1)
+                        throw Error(SPORCO_AMD_EHIP, "device-driven solve: record not written");
+                    continue;
+                }
+                if (rec_ring[done].stop) stop_at = done;
+                ++done;
+            }
+        };
+        for (; enq < c.max_iter && stop_at < 0;) {
+            const int64_t nt = enqueue_iter_ctl(p);
+            if (want_sums) {
+                const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                                      SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
+                const double scales[6] = {1, 1, 1, 1, 1, 1};
+                const int fslots[2] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_RGR};
+                const double fscales[2] = {1.0 / ((double)H * W), 1.0 / ((double)H * W)};
+                const bool dfid = p.flags & F_OBJ;
+                {
+                    ProfScope ps(prof, PS_FINALIZE);
+                    launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, part_f_rows,
+                                     1, dfid ? 1 : 0, fslots, fscales, out_dev);
+                }
+                if (reduce) reduce(user, out_dev);
+            }
+            launch_admm_ctl_update(st, ctl_dev, out_dev, rec_ring + enq, enq, true);
+            ++enq;
+            if (c.need_residuals) {
+                poll(false);
+                while (stop_at < 0 && enq - lag - done > ahead) poll(true);
+            }
+        }
+        sync();
+        lag = 0;
+        poll(false);
+        const int n = stop_at >= 0 ? stop_at + 1 : enq;
+        // launches enqueued after the stopping iteration did nothing: undo their buffer swaps
+        if ((enq - n) & 1) {
+            std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
+            std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
+        }
+        AdmmCtl fin;
+        SA_HIP(hipMemcpy(&fin, ctl_dev, sizeof(AdmmCtl), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            const AdmmRecord &r = rec_ring[i];
+            sporco_amd_admm_record &o = records[i];
+            for (int j = 0; j < kOutSlots; ++j) o.sums[j] = r.sums[j];
+            o.r = r.r;
+            o.s = r.s;
+            o.epri = r.epri;
+            o.edua = r.edua;
+            o.rho = r.rho;
+            o.u_scale = r.u_scale;
+            o.seconds = (double)r.ticks * 1e-8;
+            o.k = r.k;
+            o.stop = r.stop;
+        }
+        *rho_out = fin.rho;
+        *u_scale_out = fin.u_scale;
+        // host-side mirrors of the state the per-iteration path keeps
+        stable_run = fin.stable_run > 0 ? fin.stable_run - 1 : 0;   // (admm_iter_fused re-derives it)
+        if (fin.u_scale != 1.0) stable_run = 0;
+        t_ready = fin.emitted != 0;
+        last_p = p;
+        last_p.rho = rec_ring[n - 1].rho;
+        last_p.u_scale = rec_ring[n - 1].u_scale;
+        x_stale = true;
+        x_invalid = p.flags & F_NO_X;
+        return n;
     }
 
     // X = irfft_W(tile-major spectrum in the Xf buffer) / (H W): the row pass of
@@ -2636,6 +2860,22 @@ int sporco_amd_csc_admm_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p
     SA_REQUIRE(p && out, "null argument");
     h->impl->admm_iter(*p, h->impl->out_dev_default);
     h->impl->read_out(h->impl->out_dev_default, out);
+    SA_API_END
+}
+
+int sporco_amd_csc_admm_run(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
+                            const sporco_amd_admm_ctrl *c, sporco_amd_admm_record *records,
+                            int32_t *n_done, double *rho_out, double *u_scale_out,
+                            sporco_amd_reduce_fn reduce, void *user) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(p && c && records && n_done && rho_out && u_scale_out, "null argument");
+    const int n = h->impl->admm_run(*p, *c, records, rho_out, u_scale_out, reduce, user);
+    if (n < 0) {
+        *n_done = 0;
+        return SPORCO_AMD_EUNSUPPORTED;
+    }
+    *n_done = n;
     SA_API_END
 }
 

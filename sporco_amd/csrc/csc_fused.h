@@ -16,6 +16,7 @@
 #pragma once
 
 #include "common.h"
+#include "csc_kernels.h"
 
 namespace sporco_amd {
 
@@ -58,6 +59,9 @@ template <typename T> struct FusedColsArgs {
     // persistent launch: workgroup slot s starts (s % stagger_groups) * stagger_sleeps * 8128
     // cycles late, so that the workgroups' memory and arithmetic phases interleave across CUs
     int stagger_groups = 1, stagger_sleeps = 0;
+    // device-driven solve (csc_kernels.h AdmmCtl): rho is ctl->rho_f, and the launch returns at
+    // once when ctl->stop is set
+    const AdmmCtl *ctl = nullptr;
     const T *g1t = nullptr;
     T *g1t_out = nullptr;
     const T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;

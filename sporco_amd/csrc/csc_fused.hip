@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     const int cvoff = k == 0 ? 0 : (int)0x80000000;
     const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
     int token = 0;
+    if (a.ctl && a.ctl->stop) return;     // device-driven solve: stopping test already met
     if constexpr (PERSIST) {
         const int ph = (int)(blockIdx.x >> 3) % a.stagger_groups;
         for (int i = 0; i < ph * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
@@ -116,7 +117,8 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     const int wf = (slot / CN) * 8 + xcd;
     if (wf >= Wf) break;
     const int tile = wf * CN + slot % CN;
-    const float rho = ap->rho;
+    const AdmmCtl *ctl = ap->ctl;
+    const float rho = ctl ? ctl->rho_f : ap->rho;
     const float *GH = ap->ghh + w;
     const cf *twA = ap->twA + w * N1;                         // W_H^(w * brev(i)),      i < N1
     const cf *twB = ap->twB + w * N1;                         // W_H^((w + NW j) * h2), [j][h2]

@@ -261,4 +261,49 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
                       int stride_b, int nvals_b, const int *slots_b, const double *scales_b,
                       double *out);
 
+// ---------------------------------------------------------------------------
+// Device-resident ADMM control (sporco_amd_csc_admm_run): the residuals, tolerances, the
+// adaptive penalty parameter and the stopping test of sporco/admm/admm.py:462-486, 549-575,
+// 375-377 evaluated by a one-thread kernel at the end of every iteration, in the same
+// precisions and order as the host code of sporco_amd/admm/admm.py evaluates them, so that
+// a solve driven from here reproduces the host-driven one bit for bit.  The iteration's
+// kernels take rho, lambda / rho, the pending U scale and the speculate / skip / stop
+// decisions from this block instead of from launch arguments; the host only enqueues.
+// ---------------------------------------------------------------------------
+struct AdmmCtl {
+    // read by the iteration kernels
+    float rho_f, thr_f, u_scale_f;
+    int skip_fwd;      // T already holds rows_fwd of the current iterate (emitted, rho unchanged)
+    int emit;          // this iteration's epilogue also emits the next iteration's T
+    int stop;          // stopping test met: every later launch returns at once
+    int k, stable_run;
+    int emitted;       // the last executed epilogue emitted T (valid while u_scale == 1)
+    int is_f32;
+    double rho, u_scale;   // (rho: exact image of the solver-precision value)
+    // constants of the solve
+    double lmbda, abstol, reltol, sqrt_nc, sqrt_nx, tau, mu, xi;
+    int autorho, period, autoscaling, stdres;
+    int need_resid, no_speculation, pad0, pad1;
+    unsigned long long t0;
+};
+// One per executed iteration, written to host-visible (pinned) memory; `seq` last.
+struct AdmmRecord {
+    double sums[16];
+    double r, s, epri, edua, rho, u_scale;   // rho / u_scale: the values the iteration ran with
+    unsigned long long ticks;                 // 100 MHz device clock at the end of the iteration
+    int k, stop, emit, skip_fwd;
+    volatile int seq;                         // index in the run + 1
+    int pad;
+};
+struct AdmmCtlInit {
+    double rho, u_scale, lmbda, abstol, reltol, sqrt_nc, sqrt_nx, tau, mu, xi;
+    int k, stable_run, emitted, is_f32, autorho, period, autoscaling, stdres, need_resid,
+        no_speculation;
+};
+void launch_admm_ctl_init(hipStream_t st, AdmmCtl *ctl, const AdmmCtlInit &in);
+// sums: the 16 output slots of the iteration in device memory (already all-reduced when the
+// images are sharded); rec: slot of this iteration in the host-visible ring
+void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, AdmmRecord *rec,
+                            int index, bool f32);
+
 }  // namespace sporco_amd

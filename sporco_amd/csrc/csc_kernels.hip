@@ -7,6 +7,10 @@
 // (summed in a fixed order by finalize_kernel => run-to-run deterministic).
 #include "csc_kernels.h"
 
+#include <gfx950_intrin.h>
+
+#include "../../include/sporco_amd.h"
+
 namespace sporco_amd {
 
 constexpr int kThreads = 256;
@@ -2065,6 +2069,138 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
     if (nvals_a + nvals_b <= 0) return;
     hipLaunchKernelGGL(finalize_kernel, dim3(nvals_a + nvals_b), dim3(kThreads),
                        sizeof(double) * kThreads, st, a);
+    SA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
+// device-resident ADMM control (csc_kernels.h)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {
+    // what the iteration kernels read, from (rho, u_scale): the casts of
+    // csc_api.hip admm_iter_fused ((T)p.rho, (T)(p.lmbda / p.rho), (T)p.u_scale)
+    c->rho_f = (float)c->rho;
+    c->thr_f = (float)(c->lmbda / c->rho);
+    c->u_scale_f = (float)c->u_scale;
+    c->stable_run = c->u_scale == 1.0 ? c->stable_run + 1 : 0;
+    c->emit = (c->stable_run >= 2 && !c->no_speculation) ? 1 : 0;
+    c->skip_fwd = (c->emitted && c->u_scale == 1.0) ? 1 : 0;
+}
+
+__global__ void admm_ctl_init_kernel(AdmmCtl *c, const AdmmCtlInit in) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    c->rho = in.rho;
+    c->u_scale = in.u_scale;
+    c->lmbda = in.lmbda;
+    c->abstol = in.abstol;
+    c->reltol = in.reltol;
+    c->sqrt_nc = in.sqrt_nc;
+    c->sqrt_nx = in.sqrt_nx;
+    c->tau = in.tau;
+    c->mu = in.mu;
+    c->xi = in.xi;
+    c->k = in.k;
+    c->stable_run = in.stable_run;
+    c->emitted = in.emitted;
+    c->is_f32 = in.is_f32;
+    c->autorho = in.autorho;
+    c->period = in.period;
+    c->autoscaling = in.autoscaling;
+    c->stdres = in.stdres;
+    c->need_resid = in.need_resid;
+    c->no_speculation = in.no_speculation;
+    c->stop = 0;
+    c->t0 = sa_wall_clock();
+    admm_ctl_derive(c);
+}
+
+// The arithmetic below restates, operation by operation, sporco_amd/admm/cbpdn.py
+// residual_norms and sporco_amd/admm/admm.py compute_residuals / rho_scale_factor /
+// update_rho (themselves sporco/admm/admm.py:462-486, 549-575) for a solver whose real
+// type is T: sums, norms, residuals and tolerances are float64; rho, tau, mu, xi are T
+// scalars, products of two of them are formed in T, and a multiplier that was clipped to
+// tau is a T value (so 1 / tau is a T division) -- NumPy's scalar promotion rules.
+template <typename T>
+__global__ void admm_ctl_update_kernel(AdmmCtl *c, const double *sums, AdmmRecord *rec, int index) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (c->stop) return;
+    const double rho = c->rho;
+    for (int i = 0; i < 16; ++i) rec->sums[i] = sums[i];
+    rec->rho = rho;
+    rec->u_scale = c->u_scale;
+    rec->k = c->k;
+    rec->emit = c->emit;
+    rec->skip_fwd = c->skip_fwd;
+    double r = 0.0, s = 0.0, epri = 0.0, edua = 0.0;
+    double rho_new = rho, u_scale_new = 1.0;
+    int stop = 0;
+    if (c->need_resid) {
+        const double nr = sqrt(sums[SPORCO_AMD_OUT_R2]);
+        const double ns = rho * sqrt(sums[SPORCO_AMD_OUT_S2]);
+        const double nax = sqrt(sums[SPORCO_AMD_OUT_AX2]), ny = sqrt(sums[SPORCO_AMD_OUT_Y2]);
+        double rn = nax >= ny ? nax : ny;
+        double sn = rho * sqrt(sums[SPORCO_AMD_OUT_U2]);
+        if (c->stdres) {
+            r = nr;
+            s = ns;
+            epri = c->sqrt_nc * c->abstol + rn * c->reltol;
+            edua = c->sqrt_nx * c->abstol + sn * c->reltol;
+        } else {
+            if (rn == 0.0) rn = 1.0;
+            if (sn == 0.0) sn = 1.0;
+            r = nr / rn;
+            s = ns / sn;
+            epri = c->sqrt_nc * c->abstol / rn + c->reltol;
+            edua = c->sqrt_nx * c->abstol / sn + c->reltol;
+        }
+        const int k = c->k;
+        if (c->autorho && k != 0 && ((k + 1) % c->period) == 0) {
+            const T tau = (T)c->tau, mu = (T)c->mu, xi = (T)c->xi;
+            double mlt_d = 0.0;     // the multiplier when it is a float64 value ...
+            bool mlt_is_t = true;   // ... or tau itself (a T value)
+            if (c->autoscaling && !(s == 0.0 || r == 0.0)) {
+                const double sx = s * (double)xi;
+                mlt_d = sqrt(r > sx ? r / sx : sx / r);
+                mlt_is_t = mlt_d > (double)tau;
+            }
+            double rsf = 1.0;       // float(rsf) of the host code
+            if (r > (double)(T)(xi * mu) * s) {
+                rsf = mlt_is_t ? (double)tau : mlt_d;
+            } else if (s > (double)(T)(mu / xi) * r) {
+                rsf = mlt_is_t ? (double)(T)(T(1) / tau) : 1.0 / mlt_d;
+            }
+            rho_new = (double)(T)((T)rho * (T)rsf);
+            u_scale_new = 1.0 / rsf;
+        }
+        stop = (r < epri && s < edua) ? 1 : 0;
+    }
+    rec->r = r;
+    rec->s = s;
+    rec->epri = epri;
+    rec->edua = edua;
+    rec->stop = stop;
+    rec->ticks = sa_wall_clock() - c->t0;
+    c->rho = rho_new;
+    c->u_scale = u_scale_new;
+    c->emitted = c->emit;
+    c->k = c->k + 1;
+    c->stop = stop;
+    admm_ctl_derive(c);
+    sa_fence_system();
+    rec->seq = index + 1;
+    sa_fence_system();
+}
+
+void launch_admm_ctl_init(hipStream_t st, AdmmCtl *ctl, const AdmmCtlInit &in) {
+    hipLaunchKernelGGL(admm_ctl_init_kernel, dim3(1), dim3(64), 0, st, ctl, in);
+    SA_HIP(hipGetLastError());
+}
+void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, AdmmRecord *rec,
+                            int index, bool f32) {
+    if (f32)
+        hipLaunchKernelGGL(admm_ctl_update_kernel<float>, dim3(1), dim3(64), 0, st, ctl, sums, rec, index);
+    else
+        hipLaunchKernelGGL(admm_ctl_update_kernel<double>, dim3(1), dim3(64), 0, st, ctl, sums, rec,
+                           index);
     SA_HIP(hipGetLastError());
 }
 

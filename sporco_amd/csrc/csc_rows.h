@@ -33,6 +33,9 @@ template <typename T> struct RowsFwdArgs {
     int64_t P;
     int y_bcast = 0;   // y is (H, W, K), broadcast over the CN blocks (consensus D-step)
     int Ks = 0;        // row stride of t in filters when it is not K (0: K), see csc_fused.h
+    // device-driven solve (csc_kernels.h AdmmCtl): s2 is ctl->u_scale_f, and the launch returns
+    // at once when ctl->stop or ctl->skip_fwd is set
+    const AdmmCtl *ctl = nullptr;
 };
 
 template <typename T> struct RowsPostArgs {
@@ -54,6 +57,9 @@ template <typename T> struct RowsPostArgs {
     const uint32_t *ams_bits = nullptr;   // AddMaskSim mask packed by launch_ams_pack, or null
     int ams_k = -1;    // filter index of the impulse slice
     double *partials;  // per tile 8 doubles: r2, s2, ax2, y2, u2, l1, 0, 0
+    // device-driven solve: thr, u_scale and whether t_next is emitted come from this block,
+    // and the launch returns at once when ctl->stop is set
+    const AdmmCtl *ctl = nullptr;
 };
 
 // Pack an AddMaskSim mask (as PostParams::ams: broadcastable (H, W, C, N, 1), nonzero = masked)

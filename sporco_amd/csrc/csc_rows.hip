@@ -275,6 +275,13 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int h = blockIdx.y;
+    float s2 = a.s2;
+    if (a.ctl) {
+        // device-driven solve: nothing to do once the stopping test is met, or when the
+        // previous epilogue already left this spectrum behind
+        if (a.ctl->stop | a.ctl->skip_fwd) return;
+        s2 = a.ctl->u_scale_f;
+    }
     const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
     const bool pv = p < a.P;
     const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
@@ -295,7 +302,6 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
     const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
     const int yvoff = BCAST ? (pv ? k * (int)sizeof(float) : (int)0x80000000) : voff;
     const int ypixbytes = BCAST ? a.K * (int)sizeof(float) : pixbytes;
-    const float s2 = a.s2;
     cf v[N1];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -329,6 +335,15 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int h = blockIdx.y;
+    float thr = a.thr, usc = a.u_scale;
+    bool emit = EMIT_T;
+    if (a.ctl) {
+        // device-driven solve: parameters and the speculation decision of this iteration
+        if (a.ctl->stop) return;
+        thr = a.ctl->thr_f;
+        usc = a.ctl->u_scale_f;
+        emit = EMIT_T && a.ctl->emit;
+    }
     const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
     const bool pv = p < a.P;
     const int CN = a.C * a.N;
@@ -348,7 +363,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const BufRsrc Xb = make_rsrc(WRITE_X ? a.x + rowoff : a.y_out + rowoff, rowbytes);
     const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;
     const int pixbytes = (int)(a.P * (int64_t)sizeof(float));
-    const float al = a.rlx, oma = 1.f - a.rlx, usc = a.u_scale, scale = a.scale;
+    const float al = a.rlx, oma = 1.f - a.rlx, scale = a.scale;
     const bool nonneg = a.flags & F_NONNEG, nob = a.flags & F_NOBNDRY, gy = a.flags & F_GEVAL_Y;
     // weight of element (h, x, c, n, k): wave-uniform row pointer + 32-bit lane offset
     int wlane = 0;
@@ -411,7 +426,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
                     wt = wrow[wlane + e * ws4];
                 }
                 if (GENERAL) wt = am ? 0.f : wt;
-                float y1 = soft1(ax + uo[e], a.thr * wt);
+                float y1 = soft1(ax + uo[e], thr * wt);
                 if (nonneg && !am && y1 < 0.f) y1 = 0.f;
                 if (GENERAL) y1 *= am ? mkeep : keep;
                 const float u1 = uo[e] + ax - y1;
@@ -436,7 +451,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     // transform that follows and keeps every per-element term alive until then)
     SA_VGPR_FENCE3(s_r2, s_s2, s_x2);
     SA_VGPR_FENCE3(s_y2, s_u2, s_l1);
-    if (EMIT_T) {
+    if (EMIT_T && emit) {
         // Speculation on an unchanged rho: the row spectra of Y' - U' that the next
         // iteration's rows_fwd would compute from these very values, stored over the
         // units this thread consumed (same spectral-side ownership: in place is safe).

@@ -127,6 +127,10 @@ __device__ __forceinline__ float sa_lane_xor15(float v) { return sa_dpp<0x140>(v
 // emitted, it only orders the scheduler.
 #define SA_VGPR_FENCE3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
 
+// constant-rate device clock (100 MHz) and a system-scope fence (host-visible records)
+__device__ __forceinline__ unsigned long long sa_wall_clock() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void sa_fence_system() { __threadfence_system(); }
+
 // A wave-uniform pointer made opaque to the optimiser (no instruction emitted): inside a
 // persistent tile loop this keeps loop-invariant operand loads (twiddle tables, ...) where
 // they are used instead of being hoisted in front of the loop, where they would occupy

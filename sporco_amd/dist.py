@@ -63,6 +63,40 @@ class TorchReducer(object):
             return self.buf.cpu().tolist()
         return self.sum(solver.admm_iter(params))
 
+    def device_sum_hook(self, solver):
+        """Hook for the device-driven solve (``Solver.admm_run``): called once per iteration
+        with the device address of the 16 sums, it all-reduces them in place without a host
+        round trip -- over RCCL the collective is enqueued behind the kernels that produced
+        the sums (the solver shares torch's current stream) and the control kernel that
+        follows is enqueued behind it.  Returns None when that is not possible (gloo on a real
+        GPU): the caller then keeps the per-iteration host loop."""
+        from . import _lib
+        views = {}
+        if self.on_gpu:
+            def hook(ptr):
+                t = views.get(ptr)
+                if t is None:
+                    t = views[ptr] = self.torch.as_tensor(_DeviceView(ptr, 16, '<f8'),
+                                                          device=self.buf.device)
+                self.dist.all_reduce(t, group=self.group)
+            try:
+                self.torch.as_tensor(_DeviceView(solver.device_ptr(_lib.VAR_Y), 1, '<f4'),
+                                     device=self.buf.device)
+            except (TypeError, RuntimeError, ValueError):
+                return None
+            return hook
+        if 'hostsim' not in str(_lib.library_path()):
+            return None
+
+        def hook(ptr):      # CPU simulator: "device" memory is host memory
+            import numpy as np
+            t = views.get(ptr)
+            if t is None:
+                a = np.ctypeslib.as_array((ctypes.c_double * 16).from_address(ptr))
+                t = views[ptr] = self.torch.from_numpy(a)
+            self.dist.all_reduce(t, group=self.group)
+        return hook
+
     def all_reduce_array(self, solver, var):
         """Sum state array ``var`` of ``solver`` over the ranks, in place, in device memory."""
         ptr = solver.device_ptr(var)

@@ -4,6 +4,7 @@
 // kernels include <gfx950_intrin.h> and this directory comes first on the
 // simulator's include path.  Never seen by the hipcc build.
 #pragma once
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 
@@ -114,6 +115,11 @@ inline float sa_lane_xor15(float v) { return hostsim_gather(v, ((int)threadIdx.x
 
 #define SA_VGPR_FENCE3(a, b, c) ((void)0)
 
+inline unsigned long long sa_wall_clock() {
+    return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(
+                                    std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
+inline void sa_fence_system() {}
 template <typename P> inline P *sa_opaque_sptr(P *p) { return p; }
 inline void __builtin_amdgcn_s_sleep(int) {}
 #define SA_ARGS_PTR_T(A) const A *

@@ -74,6 +74,7 @@ hipError_t hipStreamSynchronize(hipStream_t st);
 hipError_t hipDeviceSynchronize();
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
+hipError_t hipStreamQuery(hipStream_t s);
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 hipError_t hipGetLastError();

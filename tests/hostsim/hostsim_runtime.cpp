@@ -214,6 +214,7 @@ hipError_t hipStreamCreate(hipStream_t *st) {
 }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetDevice(int *d) {
