@@ -302,10 +302,18 @@ def main():
     b, elapsed = timed_run(args.fastsolve)
     # per-kernel durations: HIP events recorded by the library on its own stream
     # around every launch, over a second run of the same iterations
+    # (this pass runs the host-driven loop, which launches exactly the kernels that execute:
+    # the device-driven loop of the timed region enqueues both epilogue variants and a forward
+    # row pass every iteration and lets the device skip the ones not needed, so its event
+    # timings would average idle launches in)
     prof_steps = min(args.steps, 10)
     b.opt['MaxMainIter'] = prof_steps
     b.profile(True)
-    b.solve()
+    os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+    try:
+        b.solve()
+    finally:
+        os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
     sync_all(b)
     prof = b.profile_read()
     b.profile(False)
@@ -380,6 +388,9 @@ def main():
                           'value': args.steps / elapsed2 * world,
                           'ms_per_step': 1e3 * elapsed2 / args.steps},
         'parity': parity,
+        'loop': ('device-driven (sporco_amd_csc_admm_run): residuals, rho schedule and stopping '
+                 'test on the device, host enqueues only') if not os.environ.get('SPORCO_AMD_HOST_LOOP')
+                else 'host-driven (one sporco_amd_csc_admm_iter call per iteration)',
         'result_download_ms': download_ms,
         'kernels_ms_per_iter': {k: round(v[0] / prof_steps, 4) for k, v in timed.items()},
         'kernel_roofline': per_kernel,

@@ -1068,7 +1068,7 @@ template <typename T> struct Csc : CscBase {
         }
         RowsPostArgs<T> pa;
         pa.twA = twRows;
-        pa.t_next = Xf;          // the emitting variant; ctl->emit decides per iteration
+        pa.t_next = nullptr;     // plain variant first, then the emitting one: ctl->emit picks
         pa.t = Xf;
         pa.twW = planW.tw<T>();
         pa.y = Y;
@@ -1097,8 +1097,13 @@ template <typename T> struct Csc : CscBase {
         pa.ctl = ctl_dev;
         int64_t nt;
         {
-            ProfScope ps(prof, PS_ROWS_INV_POST_EMIT);
+            ProfScope ps(prof, PS_ROWS_INV_POST);
             nt = launch_rows_inv_post<T>(st, pa);
+        }
+        pa.t_next = Xf;
+        {
+            ProfScope ps(prof, PS_ROWS_INV_POST_EMIT);
+            launch_rows_inv_post<T>(st, pa);
         }
         std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
         std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));

@@ -2076,6 +2076,7 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
 // device-resident ADMM control (csc_kernels.h)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {
+#pragma clang fp contract(off)
     // what the iteration kernels read, from (rho, u_scale): the casts of
     // csc_api.hip admm_iter_fused ((T)p.rho, (T)(p.lmbda / p.rho), (T)p.u_scale)
     c->rho_f = (float)c->rho;
@@ -2121,6 +2122,8 @@ __global__ void admm_ctl_init_kernel(AdmmCtl *c, const AdmmCtlInit in) {
 // tau is a T value (so 1 / tau is a T division) -- NumPy's scalar promotion rules.
 template <typename T>
 __global__ void admm_ctl_update_kernel(AdmmCtl *c, const double *sums, AdmmRecord *rec, int index) {
+    // (no fused multiply-adds: the host code this mirrors rounds every product)
+#pragma clang fp contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (c->stop) return;
     const double rho = c->rho;

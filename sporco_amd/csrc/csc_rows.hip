@@ -336,13 +336,14 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     const int w = sa_readfirstlane(tid >> 6);
     const int h = blockIdx.y;
     float thr = a.thr, usc = a.u_scale;
-    bool emit = EMIT_T;
     if (a.ctl) {
-        // device-driven solve: parameters and the speculation decision of this iteration
-        if (a.ctl->stop) return;
+        // device-driven solve: both variants are enqueued every iteration and the one whose
+        // EMIT_T matches the speculation decision runs (an idle launch costs about 12 us; the
+        // emitting variant keeps half as many Y / U loads in flight, so it is not the one to
+        // run when nothing is emitted)
+        if (a.ctl->stop | (a.ctl->emit != (EMIT_T ? 1 : 0))) return;
         thr = a.ctl->thr_f;
         usc = a.ctl->u_scale_f;
-        emit = EMIT_T && a.ctl->emit;
     }
     const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
     const bool pv = p < a.P;
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     // transform that follows and keeps every per-element term alive until then)
     SA_VGPR_FENCE3(s_r2, s_s2, s_x2);
     SA_VGPR_FENCE3(s_y2, s_u2, s_l1);
-    if (EMIT_T && emit) {
+    if (EMIT_T) {
         // Speculation on an unchanged rho: the row spectra of Y' - U' that the next
         // iteration's rows_fwd would compute from these very values, stored over the
         // units this thread consumed (same spectral-side ownership: in place is safe).
