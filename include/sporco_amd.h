@@ -514,6 +514,10 @@ int sporco_amd_inner(int dtype, int64_t npix, int64_t CN, int32_t K, const void 
                      const void *y, void *out);
 /* prox_l1 (sporco/prox/_lp.py:144-183), real v of n elements, scalar alpha. */
 int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *out);
+/* The same with an array-valued threshold (sporco/prox/_lp.py:144-183 accepts one): v viewed as
+ * a 5-D array of `shape`, alpha of `ashape` with extent 1 or the full extent on each axis. */
+int sporco_amd_prox_l1w(int dtype, const int64_t shape[5], const void *v, const int64_t ashape[5],
+                        const void *alpha, void *out);
 /* prox_sl1l2 (sporco/prox/_l21.py:51-88) with the l2 norm over the middle axis
  * of real v shaped (outer, C, inner). */
 int sporco_amd_prox_sl1l2(int dtype, int64_t outer, int32_t C, int64_t inner, const void *v,

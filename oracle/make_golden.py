@@ -378,6 +378,15 @@ def gen_dictlearn():
         D1 = b.solve()
         save(name, D0=D0, S=S, lmbda=np.float64(lmbda), D1=D1,
              X=b.getcoef(), **itstat_dict(b))
+    # ReturnX: the D-step is fed the X variable of the sparse coding step (dictlrn.py:379-382
+    # through admm.py:955-956), not the default Y
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+        {'MaxMainIter': 8, 'AccurateDFid': True, 'CBPDN': {'ReturnX': True}},
+        xmethod='admm', dmethod='pgm')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, lmbda, opt, xmethod='admm', dmethod='pgm')
+    D1 = b.solve()
+    save('cbpdndl_returnx_f64', D0=D0, S=S, lmbda=np.float64(lmbda), D1=D1, X=b.getcoef(),
+         recon=b.reconstruct(), **itstat_dict(b))
     # PGM D-step alone with known coefficients (pgm/ccmod.py)
     X = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
     opt = ref_pgm_ccmod.ConvCnstrMOD.Options({'MaxMainIter': 25, 'L': 800.0})

@@ -73,7 +73,7 @@ EXPORTS = (
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
-    'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_sl1l2',
+    'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_l1w', 'sporco_amd_prox_sl1l2',
     'sporco_amd_rfl2norm2',
 )
 
@@ -272,6 +272,7 @@ def load(path=None):
         'sporco_amd_solvedbi_sm': [ctypes.c_int, i64, i64, i32, vp, dbl, vp, vp],
         'sporco_amd_inner': [ctypes.c_int, i64, i64, i32, vp, vp, vp],
         'sporco_amd_prox_l1': [ctypes.c_int, i64, vp, dbl, vp],
+        'sporco_amd_prox_l1w': [ctypes.c_int, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), vp, vp],
         'sporco_amd_prox_sl1l2': [ctypes.c_int, i64, i32, i64, vp, dbl, dbl, vp],
         'sporco_amd_rfl2norm2': [ctypes.c_int, i32, i32, i64, vp, dptr],
     }

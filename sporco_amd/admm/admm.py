@@ -19,6 +19,31 @@ from .. import util
 from ..fft import real_dtype
 
 
+STEP_HOOKS = ('xstep', 'relax_AX', 'ystep', 'ustep', 'save_yprev', 'rsdl_r', 'rsdl_s', 'rsdl_rn',
+              'rsdl_sn', 'cnst_A', 'cnst_AT', 'cnst_B', 'cnst_c', 'obfn_f', 'obfn_g',
+              'obfn_fvar', 'obfn_gvar', 'obfn_g0', 'obfn_g1', 'obfn_g0var', 'obfn_g1var')
+
+
+def refuse_step_overrides(obj, names=STEP_HOOKS):
+    """For solver classes whose whole iteration is one device call: overriding or
+    monkey-patching a step method of the reference's template (admm.py:331-367) cannot take
+    effect, so it raises instead of being silently ignored.  An override is a definition of
+    the name anywhere below this package's classes, or on the instance."""
+    cls = type(obj)
+    for name in names:
+        if name in obj.__dict__:
+            raise NotImplementedError(
+                "%s: instance attribute %r replaces a step that runs on the device as part "
+                "of one fused call; it would have no effect" % (cls.__name__, name))
+        for c in cls.__mro__:
+            if name in c.__dict__:
+                if not c.__module__.startswith('sporco_amd.'):
+                    raise NotImplementedError(
+                        "%s.%s overrides a step that runs on the device as part of one fused "
+                        "call; it would have no effect" % (c.__name__, name))
+                break
+
+
 class ADMM(common.IterativeSolver):
     r"""Base class: minimise f(x) + g(y) subject to Ax + By = c."""
 

@@ -96,6 +96,12 @@ class GenericConvBPDN(admm.ADMMEqual):
                    'compute_residuals', 'residual_norms', 'eval_objfn', 'obfn_dfd',
                    'obfn_reg', 'iteration_stats', 'itstat_extra', 'rescale_u')
     _fused_base = None   # set after each fused-capable class definition
+    # methods whose arithmetic runs inside the device kernels on EVERY path (fused or staged):
+    # the objective terms and the residual definitions.  Overriding them cannot take effect
+    # here, so it is refused rather than silently ignored (the reference's own AddMaskSim
+    # patches obfn_gvar: that case is the FLAG_AMS treatment of this backend)
+    _device_only_names = ('obfn_gvar', 'obfn_fvar', 'obfn_f', 'obfn_g', 'rsdl_r', 'rsdl_s',
+                          'rsdl_rn', 'rsdl_sn', 'cnst_A', 'cnst_AT', 'cnst_B', 'cnst_c')
     # multi-channel dictionaries (cri.Cd > 1): X-step by iterated Sherman-Morrison
     # (linalg.solvemdbi_ism, cbpdn.py:277-279); the variants below that need a different
     # system matrix switch this off
@@ -290,6 +296,9 @@ class GenericConvBPDN(admm.ADMMEqual):
                 return False
         return True
 
+    def _check_device_only_hooks(self):
+        admm.refuse_step_overrides(self, self._device_only_names)
+
     def iteration(self):
         if not self._fused_ok():
             return super(GenericConvBPDN, self).iteration()
@@ -330,6 +339,7 @@ class GenericConvBPDN(admm.ADMMEqual):
         assembled from the per-iteration records afterwards (identical values; ``Time`` from
         the device clock; the ``solve_wo_func`` / ``solve_wo_rsdl`` timers then equal
         ``solve``)."""
+        self._check_device_only_hooks()
         if not self._device_loop_ok():
             return super(GenericConvBPDN, self).solve()
         o = self.opt
@@ -394,6 +404,8 @@ class GenericConvBPDN(admm.ADMMEqual):
     def xstep(self):
         """Y - U -> rfftn -> Sherman-Morrison -> irfftn (cbpdn.py:267-293)."""
         out = self._dev.admm_xstep(self._params())
+        if self._reducer is not None:       # image shards: the sums of the other ranks
+            out = self._reducer.sum(out)
         for slot in (_lib.OUT_DFID, _lib.OUT_XRRS_D2, _lib.OUT_XRRS_AX2, _lib.OUT_XRRS_B2,
                      _lib.OUT_RGR):
             self._sums[slot] = out[slot]
@@ -842,6 +854,7 @@ class ConvBPDNMaskDcpl(ConvBPDN):
 
     # -- iteration ----------------------------------------------------------------------------
     def iteration(self):
+        admm.refuse_step_overrides(self)
         p = self._params()
         flags = 0
         if self.opt['NonNegCoef']:

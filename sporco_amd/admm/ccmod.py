@@ -218,6 +218,7 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
 
     # -- iteration --------------------------------------------------------------------------
     def iteration(self):
+        admm.refuse_step_overrides(self)
         flags = 0
         if self._needs_residuals():
             flags |= _lib.FLAG_RESID
@@ -351,6 +352,7 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
         return 1e-3, 1000
 
     def iteration(self):
+        admm.refuse_step_overrides(self)
         flags = 0
         if not self.opt['FastSolve']:
             flags |= _lib.FLAG_OBJ

@@ -149,6 +149,7 @@ class ConvCnstrMODMaskDcplBase(ccmod.ConvCnstrMODBase):
 
     # -- iteration ----------------------------------------------------------------------------
     def iteration(self):
+        admm.refuse_step_overrides(self)
         flags = 0
         if not self.opt['FastSolve']:
             flags |= _lib.FLAG_OBJ

@@ -299,6 +299,9 @@ template <typename T> struct Csc : CscBase {
     // X-step on it with the parameters of the iteration (`last_p`).
     T *y_alt = nullptr, *u_alt = nullptr;
     bool x_stale = false, x_invalid = false;
+    // after a three-launch iteration the previous iterate sits in y_alt and AX was never
+    // formed: a host read of VAR_YPREV / VAR_AX derives them (download)
+    bool prev_in_alt = false;
     // t_ready: the Xf buffer already holds rows_fwd(Y, U, s = 1) of the current
     // iterate, emitted by the previous rows_inv_post on the bet that rho stays put
     bool t_ready = false;
@@ -574,6 +577,7 @@ template <typename T> struct Csc : CscBase {
     void before_state_change() {
         if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
         t_ready = false;
+        prev_in_alt = false;
     }
     void x_written() {
         x_stale = false;
@@ -792,6 +796,20 @@ template <typename T> struct Csc : CscBase {
         sync();
     }
     void download(int var, void *dst) override {
+        if (prev_in_alt && y_alt && (var == SPORCO_AMD_VAR_YPREV || var == SPORCO_AMD_VAR_AX)) {
+            // Yprev = the other half of the (Y, U) ping-pong; AX = rlx X + (1 - rlx) Yprev
+            // (admm.py:877-885) with X rebuilt from that same previous iterate
+            if (var == SPORCO_AMD_VAR_YPREV) {
+                SA_HIP(hipMemcpyAsync(rv(var), y_alt, sizeof(T) * E, hipMemcpyDeviceToDevice, st));
+            } else {
+                const bool keep = prev_in_alt;
+                materialize_x();
+                prev_in_alt = keep;
+                ProfScope ps(prof, PS_OTHER);
+                launch_relax<T>(st, rv(SPORCO_AMD_VAR_X), y_alt, rv(SPORCO_AMD_VAR_AX),
+                                (T)last_p.rlx, E);
+            }
+        }
         before_read(var);
         host_copy(var, dst, false);
         sync();
@@ -1012,6 +1030,7 @@ template <typename T> struct Csc : CscBase {
             last_p = p;
             x_stale = true;
             x_invalid = p.flags & F_NO_X;
+            prev_in_alt = true;
         }
         t_ready = emit;
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
@@ -1234,6 +1253,7 @@ template <typename T> struct Csc : CscBase {
         last_p.u_scale = rec_ring[n - 1].u_scale;
         x_stale = true;
         x_invalid = p.flags & F_NO_X;
+        prev_in_alt = true;
         return n;
     }
 
@@ -3340,6 +3360,34 @@ template <typename T> void prim_prox_l1(int64_t n, const void *v, double alpha, 
     SA_HIP(hipMemcpy(out, dv.p, sizeof(T) * n, hipMemcpyDeviceToHost));
 }
 
+// array-valued threshold: alpha has extent 1 or the full extent on each of the five axes
+template <typename T>
+void prim_prox_l1w(const int64_t *shape, const void *v, const int64_t *ashape, const void *alpha,
+                   void *out) {
+    int64_t n = 1, na = 1;
+    for (int i = 0; i < 5; ++i) {
+        SA_REQUIRE(shape[i] >= 1 && shape[i] < ((int64_t)1 << 31), "bad shape");
+        SA_REQUIRE(ashape[i] == 1 || ashape[i] == shape[i],
+                   "alpha must have extent 1 or the full extent on every axis");
+        n *= shape[i];
+        na *= ashape[i];
+    }
+    DevBuf dv(sizeof(T) * n), da(sizeof(T) * na), dpart(sizeof(double) * kMaxPartialBlocks);
+    SA_HIP(hipMemcpy(dv.p, v, sizeof(T) * n, hipMemcpyHostToDevice));
+    SA_HIP(hipMemcpy(da.p, alpha, sizeof(T) * na, hipMemcpyHostToDevice));
+    Weight<T> w;
+    w.ptr = da.as<T>();
+    int64_t st = 1;
+    for (int i = 4; i >= 0; --i) {
+        w.stride[i] = ashape[i] == 1 ? 0 : st;
+        st *= ashape[i];
+    }
+    Dims5 d{(int)shape[0], (int)shape[1], (int)shape[2], (int)shape[3], (int)shape[4]};
+    launch_prox_l1<T>(nullptr, dv.as<T>(), dv.as<T>(), T(1), 0u, d, 1, 1, w, dpart.as<double>());
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(out, dv.p, sizeof(T) * n, hipMemcpyDeviceToHost));
+}
+
 template <typename T>
 void prim_prox_sl1l2(int64_t outer, int C, int64_t inner, const void *v, double alpha, double beta,
                      void *out) {
@@ -3412,6 +3460,14 @@ int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *
     SA_API_BEGIN
     SA_REQUIRE(v && out && n >= 1, "bad argument");
     SA_DISPATCH(dtype, prim_prox_l1, n, v, alpha, out)
+    SA_API_END
+}
+
+int sporco_amd_prox_l1w(int dtype, const int64_t shape[5], const void *v, const int64_t ashape[5],
+                        const void *alpha, void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(shape && v && ashape && alpha && out, "null argument");
+    SA_DISPATCH(dtype, prim_prox_l1w, shape, v, ashape, alpha, out)
     SA_API_END
 }
 

@@ -161,9 +161,10 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         bk = {} if reducer is None else {'reducer': reducer}
         xstep = ConvBPDN(D0, S, lmbda, opt['CBPDN'], method=xmethod, dimK=dimK, dimN=dimN,
                          device=device, stream=stream, **bk)
-        if xmethod == 'admm':
+        if xmethod == 'admm' and not opt['CBPDN', 'ReturnX']:
             # the alternation only ever consumes Y (var_y) of the X-step: tell the
-            # device that X / Xf of the inner iterations are never read
+            # device that X / Xf of the inner iterations are never read.  (With ReturnX the
+            # D-step is fed xstep.getcoef() = X, as in the reference, dictlrn.py:379-382.)
             xstep._no_x = True
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
         xdev = getattr(xdev, '_raw', xdev)     # (the D-step's own sums are reduced explicitly)
@@ -182,7 +183,16 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
 
     # -- coupling between the two steps, kept on the device -------------------------------
     def _coef_var(self):
-        return _lib.VAR_Y if self.xmethod == 'admm' else _lib.VAR_X
+        """The device array behind ``xstep.getcoef()``: X for the PGM X-step, and for the ADMM
+        ones what ``ReturnX`` / ``ReturnVar`` select (admm.py:955-956, cbpdn.py:1693-1704)."""
+        if self.xmethod != 'admm':
+            return _lib.VAR_X
+        o = self.xstep.opt
+        if 'ReturnVar' in o:
+            if o['ReturnVar'] == 'Y0':
+                raise NotImplementedError("ReturnVar 'Y0' is not a coefficient array")
+            return _lib.VAR_X if o['ReturnVar'] == 'X' else _lib.VAR_Y
+        return _lib.VAR_X if o['ReturnX'] else _lib.VAR_Y
 
     def post_xstep(self):
         """dstep.setcoef(xstep.getcoef()) (dictlrn.py:379-382) without the host trip."""
@@ -208,8 +218,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
     def reconstruct(self, D=None, X=None):
         """irfftn(sum_m rfftn(D) rfftn(X)) (cbpdndl.py:486-498)."""
         if D is None and X is None:
-            return self.xstep._dev.reconstruct(_lib.VAR_Y)[..., 0] if self.xmethod == 'admm' \
-                else self.xstep.dev.reconstruct(_lib.VAR_X)[..., 0]
+            dev = self.xstep._dev if self.xmethod == 'admm' else self.xstep.dev
+            return dev.reconstruct(self._coef_var())      # (5-D, as the reference's inner())
         if D is None:
             D = self.getdict(crop=False)
         if X is None:
@@ -226,6 +236,16 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         if not self.opt['AccurateDFid']:
             return None
         dev = self.dstep.dev
+        if self.xmethod == 'admm' and self._coef_var() != _lib.VAR_Y:
+            # ReturnX: the D-step was given X, but the reference evaluates at var_y()
+            # (cbpdndl.py:509-511): reconstruct D * Y with the new dictionary (the X-step
+            # already has it) and take the residual in the spatial domain -- signal sized
+            rec = self.xstep._dev.reconstruct(_lib.VAR_Y)
+            dfd = 0.5 * float(np.sum((rec.astype(np.float64) - self.xstep.S) ** 2))
+            rl1 = dev.asum(_lib.VAR_Y)
+            if self._reducer is not None:
+                dfd, rl1 = self._reducer.sum([dfd, rl1])
+            return dict(DFid=dfd, RegL1=rl1, ObjFun=dfd + self.xstep.lmbda * rl1)
         dfd = dev.ccmod_eval(_lib.VAR_DXF)[_lib.PGM_DFID] / 2.0
         rl1 = dev.asum(self._coef_var())
         if self._reducer is not None:

@@ -21,13 +21,29 @@ def _real(v):
 
 
 def prox_l1(v, alpha):
-    """sign(v) * max(|v| - alpha, 0)."""
-    if np.ndim(alpha) != 0:
-        raise NotImplementedError("array-valued alpha is handled inside the solvers only")
+    """sign(v) * max(|v| - alpha, 0); ``alpha`` a scalar or an array that broadcasts against
+    ``v`` (sporco/prox/_lp.py:144-183)."""
     v = _real(v)
     out = np.empty_like(v)
-    _lib.check(_lib.lib().sporco_amd_prox_l1(_lib.dtype_code(v.dtype), v.size, _lib._ptr(v),
-                                             float(alpha), _lib._ptr(out)))
+    if np.ndim(alpha) == 0:
+        _lib.check(_lib.lib().sporco_amd_prox_l1(_lib.dtype_code(v.dtype), v.size, _lib._ptr(v),
+                                                 float(alpha), _lib._ptr(out)))
+        return out
+    a = np.asarray(alpha, dtype=v.dtype)
+    if a.ndim > v.ndim or np.broadcast_shapes(a.shape, v.shape) != v.shape:
+        raise ValueError("alpha of shape %s does not broadcast against v of shape %s"
+                         % (a.shape, v.shape))
+    a = a.reshape((1,) * (v.ndim - a.ndim) + a.shape)
+    if v.ndim <= 5:
+        vs = [1] * (5 - v.ndim) + list(v.shape)
+        as_ = [1] * (5 - v.ndim) + [na if nv > 1 else 1 for nv, na in zip(v.shape, a.shape)]
+    else:           # more than five axes: expand alpha (no compact 5-D form in general)
+        a = np.broadcast_to(a, v.shape)
+        vs, as_ = [1, 1, 1, 1, v.size], [1, 1, 1, 1, v.size]
+    i64 = _lib.ctypes.c_int64
+    _lib.check(_lib.lib().sporco_amd_prox_l1w(_lib.dtype_code(v.dtype), (i64 * 5)(*vs), _lib._ptr(v),
+                                              (i64 * 5)(*as_), _lib._ptr(np.ascontiguousarray(a)),
+                                              _lib._ptr(out)))
     return out
 
 

@@ -31,6 +31,43 @@ def main():
     np.savez(out_path + '.%d.npz' % rank, Y=Y, ObjFun=np.array(its.ObjFun),
              Rho=np.array(its.Rho), PrimalRsdl=np.array(its.PrimalRsdl),
              DualRsdl=np.array(its.DualRsdl), k=b.k)
+    # the staged path (a step method overridden => one device call per step) under sharding:
+    # the X-step's own sums (data fidelity) are all-reduced like the residual sums
+
+    class Hooked(cbpdn.ConvBPDN):
+        def ystep(self):
+            super(Hooked, self).ystep()
+    h = Hooked(g['D'], S, float(g['lmbda']), cbpdn.ConvBPDN.Options({'MaxMainIter': 25}),
+               reducer=TorchReducer())
+    assert not h._fused_ok()
+    Yh = h.solve()
+    its = h.getitstat()
+    np.savez(out_path + '.hook.%d.npz' % rank, Y=Yh, ObjFun=np.array(its.ObjFun),
+             DFid=np.array(its.DFid), Rho=np.array(its.Rho), k=h.k)
+    # the device-driven loop (three-launch float32 path) under sharding: one image per rank,
+    # the all-reduce hooked in between the local sums and the device-side control update
+    rng = np.random.RandomState(99)
+    Df = rng.randn(4, 4, 4).astype(np.float32)
+    Df /= np.sqrt(np.sum(Df ** 2, axis=(0, 1), keepdims=True))
+    Sf = rng.randn(256, 256, 2).astype(np.float32)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0}
+    bd = cbpdn.ConvBPDN(Df, shard_images(Sf, rank, world, axis=-1), 0.05,
+                        cbpdn.ConvBPDN.Options(optd), reducer=TorchReducer())
+    assert bd._device_loop_ok() and bd._dev.uses_fused_rows()
+    assert bd._reducer.device_sum_hook(bd._dev) is not None
+    Yd = bd.solve()
+    its = bd.getitstat()
+    out = dict(Y=Yd, k=bd.k, **{f: np.asarray(getattr(its, f), dtype=float)
+                                for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho')})
+    if rank == 0:       # the single-process run of both images, host-driven loop
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+        b1 = cbpdn.ConvBPDN(Df, Sf, 0.05, cbpdn.ConvBPDN.Options(optd))
+        out['Y_single'] = b1.solve()
+        i1 = b1.getitstat()
+        out.update({f + '_single': np.asarray(getattr(i1, f), dtype=float)
+                    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho')})
+        os.environ.pop('SPORCO_AMD_HOST_LOOP')
+    np.savez(out_path + '.devloop.%d.npz' % rank, **out)
     # dictionary learning, four images over the two ranks: X-step sums and the D-step
     # gradient are all-reduced, the dictionary is replicated
     from sporco_amd.dictlrn import cbpdndl

@@ -358,3 +358,41 @@ def test_abi_error_paths_of_the_widened_calls(backend):
     fresh.cns_init(None, 1.0)
     with pytest.raises(_lib.BackendError):
         fresh.cns_iter(1.0, 1.8, 1.0, _lib.FLAG_RESID, 5, 5, False)
+
+
+def test_yprev_and_ax_after_fused_iterations_and_refused_overrides(backend):
+    """Callbacks that read b.Yprev / b.AX get the reference's values although the three-launch
+    iteration never forms them (Yprev: the other half of the (Y, U) ping-pong; AX = rlx X +
+    (1 - rlx) Yprev, admm.py:877-885).  Overrides of methods that only exist inside the device
+    kernels are refused instead of being ignored."""
+    from sporco_amd.admm import cbpdn
+    from oracle import cbpdn_oracle as orc
+    H = 256 if backend == 'gpu' else 256
+    rng = np.random.RandomState(17)
+    D = rng.randn(4, 4, 4).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, H, 1).astype(np.float32)
+    iters = 3
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options({'MaxMainIter': iters, 'RelStopTol': 0.0}))
+    assert b._dev.uses_fused_rows()
+    b.solve()
+    ref_prev = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, 4), S.reshape(H, H, 1, 1, 1), 0.05,
+                              dtype=np.float64, maxiter=iters - 1, rel_tol=0.0)
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, 4), S.reshape(H, H, 1, 1, 1), 0.05,
+                         dtype=np.float64, maxiter=iters, rel_tol=0.0)
+    assert rel_l2(b.Yprev, ref_prev['Y']) < 1e-5
+    ax = 1.8 * ref['X'] - 0.8 * ref_prev['Y']
+    assert rel_l2(b.AX, ax) < 1e-5
+    assert rel_l2(b.Y, ref['Y']) < 1e-5 and rel_l2(b.X, ref['X']) < 1e-5
+
+    class Patched(cbpdn.ConvBPDN):
+        def obfn_gvar(self):
+            return self.Y
+    p = Patched(D, S, 0.05, cbpdn.ConvBPDN.Options({'MaxMainIter': 1}))
+    with pytest.raises(NotImplementedError):
+        p.solve()
+    m = cbpdn.ConvBPDNMaskDcpl(D, S, 0.05, np.ones((H, H, 1), np.float32),
+                               cbpdn.ConvBPDNMaskDcpl.Options({'MaxMainIter': 1}))
+    m.ystep = lambda: None
+    with pytest.raises(NotImplementedError):
+        m.solve()

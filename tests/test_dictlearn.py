@@ -65,6 +65,25 @@ def test_dictlearn_trace(backend, name, dt, tol):
     assert rec.shape == S.shape
 
 
+def test_dictlearn_returnx_feeds_x_to_the_dstep(backend):
+    """CBPDN option ReturnX: xstep.getcoef() -- what the D-step receives, dictlrn.py:379-382 --
+    is the X variable, not Y; the learned dictionary then differs from the default run."""
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden('cbpdndl_returnx_f64')
+    opt = cbpdndl.ConvBPDNDictLearn.Options(
+        {'MaxMainIter': 8, 'AccurateDFid': True, 'CBPDN': {'ReturnX': True}},
+        xmethod='admm', dmethod='pgm')
+    b = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], float(g['lmbda']), opt, xmethod='admm',
+                                  dmethod='pgm')
+    D1 = b.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(b.getcoef(), g['X']) < 1e-9
+    assert b.reconstruct().shape == g['recon'].shape and rel_l2(b.reconstruct(), g['recon']) < 1e-9
+    errs = trace_errors(b.getitstat(), g)
+    assert max(errs.values()) < 1e-9, errs
+    assert rel_l2(D1.squeeze(), load_golden('cbpdndl_f64')['D1'].squeeze()) > 1e-3
+
+
 def test_dictlearn_variants_run(backend):
     """Option plumbing of the reference's tests/dictlrn/test_cbpdndl.py: PGM
     X-step, backtracking D-step, DictSize, inaccurate DFid, callback stop."""

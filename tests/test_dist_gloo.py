@@ -19,7 +19,7 @@ def test_two_rank_image_sharding(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', '29613',
            os.path.join(REPO, 'tests', '_dist_worker.py'), out]
-    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=REPO)
+    subprocess.run(cmd, check=True, env=env, timeout=900, cwd=REPO)
     g = load_golden('admm_multichan_f64')
     parts = [np.load(out + '.%d.npz' % r) for r in range(2)]
     Y = np.concatenate([p['Y'] for p in parts], axis=3)      # axisK = image axis
@@ -30,6 +30,23 @@ def test_two_rank_image_sharding(tmp_path):
         assert rel_l2(p['Rho'], g['it_Rho']) < 1e-9
         assert rel_l2(p['PrimalRsdl'], g['it_PrimalRsdl']) < 1e-9
         assert rel_l2(p['DualRsdl'], g['it_DualRsdl']) < 1e-9
+    # staged path (overridden step) under sharding
+    hp = [np.load(out + '.hook.%d.npz' % r) for r in range(2)]
+    assert rel_l2(np.concatenate([p['Y'] for p in hp], axis=3), g['Y']) < 1e-9
+    for p in hp:
+        assert int(p['k']) == int(g['k_final'])
+        for f in ('ObjFun', 'DFid', 'Rho'):
+            assert rel_l2(p[f], g['it_' + f]) < 1e-9, f
+    # device-driven loop under sharding == single-process host-driven loop on both images
+    # (same float32 kernels; the sums differ only in the order the two images are added)
+    dp = [np.load(out + '.devloop.%d.npz' % r) for r in range(2)]
+    Ys = dp[0]['Y_single']
+    assert rel_l2(np.concatenate([p['Y'] for p in dp], axis=3), Ys) < 1e-6
+    for p in dp:
+        assert int(p['k']) == 3
+        for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+            assert rel_l2(p[f], dp[0][f + '_single']) < 1e-6, f
+            assert np.array_equal(p[f], dp[0][f])              # identical on every rank
     # dictionary learning: both ranks hold the dictionary of the single-process run, each its
     # own images' coefficient maps; every statistic is the global one
     g = load_golden('cbpdndl_shard_f64')
