@@ -411,7 +411,33 @@ typedef struct {
     uint32_t flags;  /* SPORCO_AMD_FLAG_RESID | SPORCO_AMD_FLAG_OBJ                     */
     int32_t dH, dW;  /* filter support of the constraint set                            */
     int32_t zero_mean;
+    int32_t mask_dcpl;  /* 1: ConvCnstrMODMaskDcpl_Consensus (sporco/admm/ccmodmd.py:766-1083), the
+                           consensus update with the masked data fidelity split off into a
+                           signal-sized block (Y1, U1 = VAR_DMY0, VAR_DMU0; mask by
+                           sporco_amd_csc_set_data_mask; state by sporco_amd_csc_cns_md_init).
+                           out then holds: R2 = sum_n |X_n - Y|^2, AX2 = sum_n |X_n|^2, Y2 = |Y|^2,
+                           U2 = sum_n |U_n|^2, S2 = Parseval sum of |rfftn(U_n) + conj(Zf_n)
+                           rfftn(U1_n)|^2 / (H W) (the dual residual's A^T u, :993-996), and for
+                           the signal-sized block XRRS_D2 = |AX1nr - Y1 - S|^2, XRRS_AX2 =
+                           |AX1nr|^2, XRRS_B2 = |Y1|^2, CGIT = |U1|^2; DFID = |W irfftn(sum_m Zf Yf
+                           - Sf)|^2 (:961-970), CNSTR as for the unmasked update.              */
+    int32_t phase;      /* image shards over ranks (one process per GPU): 0 = the whole iteration;
+                           1 = up to the local mean over this rank's images of alpha X_n +
+                           (1 - alpha) Y + U_n, left in the buffer of sporco_amd_csc_cns_mean_ptr;
+                           2 = the rest (constraint projection, dual update, sums), after the
+                           caller has made that buffer the mean over ALL images -- the consensus
+                           average is the one array all-reduce of this update (SURVEY.md 8(e);
+                           reference: admm.py:1585-1591).  The X-sized sums of phase 2 are
+                           rank-local and are added over the ranks by the caller; S2, Y2 and
+                           CNSTR of the unmasked update are dictionary sized (identical on every
+                           rank). */
 } sporco_amd_cns_params;
+/* The dictionary-sized real buffer (H, W, K) that holds the consensus mean between the two
+ * phases, and its element count. */
+int sporco_amd_csc_cns_mean_ptr(sporco_amd_csc_t h, void **ptr_dev, int64_t *count);
+/* State of the masked consensus update: the real signal S (H,W,C,N) kept on the device, Y1 = U1 = 0
+ * (ccmodmd.py:869-871).  Call after sporco_amd_csc_cns_init. */
+int sporco_amd_csc_cns_md_init(sporco_amd_csc_t h, const void *S);
 /* One iteration: xstep per image by Sherman-Morrison (ccmod.py:766-778), relax_AX
  * (admm.py:1608-1616), ystep Y = Pcn(mean_n(AX_n + U_n)) (admm.py:1585-1591, ccmod.py:832-835),
  * ustep.  out: R2 = sum_n |X_n - Y|^2, S2 = |Y - Yprev|^2, AX2 = sum_n |X_n|^2, Y2 = |Y|^2,

@@ -625,6 +625,44 @@ def gen_shard():
              X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_shard_cns():
+    """The consensus dictionary updates on FOUR images in one process: what their two-rank
+    image-sharded runs (the consensus average as an all-reduce) must reproduce."""
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    np.random.seed(2424)
+    N, M, Nd, K = 16, 4, 5, 4
+    D0 = np.random.randn(Nd, Nd, M)
+    S = np.random.randn(N, N, K)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    Wd = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    autorho = {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+               'AutoScaling': True, 'RsdlTarget': 1.0}
+    optd = {'MaxMainIter': 15, 'ZeroMean': True, 'AutoRho': autorho}
+    c = ref_admm_ccmod.ConvCnstrMOD_Consensus(Z, S, (Nd, Nd, M),
+                                               ref_admm_ccmod.ConvCnstrMOD_Consensus.Options(optd))
+    c.solve()
+    save('ccmod_cns_shard_f64', Z=Z, S=S, dsz=np.array((Nd, Nd, M)), D=c.getdict(), Y=c.Y,
+         k_final=np.int64(c.k), **itstat_dict(c))
+    cm = ref_ccmodmd.ConvCnstrMODMaskDcpl_Consensus(
+        Z, S, Wd, (Nd, Nd, M), ref_admm_ccmod.ConvCnstrMOD_Consensus.Options(optd))
+    cm.solve()
+    save('ccmodmd_cns_shard_f64', Z=Z, S=S, W=Wd, dsz=np.array((Nd, Nd, M)), D=cm.getdict(),
+         Y=cm.Y, k_final=np.int64(cm.k), **itstat_dict(cm))
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                                xmethod='admm', dmethod='cns')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod='cns')
+    D1 = b.solve()
+    save('cbpdndl_shard_cns_f64', D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(),
+         **itstat_dict(b))
+    opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                               xmethod='admm', dmethod='cns')
+    b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, Wd, opt, xmethod='admm', dmethod='cns')
+    D1 = b.solve()
+    save('cbpdndlmd_shard_cns_f64', D0=D0, S=S, W=Wd, lmbda=np.float64(0.1), D1=D1,
+         X=b.getcoef(), **itstat_dict(b))
+
+
 def gen_maskdcpl():
     """admm.cbpdn.ConvBPDNMaskDcpl (sporco/admm/cbpdn.py:2066-2283): mask decoupling, the ADMM
     X-step of masked dictionary learning.  SURVEY.md 8(f) rank 3."""
@@ -733,6 +771,52 @@ def gen_ccmodmd():
          X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_ccmodmd_cns():
+    """ConvCnstrMODMaskDcpl_Consensus (sporco/admm/ccmodmd.py:766-1083): the hybrid consensus /
+    mask-decoupling dictionary update, alone and as dmethod='cns' of ConvBPDNMaskDictLearn with
+    either X-step (sporco/dictlrn/cbpdndlmd.py:130-132, :474).  SURVEY.md 8(f) rank 3."""
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    np.random.seed(14142)
+    N, M, Nd, K = 16, 4, 5, 3
+    S = np.random.randn(N, N, K)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    W = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    Wb = (np.random.rand(N, N) > 0.3).astype(np.float64)          # one mask for all images
+    D0 = np.random.randn(Nd, Nd, M)
+    autorho = {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+               'AutoScaling': True, 'RsdlTarget': 1.0}
+    cls = ref_ccmodmd.ConvCnstrMODMaskDcpl_Consensus
+    for name, WW, optd in (
+            ('f64', W, {'MaxMainIter': 20}),
+            ('f32', W, {'MaxMainIter': 20, 'DataType': np.float32}),
+            ('opts_f64', Wb, {'MaxMainIter': 20, 'rho': 3.0, 'RelaxParam': 1.5,
+                              'ZeroMean': True, 'AutoRho': autorho}),
+            ('std_f64', W, {'MaxMainIter': 20, 'AbsStopTol': 1e-4, 'RelStopTol': 1e-3,
+                            'AutoRho': dict(autorho, StdResiduals=True, AutoScaling=False)})):
+        opt = cls.Options(optd)
+        c = cls(Z, S, WW, (Nd, Nd, M), opt)
+        c.solve()
+        save('ccmodmd_cns_%s' % name, Z=Z, S=S, W=WW, dsz=np.array((Nd, Nd, M)),
+             D=c.getdict(), Y=c.Y, X=c.X, U=c.U, Y1=c.Y1, U1=c.U1, rho_final=np.float64(c.rho),
+             k_final=np.int64(c.k), **itstat_dict(c))
+    for xm in ('admm', 'pgm'):
+        opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                                   xmethod=xm, dmethod='cns')
+        b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, W, opt, xmethod=xm, dmethod='cns')
+        D1 = b.solve()
+        save('cbpdndlmd_%s_cns_f64' % xm, D0=D0, S=S, W=W, lmbda=np.float64(0.1), D1=D1,
+             X=b.getcoef(), **itstat_dict(b))
+    # two-channel signal, single-channel dictionary (channels fold into the consensus blocks)
+    Sc = np.random.randn(N, N, 2, 2)
+    Wc = (np.random.rand(N, N, 2, 2) > 0.3).astype(np.float64)
+    Zc = np.random.randn(N, N, 2, 2, M) * (np.random.rand(N, N, 2, 2, M) > 0.7)
+    c = cls(Zc, Sc, Wc, (Nd, Nd, M), cls.Options({'MaxMainIter': 12}))
+    c.solve()
+    save('ccmodmd_cns_chan_f64', Z=Zc, S=Sc, W=Wc, dsz=np.array((Nd, Nd, M)), D=c.getdict(),
+         Y=c.Y, rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+
+
 def gen_signal():
     """Pre/post-processing around the solver: signal.tikhonov_filter
     (sporco/signal.py:244-301), fft.fftconv (sporco/fft.py:376-417), signal.gradient_filters."""
@@ -814,10 +898,11 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'signal', 'mask']
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
+             'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
              'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

@@ -67,7 +67,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
-    'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter',
+    'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter', 'sporco_amd_csc_cns_md_init', 'sporco_amd_csc_cns_mean_ptr',
     'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter', 'sporco_amd_csc_ccmod_sgd_step',
     'sporco_amd_csc_mdcpl_init', 'sporco_amd_csc_mdcpl_iter', 'sporco_amd_csc_dstep_md_init',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
@@ -96,7 +96,8 @@ class PgmParams(ctypes.Structure):
 class CnsParams(ctypes.Structure):
     _fields_ = [('rho', ctypes.c_double), ('rlx', ctypes.c_double), ('u_scale', ctypes.c_double),
                 ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32), ('dW', ctypes.c_int32),
-                ('zero_mean', ctypes.c_int32)]
+                ('zero_mean', ctypes.c_int32), ('mask_dcpl', ctypes.c_int32),
+                ('phase', ctypes.c_int32)]
 
 
 class DstepParams(ctypes.Structure):
@@ -252,6 +253,8 @@ def load(path=None):
         'sporco_amd_csc_ccmod_cnstr': [vp, i32, i32, i32, dptr],
         'sporco_amd_csc_ccmod_getdict': [vp, i32, i32, vp],
         'sporco_amd_csc_cns_init': [vp, vp, dbl],
+        'sporco_amd_csc_cns_md_init': [vp, vp],
+        'sporco_amd_csc_cns_mean_ptr': [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)],
         'sporco_amd_csc_set_data_mask': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_masked_grad': [vp, ctypes.c_int, i32, i32, dptr],
         'sporco_amd_csc_cns_iter': [vp, ctypes.POINTER(CnsParams), dptr],
@@ -599,10 +602,25 @@ class Solver(object):
         Y0 = _carr(Y0, self.dtype).reshape(H, W, K)
         check(self._lib.sporco_amd_csc_cns_init(self._h, _ptr(Y0), float(rho)))
 
-    def cns_iter(self, rho, rlx, u_scale, flags, dH, dW, zero_mean):
-        """One consensus D-step iteration (sporco_amd_csc_cns_iter)."""
+    def cns_md_init(self, S):
+        """State of the masked consensus D-step: the real signal on the device, Y1 = U1 = 0."""
+        H, W, C, N, K = self.dims
+        S = _carr(S, self.dtype)
+        if S.size != H * W * self.Cs * N:
+            raise ValueError("signal of shape %s does not match the solver" % (S.shape,))
+        check(self._lib.sporco_amd_csc_cns_md_init(self._h, _ptr(S)))
+
+    def cns_mean_ptr(self):
+        """(device address, element count) of the consensus-mean buffer (phase 1 -> phase 2)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64(0)
+        check(self._lib.sporco_amd_csc_cns_mean_ptr(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def cns_iter(self, rho, rlx, u_scale, flags, dH, dW, zero_mean, mask_dcpl=False, phase=0):
+        """One consensus D-step iteration (sporco_amd_csc_cns_iter), or one of its two phases
+        when the images are sharded over ranks."""
         p = CnsParams(float(rho), float(rlx), float(u_scale), int(flags), int(dH), int(dW),
-                      1 if zero_mean else 0)
+                      1 if zero_mean else 0, 1 if mask_dcpl else 0, int(phase))
         out = self._out()
         check(self._lib.sporco_amd_csc_cns_iter(self._h, ctypes.byref(p), out))
         return list(out)

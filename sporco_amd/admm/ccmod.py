@@ -149,10 +149,22 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
                 self['fEvalX'] = value is not True
                 self['gEvalY'] = value is True
 
-    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
+    # sums of one iteration that are rank-local when the images are sharded (the others are
+    # dictionary sized, i.e. identical on every rank)
+    _shard_slots = (_lib.OUT_R2, _lib.OUT_AX2, _lib.OUT_U2, _lib.OUT_DFID)
+    _mask_dcpl = False
+
+    def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None,
+                 reducer=None):
         """``Z, S, dsz, opt, dimK, dimN`` as in the reference (ccmod.py:653-712).  Backend
-        keyword ``dev``: a :class:`sporco_amd._lib.Solver` to share with the sparse coding
-        step, so that coefficient maps and dictionary stay on the GPU."""
+        keywords: ``dev``, a :class:`sporco_amd._lib.Solver` to share with the sparse coding
+        step, so that coefficient maps and dictionary stay on the GPU; ``reducer``
+        (:class:`sporco_amd.dist.TorchReducer`), one process per GPU with ``S`` / ``Z`` holding
+        this rank's images: the consensus average over the images -- the ystep of
+        admm.py:1585-1591 -- becomes one all-reduce of a dictionary-sized array per iteration
+        (SURVEY.md 8(e)), the X-sized sums are added over the ranks, and every rank holds
+        the same dictionary."""
+        self._reducer = reducer
         if opt is None:
             opt = ConvCnstrMOD_Consensus.Options()
         if dimN != 2:
@@ -173,8 +185,11 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         self._attach_device(S, dev, device, stream)     # one consensus block per image
         self.yshape = self.cri.shpD
         self.xshape = self.cri.shpD + (self.Nb,)
-        Nx = self.Nb * int(np.prod(self.yshape))
+        # (blocks of the whole problem: the residual scalings and tolerances refer to them)
+        self._nb_all = self.Nb * (1 if reducer is None else reducer.world_size)
+        Nx = self._nb_all * int(np.prod(self.yshape))
         super(ConvCnstrMOD_Consensus, self).__init__(Nx, self.yshape, self.xshape, S.dtype, opt)
+        self.Nc = self._nb_all * int(np.prod(self.yshape))
         # (the reference's `dval=cri.K` at ccmod.py:700 never takes effect: the base class has
         # already set rho, default 1.0)
         self.xrrs = None
@@ -224,8 +239,7 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
             flags |= _lib.FLAG_RESID
         if not self.opt['FastSolve']:
             flags |= _lib.FLAG_OBJ
-        self._sums = self.dev.cns_iter(self.rho, self.rlx, self._u_scale, flags,
-                                       self.cri.dsz[0], self.cri.dsz[1], self.opt['ZeroMean'])
+        self._sums = self._device_iteration(flags)
         self._u_scale = 1.0
         self._cache.clear()
         if not self._needs_residuals():
@@ -235,10 +249,24 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         self.timer.start('solve_wo_rsdl')
         return res
 
+    def _device_iteration(self, flags):
+        """One ``sporco_amd_csc_cns_iter`` call -- or, with image shards, its two phases around
+        the all-reduce that turns the rank-local mean into the consensus average."""
+        args = (self.rho, self.rlx, self._u_scale, flags, self.cri.dsz[0], self.cri.dsz[1],
+                self.opt['ZeroMean'])
+        if self._reducer is None:
+            return self.dev.cns_iter(*args, mask_dcpl=self._mask_dcpl)
+        self.dev.cns_iter(*args, mask_dcpl=self._mask_dcpl, phase=1)
+        ptr, count = self.dev.cns_mean_ptr()
+        self._reducer.all_reduce_ptr(self.dev, ptr, count, self.dtype == np.float32,
+                                     prescale=float(self.Nb) / float(self._nb_all))
+        sums = self.dev.cns_iter(*args, mask_dcpl=self._mask_dcpl, phase=2)
+        return self._reducer.sum_slots(sums, self._shard_slots)
+
     def residual_norms(self):
         """Consensus residuals and normalisations (admm.py:1673-1707)."""
         s = self._sums
-        rho, nb = float(self.rho), float(self.Nb)
+        rho, nb = float(self.rho), float(self._nb_all)
         nr = np.sqrt(s[_lib.OUT_R2])
         ns = np.sqrt(nb) * rho * np.sqrt(s[_lib.OUT_S2])
         rn = max(np.sqrt(s[_lib.OUT_AX2]), np.sqrt(nb) * np.sqrt(s[_lib.OUT_Y2]))

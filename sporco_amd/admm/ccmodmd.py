@@ -4,8 +4,8 @@ Drop-ins for ``sporco.admm.ccmodmd.ConvCnstrMODMaskDcpl_IterSM`` and ``ConvCnstr
 (sporco/admm/ccmodmd.py:573-762 on ``ConvCnstrMODMaskDcplBase`` :27-567 and
 ``admm.ADMMTwoBlockCnstrnt``, sporco/admm/admm.py:989-1437): minimise
 (1/2) sum_k ||W (sum_m d_m * x_{k,m} - s_k)||^2 over constrained filters through the two-block
-constraint [Z; I] d - [y0; y1] = [s; 0].  The consensus variant
-(``ConvCnstrMODMaskDcpl_Consensus``, :766-1083) is not part of this backend.
+constraint [Z; I] d - [y0; y1] = [s; 0]; and for the hybrid consensus form
+``ConvCnstrMODMaskDcpl_Consensus`` (:766-1083, at the end of this module).
 
 One iteration is one call of ``sporco_amd_csc_dstep_iter`` with ``mask_dcpl`` set: the X-step
 solves (Z^H Z + I) Xf = sum_n conj(Zf_n) rfftn(y0 - u0 + s)_n + rfftn(y1 - u1) with the kernels
@@ -23,7 +23,8 @@ from . import ccmod
 from .. import _lib
 from .. import cnvrep as cr
 
-__all__ = ['ConvCnstrMODMaskDcpl_IterSM', 'ConvCnstrMODMaskDcpl_CG', 'ConvCnstrMODMaskDcpl',
+__all__ = ['ConvCnstrMODMaskDcpl_IterSM', 'ConvCnstrMODMaskDcpl_CG',
+           'ConvCnstrMODMaskDcpl_Consensus', 'ConvCnstrMODMaskDcpl',
            'ConvCnstrMODMaskDcplOptions']
 
 
@@ -226,15 +227,102 @@ class ConvCnstrMODMaskDcpl_CG(ConvCnstrMODMaskDcplBase):
         return (self.xrrs, self.cgit)
 
 
-_METHODS = {'ism': ConvCnstrMODMaskDcpl_IterSM, 'cg': ConvCnstrMODMaskDcpl_CG}
+class ConvCnstrMODMaskDcpl_Consensus(ccmod.ConvCnstrMOD_Consensus):
+    r"""Hybrid consensus / mask-decoupling dictionary update (sporco/admm/ccmodmd.py:766-1083):
+    minimise (1/2) ||W (sum_m d_m * x_m - s)||_2^2 over filters of unit norm and constrained
+    support, with one dictionary copy per image (the consensus splitting of
+    :class:`sporco_amd.admm.ccmod.ConvCnstrMOD_Consensus`) and a signal-sized block ``Y1, U1``
+    that carries the mask.  One iteration is one call of ``sporco_amd_csc_cns_iter`` with
+    ``mask_dcpl`` set; the host forms the residuals of :976-1034 from the returned sums.
+
+    IterationStats fields: ``Iter, DFid, Cnstr, PrimalRsdl, DualRsdl, EpsPrimal, EpsDual,
+    Rho, XSlvRelRes, Time``.
+    """
+
+    _mask_dcpl = True
+    _shard_slots = (_lib.OUT_R2, _lib.OUT_AX2, _lib.OUT_U2, _lib.OUT_S2, _lib.OUT_XRRS_D2,
+                    _lib.OUT_XRRS_AX2, _lib.OUT_XRRS_B2, _lib.OUT_CGIT, _lib.OUT_DFID)
+
+    def __init__(self, Z, S, W, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None,
+                 reducer=None):
+        """``reducer``: image shards over ranks as for
+        :class:`sporco_amd.admm.ccmod.ConvCnstrMOD_Consensus` (``S``, ``W``, ``Z`` hold this
+        rank's images)."""
+        if opt is None:
+            opt = ccmod.ConvCnstrMOD_Consensus.Options()
+        self._W_in = np.asarray([1.0]) if W is None else np.asarray(W)
+        super(ConvCnstrMODMaskDcpl_Consensus, self).__init__(Z, S, dsz, opt, dimK=dimK, dimN=dimN,
+                                                             device=device, stream=stream, dev=dev,
+                                                             reducer=reducer)
+        s2 = float(np.linalg.norm(self.S)) ** 2
+        if reducer is not None:
+            s2 = reducer.sum([s2])[0]
+        self._nrm_s = float(np.sqrt(s2))
+
+    _mask5 = ConvCnstrMODMaskDcplBase._mask5
+
+    def init_state(self, yshape, ushape):
+        super(ConvCnstrMODMaskDcpl_Consensus, self).init_state(yshape, ushape)
+        self.W = self._mask5()
+        H, Wd = self.cri.Nv
+        if self.cri.C > 1:
+            full = np.ascontiguousarray(np.broadcast_to(self.W, (H, Wd, 1, self.Nb, 1)))
+            self.dev.set_data_mask(full.reshape(H, Wd, self.cri.C, self.cri.K, 1))
+        else:
+            self.dev.set_data_mask(ccmod_broadcastable(self.W, (H, Wd, 1, self.Nb, 1)))
+        self.dev.cns_md_init(self.S)
+
+    # the signal-sized block, in the reference's (H, W, 1, Nb, 1) layout
+    @property
+    def Y1(self):
+        return self.dev.download(_lib.VAR_DMY0)
+
+    @property
+    def U1(self):
+        # (not touched by update_rho's rescaling of U: the reference scales self.U only)
+        return self.dev.download(_lib.VAR_DMU0)
+
+    def var_y1(self):
+        """The dictionary (named for compatibility with the IterSM / CG classes, :889-897)."""
+        return self.Y
+
+    def iteration(self):
+        admm.refuse_step_overrides(self)
+        flags = 0
+        if self._needs_residuals():
+            flags |= _lib.FLAG_RESID
+        if not self.opt['FastSolve']:
+            flags |= _lib.FLAG_OBJ
+        self._sums = self._device_iteration(flags)
+        self._u_scale = 1.0
+        self._cache.clear()
+        if not self._needs_residuals():
+            return None
+        self.timer.stop('solve_wo_rsdl')
+        res = self.compute_residuals()
+        self.timer.start('solve_wo_rsdl')
+        return res
+
+    def residual_norms(self):
+        """ccmodmd.py:976-1012: both blocks enter every norm; the dual residual is rho ||A^T u||
+        with the new duals; the primal normalisation also sees ||s||."""
+        s = self._sums
+        rho = float(self.rho)
+        nr = np.sqrt(s[_lib.OUT_R2] + s[_lib.OUT_XRRS_D2])
+        ns = rho * np.sqrt(s[_lib.OUT_S2])
+        rn = max(np.sqrt(s[_lib.OUT_AX2] + s[_lib.OUT_XRRS_AX2]),
+                 np.sqrt(s[_lib.OUT_Y2] + s[_lib.OUT_XRRS_B2]), self._nrm_s)
+        sn = rho * np.sqrt(s[_lib.OUT_U2] + s[_lib.OUT_CGIT])
+        return nr, ns, rn, sn
+
+
+_METHODS = {'ism': ConvCnstrMODMaskDcpl_IterSM, 'cg': ConvCnstrMODMaskDcpl_CG,
+            'cns': ConvCnstrMODMaskDcpl_Consensus}
 
 
 def _lookup(method):
     if method in _METHODS:
         return _METHODS[method]
-    if method == 'cns':
-        raise NotImplementedError("ConvCnstrMODMaskDcpl_Consensus is not part of the sporco_amd "
-                                  "backend; use 'ism' or 'cg'")
     raise ValueError('Unknown ConvCnstrMODMaskDcpl solver method %s' % method)
 
 

@@ -155,6 +155,8 @@ struct CscBase {
     virtual void masked_grad(int var, bool dstep, int mode, double *out_dev) = 0;
     virtual void cns_init(const void *Y0, double rho) = 0;
     virtual void cns_iter(const sporco_amd_cns_params &p, double *out_dev) = 0;
+    virtual void cns_md_init(const void *S) = 0;
+    virtual void *cns_mean_ptr(int64_t *count) = 0;
     virtual void mdcpl_init(const void *S) = 0;
     virtual void mdcpl_iter(const sporco_amd_admm_params &p, double *out_dev) = 0;
     virtual void dstep_init(const void *Y0) = 0;
@@ -2090,10 +2092,187 @@ template <typename T> struct Csc : CscBase {
         sync();
     }
 
+    void cns_buffers() {
+        if (cns_f) return;
+        const int64_t npixr = (int64_t)H * W;
+        SA_HIP(hipMalloc((void **)&cns_f, sizeof(cx<T>) * EF));
+        SA_HIP(hipMalloc((void **)&cns_m, sizeof(T) * npixr * K));
+        SA_HIP(hipMalloc((void **)&cns_yold, sizeof(T) * npixr * K));
+    }
+    void *cns_mean_ptr(int64_t *count) override {
+        cns_buffers();
+        *count = (int64_t)H * W * K;
+        return cns_m;
+    }
+
+    // ---- consensus update with mask decoupling (ConvCnstrMODMaskDcpl_Consensus) ----------------
+    void cns_md_init(const void *S) override {
+        require_single_channel_dict();
+        SA_REQUIRE(S != nullptr, "S is null");
+        const size_t nb = sizeof(T) * (int64_t)H * W * CN;
+        if (!md_s) SA_HIP(hipMalloc((void **)&md_s, nb));
+        SA_HIP(hipMemcpyAsync(md_s, S, nb, hipMemcpyHostToDevice, st));
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_DMY0), 0, nb, st));
+        SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_DMU0), 0, nb, st));
+        sync();
+    }
+
+    // One iteration of sporco/admm/ccmodmd.py:766-1083 in the order of ADMM.solve
+    // (admm.py:331-367): xstep (:922-939, the consensus solve with rho = 1 and S + Y1 - U1 in
+    // the signal's place), relax_AX (:899-918), ystep (:943-952), ustep (:956-963), and the
+    // sums of compute_residuals (:976-1034) / obfn_dfd (:966-972).  Generic FFT chain.
+    void cns_md_iter(const sporco_amd_cns_params &p, double *out_dev) {
+        SA_REQUIRE(md_s != nullptr, "cns_md_init must be called first");
+        SA_REQUIRE(p.rho > 0.0, "rho must be positive");
+        need_natural(SPORCO_AMD_VAR_ZF);
+        const int64_t npixr = (int64_t)H * W, ns = npixr * CN;
+        const T us = (T)p.u_scale;
+        T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_CX), *U = rv(SPORCO_AMD_VAR_CU);
+        T *Y1 = rv(SPORCO_AMD_VAR_DMY0), *U1 = rv(SPORCO_AMD_VAR_DMU0);
+        cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF);
+        cns_buffers();
+        cx<T> *wk = work_buf();
+        if (p.phase != 2) {
+        // xstep: ZSf = conj(Zf) rfftn(S + Y1 - U1); X_n = irfftn(SM(Zf_n, 1, ZSf_n + rfftn(Y - U_n)))
+        {
+            ProfScope ps(prof, PS_OTHER);
+            // (U1 takes no part in update_rho's `U /= rsf`, admm.py:573: the reference rescales
+            // the consensus duals only, so the pending scale does not apply to it)
+            launch_md_pre<T>(st, Y1, U1, md_s, sreal, T(1), ns);
+        }
+        fwd2(sreal, nullptr, T(0), innerb, CN);
+        {
+            ProfScope ps(prof, PS_FFT_R2C);
+            fft_r2c<T>(st, planW, Y, U, us, cns_f, H, P, (int64_t)W * P, P, (int64_t)Wf * P, P, 0, 0,
+                       K);
+        }
+        {
+            ProfScope ps(prof, PS_FFT_C2C_FWD);
+            fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * P, 0, (int64_t)Wf * P, 0,
+                       (int64_t)Wf * P, T(1));
+        }
+        {
+            ProfScope ps(prof, PS_SM_SOLVE);
+            launch_sm_solve<T>(st, cns_f, cns_f, Zf, innerb, nullptr, T(1), npix, CN, K, W, false,
+                               false, part_a, nullptr, true);
+        }
+        inv2(cns_f, wk, X, P);
+        // relax_AX, block 1: AX1nr_n = irfftn(sum_m Zf_{n,m} Xf_{n,m}) -- the inner product of
+        // every (frequency, image) row with itself-indexed coefficients: npix * CN "pixels"
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_inner<T>(st, Zf, cns_f, innerb, npix * CN, 1, K);
+        }
+        inv2(innerb, innerb, sreal, CN);
+        // consensus part: Y = Pcn(mean_n(alpha X_n + (1 - alpha) Y + U_n))
+        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * K, hipMemcpyDeviceToDevice, st));
+        {
+            ProfScope ps(prof, PS_OTHER);
+            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, us, npixr, CN, K);
+        }
+        }   // phase != 2
+        if (p.phase == 1) return;
+        pcn_project(cns_m, Y, p.dH, p.dW, p.zero_mean != 0, nullptr);
+        // block 1: AX1 = alpha AX1nr + (1 - alpha)(Y1 + S); Y1 = rho (AX1 + U1 - S) / (W^2 + rho);
+        // U1 += AX1 - Y1 - S  -- the block-0 step of ConvBPDNMaskDcpl, same kernel
+        MdY0Args<T> ya;
+        ya.ax0nr = sreal;
+        ya.y0 = Y1;
+        ya.u0 = U1;
+        ya.s = md_s;
+        ya.w = have_wdat ? wdat : Weight<T>();
+        ya.rho = (T)p.rho;
+        ya.rlx = (T)p.rlx;
+        ya.us = T(1);
+        ya.geval_y = 1;
+        ya.H = H;
+        ya.W = W;
+        ya.C = C;
+        ya.N = N;
+        int nb;
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_md_y0step<T>(st, ya, part_a);
+        }
+        {
+            const int slots[4] = {SPORCO_AMD_OUT_XRRS_D2, SPORCO_AMD_OUT_XRRS_AX2,
+                                  SPORCO_AMD_OUT_XRRS_B2, SPORCO_AMD_OUT_CGIT};
+            const double scales[4] = {1, 1, 1, 1};
+            finalize(part_a, nb, 5, 4, slots, scales, out_dev);
+        }
+        // consensus ustep + the X-sized sums
+        {
+            ProfScope ps(prof, PS_ADMM_POST);
+            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, us, npixr, CN, K, part_b);
+        }
+        {
+            const int slots[3] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_AX2, SPORCO_AMD_OUT_U2};
+            const double scales[3] = {1, 1, 1};
+            finalize(part_b, nb, 4, 3, slots, scales, out_dev);
+        }
+        {
+            ProfScope ps(prof, PS_OTHER);
+            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * K, part_a);
+        }
+        {
+            const int slots[2] = {SPORCO_AMD_OUT_L21, SPORCO_AMD_OUT_Y2};   // (|Y - Yprev|^2 unused)
+            const double scales[2] = {0, 1};
+            finalize(part_a, nb, 2, 2, slots, scales, out_dev);
+        }
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        if (p.flags & F_RESID) {
+            // dual residual: A^T u = U_n + irfftn(conj(Zf_n) rfftn(U1_n)), new duals (:993-996)
+            fwd2(U1, nullptr, T(0), innerb, CN);
+            fwd2(U, nullptr, T(0), cns_f, P);
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_conj_outer<T>(st, Zf, innerb, wk, npix * CN, 1, K);
+                launch_lincomb<T>(st, wk, T(1), wk, T(1), cns_f, T(0), nullptr, EF);
+                nb = launch_pair_stats<T>(st, wk, nullptr, nullptr, npix, P, W, part_b);
+            }
+            const int slots[1] = {SPORCO_AMD_OUT_S2};
+            const double scales[1] = {1.0 / ((double)H * W)};
+            finalize(part_b, nb, 4, 1, slots, scales, out_dev);
+        }
+        if (p.flags & F_OBJ) {
+            // (1/2) |W irfftn(sum_m Zf Yf - Sf)|^2 at the consensus variable (:961-970)
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DXF), Zf, innerb, npix, CN, K);
+                launch_lincomb<T>(st, innerb, T(1), innerb, T(-1), cv(SPORCO_AMD_VAR_SF), T(0),
+                                  nullptr, npix * CN);
+            }
+            inv2(innerb, innerb, sreal, CN);
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), false, H, W, C, N,
+                                          part_a);
+            }
+            const int slots[1] = {SPORCO_AMD_OUT_DFID};
+            const double scales[1] = {1.0};
+            finalize(part_a, nb, 1, 1, slots, scales, out_dev);
+            int nbc;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                launch_pcn_stats<T>(st, Y, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                nbc = launch_pcn_apply<T>(st, Y, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
+                                          Ku);
+            }
+            const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
+            const double cscales[1] = {1.0};
+            finalize(part_b, nbc, 1, 1, cslots, cscales, out_dev);
+        }
+    }
+
     void cns_iter(const sporco_amd_cns_params &p, double *out_dev) override {
         require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        SA_REQUIRE(p.phase >= 0 && p.phase <= 2, "phase must be 0, 1 or 2");
+        if (p.mask_dcpl) {
+            cns_md_iter(p, out_dev);
+            return;
+        }
         const bool fusedx = cns_fused();
         if (fusedx) {
             if (!zf_tiled) relayout(SPORCO_AMD_VAR_ZF, true), zf_tiled = true;
@@ -2103,11 +2282,8 @@ template <typename T> struct Csc : CscBase {
         const int64_t npixr = (int64_t)H * W;
         T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_CX), *U = rv(SPORCO_AMD_VAR_CU);
         cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF);
-        if (!cns_f) {
-            SA_HIP(hipMalloc((void **)&cns_f, sizeof(cx<T>) * EF));
-            SA_HIP(hipMalloc((void **)&cns_m, sizeof(T) * npixr * K));
-            SA_HIP(hipMalloc((void **)&cns_yold, sizeof(T) * npixr * K));
-        }
+        cns_buffers();
+        if (p.phase != 2) {
         // xstep (ccmod.py:766-778): X_n = irfftn(SM(Zf_n, rho, conj(Zf_n) Sf_n + rho rfftn(Y - U_n)));
         // Y is broadcast over the images by the row transform itself
         if (fusedx) {
@@ -2178,6 +2354,8 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, (T)p.u_scale, npixr, CN, K);
         }
+        }   // phase != 2
+        if (p.phase == 1) return;
         pcn_project(cns_m, Y, p.dH, p.dW, p.zero_mean != 0, nullptr);
         // ustep + the X-sized sums
         int nb;
@@ -3155,6 +3333,21 @@ int sporco_amd_csc_cns_init(sporco_amd_csc_t h, const void *Y0, double rho) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->cns_init(Y0, rho);
+    SA_API_END
+}
+
+int sporco_amd_csc_cns_mean_ptr(sporco_amd_csc_t h, void **ptr_dev, int64_t *count) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(ptr_dev && count, "null argument");
+    *ptr_dev = h->impl->cns_mean_ptr(count);
+    SA_API_END
+}
+
+int sporco_amd_csc_cns_md_init(sporco_amd_csc_t h, const void *S) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->cns_md_init(S);
     SA_API_END
 }
 

@@ -138,7 +138,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         ``stream``, and ``reducer`` (:class:`sporco_amd.dist.TorchReducer`) for one process per
         GPU with ``S`` holding this rank's block of the training images: the
         X-step exchanges its per-iteration sums, the D-step all-reduces its gradient; every
-        rank ends with the same dictionary.  Offered for ``dmethod='pgm'`` with either X-step."""
+        rank ends with the same dictionary.  Offered for ``dmethod='pgm'`` and ``'cns'`` (whose consensus
+        average over the images becomes an all-reduce) with either X-step."""
         self._reducer = reducer
         if opt is None:
             opt = ConvBPDNDictLearn.Options(xmethod=xmethod, dmethod=dmethod)
@@ -146,8 +147,11 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             xmethod = opt.xmethod
         if dmethod is None:
             dmethod = opt.dmethod
-        if reducer is not None and dmethod != 'pgm':
-            raise NotImplementedError("image sharding is offered for dmethod='pgm'")
+        if reducer is not None and dmethod not in ('pgm', 'cns'):
+            raise NotImplementedError(
+                "image sharding is offered for dmethod='pgm' (gradient all-reduce) and 'cns' "
+                "(consensus average all-reduce); 'ism' / 'cg' solve with all images' coefficient "
+                "spectra at once")
         if opt.xmethod != xmethod or opt.dmethod != dmethod:
             raise ValueError('Parameters xmethod and dmethod must have the same values used '
                              'to initialise the Options object')

@@ -5,7 +5,7 @@ Drop-in for ``sporco.dictlrn.cbpdndlmd.ConvBPDNMaskDictLearn`` (sporco/dictlrn/c
 :class:`sporco_amd.admm.cbpdn.ConvBPDNMaskDcpl`) or ``'pgm'``
 (:class:`sporco_amd.pgm.cbpdn.ConvBPDNMask`); ``dmethod='pgm'``
 (:class:`sporco_amd.pgm.ccmod.ConvCnstrMODMask`), ``'ism'`` or ``'cg'`` (mask decoupling:
-:mod:`sporco_amd.admm.ccmodmd`; the consensus variant ``'cns'`` is not part of this backend).
+:mod:`sporco_amd.admm.ccmodmd`) or ``'cns'`` (its consensus form).
 Both steps share one device handle, as in :mod:`sporco_amd.dictlrn.cbpdndl`.
 """
 
@@ -40,8 +40,7 @@ def _d_class(method):
     if method == 'cg':
         return admm_ccmodmd.ConvCnstrMODMaskDcpl_CG
     if method == 'cns':
-        raise NotImplementedError("ConvCnstrMODMaskDcpl_Consensus (dmethod='cns') is not part of "
-                                  "the sporco_amd backend; use 'pgm', 'ism' or 'cg'")
+        return admm_ccmodmd.ConvCnstrMODMaskDcpl_Consensus
     raise ValueError('Unknown ConvCnstrMODMask solver method %s' % method)
 
 
@@ -91,8 +90,11 @@ class ConvBPDNMaskDictLearn(cbpdndl.ConvBPDNDictLearn):
             raise ValueError('Parameters xmethod and dmethod must have the same values used '
                              'to initialise the Options object')
         xcls, dcls = _x_class(xmethod), _d_class(dmethod)
-        if reducer is not None and dmethod != 'pgm':
-            raise NotImplementedError("image sharding is offered for dmethod='pgm'")
+        if reducer is not None and dmethod not in ('pgm', 'cns'):
+            raise NotImplementedError(
+                "image sharding is offered for dmethod='pgm' (gradient all-reduce) and 'cns' "
+                "(consensus average all-reduce); 'ism' / 'cg' solve with all images' coefficient "
+                "spectra at once")
         self._reducer = reducer
         bk = {} if reducer is None else {'reducer': reducer}
         self.opt, self.xmethod, self.dmethod = opt, xmethod, dmethod

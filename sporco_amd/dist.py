@@ -129,6 +129,35 @@ class TorchReducer(object):
             a = np.ctypeslib.as_array((ct * count).from_address(ptr))
             self.dist.all_reduce(self.torch.from_numpy(a), group=self.group)
 
+    def all_reduce_ptr(self, solver, ptr, count, f32, prescale=1.0):
+        """Sum ``count`` reals at device address ``ptr`` of ``solver`` over the ranks, in place,
+        each rank's contribution first multiplied by ``prescale`` (a local mean over N_local
+        images becomes the global mean with prescale = N_local / N_total)."""
+        solver.sync()
+        typestr = '<f4' if f32 else '<f8'
+        if self.on_gpu:
+            t = self.torch.as_tensor(_DeviceView(ptr, count, typestr), device=self.buf.device)
+            if prescale != 1.0:
+                t.mul_(prescale)
+            self.dist.all_reduce(t, group=self.group)
+            self.torch.cuda.current_stream().synchronize()
+            return
+        import numpy as np
+        ct = ctypes.c_float if f32 else ctypes.c_double
+        a = np.ctypeslib.as_array((ct * count).from_address(ptr))
+        if prescale != 1.0:
+            a *= a.dtype.type(prescale)
+        self.dist.all_reduce(self.torch.from_numpy(a), group=self.group)
+
+    def sum_slots(self, values, slots):
+        """``values`` with the entries at ``slots`` summed over the ranks (the others are
+        replicated quantities and stay as they are)."""
+        red = self.sum([values[i] for i in slots])
+        out = list(values)
+        for i, v in zip(slots, red):
+            out[i] = v
+        return out
+
     def sum(self, values):
         t = self.torch.tensor(list(values), dtype=self.torch.float64)
         if self.on_gpu:

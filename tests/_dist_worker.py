@@ -137,6 +137,51 @@ def main():
         np.savez(out_path + '.dlmd_%s.%d.npz' % (xm, rank), D1=D1, X=d.getcoef(),
                  **{f: np.asarray(getattr(its, f), dtype=float)
                     for f in ('ObjFun', 'DFid', 'RegL1')})
+    # ADMM consensus dictionary updates, images sharded: the consensus average is the one array
+    # all-reduce per iteration; standalone (plain and mask decoupling), then inside dictionary
+    # learning with the sharded ADMM X-steps
+    from sporco_amd.admm import ccmod as admm_ccmod
+    from sporco_amd.admm import ccmodmd as admm_ccmodmd
+    autorho = {'Enabled': True, 'Period': 3, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+               'AutoScaling': True, 'RsdlTarget': 1.0}
+    optd = {'MaxMainIter': 15, 'ZeroMean': True, 'AutoRho': autorho}
+    for name, masked in (('ccmod_cns_shard_f64', False), ('ccmodmd_cns_shard_f64', True)):
+        g = load_golden(name)
+        dsz = tuple(int(v) for v in g['dsz'])
+        Zs, Ss = shard_images(g['Z'], rank, world, axis=3), shard_images(g['S'], rank, world)
+        o = admm_ccmod.ConvCnstrMOD_Consensus.Options(optd)
+        if masked:
+            c = admm_ccmodmd.ConvCnstrMODMaskDcpl_Consensus(
+                Zs, Ss, shard_images(g['W'], rank, world), dsz, o, reducer=TorchReducer())
+        else:
+            c = admm_ccmod.ConvCnstrMOD_Consensus(Zs, Ss, dsz, o, reducer=TorchReducer())
+        c.solve()
+        its = c.getitstat()
+        np.savez(out_path + '.%s.%d.npz' % (name, rank), D=c.getdict(), Y=c.Y, k=c.k,
+                 **{f: np.asarray(getattr(its, f), dtype=float)
+                    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho')})
+    g = load_golden('cbpdndl_shard_cns_f64')
+    opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                            xmethod='admm', dmethod='cns')
+    d = cbpdndl.ConvBPDNDictLearn(g['D0'], shard_images(g['S'], rank, world), float(g['lmbda']),
+                                  opt, xmethod='admm', dmethod='cns', reducer=TorchReducer())
+    D1 = d.solve()
+    its = d.getitstat()
+    np.savez(out_path + '.dlcns.%d.npz' % rank, D1=D1, X=d.getcoef(),
+             **{f: np.asarray(getattr(its, f), dtype=float) for f in its._fields
+                if f not in ('Iter', 'Time')})
+    g = load_golden('cbpdndlmd_shard_cns_f64')
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                                  xmethod='admm', dmethod='cns')
+    d = cbpdndlmd.ConvBPDNMaskDictLearn(
+        g['D0'], shard_images(g['S'], rank, world), float(g['lmbda']),
+        shard_images(g['W'], rank, world), opt, xmethod='admm', dmethod='cns',
+        reducer=TorchReducer())
+    D1 = d.solve()
+    its = d.getitstat()
+    np.savez(out_path + '.dlmdcns.%d.npz' % rank, D1=D1, X=d.getcoef(),
+             **{f: np.asarray(getattr(its, f), dtype=float) for f in its._fields
+                if f not in ('Iter', 'Time')})
     dist.destroy_process_group()
 
 

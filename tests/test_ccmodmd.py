@@ -67,8 +67,6 @@ def test_surface(backend):
     c.solve()
     c.solve()
     assert c.k == 6 and c.reconstruct().shape[:2] == g['S'].shape[:2]
-    with pytest.raises(NotImplementedError):
-        ccmodmd.ConvCnstrMODMaskDcpl(g['Z'], g['S'], g['W'], dsz, method='cns')
     with pytest.raises(ValueError):
         ccmodmd.ConvCnstrMODMaskDcpl(g['Z'], g['S'], g['W'], dsz, method='nosuch')
 
@@ -94,8 +92,8 @@ def test_masked_dictionary_learning(backend, method):
     for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'XRho', 'DPrRsdl', 'DDlRsdl',
               'DRho'):
         assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < tol, f
-    with pytest.raises(NotImplementedError):
-        cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')
+    with pytest.raises(ValueError):
+        cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='nosuch')
 
 
 @pytest.mark.parametrize('method', ['ism', 'cg'])
@@ -154,3 +152,85 @@ def test_masked_dictionary_learning_multichannel_signal(backend):
     its = d.getitstat()
     for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'DPrRsdl', 'DDlRsdl'):
         assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+
+
+# ---------------------------------------------------------------------------
+# ConvCnstrMODMaskDcpl_Consensus (sporco/admm/ccmodmd.py:766-1083) and dmethod='cns'
+# ---------------------------------------------------------------------------
+CNS_CASES = {
+    'f64': {'MaxMainIter': 20},
+    'f32': {'MaxMainIter': 20, 'DataType': np.float32},
+    'opts_f64': {'MaxMainIter': 20, 'rho': 3.0, 'RelaxParam': 1.5, 'ZeroMean': True,
+                 'AutoRho': AUTORHO},
+    'std_f64': {'MaxMainIter': 20, 'AbsStopTol': 1e-4, 'RelStopTol': 1e-3,
+                'AutoRho': dict(AUTORHO, StdResiduals=True, AutoScaling=False)},
+    'chan_f64': {'MaxMainIter': 12},
+}
+
+
+@pytest.mark.parametrize('case', sorted(CNS_CASES))
+def test_consensus_golden_traces(backend, case):
+    from sporco_amd.admm import ccmodmd
+    g = load_golden('ccmodmd_cns_' + case)
+    optd = CNS_CASES[case]
+    tol = 1e-3 if optd.get('DataType') is np.float32 else 1e-9
+    cls = ccmodmd.ConvCnstrMODMaskDcpl_Consensus
+    c = cls(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']), cls.Options(optd))
+    c.solve()
+    assert c.k == int(g['k_final'])
+    assert c.Y.shape == g['Y'].shape and rel_l2(c.Y, g['Y']) < tol
+    assert rel_l2(c.getdict(), g['D']) < tol and rel_l2(c.var_y1(), g['Y']) < tol
+    assert rel_l2(float(c.rho), float(g['rho_final'])) < tol
+    if 'X' in g:
+        assert c.X.shape == g['X'].shape and rel_l2(c.X, g['X']) < tol
+        assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+        assert rel_l2(c.Y1, g['Y1']) < tol and rel_l2(c.U1, g['U1']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < max(10 * tol, 1e-9)
+
+
+@pytest.mark.parametrize('xm', ['admm', 'pgm'])
+def test_masked_dictlearn_consensus_dstep(backend, xm):
+    """ConvBPDNMaskDictLearn(dmethod='cns') (cbpdndlmd.py:130-132, :474) with either X-step."""
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_%s_cns_f64' % xm)
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True},
+                                                  xmethod=xm, dmethod='cns')
+    b = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod=xm, dmethod='cns')
+    D1 = b.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(b.getcoef(), g['X']) < 1e-9
+    its = b.getitstat()
+    for f in its._fields:
+        if 'it_' + f in g and f not in ('Iter', 'Cnstr'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+
+
+def test_consensus_wrapper_and_fast_shape(backend):
+    """method='cns' is the wrapper's default, as in the reference (ccmodmd.py:1056-1095); on a
+    shape of the register-resident kernels (float32, 256 x 256) the update keeps working (the
+    coefficient spectrum is re-laid to the natural layout its generic chain reads)."""
+    from sporco_amd.admm import ccmodmd
+    assert ccmodmd.ConvCnstrMODMaskDcplOptions()['RelaxParam'] == 1.8
+    if backend == 'hostsim':
+        return
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(8)
+    H, N, K = 256, 2, 4
+    Z = (rng.randn(H, H, 1, N, K) * (rng.rand(H, H, 1, N, K) < 0.05)).astype(np.float32)
+    S = rng.randn(H, H, N).astype(np.float32)
+    Wm = (rng.rand(H, H, 1, N) > 0.3).astype(np.float32)
+    c = ccmodmd.ConvCnstrMODMaskDcpl(Z, S, Wm, (5, 5, K),
+                                     ccmodmd.ConvCnstrMODMaskDcplOptions({'MaxMainIter': 3}))
+    assert type(c).__name__ == 'ConvCnstrMODMaskDcpl_Consensus'
+    c.solve()
+    c64 = ccmodmd.ConvCnstrMODMaskDcpl_Consensus(
+        Z, S, Wm, (5, 5, K), ccmodmd.ConvCnstrMODMaskDcplOptions(
+            {'MaxMainIter': 3, 'DataType': np.float64}))
+    c64.solve()
+    assert rel_l2(c.getdict(), c64.getdict()) < 1e-3
+    assert rel_l2(np.asarray(c.getitstat().DFid, float),
+                  np.asarray(c64.getitstat().DFid, float)) < 1e-4

@@ -90,3 +90,23 @@ def test_two_rank_image_sharding(tmp_path):
             assert rel_l2(p['D1'].squeeze(), g['D1'].squeeze()) < 1e-9
             for f in ('ObjFun', 'DFid', 'RegL1'):
                 assert rel_l2(p[f], g['it_' + f]) < 1e-9, (xm, f)
+    # consensus dictionary updates with the average as an all-reduce: every rank reproduces the
+    # single-process dictionary and traces of the four-image reference runs
+    for name in ('ccmod_cns_shard_f64', 'ccmodmd_cns_shard_f64'):
+        g = load_golden(name)
+        parts = [np.load(out + '.%s.%d.npz' % (name, r)) for r in range(2)]
+        for p in parts:
+            assert int(p['k']) == int(g['k_final'])
+            assert rel_l2(p['D'], g['D']) < 1e-9 and rel_l2(p['Y'], g['Y']) < 1e-9
+            for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+                assert rel_l2(p[f], g['it_' + f]) < 1e-9, (name, f)
+        assert np.array_equal(parts[0]['D'], parts[1]['D'])
+    for tag, name in (('dlcns', 'cbpdndl_shard_cns_f64'), ('dlmdcns', 'cbpdndlmd_shard_cns_f64')):
+        g = load_golden(name)
+        parts = [np.load(out + '.%s.%d.npz' % (tag, r)) for r in range(2)]
+        assert rel_l2(np.concatenate([p['X'] for p in parts], axis=3), g['X']) < 1e-9
+        for p in parts:
+            assert rel_l2(p['D1'].squeeze(), g['D1'].squeeze()) < 1e-9
+            for f in g.keys():
+                if f.startswith('it_') and f[3:] in p.files and f[3:] not in ('Cnstr', 'Iter'):
+                    assert rel_l2(p[f[3:]], g[f]) < 1e-9, (name, f)
