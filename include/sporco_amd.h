@@ -538,6 +538,38 @@ int sporco_amd_solvedbi_sm(int dtype, int64_t npix, int64_t CN, int32_t K, const
  * over CN, y complex (npix,CN,K) -> out complex (npix,CN). */
 int sporco_amd_inner(int dtype, int64_t npix, int64_t CN, int32_t K, const void *x,
                      const void *y, void *out);
+/* ---- Device arrays and the pre / post-processing around the solvers -------------------------
+ * The reference's example pipelines (examples/scripts/csc/cbpdn_gry.py:45-47, :66-77) highpass
+ * the image with signal.tikhonov_filter, sparse-code the highpass part and add the lowpass part
+ * back to the reconstruction.  With the entry points below the whole chain stays in HBM: one
+ * upload of the image, one download of the result.  Buffers are plain device pointers. */
+int sporco_amd_dev_malloc(size_t bytes, void **ptr_dev);
+int sporco_amd_dev_free(void *ptr_dev);
+int sporco_amd_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int sporco_amd_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+/* out = a x + b y on real device arrays of n elements (y may be NULL). */
+int sporco_amd_dev_axpby(int dtype, int64_t n, double a, const void *x, double b, const void *y,
+                         void *out);
+/* signal.tikhonov_filter (sporco/signal.py:244-301) on a device array s (H, W, P), P = product of
+ * the remaining axes: symmetric padding by npd, division by 1 + lmbda sum_i |G_i|^2 in the DFT
+ * domain, crop; slp and shp = s - slp are device arrays of the shape of s. */
+int sporco_amd_tikhonov_filter_dev(int dtype, int32_t H, int32_t W, int64_t P, const void *s_dev,
+                                   double lmbda, int32_t npd, void *slp_dev, void *shp_dev);
+/* fft.fftconv (sporco/fft.py:376-417) over axes (0, 1) of real device arrays a (ha, wa, ...) and
+ * b (hb, wb, ...) whose remaining (up to three, after merging) axes have the extents da / db --
+ * each 1 or the output extent d -- circular over (max(ha,hb), max(wa,wb)), result rolled by
+ * -(origin_h, origin_w).  out: (H, W, d0, d1, d2). */
+int sporco_amd_fftconv_dev(int dtype, int32_t ha, int32_t wa, const int64_t da[3], const void *a_dev,
+                           int32_t hb, int32_t wb, const int64_t db[3], const void *b_dev,
+                           int32_t origin_h, int32_t origin_w, void *out_dev);
+/* set_signal from a device array (H, W, C, N) (no host copy). */
+int sporco_amd_csc_set_signal_dev(sporco_amd_csc_t h, const void *S_dev);
+/* reconstruct into a device array (H, W, C, N). */
+int sporco_amd_csc_reconstruct_dev(sporco_amd_csc_t h, int var, void *dst_dev);
+/* Bytes and calls of host <-> device copies made by this library since the last reset:
+ * out = {h2d_bytes, h2d_calls, d2h_bytes, d2h_calls}. */
+int sporco_amd_transfer_stats(int64_t out[4], int reset);
+
 /* prox_l1 (sporco/prox/_lp.py:144-183), real v of n elements, scalar alpha. */
 int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *out);
 /* The same with an array-valued threshold (sporco/prox/_lp.py:144-183 accepts one): v viewed as

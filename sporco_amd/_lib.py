@@ -72,6 +72,10 @@ EXPORTS = (
     'sporco_amd_csc_mdcpl_init', 'sporco_amd_csc_mdcpl_iter', 'sporco_amd_csc_dstep_md_init',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
     'sporco_amd_csc_profile', 'sporco_amd_csc_profile_read', 'sporco_amd_profile_slots',
+    'sporco_amd_dev_malloc', 'sporco_amd_dev_free', 'sporco_amd_dev_upload',
+    'sporco_amd_dev_download', 'sporco_amd_dev_axpby', 'sporco_amd_tikhonov_filter_dev',
+    'sporco_amd_fftconv_dev', 'sporco_amd_csc_set_signal_dev', 'sporco_amd_csc_reconstruct_dev',
+    'sporco_amd_transfer_stats',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
     'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_l1w', 'sporco_amd_prox_sl1l2',
     'sporco_amd_rfl2norm2',
@@ -274,6 +278,19 @@ def load(path=None):
         'sporco_amd_irfftn2': [ctypes.c_int, i32, i32, i64, vp, vp],
         'sporco_amd_solvedbi_sm': [ctypes.c_int, i64, i64, i32, vp, dbl, vp, vp],
         'sporco_amd_inner': [ctypes.c_int, i64, i64, i32, vp, vp, vp],
+        'sporco_amd_dev_malloc': [ctypes.c_size_t, ctypes.POINTER(vp)],
+        'sporco_amd_dev_free': [vp],
+        'sporco_amd_dev_upload': [vp, vp, ctypes.c_size_t],
+        'sporco_amd_dev_download': [vp, vp, ctypes.c_size_t],
+        'sporco_amd_dev_axpby': [ctypes.c_int, i64, dbl, vp, dbl, vp, vp],
+        'sporco_amd_tikhonov_filter_dev': [ctypes.c_int, ctypes.c_int32, ctypes.c_int32, i64, vp, dbl,
+                                           ctypes.c_int32, vp, vp],
+        'sporco_amd_fftconv_dev': [ctypes.c_int, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(i64),
+                                   vp, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(i64), vp,
+                                   ctypes.c_int32, ctypes.c_int32, vp],
+        'sporco_amd_csc_set_signal_dev': [vp, vp],
+        'sporco_amd_csc_reconstruct_dev': [vp, ctypes.c_int, vp],
+        'sporco_amd_transfer_stats': [ctypes.POINTER(i64), ctypes.c_int],
         'sporco_amd_prox_l1': [ctypes.c_int, i64, vp, dbl, vp],
         'sporco_amd_prox_l1w': [ctypes.c_int, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), vp, vp],
         'sporco_amd_prox_sl1l2': [ctypes.c_int, i64, i32, i64, vp, dbl, dbl, vp],
@@ -294,6 +311,14 @@ def lib():
 
 def library_path():
     return _lib_path
+
+
+def transfer_stats(reset=False):
+    """Host <-> device traffic of the library since the last reset:
+    ``{'h2d_bytes', 'h2d_calls', 'd2h_bytes', 'd2h_calls'}``."""
+    out = (ctypes.c_int64 * 4)()
+    check(lib().sporco_amd_transfer_stats(out, 1 if reset else 0))
+    return dict(h2d_bytes=out[0], h2d_calls=out[1], d2h_bytes=out[2], d2h_calls=out[3])
 
 
 def check(rc):
@@ -573,6 +598,14 @@ class Solver(object):
         out = np.empty((H, W, self.Cs, N, 1), dtype=self.dtype)
         check(self._lib.sporco_amd_csc_reconstruct(self._h, var, _ptr(out)))
         return out
+
+    def reconstruct_dev(self, var, dst_ptr):
+        """The same into a device array (H, W, Cs, N) at ``dst_ptr``."""
+        check(self._lib.sporco_amd_csc_reconstruct_dev(self._h, var, ctypes.c_void_p(dst_ptr)))
+
+    def set_signal_dev(self, ptr):
+        """set_signal from a device array (H, W, Cs, N): no host copy."""
+        check(self._lib.sporco_amd_csc_set_signal_dev(self._h, ctypes.c_void_p(ptr)))
 
     def dhs_absmax(self):
         v = ctypes.c_double(0.0)

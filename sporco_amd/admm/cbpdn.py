@@ -108,18 +108,24 @@ class GenericConvBPDN(admm.ADMMEqual):
     _multichannel_dict_ok = True
 
     def __init__(self, D, S, opt=None, dimK=None, dimN=2, device=0, stream=None,
-                 reducer=None):
+                 reducer=None, resident=False):
         """``D``, ``S``, ``opt``, ``dimK``, ``dimN`` as in the reference
         (sporco/admm/cbpdn.py:175-204).  Backend-only keyword arguments:
         ``device`` (HIP device index), ``stream`` (a hipStream_t to share, e.g.
-        ``torch.cuda.current_stream().cuda_stream``) and ``reducer`` (sums the
+        ``torch.cuda.current_stream().cuda_stream``), ``reducer`` (sums the
         per-iteration scalars over image shards held by other ranks, see
-        :mod:`sporco_amd.dist`)."""
+        :mod:`sporco_amd.dist`) and ``resident`` (results stay in HBM: ``solve()`` /
+        ``getcoef()`` return a :class:`sporco_amd.device.DeviceArray` view instead of
+        downloading).  ``S`` may itself be a ``DeviceArray`` -- e.g. the highpass output of
+        :func:`sporco_amd.signal.tikhonov_filter` -- and is then taken without a host copy."""
+        from ..device import DeviceArray
+        self._S_dev = S if isinstance(S, DeviceArray) else None
+        self._resident = bool(resident)
         if opt is None:
             opt = GenericConvBPDN.Options()
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
-        if not (np.isrealobj(D) and np.isrealobj(S)):
+        if not (np.isrealobj(D) and (self._S_dev is not None or np.isrealobj(S))):
             raise NotImplementedError("sporco_amd handles real-valued D and S")
         self.real_dtype = True
         if not hasattr(self, 'cri'):
@@ -139,9 +145,35 @@ class GenericConvBPDN(admm.ADMMEqual):
             self.Nx = self.Nx * reducer.world_size
             self.Nc = self.Nc * reducer.world_size
         self.D = np.asarray(D.reshape(self.cri.shpD), dtype=self.dtype)
-        self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
-        self._dev.set_signal(self.S)
+        if self._S_dev is not None:
+            if self._S_dev.dtype != self.dtype:
+                raise TypeError("a device-resident signal must already have the solver's dtype")
+            self._S_host = None            # (downloaded on first access of .S)
+            self._dev.set_signal_dev(self._S_dev.ptr)
+        else:
+            self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
+            self._dev.set_signal(self.S)
         self.setdict()
+
+    @property
+    def S(self):
+        """The signal in the internal layout; for a device-resident input, a host copy made
+        on first access."""
+        if self._S_host is None and self._S_dev is not None:
+            self._S_host = self._S_dev.get().reshape(self.cri.shpS)
+        return self._S_host
+
+    @S.setter
+    def S(self, value):
+        self._S_host = value
+
+    def getmin(self):
+        """The minimiser (``ReturnX``: X, else Y) -- as a device view when ``resident``."""
+        var = _lib.VAR_X if self.opt['ReturnX'] else _lib.VAR_Y
+        if getattr(self, '_resident', False):
+            from ..device import DeviceArray
+            return DeviceArray(self.cri.shpX, self.dtype, ptr=self._dev.device_ptr(var), base=self)
+        return self._fetch(var)
 
     # -- device plumbing --------------------------------------------------------
     def _new_handle(self):
@@ -189,6 +221,8 @@ class GenericConvBPDN(admm.ADMMEqual):
         state = self.__dict__.copy()
         for key in ('_dev', '_cache'):
             state.pop(key, None)
+        state['_S_host'] = self.S          # (a device-resident signal travels as a host copy)
+        state['_S_dev'] = None
         # raw device contents: U is saved WITHOUT the pending scale (kept in
         # _u_scale) so that a restored solver continues bit-identically
         state['_saved_arrays'] = {v: self._dev.download(v)
@@ -486,8 +520,17 @@ class GenericConvBPDN(admm.ADMMEqual):
     def rhochange(self):
         pass
 
-    def reconstruct(self, X=None):
-        """irfftn(sum_m Df * rfftn(X)), X defaulting to Y (cbpdn.py:373-380)."""
+    def reconstruct(self, X=None, device=False):
+        """irfftn(sum_m Df * rfftn(X)), X defaulting to Y (cbpdn.py:373-380).  ``device=True``:
+        the result stays in HBM (a :class:`sporco_amd.device.DeviceArray` (H, W, C, N))."""
+        if device:
+            from ..device import DeviceArray
+            if X is not None:
+                raise NotImplementedError("reconstruct(device=True) reconstructs from Y")
+            H, W_ = self.cri.Nv
+            out = DeviceArray((H, W_, self._dev.Cs, self.cri.K), self.dtype)
+            self._dev.reconstruct_dev(_lib.VAR_Y, out.ptr)
+            return out
         if X is None:
             var = _lib.VAR_Y
         else:

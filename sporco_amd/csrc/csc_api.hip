@@ -19,9 +19,41 @@
 #include "csc_rows.h"
 #include "fft.h"
 
+#include <atomic>
+
 namespace sporco_amd {
 
 static thread_local std::string g_last_error;
+
+// Every host <-> device copy of this file is counted (sporco_amd_transfer_stats): the claim
+// "the pipeline makes one upload and one download" is then something a test can check.
+static std::atomic<int64_t> g_xfer[4];
+static inline void count_xfer(hipMemcpyKind k, size_t bytes) {
+    if (k == hipMemcpyHostToDevice) {
+        g_xfer[0] += (int64_t)bytes;
+        g_xfer[1] += 1;
+    } else if (k == hipMemcpyDeviceToHost) {
+        g_xfer[2] += (int64_t)bytes;
+        g_xfer[3] += 1;
+    }
+}
+static inline hipError_t sa_memcpy(void *d, const void *s, size_t n, hipMemcpyKind k) {
+    count_xfer(k, n);
+    return hipMemcpy(d, s, n, k);
+}
+static inline hipError_t sa_memcpy_async(void *d, const void *s, size_t n, hipMemcpyKind k,
+                                         hipStream_t st) {
+    count_xfer(k, n);
+    return hipMemcpyAsync(d, s, n, k, st);
+}
+static inline hipError_t sa_memcpy2d_async(void *d, size_t dp, const void *s, size_t sp, size_t w,
+                                           size_t h, hipMemcpyKind k, hipStream_t st) {
+    count_xfer(k, w * h);
+    return hipMemcpy2DAsync(d, dp, s, sp, w, h, k, st);
+}
+#define hipMemcpy sa_memcpy
+#define hipMemcpyAsync sa_memcpy_async
+#define hipMemcpy2DAsync sa_memcpy2d_async
 
 enum ProfSlot {
     PS_FFT_R2C = 0,
@@ -118,6 +150,8 @@ struct CscBase {
     virtual void sync() = 0;
     virtual int query(int what) = 0;
     virtual void set_signal(const void *S) = 0;
+    virtual void set_signal_dev(const void *S_dev) = 0;
+    virtual void reconstruct_dev(int var, void *dst_dev) = 0;
     virtual void set_dict(const void *D, int dH, int dW) = 0;
     virtual void set_weight(int which, const void *w, const int64_t shape[5]) = 0;
     virtual void set_grad_weight(const void *w) = 0;
@@ -637,6 +671,16 @@ template <typename T> struct Csc : CscBase {
         fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CNs);
         refresh_fused_signal();
         sync();  // the host buffer may be released after return
+        have_signal = true;
+    }
+
+    void set_signal_dev(const void *S_dev) override {
+        before_state_change();
+        SA_HIP(hipMemcpyAsync(sreal, S_dev, sizeof(T) * (int64_t)H * W * CNs,
+                              hipMemcpyDeviceToDevice, st));
+        fwd2(sreal, nullptr, T(0), cv(SPORCO_AMD_VAR_SF), CNs);
+        refresh_fused_signal();
+        sync();
         have_signal = true;
     }
 
@@ -1552,6 +1596,21 @@ template <typename T> struct Csc : CscBase {
         }
         inv2(innerb, innerb, sreal, CNs);
         SA_HIP(hipMemcpyAsync(dst, sreal, sizeof(T) * (int64_t)H * W * CNs, hipMemcpyDeviceToHost, st));
+        sync();
+    }
+    void reconstruct_dev(int var, void *dst_dev) override {
+        require_ready();
+        SA_REQUIRE(!var_is_complex(var), "reconstruct needs a real state variable");
+        before_read(var);
+        cx<T> *wk = work_buf();
+        fwd2(rv(var), nullptr, T(0), wk, P);
+        {
+            ProfScope ps(prof, PS_OTHER);
+            inner_df(wk);
+        }
+        inv2(innerb, innerb, sreal, CNs);
+        SA_HIP(hipMemcpyAsync(dst_dev, sreal, sizeof(T) * (int64_t)H * W * CNs,
+                              hipMemcpyDeviceToDevice, st));
         sync();
     }
 
@@ -3511,6 +3570,76 @@ template <typename T> void prim_irfftn2(int H, int W, int64_t P, const void *in,
     ph.destroy();
 }
 
+// signal.tikhonov_filter on device arrays (csc_kernels.h has the elementwise pieces)
+template <typename T>
+void prim_tikhonov_dev(int H, int W, int64_t P, const void *s, double lmbda, int npd, void *slp,
+                       void *shp) {
+    const int Hp = H + 2 * npd, Wp = W + 2 * npd;
+    const int64_t Wfp = Wp / 2 + 1;
+    DevBuf sp(sizeof(T) * (size_t)Hp * Wp * P), spf(sizeof(cx<T>) * (size_t)Hp * Wfp * P);
+    FftPlan pw, ph;
+    pw.init(Wp);
+    ph.init(Hp);
+    launch_sympad<T>(nullptr, static_cast<const T *>(s), sp.as<T>(), H, W, P, npd);
+    rfft2<T>(nullptr, pw, ph, sp.as<T>(), nullptr, T(0), spf.as<cx<T>>(), Hp, Wp, P);
+    launch_tikhonov_divide<T>(nullptr, spf.as<cx<T>>(), Hp, Wp, P, lmbda);
+    irfft2<T>(nullptr, pw, ph, spf.as<cx<T>>(), spf.as<cx<T>>(), sp.as<T>(), Hp, Wp, P);
+    launch_crop_highpass<T>(nullptr, sp.as<T>(), static_cast<const T *>(s), static_cast<T *>(slp),
+                            static_cast<T *>(shp), H, W, P, npd);
+    SA_HIP(hipDeviceSynchronize());
+    pw.destroy();
+    ph.destroy();
+}
+
+template <typename T>
+void prim_fftconv_dev(int ha, int wa, const int64_t *da, const void *a, int hb, int wb,
+                      const int64_t *db, const void *b, int oh, int ow, void *out) {
+    const int H = std::max(ha, hb), W = std::max(wa, wb);
+    const int64_t Wf = W / 2 + 1;
+    int64_t d[3], sa[3], sb[3], pa = 1, pb = 1, po = 1;
+    for (int i = 0; i < 3; ++i) {
+        d[i] = std::max(da[i], db[i]);
+        SA_REQUIRE((da[i] == 1 || da[i] == d[i]) && (db[i] == 1 || db[i] == d[i]) && d[i] >= 1,
+                   "fftconv: the trailing axes must broadcast");
+        pa *= da[i];
+        pb *= db[i];
+        po *= d[i];
+    }
+    int64_t ra = 1, rb = 1;
+    for (int i = 2; i >= 0; --i) {
+        sa[i] = da[i] == 1 ? 0 : ra;
+        sb[i] = db[i] == 1 ? 0 : rb;
+        ra *= da[i];
+        rb *= db[i];
+    }
+    DevBuf pada(sizeof(T) * (size_t)H * W * pa), padb(sizeof(T) * (size_t)H * W * pb);
+    DevBuf af(sizeof(cx<T>) * (size_t)H * Wf * pa), bf(sizeof(cx<T>) * (size_t)H * Wf * pb);
+    DevBuf of(sizeof(cx<T>) * (size_t)H * Wf * po), tmp(sizeof(T) * (size_t)H * W * po);
+    FftPlan pw, ph;
+    pw.init(W);
+    ph.init(H);
+    launch_zeropad2<T>(nullptr, static_cast<const T *>(a), pada.as<T>(), ha, wa, H, W, pa);
+    launch_zeropad2<T>(nullptr, static_cast<const T *>(b), padb.as<T>(), hb, wb, H, W, pb);
+    rfft2<T>(nullptr, pw, ph, pada.as<T>(), nullptr, T(0), af.as<cx<T>>(), H, W, pa);
+    rfft2<T>(nullptr, pw, ph, padb.as<T>(), nullptr, T(0), bf.as<cx<T>>(), H, W, pb);
+    launch_cmul_bcast<T>(nullptr, af.as<cx<T>>(), bf.as<cx<T>>(), of.as<cx<T>>(), (int64_t)H * Wf, d, sa,
+                         sb, pa, pb);
+    const bool roll = oh != 0 || ow != 0;
+    T *dst = roll ? tmp.as<T>() : static_cast<T *>(out);
+    irfft2<T>(nullptr, pw, ph, of.as<cx<T>>(), of.as<cx<T>>(), dst, H, W, po);
+    if (roll) launch_roll2<T>(nullptr, tmp.as<T>(), static_cast<T *>(out), H, W, po, oh, ow);
+    SA_HIP(hipDeviceSynchronize());
+    pw.destroy();
+    ph.destroy();
+}
+
+template <typename T> void prim_axpby(int64_t n, double a, const void *x, double b, const void *y,
+                                      void *out) {
+    launch_axpby<T>(nullptr, (T)a, static_cast<const T *>(x), (T)b, static_cast<const T *>(y),
+                    static_cast<T *>(out), n);
+    SA_HIP(hipDeviceSynchronize());
+}
+
 template <typename T>
 void prim_solvedbi_sm(int64_t npix, int64_t CN, int K, const void *ah, double rho, const void *b,
                       void *x) {
@@ -3653,6 +3782,79 @@ int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *
     SA_API_BEGIN
     SA_REQUIRE(v && out && n >= 1, "bad argument");
     SA_DISPATCH(dtype, prim_prox_l1, n, v, alpha, out)
+    SA_API_END
+}
+
+int sporco_amd_dev_malloc(size_t bytes, void **ptr_dev) {
+    SA_API_BEGIN
+    SA_REQUIRE(ptr_dev != nullptr, "null argument");
+    require_gpu();
+    SA_HIP(hipMalloc(ptr_dev, bytes ? bytes : 1));
+    SA_API_END
+}
+int sporco_amd_dev_free(void *ptr_dev) {
+    SA_API_BEGIN
+    if (ptr_dev) SA_HIP(hipFree(ptr_dev));
+    SA_API_END
+}
+int sporco_amd_dev_upload(void *dst_dev, const void *src_host, size_t bytes) {
+    SA_API_BEGIN
+    SA_REQUIRE(dst_dev && src_host, "null argument");
+    SA_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    SA_API_END
+}
+int sporco_amd_dev_download(void *dst_host, const void *src_dev, size_t bytes) {
+    SA_API_BEGIN
+    SA_REQUIRE(dst_host && src_dev, "null argument");
+    SA_HIP(hipDeviceSynchronize());
+    SA_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    SA_API_END
+}
+int sporco_amd_dev_axpby(int dtype, int64_t n, double a, const void *x, double b, const void *y,
+                         void *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(x && out && n >= 1, "bad argument");
+    SA_DISPATCH(dtype, prim_axpby, n, a, x, b, y, out)
+    SA_API_END
+}
+int sporco_amd_tikhonov_filter_dev(int dtype, int32_t H, int32_t W, int64_t P, const void *s_dev,
+                                   double lmbda, int32_t npd, void *slp_dev, void *shp_dev) {
+    SA_API_BEGIN
+    SA_REQUIRE(s_dev && slp_dev && shp_dev && H >= 1 && W >= 1 && P >= 1 && npd >= 0, "bad argument");
+    SA_DISPATCH(dtype, prim_tikhonov_dev, H, W, P, s_dev, lmbda, npd, slp_dev, shp_dev)
+    SA_API_END
+}
+int sporco_amd_fftconv_dev(int dtype, int32_t ha, int32_t wa, const int64_t da[3], const void *a_dev,
+                           int32_t hb, int32_t wb, const int64_t db[3], const void *b_dev,
+                           int32_t origin_h, int32_t origin_w, void *out_dev) {
+    SA_API_BEGIN
+    SA_REQUIRE(da && db && a_dev && b_dev && out_dev && ha >= 1 && wa >= 1 && hb >= 1 && wb >= 1,
+               "bad argument");
+    SA_DISPATCH(dtype, prim_fftconv_dev, ha, wa, da, a_dev, hb, wb, db, b_dev, origin_h, origin_w,
+                out_dev)
+    SA_API_END
+}
+int sporco_amd_csc_set_signal_dev(sporco_amd_csc_t h, const void *S_dev) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(S_dev != nullptr, "S_dev is null");
+    h->impl->set_signal_dev(S_dev);
+    SA_API_END
+}
+int sporco_amd_csc_reconstruct_dev(sporco_amd_csc_t h, int var, void *dst_dev) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(dst_dev != nullptr, "dst_dev is null");
+    h->impl->reconstruct_dev(var, dst_dev);
+    SA_API_END
+}
+int sporco_amd_transfer_stats(int64_t out[4], int reset) {
+    SA_API_BEGIN
+    SA_REQUIRE(out != nullptr, "null argument");
+    for (int i = 0; i < 4; ++i) {
+        out[i] = g_xfer[i];
+        if (reset) g_xfer[i] = 0;
+    }
     SA_API_END
 }
 

@@ -262,6 +262,37 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
                       double *out);
 
 // ---------------------------------------------------------------------------
+// Pre / post-processing around the solvers, on device arrays (sporco/signal.py:244-301,
+// sporco/fft.py:376-417): elementwise pieces; the transforms are fft.h's.
+// ---------------------------------------------------------------------------
+// out(H + 2 npd, W + 2 npd, P) = numpy.pad(in(H, W, P), npd on axes 0 and 1, 'symmetric')
+template <typename T>
+void launch_sympad(hipStream_t st, const T *in, T *out, int H, int W, int64_t P, int npd);
+// spf(Hp, Wp/2+1, P) /= 1 + lmbda (|Gr|^2 + |Gc|^2), the two-tap gradient spectra
+// 2 - 2 cos(2 pi f / n) of signal.py:286-289 written down directly
+template <typename T>
+void launch_tikhonov_divide(hipStream_t st, cx<T> *spf, int Hp, int Wp, int64_t P, double lmbda);
+// slp = sp[npd : npd + H, npd : npd + W]; shp = s - slp
+template <typename T>
+void launch_crop_highpass(hipStream_t st, const T *sp, const T *s, T *slp, T *shp, int H, int W,
+                          int64_t P, int npd);
+// out(H, W, P) = in(h, w, P) zero-padded (or cropped) to (H, W)
+template <typename T>
+void launch_zeropad2(hipStream_t st, const T *in, T *out, int h, int w, int H, int W, int64_t P);
+// out[pix, i0, i1, i2] = a[pix, ...] * b[pix, ...] over three trailing axes of extents d[0..2],
+// element strides sa / sb (0 on an axis the operand broadcasts over)
+template <typename T>
+void launch_cmul_bcast(hipStream_t st, const cx<T> *a, const cx<T> *b, cx<T> *out, int64_t npix,
+                       const int64_t d[3], const int64_t sa[3], const int64_t sb[3], int64_t pa,
+                       int64_t pb);
+// out[h, w, p] = in[(h + oh) mod H, (w + ow) mod W, p]   (numpy.roll by -origin)
+template <typename T>
+void launch_roll2(hipStream_t st, const T *in, T *out, int H, int W, int64_t P, int oh, int ow);
+// out = a x + b y (y may be null)
+template <typename T>
+void launch_axpby(hipStream_t st, T a, const T *x, T b, const T *y, T *out, int64_t n);
+
+// ---------------------------------------------------------------------------
 // Device-resident ADMM control (sporco_amd_csc_admm_run): the residuals, tolerances, the
 // adaptive penalty parameter and the stopping test of sporco/admm/admm.py:462-486, 549-575,
 // 375-377 evaluated by a one-thread kernel at the end of every iteration, in the same

@@ -2073,6 +2073,189 @@ void launch_finalize2(hipStream_t st, const double *pa, int nblocks_a, int strid
 }
 
 // ---------------------------------------------------------------------------
+// pre / post-processing on device arrays (csc_kernels.h)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(kThreads) sympad_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                          int H, int W, int64_t P, int npd) {
+    const int Hp = H + 2 * npd, Wp = W + 2 * npd;
+    const int64_t total = (int64_t)Hp * Wp * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % P, pix = i / P;
+        int w = (int)(pix % Wp) - npd, h = (int)(pix / Wp) - npd;
+        // 'symmetric': reflect about the edge, edge sample repeated; period 2n
+        auto refl = [](int v, int n) {
+            const int m = 2 * n;
+            v = ((v % m) + m) % m;
+            return v < n ? v : m - 1 - v;
+        };
+        h = refl(h, H);
+        w = refl(w, W);
+        out[i] = in[((int64_t)h * W + w) * P + p];
+    }
+}
+template <typename T>
+void launch_sympad(hipStream_t st, const T *in, T *out, int H, int W, int64_t P, int npd) {
+    const int64_t total = (int64_t)(H + 2 * npd) * (W + 2 * npd) * P;
+    hipLaunchKernelGGL((sympad_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, in, out, H, W,
+                       P, npd);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) tikhonov_divide_kernel(cx<T> *__restrict__ spf, int Hp,
+                                                                   int Wp, int64_t P, double lmbda) {
+    const int Wf = Wp / 2 + 1;
+    const int64_t total = (int64_t)Hp * Wf * P;
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / P;
+        const int wf = (int)(pix % Wf), h = (int)(pix / Wf);
+        const double a = 1.0 + lmbda * ((2.0 - 2.0 * cos(two_pi * h / Hp)) +
+                                        (2.0 - 2.0 * cos(two_pi * wf / Wp)));
+        const cx<T> v = spf[i];
+        spf[i] = mk<T>((T)((double)v.re / a), (T)((double)v.im / a));
+    }
+}
+template <typename T>
+void launch_tikhonov_divide(hipStream_t st, cx<T> *spf, int Hp, int Wp, int64_t P, double lmbda) {
+    const int64_t total = (int64_t)Hp * (Wp / 2 + 1) * P;
+    hipLaunchKernelGGL((tikhonov_divide_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, spf,
+                       Hp, Wp, P, lmbda);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) crop_highpass_kernel(const T *__restrict__ sp,
+                                                                 const T *__restrict__ s,
+                                                                 T *__restrict__ slp,
+                                                                 T *__restrict__ shp, int H, int W,
+                                                                 int64_t P, int npd) {
+    const int Wp = W + 2 * npd;
+    const int64_t total = (int64_t)H * W * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % P, pix = i / P;
+        const int w = (int)(pix % W), h = (int)(pix / W);
+        const T lo = sp[((int64_t)(h + npd) * Wp + (w + npd)) * P + p];
+        slp[i] = lo;
+        shp[i] = s[i] - lo;
+    }
+}
+template <typename T>
+void launch_crop_highpass(hipStream_t st, const T *sp, const T *s, T *slp, T *shp, int H, int W,
+                          int64_t P, int npd) {
+    hipLaunchKernelGGL((crop_highpass_kernel<T>), dim3(grid_for((int64_t)H * W * P)), dim3(kThreads), 0,
+                       st, sp, s, slp, shp, H, W, P, npd);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) zeropad2_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                            int h, int w, int H, int W, int64_t P) {
+    const int64_t total = (int64_t)H * W * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % P, pix = i / P;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        out[i] = (y < h && x < w) ? in[((int64_t)y * w + x) * P + p] : T(0);
+    }
+}
+template <typename T>
+void launch_zeropad2(hipStream_t st, const T *in, T *out, int h, int w, int H, int W, int64_t P) {
+    hipLaunchKernelGGL((zeropad2_kernel<T>), dim3(grid_for((int64_t)H * W * P)), dim3(kThreads), 0, st,
+                       in, out, h, w, H, W, P);
+    SA_HIP(hipGetLastError());
+}
+
+struct Bcast3 {
+    int64_t d[3], sa[3], sb[3], pa, pb;
+};
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cmul_bcast_kernel(const cx<T> *__restrict__ a,
+                                                              const cx<T> *__restrict__ b,
+                                                              cx<T> *__restrict__ out, int64_t npix,
+                                                              const Bcast3 bc) {
+    const int64_t po = bc.d[0] * bc.d[1] * bc.d[2];
+    const int64_t total = npix * po;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / po;
+        int64_t r = i - pix * po;
+        const int64_t i2 = r % bc.d[2];
+        r /= bc.d[2];
+        const int64_t i1 = r % bc.d[1], i0 = r / bc.d[1];
+        const cx<T> x = a[pix * bc.pa + i0 * bc.sa[0] + i1 * bc.sa[1] + i2 * bc.sa[2]];
+        const cx<T> y = b[pix * bc.pb + i0 * bc.sb[0] + i1 * bc.sb[1] + i2 * bc.sb[2]];
+        out[i] = cmul(x, y);
+    }
+}
+template <typename T>
+void launch_cmul_bcast(hipStream_t st, const cx<T> *a, const cx<T> *b, cx<T> *out, int64_t npix,
+                       const int64_t d[3], const int64_t sa[3], const int64_t sb[3], int64_t pa,
+                       int64_t pb) {
+    Bcast3 bc;
+    for (int i = 0; i < 3; ++i) {
+        bc.d[i] = d[i];
+        bc.sa[i] = sa[i];
+        bc.sb[i] = sb[i];
+    }
+    bc.pa = pa;
+    bc.pb = pb;
+    hipLaunchKernelGGL((cmul_bcast_kernel<T>), dim3(grid_for(npix * d[0] * d[1] * d[2])), dim3(kThreads),
+                       0, st, a, b, out, npix, bc);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) roll2_kernel(const T *__restrict__ in, T *__restrict__ out,
+                                                         int H, int W, int64_t P, int oh, int ow) {
+    const int64_t total = (int64_t)H * W * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % P, pix = i / P;
+        const int w = (int)(pix % W), h = (int)(pix / W);
+        const int hs = (((h + oh) % H) + H) % H, ws = (((w + ow) % W) + W) % W;
+        out[i] = in[((int64_t)hs * W + ws) * P + p];
+    }
+}
+template <typename T>
+void launch_roll2(hipStream_t st, const T *in, T *out, int H, int W, int64_t P, int oh, int ow) {
+    hipLaunchKernelGGL((roll2_kernel<T>), dim3(grid_for((int64_t)H * W * P)), dim3(kThreads), 0, st, in,
+                       out, H, W, P, oh, ow);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) axpby_kernel(T a, const T *__restrict__ x, T b,
+                                                         const T *__restrict__ y, T *__restrict__ out,
+                                                         int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y ? a * x[i] + b * y[i] : a * x[i];
+}
+template <typename T>
+void launch_axpby(hipStream_t st, T a, const T *x, T b, const T *y, T *out, int64_t n) {
+    hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, a, x, b, y, out, n);
+    SA_HIP(hipGetLastError());
+}
+#define SA_INST_PREPOST(T)                                                                          \
+    template void launch_sympad<T>(hipStream_t, const T *, T *, int, int, int64_t, int);            \
+    template void launch_tikhonov_divide<T>(hipStream_t, cx<T> *, int, int, int64_t, double);       \
+    template void launch_crop_highpass<T>(hipStream_t, const T *, const T *, T *, T *, int, int,    \
+                                          int64_t, int);                                            \
+    template void launch_zeropad2<T>(hipStream_t, const T *, T *, int, int, int, int, int64_t);     \
+    template void launch_cmul_bcast<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t, \
+                                       const int64_t[3], const int64_t[3], const int64_t[3],        \
+                                       int64_t, int64_t);                                           \
+    template void launch_roll2<T>(hipStream_t, const T *, T *, int, int, int64_t, int, int);        \
+    template void launch_axpby<T>(hipStream_t, T, const T *, T, const T *, T *, int64_t);
+SA_INST_PREPOST(float)
+SA_INST_PREPOST(double)
+
+// ---------------------------------------------------------------------------
 // device-resident ADMM control (csc_kernels.h)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {

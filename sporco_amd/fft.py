@@ -81,19 +81,59 @@ def rfl2norm2(xf, xs, axis=(0, 1)):
 
 def fftconv(a, b, axes=(0, 1), origin=None):
     """Circular convolution of real arrays over axes (0, 1) by multiplication in the DFT
-    domain, ``origin`` shifting the result (sporco/fft.py:376-417).  The remaining axes of
-    ``a`` and ``b`` broadcast against each other."""
+    domain, ``origin`` shifting the result (sporco/fft.py:376-417), on the device
+    (``sporco_amd_fftconv_dev``).  The remaining axes of ``a`` and ``b`` broadcast against each
+    other.  NumPy arrays: one upload per operand, one download; device arrays
+    (:class:`sporco_amd.device.DeviceArray`) in, device array out."""
+    from .device import DeviceArray
     _check_axes(axes)
-    a, b = np.asarray(a), np.asarray(b)
-    if np.iscomplexobj(a) or np.iscomplexobj(b):
-        raise NotImplementedError("sporco_amd.fft handles real-valued arrays")
+    dev = isinstance(a, DeviceArray) or isinstance(b, DeviceArray)
+    ops = []
+    for x in (a, b):
+        if not isinstance(x, DeviceArray):
+            x = np.asarray(x)
+            if np.iscomplexobj(x):
+                raise NotImplementedError("sporco_amd.fft handles real-valued arrays")
+        ops.append(x)
+    a, b = ops
+    dt = np.result_type(a.dtype, b.dtype, np.float32)
     nd = max(a.ndim, b.ndim)
-    a = a.reshape(a.shape + (1,) * (nd - a.ndim))
-    b = b.reshape(b.shape + (1,) * (nd - b.ndim))
-    dims = tuple(int(max(x, y)) for x, y in zip(a.shape[:2], b.shape[:2]))
-    af = rfftn(a, dims, axes)
-    bf = rfftn(b, dims, axes)
-    ab = irfftn(np.ascontiguousarray(af * bf), dims, axes)
-    if origin is not None:
-        ab = np.roll(ab, -np.array(origin), axis=axes)
-    return ab
+    ash = tuple(a.shape) + (1,) * (nd - a.ndim)
+    bsh = tuple(b.shape) + (1,) * (nd - b.ndim)
+    osh = tuple(max(x, y) for x, y in zip(ash, bsh))
+    for x, y, o in zip(ash[2:], bsh[2:], osh[2:]):
+        if x not in (1, o) or y not in (1, o):
+            raise ValueError("operands of shapes %s and %s do not broadcast" % (ash, bsh))
+    # merge the trailing axes into at most three groups on which both operands behave alike
+    groups = []
+    for x, y in zip(ash[2:], bsh[2:]):
+        kind = (x == 1, y == 1)
+        if x == 1 and y == 1:
+            continue
+        if groups and groups[-1][2] == kind:
+            groups[-1][0] *= x
+            groups[-1][1] *= y
+        else:
+            groups.append([x, y, kind])
+    if len(groups) > 3:
+        raise NotImplementedError("fftconv: more than three broadcast groups of trailing axes")
+    while len(groups) < 3:
+        groups.insert(0, [1, 1, None])
+    i64 = ctypes.c_int64
+    da = (i64 * 3)(*[g[0] for g in groups])
+    db = (i64 * 3)(*[g[1] for g in groups])
+
+    def to_dev(x):
+        if isinstance(x, DeviceArray):
+            if x.dtype != dt:
+                raise TypeError("device operands must share one dtype")
+            return x
+        return DeviceArray.from_host(np.ascontiguousarray(x, dtype=dt))
+    ad, bd = to_dev(a), to_dev(b)
+    out = DeviceArray(osh, dt)
+    og = (0, 0) if origin is None else tuple(int(v) for v in origin)
+    vp = ctypes.c_void_p
+    _lib.check(_lib.lib().sporco_amd_fftconv_dev(
+        _lib.dtype_code(dt), ash[0], ash[1], da, vp(ad.ptr), bsh[0], bsh[1], db, vp(bd.ptr),
+        og[0], og[1], vp(out.ptr)))
+    return out if dev else out.get()

@@ -42,22 +42,31 @@ def tikhonov_filter(s, lmbda, npd=16):
     r"""Lowpass / highpass split by Tikhonov regularisation with a gradient operator:
     ``sl = argmin_x (1/2)||x - s||^2 + (lmbda/2) sum_i ||G_i x||^2``, ``sh = s - sl``
     (sporco/signal.py:244-301): symmetric padding by ``npd``, division by
-    ``1 + lmbda sum_i |G_i|^2`` in the DFT domain, crop.  ``s`` is (H, W) or (H, W, ...) real."""
-    s = np.asarray(s)
-    if np.iscomplexobj(s):
-        raise NotImplementedError("sporco_amd handles real-valued signals")
+    ``1 + lmbda sum_i |G_i|^2`` in the DFT domain, crop -- all on the device
+    (``sporco_amd_tikhonov_filter_dev``).  ``s`` is (H, W) or (H, W, ...) real: a NumPy array
+    (one upload, one download of the two results together) or a
+    :class:`sporco_amd.device.DeviceArray`, in which case the results are device arrays too and
+    nothing crosses PCIe -- ``ConvBPDN(D, sh, ...)`` then takes the highpass part as it is."""
+    from . import _lib
+    from .device import DeviceArray
+    dev_in = isinstance(s, DeviceArray)
+    if not dev_in:
+        s = np.asarray(s)
+        if np.iscomplexobj(s):
+            raise NotImplementedError("sporco_amd handles real-valued signals")
     sdt = s.dtype
-    wrk = s if s.dtype in (np.float32, np.float64) else s.astype(np.float64)
-    Hp, Wp = s.shape[0] + 2 * npd, s.shape[1] + 2 * npd
-    # |FFT of [-1, 1]|^2 along an axis of length n is 2 - 2 cos(2 pi f / n)
-    gr = 2.0 - 2.0 * np.cos(2.0 * np.pi * np.arange(Hp) / Hp)
-    gc = 2.0 - 2.0 * np.cos(2.0 * np.pi * np.arange(Wp // 2 + 1) / Wp)
-    A = 1.0 + lmbda * (gr[:, np.newaxis] + gc[np.newaxis, :])
-    A = A.reshape(A.shape + (1,) * (s.ndim - 2)).astype(wrk.dtype)
-    sp = np.pad(wrk, ((npd, npd),) * 2 + ((0, 0),) * (s.ndim - 2), 'symmetric')
-    spf = sfft.rfftn(sp, None, (0, 1))
-    spf /= A
-    sp = sfft.irfftn(spf, (Hp, Wp), (0, 1))
-    slp = sp[npd:Hp - npd, npd:Wp - npd]
-    shp = wrk - slp
-    return slp.astype(sdt), shp.astype(sdt)
+    sd = s if dev_in else DeviceArray.from_host(s)
+    H, W = sd.shape[0], sd.shape[1]
+    P = int(np.prod(sd.shape[2:])) if sd.ndim > 2 else 1
+    # the two results side by side in one allocation: one download for a host caller
+    both = DeviceArray((2,) + sd.shape, sd.dtype)
+    slp = DeviceArray(sd.shape, sd.dtype, ptr=both.ptr, base=both)
+    shp = DeviceArray(sd.shape, sd.dtype, ptr=both.ptr + sd.nbytes, base=both)
+    vp = _lib.ctypes.c_void_p
+    _lib.check(_lib.lib().sporco_amd_tikhonov_filter_dev(
+        _lib.dtype_code(sd.dtype), H, W, P, vp(sd.ptr), float(lmbda), int(npd), vp(slp.ptr),
+        vp(shp.ptr)))
+    if dev_in:
+        return slp, shp
+    out = both.get()
+    return out[0].astype(sdt), out[1].astype(sdt)
