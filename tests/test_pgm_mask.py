@@ -71,5 +71,5 @@ def test_masked_dictionary_learning_trace(backend):
             assert max(getattr(its, f)) < 1e-10
         else:
             assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
-    with pytest.raises(NotImplementedError):
-        cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')
+    # every D-step of the reference's wrapper is offered (cbpdndlmd.py:130-132)
+    assert cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')['CCMOD', 'AutoRho', 'Period'] == 10
