@@ -455,7 +455,10 @@ template <typename T> struct Csc : CscBase {
             std::vector<cx<T>> ta(W);
             rows_twiddles<T>(W, ta.data());
             SA_HIP(hipMemcpy(twRows, ta.data(), sizeof(cx<T>) * W, hipMemcpyHostToDevice));
-            SA_HIP(hipMalloc((void **)&part_rows, sizeof(double) * 8 * (int64_t)H * ceil_div(P, 128)));
+            // (the joint epilogue tiles by (image, 32 filters): N K / 32 workgroups per row)
+            SA_HIP(hipMalloc((void **)&part_rows,
+                             sizeof(double) * 8 * (int64_t)H *
+                                 std::max<int64_t>(ceil_div(P, 128), (int64_t)N * ceil_div(K, 32))));
         }
         // the three ADMM state arrays start at zero (yinit/uinit, admm.py:279-289)
         for (int v : {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U, SPORCO_AMD_VAR_X}) (void)var_ptr(v);
@@ -1019,7 +1022,11 @@ template <typename T> struct Csc : CscBase {
         // while AutoRho is still moving it almost every iteration a lost bet costs one
         // extra pass, a won one saves three (rows_fwd of the next iteration).
         stable_run = p.u_scale == 1.0 ? stable_run + 1 : 0;
-        const bool emit = stable_run >= 2 && !std::getenv("SPORCO_AMD_NO_SPECULATION");
+        // (the joint epilogue has no registers left for the forward transform -- the emitting
+        // variant spills the tile, 22.4 ms against 13.0 + 6.6 ms for epilogue + rows_fwd at
+        // config 3, profiles/r02i_config3_*.json -- so ConvBPDNJoint does not speculate)
+        const bool emit = stable_run >= 2 && !std::getenv("SPORCO_AMD_NO_SPECULATION") &&
+                          !((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT"));
         RowsPostArgs<T> pa;
         pa.twA = twRows;
         pa.t_next = emit ? Xf : nullptr;
@@ -1033,6 +1040,7 @@ template <typename T> struct Csc : CscBase {
         pa.scale = T(1.0 / ((double)H * (double)W));
         pa.rlx = (T)p.rlx;
         pa.thr = (T)(p.lmbda / p.rho);
+        pa.thr21 = (T)(p.mu / p.rho);
         pa.u_scale = (T)p.u_scale;
         pa.flags = p.flags;
         pa.H = H;
@@ -1054,17 +1062,19 @@ template <typename T> struct Csc : CscBase {
             nt = launch_rows_inv_post<T>(st, pa);
         }
         if (p.flags & (F_RESID | F_OBJ)) {
-            // one launch sums both partial arrays: the six epilogue sums and the
+            // one launch sums both partial arrays: the six (joint: seven) epilogue sums and the
             // data-fidelity term of the column kernel
-            const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
-                                  SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
-            const double scales[6] = {1, 1, 1, 1, 1, 1};
+            const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                                  SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
+                                  SPORCO_AMD_OUT_L21};
+            const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
+            const int nrow = (p.flags & F_JOINT) ? 7 : 6;
             const int fslots[2] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_RGR};
             const double fscales[2] = {1.0 / ((double)H * W), 1.0 / ((double)H * W)};
             const bool dfid = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
             const int fnv = (p.flags & F_GRADREG) ? 2 : 1;
             ProfScope ps(prof, PS_FINALIZE);
-            launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, part_f_rows, fnv,
+            launch_finalize2(st, part_rows, (int)nt, 8, nrow, slots, scales, part_f, part_f_rows, fnv,
                              dfid ? fnv : 0, fslots, fscales, out_dev);
         }
         if (keep_x) {
@@ -1084,10 +1094,9 @@ template <typename T> struct Csc : CscBase {
 
     // ---- device-driven solve (include/sporco_amd.h: sporco_amd_csc_admm_run) -----------------
     bool admm_run_supported(const sporco_amd_admm_params &p) const {
-        return std::is_same<T, float>::value && rows_ok && fused && !fused_mc && !fused_slabs &&
-               !tail_mode &&
-               !(p.flags & (F_XRRS | F_JOINT | F_GRADREG | F_KEEP_X | F_FEVAL_Y)) &&
-               !std::getenv("SPORCO_AMD_HOST_LOOP");
+        return std::is_same<T, float>::value && rows_ok && (fused || fused_slabs) && !fused_mc &&
+               !tail_mode && !(p.flags & (F_XRRS | F_GRADREG | F_KEEP_X | F_FEVAL_Y)) &&
+               (!(p.flags & F_JOINT) || joint_rows_ok(p)) && !std::getenv("SPORCO_AMD_HOST_LOOP");
     }
 
     // one iteration of admm_iter_fused with every iteration-dependent scalar taken from ctl_dev
@@ -1128,7 +1137,15 @@ template <typename T> struct Csc : CscBase {
             fa.Ks = Ks;
             fa.ctl = ctl_dev;
             ProfScope ps(prof, PS_FUSED_COLS);
-            part_f_rows = (int)launch_fused_cols<T>(st, fa);
+            if (fused_slabs) {      // 64 < K <= 256: the two slab kernels (csc_fused.h)
+                FusedSlabArgs<T> sa;
+                sa.c = fa;
+                sa.qpart = qpart;
+                launch_cols_fwd_partial<T>(st, sa);
+                part_f_rows = (int)launch_cols_sm_apply_inv<T>(st, sa);
+            } else {
+                part_f_rows = (int)launch_fused_cols<T>(st, fa);
+            }
             xf_tiled = true;
         }
         RowsPostArgs<T> pa;
@@ -1210,6 +1227,7 @@ template <typename T> struct Csc : CscBase {
         in.tau = c.rho_tau;
         in.mu = c.rho_mu;
         in.xi = c.rho_xi;
+        in.mu21 = p.mu;
         in.k = c.k0;
         in.stable_run = stable_run;
         in.emitted = t_ready ? 1 : 0;
@@ -1219,7 +1237,10 @@ template <typename T> struct Csc : CscBase {
         in.autoscaling = c.auto_scaling;
         in.stdres = c.std_residuals;
         in.need_resid = c.need_residuals;
-        in.no_speculation = std::getenv("SPORCO_AMD_NO_SPECULATION") ? 1 : 0;
+        in.no_speculation = (std::getenv("SPORCO_AMD_NO_SPECULATION") ||
+                             ((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT")))
+                                ? 1
+                                : 0;
         launch_admm_ctl_init(st, ctl_dev, in);
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         const int ahead = c.lookahead > 0 ? c.lookahead : 3;
@@ -1243,15 +1264,17 @@ template <typename T> struct Csc : CscBase {
         for (; enq < c.max_iter && stop_at < 0;) {
             const int64_t nt = enqueue_iter_ctl(p);
             if (want_sums) {
-                const int slots[6] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
-                                      SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1};
-                const double scales[6] = {1, 1, 1, 1, 1, 1};
+                const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
+                                      SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
+                                      SPORCO_AMD_OUT_L21};
+                const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
                 const int fslots[2] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_RGR};
                 const double fscales[2] = {1.0 / ((double)H * W), 1.0 / ((double)H * W)};
                 const bool dfid = p.flags & F_OBJ;
                 {
                     ProfScope ps(prof, PS_FINALIZE);
-                    launch_finalize2(st, part_rows, (int)nt, 8, 6, slots, scales, part_f, part_f_rows,
+                    launch_finalize2(st, part_rows, (int)nt, 8, (p.flags & F_JOINT) ? 7 : 6, slots,
+                                     scales, part_f, part_f_rows,
                                      1, dfid ? 1 : 0, fslots, fscales, out_dev);
                 }
                 if (reduce) reduce(user, out_dev);
@@ -1497,9 +1520,17 @@ template <typename T> struct Csc : CscBase {
         return ams_bits;
     }
 
+    // ConvBPDNJoint inside the row epilogue (csc_rows.h): scalar weights, no NoBndryCross /
+    // AddMaskSim, C <= 4 channels, K a multiple of 32, single-channel dictionary
+    bool joint_rows_ok(const sporco_amd_admm_params &p) const {
+        return rows_ok && !fused_mc && rows_joint_supported<T>(W, C, K) && !wl1.ptr && !wl21.ptr &&
+               !(p.flags & (F_NOBNDRY | F_AMS | F_KEEP_X | F_GRADREG)) &&
+               !std::getenv("SPORCO_AMD_JOINT_SEPARATE");
+    }
+
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        if (rows_ok && !(p.flags & (F_XRRS | F_JOINT)) &&
+        if (rows_ok && !(p.flags & F_XRRS) && (!(p.flags & F_JOINT) || joint_rows_ok(p)) &&
             (fused || fused_slabs || !(p.flags & F_GRADREG))) {
             admm_iter_fused(p, out_dev);
             return;

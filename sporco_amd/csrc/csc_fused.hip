@@ -389,6 +389,7 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int wf = (slot / a.CN) * 8 + xcd;
     if (wf >= Wf) return;
+    if (a.ctl && a.ctl->stop) return;
     const int tile = wf * a.CN + slot % a.CN;
     const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
     const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
@@ -512,7 +513,9 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
     const cf *qp = aa.qpart + (int64_t)tile * NH * H + w;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
-    const float rho = a.rho;
+    // (device-driven solve: rho from the control block; nothing to do once it has stopped)
+    if (a.ctl && a.ctl->stop) return;
+    const float rho = a.ctl ? a.ctl->rho_f : a.rho;
     int token = 0;
     float obj = 0.f, rg = 0.f, ak = 0.f, bk = 0.f, gw = 0.f;
     if constexpr (GRAD) {

@@ -303,7 +303,7 @@ void launch_axpby(hipStream_t st, T a, const T *x, T b, const T *y, T *out, int6
 // ---------------------------------------------------------------------------
 struct AdmmCtl {
     // read by the iteration kernels
-    float rho_f, thr_f, u_scale_f;
+    float rho_f, thr_f, u_scale_f, thr21_f;
     int skip_fwd;      // T already holds rows_fwd of the current iterate (emitted, rho unchanged)
     int emit;          // this iteration's epilogue also emits the next iteration's T
     int stop;          // stopping test met: every later launch returns at once
@@ -313,8 +313,9 @@ struct AdmmCtl {
     double rho, u_scale;   // (rho: exact image of the solver-precision value)
     // constants of the solve
     double lmbda, abstol, reltol, sqrt_nc, sqrt_nx, tau, mu, xi;
+    double mu21;       // l2,1 weight of ConvBPDNJoint (thr21 = mu21 / rho)
     int autorho, period, autoscaling, stdres;
-    int need_resid, no_speculation, pad0, pad1;
+    int need_resid, no_speculation, pad0;
     unsigned long long t0;
 };
 // One per executed iteration, written to host-visible (pinned) memory; `seq` last.
@@ -327,7 +328,7 @@ struct AdmmRecord {
     int pad;
 };
 struct AdmmCtlInit {
-    double rho, u_scale, lmbda, abstol, reltol, sqrt_nc, sqrt_nx, tau, mu, xi;
+    double rho, u_scale, lmbda, abstol, reltol, sqrt_nc, sqrt_nx, tau, mu, xi, mu21;
     int k, stable_run, emitted, is_f32, autorho, period, autoscaling, stdres, need_resid,
         no_speculation;
 };

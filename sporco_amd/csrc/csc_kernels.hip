@@ -2264,6 +2264,7 @@ __device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {
     // csc_api.hip admm_iter_fused ((T)p.rho, (T)(p.lmbda / p.rho), (T)p.u_scale)
     c->rho_f = (float)c->rho;
     c->thr_f = (float)(c->lmbda / c->rho);
+    c->thr21_f = (float)(c->mu21 / c->rho);
     c->u_scale_f = (float)c->u_scale;
     c->stable_run = c->u_scale == 1.0 ? c->stable_run + 1 : 0;
     c->emit = (c->stable_run >= 2 && !c->no_speculation) ? 1 : 0;
@@ -2282,6 +2283,7 @@ __global__ void admm_ctl_init_kernel(AdmmCtl *c, const AdmmCtlInit in) {
     c->tau = in.tau;
     c->mu = in.mu;
     c->xi = in.xi;
+    c->mu21 = in.mu21;
     c->k = in.k;
     c->stable_run = in.stable_run;
     c->emitted = in.emitted;

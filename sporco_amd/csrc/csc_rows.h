@@ -49,7 +49,8 @@ template <typename T> struct RowsPostArgs {
     T *x;              // out (optional, may be null): X = irfftn(Xf)
     T scale;           // 1 / (H W)
     T rlx, thr, u_scale;
-    uint32_t flags;    // F_NONNEG | F_NOBNDRY | F_GEVAL_Y
+    T thr21 = T(0);    // F_JOINT: mu / rho, the l2,1 threshold of prox_sl1l2 (cbpdn.py:785-794)
+    uint32_t flags;    // F_NONNEG | F_NOBNDRY | F_GEVAL_Y | F_JOINT
     int H, W, C, N, K, dH, dW;
     int64_t P;
     Weight<T> wl1;
@@ -88,6 +89,12 @@ template <typename T> struct RowsProxArgs {
 };
 template <typename T> int64_t launch_rows_inv_prox_fwd(hipStream_t st, const RowsProxArgs<T> &a);
 
+// ConvBPDNJoint in the row epilogue (F_JOINT): a workgroup then owns one row, one image and 32
+// filters of ALL C <= 4 channels -- lane = (channel, filter pair), 16 lanes per channel -- so
+// that the l2 norm over the channels that prox_sl1l2 needs (prox/_l21.py:51-88 through
+// prox_l2, _lp.py:283-290) is a sum over the 16-lane rows of a wave (two permlane swaps).
+// Scalar weights, no NoBndryCross / AddMaskSim; K a multiple of 32.  partials[6] = the l2,1 sum.
+template <typename T> bool rows_joint_supported(int W, int C, int K);
 // Shapes the register-resident row kernels handle (float32, W in {256, 512}, K even).
 template <typename T> bool rows_supported(int W, int K);
 // Host table for RowsFwdArgs::twA ((W/32) * 32 entries).

@@ -327,9 +327,10 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // ---------------------------------------------------------------------------
 // MODE: 0 = plain epilogue; 1 = L1Weight array (+ NoBndryCross, AddMaskSim); 2 = NoBndryCross
 // and / or AddMaskSim without a weight array (no weight loads).
-template <int NW, bool WRITE_X, int MODE, bool EMIT_T>
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a) {
     constexpr bool GENERAL = MODE != 0;
+    static_assert(!JOINT || MODE == 0, "the joint epilogue takes scalar weights only");
     constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -345,10 +346,25 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
         thr = a.ctl->thr_f;
         usc = a.ctl->u_scale_f;
     }
-    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
-    const bool pv = p < a.P;
+    // columns of this thread: 128 consecutive ones of (c, n, k) per workgroup -- or, JOINT,
+    // (channel lane >> 4, image blockIdx / (K/32), filters 32 (blockIdx % (K/32)) + 2 (lane & 15))
     const int CN = a.C * a.N;
-    const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
+    int64_t p;
+    bool pv;
+    int cn, k;
+    if constexpr (JOINT) {
+        const int kbn = a.K >> 5, n = (int)blockIdx.x / kbn, kb = (int)blockIdx.x % kbn;
+        const int c = lane >> 4;
+        pv = c < a.C;
+        cn = pv ? c * a.N + n : 0;
+        k = pv ? kb * 32 + 2 * (lane & 15) : 0;
+        p = (int64_t)cn * a.K + k;
+    } else {
+        p = (int64_t)blockIdx.x * 128 + 2 * lane;
+        pv = p < a.P;
+        cn = pv ? (int)(p / a.K) : 0;
+        k = pv ? (int)(p % a.K) : 0;
+    }
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
     int token = 0;
@@ -388,8 +404,13 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
         const int mvoff = aml ? cn * NW * 4 : (int)0x80000000;
         mbits = __builtin_bit_cast(uint32_t, sa_buf_load1(Mb, mvoff, (h * CN * NW + w) * 4));
     }
-    float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f;
-    constexpr int B = EMIT_T ? 2 : 4;   // pixels per batch (Y, U of the next batch are in flight)
+    float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f, s_l21 = 0.f;
+    float thr21 = a.thr21;
+    if (JOINT && a.ctl) thr21 = a.ctl->thr21_f;
+    const float l21w = lane < 16 ? 1.f : 0.f;  // the l2,1 sum counts each channel group once
+    // pixels per batch (Y, U of the next batch are in flight); the emitting variants keep the
+    // tile for the forward transform and have fewer registers to spare
+    constexpr int B = EMIT_T ? (JOINT ? 1 : 2) : 4;
     cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll
@@ -416,6 +437,37 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
             // epilogue into dozens of blocks and the register allocator spills the tile)
             const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
             const float mkeep = (GENERAL && ((mbits >> n1) & 1u)) ? 0.f : 1.f;
+            if constexpr (JOINT) {
+                // prox_sl1l2 over the channel axis (cbpdn.py:785-794): soft threshold, then the
+                // channel vector of each (pixel, image, filter) shrunk in l2 norm,
+                // y = s max(0, 1 - thr21 / ||s||) (prox/_lp.py:283-290, zero where ||s|| = 0).
+                // The channels sit 16 lanes apart (idle lanes hold zeros).
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float ax = al * xs[e] + oma * yo[e];
+                    const float sv = soft1(ax + uo[e], thr);
+                    const float q = sum_over_rows(sv * sv);
+                    float fac = 1.f - thr21 * sa_rsq(q);      // (q = 0: -inf, or NaN when thr21 = 0)
+                    fac = fac > 0.f ? fac : 0.f;
+                    float y1 = fac * sv;
+                    if (nonneg && y1 < 0.f) y1 = 0.f;
+                    const float u1 = uo[e] + ax - y1;
+                    yn[e] = y1;
+                    un[e] = u1;
+                    const float dr = xs[e] - y1, ds = y1 - yo[e];
+                    s_r2 += dr * dr;
+                    s_s2 += ds * ds;
+                    s_x2 += xs[e] * xs[e];
+                    s_y2 += y1 * y1;
+                    s_u2 += u1 * u1;
+                    // (always formed: a branch on F_OBJ here would split the unrolled epilogue
+                    // into blocks and spill the tile, see the NoBndryCross note above)
+                    const float gvar = gy ? y1 : xs[e];
+                    s_l1 += fabsf(gvar);
+                    const float g2 = sum_over_rows(gvar * gvar);
+                    s_l21 += l21w * sa_sqrt(g2);
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 const float ax = al * xs[e] + oma * yo[e];
@@ -441,8 +493,10 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
                 s_u2 += u1 * u1;
                 s_l1 += fabsf(wt * (gy ? y1 : xs[e]));
             }
+            }
             buf_store_cf(Yo, voff, soff, mk<float>(yn[0], yn[1]));
             buf_store_cf(Uo, voff, soff, mk<float>(un[0], un[1]));
+
             if (WRITE_X) buf_store_cf(Xb, voff, soff, mk<float>(xs[0], xs[1]));
             if (EMIT_T) v[n1] = mk<float>(yn[0] - un[0], yn[1] - un[1]);
         }
@@ -464,8 +518,8 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
 
     // masked lanes contributed zeros everywhere except possibly the threshold of 0: their
     // inputs are all zero, so every term above is exactly 0
-    double acc[8] = {(double)s_r2, (double)s_s2, (double)s_x2, (double)s_y2,
-                     (double)s_u2, (double)s_l1, 0.0,          0.0};
+    double acc[8] = {(double)s_r2, (double)s_s2, (double)s_x2,   (double)s_y2,
+                     (double)s_u2, (double)s_l1, (double)s_l21, 0.0};
     const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
     block_sum_store<8>(acc, scratch, a.partials + tile * 8);
 }
@@ -662,9 +716,40 @@ template <> void launch_ams_pack<double>(hipStream_t, const Weight<double> &, ui
     throw Error(-1, "the fused row kernels are float32 only");
 }
 
+template <> bool rows_joint_supported<float>(int W, int C, int K) {
+    return rows_supported<float>(W, K) && C >= 1 && C <= 4 && K % 32 == 0;
+}
+template <> bool rows_joint_supported<double>(int, int, int) { return false; }
+
+template <int NW, bool EMIT>
+static void launch_post_joint_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true>);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, true>), grid, dim3(NW * 64),
+                       rows_lds_bytes(NW), st, a);
+}
+
 template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostArgs<float> &a) {
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
+    if (a.flags & F_JOINT) {
+        SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && !a.wl1.ptr && !a.ams_bits &&
+                       !(a.flags & F_NOBNDRY) && !a.x,
+                   "configuration not handled by the joint row epilogue");
+        const dim3 jgrid((unsigned)(a.N * (a.K / 32)), (unsigned)a.H);
+        if (a.W == 256) {
+            if (a.t_next) launch_post_joint_nw<8, true>(st, a, jgrid);
+            else launch_post_joint_nw<8, false>(st, a, jgrid);
+        } else {
+            if (a.t_next) launch_post_joint_nw<16, true>(st, a, jgrid);
+            else launch_post_joint_nw<16, false>(st, a, jgrid);
+        }
+        SA_HIP(hipGetLastError());
+        return (int64_t)jgrid.x * jgrid.y;
+    }
     const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
     if (a.W == 256) {
         if (a.t_next) launch_post_nw<8, true>(st, a, grid);

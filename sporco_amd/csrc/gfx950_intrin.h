@@ -16,6 +16,10 @@ __device__ __forceinline__ float sa_readlane(float v, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
+// 1 / sqrt(x) and sqrt(x) to 1 ulp, no denormal / IEEE fix-up sequences (v_rsq_f32, v_sqrt_f32)
+__device__ __forceinline__ float sa_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float sa_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 // 1 / x to 1 ulp (v_rcp_f32)
 __device__ __forceinline__ float sa_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

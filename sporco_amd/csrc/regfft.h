@@ -139,6 +139,18 @@ __device__ __forceinline__ float reduce8_across_lanes(const float (&r)[8], int l
     return t;
 }
 
+// v summed over the four 16-lane rows of the wave, in every lane (two VALU permlane swaps, no
+// LDS traffic): with both operands of a swap set to v, the swapped pair holds v and v of the
+// lane 16 (32) away in SOME order in every lane, so their sum needs no select.
+__device__ __forceinline__ float sum_over_rows(float v) {
+    float a = v, b = v;
+    sa_swap16(a, b);
+    const float t = a + b;      // v[l] + v[l ^ 16]
+    float c = t, d = t;
+    sa_swap32(c, d);
+    return c + d;               // ... + the same of the lane 32 away
+}
+
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
 template <typename F, int... Is>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {

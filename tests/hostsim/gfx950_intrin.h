@@ -4,6 +4,7 @@
 // kernels include <gfx950_intrin.h> and this directory comes first on the
 // simulator's include path.  Never seen by the hipcc build.
 #pragma once
+#include <cmath>
 #include <chrono>
 
 #include <hip/hip_runtime.h>
@@ -108,6 +109,8 @@ inline void sa_swap16(float &a, float &b) {
     else
         b = a_odd;
 }
+inline float sa_rsq(float x) { return 1.0f / std::sqrt(x); }
+inline float sa_sqrt(float x) { return std::sqrt(x); }
 inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }
 inline float sa_lane_xor2(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 2); }
 inline float sa_lane_xor7(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 7); }

@@ -77,6 +77,67 @@ def test_fused_joint_multichannel(backend):
     assert rel_l2(b.getitstat().ObjFun, ref['ObjFun']) < 1e-3
 
 
+def test_joint_l21_inside_the_row_epilogue(backend):
+    """ConvBPDNJoint on the three-launch path: the l2 norm over the channels that prox_sl1l2
+    needs (cbpdn.py:785-794, prox/_l21.py:51-88) is taken inside `rows_inv_post` -- lanes =
+    (channel, filter pair), channel sums by permlane swaps -- so no separate epilogue pass
+    runs.  Against the float64 oracle; a weight array falls back to the separate epilogue."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    H, W, C, K = 256, 256, 3, 32
+    N, iters = (1, 2) if backend == 'hostsim' else (3, 8)
+    D, S = problem(H, W, K, N, seed=31, C=C)
+    opt = cbpdn.ConvBPDNJoint.Options({'MaxMainIter': iters, 'RelStopTol': 0.0})
+    b = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, opt)
+    assert b._dev.uses_fused_rows() and b._fused_ok()
+    b.profile(True)
+    os.environ['SPORCO_AMD_HOST_LOOP'] = '1'       # (so that the counters name what ran)
+    try:
+        Y = b.solve()
+    finally:
+        os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
+    cnt = {k: v[1] for k, v in b.profile_read().items() if v[1] > 0}
+    assert cnt.get('rows_inv_post', 0) + cnt.get('rows_inv_post_emit', 0) == iters
+    assert 'admm_post' not in cnt and 'fft_c2r_rows' not in cnt
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, C, N, 1), 0.05, mu=0.02,
+                         dtype=np.float64, maxiter=iters, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 1e-5 and rel_l2(b.U, ref['U']) < 1e-5
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
+    if backend == 'hostsim':
+        return
+    # device-driven loop == host loop, bit for bit; NonNegCoef + gEvalY through the same kernel
+    for extra in ({}, {'NonNegCoef': True, 'AuxVarObj': False, 'gEvalY': True}):
+        optd = dict({'MaxMainIter': iters, 'RelStopTol': 0.0}, **extra)
+        bd = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(optd))
+        assert bd._device_loop_ok()
+        Yd = bd.solve()
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+        try:
+            bh = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(optd))
+            Yh = bh.solve()
+        finally:
+            os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
+        assert np.array_equal(Yd, Yh)
+        assert np.array_equal(np.asarray(bd.getitstat().RegL21), np.asarray(bh.getitstat().RegL21))
+        refx = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, C, N, 1), 0.05, mu=0.02,
+                              dtype=np.float64, maxiter=iters, rel_tol=0.0,
+                              nonneg=bool(extra), gevaly=bool(extra))
+        assert rel_l2(Yd, refx['Y']) < 1e-5
+        assert rel_l2(bd.getitstat().RegL21, refx['RegL21']) < 1e-5
+    # an L21Weight array: the separate register-resident epilogue, same answer
+    w21 = (0.5 + np.random.RandomState(2).rand(1, 1, N, K)).astype(np.float32)
+    bw = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(
+        {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L21Weight': w21}))
+    bw.profile(True)
+    Yw = bw.solve()
+    assert {k: v[1] for k, v in bw.profile_read().items() if v[1] > 0}.get('admm_post', 0) == 3
+    refw = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, C, N, 1), 0.05, mu=0.02,
+                          dtype=np.float64, maxiter=3, rel_tol=0.0, wl21=w21[:, :, np.newaxis])
+    assert rel_l2(Yw, refw['Y']) < 1e-5
+
+
 def test_fused_fixed_rho_fastsolve_and_setdict(backend):
     """FastSolve (no sums read back) and a dictionary change between solves."""
     H, W, K, N = 256, 8, 8, 2
