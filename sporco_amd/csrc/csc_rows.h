@@ -36,6 +36,8 @@ template <typename T> struct RowsFwdArgs {
     // device-driven solve (csc_kernels.h AdmmCtl): s2 is ctl->u_scale_f, and the launch returns
     // at once when ctl->stop or ctl->skip_fwd is set
     const AdmmCtl *ctl = nullptr;
+    int persist = 0;   // set by the launcher: a device-filling grid of workgroups that loop over tiles
+    int stagger_groups = 1, stagger_sleeps = 0;
 };
 
 template <typename T> struct RowsPostArgs {
@@ -61,6 +63,8 @@ template <typename T> struct RowsPostArgs {
     // device-driven solve: thr, u_scale and whether t_next is emitted come from this block,
     // and the launch returns at once when ctl->stop is set
     const AdmmCtl *ctl = nullptr;
+    int persist = 0;   // set by the launcher (see RowsFwdArgs)
+    int stagger_groups = 1, stagger_sleeps = 0;   // persistent launch: start-up stagger (csc_fused.h)
 };
 
 // Pack an AddMaskSim mask (as PostParams::ams: broadcastable (H, W, C, N, 1), nonzero = masked)
