@@ -346,6 +346,8 @@ template <typename T> struct Csc : CscBase {
     AdmmCtl *ctl_dev = nullptr;
     AdmmRecord *rec_ring = nullptr;
     int rec_cap = 0;
+    CgCtl *cg_dev = nullptr;        // CG dictionary update: scalars on the device
+    CgPinned *cg_pin = nullptr;
     sporco_amd_admm_params last_p;
     // fused PGM iteration (csc_pgm.h): Xf, Yf, Xfprv, Yfprv tile-major; X of the last
     // iteration is prox(irfft_W(work)) and is rebuilt on demand with `last_pgm`
@@ -479,6 +481,8 @@ template <typename T> struct Csc : CscBase {
             if (p) (void)hipFree(p);
         if (out_pinned) (void)hipHostFree(out_pinned);
         if (rec_ring) (void)hipHostFree(rec_ring);
+        if (cg_pin) (void)hipHostFree((void *)cg_pin);
+        if (cg_dev) (void)hipFree(cg_dev);
         if (ctl_dev) (void)hipFree(ctl_dev);
         planW.destroy();
         planH.destroy();
@@ -2785,6 +2789,40 @@ template <typename T> struct Csc : CscBase {
                     SA_HIP(hipMemcpyAsync(r, bf, sizeof(cx<T>) * nd, hipMemcpyDeviceToDevice, st));
                 }
                 info = p.cg_maxiter;
+                if (!std::getenv("SPORCO_AMD_CG_HOST")) {
+                    // Device-driven loop: alpha, beta and the stopping test stay on the device
+                    // (csc_kernels.h CgCtl); the host enqueues iterations a few ahead of the
+                    // last top-of-iteration it has seen finish and stops when the verdict is in.
+                    if (!cg_dev) {
+                        SA_HIP(hipMalloc((void **)&cg_dev, sizeof(CgCtl)));
+                        SA_HIP(hipHostMalloc((void **)&cg_pin, sizeof(CgPinned), 0));
+                    }
+                    double *cgout = out_dev + SPORCO_AMD_OUT_CGIT;
+                    launch_cg_init(st, cg_dev, cg_pin, atol, p.cg_maxiter);
+                    ProfScope ps(prof, PS_SM_SOLVE);
+                    const int ahead = 4;
+                    for (int enq = 0; enq <= p.cg_maxiter; ++enq) {
+                        int nb = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
+                        launch_cg_ctl<T>(st, 0, part_a, nb, cg_dev, cg_pin, cgout);
+                        launch_cg_update_p<T>(st, cg_dev, r, pv, nd);
+                        launch_inner<T>(st, pv, cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
+                        launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, q, npix, CN, K);
+                        launch_lincomb<T>(st, q, T(1), q, rho, pv, T(0), nullptr, nd);
+                        nb = launch_pair_stats<T>(st, pv, nullptr, q, npix, K, W, part_b);
+                        launch_cg_ctl<T>(st, 1, part_b, nb, cg_dev, cg_pin, cgout);
+                        launch_cg_update_xr<T>(st, cg_dev, Xf, r, pv, q, nd);
+                        while (!cg_pin->done && enq + 1 - cg_pin->seq > ahead) {
+                            if (hipStreamQuery(st) == hipSuccess && !cg_pin->done &&
+                                enq + 1 - cg_pin->seq > ahead)
+                                throw Error(SPORCO_AMD_EHIP, "CG: progress record not written");
+                        }
+                        if (cg_pin->done) break;
+                    }
+                    sync();
+                    SA_REQUIRE(cg_pin->done, "CG: the device loop did not reach a verdict");
+                    info = cg_pin->info;
+                    it = cg_pin->it;
+                } else
                 for (it = 0; it < p.cg_maxiter; ++it) {
                     cdots(r, nullptr, rr, dummy);
                     if (std::sqrt(rr) < atol) {

@@ -293,6 +293,34 @@ template <typename T>
 void launch_axpby(hipStream_t st, T a, const T *x, T b, const T *y, T *out, int64_t n);
 
 // ---------------------------------------------------------------------------
+// Conjugate gradients with the scalars on the device (the CG dictionary update,
+// linalg.solvemdbi_cg -> scipy.sparse.linalg.cg, sporco/linalg.py:570-579): alpha, beta and the
+// stopping test live in a control block that the vector updates read, so an iteration is
+// nine launches and no host read-back.
+// ---------------------------------------------------------------------------
+struct CgCtl {
+    double rr, rr_prev, pq, atol;
+    double alpha, beta;        // as T values (the casts of the host-driven loop)
+    int done, it, info, maxit;
+};
+struct CgPinned {              // host-visible progress: tops processed, and the verdict
+    volatile int seq, done, it, info;
+};
+void launch_cg_init(hipStream_t st, CgCtl *c, CgPinned *pin, double atol, int maxit);
+// phase 0 (top of an iteration): rr = sum_b partials[b][2]; stop when maxit iterations ran
+// (info = maxit) or sqrt(rr) < atol (info = 0); else beta = rr / rr_prev (0 in the first).
+// phase 1: pq = sum_b partials[b][1]; alpha = rr / pq; rr_prev = rr; ++it.
+// Both sum in the fixed order of launch_finalize.  cgout: device double[2] <- (info, it) when done.
+template <typename T>
+void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, CgCtl *c, CgPinned *pin,
+                   double *cgout);
+template <typename T>   // p = r + beta p (p = r when beta = 0); nothing once done
+void launch_cg_update_p(hipStream_t st, const CgCtl *c, const cx<T> *r, cx<T> *p, int64_t n);
+template <typename T>   // x += alpha p; r -= alpha q; nothing once done
+void launch_cg_update_xr(hipStream_t st, const CgCtl *c, cx<T> *x, cx<T> *r, const cx<T> *p,
+                         const cx<T> *q, int64_t n);
+
+// ---------------------------------------------------------------------------
 // Device-resident ADMM control (sporco_amd_csc_admm_run): the residuals, tolerances, the
 // adaptive penalty parameter and the stopping test of sporco/admm/admm.py:462-486, 549-575,
 // 375-377 evaluated by a one-thread kernel at the end of every iteration, in the same

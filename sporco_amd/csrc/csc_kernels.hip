@@ -2256,6 +2256,135 @@ SA_INST_PREPOST(float)
 SA_INST_PREPOST(double)
 
 // ---------------------------------------------------------------------------
+// conjugate gradients with device-side scalars (csc_kernels.h)
+// ---------------------------------------------------------------------------
+__global__ void cg_init_kernel(CgCtl *c, CgPinned *pin, double atol, int maxit) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    c->rr = c->rr_prev = c->pq = 0.0;
+    c->atol = atol;
+    c->alpha = c->beta = 0.0;
+    c->done = c->it = 0;
+    c->info = maxit;
+    c->maxit = maxit;
+    pin->done = 0;
+    pin->it = 0;
+    pin->info = maxit;
+    sa_fence_system();
+    pin->seq = 0;
+}
+void launch_cg_init(hipStream_t st, CgCtl *c, CgPinned *pin, double atol, int maxit) {
+    hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(64), 0, st, c, pin, atol, maxit);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T, int PHASE>
+__global__ void __launch_bounds__(kThreads) cg_ctl_kernel(const double *partials, int nb, CgCtl *c,
+                                                          CgPinned *pin, double *cgout) {
+#pragma clang fp contract(off)
+    if (c->done) return;
+    // the sum of launch_finalize: thread t adds blocks t, t + 256, ..., then a fixed-shape tree
+    double *scratch = dyn_lds<double>();
+    constexpr int idx = PHASE == 0 ? 2 : 1;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partials[(int64_t)b * 4 + idx];
+    scratch[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) scratch[threadIdx.x] += scratch[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double v = scratch[0];
+    if (PHASE == 0) {
+        int done = 0, info = c->maxit;
+        if (c->it >= c->maxit) {
+            done = 1;
+        } else {
+            c->rr = v;
+            if (sqrt(v) < c->atol) {
+                done = 1;
+                info = 0;
+            } else {
+                c->beta = c->it == 0 ? 0.0 : (double)(T)(v / c->rr_prev);
+            }
+        }
+        if (done) {
+            c->done = 1;
+            c->info = info;
+            cgout[0] = (double)info;
+            cgout[1] = (double)c->it;
+            pin->done = 1;
+            pin->it = c->it;
+            pin->info = info;
+        }
+        sa_fence_system();
+        pin->seq = pin->seq + 1;
+        sa_fence_system();
+    } else {
+        c->pq = v;
+        c->alpha = (double)(T)(c->rr / v);
+        c->rr_prev = c->rr;
+        c->it = c->it + 1;
+    }
+}
+template <typename T>
+void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, CgCtl *c, CgPinned *pin,
+                   double *cgout) {
+    if (phase == 0)
+        hipLaunchKernelGGL((cg_ctl_kernel<T, 0>), dim3(1), dim3(kThreads), sizeof(double) * kThreads, st,
+                           partials, nb, c, pin, cgout);
+    else
+        hipLaunchKernelGGL((cg_ctl_kernel<T, 1>), dim3(1), dim3(kThreads), sizeof(double) * kThreads, st,
+                           partials, nb, c, pin, cgout);
+    SA_HIP(hipGetLastError());
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cg_update_p_kernel(const CgCtl *c, const cx<T> *__restrict__ r,
+                                                               cx<T> *__restrict__ p, int64_t n) {
+    if (c->done) return;
+    const T beta = (T)c->beta;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        // (lincomb form of the host-driven loop: 1 r + beta p)
+        p[i] = beta == T(0) ? r[i] : cscale(r[i], T(1)) + cscale(p[i], beta);
+    }
+}
+template <typename T>
+void launch_cg_update_p(hipStream_t st, const CgCtl *c, const cx<T> *r, cx<T> *p, int64_t n) {
+    hipLaunchKernelGGL((cg_update_p_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, c, r, p, n);
+    SA_HIP(hipGetLastError());
+}
+template <typename T>
+__global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(const CgCtl *c, cx<T> *__restrict__ x,
+                                                                cx<T> *__restrict__ r,
+                                                                const cx<T> *__restrict__ p,
+                                                                const cx<T> *__restrict__ q, int64_t n) {
+    if (c->done) return;
+    const T alpha = (T)c->alpha;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] = cscale(x[i], T(1)) + cscale(p[i], alpha);
+        r[i] = cscale(r[i], T(1)) + cscale(q[i], -alpha);
+    }
+}
+template <typename T>
+void launch_cg_update_xr(hipStream_t st, const CgCtl *c, cx<T> *x, cx<T> *r, const cx<T> *p,
+                         const cx<T> *q, int64_t n) {
+    hipLaunchKernelGGL((cg_update_xr_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, c, x, r, p, q,
+                       n);
+    SA_HIP(hipGetLastError());
+}
+#define SA_INST_CG(T)                                                                               \
+    template void launch_cg_ctl<T>(hipStream_t, int, const double *, int, CgCtl *, CgPinned *,      \
+                                   double *);                                                       \
+    template void launch_cg_update_p<T>(hipStream_t, const CgCtl *, const cx<T> *, cx<T> *, int64_t); \
+    template void launch_cg_update_xr<T>(hipStream_t, const CgCtl *, cx<T> *, cx<T> *, const cx<T> *, \
+                                         const cx<T> *, int64_t);
+SA_INST_CG(float)
+SA_INST_CG(double)
+
+// ---------------------------------------------------------------------------
 // device-resident ADMM control (csc_kernels.h)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {

@@ -74,6 +74,34 @@ def test_golden_traces(backend, method, case):
     assert c.Y.dtype == (np.float32 if f32 else np.float64)
 
 
+def test_cg_scalars_on_the_device_match_the_host_loop(backend):
+    """The CG update keeps alpha, beta and the stopping test on the device (no read-back per
+    iteration); iterates, iteration counts and status flags are identical to the host-driven
+    loop of the same library (SPORCO_AMD_CG_HOST=1), at the default loose tolerance (where the
+    count is sensitive) and with MaxIter cutting the solve short."""
+    import os
+    from sporco_amd.admm import ccmod
+    g = load_golden('ccmod_cg_f64')
+    dsz = tuple(int(v) for v in g['dsz'])
+    cls = dstep_class('cg')
+    for cg in ({'MaxIter': 1000, 'StopTol': 1e-3}, {'MaxIter': 3, 'StopTol': 1e-12}):
+        runs = []
+        for host in (True, False):
+            if host:
+                os.environ['SPORCO_AMD_CG_HOST'] = '1'
+            try:
+                c = cls(g['Z'], g['S'], dsz, cls.Options({'MaxMainIter': 8, 'CG': cg}))
+                c.solve()
+            finally:
+                os.environ.pop('SPORCO_AMD_CG_HOST', None)
+            its = c.getitstat()
+            runs.append((c.Y.copy(), c.X.copy(), list(its.XSlvCGIt), c.cg_iterations))
+        assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])
+        assert runs[0][2] == runs[1][2] and runs[0][3] == runs[1][3]
+        if cg['MaxIter'] == 3:
+            assert set(runs[1][2]) == {3} and runs[1][3] == 3      # scipy's info = maxiter
+
+
 @pytest.mark.parametrize('method', ['ism', 'cg'])
 def test_surface(backend, method):
     from sporco_amd.admm import ccmod
