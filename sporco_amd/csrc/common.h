@@ -91,9 +91,13 @@ template <typename T> __device__ __forceinline__ T *dyn_lds() {
 // deterministic reductions of double accumulators
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
+#ifdef SPORCO_AMD_HOSTSIM
+    return hostsim::wave_allreduce(v);      // (the CPU test simulator: same tree, one exchange)
+#else
 #pragma unroll
     for (int m = kWave / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, kWave);
     return v;
+#endif
 }
 
 // Sum `NV` per-thread doubles over the block; thread 0 writes them to

@@ -2698,11 +2698,22 @@ template <typename T> struct Csc : CscBase {
     }
 
     // q = (Z^H Z + rho I) v on dictionary-sized spectra
-    void dstep_op(const cx<T> *v, cx<T> *q, T rho) {
+    // (one wave per frequency, the coefficient spectra read once: csc_kernels.h launch_cg_op;
+    // part_b[.][1] receives the partial sums of Re <v, q>)
+    int dstep_op(const cx<T> *v, cx<T> *q, T rho) {
         ProfScope ps(prof, PS_SM_SOLVE);
-        launch_inner<T>(st, v, cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
-        launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, q, npix, CN, K);
-        launch_lincomb<T>(st, q, T(1), q, rho, v, T(0), nullptr, npix * K);
+        return launch_cg_op<T>(st, nullptr, false, cv(SPORCO_AMD_VAR_ZF), nullptr,
+                               const_cast<cx<T> *>(v), q, rho, npix, CN, K, part_b);
+    }
+    // sum of column `idx` of a 4-wide partial array, read back
+    double partial_sum(const double *part, int nb, int idx) {
+        SA_HIP(hipMemsetAsync(out_dev_own, 0, sizeof(double) * kOutSlots, st));
+        const int slots[1] = {0};
+        const double scales[1] = {1.0};
+        finalize(part + idx, nb, 4, 1, slots, scales, out_dev_own);
+        double tmp[kOutSlots];
+        read_out(out_dev_own, tmp);
+        return tmp[0];
     }
 
     void dstep_iter(const sporco_amd_dstep_params &p, double *out_dev) override {
@@ -2798,19 +2809,23 @@ template <typename T> struct Csc : CscBase {
                         SA_HIP(hipHostMalloc((void **)&cg_pin, sizeof(CgPinned), 0));
                     }
                     double *cgout = out_dev + SPORCO_AMD_OUT_CGIT;
+                    // (the record is reset here, by the host: nothing of the previous solve is in
+                    // flight, and the init kernel may not have run when the loop below first looks)
+                    cg_pin->done = 0;
+                    cg_pin->seq = 0;
+                    cg_pin->it = 0;
+                    cg_pin->info = p.cg_maxiter;
                     launch_cg_init(st, cg_dev, cg_pin, atol, p.cg_maxiter);
                     ProfScope ps(prof, PS_SM_SOLVE);
                     const int ahead = 4;
+                    // <r, r> of the first iteration; later ones come out of the update kernel
+                    int nba = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
                     for (int enq = 0; enq <= p.cg_maxiter; ++enq) {
-                        int nb = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
-                        launch_cg_ctl<T>(st, 0, part_a, nb, cg_dev, cg_pin, cgout);
-                        launch_cg_update_p<T>(st, cg_dev, r, pv, nd);
-                        launch_inner<T>(st, pv, cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
-                        launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, q, npix, CN, K);
-                        launch_lincomb<T>(st, q, T(1), q, rho, pv, T(0), nullptr, nd);
-                        nb = launch_pair_stats<T>(st, pv, nullptr, q, npix, K, W, part_b);
-                        launch_cg_ctl<T>(st, 1, part_b, nb, cg_dev, cg_pin, cgout);
-                        launch_cg_update_xr<T>(st, cg_dev, Xf, r, pv, q, nd);
+                        launch_cg_ctl<T>(st, 0, part_a, nba, cg_dev, cg_pin, cgout);
+                        const int nbb = launch_cg_op<T>(st, cg_dev, true, cv(SPORCO_AMD_VAR_ZF), r, pv,
+                                                        q, rho, npix, CN, K, part_b);
+                        launch_cg_ctl<T>(st, 1, part_b, nbb, cg_dev, cg_pin, cgout);
+                        nba = launch_cg_update_xr<T>(st, cg_dev, T(0), Xf, r, pv, q, nd, part_a);
                         while (!cg_pin->done && enq + 1 - cg_pin->seq > ahead) {
                             if (hipStreamQuery(st) == hipSuccess && !cg_pin->done &&
                                 enq + 1 - cg_pin->seq > ahead)
@@ -2823,8 +2838,12 @@ template <typename T> struct Csc : CscBase {
                     info = cg_pin->info;
                     it = cg_pin->it;
                 } else
+                {
+                // the same kernels with the scalars read back every iteration (SPORCO_AMD_CG_HOST:
+                // the loop the device-driven one is checked against)
+                int nba = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
                 for (it = 0; it < p.cg_maxiter; ++it) {
-                    cdots(r, nullptr, rr, dummy);
+                    rr = partial_sum(part_a, nba, 2);
                     if (std::sqrt(rr) < atol) {
                         info = 0;
                         break;
@@ -2838,15 +2857,15 @@ template <typename T> struct Csc : CscBase {
                             launch_lincomb<T>(st, pv, T(1), r, (T)(rr / rr_prev), pv, T(0), nullptr,
                                               nd);
                     }
-                    dstep_op(pv, q, rho);
-                    cdots(pv, q, dummy, pq);
+                    const int nbb = dstep_op(pv, q, rho);
+                    pq = partial_sum(part_b, nbb, 1);
                     const T alpha = (T)(rr / pq);
                     {
                         ProfScope ps(prof, PS_OTHER);
-                        launch_lincomb<T>(st, Xf, T(1), Xf, alpha, pv, T(0), nullptr, nd);
-                        launch_lincomb<T>(st, r, T(1), r, -alpha, q, T(0), nullptr, nd);
+                        nba = launch_cg_update_xr<T>(st, nullptr, alpha, Xf, r, pv, q, nd, part_a);
                     }
                     rr_prev = rr;
+                }
                 }
             }
             const double cgv[2] = {(double)info, (double)it};

@@ -314,11 +314,23 @@ void launch_cg_init(hipStream_t st, CgCtl *c, CgPinned *pin, double atol, int ma
 template <typename T>
 void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, CgCtl *c, CgPinned *pin,
                    double *cgout);
+// q = (Z^H Z + rho I) p per frequency, one wave per pixel with the coefficient spectra of all
+// images passing through registers once: t_n = sum_k zf[n,k] p[k] (wave reduction), q[k] = sum_n
+// conj(zf[n,k]) t_n + rho p[k].  with_update: p <- r + beta p first (ctl->beta; p = r when 0).
+// partials[block][1] = sum Re(conj(p) q) (the <p, Ap> of CG).  ctl may be null (plain operator);
+// with ctl the launch does nothing once ctl->done.  Returns the number of blocks.
+template <typename T>
+int launch_cg_op(hipStream_t st, const CgCtl *ctl, bool with_update, const cx<T> *zf,
+                 const cx<T> *r, cx<T> *p, cx<T> *q, T rho, int64_t npix, int CN, int K,
+                 double *partials);
 template <typename T>   // p = r + beta p (p = r when beta = 0); nothing once done
 void launch_cg_update_p(hipStream_t st, const CgCtl *c, const cx<T> *r, cx<T> *p, int64_t n);
-template <typename T>   // x += alpha p; r -= alpha q; nothing once done
-void launch_cg_update_xr(hipStream_t st, const CgCtl *c, cx<T> *x, cx<T> *r, const cx<T> *p,
-                         const cx<T> *q, int64_t n);
+// x += alpha p; r -= alpha q; partials[block][2] = sum |r_new|^2 (the next iteration's <r, r>, in
+// the element order of launch_pair_stats); nothing once done.  alpha from ctl, or `alpha_host`
+// when ctl is null.  Returns the number of blocks.
+template <typename T>
+int launch_cg_update_xr(hipStream_t st, const CgCtl *c, T alpha_host, cx<T> *x, cx<T> *r,
+                        const cx<T> *p, const cx<T> *q, int64_t n, double *partials);
 
 // ---------------------------------------------------------------------------
 // Device-resident ADMM control (sporco_amd_csc_admm_run): the residuals, tolerances, the

@@ -2266,11 +2266,7 @@ __global__ void cg_init_kernel(CgCtl *c, CgPinned *pin, double atol, int maxit) 
     c->done = c->it = 0;
     c->info = maxit;
     c->maxit = maxit;
-    pin->done = 0;
-    pin->it = 0;
-    pin->info = maxit;
-    sa_fence_system();
-    pin->seq = 0;
+    (void)pin;     // reset by the host before this launch (csc_api.hip dstep_iter)
 }
 void launch_cg_init(hipStream_t st, CgCtl *c, CgPinned *pin, double atol, int maxit) {
     hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(64), 0, st, c, pin, atol, maxit);
@@ -2340,6 +2336,82 @@ void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, Cg
 }
 
 template <typename T>
+__global__ void __launch_bounds__(kThreads) cg_op_kernel(const CgCtl *ctl, int with_update,
+                                                         const cx<T> *__restrict__ zf,
+                                                         const cx<T> *__restrict__ r,
+                                                         cx<T> *__restrict__ p, cx<T> *__restrict__ q,
+                                                         T rho, int64_t npix, int CN, int K,
+                                                         double *partials) {
+    if (ctl && ctl->done) return;
+    constexpr int JM = 4;                       // K <= 256: up to four filters per lane
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wpb = blockDim.x / kWave;
+    const T beta = (ctl && with_update) ? (T)ctl->beta : T(0);
+    double acc[1] = {0.0};                      // <p, q>, slot 1 of the block's partial row
+    for (int64_t pix = (int64_t)blockIdx.x * wpb + threadIdx.x / kWave; pix < npix;
+         pix += (int64_t)gridDim.x * wpb) {
+        cx<T> pk[JM], qk[JM];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+            const int k = lane + kWave * j;
+            pk[j] = mk<T>(T(0), T(0));
+            qk[j] = mk<T>(T(0), T(0));
+            if (k < K) {
+                if (with_update) {
+                    const cx<T> rv = r[pix * K + k];
+                    pk[j] = beta == T(0) ? rv : cscale(rv, T(1)) + cscale(p[pix * K + k], beta);
+                    p[pix * K + k] = pk[j];
+                } else {
+                    pk[j] = p[pix * K + k];
+                }
+            }
+        }
+        for (int n = 0; n < CN; ++n) {
+            const cx<T> *zrow = zf + (pix * CN + n) * K;
+            cx<T> zk[JM];
+            cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < JM; ++j) {
+                const int k = lane + kWave * j;
+                zk[j] = k < K ? zrow[k] : mk<T>(T(0), T(0));
+                t = t + cmul(zk[j], pk[j]);
+            }
+            sa_wave_allreduce2(t.re, t.im);
+#pragma unroll
+            for (int j = 0; j < JM; ++j) qk[j] = qk[j] + cmulc(zk[j], t);
+        }
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+            const int k = lane + kWave * j;
+            if (k < K) {
+                const cx<T> qq = cscale(qk[j], T(1)) + cscale(pk[j], rho);
+                q[pix * K + k] = qq;
+                acc[0] += (double)pk[j].re * (double)qq.re + (double)pk[j].im * (double)qq.im;
+            }
+        }
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 4 + 1);
+}
+template <typename T>
+int launch_cg_op(hipStream_t st, const CgCtl *ctl, bool with_update, const cx<T> *zf,
+                 const cx<T> *r, cx<T> *p, cx<T> *q, T rho, int64_t npix, int CN, int K,
+                 double *partials) {
+    SA_REQUIRE(K <= 4 * kWave, "cg_op: at most 256 filters");
+#ifdef SPORCO_AMD_HOSTSIM
+    const int threads = kWave;                    // (the simulator's scheduler walks the whole block)
+#else
+    const int threads = kThreads;
+#endif
+    // one wave per pixel, grid-stride beyond the cap on partial rows
+    const int grid = grid_for(npix * kWave, threads);
+    hipLaunchKernelGGL((cg_op_kernel<T>), dim3(grid), dim3(threads),
+                       sizeof(double) * 4 * (threads / kWave), st, ctl, with_update ? 1 : 0, zf, r, p,
+                       q, rho, npix, CN, K, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+template <typename T>
 __global__ void __launch_bounds__(kThreads) cg_update_p_kernel(const CgCtl *c, const cx<T> *__restrict__ r,
                                                                cx<T> *__restrict__ p, int64_t n) {
     if (c->done) return;
@@ -2356,31 +2428,42 @@ void launch_cg_update_p(hipStream_t st, const CgCtl *c, const cx<T> *r, cx<T> *p
     SA_HIP(hipGetLastError());
 }
 template <typename T>
-__global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(const CgCtl *c, cx<T> *__restrict__ x,
+__global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(const CgCtl *c, T alpha_host,
+                                                                cx<T> *__restrict__ x,
                                                                 cx<T> *__restrict__ r,
                                                                 const cx<T> *__restrict__ p,
-                                                                const cx<T> *__restrict__ q, int64_t n) {
-    if (c->done) return;
-    const T alpha = (T)c->alpha;
+                                                                const cx<T> *__restrict__ q, int64_t n,
+                                                                double *partials) {
+    if (c && c->done) return;
+    const T alpha = c ? (T)c->alpha : alpha_host;
+    double acc[1] = {0.0};                      // <r, r>, slot 2 of the block's partial row
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         x[i] = cscale(x[i], T(1)) + cscale(p[i], alpha);
-        r[i] = cscale(r[i], T(1)) + cscale(q[i], -alpha);
+        const cx<T> rn = cscale(r[i], T(1)) + cscale(q[i], -alpha);
+        r[i] = rn;
+        acc[0] += (double)cabs2(rn);
     }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 4 + 2);
 }
 template <typename T>
-void launch_cg_update_xr(hipStream_t st, const CgCtl *c, cx<T> *x, cx<T> *r, const cx<T> *p,
-                         const cx<T> *q, int64_t n) {
-    hipLaunchKernelGGL((cg_update_xr_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, c, x, r, p, q,
-                       n);
+int launch_cg_update_xr(hipStream_t st, const CgCtl *c, T alpha_host, cx<T> *x, cx<T> *r,
+                        const cx<T> *p, const cx<T> *q, int64_t n, double *partials) {
+    const int grid = grid_for(n);
+    hipLaunchKernelGGL((cg_update_xr_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 4 * (kThreads / kWave), st, c, alpha_host, x, r, p, q, n,
+                       partials);
     SA_HIP(hipGetLastError());
+    return grid;
 }
 #define SA_INST_CG(T)                                                                               \
+    template int launch_cg_op<T>(hipStream_t, const CgCtl *, bool, const cx<T> *, const cx<T> *,    \
+                                 cx<T> *, cx<T> *, T, int64_t, int, int, double *);                 \
     template void launch_cg_ctl<T>(hipStream_t, int, const double *, int, CgCtl *, CgPinned *,      \
                                    double *);                                                       \
     template void launch_cg_update_p<T>(hipStream_t, const CgCtl *, const cx<T> *, cx<T> *, int64_t); \
-    template void launch_cg_update_xr<T>(hipStream_t, const CgCtl *, cx<T> *, cx<T> *, const cx<T> *, \
-                                         const cx<T> *, int64_t);
+    template int launch_cg_update_xr<T>(hipStream_t, const CgCtl *, T, cx<T> *, cx<T> *,            \
+                                        const cx<T> *, const cx<T> *, int64_t, double *);
 SA_INST_CG(float)
 SA_INST_CG(double)
 

@@ -16,6 +16,16 @@ __device__ __forceinline__ float sa_readlane(float v, int src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
 }
 
+// all-reduce of (a, b) over the 64 lanes of the wave by an xor butterfly (every lane ends with
+// the same bits: the tree is the same up to the order of the operands of each add)
+template <typename T> __device__ __forceinline__ void sa_wave_allreduce2(T &a, T &b) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        a += __shfl_xor(a, m, 64);
+        b += __shfl_xor(b, m, 64);
+    }
+}
+
 // 1 / sqrt(x) and sqrt(x) to 1 ulp, no denormal / IEEE fix-up sequences (v_rsq_f32, v_sqrt_f32)
 __device__ __forceinline__ float sa_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sa_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }

@@ -109,6 +109,14 @@ inline void sa_swap16(float &a, float &b) {
     else
         b = a_odd;
 }
+// all-reduce of (a, b) over the 64 lanes in the association of the xor-butterfly
+// (m = 32, 16, ..., 1): ONE exchange on the simulator instead of six shuffle rounds per value
+template <typename T> inline void sa_wave_allreduce2(T &a, T &b) {
+    T v[2] = {a, b};
+    hostsim::wave_allreduce_n<T, 2>(v);
+    a = v[0];
+    b = v[1];
+}
 inline float sa_rsq(float x) { return 1.0f / std::sqrt(x); }
 inline float sa_sqrt(float x) { return std::sqrt(x); }
 inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }

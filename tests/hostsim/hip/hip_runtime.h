@@ -109,6 +109,39 @@ template <typename T> inline T shfl_xor(T v, int mask, int width) {
     return r;
 }
 
+// Sum of NV values per lane over the 64 lanes in the association of the xor butterfly
+// (m = 32, ..., 1), delivered to every lane: the first lane of the wave computes the tree once
+// between the two syncs (a shuffle-per-level emulation costs six exchange rounds, and a
+// butterfly per lane costs 64 times the arithmetic).
+template <typename T, int NV> inline void wave_allreduce_n(T (&v)[NV]) {
+    static_assert(sizeof(T) * NV <= 16, "payload too large");
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, base = tid - lane;
+    std::memcpy(shuffle_slot(tid), v, sizeof(T) * NV);
+    wave_sync();
+    if (lane == 0) {
+        const int nl = block_threads() - base < 64 ? block_threads() - base : 64;
+        T a[64][NV], n[64][NV];
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < NV; ++j) a[l][j] = T(0);
+        for (int l = 0; l < nl; ++l) std::memcpy(a[l], shuffle_slot(base + l), sizeof(T) * NV);
+        for (int m = 32; m > 0; m >>= 1) {
+            // (a lane beyond the block reads as the caller's own value in __shfl_xor)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < NV; ++j) n[l][j] = a[l][j] + (((l ^ m) < nl) ? a[l ^ m][j] : a[l][j]);
+            std::memcpy(a, n, sizeof(a));
+        }
+        for (int l = 0; l < nl; ++l) std::memcpy(shuffle_slot(base + l), a[l], sizeof(T) * NV);
+    }
+    wave_sync();
+    std::memcpy(v, shuffle_slot(tid), sizeof(T) * NV);
+}
+template <typename T> inline T wave_allreduce(T v) {
+    T a[1] = {v};
+    wave_allreduce_n<T, 1>(a);
+    return a[0];
+}
+
 template <typename... KA, typename... A>
 inline void launch(void (*kernel)(KA...), dim3 grid, dim3 block, size_t shmem, hipStream_t,
                    A &&...args) {
