@@ -2817,15 +2817,21 @@ template <typename T> struct Csc : CscBase {
                     cg_pin->info = p.cg_maxiter;
                     launch_cg_init(st, cg_dev, cg_pin, atol, p.cg_maxiter);
                     ProfScope ps(prof, PS_SM_SOLVE);
-                    const int ahead = 4;
+                    const int ahead = 2;
                     // <r, r> of the first iteration; later ones come out of the update kernel
-                    int nba = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
+                    const int nba = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
+                    // An iteration: the scalar step at its top (stopping test, beta), the operator
+                    // (p <- r + beta p, q = A p, <p, q>), the scalar step for alpha, the update (x,
+                    // r, <r, r>).  (Folding the scalar steps into the last workgroup to finish the
+                    // preceding kernel was measured: the per-workgroup ticket costs what the two
+                    // small launches cost)
+                    int nb_rr = nba;
                     for (int enq = 0; enq <= p.cg_maxiter; ++enq) {
-                        launch_cg_ctl<T>(st, 0, part_a, nba, cg_dev, cg_pin, cgout);
+                        launch_cg_ctl<T>(st, 0, part_a, nb_rr, cg_dev, cg_pin, cgout);
                         const int nbb = launch_cg_op<T>(st, cg_dev, true, cv(SPORCO_AMD_VAR_ZF), r, pv,
                                                         q, rho, npix, CN, K, part_b);
                         launch_cg_ctl<T>(st, 1, part_b, nbb, cg_dev, cg_pin, cgout);
-                        nba = launch_cg_update_xr<T>(st, cg_dev, T(0), Xf, r, pv, q, nd, part_a);
+                        nb_rr = launch_cg_update_xr<T>(st, cg_dev, T(0), Xf, r, pv, q, nd, part_a);
                         while (!cg_pin->done && enq + 1 - cg_pin->seq > ahead) {
                             if (hipStreamQuery(st) == hipSuccess && !cg_pin->done &&
                                 enq + 1 - cg_pin->seq > ahead)

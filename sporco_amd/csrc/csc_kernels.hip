@@ -2273,20 +2273,23 @@ void launch_cg_init(hipStream_t st, CgCtl *c, CgPinned *pin, double atol, int ma
     SA_HIP(hipGetLastError());
 }
 
+// The scalar step of CG on the sums of the block partials (csc_kernels.h CgCtl), run by one
+// whole workgroup: thread t adds rows t, t + 256, ..., then a fixed-shape tree (the order of
+// launch_finalize, which the host-driven loop reads its sums through).
 template <typename T, int PHASE>
-__global__ void __launch_bounds__(kThreads) cg_ctl_kernel(const double *partials, int nb, CgCtl *c,
-                                                          CgPinned *pin, double *cgout) {
+__device__ __forceinline__ void cg_scalar_step(const double *partials, int nb, CgCtl *c, CgPinned *pin,
+                                               double *cgout, double *scratch) {
 #pragma clang fp contract(off)
-    if (c->done) return;
-    // the sum of launch_finalize: thread t adds blocks t, t + 256, ..., then a fixed-shape tree
-    double *scratch = dyn_lds<double>();
     constexpr int idx = PHASE == 0 ? 2 : 1;
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partials[(int64_t)b * 4 + idx];
-    scratch[threadIdx.x] = s;
+    // (kThreads summation slots whatever the size of this workgroup)
+    for (int t = threadIdx.x; t < kThreads; t += blockDim.x) {
+        double s = 0.0;
+        for (int b = t; b < nb; b += kThreads) s += partials[(int64_t)b * 4 + idx];
+        scratch[t] = s;
+    }
     __syncthreads();
-    for (int w = blockDim.x / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) scratch[threadIdx.x] += scratch[threadIdx.x + w];
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        for (int t = threadIdx.x; t < w; t += blockDim.x) scratch[t] += scratch[t + w];
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
@@ -2323,6 +2326,12 @@ __global__ void __launch_bounds__(kThreads) cg_ctl_kernel(const double *partials
         c->it = c->it + 1;
     }
 }
+template <typename T, int PHASE>
+__global__ void __launch_bounds__(kThreads) cg_ctl_kernel(const double *partials, int nb, CgCtl *c,
+                                                          CgPinned *pin, double *cgout) {
+    if (c->done) return;
+    cg_scalar_step<T, PHASE>(partials, nb, c, pin, cgout, dyn_lds<double>());
+}
 template <typename T>
 void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, CgCtl *c, CgPinned *pin,
                    double *cgout) {
@@ -2335,7 +2344,9 @@ void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, Cg
     SA_HIP(hipGetLastError());
 }
 
-template <typename T>
+// (the CG kernels: grid-stride over at most eight workgroups per CU)
+constexpr int kCgMaxBlocks = 2048;
+template <typename T, int JM>     // JM filters per lane: K <= 64 JM
 __global__ void __launch_bounds__(kThreads) cg_op_kernel(const CgCtl *ctl, int with_update,
                                                          const cx<T> *__restrict__ zf,
                                                          const cx<T> *__restrict__ r,
@@ -2343,7 +2354,7 @@ __global__ void __launch_bounds__(kThreads) cg_op_kernel(const CgCtl *ctl, int w
                                                          T rho, int64_t npix, int CN, int K,
                                                          double *partials) {
     if (ctl && ctl->done) return;
-    constexpr int JM = 4;                       // K <= 256: up to four filters per lane
+    constexpr int NB = 4;                       // images whose spectra are in flight together
     const int lane = threadIdx.x & (kWave - 1);
     const int wpb = blockDim.x / kWave;
     const T beta = (ctl && with_update) ? (T)ctl->beta : T(0);
@@ -2366,19 +2377,31 @@ __global__ void __launch_bounds__(kThreads) cg_op_kernel(const CgCtl *ctl, int w
                 }
             }
         }
-        for (int n = 0; n < CN; ++n) {
-            const cx<T> *zrow = zf + (pix * CN + n) * K;
-            cx<T> zk[JM];
-            cx<T> t = mk<T>(T(0), T(0));
+        for (int n0 = 0; n0 < CN; n0 += NB) {
+            cx<T> zk[NB][JM], t[NB];
 #pragma unroll
-            for (int j = 0; j < JM; ++j) {
-                const int k = lane + kWave * j;
-                zk[j] = k < K ? zrow[k] : mk<T>(T(0), T(0));
-                t = t + cmul(zk[j], pk[j]);
+            for (int b = 0; b < NB; ++b) {
+                const bool have = n0 + b < CN;
+                const cx<T> *zrow = zf + (pix * CN + (have ? n0 + b : n0)) * K;
+#pragma unroll
+                for (int j = 0; j < JM; ++j) {
+                    const int k = lane + kWave * j;
+                    zk[b][j] = (have && k < K) ? zrow[k] : mk<T>(T(0), T(0));
+                }
             }
-            sa_wave_allreduce2(t.re, t.im);
 #pragma unroll
-            for (int j = 0; j < JM; ++j) qk[j] = qk[j] + cmulc(zk[j], t);
+            for (int b = 0; b < NB; ++b) {
+                t[b] = mk<T>(T(0), T(0));
+#pragma unroll
+                for (int j = 0; j < JM; ++j) t[b] = t[b] + cmul(zk[b][j], pk[j]);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) sa_wave_allreduce2(t[b].re, t[b].im);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int j = 0; j < JM; ++j) qk[j] = qk[j] + cmulc(zk[b][j], t[b]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < JM; ++j) {
@@ -2399,14 +2422,24 @@ int launch_cg_op(hipStream_t st, const CgCtl *ctl, bool with_update, const cx<T>
     SA_REQUIRE(K <= 4 * kWave, "cg_op: at most 256 filters");
 #ifdef SPORCO_AMD_HOSTSIM
     const int threads = kWave;                    // (the simulator's scheduler walks the whole block)
+    const int cap = kMaxPartialBlocks;
 #else
     const int threads = kThreads;
+    const int cap = kCgMaxBlocks;
 #endif
-    // one wave per pixel, grid-stride beyond the cap on partial rows
-    const int grid = grid_for(npix * kWave, threads);
-    hipLaunchKernelGGL((cg_op_kernel<T>), dim3(grid), dim3(threads),
-                       sizeof(double) * 4 * (threads / kWave), st, ctl, with_update ? 1 : 0, zf, r, p,
-                       q, rho, npix, CN, K, partials);
+    // one wave per pixel, grid-stride beyond the cap on workgroups
+    const int grid = std::min(grid_for(npix * kWave, threads), cap);
+    const size_t lds = sizeof(double) * (threads / kWave);
+    const int wu = with_update ? 1 : 0;
+    if (K <= kWave)
+        hipLaunchKernelGGL((cg_op_kernel<T, 1>), dim3(grid), dim3(threads), lds, st, ctl, wu, zf, r, p, q,
+                           rho, npix, CN, K, partials);
+    else if (K <= 2 * kWave)
+        hipLaunchKernelGGL((cg_op_kernel<T, 2>), dim3(grid), dim3(threads), lds, st, ctl, wu, zf, r, p, q,
+                           rho, npix, CN, K, partials);
+    else
+        hipLaunchKernelGGL((cg_op_kernel<T, 4>), dim3(grid), dim3(threads), lds, st, ctl, wu, zf, r, p, q,
+                           rho, npix, CN, K, partials);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -2437,22 +2470,39 @@ __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(const CgCtl *c, 
     if (c && c->done) return;
     const T alpha = c ? (T)c->alpha : alpha_host;
     double acc[1] = {0.0};                      // <r, r>, slot 2 of the block's partial row
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        x[i] = cscale(x[i], T(1)) + cscale(p[i], alpha);
-        const cx<T> rn = cscale(r[i], T(1)) + cscale(q[i], -alpha);
-        r[i] = rn;
-        acc[0] += (double)cabs2(rn);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // two grid-stride steps per trip (eight loads in flight per thread); the thread's elements
+    // enter its sum in the order of the plain loop
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 2 * stride) {
+        const int64_t i1 = i + stride;
+        const bool two = i1 < n;
+        const cx<T> x0 = x[i], r0 = r[i], p0 = p[i], q0 = q[i];
+        cx<T> x1 = x0, r1 = r0, p1 = p0, q1 = q0;
+        if (two) {
+            x1 = x[i1];
+            r1 = r[i1];
+            p1 = p[i1];
+            q1 = q[i1];
+        }
+        x[i] = cscale(x0, T(1)) + cscale(p0, alpha);
+        const cx<T> rn0 = cscale(r0, T(1)) + cscale(q0, -alpha);
+        r[i] = rn0;
+        acc[0] += (double)cabs2(rn0);
+        if (two) {
+            x[i1] = cscale(x1, T(1)) + cscale(p1, alpha);
+            const cx<T> rn1 = cscale(r1, T(1)) + cscale(q1, -alpha);
+            r[i1] = rn1;
+            acc[0] += (double)cabs2(rn1);
+        }
     }
     block_sum_store<1>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 4 + 2);
 }
 template <typename T>
 int launch_cg_update_xr(hipStream_t st, const CgCtl *c, T alpha_host, cx<T> *x, cx<T> *r,
                         const cx<T> *p, const cx<T> *q, int64_t n, double *partials) {
-    const int grid = grid_for(n);
+    const int grid = std::min(grid_for(n), kCgMaxBlocks);
     hipLaunchKernelGGL((cg_update_xr_kernel<T>), dim3(grid), dim3(kThreads),
-                       sizeof(double) * 4 * (kThreads / kWave), st, c, alpha_host, x, r, p, q, n,
-                       partials);
+                       sizeof(double) * (kThreads / kWave), st, c, alpha_host, x, r, p, q, n, partials);
     SA_HIP(hipGetLastError());
     return grid;
 }

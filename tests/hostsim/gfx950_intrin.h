@@ -117,6 +117,8 @@ template <typename T> inline void sa_wave_allreduce2(T &a, T &b) {
     a = v[0];
     b = v[1];
 }
+inline void sa_store_agent(double *p, double v) { *p = v; }
+inline double sa_load_agent(const double *p) { return *p; }
 inline float sa_rsq(float x) { return 1.0f / std::sqrt(x); }
 inline float sa_sqrt(float x) { return std::sqrt(x); }
 inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }
