@@ -301,6 +301,9 @@ int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out);
 
 #define SPORCO_AMD_PGM_RSDL 4    /* rfl2norm2(Xf - Yfprv) of pgm_iter (rsdl, pgm/cbpdn.py:314-320) */
 #define SPORCO_AMD_PGM_FY 5      /* f at the Yf the step started from (pgm_iter)             */
+#define SPORCO_AMD_PGM_LIN 6     /* sum Re(conj(Xf - Yf) grad f(Yf)) of a held pgm_iter
+                                    (eval_linear_approx, pgm.py:886-894)                  */
+#define SPORCO_AMD_PGM_DXY2 7    /* sum |Xf - Yf|^2, unweighted (backtrack.py:98-100)       */
 
 /* One whole default-option FISTA iteration on device (float32, H and W in {256, 512},
  * even K <= 64; SPORCO_AMD_EINVAL otherwise -- compose the calls below instead):
@@ -318,9 +321,16 @@ typedef struct {
     uint32_t flags;  /* SPORCO_AMD_FLAG_NONNEG | SPORCO_AMD_FLAG_NOBNDRY     */
     int32_t dH, dW;  /* filter support, for NOBNDRY                         */
     int32_t want_stats; /* evaluate the objective at the new Xf             */
+    int32_t hold;    /* backtracking trial: also out[PGM_LIN], out[PGM_DXY2] (the terms of
+                        Q_L, backtrack.py:95-100); the new iterates are kept aside and the
+                        call may be repeated with another L from the same Yf until
+                        sporco_amd_csc_pgm_commit adopts the last trial                   */
 } sporco_amd_pgm_params;
 int sporco_amd_csc_pgm_iter(sporco_amd_csc_t h, const sporco_amd_pgm_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]);
+/* Adopt the iterates of the last held pgm_iter (the buffer rotation of on_iteration_start,
+ * pgm.py:835-846); SPORCO_AMD_EINVAL without one. */
+int sporco_amd_csc_pgm_commit(sporco_amd_csc_t h);
 
 /* GF = conj(Df) * (sum_k Df*v - Sf) for v = complex state `var` (grad_f,
  * pgm/cbpdn.py:263-279); out[PGM_F], out[PGM_DFID] receive f(v). */

@@ -309,6 +309,30 @@ def gen_pgm():
     pgm_case('pgm_multichan_f64', D, S3, 0.1, {'MaxMainIter': 30, 'L': 500.0})
 
 
+def gen_pgm_bt256():
+    """pgm.cbpdn.ConvBPDN with BacktrackStandard at a shape the fused FISTA kernels serve
+    (256x256, K = 8, 8x8 filters, one image), float32 and float64 reference runs from L = 1:
+    the first iterations fail many trials, the later ones accept the first."""
+    rng = np.random.RandomState(4242)
+    D = rng.randn(8, 8, 8).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    X0 = np.zeros((256, 256, 8), np.float32)
+    idx = rng.rand(*X0.shape) < 0.004
+    X0[idx] = rng.randn(int(idx.sum())).astype(np.float32)
+    S = np.sum(np.fft.irfft2(np.fft.rfft2(D, (256, 256), axes=(0, 1)) *
+                             np.fft.rfft2(X0, axes=(0, 1)), (256, 256), axes=(0, 1)), axis=2)
+    S = (S + 0.01 * rng.randn(256, 256)).astype(np.float32)
+    for tag, extra in (('f32', {'DataType': np.float32}), ('f64', {'DataType': np.float64})):
+        optd = {'MaxMainIter': 14, 'RelStopTol': 0.0, 'L': 1.0,
+                'Backtrack': BacktrackStandard(gamma_u=1.5)}
+        optd.update(extra)
+        b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.02, ref_pgm_cbpdn.ConvBPDN.Options(optd))
+        X = b.solve()
+        save('pgm_bt256_' + tag, D=D, S=S, lmbda=np.float64(0.02), X_sub=_strided(X),
+             X_l2=np.float64(np.linalg.norm(X.astype(np.float64))),
+             X_nnz=np.int64(np.count_nonzero(X)), L_final=np.float64(b.L), **itstat_dict(b))
+
+
 # ---------------------------------------------------------------------------
 def gen_primitives():
     np.random.seed(12345)
@@ -903,6 +927,6 @@ if __name__ == '__main__':
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
-             'pgm': gen_pgm, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
+             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

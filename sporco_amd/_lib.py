@@ -45,7 +45,7 @@ OUT_CNSTR = 12
 OUT_CGIT, OUT_CGN = 13, 14
 OUT_COUNT = 16
 
-PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY = range(6)
+PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY, PGM_LIN, PGM_DXY2 = range(8)
 
 EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
@@ -61,7 +61,7 @@ EXPORTS = (
     'sporco_amd_csc_admm_stats', 'sporco_amd_csc_scale_u',
     'sporco_amd_csc_reconstruct', 'sporco_amd_csc_dhs_absmax',
     'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_eval', 'sporco_amd_csc_pgm_prox_step',
-    'sporco_amd_csc_pgm_iter',
+    'sporco_amd_csc_pgm_iter', 'sporco_amd_csc_pgm_commit',
     'sporco_amd_csc_lincomb', 'sporco_amd_csc_pair_stats', 'sporco_amd_csc_copy',
     'sporco_amd_csc_fft_var', 'sporco_amd_csc_ifft_var',
     'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
@@ -94,7 +94,7 @@ class Dims(ctypes.Structure):
 class PgmParams(ctypes.Structure):
     _fields_ = [('L', ctypes.c_double), ('lmbda', ctypes.c_double), ('beta', ctypes.c_double),
                 ('flags', ctypes.c_uint32), ('dH', ctypes.c_int32), ('dW', ctypes.c_int32),
-                ('want_stats', ctypes.c_int32)]
+                ('want_stats', ctypes.c_int32), ('hold', ctypes.c_int32)]
 
 
 class CnsParams(ctypes.Structure):
@@ -243,6 +243,7 @@ def load(path=None):
         'sporco_amd_csc_pgm_grad': [vp, ctypes.c_int, dptr],
         'sporco_amd_csc_pgm_eval': [vp, ctypes.c_int, dptr],
         'sporco_amd_csc_pgm_iter': [vp, ctypes.POINTER(PgmParams), dptr],
+        'sporco_amd_csc_pgm_commit': [vp],
         'sporco_amd_csc_pgm_prox_step': [vp, dbl, dbl, ctypes.c_uint32, i32, i32, dptr],
         'sporco_amd_csc_lincomb': [vp, ctypes.c_int, dbl, ctypes.c_int, dbl, ctypes.c_int, dbl,
                                    ctypes.c_int],
@@ -618,13 +619,18 @@ class Solver(object):
         check(self._lib.sporco_amd_csc_pgm_grad(self._h, var, out))
         return list(out)
 
-    def pgm_iter(self, L, lmbda, beta, flags, dH, dW, want_stats):
-        """One fused default-option FISTA iteration (sporco_amd_csc_pgm_iter)."""
+    def pgm_iter(self, L, lmbda, beta, flags, dH, dW, want_stats, hold=False):
+        """One fused default-option FISTA iteration (sporco_amd_csc_pgm_iter).  hold: a
+        backtracking trial -- out[PGM_LIN], out[PGM_DXY2] too, and the new iterates wait for
+        pgm_commit (the call may be repeated with another L)."""
         p = PgmParams(float(L), float(lmbda), float(beta), int(flags), int(dH), int(dW),
-                      1 if want_stats else 0)
+                      1 if want_stats else 0, 1 if hold else 0)
         out = self._out()
         check(self._lib.sporco_amd_csc_pgm_iter(self._h, ctypes.byref(p), out))
         return list(out)
+
+    def pgm_commit(self):
+        check(self._lib.sporco_amd_csc_pgm_commit(self._h))
 
     def cns_init(self, Y0, rho):
         """Consensus D-step state: Y = Y0 (H, W, 1, 1, K) or zero, U_n = Y0 / rho or zero."""

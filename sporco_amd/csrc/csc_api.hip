@@ -173,6 +173,7 @@ struct CscBase {
     virtual void pgm_grad(int var, double *out_dev) = 0;
     virtual void pgm_eval(int var, double *out_dev) = 0;
     virtual void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) = 0;
+    virtual void pgm_commit() = 0;
     virtual void pgm_prox_step(double L, double lmbda, uint32_t flags, int dH, int dW,
                                double *out_dev) = 0;
     virtual void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) = 0;
@@ -357,6 +358,8 @@ template <typename T> struct Csc : CscBase {
     bool pgm_tiled = false, pgm_x_stale = false;
     sporco_amd_pgm_params last_pgm;
     double *part_pgm = nullptr;
+    cx<T> *pgm_ey = nullptr;        // e_y of a held (backtracking) pgm_iter, tile-major (Wf, CN, H)
+    bool pgm_held = false;          // a trial's iterates wait in the spare buffers
     // ConvBPDNGradReg (F_GRADREG): separable gradient spectrum tables and filter weights
     T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
     bool have_wg = false;
@@ -472,7 +475,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
-                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)gpart,
+                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)pgm_ey, (void *)gpart,
                         (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold, (void *)md_s, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
@@ -1710,7 +1713,9 @@ template <typename T> struct Csc : CscBase {
             throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
         t_ready = false;
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        if (!part_pgm) SA_HIP(hipMalloc((void **)&part_pgm, sizeof(double) * 4 * (int64_t)Wf * CN));
+        if (!part_pgm)
+            SA_HIP(hipMalloc((void **)&part_pgm, sizeof(double) * kPgmPartialStride * (int64_t)Wf * CN));
+        if (p.hold && !pgm_ey) SA_HIP(hipMalloc((void **)&pgm_ey, sizeof(cx<T>) * (int64_t)Wf * CN * H));
         if (!pgm_tiled) {
             // enter the tile-major regime: the two live iterates are re-laid out once
             need_natural(SPORCO_AMD_VAR_XF);   // (an ADMM leftover in the Xf buffer is resolved first)
@@ -1737,7 +1742,8 @@ template <typename T> struct Csc : CscBase {
         ca.W = W;
         ca.CN = CN;
         ca.K = K;
-        ca.want_stats = p.want_stats;
+        ca.want_stats = p.want_stats || p.hold;
+        ca.ey = p.hold ? pgm_ey : nullptr;
         // 1. gradient step at Yf, inverse transform along H
         ca.yf = Yf;
         ca.xf_old = nullptr;
@@ -1768,11 +1774,25 @@ template <typename T> struct Csc : CscBase {
             launch_pgm_fft_momentum<T>(st, ca);
         }
         {
-            const int slots[3] = {SPORCO_AMD_PGM_RSDL, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F};
-            const double scales[3] = {1.0 / ((double)H * W), 1.0 / ((double)H * W), 0.5};
-            finalize(part_pgm, (int)ntile, 4, p.want_stats ? 3 : 1, slots, scales, out_dev);
+            const int slots[5] = {SPORCO_AMD_PGM_RSDL, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F,
+                                  SPORCO_AMD_PGM_LIN, SPORCO_AMD_PGM_DXY2};
+            const double scales[5] = {1.0 / ((double)H * W), 1.0 / ((double)H * W), 0.5, 1.0, 1.0};
+            finalize(part_pgm, (int)ntile, kPgmPartialStride, p.hold ? 5 : ca.want_stats ? 3 : 1, slots,
+                     scales, out_dev);
         }
-        // on_iteration_start's copies as a rotation of buffers (pgm.py:835-846)
+        last_pgm = p;
+        pgm_held = true;
+        if (!p.hold) pgm_commit();
+    }
+
+    // on_iteration_start's copies as a rotation of buffers (pgm.py:835-846): the trial in the
+    // spare buffers becomes the state
+    void pgm_commit() override {
+        SA_REQUIRE(pgm_held, "pgm_commit without a held pgm_iter");
+        pgm_held = false;
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF), *Yf = cv(SPORCO_AMD_VAR_YF);
+        cx<T> *Xprv = cv(SPORCO_AMD_VAR_XFPRV), *Yprv = cv(SPORCO_AMD_VAR_YFPRV);
+        cx<T> *spare = cv(SPORCO_AMD_VAR_VF);
         vars[SPORCO_AMD_VAR_XF] = spare;
         vars[SPORCO_AMD_VAR_XFPRV] = Xf;
         vars[SPORCO_AMD_VAR_VF] = Xprv;
@@ -1782,7 +1802,6 @@ template <typename T> struct Csc : CscBase {
         x_stale = false;
         x_invalid = false;
         pgm_x_stale = true;
-        last_pgm = p;
     }
 
     void pgm_grad(int var, double *out_dev) override {
@@ -1941,6 +1960,7 @@ template <typename T> struct Csc : CscBase {
             ca.xf_old = nullptr;
             ca.t = cv(SPORCO_AMD_VAR_ZF);
             ca.yf_new = nullptr;
+            ca.ey = nullptr;
             ca.dft = nullptr;
             ca.sft = nullptr;
             ca.twA = twA;
@@ -3328,6 +3348,12 @@ int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_O
     SA_API_END
 }
 
+int sporco_amd_csc_pgm_commit(sporco_amd_csc_t h) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->pgm_commit();
+    SA_API_END
+}
 int sporco_amd_csc_pgm_iter(sporco_amd_csc_t h, const sporco_amd_pgm_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN

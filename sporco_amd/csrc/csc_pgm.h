@@ -29,9 +29,14 @@ template <typename T> struct PgmColsArgs {
     T inv_L, beta;
     int H, W, CN, K;
     int want_stats;       // fft_momentum: also evaluate f(Xf') (needs the Df inner products)
+    cx<T> *ey;            // tile-major (Wf, CN, H), or null: e_y = sum_k Df Yf - Sf per frequency,
+                          // written by grad_ifft and read by fft_momentum (with want_stats) for
+                          // the linear term of the backtracking model Q_L (pgm.py:886-894)
     double *partials;     // grad_ifft: [tile] sum |sum_k Df Yf - Sf|^2;
-                          // fft_momentum: [tile][4] pw*|Xf' - Yf|^2, pw*|e|^2, |e|^2, 0
+                          // fft_momentum: [tile][6] pw*|Xf' - Yf|^2, pw*|e|^2, |e|^2,
+                          //   Re<e - e_y, e_y> (= <Xf' - Yf, grad f(Yf)>, 0 without ey), |Xf' - Yf|^2, 0
 };
+constexpr int kPgmPartialStride = 6;
 
 template <typename T> int64_t launch_pgm_grad_ifft(hipStream_t st, const PgmColsArgs<T> &a);
 // t <- FFT_H(t) only (row spectra -> full tile-major spectrum, in place): uses t, twA, H, W, CN, K

@@ -19,7 +19,7 @@ namespace {
 using namespace regfft;
 
 constexpr size_t pgm_lds_bytes(int NW, int LP) {
-    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * 4 * 16;
+    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * kPgmPartialStride * 16;
 }
 
 // sum over the K filters of d[e] * x[e] for 4 frequencies e at once (wave reduction);
@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
     const int ko = (w * K + k) * (int)sizeof(cf);   // row w, filter k
     const cf *S = a.sft + (int64_t)tile * H + w;
+    cf *EY = a.ey ? a.ey + (int64_t)tile * H + w : nullptr;
     const cf *twB = a.twB + w * N1;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
@@ -99,6 +100,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
             for (int e = 0; e < 4; ++e) {
                 const cf r = qq[e] - sv[e];   // sum_k Df Yf - Sf
                 fsum += cabs2(r);
+                if (EY && k == 0) EY[NW * j + N1 * brev(4 * c + e, LBW)] = r;
                 u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] - cscale(cmulc(dd[e], r), inv_L);
             }
             if constexpr (c == CPL - 1) {
@@ -151,7 +153,8 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
 // (sporco/pgm/pgm.py:803, :815-831; sporco/pgm/cbpdn.py:314-345)
 // ---------------------------------------------------------------------------
 // PLAIN: forward transform only (no momentum, no sums): t <- FFT_H(t)
-template <int NW, int LP, int KC, bool STATS, bool PLAIN = false>
+// BT: with STATS, also the linear term of the backtracking model from a.ey
+template <int NW, int LP, int KC, bool STATS, bool PLAIN = false, bool BT = false>
 __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmColsArgs<float> a) {
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
@@ -174,13 +177,14 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
     const int ko = (w * K + k) * (int)sizeof(cf);
     const cf *S = a.sft + (int64_t)tile * H + w;
+    const cf *EY = BT ? a.ey + (int64_t)tile * H + w : nullptr;
     const cf *twA = a.twA + w * N1;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
     const float beta = a.beta;
     int token = 0;
-    float rs = 0.f, fsum = 0.f;
+    float rs = 0.f, fsum = 0.f, lin = 0.f;
 
     // rows h = NW h1 + w of T', forward FFT over h1, twiddle
     cf v[N1];
@@ -259,7 +263,16 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                 }
                 inner4(dd, &u[NW * jl + 4 * c], k, qq);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) fsum += cabs2(qq[e] - sv[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const cf ex = qq[e] - sv[e];
+                    fsum += cabs2(ex);
+                    if constexpr (BT) {
+                        cf ey;
+                        sa_uload2(reinterpret_cast<const float *>(EY + NW * j + N1 * brev(4 * c + e, LBW)),
+                                  ey.re, ey.im);
+                        lin += (ex.re - ey.re) * ey.re + (ex.im - ey.im) * ey.im;
+                    }
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -285,9 +298,10 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     if constexpr (PLAIN) return;
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
     const double rsw = wave_sum((double)rs);   // rs is per lane (all filters); fsum is wave-uniform
-    double acc[4] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
-                     k == 0 ? (double)fsum : 0.0, 0.0};
-    block_sum_store<4>(acc, scratch, a.partials + (int64_t)tile * 4);
+    double acc[kPgmPartialStride] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
+                                     k == 0 ? (double)fsum : 0.0, k == 0 ? (double)lin : 0.0,
+                                     k == 0 ? rsw : 0.0, 0.0};
+    block_sum_store<kPgmPartialStride>(acc, scratch, a.partials + (int64_t)tile * kPgmPartialStride);
 }
 
 // ---------------------------------------------------------------------------
@@ -406,16 +420,16 @@ template <int NW, int LP, int KC> void launch_grad(hipStream_t st, const PgmCols
                        pgm_lds_bytes(NW, LP), st, a);
 }
 
-template <int NW, int LP, int KC, bool STATS>
+template <int NW, int LP, int KC, bool STATS, bool BT = false>
 void launch_mom(hipStream_t st, const PgmColsArgs<float> &a) {
     static bool attr_set = false;
     if (!attr_set) {
-        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, STATS>, pgm_lds_bytes(NW, LP));
+        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, STATS, false, BT>, pgm_lds_bytes(NW, LP));
         attr_set = true;
     }
     const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
-    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS>), dim3(grid), dim3(NW * 64),
-                       pgm_lds_bytes(NW, LP), st, a);
+    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS, false, BT>), dim3(grid),
+                       dim3(NW * 64), pgm_lds_bytes(NW, LP), st, a);
 }
 
 }  // namespace
@@ -438,7 +452,11 @@ template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmCols
     SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
                "shape not handled by the fused PGM kernels");
     const bool k64 = a.K == 64, st8 = a.H == 256, stats = a.want_stats != 0;
-    if (st8) {
+    if (a.ey) {      // a backtracking trial
+        SA_REQUIRE(stats, "the backtracking sums need want_stats");
+        if (st8) { if (k64) launch_mom<8, 2, 64, true, true>(st, a); else launch_mom<8, 2, 0, true, true>(st, a); }
+        else { if (k64) launch_mom<16, 1, 64, true, true>(st, a); else launch_mom<16, 1, 0, true, true>(st, a); }
+    } else if (st8) {
         if (k64) { if (stats) launch_mom<8, 2, 64, true>(st, a); else launch_mom<8, 2, 64, false>(st, a); }
         else { if (stats) launch_mom<8, 2, 0, true>(st, a); else launch_mom<8, 2, 0, false>(st, a); }
     } else {

@@ -17,6 +17,7 @@ import copy
 import numpy as np
 
 from . import pgm
+from .backtrack import BacktrackStandard
 from .. import _lib
 from .. import cnvrep as cr
 from ..admm.cbpdn import _DeviceArray, _broadcastable
@@ -175,7 +176,9 @@ class ConvBPDN(pgm.PGMDFT):
                    'eval_linear_approx', 'hess_quad')
 
     def _fused_ok(self):
-        if self.opt['Backtrack'] is not None or self.stepsizepolicy is not None \
+        # (BacktrackStandard itself, not a subclass: a subclass may change the search)
+        bt = self.opt['Backtrack']
+        if (bt is not None and type(bt) is not BacktrackStandard) or self.stepsizepolicy is not None \
                 or self.opt['Monotone'] or not self.dev.uses_fused_pgm():
             return False
         for name in self._hook_names:
@@ -185,7 +188,12 @@ class ConvBPDN(pgm.PGMDFT):
 
     def fused_iteration(self):
         """on_iteration_start, xstep and ystep (pgm.py:835-846, :779-831) as one
-        device call (csc_pgm.h); the sums it returns serve rsdl and eval_objfn."""
+        device call (csc_pgm.h); the sums it returns serve rsdl and eval_objfn.
+
+        With BacktrackStandard (backtrack.py:50-117) the call is a trial: F = f(X) and the
+        terms of Q_L come back with it, the iterates are adopted (pgm_commit) once F <= Q, and a
+        failed trial is repeated from the same Y with L gamma_u (Y = X + beta (X - Xprv) does
+        not depend on L, so the momentum step rides along with the accepted trial)."""
         if not self._fused_ok():
             self._fused_sums = None
             return False
@@ -193,8 +201,27 @@ class ConvBPDN(pgm.PGMDFT):
         self.t = self.momentum.update(self.var_momentum())
         beta = (tprv - 1.) / self.t
         stats = not self.opt['FastSolve']
-        out = self.dev.pgm_iter(self.L, float(self.lmbda) * self._wl1_scalar, beta, self._flags(),
-                                self.D.shape[0], self.D.shape[1], stats)
+        bt = self.opt['Backtrack']
+        lm = float(self.lmbda) * self._wl1_scalar
+        if bt is None:
+            out = self.dev.pgm_iter(self.L, lm, beta, self._flags(), self.D.shape[0],
+                                    self.D.shape[1], stats)
+        else:
+            it = 0
+            while True:
+                out = self.dev.pgm_iter(self.L, lm, beta, self._flags(), self.D.shape[0],
+                                        self.D.shape[1], True, hold=True)
+                f = out[_lib.PGM_F]
+                Q = out[_lib.PGM_FY] + out[_lib.PGM_LIN] + (self.L / 2.) * out[_lib.PGM_DXY2]
+                it += 1
+                if f <= Q or it >= bt.maxiter:
+                    if f > Q:
+                        self.L *= bt.gamma_u
+                    break
+                self.L *= bt.gamma_u
+            self.dev.pgm_commit()
+            self.F, self.Q, self.iterBTrack = f, Q, it
+            stats = True
         self._fused_sums = out
         self._rl1 = abs(self._wl1_scalar) * out[_lib.PGM_L1]
         self._cache.clear()

@@ -1,7 +1,7 @@
 """The fused FISTA iteration (csc_pgm.hip + csc_rows.hip: three launches, tile-major
 spectral iterates, X rebuilt on demand) against the NumPy oracle and against the
 generic composition of the same library.  Engages for float32, H and W in
-{256, 512}, even K <= 64 and default policies (no backtracking / step-size policy /
+{256, 512}, even K <= 64 and default policies or BacktrackStandard (no step-size policy /
 monotone restart); anything else composes the staged calls.
 
 Tolerance: 1e-5 relative l2 against the float64 oracle after 4 iterations (observed
@@ -107,15 +107,47 @@ def test_fused_pgm_options_and_pickle(backend):
     assert rel_l2(bf.solve(), bf0.solve()) < 1e-5
 
 
+def test_fused_backtracking_against_the_reference(backend):
+    """BacktrackStandard inside the fused iteration (a held pgm_iter per trial, F and the terms
+    of Q_L out of the momentum kernel, pgm_commit on acceptance) against the reference's own
+    float32 and float64 runs (tests/golden/pgm_bt256_*.npz: 7 trials in the first iteration,
+    one in each later one; sporco/pgm/backtrack.py:50-117)."""
+    from conftest import load_golden
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackStandard, BacktrackRobust
+    g32, g64 = load_golden('pgm_bt256_f32'), load_golden('pgm_bt256_f64')
+    iters = 4 if backend == 'hostsim' else 14
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 1.0,
+            'Backtrack': BacktrackStandard(gamma_u=1.5)}
+    b = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optd))
+    assert b._fused_ok()
+    X = b.solve()
+    its = b.getitstat()
+    for g, tol in ((g32, 2e-5), (g64, 1e-4)):
+        assert np.array_equal(np.asarray(its.IterBTrack, float), g['it_IterBTrack'][:iters])
+        for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L', 'F_Btrack', 'Q_Btrack'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f][:iters]) < tol, f
+        if iters == 14:
+            assert rel_l2(X[::16, ::16], g['X_sub']) < tol
+            assert abs(np.linalg.norm(X.astype(np.float64)) - float(g['X_l2'])) < tol * float(g['X_l2'])
+            assert abs(float(b.L) - float(g['L_final'])) < 1e-6 * float(g['L_final'])
+    # a search the fused call does not restate (robust backtracking) composes the staged calls
+    optr = dict(optd, Backtrack=BacktrackRobust(), MaxMainIter=1)
+    br = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optr))
+    assert not br._fused_ok()
+
+
 @pytest.mark.gpu
-def test_backtracking_still_composes(gpu_backend):
-    """A policy the fused call does not cover falls back to the staged composition."""
+def test_backtracking_fused_and_composed_agree(gpu_backend):
     from sporco_amd.pgm.backtrack import BacktrackStandard
-    H, W, K, N = 256, 256, 4, 1
+    H, W, K, N = 256, 256, 4, 2
     D, S = problem(H, W, K, N, seed=8)
-    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L': 1.0, 'Backtrack': BacktrackStandard()}
+    optd = {'MaxMainIter': 6, 'RelStopTol': 0.0, 'L': 1.0, 'Backtrack': BacktrackStandard()}
     b = make(D, S, optd)
-    assert not b._fused_ok()
+    assert b._fused_ok()
     b0 = make(D, S, optd, generic=True)
+    assert not b0._fused_ok()
     assert rel_l2(b.solve(), b0.solve()) < 1e-5
-    assert rel_l2(b.getitstat().L, b0.getitstat().L) < 1e-6
+    for f in ('L', 'IterBTrack', 'F_Btrack', 'Q_Btrack', 'ObjFun', 'Rsdl'):
+        assert rel_l2(np.asarray(getattr(b.getitstat(), f), float),
+                      np.asarray(getattr(b0.getitstat(), f), float)) < 1e-5, f

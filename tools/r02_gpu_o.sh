@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_fused_pgm.py tests/test_pgm_cbpdn.py tests/test_pgm_mask.py tests/test_parity_baseline_shapes.py -m gpu -x -q -k "pgm or PGM or fista or FISTA or config4 or backtrack" 2>&1 | tail -5
+timeout 300 python tools/bench_other.py pgm 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02o_config4.json
