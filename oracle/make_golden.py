@@ -783,6 +783,7 @@ def gen_ccmodmd():
         D1 = b.solve()
         save('cbpdndlmd_admm_%s_f64' % meth, D0=D0, S=S, W=W, lmbda=np.float64(0.1), D1=D1,
              X=b.getcoef(), **itstat_dict(b))
+    gen_maskdl_cg_default()
     # two-channel signal, single-channel dictionary: channels fold into the image axis in the
     # D-step and stay an axis of their own in the X-step
     Sc = np.random.randn(N, N, 2, 2)
@@ -793,6 +794,41 @@ def gen_ccmodmd():
     D1 = b.solve()
     save('cbpdndlmd_chan_admm_ism_f64', D0=D0, S=Sc, W=Wc, lmbda=np.float64(0.1), D1=D1,
          X=b.getcoef(), **itstat_dict(b))
+
+
+def gen_maskdl_cg_default():
+    """ConvBPDNMaskDictLearn(xmethod='admm', dmethod='cg') at the DEFAULT CG StopTol (1e-3), and
+    the same reference run with linalg.inner summing the filter axis in reversed order: the rho-free
+    system Z^H Z + I solved inexactly makes the outer iterates sensitive to the summation order of
+    the CG operator, and the second run measures by how much (the tolerance of the test)."""
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    rng = np.random.RandomState(1)
+    N = 4
+    S = rng.randn(16, 16, N)
+    W = (rng.rand(16, 16, N) > 0.2).astype(np.float64)
+    D0 = rng.randn(5, 5, 6)
+    inner0 = ref_linalg.inner
+
+    def inner_rev(x, y, axis=-1):
+        xr = np.flip(x, axis=axis) if x.shape[axis] > 1 else x
+        yr = np.flip(y, axis=axis) if y.shape[axis] > 1 else y
+        return inner0(xr, yr, axis=axis)
+
+    out = {}
+    for tag, fn in (('', inner0), ('_rev', inner_rev)):
+        ref_linalg.inner = fn
+        try:
+            opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8}, xmethod='admm', dmethod='cg')
+            b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, W, opt, xmethod='admm', dmethod='cg')
+            out['D1' + tag] = b.solve().copy()
+            out['X' + tag] = b.getcoef().copy()
+            if not tag:
+                out.update(itstat_dict(b))
+            else:
+                out.update(itstat_dict(b, prefix='rev_'))
+        finally:
+            ref_linalg.inner = inner0
+    save('cbpdndlmd_admm_cg_default_f64', D0=D0, S=S, W=W, lmbda=np.float64(0.1), **out)
 
 
 def gen_ccmodmd_cns():
@@ -927,6 +963,6 @@ if __name__ == '__main__':
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
-             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
+             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

@@ -96,6 +96,33 @@ def test_masked_dictionary_learning(backend, method):
         cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='nosuch')
 
 
+def test_masked_learning_cg_at_its_default_tolerance(backend):
+    """ConvBPDNMaskDictLearn(xmethod='admm', dmethod='cg') at the default CG StopTol (1e-3).  The
+    rho-free system Z^H Z + I solved inexactly makes the outer iterates sensitive to the summation
+    order of the CG operator: the fixture holds the reference's run and the reference's run with
+    linalg.inner summing the filter axis in reversed order (oracle/make_golden.py
+    gen_maskdl_cg_default; they are 7e-4 apart after 8 outer iterations, 2e-10 after the first).
+    Tolerance: the first outer iteration to 1e-8, the rest to three times the reference's own
+    spread."""
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_admm_cg_default_f64')
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8}, xmethod='admm', dmethod='cg')
+    d = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod='admm', dmethod='cg')
+    D1 = d.solve()
+    spread_d = rel_l2(g['D1_rev'].squeeze(), g['D1'].squeeze())
+    spread_x = rel_l2(g['X_rev'], g['X'])
+    assert 1e-5 < spread_d < 5e-3           # (the fixture does show the sensitivity)
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 3 * spread_d
+    assert rel_l2(d.getcoef(), g['X']) < 3 * spread_x
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'DPrRsdl', 'DDlRsdl'):
+        ours, ref, rev = np.asarray(getattr(its, f), float), g['it_' + f], g['rev_' + f]
+        assert abs(ours[0] - ref[0]) < 1e-8 * abs(ref[0]), f
+        spread = np.max(np.abs(rev - ref) / np.abs(ref))
+        assert np.max(np.abs(ours - ref) / np.abs(ref)) < 3 * spread + 1e-8, f
+
+
 @pytest.mark.parametrize('method', ['ism', 'cg'])
 def test_odd_filter_count_against_oracle(backend, method):
     from oracle import cbpdn_oracle as orc
