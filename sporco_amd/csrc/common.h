@@ -83,8 +83,12 @@ template <typename T> __host__ __device__ __forceinline__ cx<T> mul_pi(cx<T> a) 
 // base 16-byte aligned and leaves no static __shared__ objects around).
 // ---------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T *dyn_lds() {
+#ifdef SPORCO_AMD_HOSTSIM
+    return reinterpret_cast<T *>(hostsim::lds_base());   // (the CPU test simulator)
+#else
     extern __shared__ __attribute__((aligned(16))) unsigned char sporco_amd_lds_raw[];
     return reinterpret_cast<T *>(sporco_amd_lds_raw);
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -322,6 +322,9 @@ template <typename T> struct Csc : CscBase {
     bool fused = false, xf_tiled = false;
     bool fused_slabs = false;       // K = 64*NH: column pass as two slab kernels (csc_fused.h)
     cx<T> *qpart = nullptr;
+    unsigned *coop_flags = nullptr;     // cooperating slab workgroups (csc_fused.h): per (tile, slab)
+    unsigned coop_seq = 0;              // ... the launch counter their flags carry
+    int *coop_err = nullptr;            // ... pinned: set by a workgroup whose partner never showed up
     cx<T> *dft = nullptr, *sft = nullptr, *twA = nullptr, *twB = nullptr;
     T *gramt = nullptr;
     double *part_f = nullptr;
@@ -476,13 +479,14 @@ template <typename T> struct Csc : CscBase {
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)pgm_ey, (void *)gpart,
-                        (void *)qpart, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
+                        (void *)qpart, (void *)coop_flags, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold, (void *)md_s, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
                         (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)wdat_buf, (void *)part_a, (void *)part_b,
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
         if (out_pinned) (void)hipHostFree(out_pinned);
+        if (coop_err) (void)hipHostFree(coop_err);
         if (rec_ring) (void)hipHostFree(rec_ring);
         if (cg_pin) (void)hipHostFree((void *)cg_pin);
         if (cg_dev) (void)hipFree(cg_dev);
@@ -565,6 +569,33 @@ template <typename T> struct Csc : CscBase {
             fft_c2r<T>(st, planW, tmp, out, H, cols, (int64_t)Wf * cols, cols, (int64_t)W * cols,
                        cols, T(1.0 / ((double)H * (double)W)));
         }
+    }
+
+    // The column pass for 64 < K <= 256: one launch of cooperating slab workgroups, or the two
+    // slab kernels (SPORCO_AMD_SLAB_COOP=0).  Returns the number of tiles.
+    int64_t run_slab_cols(FusedSlabArgs<T> &sa) {
+        static const bool coop = !(std::getenv("SPORCO_AMD_SLAB_COOP") &&
+                                   std::atoi(std::getenv("SPORCO_AMD_SLAB_COOP")) == 0);
+        if (!coop) {
+            launch_cols_fwd_partial<T>(st, sa);
+            return launch_cols_sm_apply_inv<T>(st, sa);
+        }
+        if (!coop_flags) {
+            const size_t n = sizeof(unsigned) * (size_t)Wf * CN * ((K + 63) / 64);
+            SA_HIP(hipMalloc((void **)&coop_flags, n));
+            SA_HIP(hipMemsetAsync(coop_flags, 0, n, st));
+            SA_HIP(hipHostMalloc((void **)&coop_err, sizeof(int), 0));
+            *coop_err = 0;
+        }
+        if (*coop_err)
+            throw Error(SPORCO_AMD_EHIP, "cooperating slab workgroups: a partner's partial sums never arrived");
+        sa.coop_flags = coop_flags;
+        sa.coop_seq = ++coop_seq;
+        // (timing experiment only: the flags are never waited for, results are WRONG)
+        static const bool nowait = std::getenv("SPORCO_AMD_SLAB_COOP_NOWAIT") != nullptr;
+        if (nowait) sa.coop_seq = 0;
+        sa.coop_err = coop_err;
+        return launch_cols_slab_coop<T>(st, sa);
     }
 
     void finalize(const double *part, int nblocks, int stride, int nvals, const int *slots,
@@ -993,8 +1024,7 @@ template <typename T> struct Csc : CscBase {
             sa.c = fa;
             sa.qpart = qpart;
             ProfScope ps(prof, PS_FUSED_COLS);
-            launch_cols_fwd_partial<T>(st, sa);
-            ntiles = launch_cols_sm_apply_inv<T>(st, sa);
+            ntiles = run_slab_cols(sa);
             if (gradreg) ntiles *= (K + 63) / 64;   // (one row of partials per tile and slab)
         } else {
             ProfScope ps(prof, PS_FUSED_COLS);
@@ -1148,8 +1178,7 @@ template <typename T> struct Csc : CscBase {
                 FusedSlabArgs<T> sa;
                 sa.c = fa;
                 sa.qpart = qpart;
-                launch_cols_fwd_partial<T>(st, sa);
-                part_f_rows = (int)launch_cols_sm_apply_inv<T>(st, sa);
+                part_f_rows = (int)run_slab_cols(sa);
             } else {
                 part_f_rows = (int)launch_fused_cols<T>(st, fa);
             }

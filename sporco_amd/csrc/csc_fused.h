@@ -89,7 +89,15 @@ template <typename T> void launch_grad_g1(hipStream_t st, const FusedColsArgs<T>
 template <typename T> struct FusedSlabArgs {
     FusedColsArgs<T> c;
     cx<T> *qpart;   // (Wf*CN, NH, H) complex
+    // the one-launch form (launch_cols_slab_coop): per (tile, slab) flags that the slab's
+    // partial sums of launch `coop_seq` are in qpart, and a host-visible error word
+    unsigned *coop_flags = nullptr;
+    unsigned coop_seq = 0;
+    int *coop_err = nullptr;
 };
+// Both kernels above as ONE launch of cooperating slab workgroups (csc_fused.hip): two X-sized
+// passes instead of four.  Returns the number of tiles.
+template <typename T> int64_t launch_cols_slab_coop(hipStream_t st, const FusedSlabArgs<T> &a);
 template <typename T> bool fused_slabs_supported(int H, int K);
 template <typename T> void launch_cols_fwd_partial(hipStream_t st, const FusedSlabArgs<T> &a);
 template <typename T> int64_t launch_cols_sm_apply_inv(hipStream_t st, const FusedSlabArgs<T> &a);

@@ -619,6 +619,285 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same column pass as ONE launch: the NH slab workgroups of a tile run side by side on
+// different CUs, keep their 64-filter slab of the spectrum in registers, and exchange only
+// the partial inner products through `qpart` (written through, flagged per (tile, slab) with
+// the launch's sequence number).  Two X-sized passes instead of four.  The grid is persistent
+// and never larger than the device holds at once (one 16-wave / two 8-wave workgroups per
+// CU): partners are consecutive workgroup indices and walk the same tiles in the same order,
+// so whoever waits, waits for a workgroup that is resident.  A poll that does not complete
+// (2^22 rounds) raises `*coop_err` instead of hanging the device.
+// ---------------------------------------------------------------------------
+template <int NW, int LP, int KS, bool GRAD>
+__global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlabArgs<float> aa) {
+    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr int LBW = ilog2(NW);
+    constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    static_assert(Q * FP == N1, "a thread holds N1 spectrum rows");
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KS ? KS : aa.c.K;
+    const int NH = (K + 63) / 64;
+    const int slab = blockIdx.x % NH, pair = blockIdx.x / NH, npairs = gridDim.x / NH;
+    const bool kv = KS == 128 ? true : slab * 64 + k < K;   // the last slab may be partial
+    const cf zero = mk<float>(0.f, 0.f);
+    const int xcd = pair & 7;          // (virtual: the residue of the row frequencies it walks)
+    const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
+    f2 *L = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
+    int token = 0;
+    if (aa.c.ctl && aa.c.ctl->stop) return;     // (every workgroup of the launch sees the same value)
+    {   // groups start a fraction of a tile's time apart (the partners of a group together)
+        const int ph = (pair >> 3) % aa.c.stagger_groups;
+        for (int i = 0; i < ph * aa.c.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    // the partial sums this wave needs in phase 2, one row per lane: lane l < 32 holds row
+    // r = l of slab 0 (+ 2, ...), lane l >= 32 the same row of slab 1 (+ 3, ...)
+    const int rl = k & 31;
+    const int fo_lane = NW * (rl / NW) + N1 * brev(rl % NW, LBW);
+
+    for (int slot = pair >> 3;; slot += npairs >> 3) {
+    SA_ARGS_PTR_T(FusedSlabArgs<float>) ap = sa_args_reload<true>(aa);
+    const int Wf = ap->c.W / 2 + 1, CN = ap->c.CN;
+    if (slot >= ((Wf + 7) / 8) * CN) break;
+    const int wf = (slot / CN) * 8 + xcd;
+    if (wf >= Wf) break;
+    const int tile = wf * CN + slot % CN;
+    const AdmmCtl *ctl = ap->c.ctl;
+    const float rho = ctl ? ctl->rho_f : ap->c.rho;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Tb = make_rsrc(ap->c.t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(ap->c.dft + (int64_t)wf * H * K, tbytes);
+    const cf *twA = ap->c.twA + w * N1;
+    const cf *twB = ap->c.twB + w * N1;
+    const cf *S = ap->c.sft + (int64_t)tile * H + w;
+    const float *G = (GRAD ? ap->c.g1t : ap->c.gramt) + (int64_t)wf * H + w;
+    const float *GH = ap->c.ghh + w;
+    cf *qp = ap->qpart + (int64_t)tile * NH * H + w;      // [slab][f]
+    // where this lane publishes: lane 16 e (+ 8) -> Re (Im) of row N1 brev(e, 2) 2^(LBW - 2) + ...
+    float *pub = reinterpret_cast<float *>(qp + (int64_t)slab * H) +
+                 2 * (N1 * (brev(k >> 4, 2) << (LBW - 2))) + ((k >> 3) & 1);
+    unsigned *flags = ap->coop_flags + (int64_t)tile * NH;
+    const unsigned seq = ap->coop_seq;
+    float rg = 0.f, ak = 0.f, bk = 0.f, gw = 0.f;
+    if constexpr (GRAD) {
+        gw = sa_uload(ap->c.ghw + wf);
+        ak = ap->c.mu * ((ap->c.wg && kv) ? ap->c.wg[slab * 64 + k] : 1.f);
+        bk = ak * gw + rho;
+    }
+
+    // ---- phase 1: FFT along H, this slab's share of sum_k Df yuf ------------------------
+    cf uall[N1];                       // the slab's spectrum rows: group q in [q FP, (q + 1) FP)
+    {
+        cf v[N1];
+#pragma unroll
+        for (int h1 = 0; h1 < N1; ++h1)
+            v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
+        dif<N1, false>(v, 0);
+        reg_fence<N1>(v, 0, token);
+#pragma unroll
+        for (int i = 1; i < N1; ++i) {
+            cf tw;
+            sa_uload2(reinterpret_cast<const float *>(twA + i), tw.re, tw.im);
+            v[i] = cmul(v[i], tw);
+        }
+        reg_fence<N1>(v, 0, token);
+        static_for<Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int fl = 0; fl < FP; ++fl) {
+                const cf x = v[brev(q * FP + fl, 5)];
+                f2 t;
+                t.x = x.re;
+                t.y = x.im;
+                L[(fl * NW + w) * 64 + k] = t;
+            }
+            cf dn[4];
+            auto prefetch = [&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                    dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                }
+            };
+            prefetch(std::integral_constant<int, 0>{});
+            __syncthreads();
+#pragma unroll
+            for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+                for (int h2 = 0; h2 < NW; ++h2) {
+                    const f2 t = L[((w + NW * jl) * NW + h2) * 64 + k];
+                    uall[q * FP + NW * jl + h2] = mk<float>(t.x, t.y);
+                }
+            }
+            if (q + 1 < Q) __syncthreads();
+            static_for<NCH>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+                if constexpr (c == 0) dif<NW, false>(uall, q * FP + NW * jl);
+                cf d[4];
+                float red[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = dn[e];
+                if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cf p = cmul(d[e], uall[q * FP + NW * jl + 4 * c + e]);
+                    if constexpr (GRAD) {
+                        const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                        p = cscale(p, sa_rcp(ak * sa_uload(GH + fo) + bk));
+                    }
+                    red[2 * e] = p.re;
+                    red[2 * e + 1] = p.im;
+                }
+                const float tot = reduce8_across_lanes(red, k);
+                // lane 16 e holds Re, lane 16 e + 8 holds Im of the slab's partial sum for row
+                // fo(e) = NW j + N1 brev(4 c + e): one store by those eight lanes
+                constexpr int fo_c = NW * j + N1 * brev(c, LBW - 2);
+                if ((k & 7) == 0) sa_store_agent(pub + 2 * fo_c, tot);
+            });
+        });
+    }
+    // ---- publish, and wait for the other slabs of this tile ------------------------------
+    sa_wait_stores();
+    __syncthreads();
+    if (tid == 0) sa_store_agent(flags + slab, seq);
+    // what phase 2 needs besides the sums, requested before the wait: per row (one row per
+    // lane, as the sums below) Sf and the Sherman-Morrison denominator; the first rows of Df
+    float s_re, s_im, g_l, gh_l = 0.f;
+    {
+        const f2 t = *reinterpret_cast<const f2 *>(S + fo_lane);
+        s_re = t.x;
+        s_im = t.y;
+        g_l = G[fo_lane];
+        if constexpr (GRAD) gh_l = GH[fo_lane];
+    }
+    cf dn[4];
+    auto prefetch_d = [&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr int q = n / NCH, g = n % NCH, jl = g / CPL, c = g % CPL, j = q * LP + jl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+            dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+        }
+    };
+    prefetch_d(std::integral_constant<int, 0>{});
+    if (tid < NH && tid != slab) {
+        int polls = 0;
+        while (sa_load_agent(flags + tid) != seq) {
+            sa_spin_pause();
+            if (++polls > (1 << 22)) {
+                *ap->coop_err = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    float qre = 0.f, qim = 0.f;
+    for (int sl = 0; sl < NH; sl += 2) {
+        const int mine = sl + (k >> 5);
+        if (mine < NH) {
+            float a0, b0;
+            sa_load_agent2(reinterpret_cast<const float *>(qp + (int64_t)mine * H + fo_lane), a0, b0);
+            qre += a0;
+            qim += b0;
+        }
+    }
+    qre += __shfl_xor(qre, 32, 64);
+    qim += __shfl_xor(qim, 32, 64);
+    // the Sherman-Morrison coefficient of this lane's row (both halves of the wave hold it)
+    cf coef_l;
+    if constexpr (GRAD)
+        coef_l = cscale(mk<float>(s_re - rho * qre, s_im - rho * qim), sa_rcp(g_l));
+    else
+        coef_l = cscale(mk<float>(s_re - qre, s_im - qim), sa_rcp(g_l + rho));
+    const float obj_l = k < 32 ? cabs2(coef_l) : 0.f;
+
+    // ---- phase 2: Sherman-Morrison with the complete sums, IFFT along H --------------------
+    static_for<Q * NCH>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        constexpr int q = n / NCH, g = n % NCH, jl = g / CPL, c = g % CPL, j = q * LP + jl;
+        cf d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = dn[e];
+        if constexpr (n + 1 < Q * NCH) prefetch_d(std::integral_constant<int, n + 1>{});
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = NW * j + 4 * c + e;        // the lane that holds this row's values
+            const cf coef = mk<float>(sa_readlane(coef_l.re, r), sa_readlane(coef_l.im, r));
+            cf &ue = uall[q * FP + NW * jl + 4 * c + e];
+            if constexpr (GRAD) {
+                const float gh = sa_readlane(gh_l, r);
+                const cf xn = cscale(cscale(ue, rho) + cmulc(d[e], coef), sa_rcp(ak * gh + bk));
+                rg += (gh + gw) * cabs2(xn);
+                ue = xn;
+            } else {
+                ue = ue + cmulc(d[e], coef);
+            }
+        }
+        if constexpr (c == CPL - 1) {
+            dit<NW, true>(uall, q * FP + NW * jl);
+#pragma unroll
+            for (int h2 = 1; h2 < NW; ++h2) {
+                cf tw;
+                sa_uload2(reinterpret_cast<const float *>(twB + NW * j + h2), tw.re, tw.im);
+                uall[q * FP + NW * jl + h2] = cmulc(tw, uall[q * FP + NW * jl + h2]);
+            }
+        }
+        if constexpr (g == NCH - 1) {
+            {
+                float &rg_ = rg;
+                int &tk_ = token;
+                SA_VGPR_FENCE3(rg_, tk_, tk_);
+            }
+#pragma unroll
+            for (int jl2 = 0; jl2 < LP; ++jl2) {
+#pragma unroll
+                for (int h2 = 0; h2 < NW; ++h2) {
+                    f2 t;
+                    t.x = uall[q * FP + NW * jl2 + h2].re;
+                    t.y = uall[q * FP + NW * jl2 + h2].im;
+                    L[((w + NW * jl2) * NW + h2) * 64 + k] = t;
+                }
+            }
+            __syncthreads();
+            // (back into the group's own registers: rows h1 = brev(q FP + fl) of the last stage)
+#pragma unroll
+            for (int fl = 0; fl < FP; ++fl) {
+                const f2 t = L[(fl * NW + w) * 64 + k];
+                uall[q * FP + fl] = mk<float>(t.x, t.y);
+            }
+            if (q + 1 < Q) __syncthreads();
+        }
+    });
+    cf v[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) v[brev(i, 5)] = uall[i];
+    reg_fence<N1>(v, 0, token);
+    dit<N1, true>(v, 0);
+#pragma unroll
+    for (int h1 = 0; h1 < N1; ++h1)
+        if (kv) buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
+
+    // every slab computes the same |coef|^2: slab 0 reports it
+    const double pw = (wf == 0 || ((ap->c.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    if constexpr (GRAD) {
+        const float wk = (ap->c.wg && kv) ? ap->c.wg[slab * 64 + k] : 1.f;
+        double acc[2] = {slab == 0 ? (double)obj_l * pw : 0.0, kv ? (double)(rg * wk) * pw : 0.0};
+        block_sum_store<2>(acc, scratch, ap->c.partials + 2 * ((int64_t)tile * NH + slab));
+    } else {
+        double acc[1] = {(double)obj_l * pw * (double)rho * (double)rho};
+        if (slab == 0) block_sum_store<1>(acc, scratch, ap->c.partials + tile);
+    }
+    __syncthreads();      // (scratch and the exchange buffer are reused by the next tile)
+    }
+}
+
 template <typename E>
 __global__ void __launch_bounds__(256) permute_ab_kernel(const E *__restrict__ in,
                                                          E *__restrict__ out, int64_t A, int64_t B,
@@ -904,6 +1183,59 @@ static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool sec
         hipLaunchKernelGGL((cols_sm_apply_inv_kernel<NW, LP, KS, GRAD>), grid, dim3(NW * 64),
                            fused_lds_bytes(NW, LP), st, a);
     SA_HIP(hipGetLastError());
+}
+
+// Workgroups of the one-launch form: NH per tile side by side, as many groups as the device
+// holds at once with one workgroup per CU (a multiple of 8 groups: the residue of the row
+// frequencies a group walks stays fixed).
+template <int NW, int LP, int KS, bool GRAD>
+static void launch_slab_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
+    static bool attr_set = false;
+    static int cus = 0;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, GRAD>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)fused_lds_bytes(NW, LP)));
+        int dev = 0;
+        hipDeviceProp_t pr;
+        SA_HIP(hipGetDevice(&dev));
+        SA_HIP(hipGetDeviceProperties(&pr, dev));
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        attr_set = true;
+    }
+    const int NH = (int)ceil_div(a.c.K, 64);
+    int groups = (cus / NH) & ~7;
+#ifdef SPORCO_AMD_HOSTSIM
+    groups = 8;
+    hostsim::set_coop(NH);     // (the CPU test simulator runs the NH partners side by side)
+#endif
+    SA_REQUIRE(groups >= 8, "too few compute units for cooperating slab workgroups");
+    const int64_t slots = ceil_div(a.c.W / 2 + 1, 8) * a.c.CN;
+    if ((int64_t)(groups >> 3) > slots) groups = (int)slots * 8;
+    hipLaunchKernelGGL((cols_slab_coop_kernel<NW, LP, KS, GRAD>), dim3((unsigned)(groups * NH)),
+                       dim3(NW * 64), fused_lds_bytes(NW, LP), st, a);
+    SA_HIP(hipGetLastError());
+}
+template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlabArgs<float> &a_in) {
+    SA_REQUIRE(fused_slabs_supported<float>(a_in.c.H, a_in.c.K), "shape not handled by the slab column kernels");
+    SA_REQUIRE(a_in.coop_flags && a_in.coop_err, "the cooperating slab kernel needs its flag buffers");
+    FusedSlabArgs<float> a = a_in;
+    static const int sg = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS")) : 4;
+    static const int ss = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS")) : 2;
+    a.c.stagger_groups = sg > 0 ? sg : 1;
+    a.c.stagger_sleeps = ss;
+    const bool g = a.c.g1t != nullptr;
+    if (a.c.H == 256) {
+        if (a.c.K == 128) { if (g) launch_slab_coop<8, 2, 128, true>(st, a); else launch_slab_coop<8, 2, 128, false>(st, a); }
+        else { if (g) launch_slab_coop<8, 2, 0, true>(st, a); else launch_slab_coop<8, 2, 0, false>(st, a); }
+    } else {
+        if (a.c.K == 128) { if (g) launch_slab_coop<16, 1, 128, true>(st, a); else launch_slab_coop<16, 1, 128, false>(st, a); }
+        else { if (g) launch_slab_coop<16, 1, 0, true>(st, a); else launch_slab_coop<16, 1, 0, false>(st, a); }
+    }
+    return (int64_t)(a.c.W / 2 + 1) * a.c.CN;
+}
+template <> int64_t launch_cols_slab_coop<double>(hipStream_t, const FusedSlabArgs<double> &) {
+    throw Error(-1, "the fused column kernels are float32 only");
 }
 
 template <int NW, int LP, int KS>

@@ -145,6 +145,28 @@ __device__ __forceinline__ float sa_lane_xor15(float v) { return sa_dpp<0x140>(v
 __device__ __forceinline__ unsigned long long sa_wall_clock() { return __builtin_amdgcn_s_memrealtime(); }
 __device__ __forceinline__ void sa_fence_system() { __threadfence_system(); }
 
+// Exchange between workgroups of ONE launch (the cooperating slab workgroups of csc_fused.hip):
+// agent-scope stores are written through to where every XCD sees them, agent-scope loads bypass
+// the non-coherent cache levels; sa_wait_stores holds the wave until its stores are acknowledged.
+// (No acquire / release fences: at agent scope they write back and invalidate the whole L2.)
+__device__ __forceinline__ void sa_store_agent(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sa_store_agent(unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned sa_load_agent(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sa_load_agent2(const float *p, float &a, float &b) {   // 8-byte aligned
+    const unsigned long long t = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __builtin_bit_cast(float, (unsigned)(t & 0xffffffffull));
+    b = __builtin_bit_cast(float, (unsigned)(t >> 32));
+}
+__device__ __forceinline__ void sa_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void sa_spin_pause() { __builtin_amdgcn_s_sleep(8); }
+
 // A wave-uniform pointer made opaque to the optimiser (no instruction emitted): inside a
 // persistent tile loop this keeps loop-invariant operand loads (twiddle tables, ...) where
 // they are used instead of being hoisted in front of the loop, where they would occupy

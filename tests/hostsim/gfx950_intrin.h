@@ -119,6 +119,15 @@ template <typename T> inline void sa_wave_allreduce2(T &a, T &b) {
 }
 inline void sa_store_agent(double *p, double v) { *p = v; }
 inline double sa_load_agent(const double *p) { return *p; }
+inline void sa_store_agent(float *p, float v) { *p = v; }
+inline void sa_store_agent(unsigned *p, unsigned v) { *p = v; }
+inline unsigned sa_load_agent(const unsigned *p) { return *(const volatile unsigned *)p; }
+inline void sa_load_agent2(const float *p, float &a, float &b) {
+    a = p[0];
+    b = p[1];
+}
+inline void sa_wait_stores() {}
+inline void sa_spin_pause() { hostsim::spin_pause(); }
 inline float sa_rsq(float x) { return 1.0f / std::sqrt(x); }
 inline float sa_sqrt(float x) { return std::sqrt(x); }
 inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }

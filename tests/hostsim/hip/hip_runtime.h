@@ -91,6 +91,9 @@ namespace hostsim {
 void syncthreads();
 void wave_sync();
 void *shuffle_slot(int tid);
+void *lds_base();          // the running workgroup's dynamic LDS
+void set_coop(int n);      // the next launch runs n consecutive workgroups side by side
+void spin_pause();         // inside a poll of memory another workgroup writes
 int block_threads();
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 

@@ -12,10 +12,11 @@
 
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
-namespace sporco_amd {
-// the dynamic-LDS region that sporco_amd::dyn_lds() declares `extern`
-alignas(16) unsigned char sporco_amd_lds_raw[160 * 1024];
-}  // namespace sporco_amd
+namespace {
+constexpr int kMaxCoop = 4;               // workgroups that may run side by side (set_coop)
+constexpr size_t kLdsBytes = 160 * 1024;
+alignas(16) unsigned char lds_store[kMaxCoop][kLdsBytes];
+}  // namespace
 
 struct hostsim_event {
     std::chrono::steady_clock::time_point t;
@@ -61,14 +62,16 @@ struct Fiber {
 
 std::vector<Fiber> fibers;
 void *sched_sp = nullptr;
-int cur = -1;
+int cur = -1;          // fiber index = slot * nthreads + thread
+int cur_slot = 0;      // which of the side-by-side workgroups the running fiber belongs to
 int nthreads = 0;
+int coop = 1;          // workgroups of consecutive index run side by side (next launch only)
 const std::function<void()> *body_fn = nullptr;
 
-int bar_arrived = 0, bar_gen = 0;
-int wave_arrived[32], wave_gen[32];
+int bar_arrived[kMaxCoop], bar_gen[kMaxCoop];
+int wave_arrived[kMaxCoop][32], wave_gen[kMaxCoop][32];
 unsigned long progress = 0;
-alignas(16) unsigned char slots[2048][16];
+alignas(16) unsigned char slots[kMaxCoop][2048][16];
 
 void yield() { hostsim_switch(&fibers[cur].sp, sched_sp); }
 
@@ -96,34 +99,49 @@ void prepare(Fiber &f) {
 }  // namespace
 
 int block_threads() { return nthreads; }
-void *shuffle_slot(int tid) { return slots[tid]; }
+void *shuffle_slot(int tid) { return slots[cur_slot][tid]; }
+void *lds_base() { return lds_store[cur_slot]; }
+void set_coop(int n) {
+    if (n < 1 || n > kMaxCoop) {
+        std::fprintf(stderr, "hostsim: at most %d workgroups side by side\n", kMaxCoop);
+        std::abort();
+    }
+    coop = n;
+}
+// a thread that polls memory written by another workgroup gives the others a turn
+void spin_pause() {
+    ++progress;      // (a poll is not a deadlock: the writer may need many rounds to get there)
+    yield();
+}
 
 void syncthreads() {
-    const int g = bar_gen;
-    if (++bar_arrived == nthreads) {
-        bar_arrived = 0;
-        ++bar_gen;
+    const int s = cur_slot;
+    const int g = bar_gen[s];
+    if (++bar_arrived[s] == nthreads) {
+        bar_arrived[s] = 0;
+        ++bar_gen[s];
         ++progress;
     } else {
-        while (bar_gen == g) yield();
+        while (bar_gen[s] == g) yield();
     }
 }
 
 void wave_sync() {
+    const int s = cur_slot;
     const int w = (int)threadIdx.x / 64;
     const int wsize = (nthreads - w * 64) < 64 ? (nthreads - w * 64) : 64;
-    const int g = wave_gen[w];
-    if (++wave_arrived[w] == wsize) {
-        wave_arrived[w] = 0;
-        ++wave_gen[w];
+    const int g = wave_gen[s][w];
+    if (++wave_arrived[s][w] == wsize) {
+        wave_arrived[s][w] = 0;
+        ++wave_gen[s][w];
         ++progress;
     } else {
-        while (wave_gen[w] == g) yield();
+        while (wave_gen[s][w] == g) yield();
     }
 }
 
 void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body) {
-    if (shmem > sizeof(sporco_amd::sporco_amd_lds_raw)) {
+    if (shmem > kLdsBytes) {
         std::fprintf(stderr, "hostsim: dynamic LDS request %zu exceeds 160 KiB\n", shmem);
         std::abort();
     }
@@ -132,44 +150,53 @@ void run_grid(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &
         std::fprintf(stderr, "hostsim: unsupported block shape\n");
         std::abort();
     }
-    if ((int)fibers.size() < nthreads) {
+    const int group = coop;
+    coop = 1;
+    if ((int)fibers.size() < nthreads * group) {
         const size_t old = fibers.size();
-        fibers.resize(nthreads);
+        fibers.resize((size_t)nthreads * group);
         for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char *)std::malloc(kStack);
     }
     body_fn = &body;
     blockDim = block;
     gridDim = grid;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
-                blockIdx = dim3(bx, by, bz);
-                bar_arrived = 0;
-                for (int w = 0; w < 32; ++w) wave_arrived[w] = 0;
-                for (int t = 0; t < nthreads; ++t) {
-                    prepare(fibers[t]);
-                }
-                int live = nthreads;
-                while (live > 0) {
-                    const unsigned long before = progress;
-                    live = 0;
-                    for (int t = 0; t < nthreads; ++t) {
-                        if (fibers[t].done) continue;
-                        cur = t;
-                        threadIdx = dim3((unsigned)t, 0, 0);
-                        hostsim_switch(&sched_sp, fibers[t].sp);
-                        if (!fibers[t].done) ++live;
-                    }
-                    if (live > 0 && progress == before) {
-                        std::fprintf(stderr,
-                                     "hostsim: deadlock -- %d threads wait at a barrier that the "
-                                     "others never reach (divergent __syncthreads/shuffle)\n",
-                                     live);
-                        std::abort();
-                    }
-                }
+    // workgroups in x-fastest order, `group` of them side by side (1 unless set_coop was called)
+    const unsigned long nblocks = (unsigned long)grid.x * grid.y * grid.z;
+    dim3 idx[kMaxCoop];
+    for (unsigned long b0 = 0; b0 < nblocks; b0 += group) {
+        const int nb = (int)((nblocks - b0) < (unsigned long)group ? (nblocks - b0) : group);
+        for (int s = 0; s < nb; ++s) {
+            const unsigned long b = b0 + s;
+            idx[s] = dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y),
+                          (unsigned)(b / ((unsigned long)grid.x * grid.y)));
+            bar_arrived[s] = 0;
+            for (int w = 0; w < 32; ++w) wave_arrived[s][w] = 0;
+            for (int t = 0; t < nthreads; ++t) prepare(fibers[s * nthreads + t]);
+        }
+        int live = nb * nthreads;
+        while (live > 0) {
+            const unsigned long before = progress;
+            live = 0;
+            for (int f = 0; f < nb * nthreads; ++f) {
+                if (fibers[f].done) continue;
+                cur = f;
+                cur_slot = f / nthreads;
+                blockIdx = idx[cur_slot];
+                threadIdx = dim3((unsigned)(f % nthreads), 0, 0);
+                hostsim_switch(&sched_sp, fibers[f].sp);
+                if (!fibers[f].done) ++live;
             }
+            if (live > 0 && progress == before) {
+                std::fprintf(stderr,
+                             "hostsim: deadlock -- %d threads wait at a barrier that the "
+                             "others never reach (divergent __syncthreads/shuffle)\n",
+                             live);
+                std::abort();
+            }
+        }
+    }
     cur = -1;
+    cur_slot = 0;
 }
 
 }  // namespace hostsim
