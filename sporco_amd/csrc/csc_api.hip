@@ -591,9 +591,6 @@ template <typename T> struct Csc : CscBase {
             throw Error(SPORCO_AMD_EHIP, "cooperating slab workgroups: a partner's partial sums never arrived");
         sa.coop_flags = coop_flags;
         sa.coop_seq = ++coop_seq;
-        // (timing experiment only: the flags are never waited for, results are WRONG)
-        static const bool nowait = std::getenv("SPORCO_AMD_SLAB_COOP_NOWAIT") != nullptr;
-        if (nowait) sa.coop_seq = 0;
         sa.coop_err = coop_err;
         return launch_cols_slab_coop<T>(st, sa);
     }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic_bytes.json from the two rocprofv3 --pmc passes of `python bench.py`
+(FETCH_SIZE and WRITE_SIZE, separate runs, summarised by tools/rocpd_summary.py):
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE counts 64 B
+per 128-B request (MI355X_MICROARCH.md, HBM section).
+
+    python tools/hbm_traffic_from_pmc.py <pmc_fetch_size.csv> <pmc_write_size.csv> <out.json> [tag]
+"""
+import csv
+import json
+import sys
+
+
+def counters(path, name):
+    rows = list(csv.reader(open(path)))
+    start = [i for i, r in enumerate(rows) if len(r) > 1 and r[0] == 'Name' and r[1] == 'Counter'][0]
+    return {r[0]: float(r[3]) for r in rows[start + 1:] if len(r) >= 4 and r[1] == name}
+
+
+KERNELS = {      # bench.py's kernel names -> a substring of the dispatch name
+    'rows_fwd': 'rows_fwd_kernel<16, false>',
+    'fused_cols_sm': 'fused_cols_kernel<32, 16, 1, 64, false, false, false, 0>',
+    'rows_inv_post': 'rows_inv_post_kernel<16, false, 0, false, false>',
+    'rows_inv_post_emit': 'rows_inv_post_kernel<16, false, 0, true, false>',
+}
+
+
+def main():
+    f, w = counters(sys.argv[1], 'FETCH_SIZE'), counters(sys.argv[2], 'WRITE_SIZE')
+    tag = sys.argv[4] if len(sys.argv) > 4 else ''
+    out = {'_comment': "HBM bytes per launch at config 2 (512x512, K=64, N=32, f32) from rocprofv3 --pmc "
+                       "FETCH_SIZE / WRITE_SIZE (separate passes of `python bench.py --steps 6 --warmup 2`%s): "
+                       "(2*FETCH_SIZE + WRITE_SIZE)*1024 -- gfx950 FETCH_SIZE counts 64 B per 128-B request "
+                       "(MI355X_MICROARCH.md, HBM section; confirmed in round 1 on gram_kernel, which reads "
+                       "the 67.4 MB Df once and reports FETCH_SIZE*1024 = 33.7 MB)." % (', ' + tag if tag else '')}
+    for key, sub in KERNELS.items():
+        fk = [v for n, v in f.items() if sub in n]
+        wk = [v for n, v in w.items() if sub in n]
+        if fk and wk:
+            out[key] = (2.0 * fk[0] + wk[0]) * 1024.0
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()
