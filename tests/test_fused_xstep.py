@@ -330,6 +330,9 @@ def test_state_machine_random_walk(gpu_backend, seed):
                                        pytest.param(512, 512, 128, 1, None, marks=pytest.mark.gpu),
                                        pytest.param(256, 512, 192, 1, None, marks=pytest.mark.gpu),
                                        pytest.param(256, 256, 96, 2, None, marks=pytest.mark.gpu),
+                                       # four cooperating slab workgroups per tile
+                                       pytest.param(256, 256, 256, 1, None, marks=pytest.mark.gpu),
+                                       pytest.param(512, 256, 250, 1, None, marks=pytest.mark.gpu),
                                        pytest.param(256, 256, 128, 1, 3, marks=pytest.mark.gpu)])
 def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
     from oracle import cbpdn_oracle as orc
