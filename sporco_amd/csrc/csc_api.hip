@@ -536,7 +536,15 @@ template <typename T> struct Csc : CscBase {
     }
     Dims5 d5() const { return Dims5{H, W, C, N, K}; }
 
-    void sync() override { SA_HIP(hipStreamSynchronize(st)); }
+    void sync() override {
+        SA_HIP(hipStreamSynchronize(st));
+        // (cooperating slab workgroups, csc_fused.h: a partner's partial sums never arrived)
+        if (coop_err && *coop_err) {
+            *coop_err = 0;
+            throw Error(SPORCO_AMD_EHIP, "cooperating slab workgroups: a partner's partial sums never "
+                                         "arrived; the iterates of this handle are invalid");
+        }
+    }
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
@@ -587,8 +595,6 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipHostMalloc((void **)&coop_err, sizeof(int), 0));
             *coop_err = 0;
         }
-        if (*coop_err)
-            throw Error(SPORCO_AMD_EHIP, "cooperating slab workgroups: a partner's partial sums never arrived");
         sa.coop_flags = coop_flags;
         sa.coop_seq = ++coop_seq;
         sa.coop_err = coop_err;
@@ -652,6 +658,12 @@ template <typename T> struct Csc : CscBase {
         if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
         t_ready = false;
         prev_in_alt = false;
+    }
+    // The dictionary changes: a pending X depends on the old one, but the speculatively emitted
+    // row spectra of Y - U (t_ready) and the ping-pong parity do not -- a dictionary-learning
+    // loop keeps skipping the forward row pass of its one-iteration X-steps.
+    void before_dict_change() {
+        if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
     }
     void x_written() {
         x_stale = false;
@@ -725,7 +737,7 @@ template <typename T> struct Csc : CscBase {
     void set_dict(const void *D, int dH, int dW) override {
         SA_REQUIRE(dH >= 1 && dW >= 1 && dH <= H && dW <= W,
                    "filter support must fit inside the signal");
-        before_state_change();
+        before_dict_change();
         if (!dpad) SA_HIP(hipMalloc((void **)&dpad, sizeof(T) * (int64_t)H * W * Cd * K));
         // stage the compact filters at the tail of dpad's own allocation? no: use `work`-free
         // dedicated staging so set_dict is safe while iterates are live.
@@ -2136,7 +2148,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void setdict_from_dstep(int dH, int dW) override {
-        before_state_change();
+        before_dict_change();
         SA_HIP(hipMemcpyAsync(cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_DXF),
                               sizeof(cx<T>) * npix * KD(), hipMemcpyDeviceToDevice, st));
         ism_valid = false;
