@@ -38,9 +38,6 @@ struct alignas(16) cf2 {
 };
 
 constexpr int kN1 = 32;
-#ifndef SA_POST_END_FENCE
-#define SA_POST_END_FENCE false
-#endif
 constexpr size_t rows_lds_bytes(int NW) {
     return sizeof(f2) * 16 * NW * 64 + sizeof(double) * 8 * 16;
 }
@@ -170,7 +167,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 // Spectral side -> spatial side: the bins f <= W/2 of t[f][cn][h][k..k+1] are loaded,
 // the packed spectrum Z is rebuilt, and v[n1] receives the unnormalised inverse
 // transform at x = NW n1 + w: (re, im) = (filter k, filter k+1).
-template <int NW, bool END_FENCE = false>
+template <int NW>
 __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW, const cf *t, int CN,
                                                     int H, int K, int cn, int k, int h, bool pv, int w,
                                                     int lane, f2 *L, int &token) {
@@ -266,10 +263,6 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
     });
     reg_fence<N1>(v, 0, token);
     dit<N1, true>(v, 0);   // v[n1] = (X_p, X_{p+1}) at x = NW n1 + w, unnormalised
-    // (END_FENCE: nothing of what follows may be scheduled into the transform -- with the
-    // l2,1 epilogue it takes the spills of rows_inv_post<16> from 148 to 21 dwords; the other
-    // variants allocate worse with it)
-    if constexpr (END_FENCE) reg_fence<N1>(v, 0, token);
 }
 
 // ---------------------------------------------------------------------------
@@ -395,8 +388,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     int token = 0;
 
     cf v[N1];
-    spectral_to_spatial<NW, (JOINT && !EMIT_T) || SA_POST_END_FENCE>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k,
-                                                                    h, pv, w, lane, L, token);
+    spectral_to_spatial<NW>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L, token);
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a->P;
