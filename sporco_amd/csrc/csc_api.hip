@@ -360,7 +360,7 @@ template <typename T> struct Csc : CscBase {
     int ccmod_groups = 1;
     bool pgm_tiled = false, pgm_x_stale = false;
     sporco_amd_pgm_params last_pgm;
-    double *part_pgm = nullptr;
+    double *part_pgm = nullptr, *part_pgm2 = nullptr;
     cx<T> *pgm_ey = nullptr;        // e_y of a held (backtracking) pgm_iter, tile-major (Wf, CN, H)
     bool pgm_held = false;          // a trial's iterates wait in the spare buffers
     // ConvBPDNGradReg (F_GRADREG): separable gradient spectrum tables and filter weights
@@ -478,7 +478,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
-                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)pgm_ey, (void *)gpart,
+                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)pgm_ey, (void *)gpart,
                         (void *)qpart, (void *)coop_flags, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold, (void *)md_s, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
@@ -548,7 +548,7 @@ template <typename T> struct Csc : CscBase {
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
-        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && fused) ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && (fused || fused_slabs)) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
@@ -588,6 +588,11 @@ template <typename T> struct Csc : CscBase {
             launch_cols_fwd_partial<T>(st, sa);
             return launch_cols_sm_apply_inv<T>(st, sa);
         }
+        coop_prepare(sa);
+        return launch_cols_slab_coop<T>(st, sa);
+    }
+    // flags, launch counter and error word of a launch of cooperating slab workgroups
+    void coop_prepare(FusedSlabArgs<T> &sa) {
         if (!coop_flags) {
             const size_t n = sizeof(unsigned) * (size_t)Wf * CN * ((K + 63) / 64);
             SA_HIP(hipMalloc((void **)&coop_flags, n));
@@ -598,7 +603,6 @@ template <typename T> struct Csc : CscBase {
         sa.coop_flags = coop_flags;
         sa.coop_seq = ++coop_seq;
         sa.coop_err = coop_err;
-        return launch_cols_slab_coop<T>(st, sa);
     }
 
     void finalize(const double *part, int nblocks, int stride, int nvals, const int *slots,
@@ -1747,12 +1751,16 @@ template <typename T> struct Csc : CscBase {
     void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
         require_single_channel_dict();
         require_ready();
-        if (!(rows_ok && fused))
+        if (!(rows_ok && (fused || fused_slabs)))
             throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
         t_ready = false;
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
-        if (!part_pgm)
-            SA_HIP(hipMalloc((void **)&part_pgm, sizeof(double) * kPgmPartialStride * (int64_t)Wf * CN));
+        const int NHp = (K + 63) / 64;      // 64-filter slabs of the column kernels (1: K <= 64)
+        if (!part_pgm) {
+            SA_HIP(hipMalloc((void **)&part_pgm,
+                             sizeof(double) * kPgmPartialStride * (int64_t)Wf * CN * NHp));
+            if (NHp > 1) SA_HIP(hipMalloc((void **)&part_pgm2, sizeof(double) * 3 * (int64_t)Wf * CN));
+        }
         if (p.hold && !pgm_ey) SA_HIP(hipMalloc((void **)&pgm_ey, sizeof(cx<T>) * (int64_t)Wf * CN * H));
         if (!pgm_tiled) {
             // enter the tile-major regime: the two live iterates are re-laid out once
@@ -1789,7 +1797,27 @@ template <typename T> struct Csc : CscBase {
         ca.yf_new = nullptr;
         ca.partials = part_f;
         int64_t ntile;
-        {
+        if (NHp > 1) {
+            // K > 64: cooperating slab workgroups (csc_fused.h launch_pgm_grad_slabs)
+            FusedSlabArgs<T> sa;
+            sa.c.t = Tm;
+            sa.c.dft = dft;
+            sa.c.sft = sft;
+            sa.c.twA = twA;
+            sa.c.twB = twB;
+            sa.c.H = H;
+            sa.c.W = W;
+            sa.c.CN = CN;
+            sa.c.K = K;
+            sa.c.partials = part_f;
+            sa.qpart = qpart;
+            sa.pgm_yf = Yf;
+            sa.pgm_inv_L = ca.inv_L;
+            sa.pgm_ey = ca.ey;
+            coop_prepare(sa);
+            ProfScope ps(prof, PS_PGM_GRAD_IFFT);
+            ntile = launch_pgm_grad_slabs<T>(st, sa);
+        } else {
             ProfScope ps(prof, PS_PGM_GRAD_IFFT);
             ntile = launch_pgm_grad_ifft<T>(st, ca);
         }
@@ -1807,11 +1835,28 @@ template <typename T> struct Csc : CscBase {
         ca.t = spare;
         ca.yf_new = Yprv;
         ca.partials = part_pgm;
+        ca.qpart = (NHp > 1 && ca.want_stats) ? qpart : nullptr;
+        int64_t nrows;
         {
             ProfScope ps(prof, PS_PGM_FFT_MOM);
-            launch_pgm_fft_momentum<T>(st, ca);
+            nrows = launch_pgm_fft_momentum<T>(st, ca);
         }
-        {
+        if (NHp > 1) {
+            // per (tile, slab): the residual sums; per tile, from the slabs' shares: the objective
+            const int s0[1] = {SPORCO_AMD_PGM_RSDL}, s4[1] = {SPORCO_AMD_PGM_DXY2};
+            const double c0[1] = {1.0 / ((double)H * W)}, c4[1] = {1.0};
+            finalize(part_pgm, (int)nrows, kPgmPartialStride, 1, s0, c0, out_dev);
+            if (p.hold) finalize(part_pgm + 4, (int)nrows, kPgmPartialStride, 1, s4, c4, out_dev);
+            if (ca.want_stats) {
+                {
+                    ProfScope ps(prof, PS_PGM_FFT_MOM);
+                    launch_pgm_stats_slabs<T>(st, ca, part_pgm2);
+                }
+                const int s2[3] = {SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_LIN};
+                const double c2[3] = {1.0 / ((double)H * W), 0.5, 1.0};
+                finalize(part_pgm2, (int)ntile, 3, p.hold ? 3 : 2, s2, c2, out_dev);
+            }
+        } else {
             const int slots[5] = {SPORCO_AMD_PGM_RSDL, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_F,
                                   SPORCO_AMD_PGM_LIN, SPORCO_AMD_PGM_DXY2};
             const double scales[5] = {1.0 / ((double)H * W), 1.0 / ((double)H * W), 0.5, 1.0, 1.0};

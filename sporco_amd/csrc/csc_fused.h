@@ -94,10 +94,19 @@ template <typename T> struct FusedSlabArgs {
     unsigned *coop_flags = nullptr;
     unsigned coop_seq = 0;
     int *coop_err = nullptr;
+    // launch_pgm_grad_slabs (the gradient step of the fused FISTA iteration, csc_pgm.h, for K > 64):
+    // input spectrum Yf (output: c.t), 1 / L, and optionally e_y per frequency (Wf, CN, H)
+    const cx<T> *pgm_yf = nullptr;
+    T pgm_inv_L = T(0);
+    cx<T> *pgm_ey = nullptr;
 };
 // Both kernels above as ONE launch of cooperating slab workgroups (csc_fused.hip): two X-sized
 // passes instead of four.  Returns the number of tiles.
 template <typename T> int64_t launch_cols_slab_coop(hipStream_t st, const FusedSlabArgs<T> &a);
+// pgm_grad_ifft of csc_pgm.h for 64 < K <= 256 by the same cooperating slab workgroups:
+// t = IFFT_H(Yf - conj(Df)(sum_k Df Yf - Sf) / L), partials[tile] = sum_f |sum_k Df Yf - Sf|^2.
+// Uses c.{t, dft, sft, twA, twB, H, W, CN, K, partials}, qpart, the coop fields and the pgm ones.
+template <typename T> int64_t launch_pgm_grad_slabs(hipStream_t st, const FusedSlabArgs<T> &a);
 template <typename T> bool fused_slabs_supported(int H, int K);
 template <typename T> void launch_cols_fwd_partial(hipStream_t st, const FusedSlabArgs<T> &a);
 template <typename T> int64_t launch_cols_sm_apply_inv(hipStream_t st, const FusedSlabArgs<T> &a);

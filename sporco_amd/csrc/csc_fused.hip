@@ -629,8 +629,12 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
 // so whoever waits, waits for a workgroup that is resident.  A poll that does not complete
 // (2^22 rounds) raises `*coop_err` instead of hanging the device.
 // ---------------------------------------------------------------------------
-template <int NW, int LP, int KS, bool GRAD>
+// PGM: the gradient step of the fused FISTA iteration for K > 64 instead (csc_pgm.h pgm_grad_ifft):
+// the input rows are the spectrum Yf itself (no forward transform), the per-row coefficient is
+// -(sum_k Df Yf - Sf) / L, the output goes to a.c.t, and partials[tile] = sum |sum_k Df Yf - Sf|^2.
+template <int NW, int LP, int KS, bool GRAD, bool PGM = false>
 __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlabArgs<float> aa) {
+    static_assert(!(GRAD && PGM), "one or the other");
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
@@ -673,7 +677,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     const cf *twA = ap->c.twA + w * N1;
     const cf *twB = ap->c.twB + w * N1;
     const cf *S = ap->c.sft + (int64_t)tile * H + w;
-    const float *G = (GRAD ? ap->c.g1t : ap->c.gramt) + (int64_t)wf * H + w;
+    const float *G = PGM ? nullptr : (GRAD ? ap->c.g1t : ap->c.gramt) + (int64_t)wf * H + w;
     const float *GH = ap->c.ghh + w;
     cf *qp = ap->qpart + (int64_t)tile * NH * H + w;      // [slab][f]
     // where this lane publishes: lane 16 e (+ 8) -> Re (Im) of row N1 brev(e, 2) 2^(LBW - 2) + ...
@@ -690,7 +694,38 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
 
     // ---- phase 1: FFT along H, this slab's share of sum_k Df yuf ------------------------
     cf uall[N1];                       // the slab's spectrum rows: group q in [q FP, (q + 1) FP)
-    {
+    if constexpr (PGM) {
+        // the iterate is already a spectrum: rows f = w + NW j + N1 brev(i) of Yf, and the slab's
+        // share of sum_k Df Yf
+        const BufRsrc Yb = make_rsrc(ap->pgm_yf + (int64_t)tile * H * K, tbytes);
+        static_for<Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const int fo = NW * (q * LP + jl) + N1 * brev(i, LBW);
+                    uall[q * FP + NW * jl + i] = kv ? buf_load_cf(Yb, ko, fo * K * (int)sizeof(cf)) : zero;
+                }
+            }
+            static_for<NCH>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
+                float red[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fo = NW * j + N1 * brev(4 * c + e, LBW);
+                    const cf d = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                    const cf p = cmul(d, uall[q * FP + NW * jl + 4 * c + e]);
+                    red[2 * e] = p.re;
+                    red[2 * e + 1] = p.im;
+                }
+                const float tot = reduce8_across_lanes(red, k);
+                constexpr int fo_c = NW * j + N1 * brev(c, LBW - 2);
+                if ((k & 7) == 0) sa_store_agent(pub + 2 * fo_c, tot);
+            });
+        });
+    } else {
         cf v[N1];
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1)
@@ -773,7 +808,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
         const f2 t = *reinterpret_cast<const f2 *>(S + fo_lane);
         s_re = t.x;
         s_im = t.y;
-        g_l = G[fo_lane];
+        g_l = PGM ? 0.f : G[fo_lane];
         if constexpr (GRAD) gh_l = GH[fo_lane];
     }
     cf dn[4];
@@ -812,11 +847,19 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     qim += __shfl_xor(qim, 32, 64);
     // the Sherman-Morrison coefficient of this lane's row (both halves of the wave hold it)
     cf coef_l;
-    if constexpr (GRAD)
-        coef_l = cscale(mk<float>(s_re - rho * qre, s_im - rho * qim), sa_rcp(g_l));
-    else
-        coef_l = cscale(mk<float>(s_re - qre, s_im - qim), sa_rcp(g_l + rho));
-    const float obj_l = k < 32 ? cabs2(coef_l) : 0.f;
+    float obj_l;
+    if constexpr (PGM) {
+        const cf r = mk<float>(qre - s_re, qim - s_im);        // e_y = sum_k Df Yf - Sf
+        coef_l = cscale(r, -ap->pgm_inv_L);
+        obj_l = k < 32 ? cabs2(r) : 0.f;
+        if (ap->pgm_ey && slab == 0 && k < 32) ap->pgm_ey[(int64_t)tile * H + w + fo_lane] = r;
+    } else {
+        if constexpr (GRAD)
+            coef_l = cscale(mk<float>(s_re - rho * qre, s_im - rho * qim), sa_rcp(g_l));
+        else
+            coef_l = cscale(mk<float>(s_re - qre, s_im - qim), sa_rcp(g_l + rho));
+        obj_l = k < 32 ? cabs2(coef_l) : 0.f;
+    }
 
     // ---- phase 2: Sherman-Morrison with the complete sums, IFFT along H --------------------
     static_for<Q * NCH>([&](auto nc) {
@@ -890,6 +933,9 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
         const float wk = (ap->c.wg && kv) ? ap->c.wg[slab * 64 + k] : 1.f;
         double acc[2] = {slab == 0 ? (double)obj_l * pw : 0.0, kv ? (double)(rg * wk) * pw : 0.0};
         block_sum_store<2>(acc, scratch, ap->c.partials + 2 * ((int64_t)tile * NH + slab));
+    } else if constexpr (PGM) {
+        double acc[1] = {(double)obj_l};
+        if (slab == 0) block_sum_store<1>(acc, scratch, ap->c.partials + tile);
     } else {
         double acc[1] = {(double)obj_l * pw * (double)rho * (double)rho};
         if (slab == 0) block_sum_store<1>(acc, scratch, ap->c.partials + tile);
@@ -1233,6 +1279,52 @@ template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlab
         else { if (g) launch_slab_coop<16, 1, 0, true>(st, a); else launch_slab_coop<16, 1, 0, false>(st, a); }
     }
     return (int64_t)(a.c.W / 2 + 1) * a.c.CN;
+}
+template <int NW, int LP, int KS>
+static void launch_pgm_grad_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
+    static bool attr_set = false;
+    static int cus = 0;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, false, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
+        int dev = 0;
+        hipDeviceProp_t pr;
+        SA_HIP(hipGetDevice(&dev));
+        SA_HIP(hipGetDeviceProperties(&pr, dev));
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        attr_set = true;
+    }
+    const int NH = (int)ceil_div(a.c.K, 64);
+    int groups = (cus / NH) & ~7;
+#ifdef SPORCO_AMD_HOSTSIM
+    groups = 8;
+    hostsim::set_coop(NH);
+#endif
+    SA_REQUIRE(groups >= 8, "too few compute units for cooperating slab workgroups");
+    const int64_t slots = ceil_div(a.c.W / 2 + 1, 8) * a.c.CN;
+    if ((int64_t)(groups >> 3) > slots) groups = (int)slots * 8;
+    hipLaunchKernelGGL((cols_slab_coop_kernel<NW, LP, KS, false, true>), dim3((unsigned)(groups * NH)),
+                       dim3(NW * 64), fused_lds_bytes(NW, LP), st, a);
+    SA_HIP(hipGetLastError());
+}
+template <> int64_t launch_pgm_grad_slabs<float>(hipStream_t st, const FusedSlabArgs<float> &a_in) {
+    SA_REQUIRE(fused_slabs_supported<float>(a_in.c.H, a_in.c.K), "shape not handled by the slab column kernels");
+    SA_REQUIRE(a_in.coop_flags && a_in.coop_err && a_in.pgm_yf, "the cooperating slab kernel needs its buffers");
+    FusedSlabArgs<float> a = a_in;
+    a.c.stagger_groups = 1;
+    a.c.stagger_sleeps = 0;
+    if (a.c.H == 256) {
+        if (a.c.K == 128) launch_pgm_grad_coop<8, 2, 128>(st, a);
+        else launch_pgm_grad_coop<8, 2, 0>(st, a);
+    } else {
+        if (a.c.K == 128) launch_pgm_grad_coop<16, 1, 128>(st, a);
+        else launch_pgm_grad_coop<16, 1, 0>(st, a);
+    }
+    return (int64_t)(a.c.W / 2 + 1) * a.c.CN;
+}
+template <> int64_t launch_pgm_grad_slabs<double>(hipStream_t, const FusedSlabArgs<double> &) {
+    throw Error(-1, "the fused column kernels are float32 only");
 }
 template <> int64_t launch_cols_slab_coop<double>(hipStream_t, const FusedSlabArgs<double> &) {
     throw Error(-1, "the fused column kernels are float32 only");

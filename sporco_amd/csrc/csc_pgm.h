@@ -32,6 +32,9 @@ template <typename T> struct PgmColsArgs {
     cx<T> *ey;            // tile-major (Wf, CN, H), or null: e_y = sum_k Df Yf - Sf per frequency,
                           // written by grad_ifft and read by fft_momentum (with want_stats) for
                           // the linear term of the backtracking model Q_L (pgm.py:886-894)
+    cx<T> *qpart = nullptr;   // K > 64 (fft_momentum runs per (tile, 64-filter slab), grid.y = slabs):
+                          // with want_stats the slab's share of sum_k Df Xf' goes to
+                          // qpart[tile][slab][f] and launch_pgm_stats_slabs forms the objective sums
     double *partials;     // grad_ifft: [tile] sum |sum_k Df Yf - Sf|^2;
                           // fft_momentum: [tile][6] pw*|Xf' - Yf|^2, pw*|e|^2, |e|^2,
                           //   Re<e - e_y, e_y> (= <Xf' - Yf, grad f(Yf)>, 0 without ey), |Xf' - Yf|^2, 0
@@ -62,6 +65,13 @@ template <typename T> int64_t launch_ccmod_grad_tiled(hipStream_t st, const Ccmo
 // out[i] = sum_g part[g * n + i]
 template <typename T>
 void launch_sum_groups(hipStream_t st, const cx<T> *part, cx<T> *out, int64_t n, int G);
+// (K > 64: returns tiles * slabs rows of partials, of which only the residual sums [0] and [4] are
+// filled; the objective sums come from launch_pgm_stats_slabs)
 template <typename T> int64_t launch_pgm_fft_momentum(hipStream_t st, const PgmColsArgs<T> &a);
+// K > 64, after fft_momentum with want_stats: e_x = sum_slab qpart - Sf per frequency;
+// partials2[tile][0..2] = pw |e_x|^2, |e_x|^2, Re<e_x - e_y, e_y> (0 without a.ey).  Returns the
+// number of rows (tiles).
+template <typename T>
+int64_t launch_pgm_stats_slabs(hipStream_t st, const PgmColsArgs<T> &a, double *partials2);
 
 }  // namespace sporco_amd

@@ -163,7 +163,9 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int K = KC ? KC : a.K;
-    const bool kv = KC == 64 ? true : k < K;
+    // (K > 64, run-time K only: one workgroup per (tile, 64-filter slab), slab = blockIdx.y)
+    const int slab = KC ? 0 : (int)blockIdx.y, NHs = KC ? 1 : (int)gridDim.y;
+    const bool kv = KC == 64 ? true : slab * 64 + k < K;
     const int Wf = a.W / 2 + 1;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int wf = (slot / a.CN) * 8 + xcd;
@@ -175,9 +177,10 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     const BufRsrc Yo = PLAIN ? Tb : make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
     const BufRsrc Yn = PLAIN ? Tb : make_rsrc(a.yf_new + (int64_t)tile * H * K, tbytes);
     const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
-    const int ko = (w * K + k) * (int)sizeof(cf);
+    const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
     const cf *S = a.sft + (int64_t)tile * H + w;
     const cf *EY = BT ? a.ey + (int64_t)tile * H + w : nullptr;
+    cf *QP = (STATS && !KC && a.qpart) ? a.qpart + ((int64_t)tile * NHs + slab) * H + w : nullptr;
     const cf *twA = a.twA + w * N1;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
@@ -262,6 +265,11 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                     sa_uload2(reinterpret_cast<const float *>(S + fo), sv[e].re, sv[e].im);
                 }
                 inner4(dd, &u[NW * jl + 4 * c], k, qq);
+                if (QP) {     // the slab's share only: the sums are formed by pgm_stats_slabs
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k == 0) QP[NW * j + N1 * brev(4 * c + e, LBW)] = qq[e];
+                } else
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const cf ex = qq[e] - sv[e];
@@ -301,7 +309,31 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     double acc[kPgmPartialStride] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
                                      k == 0 ? (double)fsum : 0.0, k == 0 ? (double)lin : 0.0,
                                      k == 0 ? rsw : 0.0, 0.0};
-    block_sum_store<kPgmPartialStride>(acc, scratch, a.partials + (int64_t)tile * kPgmPartialStride);
+    block_sum_store<kPgmPartialStride>(acc, scratch,
+                                       a.partials + ((int64_t)tile * NHs + slab) * kPgmPartialStride);
+}
+
+// K > 64: the objective sums from the slabs' shares of sum_k Df Xf' (see csc_pgm.h)
+__global__ void __launch_bounds__(256) pgm_stats_slabs_kernel(const PgmColsArgs<float> a, int NH,
+                                                              double *partials2) {
+    const int tile = blockIdx.x, Wf = a.W / 2 + 1, wf = tile / a.CN;
+    const cf *qp = a.qpart + (int64_t)tile * NH * a.H;
+    const cf *S = a.sft + (int64_t)tile * a.H;
+    const cf *EY = a.ey ? a.ey + (int64_t)tile * a.H : nullptr;
+    double fs = 0.0, lin = 0.0;
+    for (int f = threadIdx.x; f < a.H; f += blockDim.x) {
+        cf ex = mk<float>(0.f, 0.f);
+        for (int sl = 0; sl < NH; ++sl) ex = ex + qp[(int64_t)sl * a.H + f];
+        ex = ex - S[f];
+        fs += (double)cabs2(ex);
+        if (EY) {
+            const cf ey = EY[f];
+            lin += (double)((ex.re - ey.re) * ey.re + (ex.im - ey.im) * ey.im);
+        }
+    }
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    double acc[3] = {fs * pw, fs, lin};
+    block_sum_store<3>(acc, dyn_lds<double>(), partials2 + (int64_t)tile * 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -428,7 +460,8 @@ void launch_mom(hipStream_t st, const PgmColsArgs<float> &a) {
         attr_set = true;
     }
     const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
-    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS, false, BT>), dim3(grid),
+    const unsigned slabs = KC ? 1u : (unsigned)ceil_div(a.K, 64);
+    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS, false, BT>), dim3(grid, slabs),
                        dim3(NW * 64), pgm_lds_bytes(NW, LP), st, a);
 }
 
@@ -448,9 +481,21 @@ template <> int64_t launch_pgm_grad_ifft<float>(hipStream_t st, const PgmColsArg
     return (int64_t)(a.W / 2 + 1) * a.CN;
 }
 
+template <> int64_t launch_pgm_stats_slabs<float>(hipStream_t st, const PgmColsArgs<float> &a,
+                                                  double *partials2) {
+    const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
+    hipLaunchKernelGGL(pgm_stats_slabs_kernel, dim3((unsigned)ntiles), dim3(256), sizeof(double) * 3 * 4,
+                       st, a, (int)ceil_div(a.K, 64), partials2);
+    SA_HIP(hipGetLastError());
+    return ntiles;
+}
+template <> int64_t launch_pgm_stats_slabs<double>(hipStream_t, const PgmColsArgs<double> &, double *) {
+    throw Error(-1, "the fused FISTA kernels are float32 only");
+}
 template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmColsArgs<float> &a) {
-    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
+    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
                "shape not handled by the fused PGM kernels");
+    SA_REQUIRE(a.K <= 64 || !a.want_stats || a.qpart, "K > 64 with statistics needs qpart");
     const bool k64 = a.K == 64, st8 = a.H == 256, stats = a.want_stats != 0;
     if (a.ey) {      // a backtracking trial
         SA_REQUIRE(stats, "the backtracking sums need want_stats");
@@ -464,7 +509,7 @@ template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmCols
         else { if (stats) launch_mom<16, 1, 0, true>(st, a); else launch_mom<16, 1, 0, false>(st, a); }
     }
     SA_HIP(hipGetLastError());
-    return (int64_t)(a.W / 2 + 1) * a.CN;
+    return (int64_t)(a.W / 2 + 1) * a.CN * ceil_div(a.K, 64);
 }
 
 template <int NW, int LP, int KC> static void launch_plain(hipStream_t st, const PgmColsArgs<float> &a) {

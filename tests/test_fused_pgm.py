@@ -31,7 +31,13 @@ def make(D, S, optd, generic=False):
 
 
 @pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1),
-                                     pytest.param(256, 256, 5, 2, marks=pytest.mark.gpu)])
+                                     pytest.param(256, 256, 5, 2, marks=pytest.mark.gpu),
+                                     # K > 64: cooperating slab workgroups in the gradient step,
+                                     # per-slab momentum kernels + the slab statistics kernel
+                                     (256, 256, 128, 1),
+                                     pytest.param(512, 512, 128, 1, marks=pytest.mark.gpu),
+                                     pytest.param(512, 256, 250, 1, marks=pytest.mark.gpu),
+                                     pytest.param(256, 512, 192, 2, marks=pytest.mark.gpu)])
 def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     from oracle import cbpdn_oracle as orc
     if backend == 'hostsim' and W == 512:
@@ -62,8 +68,9 @@ def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     for name in ('Yf', 'Xfprv', 'Yfprv'):
         assert rel_l2(getattr(b, name), getattr(b0, name)) < 1e-5, name
     # X is exactly sparse: it is the prox output itself, not a transform of Xf (a value on
-    # the threshold may round either way in two float32 implementations: allow a handful)
-    assert abs(np.count_nonzero(X) - np.count_nonzero(b0.X)) <= 4
+    # the threshold may round either way in two float32 implementations: allow a handful, one
+    # per two million elements)
+    assert abs(np.count_nonzero(X) - np.count_nonzero(b0.X)) <= max(4, X.size // 2000000)
     assert np.count_nonzero(X) < X.size
     # continue after the layout round trip
     b.solve()
@@ -138,9 +145,10 @@ def test_fused_backtracking_against_the_reference(backend):
 
 
 @pytest.mark.gpu
-def test_backtracking_fused_and_composed_agree(gpu_backend):
+@pytest.mark.parametrize('K', [4, 128])
+def test_backtracking_fused_and_composed_agree(gpu_backend, K):
     from sporco_amd.pgm.backtrack import BacktrackStandard
-    H, W, K, N = 256, 256, 4, 2
+    H, W, N = 256, 256, 2
     D, S = problem(H, W, K, N, seed=8)
     optd = {'MaxMainIter': 6, 'RelStopTol': 0.0, 'L': 1.0, 'Backtrack': BacktrackStandard()}
     b = make(D, S, optd)
