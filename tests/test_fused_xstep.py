@@ -340,7 +340,7 @@ def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
     iters = 2 if backend == 'hostsim' else 3
     optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
     b, Y = solve(D, S, optd, joint=C is not None)
-    assert b._dev.uses_fused_rows() and not b._dev.uses_fused_pgm()
+    assert b._dev.uses_fused_rows() and b._dev.uses_fused_pgm()    # (K > 64: slab kernels in both solvers)
     if H * W * K * N * (C or 1) > 2 ** 25:
         # (not reached by the cases above: every one of them, including ConvBPDNJoint with
         # K = 128, C = 3 -- 25 M elements -- is checked against the float64 oracle)
