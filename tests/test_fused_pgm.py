@@ -1,7 +1,7 @@
 """The fused FISTA iteration (csc_pgm.hip + csc_rows.hip: three launches, tile-major
 spectral iterates, X rebuilt on demand) against the NumPy oracle and against the
 generic composition of the same library.  Engages for float32, H and W in
-{256, 512}, even K <= 64 and default policies or BacktrackStandard (no step-size policy /
+{256, 512}, even K <= 256 and default policies or BacktrackStandard (no step-size policy /
 monotone restart); anything else composes the staged calls.
 
 Tolerance: 1e-5 relative l2 against the float64 oracle after 4 iterations (observed
