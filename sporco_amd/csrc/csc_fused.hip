@@ -661,6 +661,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     // r = l of slab 0 (+ 2, ...), lane l >= 32 the same row of slab 1 (+ 3, ...)
     const int rl = k & 31;
     const int fo_lane = NW * (rl / NW) + N1 * brev(rl % NW, LBW);
+    bool gave_up = false;
 
     for (int slot = pair >> 3;; slot += npairs >> 3) {
     SA_ARGS_PTR_T(FusedSlabArgs<float>) ap = sa_args_reload<true>(aa);
@@ -822,12 +823,13 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
         }
     };
     prefetch_d(std::integral_constant<int, 0>{});
-    if (tid < NH && tid != slab) {
+    if (tid < NH && tid != slab && !gave_up) {
         int polls = 0;
         while (sa_load_agent(flags + tid) != seq) {
             sa_spin_pause();
             if (++polls > (1 << 22)) {
                 *ap->coop_err = 1;
+                gave_up = true;      // (no further waiting in this launch: the result is void anyway)
                 break;
             }
         }

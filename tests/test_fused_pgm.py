@@ -43,18 +43,22 @@ def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     if backend == 'hostsim' and W == 512:
         pytest.skip("W = 512 row kernels run under the simulator in test_fused_xstep; here GPU only")
     D, S = problem(H, W, K, N, seed=H + W)
-    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'L': 50.0}
+    slow = backend == 'hostsim' and K > 64       # (keeps the CPU suite short)
+    iters = 2 if slow else 3
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 50.0}
     b = make(D, S, optd)
     assert b.dev.uses_fused_rows() and b._fused_ok()
     X = b.solve()
     ref = orc.pgm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
-                        dtype=np.float64, maxiter=3, L=50.0, rel_tol=0.0)
+                        dtype=np.float64, maxiter=iters, L=50.0, rel_tol=0.0)
     assert rel_l2(X, ref['X']) < 1e-5
     its = b.getitstat()
     for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl'):
         assert rel_l2(getattr(its, f), ref[f]) < 1e-5, f
     # the spectral iterates come back in the reference layout
     assert rel_l2(b.Xf, np.fft.rfftn(ref['X'], axes=(0, 1))) < 1e-5
+    if slow:
+        return
     if backend == 'hostsim':
         # after the layout round trip the solver continues in step with the oracle
         b.solve()
