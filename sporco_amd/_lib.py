@@ -358,6 +358,12 @@ def _ptr(a):
 
 
 def _carr(a, dtype):
+    a = np.asarray(a)
+    if np.iscomplexobj(a) and not np.issubdtype(np.dtype(dtype), np.complexfloating):
+        # (the reference solves complex-valued problems with complex FFTs,
+        # sporco/admm/cbpdn.py:213-217; this backend's transforms are real-to-complex)
+        raise NotImplementedError("complex-valued signals, dictionaries and weights are not "
+                                  "supported by the sporco_amd backend")
     return np.ascontiguousarray(a, dtype=dtype)
 
 

@@ -396,3 +396,17 @@ def test_yprev_and_ax_after_fused_iterations_and_refused_overrides(backend):
     m.ystep = lambda: None
     with pytest.raises(NotImplementedError):
         m.solve()
+
+
+def test_complex_input_is_refused(backend):
+    """The reference solves complex-valued problems with complex transforms
+    (sporco/admm/cbpdn.py:213-217, tests/admm/test_cbpdn.py:179-201); this backend's transforms are
+    real-to-complex, and it says so instead of dropping the imaginary part."""
+    from sporco_amd.admm import cbpdn
+    from sporco_amd.pgm import cbpdn as pc
+    rng = np.random.RandomState(0)
+    D, S = rng.randn(4, 4, 3), rng.randn(16, 16, 2)
+    for make in (lambda: cbpdn.ConvBPDN(D, S + 1j * S, 0.1), lambda: cbpdn.ConvBPDN(D * (1 + 1j), S, 0.1),
+                 lambda: pc.ConvBPDN(D, S + 1j * S, 0.1)):
+        with pytest.raises(NotImplementedError):
+            make()
