@@ -363,6 +363,7 @@ template <typename T> struct Csc : CscBase {
     double *part_pgm = nullptr, *part_pgm2 = nullptr;
     cx<T> *pgm_ey = nullptr;        // e_y of a held (backtracking) pgm_iter, tile-major (Wf, CN, H)
     bool pgm_held = false;          // a trial's iterates wait in the spare buffers
+    bool run_always_emit = false;   // device-driven solve of a small problem (admm_run)
     // ConvBPDNGradReg (F_GRADREG): separable gradient spectrum tables and filter weights
     T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;
     bool have_wg = false;
@@ -1226,15 +1227,15 @@ template <typename T> struct Csc : CscBase {
         pa.ams_k = Ku - 1;
         pa.partials = part_rows;
         pa.ctl = ctl_dev;
-        int64_t nt;
-        {
+        int64_t nt = 0;
+        if (!run_always_emit) {
             ProfScope ps(prof, PS_ROWS_INV_POST);
             nt = launch_rows_inv_post<T>(st, pa);
         }
         pa.t_next = Xf;
         {
             ProfScope ps(prof, PS_ROWS_INV_POST_EMIT);
-            launch_rows_inv_post<T>(st, pa);
+            nt = launch_rows_inv_post<T>(st, pa);
         }
         std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
         std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
@@ -1290,6 +1291,14 @@ template <typename T> struct Csc : CscBase {
                              ((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT")))
                                 ? 1
                                 : 0;
+        // Small problems (kernels of a few microseconds): the emitting epilogue always, and its
+        // plain twin is not enqueued at all -- a wasted emit costs less than a launch that
+        // returns at once (SPORCO_AMD_RUN_ALWAYS_EMIT=0/1 overrides the size rule).
+        {
+            const char *e = std::getenv("SPORCO_AMD_RUN_ALWAYS_EMIT");
+            run_always_emit = !in.no_speculation && (e ? std::atoi(e) != 0 : E <= ((int64_t)1 << 22));
+            if (run_always_emit) in.no_speculation = 2;
+        }
         launch_admm_ctl_init(st, ctl_dev, in);
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         const int ahead = c.lookahead > 0 ? c.lookahead : 3;

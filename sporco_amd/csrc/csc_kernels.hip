@@ -2529,7 +2529,9 @@ __device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {
     c->thr21_f = (float)(c->mu21 / c->rho);
     c->u_scale_f = (float)c->u_scale;
     c->stable_run = c->u_scale == 1.0 ? c->stable_run + 1 : 0;
-    c->emit = (c->stable_run >= 2 && !c->no_speculation) ? 1 : 0;
+    // (no_speculation: 0 = emit once rho has been stable for two iterations, 1 = never,
+    // 2 = always -- small problems, where a wasted emit costs less than a launch that returns)
+    c->emit = c->no_speculation == 2 ? 1 : ((c->stable_run >= 2 && !c->no_speculation) ? 1 : 0);
     c->skip_fwd = (c->emitted && c->u_scale == 1.0) ? 1 : 0;
 }
 
