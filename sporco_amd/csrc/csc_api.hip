@@ -361,6 +361,7 @@ template <typename T> struct Csc : CscBase {
     bool pgm_tiled = false, pgm_x_stale = false;
     sporco_amd_pgm_params last_pgm;
     double *part_pgm = nullptr, *part_pgm2 = nullptr;
+    cx<T> *ccmod_r = nullptr;       // K > 64 tiled dictionary-update gradient: the residual per frequency
     cx<T> *pgm_ey = nullptr;        // e_y of a held (backtracking) pgm_iter, tile-major (Wf, CN, H)
     bool pgm_held = false;          // a trial's iterates wait in the spare buffers
     bool run_always_emit = false;   // device-driven solve of a small problem (admm_run)
@@ -479,7 +480,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
-                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)pgm_ey, (void *)gpart,
+                        (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)ccmod_r, (void *)pgm_ey, (void *)gpart,
                         (void *)qpart, (void *)coop_flags, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold, (void *)md_s, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
@@ -2030,7 +2031,10 @@ template <typename T> struct Csc : CscBase {
         zsf_valid = dism_valid = false;
         // (the generic consensus D-step and the single-copy ADMM D-step read Zf in the natural
         // layout)
-        if (rows_ok && fused && !(cns_active && !cns_fused()) && !eq_active) {
+        // (K > 64: the slab forms of the column transform and of the PGM gradient; the ADMM
+        // dictionary updates read Zf in the natural layout there)
+        if (rows_ok && (fused || (fused_slabs && !cns_active)) &&
+            !(cns_active && !cns_fused()) && !eq_active) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;
             ra.y = rv(var);
@@ -2099,6 +2103,13 @@ template <typename T> struct Csc : CscBase {
             ga.K = K;
             ga.G = ccmod_groups;
             ga.partials = part_a;
+            if (K > 64) {
+                // (one row of sums per tile: part_f holds 2 * slabs doubles per tile)
+                if (!ccmod_r) SA_HIP(hipMalloc((void **)&ccmod_r, sizeof(cx<T>) * (int64_t)Wf * CN * H));
+                ga.qpart = qpart;
+                ga.rbuf = ccmod_r;
+                ga.partials = part_f;
+            }
             int64_t nwg;
             {
                 ProfScope ps(prof, PS_PGM);
@@ -2108,7 +2119,7 @@ template <typename T> struct Csc : CscBase {
             }
             const int slots[3] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_HESS};
             const double scales[3] = {0.5, 1.0 / ((double)H * W), 1.0};
-            finalize(part_a, (int)nwg, 4, 3, slots, scales, out_dev);
+            finalize(ga.partials, (int)nwg, 4, 3, slots, scales, out_dev);
             return;
         }
         int nb;

@@ -58,6 +58,10 @@ template <typename T> struct CcmodTiledArgs {
     cx<T> *gpart;        // (G, H, Wf, K), or null: sums only
     int H, W, CN, K, G;
     double *partials;    // per workgroup 4 doubles: |r|^2, pw |r|^2, |r + sf|^2, 0
+    // K > 64 (two passes over zf, one workgroup per (row frequency, group, 64-filter slab)): the
+    // slabs' shares of sum_k zf d, (Wf*CN, slabs, H) complex, and the residual r, (Wf*CN, H)
+    // complex; `partials` then has one row per tile
+    cx<T> *qpart = nullptr, *rbuf = nullptr;
 };
 template <typename T> bool ccmod_tiled_supported(int H, int K);
 // returns the number of workgroups (rows of `partials`)

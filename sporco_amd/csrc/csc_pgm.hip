@@ -339,14 +339,18 @@ __global__ void __launch_bounds__(256) pgm_stats_slabs_kernel(const PgmColsArgs<
 // ---------------------------------------------------------------------------
 // dictionary-update gradient on tile-major coefficient spectra (see csc_pgm.h)
 // ---------------------------------------------------------------------------
-template <int NW, int KC>
+// MODE 0: everything in one pass (K <= 64).  K > 64, one workgroup per 64-filter slab
+// (blockIdx.y): MODE 1 writes the slab's share of sum_k zf d to a.qpart; MODE 2 forms the
+// gradient from the residual in a.rbuf (ccmod_resid_sum_kernel in between).
+template <int NW, int KC, int MODE = 0>
 __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTiledArgs<float> a) {
     constexpr int N1 = 32, H = N1 * NW;
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int K = KC ? KC : a.K;
-    const bool kv = KC == 64 ? true : k < K;
+    const int slab = MODE ? (int)blockIdx.y : 0, NHs = MODE ? (int)gridDim.y : 1;
+    const bool kv = KC == 64 ? true : slab * 64 + k < K;
     const int Wf = a.W / 2 + 1;
     const int g = blockIdx.x % a.G, wf = blockIdx.x / a.G;
     const int cng = (a.CN + a.G - 1) / a.G;
@@ -356,9 +360,9 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
     // rows f = NW i + w of this thread; d(f, wf, k) is re-read per tile (L2-resident)
     const uint32_t dbytes = (uint32_t)((int64_t)H * Wf * K * sizeof(cf));
     const BufRsrc Db = make_rsrc(a.d, dbytes);
-    const int dko = ((w * Wf + wf) * K + k) * (int)sizeof(cf);
+    const int dko = ((w * Wf + wf) * K + slab * 64 + k) * (int)sizeof(cf);
     const int drow = NW * Wf * K * (int)sizeof(cf);   // from row f to row f + NW
-    const int ko = (w * K + k) * (int)sizeof(cf);
+    const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
     cf acc[N1];
 #pragma unroll
     for (int i = 0; i < N1; ++i) acc[i] = zero;
@@ -378,7 +382,7 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * c + e;
                 zn[e] = kv ? buf_load_cf(Zb, kov, NW * i * K * (int)sizeof(cf)) : zero;
-                dn[e] = kv ? buf_load_cf_cached(Db, dkov, i * drow) : zero;
+                dn[e] = (MODE != 2 && kv) ? buf_load_cf_cached(Db, dkov, i * drow) : zero;
             }
         };
         prefetch(std::integral_constant<int, 0>{});
@@ -398,6 +402,22 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
                 }
                 prefetch(std::integral_constant<int, c + 1>{});
             }
+            if constexpr (MODE == 1) {
+                inner4(d, z, k, q);
+                cf *qp = a.qpart + ((int64_t)tile * NHs + slab) * H + w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k == 0) qp[NW * (4 * c + e)] = q[e];
+            } else if constexpr (MODE == 2) {
+                const cf *R = a.rbuf + (int64_t)tile * H + w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * c + e;
+                    cf r;
+                    sa_uload2(reinterpret_cast<const float *>(R + NW * i), r.re, r.im);
+                    acc[i] = acc[i] + cmulc(z[e], r);
+                }
+            } else {
             inner4(d, z, k, q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -409,21 +429,45 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
                 s_q2 += cabs2(q[e]);
                 acc[i] = acc[i] + cmulc(z[e], r);
             }
+            }
         });
         {
             float &dep = acc[N1 - 1].re;
             SA_VGPR_FENCE3(dep, kov, token);
         }
     }
-    if (a.gpart && kv) {
+    if (MODE != 1 && a.gpart && kv) {
         cf *gp = a.gpart + (int64_t)g * H * Wf * K;
 #pragma unroll
-        for (int i = 0; i < N1; ++i) gp[((int64_t)(NW * i + w) * Wf + wf) * K + k] = acc[i];
+        for (int i = 0; i < N1; ++i) gp[((int64_t)(NW * i + w) * Wf + wf) * K + slab * 64 + k] = acc[i];
+    }
+    if constexpr (MODE == 0) {
+        const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+        double accd[4] = {k == 0 ? (double)s_r2 : 0.0, k == 0 ? (double)s_r2 * pw : 0.0,
+                          k == 0 ? (double)s_q2 : 0.0, 0.0};
+        block_sum_store<4>(accd, scratch, a.partials + (int64_t)blockIdx.x * 4);
+    }
+}
+
+// K > 64, between the two passes: r = sum_slab qpart - sf per frequency of a tile, and the sums
+// of the one-pass kernel per tile
+__global__ void __launch_bounds__(256) ccmod_resid_sum_kernel(const CcmodTiledArgs<float> a, int NH) {
+    const int tile = blockIdx.x, Wf = a.W / 2 + 1, wf = tile / a.CN;
+    const cf *qp = a.qpart + (int64_t)tile * NH * a.H;
+    const cf *S = a.sft + (int64_t)tile * a.H;
+    cf *R = a.rbuf + (int64_t)tile * a.H;
+    double r2 = 0.0, q2 = 0.0;
+    for (int f = threadIdx.x; f < a.H; f += blockDim.x) {
+        cf q = mk<float>(0.f, 0.f);
+        for (int sl = 0; sl < NH; ++sl) q = q + qp[(int64_t)sl * a.H + f];
+        const cf r = q - S[f];
+        R[f] = r;
+        r2 += (double)cabs2(r);
+        q2 += (double)cabs2(q);
     }
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
-    double accd[4] = {k == 0 ? (double)s_r2 : 0.0, k == 0 ? (double)s_r2 * pw : 0.0,
-                      k == 0 ? (double)s_q2 : 0.0, 0.0};
-    block_sum_store<4>(accd, scratch, a.partials + (int64_t)blockIdx.x * 4);
+    double accd[4] = {r2, r2 * pw, q2, 0.0};
+    block_sum_store<4>(accd, dyn_lds<double>(), a.partials + (int64_t)tile * 4);
 }
 
 __global__ void __launch_bounds__(256) sum_groups_kernel(const cf *__restrict__ part,
@@ -519,12 +563,13 @@ template <int NW, int LP, int KC> static void launch_plain(hipStream_t st, const
         attr_set = true;
     }
     const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
-    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, false, true>), dim3(grid), dim3(NW * 64),
-                       pgm_lds_bytes(NW, LP), st, a);
+    const unsigned slabs = KC ? 1u : (unsigned)ceil_div(a.K, 64);      // (K > 64: per 64-filter slab)
+    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, false, true>), dim3(grid, slabs),
+                       dim3(NW * 64), pgm_lds_bytes(NW, LP), st, a);
 }
 
 template <> int64_t launch_cols_fft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
-    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
+    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
                "shape not handled by the fused column kernels");
     if (a.H == 256) {
         if (a.K == 64) launch_plain<8, 2, 64>(st, a);
@@ -541,7 +586,7 @@ template <> int64_t launch_cols_fft<double>(hipStream_t, const PgmColsArgs<doubl
 }
 
 template <> bool ccmod_tiled_supported<float>(int H, int K) {
-    return (H == 256 || H == 512) && K >= 1 && K <= 64;
+    return (H == 256 || H == 512) && K >= 1 && K <= 256;
 }
 template <> bool ccmod_tiled_supported<double>(int, int) { return false; }
 
@@ -549,6 +594,23 @@ template <> int64_t launch_ccmod_grad_tiled<float>(hipStream_t st, const CcmodTi
     SA_REQUIRE(ccmod_tiled_supported<float>(a.H, a.K), "shape not handled by the tiled D-step kernel");
     const unsigned grid = (unsigned)((a.W / 2 + 1) * a.G);
     const size_t lds = sizeof(double) * 4 * 16;
+    if (a.K > 64) {
+        // two passes over zf: the slabs' shares of sum_k zf d, the residual per frequency, then
+        // (when a gradient is wanted) conj(zf) r per slab
+        SA_REQUIRE(a.qpart && a.rbuf, "the K > 64 tiled D-step needs its exchange buffers");
+        const dim3 g2(grid, (unsigned)ceil_div(a.K, 64));
+        const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
+        if (a.H == 256) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0, 1>), g2, dim3(512), lds, st, a);
+        else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 0, 1>), g2, dim3(1024), lds, st, a);
+        hipLaunchKernelGGL(ccmod_resid_sum_kernel, dim3((unsigned)ntiles), dim3(256), lds, st, a,
+                           (int)g2.y);
+        if (a.gpart) {
+            if (a.H == 256) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0, 2>), g2, dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 0, 2>), g2, dim3(1024), lds, st, a);
+        }
+        SA_HIP(hipGetLastError());
+        return ntiles;
+    }
     if (a.H == 256) {
         if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 64>), dim3(grid), dim3(512), lds, st, a);
         else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0>), dim3(grid), dim3(512), lds, st, a);

@@ -123,13 +123,17 @@ def test_dictlearn_variants_run(backend):
 
 # ---------------------------------------------------------------------------
 # the tile-major D-step (csc_pgm.hip: register-resident setcoef + grouped gradient),
-# engaged for float32, H and W in {256, 512}, even K <= 64
+# engaged for float32, H and W in {256, 512}, even K <= 256
 # ---------------------------------------------------------------------------
-def test_tiled_dstep_one_fista_step(backend):
-    """One ConvCnstrMOD iteration against its NumPy restatement (pgm/ccmod.py:295-323)."""
+@pytest.mark.parametrize('K', [4, 66, pytest.param(128, marks=pytest.mark.gpu),
+                               pytest.param(70, marks=pytest.mark.gpu)])
+def test_tiled_dstep_one_fista_step(backend, K):
+    """One ConvCnstrMOD iteration against its NumPy restatement (pgm/ccmod.py:295-323).
+    K > 64: the column transform of setcoef and the gradient run per 64-filter slab (two passes
+    over the coefficient spectrum)."""
     from oracle import cbpdn_oracle as orc
     from sporco_amd.pgm import ccmod
-    H, W, K, N = 256, 256, 4, 2
+    H, W, N = 256, 256, 2
     rng = np.random.RandomState(21)
     Z = (rng.randn(H, W, 1, N, K) * (rng.rand(H, W, 1, N, K) < 0.05)).astype(np.float32)
     S = rng.randn(H, W, N).astype(np.float32)
