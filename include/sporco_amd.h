@@ -122,11 +122,11 @@ int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels,
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
 int sporco_amd_csc_sync(sporco_amd_csc_t h);
 /* Which kernels serve this handle's shape: *out = 1 when the fused path named by
- * `what` is active (float32, H and/or W in {256, 512}, even K <= 64 -- or K = 128,
- * 192, 256 for the ADMM column pass, which then runs as two kernels), else 0. */
+ * `what` is active (float32, H and/or W in {128, 256, 512}, even K <= 64 -- or even
+ * 64 < K <= 256, where the column pass runs as cooperating 64-filter slab workgroups), else 0. */
 #define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
 #define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
-#define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step (K <= 64) */
+#define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step (H in {256, 512}) */
 #define SPORCO_AMD_QUERY_DEVICE_FILTERS 3 /* filter count of the device-resident arrays: K, or
                                             K + 1 when an odd K was padded with one all-zero
                                             filter to reach the fused kernels (host arrays

@@ -294,7 +294,7 @@ template <typename T> struct Csc : CscBase {
     T *gramz_t = nullptr;      // its fused path: sum_k |Zf|^2 per row of the tile-major Zf
     bool gramz_valid = false;
     bool cns_fused() const {
-        return rows_ok && fused && !std::getenv("SPORCO_AMD_CNS_GENERIC");
+        return rows_ok && fused && cols256 && !std::getenv("SPORCO_AMD_CNS_GENERIC");
     }
     bool ism_valid = false;
     double ism_rho = 0.0;
@@ -320,6 +320,8 @@ template <typename T> struct Csc : CscBase {
     // fused X-step (csc_fused.h): tile-major copies of Df, Sf, gram, its twiddles and
     // per-tile partials; xf_tiled marks VAR_XF as holding a tile-major intermediate
     bool fused = false, xf_tiled = false;
+    bool cols256 = false;           // H in {256, 512}: the FISTA, dictionary-update and per-tile
+                                    // (consensus) column kernels exist for it (H = 128: ADMM only)
     bool fused_slabs = false;       // K = 64*NH: column pass as two slab kernels (csc_fused.h)
     cx<T> *qpart = nullptr;
     unsigned *coop_flags = nullptr;     // cooperating slab workgroups (csc_fused.h): per (tile, slab)
@@ -420,6 +422,7 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CNs));
         fused = Cd == 1 && fused_cols_supported<T>(H, K) && K % 2 == 0 &&
                 !std::getenv("SPORCO_AMD_UNFUSED");
+        cols256 = H == 256 || H == 512;
         fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
         fused_mc = Cd > 1 && fused_mc_supported<T>(H, K, Cd) && K % 2 == 0 &&
                    !std::getenv("SPORCO_AMD_UNFUSED");
@@ -550,7 +553,7 @@ template <typename T> struct Csc : CscBase {
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
-        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && (fused || fused_slabs)) ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && cols256 && (fused || fused_slabs)) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
@@ -1761,7 +1764,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
         require_single_channel_dict();
         require_ready();
-        if (!(rows_ok && (fused || fused_slabs)))
+        if (!(rows_ok && cols256 && (fused || fused_slabs)))
             throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
         t_ready = false;
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
@@ -2033,7 +2036,7 @@ template <typename T> struct Csc : CscBase {
         // layout)
         // (K > 64: the slab forms of the column transform and of the PGM gradient; the ADMM
         // dictionary updates read Zf in the natural layout there)
-        if (rows_ok && (fused || (fused_slabs && !cns_active)) &&
+        if (rows_ok && cols256 && (fused || (fused_slabs && !cns_active)) &&
             !(cns_active && !cns_fused()) && !eq_active) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;

@@ -981,6 +981,7 @@ struct FusedSplit {
 };
 static FusedSplit fused_split(int H, int K) {
     (void)K;
+    if (H == 128) return {32, 4, 4};
     if (H == 256) return {32, 8, 2};
     return {32, 16, 1};
 }
@@ -1006,7 +1007,7 @@ template void fused_twiddles<float>(int, int, cx<float> *, cx<float> *);
 template void fused_twiddles<double>(int, int, cx<double> *, cx<double> *);
 
 template <> bool fused_cols_supported<float>(int H, int K) {
-    return (H == 256 || H == 512) && K >= 1 && K <= 64;
+    return (H == 128 || H == 256 || H == 512) && K >= 1 && K <= 64;
 }
 template <> bool fused_cols_supported<double>(int, int) { return false; }
 
@@ -1085,7 +1086,9 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     // measured 1.13 -> 1.06 ms at 512 x 512, K = 64, N = 32 (profiles/r02_fused_cols_notes.md)
     a.stagger_groups = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? (sg > 0 ? sg : 1) : 4;
     a.stagger_sleeps = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? ss : 2;
-    if (sp.NW == 8)
+    if (sp.NW == 4)
+        launch_fused_k<32, 4, 4>(st, a, ntiles);
+    else if (sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);
     else
         launch_fused_k<32, 16, 1>(st, a, ntiles);

@@ -42,21 +42,36 @@ constexpr size_t rows_lds_bytes(int NW) {
     return sizeof(f2) * 16 * NW * 64 + sizeof(double) * 8 * 16;
 }
 
-// line k1 held in slot j of spectral-side wave w (see the file header)
-__device__ __forceinline__ int line_of(int w, int j) {
+// line k1 held in slot j of spectral-side wave w (see the file header): slots (2 m, 2 m + 1) hold
+// a pair {k1, 32 - k1} (wave 0, m = 0: the self-paired lines 0 and 16).  NW = 4 (W = 128) has
+// eight slots per wave: the four of the other splits, then {4 + w, 28 - w} and {9 + w, 23 - w}.
+template <int NW> __device__ __forceinline__ int line_of(int w, int j) {
     if (j == 0) return w;
     if (j == 1) return w == 0 ? 16 : 32 - w;
     if (j == 2) return w == 0 ? 8 : 16 - w;
-    return w == 0 ? 24 : 16 + w;
+    if (j == 3) return w == 0 ? 24 : 16 + w;
+    if (j == 4) return 4 + w;
+    if (j == 5) return 28 - w;
+    if (j == 6) return 9 + w;
+    return 23 - w;
 }
 
-// The exchange moves 16 lines at a time (64 KiB for NW = 8, 128 KiB for NW = 16):
-// group_of / kl_of give the half a line travels in and its slot there.  Each
-// half holds whole {k1, 32 - k1} pairs, i.e. slots (0, 1) or (2, 3) of a wave.
+// The exchange moves 16 lines at a time (32 KiB for NW = 4, 64 KiB for NW = 8, 128 KiB for
+// NW = 16): group_of / kl_of give the half a line travels in and its slot there.  Each half
+// holds whole {k1, 32 - k1} pairs: the first half of a wave's slots, or the second.
+__host__ __device__ constexpr bool first_half4(int k1) {
+    return k1 < 4 || k1 == 8 || (k1 >= 13 && k1 <= 19) || k1 == 24 || k1 > 28;
+}
 __host__ __device__ constexpr int group_of(int NW, int k1) {
+    if (NW == 4) return first_half4(k1) ? 0 : 1;
     return NW == 16 ? (k1 >> 4) : ((k1 < 8 || k1 == 16 || k1 > 24) ? 0 : 1);
 }
 __host__ __device__ constexpr int kl_of(int NW, int k1) {
+    if (NW == 4) {       // rank of the line among the 16 of its half
+        int r = 0;
+        for (int o = 0; o < k1; ++o) r += first_half4(o) == first_half4(k1) ? 1 : 0;
+        return r;
+    }
     if (NW == 16) return k1 & 15;
     if (group_of(NW, k1) == 0) return k1 < 8 ? k1 : (k1 == 16 ? 8 : k1 - 16);
     return k1 < 16 ? k1 - 8 : k1 - 9;
@@ -89,7 +104,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
     }
     reg_fence<N1>(v, 0, token);
 
-    // ---- exchange to the spectral side: z[NW j + n2] = C[line_of(w, j)][n2] ------------
+    // ---- exchange to the spectral side: z[NW j + n2] = C[line_of<NW>(w, j)][n2] ------------
     cf z[N1];
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
@@ -106,7 +121,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 #pragma unroll
         for (int jl = 0; jl < LPG; ++jl) {
             const int j = g * LPG + jl;
-            const int kl = kl_of(NW, line_of(w, j));
+            const int kl = kl_of(NW, line_of<NW>(w, j));
 #pragma unroll
             for (int n2 = 0; n2 < NW; ++n2) {
                 const f2 t = L[(kl * NW + n2) * 64 + lane];
@@ -136,7 +151,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 #pragma unroll
     for (int pr = 0; pr < J / 2; ++pr) {
         const int ja = 2 * pr, jb = 2 * pr + 1;
-        const int k1a = line_of(w, ja), k1b = line_of(w, jb);
+        const int k1a = line_of<NW>(w, ja), k1b = line_of<NW>(w, jb);
         if (pr == 0 && w == 0) {
             // self-paired lines 0 and 16: f and W - f sit in the same line
 #pragma unroll
@@ -191,11 +206,11 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
         }
         return ab;
     };
-    cf z[N1];   // z[NW j + i] = Z[line_of(w, j) + 32 brev(i)]
+    cf z[N1];   // z[NW j + i] = Z[line_of<NW>(w, j) + 32 brev(i)]
 #pragma unroll
     for (int pr = 0; pr < J / 2; ++pr) {
         const int ja = 2 * pr, jb = 2 * pr + 1;
-        const int k1a = line_of(w, ja), k1b = line_of(w, jb);
+        const int k1a = line_of<NW>(w, ja), k1b = line_of<NW>(w, jb);
         if (pr == 0 && w == 0) {
 #pragma unroll
             for (int k2 = 0; k2 <= NW / 2; ++k2) {
@@ -234,7 +249,7 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 #pragma unroll
         for (int jl = 0; jl < LPG; ++jl) {
             const int j = g * LPG + jl;
-            const int k1 = line_of(w, j);
+            const int k1 = line_of<NW>(w, j);
             const int kl = kl_of(NW, k1);
             dit<NW, true>(z, NW * j);
 #pragma unroll
@@ -636,7 +651,7 @@ void set_lds_attr(K kernel) {
 }  // namespace
 
 template <> bool rows_supported<float>(int W, int K) {
-    return (W == 256 || W == 512) && K >= 2 && K % 2 == 0;
+    return (W == 128 || W == 256 || W == 512) && K >= 2 && K % 2 == 0;
 }
 template <> bool rows_supported<double>(int, int) { return false; }
 
@@ -666,7 +681,7 @@ static int64_t rows_persistent_grid(int NW) {
         const char *e = std::getenv("SPORCO_AMD_ROWS_PERSIST");
         off = e && e[0] == '0';
     }
-    return off ? 0 : (int64_t)cus * (NW == 16 ? 1 : 2);
+    return off ? 0 : (int64_t)cus * (NW == 16 ? 1 : NW == 8 ? 2 : 4);
 }
 // want: 1 = persistent unless disabled; 0 = one workgroup per tile (SPORCO_AMD_ROWS_PERSIST=2
 // forces the loop form on every row kernel, for measurements)
@@ -693,15 +708,20 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     static bool attr_set = false;
     if (!attr_set) {
+        set_lds_attr<4>(&rows_fwd_kernel<4, false>);
         set_lds_attr<8>(&rows_fwd_kernel<8, false>);
         set_lds_attr<16>(&rows_fwd_kernel<16, false>);
+        set_lds_attr<4>(&rows_fwd_kernel<4, true>);
         set_lds_attr<8>(&rows_fwd_kernel<8, true>);
         set_lds_attr<16>(&rows_fwd_kernel<16, true>);
         attr_set = true;
     }
     // (measured at config 2: the tile loop gains nothing for this kernel)
     const dim3 grid = rows_grid(a, a.W / kN1, ceil_div(a.P, 128), a.H, 0);
-    if (a.W == 256) {
+    if (a.W == 128) {
+        if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<4, true>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
+        else hipLaunchKernelGGL((rows_fwd_kernel<4, false>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
+    } else if (a.W == 256) {
         if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<8, true>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
         else hipLaunchKernelGGL((rows_fwd_kernel<8, false>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
     } else {
@@ -810,7 +830,10 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
                    "configuration not handled by the joint row epilogue");
         const int64_t jtx = (int64_t)a.N * (a.K / 32);
         const dim3 jgrid = rows_grid(a, a.W / kN1, jtx, a.H, a.t_next != nullptr);
-        if (a.W == 256) {
+        if (a.W == 128) {
+            if (a.t_next) launch_post_joint_nw<4, true>(st, a, jgrid);
+            else launch_post_joint_nw<4, false>(st, a, jgrid);
+        } else if (a.W == 256) {
             if (a.t_next) launch_post_joint_nw<8, true>(st, a, jgrid);
             else launch_post_joint_nw<8, false>(st, a, jgrid);
         } else {
@@ -824,7 +847,10 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
     // persistent for the emitting variant (2.39 -> 2.21 ms at config 2: a tile's spectrum stores
     // drain under the next tile's loads); the plain epilogue is faster one tile per workgroup
     const dim3 grid = rows_grid(a, a.W / kN1, tx, a.H, a.t_next != nullptr);
-    if (a.W == 256) {
+    if (a.W == 128) {
+        if (a.t_next) launch_post_nw<4, true>(st, a, grid);
+        else launch_post_nw<4, false>(st, a, grid);
+    } else if (a.W == 256) {
         if (a.t_next) launch_post_nw<8, true>(st, a, grid);
         else launch_post_nw<8, false>(st, a, grid);
     } else {
@@ -857,7 +883,9 @@ template <> int64_t launch_rows_inv_prox_fwd<float>(hipStream_t st, const RowsPr
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
-    if (a.W == 256)
+    if (a.W == 128)
+        launch_prox_nw<4>(st, a, grid);
+    else if (a.W == 256)
         launch_prox_nw<8>(st, a, grid);
     else
         launch_prox_nw<16>(st, a, grid);

@@ -2,7 +2,7 @@
 registers, tile-major intermediates) against (a) the NumPy oracle and (b) the
 unfused kernel chain of the same library.
 
-The fused path engages for float32, H in {256, 512}, even K <= 64; the widths
+The fused path engages for float32, H in {128, 256, 512}, even K <= 64; the widths
 are kept tiny so that the CPU fiber simulator finishes in seconds (the row
 kernels are size-generic, so W does not matter to the code under test).
 
@@ -157,7 +157,12 @@ def test_fused_fixed_rho_fastsolve_and_setdict(backend):
 # ---------------------------------------------------------------------------
 # the three-launch iteration (csc_rows.hip + csc_fused.hip): H and W in {256, 512}
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1)])
+@pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1),
+                                     # 128 in either direction (32 x 4 splits, round 2)
+                                     (128, 128, 4, 1), (128, 256, 6, 2), (256, 128, 4, 1),
+                                     pytest.param(128, 512, 64, 2, marks=pytest.mark.gpu),
+                                     pytest.param(512, 128, 64, 2, marks=pytest.mark.gpu),
+                                     pytest.param(128, 128, 64, 8, marks=pytest.mark.gpu)])
 def test_three_launch_iteration_matches_oracle(backend, H, W, K, N):
     from oracle import cbpdn_oracle as orc
     D, S = problem(H, W, K, N, seed=H + W + K)
@@ -199,6 +204,46 @@ def test_three_launch_weights_nonneg_nobndry(backend):
     assert np.all(Y >= 0) and np.all(Y[-3:] == 0) and np.all(Y[:, -3:] == 0)
     for f in ('ObjFun', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(getattr(b.getitstat(), f), getattr(b0.getitstat(), f)) < 1e-5, f
+
+
+def test_size_128_options_joint_gradreg_and_many_iterations(backend):
+    """H = W = 128 through the option-dependent kernel variants: the GENERAL epilogue (L1Weight
+    array, NonNegCoef, NoBndryCross), the l2,1 epilogue (ConvBPDNJoint), the gradient-regularised
+    column kernel, and 30 default-option iterations (rho changes, then the emitting epilogue)
+    against the float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    H, W, K, N = 128, 128, 4, 2
+    D, S = problem(H, W, K, N, seed=5)
+    rng = np.random.RandomState(3)
+    wl1 = (0.5 + rng.rand(H, W, 1, 1, K)).astype(np.float32)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'NonNegCoef': True, 'NoBndryCross': True,
+            'L1Weight': wl1}
+    b, Y = solve(D, S, optd)
+    b0, Y0 = solve(D, S, optd, unfused=True)
+    assert b._dev.uses_fused_rows() and not b0._dev.uses_fused_rows()
+    assert rel_l2(Y, Y0) < 1e-5 and np.all(Y >= 0) and np.all(Y[-3:] == 0) and np.all(Y[:, -3:] == 0)
+    # 30 iterations, default options
+    optd = {'MaxMainIter': 30, 'RelStopTol': 0.0}
+    b, Y = solve(D, S, optd)
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05,
+                         dtype=np.float64, maxiter=30, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 1e-4
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(b.getitstat(), f), ref[f]) < 1e-3, f
+    # ConvBPDNJoint, C = 3, K = 32 (the joint epilogue needs K % 32 == 0)
+    Dj, Sj = problem(H, W, 32, 1, seed=7, C=3)
+    bj, Yj = solve(Dj, Sj, {'MaxMainIter': 3, 'RelStopTol': 0.0}, joint=True)
+    refj = orc.admm_cbpdn(Dj.reshape(4, 4, 1, 1, 32), Sj.reshape(H, W, 3, 1, 1), 0.05, mu=0.02,
+                          dtype=np.float64, maxiter=3, rel_tol=0.0)
+    assert bj._dev.uses_fused_rows() and rel_l2(Yj, refj['Y']) < 1e-5
+    # ConvBPDNGradReg
+    bg = cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.3, cbpdn.ConvBPDNGradReg.Options(
+        {'MaxMainIter': 3, 'RelStopTol': 0.0}))
+    Yg = bg.solve()
+    refg = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, grad_mu=0.3,
+                          dtype=np.float64, maxiter=3, rel_tol=0.0)
+    assert bg._dev.uses_fused_rows() and rel_l2(Yg, refg['Y']) < 1e-5
 
 
 def test_no_x_hint_and_pickle(backend):
