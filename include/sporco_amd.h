@@ -126,7 +126,7 @@ int sporco_amd_csc_sync(sporco_amd_csc_t h);
  * 64 < K <= 256, where the column pass runs as cooperating 64-filter slab workgroups), else 0. */
 #define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
 #define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
-#define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step (H in {256, 512}) */
+#define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step               */
 #define SPORCO_AMD_QUERY_DEVICE_FILTERS 3 /* filter count of the device-resident arrays: K, or
                                             K + 1 when an odd K was padded with one all-zero
                                             filter to reach the fused kernels (host arrays

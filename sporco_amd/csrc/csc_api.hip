@@ -422,7 +422,7 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CNs));
         fused = Cd == 1 && fused_cols_supported<T>(H, K) && K % 2 == 0 &&
                 !std::getenv("SPORCO_AMD_UNFUSED");
-        cols256 = H == 256 || H == 512;
+        cols256 = H == 128 || H == 256 || H == 512;   // (every column kernel family has the 32 x 4 split)
         fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
         fused_mc = Cd > 1 && fused_mc_supported<T>(H, K, Cd) && K % 2 == 0 &&
                    !std::getenv("SPORCO_AMD_UNFUSED");

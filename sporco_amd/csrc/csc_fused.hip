@@ -1211,7 +1211,7 @@ template <> void launch_tail_update<double>(hipStream_t, const FusedColsArgs<dou
 }
 
 template <> bool fused_slabs_supported<float>(int H, int K) {
-    return (H == 256 || H == 512) && K > 64 && K <= 256 && K % 2 == 0;
+    return (H == 128 || H == 256 || H == 512) && K > 64 && K <= 256 && K % 2 == 0;
 }
 template <> bool fused_slabs_supported<double>(int, int) { return false; }
 
@@ -1276,7 +1276,10 @@ template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlab
     a.c.stagger_groups = sg > 0 ? sg : 1;
     a.c.stagger_sleeps = ss;
     const bool g = a.c.g1t != nullptr;
-    if (a.c.H == 256) {
+    if (a.c.H == 128) {
+        if (a.c.K == 128) { if (g) launch_slab_coop<4, 4, 128, true>(st, a); else launch_slab_coop<4, 4, 128, false>(st, a); }
+        else { if (g) launch_slab_coop<4, 4, 0, true>(st, a); else launch_slab_coop<4, 4, 0, false>(st, a); }
+    } else if (a.c.H == 256) {
         if (a.c.K == 128) { if (g) launch_slab_coop<8, 2, 128, true>(st, a); else launch_slab_coop<8, 2, 128, false>(st, a); }
         else { if (g) launch_slab_coop<8, 2, 0, true>(st, a); else launch_slab_coop<8, 2, 0, false>(st, a); }
     } else {
@@ -1319,7 +1322,10 @@ template <> int64_t launch_pgm_grad_slabs<float>(hipStream_t st, const FusedSlab
     FusedSlabArgs<float> a = a_in;
     a.c.stagger_groups = 1;
     a.c.stagger_sleeps = 0;
-    if (a.c.H == 256) {
+    if (a.c.H == 128) {
+        if (a.c.K == 128) launch_pgm_grad_coop<4, 4, 128>(st, a);
+        else launch_pgm_grad_coop<4, 4, 0>(st, a);
+    } else if (a.c.H == 256) {
         if (a.c.K == 128) launch_pgm_grad_coop<8, 2, 128>(st, a);
         else launch_pgm_grad_coop<8, 2, 0>(st, a);
     } else {
@@ -1343,7 +1349,10 @@ static void launch_slabs_g(hipStream_t st, const FusedSlabArgs<float> &a, bool s
 
 static void launch_slabs_any(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
     SA_REQUIRE(fused_slabs_supported<float>(a.c.H, a.c.K), "shape not handled by the slab column kernels");
-    if (a.c.H == 256) {
+    if (a.c.H == 128) {
+        if (a.c.K == 128) launch_slabs_g<4, 4, 128>(st, a, second);
+        else launch_slabs_g<4, 4, 0>(st, a, second);
+    } else if (a.c.H == 256) {
         if (a.c.K == 128) launch_slabs_g<8, 2, 128>(st, a, second);
         else launch_slabs_g<8, 2, 0>(st, a, second);
     } else {

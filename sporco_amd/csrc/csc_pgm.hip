@@ -512,9 +512,12 @@ void launch_mom(hipStream_t st, const PgmColsArgs<float> &a) {
 }  // namespace
 
 template <> int64_t launch_pgm_grad_ifft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
-    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
+    SA_REQUIRE((a.H == 128 || a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
                "shape not handled by the fused PGM kernels");
-    if (a.H == 256) {
+    if (a.H == 128) {
+        if (a.K == 64) launch_grad<4, 4, 64>(st, a);
+        else launch_grad<4, 4, 0>(st, a);
+    } else if (a.H == 256) {
         if (a.K == 64) launch_grad<8, 2, 64>(st, a);
         else launch_grad<8, 2, 0>(st, a);
     } else {
@@ -537,11 +540,15 @@ template <> int64_t launch_pgm_stats_slabs<double>(hipStream_t, const PgmColsArg
     throw Error(-1, "the fused FISTA kernels are float32 only");
 }
 template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmColsArgs<float> &a) {
-    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
+    SA_REQUIRE((a.H == 128 || a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
                "shape not handled by the fused PGM kernels");
     SA_REQUIRE(a.K <= 64 || !a.want_stats || a.qpart, "K > 64 with statistics needs qpart");
     const bool k64 = a.K == 64, st8 = a.H == 256, stats = a.want_stats != 0;
-    if (a.ey) {      // a backtracking trial
+    if (a.H == 128) {
+        if (a.ey) { if (k64) launch_mom<4, 4, 64, true, true>(st, a); else launch_mom<4, 4, 0, true, true>(st, a); }
+        else if (k64) { if (stats) launch_mom<4, 4, 64, true>(st, a); else launch_mom<4, 4, 64, false>(st, a); }
+        else { if (stats) launch_mom<4, 4, 0, true>(st, a); else launch_mom<4, 4, 0, false>(st, a); }
+    } else if (a.ey) {      // a backtracking trial
         SA_REQUIRE(stats, "the backtracking sums need want_stats");
         if (st8) { if (k64) launch_mom<8, 2, 64, true, true>(st, a); else launch_mom<8, 2, 0, true, true>(st, a); }
         else { if (k64) launch_mom<16, 1, 64, true, true>(st, a); else launch_mom<16, 1, 0, true, true>(st, a); }
@@ -569,9 +576,12 @@ template <int NW, int LP, int KC> static void launch_plain(hipStream_t st, const
 }
 
 template <> int64_t launch_cols_fft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
-    SA_REQUIRE((a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
+    SA_REQUIRE((a.H == 128 || a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
                "shape not handled by the fused column kernels");
-    if (a.H == 256) {
+    if (a.H == 128) {
+        if (a.K == 64) launch_plain<4, 4, 64>(st, a);
+        else launch_plain<4, 4, 0>(st, a);
+    } else if (a.H == 256) {
         if (a.K == 64) launch_plain<8, 2, 64>(st, a);
         else launch_plain<8, 2, 0>(st, a);
     } else {
@@ -586,7 +596,7 @@ template <> int64_t launch_cols_fft<double>(hipStream_t, const PgmColsArgs<doubl
 }
 
 template <> bool ccmod_tiled_supported<float>(int H, int K) {
-    return (H == 256 || H == 512) && K >= 1 && K <= 256;
+    return (H == 128 || H == 256 || H == 512) && K >= 1 && K <= 256;
 }
 template <> bool ccmod_tiled_supported<double>(int, int) { return false; }
 
@@ -600,18 +610,23 @@ template <> int64_t launch_ccmod_grad_tiled<float>(hipStream_t st, const CcmodTi
         SA_REQUIRE(a.qpart && a.rbuf, "the K > 64 tiled D-step needs its exchange buffers");
         const dim3 g2(grid, (unsigned)ceil_div(a.K, 64));
         const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
-        if (a.H == 256) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0, 1>), g2, dim3(512), lds, st, a);
+        if (a.H == 128) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<4, 0, 1>), g2, dim3(256), lds, st, a);
+        else if (a.H == 256) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0, 1>), g2, dim3(512), lds, st, a);
         else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 0, 1>), g2, dim3(1024), lds, st, a);
         hipLaunchKernelGGL(ccmod_resid_sum_kernel, dim3((unsigned)ntiles), dim3(256), lds, st, a,
                            (int)g2.y);
         if (a.gpart) {
-            if (a.H == 256) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0, 2>), g2, dim3(512), lds, st, a);
+            if (a.H == 128) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<4, 0, 2>), g2, dim3(256), lds, st, a);
+            else if (a.H == 256) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0, 2>), g2, dim3(512), lds, st, a);
             else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 0, 2>), g2, dim3(1024), lds, st, a);
         }
         SA_HIP(hipGetLastError());
         return ntiles;
     }
-    if (a.H == 256) {
+    if (a.H == 128) {
+        if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<4, 64>), dim3(grid), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<4, 0>), dim3(grid), dim3(256), lds, st, a);
+    } else if (a.H == 256) {
         if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 64>), dim3(grid), dim3(512), lds, st, a);
         else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0>), dim3(grid), dim3(512), lds, st, a);
     } else {

@@ -158,6 +158,31 @@ def test_tiled_dstep_one_fista_step(backend, K):
     assert rel_l2(c.Zf, Zf) < 1e-5
 
 
+@pytest.mark.parametrize('dmethod', ['pgm', 'cns'])
+def test_dictlearn_at_128_fused_vs_generic(backend, dmethod):
+    """128 x 128 images: the register-resident kernels of both steps (32 x 4 splits) against the
+    generic kernel chain of the same library."""
+    import os
+    from sporco_amd.dictlrn import cbpdndl
+    rng = np.random.RandomState(1)
+    D0 = rng.randn(4, 4, 4).astype(np.float32)
+    S = rng.randn(128, 128, 2).astype(np.float32)
+    out = []
+    for generic in (False, True):
+        if generic:
+            os.environ['SPORCO_AMD_UNFUSED'] = '1'
+        try:
+            opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 4}, xmethod='admm', dmethod=dmethod)
+            d = cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod=dmethod)
+        finally:
+            os.environ.pop('SPORCO_AMD_UNFUSED', None)
+        assert bool(d.xstep._dev.uses_fused_rows()) == (not generic)
+        out.append((d.solve().copy(), d.getitstat()))
+    assert rel_l2(out[0][0], out[1][0]) < 1e-5
+    for f in ('ObjFun', 'DFid', 'RegL1'):
+        assert rel_l2(getattr(out[0][1], f), getattr(out[1][1], f)) < 1e-5, f
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('K', [8, 7])
 def test_dictlearn_fused_vs_generic(gpu_backend, K):

@@ -32,6 +32,7 @@ def make(D, S, optd, generic=False):
 
 @pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1),
                                      (256, 128, 4, 2),      # W = 128: the 32 x 4 row kernels
+                                     (128, 128, 4, 2),      # H = 128: the 32 x 4 column kernels
                                      pytest.param(256, 256, 5, 2, marks=pytest.mark.gpu),
                                      # K > 64: cooperating slab workgroups in the gradient step,
                                      # per-slab momentum kernels + the slab statistics kernel

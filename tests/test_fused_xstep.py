@@ -367,6 +367,7 @@ def test_state_machine_random_walk(gpu_backend, seed):
 # K = 64 * NH filters: the column pass runs as two kernels over 64-filter slabs
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize('H,W,K,N,C', [(256, 256, 128, 1, None),
+                                       (128, 128, 128, 1, None),
                                        # 64 < K <= 72: one column kernel on the first 64
                                        # filters, the tail through the generic column FFT
                                        (256, 256, 70, 1, None),
