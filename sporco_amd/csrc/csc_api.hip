@@ -2946,6 +2946,36 @@ template <typename T> struct Csc : CscBase {
                     const int ahead = 2;
                     // <r, r> of the first iteration; later ones come out of the update kernel
                     const int nba = launch_pair_stats<T>(st, r, nullptr, nullptr, npix, K, W, part_a);
+                    static const bool self_serve = !(std::getenv("SPORCO_AMD_CG_SELF") &&
+                                                     std::atoi(std::getenv("SPORCO_AMD_CG_SELF")) == 0);
+                    if (self_serve) {
+                        // Two launches per iteration: every workgroup of the operator sums the
+                        // residual partials itself (stopping test, beta), every workgroup of the
+                        // update the <p, q> partials (alpha); workgroup 0 keeps the records
+                        // (csc_kernels.h CgSelf).
+                        CgSelf so, su;
+                        so.c = su.c = cg_dev;
+                        so.pin = su.pin = cg_pin;
+                        so.cgout = su.cgout = cgout;
+                        int nb_rr = nba;
+                        for (int enq = 0; enq <= p.cg_maxiter; ++enq) {
+                            so.prev = part_a;
+                            so.prev_nb = nb_rr;
+                            so.iter = enq;
+                            const int nbb = launch_cg_op<T>(st, cg_dev, true, cv(SPORCO_AMD_VAR_ZF), r, pv,
+                                                            q, rho, npix, CN, K, part_b, so);
+                            su.prev = part_b;
+                            su.prev_nb = nbb;
+                            su.iter = enq;
+                            nb_rr = launch_cg_update_xr<T>(st, cg_dev, T(0), Xf, r, pv, q, nd, part_a, su);
+                            while (!cg_pin->done && enq + 1 - cg_pin->seq > ahead) {
+                                if (hipStreamQuery(st) == hipSuccess && !cg_pin->done &&
+                                    enq + 1 - cg_pin->seq > ahead)
+                                    throw Error(SPORCO_AMD_EHIP, "CG: progress record not written");
+                            }
+                            if (cg_pin->done) break;
+                        }
+                    } else {
                     // An iteration: the scalar step at its top (stopping test, beta), the operator
                     // (p <- r + beta p, q = A p, <p, q>), the scalar step for alpha, the update (x,
                     // r, <r, r>).  (Folding the scalar steps into the last workgroup to finish the
@@ -2964,6 +2994,7 @@ template <typename T> struct Csc : CscBase {
                                 throw Error(SPORCO_AMD_EHIP, "CG: progress record not written");
                         }
                         if (cg_pin->done) break;
+                    }
                     }
                     sync();
                     SA_REQUIRE(cg_pin->done, "CG: the device loop did not reach a verdict");

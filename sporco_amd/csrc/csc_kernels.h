@@ -302,9 +302,22 @@ struct CgCtl {
     double rr, rr_prev, pq, atol;
     double alpha, beta;        // as T values (the casts of the host-driven loop)
     int done, it, info, maxit;
+    double rr2[2];             // self-serve mode (CgSelf): <r, r> of iteration i in slot i & 1
 };
 struct CgPinned {              // host-visible progress: tops processed, and the verdict
     volatile int seq, done, it, info;
+};
+// Self-serve mode of the operator / update kernels: every workgroup starts by summing the partial
+// rows of the preceding kernel itself (launch_finalize's order) and derives beta and the
+// stopping verdict (operator) or alpha (update) from them; workgroup 0 records the sums, the
+// verdict and the progress word.  No scalar-step launches: two launches per CG iteration.
+struct CgSelf {
+    CgCtl *c = nullptr;
+    CgPinned *pin = nullptr;
+    double *cgout = nullptr;
+    const double *prev = nullptr;   // partial rows to sum (stride 4)
+    int prev_nb = 0;
+    int iter = 0;                   // CG iteration index
 };
 void launch_cg_init(hipStream_t st, CgCtl *c, CgPinned *pin, double atol, int maxit);
 // phase 0 (top of an iteration): rr = sum_b partials[b][2]; stop when maxit iterations ran
@@ -322,7 +335,7 @@ void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, Cg
 template <typename T>
 int launch_cg_op(hipStream_t st, const CgCtl *ctl, bool with_update, const cx<T> *zf,
                  const cx<T> *r, cx<T> *p, cx<T> *q, T rho, int64_t npix, int CN, int K,
-                 double *partials);
+                 double *partials, const CgSelf &self = CgSelf());
 template <typename T>   // p = r + beta p (p = r when beta = 0); nothing once done
 void launch_cg_update_p(hipStream_t st, const CgCtl *c, const cx<T> *r, cx<T> *p, int64_t n);
 // x += alpha p; r -= alpha q; partials[block][2] = sum |r_new|^2 (the next iteration's <r, r>, in
@@ -330,7 +343,8 @@ void launch_cg_update_p(hipStream_t st, const CgCtl *c, const cx<T> *r, cx<T> *p
 // when ctl is null.  Returns the number of blocks.
 template <typename T>
 int launch_cg_update_xr(hipStream_t st, const CgCtl *c, T alpha_host, cx<T> *x, cx<T> *r,
-                        const cx<T> *p, const cx<T> *q, int64_t n, double *partials);
+                        const cx<T> *p, const cx<T> *q, int64_t n, double *partials,
+                        const CgSelf &self = CgSelf());
 
 // ---------------------------------------------------------------------------
 // Device-resident ADMM control (sporco_amd_csc_admm_run): the residuals, tolerances, the

@@ -2264,6 +2264,7 @@ __global__ void cg_init_kernel(CgCtl *c, CgPinned *pin, double atol, int maxit) 
     c->atol = atol;
     c->alpha = c->beta = 0.0;
     c->done = c->it = 0;
+    c->rr2[0] = c->rr2[1] = 0.0;
     c->info = maxit;
     c->maxit = maxit;
     (void)pin;     // reset by the host before this launch (csc_api.hip dstep_iter)
@@ -2344,20 +2345,72 @@ void launch_cg_ctl(hipStream_t st, int phase, const double *partials, int nb, Cg
     SA_HIP(hipGetLastError());
 }
 
-// (the CG kernels: grid-stride over at most eight workgroups per CU)
-constexpr int kCgMaxBlocks = 2048;
+// (T)(a / b) as the scalar steps form alpha and beta: a float64 quotient rounded to T
+template <typename T> __device__ __forceinline__ T cg_ratio(double a, double b) {
+#pragma clang fp contract(off)
+    return (T)(a / b);
+}
+// Sum of column `idx` of `nb` partial rows in the order of launch_finalize, delivered to every
+// thread of the workgroup (CgSelf).  scratch: kThreads doubles.
+__device__ __forceinline__ double cg_rows_sum(const double *partials, int nb, int idx, double *scratch) {
+    for (int t = threadIdx.x; t < kThreads; t += blockDim.x) {
+        double s = 0.0;
+        for (int b = t; b < nb; b += kThreads) s += partials[(int64_t)b * 4 + idx];
+        scratch[t] = s;
+    }
+    __syncthreads();
+    for (int w = kThreads / 2; w > 0; w >>= 1) {
+        for (int t = threadIdx.x; t < w; t += blockDim.x) scratch[t] += scratch[t + w];
+        __syncthreads();
+    }
+    const double v = scratch[0];
+    __syncthreads();
+    return v;
+}
+
+// (the CG kernels: grid-stride over at most four workgroups per CU)
+// (1024 workgroups: four per CU; measured 411 outer it/s at the bench shape against 393 with 2048
+// and 388 with 512 -- every workgroup sums the partial rows of the preceding launch, CgSelf)
+constexpr int kCgMaxBlocks = 1024;
 template <typename T, int JM>     // JM filters per lane: K <= 64 JM
 __global__ void __launch_bounds__(kThreads) cg_op_kernel(const CgCtl *ctl, int with_update,
                                                          const cx<T> *__restrict__ zf,
                                                          const cx<T> *__restrict__ r,
                                                          cx<T> *__restrict__ p, cx<T> *__restrict__ q,
                                                          T rho, int64_t npix, int CN, int K,
-                                                         double *partials) {
+                                                         double *partials, const CgSelf self) {
     if (ctl && ctl->done) return;
     constexpr int NB = 4;                       // images whose spectra are in flight together
     const int lane = threadIdx.x & (kWave - 1);
     const int wpb = blockDim.x / kWave;
-    const T beta = (ctl && with_update) ? (T)ctl->beta : T(0);
+    T beta = (ctl && with_update) ? (T)ctl->beta : T(0);
+    if (self.c) {
+        // top of CG iteration `iter` (cg_scalar_step, phase 0): <r, r>, stopping test, beta
+        CgCtl *c = self.c;
+        const double rr = cg_rows_sum(self.prev, self.prev_nb, 2, dyn_lds<double>());
+        const bool out_of_iters = self.iter >= c->maxit;
+        const bool converged = !out_of_iters && sqrt(rr) < c->atol;
+        beta = (self.iter == 0 || out_of_iters || converged) ? T(0)
+                                                               : cg_ratio<T>(rr, c->rr2[(self.iter - 1) & 1]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (!out_of_iters) c->rr2[self.iter & 1] = rr;
+            if (out_of_iters || converged) {
+                const int info = converged ? 0 : c->maxit;
+                c->done = 1;
+                c->info = info;
+                c->it = self.iter;
+                self.cgout[0] = (double)info;
+                self.cgout[1] = (double)self.iter;
+                self.pin->done = 1;
+                self.pin->it = self.iter;
+                self.pin->info = info;
+            }
+            sa_fence_system();
+            self.pin->seq = self.iter + 1;
+            sa_fence_system();
+        }
+        if (out_of_iters || converged) return;
+    }
     double acc[1] = {0.0};                      // <p, q>, slot 1 of the block's partial row
     for (int64_t pix = (int64_t)blockIdx.x * wpb + threadIdx.x / kWave; pix < npix;
          pix += (int64_t)gridDim.x * wpb) {
@@ -2418,7 +2471,7 @@ __global__ void __launch_bounds__(kThreads) cg_op_kernel(const CgCtl *ctl, int w
 template <typename T>
 int launch_cg_op(hipStream_t st, const CgCtl *ctl, bool with_update, const cx<T> *zf,
                  const cx<T> *r, cx<T> *p, cx<T> *q, T rho, int64_t npix, int CN, int K,
-                 double *partials) {
+                 double *partials, const CgSelf &self) {
     SA_REQUIRE(K <= 4 * kWave, "cg_op: at most 256 filters");
 #ifdef SPORCO_AMD_HOSTSIM
     const int threads = kWave;                    // (the simulator's scheduler walks the whole block)
@@ -2429,17 +2482,17 @@ int launch_cg_op(hipStream_t st, const CgCtl *ctl, bool with_update, const cx<T>
 #endif
     // one wave per pixel, grid-stride beyond the cap on workgroups
     const int grid = std::min(grid_for(npix * kWave, threads), cap);
-    const size_t lds = sizeof(double) * (threads / kWave);
+    const size_t lds = sizeof(double) * kThreads;
     const int wu = with_update ? 1 : 0;
     if (K <= kWave)
         hipLaunchKernelGGL((cg_op_kernel<T, 1>), dim3(grid), dim3(threads), lds, st, ctl, wu, zf, r, p, q,
-                           rho, npix, CN, K, partials);
+                           rho, npix, CN, K, partials, self);
     else if (K <= 2 * kWave)
         hipLaunchKernelGGL((cg_op_kernel<T, 2>), dim3(grid), dim3(threads), lds, st, ctl, wu, zf, r, p, q,
-                           rho, npix, CN, K, partials);
+                           rho, npix, CN, K, partials, self);
     else
         hipLaunchKernelGGL((cg_op_kernel<T, 4>), dim3(grid), dim3(threads), lds, st, ctl, wu, zf, r, p, q,
-                           rho, npix, CN, K, partials);
+                           rho, npix, CN, K, partials, self);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -2466,9 +2519,18 @@ __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(const CgCtl *c, 
                                                                 cx<T> *__restrict__ r,
                                                                 const cx<T> *__restrict__ p,
                                                                 const cx<T> *__restrict__ q, int64_t n,
-                                                                double *partials) {
+                                                                double *partials, const CgSelf self) {
     if (c && c->done) return;
-    const T alpha = c ? (T)c->alpha : alpha_host;
+    T alpha = c ? (T)c->alpha : alpha_host;
+    if (self.c) {
+        // (cg_scalar_step, phase 1): <p, q> of the operator launch before this one, alpha
+        const double pq = cg_rows_sum(self.prev, self.prev_nb, 1, dyn_lds<double>());
+        alpha = cg_ratio<T>(self.c->rr2[self.iter & 1], pq);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            self.c->pq = pq;
+            self.c->it = self.iter + 1;
+        }
+    }
     double acc[1] = {0.0};                      // <r, r>, slot 2 of the block's partial row
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // two grid-stride steps per trip (eight loads in flight per thread); the thread's elements
@@ -2499,21 +2561,22 @@ __global__ void __launch_bounds__(kThreads) cg_update_xr_kernel(const CgCtl *c, 
 }
 template <typename T>
 int launch_cg_update_xr(hipStream_t st, const CgCtl *c, T alpha_host, cx<T> *x, cx<T> *r,
-                        const cx<T> *p, const cx<T> *q, int64_t n, double *partials) {
+                        const cx<T> *p, const cx<T> *q, int64_t n, double *partials, const CgSelf &self) {
     const int grid = std::min(grid_for(n), kCgMaxBlocks);
-    hipLaunchKernelGGL((cg_update_xr_kernel<T>), dim3(grid), dim3(kThreads),
-                       sizeof(double) * (kThreads / kWave), st, c, alpha_host, x, r, p, q, n, partials);
+    hipLaunchKernelGGL((cg_update_xr_kernel<T>), dim3(grid), dim3(kThreads), sizeof(double) * kThreads, st,
+                       c, alpha_host, x, r, p, q, n, partials, self);
     SA_HIP(hipGetLastError());
     return grid;
 }
 #define SA_INST_CG(T)                                                                               \
     template int launch_cg_op<T>(hipStream_t, const CgCtl *, bool, const cx<T> *, const cx<T> *,    \
-                                 cx<T> *, cx<T> *, T, int64_t, int, int, double *);                 \
+                                 cx<T> *, cx<T> *, T, int64_t, int, int, double *, const CgSelf &); \
     template void launch_cg_ctl<T>(hipStream_t, int, const double *, int, CgCtl *, CgPinned *,      \
                                    double *);                                                       \
     template void launch_cg_update_p<T>(hipStream_t, const CgCtl *, const cx<T> *, cx<T> *, int64_t); \
     template int launch_cg_update_xr<T>(hipStream_t, const CgCtl *, T, cx<T> *, cx<T> *,            \
-                                        const cx<T> *, const cx<T> *, int64_t, double *);
+                                        const cx<T> *, const cx<T> *, int64_t, double *,            \
+                                        const CgSelf &);
 SA_INST_CG(float)
 SA_INST_CG(double)
 
