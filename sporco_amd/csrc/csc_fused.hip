@@ -1061,12 +1061,16 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
         if (grad) launch_fused_inst<N1, NW, LP, 64, true, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
     } else if (a.K == 64) {
+#ifdef SA_COLS_MEASUREMENT_BUILD
+        // (builds made for profiles/r02_fused_cols_notes.md only: the variants 1..4 leave out
+        // phases of the kernel and do not compute the X-step; the product library has none)
         static const int dbg = std::getenv("SPORCO_AMD_COLS_DEBUG") ? std::atoi(std::getenv("SPORCO_AMD_COLS_DEBUG")) : 0;
+        if (!grad && NW == 16 && dbg == 1) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 1>(st, a, ntiles);
+        if (!grad && NW == 16 && dbg == 2) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 2>(st, a, ntiles);
+        if (!grad && NW == 16 && dbg == 3) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 3>(st, a, ntiles);
+        if (!grad && NW == 16 && dbg == 4) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 4>(st, a, ntiles);
+#endif
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
-        else if (NW == 16 && dbg == 1) launch_fused_inst<N1, NW, LP, 64, false, false, false, 1>(st, a, ntiles);
-        else if (NW == 16 && dbg == 2) launch_fused_inst<N1, NW, LP, 64, false, false, false, 2>(st, a, ntiles);
-        else if (NW == 16 && dbg == 3) launch_fused_inst<N1, NW, LP, 64, false, false, false, 3>(st, a, ntiles);
-        else if (NW == 16 && dbg == 4) launch_fused_inst<N1, NW, LP, 64, false, false, false, 4>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false>(st, a, ntiles);
     } else {
         if (grad) launch_fused_inst<N1, NW, LP, 0, true>(st, a, ntiles);
