@@ -264,7 +264,10 @@ void launch_mc_inst(hipStream_t st, const FusedMcArgs<float> &a) {
 }
 
 template <int CC> void launch_mc_cc(hipStream_t st, const FusedMcArgs<float> &a) {
-    if (a.H == 256) {
+    if (a.H == 128) {
+        if (a.K == 64) launch_mc_inst<32, 4, 4, 64, CC>(st, a);
+        else launch_mc_inst<32, 4, 4, 0, CC>(st, a);
+    } else if (a.H == 256) {
         if (a.K == 64) launch_mc_inst<32, 8, 2, 64, CC>(st, a);
         else launch_mc_inst<32, 8, 2, 0, CC>(st, a);
     } else {
@@ -276,7 +279,7 @@ template <int CC> void launch_mc_cc(hipStream_t st, const FusedMcArgs<float> &a)
 }  // namespace
 
 template <> bool fused_mc_supported<float>(int H, int K, int Cd) {
-    return (H == 256 || H == 512) && K >= 1 && K <= 64 && Cd >= 2 && Cd <= 4;
+    return (H == 128 || H == 256 || H == 512) && K >= 1 && K <= 64 && Cd >= 2 && Cd <= 4;
 }
 template <> bool fused_mc_supported<double>(int, int, int) { return false; }
 

@@ -581,7 +581,7 @@ def test_odd_filter_count_matches_unpadded(backend, K):
 # ---------------------------------------------------------------------------
 # multi-channel dictionaries on the three-launch iteration (csc_fused_mc.hip)
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize('H,W,C,K,N', [(256, 256, 3, 4, 1),
+@pytest.mark.parametrize('H,W,C,K,N', [(256, 256, 3, 4, 1), (128, 128, 3, 4, 1),
                                        pytest.param(256, 256, 2, 6, 2, marks=pytest.mark.gpu),
                                        pytest.param(512, 256, 4, 8, 1, marks=pytest.mark.gpu),
                                        pytest.param(512, 512, 3, 64, 3, marks=pytest.mark.gpu)])
