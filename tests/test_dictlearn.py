@@ -172,7 +172,8 @@ def test_dictlearn_at_128_fused_vs_generic(backend, dmethod):
         if generic:
             os.environ['SPORCO_AMD_UNFUSED'] = '1'
         try:
-            opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 4}, xmethod='admm', dmethod=dmethod)
+            opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 2 if backend == 'hostsim' else 5},
+                                                    xmethod='admm', dmethod=dmethod)
             d = cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod=dmethod)
         finally:
             os.environ.pop('SPORCO_AMD_UNFUSED', None)
