@@ -550,10 +550,14 @@ template <typename T> struct Csc : CscBase {
                                          "arrived; the iterates of this handle are invalid");
         }
     }
+    // The fused FISTA iteration: the register-resident kernels of both directions, and -- for
+    // K > 64 -- rows of exactly K filters (a handle in tail mode, 64 < K <= 72, pads the rows of
+    // its Xf buffer to 80 for the ADMM tail kernels: the staged composition serves it).
+    bool pgm_fused_ok() const { return rows_ok && cols256 && (fused || (fused_slabs && !tail_mode)); }
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
-        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return (rows_ok && cols256 && (fused || fused_slabs)) ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_FUSED_PGM) return pgm_fused_ok() ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
@@ -1764,7 +1768,7 @@ template <typename T> struct Csc : CscBase {
     void pgm_iter(const sporco_amd_pgm_params &p, double *out_dev) override {
         require_single_channel_dict();
         require_ready();
-        if (!(rows_ok && cols256 && (fused || fused_slabs)))
+        if (!pgm_fused_ok())
             throw Error(SPORCO_AMD_EINVAL, "pgm_iter: shape not served by the fused kernels");
         t_ready = false;
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));

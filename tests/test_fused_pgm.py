@@ -84,6 +84,25 @@ def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     assert rel_l2(b.X, b0.X) < 1e-5
 
 
+@pytest.mark.parametrize('K,fused', [(66, False), (74, True), (65, False)])
+def test_filter_counts_just_above_64(backend, K, fused):
+    """64 < K <= 72 (and the odd counts padded into that range): the ADMM tail kernels of such a
+    handle pad the rows of its Xf buffer, so FISTA composes the staged calls there; from 74 on the
+    slab kernels serve the fused iteration.  Both against the float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.pgm import cbpdn as pc
+    H = W = 128
+    D, S = problem(H, W, K, 1, seed=K)
+    b = pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options({'MaxMainIter': 2, 'L': 50.0, 'RelStopTol': 0.0}))
+    assert b._fused_ok() == fused
+    X = b.solve()
+    ref = orc.pgm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, 1, 1), 0.05, dtype=np.float64,
+                        maxiter=2, L=50.0, rel_tol=0.0)
+    assert rel_l2(X, ref['X']) < 1e-5
+    for f in ('ObjFun', 'Rsdl'):
+        assert rel_l2(getattr(b.getitstat(), f), ref[f]) < 1e-5, f
+
+
 def test_fused_pgm_options_and_pickle(backend):
     """Linear momentum, NonNegCoef + L1Weight array (GENERAL prox), FastSolve, pickling."""
     if backend == 'hostsim':
