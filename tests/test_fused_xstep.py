@@ -387,7 +387,8 @@ def test_slab_column_pass_many_filters(backend, H, W, K, N, C):
     iters = 2 if backend == 'hostsim' else 3
     optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
     b, Y = solve(D, S, optd, joint=C is not None)
-    assert b._dev.uses_fused_rows() and b._dev.uses_fused_pgm()    # (K > 64: slab kernels in both solvers)
+    # (K > 72: slab kernels in both solvers; 64 < K <= 72: the ADMM tail form, FISTA staged)
+    assert b._dev.uses_fused_rows() and bool(b._dev.uses_fused_pgm()) == (K > 72)
     if H * W * K * N * (C or 1) > 2 ** 25:
         # (not reached by the cases above: every one of them, including ConvBPDNJoint with
         # K = 128, C = 3 -- 25 M elements -- is checked against the float64 oracle)
