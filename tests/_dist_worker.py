@@ -46,10 +46,12 @@ def main():
              DFid=np.array(its.DFid), Rho=np.array(its.Rho), k=h.k)
     # the device-driven loop (three-launch float32 path) under sharding: one image per rank,
     # the all-reduce hooked in between the local sums and the device-side control update
+    # (128 x 128, K = 130: the 32 x 4 splits and the cooperating slab workgroups of the K > 64
+    # column pass run under the hook as well)
     rng = np.random.RandomState(99)
-    Df = rng.randn(4, 4, 4).astype(np.float32)
+    Df = rng.randn(4, 4, 130).astype(np.float32)
     Df /= np.sqrt(np.sum(Df ** 2, axis=(0, 1), keepdims=True))
-    Sf = rng.randn(256, 256, 2).astype(np.float32)
+    Sf = rng.randn(128, 128, 2).astype(np.float32)
     optd = {'MaxMainIter': 3, 'RelStopTol': 0.0}
     bd = cbpdn.ConvBPDN(Df, shard_images(Sf, rank, world, axis=-1), 0.05,
                         cbpdn.ConvBPDN.Options(optd), reducer=TorchReducer())
