@@ -82,7 +82,7 @@ def test_launches_past_the_stopping_iteration_do_nothing(backend, lag):
     land behind the stopping iteration must leave every array untouched (and the ping-pong
     buffer roles are put right afterwards).  (On the CPU simulator: a loose tolerance, so
     that the run is a handful of iterations.)"""
-    D, S = problem(256, 256, 4, 1, seed=71)
+    D, S = problem(128 if backend == 'hostsim' else 256, 256, 4, 1, seed=71)
     optd = {'MaxMainIter': 40, 'RelStopTol': 0.25 if backend == 'hostsim' else 5e-2}
     b0, Y0 = run(D, S, optd, host=True)
     b1, Y1 = run(D, S, optd, host=False, lag=lag)

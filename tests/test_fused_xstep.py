@@ -84,7 +84,7 @@ def test_joint_l21_inside_the_row_epilogue(backend):
     runs.  Against the float64 oracle; a weight array falls back to the separate epilogue."""
     from oracle import cbpdn_oracle as orc
     from sporco_amd.admm import cbpdn
-    H, W, C, K = 256, 256, 3, 32
+    H, W, C, K = (128, 256, 3, 32) if backend == 'hostsim' else (256, 256, 3, 32)
     N, iters = (1, 2) if backend == 'hostsim' else (3, 8)
     D, S = problem(H, W, K, N, seed=31, C=C)
     opt = cbpdn.ConvBPDNJoint.Options({'MaxMainIter': iters, 'RelStopTol': 0.0})
