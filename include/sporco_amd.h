@@ -305,8 +305,8 @@ int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out);
                                     (eval_linear_approx, pgm.py:886-894)                  */
 #define SPORCO_AMD_PGM_DXY2 7    /* sum |Xf - Yf|^2, unweighted (backtrack.py:98-100)       */
 
-/* One whole default-option FISTA iteration on device (float32, H and W in {256, 512},
- * even K <= 256; SPORCO_AMD_EINVAL otherwise -- compose the calls below instead):
+/* One whole default-option FISTA iteration on device (float32, H and W in {128, 256, 512},
+ * even K <= 64 or 72 < K <= 256; SPORCO_AMD_EINVAL otherwise -- compose the calls below instead):
  * on_iteration_start (Xfprv = Xf, Yfprv = Yf, by buffer rotation), PGMDFT.xstep
  * (grad_f at Yf, Vf = Yf - grad/L, X = prox_g(irfftn(Vf)), Xf = rfftn(X);
  * sporco/pgm/pgm.py:779-811) and PGMDFT.ystep with the caller's momentum factor
