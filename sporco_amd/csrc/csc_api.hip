@@ -320,8 +320,7 @@ template <typename T> struct Csc : CscBase {
     // fused X-step (csc_fused.h): tile-major copies of Df, Sf, gram, its twiddles and
     // per-tile partials; xf_tiled marks VAR_XF as holding a tile-major intermediate
     bool fused = false, xf_tiled = false;
-    bool cols256 = false;           // H in {256, 512}: the FISTA, dictionary-update and per-tile
-                                    // (consensus) column kernels exist for it (H = 128: ADMM only)
+    bool cols256 = false;           // H in {128, 256, 512}: every column kernel family serves it
     bool fused_slabs = false;       // K = 64*NH: column pass as two slab kernels (csc_fused.h)
     cx<T> *qpart = nullptr;
     unsigned *coop_flags = nullptr;     // cooperating slab workgroups (csc_fused.h): per (tile, slab)

@@ -99,7 +99,7 @@ template <typename T> int64_t launch_rows_inv_prox_fwd(hipStream_t st, const Row
 // prox_l2, _lp.py:283-290) is a sum over the 16-lane rows of a wave (two permlane swaps).
 // Scalar weights, no NoBndryCross / AddMaskSim; K a multiple of 32.  partials[6] = the l2,1 sum.
 template <typename T> bool rows_joint_supported(int W, int C, int K);
-// Shapes the register-resident row kernels handle (float32, W in {256, 512}, K even).
+// Shapes the register-resident row kernels handle (float32, W in {128, 256, 512}, K even).
 template <typename T> bool rows_supported(int W, int K);
 // Host table for RowsFwdArgs::twA ((W/32) * 32 entries).
 template <typename T> void rows_twiddles(int W, cx<T> *twA);
