@@ -121,6 +121,11 @@ int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels,
                              void *stream, sporco_amd_csc_t *out);
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
 int sporco_amd_csc_sync(sporco_amd_csc_t h);
+/* The hipStream_t every launch of this handle goes to (the `stream` given at creation, or the
+ * stream the handle created for itself): a caller that enqueues its own work between two
+ * calls -- the all-reduce hook of sporco_amd_csc_admm_run under torch.distributed -- orders
+ * it on this stream (no reference counterpart: the reference is synchronous NumPy). */
+int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
 /* Which kernels serve this handle's shape: *out = 1 when the fused path named by
  * `what` is active (float32, H and/or W in {128, 256, 512}, even K <= 64 -- or even
  * 64 < K <= 256, where the column pass runs as cooperating 64-filter slab workgroups), else 0. */
@@ -242,9 +247,14 @@ int sporco_amd_csc_admm_iter_dev(sporco_amd_csc_t h, const sporco_amd_admm_param
  * pending U scale from device memory: the host only enqueues launches (a few iterations
  * ahead) and reads the per-iteration records back when the run ends.  Iterates and statistics
  * are identical to those of the same number of sporco_amd_csc_admm_iter calls driven by the
- * host rule.  Available for the three-launch float32 path (query FUSED_ROWS, K <= 64,
- * single-channel dictionary) without FLAG_XRRS / JOINT / GRADREG / KEEP_X / FEVAL_Y;
- * otherwise the call returns SPORCO_AMD_EUNSUPPORTED and changes nothing. */
+ * host rule.  Available for the three-launch float32 path (query FUSED_ROWS; single-channel
+ * dictionary; K <= 64, or 72 < K <= 256 on the slab column kernels -- not the 64 < K <= 72
+ * tail form) without FLAG_XRRS / GRADREG / KEEP_X / FEVAL_Y; FLAG_JOINT is served when the
+ * l2,1 row epilogue is (scalar weights, C <= 4, K a multiple of 32, no NoBndryCross /
+ * AddMaskSim); otherwise the call returns SPORCO_AMD_EUNSUPPORTED and changes nothing.
+ * With a `reduce` hook (image shards) the number of hook calls is a function of the
+ * stopping iteration alone -- min(max_iter, stop + 1 + lookahead) -- so that every rank
+ * issues the same number of collectives whatever its host's timing. */
 #define SPORCO_AMD_EUNSUPPORTED (-5)
 typedef struct {
     double abs_tol, rel_tol;        /* AbsStopTol, RelStopTol                                */

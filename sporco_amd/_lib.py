@@ -51,7 +51,7 @@ EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc',
     'sporco_amd_csc_destroy',
-    'sporco_amd_csc_sync', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
+    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
@@ -217,6 +217,7 @@ def load(path=None):
                                    ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_size_t)],
         'sporco_amd_csc_destroy': [vp], 'sporco_amd_csc_sync': [vp],
+        'sporco_amd_csc_stream': [vp, ctypes.POINTER(ctypes.c_void_p)],
         'sporco_amd_csc_query': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         'sporco_amd_csc_set_signal': [vp, vp],
         'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
@@ -430,6 +431,12 @@ class Solver(object):
     # -- set-up -----------------------------------------------------------
     def sync(self):
         check(self._lib.sporco_amd_csc_sync(self._h))
+
+    def stream_handle(self):
+        """hipStream_t (as an int) of every launch this handle makes."""
+        out = ctypes.c_void_p(0)
+        check(self._lib.sporco_amd_csc_stream(self._h, ctypes.byref(out)))
+        return int(out.value or 0)
 
     def query(self, what):
         out = ctypes.c_int(0)

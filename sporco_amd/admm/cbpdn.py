@@ -233,6 +233,9 @@ class GenericConvBPDN(admm.ADMMEqual):
     def __setstate__(self, state):
         saved = state.pop('_saved_arrays')
         u_scale = state.get('_u_scale', 1.0)
+        if 'S' in state:       # pickled before `S` became a property: the key would be shadowed
+            state.setdefault('_S_host', state.pop('S'))
+        state.setdefault('_S_dev', None)
         self.__dict__.update(state)
         self._new_handle()
         self._dev.set_signal(self.S)
@@ -360,11 +363,22 @@ class GenericConvBPDN(admm.ADMMEqual):
         :meth:`ADMM.solve` when no callback, status display or overridden step has to run on
         the host between iterations; anything else keeps the per-iteration loop."""
         o = self.opt
+        cls = type(self)
+        # host methods the device loop never calls: an override of any of them (class or
+        # instance) has to keep the per-iteration loop, or it would silently not run
+        # (rhochange is the reference's documented hook, admm.py:575)
+        host_only = (('solve', GenericConvBPDN), ('iteration', GenericConvBPDN),
+                     ('finish_solve', GenericConvBPDN), ('rhochange', GenericConvBPDN),
+                     ('update_rho', admm.ADMM), ('rho_scale_factor', admm.ADMM),
+                     ('display_start', admm.ADMM), ('display_status', admm.ADMM),
+                     ('display_end', admm.ADMM), ('iteration_stats', admm.ADMM))
+        for name, base in host_only:
+            if name in self.__dict__:
+                return False
+            if hasattr(base, name) and getattr(cls, name) is not getattr(base, name):
+                return False
         return (self._fused_ok() and o['Callback'] is None and not o['Verbose'] and
-                o['IterTimer'] == 'solve' and type(self).solve is GenericConvBPDN.solve and
-                type(self).update_rho is admm.ADMM.update_rho and
-                type(self).rho_scale_factor is admm.ADMM.rho_scale_factor and
-                'update_rho' not in self.__dict__ and o['MaxMainIter'] > 0)
+                o['IterTimer'] == 'solve' and o['MaxMainIter'] > 0)
 
     def solve(self):
         """:meth:`ADMM.solve` (sporco/admm/admm.py:293-389).  When the iterations need no host

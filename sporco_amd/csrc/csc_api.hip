@@ -148,6 +148,7 @@ struct ProfScope {
 struct CscBase {
     virtual ~CscBase() {}
     virtual void sync() = 0;
+    virtual void *stream_handle() = 0;
     virtual int query(int what) = 0;
     virtual void set_signal(const void *S) = 0;
     virtual void set_signal_dev(const void *S_dev) = 0;
@@ -540,6 +541,7 @@ template <typename T> struct Csc : CscBase {
     }
     Dims5 d5() const { return Dims5{H, W, C, N, K}; }
 
+    void *stream_handle() override { return (void *)st; }
     void sync() override {
         SA_HIP(hipStreamSynchronize(st));
         // (cooperating slab workgroups, csc_fused.h: a partner's partial sums never arrived)
@@ -1313,9 +1315,10 @@ template <typename T> struct Csc : CscBase {
         // (test knob: pretend the newest `lag` records are not visible yet, so that launches
         // enqueued past the stopping iteration -- which must do nothing -- occur on any device)
         int lag = std::getenv("SPORCO_AMD_RUN_LAG") ? std::atoi(std::getenv("SPORCO_AMD_RUN_LAG")) : 0;
-        auto poll = [&](bool block) {
-            // advance over finished iterations; returns at the first unfinished one
-            while (done < enq - lag && stop_at < 0) {
+        // Advance `done` over finished iterations up to `upto` records: without `block` it
+        // returns at the first unfinished one, with `block` it waits for each.
+        auto poll = [&](int upto, bool block) {
+            while (done < upto && stop_at < 0) {
                 if (rec_ring[done].seq != done + 1) {
                     if (!block) return;
                     if (hipStreamQuery(st) == hipSuccess && rec_ring[done].seq != done + 1)
@@ -1326,7 +1329,7 @@ template <typename T> struct Csc : CscBase {
                 ++done;
             }
         };
-        for (; enq < c.max_iter && stop_at < 0;) {
+        auto enqueue_one = [&]() {
             const int64_t nt = enqueue_iter_ctl(p);
             if (want_sums) {
                 const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
@@ -1346,14 +1349,29 @@ template <typename T> struct Csc : CscBase {
             }
             launch_admm_ctl_update(st, ctl_dev, out_dev, rec_ring + enq, enq, true);
             ++enq;
+        };
+        // Iteration e is enqueued once the records of iterations < e - ahead have been seen
+        // (a sliding window: the device always has up to `ahead` iterations queued).  With
+        // image shards (`reduce`) that window is exact -- the blocking wait ignores the lag
+        // knob -- so a rank never has more than stop + 1 + ahead iterations enqueued, and
+        // every rank is topped up to exactly that many below: the number of collectives is
+        // the same on all ranks however late each host notices the stop (the surplus
+        // iterations are launches that return at once around an all-reduce nobody reads).
+        const int wlag = reduce ? 0 : lag;
+        for (; enq < c.max_iter && stop_at < 0;) {
+            enqueue_one();
             if (c.need_residuals) {
-                poll(false);
-                while (stop_at < 0 && enq - lag - done > ahead) poll(true);
+                poll(enq - lag, false);
+                if (stop_at < 0 && enq - wlag - done > ahead) poll(enq - wlag - ahead, true);
             }
         }
+        if (reduce && want_sums && c.need_residuals) {
+            if (stop_at < 0) poll(enq, true);       // (the last window: a stop may sit in it)
+            if (stop_at >= 0)
+                while (enq < c.max_iter && enq < stop_at + 1 + ahead) enqueue_one();
+        }
         sync();
-        lag = 0;
-        poll(false);
+        poll(enq, false);
         const int n = stop_at >= 0 ? stop_at + 1 : enq;
         // launches enqueued after the stopping iteration did nothing: undo their buffer swaps
         if ((enq - n) & 1) {
@@ -3287,6 +3305,14 @@ int sporco_amd_csc_sync(sporco_amd_csc_t h) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->sync();
+    SA_API_END
+}
+
+int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(stream, "null argument");
+    *stream = h->impl->stream_handle();
     SA_API_END
 }
 

@@ -65,35 +65,61 @@ class TorchReducer(object):
 
     def device_sum_hook(self, solver):
         """Hook for the device-driven solve (``Solver.admm_run``): called once per iteration
-        with the device address of the 16 sums, it all-reduces them in place without a host
-        round trip -- over RCCL the collective is enqueued behind the kernels that produced
-        the sums (the solver shares torch's current stream) and the control kernel that
-        follows is enqueued behind it.  Returns None when that is not possible (gloo on a real
-        GPU): the caller then keeps the per-iteration host loop."""
+        with the device address of the 16 sums, it all-reduces them in place.
+
+        RCCL (``nccl``): no host round trip.  The collective is issued with the SOLVER's stream
+        as torch's current stream (``torch.cuda.ExternalStream`` over the handle's
+        ``hipStream_t``), which is how ProcessGroupNCCL orders a collective: it records an
+        event on the current stream, makes its own communication stream wait for it, and --
+        for a blocking call -- makes the current stream wait for the collective's end event.
+        So the all-reduce runs behind the kernels that produced the sums and the control
+        kernel the library enqueues next runs behind the all-reduce, whichever stream the
+        handle was created with; nothing relies on the legacy default stream.
+
+        gloo with the library on a real GPU (two ranks sharing one device: a correctness
+        configuration, e.g. ``SPORCO_AMD_BENCH_BACKEND=gloo``): the 16 doubles are staged
+        through the host around a CPU all-reduce -- one stream synchronisation per iteration.
+
+        gloo on the CPU simulator: "device" memory is host memory."""
         from . import _lib
+        torch = self.torch
         views = {}
         if self.on_gpu:
+            try:
+                torch.as_tensor(_DeviceView(solver.device_ptr(_lib.VAR_Y), 1, '<f4'),
+                                device=self.buf.device)
+                ext = torch.cuda.ExternalStream(solver.stream_handle(), device=self.buf.device)
+            except (TypeError, RuntimeError, ValueError, AttributeError):
+                return None
+
             def hook(ptr):
                 t = views.get(ptr)
                 if t is None:
-                    t = views[ptr] = self.torch.as_tensor(_DeviceView(ptr, 16, '<f8'),
-                                                          device=self.buf.device)
-                self.dist.all_reduce(t, group=self.group)
-            try:
-                self.torch.as_tensor(_DeviceView(solver.device_ptr(_lib.VAR_Y), 1, '<f4'),
-                                     device=self.buf.device)
-            except (TypeError, RuntimeError, ValueError):
-                return None
+                    t = views[ptr] = torch.as_tensor(_DeviceView(ptr, 16, '<f8'),
+                                                     device=self.buf.device)
+                with torch.cuda.stream(ext):
+                    self.dist.all_reduce(t, group=self.group)
             return hook
         if 'hostsim' not in str(_lib.library_path()):
-            return None
+            import numpy as np
+            stage = np.zeros(16, dtype=np.float64)
+            tstage = torch.from_numpy(stage)
+
+            def hook(ptr):      # real GPU, CPU collective: host staging
+                solver.sync()
+                _lib.check(_lib.lib().sporco_amd_dev_download(_lib._ptr(stage), ctypes.c_void_p(ptr),
+                                                              stage.nbytes))
+                self.dist.all_reduce(tstage, group=self.group)
+                _lib.check(_lib.lib().sporco_amd_dev_upload(ctypes.c_void_p(ptr), _lib._ptr(stage),
+                                                            stage.nbytes))
+            return hook
 
         def hook(ptr):      # CPU simulator: "device" memory is host memory
             import numpy as np
             t = views.get(ptr)
             if t is None:
                 a = np.ctypeslib.as_array((ctypes.c_double * 16).from_address(ptr))
-                t = views[ptr] = self.torch.from_numpy(a)
+                t = views[ptr] = torch.from_numpy(a)
             self.dist.all_reduce(t, group=self.group)
         return hook
 

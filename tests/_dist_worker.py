@@ -70,6 +70,30 @@ def main():
                     for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho')})
         os.environ.pop('SPORCO_AMD_HOST_LOOP')
     np.savez(out_path + '.devloop.%d.npz' % rank, **out)
+    # the same loop stopping EARLY on its tolerance test, with the ranks' hosts noticing the
+    # stop at different times (rank 1 does not see its newest three records): every rank must
+    # still issue the same number of all-reduces, or the collective after the solve pairs
+    # with a surplus one (a hang or a corrupted sum over RCCL)
+    Ds = Df[:, :, :8].copy()
+    opts = {'MaxMainIter': 60, 'RelStopTol': 2e-2}
+    os.environ['SPORCO_AMD_RUN_LAG'] = '3' if rank == 1 else '0'
+    red = TorchReducer()
+    be = cbpdn.ConvBPDN(Ds, shard_images(Sf, rank, world, axis=-1), 0.05,
+                        cbpdn.ConvBPDN.Options(opts), reducer=red)
+    assert be._device_loop_ok() and be._reducer.device_sum_hook(be._dev) is not None
+    Ye = be.solve()
+    os.environ.pop('SPORCO_AMD_RUN_LAG')
+    after = red.sum([float(rank + 1)])[0]          # 3.0 only if the collectives are aligned
+    ite = be.getitstat()
+    oute = dict(Y=Ye, k=be.k, after=after, Rho=np.asarray(ite.Rho, dtype=float),
+                PrimalRsdl=np.asarray(ite.PrimalRsdl, dtype=float))
+    if rank == 0:
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+        b1 = cbpdn.ConvBPDN(Ds, Sf, 0.05, cbpdn.ConvBPDN.Options(opts))
+        oute['Y_single'] = b1.solve()
+        oute['k_single'] = b1.k
+        os.environ.pop('SPORCO_AMD_HOST_LOOP')
+    np.savez(out_path + '.earlystop.%d.npz' % rank, **oute)
     # dictionary learning, four images over the two ranks: X-step sums and the D-step
     # gradient are all-reduced, the dictionary is replicated
     from sporco_amd.dictlrn import cbpdndl

@@ -137,3 +137,50 @@ def test_host_loop_is_kept_when_the_host_has_to_see_iterations(backend):
     assert not g._dev.uses_fused_rows()
     g.solve()
     assert g.k == 3 and len(g.itstat) == 3
+
+
+def test_host_methods_the_device_loop_never_calls_keep_the_host_loop(backend):
+    """`rhochange` (the reference's documented hook, sporco/admm/admm.py:575), `iteration`,
+    the display methods: an override of any of them -- on the class or on the instance --
+    must run, so the solve stays on the per-iteration loop."""
+    from sporco_amd.admm import cbpdn
+    H = 128
+    D, S = problem(H, H, 4, 1, seed=92)
+    optd = {'MaxMainIter': 6, 'RelStopTol': 0.0, 'AutoRho': {'Period': 2}}
+    plain = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    assert plain._device_loop_ok()
+    calls = []
+
+    class WithHook(cbpdn.ConvBPDN):
+        def rhochange(self):
+            calls.append(self.k)
+    b = WithHook(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    assert not b._device_loop_ok()
+    b.solve()
+    # update_rho acts at k = 1, 3, 5 ((k + 1) % Period == 0, k != 0) and calls the hook whenever
+    # it changes rho
+    assert set(calls) <= {1, 3, 5}
+    assert calls, "rhochange() was never called"
+    Y0 = plain.solve()
+    assert np.array_equal(Y0, b.Y)           # the hook does nothing: same iterates
+    # instance-level overrides
+    c = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    c.display_status = lambda fmtstr, itst: None
+    assert not c._device_loop_ok()
+    d = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    d.iteration = d.iteration
+    assert not d._device_loop_ok()
+
+
+def test_pickle_from_before_the_signal_property(backend):
+    """A state pickled when `S` was a plain attribute restores (the key is migrated)."""
+    from sporco_amd.admm import cbpdn
+    D, S = problem(48, 48, 4, 1, seed=93)
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options({'MaxMainIter': 2, 'RelStopTol': 0.0}))
+    b.solve()
+    st = b.__getstate__()
+    st['S'] = st.pop('_S_host')
+    st.pop('_S_dev')
+    r = cbpdn.ConvBPDN.__new__(cbpdn.ConvBPDN)
+    r.__setstate__(st)
+    assert np.array_equal(r.S, b.S) and np.array_equal(r.Y, b.Y)

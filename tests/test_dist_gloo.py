@@ -47,6 +47,16 @@ def test_two_rank_image_sharding(tmp_path):
         for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
             assert rel_l2(p[f], dp[0][f + '_single']) < 1e-6, f
             assert np.array_equal(p[f], dp[0][f])              # identical on every rank
+    # ... stopping early with unequal host lags: same stopping iteration as the single-process
+    # run, aligned collectives afterwards
+    ep = [np.load(out + '.earlystop.%d.npz' % r) for r in range(2)]
+    k1 = int(ep[0]['k_single'])
+    assert 3 < k1 < 60                                          # (it did stop on the tolerance)
+    for p in ep:
+        assert int(p['k']) == k1
+        assert float(p['after']) == 3.0
+        assert np.array_equal(p['Rho'], ep[0]['Rho'])
+    assert rel_l2(np.concatenate([p['Y'] for p in ep], axis=3), ep[0]['Y_single']) < 1e-5
     # dictionary learning: both ranks hold the dictionary of the single-process run, each its
     # own images' coefficient maps; every statistic is the global one
     g = load_golden('cbpdndl_shard_f64')
