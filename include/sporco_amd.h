@@ -137,6 +137,9 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
                                             filter to reach the fused kernels (host arrays
                                             always have K; only sporco_amd_csc_device_ptr
                                             exposes the padded layout) */
+#define SPORCO_AMD_QUERY_VFORM_LIVE 4   /* 1 while the ADMM iterate lives in the single-array
+                                            form of the fused iteration (V = AX + U; Y and U
+                                            are derived on the next access) -- diagnostics */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))

@@ -48,15 +48,31 @@ def real_dtype(dtype):
 # FFT primitives (sporco/fft.py:257-314; numpy fallback :631-639)
 # ---------------------------------------------------------------------------
 
+# Threads of the FFTs.  None: numpy.fft, the reference's fallback and what every parity test
+# runs.  An int: scipy.fft (pocketfft) with that many workers -- the counterpart of the
+# reference's normal install, which runs its FFTs in pyFFTW on multiprocessing.cpu_count()
+# threads (sporco/fft.py:37, call sites :222-312) while the rest stays single-threaded NumPy;
+# used only by bench.py's threaded cpu_baseline leg.
+FFT_WORKERS = None
+
+
 def rfftn2(a, s=None):
     """Unnormalised 2-D real FFT over axes (0, 1), result cast to the complex
     type matching ``a`` -- sporco/fft.py:631-634 (`_rfftn`)."""
+    if FFT_WORKERS:
+        import scipy.fft as sfft
+        return sfft.rfftn(a, s, AX_SPATIAL, workers=FFT_WORKERS).astype(complex_dtype(a.dtype),
+                                                                       copy=False)
     return np.fft.rfftn(a, s, AX_SPATIAL).astype(complex_dtype(a.dtype))
 
 
 def irfftn2(af, s):
     """Inverse of :func:`rfftn2`; ``s`` = (H, W) is mandatory because W may be
     odd -- sporco/fft.py:636-639 (`_irfftn`)."""
+    if FFT_WORKERS:
+        import scipy.fft as sfft
+        return sfft.irfftn(af, s, AX_SPATIAL, workers=FFT_WORKERS).astype(real_dtype(af.dtype),
+                                                                         copy=False)
     return np.fft.irfftn(af, s, AX_SPATIAL).astype(real_dtype(af.dtype))
 
 

@@ -66,6 +66,9 @@ enum ProfSlot {
     PS_ROWS_FWD,
     PS_ROWS_INV_POST,
     PS_ROWS_INV_POST_EMIT,
+    PS_ROWS_FWD_V,              // the same three in the single-array state (csc_rows.h):
+    PS_ROWS_INV_POST_V,         // V in and out (the (Y, U) -> V transition counts with the
+    PS_ROWS_INV_POST_V_EMIT,    // (Y, U) slots: it reads both arrays)
     PS_PGM_GRAD_IFFT,
     PS_PGM_ROWS_PROX,
     PS_PGM_FFT_MOM,
@@ -78,6 +81,7 @@ static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd
                                            "fft_c2c_cols_inv", "fft_c2r_rows",     "admm_post",
                                            "fused_cols_sm",    "rows_fwd",         "rows_inv_post",
                                            "rows_inv_post_emit",
+                                           "rows_fwd_v",       "rows_inv_post_v",  "rows_inv_post_v_emit",
                                            "pgm_grad_ifft",    "pgm_rows_prox",    "pgm_fft_momentum",
                                            "finalize",         "pgm_elementwise",  "other"};
 
@@ -344,6 +348,23 @@ template <typename T> struct Csc : CscBase {
     // after a three-launch iteration the previous iterate sits in y_alt and AX was never
     // formed: a host read of VAR_YPREV / VAR_AX derives them (download)
     bool prev_in_alt = false;
+    // Single-array state of the fused iteration (csc_rows.h, "V form").  While v_live, the
+    // current iterate is V = AX + U of the iteration that produced it, in v_cur (one of y_alt /
+    // u_alt, which ping-pong as V buffers); vars[Y] / vars[U] then hold the iterate the run
+    // started from (v_prev_kind 1: it is the previous iterate) or stale data (v_prev_kind 2:
+    // the previous iterate is the V in the other alt buffer, produced with v_prev_thr).
+    // ensure_yu() returns the handle to the (Y, U) form every other code path expects;
+    // ensure_prev_yu() also brings the previous iterate back into (y_alt, u_alt).
+    bool v_live = false;
+    T *v_cur = nullptr;
+    T v_thr = T(0), v_prev_thr = T(0);
+    bool v_nonneg = false;
+    int v_prev_kind = 0;
+    bool vp_pending = false;       // the previous iterate still waits, in V form, in vp_buf
+    T *vp_buf = nullptr, *vp_free = nullptr;
+    T vp_thr = T(0);
+    bool vp_nonneg = false;
+    uint64_t touch_epoch = 0, fused_epoch = ~(uint64_t)0;   // host accesses between fused iterations
     // t_ready: the Xf buffer already holds rows_fwd(Y, U, s = 1) of the current
     // iterate, emitted by the previous rows_inv_post on the bet that rho stays put
     bool t_ready = false;
@@ -516,6 +537,10 @@ template <typename T> struct Csc : CscBase {
 
     void *var_ptr(int var) {
         SA_REQUIRE(var_is_valid(var), "unknown state variable id");
+        if (var == SPORCO_AMD_VAR_Y || var == SPORCO_AMD_VAR_U) {
+            ++touch_epoch;
+            if (v_live) ensure_yu();
+        }
         if (!vars[var]) {
             // (the Xf buffer also holds the tile-major spectrum, whose rows may be padded)
             const size_t nb = var == SPORCO_AMD_VAR_XF ? sizeof(cx<T>) * (size_t)std::max(EF, EFt)
@@ -560,6 +585,7 @@ template <typename T> struct Csc : CscBase {
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_PGM) return pgm_fused_ok() ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
+        if (what == SPORCO_AMD_QUERY_VFORM_LIVE) return v_live ? 1 : 0;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
 
@@ -645,6 +671,52 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_OTHER);
         launch_permute_ab<cx<T>>(st, cv(SPORCO_AMD_VAR_SF), sft, H, (int64_t)Wf * CN, 1);
     }
+    // ---- single-array state (csc_rows.h): back to the (Y, U) form ----------------------------
+    bool vform_ok(const sporco_amd_admm_params &p) const {
+        const bool off = std::getenv("SPORCO_AMD_NO_VFORM") != nullptr;   // (test switch)
+        return !off && std::is_same<T, float>::value && rows_ok && !wl1.ptr &&
+               !(p.flags & (F_NOBNDRY | F_AMS | F_JOINT | F_KEEP_X | F_FEVAL_Y | F_XRRS));
+    }
+    void ensure_yu() {
+        if (!v_live) return;
+        v_live = false;
+        T *other = v_cur == y_alt ? u_alt : y_alt;
+        ProfScope ps(prof, PS_OTHER);
+        if (v_prev_kind == 1) {
+            // vars hold the previous iterate as (Y, U) and the other alt buffer is free: the
+            // new pair goes to (other, v_cur) and the buffers trade places -- exactly the state
+            // an iteration of the (Y, U) form leaves behind
+            launch_vform_split<T>(st, v_cur, other, v_cur, v_thr, v_nonneg, E);
+            T *oldY = static_cast<T *>(vars[SPORCO_AMD_VAR_Y]), *oldU = static_cast<T *>(vars[SPORCO_AMD_VAR_U]);
+            vars[SPORCO_AMD_VAR_Y] = other;
+            vars[SPORCO_AMD_VAR_U] = v_cur;
+            y_alt = oldY;
+            u_alt = oldU;
+            prev_in_alt = true;
+        } else {
+            launch_vform_split<T>(st, v_cur, static_cast<T *>(vars[SPORCO_AMD_VAR_Y]),
+                                  static_cast<T *>(vars[SPORCO_AMD_VAR_U]), v_thr, v_nonneg, E);
+            // the previous iterate stays in V form until somebody asks for it
+            vp_pending = v_prev_kind == 2;
+            vp_buf = other;
+            vp_free = v_cur;
+            vp_thr = v_prev_thr;
+            vp_nonneg = v_nonneg;
+            prev_in_alt = false;
+        }
+        v_cur = nullptr;
+    }
+    void ensure_prev_yu() {
+        ensure_yu();
+        if (!vp_pending) return;
+        vp_pending = false;
+        ProfScope ps(prof, PS_OTHER);
+        launch_vform_split<T>(st, vp_buf, vp_free, vp_buf, vp_thr, vp_nonneg, E);
+        y_alt = vp_free;
+        u_alt = vp_buf;
+        prev_in_alt = true;
+    }
+
     // X of the last three-launch iteration, rebuilt from the previous iterate.
     void materialize_x() {
         if (x_invalid)
@@ -655,6 +727,7 @@ template <typename T> struct Csc : CscBase {
             pgm_rows_prox(last_pgm, work_buf(), nullptr, rv(SPORCO_AMD_VAR_X), nullptr);
         }
         if (!x_stale) return;
+        ensure_prev_yu();
         x_stale = false;
         t_ready = false;   // the Xf buffer is about to be reused
         sporco_amd_admm_params q = last_p;
@@ -665,11 +738,15 @@ template <typename T> struct Csc : CscBase {
     }
     // call before reading `var` / before changing anything X depends on
     void before_read(int var) {
+        ++touch_epoch;
         if (var == SPORCO_AMD_VAR_X || var == SPORCO_AMD_VAR_XF) materialize_x();
         need_natural(var);
     }
     void before_state_change() {
+        ++touch_epoch;
         if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
+        ensure_yu();
+        vp_pending = false;
         t_ready = false;
         prev_in_alt = false;
     }
@@ -677,6 +754,7 @@ template <typename T> struct Csc : CscBase {
     // row spectra of Y - U (t_ready) and the ping-pong parity do not -- a dictionary-learning
     // loop keeps skipping the forward row pass of its one-iteration X-steps.
     void before_dict_change() {
+        ++touch_epoch;
         if ((x_stale && !x_invalid) || pgm_x_stale) materialize_x();
     }
     void x_written() {
@@ -906,6 +984,7 @@ template <typename T> struct Csc : CscBase {
         sync();
     }
     void download(int var, void *dst) override {
+        if (var == SPORCO_AMD_VAR_YPREV || var == SPORCO_AMD_VAR_AX) ensure_prev_yu();
         if (prev_in_alt && y_alt && (var == SPORCO_AMD_VAR_YPREV || var == SPORCO_AMD_VAR_AX)) {
             // Yprev = the other half of the (Y, U) ping-pong; AX = rlx X + (1 - rlx) Yprev
             // (admm.py:877-885) with X rebuilt from that same previous iterate
@@ -1067,15 +1146,28 @@ template <typename T> struct Csc : CscBase {
     // rows_inv_post.  X is written only on request (F_KEEP_X).
     void admm_iter_fused(const sporco_amd_admm_params &p, double *out_dev) {
         require_ready();
-        T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U);
-        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         const bool keep_x = p.flags & F_KEEP_X;
+        // Single-array state (csc_rows.h): from the second fused iteration in a row with no host
+        // access to the iterates in between, the epilogue stores V' = AX + U alone and the next
+        // iteration derives (Y, U) from it -- seven passes instead of ten (six instead of eight
+        // with an emitted spectrum).  Anything else that wants Y or U gets them through
+        // ensure_yu() (var_ptr).
+        const bool nn = p.flags & F_NONNEG;
+        if (v_live && (!vform_ok(p) || nn != v_nonneg)) ensure_yu();
+        const bool vf = vform_ok(p) && (v_live || touch_epoch == fused_epoch);
+        T *vin = vf && v_live ? v_cur : nullptr;
+        T *Y = vin ? nullptr : rv(SPORCO_AMD_VAR_Y), *U = vin ? nullptr : rv(SPORCO_AMD_VAR_U);
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         if (!keep_x && !y_alt) {
             SA_HIP(hipMalloc((void **)&y_alt, sizeof(T) * E));
             SA_HIP(hipMalloc((void **)&u_alt, sizeof(T) * E));
         }
+        T *vout = vf ? (vin == y_alt ? u_alt : y_alt) : nullptr;
         // rows_fwd, unless the previous iteration already left its result behind
-        if (!(t_ready && p.u_scale == 1.0)) launch_rows_fwd_on(Y, U, (T)p.u_scale);
+        if (!(t_ready && p.u_scale == 1.0)) {
+            if (vin) launch_rows_fwd_on(nullptr, nullptr, (T)p.u_scale, vin, v_thr, p.flags);
+            else launch_rows_fwd_on(Y, U, (T)p.u_scale);
+        }
         t_ready = false;
         run_fused_cols(p, nullptr);
         // Bet on an unchanged rho only once it has stayed put for two updates in a row:
@@ -1096,6 +1188,9 @@ template <typename T> struct Csc : CscBase {
         pa.u = U;
         pa.y_out = keep_x ? Y : y_alt;
         pa.u_out = keep_x ? U : u_alt;
+        pa.v_in = vin;
+        pa.v_out = vout;
+        pa.thr_prev = v_thr;
         pa.x = keep_x ? rv(SPORCO_AMD_VAR_X) : nullptr;
         pa.scale = T(1.0 / ((double)H * (double)W));
         pa.rlx = (T)p.rlx;
@@ -1118,7 +1213,8 @@ template <typename T> struct Csc : CscBase {
         pa.partials = part_rows;
         int64_t nt;
         {
-            ProfScope ps(prof, emit ? PS_ROWS_INV_POST_EMIT : PS_ROWS_INV_POST);
+            ProfScope ps(prof, vin ? (emit ? PS_ROWS_INV_POST_V_EMIT : PS_ROWS_INV_POST_V)
+                                   : (emit ? PS_ROWS_INV_POST_EMIT : PS_ROWS_INV_POST));
             nt = launch_rows_inv_post<T>(st, pa);
         }
         if (p.flags & (F_RESID | F_OBJ)) {
@@ -1139,10 +1235,25 @@ template <typename T> struct Csc : CscBase {
         }
         if (keep_x) {
             x_written();
+        } else if (vf) {
+            // the new iterate is the V in vout; the previous one is (Y, U) in vars (first V
+            // iteration) or the V this iteration read
+            v_prev_kind = vin ? 2 : 1;
+            v_prev_thr = v_thr;
+            v_cur = vout;
+            v_thr = pa.thr;
+            v_nonneg = nn;
+            v_live = true;
+            vp_pending = false;
+            last_p = p;
+            x_stale = true;
+            x_invalid = p.flags & F_NO_X;
+            prev_in_alt = false;
         } else {
             // the new iterate lives in the alternate buffers: swap roles
             std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
             std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
+            vp_pending = false;
             last_p = p;
             x_stale = true;
             x_invalid = p.flags & F_NO_X;
@@ -1150,6 +1261,7 @@ template <typename T> struct Csc : CscBase {
         }
         t_ready = emit;
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
+        fused_epoch = touch_epoch;
     }
 
     // ---- device-driven solve (include/sporco_amd.h: sporco_amd_csc_admm_run) -----------------
@@ -1160,13 +1272,19 @@ template <typename T> struct Csc : CscBase {
     }
 
     // one iteration of admm_iter_fused with every iteration-dependent scalar taken from ctl_dev
-    int64_t enqueue_iter_ctl(const sporco_amd_admm_params &p) {
-        T *Y = rv(SPORCO_AMD_VAR_Y), *U = rv(SPORCO_AMD_VAR_U);
+    // vout set: the single-array state of csc_rows.h -- the iterate is read from vin (null: from
+    // (Y, U), the first iteration of such a run) and V' is written to vout
+    int64_t enqueue_iter_ctl(const sporco_amd_admm_params &p, const T *vin = nullptr,
+                             T *vout = nullptr) {
+        T *Y = vin ? nullptr : static_cast<T *>(vars[SPORCO_AMD_VAR_Y]);
+        T *U = vin ? nullptr : static_cast<T *>(vars[SPORCO_AMD_VAR_U]);
         cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
         {
             RowsFwdArgs<T> ra;
             ra.y = Y;
             ra.u = U;
+            ra.v = vin;
+            ra.flags = p.flags;
             ra.s2 = T(1);
             ra.t = Xf;
             ra.Ks = Ks;
@@ -1177,7 +1295,7 @@ template <typename T> struct Csc : CscBase {
             ra.K = K;
             ra.P = P;
             ra.ctl = ctl_dev;
-            ProfScope ps(prof, PS_ROWS_FWD);
+            ProfScope ps(prof, vin ? PS_ROWS_FWD_V : PS_ROWS_FWD);
             launch_rows_fwd<T>(st, ra);
         }
         {
@@ -1216,6 +1334,8 @@ template <typename T> struct Csc : CscBase {
         pa.u = U;
         pa.y_out = y_alt;
         pa.u_out = u_alt;
+        pa.v_in = vin;
+        pa.v_out = vout;
         pa.x = nullptr;
         pa.scale = T(1.0 / ((double)H * (double)W));
         pa.rlx = (T)p.rlx;
@@ -1238,16 +1358,18 @@ template <typename T> struct Csc : CscBase {
         pa.ctl = ctl_dev;
         int64_t nt = 0;
         if (!run_always_emit) {
-            ProfScope ps(prof, PS_ROWS_INV_POST);
+            ProfScope ps(prof, vin ? PS_ROWS_INV_POST_V : PS_ROWS_INV_POST);
             nt = launch_rows_inv_post<T>(st, pa);
         }
         pa.t_next = Xf;
         {
-            ProfScope ps(prof, PS_ROWS_INV_POST_EMIT);
+            ProfScope ps(prof, vin ? PS_ROWS_INV_POST_V_EMIT : PS_ROWS_INV_POST_EMIT);
             nt = launch_rows_inv_post<T>(st, pa);
         }
-        std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
-        std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
+        if (!vout) {
+            std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
+            std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
+        }
         return nt;
     }
 
@@ -1266,6 +1388,17 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMalloc((void **)&y_alt, sizeof(T) * E));
             SA_HIP(hipMalloc((void **)&u_alt, sizeof(T) * E));
         }
+        // Single-array state (csc_rows.h) for runs of several iterations: the epilogue stores
+        // V' = AX + U alone, rows_fwd and the next epilogue derive (Y, U) from it.  A run of a
+        // few iterations (a dictionary-learning X-step) stays in the (Y, U) form: it would pay
+        // the conversion back at once.
+        const bool nn = p.flags & F_NONNEG;
+        if (v_live && (!vform_ok(p) || nn != v_nonneg)) ensure_yu();
+        const bool vf = vform_ok(p) && (v_live || c.max_iter >= 4);
+        if (!vf) ensure_yu();
+        const bool v_at_entry = v_live;
+        T *const v_entry = v_cur;
+        const T v_entry_thr = v_thr;
         if (!ctl_dev) SA_HIP(hipMalloc((void **)&ctl_dev, sizeof(AdmmCtl)));
         if (rec_cap < c.max_iter) {
             if (rec_ring) SA_HIP(hipHostFree(rec_ring));
@@ -1296,6 +1429,7 @@ template <typename T> struct Csc : CscBase {
         in.autoscaling = c.auto_scaling;
         in.stdres = c.std_residuals;
         in.need_resid = c.need_residuals;
+        in.thr_prev = v_at_entry ? (float)v_entry_thr : 0.f;
         in.no_speculation = (std::getenv("SPORCO_AMD_NO_SPECULATION") ||
                              ((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT")))
                                 ? 1
@@ -1329,8 +1463,12 @@ template <typename T> struct Csc : CscBase {
                 ++done;
             }
         };
+        T *vb_in = v_at_entry ? v_entry : nullptr;     // V form: input of the next enqueued iteration
+        T *const vb_first = vf ? (vb_in == y_alt ? u_alt : y_alt) : nullptr;   // output of the first
         auto enqueue_one = [&]() {
-            const int64_t nt = enqueue_iter_ctl(p);
+            T *vb_out = vf ? (vb_in == y_alt ? u_alt : y_alt) : nullptr;
+            const int64_t nt = enqueue_iter_ctl(p, vb_in, vb_out);
+            vb_in = vb_out;
             if (want_sums) {
                 const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
                                       SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
@@ -1374,10 +1512,29 @@ template <typename T> struct Csc : CscBase {
         poll(enq, false);
         const int n = stop_at >= 0 ? stop_at + 1 : enq;
         // launches enqueued after the stopping iteration did nothing: undo their buffer swaps
-        if ((enq - n) & 1) {
+        if (!vf && ((enq - n) & 1)) {
             std::swap(vars[SPORCO_AMD_VAR_Y], reinterpret_cast<void *&>(y_alt));
             std::swap(vars[SPORCO_AMD_VAR_U], reinterpret_cast<void *&>(u_alt));
         }
+        if (vf) {
+            // iteration j wrote its V' to vb_first (j even) or to the other alt buffer (j odd);
+            // thresholds as the control block formed them: (float)(lambda / rho of the iteration)
+            T *other_first = vb_first == y_alt ? u_alt : y_alt;
+            v_cur = ((n - 1) & 1) ? other_first : vb_first;
+            v_thr = (T)(p.lmbda / rec_ring[n - 1].rho);
+            if (n >= 2) {
+                v_prev_kind = 2;
+                v_prev_thr = (T)(p.lmbda / rec_ring[n - 2].rho);
+            } else if (v_at_entry) {
+                v_prev_kind = 2;
+                v_prev_thr = v_entry_thr;
+            } else {
+                v_prev_kind = 1;
+            }
+            v_nonneg = nn;
+            v_live = true;
+        }
+        vp_pending = false;
         AdmmCtl fin;
         SA_HIP(hipMemcpy(&fin, ctl_dev, sizeof(AdmmCtl), hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) {
@@ -1405,7 +1562,7 @@ template <typename T> struct Csc : CscBase {
         last_p.u_scale = rec_ring[n - 1].u_scale;
         x_stale = true;
         x_invalid = p.flags & F_NO_X;
-        prev_in_alt = true;
+        prev_in_alt = !vf;
         return n;
     }
 
@@ -1436,10 +1593,14 @@ template <typename T> struct Csc : CscBase {
         launch_rows_inv_prox_fwd<T>(st, ra);
     }
 
-    void launch_rows_fwd_on(const T *Yin, const T *Uin, T s2) {
+    void launch_rows_fwd_on(const T *Yin, const T *Uin, T s2, const T *Vin = nullptr,
+                            T thr_prev = T(0), uint32_t flags = 0) {
         RowsFwdArgs<T> ra;
         ra.y = Yin;
         ra.u = Uin;
+        ra.v = Vin;
+        ra.thr_prev = thr_prev;
+        ra.flags = flags;
         ra.s2 = s2;
         ra.t = cv(SPORCO_AMD_VAR_XF);
         ra.Ks = Ks;
@@ -1449,7 +1610,7 @@ template <typename T> struct Csc : CscBase {
         ra.CN = CN;
         ra.K = K;
         ra.P = P;
-        ProfScope ps(prof, PS_ROWS_FWD);
+        ProfScope ps(prof, Vin ? PS_ROWS_FWD_V : PS_ROWS_FWD);
         launch_rows_fwd<T>(st, ra);
     }
 

@@ -108,6 +108,10 @@ template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &
 // Staged pieces (each mirrors one overridable method of the reference class).
 template <typename T>
 void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t n);   // relax_AX
+// the (Y, U) pair of an iterate kept as V = AX + U (csc_rows.h): Y = prox_l1(V; thr) (+ NonNeg),
+// U = V - Y; y or u may be null, u may alias v
+template <typename T>
+void launch_vform_split(hipStream_t st, const T *v, T *y, T *u, T thr, bool nonneg, int64_t n);
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
                   uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
@@ -358,6 +362,7 @@ int launch_cg_update_xr(hipStream_t st, const CgCtl *c, T alpha_host, cx<T> *x, 
 struct AdmmCtl {
     // read by the iteration kernels
     float rho_f, thr_f, u_scale_f, thr21_f;
+    float thr_prev_f, thr21_prev_f;   // thr_f / thr21_f of the previous iteration (V form: csc_rows.h)
     int skip_fwd;      // T already holds rows_fwd of the current iterate (emitted, rho unchanged)
     int emit;          // this iteration's epilogue also emits the next iteration's T
     int stop;          // stopping test met: every later launch returns at once
@@ -385,6 +390,7 @@ struct AdmmCtlInit {
     double rho, u_scale, lmbda, abstol, reltol, sqrt_nc, sqrt_nx, tau, mu, xi, mu21;
     int k, stable_run, emitted, is_f32, autorho, period, autoscaling, stdres, need_resid,
         no_speculation;
+    float thr_prev = 0.f, thr21_prev = 0.f;   // thresholds that produced an incoming V-form iterate
 };
 void launch_admm_ctl_init(hipStream_t st, AdmmCtl *ctl, const AdmmCtlInit &in);
 // sums: the 16 output slots of the iteration in device memory (already all-reduced when the

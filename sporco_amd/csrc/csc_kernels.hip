@@ -702,6 +702,29 @@ void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t 
     SA_HIP(hipGetLastError());
 }
 
+// (Y, U) of an iterate kept in the single-array form of csc_rows.h: Y = prox_l1(V; thr)
+// (+ NonNeg), U = V - Y, element for element the operations of the row epilogue.  y or u may be
+// null; u may alias v (each element is read, then written, by one thread).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) vform_split_kernel(const T *v, T *y, T *u, T thr,
+                                                               int nonneg, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T vv = v[i];
+        T yy = soft(vv, thr);
+        if (nonneg && yy < T(0)) yy = T(0);
+        if (y) y[i] = yy;
+        if (u) u[i] = vv - yy;
+    }
+}
+
+template <typename T>
+void launch_vform_split(hipStream_t st, const T *v, T *y, T *u, T thr, bool nonneg, int64_t n) {
+    hipLaunchKernelGGL((vform_split_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, v, y, u, thr,
+                       nonneg ? 1 : 0, n);
+    SA_HIP(hipGetLastError());
+}
+
 template <typename T> struct YstepArgs {
     const T *ax;
     const T *u;
@@ -2624,6 +2647,8 @@ __global__ void admm_ctl_init_kernel(AdmmCtl *c, const AdmmCtlInit in) {
     c->stop = 0;
     c->t0 = sa_wall_clock();
     admm_ctl_derive(c);
+    c->thr_prev_f = in.thr_prev;
+    c->thr21_prev_f = in.thr21_prev;
 }
 
 // The arithmetic below restates, operation by operation, sporco_amd/admm/cbpdn.py
@@ -2699,6 +2724,8 @@ __global__ void admm_ctl_update_kernel(AdmmCtl *c, const double *sums, AdmmRecor
     c->emitted = c->emit;
     c->k = c->k + 1;
     c->stop = stop;
+    c->thr_prev_f = c->thr_f;       // (of the iteration just finished)
+    c->thr21_prev_f = c->thr21_f;
     admm_ctl_derive(c);
     sa_fence_system();
     rec->seq = index + 1;
@@ -2733,6 +2760,7 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
                                      int, double *);                                               \
     template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *);                \
     template void launch_relax<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
+    template void launch_vform_split<T>(hipStream_t, const T *, T *, T *, T, bool, int64_t);       \
     template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \
                                   Dims5, int, int, Weight<T>, Weight<T>, Weight<T>, int);          \
     template void launch_ustep<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \

@@ -8,6 +8,19 @@
 //   fused_cols     T                    -> T   csc_fused.h                 (2 passes)
 //   rows_inv_post  T, Y, U [, X]        -> Y, U [, X] + reduction partials (5 passes)
 //
+// Single-array state ("V form").  The epilogue forms V' = AX + U, Y' = prox(V'), U' = V' - Y':
+// the new iterate is a function of V' alone.  Storing V' instead of (Y', U') and re-deriving
+// Y, U from V wherever they are read (here and in rows_fwd) takes the iteration from ten
+// X-sized passes to seven (six when the epilogue also emits the next row spectra):
+//
+//   rows_fwd       V                    -> T                               (2 passes)
+//   fused_cols     T                    -> T                               (2 passes)
+//   rows_inv_post  T, V                 -> V' [, T']                       (3 [4] passes)
+//
+// with iterates identical, bit for bit, to the (Y, U) form.  The API layer (csc_api.hip)
+// switches a handle into this form for runs of several iterations and materialises Y, U
+// (and the previous iterate) when anything else needs them.
+//
 // rows_inv_post fuses irfft along W (the second half of irfftn in
 // GenericConvBPDN.xstep, cbpdn.py:281) with relax_AX (admm.py:877-885), the
 // l1 shrinkage ystep (cbpdn.py:614-620, :297-311), ustep (admm.py:434-437) and
@@ -31,6 +44,13 @@ template <typename T> struct RowsFwdArgs {
     const cx<T> *twA;  // [NW][32]: exp(-2 pi i w brev5(i) / W)   (rows_twiddles)
     int H, W, CN, K;
     int64_t P;
+    // Single-array state (csc_rows.h, "V form"): when set, y and u are not read; the iterate is
+    // derived from V = AX + U of the iteration that produced it, Y = prox(V; thr_prev) (+ NonNeg),
+    // U = V - Y -- the very operations that produced Y and U from V in the epilogue, so the
+    // values are those a stored (Y, U) pair would hold, for one read pass instead of two.
+    const T *v = nullptr;
+    T thr_prev = T(0);     // lambda / rho of the iteration that produced v (ctl: ctl->thr_prev_f)
+    uint32_t flags = 0;    // F_NONNEG (the derivation repeats the clamp)
     int y_bcast = 0;   // y is (H, W, K), broadcast over the CN blocks (consensus D-step)
     int Ks = 0;        // row stride of t in filters when it is not K (0: K), see csc_fused.h
     // device-driven solve (csc_kernels.h AdmmCtl): s2 is ctl->u_scale_f, and the launch returns
@@ -49,6 +69,16 @@ template <typename T> struct RowsPostArgs {
     const T *y, *u;    // in: real (H, W, P)
     T *y_out, *u_out;  // out (may alias y, u: every element is read and written by one thread)
     T *x;              // out (optional, may be null): X = irfftn(Xf)
+    // Single-array state ("V form", plain epilogue only: scalar weights, no X output):
+    //   v_out  the epilogue stores V' = AX + U (scaled) instead of Y' and U' -- both are
+    //          functions of V' alone (Y' = prox(V'), U' = V' - Y'), so one array carries the
+    //          iterate: one write pass instead of two;
+    //   v_in   the previous iterate arrives the same way (y, u are not read): Y = prox(V;
+    //          thr_prev) (+ NonNeg), U = V - Y, recomputed per element -- one read pass instead
+    //          of two.  Same arithmetic as the (Y, U) form, operation by operation.
+    const T *v_in = nullptr;
+    T *v_out = nullptr;
+    T thr_prev = T(0);     // lambda / rho of the iteration that produced v_in (ctl: thr_prev_f)
     T scale;           // 1 / (H W)
     T rlx, thr, u_scale;
     T thr21 = T(0);    // F_JOINT: mu / rho, the l2,1 threshold of prox_sl1l2 (cbpdn.py:785-794)

@@ -284,14 +284,21 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // rows_fwd: T = rfft_W(Y - s2 U), tile-major
 // ---------------------------------------------------------------------------
 // One tile (image row `h`, 128-column block `bx`) of rows_fwd.
-template <int NW, bool BCAST, typename AP>
+// VFORM: the iterate arrives as V = AX + U of the iteration that produced it (csc_rows.h):
+// Y = prox(V; thr_prev) (+ NonNeg), U = V - Y per element, then Y - s2 U as before.
+template <int NW, bool BCAST, bool VFORM, typename AP>
 __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     constexpr int N1 = kN1, W = N1 * NW;
+    static_assert(!(BCAST && VFORM), "the broadcast form reads a dictionary-sized Y");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
-    float s2 = a->s2;
-    if (a->ctl) s2 = a->ctl->u_scale_f;       // device-driven solve
+    float s2 = a->s2, thr_p = a->thr_prev;
+    if (a->ctl) {       // device-driven solve
+        s2 = a->ctl->u_scale_f;
+        thr_p = a->ctl->thr_prev_f;
+    }
+    const bool nonneg = VFORM && (a->flags & F_NONNEG);
     const int64_t p = (int64_t)bx * 128 + 2 * lane;
     const bool pv = p < a->P;
     const int cn = pv ? (int)(p / a->K) : 0, k = pv ? (int)(p % a->K) : 0;
@@ -307,7 +314,8 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     const BufRsrc Yb = BCAST ? make_rsrc(a->y + (int64_t)h * W * a->K,
                                          (uint32_t)((int64_t)W * a->K * sizeof(float)))
                              : make_rsrc(a->y + rowoff, rowbytes);
-    const BufRsrc Ub = a->u ? make_rsrc(a->u + rowoff, rowbytes) : make_rsrc(a->y, 0u);
+    const BufRsrc Ub = VFORM ? make_rsrc(a->v + rowoff, rowbytes)
+                             : (a->u ? make_rsrc(a->u + rowoff, rowbytes) : make_rsrc(a->y, 0u));
     const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;  // masked lanes read 0
     const int pixbytes = (int)(a->P * (int64_t)sizeof(float));
     const int yvoff = BCAST ? (pv ? k * (int)sizeof(float) : (int)0x80000000) : voff;
@@ -320,8 +328,19 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
         for (int i = 0; i < N1 / 2; ++i) {
             const int n1 = half * (N1 / 2) + i;
             const int soff = (NW * n1 + w) * pixbytes;
-            yv[i] = buf_load_cf(Yb, yvoff, (NW * n1 + w) * ypixbytes);
+            if constexpr (!VFORM) yv[i] = buf_load_cf(Yb, yvoff, (NW * n1 + w) * ypixbytes);
             uv[i] = buf_load_cf(Ub, voff, soff);
+        }
+        if constexpr (VFORM) {
+#pragma unroll
+            for (int i = 0; i < N1 / 2; ++i) {
+                const cf vv = uv[i];
+                float y0 = soft1(vv.re, thr_p), y1 = soft1(vv.im, thr_p);
+                if (nonneg && y0 < 0.f) y0 = 0.f;
+                if (nonneg && y1 < 0.f) y1 = 0.f;
+                yv[i] = mk<float>(y0, y1);
+                uv[i] = mk<float>(vv.re - y0, vv.im - y1);
+            }
         }
 #pragma unroll
         for (int i = 0; i < N1 / 2; ++i)
@@ -352,13 +371,13 @@ __device__ __forceinline__ void rows_tile_loop(const A &a_in, int tiles_x, int t
     }
 }
 
-template <int NW, bool BCAST>
+template <int NW, bool BCAST, bool VFORM = false>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a_in) {
     // device-driven solve: nothing to do once the stopping test is met, or when the previous
     // epilogue already left this spectrum behind
     if (a_in.ctl && (a_in.ctl->stop | a_in.ctl->skip_fwd)) return;
     rows_tile_loop(a_in, (int)((a_in.P + 127) / 128), a_in.H,
-                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST>(a, bx, h); });
+                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM>(a, bx, h); });
 }
 
 // ---------------------------------------------------------------------------
@@ -366,18 +385,22 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // ---------------------------------------------------------------------------
 // MODE: 0 = plain epilogue; 1 = L1Weight array (+ NoBndryCross, AddMaskSim); 2 = NoBndryCross
 // and / or AddMaskSim without a weight array (no weight loads).
-template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT, typename AP>
+// SF (state form, csc_rows.h): 0 = (Y, U) in and out; 1 = (Y, U) in, V' out; 2 = V in, V' out.
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT, int SF, typename AP>
 __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tiles_x) {
     constexpr bool GENERAL = MODE != 0;
+    constexpr bool VIN = SF == 2, VOUT = SF != 0;
     static_assert(!JOINT || MODE == 0, "the joint epilogue takes scalar weights only");
+    static_assert(SF == 0 || (MODE == 0 && !WRITE_X && !JOINT), "V form: plain epilogue only");
     constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
-    float thr = a->thr, usc = a->u_scale;
+    float thr = a->thr, usc = a->u_scale, thr_p = a->thr_prev;
     if (a->ctl) {     // device-driven solve
         thr = a->ctl->thr_f;
         usc = a->ctl->u_scale_f;
+        thr_p = a->ctl->thr_prev_f;
     }
     // columns of this thread: 128 consecutive ones of (c, n, k) per workgroup -- or, JOINT,
     // (channel lane >> 4, image blockIdx / (K/32), filters 32 (blockIdx % (K/32)) + 2 (lane & 15))
@@ -408,8 +431,11 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a->P;
     const uint32_t rowbytes = (uint32_t)((int64_t)W * a->P * sizeof(float));
-    const BufRsrc Yb = make_rsrc(a->y + rowoff, rowbytes), Ub = make_rsrc(a->u + rowoff, rowbytes);
-    const BufRsrc Yo = make_rsrc(a->y_out + rowoff, rowbytes), Uo = make_rsrc(a->u_out + rowoff, rowbytes);
+    // (V form: the one input array through Yb, the one output array through Yo)
+    const BufRsrc Yb = make_rsrc((VIN ? a->v_in : a->y) + rowoff, rowbytes);
+    const BufRsrc Ub = VIN ? Yb : make_rsrc(a->u + rowoff, rowbytes);
+    const BufRsrc Yo = make_rsrc((VOUT ? a->v_out : a->y_out) + rowoff, rowbytes);
+    const BufRsrc Uo = VOUT ? Yo : make_rsrc(a->u_out + rowoff, rowbytes);
     const BufRsrc Xb = make_rsrc(WRITE_X ? a->x + rowoff : a->y_out + rowoff, rowbytes);
     const int voff = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;
     const int pixbytes = (int)(a->P * (int64_t)sizeof(float));
@@ -443,14 +469,15 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     const float l21w = lane < 16 ? 1.f : 0.f;  // the l2,1 sum counts each channel group once
     // pixels per batch (Y, U of the next batch are in flight); the emitting variants keep the
     // tile for the forward transform and have fewer registers to spare
-    constexpr int B = EMIT_T ? (JOINT ? 1 : 2) : 4;
+    // (V form reads one array instead of two: twice the pixels per batch for the same registers)
+    constexpr int B = EMIT_T ? (JOINT ? 1 : (VIN ? 4 : 2)) : 4;
     cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll
         for (int i = 0; i < B; ++i) {
             const int soff = (NW * (b * B + i) + w) * pixbytes;
             yb[slot][i] = buf_load_cf(Yb, voff, soff);
-            ub[slot][i] = buf_load_cf(Ub, voff, soff);
+            if constexpr (!VIN) ub[slot][i] = buf_load_cf(Ub, voff, soff);
         }
     };
     fetch(0, 0);
@@ -463,9 +490,24 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             const int xw = NW * n1 + w;
             const int soff = xw * pixbytes;
             const float xs[2] = {v[n1].re * scale, v[n1].im * scale};
-            const float yo[2] = {yb[b & 1][i].re, yb[b & 1][i].im};
-            const float uo[2] = {usc * ub[b & 1][i].re, usc * ub[b & 1][i].im};
-            float yn[2], un[2];
+            float yo[2] = {yb[b & 1][i].re, yb[b & 1][i].im};
+            float uraw[2];
+            if constexpr (VIN) {
+                // the previous iterate from its V: Y = prox(V; thr_prev) (+ NonNeg), U = V - Y
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float vp = yo[e];
+                    float yp = soft1(vp, thr_p);
+                    if (nonneg && yp < 0.f) yp = 0.f;
+                    yo[e] = yp;
+                    uraw[e] = vp - yp;
+                }
+            } else {
+                uraw[0] = ub[b & 1][i].re;
+                uraw[1] = ub[b & 1][i].im;
+            }
+            const float uo[2] = {usc * uraw[0], usc * uraw[1]};
+            float yn[2], un[2], vn[2] = {0.f, 0.f};
             // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
             // epilogue into dozens of blocks and the register allocator spills the tile)
             const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
@@ -478,13 +520,14 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float ax = al * xs[e] + oma * yo[e];
-                    const float sv = soft1(ax + uo[e], thr);
+                    const float vv = ax + uo[e];
+                    const float sv = soft1(vv, thr);
                     const float q = sum_over_rows(sv * sv);
                     float fac = 1.f - thr21 * sa_rsq(q);      // (q = 0: -inf, or NaN when thr21 = 0)
                     fac = fac > 0.f ? fac : 0.f;
                     float y1 = fac * sv;
                     if (nonneg && y1 < 0.f) y1 = 0.f;
-                    const float u1 = uo[e] + ax - y1;
+                    const float u1 = vv - y1;
                     yn[e] = y1;
                     un[e] = u1;
                     const float dr = xs[e] - y1, ds = y1 - yo[e];
@@ -512,12 +555,16 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                     wt = wrow[wlane + e * ws4];
                 }
                 if (GENERAL) wt = am ? 0.f : wt;
-                float y1 = soft1(ax + uo[e], thr * wt);
+                // V' = AX + U: the new iterate is a function of it alone (Y' = prox(V'),
+                // U' = V' - Y'), which is what the V form stores
+                const float vv = ax + uo[e];
+                float y1 = soft1(vv, thr * wt);
                 if (nonneg && !am && y1 < 0.f) y1 = 0.f;
                 if (GENERAL) y1 *= am ? mkeep : keep;
-                const float u1 = uo[e] + ax - y1;
+                const float u1 = vv - y1;
                 yn[e] = y1;
                 un[e] = u1;
+                vn[e] = vv;
                 const float dr = xs[e] - y1, ds = y1 - yo[e];
                 s_r2 += dr * dr;
                 s_s2 += ds * ds;
@@ -527,8 +574,12 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 s_l1 += fabsf(wt * (gy ? y1 : xs[e]));
             }
             }
-            buf_store_cf(Yo, voff, soff, mk<float>(yn[0], yn[1]));
-            buf_store_cf(Uo, voff, soff, mk<float>(un[0], un[1]));
+            if constexpr (VOUT) {
+                buf_store_cf(Yo, voff, soff, mk<float>(vn[0], vn[1]));
+            } else {
+                buf_store_cf(Yo, voff, soff, mk<float>(yn[0], yn[1]));
+                buf_store_cf(Uo, voff, soff, mk<float>(un[0], un[1]));
+            }
 
             if (WRITE_X) buf_store_cf(Xb, voff, soff, mk<float>(xs[0], xs[1]));
             if (EMIT_T) v[n1] = mk<float>(yn[0] - un[0], yn[1] - un[1]);
@@ -557,7 +608,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     block_sum_store<8>(acc, scratch, a->partials + tile * 8);
 }
 
-template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false>
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false, int SF = 0>
 __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a_in) {
     // device-driven solve: both variants are enqueued every iteration and the one whose EMIT_T
     // matches the speculation decision runs (an idle launch costs about 12 us; the emitting
@@ -566,7 +617,7 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
     if (a_in.ctl && (a_in.ctl->stop | (a_in.ctl->emit != (EMIT_T ? 1 : 0)))) return;
     const int tiles_x = JOINT ? a_in.N * (a_in.K >> 5) : (int)((a_in.P + 127) / 128);
     rows_tile_loop(a_in, tiles_x, a_in.H, [tiles_x](auto a, int bx, int h) {
-        rows_inv_post_tile<NW, WRITE_X, MODE, EMIT_T, JOINT>(a, bx, h, tiles_x);
+        rows_inv_post_tile<NW, WRITE_X, MODE, EMIT_T, JOINT, SF>(a, bx, h, tiles_x);
     });
 }
 
@@ -714,18 +765,25 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
         set_lds_attr<4>(&rows_fwd_kernel<4, true>);
         set_lds_attr<8>(&rows_fwd_kernel<8, true>);
         set_lds_attr<16>(&rows_fwd_kernel<16, true>);
+        set_lds_attr<4>(&rows_fwd_kernel<4, false, true>);
+        set_lds_attr<8>(&rows_fwd_kernel<8, false, true>);
+        set_lds_attr<16>(&rows_fwd_kernel<16, false, true>);
         attr_set = true;
     }
+    SA_REQUIRE(!(a.v && a.y_bcast), "the broadcast row pass has no V form");
     // (measured at config 2: the tile loop gains nothing for this kernel)
     const dim3 grid = rows_grid(a, a.W / kN1, ceil_div(a.P, 128), a.H, 0);
     if (a.W == 128) {
         if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<4, true>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
+        else if (a.v) hipLaunchKernelGGL((rows_fwd_kernel<4, false, true>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
         else hipLaunchKernelGGL((rows_fwd_kernel<4, false>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
     } else if (a.W == 256) {
         if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<8, true>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
+        else if (a.v) hipLaunchKernelGGL((rows_fwd_kernel<8, false, true>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
         else hipLaunchKernelGGL((rows_fwd_kernel<8, false>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
     } else {
         if (a.y_bcast) hipLaunchKernelGGL((rows_fwd_kernel<16, true>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+        else if (a.v) hipLaunchKernelGGL((rows_fwd_kernel<16, false, true>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
         else hipLaunchKernelGGL((rows_fwd_kernel<16, false>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
     }
     SA_HIP(hipGetLastError());
@@ -755,11 +813,20 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 gr
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 1, EMIT>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 2, EMIT>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 2, EMIT>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, false, 1>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, false, 2>);
         attr_set = true;
     }
     const int mode = a.wl1.ptr != nullptr ? 1 : (((a.flags & F_NOBNDRY) || a.ams_bits) ? 2 : 0);
     const dim3 block(NW * 64);
     const size_t lds = rows_lds_bytes(NW);
+    if (a.v_out) {      // single-array state (csc_rows.h)
+        SA_REQUIRE(mode == 0 && !a.x, "the V form serves the plain epilogue only");
+        if (a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, false, 2>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, false, 1>), grid, block, lds, st, a);
+        return;
+    }
+    SA_REQUIRE(!a.v_in, "a V-form input needs a V-form output");
     if (a.x) {
         if (mode == 1) hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, 1, EMIT>), grid, block, lds, st, a);
         else if (mode == 2) hipLaunchKernelGGL((rows_inv_post_kernel<NW, true, 2, EMIT>), grid, block, lds, st, a);
@@ -825,6 +892,7 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     if (a.flags & F_JOINT) {
+        SA_REQUIRE(!a.v_in && !a.v_out, "the joint epilogue has no V form");
         SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && !a.wl1.ptr && !a.ams_bits &&
                        !(a.flags & F_NOBNDRY) && !a.x,
                    "configuration not handled by the joint row epilogue");

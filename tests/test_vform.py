@@ -1,0 +1,138 @@
+"""The single-array state of the fused ADMM iteration (csc_rows.h, "V form").
+
+The row epilogue forms V' = AX + U (scaled), Y' = prox(V'), U' = V' - Y' (sporco/admm/cbpdn.py:
+614-620, sporco/prox/_lp.py:144-183, sporco/admm/admm.py:434-437): the new iterate is a
+function of V' alone, so runs of several fused iterations store V' instead of (Y', U') and
+derive Y, U from it wherever they are read -- seven X-sized passes per iteration instead of
+ten.  The contract tested here: iterates (Y, U, X, Yprev, AX), statistics and stopping
+iterations are IDENTICAL, bit for bit, to the (Y, U) form of the same library
+(SPORCO_AMD_NO_VFORM=1), which the fixtures of test_admm_cbpdn.py / test_fused_xstep.py /
+test_parity_baseline_shapes.py pin to the reference; plus the float64 oracle directly.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+from test_fused_xstep import problem
+
+FIELDS = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho')
+
+
+def run(D, S, optd, vform, host=False, lmbda=0.05, calls=1, cls=None):
+    from sporco_amd import _lib
+    from sporco_amd.admm import cbpdn
+    env = {}
+    if not vform:
+        env['SPORCO_AMD_NO_VFORM'] = '1'
+    if host:
+        env['SPORCO_AMD_HOST_LOOP'] = '1'
+    os.environ.update(env)
+    try:
+        b = cbpdn.ConvBPDN(D, S, lmbda, cbpdn.ConvBPDN.Options(optd))
+        live = []
+        for _ in range(calls):
+            b._return_min = False         # (solve() without fetching Y: the state stays put)
+            b.solve()
+            live.append(b._dev.query(_lib.QUERY_VFORM_LIVE))
+        out = dict(Y=b.Y.copy(), U=b.U.copy(), X=b.X.copy(), Yprev=b._fetch(_lib.VAR_YPREV).copy(),
+                   AX=b._fetch(_lib.VAR_AX).copy(), k=b.k, live=live,
+                   stats={f: np.asarray(getattr(b.getitstat(), f), float) for f in FIELDS}
+                   if b.itstat else {})
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    return b, out
+
+
+def same(o0, o1):
+    assert o0['k'] == o1['k']
+    for f in ('Y', 'U', 'X', 'Yprev', 'AX'):
+        assert np.array_equal(o0[f], o1[f]), f
+    assert sorted(o0['stats']) == sorted(o1['stats'])
+    for f in o0['stats']:
+        assert np.array_equal(o0['stats'][f], o1['stats'][f], equal_nan=True), f
+
+
+CASES = {
+    'default': {'MaxMainIter': 9, 'RelStopTol': 0.0},
+    'nonneg_period3': {'MaxMainIter': 8, 'RelStopTol': 0.0, 'NonNegCoef': True,
+                       'AutoRho': {'Period': 3}},
+    'fixed_rho_fast': {'MaxMainIter': 7, 'RelStopTol': 0.0, 'FastSolve': True,
+                       'AutoRho': {'Enabled': False}, 'rho': 2.5},
+    'rlx1_std': {'MaxMainIter': 6, 'RelStopTol': 0.0, 'RelaxParam': 1.0,
+                 'AutoRho': {'StdResiduals': True}},
+    'stops_at_once': {'MaxMainIter': 12, 'RelStopTol': 10.0},          # one iteration
+    'stops_early': {'MaxMainIter': 40, 'RelStopTol': 5e-2},
+}
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+@pytest.mark.parametrize('host', [False, True])
+def test_v_form_is_bit_identical_to_the_yu_form(backend, case, host):
+    H = 256 if backend == 'gpu' else 128
+    K, N = (16, 3) if backend == 'gpu' else (4, 2)
+    D, S = problem(H, H, K, N, seed=11)
+    optd = CASES[case]
+    b0, o0 = run(D, S, optd, vform=False, host=host)
+    b1, o1 = run(D, S, optd, vform=True, host=host)
+    assert b1._dev.uses_fused_rows()
+    assert o0['live'] == [0]
+    # the device-driven run enters the V form at once (MaxMainIter >= 4); the host-driven loop
+    # from its second iteration on
+    if o1['k'] >= 2 or not host:
+        assert o1['live'] == [1], (case, host, o1['k'])
+    same(o0, o1)
+
+
+def test_v_form_survives_restarts_and_reads_in_between(backend):
+    """solve() three times on one object (the second call starts from the V left by the first);
+    reading Y between calls takes the handle back to the (Y, U) form and on again."""
+    H = 256 if backend == 'gpu' else 128
+    D, S = problem(H, H, 4, 2, seed=12)
+    optd = {'MaxMainIter': 5, 'RelStopTol': 0.0}
+    b0, o0 = run(D, S, optd, vform=False, calls=3)
+    b1, o1 = run(D, S, optd, vform=True, calls=3)
+    assert o1['live'] == [1, 1, 1] and o1['k'] == 15
+    same(o0, o1)
+    from sporco_amd import _lib
+    from sporco_amd.admm import cbpdn
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    for _ in range(3):
+        Y = b.solve()                     # (fetches Y: back to (Y, U))
+        assert b._dev.query(_lib.QUERY_VFORM_LIVE) == 0
+    assert np.array_equal(Y, o0['Y']) and np.array_equal(b.U, o0['U'])
+    assert np.array_equal(b.X, o0['X'])
+
+
+def test_v_form_against_the_oracle(backend):
+    from oracle import cbpdn_oracle as orc
+    H = 256 if backend == 'gpu' else 128
+    K, N = 8, 2
+    D, S = problem(H, H, K, N, seed=13)
+    optd = {'MaxMainIter': 12, 'RelStopTol': 0.0}
+    b, o = run(D, S, optd, vform=True)
+    assert o['live'] == [1]
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, H, 1, N, 1), 0.05,
+                         dtype=np.float64, maxiter=12, rel_tol=0.0)
+    assert rel_l2(o['Y'], ref['Y']) < 1e-4
+    assert rel_l2(o['U'], ref['U']) < 1e-4
+    assert rel_l2(o['X'], ref['X']) < 1e-4
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(o['stats'][f], ref[f]) < 1e-3, f
+
+
+def test_options_outside_the_v_form_keep_the_yu_form(backend):
+    """Weight arrays / NoBndryCross / ConvBPDNJoint run the (Y, U) epilogues."""
+    from sporco_amd import _lib
+    from sporco_amd.admm import cbpdn
+    D, S = problem(128, 128, 4, 2, seed=14)
+    w = np.abs(np.random.RandomState(3).randn(128, 128, 1, 1, 4)).astype(np.float32)
+    for extra in ({'L1Weight': w}, {'NoBndryCross': True}):
+        optd = dict({'MaxMainIter': 5, 'RelStopTol': 0.0}, **extra)
+        b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+        b._return_min = False
+        b.solve()
+        assert b._dev.uses_fused_rows() and b._dev.query(_lib.QUERY_VFORM_LIVE) == 0

@@ -21,10 +21,13 @@ def counters(path, name):
 
 
 KERNELS = {      # bench.py's kernel names -> a substring of the dispatch name
-    'rows_fwd': 'rows_fwd_kernel<16, false>',
+    'rows_fwd': 'rows_fwd_kernel<16, false, false>',
+    'rows_fwd_v': 'rows_fwd_kernel<16, false, true>',
     'fused_cols_sm': 'fused_cols_kernel<32, 16, 1, 64, false, false, false, 0>',
-    'rows_inv_post': 'rows_inv_post_kernel<16, false, 0, false, false>',
-    'rows_inv_post_emit': 'rows_inv_post_kernel<16, false, 0, true, false>',
+    'rows_inv_post': 'rows_inv_post_kernel<16, false, 0, false, false, 0>',
+    'rows_inv_post_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 0>',
+    'rows_inv_post_v': 'rows_inv_post_kernel<16, false, 0, false, false, 2>',
+    'rows_inv_post_v_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 2>',
 }
 
 

@@ -17,4 +17,4 @@ for l in out.split('\n'):
     m = re.search(r'remark:\s+(\w[\w /\[\]]*): (\d+)', l)
     if m and name: rows[name][m.group(1).strip()] = int(m.group(2))
 for n, r in rows.items():
-    print('%-46s VGPR %3d SGPR %3d scratch %4d occ %d' % (n[:46], r.get('VGPRs', -1), r.get('TotalSGPRs', -1), r.get('ScratchSize [bytes/lane]', -1), r.get('Occupancy [waves/SIMD]', -1)))
+    print('%-60s VGPR %3d SGPR %3d scratch %4d occ %d' % (n[:60], r.get('VGPRs', -1), r.get('TotalSGPRs', -1), r.get('ScratchSize [bytes/lane]', -1), r.get('Occupancy [waves/SIMD]', -1)))
