@@ -35,7 +35,10 @@ template <typename T> struct PgmColsArgs {
     cx<T> *qpart = nullptr;   // K > 64 (fft_momentum runs per (tile, 64-filter slab), grid.y = slabs):
                           // with want_stats the slab's share of sum_k Df Xf' goes to
                           // qpart[tile][slab][f] and launch_pgm_stats_slabs forms the objective sums
-    double *partials;     // grad_ifft: [tile] sum |sum_k Df Yf - Sf|^2;
+    // persistent launch (H = 512, K = 64; csc_fused.h): workgroup slot s starts
+    // (s % stagger_groups) * stagger_sleeps * 8128 cycles late (set by the launchers)
+    int stagger_groups = 1, stagger_sleeps = 0;
+    double *partials;     // grad_ifft: [tile] sum |sum_k Df Yf - Sf|^2 (only with ey: a held trial);
                           // fft_momentum: [tile][6] pw*|Xf' - Yf|^2, pw*|e|^2, |e|^2,
                           //   Re<e - e_y, e_y> (= <Xf' - Yf, grad f(Yf)>, 0 without ey), |Xf' - Yf|^2, 0
 };

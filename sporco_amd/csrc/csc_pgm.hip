@@ -42,34 +42,47 @@ __device__ __forceinline__ void inner4(const cf (&d)[4], const cf *x, int lane, 
 // Vf = Yf - conj(Df) (sum_k Df Yf - Sf) / L;  T = IFFT_H(Vf)      (grad_f + the step,
 // sporco/pgm/cbpdn.py:263-279, sporco/pgm/pgm.py:800)
 // ---------------------------------------------------------------------------
-template <int NW, int LP, int KC>
+// BT: a held (backtracking) trial -- e_y = sum_k Df Yf - Sf is stored per frequency and f(Yf)
+// summed; the default iteration needs neither and compiles them out.
+// With 16 waves and K = 64 the launch is persistent (one workgroup per CU walking its XCD's
+// tile list, staggered start): see fused_cols_kernel, whose measurements carried over.
+template <int NW, int LP, int KC, bool BT, bool PERS = false>
 __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArgs<float> a) {
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    constexpr bool PERSIST = PERS;
+    static_assert(!PERS || (NW == 16 && KC == 64), "persistent form: 16 waves, K = 64");
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
     const int K = KC ? KC : a.K;
     const bool kv = KC == 64 ? true : k < K;
-    const int Wf = a.W / 2 + 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int wf = (slot / a.CN) * 8 + xcd;   // see fused_cols_kernel for the tile order
-    if (wf >= Wf) return;
-    const int tile = wf * a.CN + slot % a.CN;
-    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
-    const BufRsrc Yb = make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Ob = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
+    const int xcd = blockIdx.x & 7;
     const int ko = (w * K + k) * (int)sizeof(cf);   // row w, filter k
-    const cf *S = a.sft + (int64_t)tile * H + w;
-    cf *EY = a.ey ? a.ey + (int64_t)tile * H + w : nullptr;
-    const cf *twB = a.twB + w * N1;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
-    const float inv_L = a.inv_L;
     int token = 0;
+    if constexpr (PERSIST) {
+        const int ph = (int)(blockIdx.x >> 3) % a.stagger_groups;
+        for (int i = 0; i < ph * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    for (int slot = blockIdx.x >> 3;; slot += gridDim.x >> 3) {
+    SA_ARGS_PTR_T(PgmColsArgs<float>) ap = sa_args_reload<PERSIST>(a);
+    const int Wf = ap->W / 2 + 1, CN = ap->CN;
+    if (slot >= ((Wf + 7) / 8) * CN) break;
+    const int wf = (slot / CN) * 8 + xcd;   // see fused_cols_kernel for the tile order
+    if (wf >= Wf) break;
+    const int tile = wf * CN + slot % CN;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Yb = make_rsrc(ap->yf + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Ob = make_rsrc(ap->t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(ap->dft + (int64_t)wf * H * K, tbytes);
+    const cf *S = ap->sft + (int64_t)tile * H + w;
+    cf *EY = BT ? ap->ey + (int64_t)tile * H + w : nullptr;
+    const cf *twB = ap->twB + w * N1;
+    const float inv_L = ap->inv_L;
     float fsum = 0.f;
 
     cf v[N1];
@@ -99,8 +112,10 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const cf r = qq[e] - sv[e];   // sum_k Df Yf - Sf
-                fsum += cabs2(r);
-                if (EY && k == 0) EY[NW * j + N1 * brev(4 * c + e, LBW)] = r;
+                if constexpr (BT) {
+                    fsum += cabs2(r);
+                    if (k == 0) EY[NW * j + N1 * brev(4 * c + e, LBW)] = r;
+                }
                 u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] - cscale(cmulc(dd[e], r), inv_L);
             }
             if constexpr (c == CPL - 1) {
@@ -139,13 +154,21 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
         if (q + 1 < Q) __syncthreads();
     });
     reg_fence<N1>(v, 0, token);
+    // (the tile's sum before the last transform: the stores are then the last thing a wave does
+    // for this tile, and the next tile's loads follow them directly)
+    if constexpr (BT) {
+        double acc[1] = {k == 0 ? (double)fsum : 0.0};
+        block_sum_store<1>(acc, scratch, ap->partials + tile);
+    } else if constexpr (PERSIST) {
+        __syncthreads();     // the exchange buffer is reused by the next tile
+    }
     dit<N1, true>(v, 0);
     if (kv) {
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1) buf_store_cf(Ob, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
     }
-    double acc[1] = {k == 0 ? (double)fsum : 0.0};
-    block_sum_store<1>(acc, scratch, a.partials + tile);
+    if constexpr (!PERSIST) break;
+    }   // persistent loop over this workgroup's tiles
 }
 
 // ---------------------------------------------------------------------------
@@ -154,11 +177,14 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
 // ---------------------------------------------------------------------------
 // PLAIN: forward transform only (no momentum, no sums): t <- FFT_H(t)
 // BT: with STATS, also the linear term of the backtracking model from a.ey
-template <int NW, int LP, int KC, bool STATS, bool PLAIN = false, bool BT = false>
+template <int NW, int LP, int KC, bool STATS, bool PLAIN = false, bool BT = false, bool PERS = false>
 __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmColsArgs<float> a) {
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
+    // (persistent as pgm_grad_ifft: 16 waves, K = 64 -- there is no slab axis then)
+    constexpr bool PERSIST = PERS;
+    static_assert(!PERS || (NW == 16 && KC == 64), "persistent form: 16 waves, K = 64");
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -166,27 +192,34 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     // (K > 64, run-time K only: one workgroup per (tile, 64-filter slab), slab = blockIdx.y)
     const int slab = KC ? 0 : (int)blockIdx.y, NHs = KC ? 1 : (int)gridDim.y;
     const bool kv = KC == 64 ? true : slab * 64 + k < K;
-    const int Wf = a.W / 2 + 1;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int wf = (slot / a.CN) * 8 + xcd;
-    if (wf >= Wf) return;
-    const int tile = wf * a.CN + slot % a.CN;
-    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
-    const BufRsrc Tb = make_rsrc(a.t + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Xo = PLAIN ? Tb : make_rsrc(a.xf_old + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Yo = PLAIN ? Tb : make_rsrc(a.yf + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Yn = PLAIN ? Tb : make_rsrc(a.yf_new + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, tbytes);
+    const int xcd = blockIdx.x & 7;
     const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
-    const cf *S = a.sft + (int64_t)tile * H + w;
-    const cf *EY = BT ? a.ey + (int64_t)tile * H + w : nullptr;
-    cf *QP = (STATS && !KC && a.qpart) ? a.qpart + ((int64_t)tile * NHs + slab) * H + w : nullptr;
-    const cf *twA = a.twA + w * N1;
     f2 *L = dyn_lds<f2>();
     double *scratch = reinterpret_cast<double *>(L + FP * NW * 64);
     const cf zero = mk<float>(0.f, 0.f);
-    const float beta = a.beta;
     int token = 0;
+    if constexpr (PERSIST) {
+        const int ph = (int)(blockIdx.x >> 3) % a.stagger_groups;
+        for (int i = 0; i < ph * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    for (int slot = blockIdx.x >> 3;; slot += gridDim.x >> 3) {
+    SA_ARGS_PTR_T(PgmColsArgs<float>) ap = sa_args_reload<PERSIST>(a);
+    const int Wf = ap->W / 2 + 1, CN = ap->CN;
+    if (slot >= ((Wf + 7) / 8) * CN) break;
+    const int wf = (slot / CN) * 8 + xcd;
+    if (wf >= Wf) break;
+    const int tile = wf * CN + slot % CN;
+    const uint32_t tbytes = (uint32_t)(H * K * sizeof(cf));
+    const BufRsrc Tb = make_rsrc(ap->t + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Xo = PLAIN ? Tb : make_rsrc(ap->xf_old + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Yo = PLAIN ? Tb : make_rsrc(ap->yf + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Yn = PLAIN ? Tb : make_rsrc(ap->yf_new + (int64_t)tile * H * K, tbytes);
+    const BufRsrc Db = make_rsrc(ap->dft + (int64_t)wf * H * K, tbytes);
+    const cf *S = ap->sft + (int64_t)tile * H + w;
+    const cf *EY = BT ? ap->ey + (int64_t)tile * H + w : nullptr;
+    cf *QP = (STATS && !KC && ap->qpart) ? ap->qpart + ((int64_t)tile * NHs + slab) * H + w : nullptr;
+    const cf *twA = ap->twA + w * N1;
+    const float beta = ap->beta;
     float rs = 0.f, fsum = 0.f, lin = 0.f;
 
     // rows h = NW h1 + w of T', forward FFT over h1, twiddle
@@ -204,7 +237,8 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     }
     reg_fence<N1>(v, 0, token);
 
-    static_for<Q>([&](auto qc) {
+    // group q of the exchange leaves the register tile: (wave = h2; f1 in registers) -> LDS
+    auto write_group = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
 #pragma unroll
         for (int fl = 0; fl < FP; ++fl) {
@@ -214,6 +248,10 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
             t.y = x.im;
             L[(fl * NW + w) * 64 + k] = t;
         }
+    };
+    write_group(std::integral_constant<int, 0>{});
+    static_for<Q>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
         // previous iterates (and Df / Sf for the objective) of chunk g+1 are requested while
         // chunk g is processed; chunk 0's before the barrier
         cf xn4[4], yn4[4];
@@ -243,7 +281,13 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                 u[NW * jl + h2] = mk<float>(t.x, t.y);
             }
         }
-        if (q + 1 < Q) __syncthreads();
+        if constexpr (q + 1 < Q) {
+            // the next group goes to the exchange buffer as soon as this one has been read:
+            // its half of the register tile is then free while this group's chunks -- the
+            // register-hungry part: momentum operands, Df rows, the wave reduction -- run
+            __syncthreads();
+            write_group(std::integral_constant<int, q + 1>{});
+        }
         static_for<NCH>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
@@ -303,14 +347,19 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
         }
     });
 
-    if constexpr (PLAIN) return;
-    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
-    const double rsw = wave_sum((double)rs);   // rs is per lane (all filters); fsum is wave-uniform
-    double acc[kPgmPartialStride] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
-                                     k == 0 ? (double)fsum : 0.0, k == 0 ? (double)lin : 0.0,
-                                     k == 0 ? rsw : 0.0, 0.0};
-    block_sum_store<kPgmPartialStride>(acc, scratch,
-                                       a.partials + ((int64_t)tile * NHs + slab) * kPgmPartialStride);
+    if constexpr (PLAIN) {
+        if constexpr (PERSIST) __syncthreads();     // the exchange buffer is reused by the next tile
+    } else {
+        const double pw = (wf == 0 || ((ap->W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+        const double rsw = wave_sum((double)rs);   // rs is per lane (all filters); fsum is wave-uniform
+        double acc[kPgmPartialStride] = {(k == 0 ? rsw : 0.0) * pw, k == 0 ? (double)fsum * pw : 0.0,
+                                         k == 0 ? (double)fsum : 0.0, k == 0 ? (double)lin : 0.0,
+                                         k == 0 ? rsw : 0.0, 0.0};
+        block_sum_store<kPgmPartialStride>(acc, scratch,
+                                           ap->partials + ((int64_t)tile * NHs + slab) * kPgmPartialStride);
+    }
+    if constexpr (!PERSIST) break;
+    }   // persistent loop over this workgroup's tiles
 }
 
 // K > 64: the objective sums from the slabs' shares of sum_k Df Xf' (see csc_pgm.h)
@@ -485,28 +534,76 @@ template <typename F> void set_lds(F kernel, size_t bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 }
 
-template <int NW, int LP, int KC> void launch_grad(hipStream_t st, const PgmColsArgs<float> &a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        set_lds(&pgm_grad_ifft_kernel<NW, LP, KC>, pgm_lds_bytes(NW, LP));
-        attr_set = true;
+// Workgroups of a persistent launch (16 waves, K = 64): one per CU, a multiple of 8 (the XCD
+// of a workgroup is blockIdx % 8 for every slot it walks); 0 = one workgroup per tile
+// (SPORCO_AMD_PGM_PERSIST=0, or bit 0 / bit 1 of its value for the gradient / momentum kernel
+// alone).  Stagger as in csc_fused.hip (SPORCO_AMD_PGM_STAGGER_GROUPS / _SLEEPS).
+static unsigned pgm_persist_grid(PgmColsArgs<float> &a, int NW, int KC, int which) {
+    static int cus = 0, sg = 4, ss = 2, mask = 3;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        SA_HIP(hipGetDevice(&dev));
+        SA_HIP(hipGetDeviceProperties(&pr, dev));
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        if (std::getenv("SPORCO_AMD_PGM_PERSIST")) mask = std::atoi(std::getenv("SPORCO_AMD_PGM_PERSIST"));
+        if (std::getenv("SPORCO_AMD_PGM_STAGGER_GROUPS")) sg = std::max(1, std::atoi(std::getenv("SPORCO_AMD_PGM_STAGGER_GROUPS")));
+        if (std::getenv("SPORCO_AMD_PGM_STAGGER_SLEEPS")) ss = std::atoi(std::getenv("SPORCO_AMD_PGM_STAGGER_SLEEPS"));
     }
-    const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
-    hipLaunchKernelGGL((pgm_grad_ifft_kernel<NW, LP, KC>), dim3(grid), dim3(NW * 64),
-                       pgm_lds_bytes(NW, LP), st, a);
+    const int64_t all = ceil_div(a.W / 2 + 1, 8) * 8 * a.CN;
+    a.stagger_groups = sg;
+    a.stagger_sleeps = ss;
+    const int64_t g = std::max(8, cus / 8 * 8);
+    if (!(mask & which) || NW != 16 || KC != 64 || all <= g) return 0u;
+    return (unsigned)g;
+}
+static unsigned pgm_all_tiles(const PgmColsArgs<float> &a) {
+    return (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
 }
 
-template <int NW, int LP, int KC, bool STATS, bool BT = false>
-void launch_mom(hipStream_t st, const PgmColsArgs<float> &a) {
+template <int NW, int LP, int KC, bool BT, bool PERS>
+void launch_grad_inst(hipStream_t st, const PgmColsArgs<float> &a, unsigned grid) {
     static bool attr_set = false;
     if (!attr_set) {
-        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, STATS, false, BT>, pgm_lds_bytes(NW, LP));
+        set_lds(&pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS>, pgm_lds_bytes(NW, LP));
         attr_set = true;
     }
-    const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
+    hipLaunchKernelGGL((pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS>), dim3(grid), dim3(NW * 64),
+                       pgm_lds_bytes(NW, LP), st, a);
+}
+template <int NW, int LP, int KC> void launch_grad(hipStream_t st, const PgmColsArgs<float> &a_in) {
+    PgmColsArgs<float> a = a_in;
+    const unsigned pg = pgm_persist_grid(a, NW, KC, 1);
+    if constexpr (NW == 16 && KC == 64) {
+        if (pg) {
+            if (a.ey) launch_grad_inst<NW, LP, KC, true, true>(st, a, pg);
+            else launch_grad_inst<NW, LP, KC, false, true>(st, a, pg);
+            return;
+        }
+    }
+    if (a.ey) launch_grad_inst<NW, LP, KC, true, false>(st, a, pgm_all_tiles(a));
+    else launch_grad_inst<NW, LP, KC, false, false>(st, a, pgm_all_tiles(a));
+}
+
+template <int NW, int LP, int KC, bool STATS, bool PLAIN, bool BT, bool PERS>
+void launch_mom_inst(hipStream_t st, const PgmColsArgs<float> &a, unsigned grid) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, STATS, PLAIN, BT, PERS>, pgm_lds_bytes(NW, LP));
+        attr_set = true;
+    }
     const unsigned slabs = KC ? 1u : (unsigned)ceil_div(a.K, 64);
-    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS, false, BT>), dim3(grid, slabs),
+    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS, PLAIN, BT, PERS>), dim3(grid, slabs),
                        dim3(NW * 64), pgm_lds_bytes(NW, LP), st, a);
+}
+template <int NW, int LP, int KC, bool STATS, bool BT = false, bool PLAIN = false>
+void launch_mom(hipStream_t st, const PgmColsArgs<float> &a_in) {
+    PgmColsArgs<float> a = a_in;
+    const unsigned pg = pgm_persist_grid(a, NW, KC, 2);
+    if constexpr (NW == 16 && KC == 64) {
+        if (pg) return launch_mom_inst<NW, LP, KC, STATS, PLAIN, BT, true>(st, a, pg);
+    }
+    launch_mom_inst<NW, LP, KC, STATS, PLAIN, BT, false>(st, a, pgm_all_tiles(a));
 }
 
 }  // namespace
@@ -564,15 +661,7 @@ template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmCols
 }
 
 template <int NW, int LP, int KC> static void launch_plain(hipStream_t st, const PgmColsArgs<float> &a) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, false, true>, pgm_lds_bytes(NW, LP));
-        attr_set = true;
-    }
-    const unsigned grid = (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
-    const unsigned slabs = KC ? 1u : (unsigned)ceil_div(a.K, 64);      // (K > 64: per 64-filter slab)
-    hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, false, true>), dim3(grid, slabs),
-                       dim3(NW * 64), pgm_lds_bytes(NW, LP), st, a);
+    launch_mom<NW, LP, KC, false, false, true>(st, a);
 }
 
 template <> int64_t launch_cols_fft<float>(hipStream_t st, const PgmColsArgs<float> &a) {

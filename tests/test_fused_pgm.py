@@ -33,6 +33,9 @@ def make(D, S, optd, generic=False):
 @pytest.mark.parametrize('H,W,K,N', [(256, 256, 4, 1), (256, 512, 6, 1),
                                      (256, 128, 4, 2),      # W = 128: the 32 x 4 row kernels
                                      (128, 128, 4, 2),      # H = 128: the 32 x 4 column kernels
+                                     # H = 512, K = 64: the persistent column kernels (65 tiles
+                                     # over the simulator's 8 workgroups; 256 on the GPU)
+                                     (512, 128, 64, 1),
                                      pytest.param(256, 256, 5, 2, marks=pytest.mark.gpu),
                                      # K > 64: cooperating slab workgroups in the gradient step,
                                      # per-slab momentum kernels + the slab statistics kernel
@@ -45,7 +48,7 @@ def test_fused_pgm_matches_oracle(backend, H, W, K, N):
     if backend == 'hostsim' and W == 512:
         pytest.skip("W = 512 row kernels run under the simulator in test_fused_xstep; here GPU only")
     D, S = problem(H, W, K, N, seed=H + W)
-    slow = backend == 'hostsim' and K > 64       # (keeps the CPU suite short)
+    slow = backend == 'hostsim' and (K > 64 or H * K >= 512 * 64)   # (keeps the CPU suite short)
     iters = 2 if slow else 3
     optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 50.0}
     b = make(D, S, optd)
