@@ -358,7 +358,8 @@ template <typename T> struct Csc : CscBase {
     bool v_live = false;
     T *v_cur = nullptr;
     T v_thr = T(0), v_prev_thr = T(0);
-    bool v_nonneg = false;
+    T v_thr21 = T(0), v_prev_thr21 = T(0), vp_thr21 = T(0);   // ConvBPDNJoint: the l2,1 thresholds
+    bool v_nonneg = false, v_joint = false;
     int v_prev_kind = 0;
     bool vp_pending = false;       // the previous iterate still waits, in V form, in vp_buf
     T *vp_buf = nullptr, *vp_free = nullptr;
@@ -675,7 +676,16 @@ template <typename T> struct Csc : CscBase {
     bool vform_ok(const sporco_amd_admm_params &p) const {
         const bool off = std::getenv("SPORCO_AMD_NO_VFORM") != nullptr;   // (test switch)
         return !off && std::is_same<T, float>::value && rows_ok && !wl1.ptr &&
-               !(p.flags & (F_NOBNDRY | F_AMS | F_JOINT | F_KEEP_X | F_FEVAL_Y | F_XRRS));
+               !(p.flags & (F_NOBNDRY | F_AMS | F_KEEP_X | F_FEVAL_Y | F_XRRS)) &&
+               (!(p.flags & F_JOINT) || joint_rows_ok(p));
+    }
+    // Y (and / or U) of an iterate held as V: y or u may be null, u may alias v
+    void vform_split(const T *v, T *y, T *u, T thr, T thr21) {
+        if (v_joint)
+            launch_vform_split_joint<T>(st, v, y, u, thr, thr21, v_nonneg, C, (int64_t)N * K,
+                                        (int64_t)H * W);
+        else
+            launch_vform_split<T>(st, v, y, u, thr, v_nonneg, E);
     }
     void ensure_yu() {
         if (!v_live) return;
@@ -686,7 +696,7 @@ template <typename T> struct Csc : CscBase {
             // vars hold the previous iterate as (Y, U) and the other alt buffer is free: the
             // new pair goes to (other, v_cur) and the buffers trade places -- exactly the state
             // an iteration of the (Y, U) form leaves behind
-            launch_vform_split<T>(st, v_cur, other, v_cur, v_thr, v_nonneg, E);
+            vform_split(v_cur, other, v_cur, v_thr, v_thr21);
             T *oldY = static_cast<T *>(vars[SPORCO_AMD_VAR_Y]), *oldU = static_cast<T *>(vars[SPORCO_AMD_VAR_U]);
             vars[SPORCO_AMD_VAR_Y] = other;
             vars[SPORCO_AMD_VAR_U] = v_cur;
@@ -694,13 +704,14 @@ template <typename T> struct Csc : CscBase {
             u_alt = oldU;
             prev_in_alt = true;
         } else {
-            launch_vform_split<T>(st, v_cur, static_cast<T *>(vars[SPORCO_AMD_VAR_Y]),
-                                  static_cast<T *>(vars[SPORCO_AMD_VAR_U]), v_thr, v_nonneg, E);
+            vform_split(v_cur, static_cast<T *>(vars[SPORCO_AMD_VAR_Y]),
+                        static_cast<T *>(vars[SPORCO_AMD_VAR_U]), v_thr, v_thr21);
             // the previous iterate stays in V form until somebody asks for it
             vp_pending = v_prev_kind == 2;
             vp_buf = other;
             vp_free = v_cur;
             vp_thr = v_prev_thr;
+            vp_thr21 = v_prev_thr21;
             vp_nonneg = v_nonneg;
             prev_in_alt = false;
         }
@@ -711,7 +722,12 @@ template <typename T> struct Csc : CscBase {
         if (!vp_pending) return;
         vp_pending = false;
         ProfScope ps(prof, PS_OTHER);
-        launch_vform_split<T>(st, vp_buf, vp_free, vp_buf, vp_thr, vp_nonneg, E);
+        {
+            const bool nn = v_nonneg;
+            v_nonneg = vp_nonneg;
+            vform_split(vp_buf, vp_free, vp_buf, vp_thr, vp_thr21);
+            v_nonneg = nn;
+        }
         y_alt = vp_free;
         u_alt = vp_buf;
         prev_in_alt = true;
@@ -1152,8 +1168,8 @@ template <typename T> struct Csc : CscBase {
         // iteration derives (Y, U) from it -- seven passes instead of ten (six instead of eight
         // with an emitted spectrum).  Anything else that wants Y or U gets them through
         // ensure_yu() (var_ptr).
-        const bool nn = p.flags & F_NONNEG;
-        if (v_live && (!vform_ok(p) || nn != v_nonneg)) ensure_yu();
+        const bool nn = p.flags & F_NONNEG, jn = p.flags & F_JOINT;
+        if (v_live && (!vform_ok(p) || nn != v_nonneg || jn != v_joint)) ensure_yu();
         const bool vf = vform_ok(p) && (v_live || touch_epoch == fused_epoch);
         T *vin = vf && v_live ? v_cur : nullptr;
         T *Y = vin ? nullptr : rv(SPORCO_AMD_VAR_Y), *U = vin ? nullptr : rv(SPORCO_AMD_VAR_U);
@@ -1165,7 +1181,7 @@ template <typename T> struct Csc : CscBase {
         T *vout = vf ? (vin == y_alt ? u_alt : y_alt) : nullptr;
         // rows_fwd, unless the previous iteration already left its result behind
         if (!(t_ready && p.u_scale == 1.0)) {
-            if (vin) launch_rows_fwd_on(nullptr, nullptr, (T)p.u_scale, vin, v_thr, p.flags);
+            if (vin) launch_rows_fwd_on(nullptr, nullptr, (T)p.u_scale, vin, v_thr, p.flags, v_thr21);
             else launch_rows_fwd_on(Y, U, (T)p.u_scale);
         }
         t_ready = false;
@@ -1191,6 +1207,7 @@ template <typename T> struct Csc : CscBase {
         pa.v_in = vin;
         pa.v_out = vout;
         pa.thr_prev = v_thr;
+        pa.thr21_prev = v_thr21;
         pa.x = keep_x ? rv(SPORCO_AMD_VAR_X) : nullptr;
         pa.scale = T(1.0 / ((double)H * (double)W));
         pa.rlx = (T)p.rlx;
@@ -1240,9 +1257,12 @@ template <typename T> struct Csc : CscBase {
             // iteration) or the V this iteration read
             v_prev_kind = vin ? 2 : 1;
             v_prev_thr = v_thr;
+            v_prev_thr21 = v_thr21;
             v_cur = vout;
             v_thr = pa.thr;
+            v_thr21 = pa.thr21;
             v_nonneg = nn;
+            v_joint = jn;
             v_live = true;
             vp_pending = false;
             last_p = p;
@@ -1285,6 +1305,8 @@ template <typename T> struct Csc : CscBase {
             ra.u = U;
             ra.v = vin;
             ra.flags = p.flags;
+            ra.C = C;
+            ra.N = N;
             ra.s2 = T(1);
             ra.t = Xf;
             ra.Ks = Ks;
@@ -1392,13 +1414,13 @@ template <typename T> struct Csc : CscBase {
         // V' = AX + U alone, rows_fwd and the next epilogue derive (Y, U) from it.  A run of a
         // few iterations (a dictionary-learning X-step) stays in the (Y, U) form: it would pay
         // the conversion back at once.
-        const bool nn = p.flags & F_NONNEG;
-        if (v_live && (!vform_ok(p) || nn != v_nonneg)) ensure_yu();
+        const bool nn = p.flags & F_NONNEG, jn = p.flags & F_JOINT;
+        if (v_live && (!vform_ok(p) || nn != v_nonneg || jn != v_joint)) ensure_yu();
         const bool vf = vform_ok(p) && (v_live || c.max_iter >= 4);
         if (!vf) ensure_yu();
         const bool v_at_entry = v_live;
         T *const v_entry = v_cur;
-        const T v_entry_thr = v_thr;
+        const T v_entry_thr = v_thr, v_entry_thr21 = v_thr21;
         if (!ctl_dev) SA_HIP(hipMalloc((void **)&ctl_dev, sizeof(AdmmCtl)));
         if (rec_cap < c.max_iter) {
             if (rec_ring) SA_HIP(hipHostFree(rec_ring));
@@ -1430,6 +1452,7 @@ template <typename T> struct Csc : CscBase {
         in.stdres = c.std_residuals;
         in.need_resid = c.need_residuals;
         in.thr_prev = v_at_entry ? (float)v_entry_thr : 0.f;
+        in.thr21_prev = v_at_entry ? (float)v_entry_thr21 : 0.f;
         in.no_speculation = (std::getenv("SPORCO_AMD_NO_SPECULATION") ||
                              ((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT")))
                                 ? 1
@@ -1522,16 +1545,20 @@ template <typename T> struct Csc : CscBase {
             T *other_first = vb_first == y_alt ? u_alt : y_alt;
             v_cur = ((n - 1) & 1) ? other_first : vb_first;
             v_thr = (T)(p.lmbda / rec_ring[n - 1].rho);
+            v_thr21 = (T)(p.mu / rec_ring[n - 1].rho);
             if (n >= 2) {
                 v_prev_kind = 2;
                 v_prev_thr = (T)(p.lmbda / rec_ring[n - 2].rho);
+                v_prev_thr21 = (T)(p.mu / rec_ring[n - 2].rho);
             } else if (v_at_entry) {
                 v_prev_kind = 2;
                 v_prev_thr = v_entry_thr;
+                v_prev_thr21 = v_entry_thr21;
             } else {
                 v_prev_kind = 1;
             }
             v_nonneg = nn;
+            v_joint = jn;
             v_live = true;
         }
         vp_pending = false;
@@ -1594,13 +1621,16 @@ template <typename T> struct Csc : CscBase {
     }
 
     void launch_rows_fwd_on(const T *Yin, const T *Uin, T s2, const T *Vin = nullptr,
-                            T thr_prev = T(0), uint32_t flags = 0) {
+                            T thr_prev = T(0), uint32_t flags = 0, T thr21_prev = T(0)) {
         RowsFwdArgs<T> ra;
         ra.y = Yin;
         ra.u = Uin;
         ra.v = Vin;
         ra.thr_prev = thr_prev;
+        ra.thr21_prev = thr21_prev;
         ra.flags = flags;
+        ra.C = C;
+        ra.N = N;
         ra.s2 = s2;
         ra.t = cv(SPORCO_AMD_VAR_XF);
         ra.Ks = Ks;

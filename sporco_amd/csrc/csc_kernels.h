@@ -112,6 +112,11 @@ void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t 
 // U = V - Y; y or u may be null, u may alias v
 template <typename T>
 void launch_vform_split(hipStream_t st, const T *v, T *y, T *u, T thr, bool nonneg, int64_t n);
+// ... of ConvBPDNJoint: Y = prox_sl1l2(V; thr, thr21) over the C <= 4 channels (arrays
+// (npixel, C, NK), NK = N * K)
+template <typename T>
+void launch_vform_split_joint(hipStream_t st, const T *v, T *y, T *u, T thr, T thr21, bool nonneg,
+                              int C, int64_t NK, int64_t npixel);
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
                   uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,

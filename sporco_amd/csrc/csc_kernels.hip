@@ -718,6 +718,47 @@ __global__ void __launch_bounds__(kThreads) vform_split_kernel(const T *v, T *y,
     }
 }
 
+// The same for ConvBPDNJoint: Y = prox_sl1l2(V; thr, thr21) over the C <= 4 channels of each
+// (pixel, image, filter) -- soft threshold, then the channel vector shrunk in l2 norm
+// (cbpdn.py:785-794, prox/_l21.py:51-88), with the sum of squares taken in the order the row
+// epilogue's cross-lane sum takes it, (s0 + s1) + (s2 + s3).  One thread per (pixel, n, k).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) vform_split_joint_kernel(const T *v, T *y, T *u, T thr,
+                                                                     T thr21, int nonneg, int C,
+                                                                     int64_t NK, int64_t npixel) {
+#pragma clang fp contract(off)
+    const int64_t total = npixel * NK;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / NK, r = i - pix * NK;
+        const int64_t base = pix * C * NK + r;
+        T vv[4] = {T(0), T(0), T(0), T(0)}, sv[4], sq[4];
+        for (int c = 0; c < 4; ++c) {
+            if (c < C) vv[c] = v[base + c * NK];
+            sv[c] = soft(vv[c], thr);
+            sq[c] = sv[c] * sv[c];
+        }
+        const T q = (sq[0] + sq[1]) + (sq[2] + sq[3]);
+        T fac = T(1) - thr21 * (T)sa_rsq((float)q);
+        fac = fac > T(0) ? fac : T(0);
+        for (int c = 0; c < C; ++c) {
+            T yy = fac * sv[c];
+            if (nonneg && yy < T(0)) yy = T(0);
+            if (y) y[base + c * NK] = yy;
+            if (u) u[base + c * NK] = vv[c] - yy;
+        }
+    }
+}
+
+template <typename T>
+void launch_vform_split_joint(hipStream_t st, const T *v, T *y, T *u, T thr, T thr21, bool nonneg,
+                              int C, int64_t NK, int64_t npixel) {
+    SA_REQUIRE(C >= 1 && C <= 4, "the joint V form serves up to four channels");
+    hipLaunchKernelGGL((vform_split_joint_kernel<T>), dim3(grid_for(npixel * NK)), dim3(kThreads), 0,
+                       st, v, y, u, thr, thr21, nonneg ? 1 : 0, C, NK, npixel);
+    SA_HIP(hipGetLastError());
+}
+
 template <typename T>
 void launch_vform_split(hipStream_t st, const T *v, T *y, T *u, T thr, bool nonneg, int64_t n) {
     hipLaunchKernelGGL((vform_split_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, v, y, u, thr,
@@ -2761,6 +2802,8 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *);                \
     template void launch_relax<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template void launch_vform_split<T>(hipStream_t, const T *, T *, T *, T, bool, int64_t);       \
+    template void launch_vform_split_joint<T>(hipStream_t, const T *, T *, T *, T, T, bool, int,   \
+                                              int64_t, int64_t);                                \
     template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \
                                   Dims5, int, int, Weight<T>, Weight<T>, Weight<T>, int);          \
     template void launch_ustep<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \

@@ -50,7 +50,11 @@ template <typename T> struct RowsFwdArgs {
     // values are those a stored (Y, U) pair would hold, for one read pass instead of two.
     const T *v = nullptr;
     T thr_prev = T(0);     // lambda / rho of the iteration that produced v (ctl: ctl->thr_prev_f)
-    uint32_t flags = 0;    // F_NONNEG (the derivation repeats the clamp)
+    uint32_t flags = 0;    // F_NONNEG (the derivation repeats the clamp); F_JOINT: Y =
+                           // prox_sl1l2(V) over the channel axis -- the kernel then tiles as the
+                           // joint epilogue does (lane = (channel, filter pair)) and needs C, N
+    T thr21_prev = T(0);   // F_JOINT: mu / rho of that iteration (ctl: ctl->thr21_prev_f)
+    int C = 1, N = 0;      // F_JOINT: channels and images (CN = C * N)
     int y_bcast = 0;   // y is (H, W, K), broadcast over the CN blocks (consensus D-step)
     int Ks = 0;        // row stride of t in filters when it is not K (0: K), see csc_fused.h
     // device-driven solve (csc_kernels.h AdmmCtl): s2 is ctl->u_scale_f, and the launch returns
@@ -69,7 +73,7 @@ template <typename T> struct RowsPostArgs {
     const T *y, *u;    // in: real (H, W, P)
     T *y_out, *u_out;  // out (may alias y, u: every element is read and written by one thread)
     T *x;              // out (optional, may be null): X = irfftn(Xf)
-    // Single-array state ("V form", plain epilogue only: scalar weights, no X output):
+    // Single-array state ("V form"; the plain and the joint epilogue: scalar weights, no X output):
     //   v_out  the epilogue stores V' = AX + U (scaled) instead of Y' and U' -- both are
     //          functions of V' alone (Y' = prox(V'), U' = V' - Y'), so one array carries the
     //          iterate: one write pass instead of two;
@@ -79,6 +83,7 @@ template <typename T> struct RowsPostArgs {
     const T *v_in = nullptr;
     T *v_out = nullptr;
     T thr_prev = T(0);     // lambda / rho of the iteration that produced v_in (ctl: thr_prev_f)
+    T thr21_prev = T(0);   // F_JOINT: mu / rho of that iteration (ctl: thr21_prev_f)
     T scale;           // 1 / (H W)
     T rlx, thr, u_scale;
     T thr21 = T(0);    // F_JOINT: mu / rho, the l2,1 threshold of prox_sl1l2 (cbpdn.py:785-794)

@@ -286,22 +286,39 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // One tile (image row `h`, 128-column block `bx`) of rows_fwd.
 // VFORM: the iterate arrives as V = AX + U of the iteration that produced it (csc_rows.h):
 // Y = prox(V; thr_prev) (+ NonNeg), U = V - Y per element, then Y - s2 U as before.
-template <int NW, bool BCAST, bool VFORM, typename AP>
+// JOINT (with VFORM): Y = prox_sl1l2(V) couples the channels, so the tile is the joint epilogue's
+// -- one image, 32 filters, all C <= 4 channels, lane = (channel, filter pair).
+template <int NW, bool BCAST, bool VFORM, bool JOINT, typename AP>
 __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     constexpr int N1 = kN1, W = N1 * NW;
     static_assert(!(BCAST && VFORM), "the broadcast form reads a dictionary-sized Y");
+    static_assert(!JOINT || VFORM, "only the V form needs the joint tiling");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
-    float s2 = a->s2, thr_p = a->thr_prev;
+    float s2 = a->s2, thr_p = a->thr_prev, thr21_p = a->thr21_prev;
     if (a->ctl) {       // device-driven solve
         s2 = a->ctl->u_scale_f;
         thr_p = a->ctl->thr_prev_f;
+        thr21_p = a->ctl->thr21_prev_f;
     }
     const bool nonneg = VFORM && (a->flags & F_NONNEG);
-    const int64_t p = (int64_t)bx * 128 + 2 * lane;
-    const bool pv = p < a->P;
-    const int cn = pv ? (int)(p / a->K) : 0, k = pv ? (int)(p % a->K) : 0;
+    int64_t p;
+    bool pv;
+    int cn, k;
+    if constexpr (JOINT) {
+        const int kbn = a->K >> 5, n = bx / kbn, kb = bx % kbn;
+        const int c = lane >> 4;
+        pv = c < a->C;
+        cn = pv ? c * a->N + n : 0;
+        k = pv ? kb * 32 + 2 * (lane & 15) : 0;
+        p = (int64_t)cn * a->K + k;
+    } else {
+        p = (int64_t)bx * 128 + 2 * lane;
+        pv = p < a->P;
+        cn = pv ? (int)(p / a->K) : 0;
+        k = pv ? (int)(p % a->K) : 0;
+    }
     f2 *L = dyn_lds<f2>();
     int token = 0;
 
@@ -334,8 +351,20 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
         if constexpr (VFORM) {
 #pragma unroll
             for (int i = 0; i < N1 / 2; ++i) {
+                // (no fused multiply-adds here or in the epilogue: the (Y, U) and the V form of
+                // an iteration must round alike, and which product of a sum the compiler
+                // fuses depends on the code around it)
+#pragma clang fp contract(off)
                 const cf vv = uv[i];
                 float y0 = soft1(vv.re, thr_p), y1 = soft1(vv.im, thr_p);
+                if constexpr (JOINT) {      // the l2 shrinkage over the channels, as the epilogue
+                    float f0 = 1.f - thr21_p * sa_rsq(sum_over_rows(y0 * y0));
+                    float f1 = 1.f - thr21_p * sa_rsq(sum_over_rows(y1 * y1));
+                    f0 = f0 > 0.f ? f0 : 0.f;
+                    f1 = f1 > 0.f ? f1 : 0.f;
+                    y0 = f0 * y0;
+                    y1 = f1 * y1;
+                }
                 if (nonneg && y0 < 0.f) y0 = 0.f;
                 if (nonneg && y1 < 0.f) y1 = 0.f;
                 yv[i] = mk<float>(y0, y1);
@@ -343,8 +372,10 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < N1 / 2; ++i)
+        for (int i = 0; i < N1 / 2; ++i) {
+#pragma clang fp contract(off)
             v[half * (N1 / 2) + i] = mk<float>(yv[i].re - s2 * uv[i].re, yv[i].im - s2 * uv[i].im);
+        }
         reg_fence<N1 / 2>(v, half * (N1 / 2), token);
     }
     spatial_to_spectral<NW>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
@@ -371,13 +402,14 @@ __device__ __forceinline__ void rows_tile_loop(const A &a_in, int tiles_x, int t
     }
 }
 
-template <int NW, bool BCAST, bool VFORM = false>
+template <int NW, bool BCAST, bool VFORM = false, bool JOINT = false>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a_in) {
     // device-driven solve: nothing to do once the stopping test is met, or when the previous
     // epilogue already left this spectrum behind
     if (a_in.ctl && (a_in.ctl->stop | a_in.ctl->skip_fwd)) return;
-    rows_tile_loop(a_in, (int)((a_in.P + 127) / 128), a_in.H,
-                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM>(a, bx, h); });
+    const int tiles_x = JOINT ? a_in.N * (a_in.K >> 5) : (int)((a_in.P + 127) / 128);
+    rows_tile_loop(a_in, tiles_x, a_in.H,
+                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM, JOINT>(a, bx, h); });
 }
 
 // ---------------------------------------------------------------------------
@@ -391,7 +423,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     constexpr bool GENERAL = MODE != 0;
     constexpr bool VIN = SF == 2, VOUT = SF != 0;
     static_assert(!JOINT || MODE == 0, "the joint epilogue takes scalar weights only");
-    static_assert(SF == 0 || (MODE == 0 && !WRITE_X && !JOINT), "V form: plain epilogue only");
+    static_assert(SF == 0 || (MODE == 0 && !WRITE_X), "V form: scalar weights, no X output");
     constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -464,13 +496,16 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
         mbits = __builtin_bit_cast(uint32_t, sa_buf_load1(Mb, mvoff, (h * CN * NW + w) * 4));
     }
     float s_r2 = 0.f, s_s2 = 0.f, s_x2 = 0.f, s_y2 = 0.f, s_u2 = 0.f, s_l1 = 0.f, s_l21 = 0.f;
-    float thr21 = a->thr21;
-    if (JOINT && a->ctl) thr21 = a->ctl->thr21_f;
+    float thr21 = a->thr21, thr21_p = a->thr21_prev;
+    if (JOINT && a->ctl) {
+        thr21 = a->ctl->thr21_f;
+        thr21_p = a->ctl->thr21_prev_f;
+    }
     const float l21w = lane < 16 ? 1.f : 0.f;  // the l2,1 sum counts each channel group once
     // pixels per batch (Y, U of the next batch are in flight); the emitting variants keep the
     // tile for the forward transform and have fewer registers to spare
     // (V form reads one array instead of two: twice the pixels per batch for the same registers)
-    constexpr int B = EMIT_T ? (JOINT ? 1 : (VIN ? 4 : 2)) : 4;
+    constexpr int B = EMIT_T ? (JOINT ? (VIN ? 2 : 1) : (VIN ? 4 : 2)) : 4;
     cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll
@@ -482,6 +517,9 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     };
     fetch(0, 0);
     static_for<N1 / B>([&](auto bc) {
+        // (every product rounded: the state forms of csc_rows.h must agree bit for bit, see
+        // rows_fwd_tile)
+#pragma clang fp contract(off)
         constexpr int b = decltype(bc)::value;
         if constexpr (b + 1 < N1 / B) fetch((b + 1) & 1, b + 1);
 #pragma unroll
@@ -498,6 +536,11 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 for (int e = 0; e < 2; ++e) {
                     const float vp = yo[e];
                     float yp = soft1(vp, thr_p);
+                    if constexpr (JOINT) {
+                        float fp = 1.f - thr21_p * sa_rsq(sum_over_rows(yp * yp));
+                        fp = fp > 0.f ? fp : 0.f;
+                        yp = fp * yp;
+                    }
                     if (nonneg && yp < 0.f) yp = 0.f;
                     yo[e] = yp;
                     uraw[e] = vp - yp;
@@ -530,6 +573,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                     const float u1 = vv - y1;
                     yn[e] = y1;
                     un[e] = u1;
+                    vn[e] = vv;
                     const float dr = xs[e] - y1, ds = y1 - yo[e];
                     s_r2 += dr * dr;
                     s_s2 += ds * ds;
@@ -705,6 +749,10 @@ template <> bool rows_supported<float>(int W, int K) {
     return (W == 128 || W == 256 || W == 512) && K >= 2 && K % 2 == 0;
 }
 template <> bool rows_supported<double>(int, int) { return false; }
+template <> bool rows_joint_supported<float>(int W, int C, int K) {
+    return rows_supported<float>(W, K) && C >= 1 && C <= 4 && K % 32 == 0;
+}
+template <> bool rows_joint_supported<double>(int, int, int) { return false; }
 
 template <typename T> void rows_twiddles(int W, cx<T> *twA) {
     const int NW = W / kN1;
@@ -768,9 +816,24 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
         set_lds_attr<4>(&rows_fwd_kernel<4, false, true>);
         set_lds_attr<8>(&rows_fwd_kernel<8, false, true>);
         set_lds_attr<16>(&rows_fwd_kernel<16, false, true>);
+        set_lds_attr<4>(&rows_fwd_kernel<4, false, true, true>);
+        set_lds_attr<8>(&rows_fwd_kernel<8, false, true, true>);
+        set_lds_attr<16>(&rows_fwd_kernel<16, false, true, true>);
         attr_set = true;
     }
     SA_REQUIRE(!(a.v && a.y_bcast), "the broadcast row pass has no V form");
+    if (a.v && (a.flags & F_JOINT)) {
+        // the V form of ConvBPDNJoint: tiles as the joint epilogue (one image, 32 filters, all
+        // channels per workgroup)
+        SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && a.C * a.N == a.CN,
+                   "configuration not handled by the joint row pass");
+        const dim3 jgrid = rows_grid(a, a.W / kN1, (int64_t)a.N * (a.K / 32), a.H, 0);
+        if (a.W == 128) hipLaunchKernelGGL((rows_fwd_kernel<4, false, true, true>), jgrid, dim3(4 * 64), rows_lds_bytes(4), st, a);
+        else if (a.W == 256) hipLaunchKernelGGL((rows_fwd_kernel<8, false, true, true>), jgrid, dim3(8 * 64), rows_lds_bytes(8), st, a);
+        else hipLaunchKernelGGL((rows_fwd_kernel<16, false, true, true>), jgrid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+        SA_HIP(hipGetLastError());
+        return;
+    }
     // (measured at config 2: the tile loop gains nothing for this kernel)
     const dim3 grid = rows_grid(a, a.W / kN1, ceil_div(a.P, 128), a.H, 0);
     if (a.W == 128) {
@@ -871,20 +934,25 @@ template <> void launch_ams_pack<double>(hipStream_t, const Weight<double> &, ui
     throw Error(-1, "the fused row kernels are float32 only");
 }
 
-template <> bool rows_joint_supported<float>(int W, int C, int K) {
-    return rows_supported<float>(W, K) && C >= 1 && C <= 4 && K % 32 == 0;
-}
-template <> bool rows_joint_supported<double>(int, int, int) { return false; }
 
 template <int NW, bool EMIT>
 static void launch_post_joint_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
     static bool attr_set = false;
     if (!attr_set) {
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true, 1>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true, 2>);
         attr_set = true;
     }
-    hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, true>), grid, dim3(NW * 64),
-                       rows_lds_bytes(NW), st, a);
+    if (a.v_out && a.v_in)
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, true, 2>), grid, dim3(NW * 64),
+                           rows_lds_bytes(NW), st, a);
+    else if (a.v_out)
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, true, 1>), grid, dim3(NW * 64),
+                           rows_lds_bytes(NW), st, a);
+    else
+        hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, true>), grid, dim3(NW * 64),
+                           rows_lds_bytes(NW), st, a);
 }
 
 template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostArgs<float> &a_in) {
@@ -892,7 +960,7 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     if (a.flags & F_JOINT) {
-        SA_REQUIRE(!a.v_in && !a.v_out, "the joint epilogue has no V form");
+        SA_REQUIRE(!a.v_in || a.v_out, "a V-form input needs a V-form output");
         SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && !a.wl1.ptr && !a.ams_bits &&
                        !(a.flags & F_NOBNDRY) && !a.x,
                    "configuration not handled by the joint row epilogue");

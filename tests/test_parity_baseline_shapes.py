@@ -304,6 +304,39 @@ def test_config3_joint_k128_slabs_vs_oracle(gpu_backend):
         assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f
 
 
+@pytest.mark.parametrize('K', [32, 128])
+def test_config3_joint_at_w512_vs_oracle(gpu_backend, K):
+    """Config 3's own instantiations: the W = 512 joint row epilogue
+    (rows_inv_post<16, ..., JOINT>) with rows_fwd<16> and the H = 512 column kernels --
+    fused_cols at K = 32, the cooperating 64-filter slabs at K = 128 -- on one 512x512 RGB image,
+    lambda = 0.1, mu = 0.01, default options, against the float64 oracle (ConvBPDNJoint.ystep
+    sporco/admm/cbpdn.py:785-794, prox_sl1l2 sporco/prox/_l21.py:51-88, obfn_reg :798-807).
+    K = 128 is 100 M elements per array: the comparison runs blockwise."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(512 + K)
+    H, W, C, N = 512, 512, 3, 1
+    iters = 5 if K == 32 else 3
+    D = rng.randn(8, 8, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, C, N).astype(np.float32)
+    opt = cbpdn.ConvBPDNJoint.Options({'MaxMainIter': iters, 'RelStopTol': 0.0})
+    b = cbpdn.ConvBPDNJoint(D, S, 0.1, 0.01, opt)
+    assert b._dev.uses_fused_rows() and b._dev.uses_fused_cols() and b._fused_ok()
+    Y = b.solve()
+    ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, C, N, 1), 0.1, mu=0.01,
+                         dtype=np.float64, maxiter=iters, rel_tol=0.0)
+    num = den = 0.0
+    for h in range(0, H, 64):
+        d = Y[h:h + 64].astype(np.float64) - ref['Y'][h:h + 64]
+        num += float(np.sum(d * d))
+        den += float(np.sum(ref['Y'][h:h + 64] ** 2))
+    assert np.sqrt(num / den) < 1e-4
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 1e-3, f
+
+
 def test_stopping_iteration_fused_f32_vs_reference(gpu_backend):
     """Time-to-tolerance known answer: the sparse-synthesis input of
     bench.make_structured_problem at 512x512, K=64, N=2, lambda 0.01, default options,

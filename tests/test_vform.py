@@ -21,7 +21,7 @@ from test_fused_xstep import problem
 FIELDS = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho')
 
 
-def run(D, S, optd, vform, host=False, lmbda=0.05, calls=1, cls=None):
+def run(D, S, optd, vform, host=False, lmbda=0.05, calls=1, joint_mu=None):
     from sporco_amd import _lib
     from sporco_amd.admm import cbpdn
     env = {}
@@ -31,7 +31,10 @@ def run(D, S, optd, vform, host=False, lmbda=0.05, calls=1, cls=None):
         env['SPORCO_AMD_HOST_LOOP'] = '1'
     os.environ.update(env)
     try:
-        b = cbpdn.ConvBPDN(D, S, lmbda, cbpdn.ConvBPDN.Options(optd))
+        if joint_mu is not None:
+            b = cbpdn.ConvBPDNJoint(D, S, lmbda, joint_mu, cbpdn.ConvBPDNJoint.Options(optd))
+        else:
+            b = cbpdn.ConvBPDN(D, S, lmbda, cbpdn.ConvBPDN.Options(optd))
         live = []
         for _ in range(calls):
             b._return_min = False         # (solve() without fetching Y: the state stays put)
@@ -124,8 +127,40 @@ def test_v_form_against_the_oracle(backend):
         assert rel_l2(o['stats'][f], ref[f]) < 1e-3, f
 
 
+@pytest.mark.parametrize('host', [False, True])
+@pytest.mark.parametrize('case', ['default', 'nonneg_period3', 'stops_early'])
+def test_joint_v_form_is_bit_identical_and_matches_the_oracle(backend, case, host):
+    """ConvBPDNJoint: Y = prox_sl1l2(V) over the channels (sporco/admm/cbpdn.py:785-794,
+    sporco/prox/_l21.py:51-88) re-derived from V by rows_fwd (joint tiling) and by the joint
+    epilogue; the materialised (Y, U) through the joint split kernel."""
+    from oracle import cbpdn_oracle as orc
+    H = 256 if backend == 'gpu' else 128
+    C, N, K = 3, (2 if backend == 'gpu' else 1), 32
+    if backend == 'hostsim' and (case == 'stops_early' or (host and case != 'default')):
+        pytest.skip("kept short on the CPU simulator")
+    D, S = problem(H, H, K, N, seed=21, C=C)
+    optd = dict(CASES[case])
+    if backend == 'hostsim':
+        optd['MaxMainIter'] = min(optd['MaxMainIter'], 6)
+    b0, o0 = run(D, S, optd, vform=False, host=host, lmbda=0.1, joint_mu=0.02)
+    b1, o1 = run(D, S, optd, vform=True, host=host, lmbda=0.1, joint_mu=0.02)
+    assert b1._dev.uses_fused_rows() and b1._fused_ok()
+    assert o0['live'] == [0]
+    if o1['k'] >= 2 or not host:
+        assert o1['live'] == [1]
+    same(o0, o1)
+    if case == 'default' and not host:
+        n = optd['MaxMainIter']
+        ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, H, C, N, 1), 0.1, mu=0.02,
+                             dtype=np.float64, maxiter=n, rel_tol=0.0)
+        assert rel_l2(o1['Y'], ref['Y']) < 1e-4
+        assert rel_l2(o1['U'], ref['U']) < 1e-4
+        for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+            assert rel_l2(o1['stats'][f], ref[f]) < 1e-3, f
+
+
 def test_options_outside_the_v_form_keep_the_yu_form(backend):
-    """Weight arrays / NoBndryCross / ConvBPDNJoint run the (Y, U) epilogues."""
+    """Weight arrays / NoBndryCross run the (Y, U) epilogues."""
     from sporco_amd import _lib
     from sporco_amd.admm import cbpdn
     D, S = problem(128, 128, 4, 2, seed=14)

@@ -103,6 +103,36 @@ int main() {
                            "\"consumer_ms\": %.4f, \"consumer_GBps\": %.0f}\n",
                            x, pn[prod], q, cons ? "read_nt" : "read", ms[3], gbps);
                 }
+    // A mixed consumer (what the row epilogue is): copy the buffer to another one.  Source just
+    // written / read (possibly on the die) against a source that has been flushed out by 2 GB of
+    // other traffic; destination written with the nt policy.
+    for (int x : {32, 64, 128, 192, 256, 512})
+        for (int prod = 0; prod < 5; ++prod) {       // 4 = flushed source (no producer)
+            const size_t n = (size_t)x * MB / sizeof(f4);
+            std::vector<float> ms;
+            for (int rep = 0; rep < 7; ++rep) {
+                if (prod != 4) hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, P1, P2, polb / sizeof(f4));
+                switch (prod) {
+                case 0: hipLaunchKernelGGL(k_write<false>, dim3(grid), dim3(256), 0, 0, A, n, (float)rep); break;
+                case 1: hipLaunchKernelGGL(k_write<true>, dim3(grid), dim3(256), 0, 0, A, n, (float)rep); break;
+                case 2: hipLaunchKernelGGL(k_read<false>, dim3(grid), dim3(256), 0, 0, A, n, sink); break;
+                case 3: hipLaunchKernelGGL(k_read<true>, dim3(grid), dim3(256), 0, 0, A, n, sink); break;
+                default: hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, P1, P2, polb / sizeof(f4)); break;
+                }
+                CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(k_copy<true>, dim3(grid), dim3(256), 0, 0, A, P2, n);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float t;
+                CK(hipEventElapsedTime(&t, e0, e1));
+                ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            static const char *pn[] = {"write", "write_nt", "read", "read_nt", "flushed"};
+            printf("{\"copy_of_buffer_MB\": %d, \"source_state\": \"%s\", \"ms\": %.4f, "
+                   "\"GBps_read_plus_write\": %.0f}\n",
+                   x, pn[prod], ms[3], 2.0 * x * MB / (ms[3] * 1e-3) / 1e9);
+        }
     // reference: plain streaming rates at 1 GB
     for (int nt = 0; nt < 2; ++nt) {
         std::vector<float> ms;
