@@ -37,6 +37,16 @@ def main():
     Y0 = b0.solve()
     assert np.array_equal(Y, Y0), rel_l2(Y, Y0)
     assert np.array_equal(np.asarray(b.getitstat().Rho), np.asarray(b0.getitstat().Rho))
+    # ... and with the solver on a stream of its own (not torch's current one): the hook issues
+    # the collective on that stream through torch.cuda.ExternalStream, so the ordering between
+    # the kernels that produce the sums, RCCL and the control kernel does not depend on which
+    # stream the handle was created with
+    b2 = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd), reducer=red)
+    assert b2._dev.stream_handle() != red.stream_handle()
+    assert red.device_sum_hook(b2._dev) is not None
+    Y2 = b2.solve()
+    assert np.array_equal(Y2, Y0), rel_l2(Y2, Y0)
+    assert np.array_equal(np.asarray(b2.getitstat().Rho), np.asarray(b0.getitstat().Rho))
     # dictionary learning with the reducer: the D-step gradient is all-reduced in place in the
     # library's device memory (one rank: the sum is the identity, the plumbing is what runs)
     from sporco_amd.dictlrn import cbpdndl

@@ -97,7 +97,8 @@ def test_joint_l21_inside_the_row_epilogue(backend):
     finally:
         os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
     cnt = {k: v[1] for k, v in b.profile_read().items() if v[1] > 0}
-    assert cnt.get('rows_inv_post', 0) + cnt.get('rows_inv_post_emit', 0) == iters
+    assert sum(cnt.get(k, 0) for k in ('rows_inv_post', 'rows_inv_post_emit', 'rows_inv_post_v',
+                                       'rows_inv_post_v_emit')) == iters
     assert 'admm_post' not in cnt and 'fft_c2r_rows' not in cnt
     ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, C, N, 1), 0.05, mu=0.02,
                          dtype=np.float64, maxiter=iters, rel_tol=0.0)
