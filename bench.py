@@ -320,6 +320,8 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    rank_stats = {}
+
     def timed_run(fast):
         optd = {'MaxMainIter': max(args.warmup, 1), 'RelStopTol': 0.0}
         if fast:
@@ -336,10 +338,27 @@ def main():
         sync_all(b)
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64,
-                             device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            own = elapsed
+            dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.cpu()[0])
+            # per-rank spread and the cost of the per-iteration all-reduce, so that a scaling
+            # shortfall can be attributed (slow rank / collective / neither)
+            t = torch.tensor([-own], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            hc = reducer.hook_cost_ms()
+            h = torch.tensor([hc[0] if hc else 0.0, hc[1] if hc else 0.0], dtype=torch.float64,
+                             device=dev)
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            if not rank_stats:
+                rank_stats.update({
+                    'ms_per_step_slowest_rank': 1e3 * elapsed / args.steps,
+                    'ms_per_step_fastest_rank': 1e3 * -float(t.cpu()[0]) / args.steps,
+                    'allreduce_ms_mean_worst_rank': float(h.cpu()[0]),
+                    'allreduce_ms_max': float(h.cpu()[1]),
+                    'allreduce_calls_timed': hc[2] if hc else 0,
+                    'backend': dist.get_backend()})
         return b, elapsed
 
     b, elapsed = timed_run(args.fastsolve)
@@ -472,6 +491,7 @@ def main():
         'other_options': {'options': names[not args.fastsolve],
                           'value': args.steps / elapsed2 * world,
                           'ms_per_step': 1e3 * elapsed2 / args.steps},
+        'ranks': rank_stats or None,
         'parity': parity,
         'loop': ('device-driven (sporco_amd_csc_admm_run): residuals, rho schedule and stopping '
                  'test on the device, host enqueues only') if not os.environ.get('SPORCO_AMD_HOST_LOOP')

@@ -84,6 +84,11 @@ class TorchReducer(object):
         from . import _lib
         torch = self.torch
         views = {}
+        # per-call cost of the collective, for attribution of a scaling shortfall (bench.py):
+        # device time between two events around the all-reduce (RCCL), or host time of the CPU
+        # all-reduce without the stream synchronisation that precedes it (gloo)
+        self.hook_calls = 0
+        self._hook_events, self._hook_host_s = [], []
         if self.on_gpu:
             try:
                 torch.as_tensor(_DeviceView(solver.device_ptr(_lib.VAR_Y), 1, '<f4'),
@@ -98,7 +103,16 @@ class TorchReducer(object):
                     t = views[ptr] = torch.as_tensor(_DeviceView(ptr, 16, '<f8'),
                                                      device=self.buf.device)
                 with torch.cuda.stream(ext):
-                    self.dist.all_reduce(t, group=self.group)
+                    if self.hook_calls < 256:      # (timed for the first 256 calls)
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        self.dist.all_reduce(t, group=self.group)
+                        e1.record()
+                        self._hook_events.append((e0, e1))
+                    else:
+                        self.dist.all_reduce(t, group=self.group)
+                self.hook_calls += 1
             return hook
         if 'hostsim' not in str(_lib.library_path()):
             import numpy as np
@@ -109,7 +123,11 @@ class TorchReducer(object):
                 solver.sync()
                 _lib.check(_lib.lib().sporco_amd_dev_download(_lib._ptr(stage), ctypes.c_void_p(ptr),
                                                               stage.nbytes))
+                import time
+                t0 = time.perf_counter()
                 self.dist.all_reduce(tstage, group=self.group)
+                self._hook_host_s.append(time.perf_counter() - t0)
+                self.hook_calls += 1
                 _lib.check(_lib.lib().sporco_amd_dev_upload(ctypes.c_void_p(ptr), _lib._ptr(stage),
                                                             stage.nbytes))
             return hook
@@ -122,6 +140,18 @@ class TorchReducer(object):
                 t = views[ptr] = torch.from_numpy(a)
             self.dist.all_reduce(t, group=self.group)
         return hook
+
+    def hook_cost_ms(self):
+        """(mean, max, calls) of the all-reduce inside the device-driven loop's hook, in
+        milliseconds, over the timed calls since the hook was made; None when it never ran."""
+        if getattr(self, '_hook_events', None):
+            self.torch.cuda.synchronize()
+            ms = [a.elapsed_time(b) for a, b in self._hook_events]
+        elif getattr(self, '_hook_host_s', None):
+            ms = [1e3 * t for t in self._hook_host_s]
+        else:
+            return None
+        return (sum(ms) / len(ms), max(ms), len(ms))
 
     def all_reduce_array(self, solver, var):
         """Sum state array ``var`` of ``solver`` over the ranks, in place, in device memory."""
