@@ -535,11 +535,15 @@ template <typename F> void set_lds(F kernel, size_t bytes) {
 }
 
 // Workgroups of a persistent launch (16 waves, K = 64): one per CU, a multiple of 8 (the XCD
-// of a workgroup is blockIdx % 8 for every slot it walks); 0 = one workgroup per tile
-// (SPORCO_AMD_PGM_PERSIST=0, or bit 0 / bit 1 of its value for the gradient / momentum kernel
-// alone).  Stagger as in csc_fused.hip (SPORCO_AMD_PGM_STAGGER_GROUPS / _SLEEPS).
+// of a workgroup is blockIdx % 8 for every slot it walks); 0 = one workgroup per tile.
+// SPORCO_AMD_PGM_PERSIST: bit 0 the gradient kernel, bit 1 the momentum kernel.  Default 1:
+// measured at 512 x 512, K = 64, N = 32 (profiles/r03a_config4.jsonl) 253 it/s with the
+// gradient kernel persistent, 247 with both, 246 with neither, 239 with the momentum kernel
+// alone -- its tile loop costs it 20 more registers (scalar registers run out and spill into
+// vector ones; the statistics variant then spills 60 bytes), which outweighs what the loop buys.
+// Stagger as in csc_fused.hip (SPORCO_AMD_PGM_STAGGER_GROUPS / _SLEEPS).
 static unsigned pgm_persist_grid(PgmColsArgs<float> &a, int NW, int KC, int which) {
-    static int cus = 0, sg = 4, ss = 2, mask = 3;
+    static int cus = 0, sg = 4, ss = 2, mask = 1;
     if (!cus) {
         int dev = 0;
         hipDeviceProp_t pr;
