@@ -4,7 +4,7 @@
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE counts 64 B
 per 128-B request (MI355X_MICROARCH.md, HBM section).
 
-    python tools/hbm_traffic_from_pmc.py <pmc_fetch_size.csv> <pmc_write_size.csv> <out.json> [tag]
+    python tools/hbm_traffic_from_pmc.py <pmc_fetch_size.csv> <pmc_write_size.csv> <out.json> [tag] [kernel_stats.csv]
 """
 import csv
 import json
@@ -21,8 +21,8 @@ def counters(path, name):
 
 
 KERNELS = {      # bench.py's kernel names -> a substring of the dispatch name
-    'rows_fwd': 'rows_fwd_kernel<16, false, false>',
-    'rows_fwd_v': 'rows_fwd_kernel<16, false, true>',
+    'rows_fwd': 'rows_fwd_kernel<16, false, false, false>',
+    'rows_fwd_v': 'rows_fwd_kernel<16, false, true, false>',
     'fused_cols_sm': 'fused_cols_kernel<32, 16, 1, 64, false, false, false, 0>',
     'rows_inv_post': 'rows_inv_post_kernel<16, false, 0, false, false, 0>',
     'rows_inv_post_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 0>',
@@ -44,6 +44,20 @@ def main():
         wk = [v for n, v in w.items() if sub in n]
         if fk and wk:
             out[key] = (2.0 * fk[0] + wk[0]) * 1024.0
+    # optional 5th argument: the kernel statistics of the --kernel-trace --stats run of the same
+    # command (tools/rocpd_summary.py): the working-dispatch averages bench.py quotes beside its
+    # own HIP-event timings
+    if len(sys.argv) > 5:
+        rows = list(csv.reader(open(sys.argv[5])))
+        hdr = rows[0]
+        wi = hdr.index('WorkingAverageNs')
+        avg = {}
+        for key, sub in KERNELS.items():
+            for r in rows[1:]:
+                if len(r) > wi and sub in r[0]:
+                    avg[key] = float(r[wi]) * 1e-6
+        out['_rocprof_avg_ms'] = avg
+        out['_rocprof_source'] = 'rocprofv3 --kernel-trace --stats of `python bench.py` (working dispatches)'
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
