@@ -360,6 +360,8 @@ template <typename T> struct Csc : CscBase {
     T v_thr = T(0), v_prev_thr = T(0);
     T v_thr21 = T(0), v_prev_thr21 = T(0), vp_thr21 = T(0);   // ConvBPDNJoint: the l2,1 thresholds
     bool v_nonneg = false, v_joint = false;
+    uint32_t v_opts = 0;     // F_NOBNDRY | F_AMS of the iterations that produced the V's
+    int v_dH = 1, v_dW = 1;  // ... and their filter support (NoBndryCross)
     int v_prev_kind = 0;
     bool vp_pending = false;       // the previous iterate still waits, in V form, in vp_buf
     T *vp_buf = nullptr, *vp_free = nullptr;
@@ -675,15 +677,26 @@ template <typename T> struct Csc : CscBase {
     // ---- single-array state (csc_rows.h): back to the (Y, U) form ----------------------------
     bool vform_ok(const sporco_amd_admm_params &p) const {
         const bool off = std::getenv("SPORCO_AMD_NO_VFORM") != nullptr;   // (test switch)
-        return !off && std::is_same<T, float>::value && rows_ok && !wl1.ptr &&
-               !(p.flags & (F_NOBNDRY | F_AMS | F_KEEP_X | F_FEVAL_Y | F_XRRS)) &&
+        return !off && std::is_same<T, float>::value && rows_ok &&
+               !(p.flags & (F_KEEP_X | F_FEVAL_Y | F_XRRS)) &&
                (!(p.flags & F_JOINT) || joint_rows_ok(p));
+    }
+    // the live V was produced under the options of p (otherwise: back to (Y, U) first)
+    bool vform_same_opts(const sporco_amd_admm_params &p) const {
+        const uint32_t o = p.flags & (F_NOBNDRY | F_AMS);
+        return (bool)(p.flags & F_NONNEG) == v_nonneg && (bool)(p.flags & F_JOINT) == v_joint &&
+               o == v_opts && (!(o & F_NOBNDRY) || (p.dH == v_dH && p.dW == v_dW));
     }
     // Y (and / or U) of an iterate held as V: y or u may be null, u may alias v
     void vform_split(const T *v, T *y, T *u, T thr, T thr21) {
         if (v_joint)
             launch_vform_split_joint<T>(st, v, y, u, thr, thr21, v_nonneg, C, (int64_t)N * K,
                                         (int64_t)H * W);
+        else if (wl1.ptr || v_opts)
+            launch_vform_split_general<T>(st, v, y, u, thr,
+                                          (v_nonneg ? F_NONNEG : 0u) | (v_opts & F_NOBNDRY), d5(),
+                                          v_dH, v_dW, wl1, (v_opts & F_AMS) ? wams : Weight<T>(),
+                                          Ku - 1);
         else
             launch_vform_split<T>(st, v, y, u, thr, v_nonneg, E);
     }
@@ -1169,7 +1182,7 @@ template <typename T> struct Csc : CscBase {
         // with an emitted spectrum).  Anything else that wants Y or U gets them through
         // ensure_yu() (var_ptr).
         const bool nn = p.flags & F_NONNEG, jn = p.flags & F_JOINT;
-        if (v_live && (!vform_ok(p) || nn != v_nonneg || jn != v_joint)) ensure_yu();
+        if (v_live && (!vform_ok(p) || !vform_same_opts(p))) ensure_yu();
         const bool vf = vform_ok(p) && (v_live || touch_epoch == fused_epoch);
         T *vin = vf && v_live ? v_cur : nullptr;
         T *Y = vin ? nullptr : rv(SPORCO_AMD_VAR_Y), *U = vin ? nullptr : rv(SPORCO_AMD_VAR_U);
@@ -1181,7 +1194,7 @@ template <typename T> struct Csc : CscBase {
         T *vout = vf ? (vin == y_alt ? u_alt : y_alt) : nullptr;
         // rows_fwd, unless the previous iteration already left its result behind
         if (!(t_ready && p.u_scale == 1.0)) {
-            if (vin) launch_rows_fwd_on(nullptr, nullptr, (T)p.u_scale, vin, v_thr, p.flags, v_thr21);
+            if (vin) launch_rows_fwd_on(nullptr, nullptr, (T)p.u_scale, vin, v_thr, p.flags, v_thr21, &p);
             else launch_rows_fwd_on(Y, U, (T)p.u_scale);
         }
         t_ready = false;
@@ -1263,6 +1276,9 @@ template <typename T> struct Csc : CscBase {
             v_thr21 = pa.thr21;
             v_nonneg = nn;
             v_joint = jn;
+            v_opts = p.flags & (F_NOBNDRY | F_AMS);
+            v_dH = p.dH;
+            v_dW = p.dW;
             v_live = true;
             vp_pending = false;
             last_p = p;
@@ -1307,6 +1323,13 @@ template <typename T> struct Csc : CscBase {
             ra.flags = p.flags;
             ra.C = C;
             ra.N = N;
+            if (vin) {
+                ra.wl1 = wl1;
+                ra.dH = p.dH;
+                ra.dW = p.dW;
+                ra.ams_bits = ams_bits_of(p);
+                ra.ams_k = Ku - 1;
+            }
             ra.s2 = T(1);
             ra.t = Xf;
             ra.Ks = Ks;
@@ -1415,7 +1438,7 @@ template <typename T> struct Csc : CscBase {
         // few iterations (a dictionary-learning X-step) stays in the (Y, U) form: it would pay
         // the conversion back at once.
         const bool nn = p.flags & F_NONNEG, jn = p.flags & F_JOINT;
-        if (v_live && (!vform_ok(p) || nn != v_nonneg || jn != v_joint)) ensure_yu();
+        if (v_live && (!vform_ok(p) || !vform_same_opts(p))) ensure_yu();
         const bool vf = vform_ok(p) && (v_live || c.max_iter >= 4);
         if (!vf) ensure_yu();
         const bool v_at_entry = v_live;
@@ -1559,6 +1582,9 @@ template <typename T> struct Csc : CscBase {
             }
             v_nonneg = nn;
             v_joint = jn;
+            v_opts = p.flags & (F_NOBNDRY | F_AMS);
+            v_dH = p.dH;
+            v_dW = p.dW;
             v_live = true;
         }
         vp_pending = false;
@@ -1621,8 +1647,16 @@ template <typename T> struct Csc : CscBase {
     }
 
     void launch_rows_fwd_on(const T *Yin, const T *Uin, T s2, const T *Vin = nullptr,
-                            T thr_prev = T(0), uint32_t flags = 0, T thr21_prev = T(0)) {
+                            T thr_prev = T(0), uint32_t flags = 0, T thr21_prev = T(0),
+                            const sporco_amd_admm_params *vp = nullptr) {
         RowsFwdArgs<T> ra;
+        if (Vin && vp) {     // the options the derivation of Y from V repeats
+            ra.wl1 = wl1;
+            ra.dH = vp->dH;
+            ra.dW = vp->dW;
+            ra.ams_bits = ams_bits_of(*vp);
+            ra.ams_k = Ku - 1;
+        }
         ra.y = Yin;
         ra.u = Uin;
         ra.v = Vin;

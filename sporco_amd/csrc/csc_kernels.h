@@ -112,6 +112,11 @@ void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t 
 // U = V - Y; y or u may be null, u may alias v
 template <typename T>
 void launch_vform_split(hipStream_t st, const T *v, T *y, T *u, T thr, bool nonneg, int64_t n);
+// ... under an L1Weight array / NoBndryCross / AddMaskSim (flags: F_NONNEG | F_NOBNDRY; ams: the
+// mask of the impulse slice ams_k, or a null Weight)
+template <typename T>
+void launch_vform_split_general(hipStream_t st, const T *v, T *y, T *u, T thr, uint32_t flags,
+                                Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> ams, int ams_k);
 // ... of ConvBPDNJoint: Y = prox_sl1l2(V; thr, thr21) over the C <= 4 channels (arrays
 // (npixel, C, NK), NK = N * K)
 template <typename T>

@@ -759,6 +759,64 @@ void launch_vform_split_joint(hipStream_t st, const T *v, T *y, T *u, T thr, T t
     SA_HIP(hipGetLastError());
 }
 
+// ... under an L1Weight array / NoBndryCross / AddMaskSim: the per-element constants of the row
+// epilogue (csc_rows.hip rows_inv_post_tile) -- weight (0 on the AddMaskSim impulse slice, which
+// is neither shrunk nor clamped), the boundary band and the mask as multiplicative 0 / 1.
+template <typename T> struct VsplitArgs {
+    const T *v;
+    T *y, *u;
+    T thr;
+    uint32_t flags;
+    Dims5 d;
+    int dH, dW;
+    Weight<T> wl1, ams;
+    int ams_k;
+};
+template <typename T>
+__global__ void __launch_bounds__(kThreads) vform_split_general_kernel(const VsplitArgs<T> p) {
+#pragma clang fp contract(off)
+    const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY;
+    const int64_t P = (int64_t)p.d.C * p.d.N * p.d.K;
+    const int64_t total = (int64_t)p.d.H * p.d.W * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / P;
+        const int r = (int)(i - pix * P);
+        const int k = r % p.d.K, n = (r / p.d.K) % p.d.N, c = r / (p.d.K * p.d.N);
+        const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
+        const bool am = p.ams.ptr && k == p.ams_k;
+        T wt = p.wl1.ptr ? weight_at(p.wl1, h, xw, c, n, k) : T(1);
+        if (am) wt = T(0);
+        const T keep = (nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW)) ? T(0) : T(1);
+        const T mkeep = (am && weight_at(p.ams, h, xw, c, n, 0) != T(0)) ? T(0) : T(1);
+        const T vv = p.v[i];
+        T yy = soft(vv, p.thr * wt);
+        if (nonneg && !am && yy < T(0)) yy = T(0);
+        yy *= am ? mkeep : keep;
+        if (p.y) p.y[i] = yy;
+        if (p.u) p.u[i] = vv - yy;
+    }
+}
+template <typename T>
+void launch_vform_split_general(hipStream_t st, const T *v, T *y, T *u, T thr, uint32_t flags,
+                                Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> ams, int ams_k) {
+    VsplitArgs<T> p;
+    p.v = v;
+    p.y = y;
+    p.u = u;
+    p.thr = thr;
+    p.flags = flags;
+    p.d = d;
+    p.dH = dH;
+    p.dW = dW;
+    p.wl1 = wl1;
+    p.ams = ams;
+    p.ams_k = ams_k;
+    const int64_t total = (int64_t)d.H * d.W * d.C * d.N * d.K;
+    hipLaunchKernelGGL((vform_split_general_kernel<T>), dim3(grid_for(total)), dim3(kThreads), 0, st, p);
+    SA_HIP(hipGetLastError());
+}
+
 template <typename T>
 void launch_vform_split(hipStream_t st, const T *v, T *y, T *u, T thr, bool nonneg, int64_t n) {
     hipLaunchKernelGGL((vform_split_kernel<T>), dim3(grid_for(n)), dim3(kThreads), 0, st, v, y, u, thr,
@@ -2802,6 +2860,8 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *);                \
     template void launch_relax<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template void launch_vform_split<T>(hipStream_t, const T *, T *, T *, T, bool, int64_t);       \
+    template void launch_vform_split_general<T>(hipStream_t, const T *, T *, T *, T, uint32_t, Dims5, \
+                                                int, int, Weight<T>, Weight<T>, int);            \
     template void launch_vform_split_joint<T>(hipStream_t, const T *, T *, T *, T, T, bool, int,   \
                                               int64_t, int64_t);                                \
     template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \

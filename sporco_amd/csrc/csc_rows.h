@@ -54,7 +54,13 @@ template <typename T> struct RowsFwdArgs {
                            // prox_sl1l2(V) over the channel axis -- the kernel then tiles as the
                            // joint epilogue does (lane = (channel, filter pair)) and needs C, N
     T thr21_prev = T(0);   // F_JOINT: mu / rho of that iteration (ctl: ctl->thr21_prev_f)
-    int C = 1, N = 0;      // F_JOINT: channels and images (CN = C * N)
+    int C = 1, N = 0;      // channels and images (CN = C * N): F_JOINT, and the options below
+    // ... with an L1Weight array, NoBndryCross or AddMaskSim the derivation repeats those too
+    // (same fields as RowsPostArgs; flags then carries F_NOBNDRY as well)
+    Weight<T> wl1;
+    int dH = 1, dW = 1;
+    const uint32_t *ams_bits = nullptr;
+    int ams_k = -1;
     int y_bcast = 0;   // y is (H, W, K), broadcast over the CN blocks (consensus D-step)
     int Ks = 0;        // row stride of t in filters when it is not K (0: K), see csc_fused.h
     // device-driven solve (csc_kernels.h AdmmCtl): s2 is ctl->u_scale_f, and the launch returns
@@ -73,7 +79,7 @@ template <typename T> struct RowsPostArgs {
     const T *y, *u;    // in: real (H, W, P)
     T *y_out, *u_out;  // out (may alias y, u: every element is read and written by one thread)
     T *x;              // out (optional, may be null): X = irfftn(Xf)
-    // Single-array state ("V form"; the plain and the joint epilogue: scalar weights, no X output):
+    // Single-array state ("V form"; every epilogue variant without an X output):
     //   v_out  the epilogue stores V' = AX + U (scaled) instead of Y' and U' -- both are
     //          functions of V' alone (Y' = prox(V'), U' = V' - Y'), so one array carries the
     //          iterate: one write pass instead of two;

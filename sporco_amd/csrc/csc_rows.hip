@@ -288,11 +288,15 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // Y = prox(V; thr_prev) (+ NonNeg), U = V - Y per element, then Y - s2 U as before.
 // JOINT (with VFORM): Y = prox_sl1l2(V) couples the channels, so the tile is the joint epilogue's
 // -- one image, 32 filters, all C <= 4 channels, lane = (channel, filter pair).
-template <int NW, bool BCAST, bool VFORM, bool JOINT, typename AP>
+// MODE (with VFORM, as rows_inv_post): 1 = L1Weight array (+ NoBndryCross, AddMaskSim), 2 =
+// NoBndryCross and / or AddMaskSim without a weight array -- the derivation of Y repeats them.
+template <int NW, bool BCAST, bool VFORM, bool JOINT, int MODE, typename AP>
 __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     constexpr int N1 = kN1, W = N1 * NW;
+    constexpr bool GENERAL = MODE != 0;
     static_assert(!(BCAST && VFORM), "the broadcast form reads a dictionary-sized Y");
     static_assert(!JOINT || VFORM, "only the V form needs the joint tiling");
+    static_assert(!GENERAL || (VFORM && !JOINT), "options of the derivation: plain V form only");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -337,6 +341,27 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     const int pixbytes = (int)(a->P * (int64_t)sizeof(float));
     const int yvoff = BCAST ? (pv ? k * (int)sizeof(float) : (int)0x80000000) : voff;
     const int ypixbytes = BCAST ? a->K * (int)sizeof(float) : pixbytes;
+    // the per-element constants of the epilogue's prox (rows_inv_post_tile), when the options need them
+    int wlane = 0;
+    const int ws4 = GENERAL ? (int)a->wl1.stride[4] : 0;
+    bool hkill = false, am_e[2] = {false, false};
+    int x0kill = 0;
+    uint32_t mbits = 0u;
+    if constexpr (GENERAL) {
+        const bool nob = a->flags & F_NOBNDRY;
+        if (MODE == 1) {
+            const int c = cn / a->N, n = cn % a->N;
+            wlane = (int)(c * a->wl1.stride[2] + n * a->wl1.stride[3] + k * a->wl1.stride[4]);
+        }
+        hkill = nob && h >= ((a->dH > 1) ? a->H - (a->dH - 1) : 0);
+        x0kill = nob ? ((a->dW > 1) ? W - (a->dW - 1) : 0) : W;
+        const bool aml = a->ams_bits != nullptr && pv && (k | 1) == (a->ams_k | 1);
+        am_e[0] = aml && !(a->ams_k & 1);
+        am_e[1] = aml && (a->ams_k & 1);
+        const BufRsrc Mb = make_rsrc(a->ams_bits, a->ams_bits ? (uint32_t)((int64_t)a->H * a->CN * NW * 4) : 0u);
+        const int mvoff = aml ? cn * NW * 4 : (int)0x80000000;
+        mbits = __builtin_bit_cast(uint32_t, sa_buf_load1(Mb, mvoff, (h * a->CN * NW + w) * 4));
+    }
     cf v[N1];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -356,7 +381,20 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                 // fuses depends on the code around it)
 #pragma clang fp contract(off)
                 const cf vv = uv[i];
-                float y0 = soft1(vv.re, thr_p), y1 = soft1(vv.im, thr_p);
+                float t0 = thr_p, t1 = thr_p;
+                if constexpr (GENERAL) {
+                    float w0 = 1.f, w1 = 1.f;
+                    if (MODE == 1) {
+                        const int xw = NW * (half * (N1 / 2) + i) + w;
+                        const float *wrow = a->wl1.ptr + (int64_t)h * a->wl1.stride[0] +
+                                            (int64_t)xw * a->wl1.stride[1];
+                        w0 = wrow[wlane];
+                        w1 = wrow[wlane + ws4];
+                    }
+                    t0 = thr_p * (am_e[0] ? 0.f : w0);
+                    t1 = thr_p * (am_e[1] ? 0.f : w1);
+                }
+                float y0 = soft1(vv.re, t0), y1 = soft1(vv.im, t1);
                 if constexpr (JOINT) {      // the l2 shrinkage over the channels, as the epilogue
                     float f0 = 1.f - thr21_p * sa_rsq(sum_over_rows(y0 * y0));
                     float f1 = 1.f - thr21_p * sa_rsq(sum_over_rows(y1 * y1));
@@ -365,8 +403,15 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                     y0 = f0 * y0;
                     y1 = f1 * y1;
                 }
-                if (nonneg && y0 < 0.f) y0 = 0.f;
-                if (nonneg && y1 < 0.f) y1 = 0.f;
+                if (nonneg && !am_e[0] && y0 < 0.f) y0 = 0.f;
+                if (nonneg && !am_e[1] && y1 < 0.f) y1 = 0.f;
+                if constexpr (GENERAL) {
+                    const int n1 = half * (N1 / 2) + i;
+                    const float keep = (hkill || NW * n1 + w >= x0kill) ? 0.f : 1.f;
+                    const float mkeep = ((mbits >> n1) & 1u) ? 0.f : 1.f;
+                    y0 *= am_e[0] ? mkeep : keep;
+                    y1 *= am_e[1] ? mkeep : keep;
+                }
                 yv[i] = mk<float>(y0, y1);
                 uv[i] = mk<float>(vv.re - y0, vv.im - y1);
             }
@@ -402,14 +447,14 @@ __device__ __forceinline__ void rows_tile_loop(const A &a_in, int tiles_x, int t
     }
 }
 
-template <int NW, bool BCAST, bool VFORM = false, bool JOINT = false>
+template <int NW, bool BCAST, bool VFORM = false, bool JOINT = false, int MODE = 0>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a_in) {
     // device-driven solve: nothing to do once the stopping test is met, or when the previous
     // epilogue already left this spectrum behind
     if (a_in.ctl && (a_in.ctl->stop | a_in.ctl->skip_fwd)) return;
     const int tiles_x = JOINT ? a_in.N * (a_in.K >> 5) : (int)((a_in.P + 127) / 128);
     rows_tile_loop(a_in, tiles_x, a_in.H,
-                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM, JOINT>(a, bx, h); });
+                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM, JOINT, MODE>(a, bx, h); });
 }
 
 // ---------------------------------------------------------------------------
@@ -423,7 +468,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     constexpr bool GENERAL = MODE != 0;
     constexpr bool VIN = SF == 2, VOUT = SF != 0;
     static_assert(!JOINT || MODE == 0, "the joint epilogue takes scalar weights only");
-    static_assert(SF == 0 || (MODE == 0 && !WRITE_X), "V form: scalar weights, no X output");
+    static_assert(SF == 0 || !WRITE_X, "V form: no X output");
     constexpr int N1 = kN1, W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -530,18 +575,35 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             const float xs[2] = {v[n1].re * scale, v[n1].im * scale};
             float yo[2] = {yb[b & 1][i].re, yb[b & 1][i].im};
             float uraw[2];
+            // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
+            // epilogue into dozens of blocks and the register allocator spills the tile)
+            const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
+            const float mkeep = (GENERAL && ((mbits >> n1) & 1u)) ? 0.f : 1.f;
+            float wte[2] = {1.f, 1.f};
+            if constexpr (!JOINT && GENERAL) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (MODE == 1) {
+                        const float *wrow = a->wl1.ptr + (int64_t)h * a->wl1.stride[0] +
+                                            (int64_t)xw * a->wl1.stride[1];
+                        wte[e] = wrow[wlane + e * ws4];
+                    }
+                    wte[e] = am_e[e] ? 0.f : wte[e];
+                }
+            }
             if constexpr (VIN) {
-                // the previous iterate from its V: Y = prox(V; thr_prev) (+ NonNeg), U = V - Y
+                // the previous iterate from its V: Y = prox(V; thr_prev) (+ the options), U = V - Y
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float vp = yo[e];
-                    float yp = soft1(vp, thr_p);
+                    float yp = soft1(vp, thr_p * wte[e]);
                     if constexpr (JOINT) {
                         float fp = 1.f - thr21_p * sa_rsq(sum_over_rows(yp * yp));
                         fp = fp > 0.f ? fp : 0.f;
                         yp = fp * yp;
                     }
-                    if (nonneg && yp < 0.f) yp = 0.f;
+                    if (nonneg && !(GENERAL && am_e[e]) && yp < 0.f) yp = 0.f;
+                    if constexpr (GENERAL) yp *= am_e[e] ? mkeep : keep;
                     yo[e] = yp;
                     uraw[e] = vp - yp;
                 }
@@ -551,10 +613,6 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             }
             const float uo[2] = {usc * uraw[0], usc * uraw[1]};
             float yn[2], un[2], vn[2] = {0.f, 0.f};
-            // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
-            // epilogue into dozens of blocks and the register allocator spills the tile)
-            const float keep = (GENERAL && (hkill || (nob && xw >= x0kill))) ? 0.f : 1.f;
-            const float mkeep = (GENERAL && ((mbits >> n1) & 1u)) ? 0.f : 1.f;
             if constexpr (JOINT) {
                 // prox_sl1l2 over the channel axis (cbpdn.py:785-794): soft threshold, then the
                 // channel vector of each (pixel, image, filter) shrunk in l2 norm,
@@ -592,13 +650,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             for (int e = 0; e < 2; ++e) {
                 const float ax = al * xs[e] + oma * yo[e];
                 const bool am = GENERAL && am_e[e];
-                float wt = 1.f;
-                if (MODE == 1) {
-                    const float *wrow = a->wl1.ptr + (int64_t)h * a->wl1.stride[0] +
-                                        (int64_t)xw * a->wl1.stride[1];
-                    wt = wrow[wlane + e * ws4];
-                }
-                if (GENERAL) wt = am ? 0.f : wt;
+                const float wt = wte[e];
                 // V' = AX + U: the new iterate is a function of it alone (Y' = prox(V'),
                 // U' = V' - Y'), which is what the V form stores
                 const float vv = ax + uo[e];
@@ -822,6 +874,35 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
         attr_set = true;
     }
     SA_REQUIRE(!(a.v && a.y_bcast), "the broadcast row pass has no V form");
+    if (a.v && !(a.flags & F_JOINT) &&
+        (a.wl1.ptr || (a.flags & F_NOBNDRY) || a.ams_bits)) {
+        // the V form under an L1Weight array / NoBndryCross / AddMaskSim
+        static bool gattr = false;
+        if (!gattr) {
+            set_lds_attr<4>(&rows_fwd_kernel<4, false, true, false, 1>);
+            set_lds_attr<8>(&rows_fwd_kernel<8, false, true, false, 1>);
+            set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 1>);
+            set_lds_attr<4>(&rows_fwd_kernel<4, false, true, false, 2>);
+            set_lds_attr<8>(&rows_fwd_kernel<8, false, true, false, 2>);
+            set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 2>);
+            gattr = true;
+        }
+        SA_REQUIRE(a.C * a.N == a.CN, "the derivation needs the channel / image split");
+        const dim3 grid = rows_grid(a, a.W / kN1, ceil_div(a.P, 128), a.H, 0);
+        const bool m1 = a.wl1.ptr != nullptr;
+        if (a.W == 128) {
+            if (m1) hipLaunchKernelGGL((rows_fwd_kernel<4, false, true, false, 1>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
+            else hipLaunchKernelGGL((rows_fwd_kernel<4, false, true, false, 2>), grid, dim3(4 * 64), rows_lds_bytes(4), st, a);
+        } else if (a.W == 256) {
+            if (m1) hipLaunchKernelGGL((rows_fwd_kernel<8, false, true, false, 1>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
+            else hipLaunchKernelGGL((rows_fwd_kernel<8, false, true, false, 2>), grid, dim3(8 * 64), rows_lds_bytes(8), st, a);
+        } else {
+            if (m1) hipLaunchKernelGGL((rows_fwd_kernel<16, false, true, false, 1>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+            else hipLaunchKernelGGL((rows_fwd_kernel<16, false, true, false, 2>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+        }
+        SA_HIP(hipGetLastError());
+        return;
+    }
     if (a.v && (a.flags & F_JOINT)) {
         // the V form of ConvBPDNJoint: tiles as the joint epilogue (one image, 32 filters, all
         // channels per workgroup)
@@ -878,15 +959,27 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 gr
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 2, EMIT>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, false, 1>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, false, 2>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 1, EMIT, false, 1>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 1, EMIT, false, 2>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 2, EMIT, false, 1>);
+        set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 2, EMIT, false, 2>);
         attr_set = true;
     }
     const int mode = a.wl1.ptr != nullptr ? 1 : (((a.flags & F_NOBNDRY) || a.ams_bits) ? 2 : 0);
     const dim3 block(NW * 64);
     const size_t lds = rows_lds_bytes(NW);
     if (a.v_out) {      // single-array state (csc_rows.h)
-        SA_REQUIRE(mode == 0 && !a.x, "the V form serves the plain epilogue only");
-        if (a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, false, 2>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, false, 1>), grid, block, lds, st, a);
+        SA_REQUIRE(!a.x, "the V form has no X output");
+        if (mode == 1) {
+            if (a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 1, EMIT, false, 2>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 1, EMIT, false, 1>), grid, block, lds, st, a);
+        } else if (mode == 2) {
+            if (a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 2, EMIT, false, 2>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 2, EMIT, false, 1>), grid, block, lds, st, a);
+        } else {
+            if (a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, false, 2>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, false, 1>), grid, block, lds, st, a);
+        }
         return;
     }
     SA_REQUIRE(!a.v_in, "a V-form input needs a V-form output");

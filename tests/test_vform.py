@@ -159,15 +159,62 @@ def test_joint_v_form_is_bit_identical_and_matches_the_oracle(backend, case, hos
             assert rel_l2(o1['stats'][f], ref[f]) < 1e-3, f
 
 
-def test_options_outside_the_v_form_keep_the_yu_form(backend):
-    """Weight arrays / NoBndryCross run the (Y, U) epilogues."""
+@pytest.mark.parametrize('opt_case', ['l1weight', 'nobndry', 'nobndry_nonneg_weight'])
+@pytest.mark.parametrize('host', [False, True])
+def test_v_form_under_weights_and_nobndrycross(backend, opt_case, host):
+    """An L1Weight array, NoBndryCross: the derivation of Y from V repeats the weight, the clamp and
+    the boundary band of the row epilogue (sporco/admm/cbpdn.py:297-311, 614-620)."""
+    from oracle import cbpdn_oracle as orc
+    if backend == 'hostsim' and host and opt_case != 'l1weight':
+        pytest.skip("kept short on the CPU simulator")
+    H = 256 if backend == 'gpu' else 128
+    K, N = (16, 3) if backend == 'gpu' else (4, 2)
+    D, S = problem(H, H, K, N, seed=15)
+    w = (0.5 + np.abs(np.random.RandomState(3).randn(H, H, 1, 1, K))).astype(np.float32)
+    extra = {'l1weight': {'L1Weight': w}, 'nobndry': {'NoBndryCross': True},
+             'nobndry_nonneg_weight': {'NoBndryCross': True, 'NonNegCoef': True, 'L1Weight': w}}[opt_case]
+    optd = dict({'MaxMainIter': 7, 'RelStopTol': 0.0}, **extra)
+    b0, o0 = run(D, S, optd, vform=False, host=host)
+    b1, o1 = run(D, S, optd, vform=True, host=host)
+    assert b1._dev.uses_fused_rows() and b1._fused_ok()
+    assert o0['live'] == [0] and o1['live'] == [1]
+    same(o0, o1)
+    if not host:
+        ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, H, 1, N, 1), 0.05,
+                             dtype=np.float64, maxiter=7, rel_tol=0.0,
+                             wl1=extra.get('L1Weight', 1.0), nonneg='NonNegCoef' in extra,
+                             nobndry='NoBndryCross' in extra)
+        assert rel_l2(o1['Y'], ref['Y']) < 1e-4 and rel_l2(o1['U'], ref['U']) < 1e-4
+
+
+def test_v_form_under_addmasksim_and_gradreg(backend):
+    """AddMaskSim (the impulse slice: no shrinkage, masked) and ConvBPDNGradReg run the V form
+    too; against the (Y, U) form of the same library, bit for bit."""
     from sporco_amd import _lib
     from sporco_amd.admm import cbpdn
-    D, S = problem(128, 128, 4, 2, seed=14)
-    w = np.abs(np.random.RandomState(3).randn(128, 128, 1, 1, 4)).astype(np.float32)
-    for extra in ({'L1Weight': w}, {'NoBndryCross': True}):
-        optd = dict({'MaxMainIter': 5, 'RelStopTol': 0.0}, **extra)
-        b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
-        b._return_min = False
-        b.solve()
-        assert b._dev.uses_fused_rows() and b._dev.query(_lib.QUERY_VFORM_LIVE) == 0
+    H = 256 if backend == 'gpu' else 128
+    K, N = (7, 2) if backend == 'gpu' else (3, 1)
+    D, S = problem(H, H, K, N, seed=16)
+    W = (np.random.RandomState(4).rand(H, H, N) > 0.3).astype(np.float32)
+    outs = {}
+    for vform in (False, True):
+        if not vform:
+            os.environ['SPORCO_AMD_NO_VFORM'] = '1'
+        try:
+            opt = cbpdn.ConvBPDN.Options({'MaxMainIter': 6, 'RelStopTol': 0.0})
+            a = cbpdn.AddMaskSim(cbpdn.ConvBPDN, D, S, W, 0.05, opt=opt)
+            Ya = a.solve()
+            live_a = a.cbpdn._dev.query(_lib.QUERY_VFORM_LIVE) if hasattr(a, 'cbpdn') else None
+            og = cbpdn.ConvBPDNGradReg.Options({'MaxMainIter': 6, 'RelStopTol': 0.0})
+            g = cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.1, og)
+            g._return_min = False
+            g.solve()
+            live_g = g._dev.query(_lib.QUERY_VFORM_LIVE)
+            outs[vform] = (Ya, a.getitstat(), g.Y.copy(), g.U.copy(), g.getitstat(), live_g)
+        finally:
+            os.environ.pop('SPORCO_AMD_NO_VFORM', None)
+    assert outs[False][5] == 0 and outs[True][5] == 1
+    assert np.array_equal(outs[False][0], outs[True][0])
+    assert np.array_equal(np.asarray(outs[False][1].ObjFun), np.asarray(outs[True][1].ObjFun))
+    assert np.array_equal(outs[False][2], outs[True][2]) and np.array_equal(outs[False][3], outs[True][3])
+    assert np.array_equal(np.asarray(outs[False][4].ObjFun), np.asarray(outs[True][4].ObjFun))
