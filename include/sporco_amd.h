@@ -141,6 +141,14 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
                                             form of the fused iteration (V = AX + U; Y and U
                                             are derived on the next access) -- diagnostics */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
+/* Hints about how the handle will be used (never needed for correctness; no reference
+ * counterpart).  KEEP_VFORM: the caller alternates short device-driven runs with
+ * sporco_amd_csc_ccmod_setcoef(VAR_Y) and does not read Y or U in between -- the loop of
+ * dictlrn.DictLearn.solve (sporco/dictlrn/dictlrn.py:319-375) -- so even a one-iteration
+ * sporco_amd_csc_admm_run keeps the iterate in its single-array form and setcoef derives Y from
+ * it on the way into its row transform. */
+#define SPORCO_AMD_HINT_KEEP_VFORM 0
+int sporco_amd_csc_set_hint(sporco_amd_csc_t h, int what, int value);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))
  * on device -- sporco/admm/cbpdn.py:228-231, sporco/fft.py:257-286. */

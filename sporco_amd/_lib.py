@@ -36,6 +36,7 @@ FLAG_NO_X = 1 << 9
 FLAG_GRADREG = 1 << 10
 FLAG_AMS = 1 << 11
 QUERY_FUSED_COLS, QUERY_FUSED_ROWS, QUERY_FUSED_PGM, QUERY_DEVICE_FILTERS, QUERY_VFORM_LIVE = 0, 1, 2, 3, 4
+HINT_KEEP_VFORM = 0
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7
@@ -51,7 +52,7 @@ EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc',
     'sporco_amd_csc_destroy',
-    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
+    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_set_hint', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
@@ -219,6 +220,7 @@ def load(path=None):
         'sporco_amd_csc_destroy': [vp], 'sporco_amd_csc_sync': [vp],
         'sporco_amd_csc_stream': [vp, ctypes.POINTER(ctypes.c_void_p)],
         'sporco_amd_csc_query': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+        'sporco_amd_csc_set_hint': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_set_signal': [vp, vp],
         'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
         'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
@@ -437,6 +439,9 @@ class Solver(object):
         out = ctypes.c_void_p(0)
         check(self._lib.sporco_amd_csc_stream(self._h, ctypes.byref(out)))
         return int(out.value or 0)
+
+    def set_hint(self, what, value):
+        check(self._lib.sporco_amd_csc_set_hint(self._h, int(what), int(value)))
 
     def query(self, what):
         out = ctypes.c_int(0)

@@ -154,6 +154,7 @@ struct CscBase {
     virtual void sync() = 0;
     virtual void *stream_handle() = 0;
     virtual int query(int what) = 0;
+    virtual void set_hint(int what, int value) = 0;
     virtual void set_signal(const void *S) = 0;
     virtual void set_signal_dev(const void *S_dev) = 0;
     virtual void reconstruct_dev(int var, void *dst_dev) = 0;
@@ -583,6 +584,11 @@ template <typename T> struct Csc : CscBase {
     // K > 64 -- rows of exactly K filters (a handle in tail mode, 64 < K <= 72, pads the rows of
     // its Xf buffer to 80 for the ADMM tail kernels: the staged composition serves it).
     bool pgm_fused_ok() const { return rows_ok && cols256 && (fused || (fused_slabs && !tail_mode)); }
+    bool hint_vform = false;
+    void set_hint(int what, int value) override {
+        if (what == SPORCO_AMD_HINT_KEEP_VFORM) hint_vform = value != 0;
+        else throw Error(SPORCO_AMD_EINVAL, "unknown hint");
+    }
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
@@ -1439,7 +1445,7 @@ template <typename T> struct Csc : CscBase {
         // the conversion back at once.
         const bool nn = p.flags & F_NONNEG, jn = p.flags & F_JOINT;
         if (v_live && (!vform_ok(p) || !vform_same_opts(p))) ensure_yu();
-        const bool vf = vform_ok(p) && (v_live || c.max_iter >= 4);
+        const bool vf = vform_ok(p) && (v_live || c.max_iter >= 4 || hint_vform);
         if (!vf) ensure_yu();
         const bool v_at_entry = v_live;
         T *const v_entry = v_cur;
@@ -2286,7 +2292,29 @@ template <typename T> struct Csc : CscBase {
             !(cns_active && !cns_fused()) && !eq_active) {
             // rows then columns, register-resident, straight into the tile-major layout
             RowsFwdArgs<T> ra;
-            ra.y = rv(var);
+            // (the iterate in its single-array form: Y = prox(V) is derived inside the row pass
+            // -- with s2 = 0 the kernel transforms Y - 0 U = Y -- instead of being written out first)
+            const bool from_v = var == SPORCO_AMD_VAR_Y && v_live;
+            if (from_v) {
+                ra.y = nullptr;
+                ra.v = v_cur;
+                ra.thr_prev = v_thr;
+                ra.thr21_prev = v_thr21;
+                ra.flags = (v_nonneg ? F_NONNEG : 0u) | (v_joint ? F_JOINT : 0u) | v_opts;
+                ra.C = C;
+                ra.N = N;
+                ra.wl1 = wl1;
+                ra.dH = v_dH;
+                ra.dW = v_dW;
+                if (v_opts & F_AMS) {
+                    sporco_amd_admm_params q = last_p;
+                    q.flags |= F_AMS;
+                    ra.ams_bits = ams_bits_of(q);
+                    ra.ams_k = Ku - 1;
+                }
+            } else {
+                ra.y = rv(var);
+            }
             ra.u = nullptr;
             ra.s2 = T(0);
             ra.t = cv(SPORCO_AMD_VAR_ZF);
@@ -3538,6 +3566,13 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream) {
     SA_HANDLE(h);
     SA_REQUIRE(stream, "null argument");
     *stream = h->impl->stream_handle();
+    SA_API_END
+}
+
+int sporco_amd_csc_set_hint(sporco_amd_csc_t h, int what, int value) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->set_hint(what, value);
     SA_API_END
 }
 

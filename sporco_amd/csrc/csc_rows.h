@@ -131,6 +131,8 @@ template <typename T> struct RowsProxArgs {
     int Ks = 0;        // row stride of t_in / t_out in filters when it is not K (0: K)
     Weight<T> wl1;
     double *partials;  // per tile 1 double: sum |wl1 * X|
+    int persist = 0;   // set by the launcher (see RowsFwdArgs)
+    int stagger_groups = 1, stagger_sleeps = 0;
 };
 template <typename T> int64_t launch_rows_inv_prox_fwd(hipStream_t st, const RowsProxArgs<T> &a);
 

@@ -720,14 +720,14 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostAr
 // ---------------------------------------------------------------------------
 // rows_inv_prox_fwd: X = prox_l1(irfft_W(T_in) / (H W)); T_out = rfft_W(X)
 // ---------------------------------------------------------------------------
-template <int NW, bool GENERAL>
-__global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsProxArgs<float> a) {
+template <int NW, bool GENERAL, typename AP>
+__device__ __forceinline__ void rows_inv_prox_fwd_tile(AP ap, int bx, int h, int tiles_x) {
     constexpr int N1 = kN1, W = N1 * NW;
+    const auto &a = *ap;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
-    const int h = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const int64_t p = (int64_t)bx * 128 + 2 * lane;
     const bool pv = p < a.P;
     const int CN = a.C * a.N;
     const int cn = pv ? (int)(p / a.K) : 0, k = pv ? (int)(p % a.K) : 0;
@@ -780,13 +780,21 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsPr
         buf_store_cf(Xb, voff, xw * pixbytes, v[n1]);
     }
     double acc[1] = {(double)s_l1};
-    const int64_t tile = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const int64_t tile = (int64_t)h * tiles_x + bx;
     block_sum_store<1>(acc, scratch, a.partials + tile);
     if (!a.t_out) return;
     reg_fence<N1>(v, 0, token);
 
     spatial_to_spectral<NW>(v, a.twA, a.t_out, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
                             token);
+}
+
+template <int NW, bool GENERAL>
+__global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsProxArgs<float> a_in) {
+    const int tiles_x = (int)((a_in.P + 127) / 128);
+    rows_tile_loop(a_in, tiles_x, a_in.H, [tiles_x](auto a, int bx, int h) {
+        rows_inv_prox_fwd_tile<NW, GENERAL>(a, bx, h, tiles_x);
+    });
 }
 
 template <int NW, typename K>
@@ -1111,15 +1119,22 @@ static void launch_prox_nw(hipStream_t st, const RowsProxArgs<float> &a_in, dim3
 template <> int64_t launch_rows_inv_prox_fwd<float>(hipStream_t st, const RowsProxArgs<float> &a) {
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
-    const dim3 grid((unsigned)ceil_div(a.P, 128), (unsigned)a.H);
+    // (the forward half of this kernel is the emitting epilogue's, which gained 8 % from a
+    // persistent launch; this one does not -- config 4 244.7-245.8 it/s persistent against
+    // 240.7-246.2 per tile, profiles/r03g_config4_prox_persist.jsonl -- so SPORCO_AMD_PROX_PERSIST=1
+    // stays a measurement switch)
+    RowsProxArgs<float> ap = a;
+    const int64_t tx = ceil_div(a.P, 128);
+    static const int want = std::getenv("SPORCO_AMD_PROX_PERSIST") ? std::atoi(std::getenv("SPORCO_AMD_PROX_PERSIST")) : 0;
+    const dim3 grid = rows_grid(ap, a.W / kN1, tx, a.H, (a.t_out != nullptr && want) ? 1 : 0);
     if (a.W == 128)
-        launch_prox_nw<4>(st, a, grid);
+        launch_prox_nw<4>(st, ap, grid);
     else if (a.W == 256)
-        launch_prox_nw<8>(st, a, grid);
+        launch_prox_nw<8>(st, ap, grid);
     else
-        launch_prox_nw<16>(st, a, grid);
+        launch_prox_nw<16>(st, ap, grid);
     SA_HIP(hipGetLastError());
-    return (int64_t)grid.x * grid.y;
+    return tx * a.H;
 }
 template <> int64_t launch_rows_inv_prox_fwd<double>(hipStream_t, const RowsProxArgs<double> &) {
     throw Error(-1, "the fused row kernels are float32 only");

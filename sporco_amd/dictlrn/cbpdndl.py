@@ -170,6 +170,9 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             # device that X / Xf of the inner iterations are never read.  (With ReturnX the
             # D-step is fed xstep.getcoef() = X, as in the reference, dictlrn.py:379-382.)
             xstep._no_x = True
+            # ... and between its one-iteration solves nothing but setcoef(Y) looks at the iterate:
+            # it stays in the single-array form of the fused iteration (csc_rows.h)
+            xstep._dev.set_hint(_lib.HINT_KEEP_VFORM, 1)
         xdev = xstep._dev if xmethod == 'admm' else xstep.dev
         xdev = getattr(xdev, '_raw', xdev)     # (the D-step's own sums are reduced explicitly)
         dstep = ConvCnstrMOD(None, S, dsz, opt['CCMOD'], method=dmethod, dimK=dimK, dimN=dimN,
