@@ -21,6 +21,32 @@
  *   - `dtype` is SPORCO_AMD_F32 (float / complex64) or SPORCO_AMD_F64;
  *   - a handle owns one HIP stream (or borrows the one passed at creation);
  *     calls on one handle must not be issued concurrently from two threads.
+ *
+ * Environment switches.  None is needed for normal use: they select kernel variants for A/B
+ * measurements and for the tests that pin one path against another, and are read when a
+ * handle is created or a launch is made (bench.py and the tests set them around single calls).
+ *   SPORCO_AMD_LIBRARY=path          (Python) load this build instead of sporco_amd/libsporco_amd.so
+ *   SPORCO_AMD_SHARE_TORCH_RUNTIME=0 (Python) do not pre-load torch's HIP runtime before the library
+ *   SPORCO_AMD_UNFUSED=1        generic kernel chain (line FFTs + streaming kernels) for every shape
+ *   SPORCO_AMD_OLD_ROWS=1       generic row passes around the register-resident column kernel
+ *   SPORCO_AMD_NO_PAD=1         no zero filter appended to an odd filter count
+ *   SPORCO_AMD_NO_TAIL=1, SPORCO_AMD_NO_ROW_PAD=1   64 < K <= 72: slab kernels / unpadded rows
+ *   SPORCO_AMD_SLAB_COOP=0      K > 64 column pass as two kernels instead of cooperating workgroups
+ *   SPORCO_AMD_HOST_LOOP=1      one sporco_amd_csc_admm_iter per iteration, no sporco_amd_csc_admm_run
+ *   SPORCO_AMD_NO_VFORM=1       keep the ADMM iterate as (Y, U): no single-array state (csc_rows.h)
+ *   SPORCO_AMD_NO_SPECULATION=1 the row epilogue never emits the next iteration's row spectra
+ *   SPORCO_AMD_RUN_ALWAYS_EMIT=0|1, SPORCO_AMD_JOINT_EMIT=1, SPORCO_AMD_JOINT_SEPARATE=1
+ *                               epilogue variant overrides
+ *   SPORCO_AMD_RUN_LAG=n        (tests) admm_run pretends not to have seen its newest n records
+ *   SPORCO_AMD_COLS_PERSIST=0, SPORCO_AMD_COLS_STAGGER_GROUPS=g, SPORCO_AMD_COLS_STAGGER_SLEEPS=s
+ *                               launch form of the column kernel
+ *   SPORCO_AMD_ROWS_PERSIST=0|2, SPORCO_AMD_ROWS_STAGGER_GROUPS, SPORCO_AMD_ROWS_STAGGER_SLEEPS,
+ *   SPORCO_AMD_PROX_PERSIST=1   launch form of the row kernels
+ *   SPORCO_AMD_PGM_PERSIST=mask (bit 0: FISTA gradient kernel, bit 1: momentum kernel),
+ *   SPORCO_AMD_PGM_STAGGER_GROUPS, SPORCO_AMD_PGM_STAGGER_SLEEPS
+ *   SPORCO_AMD_CG_HOST=1, SPORCO_AMD_CG_SELF=0   CG dictionary update: scalars on the host / as launches
+ *   SPORCO_AMD_CNS_GENERIC=1    consensus dictionary update on the generic chain
+ *   SPORCO_AMD_BENCH_BACKEND=gloo   (bench.py) ranks reduce through gloo and may share a device
  */
 #ifndef SPORCO_AMD_H
 #define SPORCO_AMD_H
