@@ -478,6 +478,12 @@ def main():
                      'moved_bytes_per_launch': mb[dom],
                      'moved_GBps': mb[dom] / (dom_ms * 1e-3) / 1e9,
                      'moved_frac': mb[dom] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     'note': ('`achieved` / `frac` use the ALGORITHMIC bytes of SURVEY.md 8(d) for the '
+                              'stages this kernel performs; the single-array state (DESIGN 4.1c) performs '
+                              'them on fewer bytes, so for the `_v` kernels `frac` can exceed what the '
+                              'memory system moves -- `moved_frac` (bytes really moved, = `traffic` '
+                              'measured) is the distance to the HBM peak')
+                             if dom.endswith('_v') or '_v_' in dom else None,
                      'rocprof_avg_kernel_ms': rocprof_cal,
                      'rocprof_source': ('profiles/hbm_traffic_bytes.json "_rocprof_avg_ms" '
                                         '(rocprofv3 --kernel-trace --stats of this command)')
