@@ -802,8 +802,7 @@ class ConvBPDNMaskDcpl(ConvBPDN):
     residuals, objective and the rho schedule from the returned sums.
 
     IterationStats fields: ``Iter, ObjFun, DFid, RegL1, PrimalRsdl, DualRsdl, EpsPrimal,
-    EpsDual, Rho, XSlvRelRes, Time``.  Single-channel dictionaries; ``Y0`` / ``U0`` warm starts
-    are not offered.
+    EpsDual, Rho, XSlvRelRes, Time``.  Single-channel dictionaries.
     """
 
     _multichannel_dict_ok = False
@@ -831,10 +830,16 @@ class ConvBPDNMaskDcpl(ConvBPDN):
     def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
         if opt is None:
             opt = ConvBPDNMaskDcpl.Options()
-        if opt['Y0'] is not None or opt['U0'] is not None:
-            raise NotImplementedError("ConvBPDNMaskDcpl on the device starts from zero")
         if opt['ReturnVar'] not in ('X', 'Y0', 'Y1'):
             raise ValueError(str(opt['ReturnVar']) + ' is not a valid value for option ReturnVar')
+        # (the warm-start arrays are two-block arrays: kept away from ConvBPDN's own Y0 / U0
+        # handling -- its U0 = (lmbda / rho) sign(Y0) rule is not this class's, whose dual
+        # variable starts at zero, admm.py:286-289 -- and stored once the blocks exist)
+        warm = {'Y0': opt['Y0'], 'U0': opt['U0']}
+        if warm['Y0'] is not None or warm['U0'] is not None:
+            opt = copy.deepcopy(opt)
+            opt['Y0'] = None
+            opt['U0'] = None
         super(ConvBPDNMaskDcpl, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
         rdt = real_dtype(self.dtype).type
         # ADMM base values, not ConvBPDN's lambda-dependent ones (admm.py:245-253)
@@ -853,6 +858,12 @@ class ConvBPDNMaskDcpl(ConvBPDN):
         self.W = np.asarray(W.reshape(shp), dtype=self.dtype)
         self._upload_weights()
         self._dev.mdcpl_init(self.S)
+        # warm start (admm.py:262-272): Y0 / U0 are the concatenated [block 0; block 1] arrays
+        # of ADMMTwoBlockCnstrnt, (H, W, C, N, Cd + K) (cbpdn.py:1565-1574)
+        for name, v0, v1 in (('Y0', _lib.VAR_MY0, _lib.VAR_Y), ('U0', _lib.VAR_MU0, _lib.VAR_U)):
+            if warm[name] is not None:
+                self._set_blocks(np.asarray(warm[name]), v0, v1)
+                self.opt[name] = warm[name]
         s2 = float(np.linalg.norm(self.S)) ** 2
         if self._reducer is not None:
             s2 = self._reducer.sum([s2])[0]
@@ -864,8 +875,45 @@ class ConvBPDNMaskDcpl(ConvBPDN):
             H, Wd = self.cri.Nv
             self._dev.set_data_mask(_broadcastable(self.W, (H, Wd, self.cri.C, self.cri.K, 1)))
 
+    def _set_blocks(self, A, var0, var1):
+        """Store a concatenated two-block array: block 0 (the first Cd slices of the last axis,
+        signal sized) and block 1 (coefficient sized)."""
+        A = np.asarray(A, dtype=self.dtype)
+        nb0 = self.cri.Cd
+        shp = self.cri.shpX[:-1] + (nb0 + self.cri.M,)
+        if A.size != int(np.prod(shp)):
+            raise ValueError("array of shape %s is not a [block 0; block 1] array of shape %s"
+                             % (A.shape, shp))
+        A = A.reshape(shp)
+        self._dev.upload(var0, np.ascontiguousarray(A[..., :nb0]))
+        self._dev.upload(var1, np.ascontiguousarray(A[..., nb0:]))
+        self._touch(var0, var1)
+
     def __getstate__(self):
-        raise NotImplementedError("ConvBPDNMaskDcpl objects are not picklable in this backend")
+        state = self.__dict__.copy()
+        for key in ('_dev', '_cache'):
+            state.pop(key, None)
+        state['_S_host'] = self.S
+        state['_S_dev'] = None
+        state['_stream'] = None
+        # raw device contents of both blocks (U without the pending scale, kept in _u_scale)
+        state['_saved_arrays'] = {v: self._dev.download(v)
+                                  for v in (_lib.VAR_Y, _lib.VAR_U, _lib.VAR_X, _lib.VAR_MY0,
+                                            _lib.VAR_MU0)}
+        return state
+
+    def __setstate__(self, state):
+        saved = state.pop('_saved_arrays')
+        u_scale = state.get('_u_scale', 1.0)
+        self.__dict__.update(state)
+        self._new_handle()
+        self._dev.set_signal(self.S)
+        self.setdict()
+        self._upload_weights()
+        self._dev.mdcpl_init(self.S)
+        for v, a in saved.items():
+            self._dev.upload(v, a)
+        self._u_scale = u_scale
 
     # -- the two blocks -----------------------------------------------------------------------
     def var_y0(self):
