@@ -70,8 +70,8 @@ def test_surface(backend):
     assert b0.solve().shape == b0.cri.shpS
     with pytest.raises(ValueError):
         cls(g['D'], g['S'], 0.1, None, cls.Options({'ReturnVar': 'Z'}))
-    with pytest.raises(NotImplementedError):
-        cls(g['D'], g['S'], 0.1, None, cls.Options({'Y0': np.zeros((16, 16, 1, 2, 5))}))
+    with pytest.raises(ValueError):           # a warm start must be a [block 0; block 1] array
+        cls(g['D'], g['S'], 0.1, None, cls.Options({'Y0': np.zeros((16, 16, 1, 2, 2))}))
     with pytest.raises(NotImplementedError):      # multi-channel dictionary
         cls(np.zeros((5, 5, 3, 4)), np.zeros((16, 16, 3, 2)), 0.1)
 
