@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(kThreads) vform_split_joint_kernel(const T *v,
             sq[c] = sv[c] * sv[c];
         }
         const T q = (sq[0] + sq[1]) + (sq[2] + sq[3]);
-        T fac = T(1) - thr21 * (T)sa_rsq((float)q);
+        T fac = (T)sa_fma(-(float)thr21, sa_rsq((float)q), 1.f);
         fac = fac > T(0) ? fac : T(0);
         for (int c = 0; c < C; ++c) {
             T yy = fac * sv[c];

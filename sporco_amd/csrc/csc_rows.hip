@@ -396,8 +396,8 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                 }
                 float y0 = soft1(vv.re, t0), y1 = soft1(vv.im, t1);
                 if constexpr (JOINT) {      // the l2 shrinkage over the channels, as the epilogue
-                    float f0 = 1.f - thr21_p * sa_rsq(sum_over_rows(y0 * y0));
-                    float f1 = 1.f - thr21_p * sa_rsq(sum_over_rows(y1 * y1));
+                    float f0 = sa_fma(-thr21_p, sa_rsq(sum_over_rows(y0 * y0)), 1.f);
+                    float f1 = sa_fma(-thr21_p, sa_rsq(sum_over_rows(y1 * y1)), 1.f);
                     f0 = f0 > 0.f ? f0 : 0.f;
                     f1 = f1 > 0.f ? f1 : 0.f;
                     y0 = f0 * y0;
@@ -419,7 +419,7 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
 #pragma unroll
         for (int i = 0; i < N1 / 2; ++i) {
 #pragma clang fp contract(off)
-            v[half * (N1 / 2) + i] = mk<float>(yv[i].re - s2 * uv[i].re, yv[i].im - s2 * uv[i].im);
+            v[half * (N1 / 2) + i] = mk<float>(sa_fma(-s2, uv[i].re, yv[i].re), sa_fma(-s2, uv[i].im, yv[i].im));
         }
         reg_fence<N1 / 2>(v, half * (N1 / 2), token);
     }
@@ -598,7 +598,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                     const float vp = yo[e];
                     float yp = soft1(vp, thr_p * wte[e]);
                     if constexpr (JOINT) {
-                        float fp = 1.f - thr21_p * sa_rsq(sum_over_rows(yp * yp));
+                        float fp = sa_fma(-thr21_p, sa_rsq(sum_over_rows(yp * yp)), 1.f);
                         fp = fp > 0.f ? fp : 0.f;
                         yp = fp * yp;
                     }
@@ -611,7 +611,6 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 uraw[0] = ub[b & 1][i].re;
                 uraw[1] = ub[b & 1][i].im;
             }
-            const float uo[2] = {usc * uraw[0], usc * uraw[1]};
             float yn[2], un[2], vn[2] = {0.f, 0.f};
             if constexpr (JOINT) {
                 // prox_sl1l2 over the channel axis (cbpdn.py:785-794): soft threshold, then the
@@ -620,11 +619,11 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 // The channels sit 16 lanes apart (idle lanes hold zeros).
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const float ax = al * xs[e] + oma * yo[e];
-                    const float vv = ax + uo[e];
+                    const float ax = sa_fma(al, xs[e], oma * yo[e]);
+                    const float vv = sa_fma(usc, uraw[e], ax);
                     const float sv = soft1(vv, thr);
                     const float q = sum_over_rows(sv * sv);
-                    float fac = 1.f - thr21 * sa_rsq(q);      // (q = 0: -inf, or NaN when thr21 = 0)
+                    float fac = sa_fma(-thr21, sa_rsq(q), 1.f);   // (q = 0: -inf, or NaN when thr21 = 0)
                     fac = fac > 0.f ? fac : 0.f;
                     float y1 = fac * sv;
                     if (nonneg && y1 < 0.f) y1 = 0.f;
@@ -633,27 +632,27 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                     un[e] = u1;
                     vn[e] = vv;
                     const float dr = xs[e] - y1, ds = y1 - yo[e];
-                    s_r2 += dr * dr;
-                    s_s2 += ds * ds;
-                    s_x2 += xs[e] * xs[e];
-                    s_y2 += y1 * y1;
-                    s_u2 += u1 * u1;
+                    s_r2 = sa_fma(dr, dr, s_r2);
+                    s_s2 = sa_fma(ds, ds, s_s2);
+                    s_x2 = sa_fma(xs[e], xs[e], s_x2);
+                    s_y2 = sa_fma(y1, y1, s_y2);
+                    s_u2 = sa_fma(u1, u1, s_u2);
                     // (always formed: a branch on F_OBJ here would split the unrolled epilogue
                     // into blocks and spill the tile, see the NoBndryCross note above)
                     const float gvar = gy ? y1 : xs[e];
                     s_l1 += fabsf(gvar);
                     const float g2 = sum_over_rows(gvar * gvar);
-                    s_l21 += l21w * sa_sqrt(g2);
+                    s_l21 = sa_fma(l21w, sa_sqrt(g2), s_l21);
                 }
             } else {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const float ax = al * xs[e] + oma * yo[e];
+                const float ax = sa_fma(al, xs[e], oma * yo[e]);
                 const bool am = GENERAL && am_e[e];
                 const float wt = wte[e];
                 // V' = AX + U: the new iterate is a function of it alone (Y' = prox(V'),
                 // U' = V' - Y'), which is what the V form stores
-                const float vv = ax + uo[e];
+                const float vv = sa_fma(usc, uraw[e], ax);
                 float y1 = soft1(vv, thr * wt);
                 if (nonneg && !am && y1 < 0.f) y1 = 0.f;
                 if (GENERAL) y1 *= am ? mkeep : keep;
@@ -662,11 +661,11 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 un[e] = u1;
                 vn[e] = vv;
                 const float dr = xs[e] - y1, ds = y1 - yo[e];
-                s_r2 += dr * dr;
-                s_s2 += ds * ds;
-                s_x2 += xs[e] * xs[e];
-                s_y2 += y1 * y1;
-                s_u2 += u1 * u1;
+                s_r2 = sa_fma(dr, dr, s_r2);
+                s_s2 = sa_fma(ds, ds, s_s2);
+                s_x2 = sa_fma(xs[e], xs[e], s_x2);
+                s_y2 = sa_fma(y1, y1, s_y2);
+                s_u2 = sa_fma(u1, u1, s_u2);
                 s_l1 += fabsf(wt * (gy ? y1 : xs[e]));
             }
             }

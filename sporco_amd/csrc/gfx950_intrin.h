@@ -30,6 +30,12 @@ template <typename T> __device__ __forceinline__ void sa_wave_allreduce2(T &a, T
 __device__ __forceinline__ float sa_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sa_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
+// a * b + c with one rounding, as one instruction (v_fma_f32).  The row kernels spell their
+// fused multiply-adds out (and forbid the compiler's own contraction there): the two state
+// forms of an ADMM iteration (csc_rows.h) must round alike, and which product of a sum the
+// compiler fuses depends on the code around it.
+__device__ __forceinline__ float sa_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // 1 / x to 1 ulp (v_rcp_f32)
 __device__ __forceinline__ float sa_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -128,6 +128,7 @@ inline void sa_load_agent2(const float *p, float &a, float &b) {
 }
 inline void sa_wait_stores() {}
 inline void sa_spin_pause() { hostsim::spin_pause(); }
+inline float sa_fma(float a, float b, float c) { return std::fma(a, b, c); }
 inline float sa_rsq(float x) { return 1.0f / std::sqrt(x); }
 inline float sa_sqrt(float x) { return std::sqrt(x); }
 inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }
