@@ -698,6 +698,25 @@ def gen_maskdcpl():
     wl1 = 0.5 + np.random.rand(1, 1, 1, 1, 4)
     Sc = np.random.randn(16, 16, 3, 2)
     Wc = (np.random.rand(16, 16, 3, 2) > 0.3).astype(np.float64)
+    # multi-channel dictionaries (Cd > 1: X-step by solvemdbi_ism with rho = 1, block 0 swapped
+    # onto the filter axis; the cases of the reference's tests/admm/test_cbpdn.py:487-518)
+    Dm = np.random.randn(5, 5, 3, 4)
+    S1 = np.random.randn(16, 16, 3)
+    W1 = (np.random.rand(16, 16, 3) > 0.3).astype(np.float64)
+    for name, DD, SS, WW, optd in (
+            ('maskdcpl_mcdict_f64', Dm, Sc, Wc, {'MaxMainIter': 20}),
+            ('maskdcpl_mcdict_one_image_opts_f64', Dm, S1, W1,
+             {'MaxMainIter': 20, 'rho': 1.5, 'RelaxParam': 1.6, 'NonNegCoef': True,
+              'AuxVarObj': True, 'LinSolveCheck': True,
+              'AutoRho': {'Enabled': True, 'Period': 2, 'Scaling': 2.0, 'RsdlRatio': 1.2,
+                          'AutoScaling': True, 'RsdlTarget': 1.0}}),
+            ('maskdcpl_mcdict_f32', Dm, Sc, Wc, {'MaxMainIter': 20, 'DataType': np.float32})):
+        opt = ref_cbpdn.ConvBPDNMaskDcpl.Options(optd)
+        b = ref_cbpdn.ConvBPDNMaskDcpl(DD, SS, 0.1, WW, opt)
+        Y1 = b.solve()
+        save(name, D=DD, S=SS, W=WW, lmbda=np.float64(0.1), Y1=Y1, X=b.X, Y=b.Y, U=b.U,
+             Y0=b.var_y0(), recon=b.reconstruct(), rho_final=np.float64(b.rho),
+             k_final=np.int64(b.k), **itstat_dict(b))
     for name, SS, WW, optd in (
             ('maskdcpl_f64', S, W, {'MaxMainIter': 30}),
             ('maskdcpl_f32', S, W, {'MaxMainIter': 30, 'DataType': np.float32}),

@@ -802,10 +802,11 @@ class ConvBPDNMaskDcpl(ConvBPDN):
     residuals, objective and the rho schedule from the returned sums.
 
     IterationStats fields: ``Iter, ObjFun, DFid, RegL1, PrimalRsdl, DualRsdl, EpsPrimal,
-    EpsDual, Rho, XSlvRelRes, Time``.  Single-channel dictionaries.
+    EpsDual, Rho, XSlvRelRes, Time``.  Multi-channel dictionaries (``Cd > 1``): block 0 keeps the
+    signal's channels and is swapped onto the filter axis for ``Y`` / ``U`` (cbpdn.py:1688-1722).
     """
 
-    _multichannel_dict_ok = False
+    _multichannel_dict_ok = True    # (X-step by linalg.solvemdbi_ism with rho = 1, cbpdn.py:1621-1626)
     _fused_base = None
 
     class Options(admm.ADMMEqual.Options):
@@ -875,6 +876,12 @@ class ConvBPDNMaskDcpl(ConvBPDN):
             H, Wd = self.cri.Nv
             self._dev.set_data_mask(_broadcastable(self.W, (H, Wd, self.cri.C, self.cri.K, 1)))
 
+    @property
+    def _y0swap(self):
+        # block 0 has the shape of S, (.., C, K, 1); with a multi-channel dictionary its channel
+        # axis is swapped onto the filter axis so that it concatenates with block 1 (.., 1, K, M)
+        return self.cri.C > 1 and self.cri.Cd > 1
+
     def _set_blocks(self, A, var0, var1):
         """Store a concatenated two-block array: block 0 (the first Cd slices of the last axis,
         signal sized) and block 1 (coefficient sized)."""
@@ -885,7 +892,10 @@ class ConvBPDNMaskDcpl(ConvBPDN):
             raise ValueError("array of shape %s is not a [block 0; block 1] array of shape %s"
                              % (A.shape, shp))
         A = A.reshape(shp)
-        self._dev.upload(var0, np.ascontiguousarray(A[..., :nb0]))
+        A0 = A[..., :nb0]
+        if self._y0swap:
+            A0 = np.swapaxes(A0, self.cri.axisC, self.cri.axisM)
+        self._dev.upload(var0, np.ascontiguousarray(A0))
         self._dev.upload(var1, np.ascontiguousarray(A[..., nb0:]))
         self._touch(var0, var1)
 
@@ -923,12 +933,15 @@ class ConvBPDNMaskDcpl(ConvBPDN):
         return self._fetch(_lib.VAR_Y)
 
     def block_sep0(self, Y):
-        return Y[..., :self.cri.Cd]
+        Y0 = Y[..., :self.cri.Cd]
+        return np.swapaxes(Y0, self.cri.axisC, self.cri.axisM) if self._y0swap else Y0
 
     def block_sep1(self, Y):
         return Y[..., self.cri.Cd:]
 
     def block_cat(self, Y0, Y1):
+        if self._y0swap:
+            Y0 = np.swapaxes(Y0, self.cri.axisC, self.cri.axisM)
         return np.concatenate((Y0, Y1), axis=self.cri.axisM)
 
     @property

@@ -903,7 +903,9 @@ template <typename T> struct Csc : CscBase {
         }
         dst = Weight<T>();
         if (!w) return;
-        const int64_t full[5] = {H, W, C, N, Ku};
+        // (the data-fidelity mask lives on the signal, which keeps its channels under a
+        // multi-channel dictionary)
+        const int64_t full[5] = {H, W, which == 3 ? Cs : C, N, Ku};
         int64_t n = 1;
         for (int i = 0; i < 5; ++i) {
             SA_REQUIRE(shape[i] == 1 || shape[i] == full[i],
@@ -2924,9 +2926,8 @@ template <typename T> struct Csc : CscBase {
 
     // ---- ADMM with mask decoupling (ConvBPDNMaskDcpl) ---------------------------------------
     void mdcpl_init(const void *S) override {
-        require_single_channel_dict();
         SA_REQUIRE(S != nullptr, "S is null");
-        const size_t nb = sizeof(T) * (int64_t)H * W * CN;
+        const size_t nb = sizeof(T) * (int64_t)H * W * CNs;
         if (!md_s) SA_HIP(hipMalloc((void **)&md_s, nb));
         SA_HIP(hipMemcpyAsync(md_s, S, nb, hipMemcpyHostToDevice, st));
         before_state_change();
@@ -2938,7 +2939,6 @@ template <typename T> struct Csc : CscBase {
     }
 
     void mdcpl_iter(const sporco_amd_admm_params &p, double *out_dev) override {
-        require_single_channel_dict();
         require_ready();
         SA_REQUIRE(md_s != nullptr, "mdcpl_init must be called first");
         SA_REQUIRE(p.rho > 0.0, "rho must be positive");
@@ -2947,7 +2947,10 @@ template <typename T> struct Csc : CscBase {
         before_state_change();
         x_written();
         xf_tiled = false;
-        const int64_t ns = (int64_t)H * W * CN;
+        // (a multi-channel dictionary, Cd > 1: block 0 keeps the signal's Cd channels, block 1 and
+        // the coefficient maps have one -- cbpdn.py:1565-1574; the X-step is the iterated
+        // Sherman-Morrison solve with rho = 1, :1621-1626)
+        const int64_t ns = (int64_t)H * W * CNs;
         const T us = (T)p.u_scale;
         T *Y1 = rv(SPORCO_AMD_VAR_Y), *U1 = rv(SPORCO_AMD_VAR_U), *X = rv(SPORCO_AMD_VAR_X);
         T *Y0 = rv(SPORCO_AMD_VAR_MY0), *U0 = rv(SPORCO_AMD_VAR_MU0);
@@ -2958,11 +2961,25 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             launch_md_pre<T>(st, Y0, U0, md_s, sreal, us, ns);
         }
-        fwd2(sreal, nullptr, T(0), innerb, CN);
+        fwd2(sreal, nullptr, T(0), innerb, CNs);
         fwd2(Y1, U1, us, Vf, P);
         const bool xr = p.flags & F_XRRS;
         int nb;
-        {
+        if (Cd > 1) {
+            if (!ism_gam) {
+                SA_HIP(hipMalloc((void **)&ism_gam, sizeof(cx<T>) * npix * Cd * K));
+                SA_HIP(hipMalloc((void **)&ism_del, sizeof(cx<T>) * npix * Cd));
+                SA_HIP(hipMalloc((void **)&ism_mm, sizeof(cx<T>) * npix * Cd * Cd));
+            }
+            ProfScope ps(prof, PS_SM_SOLVE);
+            if (!ism_valid || ism_rho != 1.0) {
+                launch_ism_setup<T>(st, Df, ism_gam, ism_del, ism_mm, npix, Cd, K, T(1));
+                ism_valid = true;
+                ism_rho = 1.0;
+            }
+            nb = launch_ism_solve<T>(st, Vf, Xf, Df, innerb, ism_gam, ism_del, ism_mm, T(1), npix, Cd,
+                                     N, K, W, false, xr, part_a);
+        } else {
             ProfScope ps(prof, PS_SM_SOLVE);
             nb = launch_sm_solve<T>(st, Vf, Xf, Df, innerb, gram, T(1), npix, CN, K, W, false, xr,
                                     part_a);
@@ -2977,9 +2994,9 @@ template <typename T> struct Csc : CscBase {
         // block 0: AXnr = D x, relax, y0, u0
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_inner<T>(st, Df, Xf, innerb, npix, CN, K);
+            inner_df(Xf);
         }
-        inv2(innerb, innerb, sreal, CN);
+        inv2(innerb, innerb, sreal, CNs);
         // block 1: relax, y1 = prox_l1 (+ NonNegCoef / NoBndryCross), u1 and the sums
         PostParams<T> pp;
         pp.x = X;
@@ -3018,7 +3035,7 @@ template <typename T> struct Csc : CscBase {
         ya.geval_y = (p.flags & F_GEVAL_Y) ? 1 : 0;
         ya.H = H;
         ya.W = W;
-        ya.C = C;
+        ya.C = Cs;
         ya.N = N;
         {
             ProfScope ps(prof, PS_OTHER);
@@ -3033,11 +3050,12 @@ template <typename T> struct Csc : CscBase {
         if (p.flags & F_RESID) {
             // dual residual (cbpdn.py:1814-1818): A^T u = irfftn(conj(Df) rfftn(u0)) + u1, its
             // norm through the half-spectrum Parseval sum
-            fwd2(U0, nullptr, T(0), innerb, CN);
+            fwd2(U0, nullptr, T(0), innerb, CNs);
             fwd2(U1, nullptr, T(0), Vf, P);
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_conj_outer<T>(st, Df, innerb, Gf, npix, CN, K);
+                if (Cd > 1) launch_mc_conj_outer<T>(st, Df, innerb, Gf, npix, Cd, N, K, false);
+                else launch_conj_outer<T>(st, Df, innerb, Gf, npix, CN, K);
                 launch_lincomb<T>(st, Gf, T(1), Gf, T(1), Vf, T(0), nullptr, EF);
                 nb = launch_pair_stats<T>(st, Gf, nullptr, nullptr, npix, P, W, part_b);
             }

@@ -261,6 +261,10 @@ int launch_mc_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx
 template <typename T>
 void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
                      int Cd, int N, int K);
+// gf[pix, n, k] (+)= sum_c conj(df[pix, c, k]) r[pix, c, n] (adjoint of launch_mc_inner)
+template <typename T>
+void launch_mc_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *gf, int64_t npix,
+                          int Cd, int N, int K, bool add);
 // max |conj(df[pix, c, k]) sf[pix, c, n]|^2; partial[block] = block max
 template <typename T>
 int launch_mc_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64_t npix, int Cd,

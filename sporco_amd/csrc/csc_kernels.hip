@@ -1974,6 +1974,34 @@ void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out
     SA_HIP(hipGetLastError());
 }
 
+// gf[pix, n, k] (+)= sum_c conj(df[pix, c, k]) r[pix, c, n]: the adjoint of mc_inner (A_0^T of the
+// mask-decoupling constraint with a multi-channel dictionary, cbpdn.py:1762-1770; `add`: onto gf)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) mc_conj_outer_kernel(const cx<T> *__restrict__ df,
+                                                                 const cx<T> *__restrict__ r,
+                                                                 cx<T> *gf, int64_t npix, int Cd,
+                                                                 int N, int K, int add) {
+    const int64_t total = npix * N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int n = (int)((i / K) % N);
+        const int64_t pix = i / ((int64_t)N * K);
+        cx<T> g = add ? gf[i] : mk<T>(T(0), T(0));
+        for (int c = 0; c < Cd; ++c)
+            g = g + cmulc(df[(pix * Cd + c) * K + k], r[(pix * Cd + c) * N + n]);
+        gf[i] = g;
+    }
+}
+
+template <typename T>
+void launch_mc_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *gf, int64_t npix,
+                          int Cd, int N, int K, bool add) {
+    hipLaunchKernelGGL((mc_conj_outer_kernel<T>), dim3(grid_for(npix * N * K)), dim3(kThreads), 0, st,
+                       df, r, gf, npix, Cd, N, K, add ? 1 : 0);
+    SA_HIP(hipGetLastError());
+}
+
 // max |conj(df[pix, c, k]) sf[pix, c, n]| (cbpdn.py:573-578 without the channel sum)
 template <typename T>
 __global__ void __launch_bounds__(kThreads) mc_dhs_absmax_kernel(const cx<T> *__restrict__ df,
@@ -2913,6 +2941,8 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
                                        cx<T> *, int64_t, int, int, int, int, double *);            \
     template void launch_mc_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,  \
                                      int, int, int);                                               \
+    template void launch_mc_conj_outer<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,      \
+                                          int64_t, int, int, int, bool);                          \
     template int launch_mc_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,  \
                                          int, int, double *);
 SA_INST(float)

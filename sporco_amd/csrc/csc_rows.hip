@@ -550,7 +550,10 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     // pixels per batch (Y, U of the next batch are in flight); the emitting variants keep the
     // tile for the forward transform and have fewer registers to spare
     // (V form reads one array instead of two: twice the pixels per batch for the same registers)
-    constexpr int B = EMIT_T ? (JOINT ? (VIN ? 2 : 1) : (VIN ? 4 : 2)) : 4;
+#ifndef SA_POST_B_VIN
+#define SA_POST_B_VIN 8
+#endif
+    constexpr int B = EMIT_T ? (JOINT ? (VIN ? 2 : 1) : (VIN ? 4 : 2)) : ((VIN && !JOINT) ? SA_POST_B_VIN : 4);
     cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll

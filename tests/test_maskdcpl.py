@@ -17,6 +17,13 @@ CASES = {
                                   'NonNegCoef': True, 'NoBndryCross': True, 'AuxVarObj': True,
                                   'LinSolveCheck': True, 'AutoRho': AUTORHO},
     'maskdcpl_multichan_f64': {'MaxMainIter': 20},
+    # multi-channel dictionaries (Cd = 3): the reference's own tests/admm/test_cbpdn.py:487-518
+    'maskdcpl_mcdict_f64': {'MaxMainIter': 20},
+    'maskdcpl_mcdict_f32': {'MaxMainIter': 20, 'DataType': np.float32},
+    'maskdcpl_mcdict_one_image_opts_f64': {'MaxMainIter': 20, 'rho': 1.5, 'RelaxParam': 1.6,
+                                           'NonNegCoef': True, 'AuxVarObj': True,
+                                           'LinSolveCheck': True,
+                                           'AutoRho': dict(AUTORHO, Period=2)},
 }
 
 
@@ -37,7 +44,10 @@ def test_golden_traces(backend, name):
     assert Y1.dtype == (np.float32 if f32 else np.float64)
     assert rel_l2(b.X, g['X']) < tol
     assert b.Y.shape == g['Y'].shape and rel_l2(b.Y, g['Y']) < tol
-    assert rel_l2(b.var_y0(), g['Y'][..., :1]) < tol
+    if 'Y0' in g:       # (multi-channel dictionary: block 0 in the signal's own layout)
+        assert b.var_y0().shape == g['Y0'].shape and rel_l2(b.var_y0(), g['Y0']) < tol
+    else:
+        assert rel_l2(b.var_y0(), g['Y'][..., :1]) < tol
     assert b.U.shape == g['U'].shape and rel_l2(b.U, g['U']) < tol
     assert rel_l2(b.reconstruct().squeeze(), g['recon'].squeeze()) < tol
     assert rel_l2(float(b.rho), float(g['rho_final'])) < tol
@@ -72,8 +82,6 @@ def test_surface(backend):
         cls(g['D'], g['S'], 0.1, None, cls.Options({'ReturnVar': 'Z'}))
     with pytest.raises(ValueError):           # a warm start must be a [block 0; block 1] array
         cls(g['D'], g['S'], 0.1, None, cls.Options({'Y0': np.zeros((16, 16, 1, 2, 2))}))
-    with pytest.raises(NotImplementedError):      # multi-channel dictionary
-        cls(np.zeros((5, 5, 3, 4)), np.zeros((16, 16, 3, 2)), 0.1)
 
 
 
