@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
     // the Df slice in that XCD's L2 as before.  With 8 waves (H = 256) two workgroups share a
     // CU and overlap each other; the tile loop would cost them the registers for that, so
     // there it runs once.
-    constexpr bool PERSIST = NW == 16 && KC == 64;   // (run-time K: scalar registers are short)
+    constexpr bool PERSIST = (NW == 16 || N1 == 64) && KC == 64;   // (run-time K: scalar registers are short)
     const int xcd = blockIdx.x & 7;
     f2 *LA = dyn_lds<f2>();
     f2 *LB = LA;
@@ -983,6 +983,11 @@ static FusedSplit fused_split(int H, int K) {
     (void)K;
     if (H == 128) return {32, 4, 4};
     if (H == 256) return {32, 8, 2};
+#ifdef SA_COLS_MEASUREMENT_BUILD
+    // (measurement builds: H = 512 as 64 points per thread x 8 waves -- twice the registers per
+    // wave, half the waves; ADMM ConvBPDN at K = 64 only)
+    if (std::getenv("SPORCO_AMD_COLS_SPLIT64")) return {64, 8, std::atoi(std::getenv("SPORCO_AMD_COLS_SPLIT64"))};
+#endif
     return {32, 16, 1};
 }
 
@@ -1045,7 +1050,7 @@ static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
     const int64_t all = wf_groups * 8 * a.CN;
     hipLaunchKernelGGL((fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE, DBG>),
-                       dim3((unsigned)std::min<int64_t>(all, persistent_grid(KC == 64 ? NW : 0))),
+                       dim3((unsigned)std::min<int64_t>(all, persistent_grid(KC == 64 ? (N1 == 64 ? 16 : NW) : 0))),
                        dim3(NW * 64),
                        fused_lds_bytes(NW, LP), st, a);
 }
@@ -1090,6 +1095,15 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     // measured 1.13 -> 1.06 ms at 512 x 512, K = 64, N = 32 (profiles/r02_fused_cols_notes.md)
     a.stagger_groups = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? (sg > 0 ? sg : 1) : 4;
     a.stagger_sleeps = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? ss : 2;
+#ifdef SA_COLS_MEASUREMENT_BUILD
+    if (sp.N1 == 64) {
+        SA_REQUIRE(a.K == 64 && !a.g1t && !a.per_tile && !a.Kv, "64 x 8 split: plain K = 64 only");
+        if (sp.LP == 4) launch_fused_inst<64, 8, 4, 64, false>(st, a, ntiles);
+        else launch_fused_inst<64, 8, 2, 64, false>(st, a, ntiles);
+        SA_HIP(hipGetLastError());
+        return ntiles;
+    }
+#endif
     if (sp.NW == 4)
         launch_fused_k<32, 4, 4>(st, a, ntiles);
     else if (sp.NW == 8)
