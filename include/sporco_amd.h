@@ -35,7 +35,7 @@
  *   SPORCO_AMD_HOST_LOOP=1      one sporco_amd_csc_admm_iter per iteration, no sporco_amd_csc_admm_run
  *   SPORCO_AMD_NO_VFORM=1       keep the ADMM iterate as (Y, U): no single-array state (csc_rows.h)
  *   SPORCO_AMD_NO_SPECULATION=1 the row epilogue never emits the next iteration's row spectra
- *   SPORCO_AMD_RUN_ALWAYS_EMIT=0|1, SPORCO_AMD_JOINT_EMIT=1, SPORCO_AMD_JOINT_SEPARATE=1
+ *   SPORCO_AMD_RUN_ALWAYS_EMIT=0|1, SPORCO_AMD_JOINT_EMIT=0, SPORCO_AMD_JOINT_SEPARATE=1
  *                               epilogue variant overrides
  *   SPORCO_AMD_RUN_LAG=n        (tests) admm_run pretends not to have seen its newest n records
  *   SPORCO_AMD_COLS_PERSIST=0, SPORCO_AMD_COLS_STAGGER_GROUPS=g, SPORCO_AMD_COLS_STAGGER_SLEEPS=s

@@ -1211,11 +1211,12 @@ template <typename T> struct Csc : CscBase {
         // while AutoRho is still moving it almost every iteration a lost bet costs one
         // extra pass, a won one saves three (rows_fwd of the next iteration).
         stable_run = p.u_scale == 1.0 ? stable_run + 1 : 0;
-        // (the joint epilogue has no registers left for the forward transform -- the emitting
-        // variant spills the tile, 22.4 ms against 13.0 + 6.6 ms for epilogue + rows_fwd at
-        // config 3, profiles/r02i_config3_*.json -- so ConvBPDNJoint does not speculate)
+        // (ConvBPDNJoint speculates too since round 3: its emitting epilogue used to spill the
+        // tile -- 22.4 ms against 13.0 + 6.6 ms for epilogue + rows_fwd at config 3,
+        // profiles/r02i_config3_*.json -- until the two elements of a pixel were serialised;
+        // SPORCO_AMD_JOINT_EMIT=0 switches it off)
         const bool emit = stable_run >= 2 && !std::getenv("SPORCO_AMD_NO_SPECULATION") &&
-                          !((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT"));
+                          !((p.flags & F_JOINT) && joint_emit_off());
         RowsPostArgs<T> pa;
         pa.twA = twRows;
         pa.t_next = emit ? Xf : nullptr;
@@ -1485,7 +1486,7 @@ template <typename T> struct Csc : CscBase {
         in.thr_prev = v_at_entry ? (float)v_entry_thr : 0.f;
         in.thr21_prev = v_at_entry ? (float)v_entry_thr21 : 0.f;
         in.no_speculation = (std::getenv("SPORCO_AMD_NO_SPECULATION") ||
-                             ((p.flags & F_JOINT) && !std::getenv("SPORCO_AMD_JOINT_EMIT")))
+                             ((p.flags & F_JOINT) && joint_emit_off()))
                                 ? 1
                                 : 0;
         // Small problems (kernels of a few microseconds): the emitting epilogue always, and its
@@ -1838,6 +1839,10 @@ template <typename T> struct Csc : CscBase {
 
     // ConvBPDNJoint inside the row epilogue (csc_rows.h): scalar weights, no NoBndryCross /
     // AddMaskSim, C <= 4 channels, K a multiple of 32, single-channel dictionary
+    static bool joint_emit_off() {
+        const char *e = std::getenv("SPORCO_AMD_JOINT_EMIT");
+        return e && e[0] == '0';
+    }
     bool joint_rows_ok(const sporco_amd_admm_params &p) const {
         return rows_ok && !fused_mc && rows_joint_supported<T>(W, C, K) && !wl1.ptr && !wl21.ptr &&
                !(p.flags & (F_NOBNDRY | F_AMS | F_KEEP_X | F_GRADREG)) &&

@@ -553,7 +553,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 #ifndef SA_POST_B_VIN
 #define SA_POST_B_VIN 8
 #endif
-    constexpr int B = EMIT_T ? (JOINT ? (VIN ? 2 : 1) : (VIN ? 4 : 2)) : ((VIN && !JOINT) ? SA_POST_B_VIN : 4);
+    constexpr int B = EMIT_T ? (JOINT ? 1 : (VIN ? 4 : 2)) : ((VIN && !JOINT) ? SA_POST_B_VIN : 4);
     cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll
@@ -646,6 +646,14 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                     s_l1 += fabsf(gvar);
                     const float g2 = sum_over_rows(gvar * gvar);
                     s_l21 = sa_fma(l21w, sa_sqrt(g2), s_l21);
+                    if constexpr (EMIT_T) {
+                        // One element at a time: the emitting variant keeps the whole tile live for
+                        // the forward transform, and with both elements of a pixel in flight the
+                        // allocator spilled it (544 bytes of scratch in round 2, which is why
+                        // ConvBPDNJoint did not speculate); serialised, it fits 128 registers.
+                        SA_VGPR_FENCE3(s_r2, s_s2, s_l21);
+                        SA_VGPR_FENCE3(s_y2, s_u2, s_l1);
+                    }
                 }
             } else {
 #pragma unroll

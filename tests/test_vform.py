@@ -128,7 +128,7 @@ def test_v_form_against_the_oracle(backend):
 
 
 @pytest.mark.parametrize('host', [False, True])
-@pytest.mark.parametrize('case', ['default', 'nonneg_period3', 'stops_early'])
+@pytest.mark.parametrize('case', ['default', 'nonneg_period3', 'stops_early', 'fixed_rho'])
 def test_joint_v_form_is_bit_identical_and_matches_the_oracle(backend, case, host):
     """ConvBPDNJoint: Y = prox_sl1l2(V) over the channels (sporco/admm/cbpdn.py:785-794,
     sporco/prox/_l21.py:51-88) re-derived from V by rows_fwd (joint tiling) and by the joint
@@ -136,10 +136,12 @@ def test_joint_v_form_is_bit_identical_and_matches_the_oracle(backend, case, hos
     from oracle import cbpdn_oracle as orc
     H = 256 if backend == 'gpu' else 128
     C, N, K = 3, (2 if backend == 'gpu' else 1), 32
-    if backend == 'hostsim' and (case == 'stops_early' or (host and case != 'default')):
+    if backend == 'hostsim' and (case == 'stops_early' or (host and case not in ('default', 'fixed_rho'))):
         pytest.skip("kept short on the CPU simulator")
     D, S = problem(H, H, K, N, seed=21, C=C)
-    optd = dict(CASES[case])
+    # ('fixed_rho': the emitting joint epilogue runs from the third iteration on)
+    optd = dict(CASES[case]) if case != 'fixed_rho' else \
+        {'MaxMainIter': 7, 'RelStopTol': 0.0, 'AutoRho': {'Enabled': False}, 'rho': 4.0}
     if backend == 'hostsim':
         optd['MaxMainIter'] = min(optd['MaxMainIter'], 6)
     b0, o0 = run(D, S, optd, vform=False, host=host, lmbda=0.1, joint_mu=0.02)
@@ -149,10 +151,11 @@ def test_joint_v_form_is_bit_identical_and_matches_the_oracle(backend, case, hos
     if o1['k'] >= 2 or not host:
         assert o1['live'] == [1]
     same(o0, o1)
-    if case == 'default' and not host:
+    if case in ('default', 'fixed_rho') and not host:
         n = optd['MaxMainIter']
+        kw = {} if case == 'default' else {'rho': 4.0, 'auto_rho': False}
         ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, H, C, N, 1), 0.1, mu=0.02,
-                             dtype=np.float64, maxiter=n, rel_tol=0.0)
+                             dtype=np.float64, maxiter=n, rel_tol=0.0, **kw)
         assert rel_l2(o1['Y'], ref['Y']) < 1e-4
         assert rel_l2(o1['U'], ref['U']) < 1e-4
         for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
