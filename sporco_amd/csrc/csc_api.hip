@@ -1313,7 +1313,8 @@ template <typename T> struct Csc : CscBase {
     bool admm_run_supported(const sporco_amd_admm_params &p) const {
         return std::is_same<T, float>::value && rows_ok && (fused || fused_slabs) && !fused_mc &&
                !tail_mode && !(p.flags & (F_XRRS | F_GRADREG | F_KEEP_X | F_FEVAL_Y)) &&
-               (!(p.flags & F_JOINT) || joint_rows_ok(p)) && !std::getenv("SPORCO_AMD_HOST_LOOP");
+               (!(p.flags & F_JOINT) || joint_rows_ok(p)) && p.lmbda >= 0.0 && p.rho > 0.0 &&
+               !std::getenv("SPORCO_AMD_HOST_LOOP");
     }
 
     // one iteration of admm_iter_fused with every iteration-dependent scalar taken from ctl_dev
@@ -1851,8 +1852,10 @@ template <typename T> struct Csc : CscBase {
 
     void admm_iter(const sporco_amd_admm_params &p, double *out_dev) override {
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
+        // (a negative lambda -- meaningless, but the reference's soft threshold is defined for it --
+        // goes to the generic chain: the row kernels clamp with a threshold known to be >= 0)
         if (rows_ok && !(p.flags & F_XRRS) && (!(p.flags & F_JOINT) || joint_rows_ok(p)) &&
-            (fused || fused_slabs || !(p.flags & F_GRADREG))) {
+            (fused || fused_slabs || !(p.flags & F_GRADREG)) && p.lmbda >= 0.0 && p.rho > 0.0) {
             admm_iter_fused(p, out_dev);
             return;
         }

@@ -78,10 +78,18 @@ __host__ __device__ constexpr int kl_of(int NW, int k1) {
 }
 
 __device__ __forceinline__ float soft1(float v, float thr) {
-    // sign(v) * max(|v| - thr, 0)            (prox/_lp.py:181)
+    // sign(v) * max(|v| - thr, 0)            (prox/_lp.py:181), for any threshold
     float m = fabsf(v) - thr;
     m = m > 0.f ? m : 0.f;
-    return v < 0.f ? -m : m;
+    return __builtin_copysignf(m, v);
+}
+// the same for a threshold known to be >= 0 (the scalar lambda / rho: the API layer sends
+// negative lambdas to the generic chain): v minus v clamped to [-thr, thr], two instructions
+__device__ __forceinline__ float soft1_pos(float v, float thr) { return v - sa_med3(v, -thr, thr); }
+// MODE 1 carries a weight array, whose entries may have either sign
+template <int MODE> __device__ __forceinline__ float soft1_m(float v, float thr) {
+    if constexpr (MODE == 1) return soft1(v, thr);
+    else return soft1_pos(v, thr);
 }
 
 // Spatial side -> spectral side: v[n1] = z(x = NW n1 + w) (destroyed) is transformed
@@ -307,6 +315,8 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
         thr21_p = a->ctl->thr21_prev_f;
     }
     const bool nonneg = VFORM && (a->flags & F_NONNEG);
+    // (NonNegCoef as max(y, 0) in one instruction: med3(y, lo, +inf) with lo = 0, or -inf when off)
+    const float nn_lo = nonneg ? 0.f : -__builtin_inff();
     int64_t p;
     bool pv;
     int cn, k;
@@ -394,7 +404,7 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                     t0 = thr_p * (am_e[0] ? 0.f : w0);
                     t1 = thr_p * (am_e[1] ? 0.f : w1);
                 }
-                float y0 = soft1(vv.re, t0), y1 = soft1(vv.im, t1);
+                float y0 = soft1_m<MODE>(vv.re, t0), y1 = soft1_m<MODE>(vv.im, t1);
                 if constexpr (JOINT) {      // the l2 shrinkage over the channels, as the epilogue
                     float f0 = sa_fma(-thr21_p, sa_rsq(sum_over_rows(y0 * y0)), 1.f);
                     float f1 = sa_fma(-thr21_p, sa_rsq(sum_over_rows(y1 * y1)), 1.f);
@@ -403,8 +413,8 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                     y0 = f0 * y0;
                     y1 = f1 * y1;
                 }
-                if (nonneg && !am_e[0] && y0 < 0.f) y0 = 0.f;
-                if (nonneg && !am_e[1] && y1 < 0.f) y1 = 0.f;
+                y0 = sa_med3(y0, am_e[0] ? -__builtin_inff() : nn_lo, __builtin_inff());
+                y1 = sa_med3(y1, am_e[1] ? -__builtin_inff() : nn_lo, __builtin_inff());
                 if constexpr (GENERAL) {
                     const int n1 = half * (N1 / 2) + i;
                     const float keep = (hkill || NW * n1 + w >= x0kill) ? 0.f : 1.f;
@@ -518,6 +528,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     const int pixbytes = (int)(a->P * (int64_t)sizeof(float));
     const float al = a->rlx, oma = 1.f - a->rlx, scale = a->scale;
     const bool nonneg = a->flags & F_NONNEG, nob = a->flags & F_NOBNDRY, gy = a->flags & F_GEVAL_Y;
+    const float nn_lo = nonneg ? 0.f : -__builtin_inff();     // (see rows_fwd_tile)
     // weight of element (h, x, c, n, k): wave-uniform row pointer + 32-bit lane offset
     int wlane = 0;
     const int ws4 = (int)a->wl1.stride[4];
@@ -599,13 +610,13 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float vp = yo[e];
-                    float yp = soft1(vp, thr_p * wte[e]);
+                    float yp = soft1_m<MODE>(vp, thr_p * wte[e]);
                     if constexpr (JOINT) {
                         float fp = sa_fma(-thr21_p, sa_rsq(sum_over_rows(yp * yp)), 1.f);
                         fp = fp > 0.f ? fp : 0.f;
                         yp = fp * yp;
                     }
-                    if (nonneg && !(GENERAL && am_e[e]) && yp < 0.f) yp = 0.f;
+                    yp = sa_med3(yp, (GENERAL && am_e[e]) ? -__builtin_inff() : nn_lo, __builtin_inff());
                     if constexpr (GENERAL) yp *= am_e[e] ? mkeep : keep;
                     yo[e] = yp;
                     uraw[e] = vp - yp;
@@ -624,12 +635,12 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 for (int e = 0; e < 2; ++e) {
                     const float ax = sa_fma(al, xs[e], oma * yo[e]);
                     const float vv = sa_fma(usc, uraw[e], ax);
-                    const float sv = soft1(vv, thr);
+                    const float sv = soft1_pos(vv, thr);
                     const float q = sum_over_rows(sv * sv);
                     float fac = sa_fma(-thr21, sa_rsq(q), 1.f);   // (q = 0: -inf, or NaN when thr21 = 0)
                     fac = fac > 0.f ? fac : 0.f;
                     float y1 = fac * sv;
-                    if (nonneg && y1 < 0.f) y1 = 0.f;
+                    y1 = sa_med3(y1, nn_lo, __builtin_inff());
                     const float u1 = vv - y1;
                     yn[e] = y1;
                     un[e] = u1;
@@ -664,8 +675,8 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 // V' = AX + U: the new iterate is a function of it alone (Y' = prox(V'),
                 // U' = V' - Y'), which is what the V form stores
                 const float vv = sa_fma(usc, uraw[e], ax);
-                float y1 = soft1(vv, thr * wt);
-                if (nonneg && !am && y1 < 0.f) y1 = 0.f;
+                float y1 = soft1_m<MODE>(vv, thr * wt);
+                y1 = sa_med3(y1, am ? -__builtin_inff() : nn_lo, __builtin_inff());
                 if (GENERAL) y1 *= am ? mkeep : keep;
                 const float u1 = vv - y1;
                 yn[e] = y1;

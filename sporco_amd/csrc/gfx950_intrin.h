@@ -36,6 +36,9 @@ __device__ __forceinline__ float sa_sqrt(float x) { return __builtin_amdgcn_sqrt
 // compiler fuses depends on the code around it.
 __device__ __forceinline__ float sa_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// median of three (v_med3_f32): med3(v, -t, t) clamps v to [-t, t] for t >= 0
+__device__ __forceinline__ float sa_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
 // 1 / x to 1 ulp (v_rcp_f32)
 __device__ __forceinline__ float sa_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

@@ -4,6 +4,7 @@
 // kernels include <gfx950_intrin.h> and this directory comes first on the
 // simulator's include path.  Never seen by the hipcc build.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <chrono>
 
@@ -129,6 +130,9 @@ inline void sa_load_agent2(const float *p, float &a, float &b) {
 inline void sa_wait_stores() {}
 inline void sa_spin_pause() { hostsim::spin_pause(); }
 inline float sa_fma(float a, float b, float c) { return std::fma(a, b, c); }
+inline float sa_med3(float a, float b, float c) {
+    return std::max(std::min(a, b), std::min(std::max(a, b), c));
+}
 inline float sa_rsq(float x) { return 1.0f / std::sqrt(x); }
 inline float sa_sqrt(float x) { return std::sqrt(x); }
 inline float sa_lane_xor1(float v) { return hostsim_gather(v, ((int)threadIdx.x & 63) ^ 1); }
