@@ -777,6 +777,7 @@ __device__ __forceinline__ void rows_inv_prox_fwd_tile(AP ap, int bx, int h, int
     }
     const bool hkill = GENERAL && nob && h >= ((a.dH > 1) ? a.H - (a.dH - 1) : 0);
     const int x0kill = (a.dW > 1) ? W - (a.dW - 1) : 0;
+    const float nn_lo = nonneg ? 0.f : -__builtin_inff();     // (see rows_fwd_tile)
     float s_l1 = 0.f;
 #pragma unroll
     for (int n1 = 0; n1 < N1; ++n1) {
@@ -791,8 +792,9 @@ __device__ __forceinline__ void rows_inv_prox_fwd_tile(AP ap, int bx, int h, int
                                     (int64_t)xw * a.wl1.stride[1];
                 wt = wrow[wlane + e * ws4];
             }
-            float y1 = soft1(y[e], a.thr * wt);
-            if (nonneg && y1 < 0.f) y1 = 0.f;
+            // (the plain variant is launched with a threshold >= 0 only: launch_prox_nw)
+            float y1 = GENERAL ? soft1(y[e], a.thr * wt) : soft1_pos(y[e], a.thr);
+            y1 = sa_med3(y1, nn_lo, __builtin_inff());
             if (GENERAL) y1 *= keep;
             s_l1 += fabsf(wt * y1);
             y[e] = y1;
@@ -1127,7 +1129,9 @@ static void launch_prox_nw(hipStream_t st, const RowsProxArgs<float> &a_in, dim3
         set_lds_attr<NW>(&rows_inv_prox_fwd_kernel<NW, true>);
         attr_set = true;
     }
-    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY);
+    // (a negative threshold -- a negative lambda: meaningless, but defined -- takes the variant
+    // whose soft threshold makes no assumption about its sign)
+    const bool general = a_in.wl1.ptr != nullptr || (a_in.flags & F_NOBNDRY) || a_in.thr < 0.f;
     RowsProxArgs<float> a = a_in;
     if (general && !a.wl1.ptr) a.wl1.ptr = device_one();
     const dim3 block(NW * 64);
