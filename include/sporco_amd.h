@@ -201,7 +201,11 @@ int sporco_amd_csc_set_grad_weight(sporco_amd_csc_t h, const void *w);
  * broadcastable against (H,W,C,N,1), shape[4] must be 1.  With SPORCO_AMD_FLAG_AMS the last
  * filter of the dictionary is taken to be the appended impulse (:2345-2353); its slice of Y
  * is AX + U zeroed where the mask is nonzero (:2378-2394) and is left out of the l1 / l2,1
- * sums (:2398-2412).  w == NULL removes the mask. */
+ * sums (:2398-2412).  w == NULL removes the mask.
+ * Handles made by sporco_amd_csc_create_mc (multi-channel dictionary, Cd channels): the last Cd
+ * filters are the appended impulses, one per channel (:2339-2346), and the mask is
+ * broadcastable against (H,W,1,N,Cd) -- shape[4] is 1 or Cd, the mask's channels on the filter
+ * axis as the reference keeps them (:2358-2364). */
 int sporco_amd_csc_set_ams_mask(sporco_amd_csc_t h, const void *w, const int64_t shape[5]);
 
 /* Host <-> device transfer of one state array in the reference layout. */
@@ -228,7 +232,9 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
                                                 reading them fails with SPORCO_AMD_ESTATE */
 #define SPORCO_AMD_FLAG_GRADREG (1u << 10)   /* ConvBPDNGradReg xstep / objective
                                                 (cbpdn.py:1163-1214): diagonal mu*GradWeight*GHGf
-                                                + rho, params.mu = gradient weight mu */
+                                                + rho, params.mu = gradient weight mu; multi-channel
+                                                dictionary: the iterated solve with that diagonal
+                                                (:1181-1184) */
 #define SPORCO_AMD_FLAG_AMS (1u << 11)       /* AddMaskSim y step / regulariser sums on the
                                                 last filter slice (set_ams_mask) */
 

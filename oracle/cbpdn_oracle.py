@@ -239,8 +239,10 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
 
     ``ams_mask`` selects the additive-mask-simulation wrapper AddMaskSim
     (cbpdn.py:2287-2485) around the chosen class: ``D`` must already carry the
-    appended impulse filter as its last filter (:2345-2353), ``ams_mask`` is the
-    mask W in its internal 5-D shape (cnvrep.mskWshape); the y step leaves the
+    appended impulse filter as its last filter (:2345-2353; one per channel as the
+    last Cd filters for a multi-channel dictionary), ``ams_mask`` is the
+    mask W in its internal 5-D shape (cnvrep.mskWshape, channels swapped onto the
+    filter axis when Cd > 1, :2358-2364); the y step leaves the
     impulse slice unshrunk and zeroes it where W is nonzero (:2378-2394) and the
     regularisers ignore that slice (:2398-2412).
 
@@ -277,6 +279,9 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
     DSf = np.conj(Df) * Sf
     if mcd:
         DSf = np.sum(DSf, axis=AX_C, keepdims=True)        # cbpdn.py:250-251
+    # AddMaskSim: one impulse filter, or one per channel of a multi-channel dictionary
+    # (cbpdn.py:2337-2346; index_addmsk :2447-2452)
+    n_imp = D.shape[AX_C] if mcd else 1
     gradreg = grad_mu is not None
     if gradreg:
         assert not joint
@@ -306,7 +311,10 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
         # -- xstep: cbpdn.py:267-281
         YU = Y - U
         b = DSf + rho * rfftn2(YU)
-        if gradreg:
+        if gradreg and mcd:
+            # cbpdn.py:1181-1184: the iterated solve with the diagonal in place of rho
+            Xf = solvemdbi_ism(Df, grad_mu * GHGf + rho, b, AX_K, AX_C).astype(b.dtype)
+        elif gradreg:
             Xf = solvedbd_sm(Df, grad_mu * GHGf + rho, b, None,
                              AX_K).astype(b.dtype)
         elif mcd:
@@ -319,7 +327,7 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
         AX = X if rlx == 1.0 else rlx * X + (1 - rlx) * Y
         # -- ystep
         if ams_mask is not None:
-            Yi = (AX + U)[..., -1:].copy()               # cbpdn.py:2386-2387
+            Yi = (AX + U)[..., -n_imp:].copy()           # cbpdn.py:2386-2387
         if joint:
             Y = prox_sl1l2(AX + U, (lmbda / rho) * wl1, (mu / rho) * wl21,
                            axis=AX_C)
@@ -334,7 +342,7 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
             # (index semantics of the reference kept as they are: np.where on W's own
             # shape, so a broadcast axis of W addresses index 0 only)
             Yi[np.where(np.asarray(ams_mask).astype(bool))] = 0.0   # cbpdn.py:2393
-            Y[..., -1:] = Yi
+            Y[..., -n_imp:] = Yi
         # -- ustep: admm.py:434-437
         U = U + (AX - Y)
         if stats or auto_rho:
@@ -362,7 +370,7 @@ def admm_cbpdn(D, S, lmbda, mu=None, dtype=np.float32, maxiter=50,
             gvar = Y if gevaly else X
             if ams_mask is not None:
                 gvar = gvar.copy()
-                gvar[..., -1:] = 0                       # cbpdn.py:2404-2411
+                gvar[..., -n_imp:] = 0                   # cbpdn.py:2404-2411
             rl1 = np.linalg.norm((wl1 * gvar).ravel(), 1)
             if joint:
                 rl21 = np.sum(wl21 * np.sqrt(np.sum(gvar ** 2, axis=AX_C)))

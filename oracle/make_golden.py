@@ -513,6 +513,31 @@ def gen_mcdict():
     save('solvemdbi_ism', ah=ah, b=b, rho=np.float64(1.7), x=x)
 
 
+def gen_mcdict_classes():
+    """Multi-channel dictionaries under the other ADMM classes (own seed: gen_mcdict's
+    fixtures stay as they are)."""
+    np.random.seed(86420)
+    D = np.random.randn(5, 5, 3, 4)
+    S = np.random.randn(16, 16, 3, 2)
+    # the other ADMM classes with such a dictionary: ConvBPDNGradReg (solvemdbi_ism with the
+    # diagonal mu GHGf + rho, cbpdn.py:1181-1184), ConvBPDNJoint (no channel axis left in X),
+    # AddMaskSim (one impulse filter per channel, the mask's channels on the filter axis,
+    # cbpdn.py:2337-2364)
+    wg = np.array([0.5, 0.0, 1.0, 2.0])
+    gradreg_case('admm_gradreg_mcdict_f64', D, S, 0.1, 0.2,
+                 {'MaxMainIter': 20, 'LinSolveCheck': True, 'GradWeight': wg})
+    gradreg_case('admm_gradreg_mcdict_f32', D, S, 0.1, 0.2,
+                 {'MaxMainIter': 20, 'DataType': np.float32})
+    admm_case('admm_joint_mcdict_f64', D, S, 0.1, {'MaxMainIter': 20}, joint_mu=0.05)
+    Wc = (np.random.rand(16, 16, 3, 2) > 0.3).astype(np.float64)
+    W2 = (np.random.rand(16, 16) > 0.3).astype(np.float64)
+    ams_case('ams_cbpdn_mcdict_f64', ref_cbpdn.ConvBPDN, D, S, Wc, (0.1,), {'MaxMainIter': 20})
+    ams_case('ams_cbpdn_mcdict_bcast_f64', ref_cbpdn.ConvBPDN, D, S, W2, (0.1,),
+             {'MaxMainIter': 20, 'NonNegCoef': True, 'AuxVarObj': True})
+    ams_case('ams_gradreg_mcdict_f64', ref_cbpdn.ConvBPDNGradReg, D, S, Wc, (0.1, 0.2),
+             {'MaxMainIter': 15})
+
+
 def gen_cns():
     """ADMM consensus dictionary update ConvCnstrMOD_Consensus (sporco/admm/ccmod.py:605-908,
     sporco/admm/admm.py:1441-1707) alone and inside ConvBPDNDictLearn(dmethod='cns').
@@ -977,8 +1002,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -316,8 +316,10 @@ class GenericConvBPDN(admm.ADMMEqual):
         H, W_, C, N, _ = self.cri.shpX
         # the reference zeroes `Yi[np.where(W.astype(bool))]` (cbpdn.py:2393): fancy
         # indexing with W's own index tuples, so an axis that W merely broadcasts over
-        # addresses index 0 only; expanding the mask the same way keeps that behaviour
-        full = np.zeros((H, W_, C, N, 1), dtype=self.dtype)
+        # addresses index 0 only; expanding the mask the same way keeps that behaviour.
+        # (Multi-channel dictionary: one impulse slice per channel, the mask's channels
+        # already moved to the last axis by AddMaskSim.)
+        full = np.zeros((H, W_, C, N, self.cri.Cd), dtype=self.dtype)
         full[np.where(self._ams_mask.astype(bool))] = 1.0
         self._dev.set_ams_mask(full)
 
@@ -644,7 +646,9 @@ class ConvBPDNJoint(ConvBPDN):
     DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
     """
 
-    _multichannel_dict_ok = False
+    # (a multi-channel dictionary leaves the coefficient maps without a channel axis: the
+    # l2,1 term then groups single elements, as it does in the reference)
+    _multichannel_dict_ok = True
 
     class Options(ConvBPDN.Options):
         """Adds ``L21Weight`` (cbpdn.py:719-720)."""
@@ -719,11 +723,15 @@ class ConvBPDNGradReg(ConvBPDN):
     solved by the diagonal Sherman-Morrison form of ``linalg.solvedbd_sm``
     (sporco/linalg.py:300-366) inside the same kernel.
 
+    With a multi-channel dictionary the system has one rank-one term per channel and is
+    solved by iterated Sherman-Morrison with the same diagonal (``linalg.solvemdbi_ism``
+    with an array ``rho``, cbpdn.py:1181-1184).
+
     IterationStats fields: ``Iter, ObjFun, DFid, RegL1, RegGrad, PrimalRsdl,
     DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
     """
 
-    _multichannel_dict_ok = False
+    _multichannel_dict_ok = True
 
     class Options(ConvBPDN.Options):
         """Adds ``GradWeight``: scalar, or one weight per filter (cbpdn.py:1059-1073)."""
@@ -1041,18 +1049,24 @@ class AddMaskSim(object):
         dimK = kwargs.get('dimK', None)
         dimN = kwargs.get('dimN', 2)
         self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd != 1:
-            raise NotImplementedError(
-                "multi-channel dictionaries are not part of the sporco_amd hot path yet")
         if not hasattr(cbpdnclass, '_set_ams'):
             raise TypeError("AddMaskSim wraps the solver classes of sporco_amd.admm.cbpdn")
-        # impulse filter appended to the dictionary (cbpdn.py:2345-2353)
-        self.imp = np.zeros(D.shape[0:dimN] + (1,))
-        self.imp[(0,) * dimN] = 1.0
+        # impulse filter -- one per channel of a multi-channel dictionary -- appended to the
+        # dictionary (cbpdn.py:2337-2346)
+        if self.cri.Cd == 1:
+            self.imp = np.zeros(D.shape[0:dimN] + (1,))
+            self.imp[(0,) * dimN] = 1.0
+        else:
+            self.imp = np.zeros(D.shape[0:dimN] + (self.cri.Cd,) * 2)
+            for c in range(self.cri.Cd):
+                self.imp[(0,) * dimN + (c, c)] = 1.0
         Di = np.concatenate((D, self.imp), axis=D.ndim - 1)
         self.cbpdn = cbpdnclass(Di, S, *args, **kwargs)
         self.IterationStats = self.cbpdn.IterationStats
         self.W = np.asarray(W.reshape(cr.mskWshape(W, self.cri)), dtype=self.cbpdn.dtype)
+        # the mask's channels go where the per-channel impulse filters are (cbpdn.py:2358-2364)
+        if self.cri.Cd > 1 and self.W.shape[self.cri.dimN] > 1:
+            self.W = np.swapaxes(self.W, self.cri.axisC, self.cri.axisM)
         self.cbpdn._set_ams(self.W)
 
     def solve(self):

@@ -303,7 +303,7 @@ template <typename T> struct Csc : CscBase {
         return rows_ok && fused && cols256 && !std::getenv("SPORCO_AMD_CNS_GENERIC");
     }
     bool ism_valid = false;
-    double ism_rho = 0.0;
+    double ism_rho = 0.0, ism_mu = -1.0;   // (ism_mu: mu of the gradient diagonal, -1 = none)
     int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
     FftPlan planW, planH;
     void *vars[SPORCO_AMD_VAR_COUNT] = {nullptr};
@@ -907,17 +907,21 @@ template <typename T> struct Csc : CscBase {
         // multi-channel dictionary)
         const int64_t full[5] = {H, W, which == 3 ? Cs : C, N, Ku};
         int64_t n = 1;
+        // (the AddMaskSim mask of a multi-channel dictionary has one slice per impulse filter
+        // on its last axis: cbpdn.py:2358-2364 swaps the mask's channel axis there)
+        const bool ams_mc = which == 2 && Cd > 1 && shape[4] == Cd;
         for (int i = 0; i < 5; ++i) {
-            SA_REQUIRE(shape[i] == 1 || shape[i] == full[i],
+            SA_REQUIRE(shape[i] == 1 || shape[i] == full[i] || (i == 4 && ams_mc),
                        "weight shape must be 1 or the full extent on every axis");
             n *= shape[i];
         }
         if (which == 1) SA_REQUIRE(shape[2] == 1, "L21Weight must not vary over the channel axis");
-        if (which >= 2) SA_REQUIRE(shape[4] == 1, "the mask must not vary over the filter axis");
+        if (which >= 2)
+            SA_REQUIRE(shape[4] == 1 || ams_mc, "the mask must not vary over the filter axis");
         int64_t dshape[5] = {shape[0], shape[1], shape[2], shape[3], shape[4]};
         std::vector<T> padded;
         const void *srcp = w;
-        if (K != Ku && shape[4] == Ku) {
+        if (K != Ku && shape[4] == Ku && !ams_mc) {
             // weight 1 on the padding filter (its coefficients are zero whatever the weight)
             dshape[4] = K;
             const int64_t rows = n / Ku;
@@ -944,6 +948,7 @@ template <typename T> struct Csc : CscBase {
         before_state_change();
         have_wg = w != nullptr;
         g1_valid = false;
+        ism_valid = false;
         if (!w) return;
         if (!wg) SA_HIP(hipMalloc((void **)&wg, sizeof(T) * K));
         std::vector<T> tmp((size_t)K, T(1));
@@ -1728,32 +1733,38 @@ template <typename T> struct Csc : CscBase {
         const bool xr = p.flags & F_XRRS;
         if (Cd > 1) {
             // multi-channel dictionary: iterated Sherman-Morrison (cbpdn.py:277-279)
-            SA_REQUIRE(!(p.flags & (F_GRADREG | F_AMS | F_JOINT)),
-                       "this solver variant needs a single-channel dictionary");
+            // (ConvBPDNGradReg: the identity term becomes the diagonal mu wg GHGf + rho,
+            // cbpdn.py:1181-1184; AddMaskSim and ConvBPDNJoint differ in the y step only)
+            GradTerm<T> gtm;
+            if (gradreg) gtm = grad_term(p.mu);
+            const double ism_mu_now = gradreg ? p.mu : -1.0;
             if (!ism_gam) {
                 SA_HIP(hipMalloc((void **)&ism_gam, sizeof(cx<T>) * npix * Cd * K));
                 SA_HIP(hipMalloc((void **)&ism_del, sizeof(cx<T>) * npix * Cd));
                 SA_HIP(hipMalloc((void **)&ism_mm, sizeof(cx<T>) * npix * Cd * Cd));
             }
-            if (!ism_valid || ism_rho != p.rho) {
+            if (!ism_valid || ism_rho != p.rho || ism_mu != ism_mu_now) {
                 ProfScope ps(prof, PS_OTHER);
                 launch_ism_setup<T>(st, cv(SPORCO_AMD_VAR_DF), ism_gam, ism_del, ism_mm, npix, Cd, K,
-                                    (T)p.rho);
+                                    (T)p.rho, gradreg ? &gtm : nullptr, W);
                 ism_valid = true;
                 ism_rho = p.rho;
+                ism_mu = ism_mu_now;
             }
             int nbm;
             {
                 ProfScope ps(prof, PS_SM_SOLVE);
                 nbm = launch_ism_solve<T>(st, Xf, Xf, cv(SPORCO_AMD_VAR_DF), cv(SPORCO_AMD_VAR_SF),
                                           ism_gam, ism_del, ism_mm, (T)p.rho, npix, Cd, N, K, W, obj, xr,
-                                          part_a);
+                                          part_a, gradreg ? &gtm : nullptr);
             }
             if (obj || xr) {
-                const int slots[4] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
-                                      SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
-                const double scales[4] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0};
-                finalize(part_a, nbm, 4, 4, slots, scales, out_dev);
+                const int slots[5] = {SPORCO_AMD_OUT_DFID, SPORCO_AMD_OUT_XRRS_D2,
+                                      SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2,
+                                      SPORCO_AMD_OUT_RGR};
+                const double scales[5] = {1.0 / ((double)H * W), 1.0, 1.0, 1.0, 1.0 / ((double)H * W)};
+                const int nv = gradreg ? 5 : 4;
+                finalize(part_a, nbm, nv, nv, slots, scales, out_dev);
             }
             inv2(Xf, work_buf(), X, P);
             return;
@@ -1818,6 +1829,11 @@ template <typename T> struct Csc : CscBase {
     // 64 < K <= 64 + kTailMax: the gradient-regularised column pass is available too
     bool grad_tail_ok() const { return tail_mode; }
 
+    // the impulse filters AddMaskSim appended: one, or one per channel of a multi-channel
+    // dictionary (cbpdn.py:2339-2346); they are the last filters the caller passed
+    int ams_n() const { return Cd > 1 ? Cd : 1; }
+    int ams_k0() const { return Ku - ams_n(); }
+
     // the AddMaskSim mask, when the call asks for it (F_AMS)
     Weight<T> ams_of(const sporco_amd_admm_params &p) const {
         if (!(p.flags & F_AMS)) return Weight<T>();
@@ -1855,7 +1871,10 @@ template <typename T> struct Csc : CscBase {
         // (a negative lambda -- meaningless, but the reference's soft threshold is defined for it --
         // goes to the generic chain: the row kernels clamp with a threshold known to be >= 0)
         if (rows_ok && !(p.flags & F_XRRS) && (!(p.flags & F_JOINT) || joint_rows_ok(p)) &&
-            (fused || fused_slabs || !(p.flags & F_GRADREG)) && p.lmbda >= 0.0 && p.rho > 0.0) {
+            (fused || fused_slabs || !(p.flags & F_GRADREG)) && p.lmbda >= 0.0 && p.rho > 0.0 &&
+            !(Cd > 1 && (p.flags & (F_GRADREG | F_AMS | F_JOINT)))) {
+            // (a multi-channel dictionary under ConvBPDNGradReg / AddMaskSim / ConvBPDNJoint:
+            // the generic chain -- the register kernels know one impulse slice and no diagonal)
             admm_iter_fused(p, out_dev);
             return;
         }
@@ -1876,7 +1895,8 @@ template <typename T> struct Csc : CscBase {
         pp.wl1 = wl1;
         pp.wl21 = wl21;
         pp.ams = ams_of(p);
-        pp.ams_k = Ku - 1;
+        pp.ams_k = ams_k0();
+        pp.ams_n = ams_n();
         int nb;
         {
             ProfScope ps(prof, PS_ADMM_POST);
@@ -1907,7 +1927,7 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_OTHER);
         launch_ystep<T>(st, rv(SPORCO_AMD_VAR_AX), rv(SPORCO_AMD_VAR_U), rv(SPORCO_AMD_VAR_Y),
                         (T)(p.lmbda / p.rho), (T)(p.mu / p.rho), (T)p.u_scale, p.flags, d5(), p.dH,
-                        p.dW, wl1, wl21, ams_of(p), Ku - 1);
+                        p.dW, wl1, wl21, ams_of(p), ams_k0(), ams_n());
     }
 
     void admm_ustep(const sporco_amd_admm_params &p) override {
@@ -1924,7 +1944,8 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_OTHER);
             nb = launch_admm_stats<T>(st, rv(SPORCO_AMD_VAR_X), rv(SPORCO_AMD_VAR_Y),
                                       rv(SPORCO_AMD_VAR_YPREV), rv(SPORCO_AMD_VAR_U), p.flags, d5(),
-                                      wl1, wl21, (p.flags & F_AMS) ? Ku - 1 : -1, part_b);
+                                      wl1, wl21, (p.flags & F_AMS) ? ams_k0() : -1, part_b,
+                                      ams_n());
         }
         const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
                               SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,

@@ -102,6 +102,8 @@ template <typename T> struct PostParams {
     // and it does not enter the l1 / l2,1 sums.
     Weight<T> ams;
     int ams_k = -1;   // index of that filter (K - 1 unless the handle pads the filter axis)
+    int ams_n = 1;    // a multi-channel dictionary gets one impulse per channel (cbpdn.py:2339-2346):
+                      // filters ams_k .. ams_k + ams_n - 1, the mask then (H, W, 1, N, ams_n)
 };
 template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials);
 
@@ -125,14 +127,14 @@ void launch_vform_split_joint(hipStream_t st, const T *v, T *y, T *u, T thr, T t
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
                   uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
-                  Weight<T> ams = Weight<T>(), int ams_k = -1);
+                  Weight<T> ams = Weight<T>(), int ams_k = -1, int ams_n = 1);
 template <typename T>
 void launch_ustep(hipStream_t st, const T *ax, const T *y, T *u, T u_scale, int64_t n);  // ustep
 // residual/objective sums of the staged path: x, ax unused for relaxed r (r uses x = AXnr)
 template <typename T>
 int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
                       uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, int ams_k,
-                      double *partials);
+                      double *partials, int ams_n = 1);
 template <typename T> void launch_scale(hipStream_t st, T *v, T s, int64_t n);
 
 // out = soft(v, thr * w) (+ NonNeg / NoBndryCross), l1 partial = sum |w * out|
@@ -247,12 +249,16 @@ int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, d
 // sf (npix, Cd, N), yuf / xf (npix, N, K).  K <= 256, Cd <= 8.  Partials as launch_sm_solve.
 template <typename T>
 void launch_ism_setup(hipStream_t st, const cx<T> *df, cx<T> *gam, cx<T> *del, cx<T> *mm,
-                      int64_t npix, int Cd, int K, T rho);
+                      int64_t npix, int Cd, int K, T rho, const GradTerm<T> *grad = nullptr,
+                      int W = 0);
+// (grad: the identity term is the diagonal mu wg GHGf + rho -- ConvBPDNGradReg with a
+// multi-channel dictionary, cbpdn.py:1181-1184; pass the same term and W to both calls.  The
+// solve then writes 5 partials per block, the fifth as launch_sm_solve's.)
 template <typename T>
 int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                      const cx<T> *sf, const cx<T> *gam, const cx<T> *del, const cx<T> *mm, T rho,
                      int64_t npix, int Cd, int N, int K, int W, bool want_obj, bool want_xrrs,
-                     double *partials);
+                     double *partials, const GradTerm<T> *grad = nullptr);
 // PGM gradient for a multi-channel dictionary (pgm/cbpdn.py:263-279); partials as launch_pgm_grad
 template <typename T>
 int launch_mc_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T> *sf, cx<T> *gf,

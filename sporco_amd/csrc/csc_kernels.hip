@@ -127,6 +127,11 @@ __device__ __forceinline__ T grad_gh(const GradTerm<T> &g, int64_t pix, int Wf) 
 template <typename T> __device__ __forceinline__ T grad_w(const GradTerm<T> &g, int k) {
     return g.wg ? g.wg[k] : T(1);
 }
+// filter k is one of the ams_n impulse filters AddMaskSim appended at ams_k (one, or one per
+// channel of a multi-channel dictionary: cbpdn.py:2339-2346); ams_k < 0: there are none
+__device__ __forceinline__ bool is_ams(int k, int ams_k, int ams_n) {
+    return ams_k >= 0 && k >= ams_k && k < ams_k + ams_n;
+}
 
 // Fast path: K even and G = K/2 a power of two <= 64.  Each lane owns two
 // adjacent filters (one 16-byte access for f32), a group of G lanes owns one
@@ -457,13 +462,13 @@ __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T>
                 const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
                 if (p.wl1.ptr) w = weight_at(p.wl1, h, xw, c, n, k);
                 kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
-                if (p.ams.ptr && k == p.ams_k) {
+                if (p.ams.ptr && is_ams(k, p.ams_k, p.ams_n)) {
                     // AddMaskSim impulse slice (cbpdn.py:2378-2394): no shrinkage, no
                     // NonNeg / NoBndryCross, zero where the mask is set; invisible to
                     // the regulariser (:2398-2412)
                     ams = true;
                     w = T(0);
-                    kill = weight_at(p.ams, h, xw, c, n, 0) != T(0);
+                    kill = weight_at(p.ams, h, xw, c, n, k - p.ams_k) != T(0);
                 }
             }
             T yn = soft(ax + uo, p.thr * w);
@@ -506,7 +511,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostPar
         const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
         const int64_t base = pix * C * NK + nk;
         const bool kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
-        const bool ams = p.ams.ptr && k == p.ams_k;   // AddMaskSim slice, see admm_post_kernel
+        const bool ams = p.ams.ptr && is_ams(k, p.ams_k, p.ams_n);   // AddMaskSim slice, see admm_post_kernel
         // pass 1: l2 norm over channels of the soft-thresholded values
         T nrm2 = T(0);
         for (int c = 0; c < C; ++c) {
@@ -531,7 +536,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_kernel(const PostPar
             T yn = fac * soft(ax + uo, p.thr * w);
             if (nonneg && yn < T(0)) yn = T(0);
             if (kill) yn = T(0);
-            if (ams) yn = weight_at(p.ams, h, xw, c, n, 0) != T(0) ? T(0) : ax + uo;
+            if (ams) yn = weight_at(p.ams, h, xw, c, n, k - p.ams_k) != T(0) ? T(0) : ax + uo;
             const T un = uo + ax - yn;
             p.y[idx] = yn;
             p.u[idx] = un;
@@ -581,7 +586,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_reg_kernel(const Pos
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const int k = k0 + e;
-            const bool ams = p.ams.ptr && k == p.ams_k;
+            const bool ams = p.ams.ptr && is_ams(k, p.ams_k, p.ams_n);
             T ax[CC], uo[CC], sv[CC], w[CC];
             T nrm2 = T(0);
 #pragma unroll
@@ -604,7 +609,7 @@ __global__ void __launch_bounds__(kThreads) admm_post_joint_reg_kernel(const Pos
                 T yn = fac * sv[c];
                 if (nonneg && yn < T(0)) yn = T(0);
                 if (kill) yn = T(0);
-                if (ams) yn = weight_at(p.ams, h, xw, c, n, 0) != T(0) ? T(0) : ax[c] + uo[c];
+                if (ams) yn = weight_at(p.ams, h, xw, c, n, k - p.ams_k) != T(0) ? T(0) : ax[c] + uo[c];
                 const T un = uo[c] + ax[c] - yn;
                 yv[c].v[e] = yn;
                 uv[c].v[e] = un;
@@ -834,6 +839,7 @@ template <typename T> struct YstepArgs {
     int dH, dW;
     Weight<T> wl1, wl21, ams;
     int ams_k;
+    int ams_n = 1;   // number of impulse filters from ams_k on
 };
 
 template <typename T>
@@ -872,8 +878,8 @@ __global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
             T yn = fac * soft(v, p.thr * w);
             if (nonneg && yn < T(0)) yn = T(0);
             if (kill) yn = T(0);
-            if (p.ams.ptr && k == p.ams_k)   // AddMaskSim slice (cbpdn.py:2378-2394)
-                yn = weight_at(p.ams, h, xw, c, n, 0) != T(0) ? T(0) : v;
+            if (p.ams.ptr && is_ams(k, p.ams_k, p.ams_n))   // AddMaskSim slice (cbpdn.py:2378-2394)
+                yn = weight_at(p.ams, h, xw, c, n, k - p.ams_k) != T(0) ? T(0) : v;
             p.y[idx] = yn;
         }
     }
@@ -882,10 +888,11 @@ __global__ void __launch_bounds__(kThreads) ystep_kernel(const YstepArgs<T> p) {
 template <typename T>
 void launch_ystep(hipStream_t st, const T *ax, const T *u, T *y, T thr, T thr21, T u_scale,
                   uint32_t flags, Dims5 d, int dH, int dW, Weight<T> wl1, Weight<T> wl21,
-                  Weight<T> ams, int ams_k) {
+                  Weight<T> ams, int ams_k, int ams_n) {
     YstepArgs<T> p;
     p.ams = ams;
     p.ams_k = ams_k;
+    p.ams_n = ams_n;
     p.ax = ax;
     p.u = u;
     p.y = y;
@@ -928,6 +935,7 @@ template <typename T> struct StatsArgs {
     Dims5 d;
     Weight<T> wl1, wl21;
     int ams_k;   // filter index of the AddMaskSim slice, or -1
+    int ams_n = 1;   // number of impulse filters from ams_k on
 };
 
 template <typename T>
@@ -957,7 +965,7 @@ __global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T>
             acc[3] += (double)y * (double)y;
             acc[4] += (double)u * (double)u;
             // (the regularisers do not see the AddMaskSim slice, cbpdn.py:2398-2412)
-            const T gvar = (k == p.ams_k) ? T(0) : (gy ? y : x);
+            const T gvar = is_ams(k, p.ams_k, p.ams_n) ? T(0) : (gy ? y : x);
             const T gv = w * gvar;
             acc[5] += (double)(gv < T(0) ? -gv : gv);
             g2 += (double)gvar * (double)gvar;
@@ -973,9 +981,10 @@ __global__ void __launch_bounds__(kThreads) admm_stats_kernel(const StatsArgs<T>
 template <typename T>
 int launch_admm_stats(hipStream_t st, const T *x, const T *y, const T *yprev, const T *u,
                       uint32_t flags, Dims5 d, Weight<T> wl1, Weight<T> wl21, int ams_k,
-                      double *partials) {
+                      double *partials, int ams_n) {
     StatsArgs<T> p;
     p.ams_k = ams_k;
+    p.ams_n = ams_n;
     p.x = x;
     p.y = y;
     p.yprev = yprev;
@@ -1634,7 +1643,8 @@ __global__ void __launch_bounds__(kThreads) ism_setup_kernel(const cx<T> *__rest
                                                              cx<T> *__restrict__ gam,
                                                              cx<T> *__restrict__ del,
                                                              cx<T> *__restrict__ mm, int64_t npix,
-                                                             int Cd, int K, T rho) {
+                                                             int Cd, int K, T rho, GradTerm<T> gt,
+                                                             int Wf) {
     constexpr int CMAX = 8;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
@@ -1644,12 +1654,21 @@ __global__ void __launch_bounds__(kThreads) ism_setup_kernel(const cx<T> *__rest
         const cx<T> *d = df + pix * Cd * K;
         cx<T> *g = gam + pix * Cd * K;
         cx<T> dl[CMAX];
+        // the identity term is rho, or the diagonal mu wg GHGf + rho of ConvBPDNGradReg
+        // (cbpdn.py:1181-1184: solvemdbi_ism with an array for `rho`)
+        T idg[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            idg[j] = irho;
+            if (gt.ghh && k < K) idg[j] = T(1) / (gt.mu * (grad_w(gt, k) * grad_gh(gt, pix, Wf)) + rho);
+        }
         for (int c = 0; c < Cd; ++c) {
             cx<T> al[KR];
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
                 const int k = lane + kWave * j;
-                al[j] = k < K ? cscale(cconj(d[c * K + k]), irho) : mk<T>(T(0), T(0));
+                al[j] = k < K ? cscale(cconj(d[c * K + k]), idg[j]) : mk<T>(T(0), T(0));
             }
             for (int l = 0; l < c; ++l) {
                 cx<T> t = mk<T>(T(0), T(0));
@@ -1706,7 +1725,8 @@ template <typename T> struct IsmArgs {
     int64_t npix;
     int Cd, N, K, W;
     int want_obj, want_xrrs;
-    double *partials;   // 4 doubles per block, as launch_sm_solve
+    double *partials;   // 4 doubles per block (5 with the gradient term), as launch_sm_solve
+    GradTerm<T> g;      // GRAD instantiations: the diagonal is mu wg GHGf + rho
 };
 
 // xf = solvemdbi_ism(Df, rho, sum_c conj(Df) Sf + rho yuf): one workgroup per frequency, its
@@ -1715,9 +1735,10 @@ template <typename T> struct IsmArgs {
 //     f_c = (t_c - sum_{l<c} M_cl f_l) / delta_c,     x = beta0 - sum_c gamma_c f_c,
 //     (D x)_c = t_c - sum_l M_cl f_l.
 // CC: compile-time channel count (2..4), or 0 for a run-time Cd <= 8.
-template <typename T, int KR, int CC>
+template <typename T, int KR, int CC, bool GRAD>
 __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a) {
     constexpr int CM = CC ? CC : 8;
+    constexpr int NA = GRAD ? 5 : 4;
     const int lane = threadIdx.x & (kWave - 1);
     const int Wf = a.W / 2 + 1, K = a.K, Cd = CC ? CC : a.Cd;
     const T rho = a.rho, irho = T(1) / a.rho;
@@ -1725,13 +1746,23 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
     // turn: Df, gamma, M and delta of the frequency are loaded once per wave, into registers.
     constexpr int WPB = kThreads / kWave;
     const int wv = threadIdx.x / kWave;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[NA] = {};
     for (int64_t pix = blockIdx.x; pix < a.npix; pix += gridDim.x) {
         const cx<T> *dp = a.df + pix * Cd * K;
         const cx<T> *gp = a.gam + pix * Cd * K;
         const cx<T> *M = a.mm + pix * Cd * Cd;
         const double pw = parseval_weight((int)(pix % Wf), Wf, a.W);
         cx<T> d[CM][KR], g[CM][KR], dl[CM];
+        T dg[KR], gwh[KR];   // GRAD: the diagonal and wg GHGf of this lane's filters
+        if constexpr (GRAD) {
+            const T gh = grad_gh(a.g, pix, Wf);
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                gwh[j] = k < K ? grad_w(a.g, k) * gh : T(0);
+                dg[j] = a.g.mu * gwh[j] + rho;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CM; ++c)
             if (c < Cd) {
@@ -1761,9 +1792,17 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
                 be[j] = mk<T>(T(0), T(0));
                 if (k < K) {
                     cx<T> v = a.yuf[sys * K + k];
+                    if constexpr (GRAD) {
+                        v = cscale(v, rho);                      // b = rho yuf + sum_c conj(d_c) s_c
 #pragma unroll
-                    for (int c = 0; c < CM; ++c)
-                        if (c < Cd) v = v + cscale(cmulc(d[c][j], sc[c]), irho);
+                        for (int c = 0; c < CM; ++c)
+                            if (c < Cd) v = v + cmulc(d[c][j], sc[c]);
+                        v = cscale(v, T(1) / dg[j]);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CM; ++c)
+                            if (c < Cd) v = v + cscale(cmulc(d[c][j], sc[c]), irho);
+                    }
                     be[j] = v;                                   // beta0 = b / rho
 #pragma unroll
                     for (int c = 0; c < CM; ++c)
@@ -1801,12 +1840,15 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
                     for (int c = 0; c < CM; ++c)
                         if (c < Cd) x = x - cmul(g[c][j], f[c]);
                     a.xf[sys * K + k] = x;
+                    if constexpr (GRAD) {
+                        if (a.want_obj) acc[4] += pw * (double)gwh[j] * (double)cabs2(x);
+                    }
                     if (a.want_xrrs) {
-                        cx<T> ax = cscale(x, rho);
+                        cx<T> ax = cscale(x, GRAD ? dg[j] : rho);
 #pragma unroll
                         for (int c = 0; c < CM; ++c)
                             if (c < Cd) ax = ax + cmulc(d[c][j], dx[c]);
-                        const cx<T> b = cscale(be[j], rho);
+                        const cx<T> b = cscale(be[j], GRAD ? dg[j] : rho);
                         acc[1] += (double)cabs2(ax - b);
                         acc[2] += (double)cabs2(ax);
                         acc[3] += (double)cabs2(b);
@@ -1815,7 +1857,7 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
             }
         }
     }
-    block_sum_store<4>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * 4);
+    block_sum_store<NA>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * NA);
 }
 
 template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
@@ -1827,13 +1869,14 @@ template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
 
 template <typename T>
 void launch_ism_setup(hipStream_t st, const cx<T> *df, cx<T> *gam, cx<T> *del, cx<T> *mm,
-                      int64_t npix, int Cd, int K, T rho) {
+                      int64_t npix, int Cd, int K, T rho, const GradTerm<T> *grad, int W) {
     if (Cd > 8) throw Error(-1, "multi-channel dictionaries are handled for up to 8 channels");
     const int grid = grid_for(npix * kWave);
+    const GradTerm<T> gt = grad ? *grad : GradTerm<T>();
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
         hipLaunchKernelGGL((ism_setup_kernel<T, KR>), dim3(grid), dim3(kThreads), 0, st, df, gam,
-                           del, mm, npix, Cd, K, rho);
+                           del, mm, npix, Cd, K, rho, gt, W / 2 + 1);
     });
     SA_HIP(hipGetLastError());
 }
@@ -1842,8 +1885,9 @@ template <typename T>
 int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                      const cx<T> *sf, const cx<T> *gam, const cx<T> *del, const cx<T> *mm, T rho,
                      int64_t npix, int Cd, int N, int K, int W, bool want_obj, bool want_xrrs,
-                     double *partials) {
+                     double *partials, const GradTerm<T> *grad) {
     IsmArgs<T> a;
+    if (grad) a.g = *grad;
     a.yuf = yuf;
     a.xf = xf;
     a.df = df;
@@ -1861,14 +1905,19 @@ int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *d
     a.want_xrrs = want_xrrs;
     a.partials = partials;
     const int grid = (int)std::min<int64_t>(npix, kMaxPartialBlocks);
-    const size_t lds = sizeof(double) * 4 * (kThreads / kWave);
+    const size_t lds = sizeof(double) * 5 * (kThreads / kWave);
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
+        if (grad) {
+            // (one instantiation with a run-time channel count: not a path measured in it/s)
+            hipLaunchKernelGGL((ism_solve_kernel<T, KR, 0, true>), dim3(grid), dim3(kThreads), lds, st, a);
+            return;
+        }
         switch (Cd) {
-        case 2: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 2>), dim3(grid), dim3(kThreads), lds, st, a); break;
-        case 3: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 3>), dim3(grid), dim3(kThreads), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 4>), dim3(grid), dim3(kThreads), lds, st, a); break;
-        default: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 0>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 2, false>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        case 3: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 3, false>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 4, false>), dim3(grid), dim3(kThreads), lds, st, a); break;
+        default: hipLaunchKernelGGL((ism_solve_kernel<T, KR, 0, false>), dim3(grid), dim3(kThreads), lds, st, a); break;
         }
     });
     SA_HIP(hipGetLastError());
@@ -2893,10 +2942,10 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template void launch_vform_split_joint<T>(hipStream_t, const T *, T *, T *, T, T, bool, int,   \
                                               int64_t, int64_t);                                \
     template void launch_ystep<T>(hipStream_t, const T *, const T *, T *, T, T, T, uint32_t,       \
-                                  Dims5, int, int, Weight<T>, Weight<T>, Weight<T>, int);          \
+                                  Dims5, int, int, Weight<T>, Weight<T>, Weight<T>, int, int);     \
     template void launch_ustep<T>(hipStream_t, const T *, const T *, T *, T, int64_t);             \
     template int launch_admm_stats<T>(hipStream_t, const T *, const T *, const T *, const T *,     \
-                                      uint32_t, Dims5, Weight<T>, Weight<T>, int, double *);       \
+                                      uint32_t, Dims5, Weight<T>, Weight<T>, int, double *, int);  \
     template void launch_scale<T>(hipStream_t, T *, T, int64_t);                                   \
     template int launch_prox_l1<T>(hipStream_t, const T *, T *, T, uint32_t, Dims5, int, int,      \
                                    Weight<T>, double *);                                           \
@@ -2933,10 +2982,11 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
                                      int64_t, int, int, double *);                                 \
     template int launch_cns_ystats<T>(hipStream_t, const T *, const T *, int64_t, double *);       \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
-                                      int64_t, int, int, T);                                       \
+                                      int64_t, int, int, T, const GradTerm<T> *, int);             \
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \
                                      const cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *,   \
-                                     T, int64_t, int, int, int, int, bool, bool, double *);        \
+                                     T, int64_t, int, int, int, int, bool, bool, double *,         \
+                                     const GradTerm<T> *);                                         \
     template int launch_mc_pgm_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,   \
                                        cx<T> *, int64_t, int, int, int, int, double *);            \
     template void launch_mc_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,  \

@@ -58,6 +58,13 @@ CASES = {
     'admm_mcdict_single_nonneg_f64': dict(opt={'MaxMainIter': 20, 'NonNegCoef': True,
                                                'AuxVarObj': True, 'rho': 2.0,
                                                'AutoRho': {'Enabled': False}}),
+    # ... under ConvBPDNGradReg (solvemdbi_ism with the diagonal mu GHGf + rho,
+    # cbpdn.py:1181-1184) and ConvBPDNJoint
+    'admm_gradreg_mcdict_f64': dict(opt={'MaxMainIter': 20, 'LinSolveCheck': True},
+                                    gradreg=True),
+    'admm_gradreg_mcdict_f32': dict(opt={'MaxMainIter': 20, 'DataType': np.float32},
+                                    gradreg=True, tol=1e-3),
+    'admm_joint_mcdict_f64': dict(opt={'MaxMainIter': 20}, joint=True),
 }
 
 
@@ -237,6 +244,12 @@ AMS_CASES = {
                                             'NoBndryCross': True, 'AuxVarObj': True}),
     'ams_gradreg_f64': dict(cls='ConvBPDNGradReg', opt={'MaxMainIter': 20}),
     'ams_joint_f64': dict(cls='ConvBPDNJoint', opt={'MaxMainIter': 20}),
+    # multi-channel dictionaries: one impulse filter per channel, the mask's channels on the
+    # filter axis (cbpdn.py:2337-2364)
+    'ams_cbpdn_mcdict_f64': dict(cls='ConvBPDN', opt={'MaxMainIter': 20}),
+    'ams_cbpdn_mcdict_bcast_f64': dict(cls='ConvBPDN', opt={'MaxMainIter': 20, 'NonNegCoef': True,
+                                                             'AuxVarObj': True}),
+    'ams_gradreg_mcdict_f64': dict(cls='ConvBPDNGradReg', opt={'MaxMainIter': 15}),
 }
 
 
@@ -297,8 +310,7 @@ def test_ams_staged_path_and_setdict(backend):
 
 
 def test_multichannel_dictionary_surface(backend):
-    """Default lambda (0.1 max |D^H s|, cbpdn.py:573-578), attribute shapes, staged path and
-    the variants that are not offered for Cd > 1."""
+    """Default lambda (0.1 max |D^H s|, cbpdn.py:573-578), attribute shapes, staged paths."""
     from sporco_amd.admm import cbpdn
     g = load_golden('admm_mcdict_f64')
     D, S = g['D'], g['S']
@@ -318,10 +330,20 @@ def test_multichannel_dictionary_surface(backend):
     b2.solve()
     assert len(calls) == b2.k
     check_against_golden(b2, g2, 1e-9)
-    with pytest.raises(NotImplementedError):
-        cbpdn.ConvBPDNJoint(D, S, 0.1, 0.1)
-    with pytest.raises(NotImplementedError):
-        cbpdn.ConvBPDNGradReg(D, S, 0.1, 0.1)
+    # the other classes take such a dictionary too (fixtures admm_gradreg_mcdict_*,
+    # admm_joint_mcdict_f64, ams_*_mcdict_*); their staged paths:
+    for name in ('admm_gradreg_mcdict_f64', 'admm_joint_mcdict_f64'):
+        b3, g3 = build(name)
+        orig3 = b3.ystep
+        b3.ystep = lambda o=orig3: o()
+        b3.solve()
+        check_against_golden(b3, g3, 1e-9)
+    b4, g4 = build_ams('ams_cbpdn_mcdict_f64')
+    orig4 = b4.cbpdn.ustep
+    b4.cbpdn.ustep = lambda: orig4()
+    b4.solve()
+    assert rel_l2(b4.cbpdn.Y, g4['Y']) < 1e-9 and rel_l2(b4.reconstruct(), g4['recon']) < 1e-9
+    assert rel_l2(b4.getitstat().ObjFun, g4['it_ObjFun']) < 1e-9
 
 
 def test_abi_error_paths_of_the_widened_calls(backend):

@@ -14,7 +14,11 @@ from oracle import cbpdn_oracle as orc
 
 
 def to5d(D, S, dimK=None):
-    """Internal 5-D layout for single-channel dictionaries (cnvrep.py:195-198)."""
+    """Internal 5-D layout (cnvrep.py:186-198); a 4-D D is a multi-channel dictionary."""
+    if D.ndim == 4:
+        D5 = D.reshape(D.shape[0], D.shape[1], D.shape[2], 1, D.shape[3])
+        N = S.shape[3] if S.ndim == 4 else 1
+        return D5, S.reshape(S.shape[0], S.shape[1], S.shape[2], N, 1)
     D5 = D.reshape(D.shape[0], D.shape[1], 1, 1, D.shape[-1])
     rdim = S.ndim - 2
     if dimK is None:
@@ -109,6 +113,9 @@ GRADREG_CASES = {
                                      nonneg=True, _wg='optarr_GradWeight'),
     'admm_gradreg_auxvar_f64': dict(maxiter=20, gevaly=True, fevalx=False,
                                     _wg='optarr_GradWeight'),
+    # multi-channel dictionary: the iterated solve with the diagonal (cbpdn.py:1181-1184)
+    'admm_gradreg_mcdict_f64': dict(maxiter=20, _wg='optarr_GradWeight'),
+    'admm_gradreg_mcdict_f32': dict(maxiter=20, dtype=np.float32),
 }
 
 
@@ -141,6 +148,9 @@ AMS_CASES = {
                                        gevaly=True, fevalx=False),
     'ams_gradreg_f64': dict(maxiter=20, _wg='optarr_GradWeight', _gradreg=True),
     'ams_joint_f64': dict(maxiter=20, _joint=True),
+    'ams_cbpdn_mcdict_f64': dict(maxiter=20),
+    'ams_cbpdn_mcdict_bcast_f64': dict(maxiter=20, nonneg=True, gevaly=True, fevalx=False),
+    'ams_gradreg_mcdict_f64': dict(maxiter=15, _gradreg=True),
 }
 
 
@@ -148,9 +158,15 @@ def ams_inputs(g):
     """Dictionary with the impulse filter appended (cbpdn.py:2345-2353) and the
     internal 5-D arrays."""
     D = g['D']
-    imp = np.zeros(D.shape[:2] + (1,))
-    imp[0, 0] = 1.0
-    D5, S5 = to5d(np.concatenate((D, imp), axis=2), g['S'])
+    if D.ndim == 4:      # multi-channel dictionary: one impulse per channel (:2339-2346)
+        Cd = D.shape[2]
+        imp = np.zeros(D.shape[:2] + (Cd, Cd))
+        for c in range(Cd):
+            imp[0, 0, c, c] = 1.0
+    else:
+        imp = np.zeros(D.shape[:2] + (1,))
+        imp[0, 0] = 1.0
+    D5, S5 = to5d(np.concatenate((D, imp), axis=D.ndim - 1), g['S'])
     return D5, S5
 
 
@@ -165,7 +181,8 @@ def test_ams_traces(name):
     D5, S5 = ams_inputs(g)
     if kw.pop('_gradreg', False):
         kw['grad_mu'] = float(g['mu'])
-        kw['grad_weight'] = g[kw.pop('_wg')]
+        if '_wg' in kw:
+            kw['grad_weight'] = g[kw.pop('_wg')]
     if kw.pop('_joint', False):
         kw['mu'] = float(g['mu'])
     r = orc.admm_cbpdn(D5, S5, float(g['lmbda']), dtype=dtype, ams_mask=g['Wint'], **kw)
@@ -179,7 +196,8 @@ def test_ams_traces(name):
     for key in fields:
         assert rel_l2(r[key], g['it_' + key]) < tol, key
     # AddMaskSim.reconstruct / getcoef drop the impulse slice (cbpdn.py:2431-2477)
-    assert rel_l2(orc.reconstruct(r['Df'][..., :-1], r['Y'][..., :-1], S5.shape[:2]),
+    ni = D5.shape[2] if D5.shape[2] > 1 else 1      # impulse filters appended
+    assert rel_l2(orc.reconstruct(r['Df'][..., :-ni], r['Y'][..., :-ni], S5.shape[:2]),
                   g['recon']) < tol
 
 
