@@ -37,6 +37,9 @@
  *   SPORCO_AMD_NO_SPECULATION=1 the row epilogue never emits the next iteration's row spectra
  *   SPORCO_AMD_RUN_ALWAYS_EMIT=0|1, SPORCO_AMD_JOINT_EMIT=0, SPORCO_AMD_JOINT_SEPARATE=1
  *                               epilogue variant overrides
+ *   SPORCO_AMD_PERSIST=1|0      small problems: a run of iterations as ONE launch (off unless the
+ *                               handle has SPORCO_AMD_HINT_ONE_LAUNCH; see there);
+ *                               SPORCO_AMD_PERSIST_TIMING=1 prints the phase times of measurement builds
  *   SPORCO_AMD_RUN_LAG=n        (tests) admm_run pretends not to have seen its newest n records
  *   SPORCO_AMD_COLS_PERSIST=0, SPORCO_AMD_COLS_STAGGER_GROUPS=g, SPORCO_AMD_COLS_STAGGER_SLEEPS=s
  *                               launch form of the column kernel
@@ -166,6 +169,9 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
 #define SPORCO_AMD_QUERY_VFORM_LIVE 4   /* 1 while the ADMM iterate lives in the single-array
                                             form of the fused iteration (V = AX + U; Y and U
                                             are derived on the next access) -- diagnostics */
+#define SPORCO_AMD_QUERY_PERSIST_RUNS 5  /* how many sporco_amd_csc_admm_run calls of this handle
+                                            ran their iterations as one launch (small problems:
+                                            see sporco_amd_csc_admm_run) -- diagnostics */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
 /* Hints about how the handle will be used (never needed for correctness; no reference
  * counterpart).  KEEP_VFORM: the caller alternates short device-driven runs with
@@ -174,6 +180,15 @@ int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
  * sporco_amd_csc_admm_run keeps the iterate in its single-array form and setcoef derives Y from
  * it on the way into its row transform. */
 #define SPORCO_AMD_HINT_KEEP_VFORM 0
+/* ONE_LAUNCH: this process has the device to itself and the caller accepts iterates that equal
+ * the default loop's to float32 rounding (not bit for bit): sporco_amd_csc_admm_run then runs a
+ * small problem (float32, square images of 128 or 256 pixels, K <= 64, at most 4 Mi coefficients,
+ * plain ConvBPDN options: scalar weights, NonNegCoef) as ONE kernel launch whose workgroups wait
+ * for each other between the passes of an iteration.  9-12 % faster at 256 x 256, K = 32, N = 1
+ * (profiles/r03_persist.md).  A wait that cannot complete -- the device was shared after all --
+ * ends the call with SPORCO_AMD_EHIP after a few seconds; the handle's iterate is then void.
+ * The environment variable SPORCO_AMD_PERSIST=1 / 0 overrides the hint. */
+#define SPORCO_AMD_HINT_ONE_LAUNCH 1
 int sporco_amd_csc_set_hint(sporco_amd_csc_t h, int what, int value);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))

@@ -36,7 +36,9 @@ FLAG_NO_X = 1 << 9
 FLAG_GRADREG = 1 << 10
 FLAG_AMS = 1 << 11
 QUERY_FUSED_COLS, QUERY_FUSED_ROWS, QUERY_FUSED_PGM, QUERY_DEVICE_FILTERS, QUERY_VFORM_LIVE = 0, 1, 2, 3, 4
+QUERY_PERSIST_RUNS = 5
 HINT_KEEP_VFORM = 0
+HINT_ONE_LAUNCH = 1
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <gfx950_intrin.h>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -106,7 +108,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Sum `NV` per-thread doubles over the block; thread 0 writes them to
 // dst[0..NV).  `scratch` must hold NV * (blockDim.x / 64) doubles of LDS.
-template <int NV>
+// AGENT: the sums are read by other workgroups of the same launch (agent-scope stores).
+template <int NV, bool AGENT = false>
 __device__ __forceinline__ void block_sum_store(const double (&acc)[NV], double *scratch,
                                                 double *dst) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -125,7 +128,8 @@ __device__ __forceinline__ void block_sum_store(const double (&acc)[NV], double 
         for (int i = 0; i < NV; ++i) {
             double s = 0.0;
             for (int j = 0; j < nwave; ++j) s += scratch[j * NV + i];
-            dst[i] = s;
+            if constexpr (AGENT) sa_store_agent(dst + i, s);
+            else dst[i] = s;
         }
     }
 }

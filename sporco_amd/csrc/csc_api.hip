@@ -75,6 +75,7 @@ enum ProfSlot {
     PS_FINALIZE,
     PS_PGM,
     PS_OTHER,
+    PS_PERSIST,                 // a run of iterations in one launch (csc_rows.h admm_persist)
     PS_COUNT
 };
 static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_solve",
@@ -83,7 +84,8 @@ static const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd
                                            "rows_inv_post_emit",
                                            "rows_fwd_v",       "rows_inv_post_v",  "rows_inv_post_v_emit",
                                            "pgm_grad_ifft",    "pgm_rows_prox",    "pgm_fft_momentum",
-                                           "finalize",         "pgm_elementwise",  "other"};
+                                           "finalize",         "pgm_elementwise",  "other",
+                                           "admm_persist_run"};
 
 struct Profiler {
     bool on = false;
@@ -340,6 +342,13 @@ template <typename T> struct Csc : CscBase {
     bool rows_ok = false;
     cx<T> *twRows = nullptr;
     double *part_rows = nullptr;
+    // one-launch solve of small problems (csc_rows.h admm_persist): second set of partial-sum
+    // buffers, per-workgroup argument copies and control blocks, the barrier words
+    double *pst_part_rows = nullptr, *pst_part_f = nullptr;
+    void *pst_blk = nullptr;
+    AdmmCtl *pst_ctl = nullptr;
+    unsigned *pst_bar = nullptr;
+    int pst_grid = 0, pst_runs = 0;
     // The three-launch iteration writes the new (Y, U) into a second pair of
     // buffers and swaps: the previous iterate stays intact, so X (which that path
     // keeps in registers only) can be rebuilt exactly, on demand, by re-running the
@@ -507,6 +516,8 @@ template <typename T> struct Csc : CscBase {
         (void)hipStreamSynchronize(st);
         for (auto &v : vars)
             if (v) (void)hipFree(v);
+        for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar})
+            if (p) (void)hipFree(p);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)ccmod_r, (void *)pgm_ey, (void *)gpart,
                         (void *)qpart, (void *)coop_flags, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
@@ -584,9 +595,10 @@ template <typename T> struct Csc : CscBase {
     // K > 64 -- rows of exactly K filters (a handle in tail mode, 64 < K <= 72, pads the rows of
     // its Xf buffer to 80 for the ADMM tail kernels: the staged composition serves it).
     bool pgm_fused_ok() const { return rows_ok && cols256 && (fused || (fused_slabs && !tail_mode)); }
-    bool hint_vform = false;
+    bool hint_vform = false, hint_one_launch = false;
     void set_hint(int what, int value) override {
         if (what == SPORCO_AMD_HINT_KEEP_VFORM) hint_vform = value != 0;
+        else if (what == SPORCO_AMD_HINT_ONE_LAUNCH) hint_one_launch = value != 0;
         else throw Error(SPORCO_AMD_EINVAL, "unknown hint");
     }
     int query(int what) override {
@@ -595,6 +607,7 @@ template <typename T> struct Csc : CscBase {
         if (what == SPORCO_AMD_QUERY_FUSED_PGM) return pgm_fused_ok() ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
         if (what == SPORCO_AMD_QUERY_VFORM_LIVE) return v_live ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_PERSIST_RUNS) return pst_runs;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
 
@@ -1322,6 +1335,137 @@ template <typename T> struct Csc : CscBase {
                !std::getenv("SPORCO_AMD_HOST_LOOP");
     }
 
+    // The run as one launch (csc_rows.h admm_persist): small problems, plain options, the
+    // single-array state, no collective between the sums and the control update.  Opt-in
+    // (SPORCO_AMD_PERSIST=1 or SPORCO_AMD_HINT_ONE_LAUNCH): it needs the whole device to itself
+    // (its workgroups wait for each other), it buys 9-12 % where it applies
+    // (profiles/r03_persist.md), and on the GPU its iterates equal those of the launch-per-pass
+    // loop to rounding, not bit for bit.
+    bool persist_ok(const sporco_amd_admm_params &p, const sporco_amd_admm_ctrl &c, bool vf,
+                    bool has_reduce) const {
+        const char *e = std::getenv("SPORCO_AMD_PERSIST");
+        const bool off = e ? e[0] != '1' : !hint_one_launch;
+        return !off && vf && !has_reduce && fused && !fused_slabs && Ks == K && run_always_emit &&
+               admm_persist_supported<T>(H, W, K) && !wl1.ptr && c.max_iter >= 3 &&
+               !(p.flags & (F_NOBNDRY | F_AMS | F_JOINT));
+    }
+    PersistIterArgs<T> persist_iter_args(const sporco_amd_admm_params &p, const T *vin, T *vout,
+                                         double *prow, double *pcol) {
+        PersistIterArgs<T> a;
+        cx<T> *Xf = cv(SPORCO_AMD_VAR_XF);
+        a.fwd.y = a.fwd.u = nullptr;
+        a.fwd.v = vin;
+        a.fwd.flags = p.flags;
+        a.fwd.C = C;
+        a.fwd.N = N;
+        a.fwd.dH = p.dH;
+        a.fwd.dW = p.dW;
+        a.fwd.s2 = T(1);
+        a.fwd.t = Xf;
+        a.fwd.Ks = Ks;
+        a.fwd.twA = twRows;
+        a.fwd.H = H;
+        a.fwd.W = W;
+        a.fwd.CN = CN;
+        a.fwd.K = K;
+        a.fwd.P = P;
+        a.cols.t = Xf;
+        a.cols.dft = dft;
+        a.cols.sft = sft;
+        a.cols.gramt = gramt;
+        a.cols.twA = twA;
+        a.cols.twB = twB;
+        a.cols.rho = (T)p.rho;
+        a.cols.H = H;
+        a.cols.W = W;
+        a.cols.CN = CN;
+        a.cols.K = K;
+        a.cols.partials = pcol;
+        a.cols.Ks = Ks;
+        a.post.twA = twRows;
+        a.post.t_next = Xf;
+        a.post.t = Xf;
+        a.post.twW = planW.tw<T>();
+        a.post.y = a.post.u = nullptr;
+        a.post.y_out = a.post.u_out = nullptr;
+        a.post.v_in = vin;
+        a.post.v_out = vout;
+        a.post.x = nullptr;
+        a.post.scale = T(1.0 / ((double)H * (double)W));
+        a.post.rlx = (T)p.rlx;
+        a.post.thr = T(0);
+        a.post.u_scale = T(1);
+        a.post.flags = p.flags;
+        a.post.H = H;
+        a.post.W = W;
+        a.post.C = C;
+        a.post.N = N;
+        a.post.K = K;
+        a.post.dH = p.dH;
+        a.post.dW = p.dW;
+        a.post.P = P;
+        a.post.Ks = Ks;
+        a.post.partials = prow;
+        return a;
+    }
+    // iterations index0 .. max_iter - 1 of the run whose control block is ctl_dev; v_prev: the
+    // iterate iteration index0 - 1 left, v_other: the other V buffer.  Returns how many ran.
+    int run_persist(const sporco_amd_admm_params &p, int index0, int max_iter, T *v_prev, T *v_other,
+                    bool want_sums) {
+        const int grid = admm_persist_grid<T>(H, W, K, CN);
+        const int64_t nrow = (int64_t)H * ceil_div(P, 128), ncol = (int64_t)Wf * CN;
+        if (!pst_part_rows) {
+            SA_HIP(hipMalloc((void **)&pst_part_rows, sizeof(double) * 8 * nrow));
+            SA_HIP(hipMalloc((void **)&pst_part_f, sizeof(double) * 2 * ncol));
+            SA_HIP(hipMalloc((void **)&pst_bar, sizeof(unsigned) * kPersistBarWords));
+        }
+        if (pst_grid < grid) {
+            if (pst_blk) {
+                sync();
+                SA_HIP(hipFree(pst_blk));
+                SA_HIP(hipFree(pst_ctl));
+            }
+            SA_HIP(hipMalloc(&pst_blk, sizeof(PersistIterArgs<T>) * 2 * grid));
+            SA_HIP(hipMalloc((void **)&pst_ctl, sizeof(AdmmCtl) * grid));
+            pst_grid = grid;
+        }
+        AdmmPersistArgs<T> a;
+        // iteration j reads the V that iteration j - 1 wrote
+        const int p0 = index0 & 1;
+        a.iter[p0] = persist_iter_args(p, v_prev, v_other, part_rows, part_f);
+        a.iter[p0 ^ 1] = persist_iter_args(p, v_other, v_prev, pst_part_rows, pst_part_f);
+        a.blk = static_cast<PersistIterArgs<T> *>(pst_blk);
+        a.ctl_blk = pst_ctl;
+        a.ctl = ctl_dev;
+        a.rec = reinterpret_cast<AdmmRecord *>(rec_ring) + index0;
+        a.index0 = index0;
+        a.max_iter = max_iter - index0;
+        a.bar = pst_bar;
+        a.n_row_tiles = (int)nrow;
+        a.n_col_tiles = (int)ncol;
+        a.want_dfid = (p.flags & F_OBJ) ? 1 : 0;
+        a.want_sums = want_sums ? 1 : 0;
+        a.dfid_scale = 1.0 / ((double)H * W);
+        SA_HIP(hipMemsetAsync(pst_bar, 0, sizeof(unsigned) * kPersistBarWords, st));
+        {
+            ProfScope ps(prof, PS_PERSIST);
+            launch_admm_persist<T>(st, a, grid);
+        }
+        unsigned bar[16];
+        SA_HIP(hipMemcpyAsync(bar, pst_bar, sizeof(bar), hipMemcpyDeviceToHost, st));
+        sync();
+        if (std::getenv("SPORCO_AMD_PERSIST_TIMING") && bar[3])      // (measurement builds fill these)
+            std::fprintf(stderr, "admm_persist: %u iterations; ticks (10 ns) per iteration: fwd %.0f bar %.0f | cols %.0f "
+                         "bar %.0f | post %.0f bar %.0f | sums %.0f ctl %.0f\n", bar[3], bar[8] / (double)bar[3],
+                         bar[9] / (double)bar[3], bar[10] / (double)bar[3], bar[11] / (double)bar[3],
+                         bar[12] / (double)bar[3], bar[13] / (double)bar[3], bar[14] / (double)bar[3],
+                         bar[15] / (double)bar[3]);
+        if (bar[2]) throw Error(SPORCO_AMD_EHIP, "one-launch solve: a grid barrier did not complete");
+        xf_tiled = true;
+        ++pst_runs;
+        return (int)bar[3];
+    }
+
     // one iteration of admm_iter_fused with every iteration-dependent scalar taken from ctl_dev
     // vout set: the single-array state of csc_rows.h -- the iterate is read from vin (null: from
     // (Y, U), the first iteration of such a run) and V' is written to vout
@@ -1557,7 +1701,15 @@ template <typename T> struct Csc : CscBase {
         // the same on all ranks however late each host notices the stop (the surplus
         // iterations are launches that return at once around an all-reduce nobody reads).
         const int wlag = reduce ? 0 : lag;
-        for (; enq < c.max_iter && stop_at < 0;) {
+        if (persist_ok(p, c, vf, reduce != nullptr)) {
+            // small problem: the first iteration as usual (it enters the single-array state),
+            // every further one inside one launch
+            enqueue_one();
+            T *v0 = vb_in, *v1 = (v0 == y_alt) ? u_alt : y_alt;
+            enq += run_persist(p, 1, c.max_iter, v0, v1, want_sums);
+            if (c.need_residuals) poll(enq, false);
+        }
+        for (; enq < c.max_iter && stop_at < 0 && !persist_ok(p, c, vf, reduce != nullptr);) {
             enqueue_one();
             if (c.need_residuals) {
                 poll(enq - lag, false);

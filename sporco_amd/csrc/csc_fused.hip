@@ -21,6 +21,7 @@
 // out), so no reordering pass exists anywhere.
 #include "csc_fused.h"
 
+#include "csc_fused_body.h"
 #include "regfft.h"
 
 #include <cmath>
@@ -34,317 +35,14 @@ namespace {
 
 using namespace regfft;
 
-constexpr int kExchUnitsMax = 16384;  // f2 units of the largest exchange buffer (128 KiB)
-// LDS of one instantiation: its exchange group (LP lines of NW points for every wave) + scratch
-constexpr size_t fused_lds_bytes(int NW, int LP) {
-    return sizeof(f2) * LP * NW * NW * 64 + sizeof(double) * 2 * 16;   // + block_sum scratch
-}
-
-// N1 x NW = H; NW waves; KC: compile-time filter count (64), or 0 for a run-time K <= 64.
-// GRAD: the diagonal Sherman-Morrison form of ConvBPDNGradReg (cbpdn.py:1163-1175,
-// linalg.py:300-366) with dd = mu wg_k (ghh[f] + ghw[wf]) + rho per element:
-//     coef = (Sf - rho sum_k Df yuf / dd) / g1,    g1 = 1 + sum_k |Df|^2 / dd  (table)
-//     xf = (rho yuf + conj(Df) coef) / dd,         Df.xf - Sf = -coef
-// and a second partial per tile, the weighted sum of wg GHGf |xf|^2 (cbpdn.py:1204-1214).
-// KRT (with KC = 64): the kernel owns 64 filters of rows that are a.K > 64 filters long
-// (FusedColsArgs::Kv): run-time row stride, all lanes valid, multipliers stored.
-// PER_TILE (with KC = 64): the D-side operands (dft, gramt) are those of the tile, not of its
-// row frequency (FusedColsArgs::per_tile).
-#ifdef SPORCO_AMD_HOSTSIM
-#define SA_TS(i)
-#else
-#define SA_TS(i)                                                                  \
-    if constexpr (DBG >= 3) {                                                      \
-        unsigned long long t_;                                                     \
-        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_));            \
-        ts[i] = t_;                                                                \
-    }
-#endif
-// DBG (measurement builds only, SPORCO_AMD_COLS_DEBUG): 1 = loads and stores only, 2 = no tile
-// loads / stores (arithmetic, exchanges and operand loads only).
 template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false,
           int DBG = 0>
 __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
-    constexpr int H = N1 * NW;
-    constexpr int J = N1 / NW;   // stage-2 lines per thread (each NW points)
-    constexpr int LB1 = ilog2(N1), LBW = ilog2(NW);
-    // The two LDS exchanges and the solve between them are pipelined over groups
-    // of LP lines (FP = LP*NW values of f1): a group leaves the register tile,
-    // is transformed / solved / transformed back by the waves that own its
-    // lines, and returns to the same registers; the rest of the tile stays put.
-    constexpr int LP = LPARAM;
-    constexpr int FP = LP * NW, Q = J / LP;
-    static_assert(J % LP == 0, "lines per group must divide the lines per thread");
-    static_assert(FP * NW * 64 <= kExchUnitsMax, "exchange group too large");
-    const int tid = threadIdx.x;
-    const int k = tid & 63;
-    const int w = sa_readfirstlane(tid >> 6);
-    const int K = (KC && !KRT) ? KC : ((KRT && a.Ks) ? a.Ks : a.K);   // row stride, in filters
-    const bool kv = KC == 64 ? true : k < K;
-    // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).
-    // All C*N tiles of one row frequency wf share the same 256 KiB slice of Df, so
-    // they are given to one XCD, back to back: its L2 then serves the re-reads.
-    // With 16 waves (H = 512) the kernel is persistent: the launch holds one workgroup per
-    // CU (a multiple of 8 of them, launch_fused_inst) and workgroup (xcd, s) walks the slots
-    // s, s + G/8, ... of its XCD's list, so that the stores of one tile are still draining
-    // while the loads of the next are in flight -- the only overlap of memory and arithmetic
-    // a CU that holds a single 16-wave workgroup can have.  All workgroups of an XCD are on
-    // the same row frequency at about the same time (CN >= G/8 tiles share it), which keeps
-    // the Df slice in that XCD's L2 as before.  With 8 waves (H = 256) two workgroups share a
-    // CU and overlap each other; the tile loop would cost them the registers for that, so
-    // there it runs once.
     constexpr bool PERSIST = (NW == 16 || N1 == 64) && KC == 64;   // (run-time K: scalar registers are short)
-    const int xcd = blockIdx.x & 7;
-    f2 *LA = dyn_lds<f2>();
-    f2 *LB = LA;
-    double *scratch = reinterpret_cast<double *>(LA + FP * NW * 64);
-    const cf zero = mk<float>(0.f, 0.f);
-    const int cvoff = k == 0 ? 0 : (int)0x80000000;
-    const int ko = (w * K + k) * (int)sizeof(cf);             // row h = w, filter k
-    int token = 0;
-    if (a.ctl && a.ctl->stop) return;     // device-driven solve: stopping test already met
-    if constexpr (PERSIST) {
-        const int ph = (int)(blockIdx.x >> 3) % a.stagger_groups;
-        for (int i = 0; i < ph * a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    for (int slot = blockIdx.x >> 3;; slot += gridDim.x >> 3) {
-    // (the argument block is re-read per tile through an opaque pointer: neither its fields
-    // nor the operand tables' loads may be hoisted out of the tile loop, where they would
-    // hold scalar registers throughout)
-    SA_ARGS_PTR_T(FusedColsArgs<float>) ap = sa_args_reload<PERSIST>(a);
-    const int Wf = ap->W / 2 + 1, CN = ap->CN;
-    if (slot >= ((Wf + 7) / 8) * CN) break;
-    const int wf = (slot / CN) * 8 + xcd;
-    if (wf >= Wf) break;
-    const int tile = wf * CN + slot % CN;
-    const AdmmCtl *ctl = ap->ctl;
-    const float rho = ctl ? ctl->rho_f : ap->rho;
-    const float *GH = ap->ghh + w;
-    const cf *twA = ap->twA + w * N1;                         // W_H^(w * brev(i)),      i < N1
-    const cf *twB = ap->twB + w * N1;                         // W_H^((w + NW j) * h2), [j][h2]
-    // buffer addressing: wave-uniform descriptors of this tile / this Df slice, one
-    // shared 32-bit lane offset and scalar row offsets, so the 3*N1 row addresses
-    // cost no vector registers (the tile itself needs 2*N1 of them)
-    const BufRsrc Tb = make_rsrc(ap->t + (int64_t)tile * H * K, (uint32_t)(H * K * sizeof(cf)));
-    const int dsel = PER_TILE ? tile : wf;
-    const BufRsrc Db = make_rsrc(ap->dft + (int64_t)dsel * H * K, (uint32_t)(H * K * sizeof(cf)));
-    cf *const coef_out = KRT ? ap->coef_out : nullptr;
-    const BufRsrc Cb = make_rsrc(coef_out ? coef_out + (int64_t)tile * H : nullptr,
-                                 coef_out ? (uint32_t)(H * sizeof(cf)) : 0u);
-    const cf *S = ap->sft + (int64_t)tile * H + w;
-    const float *G = (GRAD ? ap->g1t : ap->gramt) + (int64_t)dsel * H + w;
-    // One buffer (LA == LB) serves both exchanges: a unit is written and read back by the
-    // same thread on either side, so only the two hand-overs need a barrier -- also from
-    // one tile to the next.
-
-    // ---- load rows h = NW*h1 + w, forward FFT over h1, twiddle -----------------------
-    unsigned long long ts[16] = {0};
-    SA_TS(0)
-    cf v[N1];
-#pragma unroll
-    for (int h1 = 0; h1 < N1; ++h1)
-        v[h1] = (kv && DBG != 2 && DBG != 4) ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf))
-                                 : mk<float>((float)(k + h1), (float)(w - h1));
-    if constexpr (DBG != 1) {
-    dif<N1, false>(v, 0);
-    reg_fence<N1>(v, 0, token);
-#pragma unroll
-    for (int i = 1; i < N1; ++i) {
-        // (scalar-cache load where the scalar registers allow it: a vector load here waits
-        // out a full L2 round trip)
-        cf tw;
-        if constexpr (KC == 64 && !GRAD) sa_uload2(reinterpret_cast<const float *>(twA + i), tw.re, tw.im);
-        else tw = twA[i];
-        v[i] = cmul(v[i], tw);
-    }
-    reg_fence<N1>(v, 0, token);
-    }
-    SA_TS(1)
-
-    float obj = 0.f;
-    if constexpr (DBG != 1) {
-    // GRAD: dd = ak * ghh[f] + bk, with the row-frequency part folded into bk
-    float ak = 0.f, bk = 0.f, gw = 0.f, rg = 0.f;
-    if constexpr (GRAD) {
-        const float *wgp = ap->wg;
-        gw = sa_uload(ap->ghw + wf);
-        ak = ap->mu * ((wgp && kv) ? wgp[k] : 1.f);
-        bk = ak * gw + rho;
-    }
-    static_for<Q>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        // ---- exchange A: (w = h2; f1 in regs) -> (w = f1 mod NW; h2 in regs) ---------
-#pragma unroll
-        for (int fl = 0; fl < FP; ++fl) {
-            const cf x = v[brev(q * FP + fl, LB1)];
-            f2 t;
-            t.x = x.re;
-            t.y = x.im;
-            LA[(fl * NW + w) * 64 + k] = t;
-        }
-        // The Df values of chunk g+1 (4 frequencies) and the Sf / gram scalars of
-        // chunk g are requested one chunk ahead of their use; chunk 0's before the
-        // barrier, so that their latency hides behind the exchange and the FFT.
-        constexpr int CPL = NW / 4, NCH = LP * CPL;   // chunks per line, per group
-        cf dn[4];
-        cf sn[4];
-        float gn[4], hn[4];
-        auto prefetch = [&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int fo = NW * j + N1 * brev(4 * c + e, LBW);  // f - w
-                dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
-                sa_uload2(reinterpret_cast<const float *>(S + fo), sn[e].re, sn[e].im);
-                gn[e] = sa_uload(G + fo);
-                if constexpr (GRAD) hn[e] = sa_uload(GH + fo);
-            }
-        };
-        prefetch(std::integral_constant<int, 0>{});
-        SA_TS(2 + 4 * q)
-        __syncthreads();
-        SA_TS(3 + 4 * q)
-        cf u[FP];   // u[NW*jl + h2] = A[h2][f1 = w + NW*(q*LP + jl)]
-#pragma unroll
-        for (int jl = 0; jl < LP; ++jl) {
-#pragma unroll
-            for (int h2 = 0; h2 < NW; ++h2) {
-                const f2 t = LA[((w + NW * jl) * NW + h2) * 64 + k];
-                u[NW * jl + h2] = mk<float>(t.x, t.y);
-            }
-        }
-        static_for<NCH>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            constexpr int jl = g / CPL, c = g % CPL;
-            // forward FFT over h2: u[NW jl + i] = X[f1 + N1 * brev(i)], f1 = w + NW j
-            if constexpr (c == 0) dif<NW, false>(u, NW * jl);
-            // Sherman-Morrison solve of 4 frequencies
-            cf d[4], sv[4];
-            float gv[4], hv[4], idd[4], red[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                d[e] = dn[e];
-                sv[e] = sn[e];
-                gv[e] = gn[e];
-                if constexpr (GRAD) hv[e] = hn[e];
-            }
-            if constexpr (g + 1 < NCH) prefetch(std::integral_constant<int, g + 1>{});
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cf p = cmul(d[e], u[NW * jl + 4 * c + e]);
-                if constexpr (GRAD) {
-                    idd[e] = sa_rcp(ak * hv[e] + bk);
-                    p = cscale(p, idd[e]);
-                }
-                red[2 * e] = p.re;
-                red[2 * e + 1] = p.im;
-            }
-            const float tot = reduce8_across_lanes(red, k);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const cf qq = mk<float>(sa_readlane(tot, 16 * e), sa_readlane(tot, 16 * e + 8));
-                if constexpr (GRAD) {
-                    const cf coef = cscale(sv[e] - cscale(qq, rho), sa_rcp(gv[e]));
-                    obj += cabs2(coef);
-                    if constexpr (KRT) {
-                        constexpr int j = q * LP + jl;
-                        const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                        buf_store_cf(Cb, cvoff, (w + fo) * (int)sizeof(cf), coef);
-                    }
-                    const cf xn = cscale(cscale(u[NW * jl + 4 * c + e], rho) + cmulc(d[e], coef),
-                                         idd[e]);
-                    rg += (hv[e] + gw) * cabs2(xn);
-                    u[NW * jl + 4 * c + e] = xn;
-                } else {
-                    const float inv = sa_rcp(gv[e] + rho);
-                    const cf coef = cscale(sv[e] - qq, inv);
-                    // Df.xf - Sf = rho (q - Sf) / (gram + rho)
-                    obj += cabs2(coef);
-                    u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d[e], coef);
-                    if constexpr (KRT) {
-                        // the multiplier of this frequency, for the filters held elsewhere
-                        // (lane 0 only; a null coef_out makes every lane out of range)
-                        constexpr int j = q * LP + jl;
-                        const int fo = NW * j + N1 * brev(4 * c + e, LBW);
-                        buf_store_cf(Cb, cvoff, (w + fo) * (int)sizeof(cf), coef);
-                    }
-                }
-            }
-            // inverse FFT over f2, conj twiddle
-            if constexpr (c == CPL - 1) {
-                constexpr int j = q * LP + jl;
-                dit<NW, true>(u, NW * jl);
-#pragma unroll
-                for (int h2 = 1; h2 < NW; ++h2) {
-                    cf tw;
-                    sa_uload2(reinterpret_cast<const float *>(twB + NW * j + h2), tw.re, tw.im);
-                    u[NW * jl + h2] = cmulc(tw, u[NW * jl + h2]);
-                }
-            }
-        });
-        SA_VGPR_FENCE3(obj, rg, token);
-        SA_TS(4 + 4 * q)
-        // ---- exchange B: back to (w = h2; f1 in regs), placed in DIT input order -----
-#pragma unroll
-        for (int jl = 0; jl < LP; ++jl) {
-#pragma unroll
-            for (int h2 = 0; h2 < NW; ++h2) {
-                f2 t;
-                t.x = u[NW * jl + h2].re;
-                t.y = u[NW * jl + h2].im;
-                LB[((w + NW * jl) * NW + h2) * 64 + k] = t;
-            }
-        }
-        __syncthreads();
-        SA_TS(5 + 4 * q)
-#pragma unroll
-        for (int fl = 0; fl < FP; ++fl) {
-            const f2 t = LB[(fl * NW + w) * 64 + k];
-            v[brev(q * FP + fl, LB1)] = mk<float>(t.x, t.y);
-        }
-    });
-    reg_fence<N1>(v, 0, token);
-    SA_TS(10)
-
-    // The tile's sums go out before the last transform, so that the stores below are the
-    // last thing a wave does for this tile and the next tile's loads follow them directly.
-    // (always written: a conditional here makes the compiler sink the whole |coef|^2
-    // chain into the branch and keep every coef alive until the end of the kernel)
-    const double pw = (wf == 0 || ((ap->W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
-    if constexpr (GRAD) {
-        const float *wgp = ap->wg;
-        const float wk = (wgp && kv) ? wgp[k] : 1.f;
-        double acc[2] = {k == 0 ? (double)obj * pw : 0.0, kv ? (double)(rg * wk) * pw : 0.0};
-        block_sum_store<2>(acc, scratch, ap->partials + 2 * tile);
-    } else {
-        double acc[1] = {k == 0 ? (double)obj * pw * (double)rho * (double)rho : 0.0};
-        block_sum_store<1>(acc, scratch, ap->partials + tile);
-    }
-    SA_VGPR_FENCE3(v[0].re, v[0].im, token);
-
-    }   // DBG != 1
-    // ---- inverse FFT over f1, store the rows this wave loaded ------------------------
-    if constexpr (DBG != 1) dit<N1, true>(v, 0);
-    if ((DBG == 2 || DBG == 4) ? v[3].re == 1234.5678f : kv) {
-#pragma unroll
-        for (int h1 = 0; h1 < N1; ++h1)
-            buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
-    }
-    if constexpr (DBG >= 3) {
-        SA_VGPR_FENCE3(v[0].re, v[1].im, token);
-        SA_TS(12)
-        if (blockIdx.x == 17 && slot == (int)(blockIdx.x >> 3) + 5 * (int)(gridDim.x >> 3) && k == 0 &&
-            (w == 0 || w == 15)) {
-            printf("w%d load+fft32 %llu | q0: wrA %llu bar %llu sm %llu wrB+bar %llu | q1: rdB+wrA %llu bar %llu sm %llu "
-                   "wrB+bar %llu | rdB %llu sums %llu ifft32 %llu | total %llu\n",
-                   w, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5],
-                   ts[7] - ts[6], ts[8] - ts[7], ts[9] - ts[8], ts[10] - ts[9], ts[11] - ts[10], ts[12] - ts[11],
-                   ts[12] - ts[0]);
-        }
-    }
-    if constexpr (!PERSIST) break;
-    }   // persistent loop over this workgroup's tiles
+    constexpr int AOFF = 0;
+    SA_ARGS_PTR_T(FusedColsArgs<float>) afix = nullptr;
+    (void)afix;
+#include "csc_fused_body.inc"
 }
 
 // g1t[wf][h] = 1 + sum_k |Df|^2 / (mu wg_k (ghh[h] + ghw[wf]) + rho): the Sherman-Morrison

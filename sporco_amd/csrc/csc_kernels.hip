@@ -8,6 +8,7 @@
 #include "csc_kernels.h"
 
 #include <gfx950_intrin.h>
+#include "csc_ctl_dev.h"
 
 #include "../../include/sporco_amd.h"
 
@@ -2782,21 +2783,6 @@ SA_INST_CG(double)
 // ---------------------------------------------------------------------------
 // device-resident ADMM control (csc_kernels.h)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void admm_ctl_derive(AdmmCtl *c) {
-#pragma clang fp contract(off)
-    // what the iteration kernels read, from (rho, u_scale): the casts of
-    // csc_api.hip admm_iter_fused ((T)p.rho, (T)(p.lmbda / p.rho), (T)p.u_scale)
-    c->rho_f = (float)c->rho;
-    c->thr_f = (float)(c->lmbda / c->rho);
-    c->thr21_f = (float)(c->mu21 / c->rho);
-    c->u_scale_f = (float)c->u_scale;
-    c->stable_run = c->u_scale == 1.0 ? c->stable_run + 1 : 0;
-    // (no_speculation: 0 = emit once rho has been stable for two iterations, 1 = never,
-    // 2 = always -- small problems, where a wasted emit costs less than a launch that returns)
-    c->emit = c->no_speculation == 2 ? 1 : ((c->stable_run >= 2 && !c->no_speculation) ? 1 : 0);
-    c->skip_fwd = (c->emitted && c->u_scale == 1.0) ? 1 : 0;
-}
-
 __global__ void admm_ctl_init_kernel(AdmmCtl *c, const AdmmCtlInit in) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     c->rho = in.rho;
@@ -2827,85 +2813,10 @@ __global__ void admm_ctl_init_kernel(AdmmCtl *c, const AdmmCtlInit in) {
     c->thr21_prev_f = in.thr21_prev;
 }
 
-// The arithmetic below restates, operation by operation, sporco_amd/admm/cbpdn.py
-// residual_norms and sporco_amd/admm/admm.py compute_residuals / rho_scale_factor /
-// update_rho (themselves sporco/admm/admm.py:462-486, 549-575) for a solver whose real
-// type is T: sums, norms, residuals and tolerances are float64; rho, tau, mu, xi are T
-// scalars, products of two of them are formed in T, and a multiplier that was clipped to
-// tau is a T value (so 1 / tau is a T division) -- NumPy's scalar promotion rules.
 template <typename T>
 __global__ void admm_ctl_update_kernel(AdmmCtl *c, const double *sums, AdmmRecord *rec, int index) {
-    // (no fused multiply-adds: the host code this mirrors rounds every product)
-#pragma clang fp contract(off)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (c->stop) return;
-    const double rho = c->rho;
-    for (int i = 0; i < 16; ++i) rec->sums[i] = sums[i];
-    rec->rho = rho;
-    rec->u_scale = c->u_scale;
-    rec->k = c->k;
-    rec->emit = c->emit;
-    rec->skip_fwd = c->skip_fwd;
-    double r = 0.0, s = 0.0, epri = 0.0, edua = 0.0;
-    double rho_new = rho, u_scale_new = 1.0;
-    int stop = 0;
-    if (c->need_resid) {
-        const double nr = sqrt(sums[SPORCO_AMD_OUT_R2]);
-        const double ns = rho * sqrt(sums[SPORCO_AMD_OUT_S2]);
-        const double nax = sqrt(sums[SPORCO_AMD_OUT_AX2]), ny = sqrt(sums[SPORCO_AMD_OUT_Y2]);
-        double rn = nax >= ny ? nax : ny;
-        double sn = rho * sqrt(sums[SPORCO_AMD_OUT_U2]);
-        if (c->stdres) {
-            r = nr;
-            s = ns;
-            epri = c->sqrt_nc * c->abstol + rn * c->reltol;
-            edua = c->sqrt_nx * c->abstol + sn * c->reltol;
-        } else {
-            if (rn == 0.0) rn = 1.0;
-            if (sn == 0.0) sn = 1.0;
-            r = nr / rn;
-            s = ns / sn;
-            epri = c->sqrt_nc * c->abstol / rn + c->reltol;
-            edua = c->sqrt_nx * c->abstol / sn + c->reltol;
-        }
-        const int k = c->k;
-        if (c->autorho && k != 0 && ((k + 1) % c->period) == 0) {
-            const T tau = (T)c->tau, mu = (T)c->mu, xi = (T)c->xi;
-            double mlt_d = 0.0;     // the multiplier when it is a float64 value ...
-            bool mlt_is_t = true;   // ... or tau itself (a T value)
-            if (c->autoscaling && !(s == 0.0 || r == 0.0)) {
-                const double sx = s * (double)xi;
-                mlt_d = sqrt(r > sx ? r / sx : sx / r);
-                mlt_is_t = mlt_d > (double)tau;
-            }
-            double rsf = 1.0;       // float(rsf) of the host code
-            if (r > (double)(T)(xi * mu) * s) {
-                rsf = mlt_is_t ? (double)tau : mlt_d;
-            } else if (s > (double)(T)(mu / xi) * r) {
-                rsf = mlt_is_t ? (double)(T)(T(1) / tau) : 1.0 / mlt_d;
-            }
-            rho_new = (double)(T)((T)rho * (T)rsf);
-            u_scale_new = 1.0 / rsf;
-        }
-        stop = (r < epri && s < edua) ? 1 : 0;
-    }
-    rec->r = r;
-    rec->s = s;
-    rec->epri = epri;
-    rec->edua = edua;
-    rec->stop = stop;
-    rec->ticks = sa_wall_clock() - c->t0;
-    c->rho = rho_new;
-    c->u_scale = u_scale_new;
-    c->emitted = c->emit;
-    c->k = c->k + 1;
-    c->stop = stop;
-    c->thr_prev_f = c->thr_f;       // (of the iteration just finished)
-    c->thr21_prev_f = c->thr21_f;
-    admm_ctl_derive(c);
-    sa_fence_system();
-    rec->seq = index + 1;
-    sa_fence_system();
+    admm_ctl_update_dev<T>(c, sums, rec, index);
 }
 
 void launch_admm_ctl_init(hipStream_t st, AdmmCtl *ctl, const AdmmCtlInit &in) {

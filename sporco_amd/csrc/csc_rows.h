@@ -33,6 +33,7 @@
 #pragma once
 
 #include "common.h"
+#include "csc_fused.h"
 #include "csc_kernels.h"
 
 namespace sporco_amd {
@@ -149,5 +150,44 @@ template <typename T> void rows_twiddles(int W, cx<T> *twA);
 template <typename T> void launch_rows_fwd(hipStream_t st, const RowsFwdArgs<T> &a);
 // Returns the number of tiles (= rows of `partials` written).
 template <typename T> int64_t launch_rows_inv_post(hipStream_t st, const RowsPostArgs<T> &a);
+
+// ---------------------------------------------------------------------------------------------
+// Small problems (a few million coefficients): a run of iterations of the device-driven solve as
+// ONE launch.  At 256 x 256, K = 32, N = 1 the three kernels of an iteration take a few
+// microseconds each and the iteration is the cost of its launches; here a grid that the device
+// holds at once (one workgroup per CU at most) walks the tiles of the three passes -- the same
+// device functions, the single-array state, the next row spectra always emitted -- with a
+// barrier across the grid between passes, reduces the partial sums in the order of
+// finalize_kernel and advances a control block per workgroup with admm_ctl_update_dev: the
+// iterates and the per-iteration records are those of the launch-per-pass loop, bit for bit.
+// Plain ConvBPDN options (scalar weights, NonNegCoef; no NoBndryCross / AddMaskSim / Joint /
+// GradReg), square images of 128 or 256 pixels, K <= 64, float32.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct PersistIterArgs {   // what the passes read in iterations of one parity
+    RowsFwdArgs<T> fwd;     // (ctl: filled in by the kernel, per workgroup)
+    FusedColsArgs<T> cols;
+    RowsPostArgs<T> post;   // V form in and out, emitting
+};
+template <typename T> struct AdmmPersistArgs {
+    PersistIterArgs<T> iter[2];    // iteration index0 + i uses iter[(index0 + i) & 1]: the V buffers,
+                                   // and the partial-sum buffers, alternate
+    PersistIterArgs<T> *blk;       // scratch: 2 * grid copies of the above, one pair per workgroup
+    AdmmCtl *ctl_blk;              // scratch: grid control blocks
+    AdmmCtl *ctl;                  // the handle's control block: state in, state out
+    AdmmRecord *rec;               // host-visible record of iteration index0 (then consecutive)
+    int index0, max_iter;          // index of the first iteration of this launch in the run; how many
+    unsigned *bar;                 // kPersistBarWords words, zero before the launch: [1] barrier
+                                   // generation, [2] gave-up flag (a wait that did not complete:
+                                   // results void), [3] iterations executed, [8..15] phase times of
+                                   // measurement builds, [16..] arrival counters
+    int n_row_tiles, n_col_tiles;  // rows of the two partial-sum buffers (8 and 1 doubles each)
+    int want_dfid, want_sums;      // the data-fidelity sum; any sums at all (FastSolve: none)
+    double dfid_scale;             // 1 / (H W)
+};
+constexpr int kPersistBarWords = 160;
+template <typename T> bool admm_persist_supported(int H, int W, int K);
+// workgroups of the launch (a multiple of 8, at most one per CU)
+template <typename T> int admm_persist_grid(int H, int W, int K, int CN);
+template <typename T> void launch_admm_persist(hipStream_t st, const AdmmPersistArgs<T> &a, int grid);
 
 }  // namespace sporco_amd

@@ -25,6 +25,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include "csc_ctl_dev.h"
+#include "csc_fused_body.h"
 #include "regfft.h"
 
 namespace sporco_amd {
@@ -95,7 +97,9 @@ template <int MODE> __device__ __forceinline__ float soft1_m(float v, float thr)
 // Spatial side -> spectral side: v[n1] = z(x = NW n1 + w) (destroyed) is transformed
 // along W, untangled into the spectra of the two packed real lines, and the bins
 // f <= W/2 are stored tile-major at t[f][cn][h][k..k+1].
-template <int NW>
+// COH (here and below): the spectrum changes hands between workgroups of the same launch
+// (admm_persist_kernel) -- agent-scope accesses instead of the streaming ones.
+template <int NW, bool COH = false>
 __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA, cf *t, int CN, int H,
                                                     int K, int cn, int k, int h, bool pv, int w,
                                                     int lane, f2 *L, int &token) {
@@ -153,7 +157,8 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
         ab.b = mk<float>(0.5f * (zf.im + zp.im), 0.5f * (zp.re - zf.re));
         if (pv) {
             const float q[4] = {ab.a.re, ab.a.im, ab.b.re, ab.b.im};
-            sa_stream_store4(reinterpret_cast<float *>(Tl + (int64_t)f * tline), q);
+            if constexpr (COH) sa_coh_store4(reinterpret_cast<float *>(Tl + (int64_t)f * tline), q);
+            else sa_stream_store4(reinterpret_cast<float *>(Tl + (int64_t)f * tline), q);
         }
     };
 #pragma unroll
@@ -190,7 +195,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 // Spectral side -> spatial side: the bins f <= W/2 of t[f][cn][h][k..k+1] are loaded,
 // the packed spectrum Z is rebuilt, and v[n1] receives the unnormalised inverse
 // transform at x = NW n1 + w: (re, im) = (filter k, filter k+1).
-template <int NW>
+template <int NW, bool COH = false>
 __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW, const cf *t, int CN,
                                                     int H, int K, int cn, int k, int h, bool pv, int w,
                                                     int lane, f2 *L, int &token) {
@@ -208,7 +213,8 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
         ab.b = zero;
         if (pv) {
             float q[4];
-            sa_stream_load4(reinterpret_cast<const float *>(Tl + (int64_t)f * tline), q);
+            if constexpr (COH) sa_coh_load4(reinterpret_cast<const float *>(Tl + (int64_t)f * tline), q);
+            else sa_stream_load4(reinterpret_cast<const float *>(Tl + (int64_t)f * tline), q);
             ab.a = mk<float>(q[0], q[1]);
             ab.b = mk<float>(q[2], q[3]);
         }
@@ -298,7 +304,7 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // -- one image, 32 filters, all C <= 4 channels, lane = (channel, filter pair).
 // MODE (with VFORM, as rows_inv_post): 1 = L1Weight array (+ NoBndryCross, AddMaskSim), 2 =
 // NoBndryCross and / or AddMaskSim without a weight array -- the derivation of Y repeats them.
-template <int NW, bool BCAST, bool VFORM, bool JOINT, int MODE, typename AP>
+template <int NW, bool BCAST, bool VFORM, bool JOINT, int MODE, bool COH = false, typename AP>
 __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     constexpr int N1 = kN1, W = N1 * NW;
     constexpr bool GENERAL = MODE != 0;
@@ -433,7 +439,7 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
         }
         reg_fence<N1 / 2>(v, half * (N1 / 2), token);
     }
-    spatial_to_spectral<NW>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
+    spatial_to_spectral<NW, COH>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
                             token);
 }
 
@@ -473,7 +479,7 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // MODE: 0 = plain epilogue; 1 = L1Weight array (+ NoBndryCross, AddMaskSim); 2 = NoBndryCross
 // and / or AddMaskSim without a weight array (no weight loads).
 // SF (state form, csc_rows.h): 0 = (Y, U) in and out; 1 = (Y, U) in, V' out; 2 = V in, V' out.
-template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT, int SF, typename AP>
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT, int SF, bool COH = false, typename AP>
 __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tiles_x) {
     constexpr bool GENERAL = MODE != 0;
     constexpr bool VIN = SF == 2, VOUT = SF != 0;
@@ -513,7 +519,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     int token = 0;
 
     cf v[N1];
-    spectral_to_spatial<NW>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L, token);
+    spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L, token);
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a->P;
@@ -712,7 +718,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
         // iteration's rows_fwd would compute from these very values, stored over the
         // units this thread consumed (same spectral-side ownership: in place is safe).
         reg_fence<N1>(v, 0, token);
-        spatial_to_spectral<NW>(v, a->twA, a->t_next, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane,
+        spatial_to_spectral<NW, COH>(v, a->twA, a->t_next, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane,
                                 L, token);
         __syncthreads();   // the reduction scratch below sits next to the exchange buffer
     }
@@ -722,7 +728,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     double acc[8] = {(double)s_r2, (double)s_s2, (double)s_x2,   (double)s_y2,
                      (double)s_u2, (double)s_l1, (double)s_l21, 0.0};
     const int64_t tile = (int64_t)h * tiles_x + bx;
-    block_sum_store<8>(acc, scratch, a->partials + tile * 8);
+    block_sum_store<8, COH>(acc, scratch, a->partials + tile * 8);
 }
 
 template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false, int SF = 0>
@@ -820,6 +826,174 @@ __global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsPr
     });
 }
 
+
+// ---------------------------------------------------------------------------
+// admm_persist: a run of iterations in one launch (csc_rows.h)
+// ---------------------------------------------------------------------------
+constexpr int kBarGroup0 = 16, kBarStride = 16;   // group counters: bar[16 + 16 g], g = 0..7; the top one at g = 8
+// Barrier across the grid.  What changes hands between workgroups -- the tile-major spectrum
+// and the tile sums -- is written and read with agent-scope accesses (COH above: written
+// through, read past the non-coherent cache levels), so no cache is written back or dropped
+// here (an agent-scope release / acquire pair per workgroup does that to the whole L2 and
+// costs more than the passes themselves): every wave waits for its stores to be acknowledged,
+// one thread per workgroup arrives on a counter and waits for the generation to change.
+// Everything else an iteration touches is private to a workgroup (its tiles of V -- the same
+// tiles in every pass --, its control block, its argument copies).  The grid is never
+// larger than the device holds at once, so whoever waits, waits for a resident workgroup; a
+// wait that does not complete (2^22 polls) raises bar[2] and later barriers do not wait.
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned nblk) {
+    sa_wait_stores();
+    __syncthreads();
+    if (threadIdx.x == 0 && sa_load_agent(bar + 2) == 0u) {
+        // two levels (256 arrivals on one word are served one after the other, a few
+        // microseconds in all): eight groups of nblk / 8 workgroups, then the eight groups; the
+        // counters only ever count up (the last of a group is the one that completes a multiple
+        // of the group size), so nothing is reset and nothing can be reset late
+        const unsigned gen = sa_load_agent(bar + 1);
+        const unsigned g = blockIdx.x & 7u, per = nblk >> 3;
+        bool last = false;
+        if ((sa_atomic_inc_agent(bar + kBarGroup0 + kBarStride * g) + 1u) % per == 0u)
+            last = (sa_atomic_inc_agent(bar + kBarGroup0 + kBarStride * 8) + 1u) % 8u == 0u;
+        if (last) {
+            sa_store_agent(bar + 1, gen + 1);
+        } else {
+            int polls = 0;
+            while (sa_load_agent(bar + 1) == gen) {
+                sa_spin_pause();
+                if (++polls > (1 << 22)) {
+                    sa_store_agent(bar + 2, 1u);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The sums of one iteration from the tile partials, each in the association of finalize_kernel
+// (csc_kernels.hip: 256 strided sums, then a fixed tree), all values side by side.
+// scratch: 7 * kFinalizeThreads doubles; sums: the 16 output slots.
+__device__ __forceinline__ void persist_finalize(const double *prow, int nrow, const double *pcol, int ncol,
+                                                 bool dfid, double dfid_scale, double *scratch, double *sums) {
+    constexpr int FT = kFinalizeThreads;
+    const int nv = 6 + (dfid ? 1 : 0);
+    const int tid = threadIdx.x, nth = blockDim.x;
+    if (tid < 16) sums[tid] = 0.0;
+    for (int idx = tid; idx < nv * FT; idx += nth) {
+        const int v = idx / FT, t = idx % FT;
+        const double *p = v < 6 ? prow + v : pcol;
+        const int n = v < 6 ? nrow : ncol, st = v < 6 ? 8 : 1;
+        double s = 0.0;
+        for (int b = t; b < n; b += FT) s = s + sa_load_agent(p + (int64_t)b * st);
+        scratch[idx] = s;
+    }
+    __syncthreads();
+    for (int w = FT / 2; w > 0; w >>= 1) {
+        for (int idx = tid; idx < nv * w; idx += nth) {
+            const int v = idx / w, t = idx % w;
+            scratch[v * FT + t] = scratch[v * FT + t] + scratch[v * FT + t + w];
+        }
+        __syncthreads();
+    }
+    if (tid < nv) {
+        const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2, SPORCO_AMD_OUT_Y2,
+                              SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1, SPORCO_AMD_OUT_DFID};
+        sums[slots[tid]] = scratch[tid * FT] * (tid == 6 ? dfid_scale : 1.0);
+    }
+    __syncthreads();
+}
+
+template <int NW, int LP>
+__global__ void __launch_bounds__(NW * 64) admm_persist_kernel(const AdmmPersistArgs<float> pa) {
+    const int tid = threadIdx.x;
+    const unsigned nblk = gridDim.x;
+    AdmmCtl *c = pa.ctl_blk + blockIdx.x;
+    // between the passes the exchange buffer holds the reduction scratch and the sums
+    double *scratch = dyn_lds<double>();
+    double *sums = scratch + 7 * kFinalizeThreads;
+    // this workgroup's copies of the arguments (one per parity) and of the control block
+    if (tid == 0) {
+        *c = *pa.ctl;
+        for (int par = 0; par < 2; ++par) {
+            PersistIterArgs<float> *b = pa.blk + (size_t)par * nblk + blockIdx.x;
+            *b = pa.iter[par];
+            b->fwd.ctl = c;
+            b->cols.ctl = c;
+            b->post.ctl = c;
+        }
+    }
+    sa_wait_stores();
+    sa_scalar_cache_inv();
+    __syncthreads();
+    const int tiles_x = (int)((pa.iter[0].fwd.P + 127) / 128), H = pa.iter[0].fwd.H;
+    const int64_t ntiles = (int64_t)tiles_x * H;
+#ifdef SA_PERSIST_TIMING
+    // (measurement builds only: where workgroup 0 spends its time, in ticks of the 100 MHz clock,
+    // summed over the iterations into bar[8 ..])
+    unsigned long long tl = sa_wall_clock(), tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SA_PT(i)                                   \
+    {                                              \
+        const unsigned long long t_ = sa_wall_clock(); \
+        tacc[i] += t_ - tl;                        \
+        tl = t_;                                   \
+    }
+#else
+#define SA_PT(i)
+#endif
+    int it = 0;
+    for (; it < pa.max_iter; ++it) {
+        if (c->stop) break;
+        const int par = (pa.index0 + it) & 1;
+        SA_ARGS_PTR_T(PersistIterArgs<float>) pb = sa_opaque_sptr(
+            (SA_ARGS_PTR_T(PersistIterArgs<float>))(pa.blk + (size_t)par * nblk + blockIdx.x));
+        if (!c->skip_fwd) {     // rho moved: the emitted spectrum of Y - U is void
+            for (int64_t t = blockIdx.x; t < ntiles; t += nblk) {
+                rows_fwd_tile<NW, false, true, false, 0, true>(&pb->fwd, (int)(t % tiles_x), (int)(t / tiles_x));
+                __syncthreads();
+            }
+            SA_PT(0)
+            grid_barrier(pa.bar, nblk);
+            SA_PT(1)
+        }
+        fused_cols_body<32, NW, LP, 0, false, false, false, 0, true, -1>(pa.iter[0].cols, &pb->cols);
+        SA_PT(2)
+        grid_barrier(pa.bar, nblk);
+        SA_PT(3)
+        for (int64_t t = blockIdx.x; t < ntiles; t += nblk) {
+            rows_inv_post_tile<NW, false, 0, true, false, 2, true>(&pb->post, (int)(t % tiles_x), (int)(t / tiles_x),
+                                                               tiles_x);
+            __syncthreads();
+        }
+        SA_PT(4)
+        grid_barrier(pa.bar, nblk);
+        SA_PT(5)
+        if (pa.want_sums) {
+            persist_finalize(pb->post.partials, pa.n_row_tiles, pb->cols.partials, pa.n_col_tiles,
+                             pa.want_dfid != 0, pa.dfid_scale, scratch, sums);
+        } else {
+            if (tid < 16) sums[tid] = 0.0;
+            __syncthreads();
+        }
+        SA_PT(6)
+        // (the host-visible record -- two system-scope fences -- is written by the LAST workgroup:
+        // it has no tile in the column pass that follows, so nobody waits for it)
+        if (tid == 0)
+            admm_ctl_update_dev<float>(c, sums, blockIdx.x == nblk - 1 ? pa.rec + it : nullptr, pa.index0 + it);
+        sa_wait_stores();
+        sa_scalar_cache_inv();
+        __syncthreads();
+        SA_PT(7)
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        *pa.ctl = *c;
+        pa.bar[3] = (unsigned)it;
+#ifdef SA_PERSIST_TIMING
+        for (int i = 0; i < 8; ++i) pa.bar[8 + i] = (unsigned)tacc[i];
+#endif
+    }
+#undef SA_PT
+}
+
 template <int NW, typename K>
 void set_lds_attr(K kernel) {
     SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -882,6 +1056,67 @@ static dim3 rows_grid(A &a, int NW, int64_t tiles_x, int64_t tiles_y, int want) 
     a.stagger_groups = sg > 0 ? sg : 1;
     a.stagger_sleeps = ss;
     return dim3((unsigned)(a.persist ? g : n), 1);
+}
+
+// ---- the one-launch solve ---------------------------------------------------------------------
+template <> bool admm_persist_supported<float>(int H, int W, int K) {
+    return H == W && (W == 128 || W == 256) && K >= 2 && K % 2 == 0 && K <= 64;
+}
+template <> bool admm_persist_supported<double>(int, int, int) { return false; }
+
+static int persist_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        SA_HIP(hipGetDevice(&dev));
+        SA_HIP(hipGetDeviceProperties(&pr, dev));
+        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return cus;
+}
+template <> int admm_persist_grid<float>(int H, int W, int K, int CN) {
+    (void)W;
+    // one workgroup per CU at most, a multiple of 8 (the column pass gives workgroup b the row
+    // frequencies = b mod 8), and no more than the larger pass has tiles
+#ifdef SPORCO_AMD_HOSTSIM
+    int g = 8;      // (the CPU test simulator runs the whole grid side by side: hostsim::set_coop)
+#else
+    int g = persist_cus() & ~7;
+#endif
+    const int64_t row_tiles = (int64_t)H * (((int64_t)CN * K + 127) / 128);
+    const int64_t col_tiles = (int64_t)(W / 2 + 1) * CN;
+    const int64_t most = std::max(row_tiles, (col_tiles + 7) / 8 * 8);
+    if (g > most) g = (int)((most + 7) / 8 * 8);
+    return g < 8 ? 8 : g;
+}
+template <> int admm_persist_grid<double>(int, int, int, int) { return 0; }
+
+template <int NW, int LP>
+static void launch_persist_inst(hipStream_t st, const AdmmPersistArgs<float> &a, int grid) {
+    const size_t lds = std::max<size_t>(std::max(rows_lds_bytes(NW), fused_lds_bytes(NW, LP)),
+                                        sizeof(double) * (7 * kFinalizeThreads + 16));
+    static bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&admm_persist_kernel<NW, LP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+#ifdef SPORCO_AMD_HOSTSIM
+    hostsim::set_coop(grid);
+#endif
+    hipLaunchKernelGGL((admm_persist_kernel<NW, LP>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
+    SA_HIP(hipGetLastError());
+}
+template <> void launch_admm_persist<float>(hipStream_t st, const AdmmPersistArgs<float> &a, int grid) {
+    const RowsFwdArgs<float> &f = a.iter[0].fwd;
+    SA_REQUIRE(admm_persist_supported<float>(f.H, f.W, f.K), "shape not handled by the one-launch solve");
+    SA_REQUIRE(grid >= 8 && grid % 8 == 0 && grid <= std::max(8, persist_cus()), "grid of the one-launch solve");
+    if (f.W == 128) launch_persist_inst<4, 4>(st, a, grid);
+    else launch_persist_inst<8, 2>(st, a, grid);
+}
+template <> void launch_admm_persist<double>(hipStream_t, const AdmmPersistArgs<double> &, int) {
+    throw Error(-1, "the one-launch solve is float32 only");
 }
 
 template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float> &a_in) {

@@ -173,7 +173,53 @@ __device__ __forceinline__ void sa_load_agent2(const float *p, float &a, float &
     a = __builtin_bit_cast(float, (unsigned)(t & 0xffffffffull));
     b = __builtin_bit_cast(float, (unsigned)(t >> 32));
 }
+__device__ __forceinline__ void sa_store_agent(double *p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double sa_load_agent(const double *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and whole arrays that change hands between the workgroups of one launch
+// (admm_persist_kernel: the tile-major spectra): the same agent-scope accesses, 8 bytes at a
+// time through plain pointers, or with the sc1 bit through a buffer descriptor.
+__device__ __forceinline__ void sa_coh_load4(const float *p, float (&v)[4]) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[0] = __builtin_bit_cast(float, (unsigned)(a & 0xffffffffull));
+    v[1] = __builtin_bit_cast(float, (unsigned)(a >> 32));
+    v[2] = __builtin_bit_cast(float, (unsigned)(b & 0xffffffffull));
+    v[3] = __builtin_bit_cast(float, (unsigned)(b >> 32));
+}
+__device__ __forceinline__ void sa_coh_store4(float *p, const float (&v)[4]) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    const unsigned long long a = (unsigned long long)__builtin_bit_cast(unsigned, v[0]) |
+                                 ((unsigned long long)__builtin_bit_cast(unsigned, v[1]) << 32);
+    const unsigned long long b = (unsigned long long)__builtin_bit_cast(unsigned, v[2]) |
+                                 ((unsigned long long)__builtin_bit_cast(unsigned, v[3]) << 32);
+    __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int kSaAuxAgent = 16;   // sc1: agent-scope coherence of a raw buffer access (gfx940+)
+__device__ __forceinline__ void sa_buf_load2_coh(SaBuf r, int voff, int soff, float &a, float &b) {
+    sa_buf_load2_aux<kSaAuxAgent>(r, voff, soff, a, b);
+}
+__device__ __forceinline__ void sa_buf_store2_coh(SaBuf r, int voff, int soff, float a, float b) {
+    sa_floatx2 t;
+    t.x = a;
+    t.y = b;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sa_b64, t), r, voff, soff, kSaAuxAgent);
+}
 __device__ __forceinline__ void sa_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Barrier across ALL workgroups of one launch (admm_persist_kernel): whole arrays change hands,
+// so here the fences are the real ones -- release writes this XCD's L2 back, acquire drops what
+// the caches hold of other XCDs' data; the scalar data cache is not covered by either.
+__device__ __forceinline__ unsigned sa_atomic_inc_agent(unsigned *p) {
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sa_fence_release_agent() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+__device__ __forceinline__ void sa_fence_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+__device__ __forceinline__ void sa_scalar_cache_inv() { __builtin_amdgcn_s_dcache_inv(); }
 __device__ __forceinline__ void sa_spin_pause() { __builtin_amdgcn_s_sleep(8); }
 
 // A wave-uniform pointer made opaque to the optimiser (no instruction emitted): inside a
@@ -188,11 +234,13 @@ template <typename P> __device__ __forceinline__ P *sa_opaque_sptr(P *p) {
 // an opaque pointer: fields used late in a long tile loop are then loaded (s_load) where
 // they are used, every iteration, instead of living in scalar registers throughout.
 #define SA_ARGS_PTR_T(A) const A __attribute__((address_space(4))) *
-template <bool OPAQUE = true, typename A>
+// OFF: byte offset of that struct inside the kernel's argument block (a kernel whose argument
+// is a struct of several such structs: admm_persist_kernel).
+template <bool OPAQUE = true, int OFF = 0, typename A>
 __device__ __forceinline__ SA_ARGS_PTR_T(A) sa_args_reload(const A &) {
     auto p = __builtin_amdgcn_kernarg_segment_ptr();
     if constexpr (OPAQUE) asm volatile("" : "+s"(p));
-    return (SA_ARGS_PTR_T(A))p;
+    return (SA_ARGS_PTR_T(A))((const char __attribute__((address_space(4))) *)p + OFF);
 }
 
 }  // namespace sporco_amd

@@ -178,6 +178,17 @@ __device__ __forceinline__ cf buf_load_cf_cached(BufRsrc r, int voff, int soff) 
 __device__ __forceinline__ void buf_store_cf(BufRsrc r, int voff, int soff, cf x) {
     sa_buf_store2(r, voff, soff, x.re, x.im);
 }
+// COH: data that other workgroups of the SAME launch wrote / will read (gfx950_intrin.h)
+template <bool COH> __device__ __forceinline__ cf buf_load_cf_x(BufRsrc r, int voff, int soff) {
+    cf x;
+    if constexpr (COH) sa_buf_load2_coh(r, voff, soff, x.re, x.im);
+    else sa_buf_load2(r, voff, soff, x.re, x.im);
+    return x;
+}
+template <bool COH> __device__ __forceinline__ void buf_store_cf_x(BufRsrc r, int voff, int soff, cf x) {
+    if constexpr (COH) sa_buf_store2_coh(r, voff, soff, x.re, x.im);
+    else sa_buf_store2(r, voff, soff, x.re, x.im);
+}
 
 // Register fence: every element passes through an (empty) volatile asm, and a
 // token chained through all of them and back makes everything after the fence

@@ -127,7 +127,15 @@ inline void sa_load_agent2(const float *p, float &a, float &b) {
     a = p[0];
     b = p[1];
 }
+inline void sa_buf_load2_coh(SaBuf r, int voff, int soff, float &a, float &b) { sa_buf_load2(r, voff, soff, a, b); }
+inline void sa_buf_store2_coh(SaBuf r, int voff, int soff, float a, float b) { sa_buf_store2(r, voff, soff, a, b); }
+inline void sa_coh_load4(const float *p, float (&v)[4]) { for (int i = 0; i < 4; ++i) v[i] = p[i]; }
+inline void sa_coh_store4(float *p, const float (&v)[4]) { for (int i = 0; i < 4; ++i) p[i] = v[i]; }
 inline void sa_wait_stores() {}
+inline unsigned sa_atomic_inc_agent(unsigned *p) { return (*p)++; }
+inline void sa_fence_release_agent() {}
+inline void sa_fence_acquire_agent() {}
+inline void sa_scalar_cache_inv() {}
 inline void sa_spin_pause() { hostsim::spin_pause(); }
 inline float sa_fma(float a, float b, float c) { return std::fma(a, b, c); }
 inline float sa_med3(float a, float b, float c) {
@@ -150,6 +158,6 @@ inline void sa_fence_system() {}
 template <typename P> inline P *sa_opaque_sptr(P *p) { return p; }
 inline void __builtin_amdgcn_s_sleep(int) {}
 #define SA_ARGS_PTR_T(A) const A *
-template <bool OPAQUE = true, typename A> inline const A *sa_args_reload(const A &a) { return &a; }
+template <bool OPAQUE = true, int OFF = 0, typename A> inline const A *sa_args_reload(const A &a) { return &a; }
 
 }  // namespace sporco_amd

@@ -13,7 +13,7 @@
 dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace {
-constexpr int kMaxCoop = 4;               // workgroups that may run side by side (set_coop)
+constexpr int kMaxCoop = 8;               // workgroups that may run side by side (set_coop)
 constexpr size_t kLdsBytes = 160 * 1024;
 alignas(16) unsigned char lds_store[kMaxCoop][kLdsBytes];
 }  // namespace
