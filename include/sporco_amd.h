@@ -40,6 +40,7 @@
  *   SPORCO_AMD_PERSIST=1|0      small problems: a run of iterations as ONE launch (off unless the
  *                               handle has SPORCO_AMD_HINT_ONE_LAUNCH; see there);
  *                               SPORCO_AMD_PERSIST_TIMING=1 prints the phase times of measurement builds
+ *   SPORCO_AMD_C2R_POST=1       generic chain: the ADMM epilogue inside the last row pass of irfftn
  *   SPORCO_AMD_RUN_LAG=n        (tests) admm_run pretends not to have seen its newest n records
  *   SPORCO_AMD_COLS_PERSIST=0, SPORCO_AMD_COLS_STAGGER_GROUPS=g, SPORCO_AMD_COLS_STAGGER_SLEEPS=s
  *                               launch form of the column kernel

@@ -516,7 +516,8 @@ template <typename T> struct Csc : CscBase {
         (void)hipStreamSynchronize(st);
         for (auto &v : vars)
             if (v) (void)hipFree(v);
-        for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar})
+        for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar,
+                        (void *)part_c2r})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)ccmod_r, (void *)pgm_ey, (void *)gpart,
@@ -624,11 +625,24 @@ template <typename T> struct Csc : CscBase {
                        (int64_t)Wf * cols, T(1));
         }
     }
+    // The generic ADMM iteration can fuse its epilogue into the half-spectrum -> real row pass
+    // (fft.h fft_c2r_post): the x step then stops after the column pass (c2r_deferred), and
+    // admm_iter runs the rest.  Opt-in (SPORCO_AMD_C2R_POST=1): measured, it saves the write and
+    // re-read of X but moves Y, U, X in the row pass's 128-byte segments instead of the epilogue
+    // kernel's long runs, and the two cancel (profiles/r03q_generic_chain.md: 392 against 387
+    // it/s at 512 x 512, K = 64, N = 8; +3 % in float64 at 256 x 256).
+    bool defer_c2r = false, c2r_deferred = false;
+    double *part_c2r = nullptr;
+    int64_t part_c2r_cap = 0;
     void inv2(const cx<T> *in, cx<T> *tmp, T *out, int64_t cols) {
         {
             ProfScope ps(prof, PS_FFT_C2C_INV);
             fft_c2c<T>(st, planH, true, in, tmp, 1, (int64_t)Wf * cols, 0, (int64_t)Wf * cols, 0,
                        (int64_t)Wf * cols, T(1));
+        }
+        if (defer_c2r && cols == P && out == rv(SPORCO_AMD_VAR_X)) {
+            c2r_deferred = true;
+            return;
         }
         {
             ProfScope ps(prof, PS_FFT_C2R);
@@ -2031,7 +2045,14 @@ template <typename T> struct Csc : CscBase {
             return;
         }
         before_state_change();
+        // (LinSolveCheck evaluates its residual from X: that combination keeps the two kernels)
+        {
+            const char *e = std::getenv("SPORCO_AMD_C2R_POST");
+            defer_c2r = e && e[0] == '1' && !(p.flags & (F_JOINT | F_XRRS));
+        }
+        c2r_deferred = false;
         xstep_impl(p, out_dev);
+        defer_c2r = false;
         PostParams<T> pp;
         pp.x = rv(SPORCO_AMD_VAR_X);
         pp.y = rv(SPORCO_AMD_VAR_Y);
@@ -2049,16 +2070,46 @@ template <typename T> struct Csc : CscBase {
         pp.ams = ams_of(p);
         pp.ams_k = ams_k0();
         pp.ams_n = ams_n();
-        int nb;
-        {
-            ProfScope ps(prof, PS_ADMM_POST);
-            nb = launch_admm_post<T>(st, pp, part_b);
-        }
         const int slots[7] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_AX2,
                               SPORCO_AMD_OUT_Y2, SPORCO_AMD_OUT_U2, SPORCO_AMD_OUT_L1,
                               SPORCO_AMD_OUT_L21};
         const double scales[7] = {1, 1, 1, 1, 1, 1, 1};
-        finalize(part_b, nb, 8, 7, slots, scales, out_dev);
+        if (c2r_deferred) {
+            // row pass of irfftn + epilogue in one kernel: X is neither written (unless the
+            // caller may read it: everything but FLAG_NO_X) nor re-read
+            c2r_deferred = false;
+            const int64_t nblk = fft_c2r_post_blocks<T>(planW, H, P);
+            if (nblk > part_c2r_cap) {
+                if (part_c2r) {
+                    sync();
+                    SA_HIP(hipFree(part_c2r));
+                }
+                SA_HIP(hipMalloc((void **)&part_c2r, sizeof(double) * 8 * nblk));
+                part_c2r_cap = nblk;
+            }
+            T *xo = (p.flags & F_NO_X) ? nullptr : rv(SPORCO_AMD_VAR_X);
+            int64_t nbp;
+            {
+                ProfScope ps(prof, PS_FFT_C2R);
+                nbp = fft_c2r_post<T>(st, planW, work_buf(), H, P, (int64_t)Wf * P, P,
+                                      T(1.0 / ((double)H * (double)W)), pp, xo, part_c2r);
+            }
+            finalize(part_c2r, (int)nbp, 8, 7, slots, scales, out_dev);
+            if (p.flags & F_NO_X) {
+                x_stale = true;     // (X of this iteration does not exist: reading it is an error)
+                x_invalid = true;
+            } else {
+                x_written();
+            }
+        } else {
+            x_written();
+            int nb;
+            {
+                ProfScope ps(prof, PS_ADMM_POST);
+                nb = launch_admm_post<T>(st, pp, part_b);
+            }
+            finalize(part_b, nb, 8, 7, slots, scales, out_dev);
+        }
         if ((p.flags & F_OBJ) && (p.flags & F_FEVAL_Y)) dfid_at(rv(SPORCO_AMD_VAR_Y), out_dev, &p);
     }
 

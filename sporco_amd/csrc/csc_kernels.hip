@@ -9,6 +9,7 @@
 
 #include <gfx950_intrin.h>
 #include "csc_ctl_dev.h"
+#include "csc_post_elem.h"
 
 #include "../../include/sporco_amd.h"
 
@@ -31,27 +32,6 @@ static inline int grid_for(int64_t work_items, int threads = kThreads) {
     return (int)g;
 }
 
-template <typename T>
-__device__ __forceinline__ T weight_at(const Weight<T> &w, int h, int x, int c, int n, int k) {
-    return w.ptr[h * w.stride[0] + x * w.stride[1] + c * w.stride[2] + n * w.stride[3] +
-                 k * w.stride[4]];
-}
-
-template <typename T> __device__ __forceinline__ T soft(T v, T thr) {
-    // sign(v) * max(|v| - thr, 0)            (prox/_lp.py:181)
-    T m = (v < T(0) ? -v : v) - thr;
-    m = m > T(0) ? m : T(0);
-    return v < T(0) ? -m : m;
-}
-
-// True when (h, x) lies in the band zeroed by NoBndryCross: Y[1-dH:, ...] = 0,
-// Y[:, 1-dW:, ...] = 0  (cbpdn.py:308-311; a size-1 filter gives slice(0, None),
-// i.e. the whole axis, which is mirrored here).
-__device__ __forceinline__ bool in_bndry(int h, int x, int H, int W, int dH, int dW) {
-    const int h0 = (dH > 1) ? H - (dH - 1) : 0;
-    const int x0 = (dW > 1) ? W - (dW - 1) : 0;
-    return h >= h0 || x >= x0;
-}
 
 // ---------------------------------------------------------------------------
 // dictionary set-up
@@ -127,11 +107,6 @@ __device__ __forceinline__ T grad_gh(const GradTerm<T> &g, int64_t pix, int Wf) 
 }
 template <typename T> __device__ __forceinline__ T grad_w(const GradTerm<T> &g, int k) {
     return g.wg ? g.wg[k] : T(1);
-}
-// filter k is one of the ams_n impulse filters AddMaskSim appended at ams_k (one, or one per
-// channel of a multi-channel dictionary: cbpdn.py:2339-2346); ams_k < 0: there are none
-__device__ __forceinline__ bool is_ams(int k, int ams_k, int ams_n) {
-    return ams_k >= 0 && k >= ams_k && k < ams_k + ams_n;
 }
 
 // Fast path: K even and G = K/2 a power of two <= 64.  Each lane owns two
@@ -441,8 +416,6 @@ template <typename T, int VEC, bool GENERAL>
 __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T> p, int64_t nvec,
                                                              double *partials) {
     double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const T a = p.rlx, oma = T(1) - p.rlx;
-    const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY, gy = p.flags & F_GEVAL_Y;
     const int64_t P = (int64_t)p.d.C * p.d.N * p.d.K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -450,43 +423,8 @@ __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T>
         Vec<T, VEC> yv = reinterpret_cast<const Vec<T, VEC> *>(p.y)[i];
         Vec<T, VEC> uv = reinterpret_cast<const Vec<T, VEC> *>(p.u)[i];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            const T x = xv.v[e], yo = yv.v[e], uo = p.u_scale * uv.v[e];
-            const T ax = a * x + oma * yo;
-            T w = T(1);
-            bool kill = false, ams = false;
-            if (GENERAL) {
-                const int64_t idx = i * VEC + e;
-                const int64_t pix = idx / P;
-                const int r = (int)(idx - pix * P);
-                const int k = r % p.d.K, n = (r / p.d.K) % p.d.N, c = r / (p.d.K * p.d.N);
-                const int xw = (int)(pix % p.d.W), h = (int)(pix / p.d.W);
-                if (p.wl1.ptr) w = weight_at(p.wl1, h, xw, c, n, k);
-                kill = nob && in_bndry(h, xw, p.d.H, p.d.W, p.dH, p.dW);
-                if (p.ams.ptr && is_ams(k, p.ams_k, p.ams_n)) {
-                    // AddMaskSim impulse slice (cbpdn.py:2378-2394): no shrinkage, no
-                    // NonNeg / NoBndryCross, zero where the mask is set; invisible to
-                    // the regulariser (:2398-2412)
-                    ams = true;
-                    w = T(0);
-                    kill = weight_at(p.ams, h, xw, c, n, k - p.ams_k) != T(0);
-                }
-            }
-            T yn = soft(ax + uo, p.thr * w);
-            if (nonneg && !ams && yn < T(0)) yn = T(0);
-            if (kill) yn = T(0);
-            const T un = uo + ax - yn;
-            yv.v[e] = yn;
-            uv.v[e] = un;
-            const double dr = (double)(x - yn), ds = (double)(yn - yo);
-            acc[0] += dr * dr;
-            acc[1] += ds * ds;
-            acc[2] += (double)x * (double)x;
-            acc[3] += (double)yn * (double)yn;
-            acc[4] += (double)un * (double)un;
-            const T gv = w * (gy ? yn : x);
-            acc[5] += (double)(gv < T(0) ? -gv : gv);
-        }
+        for (int e = 0; e < VEC; ++e)
+            admm_post_elem<T, GENERAL>(p, i * VEC + e, P, xv.v[e], yv.v[e], uv.v[e], acc);
         reinterpret_cast<Vec<T, VEC> *>(p.y)[i] = yv;
         reinterpret_cast<Vec<T, VEC> *>(p.u)[i] = uv;
     }

@@ -18,6 +18,8 @@
 // so every length that fits LDS is supported.
 #include "fft.h"
 
+#include "csc_post_elem.h"
+
 #include <cmath>
 #include <vector>
 
@@ -43,6 +45,13 @@ template <typename T> struct LineArgs {
     // lives at (p / grp) * grp_stride + p % grp instead of p.  This is how the row
     // transforms write / read the tile-major layout of csc_fused.h.
     int64_t grp, grp_stride;
+    // C2R with the ADMM epilogue fused into the store (fft_c2r_post): the transform's output is
+    // X of element (o, i, p) of an (n_outer, n, P) array; post.y / post.u are updated in place,
+    // X goes to x_out when that is set, every workgroup writes 8 partial sums.
+    PostParams<T> post;
+    T *x_out;
+    double *partials;
+    int64_t postP;
 };
 
 template <typename T> __device__ __forceinline__ int64_t col_off(const LineArgs<T> &a, int64_t p) {
@@ -158,7 +167,10 @@ __device__ __forceinline__ void direct_pass(const cx<T> *__restrict__ src, cx<T>
     }
 }
 
-template <typename T, int MODE, bool PACK>
+// POST (MODE_C2R only): 0 = plain store; 1 / 2 = the ADMM epilogue of csc_post_elem.h on every
+// output element (2: the variant that needs the element's 5-D index -- weight arrays,
+// NoBndryCross, AddMaskSim).
+template <typename T, int MODE, bool PACK, int POST = 0>
 __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
     const int n = a.n, cols = a.cols;
     cx<T> *buf0 = dyn_lds<cx<T>>();
@@ -263,6 +275,40 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
     }
 
     // ---------------- store ----------------
+    if constexpr (POST != 0) {
+        static_assert(MODE == MODE_C2R || POST == 0, "the epilogue belongs to the c2r pass");
+        constexpr bool GENERAL = POST == 2;
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (valid) {
+            const int64_t P = a.postP;
+            for (int i = lane; i < n; i += lpc) {
+                const cx<T> z = src[i * cols + col];
+                if (PACK) {
+                    const int64_t idx = (o * n + i) * P + 2 * c;
+                    const T x0 = z.re * a.scale, x1 = z.im * a.scale;
+                    cx<T> yv = *reinterpret_cast<const cx<T> *>(a.post.y + idx);
+                    cx<T> uv = *reinterpret_cast<const cx<T> *>(a.post.u + idx);
+                    admm_post_elem<T, GENERAL>(a.post, idx, P, x0, yv.re, uv.re, acc);
+                    admm_post_elem<T, GENERAL>(a.post, idx + 1, P, x1, yv.im, uv.im, acc);
+                    *reinterpret_cast<cx<T> *>(a.post.y + idx) = yv;
+                    *reinterpret_cast<cx<T> *>(a.post.u + idx) = uv;
+                    if (a.x_out) *reinterpret_cast<cx<T> *>(a.x_out + idx) = mk<T>(x0, x1);
+                } else {
+                    const int64_t idx = (o * n + i) * P + c;
+                    const T x0 = z.re * a.scale;
+                    T yv = a.post.y[idx], uv = a.post.u[idx];
+                    admm_post_elem<T, GENERAL>(a.post, idx, P, x0, yv, uv, acc);
+                    a.post.y[idx] = yv;
+                    a.post.u[idx] = uv;
+                    if (a.x_out) a.x_out[idx] = x0;
+                }
+            }
+        }
+        __syncthreads();      // the transform buffers become the reduction scratch
+        block_sum_store<8>(acc, reinterpret_cast<double *>(buf0),
+                           a.partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8);
+        return;
+    }
     if (!valid) return;
     if (MODE == MODE_C2C) {
         cx<T> *out = static_cast<cx<T> *>(a.out) + o * a.out_outer + c;
@@ -367,15 +413,15 @@ template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
     return c;
 }
 
-template <typename T, int MODE, bool PACK>
-void launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n_outer) {
+template <typename T, int MODE, bool PACK, int POST = 0>
+int64_t launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n_outer) {
     static bool attr_set = false;
     if (!attr_set) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK>),
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK, POST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         attr_set = true;
     }
-    if (a.ncols <= 0 || n_outer <= 0) return;
+    if (a.ncols <= 0 || n_outer <= 0) return 0;
     const Cfg cfg = pick_cfg<T>(plan.n, a.ncols);
     a.n = plan.n;
     a.nfreq = plan.n / 2 + 1;
@@ -385,8 +431,9 @@ void launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n
     a.tw = plan.tw<T>();
     SA_REQUIRE(n_outer <= 65535, "too many outer slices for one launch");
     const dim3 grid((unsigned)ceil_div(a.ncols, cfg.cols), (unsigned)n_outer, 1);
-    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK>), grid, dim3(cfg.threads), cfg.lds, st, a);
+    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK, POST>), grid, dim3(cfg.threads), cfg.lds, st, a);
     SA_HIP(hipGetLastError());
+    return (int64_t)grid.x * grid.y;
 }
 
 }  // namespace
@@ -480,6 +527,42 @@ void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64
 }
 
 template <typename T>
+int64_t fft_c2r_post_blocks(const FftPlan &plan, int64_t n_outer, int64_t P) {
+    const bool pack = P % 2 == 0;
+    const int64_t ncols = pack ? P / 2 : P;
+    return ceil_div(ncols, pick_cfg<T>(plan.n, ncols).cols) * n_outer;
+}
+
+template <typename T>
+int64_t fft_c2r_post(hipStream_t st, const FftPlan &plan, const cx<T> *in, int64_t n_outer, int64_t P,
+                     int64_t in_outer, int64_t in_line, T scale, const PostParams<T> &post, T *x_out,
+                     double *partials) {
+    SA_REQUIRE(!(post.flags & F_JOINT), "the fused epilogue has no l2,1 term");
+    LineArgs<T> a{};
+    a.in = in;
+    a.in2 = nullptr;
+    a.out = nullptr;
+    a.s2 = T(0);
+    a.scale = scale;
+    a.inverse = 1;
+    a.in_outer = in_outer;
+    a.in_line = in_line;
+    a.post = post;
+    a.x_out = x_out;
+    a.partials = partials;
+    a.postP = P;
+    const bool general = post.wl1.ptr != nullptr || (post.flags & F_NOBNDRY) || post.ams.ptr;
+    const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0);
+    SA_REQUIRE(pack == (P % 2 == 0), "unexpected strides of the half spectrum");
+    a.ncols = pack ? P / 2 : P;
+    if (pack)
+        return general ? launch_lines<T, MODE_C2R, true, 2>(st, plan, a, n_outer)
+                       : launch_lines<T, MODE_C2R, true, 1>(st, plan, a, n_outer);
+    return general ? launch_lines<T, MODE_C2R, false, 2>(st, plan, a, n_outer)
+                   : launch_lines<T, MODE_C2R, false, 1>(st, plan, a, n_outer);
+}
+
+template <typename T>
 void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
            T s2, cx<T> *out, int H, int W, int64_t P) {
     const int64_t Wf = W / 2 + 1;
@@ -505,6 +588,9 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
                              int64_t, int64_t);                                                  \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
                              int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
+    template int64_t fft_c2r_post_blocks<T>(const FftPlan &, int64_t, int64_t);                  \
+    template int64_t fft_c2r_post<T>(hipStream_t, const FftPlan &, const cx<T> *, int64_t, int64_t, \
+                                     int64_t, int64_t, T, const PostParams<T> &, T *, double *); \
     template void rfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const T *, const T *,  \
                            T, cx<T> *, int, int, int64_t);                                       \
     template void irfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const cx<T> *,        \
