@@ -619,6 +619,39 @@ def gen_ccmod_eq():
                  X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_ccmod_ism_many():
+    """ConvCnstrMOD_IterSM over MORE than 8 images (and images x channels): the reference takes
+    any number (sporco/admm/ccmod.py:433-604, linalg.solvemdbi_ism over axisK); also inside the
+    masked dictionary update ConvCnstrMODMaskDcpl_IterSM (ccmodmd.py:573-654)."""
+    np.random.seed(97531)
+    N, M, Nd = 12, 3, 4
+    for K, C, tag in ((11, 1, 'k11'), (5, 2, 'k5c2')):
+        shpS = (N, N, K) if C == 1 else (N, N, C, K)
+        S = np.random.randn(*shpS)
+        Z = np.random.randn(N, N, C, K, M) * (np.random.rand(N, N, C, K, M) > 0.6)
+        for name, optd in (('f64', {'MaxMainIter': 10}),
+                           ('f32', {'MaxMainIter': 10, 'DataType': np.float32})):
+            if C > 1 and name == 'f32':
+                continue
+            opt = ref_admm_ccmod.ConvCnstrMOD_IterSM.Options(optd)
+            c = ref_admm_ccmod.ConvCnstrMOD_IterSM(Z, S, (Nd, Nd, M), opt)
+            c.solve()
+            save('ccmod_ism_%s_%s' % (tag, name), Z=Z, S=S, dsz=np.array((Nd, Nd, M)),
+                 D=c.getdict(), Y=c.Y, X=c.X, U=c.U, rho_final=np.float64(c.rho),
+                 k_final=np.int64(c.k), **itstat_dict(c))
+    # masked
+    K = 10
+    S = np.random.randn(N, N, K)
+    W = (np.random.rand(N, N, K) > 0.3).astype(np.float64)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.6)
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    opt = ref_ccmodmd.ConvCnstrMODMaskDcpl_IterSM.Options({'MaxMainIter': 10})
+    c = ref_ccmodmd.ConvCnstrMODMaskDcpl_IterSM(Z, S, W, (Nd, Nd, M), opt)
+    c.solve()
+    save('ccmodmd_ism_k10_f64', Z=Z, S=S, W=W, dsz=np.array((Nd, Nd, M)), D=c.getdict(), Y=c.Y,
+         X=c.X, U=c.U, rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+
+
 def gen_online():
     """Online dictionary learning dictlrn.onlinecdl.OnlineConvBPDNDictLearn
     (sporco/dictlrn/onlinecdl.py:33-460): one solve() per training image.  SURVEY.md 8(f)
@@ -1002,8 +1035,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'ccmod_eq', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -330,11 +330,6 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
         self.Nb = self.cri.C * self.cri.K
-        if self._method == _lib.DSTEP_ISM and self.Nb > 8:
-            raise NotImplementedError(
-                "the iterated Sherman-Morrison D-step handles up to 8 images (times channels) on "
-                "the device, %d given; use 'cns' or 'cg' (the reference's own advice for larger "
-                "training sets)" % self.Nb)
         self._attach_device(S, dev, device, stream)
         Nx = int(np.prod(self.cri.shpD))
         admm.ADMM.__init__(self, Nx, self.cri.shpD, self.cri.shpD, S.dtype, opt)
@@ -427,9 +422,10 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
 
 class ConvCnstrMOD_IterSM(ConvCnstrMODBase):
     r"""ADMM dictionary update with the X-step solved by iterated Sherman-Morrison over the
-    images (sporco/admm/ccmod.py:433-505; linalg.solvemdbi_ism).  On the device the rank-one
-    terms of one frequency live in registers, which bounds the training set at 8 images
-    (times channels); the reference recommends this method for small training sets only.
+    images (sporco/admm/ccmod.py:433-505; linalg.solvemdbi_ism).  Up to 8 images (times
+    channels) the rank-one terms of one frequency live in registers; beyond that the same
+    recursion re-reads them from memory (the cost grows with the square of the number of
+    images, which is why the reference recommends this method for small training sets).
 
     IterationStats fields: ``Iter, DFid, Cnstr, PrimalRsdl, DualRsdl, EpsPrimal, EpsDual,
     Rho, XSlvRelRes, Time``.

@@ -199,8 +199,8 @@ def ccmod_broadcastable(w, full_shape):
 
 
 class ConvCnstrMODMaskDcpl_IterSM(ConvCnstrMODMaskDcplBase):
-    r"""X-step by iterated Sherman-Morrison over the images (ccmodmd.py:573-654); up to 8 images
-    (times channels), as :class:`sporco_amd.admm.ccmod.ConvCnstrMOD_IterSM`."""
+    r"""X-step by iterated Sherman-Morrison over the images (ccmodmd.py:573-654), as
+    :class:`sporco_amd.admm.ccmod.ConvCnstrMOD_IterSM`."""
 
     class Options(ConvCnstrMODMaskDcplBase.Options):
         defaults = copy.deepcopy(ConvCnstrMODMaskDcplBase.Options.defaults)

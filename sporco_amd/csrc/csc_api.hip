@@ -3373,10 +3373,6 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(p.rho > 0.0, "rho must be positive");
         SA_REQUIRE(p.method == SPORCO_AMD_DSTEP_ISM || p.method == SPORCO_AMD_DSTEP_CG,
                    "unknown D-step method");
-        if (p.method == SPORCO_AMD_DSTEP_ISM && CN > 8)
-            throw Error(SPORCO_AMD_EINVAL,
-                        "the iterated Sherman-Morrison D-step handles up to 8 images (times "
-                        "channels); use the consensus or conjugate gradient update");
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         need_natural(SPORCO_AMD_VAR_ZF);
         const int64_t npixr = (int64_t)H * W, nd = npix * K;

@@ -1799,6 +1799,134 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
     block_sum_store<NA>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * NA);
 }
 
+// ---- any number of rank-one terms (the dictionary update's iterated solve over more than 8
+// images x channels, admm/ccmod.py:433-604): the same recursions with the per-term scalars in
+// LDS (one slice per wave) and the term vectors re-read from memory instead of held in
+// registers.  One wave per frequency (setup) / per system (solve), lane = filter.
+template <typename T, int KR>
+__global__ void __launch_bounds__(kThreads) ism_setup_big_kernel(const cx<T> *__restrict__ df,
+                                                                 cx<T> *__restrict__ gam,
+                                                                 cx<T> *__restrict__ del,
+                                                                 cx<T> *__restrict__ mm, int64_t npix,
+                                                                 int Cd, int K, T rho) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    cx<T> *dl = dyn_lds<cx<T>>() + (size_t)(threadIdx.x / kWave) * Cd;   // delta_c of this wave's frequency
+    const T irho = T(1) / rho;
+    for (int64_t pix = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+         pix < npix; pix += nwaves) {
+        const cx<T> *d = df + pix * Cd * K;
+        cx<T> *g = gam + pix * Cd * K;
+        for (int c = 0; c < Cd; ++c) {
+            cx<T> al[KR];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                al[j] = k < K ? cscale(cconj(d[c * K + k]), irho) : mk<T>(T(0), T(0));
+            }
+            for (int l = 0; l < c; ++l) {
+                cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    if (k < K) t = t + cmul(d[l * K + k], al[j]);
+                }
+                const cx<T> f = cdivide(wave_sum_cx(t), dl[l]);
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    if (k < K) al[j] = al[j] - cmul(g[l * K + k], f);
+                }
+            }
+            cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) {
+                    g[c * K + k] = al[j];
+                    t = t + cmul(d[c * K + k], al[j]);
+                }
+            }
+            t = wave_sum_cx(t);
+            const cx<T> dc = mk<T>(T(1) + t.re, t.im);
+            dl[c] = dc;      // (every lane holds the same value and stores it: no lane waits for another)
+            if (lane == 0) del[pix * Cd + c] = dc;
+        }
+        // (gamma of this frequency was written by this wave's own lanes, element by element the
+        // lane that reads it back below)
+        for (int c = 0; c < Cd; ++c)
+            for (int l = 0; l < Cd; ++l) {
+                cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    if (k < K) t = t + cmul(d[c * K + k], g[l * K + k]);
+                }
+                t = wave_sum_cx(t);
+                if (lane == 0) mm[(pix * Cd + c) * Cd + l] = t;
+            }
+    }
+}
+
+template <typename T, int KR>
+__global__ void __launch_bounds__(kThreads) ism_solve_big_kernel(const IsmArgs<T> a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int K = a.K, Cd = a.Cd;
+    const T irho = T(1) / a.rho;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    cx<T> *fw = dyn_lds<cx<T>>() + (size_t)(threadIdx.x / kWave) * 2 * Cd;   // t_c, then f_c
+    const int64_t nsys = a.npix * a.N;
+    for (int64_t sys = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; sys < nsys;
+         sys += nwaves) {
+        const int64_t pix = sys / a.N;
+        const int n = (int)(sys - pix * a.N);
+        const cx<T> *dp = a.df + pix * Cd * K;
+        const cx<T> *gp = a.gam + pix * Cd * K;
+        const cx<T> *M = a.mm + pix * Cd * Cd;
+        cx<T> be[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            be[j] = k < K ? a.yuf[sys * K + k] : mk<T>(T(0), T(0));
+        }
+        for (int c = 0; c < Cd; ++c) {        // beta0 = yuf + sum_c conj(d_c) s_c / rho
+            const cx<T> sc = a.sf[(pix * Cd + c) * a.N + n];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) be[j] = be[j] + cscale(cmulc(dp[c * K + k], sc), irho);
+            }
+        }
+        for (int c = 0; c < Cd; ++c) {        // t_c = <ah_c, beta0>
+            cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) t = t + cmul(dp[c * K + k], be[j]);
+            }
+            fw[c] = wave_sum_cx(t);      // (all lanes store the same value, as above)
+        }
+        for (int c = 0; c < Cd; ++c) {        // f_c = (t_c - sum_{l<c} M_cl f_l) / delta_c
+            cx<T> r = fw[c];
+            for (int l = 0; l < c; ++l) r = r - cmul(M[c * Cd + l], fw[Cd + l]);
+            fw[Cd + c] = cdivide(r, a.del[pix * Cd + c]);
+        }
+        for (int c = 0; c < Cd; ++c) {        // x = beta0 - sum_c gamma_c f_c
+            const cx<T> f = fw[Cd + c];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) be[j] = be[j] - cmul(gp[c * K + k], f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            if (k < K) a.xf[sys * K + k] = be[j];
+        }
+    }
+}
+
 template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
     if (K <= 64) f(std::integral_constant<int, 1>{});
     else if (K <= 128) f(std::integral_constant<int, 2>{});
@@ -1809,8 +1937,17 @@ template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
 template <typename T>
 void launch_ism_setup(hipStream_t st, const cx<T> *df, cx<T> *gam, cx<T> *del, cx<T> *mm,
                       int64_t npix, int Cd, int K, T rho, const GradTerm<T> *grad, int W) {
-    if (Cd > 8) throw Error(-1, "multi-channel dictionaries are handled for up to 8 channels");
     const int grid = grid_for(npix * kWave);
+    if (Cd > 8) {
+        if (grad) throw Error(-1, "the gradient-regularised iterated solve takes up to 8 channels");
+        ism_dispatch_kr<T>(K, [&](auto kr) {
+            constexpr int KR = decltype(kr)::value;
+            hipLaunchKernelGGL((ism_setup_big_kernel<T, KR>), dim3(grid), dim3(kThreads),
+                               sizeof(cx<T>) * (kThreads / kWave) * Cd, st, df, gam, del, mm, npix, Cd, K, rho);
+        });
+        SA_HIP(hipGetLastError());
+        return;
+    }
     const GradTerm<T> gt = grad ? *grad : GradTerm<T>();
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
@@ -1843,6 +1980,18 @@ int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *d
     a.want_obj = want_obj;
     a.want_xrrs = want_xrrs;
     a.partials = partials;
+    if (Cd > 8) {
+        if (grad || want_obj || want_xrrs)
+            throw Error(-1, "more than 8 rank-one terms: the plain solve only (the dictionary update)");
+        const int gridb = grid_for(npix * N * kWave);
+        ism_dispatch_kr<T>(K, [&](auto kr) {
+            constexpr int KR = decltype(kr)::value;
+            hipLaunchKernelGGL((ism_solve_big_kernel<T, KR>), dim3(gridb), dim3(kThreads),
+                               sizeof(cx<T>) * (kThreads / kWave) * 2 * Cd, st, a);
+        });
+        SA_HIP(hipGetLastError());
+        return 0;
+    }
     const int grid = (int)std::min<int64_t>(npix, kMaxPartialBlocks);
     const size_t lds = sizeof(double) * 5 * (kThreads / kWave);
     ism_dispatch_kr<T>(K, [&](auto kr) {

@@ -261,3 +261,19 @@ def test_consensus_wrapper_and_fast_shape(backend):
     assert rel_l2(c.getdict(), c64.getdict()) < 1e-3
     assert rel_l2(np.asarray(c.getitstat().DFid, float),
                   np.asarray(c64.getitstat().DFid, float)) < 1e-4
+
+
+def test_masked_itersm_over_ten_images(backend):
+    """ConvCnstrMODMaskDcpl_IterSM over 10 images (more rank-one terms than the register kernels
+    hold: the memory-resident recursion), against the unmodified reference
+    (oracle/make_golden.py gen_ccmod_ism_many; sporco/admm/ccmodmd.py:573-654)."""
+    g = load_golden('ccmodmd_ism_k10_f64')
+    cls = dstep_class('ism')
+    c = cls(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']), cls.Options({'MaxMainIter': 10}))
+    c.solve()
+    assert c.k == int(g['k_final'])
+    assert rel_l2(c.Y, g['Y']) < 1e-9 and rel_l2(c.U, g['U']) < 1e-9
+    assert rel_l2(c.X, g['X']) < 1e-9 and rel_l2(c.getdict(), g['D']) < 1e-9
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-9, f
