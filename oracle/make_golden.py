@@ -578,6 +578,36 @@ def gen_cns():
         save(name, D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_cns_options():
+    """ConvCnstrMOD_Consensus with the options the reference's own tests switch on
+    (tests/admm/test_ccmod.py:153-259: LinSolveCheck, a multi-channel signal with dimK = 0 and
+    with several images) and with the objective evaluated at the blocks (AuxVarObj False:
+    sporco/admm/ccmod.py:870-889, admm/admm.py:1632-1646)."""
+    np.random.seed(24680)
+    N, M, K, Nc, Nd = 16, 4, 2, 3, 5
+    cls = ref_admm_ccmod.ConvCnstrMOD_Consensus
+
+    def run(name, Z, S, dsz, optd, dimK=1):
+        c = cls(Z, S, dsz, cls.Options(optd), dimK=dimK)
+        c.solve()
+        save(name, Z=Z, S=S, dsz=np.array(dsz), dimK=np.int64(dimK), D=c.getdict(), Y=c.Y, U=c.U,
+             X=c.X, rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+    Z = np.random.randn(N, N, 1, K + 1, M) * (np.random.rand(N, N, 1, K + 1, M) > 0.6)
+    S = np.random.randn(N, N, K + 1)
+    run('ccmod_cns_auxfalse_chk_zm_f64', Z, S, (Nd, Nd, M),
+        {'MaxMainIter': 12, 'AuxVarObj': False, 'LinSolveCheck': True, 'ZeroMean': True})
+    run('ccmod_cns_fevalx_f32', Z, S, (Nd, Nd, M),
+        {'MaxMainIter': 12, 'fEvalX': True, 'DataType': np.float32})
+    Zc = np.random.randn(N, N, Nc, 1, M) * (np.random.rand(N, N, Nc, 1, M) > 0.6)
+    Sc = np.random.randn(N, N, Nc)
+    run('ccmod_cns_chk_multichan_dimk0_f64', Zc, Sc, (Nd, Nd, 1, M),
+        {'MaxMainIter': 12, 'LinSolveCheck': True}, dimK=0)
+    Zck = np.random.randn(N, N, Nc, K, M) * (np.random.rand(N, N, Nc, K, M) > 0.6)
+    Sck = np.random.randn(N, N, Nc, K)
+    run('ccmod_cns_chk_multichan_f64', Zck, Sck, (Nd, Nd, 1, M),
+        {'MaxMainIter': 12, 'LinSolveCheck': True})
+
+
 def gen_ccmod_eq():
     """Single-copy ADMM dictionary updates ConvCnstrMOD_IterSM and ConvCnstrMOD_CG
     (sporco/admm/ccmod.py:433-601 on ConvCnstrMODBase :103-429) alone and inside
@@ -1035,8 +1065,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

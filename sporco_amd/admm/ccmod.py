@@ -173,12 +173,14 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         if self.cri.Cd > 1:
             raise NotImplementedError("multi-channel dictionaries are not part of the "
                                       "sporco_amd dictionary update")
-        if not opt['gEvalY'] or opt['fEvalX']:
-            raise NotImplementedError("the consensus D-step evaluates its objective at the "
-                                      "consensus variable (AuxVarObj True, the class default)")
-        if opt['LinSolveCheck']:
-            raise NotImplementedError("LinSolveCheck is not offered by the device consensus "
-                                      "D-step")
+        if (not opt['gEvalY'] or opt['fEvalX']) and (reducer is not None or self._mask_dcpl):
+            raise NotImplementedError("objective at the blocks X_n (AuxVarObj False): not with "
+                                      "image shards (the mean of X runs over ALL images) and not "
+                                      "with mask decoupling")
+        if opt['LinSolveCheck'] and (reducer is not None or self._mask_dcpl):
+            raise NotImplementedError("LinSolveCheck of the consensus D-step: not with image "
+                                      "shards (its residual is of sums over ALL images) and not "
+                                      "with mask decoupling")
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
@@ -205,11 +207,14 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
             self.U = self.opt['U0']
 
     def _from_blocks(self, a):
-        """Device layout (H, W, 1, Nb, M) -> the reference's (H, W, 1, 1, M, Nb)."""
+        """Device layout (H, W, C, K, M) -> the reference's (H, W, 1, 1, M, Nb): the channels of
+        a multi-channel signal count as images (Nb = C K, channel-major: ccmod.py:757-765)."""
+        a = a.reshape(a.shape[0], a.shape[1], 1, -1, a.shape[-1])
         return np.ascontiguousarray(np.moveaxis(a, 3, -1)[:, :, :, np.newaxis])
 
     def _to_blocks(self, a):
-        return np.ascontiguousarray(np.moveaxis(np.asarray(a)[:, :, :, 0], -1, 3))
+        a = np.moveaxis(np.asarray(a)[:, :, :, 0], -1, 3)          # (H, W, 1, Nb, M)
+        return np.ascontiguousarray(a.reshape(a.shape[0], a.shape[1], self.cri.C, -1, a.shape[-1]))
 
     @property
     def X(self):
@@ -239,9 +244,20 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
             flags |= _lib.FLAG_RESID
         if not self.opt['FastSolve']:
             flags |= _lib.FLAG_OBJ
+        if not self.opt['fEvalX']:
+            flags |= _lib.FLAG_FEVAL_Y
+        if self.opt['gEvalY']:
+            flags |= _lib.FLAG_GEVAL_Y
+        if self.opt['LinSolveCheck']:
+            flags |= _lib.FLAG_XRRS
         self._sums = self._device_iteration(flags)
         self._u_scale = 1.0
         self._cache.clear()
+        if self.opt['LinSolveCheck']:
+            # rrs(sum_n ax_n, sum_n b_n) (ccmod.py:783-792; linalg.rrs, linalg.py:1126-1153)
+            s = self._sums
+            nrm = max(np.sqrt(s[_lib.OUT_XRRS_AX2]), np.sqrt(s[_lib.OUT_XRRS_B2]))
+            self.xrrs = np.sqrt(s[_lib.OUT_XRRS_D2]) / nrm if nrm > 0.0 else 0.0
         if not self._needs_residuals():
             return None
         self.timer.stop('solve_wo_rsdl')

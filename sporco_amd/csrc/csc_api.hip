@@ -3001,7 +3001,16 @@ template <typename T> struct Csc : CscBase {
             cns_md_iter(p, out_dev);
             return;
         }
-        const bool fusedx = cns_fused();
+        // LinSolveCheck (F_XRRS; a diagnostic): the generic chain, whose solve sees the
+        // right-hand sides in the natural layout
+        const bool lsc = p.flags & F_XRRS;
+        const bool fusedx = cns_fused() && !lsc;
+        // objective at the consensus variable Y (FLAG_FEVAL_Y / FLAG_GEVAL_Y: AuxVarObj, the
+        // class default) or at the blocks X_n (fEvalX: admm/ccmod.py:870-889) and their mean
+        // (gEvalY False: admm/admm.py:1641-1646)
+        const bool dfid_x = (p.flags & F_OBJ) && !(p.flags & F_FEVAL_Y);
+        const bool cns_x = (p.flags & F_OBJ) && !(p.flags & F_GEVAL_Y);
+        SA_REQUIRE(!(cns_x && p.phase != 0), "the constraint measure at mean(X) needs all the images");
         if (fusedx) {
             if (!zf_tiled) relayout(SPORCO_AMD_VAR_ZF, true), zf_tiled = true;
         } else {
@@ -3053,9 +3062,15 @@ template <typename T> struct Csc : CscBase {
             fa.K = K;
             fa.partials = part_f;
             fa.per_tile = 1;
+            int64_t ntl;
             {
                 ProfScope ps(prof, PS_FUSED_COLS);
-                launch_fused_cols<T>(st, fa);
+                ntl = launch_fused_cols<T>(st, fa);
+            }
+            if (dfid_x) {     // (the column kernel's by-product: sum_n |Zf_n . Xf_n - Sf_n|^2)
+                const int slots[1] = {SPORCO_AMD_OUT_DFID};
+                const double scales[1] = {1.0 / ((double)H * W)};
+                finalize(part_f, (int)ntl, 1, 1, slots, scales, out_dev);
             }
             rows_inverse_to(X, cns_f);
         } else {
@@ -3069,10 +3084,30 @@ template <typename T> struct Csc : CscBase {
             fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * P, 0, (int64_t)Wf * P, 0,
                        (int64_t)Wf * P, T(1));
         }
+        if (lsc) {
+            ProfScope ps(prof, PS_OTHER);
+            launch_cns_xrrs_rhs<T>(st, Zf, cv(SPORCO_AMD_VAR_SF), cns_f, (T)p.rho, dwork_buf(), npix, CN, K);
+        }
+        int nbs;
         {   // (the per-image gram sum_k |Zf|^2 is formed inside the kernel)
             ProfScope ps(prof, PS_SM_SOLVE);
-            launch_sm_solve<T>(st, cns_f, cns_f, Zf, cv(SPORCO_AMD_VAR_SF), nullptr, (T)p.rho, npix,
-                               CN, K, W, false, false, part_a, nullptr, true);
+            nbs = launch_sm_solve<T>(st, cns_f, cns_f, Zf, cv(SPORCO_AMD_VAR_SF), nullptr, (T)p.rho, npix,
+                                     CN, K, W, dfid_x, false, part_a, nullptr, true);
+        }
+        if (dfid_x) {
+            const int slots[1] = {SPORCO_AMD_OUT_DFID};
+            const double scales[1] = {1.0 / ((double)H * W)};
+            finalize(part_a, nbs, 4, 1, slots, scales, out_dev);
+        }
+        if (lsc) {
+            int nbx;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, (T)p.rho, dwork_buf(), npix, CN, K, part_a);
+            }
+            const int xslots[3] = {SPORCO_AMD_OUT_XRRS_D2, SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
+            const double xscales[3] = {1.0, 1.0, 1.0};
+            finalize(part_a, nbx, 3, 3, xslots, xscales, out_dev);
         }
         inv2(cns_f, work_buf(), X, P);
         }
@@ -3111,7 +3146,9 @@ template <typename T> struct Csc : CscBase {
         if (p.flags & F_OBJ) {
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
             const double scales[1] = {1.0 / ((double)H * W)};
-            if (zf_tiled) {
+            if (dfid_x) {
+                // (already summed by the X-step)
+            } else if (zf_tiled) {
                 if (!gpart) {
                     ccmod_groups = (int)ceil_div(768, Wf);
                     if (ccmod_groups > CN) ccmod_groups = CN;
@@ -3144,10 +3181,16 @@ template <typename T> struct Csc : CscBase {
                 finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
             }
             int nbc;
+            const T *gv = Y;
+            if (cns_x) {      // g is evaluated at mean_n(X_n)
+                ProfScope ps(prof, PS_OTHER);
+                launch_cns_mean<T>(st, X, U, cns_yold, cns_m, T(1), T(0), npixr, CN, K);
+                gv = cns_m;
+            }
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_pcn_stats<T>(st, Y, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
-                nbc = launch_pcn_apply<T>(st, Y, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
+                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                nbc = launch_pcn_apply<T>(st, gv, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
                                           Ku);
             }
             const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};

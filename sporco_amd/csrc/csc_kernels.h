@@ -241,6 +241,18 @@ int launch_cns_ustep(hipStream_t st, const T *x, T *u, const T *yold, const T *y
                      int64_t npixr, int CN, int K, double *partials);
 template <typename T>   // partials (2): |ynew - yold|^2, |ynew|^2
 int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, double *partials);
+// LinSolveCheck of the consensus update (admm/ccmod.py:783-792): the residual of the per-image
+// systems SUMMED over the images, rrs(sum_n (Z_n^H Z_n + rho) x_n, sum_n b_n).
+//   rhs  (before the solve): bsum[pix, k] = sum_n (conj(zf) sf + rho yuf)[pix, n, k]
+//   fin  (after it):         asum = sum_n (conj(zf) <zf, xf> + rho xf); partials (3) =
+//                            |asum - bsum|^2, |asum|^2, |bsum|^2 summed over (pix, k).
+// zf, yuf / xf: (npix, CN, K); sf: (npix, CN); bsum: (npix, K).  K <= 256.
+template <typename T>
+void launch_cns_xrrs_rhs(hipStream_t st, const cx<T> *zf, const cx<T> *sf, const cx<T> *yuf, T rho,
+                         cx<T> *bsum, int64_t npix, int CN, int K);
+template <typename T>
+int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho, const cx<T> *bsum,
+                        int64_t npix, int CN, int K, double *partials);
 
 // Multi-channel dictionary (Cd > 1) X-step, linalg.solvemdbi_ism (linalg.py:370-444):
 // gam(npix, Cd, K), del(npix, Cd), mm(npix, Cd, Cd) hold the recursion's gamma / delta and the

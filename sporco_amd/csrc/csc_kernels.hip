@@ -1799,6 +1799,81 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
     block_sum_store<NA>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * NA);
 }
 
+// ---- LinSolveCheck of the consensus dictionary update (csc_kernels.h) -----------------------
+// one wave per frequency, lane = filter (KR of them per lane)
+template <typename T, int KR>
+__global__ void __launch_bounds__(kThreads) cns_xrrs_rhs_kernel(const cx<T> *__restrict__ zf,
+                                                                const cx<T> *__restrict__ sf,
+                                                                const cx<T> *__restrict__ yuf, T rho,
+                                                                cx<T> *__restrict__ bsum, int64_t npix,
+                                                                int CN, int K) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t pix = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pix < npix;
+         pix += nwaves) {
+        cx<T> b[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) b[j] = mk<T>(T(0), T(0));
+        for (int n = 0; n < CN; ++n) {
+            const int64_t row = (pix * CN + n) * K;
+            const cx<T> s = sf[pix * CN + n];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) b[j] = b[j] + cmulc(zf[row + k], s) + cscale(yuf[row + k], rho);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            if (k < K) bsum[pix * K + k] = b[j];
+        }
+    }
+}
+
+template <typename T, int KR>
+__global__ void __launch_bounds__(kThreads) cns_xrrs_fin_kernel(const cx<T> *__restrict__ zf,
+                                                                const cx<T> *__restrict__ xf, T rho,
+                                                                const cx<T> *__restrict__ bsum,
+                                                                int64_t npix, int CN, int K,
+                                                                double *partials) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t pix = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pix < npix;
+         pix += nwaves) {
+        cx<T> a[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) a[j] = mk<T>(T(0), T(0));
+        for (int n = 0; n < CN; ++n) {
+            const int64_t row = (pix * CN + n) * K;
+            cx<T> q = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) q = q + cmul(zf[row + k], xf[row + k]);
+            }
+            q = wave_sum_cx(q);
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) a[j] = a[j] + cmulc(zf[row + k], q) + cscale(xf[row + k], rho);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            if (k < K) {
+                const cx<T> b = bsum[pix * K + k];
+                acc[0] += (double)cabs2(a[j] - b);
+                acc[1] += (double)cabs2(a[j]);
+                acc[2] += (double)cabs2(b);
+            }
+        }
+    }
+    block_sum_store<3>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 3);
+}
+
 // ---- any number of rank-one terms (the dictionary update's iterated solve over more than 8
 // images x channels, admm/ccmod.py:433-604): the same recursions with the per-term scalars in
 // LDS (one slice per wave) and the term vectors re-read from memory instead of held in
@@ -1932,6 +2007,31 @@ template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
     else if (K <= 128) f(std::integral_constant<int, 2>{});
     else if (K <= 256) f(std::integral_constant<int, 4>{});
     else throw Error(-1, "multi-channel dictionaries are handled for K <= 256 filters");
+}
+
+template <typename T>
+void launch_cns_xrrs_rhs(hipStream_t st, const cx<T> *zf, const cx<T> *sf, const cx<T> *yuf, T rho,
+                         cx<T> *bsum, int64_t npix, int CN, int K) {
+    const int grid = grid_for(npix * kWave);
+    ism_dispatch_kr<T>(K, [&](auto kr) {
+        constexpr int KR = decltype(kr)::value;
+        hipLaunchKernelGGL((cns_xrrs_rhs_kernel<T, KR>), dim3(grid), dim3(kThreads), 0, st, zf, sf, yuf, rho,
+                           bsum, npix, CN, K);
+    });
+    SA_HIP(hipGetLastError());
+}
+template <typename T>
+int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho, const cx<T> *bsum,
+                        int64_t npix, int CN, int K, double *partials) {
+    const int grid = std::min(grid_for(npix * kWave), kMaxPartialBlocks);
+    ism_dispatch_kr<T>(K, [&](auto kr) {
+        constexpr int KR = decltype(kr)::value;
+        hipLaunchKernelGGL((cns_xrrs_fin_kernel<T, KR>), dim3(grid), dim3(kThreads),
+                           sizeof(double) * 3 * (kThreads / kWave), st, zf, xf, rho, bsum, npix, CN, K,
+                           partials);
+    });
+    SA_HIP(hipGetLastError());
+    return grid;
 }
 
 template <typename T>
@@ -2979,6 +3079,10 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_cns_ustep<T>(hipStream_t, const T *, T *, const T *, const T *, T, T,      \
                                      int64_t, int, int, double *);                                 \
     template int launch_cns_ystats<T>(hipStream_t, const T *, const T *, int64_t, double *);       \
+    template void launch_cns_xrrs_rhs<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, \
+                                         T, cx<T> *, int64_t, int, int);                          \
+    template int launch_cns_xrrs_fin<T>(hipStream_t, const cx<T> *, const cx<T> *, T,              \
+                                        const cx<T> *, int64_t, int, int, double *);               \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
                                       int64_t, int, int, T, const GradTerm<T> *, int);             \
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \

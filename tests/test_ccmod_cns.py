@@ -63,9 +63,7 @@ def test_consensus_surface(backend):
     assert c.reconstruct().shape[:2] == g['S'].shape[:2]
     with pytest.raises(ValueError):
         ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz, method='nosuch')
-    with pytest.raises(NotImplementedError):
-        ccmod.ConvCnstrMOD_Consensus(
-            g['Z'], g['S'], dsz, ccmod.ConvCnstrMOD_Consensus.Options({'AuxVarObj': False}))
+    # (AuxVarObj False and LinSolveCheck: test_consensus_options below)
 
 
 @pytest.mark.parametrize('name,dt,tol', [('cbpdndl_cns_f64', np.float64, 1e-9),
@@ -130,3 +128,42 @@ def test_consensus_on_fused_kernels(backend, H, K, N):
                       np.asarray(getattr(c0.getitstat(), f), float)) < 1e-5, f
     # (Y is a projected point: the constraint violation is float32 rounding noise)
     assert max(c.getitstat().Cnstr) < 1e-5 and max(c0.getitstat().Cnstr) < 1e-5
+
+
+OPTION_CASES = {
+    # objective at the blocks X_n and at their mean, LinSolveCheck, ZeroMean
+    'ccmod_cns_auxfalse_chk_zm_f64': {'MaxMainIter': 12, 'AuxVarObj': False, 'LinSolveCheck': True,
+                                      'ZeroMean': True},
+    'ccmod_cns_fevalx_f32': {'MaxMainIter': 12, 'fEvalX': True, 'DataType': np.float32},
+    # the reference's own test cases (tests/admm/test_ccmod.py:153-259): a multi-channel signal
+    # with a single-channel dictionary, dimK = 0 and several images, LinSolveCheck
+    'ccmod_cns_chk_multichan_dimk0_f64': {'MaxMainIter': 12, 'LinSolveCheck': True},
+    'ccmod_cns_chk_multichan_f64': {'MaxMainIter': 12, 'LinSolveCheck': True},
+}
+
+
+@pytest.mark.parametrize('name', sorted(OPTION_CASES))
+def test_consensus_options(backend, name):
+    """Fixtures of oracle/make_golden.py gen_cns_options (the unmodified reference)."""
+    from sporco_amd.admm import ccmod
+    g = load_golden(name)
+    optd = dict(OPTION_CASES[name])
+    f32 = optd.get('DataType') is np.float32
+    tol = 3e-4 if f32 else 1e-9
+    c = ccmod.ConvCnstrMOD_Consensus(g['Z'], g['S'], tuple(int(v) for v in g['dsz']),
+                                     ccmod.ConvCnstrMOD_Consensus.Options(optd), dimK=int(g['dimK']))
+    Y = c.solve()
+    assert c.k == int(g['k_final'])
+    assert Y.shape == g['Y'].shape and rel_l2(Y, g['Y']) < tol
+    assert rel_l2(c.getdict(), g['D']) < tol and rel_l2(c.U, g['U']) < tol
+    assert rel_l2(c.X, g['X']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < (1e-4 if f32 else 1e-11)
+    if optd.get('LinSolveCheck'):
+        # a relative residual at rounding level on both sides (the reference's own test asks
+        # for < 1e-5, tests/admm/test_ccmod.py:168)
+        assert max(its.XSlvRelRes) < 1e-10 and np.max(g['it_XSlvRelRes']) < 1e-10
+    else:
+        assert all(v is None for v in its.XSlvRelRes)
