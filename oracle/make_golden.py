@@ -1040,6 +1040,31 @@ def gen_mask():
          Xfull=c.X, **itstat_dict(c))
 
 
+def gen_mask_mcdict():
+    """The masked PGM classes with a multi-channel dictionary (pgm.cbpdn.ConvBPDNMask
+    sporco/pgm/cbpdn.py:387-506, pgm.ccmod.ConvCnstrMODMask sporco/pgm/ccmod.py:408-631; the
+    reference's dictlrn tests run both with colour dictionaries)."""
+    np.random.seed(112233)
+    N, C, K, M, Nd = 16, 3, 2, 4, 5
+    D = np.random.randn(Nd, Nd, C, M)
+    S = np.random.randn(N, N, C, K)
+    W = (np.random.rand(N, N, C, K) > 0.3).astype(np.float64)
+    Wb = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    for name, w, optd in (('pgm_mask_mcdict_f64', W, {'MaxMainIter': 15, 'L': 100.0}),
+                          ('pgm_mask_mcdict_bcast_f32', Wb, {'MaxMainIter': 15, 'L': 100.0,
+                                                             'DataType': np.float32})):
+        b = ref_pgm_cbpdn.ConvBPDNMask(D, S, 0.1, w, ref_pgm_cbpdn.ConvBPDNMask.Options(optd))
+        b.solve()
+        save(name, D=D, S=S, W=w, lmbda=np.float64(0.1), X=b.getcoef(), recon=b.reconstruct(),
+             **itstat_dict(b))
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.6)
+    c = ref_pgm_ccmod.ConvCnstrMODMask(Z, S, W, (Nd, Nd, C, M),
+                                       ref_pgm_ccmod.ConvCnstrMODMask.Options({'MaxMainIter': 15, 'L': 50.0}))
+    c.solve()
+    save('pgm_ccmod_mask_mcdict_f64', Z=Z, S=S, W=W, dsz=np.array((Nd, Nd, C, M)), D=c.getdict(),
+         **itstat_dict(c))
+
+
 def gen_ams():
     """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
     ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
@@ -1065,8 +1090,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -2750,7 +2750,8 @@ template <typename T> struct Csc : CscBase {
     // once -- the form of the online learner's dictionary step, onlinecdl.py:578-580)
     void masked_grad(int var, bool dstep, int mode, double *out_dev) override {
         const bool write_grad = mode != 0;
-        require_single_channel_dict();
+        // (multi-channel dictionary, Cd = Cs > 1: the coefficient maps have no channel axis, the
+        // residual has the signal's -- inner products and adjoints over (channel, filter))
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var) == dstep &&
                        var != SPORCO_AMD_VAR_SF && var != SPORCO_AMD_VAR_DF,
@@ -2762,18 +2763,20 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_PGM);
             if (dstep) {
                 need_natural(SPORCO_AMD_VAR_ZF);
-                launch_inner<T>(st, cv(var), cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
+                if (Cd > 1) launch_mc_inner<T>(st, cv(var), cv(SPORCO_AMD_VAR_ZF), innerb, npix, Cd, N, K);
+                else launch_inner<T>(st, cv(var), cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
             } else {
                 require_ready();
-                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(var), innerb, npix, CN, K);
+                if (Cd > 1) launch_mc_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(var), innerb, npix, Cd, N, K);
+                else launch_inner<T>(st, cv(SPORCO_AMD_VAR_DF), cv(var), innerb, npix, CN, K);
             }
-            launch_lincomb<T>(st, innerb, T(1), innerb, T(-1), Sf, T(0), nullptr, npix * CN);
+            launch_lincomb<T>(st, innerb, T(1), innerb, T(-1), Sf, T(0), nullptr, npix * CNs);
         }
-        inv2(innerb, innerb, sreal, CN);
+        inv2(innerb, innerb, sreal, CNs);
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
-            nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), mode == 1, H, W, C, N,
+            nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), mode == 1, H, W, Cs, N,
                                       part_a);
         }
         {
@@ -2781,11 +2784,11 @@ template <typename T> struct Csc : CscBase {
             const double scales[1] = {1.0};
             finalize(part_a, nb, 1, 1, slots, scales, out_dev);
         }
-        fwd2(sreal, nullptr, T(0), innerb, CN);
+        fwd2(sreal, nullptr, T(0), innerb, CNs);
         if (!write_grad) {
             {
                 ProfScope ps(prof, PS_PGM);
-                nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CN, W, part_b);
+                nb = launch_pair_stats<T>(st, innerb, nullptr, nullptr, npix, CNs, W, part_b);
             }
             const int slots[1] = {SPORCO_AMD_PGM_F};
             const double scales[1] = {0.5};
@@ -2793,10 +2796,18 @@ template <typename T> struct Csc : CscBase {
             return;
         }
         ProfScope ps(prof, PS_PGM);
-        if (dstep)
-            launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, cv(SPORCO_AMD_VAR_DGF), npix, CN, K);
-        else
+        if (dstep) {
+            if (Cd > 1)
+                launch_mc_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, cv(SPORCO_AMD_VAR_DGF), npix, Cd,
+                                        N, K);
+            else
+                launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, cv(SPORCO_AMD_VAR_DGF), npix, CN, K);
+        } else if (Cd > 1) {
+            launch_mc_conj_outer<T>(st, cv(SPORCO_AMD_VAR_DF), innerb, cv(SPORCO_AMD_VAR_GF), npix, Cd, N, K,
+                                    false);
+        } else {
             launch_conj_outer<T>(st, cv(SPORCO_AMD_VAR_DF), innerb, cv(SPORCO_AMD_VAR_GF), npix, CN, K);
+        }
     }
 
     // ---- ADMM consensus dictionary update -------------------------------------------------

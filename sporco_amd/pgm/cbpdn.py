@@ -296,13 +296,10 @@ class ConvBPDNMask(ConvBPDN):
     (1/2) ||W (sum_m d_m * x_m - s)||_2^2 + lambda sum_m ||x_m||_1 (reference class:
     sporco/pgm/cbpdn.py:387-506).  The gradient takes the residual to the spatial domain,
     weights it by W^2 and brings it back (``sporco_amd_csc_masked_grad``); everything else is
-    the unmasked solver.  Single-channel dictionaries."""
+    the unmasked solver."""
 
     def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
         super(ConvBPDNMask, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)
-        if self.cri.Cd > 1:
-            raise NotImplementedError("ConvBPDNMask with a multi-channel dictionary is not "
-                                      "part of the sporco_amd hot path")
         if W is None:
             W = np.array([1.0], dtype=self.dtype)
         W = np.asarray(W)

@@ -73,3 +73,38 @@ def test_masked_dictionary_learning_trace(backend):
             assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
     # every D-step of the reference's wrapper is offered (cbpdndlmd.py:130-132)
     assert cbpdndlmd.ConvBPDNMaskDictLearn.Options(dmethod='cns')['CCMOD', 'AutoRho', 'Period'] == 10
+
+
+@pytest.mark.parametrize('name,dt', [('pgm_mask_mcdict_f64', np.float64),
+                                     ('pgm_mask_mcdict_bcast_f32', np.float32)])
+def test_convbpdnmask_multichannel_dictionary(backend, name, dt):
+    """ConvBPDNMask with a colour dictionary (Cd = C = 3): the masked residual keeps the
+    signal's channels, inner products and adjoints run over (channel, filter).  Fixtures from
+    the unmodified reference (oracle/make_golden.py gen_mask_mcdict; sporco/pgm/cbpdn.py:387-506)."""
+    from sporco_amd.pgm import cbpdn
+    g = load_golden(name)
+    optd = {'MaxMainIter': 15, 'L': 100.0}
+    if dt is np.float32:
+        optd['DataType'] = np.float32
+    tol = 1e-4 if dt is np.float32 else 1e-9
+    b = cbpdn.ConvBPDNMask(g['D'], g['S'], float(g['lmbda']), g['W'], cbpdn.ConvBPDNMask.Options(optd))
+    X = b.solve()
+    assert X.shape == g['X'].shape and rel_l2(X, g['X']) < tol
+    assert rel_l2(b.reconstruct(), g['recon']) < tol
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < tol, f
+
+
+def test_convcnstrmodmask_multichannel_dictionary(backend):
+    """ConvCnstrMODMask updating a colour dictionary (sporco/pgm/ccmod.py:408-631)."""
+    from sporco_amd.pgm import ccmod
+    g = load_golden('pgm_ccmod_mask_mcdict_f64')
+    c = ccmod.ConvCnstrMODMask(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']),
+                               ccmod.ConvCnstrMODMask.Options({'MaxMainIter': 15, 'L': 50.0}))
+    c.solve()
+    assert rel_l2(c.getdict(), g['D']) < 1e-9
+    its = c.getitstat()
+    for f in ('DFid', 'Rsdl'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+    assert max(its.Cnstr) < 1e-12
