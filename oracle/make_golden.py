@@ -606,6 +606,15 @@ def gen_cns_options():
     Sck = np.random.randn(N, N, Nc, K)
     run('ccmod_cns_chk_multichan_f64', Zck, Sck, (Nd, Nd, 1, M),
         {'MaxMainIter': 12, 'LinSolveCheck': True})
+    # the mask-decoupled consensus update with LinSolveCheck (tests/admm/test_ccmodmd.py:258-413)
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    Wm = (np.random.rand(N, N, Nc, K) > 0.3).astype(np.float64)
+    mcls = ref_ccmodmd.ConvCnstrMODMaskDcpl_Consensus
+    c = mcls(Zck, Sck, Wm, (Nd, Nd, 1, M), mcls.Options({'MaxMainIter': 12, 'LinSolveCheck': True}))
+    c.solve()
+    save('ccmodmd_cns_chk_multichan_f64', Z=Zck, S=Sck, W=Wm, dsz=np.array((Nd, Nd, 1, M)),
+         D=c.getdict(), Y=c.Y, U=c.U, X=c.X, rho_final=np.float64(c.rho), k_final=np.int64(c.k),
+         **itstat_dict(c))
 
 
 def gen_ccmod_eq():

@@ -177,10 +177,9 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
             raise NotImplementedError("objective at the blocks X_n (AuxVarObj False): not with "
                                       "image shards (the mean of X runs over ALL images) and not "
                                       "with mask decoupling")
-        if opt['LinSolveCheck'] and (reducer is not None or self._mask_dcpl):
+        if opt['LinSolveCheck'] and reducer is not None:
             raise NotImplementedError("LinSolveCheck of the consensus D-step: not with image "
-                                      "shards (its residual is of sums over ALL images) and not "
-                                      "with mask decoupling")
+                                      "shards (its residual is of sums over ALL images)")
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
@@ -256,8 +255,11 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         if self.opt['LinSolveCheck']:
             # rrs(sum_n ax_n, sum_n b_n) (ccmod.py:783-792; linalg.rrs, linalg.py:1126-1153)
             s = self._sums
-            nrm = max(np.sqrt(s[_lib.OUT_XRRS_AX2]), np.sqrt(s[_lib.OUT_XRRS_B2]))
-            self.xrrs = np.sqrt(s[_lib.OUT_XRRS_D2]) / nrm if nrm > 0.0 else 0.0
+            # (the mask-decoupled call returns block-1 sums in the XRRS slots: csc_api.hip cns_md_iter)
+            d2, a2, b2 = (_lib.OUT_L1, _lib.OUT_RGR, _lib.OUT_CGN) if self._mask_dcpl else \
+                (_lib.OUT_XRRS_D2, _lib.OUT_XRRS_AX2, _lib.OUT_XRRS_B2)
+            nrm = max(np.sqrt(s[a2]), np.sqrt(s[b2]))
+            self.xrrs = np.sqrt(s[d2]) / nrm if nrm > 0.0 else 0.0
         if not self._needs_residuals():
             return None
         self.timer.stop('solve_wo_rsdl')

@@ -293,9 +293,17 @@ class ConvCnstrMODMaskDcpl_Consensus(ccmod.ConvCnstrMOD_Consensus):
             flags |= _lib.FLAG_RESID
         if not self.opt['FastSolve']:
             flags |= _lib.FLAG_OBJ
+        if self.opt['LinSolveCheck']:
+            flags |= _lib.FLAG_XRRS
         self._sums = self._device_iteration(flags)
         self._u_scale = 1.0
         self._cache.clear()
+        if self.opt['LinSolveCheck']:
+            # rrs(sum_n ax_n, sum_n b_n) of the consensus solve (admm/ccmod.py:783-792); the XRRS
+            # slots of this call carry block-1 sums, the three sums come back in L1 / RGR / CGN
+            s = self._sums
+            nrm = max(np.sqrt(s[_lib.OUT_RGR]), np.sqrt(s[_lib.OUT_CGN]))
+            self.xrrs = np.sqrt(s[_lib.OUT_L1]) / nrm if nrm > 0.0 else 0.0
         if not self._needs_residuals():
             return None
         self.timer.stop('solve_wo_rsdl')

@@ -2890,10 +2890,27 @@ template <typename T> struct Csc : CscBase {
             fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * P, 0, (int64_t)Wf * P, 0,
                        (int64_t)Wf * P, T(1));
         }
+        // LinSolveCheck (ccmod.py:783-792, as in cns_iter; the XRRS slots carry block-1 sums in
+        // this call, so the three sums go to the L1, RGR and CGN slots)
+        const bool lsc = p.flags & F_XRRS;
+        if (lsc) {
+            ProfScope ps(prof, PS_OTHER);
+            launch_cns_xrrs_rhs<T>(st, Zf, innerb, cns_f, T(1), dwork_buf(), npix, CN, K);
+        }
         {
             ProfScope ps(prof, PS_SM_SOLVE);
             launch_sm_solve<T>(st, cns_f, cns_f, Zf, innerb, nullptr, T(1), npix, CN, K, W, false,
                                false, part_a, nullptr, true);
+        }
+        if (lsc) {
+            int nbx;
+            {
+                ProfScope ps(prof, PS_OTHER);
+                nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, T(1), dwork_buf(), npix, CN, K, part_a);
+            }
+            const int xslots[3] = {SPORCO_AMD_OUT_L1, SPORCO_AMD_OUT_RGR, SPORCO_AMD_OUT_CGN};
+            const double xscales[3] = {1.0, 1.0, 1.0};
+            finalize(part_a, nbx, 3, 3, xslots, xscales, out_dev);
         }
         inv2(cns_f, wk, X, P);
         // relax_AX, block 1: AX1nr_n = irfftn(sum_m Zf_{n,m} Xf_{n,m}) -- the inner product of

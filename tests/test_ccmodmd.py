@@ -277,3 +277,22 @@ def test_masked_itersm_over_ten_images(backend):
     its = c.getitstat()
     for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-9, f
+
+
+def test_masked_consensus_linsolvecheck(backend):
+    """ConvCnstrMODMaskDcpl_Consensus with LinSolveCheck on a multi-channel signal (the
+    reference's own test shape, tests/admm/test_ccmodmd.py:258-330): iterates and statistics
+    against the reference, its X-step residual at rounding level on both sides."""
+    from sporco_amd.admm import ccmodmd
+    g = load_golden('ccmodmd_cns_chk_multichan_f64')
+    cls = ccmodmd.ConvCnstrMODMaskDcpl_Consensus
+    c = cls(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']),
+            cls.Options({'MaxMainIter': 12, 'LinSolveCheck': True}))
+    c.solve()
+    assert c.k == int(g['k_final'])
+    assert rel_l2(c.getdict(), g['D']) < 1e-9 and rel_l2(c.Y, g['Y']) < 1e-9
+    assert rel_l2(c.U, g['U']) < 1e-9 and rel_l2(c.X, g['X']) < 1e-9
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-9, f
+    assert max(its.XSlvRelRes) < 1e-10 and np.max(g['it_XSlvRelRes']) < 1e-10
