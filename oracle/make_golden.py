@@ -617,6 +617,32 @@ def gen_cns_options():
          **itstat_dict(c))
 
 
+def gen_cns_mcdict():
+    """ConvCnstrMOD_Consensus and ConvBPDNDictLearn(dmethod='cns') with a multi-channel (colour)
+    dictionary (sporco/admm/ccmod.py:696-698, :766-822: one block per image, the channels
+    share the image's system matrix; the reference's examples/scripts/cdl/cbpdndl_cns_clr.py)."""
+    np.random.seed(13531)
+    N, M, K, Nc, Nd = 16, 4, 3, 3, 5
+    cls = ref_admm_ccmod.ConvCnstrMOD_Consensus
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.6)
+    S = np.random.randn(N, N, Nc, K)
+    for name, optd in (('ccmod_cns_mcdict_f64', {'MaxMainIter': 12}),
+                       ('ccmod_cns_mcdict_opts_f64', {'MaxMainIter': 12, 'LinSolveCheck': True,
+                                                      'ZeroMean': True, 'AuxVarObj': False}),
+                       ('ccmod_cns_mcdict_f32', {'MaxMainIter': 12, 'DataType': np.float32})):
+        c = cls(Z, S, (Nd, Nd, Nc, M), cls.Options(optd))
+        c.solve()
+        save(name, Z=Z, S=S, dsz=np.array((Nd, Nd, Nc, M)), D=c.getdict(), Y=c.Y, U=c.U, X=c.X,
+             rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+    D0 = np.random.randn(Nd, Nd, Nc, M)
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                                xmethod='admm', dmethod='cns')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod='cns')
+    D1 = b.solve()
+    save('cbpdndl_cns_mcdict_f64', D0=D0, S=S, lmbda=np.float64(0.1), D1=D1, X=b.getcoef(),
+         **itstat_dict(b))
+
+
 def gen_ccmod_eq():
     """Single-copy ADMM dictionary updates ConvCnstrMOD_IterSM and ConvCnstrMOD_CG
     (sporco/admm/ccmod.py:433-601 on ConvCnstrMODBase :103-429) alone and inside
@@ -1099,8 +1125,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -430,6 +430,9 @@ class Solver(object):
             return (H, W, self.Cd, 1, K), self.dtype
         if VAR_DXF <= var <= VAR_DT2:
             return (H, Wf, self.Cd, 1, K), self.cdtype
+        if var in (VAR_CX, VAR_CU) and self.Cd > 1:
+            # consensus copies of a multi-channel dictionary: one (Cd, K) block per image
+            return (H, W, N, self.Cd, K), self.dtype
         return (H, W, C, N, K), self.dtype
 
     # -- set-up -----------------------------------------------------------
@@ -658,7 +661,7 @@ class Solver(object):
             check(self._lib.sporco_amd_csc_cns_init(self._h, None, float(rho)))
             return
         H, W, C, N, K = self.dims
-        Y0 = _carr(Y0, self.dtype).reshape(H, W, K)
+        Y0 = _carr(Y0, self.dtype).reshape(H, W, self.Cd, K)
         check(self._lib.sporco_amd_csc_cns_init(self._h, _ptr(Y0), float(rho)))
 
     def cns_md_init(self, S):

@@ -42,9 +42,28 @@ class _DeviceDStep(object):
         into the image axis for a single-channel dictionary, ccmod.py:695-699, :702-706) and
         ``self.dev``."""
         H, W = self.cri.Nv
+        self._shared = dev is not None
+        if self.cri.Cd > 1:
+            # multi-channel dictionary (consensus update only): S keeps its channels, the
+            # coefficient maps have none, one consensus block per image (ccmod.py:696-698)
+            self.Nb = self.cri.K
+            self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
+            if dev is None:
+                self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
+                                       device=device, stream=stream, Cd=self.cri.Cd)
+                self.dev.set_signal(self.S)
+            else:
+                if (dev.dims[:2] + (dev.Cs,) + dev.dims[3:]) != (H, W, self.cri.C, self.cri.K,
+                                                                  self.cri.M) \
+                        or dev.Cd != self.cri.Cd or dev.dtype != self.dtype:
+                    raise ValueError("shared device solver has different dimensions")
+                self.dev = dev
+            self._cache = {}
+            self._u_scale = 1.0
+            self._sums = [0.0] * _lib.OUT_COUNT
+            return
         self.Nb = self.cri.C * self.cri.K
         self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
-        self._shared = dev is not None
         if dev is None:
             self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
                                    device=device, stream=stream)
@@ -76,6 +95,7 @@ class _DeviceDStep(object):
 
     def setcoef(self, Z):
         """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:311-327, :746-755)."""
+        # (multi-channel dictionary: Nb = K and the maps have no channel axis, same reshape)
         self.Z = np.asarray(np.asarray(Z).reshape(self.cri.Nv + (1, self.Nb, self.cri.M)),
                             dtype=self.dtype)
         self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
@@ -170,9 +190,9 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd > 1:
-            raise NotImplementedError("multi-channel dictionaries are not part of the "
-                                      "sporco_amd dictionary update")
+        if self.cri.Cd > 1 and (self._mask_dcpl or reducer is not None):
+            raise NotImplementedError("a multi-channel dictionary in the consensus update: not "
+                                      "with mask decoupling or image shards")
         if (not opt['gEvalY'] or opt['fEvalX']) and (reducer is not None or self._mask_dcpl):
             raise NotImplementedError("objective at the blocks X_n (AuxVarObj False): not with "
                                       "image shards (the mean of X runs over ALL images) and not "
@@ -207,11 +227,16 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
 
     def _from_blocks(self, a):
         """Device layout (H, W, C, K, M) -> the reference's (H, W, 1, 1, M, Nb): the channels of
-        a multi-channel signal count as images (Nb = C K, channel-major: ccmod.py:757-765)."""
+        a multi-channel signal count as images (Nb = C K, channel-major: ccmod.py:757-765).
+        Multi-channel dictionary: device (H, W, K, Cd, M) -> (H, W, Cd, 1, M, Nb = K)."""
+        if self.cri.Cd > 1:
+            return np.ascontiguousarray(np.moveaxis(a, 2, -1)[:, :, :, np.newaxis])
         a = a.reshape(a.shape[0], a.shape[1], 1, -1, a.shape[-1])
         return np.ascontiguousarray(np.moveaxis(a, 3, -1)[:, :, :, np.newaxis])
 
     def _to_blocks(self, a):
+        if self.cri.Cd > 1:
+            return np.ascontiguousarray(np.moveaxis(np.asarray(a)[:, :, :, 0], -1, 2))
         a = np.moveaxis(np.asarray(a)[:, :, :, 0], -1, 3)          # (H, W, 1, Nb, M)
         return np.ascontiguousarray(a.reshape(a.shape[0], a.shape[1], self.cri.C, -1, a.shape[-1]))
 

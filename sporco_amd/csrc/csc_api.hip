@@ -517,7 +517,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar,
-                        (void *)part_c2r})
+                        (void *)part_c2r, (void *)cns_w, (void *)cns_sft})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)ccmod_r, (void *)pgm_ey, (void *)gpart,
@@ -548,6 +548,8 @@ template <typename T> struct Csc : CscBase {
         if (var_is_dict_sized(var))
             return var_is_complex(var) ? sizeof(cx<T>) * npix * KD()
                                        : sizeof(T) * (int64_t)H * W * KD();
+        // (consensus copies of a multi-channel dictionary: one (Cd, K) block per image)
+        if (var == SPORCO_AMD_VAR_CX || var == SPORCO_AMD_VAR_CU) return sizeof(T) * E * Cd;
         return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
     }
 
@@ -2811,36 +2813,45 @@ template <typename T> struct Csc : CscBase {
     }
 
     // ---- ADMM consensus dictionary update -------------------------------------------------
+    // Multi-channel dictionary (Cd > 1; admm/ccmod.py:696-698, :766-822): one dictionary copy
+    // (H, W, Cd, K) per image -- blocks laid out (H, W, N, Cd, K), so that every kernel below
+    // sees N blocks of KD() = Cd K "filters" -- whose Cd channels share the image's matrix in
+    // the per-image solve (launch_sm_solve per_grp = Cd, the signal spectrum transposed to
+    // (npix, N, Cd) to follow the systems).  Generic chain only.
     void cns_init(const void *Y0, double rho) override {
-        require_single_channel_dict();
         SA_REQUIRE(rho != 0.0, "rho must be nonzero");
         cns_active = true;
         T *Y = rv(SPORCO_AMD_VAR_DX), *U = rv(SPORCO_AMD_VAR_CU);
         (void)rv(SPORCO_AMD_VAR_CX);
-        SA_HIP(hipMemsetAsync(U, 0, sizeof(T) * E, st));
+        SA_HIP(hipMemsetAsync(U, 0, sizeof(T) * E * Cd, st));
         if (Y0) {
             host_copy(SPORCO_AMD_VAR_DX, const_cast<void *>(Y0), true);
             // U_n = Y0 / rho for every image: 0 - (-1/rho) * Y through the Y - s U kernel
             ProfScope ps(prof, PS_OTHER);
-            launch_cns_yu<T>(st, Y, U, U, T(0), (int64_t)H * W, CN, K);
-            launch_scale<T>(st, U, (T)(1.0 / rho), E);
+            launch_cns_yu<T>(st, Y, U, U, T(0), (int64_t)H * W, CN, (int)KD());
+            launch_scale<T>(st, U, (T)(1.0 / rho), E * Cd);
         } else {
             SA_HIP(hipMemsetAsync(Y, 0, var_bytes(SPORCO_AMD_VAR_DX), st));
         }
-        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), KD());
         sync();
     }
 
+    cx<T> *cns_w = nullptr, *cns_sft = nullptr;   // Cd > 1: column-pass scratch, transposed Sf
     void cns_buffers() {
         if (cns_f) return;
         const int64_t npixr = (int64_t)H * W;
-        SA_HIP(hipMalloc((void **)&cns_f, sizeof(cx<T>) * EF));
-        SA_HIP(hipMalloc((void **)&cns_m, sizeof(T) * npixr * K));
-        SA_HIP(hipMalloc((void **)&cns_yold, sizeof(T) * npixr * K));
+        SA_HIP(hipMalloc((void **)&cns_f, sizeof(cx<T>) * EF * Cd));
+        SA_HIP(hipMalloc((void **)&cns_m, sizeof(T) * npixr * KD()));
+        SA_HIP(hipMalloc((void **)&cns_yold, sizeof(T) * npixr * KD()));
+        if (Cd > 1) {
+            SA_HIP(hipMalloc((void **)&cns_w, sizeof(cx<T>) * EF * Cd));
+            SA_HIP(hipMalloc((void **)&cns_sft, sizeof(cx<T>) * npix * CNs));
+        }
     }
     void *cns_mean_ptr(int64_t *count) override {
         cns_buffers();
-        *count = (int64_t)H * W * K;
+        *count = (int64_t)H * W * KD();
         return cns_m;
     }
 
@@ -3021,7 +3032,7 @@ template <typename T> struct Csc : CscBase {
     }
 
     void cns_iter(const sporco_amd_cns_params &p, double *out_dev) override {
-        require_single_channel_dict();
+        if (p.mask_dcpl) require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         SA_REQUIRE(p.phase >= 0 && p.phase <= 2, "phase must be 0, 1 or 2");
@@ -3032,7 +3043,9 @@ template <typename T> struct Csc : CscBase {
         // LinSolveCheck (F_XRRS; a diagnostic): the generic chain, whose solve sees the
         // right-hand sides in the natural layout
         const bool lsc = p.flags & F_XRRS;
-        const bool fusedx = cns_fused() && !lsc;
+        const bool fusedx = cns_fused() && !lsc && Cd == 1;
+        const int KDi = (int)KD();              // "filters" of a consensus block: Cd K
+        const int64_t PD = P * Cd;              // columns of the blocks' spectra: N Cd K
         // objective at the consensus variable Y (FLAG_FEVAL_Y / FLAG_GEVAL_Y: AuxVarObj, the
         // class default) or at the blocks X_n (fEvalX: admm/ccmod.py:870-889) and their mean
         // (gEvalY False: admm/admm.py:1641-1646)
@@ -3104,23 +3117,30 @@ template <typename T> struct Csc : CscBase {
         } else {
         {
             ProfScope ps(prof, PS_FFT_R2C);
-            fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, cns_f, H, P, (int64_t)W * P, P,
-                       (int64_t)Wf * P, P, 0, 0, K);
+            fft_r2c<T>(st, planW, Y, U, (T)p.u_scale, cns_f, H, PD, (int64_t)W * PD, PD,
+                       (int64_t)Wf * PD, PD, 0, 0, KDi);
         }
         {
             ProfScope ps(prof, PS_FFT_C2C_FWD);
-            fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * P, 0, (int64_t)Wf * P, 0,
-                       (int64_t)Wf * P, T(1));
+            fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * PD, 0, (int64_t)Wf * PD, 0,
+                       (int64_t)Wf * PD, T(1));
+        }
+        // the right-hand sides' signal term follows the systems: (npix, N) -- or (npix, N, Cd)
+        const cx<T> *sfs = cv(SPORCO_AMD_VAR_SF);
+        if (Cd > 1) {
+            ProfScope ps(prof, PS_OTHER);
+            launch_swap_inner<T>(st, cv(SPORCO_AMD_VAR_SF), cns_sft, npix, Cd, N);
+            sfs = cns_sft;
         }
         if (lsc) {
             ProfScope ps(prof, PS_OTHER);
-            launch_cns_xrrs_rhs<T>(st, Zf, cv(SPORCO_AMD_VAR_SF), cns_f, (T)p.rho, dwork_buf(), npix, CN, K);
+            launch_cns_xrrs_rhs<T>(st, Zf, sfs, cns_f, (T)p.rho, dwork_buf(), npix, CN * Cd, K, Cd);
         }
         int nbs;
         {   // (the per-image gram sum_k |Zf|^2 is formed inside the kernel)
             ProfScope ps(prof, PS_SM_SOLVE);
-            nbs = launch_sm_solve<T>(st, cns_f, cns_f, Zf, cv(SPORCO_AMD_VAR_SF), nullptr, (T)p.rho, npix,
-                                     CN, K, W, dfid_x, false, part_a, nullptr, true);
+            nbs = launch_sm_solve<T>(st, cns_f, cns_f, Zf, sfs, nullptr, (T)p.rho, npix, CN * Cd, K, W,
+                                     dfid_x, false, part_a, nullptr, Cd);
         }
         if (dfid_x) {
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
@@ -3131,19 +3151,20 @@ template <typename T> struct Csc : CscBase {
             int nbx;
             {
                 ProfScope ps(prof, PS_OTHER);
-                nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, (T)p.rho, dwork_buf(), npix, CN, K, part_a);
+                nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, (T)p.rho, dwork_buf(), npix, CN * Cd, K, part_a,
+                                             Cd);
             }
             const int xslots[3] = {SPORCO_AMD_OUT_XRRS_D2, SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
             const double xscales[3] = {1.0, 1.0, 1.0};
             finalize(part_a, nbx, 3, 3, xslots, xscales, out_dev);
         }
-        inv2(cns_f, work_buf(), X, P);
+        inv2(cns_f, Cd > 1 ? cns_w : work_buf(), X, PD);
         }
         // relax + ystep: Y = Pcn(mean_n(alpha X_n + (1 - alpha) Y + U_n))
-        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * K, hipMemcpyDeviceToDevice, st));
+        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * KDi, hipMemcpyDeviceToDevice, st));
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, (T)p.u_scale, npixr, CN, K);
+            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, (T)p.u_scale, npixr, CN, KDi);
         }
         }   // phase != 2
         if (p.phase == 1) return;
@@ -3152,7 +3173,7 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_ADMM_POST);
-            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, (T)p.u_scale, npixr, CN, K,
+            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, (T)p.u_scale, npixr, CN, KDi,
                                      part_b);
         }
         {
@@ -3162,7 +3183,7 @@ template <typename T> struct Csc : CscBase {
         }
         {
             ProfScope ps(prof, PS_OTHER);
-            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * K, part_a);
+            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * KDi, part_a);
         }
         {
             const int slots[2] = {SPORCO_AMD_OUT_S2, SPORCO_AMD_OUT_Y2};
@@ -3170,7 +3191,7 @@ template <typename T> struct Csc : CscBase {
             finalize(part_a, nb, 2, 2, slots, scales, out_dev);
         }
         // the consensus dictionary's spectrum (for the objective, getdict / setdict_from_dstep)
-        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), KDi);
         if (p.flags & F_OBJ) {
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
             const double scales[1] = {1.0 / ((double)H * W)};
@@ -3204,7 +3225,7 @@ template <typename T> struct Csc : CscBase {
                 {
                     ProfScope ps(prof, PS_OTHER);
                     nb = launch_ccmod_grad<T>(st, Zf, cv(SPORCO_AMD_VAR_DXF), cv(SPORCO_AMD_VAR_SF),
-                                              nullptr, npix, CN, K, W, part_a);
+                                              nullptr, npix, CN, K, W, part_a, Cd);
                 }
                 finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
             }
@@ -3212,14 +3233,14 @@ template <typename T> struct Csc : CscBase {
             const T *gv = Y;
             if (cns_x) {      // g is evaluated at mean_n(X_n)
                 ProfScope ps(prof, PS_OTHER);
-                launch_cns_mean<T>(st, X, U, cns_yold, cns_m, T(1), T(0), npixr, CN, K);
+                launch_cns_mean<T>(st, X, U, cns_yold, cns_m, T(1), T(0), npixr, CN, KDi);
                 gv = cns_m;
             }
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0, Cd);
                 nbc = launch_pcn_apply<T>(st, gv, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
-                                          Ku);
+                                          Ku, Cd);
             }
             const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
             const double cscales[1] = {1.0};

@@ -66,9 +66,10 @@ template <typename T>
 int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                     const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
                     bool want_obj, bool want_xrrs, double *partials,
-                    const GradTerm<T> *grad = nullptr, bool per_grp = false);
-// (per_grp: df is (npix, CN, K) and gram (npix, CN) -- one rank-one term per (pixel, cn), the
-// consensus dictionary update's per-image systems, admm/ccmod.py:766-778)
+                    const GradTerm<T> *grad = nullptr, int per_grp = 0);
+// (per_grp = d > 0: df is (npix, CN / d, K) -- one rank-one term per d consecutive systems of a
+// pixel: d = 1 the consensus dictionary update's per-image systems, admm/ccmod.py:766-778;
+// d = Cd the same with a multi-channel dictionary, whose channels share the image's matrix)
 // partial[block] = Parseval-weighted sum of wg GHGf |vf|^2 (RegGrad at an arbitrary spectrum)
 template <typename T>
 int launch_grad_norm(hipStream_t st, const cx<T> *vf, const GradTerm<T> &g, int64_t npix, int CN,
@@ -250,12 +251,18 @@ int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, d
 //   fin  (after it):         asum = sum_n (conj(zf) <zf, xf> + rho xf); partials (3) =
 //                            |asum - bsum|^2, |asum|^2, |bsum|^2 summed over (pix, k).
 // zf, yuf / xf: (npix, CN, K); sf: (npix, CN); bsum: (npix, K).  K <= 256.
+// Cd > 1 (multi-channel dictionary): the CN systems of a pixel are (image, channel) pairs,
+// channel fastest, sharing the image's zf row (npix, CN / Cd, K); sf (npix, CN / Cd, Cd); bsum
+// (npix, Cd, K).
 template <typename T>
 void launch_cns_xrrs_rhs(hipStream_t st, const cx<T> *zf, const cx<T> *sf, const cx<T> *yuf, T rho,
-                         cx<T> *bsum, int64_t npix, int CN, int K);
+                         cx<T> *bsum, int64_t npix, int CN, int K, int Cd = 1);
 template <typename T>
 int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho, const cx<T> *bsum,
-                        int64_t npix, int CN, int K, double *partials);
+                        int64_t npix, int CN, int K, double *partials, int Cd = 1);
+// dst[r, b, a] = src[r, a, b]
+template <typename T>
+void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t rows, int A, int B);
 
 // Multi-channel dictionary (Cd > 1) X-step, linalg.solvemdbi_ism (linalg.py:370-444):
 // gam(npix, Cd, K), del(npix, Cd), mm(npix, Cd, Cd) hold the recursion's gamma / delta and the

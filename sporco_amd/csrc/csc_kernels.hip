@@ -92,7 +92,9 @@ template <typename T> struct SmArgs {
     int want_obj, want_xrrs;
     double *partials;
     GradTerm<T> g;
-    int per_grp;   // df is (npix, CN, K) and gram (npix, CN): one system matrix per (pixel, cn)
+    int per_grp;   // d > 0: df is (npix, CN / d, K) -- one system matrix per d consecutive systems of
+                   // a pixel (d = 1: per (pixel, cn); d = Cd: the consensus update of a multi-channel
+                   // dictionary, whose channels share the image's matrix); gram formed in the kernel
 };
 
 __device__ __forceinline__ double parseval_weight(int wf, int Wf, int W) {
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
         T gwa = T(0), gwb = T(0);
         if (valid) {
             yu = *reinterpret_cast<const cxpair<T> *>(a.yuf + 2 * t);
-            d = *reinterpret_cast<const cxpair<T> *>(a.df + (a.per_grp ? grp : pix) * a.K + 2 * lg);
+            d = *reinterpret_cast<const cxpair<T> *>(a.df + (a.per_grp ? grp / a.per_grp : pix) * a.K + 2 * lg);
             s = a.sf[grp];
             if constexpr (GRAD) {
                 const T gh = grad_gh(a.g, pix, a.Wf);
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs
     for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
          grp += (int64_t)gridDim.x * blockDim.x) {
         const int64_t pix = grp / a.CN;
-        const cx<T> *d = a.df + (a.per_grp ? grp : pix) * a.K;
+        const cx<T> *d = a.df + (a.per_grp ? grp / a.per_grp : pix) * a.K;
         const cx<T> *yu = a.yuf + grp * a.K;
         cx<T> *x = a.xf + grp * a.K;
         const cx<T> s = a.sf[grp];
@@ -286,9 +288,9 @@ template <typename T>
 int launch_sm_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *df,
                     const cx<T> *sf, const T *gram, T rho, int64_t npix, int CN, int K, int W,
                     bool want_obj, bool want_xrrs, double *partials, const GradTerm<T> *grad,
-                    bool per_grp) {
+                    int per_grp) {
     SmArgs<T> a;
-    a.per_grp = per_grp ? 1 : 0;
+    a.per_grp = per_grp;
     a.yuf = yuf;
     a.xf = xf;
     a.df = df;
@@ -1831,27 +1833,32 @@ __global__ void __launch_bounds__(kThreads) cns_xrrs_rhs_kernel(const cx<T> *__r
                                                                 const cx<T> *__restrict__ sf,
                                                                 const cx<T> *__restrict__ yuf, T rho,
                                                                 cx<T> *__restrict__ bsum, int64_t npix,
-                                                                int CN, int K) {
+                                                                int CN, int K, int Cd) {
+    // (Cd > 1: the CN systems of a pixel are (image, channel) pairs, channel fastest, sharing the
+    // image's zf row; one wave per (pixel, channel), bsum (npix, Cd, K))
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
-    for (int64_t pix = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pix < npix;
-         pix += nwaves) {
+    const int NI = CN / Cd;
+    for (int64_t pc = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pc < npix * Cd;
+         pc += nwaves) {
+        const int64_t pix = pc / Cd;
+        const int c = (int)(pc - pix * Cd);
         cx<T> b[KR];
 #pragma unroll
         for (int j = 0; j < KR; ++j) b[j] = mk<T>(T(0), T(0));
-        for (int n = 0; n < CN; ++n) {
-            const int64_t row = (pix * CN + n) * K;
-            const cx<T> s = sf[pix * CN + n];
+        for (int n = 0; n < NI; ++n) {
+            const int64_t zrow = (pix * NI + n) * K, row = ((pix * NI + n) * Cd + c) * K;
+            const cx<T> s = sf[(pix * NI + n) * Cd + c];
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
                 const int k = lane + kWave * j;
-                if (k < K) b[j] = b[j] + cmulc(zf[row + k], s) + cscale(yuf[row + k], rho);
+                if (k < K) b[j] = b[j] + cmulc(zf[zrow + k], s) + cscale(yuf[row + k], rho);
             }
         }
 #pragma unroll
         for (int j = 0; j < KR; ++j) {
             const int k = lane + kWave * j;
-            if (k < K) bsum[pix * K + k] = b[j];
+            if (k < K) bsum[pc * K + k] = b[j];
         }
     }
 }
@@ -1861,35 +1868,38 @@ __global__ void __launch_bounds__(kThreads) cns_xrrs_fin_kernel(const cx<T> *__r
                                                                 const cx<T> *__restrict__ xf, T rho,
                                                                 const cx<T> *__restrict__ bsum,
                                                                 int64_t npix, int CN, int K,
-                                                                double *partials) {
+                                                                double *partials, int Cd) {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    const int NI = CN / Cd;
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int64_t pix = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pix < npix;
-         pix += nwaves) {
+    for (int64_t pc = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pc < npix * Cd;
+         pc += nwaves) {
+        const int64_t pix = pc / Cd;
+        const int c = (int)(pc - pix * Cd);
         cx<T> a[KR];
 #pragma unroll
         for (int j = 0; j < KR; ++j) a[j] = mk<T>(T(0), T(0));
-        for (int n = 0; n < CN; ++n) {
-            const int64_t row = (pix * CN + n) * K;
+        for (int n = 0; n < NI; ++n) {
+            const int64_t zrow = (pix * NI + n) * K, row = ((pix * NI + n) * Cd + c) * K;
             cx<T> q = mk<T>(T(0), T(0));
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
                 const int k = lane + kWave * j;
-                if (k < K) q = q + cmul(zf[row + k], xf[row + k]);
+                if (k < K) q = q + cmul(zf[zrow + k], xf[row + k]);
             }
             q = wave_sum_cx(q);
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
                 const int k = lane + kWave * j;
-                if (k < K) a[j] = a[j] + cmulc(zf[row + k], q) + cscale(xf[row + k], rho);
+                if (k < K) a[j] = a[j] + cmulc(zf[zrow + k], q) + cscale(xf[row + k], rho);
             }
         }
 #pragma unroll
         for (int j = 0; j < KR; ++j) {
             const int k = lane + kWave * j;
             if (k < K) {
-                const cx<T> b = bsum[pix * K + k];
+                const cx<T> b = bsum[pc * K + k];
                 acc[0] += (double)cabs2(a[j] - b);
                 acc[1] += (double)cabs2(a[j]);
                 acc[2] += (double)cabs2(b);
@@ -2036,27 +2046,48 @@ template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
 
 template <typename T>
 void launch_cns_xrrs_rhs(hipStream_t st, const cx<T> *zf, const cx<T> *sf, const cx<T> *yuf, T rho,
-                         cx<T> *bsum, int64_t npix, int CN, int K) {
-    const int grid = grid_for(npix * kWave);
+                         cx<T> *bsum, int64_t npix, int CN, int K, int Cd) {
+    const int grid = grid_for(npix * Cd * kWave);
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
         hipLaunchKernelGGL((cns_xrrs_rhs_kernel<T, KR>), dim3(grid), dim3(kThreads), 0, st, zf, sf, yuf, rho,
-                           bsum, npix, CN, K);
+                           bsum, npix, CN, K, Cd);
     });
     SA_HIP(hipGetLastError());
 }
 template <typename T>
 int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho, const cx<T> *bsum,
-                        int64_t npix, int CN, int K, double *partials) {
-    const int grid = std::min(grid_for(npix * kWave), kMaxPartialBlocks);
+                        int64_t npix, int CN, int K, double *partials, int Cd) {
+    const int grid = std::min(grid_for(npix * Cd * kWave), kMaxPartialBlocks);
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
         hipLaunchKernelGGL((cns_xrrs_fin_kernel<T, KR>), dim3(grid), dim3(kThreads),
                            sizeof(double) * 3 * (kThreads / kWave), st, zf, xf, rho, bsum, npix, CN, K,
-                           partials);
+                           partials, Cd);
     });
     SA_HIP(hipGetLastError());
     return grid;
+}
+
+// dst[r, b, a] = src[r, a, b]: the two inner axes of a small array swapped (a signal spectrum
+// (npix, Cd, N) -> (npix, N, Cd))
+template <typename T>
+__global__ void __launch_bounds__(kThreads) swap_inner_kernel(const cx<T> *__restrict__ src,
+                                                              cx<T> *__restrict__ dst, int64_t rows,
+                                                              int A, int B) {
+    const int64_t total = rows * A * B;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i % B), a = (int)((i / B) % A);
+        const int64_t r = i / ((int64_t)A * B);
+        dst[(r * B + b) * A + a] = src[i];
+    }
+}
+template <typename T>
+void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t rows, int A, int B) {
+    hipLaunchKernelGGL((swap_inner_kernel<T>), dim3(grid_for(rows * A * B)), dim3(kThreads), 0, st, src, dst,
+                       rows, A, B);
+    SA_HIP(hipGetLastError());
 }
 
 template <typename T>
@@ -3052,7 +3083,7 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
                                      int, int, double *);                                          \
     template int launch_sm_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,            \
                                     const cx<T> *, const T *, T, int64_t, int, int, int, bool,     \
-                                    bool, double *, const GradTerm<T> *, bool);                    \
+                                    bool, double *, const GradTerm<T> *, int);                     \
     template void launch_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,     \
                                   int, int);                                                       \
     template int launch_rfl2norm2<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int64_t,  \
@@ -3107,9 +3138,10 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
                                      int64_t, int, int, double *);                                 \
     template int launch_cns_ystats<T>(hipStream_t, const T *, const T *, int64_t, double *);       \
     template void launch_cns_xrrs_rhs<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, \
-                                         T, cx<T> *, int64_t, int, int);                          \
+                                         T, cx<T> *, int64_t, int, int, int);                     \
     template int launch_cns_xrrs_fin<T>(hipStream_t, const cx<T> *, const cx<T> *, T,              \
-                                        const cx<T> *, int64_t, int, int, double *);               \
+                                        const cx<T> *, int64_t, int, int, double *, int);          \
+    template void launch_swap_inner<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int);    \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
                                       int64_t, int, int, T, const GradTerm<T> *, int);             \
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \

@@ -167,3 +167,54 @@ def test_consensus_options(backend, name):
         assert max(its.XSlvRelRes) < 1e-10 and np.max(g['it_XSlvRelRes']) < 1e-10
     else:
         assert all(v is None for v in its.XSlvRelRes)
+
+
+MCDICT_CASES = {
+    'ccmod_cns_mcdict_f64': {'MaxMainIter': 12},
+    'ccmod_cns_mcdict_opts_f64': {'MaxMainIter': 12, 'LinSolveCheck': True, 'ZeroMean': True,
+                                  'AuxVarObj': False},
+    'ccmod_cns_mcdict_f32': {'MaxMainIter': 12, 'DataType': np.float32},
+}
+
+
+@pytest.mark.parametrize('name', sorted(MCDICT_CASES))
+def test_consensus_multichannel_dictionary(backend, name):
+    """The consensus update of a colour dictionary (Cd = C = 3): one (Cd, M) block per image,
+    whose channels share the image's system matrix (sporco/admm/ccmod.py:696-698, :766-822).
+    Fixtures of oracle/make_golden.py gen_cns_mcdict (the unmodified reference)."""
+    from sporco_amd.admm import ccmod
+    g = load_golden(name)
+    optd = dict(MCDICT_CASES[name])
+    f32 = optd.get('DataType') is np.float32
+    tol = 3e-4 if f32 else 1e-9
+    c = ccmod.ConvCnstrMOD_Consensus(g['Z'], g['S'], tuple(int(v) for v in g['dsz']),
+                                     ccmod.ConvCnstrMOD_Consensus.Options(optd))
+    Y = c.solve()
+    assert c.k == int(g['k_final'])
+    assert Y.shape == g['Y'].shape and rel_l2(Y, g['Y']) < tol
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    assert c.X.shape == g['X'].shape and rel_l2(c.X, g['X']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < (1e-4 if f32 else 1e-11)
+    if optd.get('LinSolveCheck'):
+        assert max(its.XSlvRelRes) < 1e-10
+
+
+def test_dictlearn_consensus_colour_dictionary(backend):
+    """ConvBPDNDictLearn(dmethod='cns') learning a colour dictionary (the reference's
+    examples/scripts/cdl/cbpdndl_cns_clr.py in miniature)."""
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden('cbpdndl_cns_mcdict_f64')
+    opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                            xmethod='admm', dmethod='cns')
+    d = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], float(g['lmbda']), opt, xmethod='admm',
+                                  dmethod='cns')
+    D1 = d.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(d.getcoef(), g['X']) < 1e-9
+    its = d.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XDlRsdl', 'DPrRsdl', 'DDlRsdl', 'DRho'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
