@@ -213,6 +213,13 @@ int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64
  * sporco/admm/cbpdn.py:1063-1071, :1134-1139): K values of the handle's dtype;
  * w == NULL restores the scalar weight 1. */
 int sporco_amd_csc_set_grad_weight(sporco_amd_csc_t h, const void *w);
+/* Multi-scale dictionary (a `dsz` made of size blocks, sporco/cnvrep.py:729-812: e.g.
+ * ((8, 8, 32), (12, 12, 32), (16, 16, 32))): the support (rows fh[k], columns fw[k]) of each of
+ * the K filters for every constraint projection this handle makes (cnvrep.Pcn: crop, zero mean
+ * and norm over the filter's own support, cnvrep.py:634-662, :868-913).  The dH / dW arguments of
+ * the dictionary-update calls then name the largest support (what bcrop returns).  NULL, NULL
+ * returns to one support for all filters. */
+int sporco_amd_csc_set_filter_sizes(sporco_amd_csc_t h, const int32_t *fh, const int32_t *fw);
 /* Mask of the additive-mask-simulation wrapper (AddMaskSim, sporco/admm/cbpdn.py:2287-2485):
  * broadcastable against (H,W,C,N,1), shape[4] must be 1.  With SPORCO_AMD_FLAG_AMS the last
  * filter of the dictionary is taken to be the appended impulse (:2345-2353); its slice of Y

@@ -1100,6 +1100,42 @@ def gen_mask_mcdict():
          **itstat_dict(c))
 
 
+def gen_multiscale():
+    """Multi-scale dictionaries (a `dsz` of size blocks: cnvrep.bcrop / zeromean / Pcn,
+    sporco/cnvrep.py:609-670, :729-817, :868-913) in the dictionary updates and in dictionary
+    learning -- the reference's examples/scripts/cdl/cbpdndl_pgm_clr.py learns a multi-scale
+    colour dictionary through the DictSize option."""
+    np.random.seed(424242)
+    N, M, K, C = 16, 8, 2, 3
+    dsz = ((4, 4, 3), (6, 6, 2), (8, 8, 3))
+    v = np.random.randn(N, N, 1, 1, M)
+    save('cnvrep_multiscale', v=v, dsz=np.array(dsz), bcrop=ref_cnvrep.bcrop(v, dsz),
+         zeromean=ref_cnvrep.zeromean(v, dsz),
+         pcn=ref_cnvrep.Pcn(v, dsz, (N, N), 2, 1, crp=False, zm=True),
+         pcn_crop=ref_cnvrep.Pcn(v, dsz, (N, N), 2, 1, crp=True, zm=False))
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.6)
+    S = np.random.randn(N, N, K)
+    c = ref_pgm_ccmod.ConvCnstrMOD(Z, S, dsz, ref_pgm_ccmod.ConvCnstrMOD.Options(
+        {'MaxMainIter': 15, 'ZeroMean': True, 'L': 50.0}))
+    c.solve()
+    save('pgm_ccmod_multiscale_f64', Z=Z, S=S, dsz=np.array(dsz), D=c.getdict(), **itstat_dict(c))
+    c = ref_admm_ccmod.ConvCnstrMOD_Consensus(Z, S, dsz, ref_admm_ccmod.ConvCnstrMOD_Consensus.Options(
+        {'MaxMainIter': 12}))
+    c.solve()
+    save('ccmod_cns_multiscale_f64', Z=Z, S=S, dsz=np.array(dsz), D=c.getdict(), Y=c.Y,
+         **itstat_dict(c))
+    dszc = ((4, 4, C, 3), (6, 6, C, 2), (8, 8, C, 3))
+    D0 = np.random.randn(8, 8, C, M)
+    Sc = np.random.randn(N, N, C, K)
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+        {'MaxMainIter': 8, 'DictSize': dszc, 'CBPDN': {'L': 50.0}, 'CCMOD': {'L': 50.0}},
+        xmethod='pgm', dmethod='pgm')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, Sc, 0.1, opt, xmethod='pgm', dmethod='pgm')
+    D1 = b.solve()
+    save('cbpdndl_multiscale_clr_f64', D0=D0, S=Sc, dsz=np.array(dszc), lmbda=np.float64(0.1), D1=D1,
+         X=b.getcoef(), **itstat_dict(b))
+
+
 def gen_ams():
     """AddMaskSim (sporco/admm/cbpdn.py:2287-2485) around ConvBPDN, ConvBPDNJoint and
     ConvBPDNGradReg: SURVEY.md 8(f) rank 1."""
@@ -1125,8 +1161,8 @@ def gen_ams():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

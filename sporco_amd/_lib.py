@@ -70,7 +70,7 @@ EXPORTS = (
     'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
     'sporco_amd_csc_ccmod_getdict', 'sporco_amd_csc_setdict_from_dstep', 'sporco_amd_csc_asum',
-    'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter', 'sporco_amd_csc_cns_md_init', 'sporco_amd_csc_cns_mean_ptr',
+    'sporco_amd_csc_set_filter_sizes', 'sporco_amd_csc_cns_init', 'sporco_amd_csc_cns_iter', 'sporco_amd_csc_cns_md_init', 'sporco_amd_csc_cns_mean_ptr',
     'sporco_amd_csc_dstep_init', 'sporco_amd_csc_dstep_iter', 'sporco_amd_csc_ccmod_sgd_step',
     'sporco_amd_csc_mdcpl_init', 'sporco_amd_csc_mdcpl_iter', 'sporco_amd_csc_dstep_md_init',
     'sporco_amd_csc_set_data_mask', 'sporco_amd_csc_masked_grad',
@@ -228,6 +228,8 @@ def load(path=None):
         'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_l21_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_grad_weight': [vp, vp],
+        'sporco_amd_csc_set_filter_sizes': [vp, ctypes.POINTER(ctypes.c_int32),
+                                            ctypes.POINTER(ctypes.c_int32)],
         'sporco_amd_csc_set_ams_mask': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_upload': [vp, ctypes.c_int, vp],
         'sporco_amd_csc_download': [vp, ctypes.c_int, vp],
@@ -493,6 +495,18 @@ class Solver(object):
 
     def set_l21_weight(self, w):
         self._set_weight(self._lib.sporco_amd_csc_set_l21_weight, w)
+
+    def set_filter_sizes(self, sizes):
+        """Per-filter supports [(rows, cols)] * K of a multi-scale dictionary, or None."""
+        if sizes is None:
+            check(self._lib.sporco_amd_csc_set_filter_sizes(self._h, None, None))
+            return
+        H, W, C, N, K = self.dims
+        if len(sizes) != K:
+            raise ValueError("one (rows, cols) pair per filter")
+        fh = (ctypes.c_int32 * K)(*[int(s[0]) for s in sizes])
+        fw = (ctypes.c_int32 * K)(*[int(s[1]) for s in sizes])
+        check(self._lib.sporco_amd_csc_set_filter_sizes(self._h, fh, fw))
 
     def set_ams_mask(self, w):
         """AddMaskSim mask, 5-D with every axis 1 or full and a singleton filter axis."""

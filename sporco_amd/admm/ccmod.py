@@ -61,6 +61,7 @@ class _DeviceDStep(object):
             self._cache = {}
             self._u_scale = 1.0
             self._sums = [0.0] * _lib.OUT_COUNT
+            self.dev.set_filter_sizes(self.cri.fsz)
             return
         self.Nb = self.cri.C * self.cri.K
         self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
@@ -75,6 +76,8 @@ class _DeviceDStep(object):
         self._cache = {}
         self._u_scale = 1.0
         self._sums = [0.0] * _lib.OUT_COUNT
+        # (multi-scale dsz: every filter's own support for the projections of this handle)
+        self.dev.set_filter_sizes(self.cri.fsz)
 
     @property
     def Y(self):
@@ -109,7 +112,7 @@ class _DeviceDStep(object):
         """The dictionary, cropped to the filter support by default (ccmod.py:331-339,
         :839-848)."""
         if crop:
-            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
+            return self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
         return self.Y
 
     def finish_solve(self):
@@ -295,7 +298,7 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
     def _device_iteration(self, flags):
         """One ``sporco_amd_csc_cns_iter`` call -- or, with image shards, its two phases around
         the all-reduce that turns the rank-local mean into the consensus average."""
-        args = (self.rho, self.rlx, self._u_scale, flags, self.cri.dsz[0], self.cri.dsz[1],
+        args = (self.rho, self.rlx, self._u_scale, flags, self.cri.mxsz[0], self.cri.mxsz[1],
                 self.opt['ZeroMean'])
         if self._reducer is None:
             return self.dev.cns_iter(*args, mask_dcpl=self._mask_dcpl)
@@ -430,8 +433,7 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
             flags |= _lib.FLAG_XRRS
         tol, mit = self._cg_options()
         s = self._sums = self.dev.dstep_iter(
-            self._method, self.rho, self.rlx, self._u_scale, flags, self.cri.dsz[0],
-            self.cri.dsz[1], self.opt['ZeroMean'], tol, mit)
+            self._method, self.rho, self.rlx, self._u_scale, flags, self.cri.mxsz[0], self.cri.mxsz[1], self.opt['ZeroMean'], tol, mit)
         self._u_scale = 1.0
         self._cache.clear()
         if self.opt['LinSolveCheck']:

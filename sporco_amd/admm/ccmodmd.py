@@ -145,7 +145,7 @@ class ConvCnstrMODMaskDcplBase(ccmod.ConvCnstrMODBase):
 
     def getdict(self, crop=True):
         if crop:
-            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
+            return self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
         return self.var_y1()
 
     # -- iteration ----------------------------------------------------------------------------
@@ -160,8 +160,7 @@ class ConvCnstrMODMaskDcplBase(ccmod.ConvCnstrMODBase):
             flags |= _lib.FLAG_XRRS
         tol, mit = self._cg_options()
         s = self._sums = self.dev.dstep_iter(
-            self._method, self.rho, self.rlx, self._u_scale, flags, self.cri.dsz[0],
-            self.cri.dsz[1], self.opt['ZeroMean'], tol, mit, mask_dcpl=True)
+            self._method, self.rho, self.rlx, self._u_scale, flags, self.cri.mxsz[0], self.cri.mxsz[1], self.opt['ZeroMean'], tol, mit, mask_dcpl=True)
         self._u_scale = 1.0
         self._cache.clear()
         if self.opt['LinSolveCheck']:

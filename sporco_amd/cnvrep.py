@@ -50,17 +50,36 @@ class CSC_ConvRepIndexing(object):
 
 
 class DictionarySize(object):
-    """Parameters of a (single-scale) dictionary size tuple ``dsz``."""
+    """Parameters of a dictionary size tuple ``dsz`` (sporco/cnvrep.py:211-264): one scale
+    ``(rows, cols, [channels,] filters)``, or a tuple of such blocks for a multi-scale
+    dictionary.  ``fsz``: the (rows, cols) support of every filter for a multi-scale ``dsz``
+    (what the device's constraint projection is told), else None.  The nested form with
+    separate channel blocks (cnvrep.py:773-782) is not taken."""
 
     def __init__(self, dsz, dimN=2):
-        if isinstance(dsz[0], tuple):
-            raise NotImplementedError("multi-scale dictionary specifications are "
-                                      "outside the sporco_amd hot path")
         self.dsz = dsz
-        self.ndim = len(dsz)
-        self.mxsz = tuple(dsz[0:dimN])
-        self.nflt = dsz[-1]
-        self.nchn = 1 if self.ndim == dimN + 1 else dsz[-2]
+        self.fsz = None
+        if isinstance(dsz[0], tuple):
+            if isinstance(dsz[0][0], tuple):
+                raise NotImplementedError("dictionary size blocks with separate channel blocks "
+                                          "are outside the sporco_amd hot path")
+            self.ndim = len(dsz[0])
+            self.nchn = 1 if self.ndim == dimN + 1 else dsz[0][-2]
+            mxsz = np.zeros((dimN,), dtype=int)
+            self.nflt = 0
+            self.fsz = []
+            for blk in dsz:
+                if len(blk) != self.ndim or (self.ndim > dimN + 1 and blk[-2] != self.nchn):
+                    raise ValueError("dictionary size blocks of different kinds")
+                mxsz = np.maximum(mxsz, np.asarray(blk[0:dimN]))
+                self.nflt += blk[-1]
+                self.fsz += [tuple(int(v) for v in blk[0:dimN])] * int(blk[-1])
+            self.mxsz = tuple(int(v) for v in mxsz)
+        else:
+            self.ndim = len(dsz)
+            self.mxsz = tuple(dsz[0:dimN])
+            self.nflt = dsz[-1]
+            self.nchn = 1 if self.ndim == dimN + 1 else dsz[-2]
 
     def __str__(self):
         return pprint.pformat(vars(self))
@@ -76,6 +95,8 @@ class CDU_ConvRepIndexing(object):
         self.Cd = ds.nchn
         self.M = ds.nflt
         self.dsz = dsz
+        self.mxsz = ds.mxsz     # largest filter support (= dsz[0:dimN] for one scale)
+        self.fsz = ds.fsz       # per-filter supports of a multi-scale dsz, else None
         if dimK is None:
             rdim = S.ndim - dimN
             if rdim == 0:
@@ -153,20 +174,43 @@ def zpad(v, Nv):
     return out
 
 
+def _size_blocks(dsz, dimN):
+    """(filter slice, support) of every block of a multi-scale ``dsz``."""
+    m0 = 0
+    for blk in dsz:
+        if isinstance(blk[0], tuple):
+            raise NotImplementedError("dictionary size blocks with separate channel blocks are "
+                                      "outside the sporco_amd hot path")
+        m1 = m0 + blk[-1]
+        yield slice(m0, m1), tuple(slice(0, n) for n in blk[0:-1])
+        m0 = m1
+
+
 def bcrop(v, dsz, dimN=2):
-    """Crop to the filter support (single-scale ``dsz``)."""
+    """Crop to the filter support; a multi-scale ``dsz`` gives an array of the largest support
+    with every filter zero outside its own (sporco/cnvrep.py:729-817)."""
     if isinstance(dsz[0], tuple):
-        raise NotImplementedError("multi-scale dictionaries are outside the hot path")
+        mx = DictionarySize(dsz, dimN).mxsz
+        vc = np.zeros(tuple(mx) + v.shape[dimN:], dtype=v.dtype)
+        for fsl, sup in _size_blocks(dsz, dimN):
+            idx = sup + (Ellipsis, fsl)
+            vc[idx] = v[idx]
+        return vc
     return v[tuple(slice(0, n) for n in dsz[0:dimN])]
 
 
 def zeromean(v, dsz, dimN=2):
-    """Subtract, per filter, the mean over the filter support."""
-    if isinstance(dsz[0], tuple):
-        raise NotImplementedError("multi-scale dictionaries are outside the hot path")
+    """Subtract, per filter (and channel), the mean over the filter's support
+    (sporco/cnvrep.py:609-670)."""
     out = v.copy()
+    axisN = tuple(range(dimN))
+    if isinstance(dsz[0], tuple):
+        for fsl, sup in _size_blocks(dsz, dimN):
+            idx = sup + (Ellipsis, fsl)
+            out[idx] -= np.mean(v[idx], axisN)
+        return out
     sup = tuple(slice(0, n) for n in dsz[0:dimN])
-    out[sup] -= np.mean(v[sup], tuple(range(dimN)))
+    out[sup] -= np.mean(v[sup], axisN)
     return out
 
 

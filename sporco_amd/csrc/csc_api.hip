@@ -163,6 +163,7 @@ struct CscBase {
     virtual void set_dict(const void *D, int dH, int dW) = 0;
     virtual void set_weight(int which, const void *w, const int64_t shape[5]) = 0;
     virtual void set_grad_weight(const void *w) = 0;
+    virtual void set_filter_sizes(const int32_t *fh, const int32_t *fw) = 0;
     virtual void upload(int var, const void *src) = 0;
     virtual void download(int var, void *dst) = 0;
     virtual void *device_ptr(int var) = 0;
@@ -517,7 +518,7 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar,
-                        (void *)part_c2r, (void *)cns_w, (void *)cns_sft})
+                        (void *)part_c2r, (void *)cns_w, (void *)cns_sft, (void *)flt_h, (void *)flt_w})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)ccmod_r, (void *)pgm_ey, (void *)gpart,
@@ -2652,8 +2653,8 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_pcn_stats<T>(st, v, pcn_stats_buf(), H, W, K, dH, dW, zm, Cd);
-            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b, Ku, Cd);
+            launch_pcn_stats<T>(st, v, pcn_stats_buf(), H, W, K, dH, dW, zm, Cd, fsz());
+            nb = launch_pcn_apply<T>(st, v, pcn_stats_buf(), out, H, W, K, dH, dW, part_b, Ku, Cd, fsz());
         }
         if (out_dev) {
             const int slots[1] = {0};
@@ -2692,8 +2693,8 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_pcn_stats<T>(st, X, pcn_stats_buf(), H, W, K, dH, dW, zm, Cd);
-            nb = launch_pcn_apply<T>(st, X, pcn_stats_buf(), X, H, W, K, dH, dW, part_b, Ku, Cd);
+            launch_pcn_stats<T>(st, X, pcn_stats_buf(), H, W, K, dH, dW, zm, Cd, fsz());
+            nb = launch_pcn_apply<T>(st, X, pcn_stats_buf(), X, H, W, K, dH, dW, part_b, Ku, Cd, fsz());
         }
         const int slots[1] = {SPORCO_AMD_OUT_CNSTR};
         const double scales[1] = {1.0};
@@ -2838,6 +2839,34 @@ template <typename T> struct Csc : CscBase {
     }
 
     cx<T> *cns_w = nullptr, *cns_sft = nullptr;   // Cd > 1: column-pass scratch, transposed Sf
+    // multi-scale dictionary: per-filter support sizes of the constraint projection (K ints
+    // each; null: the one support the calls name)
+    int *flt_h = nullptr, *flt_w = nullptr;
+    FilterSizes fsz() const {
+        FilterSizes f;
+        f.h = flt_h;
+        f.w = flt_w;
+        return f;
+    }
+    void set_filter_sizes(const int32_t *fh, const int32_t *fw) override {
+        sync();
+        if (flt_h) {
+            SA_HIP(hipFree(flt_h));
+            SA_HIP(hipFree(flt_w));
+            flt_h = flt_w = nullptr;
+        }
+        if (!fh || !fw) return;
+        std::vector<int> h((size_t)K, 0), w((size_t)K, 0);     // (padding filters: empty support)
+        for (int k = 0; k < Ku; ++k) {
+            SA_REQUIRE(fh[k] >= 1 && fh[k] <= H && fw[k] >= 1 && fw[k] <= W, "filter size out of range");
+            h[k] = fh[k];
+            w[k] = fw[k];
+        }
+        SA_HIP(hipMalloc((void **)&flt_h, sizeof(int) * K));
+        SA_HIP(hipMalloc((void **)&flt_w, sizeof(int) * K));
+        SA_HIP(hipMemcpy(flt_h, h.data(), sizeof(int) * K, hipMemcpyHostToDevice));
+        SA_HIP(hipMemcpy(flt_w, w.data(), sizeof(int) * K, hipMemcpyHostToDevice));
+    }
     void cns_buffers() {
         if (cns_f) return;
         const int64_t npixr = (int64_t)H * W;
@@ -3021,9 +3050,9 @@ template <typename T> struct Csc : CscBase {
             int nbc;
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_pcn_stats<T>(st, Y, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                launch_pcn_stats<T>(st, Y, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0, Cd, fsz());
                 nbc = launch_pcn_apply<T>(st, Y, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
-                                          Ku);
+                                          Ku, Cd, fsz());
             }
             const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
             const double cscales[1] = {1.0};
@@ -3238,9 +3267,9 @@ template <typename T> struct Csc : CscBase {
             }
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0, Cd);
+                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0, Cd, fsz());
                 nbc = launch_pcn_apply<T>(st, gv, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW, part_b,
-                                          Ku, Cd);
+                                          Ku, Cd, fsz());
             }
             const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
             const double cscales[1] = {1.0};
@@ -3757,9 +3786,9 @@ template <typename T> struct Csc : CscBase {
             int nbc;
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0);
+                launch_pcn_stats<T>(st, gv, pcn_stats_buf(), H, W, K, p.dH, p.dW, p.zero_mean != 0, Cd, fsz());
                 nbc = launch_pcn_apply<T>(st, gv, pcn_stats_buf(), nullptr, H, W, K, p.dH, p.dW,
-                                          part_b, Ku);
+                                          part_b, Ku, Cd, fsz());
             }
             const int cslots[1] = {SPORCO_AMD_OUT_CNSTR};
             const double cscales[1] = {1.0};
@@ -3966,6 +3995,14 @@ int sporco_amd_csc_set_grad_weight(sporco_amd_csc_t h, const void *w) {
     SA_API_BEGIN
     SA_HANDLE(h);
     h->impl->set_grad_weight(w);
+    SA_API_END
+}
+
+int sporco_amd_csc_set_filter_sizes(sporco_amd_csc_t h, const int32_t *fh, const int32_t *fw) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE((fh == nullptr) == (fw == nullptr), "both size arrays, or neither");
+    h->impl->set_filter_sizes(fh, fw);
     SA_API_END
 }
 

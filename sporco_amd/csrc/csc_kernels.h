@@ -181,14 +181,20 @@ int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<
 // Constraint-set projection Pcn = normalise(zeromean(zpad(bcrop(v)))) of a
 // dictionary v(H, W, K) with filter support (dH, dW) (cnvrep.py:868-913).
 // stats[2k] = mean over support (0 unless zm), stats[2k+1] = 1/norm (1 if norm is 0).
+// Multi-scale dictionary (dsz a tuple of size blocks, cnvrep.py:634-662, :778-812): per-filter
+// support sizes in device memory (K ints each), or null pointers for the one support (dH, dW).
+struct FilterSizes {
+    const int *h = nullptr, *w = nullptr;
+};
 template <typename T>
 void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
-                      bool zm, int Cd = 1);   // Cd > 1: v (H, W, Cd, K), stats sized 2 Cd K
+                      bool zm, int Cd = 1,    // Cd > 1: v (H, W, Cd, K), stats sized 2 Cd K
+                      FilterSizes fs = FilterSizes());
 // out = projected v (out may be null: measure only); partial[block] = sum (P(v) - v)^2
 template <typename T>
 int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
                      int dH, int dW, double *partials, int Kvalid = -1,   // k >= Kvalid -> 0
-                     int Cd = 1);
+                     int Cd = 1, FilterSizes fs = FilterSizes());
 // partial[block] = sum |v|
 template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, double *partials);
 

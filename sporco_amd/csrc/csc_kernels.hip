@@ -2339,11 +2339,14 @@ int launch_mc_dhs_absmax(hipStream_t st, const cx<T> *df, const cx<T> *sf, int64
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict__ v,
                                                              T *__restrict__ stats, int H, int W,
-                                                             int K, int dH, int dW, int zm, int Cd) {
+                                                             int K, int dH_, int dW_, int zm, int Cd,
+                                                             FilterSizes fs) {
     // v is (H, W, Cd, K); mean per (channel, filter) over the support (cnvrep.zeromean,
     // cnvrep.py:609-670), norm per filter over support and channels (cnvrep.normalise with
     // dimN + dimC axes, cnvrep.py:696-700).  stats[2 (c K + k)] = mean, stats[2k + 1] = 1/norm.
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        // (multi-scale dictionary: every filter has its own support, cnvrep.py:634-662, :778-812)
+        const int dH = fs.h ? fs.h[k] : dH_, dW = fs.w ? fs.w[k] : dW_;
         T n2 = T(0);
         for (int c = 0; c < Cd; ++c) {
             T mean = T(0);
@@ -2367,17 +2370,18 @@ __global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict
 
 template <typename T>
 void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
-                      bool zm, int Cd) {
+                      bool zm, int Cd, FilterSizes fs) {
     hipLaunchKernelGGL((pcn_stats_kernel<T>), dim3(grid_for(K)), dim3(kThreads), 0, st, v, stats, H,
-                       W, K, dH, dW, zm ? 1 : 0, Cd);
+                       W, K, dH, dW, zm ? 1 : 0, Cd, fs);
     SA_HIP(hipGetLastError());
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict__ v,
                                                              const T *__restrict__ stats, T *out,
-                                                             int H, int W, int K, int dH, int dW,
-                                                             int Kvalid, int Cd, double *partials) {
+                                                             int H, int W, int K, int dH_, int dW_,
+                                                             int Kvalid, int Cd, double *partials,
+                                                             FilterSizes fs) {
     double acc[1] = {0.0};
     const int64_t KD = (int64_t)Cd * K;
     const int64_t n = (int64_t)H * W * KD;
@@ -2387,6 +2391,7 @@ __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict
         const int k = ck % K;
         const int64_t pix = i / KD;
         const int x = (int)(pix % W), h = (int)(pix / W);
+        const int dH = fs.h ? fs.h[k] : dH_, dW = fs.w ? fs.w[k] : dW_;
         const T vi = v[i];
         // v / vn as in cnvrep.normalise (cnvrep.py:696-700): 1/norm is applied by division
         // (filters >= Kvalid are the handle's zero padding: rounding noise must not be
@@ -2401,11 +2406,11 @@ __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict
 
 template <typename T>
 int launch_pcn_apply(hipStream_t st, const T *v, const T *stats, T *out, int H, int W, int K,
-                     int dH, int dW, double *partials, int Kvalid, int Cd) {
+                     int dH, int dW, double *partials, int Kvalid, int Cd, FilterSizes fs) {
     const int grid = grid_for((int64_t)H * W * Cd * K);
     hipLaunchKernelGGL((pcn_apply_kernel<T>), dim3(grid), dim3(kThreads),
                        sizeof(double) * (kThreads / kWave), st, v, stats, out, H, W, K, dH, dW,
-                       Kvalid < 0 ? K : Kvalid, Cd, partials);
+                       Kvalid < 0 ? K : Kvalid, Cd, partials, fs);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -3117,9 +3122,9 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_ccmod_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
                                       cx<T> *, int64_t, int, int, int, double *, int);             \
     template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool,  \
-                                      int);                                                        \
+                                      int, FilterSizes);                                           \
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
-                                     int, double *, int, int);                                               \
+                                     int, double *, int, int, FilterSizes);                        \
     template int launch_asum<T>(hipStream_t, const T *, int64_t, double *);                        \
     template int launch_mask_apply<T>(hipStream_t, T *, const Weight<T> &, bool, int, int, int,    \
                                       int, double *);                                              \

@@ -207,7 +207,7 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
 
     def post_dstep(self):
         """xstep.setdict(dstep.getdict()) (dictlrn.py:386-389), device to device."""
-        dsz = self.dstep.cri.dsz
+        dsz = self.dstep.cri.mxsz       # (largest support of a multi-scale dictionary)
         self.dstep.dev.setdict_from_dstep(dsz[0], dsz[1])
         x = self.xstep
         x._cache.pop(_lib.VAR_DF, None)

@@ -92,6 +92,7 @@ class OnlineConvBPDNDictLearn(common.IterativeSolver):
         self.dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
         self.cri = None
         ds = cr.DictionarySize(self.dsz, dimN)
+        self._mxsz, self._fsz = ds.mxsz, ds.fsz     # (multi-scale DictSize: per-filter supports)
         self._dimCd = ds.ndim - dimN - 1
         D0 = cr.stdformD(D0, ds.nchn, ds.nflt, dimN).astype(self.dtype)
         self.D = cr.Pcn(D0, self.dsz, (), dimN, self._dimCd, crp=True, zm=opt['ZeroMean'])
@@ -147,13 +148,15 @@ class OnlineConvBPDNDictLearn(common.IterativeSolver):
         the current dictionary, summed over images (and channels for a single-channel
         dictionary), step ``eta``, ``D = Pcn(G)``."""
         dev = self._xstep._dev
+        if self._fsz is not None:
+            dev.set_filter_sizes(self._fsz)
         dev.ccmod_setcoef(_lib.VAR_Y)            # Zf = rfftn(getcoef())
         dev.ccmod_grad(_lib.VAR_DF)
         self.eta = self.eta_a / (self.j + self.eta_b)
-        sums = dev.ccmod_sgd_step(self.eta, self.dsz[0], self.dsz[1], self.opt['ZeroMean'])
+        sums = dev.ccmod_sgd_step(self.eta, self._mxsz[0], self._mxsz[1], self.opt['ZeroMean'])
         self._cnstr = np.sqrt(sums[_lib.OUT_CNSTR])
         self.Dprv[:] = self.D
-        self.D[:] = dev.ccmod_getdict(self.dsz[0], self.dsz[1]).reshape(self.D.shape)
+        self.D[:] = dev.ccmod_getdict(self._mxsz[0], self._mxsz[1]).reshape(self.D.shape)
 
     @property
     def G(self):
@@ -280,11 +283,13 @@ class OnlineConvBPDNMaskDictLearn(OnlineConvBPDNDictLearn):
         """Projected SGD step with the residual weighted by the mask (once, in the spatial
         domain) before the adjoint (:574-590); the mask is the one the X-step uploaded."""
         dev = self._xstep._dev
+        if self._fsz is not None:
+            dev.set_filter_sizes(self._fsz)
         dev.ccmod_setcoef(_lib.VAR_Y)                     # Zf = rfftn(y1), the coefficient maps
         dev.copy(_lib.VAR_DYF, _lib.VAR_DF)
         dev.masked_grad(_lib.VAR_DYF, True, 2)
         self.eta = self.eta_a / (self.j + self.eta_b)
-        sums = dev.ccmod_sgd_step(self.eta, self.dsz[0], self.dsz[1], self.opt['ZeroMean'])
+        sums = dev.ccmod_sgd_step(self.eta, self._mxsz[0], self._mxsz[1], self.opt['ZeroMean'])
         self._cnstr = np.sqrt(sums[_lib.OUT_CNSTR])
         self.Dprv[:] = self.D
-        self.D[:] = dev.ccmod_getdict(self.dsz[0], self.dsz[1]).reshape(self.D.shape)
+        self.D[:] = dev.ccmod_getdict(self._mxsz[0], self._mxsz[1]).reshape(self.D.shape)

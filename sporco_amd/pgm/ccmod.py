@@ -90,6 +90,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
                     or dev.Cd != self.cri.Cd or dev.dtype != self.dtype:
                 raise ValueError("shared device solver has different dimensions")
             self.dev = dev
+        # (multi-scale dsz: every filter's own support for the projections of this handle)
+        self.dev.set_filter_sizes(self.cri.fsz)
         super(ConvCnstrMOD, self).__init__(self.cri.shpD, self.cri.Nv, self.cri.axisN,
                                            S.dtype, opt)
         nimg = self.cri.K * (1 if reducer is None else reducer.world_size)
@@ -140,7 +142,7 @@ class ConvCnstrMOD(pgm.PGMDFT):
         """Current dictionary, cropped to the filter support by default
         (pgm/ccmod.py:283-291)."""
         if crop:
-            return self.dev.ccmod_getdict(self.cri.dsz[0], self.cri.dsz[1])
+            return self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
         return self.X
 
     # -- smooth term -------------------------------------------------------------------
@@ -174,7 +176,7 @@ class ConvCnstrMOD(pgm.PGMDFT):
     def prox_step(self, gradf):
         if gradf != _lib.VAR_DGF:
             self.dev.copy(_lib.VAR_DGF, gradf)
-        self.dev.ccmod_prox_step(self.L, self.cri.dsz[0], self.cri.dsz[1], self.opt['ZeroMean'])
+        self.dev.ccmod_prox_step(self.L, self.cri.mxsz[0], self.cri.mxsz[1], self.opt['ZeroMean'])
         self.invalidate(_lib.VAR_DX, _lib.VAR_DXF, _lib.VAR_DVF)
 
     # -- objective ------------------------------------------------------------------------
@@ -186,7 +188,7 @@ class ConvCnstrMOD(pgm.PGMDFT):
 
     def obfn_cns(self):
         """||Pcn(X) - X||_2 (pgm/ccmod.py:350-355)."""
-        return self.dev.ccmod_cnstr(self.cri.dsz[0], self.cri.dsz[1], self.opt['ZeroMean'])
+        return self.dev.ccmod_cnstr(self.cri.mxsz[0], self.cri.mxsz[1], self.opt['ZeroMean'])
 
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Df) (pgm/ccmod.py:374-383); host arithmetic on the
