@@ -1,3 +1,15 @@
+#!/usr/bin/env python3
+"""Phase times of the one-launch solve of small problems (csc_rows.hip admm_persist_kernel) from a
+MEASUREMENT build of the library: compile csc_rows.hip with -DSA_PERSIST_TIMING and link it with
+the product's other objects into tools/ubench/libsporco_amd_timing.so, e.g.
+
+    cd sporco_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -fno-slp-vectorize \\
+        -DSA_PERSIST_TIMING -c csc_rows.hip -o /tmp/csc_rows_timing.o && \\
+    hipcc --offload-arch=gfx950 -shared -fPIC fft.o csc_kernels.o csc_fused.o csc_fused_mc.o \\
+        /tmp/csc_rows_timing.o csc_pgm.o csc_api.o -o ../../tools/ubench/libsporco_amd_timing.so
+
+Prints, per solve, the average ticks (10 ns) workgroup 0 spends in each phase
+(profiles/r03_persist.md)."""
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
