@@ -1157,12 +1157,37 @@ def gen_ams():
     ams_case('ams_joint_f64', ref_cbpdn.ConvBPDNJoint, D, Sc, Wc, (0.1, 0.05),
              {'MaxMainIter': 20})
 
+def gen_zchan():
+    """Dictionary updates of a multi-channel dictionary whose coefficient maps carry the
+    channels too -- (N, N, Nc, K, M) maps with an (Nd, Nd, Nc, M) dictionary -- which the
+    reference's broadcasting turns into Nc single-channel updates sharing rho, the step size
+    and the residuals (its own tests: tests/admm/test_ccmod.py:278-295, tests/pgm/test_ccmod.py
+    :175-191)."""
+    np.random.seed(24680)
+    N, M, K, Nc, Nd = 16, 4, 2, 3, 8
+    Z = np.random.randn(N, N, Nc, K, M) * (np.random.rand(N, N, Nc, K, M) > 0.5)
+    S = np.random.randn(N, N, Nc, K)
+    cls = ref_admm_ccmod.ConvCnstrMOD_Consensus
+    for name, optd in (('ccmod_cns_zchan_f64', {'MaxMainIter': 20, 'LinSolveCheck': True}),
+                       ('ccmod_cns_zchan_opts_f32', {'MaxMainIter': 12, 'ZeroMean': True,
+                                                     'AuxVarObj': False, 'DataType': np.float32})):
+        c = cls(Z, S, (Nd, Nd, Nc, M), cls.Options(optd))
+        c.solve()
+        save(name, Z=Z, S=S, dsz=np.array((Nd, Nd, Nc, M)), D=c.getdict(), Y=c.Y, U=c.U, X=c.X,
+             rho_final=np.float64(c.rho), k_final=np.int64(c.k),
+             **itstat_dict(c))
+    c = ref_pgm_ccmod.ConvCnstrMOD(Z, S, (Nd, Nd, Nc, M),
+                                   ref_pgm_ccmod.ConvCnstrMOD.Options({'MaxMainIter': 20, 'L': 400.0}))
+    c.solve()
+    save('pgm_ccmod_zchan_f64', Z=Z, S=S, dsz=np.array((Nd, Nd, Nc, M)), D=c.getdict(), X=c.X,
+         **itstat_dict(c))
+
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -99,8 +99,19 @@ class _DeviceDStep(object):
     def setcoef(self, Z):
         """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:311-327, :746-755)."""
         # (multi-channel dictionary: Nb = K and the maps have no channel axis, same reshape)
-        self.Z = np.asarray(np.asarray(Z).reshape(self.cri.Nv + (1, self.Nb, self.cri.M)),
-                            dtype=self.dtype)
+        Z = np.asarray(Z)
+        self._z_chan = self.cri.Cd > 1 and Z.size == self.cri.N * self.cri.Cd * self.Nb * self.cri.M
+        if self._z_chan:
+            # ... unless they carry the dictionary's channels: the reference's broadcasting then
+            # solves Cd independent single-channel updates (tests/admm/test_ccmod.py:278-295).
+            # The device takes them in its consensus blocks' layout (H, W, K, Cd, M).
+            self.Z = np.asarray(Z.reshape(self.cri.Nv + (self.cri.Cd, self.Nb, self.cri.M)),
+                                dtype=self.dtype)
+            self.dev.upload(_lib.VAR_CX, np.ascontiguousarray(self.Z.transpose(0, 1, 3, 2, 4)))
+            self.dev.ccmod_setcoef(_lib.VAR_CX)
+            self._cache.pop(_lib.VAR_CX, None)
+            return
+        self.Z = np.asarray(Z.reshape(self.cri.Nv + (1, self.Nb, self.cri.M)), dtype=self.dtype)
         self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
         self.dev.ccmod_setcoef(_lib.VAR_AX)
 
@@ -323,7 +334,8 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         """irfftn(sum_m Zf * Df) (ccmod.py:897-907); host arithmetic, off the iteration path."""
         Df = self.dev.download(_lib.VAR_DXF) if D is None else \
             np.fft.rfftn(np.asarray(D), axes=(0, 1))
-        Zf = self.dev.download(_lib.VAR_ZF)
+        Zf = np.fft.rfftn(self.Z, axes=(0, 1)) if getattr(self, '_z_chan', False) else \
+            self.dev.download(_lib.VAR_ZF)
         return np.fft.irfftn(np.sum(Zf * Df, axis=self.cri.axisM), self.cri.Nv,
                              axes=(0, 1)).astype(self.dtype)
 

@@ -518,7 +518,8 @@ template <typename T> struct Csc : CscBase {
         for (auto &v : vars)
             if (v) (void)hipFree(v);
         for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar,
-                        (void *)part_c2r, (void *)cns_w, (void *)cns_sft, (void *)flt_h, (void *)flt_w})
+                        (void *)part_c2r, (void *)cns_w, (void *)cns_sft, (void *)flt_h, (void *)flt_w,
+                        (void *)zf_ch})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,
                         (void *)twRows, (void *)part_rows, (void *)y_alt, (void *)u_alt, (void *)part_pgm, (void *)part_pgm2, (void *)ccmod_r, (void *)pgm_ey, (void *)gpart,
@@ -2521,6 +2522,18 @@ template <typename T> struct Csc : CscBase {
         before_read(var);
         gramz_valid = false;
         zsf_valid = dism_valid = false;
+        // A multi-channel dictionary whose coefficient maps carry the channels as well (the
+        // reference's broadcasting admits it, tests/admm/test_ccmod.py:278-295: Cd independent
+        // single-channel updates sharing rho and the residuals), staged in the consensus blocks'
+        // layout (H, W, N, Cd, K) -- VAR_CX -- and kept in a spectrum of that size
+        z_chan = Cd > 1 && var == SPORCO_AMD_VAR_CX;
+        if (z_chan) {
+            if (!zf_ch) SA_HIP(hipMalloc((void **)&zf_ch, sizeof(cx<T>) * EF * Cd));
+            zf_tiled = false;
+            fwd2(rv(var), nullptr, T(0), zf_ch, P * Cd);
+            SA_HIP(hipMemsetAsync(rv(var), 0, sizeof(T) * E * Cd, st));   // (X_n = 0 before a solve)
+            return;
+        }
         // (the generic consensus D-step and the single-copy ADMM D-step read Zf in the natural
         // layout)
         // (K > 64: the slab forms of the column transform and of the PGM gradient; the ADMM
@@ -2639,9 +2652,9 @@ template <typename T> struct Csc : CscBase {
         int nb;
         {
             ProfScope ps(prof, PS_PGM);
-            nb = launch_ccmod_grad<T>(st, cv(SPORCO_AMD_VAR_ZF), cv(var), cv(SPORCO_AMD_VAR_SF),
+            nb = launch_ccmod_grad<T>(st, zf_nat(), cv(var), cv(SPORCO_AMD_VAR_SF),
                                       write_grad ? cv(SPORCO_AMD_VAR_DGF) : nullptr, npix, CN, K, W,
-                                      part_a, Cd);
+                                      part_a, Cd, z_chan);
         }
         const int slots[3] = {SPORCO_AMD_PGM_F, SPORCO_AMD_PGM_DFID, SPORCO_AMD_PGM_HESS};
         const double scales[3] = {0.5, 1.0 / ((double)H * W), 1.0};
@@ -2759,6 +2772,8 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var) == dstep &&
                        var != SPORCO_AMD_VAR_SF && var != SPORCO_AMD_VAR_DF,
                    "masked_grad: variable of the wrong kind");
+        SA_REQUIRE(!(dstep && z_chan), "masked_grad: coefficient maps with a channel axis are served by "
+                                       "ccmod_grad / cns_iter only");
         before_read(var);
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         cx<T> *Sf = cv(SPORCO_AMD_VAR_SF);
@@ -2839,6 +2854,9 @@ template <typename T> struct Csc : CscBase {
     }
 
     cx<T> *cns_w = nullptr, *cns_sft = nullptr;   // Cd > 1: column-pass scratch, transposed Sf
+    cx<T> *zf_ch = nullptr;     // Cd > 1, channel-ful coefficient maps: spectrum (npix, N, Cd, K)
+    bool z_chan = false;
+    const cx<T> *zf_nat() { return z_chan ? zf_ch : cv(SPORCO_AMD_VAR_ZF); }
     // multi-scale dictionary: per-filter support sizes of the constraint projection (K ints
     // each; null: the one support the calls name)
     int *flt_h = nullptr, *flt_w = nullptr;
@@ -3088,7 +3106,7 @@ template <typename T> struct Csc : CscBase {
         }
         const int64_t npixr = (int64_t)H * W;
         T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_CX), *U = rv(SPORCO_AMD_VAR_CU);
-        cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF);
+        const cx<T> *Zf = zf_nat();
         cns_buffers();
         if (p.phase != 2) {
         // xstep (ccmod.py:766-778): X_n = irfftn(SM(Zf_n, rho, conj(Zf_n) Sf_n + rho rfftn(Y - U_n)));
@@ -3163,13 +3181,13 @@ template <typename T> struct Csc : CscBase {
         }
         if (lsc) {
             ProfScope ps(prof, PS_OTHER);
-            launch_cns_xrrs_rhs<T>(st, Zf, sfs, cns_f, (T)p.rho, dwork_buf(), npix, CN * Cd, K, Cd);
+            launch_cns_xrrs_rhs<T>(st, Zf, sfs, cns_f, (T)p.rho, dwork_buf(), npix, CN * Cd, K, Cd, z_chan);
         }
         int nbs;
         {   // (the per-image gram sum_k |Zf|^2 is formed inside the kernel)
             ProfScope ps(prof, PS_SM_SOLVE);
             nbs = launch_sm_solve<T>(st, cns_f, cns_f, Zf, sfs, nullptr, (T)p.rho, npix, CN * Cd, K, W,
-                                     dfid_x, false, part_a, nullptr, Cd);
+                                     dfid_x, false, part_a, nullptr, z_chan ? 1 : Cd);
         }
         if (dfid_x) {
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
@@ -3181,7 +3199,7 @@ template <typename T> struct Csc : CscBase {
             {
                 ProfScope ps(prof, PS_OTHER);
                 nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, (T)p.rho, dwork_buf(), npix, CN * Cd, K, part_a,
-                                             Cd);
+                                             Cd, z_chan);
             }
             const int xslots[3] = {SPORCO_AMD_OUT_XRRS_D2, SPORCO_AMD_OUT_XRRS_AX2, SPORCO_AMD_OUT_XRRS_B2};
             const double xscales[3] = {1.0, 1.0, 1.0};
@@ -3254,7 +3272,7 @@ template <typename T> struct Csc : CscBase {
                 {
                     ProfScope ps(prof, PS_OTHER);
                     nb = launch_ccmod_grad<T>(st, Zf, cv(SPORCO_AMD_VAR_DXF), cv(SPORCO_AMD_VAR_SF),
-                                              nullptr, npix, CN, K, W, part_a, Cd);
+                                              nullptr, npix, CN, K, W, part_a, Cd, z_chan);
                 }
                 finalize(part_a + 1, nb, 3, 1, slots, scales, out_dev);
             }

@@ -175,8 +175,9 @@ int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T
 // Parseval-weighted sum |r|^2, sum |r + sf|^2 (= <d, Hess d>).  Returns #blocks.
 template <typename T>
 int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
-                      int64_t npix, int CN, int K, int W, double *partials, int Cd = 1);
-// (Cd > 1: d, gf (npix, Cd, K), sf (npix, Cd, CN): one least-squares problem per channel)
+                      int64_t npix, int CN, int K, int W, double *partials, int Cd = 1, int zch = 0);
+// (Cd > 1: d, gf (npix, Cd, K), sf (npix, Cd, CN): one least-squares problem per channel, sharing
+// zf -- or, zch, with coefficient maps of its own: zf (npix, CN, Cd, K))
 
 // Constraint-set projection Pcn = normalise(zeromean(zpad(bcrop(v)))) of a
 // dictionary v(H, W, K) with filter support (dH, dW) (cnvrep.py:868-913).
@@ -259,13 +260,13 @@ int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, d
 // zf, yuf / xf: (npix, CN, K); sf: (npix, CN); bsum: (npix, K).  K <= 256.
 // Cd > 1 (multi-channel dictionary): the CN systems of a pixel are (image, channel) pairs,
 // channel fastest, sharing the image's zf row (npix, CN / Cd, K); sf (npix, CN / Cd, Cd); bsum
-// (npix, Cd, K).
+// (npix, Cd, K).  zch: every (image, channel) pair has a zf row of its own, (npix, CN, K).
 template <typename T>
 void launch_cns_xrrs_rhs(hipStream_t st, const cx<T> *zf, const cx<T> *sf, const cx<T> *yuf, T rho,
-                         cx<T> *bsum, int64_t npix, int CN, int K, int Cd = 1);
+                         cx<T> *bsum, int64_t npix, int CN, int K, int Cd = 1, int zch = 0);
 template <typename T>
 int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho, const cx<T> *bsum,
-                        int64_t npix, int CN, int K, double *partials, int Cd = 1);
+                        int64_t npix, int CN, int K, double *partials, int Cd = 1, int zch = 0);
 // dst[r, b, a] = src[r, a, b]
 template <typename T>
 void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t rows, int A, int B);

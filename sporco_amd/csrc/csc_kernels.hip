@@ -1249,9 +1249,10 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
                                                               const cx<T> *__restrict__ sf,
                                                               cx<T> *__restrict__ gf, int64_t npix,
                                                               int CN, int K, int Wf, int W, int Cd,
-                                                              double *partials) {
+                                                              double *partials, int zch) {
     // Cd > 1 (multi-channel dictionary): d, gf are (npix, Cd, K), sf is (npix, Cd, CN); the
-    // channels are independent least-squares problems sharing zf (pgm/ccmod.py:295-317)
+    // channels are independent least-squares problems sharing zf (pgm/ccmod.py:295-317) -- or,
+    // zch, each with its own coefficient maps: zf is (npix, CN, Cd, K)
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int nwave = blockDim.x / kWave;
     cx<T> *r = dyn_lds<cx<T>>();               // [CN]
@@ -1260,11 +1261,12 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
     double acc[3] = {0.0, 0.0, 0.0};
     for (int64_t pc = blockIdx.x; pc < npix * Cd; pc += gridDim.x) {
         const int64_t pix = pc / Cd;
-        const cx<T> *zp = zf + pix * CN * K;
+        const int64_t zs = zch ? (int64_t)Cd * K : K;      // stride of the images in zf
+        const cx<T> *zp = zf + pix * CN * zs + (zch ? (pc - pix * Cd) * K : 0);
         const cx<T> *dp = d + pc * K;
         for (int n = wave; n < CN; n += nwave) {
             cx<T> q = mk<T>(T(0), T(0));
-            for (int k = lane; k < K; k += kWave) q = q + cmul(zp[(int64_t)n * K + k], dp[k]);
+            for (int k = lane; k < K; k += kWave) q = q + cmul(zp[(int64_t)n * zs + k], dp[k]);
             q = wave_sum_cx(q);
             if (lane == 0) {
                 const cx<T> rr = q - sf[pc * CN + n];
@@ -1279,7 +1281,7 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
         if (gf) {
             for (int k = lane; k < K; k += kWave) {
                 cx<T> g = mk<T>(T(0), T(0));
-                for (int n = wave; n < CN; n += nwave) g = g + cmulc(zp[(int64_t)n * K + k], r[n]);
+                for (int n = wave; n < CN; n += nwave) g = g + cmulc(zp[(int64_t)n * zs + k], r[n]);
                 gpart[wave * K + k] = g;
             }
             __syncthreads();
@@ -1296,14 +1298,14 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
 
 template <typename T>
 int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
-                      int64_t npix, int CN, int K, int W, double *partials, int Cd) {
+                      int64_t npix, int CN, int K, int W, double *partials, int Cd, int zch) {
     int grid = (int)(npix * Cd < kMaxPartialBlocks ? npix * Cd : kMaxPartialBlocks);
     const int nwave = kThreads / kWave;
     size_t lds = sizeof(cx<T>) * ((size_t)CN + (size_t)nwave * K) + sizeof(double) * 3 * nwave;
     lds = (lds + 15) / 16 * 16;
     SA_REQUIRE(lds <= 64 * 1024, "too many images x filters for the D-step gradient kernel");
     hipLaunchKernelGGL((ccmod_grad_kernel<T>), dim3(grid), dim3(kThreads), lds, st, zf, d, sf, gf,
-                       npix, CN, K, W / 2 + 1, W, Cd, partials);
+                       npix, CN, K, W / 2 + 1, W, Cd, partials, zch);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -1833,9 +1835,10 @@ __global__ void __launch_bounds__(kThreads) cns_xrrs_rhs_kernel(const cx<T> *__r
                                                                 const cx<T> *__restrict__ sf,
                                                                 const cx<T> *__restrict__ yuf, T rho,
                                                                 cx<T> *__restrict__ bsum, int64_t npix,
-                                                                int CN, int K, int Cd) {
+                                                                int CN, int K, int Cd, int zch) {
     // (Cd > 1: the CN systems of a pixel are (image, channel) pairs, channel fastest, sharing the
-    // image's zf row; one wave per (pixel, channel), bsum (npix, Cd, K))
+    // image's zf row -- or, zch, each with its own row of a (npix, N, Cd, K) zf; one wave per
+    // (pixel, channel), bsum (npix, Cd, K))
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
     const int NI = CN / Cd;
@@ -1847,7 +1850,7 @@ __global__ void __launch_bounds__(kThreads) cns_xrrs_rhs_kernel(const cx<T> *__r
 #pragma unroll
         for (int j = 0; j < KR; ++j) b[j] = mk<T>(T(0), T(0));
         for (int n = 0; n < NI; ++n) {
-            const int64_t zrow = (pix * NI + n) * K, row = ((pix * NI + n) * Cd + c) * K;
+            const int64_t row = ((pix * NI + n) * Cd + c) * K, zrow = zch ? row : (pix * NI + n) * K;
             const cx<T> s = sf[(pix * NI + n) * Cd + c];
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
@@ -1868,7 +1871,7 @@ __global__ void __launch_bounds__(kThreads) cns_xrrs_fin_kernel(const cx<T> *__r
                                                                 const cx<T> *__restrict__ xf, T rho,
                                                                 const cx<T> *__restrict__ bsum,
                                                                 int64_t npix, int CN, int K,
-                                                                double *partials, int Cd) {
+                                                                double *partials, int Cd, int zch) {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
     const int NI = CN / Cd;
@@ -1881,7 +1884,7 @@ __global__ void __launch_bounds__(kThreads) cns_xrrs_fin_kernel(const cx<T> *__r
 #pragma unroll
         for (int j = 0; j < KR; ++j) a[j] = mk<T>(T(0), T(0));
         for (int n = 0; n < NI; ++n) {
-            const int64_t zrow = (pix * NI + n) * K, row = ((pix * NI + n) * Cd + c) * K;
+            const int64_t row = ((pix * NI + n) * Cd + c) * K, zrow = zch ? row : (pix * NI + n) * K;
             cx<T> q = mk<T>(T(0), T(0));
 #pragma unroll
             for (int j = 0; j < KR; ++j) {
@@ -2046,24 +2049,24 @@ template <typename T, typename F> static void ism_dispatch_kr(int K, F &&f) {
 
 template <typename T>
 void launch_cns_xrrs_rhs(hipStream_t st, const cx<T> *zf, const cx<T> *sf, const cx<T> *yuf, T rho,
-                         cx<T> *bsum, int64_t npix, int CN, int K, int Cd) {
+                         cx<T> *bsum, int64_t npix, int CN, int K, int Cd, int zch) {
     const int grid = grid_for(npix * Cd * kWave);
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
         hipLaunchKernelGGL((cns_xrrs_rhs_kernel<T, KR>), dim3(grid), dim3(kThreads), 0, st, zf, sf, yuf, rho,
-                           bsum, npix, CN, K, Cd);
+                           bsum, npix, CN, K, Cd, zch);
     });
     SA_HIP(hipGetLastError());
 }
 template <typename T>
 int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho, const cx<T> *bsum,
-                        int64_t npix, int CN, int K, double *partials, int Cd) {
+                        int64_t npix, int CN, int K, double *partials, int Cd, int zch) {
     const int grid = std::min(grid_for(npix * Cd * kWave), kMaxPartialBlocks);
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
         hipLaunchKernelGGL((cns_xrrs_fin_kernel<T, KR>), dim3(grid), dim3(kThreads),
                            sizeof(double) * 3 * (kThreads / kWave), st, zf, xf, rho, bsum, npix, CN, K,
-                           partials, Cd);
+                           partials, Cd, zch);
     });
     SA_HIP(hipGetLastError());
     return grid;
@@ -3120,7 +3123,7 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,     \
                                       int, double *);                                              \
     template int launch_ccmod_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,    \
-                                      cx<T> *, int64_t, int, int, int, double *, int);             \
+                                      cx<T> *, int64_t, int, int, int, double *, int, int);        \
     template void launch_pcn_stats<T>(hipStream_t, const T *, T *, int, int, int, int, int, bool,  \
                                       int, FilterSizes);                                           \
     template int launch_pcn_apply<T>(hipStream_t, const T *, const T *, T *, int, int, int, int,   \
@@ -3143,9 +3146,9 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
                                      int64_t, int, int, double *);                                 \
     template int launch_cns_ystats<T>(hipStream_t, const T *, const T *, int64_t, double *);       \
     template void launch_cns_xrrs_rhs<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, \
-                                         T, cx<T> *, int64_t, int, int, int);                     \
+                                         T, cx<T> *, int64_t, int, int, int, int);                \
     template int launch_cns_xrrs_fin<T>(hipStream_t, const cx<T> *, const cx<T> *, T,              \
-                                        const cx<T> *, int64_t, int, int, double *, int);          \
+                                        const cx<T> *, int64_t, int, int, double *, int, int);     \
     template void launch_swap_inner<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int);    \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
                                       int64_t, int, int, T, const GradTerm<T> *, int);             \

@@ -127,8 +127,17 @@ class ConvCnstrMOD(pgm.PGMDFT):
     def setcoef(self, Z):
         """Set the coefficient maps: Zf = rfftn(Z) (pgm/ccmod.py:264-279)."""
         self.Z = np.asarray(Z, dtype=self.dtype)
-        self.dev.upload(_lib.VAR_AX, self.Z)       # staging in a free X-sized real array
-        self.dev.ccmod_setcoef(_lib.VAR_AX)
+        cri = self.cri
+        if cri.Cd > 1 and self.Z.size == cri.N * cri.Cd * cri.K * cri.M:
+            # maps that carry the dictionary's channels (the reference's broadcasting makes
+            # that Cd single-channel problems, tests/pgm/test_ccmod.py:175-191): handed over in
+            # the (H, W, K, Cd, M) layout of the device's per-image dictionary blocks
+            Zc = self.Z.reshape(cri.Nv + (cri.Cd, cri.K, cri.M)).transpose(0, 1, 3, 2, 4)
+            self.dev.upload(_lib.VAR_CX, np.ascontiguousarray(Zc))
+            self.dev.ccmod_setcoef(_lib.VAR_CX)
+        else:
+            self.dev.upload(_lib.VAR_AX, self.Z)   # staging in a free X-sized real array
+            self.dev.ccmod_setcoef(_lib.VAR_AX)
         self.invalidate(_lib.VAR_ZF)
         self._fcache.clear()
 

@@ -203,6 +203,44 @@ def test_consensus_multichannel_dictionary(backend, name):
         assert max(its.XSlvRelRes) < 1e-10
 
 
+ZCHAN_CASES = {
+    'ccmod_cns_zchan_f64': {'MaxMainIter': 20, 'LinSolveCheck': True},
+    'ccmod_cns_zchan_opts_f32': {'MaxMainIter': 12, 'ZeroMean': True, 'AuxVarObj': False,
+                                 'DataType': np.float32},
+}
+
+
+@pytest.mark.parametrize('name', sorted(ZCHAN_CASES))
+def test_consensus_channelful_maps_with_multichannel_dictionary(backend, name):
+    """(N, N, Nc, K, M) coefficient maps with an (Nd, Nd, Nc, M) dictionary: every (image,
+    channel) block has a system matrix of its own, rho and the residuals are shared (the
+    reference reaches this by broadcasting; its tests/admm/test_ccmod.py:278-295).
+    Fixtures of oracle/make_golden.py gen_zchan (the unmodified reference)."""
+    from sporco_amd.admm import ccmod
+    g = load_golden(name)
+    optd = dict(ZCHAN_CASES[name])
+    f32 = optd.get('DataType') is np.float32
+    tol = 3e-4 if f32 else 1e-9
+    c = ccmod.ConvCnstrMOD_Consensus(g['Z'], g['S'], tuple(int(v) for v in g['dsz']),
+                                     ccmod.ConvCnstrMOD_Consensus.Options(optd))
+    Y = c.solve()
+    assert c.k == int(g['k_final'])
+    assert Y.shape == g['Y'].shape and rel_l2(Y, g['Y']) < tol
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    assert c.X.shape == g['X'].shape and rel_l2(c.X, g['X']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < (1e-4 if f32 else 1e-11)
+    if optd.get('LinSolveCheck'):
+        assert max(its.XSlvRelRes) < 1e-10
+    # the per-channel reconstruction sum_m Z_c,k,m * D_c,m
+    Zf = np.fft.rfftn(g['Z'], axes=(0, 1))
+    ref = np.fft.irfftn(np.sum(Zf * np.fft.rfftn(g['Y'], axes=(0, 1)), axis=4), (16, 16), axes=(0, 1))
+    assert rel_l2(c.reconstruct(), ref) < tol
+
+
 def test_dictlearn_consensus_colour_dictionary(backend):
     """ConvBPDNDictLearn(dmethod='cns') learning a colour dictionary (the reference's
     examples/scripts/cdl/cbpdndl_cns_clr.py in miniature)."""

@@ -241,6 +241,23 @@ def test_ccmod_pgm_multichannel_dictionary(backend):
     assert np.max(np.abs(np.mean(D, axis=(0, 1)))) < 1e-12
 
 
+def test_ccmod_pgm_channelful_maps_with_multichannel_dictionary(backend):
+    """Coefficient maps that carry the channels of a multi-channel dictionary -- the
+    reference's broadcasting then solves one single-channel problem per channel with a shared
+    step size (its tests/pgm/test_ccmod.py:175-191).  Fixture: oracle/make_golden.py gen_zchan."""
+    from sporco_amd.pgm import ccmod
+    g = load_golden('pgm_ccmod_zchan_f64')
+    c = ccmod.ConvCnstrMOD(g['Z'], g['S'], tuple(int(v) for v in g['dsz']),
+                           ccmod.ConvCnstrMOD.Options({'MaxMainIter': 20, 'L': 400.0}))
+    c.solve()
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < 1e-9
+    assert rel_l2(c.X, g['X']) < 1e-9
+    its = c.getitstat()
+    for f in ('DFid', 'Rsdl', 'L'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < 1e-11
+
+
 @pytest.mark.parametrize('name,dt,tol', [
     ('cbpdndl_mcdict_f64', np.float64, 1e-9),
     pytest.param('cbpdndl_mcdict_f32', np.float32, 1e-3, marks=pytest.mark.gpu)])
