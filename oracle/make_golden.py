@@ -1182,12 +1182,47 @@ def gen_zchan():
     save('pgm_ccmod_zchan_f64', Z=Z, S=S, dsz=np.array((Nd, Nd, Nc, M)), D=c.getdict(), X=c.X,
          **itstat_dict(c))
 
+def gen_ccmodmd_cns_mcdict():
+    """ConvCnstrMODMaskDcpl_Consensus with a multi-channel (colour) dictionary
+    (sporco/admm/ccmodmd.py:766-1083 on ccmod.py:696-698): channel-less coefficient maps as the
+    sparse coding step produces them, maps that carry the channels (the reference's own
+    tests/admm/test_ccmodmd.py:333-351), and masked colour dictionary learning with
+    dmethod='cns' (the reference's examples/scripts/cdl/cbpdndl_md_clr.py in miniature)."""
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    from sporco.dictlrn import cbpdndlmd as ref_md
+    np.random.seed(57721)
+    N, M, Nd, K, Nc = 16, 4, 5, 3, 3
+    S = np.random.randn(N, N, Nc, K)
+    Z = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.6)
+    Zc = np.random.randn(N, N, Nc, K, M) * (np.random.rand(N, N, Nc, K, M) > 0.6)
+    W = (np.random.rand(N, N, Nc, K) > 0.3).astype(np.float64)
+    Wb = (np.random.rand(N, N) > 0.3).astype(np.float64)
+    cls = ref_ccmodmd.ConvCnstrMODMaskDcpl_Consensus
+    for name, ZZ, WW, optd in (
+            ('f64', Z, W, {'MaxMainIter': 15, 'LinSolveCheck': True}),
+            ('opts_f32', Z, Wb, {'MaxMainIter': 15, 'rho': 3.0, 'RelaxParam': 1.5,
+                                 'ZeroMean': True, 'DataType': np.float32}),
+            ('zchan_f64', Zc, Wb, {'MaxMainIter': 15, 'LinSolveCheck': True})):
+        c = cls(ZZ, S, WW, (Nd, Nd, Nc, M), cls.Options(optd))
+        c.solve()
+        save('ccmodmd_cns_mcdict_%s' % name, Z=ZZ, S=S, W=WW, dsz=np.array((Nd, Nd, Nc, M)),
+             D=c.getdict(), Y=c.Y, X=c.X, U=c.U, Y1=c.Y1, U1=c.U1, rho_final=np.float64(c.rho),
+             k_final=np.int64(c.k), **itstat_dict(c))
+    D0 = np.random.randn(Nd, Nd, Nc, M)
+    Wd = (np.random.rand(N, N, 1, K) > 0.3).astype(np.float64)
+    opt = ref_md.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                               xmethod='admm', dmethod='cns')
+    b = ref_md.ConvBPDNMaskDictLearn(D0, S, 0.1, Wd, opt, xmethod='admm', dmethod='cns')
+    D1 = b.solve()
+    save('cbpdndlmd_admm_cns_mcdict_f64', D0=D0, S=S, W=Wd, lmbda=np.float64(0.1), D1=D1,
+         X=b.getcoef(), **itstat_dict(b))
+
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan']
-    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan,
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict']
+    table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -204,9 +204,9 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd > 1 and (self._mask_dcpl or reducer is not None):
+        if self.cri.Cd > 1 and reducer is not None:
             raise NotImplementedError("a multi-channel dictionary in the consensus update: not "
-                                      "with mask decoupling or image shards")
+                                      "with image shards")
         if (not opt['gEvalY'] or opt['fEvalX']) and (reducer is not None or self._mask_dcpl):
             raise NotImplementedError("objective at the blocks X_n (AuxVarObj False): not with "
                                       "image shards (the mean of X runs over ALL images) and not "

@@ -264,14 +264,19 @@ class ConvCnstrMODMaskDcpl_Consensus(ccmod.ConvCnstrMOD_Consensus):
         super(ConvCnstrMODMaskDcpl_Consensus, self).init_state(yshape, ushape)
         self.W = self._mask5()
         H, Wd = self.cri.Nv
-        if self.cri.C > 1:
+        if self.cri.Cd > 1:
+            # multi-channel dictionary: signal, mask and the block (Y1, U1) keep the channel axis
+            self.dev.set_data_mask(ccmod_broadcastable(
+                self.W, (H, Wd, self.cri.C, self.cri.K, 1)))
+        elif self.cri.C > 1:
             full = np.ascontiguousarray(np.broadcast_to(self.W, (H, Wd, 1, self.Nb, 1)))
             self.dev.set_data_mask(full.reshape(H, Wd, self.cri.C, self.cri.K, 1))
         else:
             self.dev.set_data_mask(ccmod_broadcastable(self.W, (H, Wd, 1, self.Nb, 1)))
         self.dev.cns_md_init(self.S)
 
-    # the signal-sized block, in the reference's (H, W, 1, Nb, 1) layout
+    # the signal-sized block, in the reference's (H, W, 1, Nb, 1) layout ((H, W, C, K, 1) with a
+    # multi-channel dictionary)
     @property
     def Y1(self):
         return self.dev.download(_lib.VAR_DMY0)

@@ -2904,9 +2904,8 @@ template <typename T> struct Csc : CscBase {
 
     // ---- consensus update with mask decoupling (ConvCnstrMODMaskDcpl_Consensus) ----------------
     void cns_md_init(const void *S) override {
-        require_single_channel_dict();
         SA_REQUIRE(S != nullptr, "S is null");
-        const size_t nb = sizeof(T) * (int64_t)H * W * CN;
+        const size_t nb = sizeof(T) * (int64_t)H * W * CNs;
         if (!md_s) SA_HIP(hipMalloc((void **)&md_s, nb));
         SA_HIP(hipMemcpyAsync(md_s, S, nb, hipMemcpyHostToDevice, st));
         SA_HIP(hipMemsetAsync(rv(SPORCO_AMD_VAR_DMY0), 0, nb, st));
@@ -2918,17 +2917,31 @@ template <typename T> struct Csc : CscBase {
     // (admm.py:331-367): xstep (:922-939, the consensus solve with rho = 1 and S + Y1 - U1 in
     // the signal's place), relax_AX (:899-918), ystep (:943-952), ustep (:956-963), and the
     // sums of compute_residuals (:976-1034) / obfn_dfd (:966-972).  Generic FFT chain.
+    // Multi-channel dictionary (Cd > 1; the reference's examples/scripts/cdl/cbpdndl_md_clr.py):
+    // one (Cd, K) block per image as in cns_iter -- systems and block spectra in (image, channel)
+    // order, the signal-sized block (Y1, U1, S, the mask) in the signal's (channel, image) order,
+    // its spectra transposed on the way in and out of the block arithmetic.
     void cns_md_iter(const sporco_amd_cns_params &p, double *out_dev) {
         SA_REQUIRE(md_s != nullptr, "cns_md_init must be called first");
         SA_REQUIRE(p.rho > 0.0, "rho must be positive");
         need_natural(SPORCO_AMD_VAR_ZF);
-        const int64_t npixr = (int64_t)H * W, ns = npixr * CN;
+        const int64_t npixr = (int64_t)H * W, ns = npixr * CNs;
+        const int KDi = (int)KD();
+        const int64_t PD = P * Cd;
+        const int64_t nblk = npix * CN * Cd;        // (frequency, image, channel) rows
         const T us = (T)p.u_scale;
         T *Y = rv(SPORCO_AMD_VAR_DX), *X = rv(SPORCO_AMD_VAR_CX), *U = rv(SPORCO_AMD_VAR_CU);
         T *Y1 = rv(SPORCO_AMD_VAR_DMY0), *U1 = rv(SPORCO_AMD_VAR_DMU0);
-        cx<T> *Zf = cv(SPORCO_AMD_VAR_ZF);
+        const cx<T> *Zf = zf_nat();
         cns_buffers();
-        cx<T> *wk = work_buf();
+        cx<T> *wk = Cd > 1 ? cns_w : work_buf();
+        // (signal-sized spectra in the blocks' order: the transposed copy when Cd > 1)
+        auto to_blocks = [&](cx<T> *sig) -> cx<T> * {
+            if (Cd == 1) return sig;
+            ProfScope ps(prof, PS_OTHER);
+            launch_swap_inner<T>(st, sig, cns_sft, npix, Cd, N);
+            return cns_sft;
+        };
         if (p.phase != 2) {
         // xstep: ZSf = conj(Zf) rfftn(S + Y1 - U1); X_n = irfftn(SM(Zf_n, 1, ZSf_n + rfftn(Y - U_n)))
         {
@@ -2937,52 +2950,61 @@ template <typename T> struct Csc : CscBase {
             // the consensus duals only, so the pending scale does not apply to it)
             launch_md_pre<T>(st, Y1, U1, md_s, sreal, T(1), ns);
         }
-        fwd2(sreal, nullptr, T(0), innerb, CN);
+        fwd2(sreal, nullptr, T(0), innerb, CNs);
+        const cx<T> *sfb = to_blocks(innerb);
         {
             ProfScope ps(prof, PS_FFT_R2C);
-            fft_r2c<T>(st, planW, Y, U, us, cns_f, H, P, (int64_t)W * P, P, (int64_t)Wf * P, P, 0, 0,
-                       K);
+            fft_r2c<T>(st, planW, Y, U, us, cns_f, H, PD, (int64_t)W * PD, PD, (int64_t)Wf * PD, PD, 0,
+                       0, KDi);
         }
         {
             ProfScope ps(prof, PS_FFT_C2C_FWD);
-            fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * P, 0, (int64_t)Wf * P, 0,
-                       (int64_t)Wf * P, T(1));
+            fft_c2c<T>(st, planH, false, cns_f, cns_f, 1, (int64_t)Wf * PD, 0, (int64_t)Wf * PD, 0,
+                       (int64_t)Wf * PD, T(1));
         }
         // LinSolveCheck (ccmod.py:783-792, as in cns_iter; the XRRS slots carry block-1 sums in
         // this call, so the three sums go to the L1, RGR and CGN slots)
         const bool lsc = p.flags & F_XRRS;
         if (lsc) {
             ProfScope ps(prof, PS_OTHER);
-            launch_cns_xrrs_rhs<T>(st, Zf, innerb, cns_f, T(1), dwork_buf(), npix, CN, K);
+            launch_cns_xrrs_rhs<T>(st, Zf, sfb, cns_f, T(1), dwork_buf(), npix, CN * Cd, K, Cd, z_chan);
         }
         {
             ProfScope ps(prof, PS_SM_SOLVE);
-            launch_sm_solve<T>(st, cns_f, cns_f, Zf, innerb, nullptr, T(1), npix, CN, K, W, false,
-                               false, part_a, nullptr, true);
+            launch_sm_solve<T>(st, cns_f, cns_f, Zf, sfb, nullptr, T(1), npix, CN * Cd, K, W, false,
+                               false, part_a, nullptr, z_chan ? 1 : Cd);
         }
         if (lsc) {
             int nbx;
             {
                 ProfScope ps(prof, PS_OTHER);
-                nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, T(1), dwork_buf(), npix, CN, K, part_a);
+                nbx = launch_cns_xrrs_fin<T>(st, Zf, cns_f, T(1), dwork_buf(), npix, CN * Cd, K, part_a, Cd,
+                                             z_chan);
             }
             const int xslots[3] = {SPORCO_AMD_OUT_L1, SPORCO_AMD_OUT_RGR, SPORCO_AMD_OUT_CGN};
             const double xscales[3] = {1.0, 1.0, 1.0};
             finalize(part_a, nbx, 3, 3, xslots, xscales, out_dev);
         }
-        inv2(cns_f, wk, X, P);
         // relax_AX, block 1: AX1nr_n = irfftn(sum_m Zf_{n,m} Xf_{n,m}) -- the inner product of
         // every (frequency, image) row with itself-indexed coefficients: npix * CN "pixels"
+        // (the Cd channel blocks of an image against the image's row when they share it)
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_inner<T>(st, Zf, cns_f, innerb, npix * CN, 1, K);
+            if (Cd == 1) {
+                launch_inner<T>(st, Zf, cns_f, innerb, npix * CN, 1, K);
+            } else {
+                if (z_chan) launch_inner<T>(st, Zf, cns_f, cns_sft, nblk, 1, K);
+                else launch_inner<T>(st, Zf, cns_f, cns_sft, npix * CN, Cd, K);
+                launch_swap_inner<T>(st, cns_sft, innerb, npix, N, Cd);
+            }
         }
-        inv2(innerb, innerb, sreal, CN);
+        inv2(cns_f, wk, X, PD);
+        inv2(innerb, innerb, sreal, CNs);
         // consensus part: Y = Pcn(mean_n(alpha X_n + (1 - alpha) Y + U_n))
-        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * K, hipMemcpyDeviceToDevice, st));
+        SA_HIP(hipMemcpyAsync(cns_yold, Y, sizeof(T) * npixr * KDi, hipMemcpyDeviceToDevice, st));
         {
             ProfScope ps(prof, PS_OTHER);
-            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, us, npixr, CN, K);
+            launch_cns_mean<T>(st, X, U, cns_yold, cns_m, (T)p.rlx, us, npixr, CN, KDi);
         }
         }   // phase != 2
         if (p.phase == 1) return;
@@ -3001,7 +3023,7 @@ template <typename T> struct Csc : CscBase {
         ya.geval_y = 1;
         ya.H = H;
         ya.W = W;
-        ya.C = C;
+        ya.C = Cs;
         ya.N = N;
         int nb;
         {
@@ -3017,7 +3039,7 @@ template <typename T> struct Csc : CscBase {
         // consensus ustep + the X-sized sums
         {
             ProfScope ps(prof, PS_ADMM_POST);
-            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, us, npixr, CN, K, part_b);
+            nb = launch_cns_ustep<T>(st, X, U, cns_yold, Y, (T)p.rlx, us, npixr, CN, KDi, part_b);
         }
         {
             const int slots[3] = {SPORCO_AMD_OUT_R2, SPORCO_AMD_OUT_AX2, SPORCO_AMD_OUT_U2};
@@ -3026,23 +3048,25 @@ template <typename T> struct Csc : CscBase {
         }
         {
             ProfScope ps(prof, PS_OTHER);
-            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * K, part_a);
+            nb = launch_cns_ystats<T>(st, cns_yold, Y, npixr * KDi, part_a);
         }
         {
             const int slots[2] = {SPORCO_AMD_OUT_L21, SPORCO_AMD_OUT_Y2};   // (|Y - Yprev|^2 unused)
             const double scales[2] = {0, 1};
             finalize(part_a, nb, 2, 2, slots, scales, out_dev);
         }
-        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), K);
+        fwd2(Y, nullptr, T(0), cv(SPORCO_AMD_VAR_DXF), KDi);
         if (p.flags & F_RESID) {
             // dual residual: A^T u = U_n + irfftn(conj(Zf_n) rfftn(U1_n)), new duals (:993-996)
-            fwd2(U1, nullptr, T(0), innerb, CN);
-            fwd2(U, nullptr, T(0), cns_f, P);
+            fwd2(U1, nullptr, T(0), innerb, CNs);
+            fwd2(U, nullptr, T(0), cns_f, PD);
+            const cx<T> *u1b = to_blocks(innerb);
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_conj_outer<T>(st, Zf, innerb, wk, npix * CN, 1, K);
-                launch_lincomb<T>(st, wk, T(1), wk, T(1), cns_f, T(0), nullptr, EF);
-                nb = launch_pair_stats<T>(st, wk, nullptr, nullptr, npix, P, W, part_b);
+                if (Cd == 1 || z_chan) launch_conj_outer<T>(st, Zf, u1b, wk, nblk, 1, K);
+                else launch_conj_outer<T>(st, Zf, u1b, wk, npix * CN, Cd, K);
+                launch_lincomb<T>(st, wk, T(1), wk, T(1), cns_f, T(0), nullptr, EF * Cd);
+                nb = launch_pair_stats<T>(st, wk, nullptr, nullptr, npix, PD, W, part_b);
             }
             const int slots[1] = {SPORCO_AMD_OUT_S2};
             const double scales[1] = {1.0 / ((double)H * W)};
@@ -3052,14 +3076,15 @@ template <typename T> struct Csc : CscBase {
             // (1/2) |W irfftn(sum_m Zf Yf - Sf)|^2 at the consensus variable (:961-970)
             {
                 ProfScope ps(prof, PS_OTHER);
-                launch_inner<T>(st, cv(SPORCO_AMD_VAR_DXF), Zf, innerb, npix, CN, K);
+                if (Cd == 1) launch_inner<T>(st, cv(SPORCO_AMD_VAR_DXF), Zf, innerb, npix, CN, K);
+                else launch_mc_inner<T>(st, cv(SPORCO_AMD_VAR_DXF), Zf, innerb, npix, Cd, N, K, z_chan);
                 launch_lincomb<T>(st, innerb, T(1), innerb, T(-1), cv(SPORCO_AMD_VAR_SF), T(0),
-                                  nullptr, npix * CN);
+                                  nullptr, npix * CNs);
             }
-            inv2(innerb, innerb, sreal, CN);
+            inv2(innerb, innerb, sreal, CNs);
             {
                 ProfScope ps(prof, PS_OTHER);
-                nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), false, H, W, C, N,
+                nb = launch_mask_apply<T>(st, sreal, have_wdat ? wdat : Weight<T>(), false, H, W, Cs, N,
                                           part_a);
             }
             const int slots[1] = {SPORCO_AMD_OUT_DFID};
@@ -3079,7 +3104,6 @@ template <typename T> struct Csc : CscBase {
     }
 
     void cns_iter(const sporco_amd_cns_params &p, double *out_dev) override {
-        if (p.mask_dcpl) require_single_channel_dict();
         if (!have_signal) throw Error(SPORCO_AMD_ESTATE, "set_signal must be called first");
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         SA_REQUIRE(p.phase >= 0 && p.phase <= 2, "phase must be 0, 1 or 2");

@@ -292,10 +292,10 @@ int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *d
 template <typename T>
 int launch_mc_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx<T> *sf, cx<T> *gf,
                        int64_t npix, int Cd, int N, int K, int W, double *partials);
-// out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]
+// out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]   (vch: v[pix, n, c, k])
 template <typename T>
 void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
-                     int Cd, int N, int K);
+                     int Cd, int N, int K, int vch = 0);
 // gf[pix, n, k] (+)= sum_c conj(df[pix, c, k]) r[pix, c, n] (adjoint of launch_mc_inner)
 template <typename T>
 void launch_mc_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *gf, int64_t npix,

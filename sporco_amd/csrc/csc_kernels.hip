@@ -2247,7 +2247,8 @@ template <typename T>
 __global__ void __launch_bounds__(kThreads) mc_inner_kernel(const cx<T> *__restrict__ df,
                                                             const cx<T> *__restrict__ v,
                                                             cx<T> *__restrict__ out, int64_t npix,
-                                                            int Cd, int N, int K) {
+                                                            int Cd, int N, int K, int vch) {
+    // (vch: v has a channel axis of its own, (npix, N, Cd, K))
     const int64_t total = npix * Cd * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -2255,7 +2256,7 @@ __global__ void __launch_bounds__(kThreads) mc_inner_kernel(const cx<T> *__restr
         const int c = (int)((i / N) % Cd);
         const int64_t pix = i / ((int64_t)N * Cd);
         const cx<T> *d = df + (pix * Cd + c) * K;
-        const cx<T> *x = v + (pix * N + n) * K;
+        const cx<T> *x = v + (vch ? (pix * N + n) * Cd + c : pix * N + n) * K;
         cx<T> q = mk<T>(T(0), T(0));
         for (int k = 0; k < K; ++k) q = q + cmul(d[k], x[k]);
         out[i] = q;
@@ -2264,9 +2265,9 @@ __global__ void __launch_bounds__(kThreads) mc_inner_kernel(const cx<T> *__restr
 
 template <typename T>
 void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
-                     int Cd, int N, int K) {
+                     int Cd, int N, int K, int vch) {
     hipLaunchKernelGGL((mc_inner_kernel<T>), dim3(grid_for(npix * Cd * N)), dim3(kThreads), 0, st,
-                       df, v, out, npix, Cd, N, K);
+                       df, v, out, npix, Cd, N, K, vch);
     SA_HIP(hipGetLastError());
 }
 
@@ -3159,7 +3160,7 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_mc_pgm_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,   \
                                        cx<T> *, int64_t, int, int, int, int, double *);            \
     template void launch_mc_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t,  \
-                                     int, int, int);                                               \
+                                     int, int, int, int);                                          \
     template void launch_mc_conj_outer<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,      \
                                           int64_t, int, int, int, bool);                          \
     template int launch_mc_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int,  \

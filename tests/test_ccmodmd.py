@@ -236,6 +236,61 @@ def test_masked_dictlearn_consensus_dstep(backend, xm):
             assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
 
 
+MCDICT_CNS_CASES = {
+    'f64': {'MaxMainIter': 15, 'LinSolveCheck': True},
+    'opts_f32': {'MaxMainIter': 15, 'rho': 3.0, 'RelaxParam': 1.5, 'ZeroMean': True,
+                 'DataType': np.float32},
+    'zchan_f64': {'MaxMainIter': 15, 'LinSolveCheck': True},
+}
+
+
+@pytest.mark.parametrize('case', sorted(MCDICT_CNS_CASES))
+def test_consensus_multichannel_dictionary(backend, case):
+    """The masked consensus update of a colour dictionary (Cd = C = 3): one (Cd, M) block per
+    image, the signal-sized block (Y1, U1) with the signal's channels -- with channel-less
+    coefficient maps (what the sparse coding step hands over) and with maps that carry the
+    channels (the reference's tests/admm/test_ccmodmd.py:333-351).  Fixtures:
+    oracle/make_golden.py gen_ccmodmd_cns_mcdict (the unmodified reference)."""
+    from sporco_amd.admm import ccmodmd
+    g = load_golden('ccmodmd_cns_mcdict_' + case)
+    optd = MCDICT_CNS_CASES[case]
+    tol = 2e-3 if optd.get('DataType') is np.float32 else 1e-9
+    cls = ccmodmd.ConvCnstrMODMaskDcpl_Consensus
+    c = cls(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']), cls.Options(optd))
+    c.solve()
+    assert c.k == int(g['k_final'])
+    assert c.Y.shape == g['Y'].shape and rel_l2(c.Y, g['Y']) < tol
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < tol
+    assert c.X.shape == g['X'].shape and rel_l2(c.X, g['X']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    assert c.Y1.shape == g['Y1'].shape and rel_l2(c.Y1, g['Y1']) < tol
+    assert c.U1.shape == g['U1'].shape and rel_l2(c.U1, g['U1']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < max(10 * tol, 1e-9)
+    if optd.get('LinSolveCheck'):
+        assert max(its.XSlvRelRes) < 1e-10 and np.max(g['it_XSlvRelRes']) < 1e-10
+
+
+def test_masked_dictlearn_colour_dictionary(backend):
+    """ConvBPDNMaskDictLearn(xmethod='admm', dmethod='cns') learning a colour dictionary under
+    a mask: the reference's examples/scripts/cdl/cbpdndl_md_clr.py in miniature."""
+    from sporco_amd.dictlrn import cbpdndlmd
+    g = load_golden('cbpdndlmd_admm_cns_mcdict_f64')
+    opt = cbpdndlmd.ConvBPDNMaskDictLearn.Options({'MaxMainIter': 8, 'AccurateDFid': True},
+                                                  xmethod='admm', dmethod='cns')
+    b = cbpdndlmd.ConvBPDNMaskDictLearn(g['D0'], g['S'], float(g['lmbda']), g['W'], opt,
+                                        xmethod='admm', dmethod='cns')
+    D1 = b.solve()
+    assert rel_l2(D1.squeeze(), g['D1'].squeeze()) < 1e-9
+    assert rel_l2(b.getcoef(), g['X']) < 1e-9
+    its = b.getitstat()
+    for f in its._fields:
+        if 'it_' + f in g and f not in ('Iter', 'Cnstr', 'Time'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+
+
 def test_consensus_wrapper_and_fast_shape(backend):
     """method='cns' is the wrapper's default, as in the reference (ccmodmd.py:1056-1095); on a
     shape of the register-resident kernels (float32, 256 x 256) the update keeps working (the
