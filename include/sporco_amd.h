@@ -440,7 +440,12 @@ int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var);
 
 /* ZF = rfftn(real state `var`): setcoef (pgm/ccmod.py:264-279).  With a handle
  * shared between the X-step and the D-step, var = VAR_Y keeps the coefficient
- * maps on the device (DictLearn.post_xstep, dictlrn/dictlrn.py:379-382). */
+ * maps on the device (DictLearn.post_xstep, dictlrn/dictlrn.py:379-382).
+ * Handles of sporco_amd_csc_create_mc: var = VAR_CX hands over coefficient maps that carry the
+ * dictionary's channels, in the layout of that array (H, W, N, Cd, K) -- Cd single-channel
+ * updates sharing the penalty / step size (the reference's broadcasting:
+ * tests/admm/test_ccmod.py:278-295); VAR_CX is zeroed afterwards.  Served by
+ * sporco_amd_csc_ccmod_grad and sporco_amd_csc_cns_iter (not by the masked gradient). */
 int sporco_amd_csc_ccmod_setcoef(sporco_amd_csc_t h, int var);
 /* DGF = sum_n conj(Zf) (sum_k Zf*v - Sf) for the D-sized complex state `var`
  * (grad_f, pgm/ccmod.py:295-309: inner over axisM then over axisK, channels of
@@ -487,7 +492,9 @@ int sporco_amd_csc_masked_grad(sporco_amd_csc_t h, int var, int32_t dstep, int32
  * One dictionary copy X_n and dual U_n per image (VAR_CX, VAR_CU), consensus variable
  * Y = VAR_DX (its spectrum VAR_DXF is kept current, so sporco_amd_csc_ccmod_getdict and
  * sporco_amd_csc_setdict_from_dstep serve this D-step too).  Coefficient maps come from
- * sporco_amd_csc_ccmod_setcoef.  Single-channel dictionaries. */
+ * sporco_amd_csc_ccmod_setcoef.  Handles of sporco_amd_csc_create_mc (a dictionary with Cd > 1
+ * channels, ccmod.py:696-698): VAR_CX / VAR_CU are (H, W, N, Cd, K) -- one (Cd, K) block per
+ * image --, VAR_DX is (H, W, Cd, K); both the plain and the mask-decoupled update serve them. */
 /* Y = Y0 (real (H,W,K), zero-padded filters) or 0; U_n = Y0 / rho or 0 (uinit, ccmod.py:734-742). */
 int sporco_amd_csc_cns_init(sporco_amd_csc_t h, const void *Y0, double rho);
 typedef struct {
