@@ -445,7 +445,7 @@ int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var);
  * dictionary's channels, in the layout of that array (H, W, N, Cd, K) -- Cd single-channel
  * updates sharing the penalty / step size (the reference's broadcasting:
  * tests/admm/test_ccmod.py:278-295); VAR_CX is zeroed afterwards.  Served by
- * sporco_amd_csc_ccmod_grad and sporco_amd_csc_cns_iter (not by the masked gradient). */
+ * sporco_amd_csc_ccmod_grad, sporco_amd_csc_masked_grad (dstep) and sporco_amd_csc_cns_iter. */
 int sporco_amd_csc_ccmod_setcoef(sporco_amd_csc_t h, int var);
 /* DGF = sum_n conj(Zf) (sum_k Zf*v - Sf) for the D-sized complex state `var`
  * (grad_f, pgm/ccmod.py:295-309: inner over axisM then over axisK, channels of

@@ -1181,6 +1181,21 @@ def gen_zchan():
     c.solve()
     save('pgm_ccmod_zchan_f64', Z=Z, S=S, dsz=np.array((Nd, Nd, Nc, M)), D=c.getdict(), X=c.X,
          **itstat_dict(c))
+    # the masked PGM update with such maps (tests/pgm/test_ccmod.py:546-563), and a dsz with an
+    # explicit single channel, which makes the third axis of S channels, not images (:453-468)
+    W = np.random.randn(N, N, Nc, K)
+    cls = ref_pgm_ccmod.ConvCnstrMODMask
+    c = cls(Z, S, W, (Nd, Nd, Nc, M), cls.Options({'MaxMainIter': 20, 'L': 400.0}))
+    c.solve()
+    save('pgm_ccmod_mask_zchan_f64', Z=Z, S=S, W=W, dsz=np.array((Nd, Nd, Nc, M)), D=c.getdict(),
+         X=c.X, **itstat_dict(c))
+    Z1 = np.random.randn(N, N, 1, 3, M)
+    S1 = np.random.randn(N, N, 3)
+    W1 = np.random.randn(N, N, 3)
+    c = cls(Z1, S1, W1, (Nd, Nd, 1, M), cls.Options({'MaxMainIter': 20, 'L': 400.0}))
+    c.solve()
+    save('pgm_ccmod_mask_dsz1chan_f64', Z=Z1, S=S1, W=W1, dsz=np.array((Nd, Nd, 1, M)),
+         D=c.getdict(), X=c.X, **itstat_dict(c))
 
 def gen_ccmodmd_cns_mcdict():
     """ConvCnstrMODMaskDcpl_Consensus with a multi-channel (colour) dictionary

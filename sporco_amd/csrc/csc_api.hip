@@ -2772,8 +2772,6 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var) && var_is_complex(var) && var_is_dict_sized(var) == dstep &&
                        var != SPORCO_AMD_VAR_SF && var != SPORCO_AMD_VAR_DF,
                    "masked_grad: variable of the wrong kind");
-        SA_REQUIRE(!(dstep && z_chan), "masked_grad: coefficient maps with a channel axis are served by "
-                                       "ccmod_grad / cns_iter only");
         before_read(var);
         SA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * kOutSlots, st));
         cx<T> *Sf = cv(SPORCO_AMD_VAR_SF);
@@ -2781,7 +2779,7 @@ template <typename T> struct Csc : CscBase {
             ProfScope ps(prof, PS_PGM);
             if (dstep) {
                 need_natural(SPORCO_AMD_VAR_ZF);
-                if (Cd > 1) launch_mc_inner<T>(st, cv(var), cv(SPORCO_AMD_VAR_ZF), innerb, npix, Cd, N, K);
+                if (Cd > 1) launch_mc_inner<T>(st, cv(var), zf_nat(), innerb, npix, Cd, N, K, z_chan);
                 else launch_inner<T>(st, cv(var), cv(SPORCO_AMD_VAR_ZF), innerb, npix, CN, K);
             } else {
                 require_ready();
@@ -2816,8 +2814,7 @@ template <typename T> struct Csc : CscBase {
         ProfScope ps(prof, PS_PGM);
         if (dstep) {
             if (Cd > 1)
-                launch_mc_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, cv(SPORCO_AMD_VAR_DGF), npix, Cd,
-                                        N, K);
+                launch_mc_zf_adjoint<T>(st, zf_nat(), innerb, cv(SPORCO_AMD_VAR_DGF), npix, Cd, N, K, z_chan);
             else
                 launch_zf_adjoint<T>(st, cv(SPORCO_AMD_VAR_ZF), innerb, cv(SPORCO_AMD_VAR_DGF), npix, CN, K);
         } else if (Cd > 1) {

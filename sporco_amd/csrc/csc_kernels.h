@@ -234,7 +234,7 @@ void launch_conj_outer(hipStream_t st, const cx<T> *df, const cx<T> *r, cx<T> *g
 // gf[pix, k] = sum_n conj(zf[pix, n, k]) r[pix, n]
 template <typename T>   // multi-channel dictionary: gf[pix, c, k] = sum_n conj(zf[pix, n, k]) r[pix, c, n]
 void launch_mc_zf_adjoint(hipStream_t st, const cx<T> *zf, const cx<T> *r, cx<T> *gf, int64_t npix,
-                          int Cd, int N, int K);
+                          int Cd, int N, int K, int zch = 0);   // (zch: zf[pix, n, c, k])
 template <typename T>
 void launch_zf_adjoint(hipStream_t st, const cx<T> *zf, const cx<T> *r, cx<T> *gf, int64_t npix,
                        int CN, int K);

@@ -1446,11 +1446,12 @@ __global__ void __launch_bounds__(kThreads) zf_adjoint_kernel(const cx<T> *__res
 }
 
 // Multi-channel dictionary: gf[pix, c, k] = sum_n conj(zf[pix, n, k]) r[pix, c, n]
+// (zch: zf[pix, n, c, k])
 template <typename T>
 __global__ void __launch_bounds__(kThreads) mc_zf_adjoint_kernel(const cx<T> *__restrict__ zf,
                                                                  const cx<T> *__restrict__ r,
                                                                  cx<T> *__restrict__ gf, int64_t npix,
-                                                                 int Cd, int N, int K) {
+                                                                 int Cd, int N, int K, int zch) {
     const int64_t total = npix * Cd * K;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -1458,15 +1459,16 @@ __global__ void __launch_bounds__(kThreads) mc_zf_adjoint_kernel(const cx<T> *__
         const int64_t pix = i / ((int64_t)K * Cd);
         cx<T> acc = mk<T>(T(0), T(0));
         for (int n = 0; n < N; ++n)
-            acc = acc + cmulc(zf[(pix * N + n) * K + k], r[(pix * Cd + c) * N + n]);
+            acc = acc + cmulc(zf[(zch ? (pix * N + n) * Cd + c : pix * N + n) * K + k],
+                              r[(pix * Cd + c) * N + n]);
         gf[i] = acc;
     }
 }
 template <typename T>
 void launch_mc_zf_adjoint(hipStream_t st, const cx<T> *zf, const cx<T> *r, cx<T> *gf, int64_t npix,
-                          int Cd, int N, int K) {
+                          int Cd, int N, int K, int zch) {
     hipLaunchKernelGGL((mc_zf_adjoint_kernel<T>), dim3(grid_for(npix * Cd * K)), dim3(kThreads), 0, st,
-                       zf, r, gf, npix, Cd, N, K);
+                       zf, r, gf, npix, Cd, N, K, zch);
     SA_HIP(hipGetLastError());
 }
 
@@ -3139,7 +3141,7 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template void launch_zf_adjoint<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,         \
                                        int64_t, int, int);                                         \
     template void launch_mc_zf_adjoint<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *,      \
-                                          int64_t, int, int, int);                                 \
+                                          int64_t, int, int, int, int);                            \
     template void launch_cns_yu<T>(hipStream_t, const T *, const T *, T *, T, int64_t, int, int);  \
     template void launch_cns_mean<T>(hipStream_t, const T *, const T *, const T *, T *, T, T,      \
                                      int64_t, int, int);                                           \

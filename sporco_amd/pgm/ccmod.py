@@ -216,8 +216,6 @@ class ConvCnstrMODMask(ConvCnstrMOD):
     def __init__(self, Z, S, W, dsz, opt=None, dimK=None, dimN=2, **backend):
         if opt is None:
             opt = ConvCnstrMODMask.Options()
-        if dimK is None:
-            dimK = 1 if np.asarray(S).ndim > dimN else 0
         cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
         W = np.asarray(W)
         if W.ndim < dimN + 3:

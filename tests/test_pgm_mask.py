@@ -108,3 +108,21 @@ def test_convcnstrmodmask_multichannel_dictionary(backend):
     for f in ('DFid', 'Rsdl'):
         assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
     assert max(its.Cnstr) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['pgm_ccmod_mask_zchan_f64', 'pgm_ccmod_mask_dsz1chan_f64'])
+def test_convcnstrmodmask_reference_test_shapes(backend, name):
+    """Two shapes of the reference's own test file: coefficient maps that carry the channels of
+    a colour dictionary (tests/pgm/test_ccmod.py:546-563), and a ``dsz`` with an explicit single
+    channel, under which the third axis of a 3-d ``S`` counts as channels (:453-468; mask
+    (N, N, 3) with it).  Fixtures: oracle/make_golden.py gen_zchan."""
+    from sporco_amd.pgm import ccmod
+    g = load_golden(name)
+    c = ccmod.ConvCnstrMODMask(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']),
+                               ccmod.ConvCnstrMODMask.Options({'MaxMainIter': 20, 'L': 400.0}))
+    c.solve()
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < 1e-9
+    assert c.X.shape == g['X'].shape and rel_l2(c.X, g['X']) < 1e-9
+    its = c.getitstat()
+    for f in ('DFid', 'Rsdl', 'L'):
+        assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
