@@ -33,6 +33,7 @@ timeout 300 python tools/bench_pgm_k128.py 2>&1 | grep "^{" >> $O/k128.jsonl
 for t in bench_ams bench_gradreg bench_joint bench_mcdict bench_grdmsk bench_size128; do timeout 300 python tools/$t.py 2>/dev/null | grep "^{" >> $O/side_benches.jsonl; done
 timeout 300 python tools/bench_masked.py 2>/dev/null | grep "^{" > $O/masked.jsonl
 timeout 300 python tools/bench_dictlearn_dsteps.py 2>&1 | grep "^{" > $O/dictlearn_dsteps.jsonl
+timeout 300 python tools/bench_dictlearn_colour.py 2>&1 | grep "^{" > $O/dictlearn_colour.jsonl
 # small problems as one launch (opt-in) against the launch-per-pass loop; the generic chain
 for v in 0 1; do SPORCO_AMD_PERSIST=$v timeout 200 python tools/bench_other.py c1 2>&1 | grep "^{" | sed "s/^{/{\"SPORCO_AMD_PERSIST\": $v, /" >> $O/config1_one_launch.jsonl; done
 timeout 400 python tools/bench_generic.py 2>&1 | grep "^{" > $O/generic_chain.jsonl
