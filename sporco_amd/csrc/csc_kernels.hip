@@ -359,26 +359,44 @@ int launch_grad_norm(hipStream_t st, const cx<T> *vf, const GradTerm<T> &g, int6
 // ---------------------------------------------------------------------------
 // inner product over filters, half-spectrum norms
 // ---------------------------------------------------------------------------
-template <typename T>
+// L lanes share one output (consecutive lanes read consecutive filters; L = 1: a thread per output)
+template <typename T, int L>
 __global__ void __launch_bounds__(kThreads) inner_kernel(const cx<T> *__restrict__ df,
                                                          const cx<T> *__restrict__ v,
                                                          cx<T> *__restrict__ out, int64_t npix,
                                                          int CN, int K) {
     const int64_t total = npix * CN;
-    for (int64_t grp = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < total;
-         grp += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = grp / CN;
+    const int sub = threadIdx.x % L;
+    const int64_t per_blk = blockDim.x / L;
+    // (every lane takes part in the shuffles: the loop bound is the same for a whole workgroup)
+    for (int64_t base = (int64_t)blockIdx.x * per_blk; base < total; base += (int64_t)gridDim.x * per_blk) {
+        const int64_t grp = base + threadIdx.x / L;
         cx<T> q = mk<T>(T(0), T(0));
-        for (int k = 0; k < K; ++k) q = q + cmul(df[pix * K + k], v[grp * K + k]);
-        out[grp] = q;
+        if (grp < total) {
+            const cx<T> *d = df + (grp / CN) * K, *x = v + grp * K;
+            for (int k = sub; k < K; k += L) q = q + cmul(d[k], x[k]);
+        }
+        if (L > 1) {
+#pragma unroll
+            for (int m = L / 2; m >= 1; m >>= 1) {
+                q.re += __shfl_xor(q.re, m, kWave);
+                q.im += __shfl_xor(q.im, m, kWave);
+            }
+        }
+        if (grp < total && sub == 0) out[grp] = q;
     }
 }
 
 template <typename T>
 void launch_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
                   int CN, int K) {
-    hipLaunchKernelGGL((inner_kernel<T>), dim3(grid_for(npix * CN)), dim3(kThreads), 0, st, df, v,
-                       out, npix, CN, K);
+    if (K >= 16) {
+        hipLaunchKernelGGL((inner_kernel<T, 16>), dim3(grid_for(npix * CN * 16)), dim3(kThreads), 0, st, df,
+                           v, out, npix, CN, K);
+    } else {
+        hipLaunchKernelGGL((inner_kernel<T, 1>), dim3(grid_for(npix * CN)), dim3(kThreads), 0, st, df, v,
+                           out, npix, CN, K);
+    }
     SA_HIP(hipGetLastError());
 }
 
@@ -2245,31 +2263,47 @@ int launch_mc_pgm_grad(hipStream_t st, const cx<T> *v, const cx<T> *df, const cx
 
 // out[pix, c, n] = sum_k df[pix, c, k] v[pix, n, k]: linalg.inner over the filter axis for a
 // multi-channel dictionary (the Cd = 1 case is launch_inner)
-template <typename T>
+template <typename T, int L>    // (L lanes per output, as inner_kernel)
 __global__ void __launch_bounds__(kThreads) mc_inner_kernel(const cx<T> *__restrict__ df,
                                                             const cx<T> *__restrict__ v,
                                                             cx<T> *__restrict__ out, int64_t npix,
                                                             int Cd, int N, int K, int vch) {
     // (vch: v has a channel axis of its own, (npix, N, Cd, K))
     const int64_t total = npix * Cd * N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(i % N);
-        const int c = (int)((i / N) % Cd);
-        const int64_t pix = i / ((int64_t)N * Cd);
-        const cx<T> *d = df + (pix * Cd + c) * K;
-        const cx<T> *x = v + (vch ? (pix * N + n) * Cd + c : pix * N + n) * K;
+    const int sub = threadIdx.x % L;
+    const int64_t per_blk = blockDim.x / L;
+    for (int64_t base = (int64_t)blockIdx.x * per_blk; base < total; base += (int64_t)gridDim.x * per_blk) {
+        const int64_t i = base + threadIdx.x / L;
         cx<T> q = mk<T>(T(0), T(0));
-        for (int k = 0; k < K; ++k) q = q + cmul(d[k], x[k]);
-        out[i] = q;
+        if (i < total) {
+            const int n = (int)(i % N);
+            const int c = (int)((i / N) % Cd);
+            const int64_t pix = i / ((int64_t)N * Cd);
+            const cx<T> *d = df + (pix * Cd + c) * K;
+            const cx<T> *x = v + (vch ? (pix * N + n) * Cd + c : pix * N + n) * K;
+            for (int k = sub; k < K; k += L) q = q + cmul(d[k], x[k]);
+        }
+        if (L > 1) {
+#pragma unroll
+            for (int m = L / 2; m >= 1; m >>= 1) {
+                q.re += __shfl_xor(q.re, m, kWave);
+                q.im += __shfl_xor(q.im, m, kWave);
+            }
+        }
+        if (i < total && sub == 0) out[i] = q;
     }
 }
 
 template <typename T>
 void launch_mc_inner(hipStream_t st, const cx<T> *df, const cx<T> *v, cx<T> *out, int64_t npix,
                      int Cd, int N, int K, int vch) {
-    hipLaunchKernelGGL((mc_inner_kernel<T>), dim3(grid_for(npix * Cd * N)), dim3(kThreads), 0, st,
-                       df, v, out, npix, Cd, N, K, vch);
+    if (K >= 16) {
+        hipLaunchKernelGGL((mc_inner_kernel<T, 16>), dim3(grid_for(npix * Cd * N * 16)), dim3(kThreads), 0,
+                           st, df, v, out, npix, Cd, N, K, vch);
+    } else {
+        hipLaunchKernelGGL((mc_inner_kernel<T, 1>), dim3(grid_for(npix * Cd * N)), dim3(kThreads), 0, st,
+                           df, v, out, npix, Cd, N, K, vch);
+    }
     SA_HIP(hipGetLastError());
 }
 
