@@ -2384,35 +2384,38 @@ __global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict
     // v is (H, W, Cd, K); mean per (channel, filter) over the support (cnvrep.zeromean,
     // cnvrep.py:609-670), norm per filter over support and channels (cnvrep.normalise with
     // dimN + dimC axes, cnvrep.py:696-700).  stats[2 (c K + k)] = mean, stats[2k + 1] = 1/norm.
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+    // One wave per filter, the lanes share the support.
+    const int lane = threadIdx.x & (kWave - 1);
+    const int nwaves = gridDim.x * (blockDim.x / kWave);
+    for (int k = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; k < K; k += nwaves) {
         // (multi-scale dictionary: every filter has its own support, cnvrep.py:634-662, :778-812)
         const int dH = fs.h ? fs.h[k] : dH_, dW = fs.w ? fs.w[k] : dW_;
+        const int np = dH * dW;
         T n2 = T(0);
         for (int c = 0; c < Cd; ++c) {
             T mean = T(0);
             if (zm) {
                 T s = T(0);
-                for (int h = 0; h < dH; ++h)
-                    for (int x = 0; x < dW; ++x) s += v[(((int64_t)h * W + x) * Cd + c) * K + k];
-                mean = s / (T)(dH * dW);
+                for (int i = lane; i < np; i += kWave)
+                    s += v[(((int64_t)(i / dW) * W + i % dW) * Cd + c) * K + k];
+                mean = (T)(wave_sum((double)s) / (double)np);
             }
-            for (int h = 0; h < dH; ++h)
-                for (int x = 0; x < dW; ++x) {
-                    const T e = v[(((int64_t)h * W + x) * Cd + c) * K + k] - mean;
-                    n2 += e * e;
-                }
-            stats[2 * (c * K + k)] = mean;
+            for (int i = lane; i < np; i += kWave) {
+                const T e = v[(((int64_t)(i / dW) * W + i % dW) * Cd + c) * K + k] - mean;
+                n2 += e * e;
+            }
+            if (lane == 0) stats[2 * (c * K + k)] = mean;
         }
-        const T nrm = sqrt(n2);
-        stats[2 * k + 1] = nrm == T(0) ? T(1) : T(1) / nrm;
+        const T nrm = (T)sqrt(wave_sum((double)n2));
+        if (lane == 0) stats[2 * k + 1] = nrm == T(0) ? T(1) : T(1) / nrm;
     }
 }
 
 template <typename T>
 void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,
                       bool zm, int Cd, FilterSizes fs) {
-    hipLaunchKernelGGL((pcn_stats_kernel<T>), dim3(grid_for(K)), dim3(kThreads), 0, st, v, stats, H,
-                       W, K, dH, dW, zm ? 1 : 0, Cd, fs);
+    hipLaunchKernelGGL((pcn_stats_kernel<T>), dim3(grid_for((int64_t)K * kWave)), dim3(kThreads), 0, st, v,
+                       stats, H, W, K, dH, dW, zm ? 1 : 0, Cd, fs);
     SA_HIP(hipGetLastError());
 }
 
