@@ -1723,6 +1723,9 @@ template <typename T> struct IsmArgs {
 //     f_c = (t_c - sum_{l<c} M_cl f_l) / delta_c,     x = beta0 - sum_c gamma_c f_c,
 //     (D x)_c = t_c - sum_l M_cl f_l.
 // CC: compile-time channel count (2..4), or 0 for a run-time Cd <= 8.
+__host__ __device__ inline int ism_waves_per_pixel(int nrhs, int wpb) {
+    return nrhs >= 3 ? wpb : (nrhs == 2 ? 2 : 1);
+}
 template <typename T, int KR, int CC, bool GRAD>
 __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a) {
     constexpr int CM = CC ? CC : 8;
@@ -1732,10 +1735,13 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
     const T rho = a.rho, irho = T(1) / a.rho;
     // The kThreads / kWave waves of a workgroup share one frequency and take its images in
     // turn: Df, gamma, M and delta of the frequency are loaded once per wave, into registers.
+    // With fewer right-hand sides than waves (the dictionary update has one: the images are
+    // the rank-one terms there) the waves spread over neighbouring frequencies instead.
     constexpr int WPB = kThreads / kWave;
-    const int wv = threadIdx.x / kWave;
+    const int wpp = ism_waves_per_pixel(a.N, WPB);
+    const int wv = (threadIdx.x / kWave) % wpp, psub = (threadIdx.x / kWave) / wpp, ppb = WPB / wpp;
     double acc[NA] = {};
-    for (int64_t pix = blockIdx.x; pix < a.npix; pix += gridDim.x) {
+    for (int64_t pix = (int64_t)blockIdx.x * ppb + psub; pix < a.npix; pix += (int64_t)gridDim.x * ppb) {
         const cx<T> *dp = a.df + pix * Cd * K;
         const cx<T> *gp = a.gam + pix * Cd * K;
         const cx<T> *M = a.mm + pix * Cd * Cd;
@@ -1765,7 +1771,7 @@ __global__ void __launch_bounds__(kThreads) ism_solve_kernel(const IsmArgs<T> a)
                     }
                 }
             }
-        for (int n = wv; n < a.N; n += WPB) {
+        for (int n = wv; n < a.N; n += wpp) {
             const int64_t sys = pix * a.N + n;
             cx<T> sc[CM], t[CM], f[CM], dx[CM];
 #pragma unroll
@@ -2171,7 +2177,8 @@ int launch_ism_solve(hipStream_t st, const cx<T> *yuf, cx<T> *xf, const cx<T> *d
         SA_HIP(hipGetLastError());
         return 0;
     }
-    const int grid = (int)std::min<int64_t>(npix, kMaxPartialBlocks);
+    const int ppb = (kThreads / kWave) / ism_waves_per_pixel(N, kThreads / kWave);
+    const int grid = (int)std::min<int64_t>(ceil_div(npix, (int64_t)ppb), kMaxPartialBlocks);
     const size_t lds = sizeof(double) * 5 * (kThreads / kWave);
     ism_dispatch_kr<T>(K, [&](auto kr) {
         constexpr int KR = decltype(kr)::value;
