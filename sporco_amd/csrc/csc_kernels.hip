@@ -1651,53 +1651,75 @@ __global__ void __launch_bounds__(kThreads) ism_setup_kernel(const cx<T> *__rest
             idg[j] = irho;
             if (gt.ghh && k < K) idg[j] = T(1) / (gt.mu * (grad_w(gt, k) * grad_gh(gt, pix, Wf)) + rho);
         }
-        for (int c = 0; c < Cd; ++c) {
-            cx<T> al[KR];
+        // (loops unrolled over the CMAX possible terms: delta and gamma stay in registers)
+        cx<T> gr[CMAX][KR];
 #pragma unroll
-            for (int j = 0; j < KR; ++j) {
-                const int k = lane + kWave * j;
-                al[j] = k < K ? cscale(cconj(d[c * K + k]), idg[j]) : mk<T>(T(0), T(0));
-            }
-            for (int l = 0; l < c; ++l) {
+        for (int c = 0; c < CMAX; ++c) {
+            if (c < Cd) {
+                cx<T> al[KR], dc[KR];
+#pragma unroll
+                for (int j = 0; j < KR; ++j) {
+                    const int k = lane + kWave * j;
+                    dc[j] = k < K ? d[c * K + k] : mk<T>(T(0), T(0));
+                    al[j] = k < K ? cscale(cconj(dc[j]), idg[j]) : mk<T>(T(0), T(0));
+                }
+#pragma unroll
+                for (int l = 0; l < CMAX; ++l) {
+                    if (l < c) {
+                        cx<T> t = mk<T>(T(0), T(0));
+#pragma unroll
+                        for (int j = 0; j < KR; ++j) {
+                            const int k = lane + kWave * j;
+                            if (k < K) t = t + cmul(d[l * K + k], al[j]);
+                        }
+                        const cx<T> f = cdivide(wave_sum_cx(t), dl[l]);
+#pragma unroll
+                        for (int j = 0; j < KR; ++j) al[j] = al[j] - cmul(gr[l][j], f);
+                    }
+                }
                 cx<T> t = mk<T>(T(0), T(0));
 #pragma unroll
                 for (int j = 0; j < KR; ++j) {
                     const int k = lane + kWave * j;
-                    if (k < K) t = t + cmul(d[l * K + k], al[j]);
+                    gr[c][j] = al[j];
+                    if (k < K) {
+                        g[c * K + k] = al[j];
+                        t = t + cmul(dc[j], al[j]);
+                    }
                 }
-                const cx<T> f = cdivide(wave_sum_cx(t), dl[l]);
-#pragma unroll
-                for (int j = 0; j < KR; ++j) {
-                    const int k = lane + kWave * j;
-                    if (k < K) al[j] = al[j] - cmul(g[l * K + k], f);
-                }
+                t = wave_sum_cx(t);
+                dl[c] = mk<T>(T(1) + t.re, t.im);
+                if (lane == 0) del[pix * Cd + c] = dl[c];
             }
-            cx<T> t = mk<T>(T(0), T(0));
-#pragma unroll
-            for (int j = 0; j < KR; ++j) {
-                const int k = lane + kWave * j;
-                if (k < K) {
-                    g[c * K + k] = al[j];
-                    t = t + cmul(d[c * K + k], al[j]);
-                }
-            }
-            t = wave_sum_cx(t);
-            dl[c] = mk<T>(T(1) + t.re, t.im);
-            if (lane == 0) del[pix * Cd + c] = dl[c];
         }
         // M_cl = sum_k d_c[k] gamma_l[k] for every pair (the solve kernel then needs only the
         // Cd inner products with b / rho, taken together)
-        for (int c = 0; c < Cd; ++c)
-            for (int l = 0; l < Cd; ++l) {
-                cx<T> t = mk<T>(T(0), T(0));
+        // (a row of M at a time: its up to CMAX reductions are independent and overlap)
+        for (int c = 0; c < Cd; ++c) {
+            cx<T> dc[KR], t[CMAX];
 #pragma unroll
-                for (int j = 0; j < KR; ++j) {
-                    const int k = lane + kWave * j;
-                    if (k < K) t = t + cmul(d[c * K + k], g[l * K + k]);
-                }
-                t = wave_sum_cx(t);
-                if (lane == 0) mm[(pix * Cd + c) * Cd + l] = t;
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                dc[j] = k < K ? d[c * K + k] : mk<T>(T(0), T(0));
             }
+#pragma unroll
+            for (int l = 0; l < CMAX; ++l) {
+                t[l] = mk<T>(T(0), T(0));
+                if (l < Cd) {
+#pragma unroll
+                    for (int j = 0; j < KR; ++j) {
+                        const int k = lane + kWave * j;
+                        if (k < K) t[l] = t[l] + cmul(dc[j], gr[l][j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < CMAX; ++l)
+                if (l < Cd) t[l] = wave_sum_cx(t[l]);
+#pragma unroll
+            for (int l = 0; l < CMAX; ++l)
+                if (l < Cd && lane == 0) mm[(pix * Cd + c) * Cd + l] = t[l];
+        }
     }
 }
 
