@@ -1314,9 +1314,74 @@ __global__ void __launch_bounds__(kThreads) ccmod_grad_kernel(const cx<T> *__res
     block_sum_store<3>(acc, red, partials + (int64_t)blockIdx.x * 3);
 }
 
+// The same for a handful of images: a wave per (frequency, channel) walks the images itself --
+// filters on the lanes, the gradient in registers, no workgroup barrier (K <= 256).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) ccmod_grad_wave_kernel(const cx<T> *__restrict__ zf,
+                                                                   const cx<T> *__restrict__ d,
+                                                                   const cx<T> *__restrict__ sf,
+                                                                   cx<T> *__restrict__ gf, int64_t npix,
+                                                                   int CN, int K, int Wf, int W, int Cd,
+                                                                   double *partials, int zch) {
+    constexpr int KR = 4;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t pc = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; pc < npix * Cd;
+         pc += nwaves) {
+        const int64_t pix = pc / Cd;
+        const int64_t zs = zch ? (int64_t)Cd * K : K;
+        const cx<T> *zp = zf + pix * CN * zs + (zch ? (pc - pix * Cd) * K : 0);
+        const cx<T> *dp = d + pc * K;
+        const double pw = parseval_weight((int)(pix % Wf), Wf, W);
+        cx<T> dk[KR], g[KR];
+#pragma unroll
+        for (int j = 0; j < KR; ++j) {
+            const int k = lane + kWave * j;
+            dk[j] = k < K ? dp[k] : mk<T>(T(0), T(0));
+            g[j] = mk<T>(T(0), T(0));
+        }
+        for (int n = 0; n < CN; ++n) {
+            cx<T> zk[KR], q = mk<T>(T(0), T(0));
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                zk[j] = k < K ? zp[(int64_t)n * zs + k] : mk<T>(T(0), T(0));
+                if (k < K) q = q + cmul(zk[j], dk[j]);
+            }
+            q = wave_sum_cx(q);
+            const cx<T> rr = q - sf[pc * CN + n];
+#pragma unroll
+            for (int j = 0; j < KR; ++j) g[j] = g[j] + cmulc(zk[j], rr);
+            if (lane == 0) {
+                const double r2 = (double)cabs2(rr);
+                acc[0] += r2;
+                acc[1] += pw * r2;
+                acc[2] += (double)cabs2(q);
+            }
+        }
+        if (gf) {
+#pragma unroll
+            for (int j = 0; j < KR; ++j) {
+                const int k = lane + kWave * j;
+                if (k < K) gf[pc * K + k] = g[j];
+            }
+        }
+    }
+    block_sum_store<3>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 3);
+}
+
 template <typename T>
 int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<T> *sf, cx<T> *gf,
                       int64_t npix, int CN, int K, int W, double *partials, int Cd, int zch) {
+    if (CN <= 16 && K <= 256) {
+        const int grid = std::min(grid_for(npix * Cd * kWave), kMaxPartialBlocks);
+        hipLaunchKernelGGL((ccmod_grad_wave_kernel<T>), dim3(grid), dim3(kThreads),
+                           sizeof(double) * 3 * (kThreads / kWave), st, zf, d, sf, gf, npix, CN, K, W / 2 + 1,
+                           W, Cd, partials, zch);
+        SA_HIP(hipGetLastError());
+        return grid;
+    }
     int grid = (int)(npix * Cd < kMaxPartialBlocks ? npix * Cd : kMaxPartialBlocks);
     const int nwave = kThreads / kWave;
     size_t lds = sizeof(cx<T>) * ((size_t)CN + (size_t)nwave * K) + sizeof(double) * 3 * nwave;
