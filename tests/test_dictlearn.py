@@ -274,3 +274,51 @@ def test_dictlearn_multichannel_dictionary(backend, name, dt, tol):
     assert rel_l2(b.getcoef(), g['X']) < tol
     errs = trace_errors(b.getitstat(), g)
     assert max(errs.values()) < tol, errs
+
+
+# ---------------------------------------------------------------------------
+# dictionary recovery: a size-independent property of the PGM D-step
+# ---------------------------------------------------------------------------
+def _policy(name):
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    from sporco_amd.pgm.momentum import MomentumLinear, MomentumGenLinear
+    from sporco_amd.pgm.stepsize import StepSizePolicyBB, StepSizePolicyCauchy
+    return {'standard': {'Backtrack': BacktrackStandard()},
+            'linear': {'Momentum': MomentumLinear()},
+            'genlinear': {'Momentum': MomentumGenLinear()},
+            'cauchy': {'StepSizePolicy': StepSizePolicyCauchy()},
+            'bb': {'StepSizePolicy': StepSizePolicyBB()},
+            'monotone': {'Monotone': True}}[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,Nd,L,policy', [
+    (32, 5, 2.5, 'standard'), (32, 5, 0.5, 'standard'), (64, 8, 0.5, 'standard'),
+    (32, 5, 2.5, 'linear'), (32, 5, 2.5, 'genlinear'), (64, 8, 0.5, 'bb'),
+    (64, 8, 0.5, 'cauchy'), (64, 8, 50.0, 'monotone')])
+def test_ccmod_recovers_the_generating_dictionary(N, Nd, L, policy):
+    """A signal synthesised from a normalised zero-mean dictionary and sparse coefficient maps:
+    3000 iterations of the update return that dictionary (relative residual < 1e-4, last
+    iterate residual < 1e-5) under every backtracking / momentum / step-size policy.  Inputs and
+    parameters of the reference's tests/pgm/test_ccmod.py:194-400 (legacy generator seeded with
+    12345, drawn in that order: the fixed-L momentum runs converge on these draws, not on every
+    one) -- runs that take the CPU simulator the better part of an hour each
+    (profiles/r03_reference_test_files.md) and the GPU about a second."""
+    from sporco_amd import cnvrep as cr
+    from sporco_amd.pgm import ccmod
+    rng = np.random.RandomState(12345)
+    M = 4
+    D0 = cr.normalise(cr.zeromean(rng.randn(Nd, Nd, M), (Nd, Nd, M), dimN=2), dimN=2)
+    X = np.zeros((N, N, M))
+    big = np.abs(rng.randn(N, N, M)) > 3
+    X[big] = rng.randn(int(big.sum()))
+    S = np.sum(np.fft.ifft2(np.fft.fft2(D0, (N, N), axes=(0, 1)) * np.fft.fft2(X, axes=(0, 1)),
+                            axes=(0, 1)).real, axis=2)
+    optd = dict({'Verbose': False, 'MaxMainIter': 3000, 'ZeroMean': True, 'RelStopTol': 0., 'L': L},
+                **_policy(policy))
+    c = ccmod.ConvCnstrMOD(X.reshape(N, N, 1, 1, M), S.reshape(N, N, 1), D0.shape,
+                           ccmod.ConvCnstrMOD.Options(optd))
+    c.solve()
+    D1 = cr.bcrop(c.X, D0.shape).squeeze()
+    assert np.linalg.norm(D0 - D1) / max(np.linalg.norm(D0), np.linalg.norm(D1)) < 1e-4
+    assert np.asarray(c.getitstat().Rsdl)[-1] < 1e-5
