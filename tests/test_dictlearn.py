@@ -322,3 +322,30 @@ def test_ccmod_recovers_the_generating_dictionary(N, Nd, L, policy):
     D1 = cr.bcrop(c.X, D0.shape).squeeze()
     assert np.linalg.norm(D0 - D1) / max(np.linalg.norm(D0), np.linalg.norm(D1)) < 1e-4
     assert np.asarray(c.getitstat().Rsdl)[-1] < 1e-5
+
+
+@pytest.mark.parametrize('N', [3, 20])
+def test_generic_dstep_gradient_few_and_many_images(backend, N):
+    """One ConvCnstrMOD iteration on the generic chain against its NumPy restatement
+    (pgm/ccmod.py:295-323) with 3 images (a wave per frequency walks them) and with 20 (the
+    images spread over the waves of a workgroup): the two forms of the gradient kernel."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.pgm import ccmod
+    H, W, K = 16, 24, 5
+    rng = np.random.RandomState(N)
+    Z = rng.randn(H, W, 1, N, K) * (rng.rand(H, W, 1, N, K) < 0.3)
+    S = rng.randn(H, W, N)
+    D0 = orc.pcn(rng.randn(H, W, 1, 1, K), (5, 5, K), (H, W))
+    L = 40.0 * N
+    c = ccmod.ConvCnstrMOD(Z, S, (5, 5, K), ccmod.ConvCnstrMOD.Options({'MaxMainIter': 1, 'L': L, 'X0': D0}))
+    c.solve()
+    Zf = np.fft.rfftn(Z, axes=(0, 1))
+    Sf = np.fft.rfftn(S.reshape(H, W, 1, N, 1), axes=(0, 1))
+    Df = np.fft.rfftn(D0, axes=(0, 1))
+    R = np.sum(Zf * Df, axis=4, keepdims=True) - Sf
+    G = np.sum(np.conj(Zf) * R, axis=3, keepdims=True)
+    D1 = orc.pcn(np.fft.irfftn(Df - G / L, (H, W), axes=(0, 1)), (5, 5, K), (H, W))
+    assert rel_l2(c.getdict(crop=False), D1) < 1e-11
+    R1 = np.sum(Zf * np.fft.rfftn(D1, axes=(0, 1)), axis=4, keepdims=True) - Sf
+    dfid = 0.5 * np.sum(np.fft.irfftn(R1, (H, W), axes=(0, 1)) ** 2)
+    assert abs(c.getitstat().DFid[-1] - dfid) < 1e-11 * dfid
