@@ -46,6 +46,16 @@ def make_problem(H, W, K, N, rank, dtype=np.float32):
     return D, S
 
 
+def make_problem_rgb(H, W, K, N, rank, dtype=np.float32):
+    """Config 3's input: N RGB images (H, W, 3, N) and a single-channel dictionary (SURVEY.md 8(d):
+    `ConvBPDNJoint(D[8,8,K], S[H,W,3,N], lambda=0.1, mu=0.01)`, Cd = 1, C = 3)."""
+    rng = np.random.RandomState(12345 + rank)
+    D = rng.randn(8, 8, K).astype(dtype)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, 3, N).astype(dtype)
+    return D, S
+
+
 def make_structured_problem(H, W, K, N, rank, dtype=np.float32, density=0.0027):
     """Sparse-synthesis input for the time-to-tolerance measurement (the recipe of the
     reference's known-answer test, tests/admm/test_cbpdn.py:160-165, at image size):

@@ -242,6 +242,44 @@ def gen_config5():
          X_l2=np.float64(np.linalg.norm(X)), **itstat_dict(b))
 
 
+def gen_config3():
+    """BASELINE config 3's kernels on ONE image of the bench's own input (bench.make_problem_rgb,
+    rank 0): ConvBPDNJoint, 512x512 RGB, K=128 8x8 filters, lambda 0.1, mu 0.01, default options,
+    6 iterations, from the float64 reference run of the float32 inputs (100 M elements per array:
+    a strided subsample of Y, its norms and the traces are kept)."""
+    sys.path.insert(0, REPO)
+    import bench
+    D, S = bench.make_problem_rgb(512, 512, 128, 1, 0)
+    opt = ref_cbpdn.ConvBPDNJoint.Options({'MaxMainIter': 6, 'RelStopTol': 0.0,
+                                           'DataType': np.float64})
+    b = ref_cbpdn.ConvBPDNJoint(D, S, 0.1, 0.01, opt)
+    b.solve()
+    Y = b.Y
+    save('admm_config3_joint_n1_f64', lmbda=np.float64(0.1), mu=np.float64(0.01),
+         Y_sub=_strided(Y), Y_l2=np.float64(np.linalg.norm(Y)),
+         Y_l1=np.float64(np.abs(Y).sum()), Y_nnz=np.int64(np.count_nonzero(Y)),
+         **itstat_dict(b))
+
+
+def gen_config4():
+    """BASELINE config 4's kernels on N = 2 of the bench's own images (bench.make_problem,
+    rank 0): pgm.cbpdn.ConvBPDN, 512x512, K=64, lambda 0.05, L = 500 (class default), 8
+    iterations, with and without BacktrackStandard, float64 reference runs of the float32
+    inputs: subsample of X, norms, traces."""
+    sys.path.insert(0, REPO)
+    import bench
+    D, S = bench.make_problem(512, 512, 64, 2, 0)
+    for tag, bt in (('', None), ('_bt', BacktrackStandard())):
+        optd = {'MaxMainIter': 8, 'RelStopTol': 0.0, 'L': 500.0, 'DataType': np.float64}
+        if bt is not None:
+            optd['Backtrack'] = bt
+        b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.05, ref_pgm_cbpdn.ConvBPDN.Options(optd))
+        X = b.solve()
+        save('pgm_config4_n2%s_f64' % tag, lmbda=np.float64(0.05), X_sub=_strided(X),
+             X_l2=np.float64(np.linalg.norm(X)), X_l1=np.float64(np.abs(X).sum()),
+             X_nnz=np.int64(np.count_nonzero(X)), L_final=np.float64(b.L), **itstat_dict(b))
+
+
 def gen_tol():
     """Time-to-tolerance known answer at the config 2 shape: the sparse-synthesis input of
     bench.make_structured_problem (512x512, K=64, N=2), lambda 0.01, default options,
@@ -1240,6 +1278,7 @@ if __name__ == '__main__':
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
+             'config3': gen_config3, 'config4': gen_config4,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
              'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
