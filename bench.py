@@ -22,6 +22,17 @@ it is the number of 512x512x64x32-sized ADMM iterations completed per second by
 the whole job.
 
 One "step" = one ADMM iteration.  Rank 0 prints ONE JSON line.
+
+The line's `configs` object carries the other BASELINE.json configurations as one GPU sees them
+(config 1; config 3 as one of its 8 image shards; config 4 with and without BacktrackStandard;
+config 5), each timed the same way, with a parity figure against a run of the UNMODIFIED reference
+on the same kernel instantiations (committed fixtures, tests/golden/ -- oracle/make_golden.py is
+the recipe) and the roofline of its dominant kernel.  `roofline.frac` is bytes really MOVED by
+the dominant kernel (by construction: its inputs and outputs once; equal to the rocprofv3 PMC
+traffic in profiles/hbm_traffic_bytes.json) / its HIP-event duration in this run / the 8 TB/s
+HBM peak; the SURVEY.md 8(d) stage-bytes figure is kept beside it as `algorithmic_frac`.
+`cpu_baseline` times the unmodified reference (staged into the git-ignored oracle/_ref by
+build()) in a subprocess on this box's host cores, and the NumPy port as a second leg.
 """
 
 import argparse
@@ -76,42 +87,393 @@ def make_structured_problem(H, W, K, N, rank, dtype=np.float32, density=0.0027):
     return D.astype(dtype), S
 
 
-def moved_bytes(H, W, P, itemsize):
-    """Bytes the kernels of the single-array state (csc_rows.h, "V form") actually move: they
-    perform the same stages as their (Y, U) twins -- whose SURVEY.md 8(d) byte counts
-    kernel_bytes() returns for them too -- but read one array (V) where those read Y and U,
-    and write one (V') where those write Y' and U'."""
-    E = H * W * P * itemsize
-    EF = H * (W // 2 + 1) * P * 2 * itemsize
-    return {'rows_fwd_v': E + EF, 'rows_inv_post_v': EF + 2 * E,
-            'rows_inv_post_v_emit': 2 * EF + 2 * E}
+def byte_model(H, W, C, N, K, itemsize=4, grad_groups=0):
+    """HBM bytes per launch of every profiled kernel slot (sporco_amd_csc_profile_read names), for
+    arrays of P = C*N*K lines.  Returns (moved, algorithmic):
 
-
-def kernel_bytes(H, W, P, itemsize):
-    """ALGORITHMIC HBM bytes (each logical stage reads its inputs and writes
-    its outputs once) of each kernel of one ADMM iteration; P = C*N*K.  See DESIGN.md
-    section 5.  The `_v` kernels are the same stages on the single-array state: same
-    algorithmic count, fewer bytes moved (moved_bytes())."""
-    E = H * W * P * itemsize                 # one pass over a real X-sized array
-    EF = H * (W // 2 + 1) * P * 2 * itemsize  # one pass over a half-spectrum array
-    return {
-        'rows_fwd_v': 2 * E + EF,
-        'rows_inv_post_v': EF + 4 * E,
-        'rows_inv_post_v_emit': 2 * EF + 4 * E,
-        'fft_r2c_rows': 2 * E + EF,          # read Y, U; write row spectra
-        'fft_c2c_cols_fwd': 2 * EF,
-        'sm_solve': 2 * EF,
-        'fused_cols_sm': 2 * EF,             # read row spectra, write solved column-IFFT (in place)
-        'fft_c2c_cols_inv': 2 * EF,
-        'fft_c2r_rows': EF + E,              # read spectra; write X
-        'admm_post': 5 * E,                  # read X, Y, U; write Y, U
-        'rows_fwd': 2 * E + EF,              # read Y, U; write tile-major row spectra
-        'rows_inv_post': EF + 4 * E,         # read spectra, Y, U; write Y, U (X stays in registers)
-        'rows_inv_post_emit': 2 * EF + 4 * E,  # ... and write the next iteration's row spectra
+    * `moved` -- what the kernel moves BY CONSTRUCTION: each X-sized input and output once (the
+      broadcast operands Df, Sf, denominators, weights -- 1/N or 1/K of an array -- are left out);
+      the rocprofv3 PMC passes measure exactly these (profiles/hbm_traffic_bytes.json).
+    * `algorithmic` -- SURVEY.md 8(d): each logical stage reading its inputs and writing its
+      outputs once.  Differs from `moved` only for the kernels of the single-array state
+      (DESIGN.md 4.1c), which read V where 8(d)'s stage reads Y and U and write V' for Y', U'."""
+    P = C * N * K
+    E = H * W * P * itemsize                   # one pass over a real X-sized array
+    EF = H * (W // 2 + 1) * P * 2 * itemsize   # one pass over a half-spectrum array
+    moved = {
+        'rows_fwd': 2 * E + EF,                # read Y, U; write tile-major row spectra
+        'rows_fwd_v': E + EF,                  # read V
+        'fused_cols_sm': 2 * EF,               # column FFT + solve + IFFT in place (K > 64: slabs)
+        'rows_inv_post': EF + 4 * E,           # read spectra, Y, U; write Y', U'
+        'rows_inv_post_emit': 2 * EF + 4 * E,  # ... and the next iteration's row spectra
+        'rows_inv_post_v': EF + 2 * E,         # read spectra, V; write V'
+        'rows_inv_post_v_emit': 2 * EF + 2 * E,
+        'fft_r2c_rows': 2 * E + EF, 'fft_c2c_cols_fwd': 2 * EF, 'sm_solve': 2 * EF,
+        'fft_c2c_cols_inv': 2 * EF, 'fft_c2r_rows': EF + E, 'admm_post': 5 * E,
+        # FISTA (DESIGN.md 4.2): spectra stay tile-major, X is rebuilt on demand
+        'pgm_grad_ifft': 2 * EF,               # Yf -> gradient step -> column IFFT
+        'pgm_rows_prox': 2 * EF,               # row IFFT -> prox -> row FFT
+        'pgm_fft_momentum': 5 * EF,            # column FFT; read Xf, Yf; write Xf', Yf'
+        # dictionary update (DESIGN.md 4.3)
+        'setcoef_rows': E + EF, 'setcoef_cols': 2 * EF,
+        # Zf once; the per-group partial gradients are written and summed (dictionary sized x G)
+        'ccmod_grad_tiled': EF + 2 * grad_groups * H * (W // 2 + 1) * K * 2 * itemsize,
     }
+    alg = dict(moved)
+    alg.update({'rows_fwd_v': 2 * E + EF, 'rows_inv_post_v': EF + 4 * E,
+                'rows_inv_post_v_emit': 2 * EF + 4 * E})
+    return moved, alg
 
 
-def cpu_baseline(H, W, K, n_full, seconds):
+def kernel_roofline(prof, moved, alg):
+    """Per-kernel table from the library's HIP-event timings {name: (total_ms, launches)}."""
+    out = {}
+    for k, v in prof.items():
+        if v[1] > 0 and k in moved:
+            ms = v[0] / v[1]
+            out[k] = {'avg_ms': round(ms, 4), 'launches': int(v[1]),
+                      'moved_bytes': moved[k], 'GBps': round(moved[k] / ms / 1e6, 1),
+                      'frac': round(moved[k] / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                      'algorithmic_frac': round(alg[k] / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    return out
+
+
+def dominant(table):
+    return max(table, key=lambda k: table[k]['avg_ms'] * table[k]['launches'])
+
+
+def roofline_of(table, extra=None):
+    """The `roofline` object of one configuration: its dominant kernel (largest total time in the
+    profiled pass), bytes moved / HIP-event duration / 8 TB/s."""
+    k = dominant(table)
+    t = table[k]
+    r = {'bound': 'hbm', 'kernel': k, 'moved_bytes': t['moved_bytes'], 'avg_kernel_ms': t['avg_ms'],
+         'achieved': t['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': t['frac'],
+         'algorithmic_frac': t['algorithmic_frac']}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def load_fixture(name):
+    p = os.path.join(REPO, 'tests', 'golden', name + '.npz')
+    if not os.path.exists(p):
+        return None
+    with np.load(p) as g:
+        return {k: g[k] for k in g.files}
+
+
+def fixture_parity(fix_name, coef, coef_key, its, fields, tol=1e-4, trace_tol=1e-3, extra=None):
+    """Compare a run of this library (float32) with the float64 run of the UNMODIFIED reference
+    on the same inputs (tests/golden/<fix_name>.npz, written by oracle/make_golden.py in the
+    authoring container): strided subsample of the coefficient array and per-iteration traces."""
+    g = load_fixture(fix_name)
+    if g is None:
+        return {'pass': None, 'note': 'fixture %s absent' % fix_name}
+    rel = rel_l2(coef[::16, ::16], g[coef_key])
+    tr = {f: rel_l2(getattr(its, f), g['it_' + f]) for f in fields if 'it_' + f in g}
+    out = {'vs': 'unmodified reference, float64 run of the same float32 inputs '
+                 '(tests/golden/%s.npz)' % fix_name,
+           'rel_l2': rel, 'compared': '%s[::16, ::16] (%d values)' % (coef_key.split('_')[0],
+                                                                   g[coef_key].size),
+           'iters': int(len(g['it_Iter'])), 'trace_rel_err': tr,
+           'pass': bool(rel <= tol and (not tr or max(tr.values()) <= trace_tol))}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def timed_solve(b, dev, warmup, steps):
+    b.opt['MaxMainIter'] = max(warmup, 1)
+    b.solve()
+    b.opt['MaxMainIter'] = steps
+    dev.sync()
+    t0 = time.perf_counter()
+    b.solve()
+    dev.sync()
+    return time.perf_counter() - t0
+
+
+def profiled_pass(b, dev, steps, host_loop=True):
+    """Per-kernel HIP-event durations over `steps` more iterations of the same solver (the
+    host-driven loop launches exactly the kernels that execute; see main())."""
+    b.opt['MaxMainIter'] = steps
+    dev.profile(True)
+    if host_loop:
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+    try:
+        b.solve()
+    finally:
+        os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
+    dev.sync()
+    prof = dev.profile_read()
+    dev.profile(False)
+    return {k: v for k, v in prof.items() if v[1] > 0}
+
+
+def iteration_summary(table, prof_steps, ms_per_step, alg_bytes_per_iter):
+    mv = sum(t['moved_bytes'] * t['launches'] for t in table.values()) / float(prof_steps)
+    return {'moved_bytes_per_iter': mv, 'frac': mv / ms_per_step / 1e6 / HBM_PEAK_GBPS,
+            'algorithmic_bytes_per_iter': alg_bytes_per_iter,
+            'algorithmic_frac': alg_bytes_per_iter / ms_per_step / 1e6 / HBM_PEAK_GBPS,
+            'note': 'moved = sum over the profiled kernels of bytes moved by construction, per '
+                    'iteration of the profiled pass; ms = the timed region'}
+
+
+# ---- the other BASELINE.json configurations, one GPU -------------------------------------------
+# (`--tiny`: the same legs at sizes the CPU fiber simulator of the test-suite finishes in seconds
+# -- exercises this file's control flow without a GPU; its numbers mean nothing and the fixture
+# comparisons, which are for the full shapes, are skipped)
+TINY_NOTE = {'pass': None, 'note': '--tiny run: shapes differ from the fixtures, parity skipped'}
+
+def run_config1(device, tiny=False):
+    """admm.cbpdn.ConvBPDN, 256x256, K=32, N=1 (BASELINE configs[0])."""
+    from sporco_amd.admm import cbpdn
+    H = W = 128 if tiny else 256
+    K = 32
+    D, S = make_problem(H, W, K, 1, 0)
+    par = TINY_NOTE
+    if not tiny:
+        # parity: the fixture is this very problem, 20 iterations, default options
+        b = cbpdn.ConvBPDN(D, S[:, :, 0], 0.05, cbpdn.ConvBPDN.Options(
+            {'MaxMainIter': 20, 'RelStopTol': 0.0}), dimK=0, device=device)
+        Y = b.solve()
+        par = fixture_parity('admm_config1_f64', Y.reshape(H, W, 1, 1, K), 'Y_sub', b.getitstat(),
+                             ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'))
+        del b
+    b = cbpdn.ConvBPDN(D, S[:, :, 0], 0.05, cbpdn.ConvBPDN.Options(
+        {'MaxMainIter': 3, 'RelStopTol': 0.0}), dimK=0, device=device)
+    b._return_min = False
+    steps, warm = (6, 2) if tiny else (500, 20)
+    el = timed_solve(b, b._dev, warm, steps)
+    ms = 1e3 * el / steps
+    psteps = 4 if tiny else 50
+    prof = profiled_pass(b, b._dev, psteps)
+    moved, alg = byte_model(H, W, 1, 1, K)
+    tab = kernel_roofline(prof, moved, alg)
+    out = {'workload': 'admm.cbpdn.ConvBPDN %dx%d greyscale, K=%d 8x8 filters, N=1, lambda=0.05, '
+                       'default options (BASELINE configs[0])' % (H, W, K),
+           'steps': steps, 'warmup': warm, 'ms_per_step': ms, 'value': steps / el,
+           'unit': 'iterations/s', 'parity': par,
+           'roofline': roofline_of(tab, {'note': '8.4 MB per array: one tile per CU and pass, the '
+                                                 'iteration is tile latency + launches, not HBM'}),
+           'iteration': iteration_summary(tab, psteps, ms, 40 * H * W * K),
+           'kernels': tab}
+    del b
+    return out
+
+
+def run_config3(device, n_shard=32, tiny=False):
+    """ConvBPDNJoint 512x512 RGB, K=128, N=256 over 8 GPUs: the shard of one GPU (N=32)."""
+    from sporco_amd.admm import cbpdn
+    H = W = 128 if tiny else 512
+    K, C = 128, 3
+    lm, mu = 0.1, 0.01
+    if tiny:
+        n_shard = 1
+    # parity on image 0 of the same input, the same kernel instantiations (H = W = 512, K = 128
+    # slab column pass, joint row epilogue in the single-array form): 6 iterations
+    par = TINY_NOTE
+    if not tiny:
+        D, S = make_problem_rgb(H, W, K, 1, 0)
+        b = cbpdn.ConvBPDNJoint(D, S, lm, mu, cbpdn.ConvBPDNJoint.Options(
+            {'MaxMainIter': 6, 'RelStopTol': 0.0}), device=device)
+        engaged = bool(b._dev.uses_fused_rows() and b._dev.uses_fused_cols() and b._fused_ok())
+        Y = b.solve()
+        par = fixture_parity('admm_config3_joint_n1_f64', Y, 'Y_sub', b.getitstat(),
+                             ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl', 'DualRsdl', 'Rho'),
+                             extra={'fused_kernels_engaged': engaged})
+        del b, Y
+    D, S = make_problem_rgb(H, W, K, n_shard, 0)
+    b = cbpdn.ConvBPDNJoint(D, S, lm, mu, cbpdn.ConvBPDNJoint.Options(
+        {'MaxMainIter': 3, 'RelStopTol': 0.0}), device=device)
+    b._return_min = False
+    steps, warm = (4, 1) if tiny else (10, 3)
+    el = timed_solve(b, b._dev, warm, steps)
+    ms = 1e3 * el / steps
+    nxt = 2 if tiny else 20
+    b.opt['MaxMainIter'] = nxt
+    b._dev.sync()
+    t0 = time.perf_counter()
+    b.solve()
+    b._dev.sync()
+    el2 = time.perf_counter() - t0
+    prof = profiled_pass(b, b._dev, 6)
+    moved, alg = byte_model(H, W, C, n_shard, K)
+    tab = kernel_roofline(prof, moved, alg)
+    E = H * W * C * n_shard * K
+    out = {'workload': 'admm.cbpdn.ConvBPDNJoint %dx%d RGB (C=3), K=%d 8x8 filters, lambda=0.1, '
+                       'mu=0.01, default options: N=%d images = one of the 8 shards of BASELINE '
+                       'configs[2] (N=256), %.1f GB per X-sized array'
+                       % (H, W, K, n_shard, 4 * E / 1e9),
+           'steps': steps, 'warmup': warm, 'ms_per_step': ms, 'value': steps / el,
+           'unit': 'iterations/s (per shard; 8 shards run concurrently, one all-reduce of 16 '
+                   'doubles per iteration)',
+           'next_steps': {'steps': nxt, 'value': nxt / el2, 'ms_per_step': 1e3 * el2 / nxt},
+           'parity': par, 'roofline': roofline_of(tab),
+           'iteration': iteration_summary(tab, 6, ms, 40 * E), 'kernels': tab}
+    del b
+    return out
+
+
+def run_config4(device, backtrack, tiny=False):
+    """pgm.cbpdn.ConvBPDN (FISTA), 512x512, K=64, N=32, L=500 (BASELINE configs[3])."""
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    H = W = 128 if tiny else 512
+    K, N = 64, (2 if tiny else 32)
+
+    def opts(iters):
+        o = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 500.0}
+        if backtrack:
+            o['Backtrack'] = BacktrackStandard()
+        return pc.ConvBPDN.Options(o)
+
+    par = TINY_NOTE
+    if not tiny:
+        D, S = make_problem(H, W, K, 2, 0)
+        b = pc.ConvBPDN(D, S, 0.05, opts(8), device=device)
+        engaged = bool(b.dev.uses_fused_rows() and b.dev.uses_fused_pgm() and b._fused_ok())
+        X = b.solve()
+        fields = ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L') + (('F_Btrack', 'Q_Btrack', 'IterBTrack')
+                                                            if backtrack else ())
+        par = fixture_parity('pgm_config4_n2_bt_f64' if backtrack else 'pgm_config4_n2_f64',
+                             X.reshape(H, W, 1, 2, K), 'X_sub', b.getitstat(), fields,
+                             extra={'fused_kernels_engaged': engaged})
+        del b, X
+    D, S = make_problem(H, W, K, N, 0)
+    b = pc.ConvBPDN(D, S, 0.05, opts(3), device=device)
+    b._return_min = False
+    steps, warm = (4, 1) if tiny else (20, 3)
+    el = timed_solve(b, b.dev, warm, steps)
+    ms = 1e3 * el / steps
+    prof = profiled_pass(b, b.dev, 10, host_loop=False)
+    moved, alg = byte_model(H, W, 1, N, K)
+    tab = kernel_roofline(prof, moved, alg)
+    out = {'workload': 'pgm.cbpdn.ConvBPDN (FISTA) %dx%d greyscale, K=%d, N=%d, lambda=0.05, '
+                       'L=500%s (BASELINE configs[3])'
+                       % (H, W, K, N, ', BacktrackStandard' if backtrack else ''),
+           'steps': steps, 'warmup': warm, 'ms_per_step': ms, 'value': steps / el,
+           'unit': 'iterations/s', 'parity': par, 'roofline': roofline_of(tab),
+           'iteration': iteration_summary(tab, 10, ms, 40 * H * W * N * K), 'kernels': tab}
+    del b
+    return out
+
+
+def run_config5(device, tiny=False):
+    """dictlrn.cbpdndl.ConvBPDNDictLearn, 256x256, K=64, N=64, admm X-step / pgm D-step
+    (BASELINE configs[4]); metric = outer iterations/s."""
+    from sporco_amd.dictlrn import cbpdndl
+    H = W = 128 if tiny else 256
+    K, N = 64, (4 if tiny else 64)
+    # parity: the reference's own float64 run of 4 outer iterations at N = 4 (same kernels)
+    g = load_fixture('cbpdndl_config5_n4_f64')
+    par = TINY_NOTE if tiny else {'pass': None, 'note': 'fixture absent'}
+    if g is not None and not tiny:
+        rng = np.random.RandomState(515)
+        D0 = rng.randn(8, 8, 64).astype(np.float32)
+        S4 = rng.randn(256, 256, 4).astype(np.float32)
+        opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 4, 'AccurateDFid': True},
+                                                xmethod='admm', dmethod='pgm')
+        d = cbpdndl.ConvBPDNDictLearn(D0, S4, float(g['lmbda']), opt, xmethod='admm', dmethod='pgm',
+                                      device=device)
+        D1 = d.solve()
+        X = d.getcoef()
+        its = d.getitstat()
+        tr = {f: rel_l2(getattr(its, f), g['it_' + f]) for f in its._fields
+              if 'it_' + f in g and f not in ('Iter', 'Cnstr')}
+        rd, rx = rel_l2(D1.squeeze(), g['D1'].squeeze()), rel_l2(X[::16, ::16], g['X_sub'])
+        par = {'vs': 'unmodified reference, float64 run, 4 outer iterations at N=4 '
+                     '(tests/golden/cbpdndl_config5_n4_f64.npz)',
+               'rel_l2_dictionary': rd, 'rel_l2_coefficients_subsample': rx, 'trace_rel_err': tr,
+               'pass': bool(rd <= 1e-4 and rx <= 1e-4 and max(tr.values()) <= 1e-3)}
+        del d
+    D, S = make_problem(H, W, K, N, 0)
+    opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 3}, xmethod='admm', dmethod='pgm')
+    d = cbpdndl.ConvBPDNDictLearn(D, S, 0.1, opt, xmethod='admm', dmethod='pgm', device=device)
+    dev = d.xstep._dev
+    steps, warm = (4, 1) if tiny else (20, 3)
+    el = timed_solve(d, dev, warm, steps)
+    ms = 1e3 * el / steps
+    prof = profiled_pass(d, dev, 10, host_loop=False)
+    groups = min(8, N, -(-768 // (W // 2 + 1)))      # ccmod_grad's image groups (api_dictupdate.inc)
+    moved, alg = byte_model(H, W, 1, N, K, grad_groups=groups)
+    # the generic FFT slots of this configuration are the D-step's transforms of the dictionary
+    # (H, W, K): dictionary-sized, 1/N of the arrays above
+    dm, da = byte_model(H, W, 1, 1, K)
+    for k in ('fft_r2c_rows', 'fft_c2c_cols_fwd', 'fft_c2c_cols_inv', 'fft_c2r_rows'):
+        moved[k], alg[k] = dm[k] - (H * W * K * 4 if k == 'fft_r2c_rows' else 0), da[k]
+    tab = kernel_roofline(prof, moved, alg)
+    out = {'workload': 'dictlrn.cbpdndl.ConvBPDNDictLearn %dx%d greyscale, K=%d 8x8 filters, N=%d, '
+                       'lambda=0.1, xmethod admm / dmethod pgm, one inner iteration each, default '
+                       'options (BASELINE configs[4])' % (H, W, K, N),
+           'steps': steps, 'warmup': warm, 'ms_per_step': ms, 'value': steps / el,
+           'unit': 'outer iterations/s', 'parity': par, 'roofline': roofline_of(tab),
+           'iteration': iteration_summary(tab, 10, ms, 56 * H * W * N * K), 'kernels': tab}
+    del d
+    return out
+
+
+def run_other_configs(device, which, tiny=False):
+    import gc
+    legs = {'config1': lambda: run_config1(device, tiny=tiny),
+            'config3_shard': lambda: run_config3(device, tiny=tiny),
+            'config4': lambda: run_config4(device, False, tiny=tiny),
+            'config4_backtrack': lambda: run_config4(device, True, tiny=tiny),
+            'config5': lambda: run_config5(device, tiny=tiny)}
+    out = {}
+    for name, fn in legs.items():
+        if which != 'all' and name.split('_')[0] not in which.split(','):
+            continue
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:   # a failing side leg must not cost the headline line
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        out[name]['leg_seconds'] = round(time.perf_counter() - t0, 1)
+        gc.collect()
+    return out
+
+
+def reference_cpu_baseline(H, W, K, n_full, seconds):
+    """The UNMODIFIED reference timed on this host (oracle/time_reference.py, a subprocess: this
+    process never imports it).  None when oracle/_ref was not staged."""
+    import subprocess
+    if not os.path.isdir(os.path.join(REPO, 'oracle', '_ref', 'sporco')):
+        return None
+    env = dict(os.environ)
+    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        env.setdefault(v, '1')     # (no BLAS on this path; the FFT fallback is single-threaded)
+    try:
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'oracle', 'time_reference.py'),
+                            str(H), str(W), str(K), '1,2', str(seconds)], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=40 * seconds + 120)
+        j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    if 'error' in j:
+        return j
+    one, two = j['runs'][0], j['runs'][-1]
+    return {'value': two['image_iterations_per_second'] / n_full, 'unit': 'iterations/s',
+            'cores': 1, 'kind': 'reference',
+            'sample': ('unmodified sporco.admm.cbpdn.ConvBPDN.solve() on this host (%d cores; the '
+                       'reference path is single-threaded NumPy with the numpy.fft fallback -- pyFFTW '
+                       'is not installed): %dx%d K=%d float32 default options, N=1: %d iterations in '
+                       '%.1f s, N=2: %d iterations in %.1f s (image-iterations/s %.3f vs %.3f: linear '
+                       'in N); value = N=2 image-iterations/s / %d'
+                       % (j['host_cores'], H, W, K, one['iterations'], one['solve_seconds'],
+                          two['iterations'], two['solve_seconds'], one['image_iterations_per_second'],
+                          two['image_iterations_per_second'], n_full)),
+            'detail': j}
+
+
+def port_cpu_baseline(H, W, K, n_full, seconds):
     """Time the NumPy oracle (a port of the reference's arithmetic; the reference itself is
     Python and is not present on the GPU box) on ONE and on TWO images of the same workload
     (to show that the cost is linear in the number of images: they are independent and the
@@ -175,6 +537,20 @@ def cpu_baseline(H, W, K, n_full, seconds):
         with open(rpath) as f:
             out['reference_here'] = json.load(f)
     return out
+
+
+def cpu_baseline(H, W, K, n_full, seconds):
+    """`cpu_baseline` of the line: the unmodified reference on this host when it is staged
+    (`kind: "reference"`), with the NumPy port (`kind: "port"`, single-threaded and with its FFTs
+    threaded over the host cores) kept beside it as `port`; the port alone otherwise."""
+    ref = reference_cpu_baseline(H, W, K, n_full, seconds)
+    port = port_cpu_baseline(H, W, K, n_full, seconds / 2.0)
+    if ref is None or 'error' in ref:
+        if ref is not None:
+            port['reference_error'] = ref['error']
+        return port
+    ref['port'] = port
+    return ref
 
 
 def parity_gate(cbpdn, H, W, K, iters, device):
@@ -266,7 +642,13 @@ def main():
     ap.add_argument('--images', type=int, default=32, help='images per GPU')
     ap.add_argument('--fastsolve', action='store_true',
                     help='FastSolve + AutoRho off as the headline run (pure iteration cost)')
-    ap.add_argument('--cpu-seconds', type=float, default=21.0)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0,
+                    help='time budget of the reference leg of cpu_baseline (the port gets half)')
+    ap.add_argument('--tiny', action='store_true',
+                    help='shrink the `configs` legs to simulator sizes (control-flow test only)')
+    ap.add_argument('--configs', default='all',
+                    help="the other BASELINE configurations to run after the headline: 'all', "
+                         "'none', or a comma list of config1,config3,config4,config5")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-time-to-tol', action='store_true')
@@ -419,41 +801,34 @@ def main():
             dist.destroy_process_group()
         return
 
-    P = N * K
-    itemsize = 4
     ms_per_step = 1e3 * elapsed / args.steps
     its_per_s = args.steps / elapsed
-    kb = kernel_bytes(H, W, P, itemsize)
-    mb = dict(kb)
-    mb.update(moved_bytes(H, W, P, itemsize))
-    timed = {k: v for k, v in prof.items() if v[1] > 0}
-    dom = max((k for k in timed if k in kb), key=lambda k: timed[k][0])
-    dom_ms = timed[dom][0] / timed[dom][1]
-    achieved = kb[dom] / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_source, rocprof_cal = None, None, None
+    moved, alg = byte_model(H, W, 1, N, K)
+    table = kernel_roofline(prof, moved, alg)
+    dom = dominant(table)
+    dom_ms = table[dom]['avg_ms']
+    # what the committed profiles say about the same kernel of the same command (rocprofv3
+    # --kernel-trace --stats average of the working dispatches; PMC FETCH_SIZE / WRITE_SIZE passes):
+    # profiles/hbm_traffic_bytes.json, produced by tools/final_prof.sh -- every figure of
+    # `from_profiles` is recomputable from that one file
+    traffic, from_profiles = None, None
     tpath = os.path.join(REPO, 'profiles', 'hbm_traffic_bytes.json')
     if os.path.exists(tpath) and (H, W, K, N) == (512, 512, 64, 32):
-        # measured for exactly this workload (rocprofv3 PMC passes, see the file)
         with open(tpath) as f:
             tj = json.load(f)
         traffic = tj.get(dom)
-        traffic_source = ('profiles/hbm_traffic_bytes.json (rocprofv3 --pmc FETCH_SIZE / '
-                          'WRITE_SIZE passes of this command; not re-measured in this run)')
-        # the rocprofv3 --kernel-trace average of the same kernel in the same command (events
-        # around a kernel read a few per cent low against its in-situ duration, and boxes of
-        # the pool differ): the figure this line's event timing is calibrated against
-        rocprof_cal = tj.get('_rocprof_avg_ms', {}).get(dom)
-    E = H * W * P
+        rp_ms = tj.get('_rocprof_avg_ms', {}).get(dom)
+        if traffic and rp_ms:
+            from_profiles = {'file': 'profiles/hbm_traffic_bytes.json', 'kernel': dom,
+                             'traffic_bytes_per_launch': traffic, 'rocprof_avg_kernel_ms': rp_ms,
+                             'achieved': traffic / rp_ms / 1e6,
+                             'frac': traffic / rp_ms / 1e6 / HBM_PEAK_GBPS,
+                             'note': 'PMC traffic (2*FETCH_SIZE + WRITE_SIZE)*1024 per working '
+                                     'dispatch / rocprofv3 --kernel-trace average of the same '
+                                     'kernel in `python bench.py`; not re-measured in this run '
+                                     '(boxes of the pool differ by up to 8 %)'}
+    E = H * W * N * K
     iter_alg_bytes = 40 * E                    # 10 float32 passes
-    per_kernel = {}
-    for k, v in timed.items():
-        if k in kb:
-            ms = v[0] / v[1]
-            per_kernel[k] = {'avg_ms': round(ms, 4), 'launches': v[1],
-                             'algorithmic_GBps': round(kb[k] / (ms * 1e-3) / 1e9, 1),
-                             'frac': round(kb[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                             'moved_GBps': round(mb[k] / (ms * 1e-3) / 1e9, 1),
-                             'moved_frac': round(mb[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     names = {False: 'default options (AutoRho, stats every iteration)',
              True: 'FastSolve, AutoRho off'}
     line = {
@@ -478,32 +853,26 @@ def main():
                          'note': 'the same solver continued for %d more iterations after the timed '
                                  '%d (rho has settled: the speculatively emitted row spectra hold)'
                                  % (steady_steps, args.steps)},
-        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': achieved,
-                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-                     'traffic': traffic, 'traffic_source': traffic_source,
-                     'avg_kernel_ms': dom_ms, 'algorithmic_bytes_per_launch': kb[dom],
-                     # what the kernel moves by construction (inputs + outputs once); below the
-                     # algorithmic count for the kernels of the single-array state, which read
-                     # V where SURVEY.md 8(d)'s stage reads Y and U and write V' for Y', U'
-                     'moved_bytes_per_launch': mb[dom],
-                     'moved_GBps': mb[dom] / (dom_ms * 1e-3) / 1e9,
-                     'moved_frac': mb[dom] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     'note': ('`achieved` / `frac` use the ALGORITHMIC bytes of SURVEY.md 8(d) for the '
-                              'stages this kernel performs; the single-array state (DESIGN 4.1c) performs '
-                              'them on fewer bytes, so for the `_v` kernels `frac` can exceed what the '
-                              'memory system moves -- `moved_frac` (bytes really moved, = `traffic` '
-                              'measured) is the distance to the HBM peak')
-                             if dom.endswith('_v') or '_v_' in dom else None,
-                     'rocprof_avg_kernel_ms': rocprof_cal,
-                     'rocprof_source': ('profiles/hbm_traffic_bytes.json "_rocprof_avg_ms" '
-                                        '(rocprofv3 --kernel-trace --stats of this command)')
-                                       if rocprof_cal else None},
-        'iteration_roofline': {'algorithmic_bytes_per_iter': iter_alg_bytes,
-                               'achieved': iter_alg_bytes * its_per_s / 1e9,
-                               'unit': 'GB/s',
-                               'frac': iter_alg_bytes * its_per_s / 1e9 / HBM_PEAK_GBPS,
-                               'steady_state_frac': iter_alg_bytes * (steady_steps / elapsed_steady)
-                                                    / 1e9 / HBM_PEAK_GBPS},
+        'roofline': {'bound': 'hbm', 'kernel': dom,
+                     # bytes the kernel MOVES (inputs + outputs once; = PMC traffic) / its average
+                     # launch duration by HIP events on the library's stream in this run
+                     'achieved': moved[dom] / dom_ms / 1e6, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                     'frac': moved[dom] / dom_ms / 1e6 / HBM_PEAK_GBPS,
+                     'traffic': traffic, 'avg_kernel_ms': dom_ms,
+                     'bytes_per_launch': moved[dom],
+                     'bytes_basis': 'moved by construction (byte_model); the measured PMC traffic '
+                                    'of profiles/hbm_traffic_bytes.json agrees to 0.1 %',
+                     # SURVEY.md 8(d)'s stage accounting of the same kernel (for the kernels of
+                     # the single-array state it credits bytes that are not moved: not a
+                     # distance to the HBM peak)
+                     'algorithmic_bytes_per_launch': alg[dom],
+                     'algorithmic_achieved': alg[dom] / dom_ms / 1e6,
+                     'algorithmic_frac': alg[dom] / dom_ms / 1e6 / HBM_PEAK_GBPS,
+                     'from_profiles': from_profiles},
+        'iteration_roofline': dict(
+            iteration_summary(table, prof_steps, ms_per_step, iter_alg_bytes),
+            steady_state_algorithmic_frac=iter_alg_bytes * (steady_steps / elapsed_steady) / 1e9
+            / HBM_PEAK_GBPS),
         'other_options': {'options': names[not args.fastsolve],
                           'value': args.steps / elapsed2 * world,
                           'ms_per_step': 1e3 * elapsed2 / args.steps},
@@ -513,9 +882,11 @@ def main():
                  'test on the device, host enqueues only') if not os.environ.get('SPORCO_AMD_HOST_LOOP')
                 else 'host-driven (one sporco_amd_csc_admm_iter call per iteration)',
         'result_download_ms': download_ms,
-        'kernels_ms_per_iter': {k: round(v[0] / prof_steps, 4) for k, v in timed.items()},
-        'kernel_roofline': per_kernel,
+        'kernels_ms_per_iter': {k: round(v[0] / prof_steps, 4) for k, v in prof.items() if v[1] > 0},
+        'kernel_roofline': table,
     }
+    if world == 1 and args.configs != 'none':
+        line['configs'] = run_other_configs(local_rank, args.configs, tiny=args.tiny)
     if world == 1 and not args.no_time_to_tol:
         line['time_to_tol'] = time_to_tol(cbpdn, H, W, K, N, local_rank)
     if world == 1 and not args.no_cpu_baseline:

@@ -20,7 +20,8 @@ const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_
                                            "rows_fwd_v",       "rows_inv_post_v",  "rows_inv_post_v_emit",
                                            "pgm_grad_ifft",    "pgm_rows_prox",    "pgm_fft_momentum",
                                            "finalize",         "pgm_elementwise",  "other",
-                                           "admm_persist_run"};
+                                           "admm_persist_run",
+                                    "setcoef_rows",     "setcoef_cols",     "ccmod_grad_tiled"};
 
 template <typename T> struct Csc : CscBase {
     sporco_amd_dims dm;

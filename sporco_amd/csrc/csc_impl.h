@@ -76,6 +76,9 @@ enum ProfSlot {
     PS_PGM,
     PS_OTHER,
     PS_PERSIST,                 // a run of iterations in one launch (csc_rows.h admm_persist)
+    PS_SETCOEF_ROWS,            // dictionary update: row / column transform of the coefficient maps
+    PS_SETCOEF_COLS,            // into the tile-major spectrum Zf (ccmod_setcoef)
+    PS_CCMOD_GRAD,              // ... and the gradient over tiles (ccmod_grad_tiled + group sum)
     PS_COUNT
 };
 extern const char *kProfNames[PS_COUNT];
