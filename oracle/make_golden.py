@@ -722,6 +722,67 @@ def gen_ccmod_eq():
                  X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_ccmod_eq_mcdict():
+    """The single-copy ADMM dictionary updates with a MULTI-CHANNEL dictionary (Cd = C > 1):
+    ConvCnstrMOD_IterSM / _CG (sporco/admm/ccmod.py:433-601: linalg.solvemdbi_ism / _cg with the
+    channel axis of b broadcast against a channel-less Zf) and their mask-decoupled forms
+    (sporco/admm/ccmodmd.py:573-760), with channel-less coefficient maps (H, W, 1, K, M) -- one
+    matrix per frequency shared by the channels -- and with maps that carry the dictionary's
+    channels (H, W, C, K, M), which the reference's broadcasting turns into C independent updates
+    sharing rho, the projection and the residuals (its own tests/admm/test_ccmodmd.py:176-194).
+    Also inside ConvBPDNDictLearn(dmethod='ism' / 'cg') on an RGB dictionary."""
+    from sporco.admm import ccmodmd as ref_ccmodmd
+    np.random.seed(24680)
+    N, M, Nd, K, C = 16, 4, 5, 3, 3
+    S = np.random.randn(N, N, C, K)
+    Wm = (np.random.rand(N, N, C, K) > 0.3).astype(np.float64)
+    Z1 = np.random.randn(N, N, 1, K, M) * (np.random.rand(N, N, 1, K, M) > 0.7)
+    Zc = np.random.randn(N, N, C, K, M) * (np.random.rand(N, N, C, K, M) > 0.7)
+    dsz = (Nd, Nd, C, M)
+    tight = {'MaxIter': 500, 'StopTol': 1e-9}
+    for meth, cls, mcls in (('ism', ref_admm_ccmod.ConvCnstrMOD_IterSM, ref_ccmodmd.ConvCnstrMODMaskDcpl_IterSM),
+                            ('cg', ref_admm_ccmod.ConvCnstrMOD_CG, ref_ccmodmd.ConvCnstrMODMaskDcpl_CG)):
+        for ztag, Z in (('', Z1), ('_zchan', Zc)):
+            for name, optd in (
+                    ('f64', {'MaxMainIter': 12}),
+                    ('chk_zm_f64', {'MaxMainIter': 12, 'ZeroMean': True, 'LinSolveCheck': True,
+                                    'RelaxParam': 1.5, 'AuxVarObj': True}),
+                    ('f32', {'MaxMainIter': 12, 'DataType': np.float32})):
+                if ztag and name != 'f64':
+                    continue
+                if meth == 'cg':
+                    optd = dict(optd, CG=tight)
+                c = cls(Z, S, dsz, cls.Options(optd))
+                c.solve()
+                save('ccmod_%s_mcdict%s_%s' % (meth, ztag, name), Z=Z, S=S, dsz=np.array(dsz),
+                     D=c.getdict(), Y=c.Y, X=c.X, U=c.U, rho_final=np.float64(c.rho),
+                     k_final=np.int64(c.k), **itstat_dict(c))
+            # mask decoupling
+            for name, optd in (('f64', {'MaxMainIter': 12}),
+                               ('chk_f64', {'MaxMainIter': 12, 'LinSolveCheck': True,
+                                            'AutoRho': {'Enabled': True}, 'ZeroMean': True})):
+                if ztag and name != 'f64':
+                    continue
+                if meth == 'cg':
+                    optd = dict(optd, CG=tight)
+                c = mcls(Z, S, Wm, dsz, mcls.Options(optd))
+                c.solve()
+                save('ccmodmd_%s_mcdict%s_%s' % (meth, ztag, name), Z=Z, S=S, W=Wm,
+                     dsz=np.array(dsz), D=c.getdict(), Y=c.Y, X=c.X, U=c.U,
+                     rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+    # dictionary learning on an RGB dictionary with both updates
+    D0 = np.random.randn(Nd, Nd, C, M)
+    for meth in ('ism', 'cg'):
+        optd = {'MaxMainIter': 8, 'AccurateDFid': True}
+        if meth == 'cg':
+            optd['CCMOD'] = {'CG': tight}
+        opt = ref_cbpdndl.ConvBPDNDictLearn.Options(optd, xmethod='admm', dmethod=meth)
+        b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod=meth)
+        D1 = b.solve()
+        save('cbpdndl_%s_mcdict_f64' % meth, D0=D0, S=S, lmbda=np.float64(0.1), D1=D1,
+             X=b.getcoef(), **itstat_dict(b))
+
+
 def gen_ccmod_ism_many():
     """ConvCnstrMOD_IterSM over MORE than 8 images (and images x channels): the reference takes
     any number (sporco/admm/ccmod.py:433-604, linalg.solvemdbi_ism over axisK); also inside the
@@ -1274,11 +1335,11 @@ def gen_ccmodmd_cns_mcdict():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
-                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict']
+                             'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
              'known': gen_known_answer, 'config1': gen_config1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
-             'config3': gen_config3, 'config4': gen_config4,
+             'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
              'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:

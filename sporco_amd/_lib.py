@@ -709,18 +709,18 @@ class Solver(object):
         return list(out)
 
     def dstep_init(self, Y0):
-        """Single-copy ADMM D-step state: Y = U = Y0 (H, W, 1, 1, K) or zero, Xf = 0."""
+        """Single-copy ADMM D-step state: Y = U = Y0 (H, W, Cd, 1, K) or zero, Xf = 0."""
         if Y0 is None:
             check(self._lib.sporco_amd_csc_dstep_init(self._h, None))
             return
         H, W, C, N, K = self.dims
-        Y0 = _carr(Y0, self.dtype).reshape(H, W, K)
+        Y0 = _carr(Y0, self.dtype).reshape(H, W, self.Cd, K)
         check(self._lib.sporco_amd_csc_dstep_init(self._h, _ptr(Y0)))
 
     def dstep_md_init(self, Y0, S):
         """Mask-decoupling D-step state: dstep_init(Y0), block 0 zeroed, real signal kept."""
         H, W, C, N, K = self.dims
-        y0 = None if Y0 is None else _carr(Y0, self.dtype).reshape(H, W, K)
+        y0 = None if Y0 is None else _carr(Y0, self.dtype).reshape(H, W, self.Cd, K)
         s = None if S is None else _carr(S, self.dtype)
         check(self._lib.sporco_amd_csc_dstep_md_init(self._h, None if y0 is None else _ptr(y0),
                                                      None if s is None else _ptr(s)))

@@ -378,9 +378,6 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
-        if self.cri.Cd > 1:
-            raise NotImplementedError("multi-channel dictionaries are not part of the "
-                                      "sporco_amd dictionary update")
         if opt['ReturnX']:
             raise NotImplementedError("the device D-step returns the constrained variable Y "
                                       "(ReturnX False, the class default)")

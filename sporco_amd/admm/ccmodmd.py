@@ -61,7 +61,7 @@ class ConvCnstrMODMaskDcplBase(ccmod.ConvCnstrMODBase):
             raise NotImplementedError("the device D-step returns the dictionary (ReturnVar 'Y1', "
                                       "the class default)")
         cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
-        Nb = cri.C * cri.K
+        Nb = (cri.C if cri.Cd == 1 else 1) * cri.K     # (CK of ccmodmd.py:273)
         y0 = opt['Y0']
         if y0 is not None and np.asarray(y0).shape[-1] == Nb + cri.M:
             # the reference's [y0; y1] on the filter axis (ccmodmd.py:400-445)
@@ -103,7 +103,11 @@ class ConvCnstrMODMaskDcplBase(ccmod.ConvCnstrMODBase):
         the real signal go to the device."""
         self.W = self._mask5()
         H, Wd = self.cri.Nv
-        if self.cri.C > 1:
+        if self.cri.Cd > 1:
+            # multi-channel dictionary: signal, mask and block 0 keep the channel axis
+            self.dev.set_data_mask(ccmod_broadcastable(
+                self.W, (H, Wd, self.cri.C, self.cri.K, 1)))
+        elif self.cri.C > 1:
             # the handle keeps channels and images on separate axes; (H, W, 1, C K) and
             # (H, W, C, K) share their memory layout
             full = np.ascontiguousarray(np.broadcast_to(self.W, (H, Wd, 1, self.Nb, 1)))

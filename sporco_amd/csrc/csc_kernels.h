@@ -271,6 +271,12 @@ int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho,
 template <typename T>
 void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t rows, int A, int B);
 
+// dst[(pix, c), n, k] = zch ? src[pix, n, c, k] : src[pix, n, k]  (npix Cd "frequencies" of a
+// single-channel dictionary update: api_dstep.inc)
+template <typename T>
+void launch_zf_per_channel(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t npix, int N, int Cd,
+                           int K, int zch);
+
 // Multi-channel dictionary (Cd > 1) X-step, linalg.solvemdbi_ism (linalg.py:370-444):
 // gam(npix, Cd, K), del(npix, Cd), mm(npix, Cd, Cd) hold the recursion's gamma / delta and the
 // products <ah_c, gamma_l> (functions of Df and rho);

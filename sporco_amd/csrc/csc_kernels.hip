@@ -2206,6 +2206,33 @@ void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t row
     SA_HIP(hipGetLastError());
 }
 
+// dst[(pix, c), n, k] = zch ? src[pix, n, c, k] : src[pix, n, k]: the coefficient spectrum of a
+// multi-channel dictionary update seen as one single-channel update per (frequency, channel)
+// -- the same matrix for every channel of a frequency (linalg.solvemdbi_ism / _cg with a
+// broadcast channel axis, admm/ccmod.py:481-487), or a matrix per channel when the maps carry
+// the channels themselves.
+template <typename T>
+__global__ void __launch_bounds__(kThreads) zf_per_channel_kernel(const cx<T> *__restrict__ src,
+                                                                  cx<T> *__restrict__ dst, int64_t npix,
+                                                                  int N, int Cd, int K, int zch) {
+    const int64_t total = npix * Cd * N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int n = (int)((i / K) % N);
+        const int c = (int)((i / ((int64_t)K * N)) % Cd);
+        const int64_t pix = i / ((int64_t)K * N * Cd);
+        dst[i] = zch ? src[((pix * N + n) * Cd + c) * K + k] : src[(pix * N + n) * K + k];
+    }
+}
+template <typename T>
+void launch_zf_per_channel(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t npix, int N, int Cd,
+                           int K, int zch) {
+    hipLaunchKernelGGL((zf_per_channel_kernel<T>), dim3(grid_for(npix * Cd * N * K)), dim3(kThreads), 0, st,
+                       src, dst, npix, N, Cd, K, zch);
+    SA_HIP(hipGetLastError());
+}
+
 template <typename T>
 void launch_ism_setup(hipStream_t st, const cx<T> *df, cx<T> *gam, cx<T> *del, cx<T> *mm,
                       int64_t npix, int Cd, int K, T rho, const GradTerm<T> *grad, int W) {
@@ -3284,6 +3311,8 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_cns_xrrs_fin<T>(hipStream_t, const cx<T> *, const cx<T> *, T,              \
                                         const cx<T> *, int64_t, int, int, double *, int, int);     \
     template void launch_swap_inner<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int);    \
+    template void launch_zf_per_channel<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int, \
+                                           int, int);                                              \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \
                                       int64_t, int, int, T, const GradTerm<T> *, int);             \
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *,           \

@@ -412,8 +412,10 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                 }
                 float y0 = soft1_m<MODE>(vv.re, t0), y1 = soft1_m<MODE>(vv.im, t1);
                 if constexpr (JOINT) {      // the l2 shrinkage over the channels, as the epilogue
-                    float f0 = sa_fma(-thr21_p, sa_rsq(sum_over_rows(y0 * y0)), 1.f);
-                    float f1 = sa_fma(-thr21_p, sa_rsq(sum_over_rows(y1 * y1)), 1.f);
+                    float q0 = y0 * y0, q1 = y1 * y1;
+                    sum_over_rows2(q0, q1);
+                    float f0 = sa_fma(-thr21_p, sa_rsq(q0), 1.f);
+                    float f1 = sa_fma(-thr21_p, sa_rsq(q1), 1.f);
                     f0 = f0 > 0.f ? f0 : 0.f;
                     f1 = f1 > 0.f ? f1 : 0.f;
                     y0 = f0 * y0;
@@ -611,17 +613,27 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                     wte[e] = am_e[e] ? 0.f : wte[e];
                 }
             }
-            if constexpr (VIN) {
+            if constexpr (VIN && JOINT) {
+                // the previous iterate from its V, both elements of the pixel together: the
+                // channel sums of their squares travel through one set of swaps (sum_over_rows2)
+                const float vp[2] = {yo[0], yo[1]};
+                float yp[2] = {soft1_pos(vp[0], thr_p), soft1_pos(vp[1], thr_p)};
+                float qp[2] = {yp[0] * yp[0], yp[1] * yp[1]};
+                sum_over_rows2(qp[0], qp[1]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float fp = sa_fma(-thr21_p, sa_rsq(qp[e]), 1.f);
+                    fp = fp > 0.f ? fp : 0.f;
+                    yp[e] = sa_med3(fp * yp[e], nn_lo, __builtin_inff());
+                    yo[e] = yp[e];
+                    uraw[e] = vp[e] - yp[e];
+                }
+            } else if constexpr (VIN) {
                 // the previous iterate from its V: Y = prox(V; thr_prev) (+ the options), U = V - Y
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float vp = yo[e];
                     float yp = soft1_m<MODE>(vp, thr_p * wte[e]);
-                    if constexpr (JOINT) {
-                        float fp = sa_fma(-thr21_p, sa_rsq(sum_over_rows(yp * yp)), 1.f);
-                        fp = fp > 0.f ? fp : 0.f;
-                        yp = fp * yp;
-                    }
                     yp = sa_med3(yp, (GENERAL && am_e[e]) ? -__builtin_inff() : nn_lo, __builtin_inff());
                     if constexpr (GENERAL) yp *= am_e[e] ? mkeep : keep;
                     yo[e] = yp;
@@ -636,42 +648,53 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
                 // prox_sl1l2 over the channel axis (cbpdn.py:785-794): soft threshold, then the
                 // channel vector of each (pixel, image, filter) shrunk in l2 norm,
                 // y = s max(0, 1 - thr21 / ||s||) (prox/_lp.py:283-290, zero where ||s|| = 0).
-                // The channels sit 16 lanes apart (idle lanes hold zeros).
+                // The channels sit 16 lanes apart (idle lanes hold zeros); the two elements of the
+                // pixel share each of the three channel sums' swaps (sum_over_rows2).  Stage by
+                // stage with fences between: the emitting variant keeps the whole tile live for the
+                // forward transform and has no registers for the scheduler's interleavings (it
+                // spilled 544 bytes of scratch in round 2).
+                float sv[2], q[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const float ax = sa_fma(al, xs[e], oma * yo[e]);
-                    const float vv = sa_fma(usc, uraw[e], ax);
-                    const float sv = soft1_pos(vv, thr);
-                    const float q = sum_over_rows(sv * sv);
-                    float fac = sa_fma(-thr21, sa_rsq(q), 1.f);   // (q = 0: -inf, or NaN when thr21 = 0)
+                    vn[e] = sa_fma(usc, uraw[e], ax);
+                    sv[e] = soft1_pos(vn[e], thr);
+                    q[e] = sv[e] * sv[e];
+                }
+                if constexpr (EMIT_T) {
+                    SA_VGPR_FENCE3(sv[0], sv[1], vn[0]);
+                    SA_VGPR_FENCE3(q[0], q[1], vn[1]);
+                }
+                sum_over_rows2(q[0], q[1]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float fac = sa_fma(-thr21, sa_rsq(q[e]), 1.f);   // (q = 0: -inf, or NaN when thr21 = 0)
                     fac = fac > 0.f ? fac : 0.f;
-                    float y1 = fac * sv;
-                    y1 = sa_med3(y1, nn_lo, __builtin_inff());
-                    const float u1 = vv - y1;
+                    const float y1 = sa_med3(fac * sv[e], nn_lo, __builtin_inff());
+                    const float u1 = vn[e] - y1;
                     yn[e] = y1;
                     un[e] = u1;
-                    vn[e] = vv;
                     const float dr = xs[e] - y1, ds = y1 - yo[e];
                     s_r2 = sa_fma(dr, dr, s_r2);
                     s_s2 = sa_fma(ds, ds, s_s2);
                     s_x2 = sa_fma(xs[e], xs[e], s_x2);
                     s_y2 = sa_fma(y1, y1, s_y2);
                     s_u2 = sa_fma(u1, u1, s_u2);
-                    // (always formed: a branch on F_OBJ here would split the unrolled epilogue
-                    // into blocks and spill the tile, see the NoBndryCross note above)
-                    const float gvar = gy ? y1 : xs[e];
-                    s_l1 += fabsf(gvar);
-                    const float g2 = sum_over_rows(gvar * gvar);
-                    s_l21 = sa_fma(l21w, sa_sqrt(g2), s_l21);
-                    if constexpr (EMIT_T) {
-                        // One element at a time: the emitting variant keeps the whole tile live for
-                        // the forward transform, and with both elements of a pixel in flight the
-                        // allocator spilled it (544 bytes of scratch in round 2, which is why
-                        // ConvBPDNJoint did not speculate); serialised, it fits 128 registers.
-                        SA_VGPR_FENCE3(s_r2, s_s2, s_l21);
-                        SA_VGPR_FENCE3(s_y2, s_u2, s_l1);
-                    }
                 }
+                if constexpr (EMIT_T) {
+                    SA_VGPR_FENCE3(s_r2, s_s2, s_x2);
+                    SA_VGPR_FENCE3(s_y2, s_u2, s_l1);
+                }
+                // (always formed: a branch on F_OBJ here would split the unrolled epilogue
+                // into blocks and spill the tile, see the NoBndryCross note above)
+                const float gv0 = gy ? yn[0] : xs[0], gv1 = gy ? yn[1] : xs[1];
+                s_l1 += fabsf(gv0);
+                s_l1 += fabsf(gv1);
+                float g2[2] = {gv0 * gv0, gv1 * gv1};
+                sum_over_rows2(g2[0], g2[1]);
+                s_l21 = sa_fma(l21w, sa_sqrt(g2[0]), s_l21);
+                s_l21 = sa_fma(l21w, sa_sqrt(g2[1]), s_l21);
+                if constexpr (EMIT_T) SA_VGPR_FENCE3(s_l21, s_l1, s_r2);
             } else {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -731,8 +754,11 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     block_sum_store<8, COH>(acc, scratch, a->partials + tile * 8);
 }
 
+// (two 8-wave workgroups share a CU only at <= 128 registers: the joint emitting variants land a
+// register or two above that on their own, so they are told -- second argument = waves per SIMD)
 template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false, int SF = 0>
-__global__ void __launch_bounds__(NW * 64) rows_inv_post_kernel(const RowsPostArgs<float> a_in) {
+__global__ void __launch_bounds__(NW * 64, (JOINT && EMIT_T && NW == 8) ? 4 : 1)
+rows_inv_post_kernel(const RowsPostArgs<float> a_in) {
     // device-driven solve: both variants are enqueued every iteration and the one whose EMIT_T
     // matches the speculation decision runs (an idle launch costs about 12 us; the emitting
     // variant keeps half as many Y / U loads in flight, so it is not the one to run when

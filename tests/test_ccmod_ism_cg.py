@@ -240,3 +240,71 @@ def test_itersm_over_more_than_eight_images(backend, name):
     its = c.getitstat()
     for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
         assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+
+
+# ---- multi-channel dictionaries (round 4) ---------------------------------------------------------
+MC_CASES = {
+    'mcdict_f64': {'MaxMainIter': 12},
+    'mcdict_chk_zm_f64': {'MaxMainIter': 12, 'ZeroMean': True, 'LinSolveCheck': True,
+                          'RelaxParam': 1.5, 'AuxVarObj': True},
+    'mcdict_f32': {'MaxMainIter': 12, 'DataType': np.float32},
+    'mcdict_zchan_f64': {'MaxMainIter': 12},
+}
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+@pytest.mark.parametrize('case', sorted(MC_CASES))
+def test_multichannel_dictionary(backend, method, case):
+    """ConvCnstrMOD_IterSM / _CG with a 3-channel dictionary (Cd = C = 3): channel-less
+    coefficient maps (one matrix per frequency shared by the channels: sporco/admm/ccmod.py:481-487,
+    :586-596 with linalg.solvemdbi_ism / _cg broadcasting over the channel axis) and maps that
+    carry the channels (`zchan`: C independent updates sharing rho, the projection and the
+    residuals), against the unmodified reference (oracle/make_golden.py gen_ccmod_eq_mcdict).  CG
+    runs tight (StopTol 1e-9) in these fixtures so that its result is a function of its inputs."""
+    if backend == 'hostsim' and method == 'cg' and case not in ('mcdict_f64', 'mcdict_zchan_f64'):
+        pytest.skip("kept for the GPU run (hundreds of CG iterations per step on the simulator)")
+    g = load_golden('ccmod_%s_%s' % (method, case))
+    optd = dict(MC_CASES[case])
+    f32 = optd.get('DataType') is np.float32
+    tol = 5e-4 if f32 else 1e-9
+    if method == 'cg':
+        optd['CG'] = {'MaxIter': 500, 'StopTol': 1e-9}
+        tol = 5e-4 if f32 else 1e-7
+    cls = dstep_class(method)
+    c = cls(g['Z'], g['S'], tuple(int(v) for v in g['dsz']), cls.Options(optd))
+    Y = c.solve()
+    assert c.k == int(g['k_final'])
+    assert Y.shape == g['Y'].shape and rel_l2(Y, g['Y']) < tol
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    assert c.X.shape == g['X'].shape and rel_l2(c.X, g['X']) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < max(10 * tol, 1e-9)
+    if optd.get('LinSolveCheck'):
+        assert np.max(np.abs(np.asarray(its.XSlvRelRes) - g['it_XSlvRelRes'])) < 1e-8
+    if method == 'cg':
+        assert np.array_equal(np.asarray(its.XSlvCGIt), g['it_XSlvCGIt'])
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+def test_dictlearn_colour_dictionary(backend, method):
+    """ConvBPDNDictLearn(xmethod='admm', dmethod='ism' / 'cg') learning an RGB dictionary
+    (5 x 5 x 3 x 4) from 3 colour images: 8 outer iterations against the reference's float64 run."""
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden('cbpdndl_%s_mcdict_f64' % method)
+    optd = {'MaxMainIter': 8, 'AccurateDFid': True}
+    if method == 'cg':
+        optd['CCMOD'] = {'CG': {'MaxIter': 500, 'StopTol': 1e-9}}
+    opt = cbpdndl.ConvBPDNDictLearn.Options(optd, xmethod='admm', dmethod=method)
+    b = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], float(g['lmbda']), opt, xmethod='admm',
+                                  dmethod=method)
+    D1 = b.solve()
+    tol = 1e-9 if method == 'ism' else 1e-7
+    assert D1.shape == g['D1'].shape and rel_l2(D1, g['D1']) < tol
+    assert rel_l2(b.getcoef(), g['X']) < tol
+    its = b.getitstat()
+    for f in its._fields:
+        if 'it_' + f in g and f not in ('Iter', 'Cnstr'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < tol, f

@@ -353,3 +353,46 @@ def test_masked_consensus_linsolvecheck(backend):
     for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-9, f
     assert max(its.XSlvRelRes) < 1e-10 and np.max(g['it_XSlvRelRes']) < 1e-10
+
+
+# ---- multi-channel dictionaries in the single-copy mask-decoupled updates (round 4) -----------------
+MD_MC_CASES = {
+    'mcdict_f64': {'MaxMainIter': 12},
+    'mcdict_chk_f64': {'MaxMainIter': 12, 'LinSolveCheck': True, 'AutoRho': {'Enabled': True},
+                       'ZeroMean': True},
+    'mcdict_zchan_f64': {'MaxMainIter': 12},
+}
+
+
+@pytest.mark.parametrize('method', ['ism', 'cg'])
+@pytest.mark.parametrize('case', sorted(MD_MC_CASES))
+def test_multichannel_dictionary(backend, method, case):
+    """ConvCnstrMODMaskDcpl_IterSM / _CG with a 3-channel dictionary (sporco/admm/ccmodmd.py:573-760;
+    block 0 keeps the signal's (channel, image) axes, ccmodmd.py:400-445), channel-less and
+    channel-ful coefficient maps -- the latter is the reference's own
+    tests/admm/test_ccmodmd.py:176-194 -- against the unmodified reference
+    (oracle/make_golden.py gen_ccmod_eq_mcdict)."""
+    if backend == 'hostsim' and method == 'cg' and case != 'mcdict_f64':
+        pytest.skip("kept for the GPU run (hundreds of CG iterations per step on the simulator)")
+    g = load_golden('ccmodmd_%s_%s' % (method, case))
+    optd = dict(MD_MC_CASES[case])
+    tol = 1e-9
+    if method == 'cg':
+        optd['CG'] = {'MaxIter': 500, 'StopTol': 1e-9}
+        tol = 1e-6
+    cls = dstep_class(method)
+    c = cls(g['Z'], g['S'], g['W'], tuple(int(v) for v in g['dsz']), cls.Options(optd))
+    Y1 = c.solve()
+    assert c.k == int(g['k_final'])
+    K = g['S'].shape[3]
+    assert Y1.shape == g['Y'][..., K:].shape and rel_l2(Y1, g['Y'][..., K:]) < tol
+    assert c.Y.shape == g['Y'].shape and rel_l2(c.Y, g['Y']) < tol
+    assert c.U.shape == g['U'].shape and rel_l2(c.U, g['U']) < tol
+    assert rel_l2(c.X, g['X']) < tol and rel_l2(c.getdict(), g['D']) < tol
+    assert rel_l2(float(c.rho), float(g['rho_final'])) < tol
+    its = c.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < tol, f
+    assert np.max(np.abs(np.asarray(its.Cnstr) - g['it_Cnstr'])) < max(10 * tol, 1e-9)
+    if optd.get('LinSolveCheck'):
+        assert np.max(np.abs(np.asarray(its.XSlvRelRes) - g['it_XSlvRelRes'])) < 1e-8
