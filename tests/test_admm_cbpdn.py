@@ -368,15 +368,13 @@ def test_abi_error_paths_of_the_widened_calls(backend):
     # a multi-channel dictionary needs the signal's channel count
     with pytest.raises(_lib.BackendError):
         _lib.Solver(16, 16, 2, 1, 4, np.float64, Cd=3)
-    # ... and serves ADMM ConvBPDN, the masked PGM gradient and the consensus D-steps (plain
-    # and mask-decoupled): the one-copy D-steps (IterSM / CG) and the fused PGM iteration
-    # refuse it
+    # ... and serves ADMM ConvBPDN, the masked PGM gradient and every ADMM D-step (plain and
+    # mask-decoupled): the fused PGM iteration refuses it
     mc = _lib.Solver(16, 16, 3, 1, 4, np.float64, Cd=3)
     mc.set_signal(rng.randn(16, 16, 3, 1))
     mc.cns_init(None, 1.0)
     mc.cns_md_init(np.zeros((16, 16, 3, 1)))
-    with pytest.raises(_lib.BackendError):
-        mc.dstep_init(None)
+    mc.dstep_init(None)            # (round 4: the one-copy D-steps take it too)
     with pytest.raises(_lib.BackendError):
         mc.pgm_iter(500.0, 0.1, 0.0, 0, 5, 5, True)
     # the consensus D-step needs a signal before it can iterate

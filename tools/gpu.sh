@@ -15,7 +15,8 @@
 #   sq                     two SQ counter passes of the quick bench -> pmc_sq_{1,2}.csv
 #   py:<script and args>   python tools/<script> ...         -> <script>.jsonl (lines starting with {)
 #   pystats:<script args>  rocprofv3 --kernel-trace --stats of python tools/<script> -> <script>_kernel_stats.csv
-#   env:<VAR=VALUE>        export for the following steps
+#   env:<VAR=VALUE>        export for the following steps (env:-VAR unsets)
+#   sh:<command>           any command (bounded to 600 s)     -> sh_<n>.txt
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 R=$PWD
 TAG=$1; shift
@@ -29,7 +30,8 @@ for step in "$@"; do
   n=$((n+1))
   kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
   case $kind in
-    env) export "$arg" ;;
+    env) if [ "${arg#-}" != "$arg" ]; then unset "${arg#-}"; else export "$arg"; fi ;;
+    sh) timeout 600 bash -c "$arg" 2>&1 | grep -v amdgpu.ids | tee $O/sh_$n.txt | tail -40 ;;
     tests)
       timeout 2400 python -m pytest ${arg:-tests} -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -6 | tee $O/pytest_gpu_$n.txt ;;
     smoke)
