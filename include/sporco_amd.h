@@ -260,6 +260,14 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
                                                 (:1181-1184) */
 #define SPORCO_AMD_FLAG_AMS (1u << 11)       /* AddMaskSim y step / regulariser sums on the
                                                 last filter slice (set_ams_mask) */
+#define SPORCO_AMD_FLAG_DMASK (1u << 12)     /* pgm_iter: data fidelity (1/2)||W (D x - s)||^2 with
+                                                the mask of set_data_mask (pgm.cbpdn.ConvBPDNMask,
+                                                sporco/pgm/cbpdn.py:387-506): the residual goes
+                                                through the spatial domain for W^2 between the
+                                                inner product and the gradient; out[PGM_DFID] =
+                                                sum (W R)^2 and out[PGM_F] = (1/2) sum_half
+                                                |rfftn(W R)|^2 at the new Xf (want_stats);
+                                                K <= 64, no held trial */
 
 typedef struct {
     double rho;      /* penalty parameter for this iteration                     */
@@ -394,7 +402,7 @@ typedef struct {
     double L;        /* inverse step size                                   */
     double lmbda;    /* l1 weight (times a scalar L1Weight)                 */
     double beta;     /* momentum factor (t_prev - 1) / t                    */
-    uint32_t flags;  /* SPORCO_AMD_FLAG_NONNEG | SPORCO_AMD_FLAG_NOBNDRY     */
+    uint32_t flags;  /* SPORCO_AMD_FLAG_NONNEG | _NOBNDRY | _DMASK           */
     int32_t dH, dW;  /* filter support, for NOBNDRY                         */
     int32_t want_stats; /* evaluate the objective at the new Xf             */
     int32_t hold;    /* backtracking trial: also out[PGM_LIN], out[PGM_DXY2] (the terms of

@@ -35,6 +35,7 @@ FLAG_KEEP_X = 1 << 8
 FLAG_NO_X = 1 << 9
 FLAG_GRADREG = 1 << 10
 FLAG_AMS = 1 << 11
+FLAG_DMASK = 1 << 12
 QUERY_FUSED_COLS, QUERY_FUSED_ROWS, QUERY_FUSED_PGM, QUERY_DEVICE_FILTERS, QUERY_VFORM_LIVE = 0, 1, 2, 3, 4
 QUERY_PERSIST_RUNS = 5
 HINT_KEEP_VFORM = 0

@@ -773,10 +773,14 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
         if (!grad && NW == 16 && dbg == 3) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 3>(st, a, ntiles);
         if (!grad && NW == 16 && dbg == 4) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 4>(st, a, ntiles);
 #endif
+        // (coef_out on a K <= 64 system: the instantiation that stores the multipliers -- the
+        // mask-decoupled X-step reads D x = Sf - rho coef off them, api_maskdcpl.inc)
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
+        else if (a.coef_out) launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false>(st, a, ntiles);
     } else {
         if (grad) launch_fused_inst<N1, NW, LP, 0, true>(st, a, ntiles);
+        else if (a.coef_out) launch_fused_inst<N1, NW, LP, 0, false, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 0, false>(st, a, ntiles);
     }
 }

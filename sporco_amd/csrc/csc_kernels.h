@@ -32,6 +32,7 @@ enum : uint32_t {
     F_NO_X = 1u << 9,
     F_GRADREG = 1u << 10,
     F_AMS = 1u << 11,
+    F_DMASK = 1u << 12,
 };
 
 // Gradient penalty of ConvBPDNGradReg (cbpdn.py:1133-1143): GHGf[h, wf] = ghh[h] + ghw[wf]
@@ -271,6 +272,16 @@ int launch_cns_xrrs_fin(hipStream_t st, const cx<T> *zf, const cx<T> *xf, T rho,
 template <typename T>
 void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t rows, int A, int B);
 
+// out[tile][h] = sum_k dft[wf][h][k] v[tile][h][k] - sft[tile][h] on the tile-major layout of
+// csc_fused.h (v: (Wf CN, H, Ks) rows of K filters; dft (Wf, H, Ks); sft, out (Wf CN, H))
+template <typename T>
+void launch_tiled_resid(hipStream_t st, const cx<T> *v, const cx<T> *dft, const cx<T> *sft, cx<T> *out,
+                        int64_t ntiles, int H, int K, int Ks, int CN);
+// sum over (tile, h, k) of pw(wf) |conj(dft[wf][h][k]) u0t[tile][h] + t[tile][h][k]|^2 on the
+// tile-major layout of csc_fused.h (rows Ks filters apart; 0 = K): one double per block
+template <typename T>
+int launch_md_dualres_tiled(hipStream_t st, const cx<T> *t, const cx<T> *dft, const cx<T> *u0t,
+                            int64_t ntiles, int H, int K, int Ks, int CN, int W, double *partials);
 // dst[(pix, c), n, k] = zch ? src[pix, n, c, k] : src[pix, n, k]  (npix Cd "frequencies" of a
 // single-channel dictionary update: api_dstep.inc)
 template <typename T>

@@ -1563,6 +1563,75 @@ void launch_zf_adjoint(hipStream_t st, const cx<T> *zf, const cx<T> *r, cx<T> *g
     SA_HIP(hipGetLastError());
 }
 
+// Residual per frequency on the TILE-MAJOR layout of the fused kernels (csc_fused.h):
+// out[tile][h] = sum_k dft[wf][h][k] v[tile][h][k] - sft[tile][h]   (eval_Rf, pgm/cbpdn.py:281-286),
+// one wave per (tile, h) row of K filters (rows Ks apart).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) tiled_resid_kernel(const cx<T> *__restrict__ v,
+                                                               const cx<T> *__restrict__ dft,
+                                                               const cx<T> *__restrict__ sft,
+                                                               cx<T> *__restrict__ out, int64_t nrows,
+                                                               int H, int K, int Ks, int CN) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; row < nrows;
+         row += nwaves) {
+        const int64_t tile = row / H;
+        const int h = (int)(row - tile * H);
+        const int64_t wf = tile / CN;
+        const cx<T> *d = dft + (wf * H + h) * Ks, *x = v + row * Ks;
+        cx<T> s = mk<T>(T(0), T(0));
+        for (int k = lane; k < K; k += kWave) s = s + cmul(d[k], x[k]);
+        s = wave_sum_cx(s);
+        if (lane == 0) out[row] = s - sft[row];
+    }
+}
+template <typename T>
+void launch_tiled_resid(hipStream_t st, const cx<T> *v, const cx<T> *dft, const cx<T> *sft, cx<T> *out,
+                        int64_t ntiles, int H, int K, int Ks, int CN) {
+    hipLaunchKernelGGL((tiled_resid_kernel<T>), dim3(grid_for(ntiles * H * kWave)), dim3(kThreads), 0, st,
+                       v, dft, sft, out, ntiles * H, H, K, Ks ? Ks : K, CN);
+    SA_HIP(hipGetLastError());
+}
+
+// Dual residual of the mask-decoupled X-step on the TILE-MAJOR layout of the fused kernels
+// (csc_fused.h): sum over (tile, h, k) of pw(wf) |conj(dft[wf][h][k]) u0t[tile][h] + t[tile][h][k]|^2
+// with t the 2-D spectrum of u1 and u0t that of u0 -- rho^2 ||A^T u||^2 H W without its factors
+// (cbpdn.py:1814-1818).  One wave per (tile, h) row of K filters (rows Ks apart).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) md_dualres_tiled_kernel(const cx<T> *__restrict__ t,
+                                                                    const cx<T> *__restrict__ dft,
+                                                                    const cx<T> *__restrict__ u0t,
+                                                                    int64_t nrows, int H, int K, int Ks,
+                                                                    int CN, int Wf, int W,
+                                                                    double *partials) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    double acc[1] = {0.0};
+    for (int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; row < nrows;
+         row += nwaves) {
+        const int64_t tile = row / H;
+        const int h = (int)(row - tile * H);
+        const int wf = (int)(tile / CN);
+        const cx<T> u0 = u0t[row];
+        const cx<T> *d = dft + ((int64_t)wf * H + h) * Ks, *x = t + row * Ks;
+        double s = 0.0;
+        for (int k = lane; k < K; k += kWave) s += (double)cabs2(cmulc(d[k], u0) + x[k]);
+        acc[0] += parseval_weight(wf, Wf, W) * s;
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+template <typename T>
+int launch_md_dualres_tiled(hipStream_t st, const cx<T> *t, const cx<T> *dft, const cx<T> *u0t,
+                            int64_t ntiles, int H, int K, int Ks, int CN, int W, double *partials) {
+    const int grid = std::min(grid_for(ntiles * H * kWave), kMaxPartialBlocks);
+    hipLaunchKernelGGL((md_dualres_tiled_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * (kThreads / kWave), st, t, dft, u0t, ntiles * H, H, K, Ks ? Ks : K, CN,
+                       W / 2 + 1, W, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
 // ---------------------------------------------------------------------------
 // ADMM consensus dictionary update (admm/ccmod.py:605-908 on admm/admm.py:1441-1707):
 // one dictionary copy X_n (and dual U_n) per image, consensus variable Y (H, W, K)
@@ -3311,6 +3380,10 @@ void launch_admm_ctl_update(hipStream_t st, AdmmCtl *ctl, const double *sums, Ad
     template int launch_cns_xrrs_fin<T>(hipStream_t, const cx<T> *, const cx<T> *, T,              \
                                         const cx<T> *, int64_t, int, int, double *, int, int);     \
     template void launch_swap_inner<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int);    \
+    template void launch_tiled_resid<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *,  \
+                                        cx<T> *, int64_t, int, int, int, int);                     \
+    template int launch_md_dualres_tiled<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, \
+                                            int64_t, int, int, int, int, int, double *);           \
     template void launch_zf_per_channel<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int, \
                                            int, int);                                              \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *,       \

@@ -32,6 +32,9 @@ template <typename T> struct PgmColsArgs {
     cx<T> *ey;            // tile-major (Wf, CN, H), or null: e_y = sum_k Df Yf - Sf per frequency,
                           // written by grad_ifft and read by fft_momentum (with want_stats) for
                           // the linear term of the backtracking model Q_L (pgm.py:886-894)
+    const cx<T> *ey_in = nullptr;   // grad_ifft: the residual per frequency, tile-major (Wf, CN, H), taken
+                          // from memory instead of formed from Yf (the masked classes: it has
+                          // been through the spatial domain for the mask); K <= 64, no held trial
     cx<T> *qpart = nullptr;   // K > 64 (fft_momentum runs per (tile, 64-filter slab), grid.y = slabs):
                           // with want_stats the slab's share of sum_k Df Xf' goes to
                           // qpart[tile][slab][f] and launch_pgm_stats_slabs forms the objective sums

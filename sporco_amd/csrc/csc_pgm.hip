@@ -46,8 +46,12 @@ __device__ __forceinline__ void inner4(const cf (&d)[4], const cf *x, int lane, 
 // summed; the default iteration needs neither and compiles them out.
 // With 16 waves and K = 64 the launch is persistent (one workgroup per CU walking its XCD's
 // tile list, staggered start): see fused_cols_kernel, whose measurements carried over.
-template <int NW, int LP, int KC, bool BT, bool PERS = false>
+// EYIN: the residual per frequency comes from memory (a.ey_in) instead of being formed from
+// Yf -- the masked classes, whose residual passes through the spatial domain for the mask
+// between the inner product and the gradient (pgm/cbpdn.py:454-477); no wave reduction then.
+template <int NW, int LP, int KC, bool BT, bool PERS = false, bool EYIN = false>
 __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArgs<float> a) {
+    static_assert(!(BT && EYIN), "a held trial forms its own residual");
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
@@ -79,7 +83,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
     const BufRsrc Yb = make_rsrc(ap->yf + (int64_t)tile * H * K, tbytes);
     const BufRsrc Ob = make_rsrc(ap->t + (int64_t)tile * H * K, tbytes);
     const BufRsrc Db = make_rsrc(ap->dft + (int64_t)wf * H * K, tbytes);
-    const cf *S = ap->sft + (int64_t)tile * H + w;
+    const cf *S = (EYIN ? ap->ey_in : ap->sft) + (int64_t)tile * H + w;
     cf *EY = BT ? ap->ey + (int64_t)tile * H + w : nullptr;
     const cf *twB = ap->twB + w * N1;
     const float inv_L = ap->inv_L;
@@ -108,10 +112,12 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
                 dd[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                 sa_uload2(reinterpret_cast<const float *>(S + fo), sv[e].re, sv[e].im);
             }
-            inner4(dd, &u[NW * jl + 4 * c], k, qq);
+            if constexpr (!EYIN) inner4(dd, &u[NW * jl + 4 * c], k, qq);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const cf r = qq[e] - sv[e];   // sum_k Df Yf - Sf
+                cf r;
+                if constexpr (EYIN) r = sv[e];          // the (masked) residual, from memory
+                else r = qq[e] - sv[e];                 // sum_k Df Yf - Sf
                 if constexpr (BT) {
                     fsum += cabs2(r);
                     if (k == 0) EY[NW * j + N1 * brev(4 * c + e, LBW)] = r;
@@ -565,19 +571,26 @@ static unsigned pgm_all_tiles(const PgmColsArgs<float> &a) {
     return (unsigned)(ceil_div(a.W / 2 + 1, 8) * 8 * a.CN);
 }
 
-template <int NW, int LP, int KC, bool BT, bool PERS>
+template <int NW, int LP, int KC, bool BT, bool PERS, bool EYIN = false>
 void launch_grad_inst(hipStream_t st, const PgmColsArgs<float> &a, unsigned grid) {
     static bool attr_set = false;
     if (!attr_set) {
-        set_lds(&pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS>, pgm_lds_bytes(NW, LP));
+        set_lds(&pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS, EYIN>, pgm_lds_bytes(NW, LP));
         attr_set = true;
     }
-    hipLaunchKernelGGL((pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS>), dim3(grid), dim3(NW * 64),
+    hipLaunchKernelGGL((pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS, EYIN>), dim3(grid), dim3(NW * 64),
                        pgm_lds_bytes(NW, LP), st, a);
 }
 template <int NW, int LP, int KC> void launch_grad(hipStream_t st, const PgmColsArgs<float> &a_in) {
     PgmColsArgs<float> a = a_in;
     const unsigned pg = pgm_persist_grid(a, NW, KC, 1);
+    if (a.ey_in) {
+        SA_REQUIRE(!a.ey, "a residual from memory does not combine with a held trial");
+        if constexpr (NW == 16 && KC == 64) {
+            if (pg) return launch_grad_inst<NW, LP, KC, false, true, true>(st, a, pg);
+        }
+        return launch_grad_inst<NW, LP, KC, false, false, true>(st, a, pgm_all_tiles(a));
+    }
     if constexpr (NW == 16 && KC == 64) {
         if (pg) {
             if (a.ey) launch_grad_inst<NW, LP, KC, true, true>(st, a, pg);

@@ -170,6 +170,10 @@ class ConvBPDN(pgm.PGMDFT):
             f |= _lib.FLAG_NOBNDRY
         return f
 
+    def _iter_flags(self):
+        """Flags of the fused iteration (the masked subclass adds the data mask)."""
+        return self._flags()
+
     # -- whole iteration in three launches when nothing is customised -----------------
     _hook_names = ('on_iteration_start', 'xstep', 'ystep', 'grad_f', 'prox_step', 'rsdl',
                    'compute_residuals', 'eval_objfn', 'obfn_dfd', 'obfn_reg', 'obfn_f',
@@ -204,12 +208,12 @@ class ConvBPDN(pgm.PGMDFT):
         bt = self.opt['Backtrack']
         lm = float(self.lmbda) * self._wl1_scalar
         if bt is None:
-            out = self.dev.pgm_iter(self.L, lm, beta, self._flags(), self.D.shape[0],
+            out = self.dev.pgm_iter(self.L, lm, beta, self._iter_flags(), self.D.shape[0],
                                     self.D.shape[1], stats)
         else:
             it = 0
             while True:
-                out = self.dev.pgm_iter(self.L, lm, beta, self._flags(), self.D.shape[0],
+                out = self.dev.pgm_iter(self.L, lm, beta, self._iter_flags(), self.D.shape[0],
                                         self.D.shape[1], True, hold=True)
                 f = out[_lib.PGM_F]
                 Q = out[_lib.PGM_FY] + out[_lib.PGM_LIN] + (self.L / 2.) * out[_lib.PGM_DXY2]
@@ -316,6 +320,31 @@ class ConvBPDNMask(ConvBPDN):
         if hasattr(self, 'W'):
             self._upload_mask()
 
+    # -- the whole iteration on the fused kernels (round 4) -----------------------------------
+    # Without backtracking, step-size policy or monotone restart the masked iteration is the
+    # unmasked one with the residual taken through the spatial domain between the inner product
+    # and the gradient (sporco_amd_csc_pgm_iter with SPORCO_AMD_FLAG_DMASK): 11 passes over an
+    # X-sized spectrum instead of the staged composition's generic FFT chain.
+    def _fused_ok(self):
+        if self.opt['Backtrack'] is not None or self.stepsizepolicy is not None \
+                or self.opt['Monotone'] or not self.dev.uses_fused_pgm() \
+                or self.cri.M > 64 or self.cri.Cd > 1:
+            return False
+        for name in self._hook_names:
+            if name in self.__dict__ or getattr(type(self), name) is not getattr(ConvBPDNMask, name):
+                return False
+        return True
+
+    def _iter_flags(self):
+        return self._flags() | _lib.FLAG_DMASK
+
+    def fused_iteration(self):
+        ok = super(ConvBPDNMask, self).fused_iteration()
+        if ok:
+            # (PGM_FY is not evaluated by the masked iteration: only a backtracking rule reads it)
+            self._fcache.pop(_lib.VAR_YFPRV, None)
+        return ok
+
     def grad_f(self, V=None):
         """conj(Df) rfftn(W^2 irfftn(sum_m Df V - Sf)) (pgm/cbpdn.py:454-477)."""
         if V is None:
@@ -326,9 +355,15 @@ class ConvBPDNMask(ConvBPDN):
 
     def obfn_dfd(self):
         """(1/2) ||W irfftn(sum_m Df Xf - Sf)||^2 (pgm/cbpdn.py:481-489)."""
+        if getattr(self, '_fused_sums', None) is not None:
+            return self._fused_sums[_lib.PGM_DFID] / 2.0
         return self.dev.masked_grad(_lib.VAR_XF, False, False)[_lib.PGM_DFID] / 2.0
 
     def obfn_f(self, Xf=None):
         """(1/2) ||rfftn(W irfftn(sum_m Df Xf - Sf))||^2, DFT scaling kept
         (pgm/cbpdn.py:493-506)."""
-        return self.dev.masked_grad(_lib.VAR_XF if Xf is None else Xf, False, False)[_lib.PGM_F]
+        if Xf is None:
+            Xf = _lib.VAR_XF
+        if Xf in self._fcache:
+            return self._fcache[Xf]
+        return self.dev.masked_grad(Xf, False, False)[_lib.PGM_F]

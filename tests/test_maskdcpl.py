@@ -180,3 +180,59 @@ def test_warm_start_and_pickling(backend):
     d.opt['MaxMainIter'] = 3
     d.solve()
     assert rel_l2(c.Y, d.Y) < 1e-12 and rel_l2(c.U, d.U) < 1e-12
+
+
+# ---- the iteration on the register-resident kernels (round 4) ---------------------------------------
+FUSED_OPTS = {
+    'default': {},
+    'options': {'NonNegCoef': True, 'NoBndryCross': True, 'AuxVarObj': True, 'RelaxParam': 1.5,
+                'AutoRho': {'Enabled': True, 'Period': 2}},
+    'fastsolve': {'FastSolve': True, 'AutoRho': {'Enabled': False}},
+}
+
+
+@pytest.mark.parametrize('H,K,N', [(128, 8, 2), pytest.param(512, 64, 2, marks=pytest.mark.gpu)])
+@pytest.mark.parametrize('case', sorted(FUSED_OPTS))
+def test_fused_iteration_vs_generic_chain_and_oracle(backend, case, H, K, N, monkeypatch):
+    """ConvBPDNMaskDcpl on the fast-path shapes (float32, 128 / 256 / 512, even K <= 64) runs its
+    X-step, block-1 epilogue and dual residual on the register-resident kernels of ConvBPDN
+    (rows_fwd, fused_cols with the block-0 spectrum in the signal's place, rows_inv_post; DESIGN
+    4.9): same iterates and statistics as the generic chain of the same library (which the
+    reference fixtures above pin), and the float64 oracle within the float32 bar."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(11)
+    D = rng.randn(8, 8, K).astype(np.float32)
+    S = rng.randn(H, H, N).astype(np.float32)
+    W = (rng.rand(H, H, N) > 0.3).astype(np.float32)
+    cls = cbpdn.ConvBPDNMaskDcpl
+    optd = dict(FUSED_OPTS[case], MaxMainIter=5)
+
+    def run(generic):
+        if generic:
+            monkeypatch.setenv('SPORCO_AMD_MD_GENERIC', '1')
+        else:
+            monkeypatch.delenv('SPORCO_AMD_MD_GENERIC', raising=False)
+        b = cls(D, S, 0.1, W, cls.Options(optd))
+        b._dev.profile(True)
+        Y1 = b.solve()
+        prof = {k for k, v in b._dev.profile_read().items() if v[1]}
+        return b, Y1, prof
+
+    bf, Yf, pf = run(False)
+    bg, Yg, pg = run(True)
+    assert {'rows_fwd', 'fused_cols_sm', 'rows_inv_post'} <= pf and 'sm_solve' not in pf
+    assert 'sm_solve' in pg and 'fused_cols_sm' not in pg
+    assert rel_l2(Yf, Yg) < 2e-5 and rel_l2(bf.X, bg.X) < 2e-5 and rel_l2(bf.U, bg.U) < 2e-5
+    assert rel_l2(bf.var_y0(), bg.var_y0()) < 5e-4
+    assert rel_l2(bf.reconstruct(), bg.reconstruct()) < 2e-5
+    if case != 'fastsolve':
+        for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho'):
+            assert rel_l2(getattr(bf.getitstat(), f), getattr(bg.getitstat(), f)) < 2e-5, f
+    if case == 'default' and H <= 128:
+        r = orc.admm_cbpdn_maskdcpl(D.reshape(8, 8, 1, 1, K).astype(np.float64),
+                                    S.reshape(H, H, 1, N, 1).astype(np.float64), 0.1,
+                                    W.reshape(H, H, 1, N, 1).astype(np.float64), maxiter=5)
+        assert rel_l2(Yf, r['Y1']) < 1e-4
+        for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+            assert rel_l2(getattr(bf.getitstat(), f), r[f]) < 1e-4, f

@@ -126,3 +126,39 @@ def test_convcnstrmodmask_reference_test_shapes(backend, name):
     its = c.getitstat()
     for f in ('DFid', 'Rsdl', 'L'):
         assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f]) < 1e-9, f
+
+
+# ---- the masked FISTA iteration on the fused kernels (round 4) ---------------------------------------
+@pytest.mark.parametrize('H,K,N', [(128, 8, 2), pytest.param(512, 64, 2, marks=pytest.mark.gpu)])
+@pytest.mark.parametrize('opts', [{}, {'NonNegCoef': True, 'NoBndryCross': True}])
+def test_fused_masked_iteration_vs_staged(backend, opts, H, K, N):
+    """pgm.cbpdn.ConvBPDNMask without backtracking runs sporco_amd_csc_pgm_iter with
+    SPORCO_AMD_FLAG_DMASK: the residual per frequency goes through the spatial domain for the mask
+    between the inner product and the gradient kernel (sporco/pgm/cbpdn.py:454-477) and the
+    objective is evaluated the same way at the new iterate (:481-489).  Same iterates and
+    statistics as the staged composition of the same library, which the reference fixtures above
+    pin."""
+    from sporco_amd.pgm import cbpdn as pc
+    rng = np.random.RandomState(11)
+    D = rng.randn(8, 8, K).astype(np.float32)
+    S = rng.randn(H, H, N).astype(np.float32)
+    W = (rng.rand(H, H, N) > 0.3).astype(np.float32)
+
+    class Staged(pc.ConvBPDNMask):
+        def _fused_ok(self):
+            return False
+
+    optd = dict(opts, MaxMainIter=6, L=500.0)
+    res = []
+    for cls in (pc.ConvBPDNMask, Staged):
+        b = cls(D, S, 0.1, W, pc.ConvBPDNMask.Options(optd))
+        b.dev.profile(True)
+        X = b.solve()
+        res.append((b, X, {k for k, v in b.dev.profile_read().items() if v[1]}))
+    (bf, Xf, pf), (bg, Xg, pg) = res
+    assert {'pgm_grad_ifft', 'pgm_rows_prox', 'pgm_fft_momentum'} <= pf
+    assert 'pgm_grad_ifft' not in pg
+    assert rel_l2(Xf, Xg) < 2e-5 and rel_l2(bf.Xf, bg.Xf) < 2e-5
+    assert rel_l2(bf.reconstruct(), bg.reconstruct()) < 2e-5
+    for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L'):
+        assert rel_l2(getattr(bf.getitstat(), f), getattr(bg.getitstat(), f)) < 2e-5, f
