@@ -129,6 +129,7 @@ template <typename T> struct Csc : CscBase {
     // X-step on it with the parameters of the iteration (`last_p`).
     T *y_alt = nullptr, *u_alt = nullptr;
     bool x_stale = false, x_invalid = false;
+    bool md_x_pending = false;   // X of a fused mask-decoupled iteration: rows_inverse of the Xf buffer
     // after a three-launch iteration the previous iterate sits in y_alt and AX was never
     // formed: a host read of VAR_YPREV / VAR_AX derives them (download)
     bool prev_in_alt = false;
