@@ -130,6 +130,11 @@ template <typename T> int64_t launch_fused_cols_mc(hipStream_t st, const FusedMc
 template <typename T>
 void launch_mc_binv(hipStream_t st, const cx<T> *dft, T *bt, int64_t nrows, int Cd, int K, T rho);
 
+// Dual residual of the mask-decoupled X-step: partials[tile] = pw(wf) sum_{f, k} |conj(dft[wf][f][k])
+// sft[tile][f] + FFT_H(t)[tile][f][k]|^2 with t the tile-major ROW spectra of u1 and sft the
+// tile-major 2-D spectrum of u0 (fields t, dft, sft, twA, H, W, CN, K, Ks, partials); t is only read.
+template <typename T> int64_t launch_cols_dualres(hipStream_t st, const FusedColsArgs<T> &a);
+
 // Host tables twA, twB (H entries each) for fused_cols_supported shapes.
 template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB);
 // True when the register-resident column kernel handles this shape.

@@ -45,6 +45,86 @@ __global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs
 #include "csc_fused_body.inc"
 }
 
+// Dual residual of the mask-decoupled X-step (cbpdn.py:1814-1818): the forward half of the column
+// pass on the row spectra of u1 -- load the tile, FFT-N1, twiddle, exchange, FFT-NW -- and then, per
+// frequency f, sum_k |conj(Df[f][k]) u0f[f] + u1f[f][k]|^2 instead of a solve; nothing is written
+// back (one read pass over the spectrum).  partials[tile] carries the Parseval weight of wf.
+template <int NW, int LP, int KC>
+__global__ void __launch_bounds__(NW * 64) cols_dualres_kernel(const FusedColsArgs<float> a) {
+    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr int LB1 = ilog2(N1), LBW = ilog2(NW);
+    constexpr int FP = LP * NW, Q = J / LP;
+    static_assert(J % LP == 0, "lines per group must divide the lines per thread");
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int K = KC ? KC : (a.Ks ? a.Ks : a.K);
+    const bool kv = KC == 64 ? true : k < a.K;
+    f2 *LA = dyn_lds<f2>();
+    double *scratch = reinterpret_cast<double *>(LA + FP * NW * 64);
+    const cf zero = mk<float>(0.f, 0.f);
+    const int ko = (w * K + k) * (int)sizeof(cf);
+    const int Wf = a.W / 2 + 1;
+    const int64_t ntiles = (int64_t)Wf * a.CN;
+    int token = 0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int wf = (int)(tile / a.CN);
+        const BufRsrc Tb = make_rsrc(a.t + tile * H * K, (uint32_t)(H * K * sizeof(cf)));
+        const BufRsrc Db = make_rsrc(a.dft + (int64_t)wf * H * K, (uint32_t)(H * K * sizeof(cf)));
+        const cf *S = a.sft + tile * H + w;
+        const cf *twA = a.twA + w * N1;
+        cf v[N1];
+#pragma unroll
+        for (int h1 = 0; h1 < N1; ++h1)
+            v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
+        dif<N1, false>(v, 0);
+        reg_fence<N1>(v, 0, token);
+#pragma unroll
+        for (int i = 1; i < N1; ++i) v[i] = cmul(v[i], twA[i]);
+        reg_fence<N1>(v, 0, token);
+        float acc = 0.f;
+        static_for<Q>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int fl = 0; fl < FP; ++fl) {
+                const cf x = v[brev(q * FP + fl, LB1)];
+                f2 t;
+                t.x = x.re;
+                t.y = x.im;
+                LA[(fl * NW + w) * 64 + k] = t;
+            }
+            __syncthreads();
+            cf u[FP];
+#pragma unroll
+            for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+                for (int h2 = 0; h2 < NW; ++h2) {
+                    const f2 t = LA[((w + NW * jl) * NW + h2) * 64 + k];
+                    u[NW * jl + h2] = mk<float>(t.x, t.y);
+                }
+                dif<NW, false>(u, NW * jl);     // u[NW jl + i] = X[f1 + N1 brev(i)], f1 = w + NW j
+            }
+#pragma unroll
+            for (int jl = 0; jl < LP; ++jl) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) {
+                    const int fo = NW * (q * LP + jl) + N1 * brev(i, LBW);   // f - w
+                    const cf d = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
+                    cf s0;
+                    sa_uload2(reinterpret_cast<const float *>(S + fo), s0.re, s0.im);
+                    const cf val = cmulc(d, s0) + u[NW * jl + i];
+                    acc += kv ? cabs2(val) : 0.f;
+                }
+            }
+            __syncthreads();     // the exchange buffer is reused by the next group / tile
+        });
+        const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+        double ac[1] = {(double)acc * pw};
+        block_sum_store<1>(ac, scratch, a.partials + tile);
+        __syncthreads();
+    }
+}
+
 // g1t[wf][h] = 1 + sum_k |Df|^2 / (mu wg_k (ghh[h] + ghw[wf]) + rho): the Sherman-Morrison
 // denominator of linalg.solvedbd_sm_c (linalg.py:346-366), refreshed when rho changes.
 // One wave per (wf, h) row of the tile-major Df, lane = filter.
@@ -814,6 +894,37 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
         launch_fused_k<32, 16, 1>(st, a, ntiles);
     SA_HIP(hipGetLastError());
     return ntiles;
+}
+template <int NW, int LP, int KC> static void launch_dualres_inst(hipStream_t st, const FusedColsArgs<float> &a) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_dualres_kernel<NW, LP, KC>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
+        attr_set = true;
+    }
+    const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    SA_HIP(hipGetDevice(&dev));
+    SA_HIP(hipGetDeviceProperties(&pr, dev));
+    const int64_t cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    // (one 16-wave workgroup fills a CU; two 8-wave, four 4-wave ones share it)
+    const int64_t grid = std::min<int64_t>(ntiles, cus * (16 / NW));
+    hipLaunchKernelGGL((cols_dualres_kernel<NW, LP, KC>), dim3((unsigned)grid), dim3(NW * 64),
+                       fused_lds_bytes(NW, LP), st, a);
+}
+template <> int64_t launch_cols_dualres<float>(hipStream_t st, const FusedColsArgs<float> &a) {
+    SA_REQUIRE(fused_cols_supported<float>(a.H, a.K), "shape not handled by the fused column kernel");
+    const FusedSplit sp = fused_split(a.H, a.K);
+    const bool k64 = a.K == 64 && (a.Ks == 0 || a.Ks == 64);
+    if (sp.NW == 4) k64 ? launch_dualres_inst<4, 4, 64>(st, a) : launch_dualres_inst<4, 4, 0>(st, a);
+    else if (sp.NW == 8) k64 ? launch_dualres_inst<8, 2, 64>(st, a) : launch_dualres_inst<8, 2, 0>(st, a);
+    else k64 ? launch_dualres_inst<16, 1, 64>(st, a) : launch_dualres_inst<16, 1, 0>(st, a);
+    SA_HIP(hipGetLastError());
+    return (int64_t)(a.W / 2 + 1) * a.CN;
+}
+template <> int64_t launch_cols_dualres<double>(hipStream_t, const FusedColsArgs<double> &) {
+    throw Error(-1, "the fused column kernel is float32 only");
 }
 __global__ void __launch_bounds__(256) gram_rows_kernel(const cf *__restrict__ z,
                                                         float *__restrict__ out, int64_t nrows,
