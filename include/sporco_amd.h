@@ -265,8 +265,8 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
                                                 sporco/pgm/cbpdn.py:387-506): the residual goes
                                                 through the spatial domain for W^2 between the
                                                 inner product and the gradient; out[PGM_DFID] =
-                                                sum (W R)^2 and out[PGM_F] = (1/2) sum_half
-                                                |rfftn(W R)|^2 at the new Xf (want_stats);
+                                                sum (W R)^2 at the new Xf (want_stats; PGM_F and
+                                                PGM_FY are not evaluated: masked_grad has them);
                                                 K <= 64, no held trial */
 
 typedef struct {

@@ -341,8 +341,10 @@ class ConvBPDNMask(ConvBPDN):
     def fused_iteration(self):
         ok = super(ConvBPDNMask, self).fused_iteration()
         if ok:
-            # (PGM_FY is not evaluated by the masked iteration: only a backtracking rule reads it)
+            # (f in the DFT scaling is not evaluated by the masked iteration, at Y or at X: only a
+            # backtracking rule reads it, and obfn_f computes it on demand)
             self._fcache.pop(_lib.VAR_YFPRV, None)
+            self._fcache.pop(_lib.VAR_XF, None)
         return ok
 
     def grad_f(self, V=None):
