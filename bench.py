@@ -683,8 +683,21 @@ def main():
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
-        from sporco_amd.dist import TorchReducer
-        reducer = TorchReducer()
+        # the all-reduce of the 16 per-iteration sums: RCCL inside the library (NativeReducer:
+        # enqueued by sporco_amd_csc_admm_run on the solver's stream, no Python per iteration;
+        # torch.distributed only hands the communicator id round), or through torch.distributed
+        # (TorchReducer: gloo runs, SPORCO_AMD_BENCH_REDUCER=torch, or when RCCL cannot be opened)
+        from sporco_amd.dist import NativeReducer, TorchReducer
+        which = os.environ.get('SPORCO_AMD_BENCH_REDUCER', 'native' if backend == 'nccl' else 'torch')
+        if which == 'native':
+            try:
+                reducer = NativeReducer.from_torch(device=local_rank)
+            except Exception as e:      # noqa: BLE001 -- any failure here must not cost the run
+                print('bench.py: native RCCL reducer unavailable (%s); using torch.distributed' % e,
+                      file=sys.stderr)
+                reducer = None
+        if reducer is None:
+            reducer = TorchReducer()
         stream = reducer.stream_handle()
 
     H = W = args.size
@@ -750,7 +763,8 @@ def main():
                     'allreduce_ms_mean_worst_rank': float(h.cpu()[0]),
                     'allreduce_ms_max': float(h.cpu()[1]),
                     'allreduce_calls_timed': hc[2] if hc else 0,
-                    'backend': dist.get_backend()})
+                    'backend': dist.get_backend(),
+                    'reducer': type(reducer).__name__})
         return b, elapsed
 
     b, elapsed = timed_run(args.fastsolve)

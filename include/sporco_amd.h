@@ -671,6 +671,36 @@ int sporco_amd_csc_reconstruct_dev(sporco_amd_csc_t h, int var, void *dst_dev);
  * out = {h2d_bytes, h2d_calls, d2h_bytes, d2h_calls}. */
 int sporco_amd_transfer_stats(int64_t out[4], int reset);
 
+/* ---- image shards over the GPUs of a node: RCCL inside the library ---------------------------
+ * (SURVEY.md 8(b) `allreduce_scalars`, 8(e); the reference's own multi-process split is
+ * sporco/dictlrn/prlcnscdl.py:241,508 -- multiprocessing over shared memory, no counterpart of a
+ * communicator.)  One communicator per process (one process per GPU): rank 0 obtains an id,
+ * the host program hands its 128 bytes to the other ranks by whatever means it has (MPI,
+ * torch.distributed's store, a file), every rank creates its communicator from it.  librccl is
+ * opened at run time (dlopen: SPORCO_AMD_RCCL_LIB, then librccl.so.1 / librccl.so): the library
+ * has no link-time dependency on it, and SPORCO_AMD_EUNSUPPORTED comes back when it is absent. */
+typedef struct sporco_amd_comm *sporco_amd_comm_t;
+#define SPORCO_AMD_COMM_ID_BYTES 128
+#define SPORCO_AMD_COMM_SUM 0
+#define SPORCO_AMD_COMM_MAX 2
+int sporco_amd_comm_unique_id(void *id128);                      /* ncclGetUniqueId          */
+int sporco_amd_comm_create(const void *id128, int32_t rank, int32_t world, int32_t device,
+                           sporco_amd_comm_t *out);              /* ncclCommInitRank         */
+int sporco_amd_comm_destroy(sporco_amd_comm_t c);
+int sporco_amd_comm_info(sporco_amd_comm_t c, int32_t *rank, int32_t *world);
+/* In-place all-reduce of `count` reals (SPORCO_AMD_F32 / _F64) of DEVICE memory, enqueued on
+ * `stream` (a hipStream_t; NULL: the null stream) -- no host synchronisation. */
+int sporco_amd_comm_allreduce(sporco_amd_comm_t c, void *buf_dev, int64_t count, int dtype, int op,
+                              void *stream);
+/* The same for a handful of HOST doubles (staged through a device buffer of the communicator;
+ * returns when the result is in `vals`). */
+int sporco_amd_comm_allreduce_host(sporco_amd_comm_t c, double *vals, int32_t n, int op);
+/* Attach a communicator to a solver handle (NULL detaches): sporco_amd_csc_admm_run then sums the
+ * 16 per-iteration doubles over the ranks itself, on the handle's stream, between the local sums
+ * and the control update -- no callback into the host program per iteration (a `reduce` hook
+ * given to admm_run takes precedence).  The communicator must outlive the handle's use of it. */
+int sporco_amd_csc_set_comm(sporco_amd_csc_t h, sporco_amd_comm_t c);
+
 /* prox_l1 (sporco/prox/_lp.py:144-183), real v of n elements, scalar alpha. */
 int sporco_amd_prox_l1(int dtype, int64_t n, const void *v, double alpha, void *out);
 /* The same with an array-valued threshold (sporco/prox/_lp.py:144-183 accepts one): v viewed as

@@ -80,6 +80,9 @@ EXPORTS = (
     'sporco_amd_dev_download', 'sporco_amd_dev_axpby', 'sporco_amd_tikhonov_filter_dev',
     'sporco_amd_fftconv_dev', 'sporco_amd_csc_set_signal_dev', 'sporco_amd_csc_reconstruct_dev',
     'sporco_amd_transfer_stats',
+    'sporco_amd_comm_unique_id', 'sporco_amd_comm_create', 'sporco_amd_comm_destroy',
+    'sporco_amd_comm_info', 'sporco_amd_comm_allreduce', 'sporco_amd_comm_allreduce_host',
+    'sporco_amd_csc_set_comm',
     'sporco_amd_rfftn2', 'sporco_amd_irfftn2', 'sporco_amd_solvedbi_sm',
     'sporco_amd_inner', 'sporco_amd_prox_l1', 'sporco_amd_prox_l1w', 'sporco_amd_prox_sl1l2',
     'sporco_amd_rfl2norm2',
@@ -300,6 +303,13 @@ def load(path=None):
         'sporco_amd_csc_set_signal_dev': [vp, vp],
         'sporco_amd_csc_reconstruct_dev': [vp, ctypes.c_int, vp],
         'sporco_amd_transfer_stats': [ctypes.POINTER(i64), ctypes.c_int],
+        'sporco_amd_comm_unique_id': [vp],
+        'sporco_amd_comm_create': [vp, i32, i32, i32, ctypes.POINTER(vp)],
+        'sporco_amd_comm_destroy': [vp],
+        'sporco_amd_comm_info': [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)],
+        'sporco_amd_comm_allreduce': [vp, vp, i64, ctypes.c_int, ctypes.c_int, vp],
+        'sporco_amd_comm_allreduce_host': [vp, dptr, i32, ctypes.c_int],
+        'sporco_amd_csc_set_comm': [vp, vp],
         'sporco_amd_prox_l1': [ctypes.c_int, i64, vp, dbl, vp],
         'sporco_amd_prox_l1w': [ctypes.c_int, ctypes.POINTER(i64), vp, ctypes.POINTER(i64), vp, vp],
         'sporco_amd_prox_sl1l2': [ctypes.c_int, i64, i32, i64, vp, dbl, dbl, vp],
@@ -450,6 +460,11 @@ class Solver(object):
 
     def set_hint(self, what, value):
         check(self._lib.sporco_amd_csc_set_hint(self._h, int(what), int(value)))
+
+    def set_comm(self, comm_handle):
+        """Attach a native RCCL communicator (sporco_amd_csc_set_comm; None detaches): the
+        device-driven solve then all-reduces its per-iteration sums itself."""
+        check(self._lib.sporco_amd_csc_set_comm(self._h, ctypes.c_void_p(comm_handle or 0)))
 
     def query(self, what):
         out = ctypes.c_int(0)

@@ -409,10 +409,12 @@ class GenericConvBPDN(admm.ADMMEqual):
         self.timer.start(all_timers)
         reduce = None
         if self._reducer is not None:
+            # (a callable: the per-iteration hook of TorchReducer; False: NativeReducer attached its
+            # communicator and the library reduces by itself; None: no device-side reduction)
             reduce = self._reducer.device_sum_hook(self._dev)
         res = None
         if self._reducer is None or reduce is not None:
-            res = self._dev.admm_run(self._params(), ctrl, reduce)
+            res = self._dev.admm_run(self._params(), ctrl, reduce or None)
         if res is None:
             self.timer.stop(all_timers)
             return super(GenericConvBPDN, self).solve()

@@ -206,7 +206,10 @@ struct CscBase {
     virtual void read_out(const double *out_dev, double *out_host) = 0;
     double *out_dev_default = nullptr;
     Profiler prof;
+    void *comm_user = nullptr;   // sporco_amd_csc_set_comm: admm_run sums its 16 doubles over the ranks
 };
+// (csc_comm.hip) all-reduce of the 16 per-iteration sums on `st`
+void comm_reduce_sums(void *user, double *sums_dev, hipStream_t st);
 
 static bool var_is_complex(int var) {
     switch (var) {

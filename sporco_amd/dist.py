@@ -229,6 +229,130 @@ class TorchReducer(object):
         return float(t.cpu()[0])
 
 
+class NativeReducer(object):
+    """Image shards over RCCL INSIDE the library (``sporco_amd_comm_*``, csc_comm.hip): the
+    device-driven solve enqueues the all-reduce of its 16 per-iteration doubles on the solver's
+    stream itself -- no Python callback per iteration, and ``torch`` is not needed (the
+    reference-side counterpart is the per-image split of sporco/dictlrn/prlcnscdl.py:241,508).
+
+    Every rank builds one from the same 128-byte id: rank 0 calls :meth:`unique_id` and hands the
+    bytes to the others by whatever the host program has (an MPI broadcast, a file, torch's
+    store -- :meth:`from_torch` does the latter when torch.distributed is initialised anyway; with
+    a single rank nothing has to be exchanged).  Same interface as :class:`TorchReducer`."""
+
+    COMM_SUM, COMM_MAX = 0, 2
+
+    def __init__(self, rank, world_size, unique_id, device=0):
+        from . import _lib
+        self._lib = _lib.lib()
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of NativeReducer.unique_id()")
+        idbuf = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+        h = ctypes.c_void_p()
+        _lib.check(self._lib.sporco_amd_comm_create(idbuf, int(rank), int(world_size), int(device),
+                                                    ctypes.byref(h)))
+        self._h = h
+        self.rank, self.world_size, self.device = int(rank), int(world_size), int(device)
+        self.on_gpu = True
+
+    @staticmethod
+    def unique_id():
+        """128 bytes identifying a new communicator (ncclGetUniqueId); call on one rank."""
+        from . import _lib
+        buf = (ctypes.c_char * 128)()
+        _lib.check(_lib.lib().sporco_amd_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, group=None, device=None):
+        """Bootstrap through an initialised torch.distributed process group: rank 0's id is
+        broadcast as an object; the collectives themselves do not go through torch."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        return cls(rank, world, box[0], device=device)
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.sporco_amd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream_handle(self):
+        return None        # (the solver keeps its own stream; the collective is enqueued on it)
+
+    # -- per-iteration scalars ----------------------------------------------------------------
+    def device_sum_hook(self, solver):
+        """The device-driven solve needs no hook: the library all-reduces on the solver's
+        stream once the communicator is attached.  Returns the marker the caller passes on."""
+        solver.set_comm(self._h.value)
+        return False       # (not None: "sharded, and the library does the reduction itself")
+
+    def admm_iter(self, solver, params):
+        return self.sum(solver.admm_iter(params))
+
+    def _host(self, values, op):
+        from . import _lib
+        vals = list(values)
+        out = []
+        for i in range(0, len(vals), 64):
+            chunk = vals[i:i + 64]
+            buf = (ctypes.c_double * len(chunk))(*[float(v) for v in chunk])
+            _lib.check(self._lib.sporco_amd_comm_allreduce_host(self._h, buf, len(chunk), op))
+            out.extend(buf)
+        return out
+
+    def sum(self, values):
+        return self._host(values, self.COMM_SUM)
+
+    def max(self, value):
+        return self._host([value], self.COMM_MAX)[0]
+
+    def sum_slots(self, values, slots):
+        red = self.sum([values[i] for i in slots])
+        out = list(values)
+        for i, v in zip(slots, red):
+            out[i] = v
+        return out
+
+    # -- arrays in device memory --------------------------------------------------------------
+    def all_reduce_ptr(self, solver, ptr, count, f32, prescale=1.0):
+        from . import _lib
+        if prescale != 1.0:
+            _lib.check(self._lib.sporco_amd_dev_axpby(_lib.F32 if f32 else _lib.F64, int(count),
+                                                      float(prescale), ctypes.c_void_p(ptr), 0.0,
+                                                      ctypes.c_void_p(ptr), ctypes.c_void_p(ptr)))
+        solver.sync()
+        _lib.check(self._lib.sporco_amd_comm_allreduce(self._h, ctypes.c_void_p(ptr), int(count),
+                                                       _lib.F32 if f32 else _lib.F64, self.COMM_SUM,
+                                                       ctypes.c_void_p(solver.stream_handle())))
+        solver.sync()
+
+    def all_reduce_array(self, solver, var):
+        import numpy as np
+        ptr = solver.device_ptr(var)
+        shape, dt = solver.var_shape_dtype(var)
+        from . import _lib
+        kdev = solver.query(_lib.QUERY_DEVICE_FILTERS)
+        n = int(np.prod(shape[:-1])) * (kdev if shape[-1] == solver.dims[4] else shape[-1])
+        if np.dtype(dt).kind == 'c':
+            n *= 2
+        f32 = np.dtype(dt) in (np.dtype(np.float32), np.dtype(np.complex64))
+        self.all_reduce_ptr(solver, ptr, n, f32)
+
+    def hook_cost_ms(self):
+        return None
+
+
 class ReducingSolver(object):
     """Stand-in for a :class:`sporco_amd._lib.Solver` holding one rank's images: every call
     that returns sums over the coefficient arrays (objective terms, residuals, the inner
