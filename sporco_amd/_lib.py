@@ -513,12 +513,19 @@ class Solver(object):
         self._set_weight(self._lib.sporco_amd_csc_set_l21_weight, w)
 
     def set_filter_sizes(self, sizes):
-        """Per-filter supports [(rows, cols)] * K of a multi-scale dictionary, or None."""
+        """Per-filter supports [(rows, cols)] * K of a multi-scale dictionary, or None.
+        (The call synchronises the stream and re-allocates two small device arrays: unchanged
+        sizes -- an online learner sets them every step -- return at once.)"""
+        key = None if sizes is None else tuple((int(s[0]), int(s[1])) for s in sizes)
+        if getattr(self, '_filter_sizes_set', False) and getattr(self, '_filter_sizes', None) == key:
+            return
+        self._filter_sizes, self._filter_sizes_set = key, True
         if sizes is None:
             check(self._lib.sporco_amd_csc_set_filter_sizes(self._h, None, None))
             return
         H, W, C, N, K = self.dims
         if len(sizes) != K:
+            self._filter_sizes_set = False
             raise ValueError("one (rows, cols) pair per filter")
         fh = (ctypes.c_int32 * K)(*[int(s[0]) for s in sizes])
         fw = (ctypes.c_int32 * K)(*[int(s[1]) for s in sizes])

@@ -136,4 +136,19 @@ __device__ __forceinline__ void block_sum_store(const double (&acc)[NV], double 
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the CURRENT device (the C ABI selects the handle's device before every call),
+// cached per device id: the persistent launches size their grids by it, and a process may drive
+// devices of different sizes or partition modes.
+inline int current_device_cus() {
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cache[dev]) {
+        hipDeviceProp_t pr;
+        SA_HIP(hipGetDeviceProperties(&pr, dev));
+        cache[dev] = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    }
+    return cache[dev];
+}
+
 }  // namespace sporco_amd

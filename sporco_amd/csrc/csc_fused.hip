@@ -798,17 +798,11 @@ template <> bool fused_cols_supported<double>(int, int) { return false; }
 // workgroups: one per CU; 8-wave ones: two), a multiple of 8 so that the XCD of a workgroup
 // is blockIdx % 8 for every slot it walks.  SPORCO_AMD_COLS_PERSIST=0: one workgroup per tile.
 static int64_t persistent_grid(int NW) {
-    static int cus = 0;
-    static bool off = false;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        SA_HIP(hipGetDevice(&dev));
-        SA_HIP(hipGetDeviceProperties(&pr, dev));
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    static const bool off = [] {
         const char *e = std::getenv("SPORCO_AMD_COLS_PERSIST");
-        off = e && e[0] == '0';
-    }
+        return e && e[0] == '0';
+    }();
+    const int cus = current_device_cus();
     if (off) return INT64_MAX;
     if (NW != 16) return INT64_MAX;      // (the 8-wave kernel takes one tile per workgroup)
     return std::max<int64_t>(8, cus / 8 * 8);
@@ -903,11 +897,7 @@ template <int NW, int LP, int KC> static void launch_dualres_inst(hipStream_t st
         attr_set = true;
     }
     const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
-    int dev = 0;
-    hipDeviceProp_t pr;
-    SA_HIP(hipGetDevice(&dev));
-    SA_HIP(hipGetDeviceProperties(&pr, dev));
-    const int64_t cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    const int64_t cus = current_device_cus();
     // (one 16-wave workgroup fills a CU; two 8-wave, four 4-wave ones share it)
     const int64_t grid = std::min<int64_t>(ntiles, cus * (16 / NW));
     hipLaunchKernelGGL((cols_dualres_kernel<NW, LP, KC>), dim3((unsigned)grid), dim3(NW * 64),
@@ -1073,18 +1063,13 @@ static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool sec
 template <int NW, int LP, int KS, bool GRAD>
 static void launch_slab_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
     static bool attr_set = false;
-    static int cus = 0;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, GRAD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)fused_lds_bytes(NW, LP)));
-        int dev = 0;
-        hipDeviceProp_t pr;
-        SA_HIP(hipGetDevice(&dev));
-        SA_HIP(hipGetDeviceProperties(&pr, dev));
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
         attr_set = true;
     }
+    const int cus = current_device_cus();
     const int NH = (int)ceil_div(a.c.K, 64);
     int groups = (cus / NH) & ~7;
 #ifdef SPORCO_AMD_HOSTSIM
@@ -1122,18 +1107,13 @@ template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlab
 template <int NW, int LP, int KS>
 static void launch_pgm_grad_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
     static bool attr_set = false;
-    static int cus = 0;
     if (!attr_set) {
         SA_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, false, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
-        int dev = 0;
-        hipDeviceProp_t pr;
-        SA_HIP(hipGetDevice(&dev));
-        SA_HIP(hipGetDeviceProperties(&pr, dev));
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
         attr_set = true;
     }
+    const int cus = current_device_cus();
     const int NH = (int)ceil_div(a.c.K, 64);
     int groups = (cus / NH) & ~7;
 #ifdef SPORCO_AMD_HOSTSIM

@@ -549,13 +549,11 @@ template <typename F> void set_lds(F kernel, size_t bytes) {
 // vector ones; the statistics variant then spills 60 bytes), which outweighs what the loop buys.
 // Stagger as in csc_fused.hip (SPORCO_AMD_PGM_STAGGER_GROUPS / _SLEEPS).
 static unsigned pgm_persist_grid(PgmColsArgs<float> &a, int NW, int KC, int which) {
-    static int cus = 0, sg = 4, ss = 2, mask = 1;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        SA_HIP(hipGetDevice(&dev));
-        SA_HIP(hipGetDeviceProperties(&pr, dev));
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    static int sg = 4, ss = 2, mask = 1;
+    static bool env_read = false;
+    const int cus = current_device_cus();
+    if (!env_read) {
+        env_read = true;
         if (std::getenv("SPORCO_AMD_PGM_PERSIST")) mask = std::atoi(std::getenv("SPORCO_AMD_PGM_PERSIST"));
         if (std::getenv("SPORCO_AMD_PGM_STAGGER_GROUPS")) sg = std::max(1, std::atoi(std::getenv("SPORCO_AMD_PGM_STAGGER_GROUPS")));
         if (std::getenv("SPORCO_AMD_PGM_STAGGER_SLEEPS")) ss = std::atoi(std::getenv("SPORCO_AMD_PGM_STAGGER_SLEEPS"));

@@ -188,6 +188,9 @@ constexpr int kPersistBarWords = 160;
 template <typename T> bool admm_persist_supported(int H, int W, int K);
 // workgroups of the launch (a multiple of 8, at most one per CU)
 template <typename T> int admm_persist_grid(int H, int W, int K, int CN);
+// ... and whether the device can hold that grid at once (occupancy of the kernel x compute units):
+// the grid barrier inside relies on it
+template <typename T> bool admm_persist_resident(int H, int W, int K, int CN);
 template <typename T> void launch_admm_persist(hipStream_t st, const AdmmPersistArgs<T> &a, int grid);
 
 }  // namespace sporco_amd

@@ -1052,18 +1052,11 @@ template void rows_twiddles<double>(int, cx<double> *);
 // Workgroups of a persistent row-kernel launch: what the device holds at once (one 16-wave
 // workgroup per CU, two 8-wave ones).  SPORCO_AMD_ROWS_PERSIST=0: one workgroup per tile.
 static int64_t rows_persistent_grid(int NW) {
-    static int cus = 0;
-    static bool off = false;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        SA_HIP(hipGetDevice(&dev));
-        SA_HIP(hipGetDeviceProperties(&pr, dev));
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    static const bool off = [] {
         const char *e = std::getenv("SPORCO_AMD_ROWS_PERSIST");
-        off = e && e[0] == '0';
-    }
-    return off ? 0 : (int64_t)cus * (NW == 16 ? 1 : NW == 8 ? 2 : 4);
+        return e && e[0] == '0';
+    }();
+    return off ? 0 : (int64_t)current_device_cus() * (NW == 16 ? 1 : NW == 8 ? 2 : 4);
 }
 // want: 1 = persistent unless disabled; 0 = one workgroup per tile (SPORCO_AMD_ROWS_PERSIST=2
 // forces the loop form on every row kernel, for measurements)
@@ -1090,17 +1083,7 @@ template <> bool admm_persist_supported<float>(int H, int W, int K) {
 }
 template <> bool admm_persist_supported<double>(int, int, int) { return false; }
 
-static int persist_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        SA_HIP(hipGetDevice(&dev));
-        SA_HIP(hipGetDeviceProperties(&pr, dev));
-        cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    }
-    return cus;
-}
+static int persist_cus() { return current_device_cus(); }
 template <> int admm_persist_grid<float>(int H, int W, int K, int CN) {
     (void)W;
     // one workgroup per CU at most, a multiple of 8 (the column pass gives workgroup b the row
@@ -1118,8 +1101,7 @@ template <> int admm_persist_grid<float>(int H, int W, int K, int CN) {
 }
 template <> int admm_persist_grid<double>(int, int, int, int) { return 0; }
 
-template <int NW, int LP>
-static void launch_persist_inst(hipStream_t st, const AdmmPersistArgs<float> &a, int grid) {
+template <int NW, int LP> static size_t persist_prepare() {
     const size_t lds = std::max<size_t>(std::max(rows_lds_bytes(NW), fused_lds_bytes(NW, LP)),
                                         sizeof(double) * (7 * kFinalizeThreads + 16));
     static bool attr_set = false;
@@ -1128,12 +1110,44 @@ static void launch_persist_inst(hipStream_t st, const AdmmPersistArgs<float> &a,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    return lds;
+}
+template <int NW, int LP>
+static void launch_persist_inst(hipStream_t st, const AdmmPersistArgs<float> &a, int grid) {
+    const size_t lds = persist_prepare<NW, LP>();
 #ifdef SPORCO_AMD_HOSTSIM
     hostsim::set_coop(grid);
 #endif
     hipLaunchKernelGGL((admm_persist_kernel<NW, LP>), dim3((unsigned)grid), dim3(NW * 64), lds, st, a);
     SA_HIP(hipGetLastError());
 }
+// The grid barrier inside the one-launch solve needs every workgroup resident at once: what the
+// device can hold of this kernel (registers, LDS) times its CUs must cover the grid -- asked of
+// the runtime here, before the solve commits to the form, rather than found out by a barrier that
+// times out.  (Work of OTHER streams or processes on the device can still starve it: the form is
+// opt-in, for exclusive use of a device, and a timed-out barrier comes back as SPORCO_AMD_EHIP.)
+template <> bool admm_persist_resident<float>(int H, int W, int K, int CN) {
+#ifdef SPORCO_AMD_HOSTSIM
+    (void)H; (void)W; (void)K; (void)CN;
+    return true;
+#else
+    if (!admm_persist_supported<float>(H, W, K)) return false;
+    const int grid = admm_persist_grid<float>(H, W, K, CN);
+    int per_cu = 0;
+    if (W == 128) {
+        const size_t lds = persist_prepare<4, 4>();
+        SA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, reinterpret_cast<const void *>(&admm_persist_kernel<4, 4>), 4 * 64, lds));
+    } else {
+        const size_t lds = persist_prepare<8, 2>();
+        SA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, reinterpret_cast<const void *>(&admm_persist_kernel<8, 2>), 8 * 64, lds));
+    }
+    return (int64_t)per_cu * current_device_cus() >= grid;
+#endif
+}
+template <> bool admm_persist_resident<double>(int, int, int, int) { return false; }
+
 template <> void launch_admm_persist<float>(hipStream_t st, const AdmmPersistArgs<float> &a, int grid) {
     const RowsFwdArgs<float> &f = a.iter[0].fwd;
     SA_REQUIRE(admm_persist_supported<float>(f.H, f.W, f.K), "shape not handled by the one-launch solve");

@@ -76,9 +76,11 @@ class TorchReducer(object):
         kernel the library enqueues next runs behind the all-reduce, whichever stream the
         handle was created with; nothing relies on the legacy default stream.
 
-        gloo with the library on a real GPU (two ranks sharing one device: a correctness
-        configuration, e.g. ``SPORCO_AMD_BENCH_BACKEND=gloo``): the 16 doubles are staged
-        through the host around a CPU all-reduce -- one stream synchronisation per iteration.
+        gloo with the library on a real GPU (two ranks sharing one device: a CORRECTNESS
+        configuration, e.g. ``SPORCO_AMD_BENCH_BACKEND=gloo`` -- not a performance path): the 16
+        doubles are staged through the host around a CPU all-reduce, i.e. one full stream
+        synchronisation, one device-to-host and one host-to-device copy per iteration, which
+        also defeats the look-ahead of ``admm_run``.
 
         gloo on the CPU simulator: "device" memory is host memory."""
         from . import _lib
@@ -115,6 +117,7 @@ class TorchReducer(object):
                 self.hook_calls += 1
             return hook
         if 'hostsim' not in str(_lib.library_path()):
+            import time
             import numpy as np
             stage = np.zeros(16, dtype=np.float64)
             tstage = torch.from_numpy(stage)
@@ -123,10 +126,10 @@ class TorchReducer(object):
                 solver.sync()
                 _lib.check(_lib.lib().sporco_amd_dev_download(_lib._ptr(stage), ctypes.c_void_p(ptr),
                                                               stage.nbytes))
-                import time
                 t0 = time.perf_counter()
                 self.dist.all_reduce(tstage, group=self.group)
-                self._hook_host_s.append(time.perf_counter() - t0)
+                if self.hook_calls < 256:      # (timed for the first 256 calls, as the RCCL branch)
+                    self._hook_host_s.append(time.perf_counter() - t0)
                 self.hook_calls += 1
                 _lib.check(_lib.lib().sporco_amd_dev_upload(ctypes.c_void_p(ptr), _lib._ptr(stage),
                                                             stage.nbytes))
