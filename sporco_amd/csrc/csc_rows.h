@@ -77,6 +77,8 @@ template <typename T> struct RowsPostArgs {
     const cx<T> *twA;  // rows_twiddles table (only read when t_next is set)
     cx<T> *t_next;     // optional: also emit rfft_W(Y' - U') tile-major, i.e. the next
                        // iteration's rows_fwd for an unchanged rho; may alias t
+    int emit_u = 0;    // (Y, U) form only: emit rfft_W(U') instead -- the row spectra the dual
+                       // residual of the mask-decoupled iteration needs (api_maskdcpl.inc)
     const T *y, *u;    // in: real (H, W, P)
     T *y_out, *u_out;  // out (may alias y, u: every element is read and written by one thread)
     T *x;              // out (optional, may be null): X = irfftn(Xf)

@@ -566,6 +566,8 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
         thr21_p = a->ctl->thr21_prev_f;
     }
     const float l21w = lane < 16 ? 1.f : 0.f;  // the l2,1 sum counts each channel group once
+    const float emit_y = (EMIT_T && SF == 0 && a->emit_u) ? 0.f : 1.f;
+    const float emit_s = (EMIT_T && SF == 0 && a->emit_u) ? -1.f : 1.f;
     // pixels per batch (Y, U of the next batch are in flight); the emitting variants keep the
     // tile for the forward transform and have fewer registers to spare
     // (V form reads one array instead of two: twice the pixels per batch for the same registers)
@@ -728,7 +730,12 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             }
 
             if (WRITE_X) buf_store_cf(Xb, voff, soff, mk<float>(xs[0], xs[1]));
-            if (EMIT_T) v[n1] = mk<float>(yn[0] - un[0], yn[1] - un[1]);
+            if constexpr (EMIT_T && SF == 0) {
+                // (emit_u: the spectrum of U' alone; 1 * y - u rounds as y - u does)
+                v[n1] = mk<float>(emit_y * yn[0] - emit_s * un[0], emit_y * yn[1] - emit_s * un[1]);
+            } else if (EMIT_T) {
+                v[n1] = mk<float>(yn[0] - un[0], yn[1] - un[1]);
+            }
         }
     });
 

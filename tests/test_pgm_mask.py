@@ -148,7 +148,7 @@ def test_fused_masked_iteration_vs_staged(backend, opts, H, K, N):
         def _fused_ok(self):
             return False
 
-    optd = dict(opts, MaxMainIter=6, L=500.0)
+    optd = dict(opts, MaxMainIter=8, L=500.0)
     res = []
     for cls in (pc.ConvBPDNMask, Staged):
         b = cls(D, S, 0.1, W, pc.ConvBPDNMask.Options(optd))
