@@ -404,13 +404,31 @@ __global__ void __launch_bounds__(kThreads) admm_post_kernel(const PostParams<T>
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
          i += (int64_t)gridDim.x * blockDim.x) {
         const Vec<T, VEC> xv = reinterpret_cast<const Vec<T, VEC> *>(p.x)[i];
-        Vec<T, VEC> yv = reinterpret_cast<const Vec<T, VEC> *>(p.y)[i];
-        Vec<T, VEC> uv = reinterpret_cast<const Vec<T, VEC> *>(p.u)[i];
+        Vec<T, VEC> yv, uv, vv;
+        if (!GENERAL && p.v_in) {
+            // single-array state: (Y, U) of the iterate follow from V as the epilogue that
+            // stored it derived them
+            vv = reinterpret_cast<const Vec<T, VEC> *>(p.v_in)[i];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                T y = soft(vv.v[e], p.thr_prev);
+                if ((p.flags & F_NONNEG) && y < T(0)) y = T(0);
+                yv.v[e] = y;
+                uv.v[e] = vv.v[e] - y;
+            }
+        } else {
+            yv = reinterpret_cast<const Vec<T, VEC> *>(p.y)[i];
+            uv = reinterpret_cast<const Vec<T, VEC> *>(p.u)[i];
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-            admm_post_elem<T, GENERAL>(p, i * VEC + e, P, xv.v[e], yv.v[e], uv.v[e], acc);
-        reinterpret_cast<Vec<T, VEC> *>(p.y)[i] = yv;
-        reinterpret_cast<Vec<T, VEC> *>(p.u)[i] = uv;
+            admm_post_elem<T, GENERAL>(p, i * VEC + e, P, xv.v[e], yv.v[e], uv.v[e], acc, &vv.v[e]);
+        if (!GENERAL && p.v_out) {
+            reinterpret_cast<Vec<T, VEC> *>(p.v_out)[i] = vv;
+        } else {
+            reinterpret_cast<Vec<T, VEC> *>(p.y)[i] = yv;
+            reinterpret_cast<Vec<T, VEC> *>(p.u)[i] = uv;
+        }
     }
     block_sum_store<8>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 8);
 }

@@ -153,6 +153,12 @@ template <typename T> struct Csc : CscBase {
     T vp_thr = T(0);
     bool vp_nonneg = false;
     uint64_t touch_epoch = 0, fused_epoch = ~(uint64_t)0;   // host accesses between fused iterations
+    // The generic chain's single-array state (api_admm.inc admm_iter): while gv_live the iterate
+    // is V = AX + U in the buffer of vars[U] (updated in place; vars[Y] is stale), produced with
+    // the threshold gv_thr.  Never live together with v_live; ensure_yu() resolves either.
+    bool gv_live = false, gv_nonneg = false;
+    T gv_thr = T(0);
+    uint64_t gen_epoch = ~(uint64_t)0;
     // t_ready: the Xf buffer already holds rows_fwd(Y, U, s = 1) of the current
     // iterate, emitted by the previous rows_inv_post on the bet that rho stays put
     bool t_ready = false;
@@ -333,7 +339,7 @@ template <typename T> struct Csc : CscBase {
         SA_REQUIRE(var_is_valid(var), "unknown state variable id");
         if (var == SPORCO_AMD_VAR_Y || var == SPORCO_AMD_VAR_U) {
             ++touch_epoch;
-            if (v_live) ensure_yu();
+            if (v_live || gv_live) ensure_yu();
         }
         if (!vars[var]) {
             // (the Xf buffer also holds the tile-major spectrum, whose rows may be padded)
@@ -385,7 +391,7 @@ template <typename T> struct Csc : CscBase {
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_PGM) return pgm_fused_ok() ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
-        if (what == SPORCO_AMD_QUERY_VFORM_LIVE) return v_live ? 1 : 0;
+        if (what == SPORCO_AMD_QUERY_VFORM_LIVE) return (v_live || gv_live) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_PERSIST_RUNS) return pst_runs;
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }

@@ -106,6 +106,13 @@ template <typename T> struct PostParams {
     int ams_k = -1;   // index of that filter (K - 1 unless the handle pads the filter axis)
     int ams_n = 1;    // a multi-channel dictionary gets one impulse per channel (cbpdn.py:2339-2346):
                       // filters ams_k .. ams_k + ams_n - 1, the mask then (H, W, 1, N, ams_n)
+    // Single-array state (csc_rows.h), plain l1 term only: v_in, when set, is the iterate as
+    // V = AX + U, from which Y = prox_l1(V; thr_prev) (+ NonNegCoef) and U = V - Y are derived in
+    // place of the y / u loads; v_out, when set, receives V' = AX' + U in place of the y / u
+    // stores (v_out may alias v_in, or u)
+    const T *v_in = nullptr;
+    T *v_out = nullptr;
+    T thr_prev = T(0);
 };
 template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials);
 

@@ -37,11 +37,12 @@ __device__ __forceinline__ bool is_ams(int k, int ams_k, int ams_n) {
 }
 
 // idx: flat index of the element in the (H, W, C, N, K) array, P = C N K.  x: X at idx; y, u: the
-// iterate at idx on entry (u unscaled), the new iterate on return.  acc: r2, s2, ax2, y2, u2, l1.
+// iterate at idx on entry (u unscaled), the new iterate on return (vnew: AX + U of it, from which
+// both follow).  acc: r2, s2, ax2, y2, u2, l1.
 // GENERAL: weight arrays, NoBndryCross or AddMaskSim need the 5-D index of the element.
 template <typename T, bool GENERAL>
 __device__ __forceinline__ void admm_post_elem(const PostParams<T> &p, int64_t idx, int64_t P, T x, T &y, T &u,
-                                               double (&acc)[8]) {
+                                               double (&acc)[8], T *vnew = nullptr) {
     const T a = p.rlx, oma = T(1) - p.rlx;
     const bool nonneg = p.flags & F_NONNEG, nob = p.flags & F_NOBNDRY, gy = p.flags & F_GEVAL_Y;
     const T yo = y, uo = p.u_scale * u;
@@ -64,7 +65,9 @@ __device__ __forceinline__ void admm_post_elem(const PostParams<T> &p, int64_t i
             kill = weight_at(p.ams, h, xw, c, n, k - p.ams_k) != T(0);
         }
     }
-    T yn = soft(ax + uo, p.thr * w);
+    const T vsum = ax + uo;   // (the iterate in its single-array form: y and u below follow from it)
+    if (vnew) *vnew = vsum;
+    T yn = soft(vsum, p.thr * w);
     if (nonneg && !ams && yn < T(0)) yn = T(0);
     if (kill) yn = T(0);
     const T un = uo + ax - yn;

@@ -39,10 +39,17 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
 // the transformed signal is in - s2*in2 (fuses `YU = Y - U`,
 // sporco/admm/cbpdn.py:271).  Output (o, f, p), f in [0, n/2], at
 // out[o*out_outer + f*out_line + p] (units: complex).
+// vf (optional): `in` is the ADMM iterate as the single array V = AX + U (csc_rows.h) and in2
+// is null: the line transformed is Y - s2 U with Y = prox_l1(V; thr) (+ NonNegCoef), U = V - Y.
+template <typename T> struct VformIn {
+    T thr;
+    bool nonneg;
+};
 template <typename T>
 void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
              int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
-             int64_t out_line, int64_t grp = 0, int64_t grp_stride = 0, int64_t bc_mod = 0);
+             int64_t out_line, int64_t grp = 0, int64_t grp_stride = 0, int64_t bc_mod = 0,
+             const VformIn<T> *vf = nullptr);
 // (bc_mod > 0: `in` is (n_outer, n, bc_mod) and is broadcast over the P / bc_mod column blocks)
 
 // Half-spectrum -> real lines (inverse, unnormalised times `scale`).  The

@@ -52,7 +52,20 @@ template <typename T> struct LineArgs {
     T *x_out;
     double *partials;
     int64_t postP;
+    // R2C only: `in` is the ADMM iterate in its single-array form V = AX + U (csc_rows.h): the line
+    // transformed is Y - s2 U with Y = prox_l1(V; vthr) (+ NonNegCoef), U = V - Y, derived per
+    // element as the epilogue derived them (csc_post_elem.h admm_post_elem)
+    int vform;
+    T vthr;
+    int vnonneg;
 };
+
+template <typename T> __device__ __forceinline__ T yu_from_v(const LineArgs<T> &a, T v) {
+    T y = soft(v, a.vthr);
+    if (a.vnonneg && y < T(0)) y = T(0);
+    const T u = v - y;
+    return y - a.s2 * u;
+}
 
 template <typename T> __device__ __forceinline__ int64_t col_off(const LineArgs<T> &a, int64_t p) {
     return a.grp ? (p / a.grp) * a.grp_stride + p % a.grp : p;
@@ -205,6 +218,7 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
                 cx<T> v = zero;
                 if (valid) {
                     v = in[i * in_ln];
+                    if (a.vform) v = mk<T>(yu_from_v(a, v.re), yu_from_v(a, v.im));
                     if (in2) {
                         const cx<T> u = in2[i * a.in_line];
                         v = mk<T>(v.re - a.s2 * u.re, v.im - a.s2 * u.im);
@@ -221,6 +235,7 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
                 T v = T(0);
                 if (valid) {
                     v = in[i * in_ln];
+                    if (a.vform) v = yu_from_v(a, v);
                     if (in2) v -= a.s2 * in2[i * a.in_line];
                 }
                 buf0[i * cols + col] = mk<T>(v, T(0));
@@ -460,8 +475,13 @@ void fft_c2c(hipStream_t st, const FftPlan &plan, bool inverse, const cx<T> *in,
 template <typename T>
 void fft_r2c(hipStream_t st, const FftPlan &plan, const T *in, const T *in2, T s2, cx<T> *out,
              int64_t n_outer, int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer,
-             int64_t out_line, int64_t grp, int64_t grp_stride, int64_t bc_mod) {
+             int64_t out_line, int64_t grp, int64_t grp_stride, int64_t bc_mod, const VformIn<T> *vf) {
     LineArgs<T> a{};
+    if (vf) {
+        a.vform = 1;
+        a.vthr = vf->thr;
+        a.vnonneg = vf->nonneg ? 1 : 0;
+    }
     // broadcast `in`: (n_outer, n, bc_mod) contiguous, i.e. line stride bc_mod
     a.bc_mod = bc_mod;
     a.bc_line = bc_mod;
@@ -585,7 +605,7 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
                              int64_t, int64_t, int64_t, int64_t, int64_t, T);                    \
     template void fft_r2c<T>(hipStream_t, const FftPlan &, const T *, const T *, T, cx<T> *,     \
                              int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,      \
-                             int64_t, int64_t);                                                  \
+                             int64_t, int64_t, const VformIn<T> *);                              \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
                              int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
     template int64_t fft_c2r_post_blocks<T>(const FftPlan &, int64_t, int64_t);                  \

@@ -221,3 +221,71 @@ def test_v_form_under_addmasksim_and_gradreg(backend):
     assert np.array_equal(np.asarray(outs[False][1].ObjFun), np.asarray(outs[True][1].ObjFun))
     assert np.array_equal(outs[False][2], outs[True][2]) and np.array_equal(outs[False][3], outs[True][3])
     assert np.array_equal(np.asarray(outs[False][4].ObjFun), np.asarray(outs[True][4].ObjFun))
+
+
+GENERIC_CASES = {
+    # (H, W, dtype, multi-channel dictionary, options)
+    'f64_default': (64, 64, np.float64, False, {'MaxMainIter': 9, 'RelStopTol': 0.0}),
+    'f64_nonneg_period3': (32, 64, np.float64, False,
+                           {'MaxMainIter': 8, 'RelStopTol': 0.0, 'NonNegCoef': True,
+                            'AutoRho': {'Period': 3}}),
+    'f32_48x40_fixed_rho': (48, 40, np.float32, False,
+                            {'MaxMainIter': 7, 'RelStopTol': 0.0, 'AutoRho': {'Enabled': False},
+                             'rho': 2.5}),
+    'f32_36x60_stops_early': (36, 60, np.float32, False, {'MaxMainIter': 40, 'RelStopTol': 5e-2}),
+    'f64_mcdict': (32, 32, np.float64, True, {'MaxMainIter': 6, 'RelStopTol': 0.0}),
+}
+
+
+@pytest.mark.parametrize('case', sorted(GENERIC_CASES))
+def test_generic_chain_v_form_is_bit_identical_to_the_yu_form(backend, case):
+    """The generic chain (sizes / precisions the register kernels do not cover) keeps the single
+    array too: its row transform derives Y - s U from V while loading, its epilogue reads V and
+    writes V' in place (fft.hip r2c loader, ck_admm.hip admm_post_kernel).  Same contract: the
+    (Y, U) form of the same library, bit for bit; that form is what the float64 fixtures of
+    test_admm_cbpdn.py pin to the reference."""
+    from sporco_amd import _lib
+    H, W, dt, mc, optd = GENERIC_CASES[case]
+    K, N = 5, 2
+    rng = np.random.RandomState(31)
+    if mc:
+        D = rng.randn(4, 4, 3, K).astype(dt)
+        S = rng.randn(H, W, 3, N).astype(dt)
+    else:
+        D = rng.randn(4, 4, K).astype(dt)
+        S = rng.randn(H, W, N).astype(dt)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    optd = dict(optd, DataType=dt)
+
+    def go(vform, calls=1):
+        from sporco_amd.admm import cbpdn
+        if not vform:
+            os.environ['SPORCO_AMD_NO_VFORM'] = '1'
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+        try:
+            b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+            live = []
+            for _ in range(calls):
+                b._return_min = False
+                b.solve()
+                live.append(b._dev.query(_lib.QUERY_VFORM_LIVE))
+            return b, dict(Y=b.Y.copy(), U=b.U.copy(), X=b.X.copy(), k=b.k, live=live,
+                           stats={f: np.asarray(getattr(b.getitstat(), f), float) for f in FIELDS})
+        finally:
+            os.environ.pop('SPORCO_AMD_NO_VFORM', None)
+            os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
+
+    for calls in (1, 2):
+        b0, o0 = go(False, calls)
+        b1, o1 = go(True, calls)
+        assert not b1._dev.uses_fused_rows() or mc or dt == np.float64
+        assert o0['live'] == [0] * calls
+        if o1['k'] >= 3 * calls:
+            assert o1['live'] == [1] * calls, (case, o1['k'])
+        assert o0['k'] == o1['k']
+        for f in ('Y', 'U', 'X'):
+            assert np.array_equal(o0[f], o1[f]), f
+        for f in o0['stats']:
+            assert np.array_equal(o0['stats'][f], o1['stats'][f], equal_nan=True), f
+    # reading the iterates takes the handle back to the (Y, U) form
+    assert b1._dev.query(_lib.QUERY_VFORM_LIVE) == 0

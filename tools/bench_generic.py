@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The generic ADMM chain (sizes / dtypes the register kernels do not serve; SPORCO_AMD_UNFUSED=1
-forces it at the other sizes): iterations per second with the epilogue fused into the row pass
-of irfftn (SPORCO_AMD_C2R_POST=1) and with the two kernels apart (default).  One JSON line per
-configuration and variant."""
+forces it at the other sizes): iterations per second in the (Y, U) form (SPORCO_AMD_NO_VFORM=1),
+in the single-array form (default: V = AX + U in place of Y and U, 13 passes instead of 16), and
+with the epilogue fused into the row pass of irfftn (SPORCO_AMD_C2R_POST=1, (Y, U) form).  One JSON
+line per configuration and variant."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,9 +11,12 @@ import numpy as np
 CONFIGS = [(512, 512, 64, 8, 'float32', True), (384, 384, 64, 8, 'float32', False),
            (320, 480, 32, 8, 'float32', False), (256, 256, 32, 8, 'float64', False)]
 for (H, W, K, N, dt, force) in CONFIGS:
-    for nofuse in (1, 0):
+    for variant in ('yu', 'v', 'yu_c2r_post'):
+        nofuse = variant != 'yu_c2r_post'
         env = {'SPORCO_AMD_UNFUSED': '1'} if force else {}
         env['SPORCO_AMD_C2R_POST'] = '0' if nofuse else '1'
+        if variant != 'v':
+            env['SPORCO_AMD_NO_VFORM'] = '1'
         os.environ.update(env)
         from sporco_amd.admm import cbpdn as ac
         rng = np.random.RandomState(1)
@@ -29,7 +33,7 @@ for (H, W, K, N, dt, force) in CONFIGS:
         b.solve(); b._dev.sync()
         prof = {k: round(v[0] / max(v[1], 1), 4) for k, v in b._dev.profile_read().items() if v[1]}
         print(json.dumps({'config': '%dx%d K=%d N=%d %s generic chain' % (H, W, K, N, dt),
-                          'fused_epilogue': not nofuse, 'it_per_s': 30 / dt_s, 'kernel_ms': prof}))
+                          'variant': variant, 'it_per_s': 30 / dt_s, 'kernel_ms': prof}))
         for k in env:
             os.environ.pop(k, None)
         del b
