@@ -20,6 +20,9 @@ struct FftPlan {
     int radix[kMaxRadixPasses] = {0};
     cx<float> *tw32 = nullptr;   // device, W_n^t = exp(-2 pi i t / n), t in [0, n)
     cx<double> *tw64 = nullptr;  // device
+    // device, n ints: the frequency held at position pos after the in-place decimation-in-
+    // frequency passes radix[0], radix[1], ... (fft_cols_sm)
+    int *drev = nullptr;
     void init(int n_);
     void destroy();
     template <typename T> const cx<T> *tw() const;
@@ -84,5 +87,16 @@ void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *
 template <typename T>
 void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx<T> *in,
             cx<T> *tmp, T *out, int H, int W, int64_t P);
+
+// The column pass of the generic ADMM X-step in one kernel: forward transform along H, the
+// Sherman-Morrison solve (sporco/linalg.py:232-297) and the inverse transform of one (wf, cn)
+// tile of n = plan.n frequencies x K filters held in LDS.  xf (n, Wf, CN, K) is transformed in
+// place (the c2r row pass is what remains of irfftn); partials (Wf * CN doubles) receive the
+// Parseval-weighted sums of |Df.xf - Sf|^2 when want_obj.  fft_cols_sm_supported: K a power of
+// two <= 64, radices <= 8, the tile fits LDS.  Returns the number of tiles.
+template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K);
+template <typename T>
+int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> *df, const cx<T> *sf,
+                    const T *gram, T rho, int Wf, int CN, int K, int W, bool want_obj, double *partials);
 
 }  // namespace sporco_amd

@@ -354,6 +354,192 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------
+// Column pass of the generic ADMM X-step in ONE kernel: forward transform along H, the
+// Sherman-Morrison solve (linalg.solvedbi_sm, sporco/linalg.py:232-297) and the inverse
+// transform, for one (wf, cn) tile of all n = H frequencies x K filters held in LDS -- two passes
+// over the spectrum instead of the six of fft_c2c + launch_sm_solve + fft_c2c.  The tile has ONE
+// buffer (a Stockham pass needs two): the forward transform is decimation in frequency in place
+// (natural order in, digit-reversed order out: a radix-R butterfly reads and writes the same R
+// positions, so a barrier between passes is all the synchronisation there is), the solve works
+// at the digit-reversed positions (plan.drev maps a position to its frequency), and the inverse
+// is the transposed flow (decimation in time: conj twiddle, then butterfly; passes in reverse
+// order), which takes the digit-reversed order back to the natural one.
+// ---------------------------------------------------------------------------
+template <typename T> struct ColsSmArgs {
+    cx<T> *xf;          // (n, Wf, CN, K): rfft_W(Y - s U) on entry, the column-inverse-transformed
+                        // solution spectrum on return (the c2r row pass is what remains of irfftn)
+    const cx<T> *df;    // (n, Wf, K)
+    const cx<T> *sf;    // (n, Wf, CN)
+    const T *gram;      // (n, Wf)
+    const cx<T> *tw;    // W_n^t
+    const int *drev;    // position -> frequency after the in-place forward transform
+    T rho;
+    int n, Wf, CN, K, W, nrad, want_obj;
+    int radix[kMaxRadixPasses];
+    double *partials;   // one per tile: Parseval-weighted sum of |Df.xf - Sf|^2
+};
+
+// R-point DFT of v (exp(-/+ 2 pi i s q / R)), any R, from the table of W_n^t (n a multiple of R)
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void small_dft(cx<T> (&v)[R], const cx<T> *tw, int n) {
+    if constexpr (R == 2 || R == 4 || R == 8) {
+        Butterfly<T, R, INV>::run(v);
+    } else {
+        const int step = n / R;
+        cx<T> o[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            cx<T> acc = v[0];
+#pragma unroll
+            for (int s = 1; s < R; ++s) {
+                const cx<T> w = tw[((s * q) % R) * step];
+                acc = acc + (INV ? cmulc(w, v[s]) : cmul(w, v[s]));
+            }
+            o[q] = acc;
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = o[q];
+    }
+}
+
+// One in-place pass over blocks of length m: the R elements j + s m/R of every block.
+// Forward (decimation in frequency): butterfly, then output q times W_m^(j q).
+// Inverse (decimation in time):      input s times conj W_m^(j s), then the conjugate butterfly.
+template <typename T, int R, bool INV>
+__device__ __forceinline__ void inplace_pass(cx<T> *buf, const cx<T> *tw, int n, int m, int K, int col,
+                                             int lane, int lpc) {
+    const int sub = m / R, nb = n / R, tstep = n / m;
+    for (int b = lane; b < nb; b += lpc) {
+        const int blk = b / sub, j = b - blk * sub;
+        const int base = blk * m + j;
+        cx<T> v[R];
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const cx<T> x = buf[(base + s * sub) * K + col];
+            v[s] = (INV && s > 0 && j > 0) ? cmulc(tw[j * s * tstep], x) : x;
+        }
+        small_dft<T, R, INV>(v, tw, n);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const cx<T> x = (!INV && q > 0 && j > 0) ? cmul(tw[j * q * tstep], v[q]) : v[q];
+            buf[(base + q * sub) * K + col] = x;
+        }
+    }
+}
+
+template <typename T, bool INV>
+__device__ __forceinline__ void inplace_pass_r(int R, cx<T> *buf, const cx<T> *tw, int n, int m, int K,
+                                               int col, int lane, int lpc) {
+    switch (R) {
+    case 8: inplace_pass<T, 8, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    case 4: inplace_pass<T, 4, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    case 2: inplace_pass<T, 2, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    case 3: inplace_pass<T, 3, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    case 5: inplace_pass<T, 5, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    default: inplace_pass<T, 7, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    }
+}
+
+// US: rows of solve operands (Df, Sf, gram) a thread requests together; when that covers all
+// its rows they are requested before the forward passes and arrive behind them.
+template <typename T, int US>
+__global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
+    const int n = a.n, K = a.K;
+    cx<T> *buf = dyn_lds<cx<T>>();
+    cx<T> *tw = buf + (size_t)n * K;
+    double *scratch = reinterpret_cast<double *>(tw + n);
+    int *drev = reinterpret_cast<int *>(scratch + 16);
+    const int tid = threadIdx.x;
+    const int col = tid % K, lane = tid / K, lpc = blockDim.x / K;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): every XCD
+    // takes a contiguous run of tiles, so that the CN tiles that share a row frequency's slice
+    // of Df find it in that XCD's L2.
+    const int ntiles = a.Wf * a.CN, per_xcd = (ntiles + 7) / 8;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
+    const int wf = tile / a.CN, cn = tile - wf * a.CN;
+    const int64_t rowstride = (int64_t)a.Wf * a.CN * K;
+    cx<T> *x = a.xf + ((int64_t)wf * a.CN + cn) * K + col;
+    const cx<T> zero = mk<T>(T(0), T(0));
+    for (int t = tid; t < n; t += blockDim.x) {
+        tw[t] = a.tw[t];
+        drev[t] = a.drev[t];
+    }
+    cx<T> d[US], sv[US];
+    T gv[US];
+    auto load_operands = [&](int pos0, const int *dr) {
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            const int pos = pos0 + u * lpc + lane;
+            const int64_t pix = pos < n ? (int64_t)dr[pos] * a.Wf + wf : 0;
+            d[u] = a.df[pix * K + col];
+            sv[u] = a.sf[pix * a.CN + cn];
+            gv[u] = a.gram[pix];
+        }
+    };
+    const bool one_batch = US * lpc >= n;
+    if (one_batch) load_operands(0, a.drev);
+    // (batches of independent loads: one row per thread in flight leaves the pass waiting out a
+    // memory round trip per row)
+    constexpr int UL = 8;
+    for (int r0 = lane; r0 < n; r0 += UL * lpc) {
+        cx<T> t[UL];
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int r = r0 + u * lpc;
+            t[u] = r < n ? x[r * rowstride] : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            const int r = r0 + u * lpc;
+            if (r < n) buf[r * K + col] = t[u];
+        }
+    }
+    __syncthreads();
+    // ---- forward, in place ------------------------------------------------------------------
+    int m = n;
+    for (int p = 0; p < a.nrad; ++p) {
+        inplace_pass_r<T, false>(a.radix[p], buf, tw, n, m, K, col, lane, lpc);
+        m /= a.radix[p];
+        __syncthreads();
+    }
+    // ---- xf = yuf + conj(Df) (Sf - sum_k Df yuf) / (sum_k |Df|^2 + rho) ------------------------
+    double acc[1] = {0.0};
+    // (half-spectrum Parseval weights 1, 2, ..., 2, 1 or 2: fft.py:476-484)
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == a.Wf - 1)) ? 1.0 : 2.0;
+    // (every lane of a wave takes part in the shuffles: the trip count is the workgroup's)
+    for (int pos0 = 0; pos0 < n; pos0 += US * lpc) {
+        if (!one_batch) load_operands(pos0, drev);
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            const int pos = pos0 + u * lpc + lane;
+            if (pos0 + u * lpc >= n) break;        // (uniform over the workgroup)
+            const bool valid = pos < n;
+            const cx<T> yu = valid ? buf[pos * K + col] : zero;
+            cx<T> q = cmul(d[u], yu);
+            for (int s = K >> 1; s > 0; s >>= 1) {     // (K: a power of two <= 64; the K lanes share pos)
+                q.re += __shfl_xor(q.re, s, kWave);
+                q.im += __shfl_xor(q.im, s, kWave);
+            }
+            const cx<T> coef = cscale(sv[u] - q, T(1) / (gv[u] + a.rho));
+            if (valid) buf[pos * K + col] = yu + cmulc(d[u], coef);
+            // Df.xf - Sf = rho (q - Sf) / (gram + rho)
+            if (a.want_obj && valid && col == 0)
+                acc[0] += pw * (double)cabs2(coef) * (double)a.rho * (double)a.rho;
+        }
+    }
+    __syncthreads();
+    // ---- inverse, in place: the transposed flow ---------------------------------------------------
+    for (int p = a.nrad - 1; p >= 0; --p) {
+        m *= a.radix[p];
+        inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, K, col, lane, lpc);
+        __syncthreads();
+    }
+    for (int r = lane; r < n; r += lpc) x[r * rowstride] = buf[r * K + col];
+    if (a.want_obj) block_sum_store<1>(acc, scratch, a.partials + tile);
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 void FftPlan::init(int n_) {
@@ -387,11 +573,29 @@ void FftPlan::init(int n_) {
     SA_HIP(hipMalloc((void **)&tw64, sizeof(cx<double>) * n));
     SA_HIP(hipMemcpy(tw32, t32.data(), sizeof(cx<float>) * n, hipMemcpyHostToDevice));
     SA_HIP(hipMemcpy(tw64, t64.data(), sizeof(cx<double>) * n, hipMemcpyHostToDevice));
+    // position -> frequency of the in-place forward transform: position q0 n/r0 + q1 n/(r0 r1) +
+    // ... holds frequency q0 + r0 (q1 + r1 (...))
+    std::vector<int> dr(n);
+    for (int pos = 0; pos < n; ++pos) {
+        int rem = pos, f = 0, weight = 1, mcur = n;
+        for (int p = 0; p < nrad; ++p) {
+            const int sub = mcur / radix[p];
+            f += (rem / sub) * weight;
+            rem %= sub;
+            weight *= radix[p];
+            mcur = sub;
+        }
+        dr[pos] = f;
+    }
+    SA_HIP(hipMalloc((void **)&drev, sizeof(int) * n));
+    SA_HIP(hipMemcpy(drev, dr.data(), sizeof(int) * n, hipMemcpyHostToDevice));
 }
 
 void FftPlan::destroy() {
     if (tw32) (void)hipFree(tw32);
     if (tw64) (void)hipFree(tw64);
+    if (drev) (void)hipFree(drev);
+    drev = nullptr;
     tw32 = nullptr;
     tw64 = nullptr;
     n = 0;
@@ -600,6 +804,66 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
                T(1.0 / ((double)H * (double)W)), 0, 0);
 }
 
+template <typename T> static size_t cols_sm_lds(int n, int K) {
+    return sizeof(cx<T>) * ((size_t)n * K + n) + sizeof(double) * 16 + sizeof(int) * n;
+}
+
+template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K) {
+    if (K < 2 || K > 64 || (K & (K - 1))) return false;
+    for (int p = 0; p < plan.nrad; ++p)
+        if (plan.radix[p] > 8 || plan.radix[p] == 6) return false;
+    return plan.n >= 2 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget;
+}
+
+template <typename T>
+int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> *df, const cx<T> *sf,
+                    const T *gram, T rho, int Wf, int CN, int K, int W, bool want_obj, double *partials) {
+    SA_REQUIRE(fft_cols_sm_supported<T>(plan, K), "fft_cols_sm: unsupported length / filter count");
+    ColsSmArgs<T> a{};
+    a.xf = xf;
+    a.df = df;
+    a.sf = sf;
+    a.gram = gram;
+    a.tw = plan.tw<T>();
+    a.drev = plan.drev;
+    a.rho = rho;
+    a.n = plan.n;
+    a.Wf = Wf;
+    a.CN = CN;
+    a.K = K;
+    a.W = W;
+    a.nrad = plan.nrad;
+    for (int i = 0; i < plan.nrad; ++i) a.radix[i] = plan.radix[i];
+    a.want_obj = want_obj ? 1 : 0;
+    a.partials = partials;
+    const size_t lds = cols_sm_lds<T>(plan.n, K);
+    const int threads = (int64_t)plan.n * K >= 4096 ? 1024 : 256;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[sizeof(T) == 8]) {
+        constexpr int UM = sizeof(T) == 8 ? 6 : 12;
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM / 3>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, 2 * UM / 3>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set[sizeof(T) == 8] = true;
+    }
+    const int64_t tiles = (int64_t)Wf * CN;
+    const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
+    // rows per thread: all operands in one batch while the registers allow it
+    const int nit = (int)ceil_div(plan.n, threads / K);
+    constexpr int UMAX = sizeof(T) == 8 ? 6 : 12;
+    if (nit <= UMAX / 3)
+        hipLaunchKernelGGL((cols_sm_kernel<T, UMAX / 3>), dim3(grid), dim3(threads), lds, st, a);
+    else if (nit <= 2 * UMAX / 3 || nit > UMAX)
+        hipLaunchKernelGGL((cols_sm_kernel<T, 2 * UMAX / 3>), dim3(grid), dim3(threads), lds, st, a);
+    else
+        hipLaunchKernelGGL((cols_sm_kernel<T, UMAX>), dim3(grid), dim3(threads), lds, st, a);
+    SA_HIP(hipGetLastError());
+    return tiles;
+}
+
 #define SA_INSTANTIATE(T)                                                                        \
     template void fft_c2c<T>(hipStream_t, const FftPlan &, bool, const cx<T> *, cx<T> *, int64_t, \
                              int64_t, int64_t, int64_t, int64_t, int64_t, T);                    \
@@ -608,6 +872,9 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
                              int64_t, int64_t, const VformIn<T> *);                              \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
                              int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
+    template bool fft_cols_sm_supported<T>(const FftPlan &, int);                               \
+    template int64_t fft_cols_sm<T>(hipStream_t, const FftPlan &, cx<T> *, const cx<T> *,        \
+                                    const cx<T> *, const T *, T, int, int, int, int, bool, double *); \
     template int64_t fft_c2r_post_blocks<T>(const FftPlan &, int64_t, int64_t);                  \
     template int64_t fft_c2r_post<T>(hipStream_t, const FftPlan &, const cx<T> *, int64_t, int64_t, \
                                      int64_t, int64_t, T, const PostParams<T> &, T *, double *); \

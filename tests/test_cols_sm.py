@@ -1,0 +1,76 @@
+"""The generic X-step's column pass as one kernel (fft.h fft_cols_sm): forward transform along H
+in place in LDS (decimation in frequency), Sherman-Morrison solve at the digit-reversed
+positions (sporco/linalg.py:232-297), inverse transform (decimation in time) -- against the
+three kernels it replaces (SPORCO_AMD_NO_COLS_SM=1: fft_c2c, launch_sm_solve, fft_c2c), which
+the float64 fixtures of test_admm_cbpdn.py pin to the reference; plus the oracle directly."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+CASES = {
+    # H, W, K, N, dtype       (lengths with radices 2, 3, 4, 5, 7, 8)
+    'f32_48x40_k8': (48, 40, 8, 2, np.float32),
+    'f64_30x36_k4': (30, 36, 4, 2, np.float64),
+    'f64_63x56_k16': (63, 56, 16, 1, np.float64),
+    'f32_32x24_k64': (32, 24, 64, 1, np.float32),
+    'f64_35x20_k2': (35, 20, 2, 3, np.float64),
+    'f32_96x80_k32': (96, 80, 32, 2, np.float32),
+}
+
+
+def run(D, S, optd, fused):
+    from sporco_amd.admm import cbpdn
+    if not fused:
+        os.environ['SPORCO_AMD_NO_COLS_SM'] = '1'
+    try:
+        b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+        b._dev.profile(True)
+        b.solve()
+        prof = b._dev.profile_read()
+    finally:
+        os.environ.pop('SPORCO_AMD_NO_COLS_SM', None)
+    return b, prof
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_fused_column_pass_equals_the_three_kernels(backend, name):
+    H, W, K, N, dt = CASES[name]
+    if backend == 'hostsim' and name == 'f32_96x80_k32':
+        pytest.skip("kept short on the CPU simulator")
+    rng = np.random.RandomState(len(name))
+    D = rng.randn(5, 5, K).astype(dt)
+    S = rng.randn(H, W, N).astype(dt)
+    optd = {'MaxMainIter': 8, 'RelStopTol': 0.0, 'DataType': dt}
+    a, pa = run(D, S, optd, False)
+    b, pb = run(D, S, optd, True)
+    assert pa['fft_c2c_cols_fwd'][1] == 8 and pb['fft_c2c_cols_fwd'][1] == 0
+    assert pb['fft_c2c_cols_inv'][1] == 0 and pb['sm_solve'][1] == 8
+    tol = 1e-11 if dt == np.float64 else 2e-5
+    for v in ('Y', 'U', 'X'):
+        assert rel_l2(getattr(a, v), getattr(b, v)) < tol, v
+    # a reader of Xf gets the spectrum of X, not the half-transformed buffer
+    assert rel_l2(np.asarray(b.Xf), np.fft.rfft2(np.asarray(b.X, np.float64), axes=(0, 1))) < 10 * tol
+    ia, ib = a.getitstat(), b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(np.asarray(getattr(ia, f)), np.asarray(getattr(ib, f))) < tol, f
+
+
+def test_fused_column_pass_against_the_oracle(backend):
+    from oracle import cbpdn_oracle as orc
+    H, W, K, N = 40, 48, 8, 2
+    rng = np.random.RandomState(7)
+    D = rng.randn(4, 4, K)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, N)
+    b, prof = run(D, S, {'MaxMainIter': 10, 'RelStopTol': 0.0}, True)
+    assert prof['fft_c2c_cols_fwd'][1] == 0
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                         maxiter=10, rel_tol=0.0)
+    assert rel_l2(b.Y, ref['Y']) < 1e-10 and rel_l2(b.U, ref['U']) < 1e-10
+    st = b.getitstat()
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(np.asarray(getattr(st, f)), ref[f]) < 1e-10, f

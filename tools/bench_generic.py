@@ -1,22 +1,30 @@
 #!/usr/bin/env python3
 """The generic ADMM chain (sizes / dtypes the register kernels do not serve; SPORCO_AMD_UNFUSED=1
 forces it at the other sizes): iterations per second in the (Y, U) form (SPORCO_AMD_NO_VFORM=1),
-in the single-array form (default: V = AX + U in place of Y and U, 13 passes instead of 16), and
+in the single-array form (V = AX + U in place of Y and U, 13 passes instead of 16), with the
+column pass as one LDS-resident kernel on top of that (the default where the tile fits: 9 passes), and
 with the epilogue fused into the row pass of irfftn (SPORCO_AMD_C2R_POST=1, (Y, U) form).  One JSON
 line per configuration and variant."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-CONFIGS = [(512, 512, 64, 8, 'float32', True), (384, 384, 64, 8, 'float32', False),
+CONFIGS = [(512, 512, 64, 8, 'float32', True), (384, 384, 64, 8, 'float32', False), (384, 384, 32, 8, 'float32', False),
+           (240, 320, 64, 8, 'float32', False), (128, 128, 64, 8, 'float64', False),
            (320, 480, 32, 8, 'float32', False), (256, 256, 32, 8, 'float64', False)]
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ''           # substring of '<H>x<W> K=<K>'
+VARIANTS = sys.argv[2].split(',') if len(sys.argv) > 2 else ['yu', 'v', 'v_cols_sm', 'yu_c2r_post']
 for (H, W, K, N, dt, force) in CONFIGS:
-    for variant in ('yu', 'v', 'yu_c2r_post'):
+    if ONLY not in '%dx%d K=%d %s' % (H, W, K, dt):
+        continue
+    for variant in VARIANTS:
         nofuse = variant != 'yu_c2r_post'
         env = {'SPORCO_AMD_UNFUSED': '1'} if force else {}
         env['SPORCO_AMD_C2R_POST'] = '0' if nofuse else '1'
-        if variant != 'v':
+        if variant not in ('v', 'v_cols_sm'):
             env['SPORCO_AMD_NO_VFORM'] = '1'
+        if variant != 'v_cols_sm':
+            env['SPORCO_AMD_NO_COLS_SM'] = '1'     # (the column pass as three kernels)
         os.environ.update(env)
         from sporco_amd.admm import cbpdn as ac
         rng = np.random.RandomState(1)
