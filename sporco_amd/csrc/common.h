@@ -136,6 +136,20 @@ __device__ __forceinline__ void block_sum_store(const double (&acc)[NV], double 
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// "once per device" for the launchers' function attributes (hipFuncSetAttribute applies to the
+// function as loaded on the CURRENT device; a process may drive several):
+//     static PerDeviceOnce attr;  if (attr.first()) { hipFuncSetAttribute(...); }
+struct PerDeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // Compute units of the CURRENT device (the C ABI selects the handle's device before every call),
 // cached per device id: the persistent launches size their grids by it, and a process may drive
 // devices of different sizes or partition modes.

@@ -811,13 +811,12 @@ static int64_t persistent_grid(int NW) {
 template <int N1, int NW, int LP, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false,
           int DBG = 0>
 static void launch_fused_inst(hipStream_t st, const FusedColsArgs<float> &a, int64_t ntiles) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void *>(
                 &fused_cols_kernel<N1, NW, LP, KC, GRAD, KRT, PER_TILE, DBG>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
-        attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);   // see the tile mapping in the kernel
     const int64_t all = wf_groups * 8 * a.CN;
@@ -890,11 +889,10 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     return ntiles;
 }
 template <int NW, int LP, int KC> static void launch_dualres_inst(hipStream_t st, const FusedColsArgs<float> &a) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_dualres_kernel<NW, LP, KC>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
-        attr_set = true;
     }
     const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
     const int64_t cus = current_device_cus();
@@ -1038,14 +1036,13 @@ template <> bool fused_slabs_supported<double>(int, int) { return false; }
 
 template <int NW, int LP, int KS, bool GRAD>
 static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool second) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         for (const void *f :
              {reinterpret_cast<const void *>(&cols_fwd_partial_kernel<NW, LP, KS, GRAD>),
               reinterpret_cast<const void *>(&cols_sm_apply_inv_kernel<NW, LP, KS, GRAD>)})
             SA_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)fused_lds_bytes(NW, LP)));
-        attr_set = true;
     }
     const dim3 grid((unsigned)(ceil_div(a.c.W / 2 + 1, 8) * 8 * a.c.CN), (unsigned)ceil_div(a.c.K, 64));
     if (!second)
@@ -1062,12 +1059,11 @@ static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool sec
 // frequencies a group walks stays fixed).
 template <int NW, int LP, int KS, bool GRAD>
 static void launch_slab_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, GRAD>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)fused_lds_bytes(NW, LP)));
-        attr_set = true;
     }
     const int cus = current_device_cus();
     const int NH = (int)ceil_div(a.c.K, 64);
@@ -1106,12 +1102,11 @@ template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlab
 }
 template <int NW, int LP, int KS>
 static void launch_pgm_grad_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, false, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
-        attr_set = true;
     }
     const int cus = current_device_cus();
     const int NH = (int)ceil_div(a.c.K, 64);

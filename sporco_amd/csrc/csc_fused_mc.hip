@@ -250,12 +250,11 @@ __global__ void __launch_bounds__(256) mc_binv_kernel(const cf *__restrict__ dft
 
 template <int N1, int NW, int LP, int KC, int CC>
 void launch_mc_inst(hipStream_t st, const FusedMcArgs<float> &a) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(
             reinterpret_cast<const void *>(&fused_cols_mc_kernel<N1, NW, LP, KC, CC>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)mc_lds_bytes(NW, LP)));
-        attr_set = true;
     }
     const int64_t wf_groups = ceil_div(a.W / 2 + 1, 8);
     hipLaunchKernelGGL((fused_cols_mc_kernel<N1, NW, LP, KC, CC>),

@@ -571,10 +571,9 @@ static unsigned pgm_all_tiles(const PgmColsArgs<float> &a) {
 
 template <int NW, int LP, int KC, bool BT, bool PERS, bool EYIN = false>
 void launch_grad_inst(hipStream_t st, const PgmColsArgs<float> &a, unsigned grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         set_lds(&pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS, EYIN>, pgm_lds_bytes(NW, LP));
-        attr_set = true;
     }
     hipLaunchKernelGGL((pgm_grad_ifft_kernel<NW, LP, KC, BT, PERS, EYIN>), dim3(grid), dim3(NW * 64),
                        pgm_lds_bytes(NW, LP), st, a);
@@ -602,10 +601,9 @@ template <int NW, int LP, int KC> void launch_grad(hipStream_t st, const PgmCols
 
 template <int NW, int LP, int KC, bool STATS, bool PLAIN, bool BT, bool PERS>
 void launch_mom_inst(hipStream_t st, const PgmColsArgs<float> &a, unsigned grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         set_lds(&pgm_fft_momentum_kernel<NW, LP, KC, STATS, PLAIN, BT, PERS>, pgm_lds_bytes(NW, LP));
-        attr_set = true;
     }
     const unsigned slabs = KC ? 1u : (unsigned)ceil_div(a.K, 64);
     hipLaunchKernelGGL((pgm_fft_momentum_kernel<NW, LP, KC, STATS, PLAIN, BT, PERS>), dim3(grid, slabs),

@@ -1111,11 +1111,10 @@ template <> int admm_persist_grid<double>(int, int, int, int) { return 0; }
 template <int NW, int LP> static size_t persist_prepare() {
     const size_t lds = std::max<size_t>(std::max(rows_lds_bytes(NW), fused_lds_bytes(NW, LP)),
                                         sizeof(double) * (7 * kFinalizeThreads + 16));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&admm_persist_kernel<NW, LP>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     return lds;
 }
@@ -1170,8 +1169,8 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
     RowsFwdArgs<float> a = a_in;
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         set_lds_attr<4>(&rows_fwd_kernel<4, false>);
         set_lds_attr<8>(&rows_fwd_kernel<8, false>);
         set_lds_attr<16>(&rows_fwd_kernel<16, false>);
@@ -1184,21 +1183,19 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
         set_lds_attr<4>(&rows_fwd_kernel<4, false, true, true>);
         set_lds_attr<8>(&rows_fwd_kernel<8, false, true, true>);
         set_lds_attr<16>(&rows_fwd_kernel<16, false, true, true>);
-        attr_set = true;
     }
     SA_REQUIRE(!(a.v && a.y_bcast), "the broadcast row pass has no V form");
     if (a.v && !(a.flags & F_JOINT) &&
         (a.wl1.ptr || (a.flags & F_NOBNDRY) || a.ams_bits)) {
         // the V form under an L1Weight array / NoBndryCross / AddMaskSim
-        static bool gattr = false;
-        if (!gattr) {
+        static PerDeviceOnce gattr;
+        if (gattr.first()) {
             set_lds_attr<4>(&rows_fwd_kernel<4, false, true, false, 1>);
             set_lds_attr<8>(&rows_fwd_kernel<8, false, true, false, 1>);
             set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 1>);
             set_lds_attr<4>(&rows_fwd_kernel<4, false, true, false, 2>);
             set_lds_attr<8>(&rows_fwd_kernel<8, false, true, false, 2>);
             set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 2>);
-            gattr = true;
         }
         SA_REQUIRE(a.C * a.N == a.CN, "the derivation needs the channel / image split");
         const dim3 grid = rows_grid(a, a.W / kN1, ceil_div(a.P, 128), a.H, 0);
@@ -1262,8 +1259,8 @@ static const float *device_one() {
 
 template <int NW, bool EMIT>
 static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, true, 0, EMIT>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 1, EMIT>);
@@ -1276,7 +1273,6 @@ static void launch_post_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 gr
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 1, EMIT, false, 2>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 2, EMIT, false, 1>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 2, EMIT, false, 2>);
-        attr_set = true;
     }
     const int mode = a.wl1.ptr != nullptr ? 1 : (((a.flags & F_NOBNDRY) || a.ams_bits) ? 2 : 0);
     const dim3 block(NW * 64);
@@ -1343,12 +1339,11 @@ template <> void launch_ams_pack<double>(hipStream_t, const Weight<double> &, ui
 
 template <int NW, bool EMIT>
 static void launch_post_joint_nw(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true, 1>);
         set_lds_attr<NW>(&rows_inv_post_kernel<NW, false, 0, EMIT, true, 2>);
-        attr_set = true;
     }
     if (a.v_out && a.v_in)
         hipLaunchKernelGGL((rows_inv_post_kernel<NW, false, 0, EMIT, true, 2>), grid, dim3(NW * 64),
@@ -1405,11 +1400,10 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
 
 template <int NW>
 static void launch_prox_nw(hipStream_t st, const RowsProxArgs<float> &a_in, dim3 grid) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         set_lds_attr<NW>(&rows_inv_prox_fwd_kernel<NW, false>);
         set_lds_attr<NW>(&rows_inv_prox_fwd_kernel<NW, true>);
-        attr_set = true;
     }
     // (a negative threshold -- a negative lambda: meaningless, but defined -- takes the variant
     // whose soft threshold makes no assumption about its sign)

@@ -634,11 +634,10 @@ template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
 
 template <typename T, int MODE, bool PACK, int POST = 0>
 int64_t launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n_outer) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK, POST>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
     }
     if (a.ncols <= 0 || n_outer <= 0) return 0;
     const Cfg cfg = pick_cfg<T>(plan.n, a.ncols);
@@ -838,8 +837,8 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
     a.partials = partials;
     const size_t lds = cols_sm_lds<T>(plan.n, K);
     const int threads = (int64_t)plan.n * K >= 4096 ? 1024 : 256;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[sizeof(T) == 8]) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         constexpr int UM = sizeof(T) == 8 ? 6 : 12;
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM / 3>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
@@ -847,7 +846,6 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set[sizeof(T) == 8] = true;
     }
     const int64_t tiles = (int64_t)Wf * CN;
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
