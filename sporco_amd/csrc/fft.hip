@@ -21,6 +21,7 @@
 #include "csc_post_elem.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace sporco_amd {
@@ -621,6 +622,18 @@ template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
     SA_REQUIRE((2 * (size_t)n * cols + n) * esz <= kLdsBudget,
                "transform length too large for the single-pass LDS FFT");
     while (cols > 1 && cols / 2 >= ncols) cols >>= 1;
+    // float32 lines of 192 < n < 512 points: 64-byte rows (8 columns).  At 16 columns such a tile
+    // takes 50-126 KiB of LDS and a CU holds one or two workgroups, whose load, transform and store
+    // phases then have nothing to overlap with; at 8 columns it holds three to five.  Measured
+    // (profiles/r04o_fft_cols.jsonl): the row and column passes of 240-, 320-, 384- and 480-point
+    // lines 17-28 % faster; 512-point columns and the float64 lines slower, so they keep 128 bytes.
+    static const int shift = std::getenv("SPORCO_AMD_FFT_COLS_SHIFT")     // (measurement knob)
+                                 ? std::atoi(std::getenv("SPORCO_AMD_FFT_COLS_SHIFT")) : -1;
+    if (shift >= 0) {
+        for (int i = 0; i < shift && cols > 1; ++i) cols >>= 1;
+    } else if (sizeof(T) == 4 && n < 512 && cols == 16 && (2 * (size_t)n * cols + n) * esz > 48 * 1024) {
+        cols = 8;
+    }
     int lpc = 1;
     while (lpc * 8 < n && lpc * 2 * cols <= 1024) lpc <<= 1;
     int threads = cols * lpc;
