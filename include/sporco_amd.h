@@ -408,7 +408,12 @@ typedef struct {
     int32_t hold;    /* backtracking trial: also out[PGM_LIN], out[PGM_DXY2] (the terms of
                         Q_L, backtrack.py:95-100); the new iterates are kept aside and the
                         call may be repeated with another L from the same Yf until
-                        sporco_amd_csc_pgm_commit adopts the last trial                   */
+                        sporco_amd_csc_pgm_commit adopts the last trial.  2: the same for a
+                        rule that forms Yf itself (BacktrackRobust, backtrack.py:162-208: Yf
+                        is set by sporco_amd_csc_lincomb before the call): no momentum
+                        output is written, and after the commit VAR_YF holds the Yf of the
+                        PREVIOUS iteration (what PGM.rsdl compares with, pgm.py:835-846,
+                        pgm/cbpdn.py:314-320) and VAR_YFPRV the one this trial used        */
 } sporco_amd_pgm_params;
 int sporco_amd_csc_pgm_iter(sporco_amd_csc_t h, const sporco_amd_pgm_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]);
@@ -428,7 +433,10 @@ int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uin
                                  int32_t dH, int32_t dW, double out[SPORCO_AMD_OUT_COUNT]);
 /* dst = a*va + b*vb + c*vc over complex state arrays (vb, vc may be -1):
  * the momentum step Yf = Xf + beta (Xf - Xfprv) (PGMDFT.ystep, pgm.py:815-831),
- * robust-backtracking and monotone combinations (backtrack.py:181-200). */
+ * robust-backtracking and monotone combinations (backtrack.py:181-200).  Between fused
+ * iterations (pgm_iter) a combination of iterates / scratch spectra (VAR_T0..T2) into VAR_YF
+ * or a scratch spectrum is formed in the internal tile-major layout, like pair_stats of such
+ * operands: the iterates stay where the fused kernels want them. */
 int sporco_amd_csc_lincomb(sporco_amd_csc_t h, int dst, double a, int va, double b, int vb,
                            double c, int vc);
 /* Statistics of d = va - vb (vb may be -1) and g = vg (may be -1):

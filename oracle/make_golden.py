@@ -347,6 +347,39 @@ def gen_pgm():
     pgm_case('pgm_multichan_f64', D, S3, 0.1, {'MaxMainIter': 30, 'L': 500.0})
 
 
+def gen_pgm_btrobust256():
+    """pgm.cbpdn.ConvBPDN with BacktrackRobust (sporco/pgm/backtrack.py:120-208) at a shape the
+    fused FISTA kernels serve (the inputs of gen_pgm_bt256): float32 and float64 reference runs
+    from L = 1 -- L grows by gamma_u over the first trials and shrinks by gamma_d every iteration."""
+    g = np.load(os.path.join(OUT, 'pgm_bt256_f32.npz'))
+    D, S = g['D'], g['S']
+    for tag, extra in (('f32', {'DataType': np.float32}), ('f64', {'DataType': np.float64})):
+        optd = {'MaxMainIter': 14, 'RelStopTol': 0.0, 'L': 1.0, 'Backtrack': BacktrackRobust()}
+        optd.update(extra)
+        b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.02, ref_pgm_cbpdn.ConvBPDN.Options(optd))
+        X = b.solve()
+        save('pgm_btrobust256_' + tag, D=D, S=S, lmbda=np.float64(0.02), X_sub=_strided(X),
+             X_l2=np.float64(np.linalg.norm(X.astype(np.float64))),
+             X_nnz=np.int64(np.count_nonzero(X)), L_final=np.float64(b.L), **itstat_dict(b))
+
+
+def gen_pgm_monotone256():
+    """pgm.cbpdn.ConvBPDN with Monotone (sporco/pgm/pgm.py:804-811, :826-829) at a shape the fused
+    FISTA kernels serve (the inputs of gen_pgm_bt256) and a step large enough (L = 8) that the
+    objective goes up in three of the 14 iterations and the reference falls back."""
+    g = np.load(os.path.join(OUT, 'pgm_bt256_f32.npz'))
+    D, S = g['D'], g['S']
+    for tag, extra in (('f32', {'DataType': np.float32}), ('f64', {'DataType': np.float64})):
+        optd = {'MaxMainIter': 14, 'RelStopTol': 0.0, 'L': 8.0, 'Monotone': True}
+        optd.update(extra)
+        b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.02, ref_pgm_cbpdn.ConvBPDN.Options(optd))
+        X = b.solve()
+        save('pgm_monotone256_' + tag, D=D, S=S, lmbda=np.float64(0.02), X_sub=_strided(X),
+             X_l2=np.float64(np.linalg.norm(X.astype(np.float64))),
+             Xf_l2=np.float64(np.linalg.norm(b.Xf.astype(np.complex128))),
+             Yf_l2=np.float64(np.linalg.norm(b.Yf.astype(np.complex128))), **itstat_dict(b))
+
+
 def gen_pgm_bt256():
     """pgm.cbpdn.ConvBPDN with BacktrackStandard at a shape the fused FISTA kernels serve
     (256x256, K = 8, 8x8 filters, one image), float32 and float64 reference runs from L = 1:
@@ -1341,6 +1374,6 @@ if __name__ == '__main__':
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
-             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
+             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pgm_btrobust256': gen_pgm_btrobust256, 'pgm_monotone256': gen_pgm_monotone256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

@@ -683,8 +683,10 @@ class Solver(object):
         """One fused default-option FISTA iteration (sporco_amd_csc_pgm_iter).  hold: a
         backtracking trial -- out[PGM_LIN], out[PGM_DXY2] too, and the new iterates wait for
         pgm_commit (the call may be repeated with another L)."""
+        # (hold = 2: a trial of a rule that forms Yf itself -- no momentum output; after the
+        # commit VAR_YF is the previous iteration's Yf and VAR_YFPRV the one this trial used)
         p = PgmParams(float(L), float(lmbda), float(beta), int(flags), int(dH), int(dW),
-                      1 if want_stats else 0, 1 if hold else 0)
+                      1 if want_stats else 0, int(hold))
         out = self._out()
         check(self._lib.sporco_amd_csc_pgm_iter(self._h, ctypes.byref(p), out))
         return list(out)

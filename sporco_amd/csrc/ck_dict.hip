@@ -122,16 +122,18 @@ __global__ void __launch_bounds__(kThreads) pair_stats_kernel(const cx<T> *__res
                                                               const cx<T> *__restrict__ b,
                                                               const cx<T> *__restrict__ g,
                                                               int64_t npix, int64_t cols, int Wf,
-                                                              int W, double *partials) {
+                                                              int W, double *partials, int64_t wf_div) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const int64_t total = npix * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = i / cols;
+        // (wf_div: the operands are tile-major (Wf, CN, H, K) -- the row frequency is the slowest
+        // index, wf_div = CN H K elements apart)
+        const int wf = wf_div ? (int)(i / wf_div) : (int)((i / cols) % Wf);
         cx<T> dlt = a[i];
         if (b) dlt = dlt - b[i];
         const double d2 = (double)cabs2(dlt);
-        acc[0] += parseval_weight((int)(pix % Wf), Wf, W) * d2;
+        acc[0] += parseval_weight(wf, Wf, W) * d2;
         acc[2] += d2;
         if (g) {
             const cx<T> gg = g[i];
@@ -144,11 +146,11 @@ __global__ void __launch_bounds__(kThreads) pair_stats_kernel(const cx<T> *__res
 
 template <typename T>
 int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *g, int64_t npix,
-                      int64_t cols, int W, double *partials) {
+                      int64_t cols, int W, double *partials, int64_t wf_div) {
     const int grid = grid_for(npix * cols);
     hipLaunchKernelGGL((pair_stats_kernel<T>), dim3(grid), dim3(kThreads),
                        sizeof(double) * 4 * (kThreads / kWave), st, a, b, g, npix, cols, W / 2 + 1,
-                       W, partials);
+                       W, partials, wf_div);
     SA_HIP(hipGetLastError());
     return grid;
 }
@@ -691,7 +693,7 @@ int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, d
     template int launch_pgm_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, cx<T> *, int64_t, int, int, int, double *); \
     template void launch_axpy_c<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, T, int64_t); \
     template void launch_lincomb<T>(hipStream_t, cx<T> *, T, const cx<T> *, T, const cx<T> *, T, const cx<T> *, int64_t); \
-    template int launch_pair_stats<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, int64_t, int64_t, int, double *); \
+    template int launch_pair_stats<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, int64_t, int64_t, int, double *, int64_t); \
     template int launch_dhs_absmax<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int, int, double *); \
     template int launch_ccmod_grad<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, cx<T> *, int64_t, int, int, int, double *, int, int); \
     template int launch_mask_apply<T>(hipStream_t, T *, const Weight<T> &, bool, int, int, int, int, double *); \

@@ -173,7 +173,7 @@ void launch_lincomb(hipStream_t st, cx<T> *dst, T a, const cx<T> *va, T b, const
 //   partial[2] = sum |a-b|^2, partial[3] = sum |g|^2
 template <typename T>
 int launch_pair_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *g, int64_t npix,
-                      int64_t cols, int W, double *partials);
+                      int64_t cols, int W, double *partials, int64_t wf_div = 0);
 
 // Dictionary-update gradient (pgm/ccmod.py:295-317), both contractions in one pass
 // over the coefficient spectra zf(npix, CN, K):

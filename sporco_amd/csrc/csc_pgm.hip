@@ -219,7 +219,11 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
     const BufRsrc Tb = make_rsrc(ap->t + (int64_t)tile * H * K, tbytes);
     const BufRsrc Xo = PLAIN ? Tb : make_rsrc(ap->xf_old + (int64_t)tile * H * K, tbytes);
     const BufRsrc Yo = PLAIN ? Tb : make_rsrc(ap->yf + (int64_t)tile * H * K, tbytes);
-    const BufRsrc Yn = PLAIN ? Tb : make_rsrc(ap->yf_new + (int64_t)tile * H * K, tbytes);
+    // (a null yf_new -- a rule that forms Yf itself, pgm_iter hold == 2 -- makes the descriptor empty:
+    // the stores are out of range and cost no traffic)
+    const BufRsrc Yn = PLAIN ? Tb
+                             : make_rsrc(ap->yf_new ? ap->yf_new + (int64_t)tile * H * K : nullptr,
+                                         ap->yf_new ? tbytes : 0u);
     const BufRsrc Db = make_rsrc(ap->dft + (int64_t)wf * H * K, tbytes);
     const cf *S = ap->sft + (int64_t)tile * H + w;
     const cf *EY = BT ? ap->ey + (int64_t)tile * H + w : nullptr;

@@ -17,7 +17,7 @@ import copy
 import numpy as np
 
 from . import pgm
-from .backtrack import BacktrackStandard
+from .backtrack import BacktrackStandard, BacktrackRobust
 from .. import _lib
 from .. import cnvrep as cr
 from ..admm.cbpdn import _DeviceArray, _broadcastable
@@ -180,10 +180,12 @@ class ConvBPDN(pgm.PGMDFT):
                    'eval_linear_approx', 'hess_quad')
 
     def _fused_ok(self):
-        # (BacktrackStandard itself, not a subclass: a subclass may change the search)
+        # (BacktrackStandard / BacktrackRobust themselves, not subclasses: a subclass may change
+        # the search)
         bt = self.opt['Backtrack']
-        if (bt is not None and type(bt) is not BacktrackStandard) or self.stepsizepolicy is not None \
-                or self.opt['Monotone'] or not self.dev.uses_fused_pgm():
+        if (bt is not None and type(bt) not in (BacktrackStandard, BacktrackRobust)) \
+                or self.stepsizepolicy is not None \
+                or (self.opt['Monotone'] and bt is not None) or not self.dev.uses_fused_pgm():
             return False
         for name in self._hook_names:
             if name in self.__dict__ or getattr(type(self), name) is not getattr(ConvBPDN, name):
@@ -201,12 +203,16 @@ class ConvBPDN(pgm.PGMDFT):
         if not self._fused_ok():
             self._fused_sums = None
             return False
+        bt = self.opt['Backtrack']
+        lm = float(self.lmbda) * self._wl1_scalar
+        if type(bt) is BacktrackRobust:
+            return self._fused_robust(bt, lm)
+        if self.opt['Monotone']:
+            return self._fused_monotone(lm)
         tprv = self.t
         self.t = self.momentum.update(self.var_momentum())
         beta = (tprv - 1.) / self.t
         stats = not self.opt['FastSolve']
-        bt = self.opt['Backtrack']
-        lm = float(self.lmbda) * self._wl1_scalar
         if bt is None:
             out = self.dev.pgm_iter(self.L, lm, beta, self._iter_flags(), self.D.shape[0],
                                     self.D.shape[1], stats)
@@ -233,6 +239,88 @@ class ConvBPDN(pgm.PGMDFT):
         self._fcache[_lib.VAR_YFPRV] = out[_lib.PGM_FY]
         if stats:
             self._fcache[_lib.VAR_XF] = out[_lib.PGM_F]
+        return True
+
+    def _fused_monotone(self, lm):
+        """One iteration of monotone FISTA (pgm.py:804-811, :826-829) on the fused kernels: a held
+        trial, the objective at the new X from its sums, the commit -- and, when the objective
+        went up, the reference's fall-back to the previous iterate composed from the staged
+        calls (Xf = Xfprv, Yf = Xf + (t_prev/t)(ZZf - Xf); rare, and the next iteration re-enters
+        the fused regime).  An accepted step IS the standard one: ZZf = Xf.  The first iteration
+        evaluates the objective at the initial state (pgm.py:843-846): left to the staged loop."""
+        if self.k == 0:
+            self._fused_sums = None
+            return False
+        self.objfn_prev = self.objfn
+        tprv = self.t
+        self.t = self.momentum.update(self.var_momentum())
+        beta = (tprv - 1.) / self.t
+        dev = self.dev
+        out = dev.pgm_iter(self.L, lm, beta, self._iter_flags(), self.D.shape[0], self.D.shape[1],
+                           True, hold=True)
+        self._fused_sums = out
+        self._rl1 = abs(self._wl1_scalar) * out[_lib.PGM_L1]
+        self._cache.clear()
+        self._fcache.clear()
+        self._fcache[_lib.VAR_YFPRV] = out[_lib.PGM_FY]
+        self._fcache[_lib.VAR_XF] = out[_lib.PGM_F]
+        self.objfn = self.eval_objfn()
+        dev.pgm_commit()
+        if self.objfn_prev[0] < self.objfn[0]:
+            v = self._v
+            dev.copy(v['t2'], v['x'])                 # ZZf = Xf.copy()
+            dev.copy(v['x'], v['xprv'])               # Xf = Xfprv
+            gamma = tprv / self.t
+            dev.lincomb(v['y'], 1.0 + beta - gamma, v['x'], -beta, v['xprv'], gamma, v['t2'])
+            self.objfn = self.objfn_prev
+            self._fused_sums = None                   # (rsdl: Xf - Yfprv of the restored iterate)
+            self._cache.clear()
+            self._fcache.clear()
+        return True
+
+    def _fused_robust(self, bt, lm):
+        """One iteration under BacktrackRobust (backtrack.py:162-208) on the fused kernels:
+        y = (Tk xprv + t Z) / T is formed on the device in the layout the iterates are in
+        (lincomb), the trial is the held call of the standard rule with no momentum output
+        (hold = 2), Z += t L (x - y) follows the commit.  xprv of the reference is X at the
+        start of the iteration (pgm.py:835-846), i.e. the device's current Xf; the residual
+        compares the new X with the Y the iteration STARTED from (pgm/cbpdn.py:314-320),
+        which after the commit is what VAR_YF holds."""
+        dev = self.dev
+        Z = self.scratch(2)
+        if not bt.have_z:
+            dev.copy(Z, _lib.VAR_XF)
+            dev.copy(_lib.VAR_YFPRV, _lib.VAR_YF)      # (on_iteration_start of the first iteration)
+            bt.have_z = True
+        self.L *= bt.gamma_d
+        it = 0
+        while True:
+            t = float(1. + np.sqrt(1. + 4. * self.L * bt.Tk)) / (2. * self.L)
+            T = bt.Tk + t
+            dev.lincomb(_lib.VAR_YF, bt.Tk / T, _lib.VAR_XF, t / T, Z)
+            out = dev.pgm_iter(self.L, lm, 0.0, self._iter_flags(), self.D.shape[0],
+                               self.D.shape[1], True, hold=2)
+            f = out[_lib.PGM_F]
+            Q = out[_lib.PGM_FY] + out[_lib.PGM_LIN] + (self.L / 2.) * out[_lib.PGM_DXY2]
+            it += 1
+            if f <= Q or it >= bt.maxiter:
+                if f > Q:
+                    self.L *= bt.gamma_u
+                break
+            self.L *= bt.gamma_u
+        dev.pgm_commit()
+        bt.Tk = T
+        tl = t * float(self.L)
+        dev.lincomb(Z, 1.0, Z, tl, _lib.VAR_XF, -tl, _lib.VAR_YFPRV)
+        self.F, self.Q, self.iterBTrack = f, Q, it
+        if not self.opt['FastSolve']:
+            out = list(out)
+            out[_lib.PGM_RSDL] = dev.pair_stats(_lib.VAR_XF, _lib.VAR_YF)[0]
+        self._fused_sums = out
+        self._rl1 = abs(self._wl1_scalar) * out[_lib.PGM_L1]
+        self._cache.clear()
+        self._fcache.clear()
+        self._fcache[_lib.VAR_XF] = out[_lib.PGM_F]
         return True
 
     def rsdl(self):

@@ -166,10 +166,45 @@ def test_fused_backtracking_against_the_reference(backend):
             assert rel_l2(X[::16, ::16], g['X_sub']) < tol
             assert abs(np.linalg.norm(X.astype(np.float64)) - float(g['X_l2'])) < tol * float(g['X_l2'])
             assert abs(float(b.L) - float(g['L_final'])) < 1e-6 * float(g['L_final'])
-    # a search the fused call does not restate (robust backtracking) composes the staged calls
-    optr = dict(optd, Backtrack=BacktrackRobust(), MaxMainIter=1)
+    # a search the fused call does not restate (a subclass of the rules) composes the staged calls
+    class MyRule(BacktrackRobust):
+        pass
+    optr = dict(optd, Backtrack=MyRule(), MaxMainIter=1)
     br = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optr))
     assert not br._fused_ok()
+
+
+def test_fused_robust_backtracking_against_the_reference(backend):
+    """BacktrackRobust (sporco/pgm/backtrack.py:120-208) on the fused kernels: Yf = (Tk Xf + t Z) / T
+    formed on the device in the tile-major layout, a held trial without momentum output per L,
+    Z += t L (Xf - Yf) after the commit, the residual against the Yf the iteration started from --
+    against the reference's own float32 and float64 runs (tests/golden/pgm_btrobust256_*.npz) and
+    against the staged composition of the same library."""
+    from conftest import load_golden
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackRobust
+    g32, g64 = load_golden('pgm_btrobust256_f32'), load_golden('pgm_btrobust256_f64')
+    iters = 4 if backend == 'hostsim' else 14
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 1.0, 'Backtrack': BacktrackRobust()}
+    b = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optd))
+    assert b._fused_ok()
+    b.dev.profile(True)
+    X = b.solve()
+    prof = b.dev.profile_read()
+    assert prof['pgm_fft_momentum'][1] >= iters          # (the trials ran on the fused kernels)
+    its = b.getitstat()
+    for g, tol in ((g32, 5e-5), (g64, 1e-4)):
+        assert np.array_equal(np.asarray(its.IterBTrack, float), g['it_IterBTrack'][:iters])
+        for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L', 'F_Btrack', 'Q_Btrack'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f][:iters]) < tol, f
+        if iters == 14:
+            assert rel_l2(X[::16, ::16], g['X_sub']) < tol
+            assert abs(float(b.L) - float(g['L_final'])) < 1e-6 * float(g['L_final'])
+    # continuing the solve (restart from the state the first call left) and reading the iterates
+    b.opt['MaxMainIter'] = 2
+    b.solve()
+    assert np.all(np.isfinite(np.asarray(b.getitstat().ObjFun, float)))
+    assert rel_l2(np.asarray(b.Xf), np.fft.rfft2(np.asarray(b.X, np.float64), axes=(0, 1))) < 1e-5
 
 
 @pytest.mark.gpu
@@ -187,3 +222,31 @@ def test_backtracking_fused_and_composed_agree(gpu_backend, K):
     for f in ('L', 'IterBTrack', 'F_Btrack', 'Q_Btrack', 'ObjFun', 'Rsdl'):
         assert rel_l2(np.asarray(getattr(b.getitstat(), f), float),
                       np.asarray(getattr(b0.getitstat(), f), float)) < 1e-5, f
+
+
+def test_fused_monotone_fista_against_the_reference(backend):
+    """Monotone FISTA (sporco/pgm/pgm.py:804-811, :826-829) on the fused kernels: a held trial, the
+    objective from its sums, the commit, and the reference's fall-back (composed from the staged
+    calls) in the iterations where the objective went up -- three of the 14 of the reference's
+    own float32 / float64 runs at L = 8 (tests/golden/pgm_monotone256_*.npz)."""
+    from conftest import load_golden
+    from sporco_amd.pgm import cbpdn as pc
+    g32, g64 = load_golden('pgm_monotone256_f32'), load_golden('pgm_monotone256_f64')
+    o = g64['it_ObjFun']
+    assert int(np.sum(o[1:] == o[:-1])) == 3 and o[3] == o[2]        # (the third step is one of them)
+    iters = 5 if backend == 'hostsim' else 14
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 8.0, 'Monotone': True}
+    b = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optd))
+    assert b._fused_ok()
+    b.dev.profile(True)
+    X = b.solve()
+    prof = b.dev.profile_read()
+    assert prof['pgm_fft_momentum'][1] == iters - 1      # (all but the first iteration)
+    its = b.getitstat()
+    for g, tol in ((g32, 5e-5), (g64, 1e-4)):
+        for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f][:iters]) < tol, f
+        if iters == 14:
+            assert rel_l2(X[::16, ::16], g['X_sub']) < tol
+            assert abs(np.linalg.norm(np.asarray(b.Xf).astype(np.complex128)) - float(g['Xf_l2'])) < tol * float(g['Xf_l2'])
+            assert abs(np.linalg.norm(np.asarray(b.Yf).astype(np.complex128)) - float(g['Yf_l2'])) < tol * float(g['Yf_l2'])

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""pgm.cbpdn.ConvBPDN at config 4's shape (512x512, K=64, N=32) under the step-size rules: fixed L,
+BacktrackStandard, BacktrackRobust on the fused kernels, and BacktrackRobust composed from the
+staged calls (a subclass of the rule: the fused iteration does not restate a rule it does not
+know).  One JSON line per variant."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from sporco_amd.pgm import cbpdn as pc
+from sporco_amd.pgm.backtrack import BacktrackStandard, BacktrackRobust
+
+
+class StagedRobust(BacktrackRobust):
+    pass
+
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+D, S = bench.make_problem(512, 512, 64, N, 0)
+for name, bt in (('fixed L', None), ('BacktrackStandard (fused)', BacktrackStandard()),
+                 ('BacktrackRobust (fused)', BacktrackRobust()),
+                 ('BacktrackRobust (staged composition)', StagedRobust())):
+    optd = {'MaxMainIter': 5, 'RelStopTol': 0.0, 'L': 500.0}
+    if bt is not None:
+        optd['Backtrack'] = bt
+    b = pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(optd))
+    b._return_min = False
+    b.solve(); b.dev.sync()
+    b.opt['MaxMainIter'] = 20
+    t0 = time.perf_counter(); b.solve(); b.dev.sync()
+    dt = time.perf_counter() - t0
+    st = b.getitstat()
+    print(json.dumps({'config': 'pgm.cbpdn.ConvBPDN 512x512 K=64 N=%d f32, %s' % (N, name),
+                      'fused': bool(b._fused_ok()), 'it_per_s': 20 / dt,
+                      'trials_per_iteration': (float(np.mean(st.IterBTrack[-20:])) if bt is not None else None),
+                      'L_final': float(b.L), 'ObjFun_final': float(st.ObjFun[-1])}))
+    del b
