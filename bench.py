@@ -441,6 +441,89 @@ def run_other_configs(device, which, tiny=False):
     return out
 
 
+def run_next_rows(device, tiny=False):
+    """Short driver-timed legs for what is built beyond the BASELINE configurations (SURVEY 8(f)
+    rows, PGM step-size rules, the generic chain every size / precision outside the register
+    kernels runs): iterations/s with everything resident, 3 warm-up + 20 timed iterations each.
+    Parity of these paths: tests/ (fixtures of the unmodified reference); here only the rate and
+    which kernels served it."""
+    import gc
+    from sporco_amd.admm import cbpdn as ac
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackRobust
+    rng = np.random.RandomState(12345)
+    H = 128 if tiny else 512
+    K, N8 = (8, 2) if tiny else (64, 8)
+
+    def rate(b, dev, iters=20):
+        b._return_min = False
+        b.opt['MaxMainIter'] = 3
+        b.solve()
+        dev.sync()
+        b.opt['MaxMainIter'] = iters
+        t0 = time.perf_counter()
+        b.solve()
+        dev.sync()
+        return iters / (time.perf_counter() - t0)
+
+    D = rng.randn(8, 8, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, H, N8).astype(np.float32)
+    Wm = (rng.rand(H, H, N8) > 0.3).astype(np.float32)
+    o0 = {'MaxMainIter': 3, 'RelStopTol': 0.0}
+
+    def leg_maskdcpl():
+        b = ac.ConvBPDNMaskDcpl(D, S, 0.05, Wm, ac.ConvBPDNMaskDcpl.Options(o0), device=device)
+        return {'workload': 'admm.cbpdn.ConvBPDNMaskDcpl %dx%d K=%d N=%d f32' % (H, H, K, N8),
+                'value': rate(b, b._dev), 'unit': 'iterations/s',
+                'path': 'register-resident kernels' if b._dev.uses_fused_rows() else 'generic chain'}
+
+    def leg_pgm_mask():
+        b = pc.ConvBPDNMask(D, S, 0.05, Wm, pc.ConvBPDNMask.Options(dict(o0, L=500.0)), device=device)
+        return {'workload': 'pgm.cbpdn.ConvBPDNMask %dx%d K=%d N=%d f32' % (H, H, K, N8),
+                'value': rate(b, b.dev), 'unit': 'iterations/s',
+                'path': 'fused iteration' if b._fused_ok() else 'staged composition'}
+
+    def leg_pgm_robust():
+        n = 2 if tiny else 32
+        Dc, Sc = make_problem(H, H, K, n, 0)
+        b = pc.ConvBPDN(Dc, Sc, 0.05, pc.ConvBPDN.Options(dict(o0, L=500.0, Backtrack=BacktrackRobust())),
+                        device=device)
+        return {'workload': 'pgm.cbpdn.ConvBPDN %dx%d K=%d N=%d f32, BacktrackRobust' % (H, H, K, n),
+                'value': rate(b, b.dev), 'unit': 'iterations/s',
+                'path': 'fused iteration' if b._fused_ok() else 'staged composition'}
+
+    def leg_generic(h, w, k, dt):
+        def go():
+            r2 = np.random.RandomState(1)
+            Dg = r2.randn(8, 8, k).astype(dt)
+            Sg = r2.randn(h, w, N8).astype(dt)
+            b = ac.ConvBPDN(Dg, Sg, 0.05, ac.ConvBPDN.Options(o0), device=device)
+            return {'workload': 'admm.cbpdn.ConvBPDN %dx%d K=%d N=%d %s (outside the register kernels)'
+                                % (h, w, k, N8, np.dtype(dt).name),
+                    'value': rate(b, b._dev), 'unit': 'iterations/s',
+                    'path': 'register-resident kernels' if b._dev.uses_fused_rows() else
+                            'generic chain (single-array state, fused column pass where the tile fits)'}
+        return go
+
+    legs = {'maskdcpl': leg_maskdcpl, 'pgm_mask': leg_pgm_mask, 'pgm_backtrack_robust': leg_pgm_robust}
+    if tiny:
+        legs['generic_48x40_k8_f32'] = leg_generic(48, 40, 8, np.float32)
+        legs['generic_32x32_k8_f64'] = leg_generic(32, 32, 8, np.float64)
+    else:
+        legs['generic_384x384_k32_f32'] = leg_generic(384, 384, 32, np.float32)
+        legs['generic_240x320_k64_f32'] = leg_generic(240, 320, 64, np.float32)
+        legs['generic_256x256_k32_f64'] = leg_generic(256, 256, 32, np.float64)
+    out = {}
+    for name, fn in legs.items():
+        try:
+            out[name] = fn()
+        except Exception as e:   # a failing side leg must not cost the headline line
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        gc.collect()
+    return out
+
+
 def reference_cpu_baseline(H, W, K, n_full, seconds):
     """The UNMODIFIED reference timed on this host (oracle/time_reference.py, a subprocess: this
     process never imports it).  None when oracle/_ref was not staged."""
@@ -901,6 +984,8 @@ def main():
     }
     if world == 1 and args.configs != 'none':
         line['configs'] = run_other_configs(local_rank, args.configs, tiny=args.tiny)
+    if world == 1 and args.configs == 'all':
+        line['next_rows'] = run_next_rows(local_rank, tiny=args.tiny)
     if world == 1 and not args.no_time_to_tol:
         line['time_to_tol'] = time_to_tol(cbpdn, H, W, K, N, local_rank)
     if world == 1 and not args.no_cpu_baseline:
