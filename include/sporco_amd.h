@@ -445,6 +445,20 @@ int sporco_amd_csc_lincomb(sporco_amd_csc_t h, int dst, double a, int va, double
  *   out[2] = sum |d|^2           out[3] = sum |g|^2 */
 int sporco_amd_csc_pair_stats(sporco_amd_csc_t h, int va, int vb, int vg,
                               double out[SPORCO_AMD_OUT_COUNT]);
+/* Residual spectra for the step-size policies (sporco/pgm/stepsize.py:67-145), so that they run
+ * beside the fused iteration without an X-sized gradient array: the gradient at v is
+ * g = conj(Df) e with e = sum_m Df v - Sf (grad_f, pgm/cbpdn.py:263-279), signal sized.
+ * pgm_resid stores e of the X-sized spectrum `var` in slot 0..3 (one read pass; shapes the fused
+ * kernels serve, single-channel dictionary).  pgm_resid_stats: with d1 = e[a] - e[b],
+ * d2 = e[c] - e[d] (b, c, d may be -1; c = -1: d2 = d1) and G = sum_m |Df|^2,
+ *   out[0] = sum G |d1|^2        = <g1, g1>                (StepSizePolicyCauchy den, BB num)
+ *   out[1] = sum G^2 |d1|^2      = <g1, hessian_f(g1)>     (StepSizePolicyCauchy num, :84-87)
+ *   out[2] = sum Re(conj(d2) d1) = <dx, dg> for iterates whose residuals differ by d2 and
+ *            gradients by conj(Df) d1                      (StepSizePolicyBB den, :137-141)
+ * summed over the rfftn arrays as they are (no Parseval weights), as the reference's np.sum does. */
+int sporco_amd_csc_pgm_resid(sporco_amd_csc_t h, int var, int slot);
+int sporco_amd_csc_pgm_resid_stats(sporco_amd_csc_t h, int a, int b, int c, int d,
+                                   double out[SPORCO_AMD_OUT_COUNT]);
 /* cplx_var = rfftn(real_var) / real_var = irfftn(cplx_var) between X-sized state
  * arrays (Xf = rfftn(X), pgm/cbpdn.py:231; Zf = rfftn(Z), pgm/ccmod.py:264-279). */
 int sporco_amd_csc_fft_var(sporco_amd_csc_t h, int real_var, int cplx_var);

@@ -380,6 +380,24 @@ def gen_pgm_monotone256():
              Yf_l2=np.float64(np.linalg.norm(b.Yf.astype(np.complex128))), **itstat_dict(b))
 
 
+def gen_pgm_stepsize256():
+    """pgm.cbpdn.ConvBPDN under StepSizePolicyCauchy and StepSizePolicyBB
+    (sporco/pgm/stepsize.py:67-145) at a shape the fused FISTA kernels serve (the inputs of
+    gen_pgm_bt256): float32 and float64 reference runs; L is the policy's from the third
+    iteration on."""
+    g = np.load(os.path.join(OUT, 'pgm_bt256_f32.npz'))
+    D, S = g['D'], g['S']
+    for pname, pol in (('cauchy', StepSizePolicyCauchy), ('bb', StepSizePolicyBB)):
+        for tag, extra in (('f32', {'DataType': np.float32}), ('f64', {'DataType': np.float64})):
+            optd = {'MaxMainIter': 14, 'RelStopTol': 0.0, 'L': 50.0, 'StepSizePolicy': pol()}
+            optd.update(extra)
+            b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.02, ref_pgm_cbpdn.ConvBPDN.Options(optd))
+            X = b.solve()
+            save('pgm_step%s256_%s' % (pname, tag), D=D, S=S, lmbda=np.float64(0.02), X_sub=_strided(X),
+                 X_l2=np.float64(np.linalg.norm(X.astype(np.float64))), L_final=np.float64(b.L),
+                 **itstat_dict(b))
+
+
 def gen_pgm_bt256():
     """pgm.cbpdn.ConvBPDN with BacktrackStandard at a shape the fused FISTA kernels serve
     (256x256, K = 8, 8x8 filters, one image), float32 and float64 reference runs from L = 1:
@@ -1374,6 +1392,6 @@ if __name__ == '__main__':
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
-             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pgm_btrobust256': gen_pgm_btrobust256, 'pgm_monotone256': gen_pgm_monotone256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
+             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pgm_btrobust256': gen_pgm_btrobust256, 'pgm_monotone256': gen_pgm_monotone256, 'pgm_stepsize256': gen_pgm_stepsize256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

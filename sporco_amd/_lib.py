@@ -67,6 +67,7 @@ EXPORTS = (
     'sporco_amd_csc_pgm_grad', 'sporco_amd_csc_pgm_eval', 'sporco_amd_csc_pgm_prox_step',
     'sporco_amd_csc_pgm_iter', 'sporco_amd_csc_pgm_commit',
     'sporco_amd_csc_lincomb', 'sporco_amd_csc_pair_stats', 'sporco_amd_csc_copy',
+    'sporco_amd_csc_pgm_resid', 'sporco_amd_csc_pgm_resid_stats',
     'sporco_amd_csc_fft_var', 'sporco_amd_csc_ifft_var',
     'sporco_amd_csc_ccmod_setcoef', 'sporco_amd_csc_ccmod_grad', 'sporco_amd_csc_ccmod_eval',
     'sporco_amd_csc_ccmod_prox_step', 'sporco_amd_csc_ccmod_cnstr',
@@ -259,6 +260,8 @@ def load(path=None):
         'sporco_amd_csc_lincomb': [vp, ctypes.c_int, dbl, ctypes.c_int, dbl, ctypes.c_int, dbl,
                                    ctypes.c_int],
         'sporco_amd_csc_pair_stats': [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, dptr],
+        'sporco_amd_csc_pgm_resid': [vp, ctypes.c_int, ctypes.c_int],
+        'sporco_amd_csc_pgm_resid_stats': [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dptr],
         'sporco_amd_csc_copy': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_fft_var': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_ifft_var': [vp, ctypes.c_int, ctypes.c_int],
@@ -779,6 +782,16 @@ class Solver(object):
         out = self._out()
         check(self._lib.sporco_amd_csc_pair_stats(self._h, va, vb, vg, out))
         return list(out)[:4]
+
+    def pgm_resid(self, var, slot):
+        """e = sum_m Df var - Sf into residual slot 0..3 (sporco_amd_csc_pgm_resid)."""
+        check(self._lib.sporco_amd_csc_pgm_resid(self._h, var, slot))
+
+    def pgm_resid_stats(self, a, b=-1, c=-1, d=-1):
+        """(<g1, g1>, <g1, H g1>, <dx, dg>) from residual slots (sporco_amd_csc_pgm_resid_stats)."""
+        out = self._out()
+        check(self._lib.sporco_amd_csc_pgm_resid_stats(self._h, a, b, c, d, out))
+        return list(out)[:3]
 
     def copy(self, dst, src):
         check(self._lib.sporco_amd_csc_copy(self._h, dst, src))

@@ -535,6 +535,51 @@ void launch_tiled_resid(hipStream_t st, const cx<T> *v, const cx<T> *dft, const 
     SA_HIP(hipGetLastError());
 }
 
+// Sums over signal-sized residual spectra e = sum_k Df v - Sf in the tile-major layout
+// (Wf CN, H) -- what the step-size policies need of the gradient g = conj(Df) e without forming it
+// (sporco/pgm/stepsize.py:67-145): with d1 = a - b, d2 = c - d (b, d may be null; c null: d2 = d1)
+// and G = sum_k |Df|^2 of the frequency,
+//   [0] sum G |d1|^2  = <g1, g1>      [1] sum G^2 |d1|^2 = <g1, hessian_f(g1)>
+//   [2] sum Re(conj(d2) d1) = <x2, g1> for a difference of iterates x2 whose residual difference is d2
+// over the half-spectrum array, unweighted (the policies sum the rfftn arrays as they are).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) resid_stats_kernel(const cx<T> *__restrict__ a,
+                                                               const cx<T> *__restrict__ b,
+                                                               const cx<T> *__restrict__ c,
+                                                               const cx<T> *__restrict__ d,
+                                                               const T *__restrict__ gramt, int64_t nrows,
+                                                               int H, int CN, double *partials) {
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < nrows;
+         row += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t tile = row / H;
+        const int h = (int)(row - tile * H);
+        const double g = (double)gramt[(tile / CN) * H + h];
+        cx<T> d1 = a[row];
+        if (b) d1 = d1 - b[row];
+        cx<T> d2 = d1;
+        if (c) {
+            d2 = c[row];
+            if (d) d2 = d2 - d[row];
+        }
+        const double m = (double)cabs2(d1);
+        acc[0] += g * m;
+        acc[1] += g * g * m;
+        acc[2] += (double)d2.re * (double)d1.re + (double)d2.im * (double)d1.im;
+    }
+    block_sum_store<3>(acc, dyn_lds<double>(), partials + (int64_t)blockIdx.x * 3);
+}
+template <typename T>
+int launch_resid_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *c, const cx<T> *d,
+                       const T *gramt, int64_t ntiles, int H, int CN, double *partials) {
+    const int grid = grid_for(ntiles * H);
+    hipLaunchKernelGGL((resid_stats_kernel<T>), dim3(grid), dim3(kThreads),
+                       sizeof(double) * 3 * (kThreads / kWave), st, a, b, c, d, gramt, ntiles * H, H, CN,
+                       partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
 // Dual residual of the mask-decoupled X-step on the TILE-MAJOR layout of the fused kernels
 // (csc_fused.h): sum over (tile, h, k) of pw(wf) |conj(dft[wf][h][k]) u0t[tile][h] + t[tile][h][k]|^2
 // with t the 2-D spectrum of u1 and u0t that of u0 -- rho^2 ||A^T u||^2 H W without its factors
@@ -707,7 +752,8 @@ int launch_cns_ystats(hipStream_t st, const T *yold, const T *ynew, int64_t n, d
     template int launch_cns_ustep<T>(hipStream_t, const T *, T *, const T *, const T *, T, T, int64_t, int, int, double *); \
     template int launch_cns_ystats<T>(hipStream_t, const T *, const T *, int64_t, double *); \
     template void launch_tiled_resid<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, cx<T> *, int64_t, int, int, int, int); \
-    template int launch_md_dualres_tiled<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, int64_t, int, int, int, int, int, double *);
+    template int launch_md_dualres_tiled<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, int64_t, int, int, int, int, int, double *); \
+    template int launch_resid_stats<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *, const T *, int64_t, int, int, double *);
 SA_INST(float)
 SA_INST(double)
 

@@ -352,6 +352,24 @@ int sporco_amd_csc_pair_stats(sporco_amd_csc_t h, int va, int vb, int vg,
     SA_API_END
 }
 
+int sporco_amd_csc_pgm_resid(sporco_amd_csc_t h, int var, int slot) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->pgm_resid(var, slot);
+    SA_API_END
+}
+
+int sporco_amd_csc_pgm_resid_stats(sporco_amd_csc_t h, int a, int b, int c, int d,
+                                   double out[SPORCO_AMD_OUT_COUNT]) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(out != nullptr, "out is null");
+    double *sb = stats_buf(h);
+    h->impl->pgm_resid_stats(a, b, c, d, sb);
+    h->impl->read_out(sb, out);
+    SA_API_END
+}
+
 int sporco_amd_csc_fft_var(sporco_amd_csc_t h, int real_var, int cplx_var) {
     SA_API_BEGIN
     SA_HANDLE(h);

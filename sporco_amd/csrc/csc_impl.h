@@ -183,6 +183,8 @@ struct CscBase {
                                double *out_dev) = 0;
     virtual void lincomb(int dst, double a, int va, double b, int vb, double c, int vc) = 0;
     virtual void pair_stats(int va, int vb, int vg, double *out_dev) = 0;
+    virtual void pgm_resid(int var, int slot) = 0;
+    virtual void pgm_resid_stats(int a, int b, int c, int d, double *out_dev) = 0;
     virtual void copy(int dst, int src) = 0;
     virtual void ccmod_setcoef(int var) = 0;
     virtual void ccmod_grad(int var, bool write_grad, double *out_dev) = 0;

@@ -289,6 +289,10 @@ void launch_tiled_resid(hipStream_t st, const cx<T> *v, const cx<T> *dft, const 
 template <typename T>
 int launch_md_dualres_tiled(hipStream_t st, const cx<T> *t, const cx<T> *dft, const cx<T> *u0t,
                             int64_t ntiles, int H, int K, int Ks, int CN, int W, double *partials);
+// sums over tile-major residual spectra for the PGM step-size policies (ck_dict.hip)
+template <typename T>
+int launch_resid_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *c, const cx<T> *d,
+                       const T *gramt, int64_t ntiles, int H, int CN, double *partials);
 // dst[(pix, c), n, k] = zch ? src[pix, n, c, k] : src[pix, n, k]  (npix Cd "frequencies" of a
 // single-channel dictionary update: api_dstep.inc)
 template <typename T>

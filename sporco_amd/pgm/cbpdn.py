@@ -18,6 +18,7 @@ import numpy as np
 
 from . import pgm
 from .backtrack import BacktrackStandard, BacktrackRobust
+from .stepsize import StepSizePolicyCauchy, StepSizePolicyBB
 from .. import _lib
 from .. import cnvrep as cr
 from ..admm.cbpdn import _DeviceArray, _broadcastable
@@ -183,10 +184,14 @@ class ConvBPDN(pgm.PGMDFT):
         # (BacktrackStandard / BacktrackRobust themselves, not subclasses: a subclass may change
         # the search)
         bt = self.opt['Backtrack']
+        pol = self.stepsizepolicy
         if (bt is not None and type(bt) not in (BacktrackStandard, BacktrackRobust)) \
-                or self.stepsizepolicy is not None \
-                or (self.opt['Monotone'] and bt is not None) or not self.dev.uses_fused_pgm():
+                or (pol is not None and type(pol) not in (StepSizePolicyCauchy, StepSizePolicyBB)) \
+                or (self.opt['Monotone'] and (bt is not None or pol is not None)) \
+                or not self.dev.uses_fused_pgm():
             return False
+        if pol is not None and (self.cri.Cd > 1 or self.cri.M % 2):
+            return False     # (the residual slots: single-channel dictionary, unpadded filter axis)
         for name in self._hook_names:
             if name in self.__dict__ or getattr(type(self), name) is not getattr(ConvBPDN, name):
                 return False
@@ -209,6 +214,9 @@ class ConvBPDN(pgm.PGMDFT):
             return self._fused_robust(bt, lm)
         if self.opt['Monotone']:
             return self._fused_monotone(lm)
+        if self.stepsizepolicy is not None and not self._fused_stepsize():
+            self._fused_sums = None
+            return False
         tprv = self.t
         self.t = self.momentum.update(self.var_momentum())
         beta = (tprv - 1.) / self.t
@@ -239,6 +247,42 @@ class ConvBPDN(pgm.PGMDFT):
         self._fcache[_lib.VAR_YFPRV] = out[_lib.PGM_FY]
         if stats:
             self._fcache[_lib.VAR_XF] = out[_lib.PGM_F]
+        return True
+
+    def _fused_stepsize(self):
+        """StepSizePolicyCauchy / StepSizePolicyBB (stepsize.py:67-145) beside the fused iteration.
+        The gradient at v is conj(Df) e(v) with e(v) = sum_m Df v - Sf, signal sized: one read
+        pass over Yf (and, for BB, over Xf) leaves e in a residual slot, and
+            <g, g> = sum G |e|^2,  <g, hessian_f g> = sum G^2 |e|^2,  G = sum_m |Df|^2,
+            <dx, dg> = sum Re(conj(e(x) - e(xprv)) (e(y) - e(yprv)))
+        are sums over those (sporco_amd_csc_pgm_resid / _pgm_resid_stats): no X-sized gradient
+        array, 10 (Cauchy) / 11 (BB) passes an iteration instead of the staged composition's ~25.
+        L changes from the third iteration on (pgm.py:790-792); BB records its two-point state
+        from the first.  Returns False when BB's previous point is not in the slots (a restored
+        object): that iteration is composed from the staged calls."""
+        pol, dev = self.stepsizepolicy, self.dev
+        bb = type(pol) is StepSizePolicyBB
+        if not bb:
+            if self.k > 1:
+                dev.pgm_resid(_lib.VAR_YF, 0)
+                s = dev.pgm_resid_stats(0)
+                self.L = self.dtype.type(s[1] / s[0])
+            return True
+        par = getattr(pol, '_slot_parity', 0)
+        have = getattr(pol, '_slots_filled', False)
+        if self.k > 1 and not have:
+            return False
+        ycur, xcur, yprv, xprv = (0, 1, 2, 3) if par == 0 else (2, 3, 0, 1)
+        dev.pgm_resid(_lib.VAR_YF, ycur)
+        dev.pgm_resid(_lib.VAR_XF, xcur)
+        if self.k > 1:
+            s = dev.pgm_resid_stats(ycur, yprv, xcur, xprv)
+            L = s[0] / s[2]
+            if L < 0.:
+                L = self.L
+            self.L = self.dtype.type(L)
+        pol._slot_parity, pol._slots_filled = par ^ 1, True
+        pol.have_prev = False     # (the staged form's scratch arrays are not kept up to date)
         return True
 
     def _fused_monotone(self, lm):

@@ -58,4 +58,4 @@ class StepSizePolicyBB(StepSizePolicyBase):
         return L
 
     def __getstate__(self):
-        return {'have_prev': False}
+        return {'have_prev': False, '_slots_filled': False}

@@ -250,3 +250,40 @@ def test_fused_monotone_fista_against_the_reference(backend):
             assert rel_l2(X[::16, ::16], g['X_sub']) < tol
             assert abs(np.linalg.norm(np.asarray(b.Xf).astype(np.complex128)) - float(g['Xf_l2'])) < tol * float(g['Xf_l2'])
             assert abs(np.linalg.norm(np.asarray(b.Yf).astype(np.complex128)) - float(g['Yf_l2'])) < tol * float(g['Yf_l2'])
+
+
+@pytest.mark.parametrize('policy', ['cauchy', 'bb'])
+def test_fused_step_size_policies_against_the_reference(backend, policy):
+    """StepSizePolicyCauchy / StepSizePolicyBB (sporco/pgm/stepsize.py:67-145) beside the fused
+    iteration: the inner products of the gradient from signal-sized residual spectra
+    (sporco_amd_csc_pgm_resid / _pgm_resid_stats) -- against the reference's own float32 and
+    float64 runs (tests/golden/pgm_step*256_*.npz; L is the policy's from the third iteration),
+    and against the staged composition of the same library."""
+    from conftest import load_golden
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.stepsize import StepSizePolicyCauchy, StepSizePolicyBB
+    cls = {'cauchy': StepSizePolicyCauchy, 'bb': StepSizePolicyBB}[policy]
+    g32, g64 = load_golden('pgm_step%s256_f32' % policy), load_golden('pgm_step%s256_f64' % policy)
+    assert len(set(np.round(g64['it_L'], 6))) > 5            # (the policy does move L)
+    iters = 5 if backend == 'hostsim' else 14
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'L': 50.0, 'StepSizePolicy': cls()}
+    b = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optd))
+    assert b._fused_ok()
+    b.dev.profile(True)
+    X = b.solve()
+    prof = b.dev.profile_read()
+    assert prof['pgm_fft_momentum'][1] == iters and prof.get('fft_c2c_cols_fwd', (0, 0))[1] == 0
+    its = b.getitstat()
+    for g, tol in ((g32, 2e-4), (g64, 2e-4)):
+        for f in ('L', 'ObjFun', 'DFid', 'RegL1', 'Rsdl'):
+            assert rel_l2(np.asarray(getattr(its, f), float), g['it_' + f][:iters]) < tol, f
+        if iters == 14:
+            assert rel_l2(X[::16, ::16], g['X_sub']) < 10 * tol
+
+    class Staged(cls):        # (a subclass: the fused iteration does not restate a rule it does not know)
+        pass
+    optd['StepSizePolicy'] = Staged()
+    b0 = pc.ConvBPDN(g32['D'], g32['S'], float(g32['lmbda']), pc.ConvBPDN.Options(optd))
+    assert not b0._fused_ok()
+    b0.solve()
+    assert rel_l2(np.asarray(its.L, float), np.asarray(b0.getitstat().L, float)) < 1e-4
