@@ -74,3 +74,28 @@ def test_fused_column_pass_against_the_oracle(backend):
     st = b.getitstat()
     for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(np.asarray(getattr(st, f)), ref[f]) < 1e-10, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,K,N,dt', [(384, 320, 32, 2, np.float32), (240, 480, 64, 2, np.float32),
+                                        (256, 192, 32, 2, np.float64), (360, 300, 16, 2, np.float32)])
+def test_generic_chain_at_mid_sizes_against_the_oracle(gpu_backend, H, W, K, N, dt):
+    """The whole generic chain as it runs outside the register kernels (single-array state, fused
+    column pass with radices 8, 4, 2, 3, 5, 64-byte tiles for the mid-sized float32 lines) against
+    the float64 oracle at sizes of a few hundred points."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd import _lib
+    rng = np.random.RandomState(H + K)
+    D = rng.randn(8, 8, K)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, N)
+    b, prof = run(D.astype(dt), S.astype(dt), {'MaxMainIter': 10, 'RelStopTol': 0.0, 'DataType': dt}, True)
+    assert not b._dev.uses_fused_rows()
+    assert prof['fft_c2c_cols_fwd'][1] == 0 and prof['sm_solve'][1] == 10
+    ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                         maxiter=10, rel_tol=0.0)
+    tol = 1e-10 if dt == np.float64 else 1e-4
+    assert rel_l2(b.Y, ref['Y']) < tol and rel_l2(b.U, ref['U']) < tol and rel_l2(b.X, ref['X']) < tol
+    st = b.getitstat()
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(np.asarray(getattr(st, f)), ref[f]) < 10 * tol, f
