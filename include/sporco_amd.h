@@ -201,6 +201,17 @@ int sporco_amd_csc_set_signal(sporco_amd_csc_t h, const void *S);
  * sporco/admm/cbpdn.py:242-256 (DSf is never materialised), and
  * sporco/pgm/cbpdn.py:239-245. */
 int sporco_amd_csc_set_dict(sporco_amd_csc_t h, const void *D, int32_t dH, int32_t dW);
+/* Complex-valued signals and dictionaries (sporco/admm/cbpdn.py:209-217: real_dtype False, fftn /
+ * ifftn in place of rfftn / irfftn; test tests/admm/test_cbpdn.py:179-201).  D_imag: the imaginary
+ * part of the dictionary, (dH,dW,K) like D of set_dict, which then holds its real part.  The handle
+ * is created with C = 2 Cc channels: the signal passed to set_signal is (Re S, Im S) along the
+ * channel axis, and so is every coefficient array -- every transform stays a real one, and the
+ * X step pairs the channel halves (A + iB at frequency f, A - iB = the conjugate at -f; two
+ * Sherman-Morrison solves per stored frequency, linalg.solvedbi_sm).  The complex soft threshold
+ * of the y step is the l2 shrinkage over the pair: callers run FLAG_JOINT with lmbda = 0 and
+ * mu = lambda.  Generic kernel chain, single-channel dictionary, no FLAG_XRRS / FLAG_GRADREG.
+ * D_imag == NULL returns the handle to a real dictionary. */
+int sporco_amd_csc_set_dict_imag(sporco_amd_csc_t h, const void *D_imag, int32_t dH, int32_t dW);
 
 /* l1 weight array (L1Weight option, sporco/admm/cbpdn.py:596-597 after
  * cnvrep.l1Wshape, sporco/cnvrep.py:492-550).  shape[d] is 1 (broadcast) or the

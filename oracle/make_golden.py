@@ -86,6 +86,21 @@ def admm_case(name, D, S, lmbda, optd, dimK=None, joint_mu=None):
          **extra, **itstat_dict(b))
 
 
+def gen_admm_cplx():
+    """admm.cbpdn.ConvBPDN on complex-valued D and S (sporco/admm/cbpdn.py:209-217; the setting of
+    the reference's tests/admm/test_cbpdn.py:179-201): default options (AutoRho, relaxation), two
+    images, float64; a fixed-rho run with AuxVarObj; a complex64 run."""
+    rng = np.random.RandomState(777)
+    D = rng.randn(5, 5, 4) + 1j * rng.randn(5, 5, 4)
+    S = rng.randn(16, 18, 2) + 1j * rng.randn(16, 18, 2)
+    admm_case('admm_cplx_default_f64', D, S, 0.1, {'MaxMainIter': 30})
+    admm_case('admm_cplx_fixedrho_auxvar_f64', D, S[..., 0], 0.05,
+              {'MaxMainIter': 25, 'rho': 2.0, 'RelaxParam': 1.0, 'AutoRho': {'Enabled': False},
+               'AuxVarObj': True})
+    admm_case('admm_cplx_default_f32', D.astype(np.complex64), S.astype(np.complex64), 0.1,
+              {'MaxMainIter': 30})
+
+
 def gen_admm():
     np.random.seed(12345)
     D = np.random.randn(5, 5, 4)
@@ -1392,6 +1407,6 @@ if __name__ == '__main__':
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
-             'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pgm_btrobust256': gen_pgm_btrobust256, 'pgm_monotone256': gen_pgm_monotone256, 'pgm_stepsize256': gen_pgm_stepsize256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
+             'admm_cplx': gen_admm_cplx, 'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pgm_btrobust256': gen_pgm_btrobust256, 'pgm_monotone256': gen_pgm_monotone256, 'pgm_stepsize256': gen_pgm_stepsize256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}
     for w in which:
         table[w]()

@@ -55,7 +55,7 @@ EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc',
     'sporco_amd_csc_destroy',
-    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_set_hint', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict',
+    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_set_hint', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict', 'sporco_amd_csc_set_dict_imag',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
@@ -230,6 +230,7 @@ def load(path=None):
         'sporco_amd_csc_set_hint': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_set_signal': [vp, vp],
         'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
+        'sporco_amd_csc_set_dict_imag': [vp, vp, i32, i32],
         'sporco_amd_csc_set_l1_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_l21_weight': [vp, vp, ctypes.POINTER(i64)],
         'sporco_amd_csc_set_grad_weight': [vp, vp],
@@ -500,6 +501,17 @@ class Solver(object):
         dH, dW = D.shape[0], D.shape[1]
         D = D.reshape(dH, dW, self.Cd * K)      # (dH, dW, Cd, 1, K) is contiguous as (.., Cd K)
         check(self._lib.sporco_amd_csc_set_dict(self._h, _ptr(D), dH, dW))
+
+    def set_dict_imag(self, D_imag):
+        """The imaginary part of a complex dictionary (complex mode, sporco_amd_csc_set_dict_imag);
+        None: back to a real dictionary."""
+        if D_imag is None:
+            check(self._lib.sporco_amd_csc_set_dict_imag(self._h, None, 1, 1))
+            return
+        K = self.dims[4]
+        D = _carr(D_imag, self.dtype)
+        dH, dW = D.shape[0], D.shape[1]
+        check(self._lib.sporco_amd_csc_set_dict_imag(self._h, _ptr(D.reshape(dH, dW, K)), dH, dW))
 
     def _set_weight(self, fn, w):
         if w is None:

@@ -586,6 +586,15 @@ class ConvBPDN(GenericConvBPDN):
     hdrtxt_objfn = ('Fnc', 'DFid', u'Regℓ1')
     hdrval_objfun = {'Fnc': 'ObjFun', 'DFid': 'DFid', u'Regℓ1': 'RegL1'}
 
+    def __new__(cls, D=None, S=None, *args, **kwargs):
+        # complex-valued signal / dictionary (cbpdn.py:209-217): the solver of cbpdn_cplx.py, which
+        # runs the real machinery on the (re, im) channel pair
+        if cls is ConvBPDN and isinstance(D, np.ndarray) and isinstance(S, np.ndarray) and \
+                (np.iscomplexobj(D) or np.iscomplexobj(S)):
+            from .cbpdn_cplx import ComplexConvBPDN
+            return ComplexConvBPDN(D, S, *args, **kwargs)
+        return super(ConvBPDN, cls).__new__(cls)
+
     def __init__(self, D, S, lmbda=None, opt=None, dimK=None, dimN=2, **backend):
         if opt is None:
             opt = ConvBPDN.Options()

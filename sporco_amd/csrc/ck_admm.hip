@@ -177,6 +177,112 @@ __global__ void __launch_bounds__(kThreads) sm_solve_wave_kernel(const SmArgs<T>
     block_sum_store<NA>(acc, dyn_lds<double>(), a.partials + (int64_t)blockIdx.x * NA);
 }
 
+// ---------------------------------------------------------------------------
+// Complex-valued signals and dictionaries (sporco/admm/cbpdn.py:209-217: the reference switches
+// to fftn / ifftn).  Here the real and imaginary parts of every complex array are two CHANNELS of
+// the real machinery (channels c and c + Cc of 2 Cc), so all transforms stay real ones: with
+// A = rfftn(Re z), B = rfftn(Im z) at a stored half-spectrum frequency f,
+//     P = A + i B = fftn(z)(f),        M = A - i B = conj(fftn(z)(-f)),
+// and the system of frequency -f, conjugated, is the system of f with the dictionary
+// conj(Df(-f)) = DA - i DB and the signal SA - i SB.  One stored element therefore takes two
+// Sherman-Morrison solves (linalg.solvedbi_sm, sporco/linalg.py:232-297), for P with
+// (DA + i DB, SA + i SB) and for M with (DA - i DB, SA - i SB), and goes back as
+// A = (XP + XM) / 2, B = (XP - XM) / (2 i).  The data-fidelity term of both frequencies is
+// pw/2 rho^2 (|coefP|^2 + |coefM|^2) with the half-spectrum weight pw of the stored element.
+// (The complex soft threshold is the l2 shrinkage over the channel pair: the caller runs the
+// ConvBPDNJoint y step with lambda_l1 = 0, mu = lambda.)
+// One thread per (pixel, complex channel, image) system.
+template <typename T> __device__ __forceinline__ cx<T> mul_i(cx<T> z) { return mk<T>(-z.im, z.re); }
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) sm_cplx_kernel(cx<T> *__restrict__ xf,
+                                                           const cx<T> *__restrict__ dfa,
+                                                           const cx<T> *__restrict__ dfb,
+                                                           const cx<T> *__restrict__ sf, int64_t npix,
+                                                           int Cc, int N, int K, T rho, int W,
+                                                           int want_obj, double *partials) {
+    double acc[1] = {0.0};
+    const int Wf = W / 2 + 1;
+    const int64_t half = (int64_t)Cc * N, total = npix * half;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / half, r = t - pix * half;
+        const int64_t ga = pix * 2 * half + r, gb = ga + half;
+        const cx<T> *da = dfa + pix * K, *db = dfb + pix * K;
+        cx<T> *xa = xf + ga * K, *xb = xf + gb * K;
+        cx<T> qp = mk<T>(T(0), T(0)), qm = qp;
+        T gp = T(0), gm = T(0);
+        for (int k = 0; k < K; ++k) {
+            const cx<T> ib = mul_i(db[k]), dp = da[k] + ib, dm = da[k] - ib;
+            const cx<T> iy = mul_i(xb[k]), p = xa[k] + iy, m = xa[k] - iy;
+            qp = qp + cmul(dp, p);
+            qm = qm + cmul(dm, m);
+            gp += cabs2(dp);
+            gm += cabs2(dm);
+        }
+        const cx<T> is = mul_i(sf[gb]);
+        const cx<T> cp = cscale(sf[ga] + is - qp, T(1) / (gp + rho));
+        const cx<T> cm = cscale(sf[ga] - is - qm, T(1) / (gm + rho));
+        for (int k = 0; k < K; ++k) {
+            const cx<T> ib = mul_i(db[k]), dp = da[k] + ib, dm = da[k] - ib;
+            const cx<T> iy = mul_i(xb[k]);
+            const cx<T> xp = xa[k] + iy + cmulc(dp, cp), xm = xa[k] - iy + cmulc(dm, cm);
+            const cx<T> df = xp - xm;
+            xa[k] = cscale(xp + xm, T(0.5));
+            xb[k] = mk<T>(T(0.5) * df.im, T(-0.5) * df.re);       // (XP - XM) / (2 i)
+        }
+        if (want_obj)
+            acc[0] += 0.5 * parseval_weight((int)(pix % Wf), Wf, W) * (double)rho * (double)rho *
+                      ((double)cabs2(cp) + (double)cabs2(cm));
+    }
+    block_sum_store<1>(acc, dyn_lds<double>(), partials + blockIdx.x);
+}
+
+template <typename T>
+int launch_sm_cplx(hipStream_t st, cx<T> *xf, const cx<T> *dfa, const cx<T> *dfb, const cx<T> *sf,
+                   int64_t npix, int Cc, int N, int K, T rho, int W, bool want_obj, double *partials) {
+    const int grid = grid_for(npix * Cc * N);
+    hipLaunchKernelGGL((sm_cplx_kernel<T>), dim3(grid), dim3(kThreads), sizeof(double) * (kThreads / kWave),
+                       st, xf, dfa, dfb, sf, npix, Cc, N, K, rho, W, want_obj ? 1 : 0, partials);
+    SA_HIP(hipGetLastError());
+    return grid;
+}
+
+// out(npix, 2 Cc N) = the channel pair of sum_k Df vf for a complex dictionary and complex maps
+// (linalg.inner over the filter axis at f and -f, see sm_cplx_kernel)
+template <typename T>
+__global__ void __launch_bounds__(kThreads) inner_cplx_kernel(const cx<T> *__restrict__ dfa,
+                                                              const cx<T> *__restrict__ dfb,
+                                                              const cx<T> *__restrict__ vf,
+                                                              cx<T> *__restrict__ out, int64_t npix,
+                                                              int Cc, int N, int K) {
+    const int64_t half = (int64_t)Cc * N, total = npix * half;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = t / half, r = t - pix * half;
+        const int64_t ga = pix * 2 * half + r, gb = ga + half;
+        const cx<T> *da = dfa + pix * K, *db = dfb + pix * K;
+        const cx<T> *xa = vf + ga * K, *xb = vf + gb * K;
+        cx<T> qp = mk<T>(T(0), T(0)), qm = qp;
+        for (int k = 0; k < K; ++k) {
+            const cx<T> ib = mul_i(db[k]), iy = mul_i(xb[k]);
+            qp = qp + cmul(da[k] + ib, xa[k] + iy);
+            qm = qm + cmul(da[k] - ib, xa[k] - iy);
+        }
+        const cx<T> df = qp - qm;
+        out[ga] = cscale(qp + qm, T(0.5));
+        out[gb] = mk<T>(T(0.5) * df.im, T(-0.5) * df.re);
+    }
+}
+
+template <typename T>
+void launch_inner_cplx(hipStream_t st, const cx<T> *dfa, const cx<T> *dfb, const cx<T> *vf, cx<T> *out,
+                       int64_t npix, int Cc, int N, int K) {
+    hipLaunchKernelGGL((inner_cplx_kernel<T>), dim3(grid_for(npix * Cc * N)), dim3(kThreads), 0, st, dfa,
+                       dfb, vf, out, npix, Cc, N, K);
+    SA_HIP(hipGetLastError());
+}
+
 // Generic path (any K): one thread per (pixel, c, n) system.
 template <typename T, bool GRAD>
 __global__ void __launch_bounds__(kThreads) sm_solve_generic_kernel(const SmArgs<T> a) {
@@ -1049,6 +1155,8 @@ void launch_prox_sl1l2(hipStream_t st, const T *v, T *out, T alpha, T beta, int6
     template void launch_gram<T>(hipStream_t, const cx<T> *, T *, int64_t, int); \
     template int launch_grad_norm<T>(hipStream_t, const cx<T> *, const GradTerm<T> &, int64_t, int, int, int, double *); \
     template int launch_sm_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *, const cx<T> *, const T *, T, int64_t, int, int, int, bool, bool, double *, const GradTerm<T> *, int); \
+    template int launch_sm_cplx<T>(hipStream_t, cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *, int64_t, int, int, int, T, int, bool, double *); \
+    template void launch_inner_cplx<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, cx<T> *, int64_t, int, int, int); \
     template void launch_inner<T>(hipStream_t, const cx<T> *, const cx<T> *, cx<T> *, int64_t, int, int); \
     template int launch_rfl2norm2<T>(hipStream_t, const cx<T> *, const cx<T> *, int64_t, int64_t, int, double *); \
     template int launch_admm_post<T>(hipStream_t, const PostParams<T> &, double *); \

@@ -113,6 +113,13 @@ int sporco_amd_csc_set_dict(sporco_amd_csc_t h, const void *D, int32_t dH, int32
     SA_API_END
 }
 
+int sporco_amd_csc_set_dict_imag(sporco_amd_csc_t h, const void *D_imag, int32_t dH, int32_t dW) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    h->impl->set_dict_imag(D_imag, dH, dW);
+    SA_API_END
+}
+
 int sporco_amd_csc_set_l1_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
     SA_API_BEGIN
     SA_HANDLE(h);

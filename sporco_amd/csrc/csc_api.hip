@@ -95,6 +95,12 @@ template <typename T> struct Csc : CscBase {
     Weight<T> wdat;              // data-fidelity mask of the *Mask PGM classes
     bool have_wdat = false;
     double *part_a = nullptr, *part_b = nullptr;  // block partials
+    // Complex-valued signals and dictionary (set_dict_imag): the real and imaginary parts are the
+    // channels c and c + C/2 of the real machinery, df_im holds rfftn of the dictionary's imaginary
+    // part beside VAR_DF, and the X-step / inner products pair them (ck_admm.hip sm_cplx_kernel).
+    // Generic chain only.
+    bool cplx = false;
+    cx<T> *df_im = nullptr;
     double *out_dev_own = nullptr;
     double *out_pinned = nullptr;
     bool have_dict = false, have_signal = false;
@@ -306,7 +312,7 @@ template <typename T> struct Csc : CscBase {
                         (void *)qpart, (void *)coop_flags, (void *)ghh, (void *)ghw, (void *)wg, (void *)g1t, (void *)ism_gam, (void *)ism_del, (void *)ism_mm, (void *)dft_mc, (void *)sft_mc, (void *)bt_mc, (void *)cns_f, (void *)cns_m, (void *)sft_eff, (void *)coef_t, (void *)ams_bits, (void *)gramz_t,
                         (void *)cns_yold, (void *)md_s, (void *)dism_gam, (void *)dism_del, (void *)dism_mm,
                         (void *)dwork, (void *)pcn_stats, (void *)work, (void *)innerb, (void *)gram, (void *)dpad, (void *)sreal,
-                        (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)wdat_buf, (void *)part_a, (void *)part_b, (void *)part_cs, (void *)pgm_es[0], (void *)pgm_es[1], (void *)pgm_es[2], (void *)pgm_es[3],
+                        (void *)wl1_buf, (void *)wl21_buf, (void *)wams_buf, (void *)wdat_buf, (void *)part_a, (void *)part_b, (void *)part_cs, (void *)df_im, (void *)pgm_es[0], (void *)pgm_es[1], (void *)pgm_es[2], (void *)pgm_es[3],
                         (void *)out_dev_own})
             if (p) (void)hipFree(p);
         if (out_pinned) (void)hipHostFree(out_pinned);

@@ -157,6 +157,7 @@ struct CscBase {
     virtual void set_signal_dev(const void *S_dev) = 0;
     virtual void reconstruct_dev(int var, void *dst_dev) = 0;
     virtual void set_dict(const void *D, int dH, int dW) = 0;
+    virtual void set_dict_imag(const void *D, int dH, int dW) = 0;
     virtual void set_weight(int which, const void *w, const int64_t shape[5]) = 0;
     virtual void set_grad_weight(const void *w) = 0;
     virtual void set_filter_sizes(const int32_t *fh, const int32_t *fw) = 0;

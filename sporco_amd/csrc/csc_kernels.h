@@ -116,6 +116,16 @@ template <typename T> struct PostParams {
 };
 template <typename T> int launch_admm_post(hipStream_t st, const PostParams<T> &p, double *partials);
 
+// Complex-valued signals / dictionaries as channel pairs of the real machinery (ck_admm.hip
+// sm_cplx_kernel): the X-step solve in place on xf (npix, 2 Cc N, K) with the half spectra of the
+// real and imaginary parts of the dictionary, and the matching inner product over the filters.
+template <typename T>
+int launch_sm_cplx(hipStream_t st, cx<T> *xf, const cx<T> *dfa, const cx<T> *dfb, const cx<T> *sf,
+                   int64_t npix, int Cc, int N, int K, T rho, int W, bool want_obj, double *partials);
+template <typename T>
+void launch_inner_cplx(hipStream_t st, const cx<T> *dfa, const cx<T> *dfb, const cx<T> *vf, cx<T> *out,
+                       int64_t npix, int Cc, int N, int K);
+
 // Staged pieces (each mirrors one overridable method of the reference class).
 template <typename T>
 void launch_relax(hipStream_t st, const T *x, const T *y, T *ax, T rlx, int64_t n);   // relax_AX

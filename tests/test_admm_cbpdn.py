@@ -422,15 +422,17 @@ def test_yprev_and_ax_after_fused_iterations_and_refused_overrides(backend):
         m.solve()
 
 
-def test_complex_input_is_refused(backend):
+def test_complex_input_outside_admm_convbpdn_is_refused(backend):
     """The reference solves complex-valued problems with complex transforms
-    (sporco/admm/cbpdn.py:213-217, tests/admm/test_cbpdn.py:179-201); this backend's transforms are
-    real-to-complex, and it says so instead of dropping the imaginary part."""
+    (sporco/admm/cbpdn.py:213-217).  admm.cbpdn.ConvBPDN takes them (tests/test_admm_cplx.py); the
+    other classes say so instead of dropping the imaginary part."""
     from sporco_amd.admm import cbpdn
     from sporco_amd.pgm import cbpdn as pc
     rng = np.random.RandomState(0)
     D, S = rng.randn(4, 4, 3), rng.randn(16, 16, 2)
-    for make in (lambda: cbpdn.ConvBPDN(D, S + 1j * S, 0.1), lambda: cbpdn.ConvBPDN(D * (1 + 1j), S, 0.1),
+    assert np.iscomplexobj(cbpdn.ConvBPDN(D, S + 1j * S, 0.1, cbpdn.ConvBPDN.Options({'MaxMainIter': 2})).solve())
+    for make in (lambda: cbpdn.ConvBPDNJoint(D, S + 1j * S, 0.1, 0.1),
+                 lambda: cbpdn.ConvBPDNGradReg(D * (1 + 1j), S, 0.1, 0.1),
                  lambda: pc.ConvBPDN(D, S + 1j * S, 0.1)):
         with pytest.raises(NotImplementedError):
             make()
