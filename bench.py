@@ -36,6 +36,7 @@ build()) in a subprocess on this box's host cores, and the NumPy port as a secon
 """
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -190,14 +191,23 @@ def fixture_parity(fix_name, coef, coef_key, its, fields, tol=1e-4, trace_tol=1e
 
 
 def timed_solve(b, dev, warmup, steps):
+    import gc
     b.opt['MaxMainIter'] = max(warmup, 1)
     b.solve()
     b.opt['MaxMainIter'] = steps
-    dev.sync()
-    t0 = time.perf_counter()
-    b.solve()
-    dev.sync()
-    return time.perf_counter() - t0
+    # (no cyclic-garbage collection inside the timed region: collecting the previous leg's solver
+    # there frees gigabytes of device memory, a device-wide stall of tens of milliseconds --
+    # one run of the r04z session timed config 5 at half its rate for it)
+    gc.collect()
+    gc.disable()
+    try:
+        dev.sync()
+        t0 = time.perf_counter()
+        b.solve()
+        dev.sync()
+        return time.perf_counter() - t0
+    finally:
+        gc.enable()
 
 
 def profiled_pass(b, dev, steps, host_loop=True):
@@ -457,14 +467,7 @@ def run_next_rows(device, tiny=False):
 
     def rate(b, dev, iters=20):
         b._return_min = False
-        b.opt['MaxMainIter'] = 3
-        b.solve()
-        dev.sync()
-        b.opt['MaxMainIter'] = iters
-        t0 = time.perf_counter()
-        b.solve()
-        dev.sync()
-        return iters / (time.perf_counter() - t0)
+        return iters / timed_solve(b, dev, 3, iters)
 
     D = rng.randn(8, 8, K).astype(np.float32)
     D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
@@ -818,13 +821,19 @@ def main():
                              stream=stream, reducer=reducer)
         if args.warmup > 0:
             b.solve()
-        # timed region: exactly `steps` iterations, no instrumentation
+        # timed region: exactly `steps` iterations, no instrumentation (and no cyclic-garbage
+        # collection: see timed_solve)
         b.opt['MaxMainIter'] = args.steps
-        sync_all(b)
-        t0 = time.perf_counter()
-        b.solve()
-        sync_all(b)
-        elapsed = time.perf_counter() - t0
+        gc.collect()
+        gc.disable()
+        try:
+            sync_all(b)
+            t0 = time.perf_counter()
+            b.solve()
+            sync_all(b)
+            elapsed = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if world > 1:
             own = elapsed
             dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
