@@ -375,7 +375,7 @@ template <typename T> struct ColsSmArgs {
     const cx<T> *tw;    // W_n^t
     const int *drev;    // position -> frequency after the in-place forward transform
     T rho;
-    int n, Wf, CN, K, W, nrad, want_obj;
+    int n, Wf, CN, K, Kp, W, nrad, want_obj;
     int radix[kMaxRadixPasses];
     double *partials;   // one per tile: Parseval-weighted sum of |Df.xf - Sf|^2
 };
@@ -410,6 +410,7 @@ template <typename T, int R, bool INV>
 __device__ __forceinline__ void inplace_pass(cx<T> *buf, const cx<T> *tw, int n, int m, int K, int col,
                                              int lane, int lpc) {
     const int sub = m / R, nb = n / R, tstep = n / m;
+    if (col >= K) return;        // (a filter count below the lane group: idle lanes)
     for (int b = lane; b < nb; b += lpc) {
         const int blk = b / sub, j = b - blk * sub;
         const int base = blk * m + j;
@@ -451,7 +452,11 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     double *scratch = reinterpret_cast<double *>(tw + n);
     int *drev = reinterpret_cast<int *>(scratch + 16);
     const int tid = threadIdx.x;
-    const int col = tid % K, lane = tid / K, lpc = blockDim.x / K;
+    // Kp = K rounded up to a power of two: the lanes of one row (the sum over the filters is a
+    // butterfly over them); columns K .. Kp - 1 stay idle
+    const int Kp = a.Kp;
+    const int col = tid % Kp, lane = tid / Kp, lpc = blockDim.x / Kp;
+    const bool cvalid = col < K;
     // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): every XCD
     // takes a contiguous run of tiles, so that the CN tiles that share a row frequency's slice
     // of Df find it in that XCD's L2.
@@ -460,7 +465,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
     const int wf = tile / a.CN, cn = tile - wf * a.CN;
     const int64_t rowstride = (int64_t)a.Wf * a.CN * K;
-    cx<T> *x = a.xf + ((int64_t)wf * a.CN + cn) * K + col;
+    cx<T> *x = a.xf + ((int64_t)wf * a.CN + cn) * K + (cvalid ? col : 0);
     const cx<T> zero = mk<T>(T(0), T(0));
     for (int t = tid; t < n; t += blockDim.x) {
         tw[t] = a.tw[t];
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
         for (int u = 0; u < US; ++u) {
             const int pos = pos0 + u * lpc + lane;
             const int64_t pix = pos < n ? (int64_t)dr[pos] * a.Wf + wf : 0;
-            d[u] = a.df[pix * K + col];
+            d[u] = cvalid ? a.df[pix * K + col] : zero;
             sv[u] = a.sf[pix * a.CN + cn];
             gv[u] = a.gram[pix];
         }
@@ -488,12 +493,12 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
             const int r = r0 + u * lpc;
-            t[u] = r < n ? x[r * rowstride] : zero;
+            t[u] = (r < n && cvalid) ? x[r * rowstride] : zero;
         }
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
             const int r = r0 + u * lpc;
-            if (r < n) buf[r * K + col] = t[u];
+            if (r < n && cvalid) buf[r * K + col] = t[u];
         }
     }
     __syncthreads();
@@ -515,10 +520,10 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
         for (int u = 0; u < US; ++u) {
             const int pos = pos0 + u * lpc + lane;
             if (pos0 + u * lpc >= n) break;        // (uniform over the workgroup)
-            const bool valid = pos < n;
+            const bool valid = pos < n && cvalid;
             const cx<T> yu = valid ? buf[pos * K + col] : zero;
             cx<T> q = cmul(d[u], yu);
-            for (int s = K >> 1; s > 0; s >>= 1) {     // (K: a power of two <= 64; the K lanes share pos)
+            for (int s = Kp >> 1; s > 0; s >>= 1) {    // (the Kp <= 64 lanes of a row share pos)
                 q.re += __shfl_xor(q.re, s, kWave);
                 q.im += __shfl_xor(q.im, s, kWave);
             }
@@ -536,7 +541,8 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
         inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, K, col, lane, lpc);
         __syncthreads();
     }
-    for (int r = lane; r < n; r += lpc) x[r * rowstride] = buf[r * K + col];
+    if (cvalid)
+        for (int r = lane; r < n; r += lpc) x[r * rowstride] = buf[r * K + col];
     if (a.want_obj) block_sum_store<1>(acc, scratch, a.partials + tile);
 }
 
@@ -821,7 +827,7 @@ template <typename T> static size_t cols_sm_lds(int n, int K) {
 }
 
 template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K) {
-    if (K < 2 || K > 64 || (K & (K - 1))) return false;
+    if (K < 2 || K > 64) return false;
     for (int p = 0; p < plan.nrad; ++p)
         if (plan.radix[p] > 8 || plan.radix[p] == 6) return false;
     return plan.n >= 2 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget;
@@ -843,6 +849,8 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
     a.Wf = Wf;
     a.CN = CN;
     a.K = K;
+    a.Kp = 2;
+    while (a.Kp < K) a.Kp <<= 1;
     a.W = W;
     a.nrad = plan.nrad;
     for (int i = 0; i < plan.nrad; ++i) a.radix[i] = plan.radix[i];
@@ -863,7 +871,7 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
     const int64_t tiles = (int64_t)Wf * CN;
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
     // rows per thread: all operands in one batch while the registers allow it
-    const int nit = (int)ceil_div(plan.n, threads / K);
+    const int nit = (int)ceil_div(plan.n, threads / a.Kp);
     constexpr int UMAX = sizeof(T) == 8 ? 6 : 12;
     if (nit <= UMAX / 3)
         hipLaunchKernelGGL((cols_sm_kernel<T, UMAX / 3>), dim3(grid), dim3(threads), lds, st, a);

@@ -19,6 +19,9 @@ CASES = {
     'f32_32x24_k64': (32, 24, 64, 1, np.float32),
     'f64_35x20_k2': (35, 20, 2, 3, np.float64),
     'f32_96x80_k32': (96, 80, 32, 2, np.float32),
+    'f64_36x30_k6': (36, 30, 6, 2, np.float64),        # filter counts that are not powers of two
+    'f32_40x48_k24': (40, 48, 24, 1, np.float32),
+    'f64_24x40_k50': (24, 40, 50, 1, np.float64),
 }
 
 
@@ -78,7 +81,8 @@ def test_fused_column_pass_against_the_oracle(backend):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('H,W,K,N,dt', [(384, 320, 32, 2, np.float32), (240, 480, 64, 2, np.float32),
-                                        (256, 192, 32, 2, np.float64), (360, 300, 16, 2, np.float32)])
+                                        (256, 192, 32, 2, np.float64), (360, 300, 16, 2, np.float32),
+                                        (320, 240, 48, 2, np.float32)])
 def test_generic_chain_at_mid_sizes_against_the_oracle(gpu_backend, H, W, K, N, dt):
     """The whole generic chain as it runs outside the register kernels (single-array state, fused
     column pass with radices 8, 4, 2, 3, 5, 64-byte tiles for the mid-sized float32 lines) against
