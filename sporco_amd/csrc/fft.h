@@ -92,8 +92,8 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
 // Sherman-Morrison solve (sporco/linalg.py:232-297) and the inverse transform of one (wf, cn)
 // tile of n = plan.n frequencies x K filters held in LDS.  xf (n, Wf, CN, K) is transformed in
 // place (the c2r row pass is what remains of irfftn); partials (Wf * CN doubles) receive the
-// Parseval-weighted sums of |Df.xf - Sf|^2 when want_obj.  fft_cols_sm_supported: 2 <= K <= 64,
-// radices <= 8, the tile fits LDS.  Returns the number of tiles.
+// Parseval-weighted sums of |Df.xf - Sf|^2 when want_obj.  fft_cols_sm_supported: radices <= 8 and
+// K <= 64 with the tile in LDS, or K <= 256 in slabs of filters that fit (four passes then).  Returns the number of tiles.
 template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K);
 template <typename T>
 int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> *df, const cx<T> *sf,

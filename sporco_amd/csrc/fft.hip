@@ -376,6 +376,7 @@ template <typename T> struct ColsSmArgs {
     const int *drev;    // position -> frequency after the in-place forward transform
     T rho;
     int n, Wf, CN, K, Kp, W, nrad, want_obj;
+    int Ks;             // cols_sm_slab_kernel: filters per slab (a power of two)
     int radix[kMaxRadixPasses];
     double *partials;   // one per tile: Parseval-weighted sum of |Df.xf - Sf|^2
 };
@@ -407,10 +408,12 @@ __device__ __forceinline__ void small_dft(cx<T> (&v)[R], const cx<T> *tw, int n)
 // Forward (decimation in frequency): butterfly, then output q times W_m^(j q).
 // Inverse (decimation in time):      input s times conj W_m^(j s), then the conjugate butterfly.
 template <typename T, int R, bool INV>
-__device__ __forceinline__ void inplace_pass(cx<T> *buf, const cx<T> *tw, int n, int m, int K, int col,
-                                             int lane, int lpc) {
+__device__ __forceinline__ void inplace_pass(cx<T> *buf, const cx<T> *tw, int n, int m, int K, int ncol,
+                                             int col, int lane, int lpc) {
+    // (K: columns per row of the buffer; ncol <= K of them hold data -- a filter count below the
+    // lane group, the last slab of a tile: the other lanes idle)
     const int sub = m / R, nb = n / R, tstep = n / m;
-    if (col >= K) return;        // (a filter count below the lane group: idle lanes)
+    if (col >= ncol) return;
     for (int b = lane; b < nb; b += lpc) {
         const int blk = b / sub, j = b - blk * sub;
         const int base = blk * m + j;
@@ -431,14 +434,14 @@ __device__ __forceinline__ void inplace_pass(cx<T> *buf, const cx<T> *tw, int n,
 
 template <typename T, bool INV>
 __device__ __forceinline__ void inplace_pass_r(int R, cx<T> *buf, const cx<T> *tw, int n, int m, int K,
-                                               int col, int lane, int lpc) {
+                                               int ncol, int col, int lane, int lpc) {
     switch (R) {
-    case 8: inplace_pass<T, 8, INV>(buf, tw, n, m, K, col, lane, lpc); break;
-    case 4: inplace_pass<T, 4, INV>(buf, tw, n, m, K, col, lane, lpc); break;
-    case 2: inplace_pass<T, 2, INV>(buf, tw, n, m, K, col, lane, lpc); break;
-    case 3: inplace_pass<T, 3, INV>(buf, tw, n, m, K, col, lane, lpc); break;
-    case 5: inplace_pass<T, 5, INV>(buf, tw, n, m, K, col, lane, lpc); break;
-    default: inplace_pass<T, 7, INV>(buf, tw, n, m, K, col, lane, lpc); break;
+    case 8: inplace_pass<T, 8, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
+    case 4: inplace_pass<T, 4, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
+    case 2: inplace_pass<T, 2, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
+    case 3: inplace_pass<T, 3, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
+    case 5: inplace_pass<T, 5, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
+    default: inplace_pass<T, 7, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
     }
 }
 
@@ -457,6 +460,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     const int Kp = a.Kp;
     const int col = tid % Kp, lane = tid / Kp, lpc = blockDim.x / Kp;
     const bool cvalid = col < K;
+    const int colc = cvalid ? col : 0;
     // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only): every XCD
     // takes a contiguous run of tiles, so that the CN tiles that share a row frequency's slice
     // of Df find it in that XCD's L2.
@@ -471,20 +475,23 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
         tw[t] = a.tw[t];
         drev[t] = a.drev[t];
     }
-    cx<T> d[US], sv[US];
-    T gv[US];
-    auto load_operands = [&](int pos0, const int *dr) {
+    cx<T> d[US];
+    // (Df of the thread's rows travels across the forward passes when one batch covers them; the
+    // per-row scalars Sf and gram are requested when the solve starts -- holding them too spilt
+    // the 12-row variant)
+    auto load_d = [&](int pos0, const int *dr) {
 #pragma unroll
         for (int u = 0; u < US; ++u) {
             const int pos = pos0 + u * lpc + lane;
             const int64_t pix = pos < n ? (int64_t)dr[pos] * a.Wf + wf : 0;
-            d[u] = cvalid ? a.df[pix * K + col] : zero;
-            sv[u] = a.sf[pix * a.CN + cn];
-            gv[u] = a.gram[pix];
+            // (an unconditional load from a clamped address, then a select: a predicated load
+            // would split the batch into blocks and serialise the requests)
+            const cx<T> dl = a.df[pix * K + colc];
+            d[u] = cvalid ? dl : zero;
         }
     };
     const bool one_batch = US * lpc >= n;
-    if (one_batch) load_operands(0, a.drev);
+    if (one_batch) load_d(0, a.drev);
     // (batches of independent loads: one row per thread in flight leaves the pass waiting out a
     // memory round trip per row)
     constexpr int UL = 8;
@@ -493,7 +500,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
             const int r = r0 + u * lpc;
-            t[u] = (r < n && cvalid) ? x[r * rowstride] : zero;
+            t[u] = r < n ? x[r * rowstride] : zero;       // (x points at column colc)
         }
 #pragma unroll
         for (int u = 0; u < UL; ++u) {
@@ -505,7 +512,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     // ---- forward, in place ------------------------------------------------------------------
     int m = n;
     for (int p = 0; p < a.nrad; ++p) {
-        inplace_pass_r<T, false>(a.radix[p], buf, tw, n, m, K, col, lane, lpc);
+        inplace_pass_r<T, false>(a.radix[p], buf, tw, n, m, K, K, col, lane, lpc);
         m /= a.radix[p];
         __syncthreads();
     }
@@ -515,7 +522,16 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == a.Wf - 1)) ? 1.0 : 2.0;
     // (every lane of a wave takes part in the shuffles: the trip count is the workgroup's)
     for (int pos0 = 0; pos0 < n; pos0 += US * lpc) {
-        if (!one_batch) load_operands(pos0, drev);
+        if (!one_batch) load_d(pos0, drev);
+        cx<T> sv[US];
+        T gv[US];
+#pragma unroll
+        for (int u = 0; u < US; ++u) {
+            const int pos = pos0 + u * lpc + lane;
+            const int64_t pix = pos < n ? (int64_t)drev[pos] * a.Wf + wf : 0;
+            sv[u] = a.sf[pix * a.CN + cn];
+            gv[u] = a.gram[pix];
+        }
 #pragma unroll
         for (int u = 0; u < US; ++u) {
             const int pos = pos0 + u * lpc + lane;
@@ -538,11 +554,141 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     // ---- inverse, in place: the transposed flow ---------------------------------------------------
     for (int p = a.nrad - 1; p >= 0; --p) {
         m *= a.radix[p];
-        inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, K, col, lane, lpc);
+        inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, K, K, col, lane, lpc);
         __syncthreads();
     }
     if (cvalid)
         for (int r = lane; r < n; r += lpc) x[r * rowstride] = buf[r * K + col];
+    if (a.want_obj) block_sum_store<1>(acc, scratch, a.partials + tile);
+}
+
+// The same pass for a tile that does not fit LDS (384 x 64 float32, 256 x 64 float64, ...): the
+// filters go through in slabs of Ks.  Phase A, per slab: load, forward transform, add the slab's
+// share of sum_k Df yuf to q (n values in LDS), write the transformed slab back over xf.  Then
+// the multiplier of every frequency from q.  Phase B, per slab: re-load the transformed slab (it
+// was written moments ago by this CU: L2 / MALL), apply the solve, inverse transform, store.
+// Four passes over the spectrum (the re-load mostly out of cache) instead of the six of the
+// three kernels.
+template <typename T>
+__global__ void __launch_bounds__(1024) cols_sm_slab_kernel(const ColsSmArgs<T> a) {
+    const int n = a.n, K = a.K, Ks = a.Ks;
+    cx<T> *buf = dyn_lds<cx<T>>();
+    cx<T> *tw = buf + (size_t)n * Ks;
+    cx<T> *q = tw + n;
+    double *scratch = reinterpret_cast<double *>(q + n);
+    int *drev = reinterpret_cast<int *>(scratch + 16);
+    const int tid = threadIdx.x;
+    const int col = tid % Ks, lane = tid / Ks, lpc = blockDim.x / Ks;
+    const int ntiles = a.Wf * a.CN, per_xcd = (ntiles + 7) / 8;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
+    const int wf = tile / a.CN, cn = tile - wf * a.CN;
+    const int64_t rowstride = (int64_t)a.Wf * a.CN * K;
+    cx<T> *xt = a.xf + ((int64_t)wf * a.CN + cn) * K;
+    const cx<T> zero = mk<T>(T(0), T(0));
+    for (int t = tid; t < n; t += blockDim.x) {
+        tw[t] = a.tw[t];
+        drev[t] = a.drev[t];
+        q[t] = zero;
+    }
+    constexpr int UL = 8;
+    const int nslab = (K + Ks - 1) / Ks;
+    auto load_slab = [&](int k0, bool cv) {
+        for (int r0 = lane; r0 < n; r0 += UL * lpc) {
+            cx<T> t[UL];
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int r = r0 + u * lpc;
+                t[u] = (r < n && cv) ? xt[r * rowstride + k0 + col] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < UL; ++u) {
+                const int r = r0 + u * lpc;
+                if (r < n && cv) buf[r * Ks + col] = t[u];
+            }
+        }
+    };
+    __syncthreads();
+    // ---- phase A ----------------------------------------------------------------------------
+    for (int s = 0; s < nslab; ++s) {
+        const int k0 = s * Ks, kw = (K - k0) < Ks ? (K - k0) : Ks;
+        const bool cv = col < kw;
+        load_slab(k0, cv);
+        __syncthreads();
+        int m = n;
+        for (int p = 0; p < a.nrad; ++p) {
+            inplace_pass_r<T, false>(a.radix[p], buf, tw, n, m, Ks, kw, col, lane, lpc);
+            m /= a.radix[p];
+            __syncthreads();
+        }
+        constexpr int US = 4;
+        for (int pos0 = 0; pos0 < n; pos0 += US * lpc) {
+            cx<T> d[US];
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+                const int pos = pos0 + u * lpc + lane;
+                const int64_t pix = pos < n ? (int64_t)drev[pos] * a.Wf + wf : 0;
+                d[u] = cv ? a.df[pix * K + k0 + col] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+                const int pos = pos0 + u * lpc + lane;
+                if (pos0 + u * lpc >= n) break;        // (uniform over the workgroup)
+                const bool valid = pos < n && cv;
+                const cx<T> v = valid ? buf[pos * Ks + col] : zero;
+                cx<T> pq = cmul(d[u], v);
+                for (int sh = Ks >> 1; sh > 0; sh >>= 1) {
+                    pq.re += __shfl_xor(pq.re, sh, kWave);
+                    pq.im += __shfl_xor(pq.im, sh, kWave);
+                }
+                if (pos < n && col == 0) q[pos] = q[pos] + pq;     // (one lane group per row)
+                if (valid) xt[pos * rowstride + k0 + col] = v;     // the transformed slab, kept in xf
+            }
+        }
+        __syncthreads();
+    }
+    // ---- the multiplier of every frequency: (Sf - sum_k Df yuf) / (sum_k |Df|^2 + rho) -----------
+    double acc[1] = {0.0};
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == a.Wf - 1)) ? 1.0 : 2.0;
+    for (int pos = tid; pos < n; pos += blockDim.x) {
+        const int64_t pix = (int64_t)drev[pos] * a.Wf + wf;
+        const cx<T> coef = cscale(a.sf[pix * a.CN + cn] - q[pos], T(1) / (a.gram[pix] + a.rho));
+        q[pos] = coef;
+        if (a.want_obj) acc[0] += pw * (double)cabs2(coef) * (double)a.rho * (double)a.rho;
+    }
+    __syncthreads();
+    // ---- phase B ----------------------------------------------------------------------------
+    for (int s = 0; s < nslab; ++s) {
+        const int k0 = s * Ks, kw = (K - k0) < Ks ? (K - k0) : Ks;
+        const bool cv = col < kw;
+        constexpr int US = 4;
+        for (int pos0 = lane; pos0 < n; pos0 += US * lpc) {
+            cx<T> d[US], v[US];
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+                const int pos = pos0 + u * lpc;
+                const bool valid = pos < n && cv;
+                const int64_t pix = pos < n ? (int64_t)drev[pos] * a.Wf + wf : 0;
+                d[u] = valid ? a.df[pix * K + k0 + col] : zero;
+                v[u] = valid ? xt[pos * rowstride + k0 + col] : zero;
+            }
+#pragma unroll
+            for (int u = 0; u < US; ++u) {
+                const int pos = pos0 + u * lpc;
+                if (pos < n && cv) buf[pos * Ks + col] = v[u] + cmulc(d[u], q[pos]);
+            }
+        }
+        __syncthreads();
+        int m = 1;
+        for (int p = a.nrad - 1; p >= 0; --p) {
+            m *= a.radix[p];
+            inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, Ks, kw, col, lane, lpc);
+            __syncthreads();
+        }
+        if (cv)
+            for (int r = lane; r < n; r += lpc) xt[r * rowstride + k0 + col] = buf[r * Ks + col];
+        __syncthreads();
+    }
     if (a.want_obj) block_sum_store<1>(acc, scratch, a.partials + tile);
 }
 
@@ -826,11 +972,27 @@ template <typename T> static size_t cols_sm_lds(int n, int K) {
     return sizeof(cx<T>) * ((size_t)n * K + n) + sizeof(double) * 16 + sizeof(int) * n;
 }
 
+template <typename T> static size_t cols_sm_slab_lds(int n, int Ks) {
+    return sizeof(cx<T>) * ((size_t)n * Ks + 2 * n) + sizeof(double) * 16 + sizeof(int) * n;
+}
+// filters per slab when the tile does not fit: the largest power of two that does (0: none >= 8)
+template <typename T> static int cols_sm_slab_width(int n, int K) {
+    if (const char *e = std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB")) {     // (test switch: slabs of this width)
+        const int ks = std::atoi(e);
+        return (ks >= 2 && ks < K && !(ks & (ks - 1)) && cols_sm_slab_lds<T>(n, ks) <= kLdsBudget) ? ks : 0;
+    }
+    for (int ks = 64; ks >= 8; ks >>= 1)
+        if (ks < K && cols_sm_slab_lds<T>(n, ks) <= kLdsBudget) return ks;
+    return 0;
+}
+
 template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K) {
-    if (K < 2 || K > 64) return false;
+    if (K < 2 || plan.n < 2) return false;
     for (int p = 0; p < plan.nrad; ++p)
         if (plan.radix[p] > 8 || plan.radix[p] == 6) return false;
-    return plan.n >= 2 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget;
+    if (K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget && !std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB"))
+        return true;
+    return K <= 256 && cols_sm_slab_width<T>(plan.n, K) > 0 && !std::getenv("SPORCO_AMD_NO_COLS_SM_SLAB");
 }
 
 template <typename T>
@@ -856,9 +1018,22 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
     for (int i = 0; i < plan.nrad; ++i) a.radix[i] = plan.radix[i];
     a.want_obj = want_obj ? 1 : 0;
     a.partials = partials;
+    static PerDeviceOnce attr_set;
+    if (!(K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget) || std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB")) {
+        // the tile goes through in slabs of filters
+        a.Ks = cols_sm_slab_width<T>(plan.n, K);
+        static PerDeviceOnce slab_attr;
+        if (slab_attr.first())
+            SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_slab_kernel<T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        const int64_t tiles = (int64_t)Wf * CN;
+        hipLaunchKernelGGL((cols_sm_slab_kernel<T>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(1024),
+                           cols_sm_slab_lds<T>(plan.n, a.Ks), st, a);
+        SA_HIP(hipGetLastError());
+        return tiles;
+    }
     const size_t lds = cols_sm_lds<T>(plan.n, K);
     const int threads = (int64_t)plan.n * K >= 4096 ? 1024 : 256;
-    static PerDeviceOnce attr_set;
     if (attr_set.first()) {
         constexpr int UM = sizeof(T) == 8 ? 6 : 12;
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM / 3>),

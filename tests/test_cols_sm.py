@@ -25,10 +25,12 @@ CASES = {
 }
 
 
-def run(D, S, optd, fused):
+def run(D, S, optd, fused, slab=None):
     from sporco_amd.admm import cbpdn
     if not fused:
         os.environ['SPORCO_AMD_NO_COLS_SM'] = '1'
+    if slab:
+        os.environ['SPORCO_AMD_COLS_SM_FORCE_SLAB'] = str(slab)
     try:
         b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
         b._dev.profile(True)
@@ -36,6 +38,7 @@ def run(D, S, optd, fused):
         prof = b._dev.profile_read()
     finally:
         os.environ.pop('SPORCO_AMD_NO_COLS_SM', None)
+        os.environ.pop('SPORCO_AMD_COLS_SM_FORCE_SLAB', None)
     return b, prof
 
 
@@ -103,3 +106,42 @@ def test_generic_chain_at_mid_sizes_against_the_oracle(gpu_backend, H, W, K, N, 
     st = b.getitstat()
     for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
         assert rel_l2(np.asarray(getattr(st, f)), ref[f]) < 10 * tol, f
+
+
+@pytest.mark.parametrize('H,W,K,slab,dt', [(48, 40, 16, 8, np.float32), (30, 36, 12, 8, np.float64),
+                                           (63, 24, 20, 4, np.float64), (32, 32, 64, 32, np.float32)])
+def test_slab_form_of_the_fused_column_pass(backend, H, W, K, slab, dt):
+    """Tiles beyond LDS go through in slabs of filters (cols_sm_slab_kernel: forward transform and
+    the slab's share of the inner product, then solve and inverse transform per slab); forced here
+    at small sizes (SPORCO_AMD_COLS_SM_FORCE_SLAB), incl. a last slab that is not full."""
+    rng = np.random.RandomState(H + K)
+    D = rng.randn(5, 5, K).astype(dt)
+    S = rng.randn(H, W, 2).astype(dt)
+    optd = {'MaxMainIter': 6, 'RelStopTol': 0.0, 'DataType': dt}
+    a, pa = run(D, S, optd, False)
+    b, pb = run(D, S, optd, True, slab=slab)
+    assert pa['fft_c2c_cols_fwd'][1] == 6 and pb['fft_c2c_cols_fwd'][1] == 0 and pb['sm_solve'][1] == 6
+    tol = 1e-11 if dt == np.float64 else 2e-5
+    for v in ('Y', 'U', 'X'):
+        assert rel_l2(getattr(a, v), getattr(b, v)) < tol, v
+    ia, ib = a.getitstat(), b.getitstat()
+    for f in ('ObjFun', 'DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(np.asarray(getattr(ia, f)), np.asarray(getattr(ib, f))) < tol, f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,K,dt', [(384, 320, 64, np.float32), (256, 192, 64, np.float64)])
+def test_slab_form_at_the_sizes_it_is_for(gpu_backend, H, W, K, dt):
+    from oracle import cbpdn_oracle as orc
+    rng = np.random.RandomState(H)
+    D = rng.randn(8, 8, K)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, 2)
+    b, prof = run(D.astype(dt), S.astype(dt), {'MaxMainIter': 8, 'RelStopTol': 0.0, 'DataType': dt}, True)
+    assert prof['fft_c2c_cols_fwd'][1] == 0 and prof['sm_solve'][1] == 8
+    ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, 2, 1), 0.05, dtype=np.float64,
+                         maxiter=8, rel_tol=0.0)
+    tol = 1e-10 if dt == np.float64 else 1e-4
+    assert rel_l2(b.Y, ref['Y']) < tol and rel_l2(b.U, ref['U']) < tol
+    for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(np.asarray(getattr(b.getitstat(), f)), ref[f]) < 10 * tol, f
