@@ -506,7 +506,7 @@ def run_next_rows(device, tiny=False):
                                 % (h, w, k, N8, np.dtype(dt).name),
                     'value': rate(b, b._dev), 'unit': 'iterations/s',
                     'path': 'register-resident kernels' if b._dev.uses_fused_rows() else
-                            'generic chain (single-array state, fused column pass where the tile fits)'}
+                            'generic chain (single-array state, fused column pass: whole tile in LDS or slabs of filters)'}
         return go
 
     legs = {'maskdcpl': leg_maskdcpl, 'pgm_mask': leg_pgm_mask, 'pgm_backtrack_robust': leg_pgm_robust}
@@ -516,6 +516,7 @@ def run_next_rows(device, tiny=False):
     else:
         legs['generic_384x384_k32_f32'] = leg_generic(384, 384, 32, np.float32)
         legs['generic_240x320_k64_f32'] = leg_generic(240, 320, 64, np.float32)
+        legs['generic_480x320_k64_f32'] = leg_generic(480, 320, 64, np.float32)
         legs['generic_256x256_k32_f64'] = leg_generic(256, 256, 32, np.float64)
     out = {}
     for name, fn in legs.items():
