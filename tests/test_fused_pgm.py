@@ -287,3 +287,43 @@ def test_fused_step_size_policies_against_the_reference(backend, policy):
     assert not b0._fused_ok()
     b0.solve()
     assert rel_l2(np.asarray(its.L, float), np.asarray(b0.getitstat().L, float)) < 1e-4
+
+
+def test_residual_slots_against_numpy(backend):
+    """sporco_amd_csc_pgm_resid / _pgm_resid_stats: the inner products the step-size policies take of
+    the gradient g = conj(Df) e, e = sum_m Df v - Sf (sporco/pgm/stepsize.py:84-87, :137-141;
+    grad_f, hessian_f: pgm/cbpdn.py:263-279, :302-312), formed from signal-sized spectra -- against
+    the same sums formed from the X-sized arrays by NumPy; from the reference layout and, after a
+    fused iteration, from the tile-major one."""
+    from sporco_amd import _lib
+    from sporco_amd.pgm import cbpdn as pc
+    H = 256 if backend == 'gpu' else 128
+    K, N = 8, 2
+    D, S = problem(H, H, K, N, seed=5)
+    b = pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options({'MaxMainIter': 3, 'RelStopTol': 0.0, 'L': 50.0}))
+    b.solve()                                    # (the iterates are tile-major now)
+    dev = b.dev
+    Df = np.fft.rfft2(D.astype(np.float64), (H, H), axes=(0, 1))[:, :, None, :]      # (H, Wf, 1, K)
+    Sf = np.fft.rfft2(S.astype(np.float64), axes=(0, 1))[..., None]                # (H, Wf, N, 1)
+
+    def e_of(vf):
+        return np.sum(Df * vf, axis=-1, keepdims=True) - Sf
+
+    for tiled in (True, False):
+        dev.pgm_resid(_lib.VAR_YF, 0)
+        dev.pgm_resid(_lib.VAR_XF, 1)
+        dev.pgm_resid(_lib.VAR_XFPRV, 2)
+        s_y = dev.pgm_resid_stats(0)
+        s_d = dev.pgm_resid_stats(0, 1, 1, 2)
+        Yf = np.asarray(b.Yf, np.complex128).reshape(H, H // 2 + 1, N, K)          # (leaves the tiled layout)
+        Xf = np.asarray(b.Xf, np.complex128).reshape(Yf.shape)
+        Xp = dev.download(_lib.VAR_XFPRV).astype(np.complex128).reshape(Yf.shape)
+        g = np.conj(Df) * e_of(Yf)
+        Hg = np.conj(Df) * np.sum(Df * g, axis=-1, keepdims=True)
+        assert abs(s_y[0] - np.sum(np.abs(g) ** 2)) < 1e-4 * np.sum(np.abs(g) ** 2)
+        assert abs(s_y[1] - np.sum(np.real(np.conj(g) * Hg))) < 1e-4 * np.sum(np.real(np.conj(g) * Hg))
+        dg = np.conj(Df) * (e_of(Yf) - e_of(Xf))
+        dx = Xf - Xp
+        assert abs(s_d[0] - np.sum(np.abs(dg) ** 2)) < 1e-4 * np.sum(np.abs(dg) ** 2)
+        ref = np.sum(np.real(np.conj(dx) * dg))
+        assert abs(s_d[2] - ref) < 1e-4 * max(abs(ref), 1e-3 * np.sqrt(np.sum(np.abs(dx) ** 2) * np.sum(np.abs(dg) ** 2)))
