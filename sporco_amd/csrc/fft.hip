@@ -132,6 +132,63 @@ template <typename T, bool INV> struct Butterfly<T, 8, INV> {
     }
 };
 
+// Radix 3 and 5 (the factors of 240-, 320-, 360-, 384-, 480-point lines) with their constants in
+// the instruction stream: out_q = sum_s v_s W_R^(s q), W_R = exp(-/+ 2 pi i / R).
+template <typename T, bool INV> struct Butterfly<T, 3, INV> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[3]) {
+        const T h = T(0.86602540378443864676);        // sin(2 pi / 3)
+        const cx<T> t1 = v[1] + v[2];
+        const cx<T> m1 = mk<T>(v[0].re - T(0.5) * t1.re, v[0].im - T(0.5) * t1.im);
+        const cx<T> dq = quarter<T, INV>(cscale(v[1] - v[2], h));     // -/+ i h (v1 - v2)
+        v[0] = v[0] + t1;
+        v[1] = m1 + dq;
+        v[2] = m1 - dq;
+    }
+};
+
+template <typename T, bool INV> struct Butterfly<T, 5, INV> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[5]) {
+        const T c1 = T(0.30901699437494742410), c2 = T(-0.80901699437494742410);   // cos(2 pi/5), cos(4 pi/5)
+        const T s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);    // sin(2 pi/5), sin(4 pi/5)
+        const cx<T> t1 = v[1] + v[4], t2 = v[2] + v[3], t3 = v[1] - v[4], t4 = v[2] - v[3];
+        const cx<T> a1 = mk<T>(v[0].re + c1 * t1.re + c2 * t2.re, v[0].im + c1 * t1.im + c2 * t2.im);
+        const cx<T> a2 = mk<T>(v[0].re + c2 * t1.re + c1 * t2.re, v[0].im + c2 * t1.im + c1 * t2.im);
+        const cx<T> b1 = quarter<T, INV>(mk<T>(s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im));
+        const cx<T> b2 = quarter<T, INV>(mk<T>(s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im));
+        v[0] = v[0] + t1 + t2;
+        v[1] = a1 + b1;           // forward: a1 - i b1
+        v[4] = a1 - b1;
+        v[2] = a2 + b2;
+        v[3] = a2 - b2;
+    }
+};
+
+template <typename T, bool INV> struct Butterfly<T, 7, INV> {
+    static __device__ __forceinline__ void run(cx<T> (&v)[7]) {
+        // cos / sin of 2 pi m / 7, m = 1, 2, 3 (224-, 448-, 336-point lines)
+        const T c1 = T(0.62348980185873353053), c2 = T(-0.22252093395631440429), c3 = T(-0.90096886790241912624);
+        const T s1 = T(0.78183148246802980871), s2 = T(0.97492791218182360702), s3 = T(0.43388373911755812048);
+        const cx<T> t1 = v[1] + v[6], t2 = v[2] + v[5], t3 = v[3] + v[4];
+        const cx<T> d1 = v[1] - v[6], d2 = v[2] - v[5], d3 = v[3] - v[4];
+        auto comb = [](cx<T> x0, T ca, cx<T> xa, T cb, cx<T> xb, T cc, cx<T> xc) {
+            return mk<T>(x0.re + ca * xa.re + cb * xb.re + cc * xc.re, x0.im + ca * xa.im + cb * xb.im + cc * xc.im);
+        };
+        const cx<T> z = mk<T>(T(0), T(0));
+        const cx<T> a1 = comb(v[0], c1, t1, c2, t2, c3, t3), a2 = comb(v[0], c2, t1, c3, t2, c1, t3),
+                    a3 = comb(v[0], c3, t1, c1, t2, c2, t3);
+        const cx<T> b1 = quarter<T, INV>(comb(z, s1, d1, s2, d2, s3, d3));
+        const cx<T> b2 = quarter<T, INV>(comb(z, s2, d1, -s3, d2, -s1, d3));
+        const cx<T> b3 = quarter<T, INV>(comb(z, s3, d1, -s1, d2, s2, d3));
+        v[0] = v[0] + t1 + t2 + t3;
+        v[1] = a1 + b1;
+        v[6] = a1 - b1;
+        v[2] = a2 + b2;
+        v[5] = a2 - b2;
+        v[3] = a3 + b3;
+        v[4] = a3 - b3;
+    }
+};
+
 // One Stockham pass of radix R over the `cols` columns held by the workgroup.
 //   read  src[j + r*n/R],  twiddle exp(-/+ 2 pi i k r /(Ns R)), k = j mod Ns,
 //   write dst[(j div Ns) Ns R + k + q Ns]
@@ -276,11 +333,17 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
             if (R == 8) radix_pass<T, 8, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
             else if (R == 4) radix_pass<T, 4, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
             else if (R == 2) radix_pass<T, 2, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 3) radix_pass<T, 3, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 5) radix_pass<T, 5, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 7) radix_pass<T, 7, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
             else direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc);
         } else {
             if (R == 8) radix_pass<T, 8, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
             else if (R == 4) radix_pass<T, 4, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
             else if (R == 2) radix_pass<T, 2, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 3) radix_pass<T, 3, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 5) radix_pass<T, 5, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
+            else if (R == 7) radix_pass<T, 7, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
             else direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc);
         }
         __syncthreads();
@@ -384,7 +447,7 @@ template <typename T> struct ColsSmArgs {
 // R-point DFT of v (exp(-/+ 2 pi i s q / R)), any R, from the table of W_n^t (n a multiple of R)
 template <typename T, int R, bool INV>
 __device__ __forceinline__ void small_dft(cx<T> (&v)[R], const cx<T> *tw, int n) {
-    if constexpr (R == 2 || R == 4 || R == 8) {
+    if constexpr (R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 8) {
         Butterfly<T, R, INV>::run(v);
     } else {
         const int step = n / R;

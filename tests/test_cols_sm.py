@@ -22,6 +22,8 @@ CASES = {
     'f64_36x30_k6': (36, 30, 6, 2, np.float64),        # filter counts that are not powers of two
     'f32_40x48_k24': (40, 48, 24, 1, np.float32),
     'f64_24x40_k50': (24, 40, 50, 1, np.float64),
+    'f32_56x28_k8': (56, 28, 8, 2, np.float32),         # 7-point butterflies in both directions
+    'f64_49x42_k4': (49, 42, 4, 1, np.float64),
 }
 
 

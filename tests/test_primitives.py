@@ -83,3 +83,17 @@ def test_prox_operators(backend):
         prox.prox_l1(v, np.ones(7))
     with pytest.raises(NotImplementedError):
         prox.prox_l1(v.astype(np.complex128), a)
+
+
+@pytest.mark.parametrize('shape', [(56, 28, 3), (49, 42, 2), (63, 35, 4), (21, 15, 1), (45, 75, 2), (96, 80, 2)])
+@pytest.mark.parametrize('dt', [np.float64, np.float32])
+def test_rfftn_lengths_with_factors_3_5_7(backend, shape, dt):
+    """Lines whose lengths carry the factors 3, 5 and 7 (fft.hip: their butterflies carry the
+    constants in the instruction stream) against numpy.fft, both directions (sporco/fft.py:257-314)."""
+    from sporco_amd import fft as sf
+    rng = np.random.RandomState(shape[0])
+    x = rng.randn(*shape).astype(dt)
+    X = sf.rfftn(x, None, (0, 1))
+    tol = 1e-14 if dt == np.float64 else 2e-6
+    assert rel_l2(X, np.fft.rfft2(x.astype(np.float64), axes=(0, 1))) < tol
+    assert rel_l2(sf.irfftn(X, shape[:2], (0, 1)), x) < tol
