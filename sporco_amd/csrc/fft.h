@@ -17,11 +17,15 @@ constexpr int kMaxRadixPasses = 24;
 struct FftPlan {
     int n = 0;
     int nrad = 0;
-    int radix[kMaxRadixPasses] = {0};
+    int radix[kMaxRadixPasses] = {0};       // Stockham passes (fft_c2c / fft_r2c / fft_c2r): 8, 4, 2, 3, 5, 7, primes
+    // passes of the in-place transform of fft_cols_sm: every 3 with a 4 or a 2 (radix 12, 6),
+    // every 5 with a 2 (radix 10) -- prime-factor butterflies, one LDS round trip for two factors
+    int nrad_ip = 0;
+    int radix_ip[kMaxRadixPasses] = {0};
     cx<float> *tw32 = nullptr;   // device, W_n^t = exp(-2 pi i t / n), t in [0, n)
     cx<double> *tw64 = nullptr;  // device
     // device, n ints: the frequency held at position pos after the in-place decimation-in-
-    // frequency passes radix[0], radix[1], ... (fft_cols_sm)
+    // frequency passes radix_ip[0], radix_ip[1], ... (fft_cols_sm)
     int *drev = nullptr;
     void init(int n_);
     void destroy();

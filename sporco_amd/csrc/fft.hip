@@ -20,6 +20,7 @@
 
 #include "csc_post_elem.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -189,6 +190,42 @@ template <typename T, bool INV> struct Butterfly<T, 7, INV> {
     }
 };
 
+// Composite radices with coprime factors, R = N1 N2 (6 = 2*3, 10 = 2*5, 12 = 4*3), by the
+// prime-factor map: inputs taken at n = (N2 e2 n1 + N1 e1 n2) mod R with
+// e2 = N2^-1 mod N1, e1 = N1^-1 mod N2, outputs delivered at k = (N2 k1 + N1 k2) mod R make
+// W_R^(n k) = W_N1^(n1 k1) W_N2^(n2 k2): N1 transforms of length N2, then N2 of length N1, no
+// twiddles in between.  One LDS round trip then covers two prime factors of the line length.
+template <int A, int M> constexpr int inv_mod() {
+    for (int x = 1; x < M; ++x)
+        if ((A * x) % M == 1) return x;
+    return 1;
+}
+template <typename T, int N1, int N2, bool INV> struct PfaButterfly {
+    static __device__ __forceinline__ void run(cx<T> (&v)[N1 * N2]) {
+        constexpr int R = N1 * N2;
+        constexpr int C1 = N2 * inv_mod<N2 % N1, N1>(), C2 = N1 * inv_mod<N1 % N2, N2>();
+        cx<T> a[N1][N2];
+#pragma unroll
+        for (int n1 = 0; n1 < N1; ++n1) {
+#pragma unroll
+            for (int n2 = 0; n2 < N2; ++n2) a[n1][n2] = v[(C1 * n1 + C2 * n2) % R];
+            Butterfly<T, N2, INV>::run(a[n1]);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2) {
+            cx<T> b[N1];
+#pragma unroll
+            for (int n1 = 0; n1 < N1; ++n1) b[n1] = a[n1][k2];
+            Butterfly<T, N1, INV>::run(b);
+#pragma unroll
+            for (int k1 = 0; k1 < N1; ++k1) v[(N2 * k1 + N1 * k2) % R] = b[k1];
+        }
+    }
+};
+template <typename T, bool INV> struct Butterfly<T, 6, INV> : PfaButterfly<T, 2, 3, INV> {};
+template <typename T, bool INV> struct Butterfly<T, 10, INV> : PfaButterfly<T, 2, 5, INV> {};
+template <typename T, bool INV> struct Butterfly<T, 12, INV> : PfaButterfly<T, 4, 3, INV> {};
+
 // One Stockham pass of radix R over the `cols` columns held by the workgroup.
 //   read  src[j + r*n/R],  twiddle exp(-/+ 2 pi i k r /(Ns R)), k = j mod Ns,
 //   write dst[(j div Ns) Ns R + k + q Ns]
@@ -235,6 +272,30 @@ __device__ __forceinline__ void direct_pass(const cx<T> *__restrict__ src, cx<T>
             if (idx >= n) idx -= n;
         }
         dst[(j0 + q * Ns) * cols + col] = acc;
+    }
+}
+
+// (BIG: the kernels that also carry the 6-, 10- and 12-point butterflies -- they need more
+// registers, so lines without those radices run the lean instantiation)
+template <typename T, bool INV, bool BIG>
+__device__ __forceinline__ void stockham_pass_r(int R, const cx<T> *src, cx<T> *dst, const cx<T> *tw, int n,
+                                                int Ns, int cols, int col, int lane, int lpc) {
+    if constexpr (BIG) {
+        switch (R) {
+        case 6: radix_pass<T, 6, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); return;
+        case 10: radix_pass<T, 10, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); return;
+        case 12: radix_pass<T, 12, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); return;
+        default: break;
+        }
+    }
+    switch (R) {
+    case 8: radix_pass<T, 8, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); break;
+    case 4: radix_pass<T, 4, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); break;
+    case 2: radix_pass<T, 2, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); break;
+    case 3: radix_pass<T, 3, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); break;
+    case 5: radix_pass<T, 5, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); break;
+    case 7: radix_pass<T, 7, INV>(src, dst, tw, n, Ns, cols, col, lane, lpc); break;
+    default: direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc); break;
     }
 }
 
@@ -330,21 +391,9 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
     for (int p = 0; p < a.nrad; ++p) {
         const int R = a.radix[p];
         if (a.inverse) {
-            if (R == 8) radix_pass<T, 8, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 4) radix_pass<T, 4, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 2) radix_pass<T, 2, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 3) radix_pass<T, 3, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 5) radix_pass<T, 5, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 7) radix_pass<T, 7, true>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc);
+            stockham_pass_r<T, true, false>(R, src, dst, tw, n, Ns, cols, col, lane, lpc);
         } else {
-            if (R == 8) radix_pass<T, 8, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 4) radix_pass<T, 4, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 2) radix_pass<T, 2, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 3) radix_pass<T, 3, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 5) radix_pass<T, 5, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else if (R == 7) radix_pass<T, 7, false>(src, dst, tw, n, Ns, cols, col, lane, lpc);
-            else direct_pass<T>(src, dst, tw, n, R, Ns, cols, col, lane, lpc);
+            stockham_pass_r<T, false, false>(R, src, dst, tw, n, Ns, cols, col, lane, lpc);
         }
         __syncthreads();
         cx<T> *t = src;
@@ -447,7 +496,7 @@ template <typename T> struct ColsSmArgs {
 // R-point DFT of v (exp(-/+ 2 pi i s q / R)), any R, from the table of W_n^t (n a multiple of R)
 template <typename T, int R, bool INV>
 __device__ __forceinline__ void small_dft(cx<T> (&v)[R], const cx<T> *tw, int n) {
-    if constexpr (R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 8) {
+    if constexpr (R == 2 || R == 3 || R == 4 || R == 5 || R == 6 || R == 7 || R == 8 || R == 10 || R == 12) {
         Butterfly<T, R, INV>::run(v);
     } else {
         const int step = n / R;
@@ -495,9 +544,17 @@ __device__ __forceinline__ void inplace_pass(cx<T> *buf, const cx<T> *tw, int n,
     }
 }
 
-template <typename T, bool INV>
+template <typename T, bool INV, bool BIG>
 __device__ __forceinline__ void inplace_pass_r(int R, cx<T> *buf, const cx<T> *tw, int n, int m, int K,
                                                int ncol, int col, int lane, int lpc) {
+    if constexpr (BIG) {
+        switch (R) {
+        case 6: inplace_pass<T, 6, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); return;
+        case 10: inplace_pass<T, 10, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); return;
+        case 12: inplace_pass<T, 12, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); return;
+        default: break;
+        }
+    }
     switch (R) {
     case 8: inplace_pass<T, 8, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
     case 4: inplace_pass<T, 4, INV>(buf, tw, n, m, K, ncol, col, lane, lpc); break;
@@ -510,7 +567,7 @@ __device__ __forceinline__ void inplace_pass_r(int R, cx<T> *buf, const cx<T> *t
 
 // US: rows of solve operands (Df, Sf, gram) a thread requests together; when that covers all
 // its rows they are requested before the forward passes and arrive behind them.
-template <typename T, int US>
+template <typename T, int US, bool BIG = false>
 __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     const int n = a.n, K = a.K;
     cx<T> *buf = dyn_lds<cx<T>>();
@@ -575,7 +632,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     // ---- forward, in place ------------------------------------------------------------------
     int m = n;
     for (int p = 0; p < a.nrad; ++p) {
-        inplace_pass_r<T, false>(a.radix[p], buf, tw, n, m, K, K, col, lane, lpc);
+        inplace_pass_r<T, false, BIG>(a.radix[p], buf, tw, n, m, K, K, col, lane, lpc);
         m /= a.radix[p];
         __syncthreads();
     }
@@ -617,7 +674,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
     // ---- inverse, in place: the transposed flow ---------------------------------------------------
     for (int p = a.nrad - 1; p >= 0; --p) {
         m *= a.radix[p];
-        inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, K, K, col, lane, lpc);
+        inplace_pass_r<T, true, BIG>(a.radix[p], buf, tw, n, m, K, K, col, lane, lpc);
         __syncthreads();
     }
     if (cvalid)
@@ -632,7 +689,7 @@ __global__ void __launch_bounds__(1024) cols_sm_kernel(const ColsSmArgs<T> a) {
 // was written moments ago by this CU: L2 / MALL), apply the solve, inverse transform, store.
 // Four passes over the spectrum (the re-load mostly out of cache) instead of the six of the
 // three kernels.
-template <typename T>
+template <typename T, bool BIG = false>
 __global__ void __launch_bounds__(1024) cols_sm_slab_kernel(const ColsSmArgs<T> a) {
     const int n = a.n, K = a.K, Ks = a.Ks;
     cx<T> *buf = dyn_lds<cx<T>>();
@@ -680,7 +737,7 @@ __global__ void __launch_bounds__(1024) cols_sm_slab_kernel(const ColsSmArgs<T> 
         __syncthreads();
         int m = n;
         for (int p = 0; p < a.nrad; ++p) {
-            inplace_pass_r<T, false>(a.radix[p], buf, tw, n, m, Ks, kw, col, lane, lpc);
+            inplace_pass_r<T, false, BIG>(a.radix[p], buf, tw, n, m, Ks, kw, col, lane, lpc);
             m /= a.radix[p];
             __syncthreads();
         }
@@ -745,7 +802,7 @@ __global__ void __launch_bounds__(1024) cols_sm_slab_kernel(const ColsSmArgs<T> 
         int m = 1;
         for (int p = a.nrad - 1; p >= 0; --p) {
             m *= a.radix[p];
-            inplace_pass_r<T, true>(a.radix[p], buf, tw, n, m, Ks, kw, col, lane, lpc);
+            inplace_pass_r<T, true, BIG>(a.radix[p], buf, tw, n, m, Ks, kw, col, lane, lpc);
             __syncthreads();
         }
         if (cv)
@@ -763,18 +820,54 @@ void FftPlan::init(int n_) {
     destroy();
     n = n_;
     nrad = 0;
+    nrad_ip = 0;
     int m = n;
-    const int small[] = {8, 4, 2, 3, 5, 7};
-    for (int r : small)
-        while (m > 1 && m % r == 0) {
+    {
+        int e2 = 0, e3 = 0, e5 = 0, e7 = 0;
+        while (m % 2 == 0) m /= 2, ++e2;
+        while (m % 3 == 0) m /= 3, ++e3;
+        while (m % 5 == 0) m /= 5, ++e5;
+        while (m % 7 == 0) m /= 7, ++e7;
+        auto push = [&](int r) {
             SA_REQUIRE(nrad < kMaxRadixPasses, "FFT length has too many factors");
             radix[nrad++] = r;
-            m /= r;
+        };
+        auto push_ip = [&](int r) {
+            SA_REQUIRE(nrad_ip < kMaxRadixPasses, "FFT length has too many factors");
+            radix_ip[nrad_ip++] = r;
+        };
+        {
+            int a2 = e2;
+            for (; a2 >= 3; a2 -= 3) push(8);
+            for (; a2 >= 2; a2 -= 2) push(4);
+            for (; a2 >= 1; --a2) push(2);
+            for (int i = 0; i < e3; ++i) push(3);
+            for (int i = 0; i < e5; ++i) push(5);
+            for (int i = 0; i < e7; ++i) push(7);
         }
+        // (the composite passes pay in the in-place kernel -- 10-20 % off the fused column pass at
+        // 240 / 320 / 384 / 480 points -- and cost the Stockham line kernels registers and occupancy:
+        // profiles/r04y9_fft_radices.jsonl; SPORCO_AMD_FFT_PLAIN_RADICES=1 keeps both lists plain)
+        const bool plain = std::getenv("SPORCO_AMD_FFT_PLAIN_RADICES") != nullptr;
+        int a2 = e2, a3 = e3, a5 = e5;
+        if (!plain) {
+            while (a3 > 0 && a2 >= 2) push_ip(12), --a3, a2 -= 2;
+            while (a3 > 0 && a2 >= 1) push_ip(6), --a3, --a2;
+            while (a5 > 0 && a2 >= 1) push_ip(10), --a5, --a2;
+        }
+        for (; a2 >= 3; a2 -= 3) push_ip(8);
+        for (; a2 >= 2; a2 -= 2) push_ip(4);
+        for (; a2 >= 1; --a2) push_ip(2);
+        for (; a3 > 0; --a3) push_ip(3);
+        for (; a5 > 0; --a5) push_ip(5);
+        for (int i = 0; i < e7; ++i) push_ip(7);
+        std::sort(radix_ip, radix_ip + nrad_ip, [](int x, int y) { return x > y; });
+    }
     for (int p = 11; m > 1; p += 2)
         while (m % p == 0) {
-            SA_REQUIRE(nrad < kMaxRadixPasses, "FFT length has too many factors");
+            SA_REQUIRE(nrad < kMaxRadixPasses && nrad_ip < kMaxRadixPasses, "FFT length has too many factors");
             radix[nrad++] = p;
+            radix_ip[nrad_ip++] = p;
             m /= p;
         }
     std::vector<cx<float>> t32(n);
@@ -794,11 +887,11 @@ void FftPlan::init(int n_) {
     std::vector<int> dr(n);
     for (int pos = 0; pos < n; ++pos) {
         int rem = pos, f = 0, weight = 1, mcur = n;
-        for (int p = 0; p < nrad; ++p) {
-            const int sub = mcur / radix[p];
+        for (int p = 0; p < nrad_ip; ++p) {
+            const int sub = mcur / radix_ip[p];
             f += (rem / sub) * weight;
             rem %= sub;
-            weight *= radix[p];
+            weight *= radix_ip[p];
             mcur = sub;
         }
         dr[pos] = f;
@@ -1051,8 +1144,10 @@ template <typename T> static int cols_sm_slab_width(int n, int K) {
 
 template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K) {
     if (K < 2 || plan.n < 2) return false;
-    for (int p = 0; p < plan.nrad; ++p)
-        if (plan.radix[p] > 8 || plan.radix[p] == 6) return false;
+    for (int p = 0; p < plan.nrad_ip; ++p) {
+        const int r = plan.radix_ip[p];
+        if (r > 12 || r == 9 || r == 11) return false;
+    }
     if (K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget && !std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB"))
         return true;
     return K <= 256 && cols_sm_slab_width<T>(plan.n, K) > 0 && !std::getenv("SPORCO_AMD_NO_COLS_SM_SLAB");
@@ -1077,21 +1172,31 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
     a.Kp = 2;
     while (a.Kp < K) a.Kp <<= 1;
     a.W = W;
-    a.nrad = plan.nrad;
-    for (int i = 0; i < plan.nrad; ++i) a.radix[i] = plan.radix[i];
+    a.nrad = plan.nrad_ip;
+    for (int i = 0; i < plan.nrad_ip; ++i) a.radix[i] = plan.radix_ip[i];
     a.want_obj = want_obj ? 1 : 0;
     a.partials = partials;
+    bool big = false;       // (a 10-, 12-, 14- or 15-point pass: the instantiations that carry them)
+    for (int i = 0; i < plan.nrad_ip; ++i) big = big || plan.radix_ip[i] == 6 || plan.radix_ip[i] >= 10;
     static PerDeviceOnce attr_set;
     if (!(K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget) || std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB")) {
         // the tile goes through in slabs of filters
         a.Ks = cols_sm_slab_width<T>(plan.n, K);
         static PerDeviceOnce slab_attr;
-        if (slab_attr.first())
-            SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_slab_kernel<T>),
+        if (slab_attr.first()) {
+            SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_slab_kernel<T, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+            SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_slab_kernel<T, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        }
         const int64_t tiles = (int64_t)Wf * CN;
-        hipLaunchKernelGGL((cols_sm_slab_kernel<T>), dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(1024),
-                           cols_sm_slab_lds<T>(plan.n, a.Ks), st, a);
+        const dim3 sgrid((unsigned)(8 * ((tiles + 7) / 8)));
+        if (big)
+            hipLaunchKernelGGL((cols_sm_slab_kernel<T, true>), sgrid, dim3(1024), cols_sm_slab_lds<T>(plan.n, a.Ks),
+                               st, a);
+        else
+            hipLaunchKernelGGL((cols_sm_slab_kernel<T, false>), sgrid, dim3(1024), cols_sm_slab_lds<T>(plan.n, a.Ks),
+                               st, a);
         SA_HIP(hipGetLastError());
         return tiles;
     }
@@ -1105,13 +1210,17 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_kernel<T, UM / 3, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     }
     const int64_t tiles = (int64_t)Wf * CN;
     const unsigned grid = (unsigned)(8 * ((tiles + 7) / 8));
     // rows per thread: all operands in one batch while the registers allow it
     const int nit = (int)ceil_div(plan.n, threads / a.Kp);
     constexpr int UMAX = sizeof(T) == 8 ? 6 : 12;
-    if (nit <= UMAX / 3)
+    if (big)       // (the wide butterflies leave no registers for a long operand batch)
+        hipLaunchKernelGGL((cols_sm_kernel<T, UMAX / 3, true>), dim3(grid), dim3(threads), lds, st, a);
+    else if (nit <= UMAX / 3)
         hipLaunchKernelGGL((cols_sm_kernel<T, UMAX / 3>), dim3(grid), dim3(threads), lds, st, a);
     else if (nit <= 2 * UMAX / 3 || nit > UMAX)
         hipLaunchKernelGGL((cols_sm_kernel<T, 2 * UMAX / 3>), dim3(grid), dim3(threads), lds, st, a);
