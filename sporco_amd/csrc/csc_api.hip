@@ -234,6 +234,12 @@ template <typename T> struct Csc : CscBase {
         planH.init(H);
         SA_HIP(hipMalloc((void **)&part_a, sizeof(double) * kMaxPartialBlocks * 8));
         SA_HIP(hipMalloc((void **)&part_b, sizeof(double) * kMaxPartialBlocks * 8));
+        if (const char *e = std::getenv("SPORCO_AMD_ALLOC_PERTURB")) {
+            // (measurement knob: a dummy allocation of e MiB first, which moves every later buffer --
+            // the multi-stream kernels are sensitive to how their arrays fall on the HBM channels)
+            void *dummy = nullptr;
+            SA_HIP(hipMalloc(&dummy, (size_t)std::atoi(e) << 20));
+        }
         SA_HIP(hipMalloc((void **)&out_dev_own, sizeof(double) * kOutSlots));
         SA_HIP(hipMemset(out_dev_own, 0, sizeof(double) * kOutSlots));
         SA_HIP(hipHostMalloc((void **)&out_pinned, sizeof(double) * kOutSlots, 0));
@@ -298,11 +304,60 @@ template <typename T> struct Csc : CscBase {
         for (int v : {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U, SPORCO_AMD_VAR_X}) (void)var_ptr(v);
     }
 
+    // Large device buffers start on 64 MiB boundaries.  hipMalloc hands out 2 MiB-aligned blocks; where
+    // an X-sized array (2 GiB at the headline configuration) starts relative to larger boundaries
+    // then depends on what the process allocated before -- and the streaming kernels feel it: the
+    // emitting row epilogue takes 1.49, 1.65 or 1.79 ms per launch with nothing but a dummy
+    // allocation of 0 / 2 / 258 MiB made first, and 1.49-1.51 ms in every case once its arrays are
+    // aligned to 64 MiB or more (profiles/r04zc_alloc_placement.txt; presumably the size of the
+    // page-table fragments the driver can map them with).  Staggering the arrays by sub-page
+    // offsets (SPORCO_AMD_ALLOC_SKEW_KB, a measurement knob) changes nothing.
+    std::vector<std::pair<void *, void *>> skew_reg;   // (pointer handed out, base of its allocation)
+    int skew_count = 0;
+    void big_alloc(void **p, size_t bytes) {
+        static const long skew_kb = std::getenv("SPORCO_AMD_ALLOC_SKEW_KB")
+                                        ? std::atol(std::getenv("SPORCO_AMD_ALLOC_SKEW_KB")) : kAllocSkewKb;
+        static const long align_mb = std::getenv("SPORCO_AMD_ALLOC_ALIGN_MB")
+                                         ? std::atol(std::getenv("SPORCO_AMD_ALLOC_ALIGN_MB")) : kAllocAlignMb;
+        if (align_mb > 0 && bytes >= ((size_t)64 << 20)) {
+            const size_t al = (size_t)align_mb << 20;
+            void *base = nullptr;
+            SA_HIP(hipMalloc(&base, bytes + al));
+            const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+            *p = reinterpret_cast<void *>((b + al - 1) / al * al);
+            skew_reg.emplace_back(*p, base);
+            return;
+        }
+        if (skew_kb <= 0 || bytes < ((size_t)64 << 20)) {
+            SA_HIP(hipMalloc(p, bytes));
+            return;
+        }
+        const size_t unit = (size_t)skew_kb * 1024, off = (size_t)(1 + skew_count++ % 7) * unit;
+        void *base = nullptr;
+        SA_HIP(hipMalloc(&base, bytes + 8 * unit));
+        *p = static_cast<char *>(base) + off;
+        skew_reg.emplace_back(*p, base);
+    }
+    void big_free(void *p) {
+        if (!p) return;
+        for (auto &e : skew_reg)
+            if (e.first == p) {
+                (void)hipFree(e.second);
+                e.first = nullptr;
+                return;
+            }
+        (void)hipFree(p);
+    }
+
     ~Csc() override {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(st);
-        for (auto &v : vars)
-            if (v) (void)hipFree(v);
+        for (auto &v : vars) big_free(v);
+        big_free(y_alt);
+        big_free(u_alt);
+        big_free(work);
+        y_alt = u_alt = nullptr;
+        work = nullptr;
         for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar,
                         (void *)part_c2r, (void *)cns_w, (void *)cns_sft, (void *)flt_h, (void *)flt_w,
                         (void *)zf_ch, (void *)zfv_buf, (void *)md_sft, (void *)md_coef, (void *)pgm_rx[0], (void *)pgm_rx[1]})
@@ -351,7 +406,7 @@ template <typename T> struct Csc : CscBase {
             // (the Xf buffer also holds the tile-major spectrum, whose rows may be padded)
             const size_t nb = var == SPORCO_AMD_VAR_XF ? sizeof(cx<T>) * (size_t)std::max(EF, EFt)
                                                        : var_bytes(var);
-            SA_HIP(hipMalloc(&vars[var], nb));
+            big_alloc(&vars[var], nb);
             SA_HIP(hipMemsetAsync(vars[var], 0, nb, st));
         }
         return vars[var];
@@ -359,7 +414,7 @@ template <typename T> struct Csc : CscBase {
     T *rv(int var) { return static_cast<T *>(var_ptr(var)); }
     cx<T> *cv(int var) { return static_cast<cx<T> *>(var_ptr(var)); }
     cx<T> *work_buf() {
-        if (!work) SA_HIP(hipMalloc((void **)&work, sizeof(cx<T>) * std::max(EF, EFt)));
+        if (!work) big_alloc((void **)&work, sizeof(cx<T>) * std::max(EF, EFt));
         return work;
     }
     cx<T> *dwork_buf() {

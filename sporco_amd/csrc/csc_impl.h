@@ -23,6 +23,10 @@
 
 namespace sporco_amd {
 
+// stagger of the large device buffers, in KiB (csc_api.hip big_alloc; SPORCO_AMD_ALLOC_SKEW_KB overrides; 0: none)
+constexpr long kAllocSkewKb = 0;
+constexpr long kAllocAlignMb = 64;    // alignment of the large device buffers, MiB (SPORCO_AMD_ALLOC_ALIGN_MB)
+
 extern thread_local std::string g_last_error;
 
 // Every host <-> device copy of this file is counted (sporco_amd_transfer_stats): the claim
