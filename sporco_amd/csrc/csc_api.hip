@@ -308,10 +308,12 @@ template <typename T> struct Csc : CscBase {
     // an X-sized array (2 GiB at the headline configuration) starts relative to larger boundaries
     // then depends on what the process allocated before -- and the streaming kernels feel it: the
     // emitting row epilogue takes 1.49, 1.65 or 1.79 ms per launch with nothing but a dummy
-    // allocation of 0 / 2 / 258 MiB made first, and 1.49-1.51 ms in every case once its arrays are
-    // aligned to 64 MiB or more (profiles/r04zc_alloc_placement.txt; presumably the size of the
-    // page-table fragments the driver can map them with).  Staggering the arrays by sub-page
-    // offsets (SPORCO_AMD_ALLOC_SKEW_KB, a measurement knob) changes nothing.
+    // allocation of 0 / 2 / 258 MiB made first.  With its arrays aligned to 64 MiB or more the
+    // perturbed cases came back to 1.49-1.51 ms in the session that tried it; later sessions showed
+    // the alignment is not sufficient (profiles/r04zc_alloc_placement.txt: the level also follows
+    // physical placement).  Kept: it costs 64 MiB per large buffer and never measured slower.
+    // Staggering the arrays by sub-page offsets (SPORCO_AMD_ALLOC_SKEW_KB, a measurement knob)
+    // changes nothing.
     std::vector<std::pair<void *, void *>> skew_reg;   // (pointer handed out, base of its allocation)
     int skew_count = 0;
     void big_alloc(void **p, size_t bytes) {
