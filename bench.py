@@ -762,6 +762,14 @@ def main():
         print("bench.py: no AMD GPU visible", file=sys.stderr)
         sys.exit(3)
 
+    if os.environ.get('SPORCO_AMD_BENCH_PREALLOC_MB'):
+        # (measurement knob of tools/placement_ab.py: device memory taken before the solver exists,
+        # which moves every array of the run to other physical memory)
+        import ctypes
+        dummy = ctypes.c_void_p()
+        _lib.check(_lib.lib().sporco_amd_dev_malloc(
+            ctypes.c_size_t(int(os.environ['SPORCO_AMD_BENCH_PREALLOC_MB']) << 20), ctypes.byref(dummy)))
+
     reducer, stream, torch, dist = None, None, None, None
     if world > 1:
         import torch
@@ -912,6 +920,9 @@ def main():
     sync_all(b)
     prof = b.profile_read()
     b.profile(False)
+    # where the library put the arrays the dominant kernel writes at the same time
+    # (sporco_amd_csc_placement_report; profiles/r05_placement_notes.md)
+    placement = b._dev.placement_report()
     t1 = time.perf_counter()
     y_host = cbpdn.ConvBPDN.getmin(b)          # what solve() would hand back to the caller
     download_ms = 1e3 * (time.perf_counter() - t1)
@@ -994,7 +1005,8 @@ def main():
                      'algorithmic_bytes_per_launch': alg[dom],
                      'algorithmic_achieved': alg[dom] / dom_ms / 1e6,
                      'algorithmic_frac': alg[dom] / dom_ms / 1e6 / HBM_PEAK_GBPS,
-                     'from_profiles': from_profiles},
+                     'from_profiles': from_profiles,
+                     'placement': placement},
         'iteration_roofline': dict(
             iteration_summary(table, prof_steps, ms_per_step, iter_alg_bytes),
             steady_state_algorithmic_frac=iter_alg_bytes * (steady_steps / elapsed_steady) / 1e9

@@ -174,6 +174,17 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
                                             ran their iterations as one launch (small problems:
                                             see sporco_amd_csc_admm_run) -- diagnostics */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
+/* Diagnostics, no reference counterpart: where the handle put the X-sized arrays that one kernel
+ * writes at the same time (the spectrum buffer T and the iterate buffers of the fused ADMM
+ * iteration).  Two arrays that take streaming stores concurrently share ~4.7 TB/s on the MI355X
+ * when their physical memory lies in the same region of the device memory and get ~6.3 TB/s when
+ * it does not (tools/ubench/place_probe.hip, profiles/r05_placement_notes.md), so the handle takes
+ * such a buffer from a few candidate allocations, each timed against the arrays it must keep
+ * clear of.  The report is a JSON list, one object per decision: role, bytes, candidates tried,
+ * the same-region reference rate, probe rate / reference of the first and of the chosen candidate
+ * (>= 1.09: clear).  Arrays below 256 MiB are placed as they come (empty list);
+ * SPORCO_AMD_PLACEMENT=0 in the environment switches the search off. */
+int sporco_amd_csc_placement_report(sporco_amd_csc_t h, char *buf, size_t cap);
 /* Hints about how the handle will be used (never needed for correctness; no reference
  * counterpart).  KEEP_VFORM: the caller alternates short device-driven runs with
  * sporco_amd_csc_ccmod_setcoef(VAR_Y) and does not read Y or U in between -- the loop of

@@ -55,7 +55,7 @@ EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
     'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc',
     'sporco_amd_csc_destroy',
-    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_set_hint', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict', 'sporco_amd_csc_set_dict_imag',
+    'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_placement_report', 'sporco_amd_csc_set_hint', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict', 'sporco_amd_csc_set_dict_imag',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
     'sporco_amd_csc_set_grad_weight', 'sporco_amd_csc_set_ams_mask',
     'sporco_amd_csc_upload', 'sporco_amd_csc_download', 'sporco_amd_csc_device_ptr',
@@ -227,6 +227,7 @@ def load(path=None):
         'sporco_amd_csc_destroy': [vp], 'sporco_amd_csc_sync': [vp],
         'sporco_amd_csc_stream': [vp, ctypes.POINTER(ctypes.c_void_p)],
         'sporco_amd_csc_query': [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+        'sporco_amd_csc_placement_report': [vp, ctypes.c_char_p, ctypes.c_size_t],
         'sporco_amd_csc_set_hint': [vp, ctypes.c_int, ctypes.c_int],
         'sporco_amd_csc_set_signal': [vp, vp],
         'sporco_amd_csc_set_dict': [vp, vp, i32, i32],
@@ -474,6 +475,14 @@ class Solver(object):
         out = ctypes.c_int(0)
         check(self._lib.sporco_amd_csc_query(self._h, int(what), ctypes.byref(out)))
         return out.value
+
+    def placement_report(self):
+        """Where the handle put the arrays one kernel writes at the same time
+        (sporco_amd_csc_placement_report): a list of dicts, one per decision."""
+        import json
+        buf = ctypes.create_string_buffer(8192)
+        check(self._lib.sporco_amd_csc_placement_report(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode() or '[]')
 
     def _query(self, what):
         return bool(self.query(what))

@@ -278,6 +278,31 @@ SA_INST_PREPOST(float)
 SA_INST_PREPOST(double)
 
 // ---------------------------------------------------------------------------
+// placement probe (csc_kernels.h launch_place_probe)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) place_probe_kernel(float *a, float *b, int64_t n16, int64_t win16,
+                                                               int64_t step_a, int64_t step_b, int fresh_a,
+                                                               int fresh_b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = i / win16, o = i - w * win16;
+        float *pa = a + 4 * (w * step_a + o), *pb = b + 4 * (w * step_b + o);
+        float xa[4] = {0.f, 0.f, 0.f, 0.f}, xb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!fresh_a) sa_stream_load4(pa, xa);     // (moved, never computed on: any bit pattern survives)
+        if (!fresh_b) sa_stream_load4(pb, xb);
+        sa_stream_store4(pa, xa);
+        sa_stream_store4(pb, xb);
+    }
+}
+void launch_place_probe(hipStream_t st, void *a, void *b, int64_t n16, int64_t win16, int64_t step_a,
+                        int64_t step_b, bool fresh_a, bool fresh_b) {
+    hipLaunchKernelGGL(place_probe_kernel, dim3(grid_for(n16)), dim3(kThreads), 0, st,
+                       static_cast<float *>(a), static_cast<float *>(b), n16, win16, step_a, step_b,
+                       fresh_a ? 1 : 0, fresh_b ? 1 : 0);
+    SA_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------
 // conjugate gradients with device-side scalars (csc_kernels.h)
 // ---------------------------------------------------------------------------
 __global__ void cg_init_kernel(CgCtl *c, CgPinned *pin, double atol, int maxit) {

@@ -97,6 +97,15 @@ int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out) {
     SA_API_END
 }
 
+int sporco_amd_csc_placement_report(sporco_amd_csc_t h, char *buf, size_t cap) {
+    SA_API_BEGIN
+    SA_HANDLE(h);
+    SA_REQUIRE(buf != nullptr && cap > 0, "null or empty report buffer");
+    const std::string r = h->impl->placement();
+    std::snprintf(buf, cap, "%s", r.c_str());
+    SA_API_END
+}
+
 int sporco_amd_csc_set_signal(sporco_amd_csc_t h, const void *S) {
     SA_API_BEGIN
     SA_HANDLE(h);

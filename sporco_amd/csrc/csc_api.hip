@@ -9,6 +9,9 @@
 // The extern "C" entry points are in csc_abi.hip, the stateless primitives in csc_prims.hip.
 #include "csc_impl.h"
 
+#include <chrono>
+#include <string>
+
 namespace sporco_amd {
 
 thread_local std::string g_last_error;
@@ -234,12 +237,6 @@ template <typename T> struct Csc : CscBase {
         planH.init(H);
         SA_HIP(hipMalloc((void **)&part_a, sizeof(double) * kMaxPartialBlocks * 8));
         SA_HIP(hipMalloc((void **)&part_b, sizeof(double) * kMaxPartialBlocks * 8));
-        if (const char *e = std::getenv("SPORCO_AMD_ALLOC_PERTURB")) {
-            // (measurement knob: a dummy allocation of e MiB first, which moves every later buffer --
-            // the multi-stream kernels are sensitive to how their arrays fall on the HBM channels)
-            void *dummy = nullptr;
-            SA_HIP(hipMalloc(&dummy, (size_t)std::atoi(e) << 20));
-        }
         SA_HIP(hipMalloc((void **)&out_dev_own, sizeof(double) * kOutSlots));
         SA_HIP(hipMemset(out_dev_own, 0, sizeof(double) * kOutSlots));
         SA_HIP(hipHostMalloc((void **)&out_pinned, sizeof(double) * kOutSlots, 0));
@@ -304,25 +301,21 @@ template <typename T> struct Csc : CscBase {
         for (int v : {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U, SPORCO_AMD_VAR_X}) (void)var_ptr(v);
     }
 
-    // Large device buffers start on 64 MiB boundaries.  hipMalloc hands out 2 MiB-aligned blocks; where
-    // an X-sized array (2 GiB at the headline configuration) starts relative to larger boundaries
-    // then depends on what the process allocated before -- and the streaming kernels feel it: the
-    // emitting row epilogue takes 1.49, 1.65 or 1.79 ms per launch with nothing but a dummy
-    // allocation of 0 / 2 / 258 MiB made first.  With its arrays aligned to 64 MiB or more the
-    // perturbed cases came back to 1.49-1.51 ms in the session that tried it; later sessions showed
-    // the alignment is not sufficient (profiles/r04zc_alloc_placement.txt: the level also follows
-    // physical placement).  Kept: it costs 64 MiB per large buffer and never measured slower.
-    // Staggering the arrays by sub-page offsets (SPORCO_AMD_ALLOC_SKEW_KB, a measurement knob)
-    // changes nothing.
+    // Large device buffers start on 64 MiB boundaries (hipMalloc hands out 2 MiB-aligned blocks).
+    // Which REGION of the device memory an array lies in is what the kernels with two concurrent
+    // write streams feel (api_placement.inc) -- the alignment is kept from round 4 because it costs
+    // 64 MiB per large buffer and never measured slower, not because it places anything.
     std::vector<std::pair<void *, void *>> skew_reg;   // (pointer handed out, base of its allocation)
-    int skew_count = 0;
     void big_alloc(void **p, size_t bytes) {
-        static const long skew_kb = std::getenv("SPORCO_AMD_ALLOC_SKEW_KB")
-                                        ? std::atol(std::getenv("SPORCO_AMD_ALLOC_SKEW_KB")) : kAllocSkewKb;
-        static const long align_mb = std::getenv("SPORCO_AMD_ALLOC_ALIGN_MB")
-                                         ? std::atol(std::getenv("SPORCO_AMD_ALLOC_ALIGN_MB")) : kAllocAlignMb;
-        if (align_mb > 0 && bytes >= ((size_t)64 << 20)) {
-            const size_t al = (size_t)align_mb << 20;
+        // a candidate an earlier placement search set aside (api_placement.inc) serves first
+        for (size_t i = 0; i < spare_big.size(); ++i)
+            if (spare_big[i].second >= bytes && spare_big[i].second <= bytes + bytes / 8) {
+                *p = spare_big[i].first;
+                spare_big.erase(spare_big.begin() + i);
+                return;
+            }
+        if (bytes >= ((size_t)64 << 20)) {
+            const size_t al = (size_t)kAllocAlignMb << 20;
             void *base = nullptr;
             SA_HIP(hipMalloc(&base, bytes + al));
             const uintptr_t b = reinterpret_cast<uintptr_t>(base);
@@ -330,15 +323,7 @@ template <typename T> struct Csc : CscBase {
             skew_reg.emplace_back(*p, base);
             return;
         }
-        if (skew_kb <= 0 || bytes < ((size_t)64 << 20)) {
-            SA_HIP(hipMalloc(p, bytes));
-            return;
-        }
-        const size_t unit = (size_t)skew_kb * 1024, off = (size_t)(1 + skew_count++ % 7) * unit;
-        void *base = nullptr;
-        SA_HIP(hipMalloc(&base, bytes + 8 * unit));
-        *p = static_cast<char *>(base) + off;
-        skew_reg.emplace_back(*p, base);
+        SA_HIP(hipMalloc(p, bytes));
     }
     void big_free(void *p) {
         if (!p) return;
@@ -354,6 +339,9 @@ template <typename T> struct Csc : CscBase {
     ~Csc() override {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(st);
+        place_release_spares();
+        for (hipEvent_t e : place_ev)
+            if (e) (void)hipEventDestroy(e);
         for (auto &v : vars) big_free(v);
         big_free(y_alt);
         big_free(u_alt);
@@ -408,7 +396,14 @@ template <typename T> struct Csc : CscBase {
             // (the Xf buffer also holds the tile-major spectrum, whose rows may be padded)
             const size_t nb = var == SPORCO_AMD_VAR_XF ? sizeof(cx<T>) * (size_t)std::max(EF, EFt)
                                                        : var_bytes(var);
-            big_alloc(&vars[var], nb);
+            if (var == SPORCO_AMD_VAR_XF && vars[SPORCO_AMD_VAR_Y] && vars[SPORCO_AMD_VAR_U]) {
+                // the spectrum buffer is written together with the iterate (emitting row epilogue):
+                // clear of the two arrays the iterate starts in (api_placement.inc)
+                vars[var] = place_alloc(nb, {{vars[SPORCO_AMD_VAR_Y], sizeof(T) * (size_t)E},
+                                             {vars[SPORCO_AMD_VAR_U], sizeof(T) * (size_t)E}}, "T");
+            } else {
+                big_alloc(&vars[var], nb);
+            }
             SA_HIP(hipMemsetAsync(vars[var], 0, nb, st));
         }
         return vars[var];
@@ -449,6 +444,16 @@ template <typename T> struct Csc : CscBase {
         else if (what == SPORCO_AMD_HINT_ONE_LAUNCH) hint_one_launch = value != 0;
         else throw Error(SPORCO_AMD_EINVAL, "unknown hint");
     }
+    std::string placement() override { return placement_report(); }
+    // the second pair of iterate buffers (the (Y, U) ping-pong, and the two V buffers of the
+    // single-array state): each clear of the spectrum buffer they are written together with
+    void alloc_alt_pair() {
+        if (y_alt) return;
+        void *t = var_ptr(SPORCO_AMD_VAR_XF);
+        const size_t tb = sizeof(cx<T>) * (size_t)std::max(EF, EFt), nb = sizeof(T) * (size_t)E;
+        y_alt = static_cast<T *>(place_alloc(nb, {{t, tb}}, "V0"));
+        u_alt = static_cast<T *>(place_alloc(nb, {{t, tb}}, "V1"));
+    }
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_FUSED_ROWS) return rows_ok ? 1 : 0;
@@ -459,6 +464,7 @@ template <typename T> struct Csc : CscBase {
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
 
+#include "api_placement.inc"
 #include "api_transforms.inc"
 #include "api_setup.inc"
 #include "api_admm_run.inc"

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <memory>
+#include <string>
 #include <utility>
 #include <cstring>
 #include <vector>
@@ -23,9 +24,7 @@
 
 namespace sporco_amd {
 
-// stagger of the large device buffers, in KiB (csc_api.hip big_alloc; SPORCO_AMD_ALLOC_SKEW_KB overrides; 0: none)
-constexpr long kAllocSkewKb = 0;
-constexpr long kAllocAlignMb = 64;    // alignment of the large device buffers, MiB (SPORCO_AMD_ALLOC_ALIGN_MB)
+constexpr long kAllocAlignMb = 64;    // alignment of the large device buffers, MiB (csc_api.hip big_alloc)
 
 extern thread_local std::string g_last_error;
 
@@ -156,6 +155,7 @@ struct CscBase {
     virtual void sync() = 0;
     virtual void *stream_handle() = 0;
     virtual int query(int what) = 0;
+    virtual std::string placement() = 0;
     virtual void set_hint(int what, int value) = 0;
     virtual void set_signal(const void *S) = 0;
     virtual void set_signal_dev(const void *S_dev) = 0;

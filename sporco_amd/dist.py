@@ -281,6 +281,15 @@ class NativeReducer(object):
 
     def close(self):
         if getattr(self, '_h', None):
+            # solvers that still hold the raw communicator pointer must not use it after this
+            for ref in getattr(self, '_attached', ()):
+                solver = ref()
+                if solver is not None:
+                    try:
+                        solver.set_comm(None)
+                    except Exception:
+                        pass
+            self._attached = []
             self._lib.sporco_amd_comm_destroy(self._h)
             self._h = None
 
@@ -298,6 +307,11 @@ class NativeReducer(object):
         """The device-driven solve needs no hook: the library all-reduces on the solver's
         stream once the communicator is attached.  Returns the marker the caller passes on."""
         solver.set_comm(self._h.value)
+        import weakref
+        if not hasattr(self, '_attached'):
+            self._attached = []
+        if not any(r() is solver for r in self._attached):
+            self._attached.append(weakref.ref(solver))
         return False       # (not None: "sharded, and the library does the reduction itself")
 
     def admm_iter(self, solver, params):
@@ -330,6 +344,7 @@ class NativeReducer(object):
     # -- arrays in device memory --------------------------------------------------------------
     def all_reduce_ptr(self, solver, ptr, count, f32, prescale=1.0):
         from . import _lib
+        solver.sync()      # (the prescale runs on the null stream: the producer of `ptr` first)
         if prescale != 1.0:
             _lib.check(self._lib.sporco_amd_dev_axpby(_lib.F32 if f32 else _lib.F64, int(count),
                                                       float(prescale), ctypes.c_void_p(ptr), 0.0,

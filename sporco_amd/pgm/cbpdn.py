@@ -188,7 +188,11 @@ class ConvBPDN(pgm.PGMDFT):
         if (bt is not None and type(bt) not in (BacktrackStandard, BacktrackRobust)) \
                 or (pol is not None and type(pol) not in (StepSizePolicyCauchy, StepSizePolicyBB)) \
                 or (self.opt['Monotone'] and (bt is not None or pol is not None)) \
+                or (bt is not None and pol is not None) \
                 or not self.dev.uses_fused_pgm():
+            # (a backtracking rule AND a step-size policy: the reference's backtrack.update calls
+            # xstep() on every trial, which re-applies the policy and BB's store_prev_state each
+            # time, backtrack.py:83-117 / pgm.py:786-803 -- the staged composition does exactly that)
             return False
         if pol is not None and (self.cri.Cd > 1 or self.cri.M % 2):
             return False     # (the residual slots: single-channel dictionary, unpadded filter axis)
@@ -266,7 +270,10 @@ class ConvBPDN(pgm.PGMDFT):
             if self.k > 1:
                 dev.pgm_resid(_lib.VAR_YF, 0)
                 s = dev.pgm_resid_stats(0)
-                self.L = self.dtype.type(s[1] / s[0])
+                # (numpy division as in stepsize.py:88-90: a zero gradient gives nan / inf and a
+                # warning there, not an exception)
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    self.L = self.dtype.type(np.float64(s[1]) / np.float64(s[0]))
             return True
         par = getattr(pol, '_slot_parity', 0)
         have = getattr(pol, '_slots_filled', False)
@@ -277,7 +284,8 @@ class ConvBPDN(pgm.PGMDFT):
         dev.pgm_resid(_lib.VAR_XF, xcur)
         if self.k > 1:
             s = dev.pgm_resid_stats(ycur, yprv, xcur, xprv)
-            L = s[0] / s[2]
+            with np.errstate(divide='ignore', invalid='ignore'):
+                L = np.float64(s[0]) / np.float64(s[2])     # (stepsize.py:139-141)
             if L < 0.:
                 L = self.L
             self.L = self.dtype.type(L)

@@ -60,6 +60,7 @@ struct hipDeviceProp_t {
 
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
+hipError_t hipMemGetInfo(size_t *free_bytes, size_t *total_bytes);
 hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
 hipError_t hipHostFree(void *p);
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
