@@ -327,7 +327,8 @@ def run_config3(device, n_shard=32, tiny=False):
                    'doubles per iteration)',
            'next_steps': {'steps': nxt, 'value': nxt / el2, 'ms_per_step': 1e3 * el2 / nxt},
            'parity': par, 'roofline': roofline_of(tab),
-           'iteration': iteration_summary(tab, 6, ms, 40 * E), 'kernels': tab}
+           'iteration': iteration_summary(tab, 6, ms, 40 * E), 'kernels': tab,
+           'placement': b._dev.placement_report()}
     del b
     return out
 
@@ -371,7 +372,8 @@ def run_config4(device, backtrack, tiny=False):
                        % (H, W, K, N, ', BacktrackStandard' if backtrack else ''),
            'steps': steps, 'warmup': warm, 'ms_per_step': ms, 'value': steps / el,
            'unit': 'iterations/s', 'parity': par, 'roofline': roofline_of(tab),
-           'iteration': iteration_summary(tab, 10, ms, 40 * H * W * N * K), 'kernels': tab}
+           'iteration': iteration_summary(tab, 10, ms, 40 * H * W * N * K), 'kernels': tab,
+           'placement': b.dev.placement_report()}
     del b
     return out
 

@@ -282,23 +282,33 @@ SA_INST_PREPOST(double)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) place_probe_kernel(float *a, float *b, int64_t n16, int64_t win16,
                                                                int64_t step_a, int64_t step_b, int fresh_a,
-                                                               int fresh_b) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t w = i / win16, o = i - w * win16;
-        float *pa = a + 4 * (w * step_a + o), *pb = b + 4 * (w * step_b + o);
-        float xa[4] = {0.f, 0.f, 0.f, 0.f}, xb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!fresh_a) sa_stream_load4(pa, xa);     // (moved, never computed on: any bit pattern survives)
-        if (!fresh_b) sa_stream_load4(pb, xb);
-        sa_stream_store4(pa, xa);
-        sa_stream_store4(pb, xb);
+                                                               int fresh_b, int64_t rot16) {
+    // even workgroups walk a, odd ones b: two independent streams, as the write streams of a real
+    // kernel are (element i of both arrays written by the same lane would tie the two streams to
+    // each other address bit by address bit, and the result would depend on the distance between
+    // the arrays modulo the interleave)
+    const bool second = blockIdx.x & 1;
+    float *base = second ? b : a;
+    const int64_t step = second ? step_b : step_a;
+    const int fresh = second ? fresh_b : fresh_a;
+    const int64_t stride = (int64_t)(gridDim.x >> 1) * blockDim.x;
+    for (int64_t i = (int64_t)(blockIdx.x >> 1) * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        // (b is walked from word rot16 on, wrapping: a sweep of rot16 pairs every part of a with
+        // every part of b)
+        int64_t j = second ? i + rot16 : i;
+        if (j >= n16) j -= n16;
+        const int64_t w = j / win16, o = j - w * win16;
+        float *p = base + 4 * (w * step + o);
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!fresh) sa_stream_load4(p, x);     // (moved, never computed on: any bit pattern survives)
+        sa_stream_store4(p, x);
     }
 }
 void launch_place_probe(hipStream_t st, void *a, void *b, int64_t n16, int64_t win16, int64_t step_a,
-                        int64_t step_b, bool fresh_a, bool fresh_b) {
-    hipLaunchKernelGGL(place_probe_kernel, dim3(grid_for(n16)), dim3(kThreads), 0, st,
+                        int64_t step_b, bool fresh_a, bool fresh_b, int64_t rot16) {
+    hipLaunchKernelGGL(place_probe_kernel, dim3(grid_for(n16) & ~1), dim3(kThreads), 0, st,
                        static_cast<float *>(a), static_cast<float *>(b), n16, win16, step_a, step_b,
-                       fresh_a ? 1 : 0, fresh_b ? 1 : 0);
+                       fresh_a ? 1 : 0, fresh_b ? 1 : 0, rot16 % (n16 > 0 ? n16 : 1));
     SA_HIP(hipGetLastError());
 }
 

@@ -386,6 +386,10 @@ template <typename T> struct Csc : CscBase {
         return var_is_complex(var) ? sizeof(cx<T>) * EF : sizeof(T) * E;
     }
 
+    // (the Xf buffer also holds the tile-major spectrum, whose rows may be padded)
+    size_t var_alloc_bytes(int var) const {
+        return var == SPORCO_AMD_VAR_XF ? sizeof(cx<T>) * (size_t)std::max(EF, EFt) : var_bytes(var);
+    }
     void *var_ptr(int var) {
         SA_REQUIRE(var_is_valid(var), "unknown state variable id");
         if (var == SPORCO_AMD_VAR_Y || var == SPORCO_AMD_VAR_U) {
@@ -393,17 +397,8 @@ template <typename T> struct Csc : CscBase {
             if (v_live || gv_live) ensure_yu();
         }
         if (!vars[var]) {
-            // (the Xf buffer also holds the tile-major spectrum, whose rows may be padded)
-            const size_t nb = var == SPORCO_AMD_VAR_XF ? sizeof(cx<T>) * (size_t)std::max(EF, EFt)
-                                                       : var_bytes(var);
-            if (var == SPORCO_AMD_VAR_XF && vars[SPORCO_AMD_VAR_Y] && vars[SPORCO_AMD_VAR_U]) {
-                // the spectrum buffer is written together with the iterate (emitting row epilogue):
-                // clear of the two arrays the iterate starts in (api_placement.inc)
-                vars[var] = place_alloc(nb, {{vars[SPORCO_AMD_VAR_Y], sizeof(T) * (size_t)E},
-                                             {vars[SPORCO_AMD_VAR_U], sizeof(T) * (size_t)E}}, "T");
-            } else {
-                big_alloc(&vars[var], nb);
-            }
+            const size_t nb = var_alloc_bytes(var);
+            big_alloc(&vars[var], nb);
             SA_HIP(hipMemsetAsync(vars[var], 0, nb, st));
         }
         return vars[var];
@@ -446,11 +441,18 @@ template <typename T> struct Csc : CscBase {
     }
     std::string placement() override { return placement_report(); }
     // the second pair of iterate buffers (the (Y, U) ping-pong, and the two V buffers of the
-    // single-array state): each clear of the spectrum buffer they are written together with
+    // single-array state): each clear of the spectrum buffer it is written together with by the
+    // emitting row epilogue (api_placement.inc)
     void alloc_alt_pair() {
         if (y_alt) return;
-        void *t = var_ptr(SPORCO_AMD_VAR_XF);
-        const size_t tb = sizeof(cx<T>) * (size_t)std::max(EF, EFt), nb = sizeof(T) * (size_t)E;
+        (void)var_ptr(SPORCO_AMD_VAR_XF);
+        // The iterate goes round all four state buffers -- the (Y, U) ping-pong swaps the pairs, and
+        // the V buffers of the single-array state are whichever pair is "alt" when a run enters it
+        // -- so the spectrum buffer is (moved) clear of the two that exist, and the two new ones
+        // are taken clear of it.
+        place_var(SPORCO_AMD_VAR_XF, {SPORCO_AMD_VAR_Y, SPORCO_AMD_VAR_U}, "T");
+        void *t = vars[SPORCO_AMD_VAR_XF];
+        const size_t tb = var_alloc_bytes(SPORCO_AMD_VAR_XF), nb = sizeof(T) * (size_t)E;
         y_alt = static_cast<T *>(place_alloc(nb, {{t, tb}}, "V0"));
         u_alt = static_cast<T *>(place_alloc(nb, {{t, tb}}, "V1"));
     }

@@ -383,13 +383,15 @@ void launch_roll2(hipStream_t st, const T *in, T *out, int H, int W, int64_t P, 
 template <typename T>
 void launch_axpby(hipStream_t st, T a, const T *x, T b, const T *y, T *out, int64_t n);
 // Placement probe (api_placement.inc; profiles/r05_placement_notes.md): writes two arrays AT THE
-// SAME TIME, 16 bytes per lane -- each either rewritten in place (every word loaded and stored back:
+// SAME TIME, 16 bytes per lane, half of the workgroups each -- each array either rewritten in place (every word loaded and stored back:
 // contents unchanged) or, `fresh`, filled with zeros.  n16 words of each, taken as windows of win16
 // words that start step_a / step_b words apart (win16 = n16, steps 0: the first n16 words).  The
 // caller times it: two arrays whose physical memory lies in the same region of the device's HBM
 // take the stores at ~4.7 TB/s together, two in different regions at ~6.3 TB/s.
+// b is walked from word rot16 on (wrapping); a real kernel's streams are not in step, so the caller
+// sweeps rot16 over the array and sums the times.
 void launch_place_probe(hipStream_t st, void *a, void *b, int64_t n16, int64_t win16, int64_t step_a,
-                        int64_t step_b, bool fresh_a, bool fresh_b);
+                        int64_t step_b, bool fresh_a, bool fresh_b, int64_t rot16 = 0);
 
 // ---------------------------------------------------------------------------
 // Conjugate gradients with the scalars on the device (the CG dictionary update,

@@ -30,5 +30,5 @@ for mb in dummies:
         print(json.dumps({'prealloc_MiB': mb, 'placement_search': on == '1', 'value': round(d['value'], 1),
                           'steady': round(d['steady_state']['value'], 1), 'kernel': rf['kernel'],
                           'avg_kernel_ms': rf['avg_kernel_ms'], 'frac': round(rf['frac'], 3),
-                          'decisions': [(p['role'], p['candidates'], p['first_ratio'], p['chosen_ratio'])
+                          'decisions': [(p['role'], p['candidates'], p['same_region_GBps'], p['first_ratio'], p['chosen_ratio'])
                                         for p in rf.get('placement') or []]}), flush=True)

@@ -310,6 +310,21 @@ int main(int argc, char **argv) {
                             std::chrono::duration<double, std::milli>(t2 - t1).count());
             }
             for (int i = 0; i < M; ++i) CK(hipFree(base[i]));
+        } else if (part == "lockstep") {
+            // does the library's probe depend on the distance between its two arrays?  one buffer,
+            // the second stream `off` behind the first
+            char *base = nullptr;
+            CK(hipMalloc((void **)&base, 6 * GiB + 64 * MiB));
+            char *x = reinterpret_cast<char *>(up(reinterpret_cast<size_t>(base), 64 * MiB));
+            const int64_t n16 = (int64_t)(GiB / 16);
+            for (size_t off : {1024 * MiB, 1028 * MiB, 1032 * MiB, 1040 * MiB, 1056 * MiB, 1088 * MiB, 1152 * MiB,
+                               1280 * MiB, 1536 * MiB, 2048 * MiB, 2052 * MiB, 3072 * MiB, 4096 * MiB, 1024 * MiB + 4096,
+                               1024 * MiB + 65536, 1025 * MiB}) {
+                const float ms = time_launch([&] { launch_place_probe(st, x, x + off, n16, n16, 0, 0, false, false); }, reps);
+                std::printf("{\"part\": \"lockstep\", \"off_MiB\": %.3f, \"rewrite_rewrite_GBps\": %.0f}\n",
+                            (double)off / MiB, 2.0 * n16 * 16 / ms * 1e-6);
+            }
+            CK(hipFree(base));
         } else if (part == "map") {
             // G chunks of 1 GiB in allocation order, each classified by the two-stream fill against
             // chunk 0 (and against the first chunk found to differ from chunk 0): the region map
