@@ -141,9 +141,10 @@ class GenericConvBPDN(admm.ADMMEqual):
         self._new_handle()
         super(GenericConvBPDN, self).__init__(self.cri.shpX, S.dtype, opt)
         if reducer is not None:
-            # residual tolerances refer to the global problem size
-            self.Nx = self.Nx * reducer.world_size
-            self.Nc = self.Nc * reducer.world_size
+            # residual tolerances refer to the global problem size (shards need not be equal)
+            from ..dist import global_count
+            self.Nx = global_count(reducer, self.Nx)
+            self.Nc = global_count(reducer, self.Nc)
         self.D = np.asarray(D.reshape(self.cri.shpD), dtype=self.dtype)
         if self._S_dev is not None:
             if self._S_dev.dtype != self.dtype:
@@ -869,8 +870,9 @@ class ConvBPDNMaskDcpl(ConvBPDN):
         self.Nx = self.cri.M * self.cri.N * self.cri.K
         self.Nc = int(np.prod(self.cri.shpX)) + int(np.prod(self.cri.shpS))
         if self._reducer is not None:       # image shards: the global problem's sizes
-            self.Nx *= self._reducer.world_size
-            self.Nc *= self._reducer.world_size
+            from ..dist import global_count
+            self.Nx = global_count(self._reducer, self.Nx)
+            self.Nc = global_count(self._reducer, self.Nc)
         if W is None:
             W = np.array([1.0], dtype=self.dtype)
         W = np.asarray(W)

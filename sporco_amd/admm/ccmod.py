@@ -221,7 +221,8 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         self.yshape = self.cri.shpD
         self.xshape = self.cri.shpD + (self.Nb,)
         # (blocks of the whole problem: the residual scalings and tolerances refer to them)
-        self._nb_all = self.Nb * (1 if reducer is None else reducer.world_size)
+        from ..dist import global_count
+        self._nb_all = global_count(reducer, self.Nb)
         Nx = self._nb_all * int(np.prod(self.yshape))
         super(ConvCnstrMOD_Consensus, self).__init__(Nx, self.yshape, self.xshape, S.dtype, opt)
         self.Nc = self._nb_all * int(np.prod(self.yshape))

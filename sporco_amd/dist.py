@@ -141,7 +141,12 @@ class TorchReducer(object):
             if t is None:
                 a = np.ctypeslib.as_array((ctypes.c_double * 16).from_address(ptr))
                 t = views[ptr] = torch.from_numpy(a)
+            import time
+            t0 = time.perf_counter()
             self.dist.all_reduce(t, group=self.group)
+            if self.hook_calls < 256:
+                self._hook_host_s.append(time.perf_counter() - t0)
+            self.hook_calls += 1
         return hook
 
     def hook_cost_ms(self):
@@ -399,14 +404,31 @@ class ReducingSolver(object):
         setattr(self._raw, name, value)
 
 
-def shard_images(S, rank, world_size, axis=-1):
-    """Contiguous block of the image axis owned by ``rank``."""
-    import numpy as np
-    n = S.shape[axis]
-    if n % world_size != 0:
-        raise ValueError("number of images (%d) must divide evenly over %d ranks" %
+def shard_bounds(n, rank, world_size):
+    """[lo, hi) of the contiguous block of ``n`` images owned by ``rank``: blocks differ by at most
+    one image, the first ``n % world_size`` ranks hold the larger ones (the per-image split of
+    the reference's parallel solvers has no divisibility condition either, prlcnscdl.py:241)."""
+    if n < world_size:
+        raise ValueError("%d images cannot be spread over %d ranks (every rank needs one)" %
                          (n, world_size))
-    per = n // world_size
+    per, extra = divmod(n, world_size)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def shard_images(S, rank, world_size, axis=-1):
+    """Contiguous block of the image axis owned by ``rank`` (see :func:`shard_bounds`)."""
+    import numpy as np
+    lo, hi = shard_bounds(S.shape[axis], rank, world_size)
     idx = [slice(None)] * S.ndim
-    idx[axis] = slice(rank * per, (rank + 1) * per)
+    idx[axis] = slice(lo, hi)
     return np.ascontiguousarray(S[tuple(idx)])
+
+
+def global_count(reducer, local):
+    """Sum over the ranks of a per-rank count (images, blocks, elements): what the residual
+    tolerances and default step sizes of a sharded solver refer to.  A collective: every rank
+    calls it at the same point (the constructors do)."""
+    if reducer is None:
+        return int(local)
+    return int(round(reducer.sum([float(local)])[0]))

@@ -94,7 +94,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
         self.dev.set_filter_sizes(self.cri.fsz)
         super(ConvCnstrMOD, self).__init__(self.cri.shpD, self.cri.Nv, self.cri.axisN,
                                            S.dtype, opt)
-        nimg = self.cri.K * (1 if reducer is None else reducer.world_size)
+        from ..dist import global_count
+        nimg = global_count(reducer, self.cri.K)
         self.set_attr('L', opt['L'], dval=nimg * 14.0, dtype=self.dtype)
         self.Pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd,
                              zm=opt['ZeroMean'])
