@@ -39,3 +39,43 @@ def test_one_rank_native_rccl_without_torch(gpu_backend):
                        env=env, timeout=600, cwd=REPO, capture_output=True, text=True)
     assert r.returncode == 0 and 'NATIVE_RCCL_WORKER_OK' in r.stdout, \
         r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _gpu_count():
+    import sporco_amd
+    try:
+        return sporco_amd.device_count()
+    except Exception:       # noqa: BLE001
+        return 0
+
+
+@pytest.mark.gpu
+def test_two_rank_native_rccl(gpu_backend, tmp_path):
+    """N > 1 over RCCL inside the library, when the box has two GPUs (the 1-GPU boxes of this build
+    skip it: RCCL refuses two ranks on one device): unequal image shards, the device-driven loop
+    stopping early with unequal host lag, the host-driven loop, the dictionary-learning gradient
+    all-reduce -- against the same problems solved by one rank."""
+    if _gpu_count() < 2:
+        pytest.skip('needs two GPUs (this box has %d)' % _gpu_count())
+    world = 2
+    idfile = str(tmp_path / 'rccl_id')
+    env = dict(os.environ, OMP_NUM_THREADS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(REPO, 'tests', '_native_rccl_worker2.py'), str(r),
+                               str(world), idfile], env=env, cwd=REPO, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and 'NATIVE_RCCL_WORKER2_OK %d' % r in so, so[-2000:] + se[-4000:]
+    one = np.load(idfile + '.single.npz')
+    parts = [np.load(idfile + '.admm.%d.npz' % r) for r in range(world)]
+    rest = [np.load(idfile + '.rest.%d.npz' % r) for r in range(world)]
+    assert 3 < int(one['k']) < 200
+    for p in parts:
+        assert int(p['k']) == int(one['k'])
+        assert np.array_equal(p['Rho'], parts[0]['Rho'])
+        assert rel_l2(p['Rho'], one['Rho']) < 1e-5
+    assert rel_l2(np.concatenate([p['Y'] for p in parts], axis=3), one['Y']) < 1e-4
+    assert rel_l2(np.concatenate([p['Yc'] for p in rest], axis=3), one['Yc']) < 1e-5
+    for p in rest:
+        assert np.array_equal(p['D1'], rest[0]['D1'])
+        assert rel_l2(p['D1'], one['D1']) < 1e-5 and rel_l2(p['Obj'], one['Obj']) < 1e-5

@@ -149,3 +149,67 @@ def test_config3_shard_fullsize(gpu_backend):
         assert rel_l2(np.asarray(getattr(its, f), float), np.asarray(getattr(its0, f), float)) < 1e-5, f
     # every image's last filter was reached (the far end of the 12.9 GB arrays is not zero)
     assert np.count_nonzero(Y[-1, -8:, :, -1, -1]) + np.count_nonzero(Y[0, :8, :, -1, -1]) > 0
+
+
+def _blockwise_rel_l2(a, b, step=64):
+    num = den = 0.0
+    for h in range(0, a.shape[0], step):
+        d = a[h:h + step].astype(np.float64) - b[h:h + step]
+        num += float(np.sum(d * d))
+        den += float(np.sum(np.asarray(b[h:h + step], dtype=np.float64) ** 2))
+    return np.sqrt(num / den)
+
+
+def test_config2_every_image_vs_oracle(gpu_backend):
+    """ALL 32 images of the benchmarked problem (512x512, K=64, N=32: bench.make_problem), 6
+    iterations at fixed rho, each against the float64 oracle run on that image alone (at fixed
+    rho the iteration is independent per image, sporco/admm/admm.py:331-367): an external witness
+    for every image slot of the batch, not only the first and the last.  About two minutes of
+    host time."""
+    import bench
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    D, S = bench.make_problem(512, 512, 64, 32, 0)
+    optd = {'MaxMainIter': 6, 'RelStopTol': 0.0, 'rho': 3.5, 'AutoRho': {'Enabled': False}}
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    assert b._dev.uses_fused_rows() and b._fused_ok()
+    Y = b.solve()
+    worst = 0.0
+    obj = 0.0
+    for n in range(32):
+        ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, 64), S[:, :, n].reshape(512, 512, 1, 1, 1), 0.05,
+                             dtype=np.float64, maxiter=6, rel_tol=0.0, rho=3.5, auto_rho=False)
+        e = rel_l2(Y[:, :, 0, n], ref['Y'][:, :, 0, 0])
+        assert e < 1e-4, (n, e)
+        worst = max(worst, e)
+        obj += ref['ObjFun'][-1]
+    # the batch objective is the sum of the images' (lambda ||x||_1 + 1/2 ||Dx - s||^2 are sums)
+    assert abs(obj - b.getitstat().ObjFun[-1]) < 1e-4 * obj
+    print('config 2, 32 images vs oracle: worst rel l2 %.2e' % worst)
+
+
+def test_config3_shard_spread_images_vs_oracle(gpu_backend):
+    """The config-3 shard (ConvBPDNJoint, 512x512 RGB, K = 128, N = 32: 3.2e9 elements per array,
+    index arithmetic past 2^31) at fixed rho, 3 iterations: images 0, 10, 21 and 31 -- the first and
+    the last, i.e. both ends of the 12.9 GB arrays, and two in between -- against the float64
+    oracle run on each image alone, over all 128 filters (both 64-filter slabs of the column pass).
+    The l2,1 term couples the channels of one image only (sporco/admm/cbpdn.py:785-794)."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(3)
+    H, C, N, K = 512, 3, 32, 128
+    D = rng.randn(8, 8, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, H, C, N).astype(np.float32)
+    optd = {'MaxMainIter': 3, 'RelStopTol': 0.0, 'rho': 6.0, 'AutoRho': {'Enabled': False}}
+    b = cbpdn.ConvBPDNJoint(D, S, 0.1, 0.02, cbpdn.ConvBPDNJoint.Options(optd))
+    assert b._dev.uses_fused_rows() and b._dev.uses_fused_cols() and b._fused_ok()
+    Y = b.solve()
+    for n in (0, 10, 21, 31):
+        ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S[:, :, :, n].reshape(H, H, C, 1, 1), 0.1, mu=0.02,
+                             dtype=np.float64, maxiter=3, rel_tol=0.0, rho=6.0, auto_rho=False)
+        e = _blockwise_rel_l2(Y[:, :, :, n], ref['Y'][:, :, :, 0])
+        assert e < 1e-4, (n, e)
+        # both slabs and both ends of the filter axis individually
+        for k in (0, 63, 64, 127):
+            assert rel_l2(Y[:, :, :, n, k], ref['Y'][:, :, :, 0, k]) < 2e-4, (n, k)
