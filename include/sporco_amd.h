@@ -22,35 +22,31 @@
  *   - a handle owns one HIP stream (or borrows the one passed at creation);
  *     calls on one handle must not be issued concurrently from two threads.
  *
- * Environment switches.  None is needed for normal use: they select kernel variants for A/B
- * measurements and for the tests that pin one path against another, and are read when a
- * handle is created or a launch is made (bench.py and the tests set them around single calls).
- *   SPORCO_AMD_LIBRARY=path          (Python) load this build instead of sporco_amd/libsporco_amd.so
- *   SPORCO_AMD_SHARE_TORCH_RUNTIME=0 (Python) do not pre-load torch's HIP runtime before the library
+ * Environment switches of the library (15).  None is needed in normal use: they pin one code path
+ * against another in the tests and in A/B measurements.  All are read ONCE, when a handle is made
+ * (csc_api.hip struct Switches) -- except HOST_LOOP and RUN_LAG, which callers flip between runs of
+ * one handle and sporco_amd_csc_admm_run reads at its entry -- and RCCL_LIB, read when RCCL is first
+ * opened.  Launch forms, staggers and the variants of reverted experiments are constants of the
+ * sources since round 5, not switches.
  *   SPORCO_AMD_UNFUSED=1        generic kernel chain (line FFTs + streaming kernels) for every shape
  *   SPORCO_AMD_OLD_ROWS=1       generic row passes around the register-resident column kernel
  *   SPORCO_AMD_NO_PAD=1         no zero filter appended to an odd filter count
- *   SPORCO_AMD_NO_TAIL=1, SPORCO_AMD_NO_ROW_PAD=1   64 < K <= 72: slab kernels / unpadded rows
- *   SPORCO_AMD_SLAB_COOP=0      K > 64 column pass as two kernels instead of cooperating workgroups
- *   SPORCO_AMD_HOST_LOOP=1      one sporco_amd_csc_admm_iter per iteration, no sporco_amd_csc_admm_run
  *   SPORCO_AMD_NO_VFORM=1       keep the ADMM iterate as (Y, U): no single-array state (csc_rows.h)
  *   SPORCO_AMD_NO_SPECULATION=1 the row epilogue never emits the next iteration's row spectra
- *   SPORCO_AMD_RUN_ALWAYS_EMIT=0|1, SPORCO_AMD_JOINT_EMIT=0, SPORCO_AMD_JOINT_SEPARATE=1
- *                               epilogue variant overrides
- *   SPORCO_AMD_PERSIST=1|0      small problems: a run of iterations as ONE launch (off unless the
- *                               handle has SPORCO_AMD_HINT_ONE_LAUNCH; see there);
- *                               SPORCO_AMD_PERSIST_TIMING=1 prints the phase times of measurement builds
- *   SPORCO_AMD_C2R_POST=1       generic chain: the ADMM epilogue inside the last row pass of irfftn
+ *   SPORCO_AMD_HOST_LOOP=1      one sporco_amd_csc_admm_iter per iteration, no sporco_amd_csc_admm_run
  *   SPORCO_AMD_RUN_LAG=n        (tests) admm_run pretends not to have seen its newest n records
- *   SPORCO_AMD_COLS_PERSIST=0, SPORCO_AMD_COLS_STAGGER_GROUPS=g, SPORCO_AMD_COLS_STAGGER_SLEEPS=s
- *                               launch form of the column kernel
- *   SPORCO_AMD_ROWS_PERSIST=0|2, SPORCO_AMD_ROWS_STAGGER_GROUPS, SPORCO_AMD_ROWS_STAGGER_SLEEPS,
- *   SPORCO_AMD_PROX_PERSIST=1   launch form of the row kernels
- *   SPORCO_AMD_PGM_PERSIST=mask (bit 0: FISTA gradient kernel, bit 1: momentum kernel),
- *   SPORCO_AMD_PGM_STAGGER_GROUPS, SPORCO_AMD_PGM_STAGGER_SLEEPS
- *   SPORCO_AMD_CG_HOST=1, SPORCO_AMD_CG_SELF=0   CG dictionary update: scalars on the host / as launches
+ *   SPORCO_AMD_PERSIST=1|0      small problems: a run of iterations as ONE launch (off unless the
+ *                               handle has SPORCO_AMD_HINT_ONE_LAUNCH; see there)
+ *   SPORCO_AMD_NO_COLS_SM=1     generic chain: the column pass as three kernels, not one (fft.h)
+ *   SPORCO_AMD_COLS_SM_FORCE_SLAB=k   (tests) ... in slabs of k filters even where the tile fits
+ *   SPORCO_AMD_MD_GENERIC=1     ConvBPDNMaskDcpl on the generic chain
  *   SPORCO_AMD_CNS_GENERIC=1    consensus dictionary update on the generic chain
- *   SPORCO_AMD_BENCH_BACKEND=gloo   (bench.py) ranks reduce through gloo and may share a device
+ *   SPORCO_AMD_CG_HOST=1        CG dictionary update: the scalars read back every iteration
+ *   SPORCO_AMD_PLACEMENT=0      no placement search for concurrently written arrays
+ *                               (sporco_amd_csc_placement_report)
+ *   SPORCO_AMD_RCCL_LIB=path    the RCCL library to open (default librccl.so.1, librccl.so)
+ * Outside the library: SPORCO_AMD_LIBRARY=path and SPORCO_AMD_SHARE_TORCH_RUNTIME=0 (the Python
+ * binding: which build to load / do not pre-load torch's HIP runtime), SPORCO_AMD_BENCH_* (bench.py).
  */
 #ifndef SPORCO_AMD_H
 #define SPORCO_AMD_H

@@ -26,7 +26,39 @@ const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_
                                            "admm_persist_run",
                                     "setcoef_rows",     "setcoef_cols",     "ccmod_grad_tiled"};
 
+// Environment switches (include/sporco_amd.h lists them; tests and measurements, none is needed in
+// normal use).  Read ONCE, when a handle is made -- except SPORCO_AMD_HOST_LOOP and
+// SPORCO_AMD_RUN_LAG, which callers flip between runs of one handle (bench.py's profiled pass, the
+// early-stop tests) and sporco_amd_csc_admm_run reads at its entry.
+struct Switches {
+    bool unfused, old_rows, no_pad, no_vform, no_speculation, no_cols_sm, md_generic, cns_generic, cg_host,
+        placement_off;
+    int persist;              // SPORCO_AMD_PERSIST: -1 unset (the hint decides), 0, 1
+    int cols_sm_force_slab;   // SPORCO_AMD_COLS_SM_FORCE_SLAB: 0 unset
+    static bool set(const char *name) { return std::getenv(name) != nullptr; }
+    static Switches read() {
+        Switches s;
+        s.unfused = set("SPORCO_AMD_UNFUSED");
+        s.old_rows = set("SPORCO_AMD_OLD_ROWS");
+        s.no_pad = set("SPORCO_AMD_NO_PAD");
+        s.no_vform = set("SPORCO_AMD_NO_VFORM");
+        s.no_speculation = set("SPORCO_AMD_NO_SPECULATION");
+        s.no_cols_sm = set("SPORCO_AMD_NO_COLS_SM");
+        s.md_generic = set("SPORCO_AMD_MD_GENERIC");
+        s.cns_generic = set("SPORCO_AMD_CNS_GENERIC");
+        s.cg_host = set("SPORCO_AMD_CG_HOST");
+        const char *e = std::getenv("SPORCO_AMD_PLACEMENT");
+        s.placement_off = e && e[0] == '0';
+        e = std::getenv("SPORCO_AMD_PERSIST");
+        s.persist = e ? (e[0] == '1' ? 1 : 0) : -1;
+        e = std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB");
+        s.cols_sm_force_slab = e ? std::atoi(e) : 0;
+        return s;
+    }
+};
+
 template <typename T> struct Csc : CscBase {
+    const Switches sw = Switches::read();
     sporco_amd_dims dm;
     int device;
     hipStream_t st = nullptr;
@@ -79,7 +111,7 @@ template <typename T> struct Csc : CscBase {
     T *gramz_t = nullptr;      // its fused path: sum_k |Zf|^2 per row of the tile-major Zf
     bool gramz_valid = false;
     bool cns_fused() const {
-        return rows_ok && fused && cols256 && !std::getenv("SPORCO_AMD_CNS_GENERIC");
+        return rows_ok && fused && cols256 && !sw.cns_generic;
     }
     bool ism_valid = false;
     double ism_rho = 0.0, ism_mu = -1.0;   // (ism_mu: mu of the gradient diagonal, -1 = none)
@@ -198,8 +230,8 @@ template <typename T> struct Csc : CscBase {
     bool g1_valid = false;
     double g1_rho = 0.0, g1_mu = 0.0;
 
-    static int padded_filters(int H_, int W_, int K_) {
-        if (K_ % 2 == 0 || std::getenv("SPORCO_AMD_UNFUSED") || std::getenv("SPORCO_AMD_NO_PAD"))
+    int padded_filters(int H_, int W_, int K_) const {
+        if (K_ % 2 == 0 || sw.unfused || sw.no_pad)
             return K_;
         const bool cols = fused_cols_supported<T>(H_, K_ + 1) || fused_slabs_supported<T>(H_, K_ + 1);
         return (cols && rows_supported<T>(W_, K_ + 1)) ? K_ + 1 : K_;
@@ -245,11 +277,11 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CNs));
         SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CNs));
         fused = Cd == 1 && fused_cols_supported<T>(H, K) && K % 2 == 0 &&
-                !std::getenv("SPORCO_AMD_UNFUSED");
+                !sw.unfused;
         cols256 = H == 128 || H == 256 || H == 512;   // (every column kernel family has the 32 x 4 split)
-        fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !std::getenv("SPORCO_AMD_UNFUSED");
+        fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !sw.unfused;
         fused_mc = Cd > 1 && fused_mc_supported<T>(H, K, Cd) && K % 2 == 0 &&
-                   !std::getenv("SPORCO_AMD_UNFUSED");
+                   !sw.unfused;
         if (fused_mc) {
             SA_HIP(hipMalloc((void **)&dft_mc, sizeof(cx<T>) * npix * Cd * K));
             SA_HIP(hipMalloc((void **)&sft_mc, sizeof(cx<T>) * npix * CNs));
@@ -279,9 +311,9 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
         }
         rows_ok = (fused || fused_slabs || fused_mc) && rows_supported<T>(W, K) &&
-                  !std::getenv("SPORCO_AMD_OLD_ROWS");
-        tail_mode = fused_slabs && K - 64 <= kTailMax && !std::getenv("SPORCO_AMD_NO_TAIL");
-        Ks = (rows_ok && tail_mode && !std::getenv("SPORCO_AMD_NO_ROW_PAD")) ? 80 : K;
+                  !sw.old_rows;
+        tail_mode = fused_slabs && K - 64 <= kTailMax;
+        Ks = (rows_ok && tail_mode) ? 80 : K;
         EFt = npix * CN * (int64_t)Ks;
         if (Ks != K) {   // dft was sized for K-filter rows above
             SA_HIP(hipFree(dft));
@@ -349,7 +381,7 @@ template <typename T> struct Csc : CscBase {
         y_alt = u_alt = nullptr;
         work = nullptr;
         for (void *p : {(void *)pst_part_rows, (void *)pst_part_f, pst_blk, (void *)pst_ctl, (void *)pst_bar,
-                        (void *)part_c2r, (void *)cns_w, (void *)cns_sft, (void *)flt_h, (void *)flt_w,
+                        (void *)cns_w, (void *)cns_sft, (void *)flt_h, (void *)flt_w,
                         (void *)zf_ch, (void *)zfv_buf, (void *)md_sft, (void *)md_coef, (void *)pgm_rx[0], (void *)pgm_rx[1]})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)dft, (void *)sft, (void *)gramt, (void *)part_f, (void *)twA, (void *)twB,

@@ -7,11 +7,13 @@
 // dependency, and a box without RCCL still runs everything single-GPU.  The few declarations
 // needed are restated here (rccl.h: ncclUniqueId is 128 opaque bytes, ncclComm_t an opaque
 // pointer, ncclSum = 0, ncclMax = 2, ncclFloat32 = 7, ncclFloat64 = 8).
+//
+// (The CPU simulator of the test-suite brings its own stand-in for librccl -- single-rank,
+// identity collectives, tests/hostsim/hostsim_runtime.cpp -- and points SPORCO_AMD_RCCL_LIB at
+// it: this file has one code path.)
 #include "csc_impl.h"
 
-#ifndef SPORCO_AMD_HOSTSIM
 #include <dlfcn.h>
-#endif
 
 using namespace sporco_amd;
 
@@ -37,7 +39,6 @@ struct Rccl {
     std::string tried;
 };
 
-#ifndef SPORCO_AMD_HOSTSIM
 Rccl &rccl() {
     static Rccl r;
     if (r.lib) return r;
@@ -70,7 +71,6 @@ void nccl_check(int rc, const char *what) {
     throw Error(SPORCO_AMD_EHIP, std::string(what) + ": " +
                                      (r.error_string ? r.error_string(rc) : "RCCL error " + std::to_string(rc)));
 }
-#endif
 
 }  // namespace
 
@@ -86,13 +86,8 @@ void comm_reduce_sums(void *user, double *sums_dev, hipStream_t st) {
     sporco_amd_comm *c = static_cast<sporco_amd_comm *>(user);
     if (!c) return;
     // (a single rank still goes through RCCL: the one-rank test exercises the real call)
-#ifndef SPORCO_AMD_HOSTSIM
     nccl_check(rccl().all_reduce(sums_dev, sums_dev, 16, 8 /* ncclFloat64 */, 0 /* ncclSum */, c->comm, st),
                "ncclAllReduce");
-#else
-    (void)sums_dev;
-    (void)st;
-#endif
 }
 }  // namespace sporco_amd
 
@@ -101,13 +96,9 @@ extern "C" {
 int sporco_amd_comm_unique_id(void *id128) {
     SA_API_BEGIN
     SA_REQUIRE(id128 != nullptr, "id128 is null");
-#ifndef SPORCO_AMD_HOSTSIM
     NcclId id;
     nccl_check(rccl().get_unique_id(&id), "ncclGetUniqueId");
     std::memcpy(id128, id.internal, SPORCO_AMD_COMM_ID_BYTES);
-#else
-    std::memset(id128, 0, SPORCO_AMD_COMM_ID_BYTES);      // (simulator: single-rank communicators only)
-#endif
     SA_API_END
 }
 
@@ -120,14 +111,10 @@ int sporco_amd_comm_create(const void *id128, int32_t rank, int32_t world, int32
     c->rank = rank;
     c->world = world;
     c->device = device;
-#ifndef SPORCO_AMD_HOSTSIM
     SA_HIP(hipSetDevice(device));
     NcclId id;
     std::memcpy(id.internal, id128, SPORCO_AMD_COMM_ID_BYTES);
     nccl_check(rccl().comm_init_rank(&c->comm, world, id, rank), "ncclCommInitRank");
-#else
-    SA_REQUIRE(world == 1, "the CPU simulator build has single-rank communicators only");
-#endif
     SA_HIP(hipMalloc((void **)&c->stage, sizeof(double) * 64));
     *out = c.release();
     SA_API_END
@@ -136,10 +123,8 @@ int sporco_amd_comm_create(const void *id128, int32_t rank, int32_t world, int32
 int sporco_amd_comm_destroy(sporco_amd_comm_t c) {
     SA_API_BEGIN
     if (c) {
-#ifndef SPORCO_AMD_HOSTSIM
         (void)hipSetDevice(c->device);
         if (c->comm) (void)rccl().comm_destroy(c->comm);
-#endif
         if (c->stage) (void)hipFree(c->stage);
         delete c;
     }
@@ -161,12 +146,10 @@ int sporco_amd_comm_allreduce(sporco_amd_comm_t c, void *buf_dev, int64_t count,
     SA_REQUIRE(dtype == SPORCO_AMD_F32 || dtype == SPORCO_AMD_F64, "dtype must be SPORCO_AMD_F32 or _F64");
     SA_REQUIRE(op == SPORCO_AMD_COMM_SUM || op == SPORCO_AMD_COMM_MAX, "op must be SUM or MAX");
     if (count > 0) {
-#ifndef SPORCO_AMD_HOSTSIM
         SA_HIP(hipSetDevice(c->device));
         nccl_check(rccl().all_reduce(buf_dev, buf_dev, (size_t)count, dtype == SPORCO_AMD_F32 ? 7 : 8, op,
                                      c->comm, (hipStream_t)stream),
                    "ncclAllReduce");
-#endif
     }
     SA_API_END
 }
@@ -176,14 +159,12 @@ int sporco_amd_comm_allreduce_host(sporco_amd_comm_t c, double *vals, int32_t n,
     SA_REQUIRE(c != nullptr && vals != nullptr && n >= 0 && n <= 64, "bad argument (n <= 64)");
     SA_REQUIRE(op == SPORCO_AMD_COMM_SUM || op == SPORCO_AMD_COMM_MAX, "op must be SUM or MAX");
     if (n > 0) {
-#ifndef SPORCO_AMD_HOSTSIM
         SA_HIP(hipSetDevice(c->device));
         SA_HIP(hipMemcpy(c->stage, vals, sizeof(double) * n, hipMemcpyHostToDevice));
         nccl_check(rccl().all_reduce(c->stage, c->stage, (size_t)n, 8, op, c->comm, (hipStream_t) nullptr),
                    "ncclAllReduce");
         SA_HIP(hipStreamSynchronize(nullptr));
         SA_HIP(hipMemcpy(vals, c->stage, sizeof(double) * n, hipMemcpyDeviceToHost));
-#endif
     }
     SA_API_END
 }

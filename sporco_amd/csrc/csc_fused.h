@@ -20,6 +20,9 @@
 
 namespace sporco_amd {
 
+// start-up stagger of the persistent column workgroups (csc_fused.hip launch_fused_cols)
+constexpr int kColsStaggerGroups = 4, kColsStaggerSleeps = 2;
+
 // out[(b*A + a)*C + c] = in[(a*B + b)*C + c]: (A, B, C) -> (B, A, C).  Used to
 // re-lay Df (H, Wf, K), the per-pixel gram (H, Wf) and Sf (H, Wf*CN) tile-major.
 // (in_stride / out_stride: elements between consecutive C-runs when they are padded; 0 = C)
@@ -58,7 +61,7 @@ template <typename T> struct FusedColsArgs {
     int per_tile = 0;
     // persistent launch: workgroup slot s starts (s % stagger_groups) * stagger_sleeps * 8128
     // cycles late, so that the workgroups' memory and arithmetic phases interleave across CUs
-    int stagger_groups = 1, stagger_sleeps = 0;
+    int stagger_groups = 1, stagger_sleeps = 0;   // (set by the launchers: kColsStagger*)
     // device-driven solve (csc_kernels.h AdmmCtl): rho is ctl->rho_f, and the launch returns at
     // once when ctl->stop is set
     const AdmmCtl *ctl = nullptr;

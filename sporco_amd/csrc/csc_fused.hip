@@ -761,11 +761,6 @@ static FusedSplit fused_split(int H, int K) {
     (void)K;
     if (H == 128) return {32, 4, 4};
     if (H == 256) return {32, 8, 2};
-#ifdef SA_COLS_MEASUREMENT_BUILD
-    // (measurement builds: H = 512 as 64 points per thread x 8 waves -- twice the registers per
-    // wave, half the waves; ADMM ConvBPDN at K = 64 only)
-    if (std::getenv("SPORCO_AMD_COLS_SPLIT64")) return {64, 8, std::atoi(std::getenv("SPORCO_AMD_COLS_SPLIT64"))};
-#endif
     return {32, 16, 1};
 }
 
@@ -796,14 +791,9 @@ template <> bool fused_cols_supported<double>(int, int) { return false; }
 
 // Workgroups of a persistent launch: as many as the device holds at once (16-wave
 // workgroups: one per CU; 8-wave ones: two), a multiple of 8 so that the XCD of a workgroup
-// is blockIdx % 8 for every slot it walks.  SPORCO_AMD_COLS_PERSIST=0: one workgroup per tile.
+// is blockIdx % 8 for every slot it walks.
 static int64_t persistent_grid(int NW) {
-    static const bool off = [] {
-        const char *e = std::getenv("SPORCO_AMD_COLS_PERSIST");
-        return e && e[0] == '0';
-    }();
     const int cus = current_device_cus();
-    if (off) return INT64_MAX;
     if (NW != 16) return INT64_MAX;      // (the 8-wave kernel takes one tile per workgroup)
     return std::max<int64_t>(8, cus / 8 * 8);
 }
@@ -837,15 +827,6 @@ static void launch_fused_k(hipStream_t st, const FusedColsArgs<float> &a, int64_
         if (grad) launch_fused_inst<N1, NW, LP, 64, true, true>(st, a, ntiles);
         else launch_fused_inst<N1, NW, LP, 64, false, true>(st, a, ntiles);
     } else if (a.K == 64) {
-#ifdef SA_COLS_MEASUREMENT_BUILD
-        // (builds made for profiles/r02_fused_cols_notes.md only: the variants 1..4 leave out
-        // phases of the kernel and do not compute the X-step; the product library has none)
-        static const int dbg = std::getenv("SPORCO_AMD_COLS_DEBUG") ? std::atoi(std::getenv("SPORCO_AMD_COLS_DEBUG")) : 0;
-        if (!grad && NW == 16 && dbg == 1) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 1>(st, a, ntiles);
-        if (!grad && NW == 16 && dbg == 2) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 2>(st, a, ntiles);
-        if (!grad && NW == 16 && dbg == 3) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 3>(st, a, ntiles);
-        if (!grad && NW == 16 && dbg == 4) return launch_fused_inst<N1, NW, LP, 64, false, false, false, 4>(st, a, ntiles);
-#endif
         // (coef_out on a K <= 64 system: the instantiation that stores the multipliers -- the
         // mask-decoupled X-step reads D x = Sf - rho coef off them, api_maskdcpl.inc)
         if (grad) launch_fused_inst<N1, NW, LP, 64, true>(st, a, ntiles);
@@ -864,21 +845,11 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     const int64_t ntiles = (int64_t)(a_in.W / 2 + 1) * a_in.CN;
     const FusedSplit sp = fused_split(a_in.H, a_in.Kv ? a_in.Kv : a_in.K);
     FusedColsArgs<float> a = a_in;
-    static const int sg = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS")) : 1;
-    static const int ss = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS")) : 0;
-    // default: 4 phase groups 2 x 8128 cycles apart (about a fifth of a tile's time each):
-    // measured 1.13 -> 1.06 ms at 512 x 512, K = 64, N = 32 (profiles/r02_fused_cols_notes.md)
-    a.stagger_groups = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? (sg > 0 ? sg : 1) : 4;
-    a.stagger_sleeps = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? ss : 2;
-#ifdef SA_COLS_MEASUREMENT_BUILD
-    if (sp.N1 == 64) {
-        SA_REQUIRE(a.K == 64 && !a.g1t && !a.per_tile && !a.Kv, "64 x 8 split: plain K = 64 only");
-        if (sp.LP == 4) launch_fused_inst<64, 8, 4, 64, false>(st, a, ntiles);
-        else launch_fused_inst<64, 8, 2, 64, false>(st, a, ntiles);
-        SA_HIP(hipGetLastError());
-        return ntiles;
-    }
-#endif
+    // start-up stagger of the persistent workgroups: 4 phase groups 2 x 8128 cycles apart (about a
+    // fifth of a tile's time each): measured 1.13 -> 1.06 ms at 512 x 512, K = 64, N = 32
+    // (profiles/r02_fused_cols_notes.md)
+    a.stagger_groups = kColsStaggerGroups;
+    a.stagger_sleeps = kColsStaggerSleeps;
     if (sp.NW == 4)
         launch_fused_k<32, 4, 4>(st, a, ntiles);
     else if (sp.NW == 8)
@@ -1083,10 +1054,8 @@ template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlab
     SA_REQUIRE(fused_slabs_supported<float>(a_in.c.H, a_in.c.K), "shape not handled by the slab column kernels");
     SA_REQUIRE(a_in.coop_flags && a_in.coop_err, "the cooperating slab kernel needs its flag buffers");
     FusedSlabArgs<float> a = a_in;
-    static const int sg = std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_GROUPS")) : 4;
-    static const int ss = std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS") ? std::atoi(std::getenv("SPORCO_AMD_COLS_STAGGER_SLEEPS")) : 2;
-    a.c.stagger_groups = sg > 0 ? sg : 1;
-    a.c.stagger_sleeps = ss;
+    a.c.stagger_groups = kColsStaggerGroups;
+    a.c.stagger_sleeps = kColsStaggerSleeps;
     const bool g = a.c.g1t != nullptr;
     if (a.c.H == 128) {
         if (a.c.K == 128) { if (g) launch_slab_coop<4, 4, 128, true>(st, a); else launch_slab_coop<4, 4, 128, false>(st, a); }

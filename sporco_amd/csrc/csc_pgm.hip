@@ -551,17 +551,10 @@ template <typename F> void set_lds(F kernel, size_t bytes) {
 // gradient kernel persistent, 247 with both, 246 with neither, 239 with the momentum kernel
 // alone -- its tile loop costs it 20 more registers (scalar registers run out and spill into
 // vector ones; the statistics variant then spills 60 bytes), which outweighs what the loop buys.
-// Stagger as in csc_fused.hip (SPORCO_AMD_PGM_STAGGER_GROUPS / _SLEEPS).
+// Stagger as in csc_fused.hip.
 static unsigned pgm_persist_grid(PgmColsArgs<float> &a, int NW, int KC, int which) {
-    static int sg = 4, ss = 2, mask = 1;
-    static bool env_read = false;
+    constexpr int sg = 4, ss = 2, mask = 1;   // (stagger as csc_fused.h kColsStagger*; mask: the gradient kernel only)
     const int cus = current_device_cus();
-    if (!env_read) {
-        env_read = true;
-        if (std::getenv("SPORCO_AMD_PGM_PERSIST")) mask = std::atoi(std::getenv("SPORCO_AMD_PGM_PERSIST"));
-        if (std::getenv("SPORCO_AMD_PGM_STAGGER_GROUPS")) sg = std::max(1, std::atoi(std::getenv("SPORCO_AMD_PGM_STAGGER_GROUPS")));
-        if (std::getenv("SPORCO_AMD_PGM_STAGGER_SLEEPS")) ss = std::atoi(std::getenv("SPORCO_AMD_PGM_STAGGER_SLEEPS"));
-    }
     const int64_t all = ceil_div(a.W / 2 + 1, 8) * 8 * a.CN;
     a.stagger_groups = sg;
     a.stagger_sleeps = ss;

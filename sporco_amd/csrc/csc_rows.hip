@@ -1057,30 +1057,18 @@ template void rows_twiddles<float>(int, cx<float> *);
 template void rows_twiddles<double>(int, cx<double> *);
 
 // Workgroups of a persistent row-kernel launch: what the device holds at once (one 16-wave
-// workgroup per CU, two 8-wave ones).  SPORCO_AMD_ROWS_PERSIST=0: one workgroup per tile.
+// workgroup per CU, two 8-wave ones).
 static int64_t rows_persistent_grid(int NW) {
-    static const bool off = [] {
-        const char *e = std::getenv("SPORCO_AMD_ROWS_PERSIST");
-        return e && e[0] == '0';
-    }();
-    return off ? 0 : (int64_t)current_device_cus() * (NW == 16 ? 1 : NW == 8 ? 2 : 4);
+    return (int64_t)current_device_cus() * (NW == 16 ? 1 : NW == 8 ? 2 : 4);
 }
-// want: 1 = persistent unless disabled; 0 = one workgroup per tile (SPORCO_AMD_ROWS_PERSIST=2
-// forces the loop form on every row kernel, for measurements)
+// want: 1 = persistent; 0 = one workgroup per tile
 template <typename A>
 static dim3 rows_grid(A &a, int NW, int64_t tiles_x, int64_t tiles_y, int want) {
-    static const int force = std::getenv("SPORCO_AMD_ROWS_PERSIST")
-                                 ? std::atoi(std::getenv("SPORCO_AMD_ROWS_PERSIST")) : -1;
-    static const int sg = std::getenv("SPORCO_AMD_ROWS_STAGGER_GROUPS")
-                              ? std::atoi(std::getenv("SPORCO_AMD_ROWS_STAGGER_GROUPS")) : 1;
-    static const int ss = std::getenv("SPORCO_AMD_ROWS_STAGGER_SLEEPS")
-                              ? std::atoi(std::getenv("SPORCO_AMD_ROWS_STAGGER_SLEEPS")) : 0;
     const int64_t g = rows_persistent_grid(NW), n = tiles_x * tiles_y;
     SA_REQUIRE(n < ((int64_t)1 << 31), "too many tiles for one launch");
-    if (force == 2) want = 1;
     a.persist = (want && g > 0 && n > g) ? 1 : 0;
-    a.stagger_groups = sg > 0 ? sg : 1;
-    a.stagger_sleeps = ss;
+    a.stagger_groups = 1;      // (a start-up stagger of the row kernels measured no gain)
+    a.stagger_sleeps = 0;
     return dim3((unsigned)(a.persist ? g : n), 1);
 }
 
@@ -1422,12 +1410,10 @@ template <> int64_t launch_rows_inv_prox_fwd<float>(hipStream_t st, const RowsPr
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
     // (the forward half of this kernel is the emitting epilogue's, which gained 8 % from a
     // persistent launch; this one does not -- config 4 244.7-245.8 it/s persistent against
-    // 240.7-246.2 per tile, profiles/r03g_config4_prox_persist.jsonl -- so SPORCO_AMD_PROX_PERSIST=1
-    // stays a measurement switch)
+    // 240.7-246.2 per tile, profiles/r03g_config4_prox_persist.jsonl: one tile per workgroup)
     RowsProxArgs<float> ap = a;
     const int64_t tx = ceil_div(a.P, 128);
-    static const int want = std::getenv("SPORCO_AMD_PROX_PERSIST") ? std::atoi(std::getenv("SPORCO_AMD_PROX_PERSIST")) : 0;
-    const dim3 grid = rows_grid(ap, a.W / kN1, tx, a.H, (a.t_out != nullptr && want) ? 1 : 0);
+    const dim3 grid = rows_grid(ap, a.W / kN1, tx, a.H, 0);
     if (a.W == 128)
         launch_prox_nw<4>(st, ap, grid);
     else if (a.W == 256)

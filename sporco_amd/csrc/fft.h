@@ -67,20 +67,6 @@ void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64
              int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer, int64_t out_line,
              T scale, int64_t grp = 0, int64_t grp_stride = 0);
 
-// The same pass with the ADMM epilogue (csc_kernels.h PostParams, csc_post_elem.h: relax_AX,
-// ystep, ustep and the residual / objective sums of admm.py:877-885, cbpdn.py:614-620,
-// admm.py:434-486) applied to every output element before it leaves the workgroup: the output
-// is X of an (n_outer, n, P) array, post.y / post.u are updated in place, X is stored to x_out
-// only if that is set, and every workgroup writes 8 partial sums (returns how many
-// workgroups; fft_c2r_post_blocks: the same number, for sizing `partials`).  Saves the write
-// and the re-read of X of the two-kernel form.  Not for ConvBPDNJoint.
-template <typename T> struct PostParams;
-template <typename T>
-int64_t fft_c2r_post(hipStream_t st, const FftPlan &plan, const cx<T> *in, int64_t n_outer, int64_t P,
-                     int64_t in_outer, int64_t in_line, T scale, const PostParams<T> &post, T *x_out,
-                     double *partials);
-template <typename T> int64_t fft_c2r_post_blocks(const FftPlan &plan, int64_t n_outer, int64_t P);
-
 // out(H, W/2+1, P) = rfftn(in [- s2*in2], axes=(0,1)) for real in(H, W, P).
 template <typename T>
 void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
@@ -98,9 +84,12 @@ void irfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const cx
 // place (the c2r row pass is what remains of irfftn); partials (Wf * CN doubles) receive the
 // Parseval-weighted sums of |Df.xf - Sf|^2 when want_obj.  fft_cols_sm_supported: radices <= 8 and
 // K <= 64 with the tile in LDS, or K <= 256 in slabs of filters that fit (four passes then).  Returns the number of tiles.
-template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K);
+// (force_slab > 0: the test switch SPORCO_AMD_COLS_SM_FORCE_SLAB, read once per handle -- slabs of
+// that many filters even where the tile fits)
+template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K, int force_slab = 0);
 template <typename T>
 int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> *df, const cx<T> *sf,
-                    const T *gram, T rho, int Wf, int CN, int K, int W, bool want_obj, double *partials);
+                    const T *gram, T rho, int Wf, int CN, int K, int W, bool want_obj, double *partials,
+                    int force_slab = 0);
 
 }  // namespace sporco_amd

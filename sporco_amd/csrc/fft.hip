@@ -47,13 +47,6 @@ template <typename T> struct LineArgs {
     // lives at (p / grp) * grp_stride + p % grp instead of p.  This is how the row
     // transforms write / read the tile-major layout of csc_fused.h.
     int64_t grp, grp_stride;
-    // C2R with the ADMM epilogue fused into the store (fft_c2r_post): the transform's output is
-    // X of element (o, i, p) of an (n_outer, n, P) array; post.y / post.u are updated in place,
-    // X goes to x_out when that is set, every workgroup writes 8 partial sums.
-    PostParams<T> post;
-    T *x_out;
-    double *partials;
-    int64_t postP;
     // R2C only: `in` is the ADMM iterate in its single-array form V = AX + U (csc_rows.h): the line
     // transformed is Y - s2 U with Y = prox_l1(V; vthr) (+ NonNegCoef), U = V - Y, derived per
     // element as the epilogue derived them (csc_post_elem.h admm_post_elem)
@@ -299,10 +292,7 @@ __device__ __forceinline__ void stockham_pass_r(int R, const cx<T> *src, cx<T> *
     }
 }
 
-// POST (MODE_C2R only): 0 = plain store; 1 / 2 = the ADMM epilogue of csc_post_elem.h on every
-// output element (2: the variant that needs the element's 5-D index -- weight arrays,
-// NoBndryCross, AddMaskSim).
-template <typename T, int MODE, bool PACK, int POST = 0>
+template <typename T, int MODE, bool PACK>
 __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
     const int n = a.n, cols = a.cols;
     cx<T> *buf0 = dyn_lds<cx<T>>();
@@ -403,40 +393,6 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
     }
 
     // ---------------- store ----------------
-    if constexpr (POST != 0) {
-        static_assert(MODE == MODE_C2R || POST == 0, "the epilogue belongs to the c2r pass");
-        constexpr bool GENERAL = POST == 2;
-        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if (valid) {
-            const int64_t P = a.postP;
-            for (int i = lane; i < n; i += lpc) {
-                const cx<T> z = src[i * cols + col];
-                if (PACK) {
-                    const int64_t idx = (o * n + i) * P + 2 * c;
-                    const T x0 = z.re * a.scale, x1 = z.im * a.scale;
-                    cx<T> yv = *reinterpret_cast<const cx<T> *>(a.post.y + idx);
-                    cx<T> uv = *reinterpret_cast<const cx<T> *>(a.post.u + idx);
-                    admm_post_elem<T, GENERAL>(a.post, idx, P, x0, yv.re, uv.re, acc);
-                    admm_post_elem<T, GENERAL>(a.post, idx + 1, P, x1, yv.im, uv.im, acc);
-                    *reinterpret_cast<cx<T> *>(a.post.y + idx) = yv;
-                    *reinterpret_cast<cx<T> *>(a.post.u + idx) = uv;
-                    if (a.x_out) *reinterpret_cast<cx<T> *>(a.x_out + idx) = mk<T>(x0, x1);
-                } else {
-                    const int64_t idx = (o * n + i) * P + c;
-                    const T x0 = z.re * a.scale;
-                    T yv = a.post.y[idx], uv = a.post.u[idx];
-                    admm_post_elem<T, GENERAL>(a.post, idx, P, x0, yv, uv, acc);
-                    a.post.y[idx] = yv;
-                    a.post.u[idx] = uv;
-                    if (a.x_out) a.x_out[idx] = x0;
-                }
-            }
-        }
-        __syncthreads();      // the transform buffers become the reduction scratch
-        block_sum_store<8>(acc, reinterpret_cast<double *>(buf0),
-                           a.partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8);
-        return;
-    }
     if (!valid) return;
     if (MODE == MODE_C2C) {
         cx<T> *out = static_cast<cx<T> *>(a.out) + o * a.out_outer + c;
@@ -847,10 +803,9 @@ void FftPlan::init(int n_) {
         }
         // (the composite passes pay in the in-place kernel -- 10-20 % off the fused column pass at
         // 240 / 320 / 384 / 480 points -- and cost the Stockham line kernels registers and occupancy:
-        // profiles/r04y9_fft_radices.jsonl; SPORCO_AMD_FFT_PLAIN_RADICES=1 keeps both lists plain)
-        const bool plain = std::getenv("SPORCO_AMD_FFT_PLAIN_RADICES") != nullptr;
+        // profiles/r04y9_fft_radices.jsonl)
         int a2 = e2, a3 = e3, a5 = e5;
-        if (!plain) {
+        {
             while (a3 > 0 && a2 >= 2) push_ip(12), --a3, a2 -= 2;
             while (a3 > 0 && a2 >= 1) push_ip(6), --a3, --a2;
             while (a5 > 0 && a2 >= 1) push_ip(10), --a5, --a2;
@@ -935,11 +890,7 @@ template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
     // phases then have nothing to overlap with; at 8 columns it holds three to five.  Measured
     // (profiles/r04o_fft_cols.jsonl): the row and column passes of 240-, 320-, 384- and 480-point
     // lines 17-28 % faster; 512-point columns and the float64 lines slower, so they keep 128 bytes.
-    static const int shift = std::getenv("SPORCO_AMD_FFT_COLS_SHIFT")     // (measurement knob)
-                                 ? std::atoi(std::getenv("SPORCO_AMD_FFT_COLS_SHIFT")) : -1;
-    if (shift >= 0) {
-        for (int i = 0; i < shift && cols > 1; ++i) cols >>= 1;
-    } else if (sizeof(T) == 4 && n < 512 && cols == 16 && (2 * (size_t)n * cols + n) * esz > 48 * 1024) {
+    if (sizeof(T) == 4 && n < 512 && cols == 16 && (2 * (size_t)n * cols + n) * esz > 48 * 1024) {
         cols = 8;
     }
     int lpc = 1;
@@ -953,11 +904,11 @@ template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
     return c;
 }
 
-template <typename T, int MODE, bool PACK, int POST = 0>
+template <typename T, int MODE, bool PACK>
 int64_t launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n_outer) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK, POST>),
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     }
     if (a.ncols <= 0 || n_outer <= 0) return 0;
@@ -970,7 +921,7 @@ int64_t launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_
     a.tw = plan.tw<T>();
     SA_REQUIRE(n_outer <= 65535, "too many outer slices for one launch");
     const dim3 grid((unsigned)ceil_div(a.ncols, cfg.cols), (unsigned)n_outer, 1);
-    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK, POST>), grid, dim3(cfg.threads), cfg.lds, st, a);
+    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK>), grid, dim3(cfg.threads), cfg.lds, st, a);
     SA_HIP(hipGetLastError());
     return (int64_t)grid.x * grid.y;
 }
@@ -1071,42 +1022,6 @@ void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64
 }
 
 template <typename T>
-int64_t fft_c2r_post_blocks(const FftPlan &plan, int64_t n_outer, int64_t P) {
-    const bool pack = P % 2 == 0;
-    const int64_t ncols = pack ? P / 2 : P;
-    return ceil_div(ncols, pick_cfg<T>(plan.n, ncols).cols) * n_outer;
-}
-
-template <typename T>
-int64_t fft_c2r_post(hipStream_t st, const FftPlan &plan, const cx<T> *in, int64_t n_outer, int64_t P,
-                     int64_t in_outer, int64_t in_line, T scale, const PostParams<T> &post, T *x_out,
-                     double *partials) {
-    SA_REQUIRE(!(post.flags & F_JOINT), "the fused epilogue has no l2,1 term");
-    LineArgs<T> a{};
-    a.in = in;
-    a.in2 = nullptr;
-    a.out = nullptr;
-    a.s2 = T(0);
-    a.scale = scale;
-    a.inverse = 1;
-    a.in_outer = in_outer;
-    a.in_line = in_line;
-    a.post = post;
-    a.x_out = x_out;
-    a.partials = partials;
-    a.postP = P;
-    const bool general = post.wl1.ptr != nullptr || (post.flags & F_NOBNDRY) || post.ams.ptr;
-    const bool pack = (P % 2 == 0) && (in_outer % 2 == 0) && (in_line % 2 == 0);
-    SA_REQUIRE(pack == (P % 2 == 0), "unexpected strides of the half spectrum");
-    a.ncols = pack ? P / 2 : P;
-    if (pack)
-        return general ? launch_lines<T, MODE_C2R, true, 2>(st, plan, a, n_outer)
-                       : launch_lines<T, MODE_C2R, true, 1>(st, plan, a, n_outer);
-    return general ? launch_lines<T, MODE_C2R, false, 2>(st, plan, a, n_outer)
-                   : launch_lines<T, MODE_C2R, false, 1>(st, plan, a, n_outer);
-}
-
-template <typename T>
 void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,
            T s2, cx<T> *out, int H, int W, int64_t P) {
     const int64_t Wf = W / 2 + 1;
@@ -1132,9 +1047,10 @@ template <typename T> static size_t cols_sm_slab_lds(int n, int Ks) {
     return sizeof(cx<T>) * ((size_t)n * Ks + 2 * n) + sizeof(double) * 16 + sizeof(int) * n;
 }
 // filters per slab when the tile does not fit: the largest power of two that does (0: none >= 8)
-template <typename T> static int cols_sm_slab_width(int n, int K) {
-    if (const char *e = std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB")) {     // (test switch: slabs of this width)
-        const int ks = std::atoi(e);
+// (force: the test switch of fft.h -- slabs of that width)
+template <typename T> static int cols_sm_slab_width(int n, int K, int force) {
+    if (force > 0) {
+        const int ks = force;
         return (ks >= 2 && ks < K && !(ks & (ks - 1)) && cols_sm_slab_lds<T>(n, ks) <= kLdsBudget) ? ks : 0;
     }
     for (int ks = 64; ks >= 8; ks >>= 1)
@@ -1142,21 +1058,21 @@ template <typename T> static int cols_sm_slab_width(int n, int K) {
     return 0;
 }
 
-template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K) {
+template <typename T> bool fft_cols_sm_supported(const FftPlan &plan, int K, int force_slab) {
     if (K < 2 || plan.n < 2) return false;
     for (int p = 0; p < plan.nrad_ip; ++p) {
         const int r = plan.radix_ip[p];
         if (r > 12 || r == 9 || r == 11) return false;
     }
-    if (K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget && !std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB"))
-        return true;
-    return K <= 256 && cols_sm_slab_width<T>(plan.n, K) > 0 && !std::getenv("SPORCO_AMD_NO_COLS_SM_SLAB");
+    if (K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget && force_slab <= 0) return true;
+    return K <= 256 && cols_sm_slab_width<T>(plan.n, K, force_slab) > 0;
 }
 
 template <typename T>
 int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> *df, const cx<T> *sf,
-                    const T *gram, T rho, int Wf, int CN, int K, int W, bool want_obj, double *partials) {
-    SA_REQUIRE(fft_cols_sm_supported<T>(plan, K), "fft_cols_sm: unsupported length / filter count");
+                    const T *gram, T rho, int Wf, int CN, int K, int W, bool want_obj, double *partials,
+                    int force_slab) {
+    SA_REQUIRE(fft_cols_sm_supported<T>(plan, K, force_slab), "fft_cols_sm: unsupported length / filter count");
     ColsSmArgs<T> a{};
     a.xf = xf;
     a.df = df;
@@ -1179,9 +1095,9 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
     bool big = false;       // (a 10-, 12-, 14- or 15-point pass: the instantiations that carry them)
     for (int i = 0; i < plan.nrad_ip; ++i) big = big || plan.radix_ip[i] == 6 || plan.radix_ip[i] >= 10;
     static PerDeviceOnce attr_set;
-    if (!(K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget) || std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB")) {
+    if (!(K <= 64 && cols_sm_lds<T>(plan.n, K) <= kLdsBudget) || force_slab > 0) {
         // the tile goes through in slabs of filters
-        a.Ks = cols_sm_slab_width<T>(plan.n, K);
+        a.Ks = cols_sm_slab_width<T>(plan.n, K, force_slab);
         static PerDeviceOnce slab_attr;
         if (slab_attr.first()) {
             SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_sm_slab_kernel<T, false>),
@@ -1238,12 +1154,9 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
                              int64_t, int64_t, const VformIn<T> *);                              \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
                              int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
-    template bool fft_cols_sm_supported<T>(const FftPlan &, int);                               \
+    template bool fft_cols_sm_supported<T>(const FftPlan &, int, int);                          \
     template int64_t fft_cols_sm<T>(hipStream_t, const FftPlan &, cx<T> *, const cx<T> *,        \
-                                    const cx<T> *, const T *, T, int, int, int, int, bool, double *); \
-    template int64_t fft_c2r_post_blocks<T>(const FftPlan &, int64_t, int64_t);                  \
-    template int64_t fft_c2r_post<T>(hipStream_t, const FftPlan &, const cx<T> *, int64_t, int64_t, \
-                                     int64_t, int64_t, T, const PostParams<T> &, T *, double *); \
+                                    const cx<T> *, const T *, T, int, int, int, int, bool, double *, int); \
     template void rfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const T *, const T *,  \
                            T, cx<T> *, int, int, int64_t);                                       \
     template void irfft2<T>(hipStream_t, const FftPlan &, const FftPlan &, const cx<T> *,        \

@@ -98,8 +98,12 @@ def use_backend(name):
     import sporco_amd
     from sporco_amd import _lib
     if name == 'hostsim':
+        # (the simulator library carries a stand-in for librccl: single-rank, identity collectives)
+        os.environ['SPORCO_AMD_RCCL_LIB'] = build_hostsim()
         sporco_amd.load_library(build_hostsim())
     else:
+        if 'hostsim' in os.environ.get('SPORCO_AMD_RCCL_LIB', ''):
+            os.environ.pop('SPORCO_AMD_RCCL_LIB')
         sporco_amd.load_library()      # in-tree libsporco_amd.so, hipcc build
         assert _lib.library_path().endswith('libsporco_amd.so')
         assert sporco_amd.device_count() > 0, "no AMD GPU visible"

@@ -283,3 +283,32 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     return hipSuccess;
 }
 hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+
+
+// ---------------------------------------------------------------------------------------------
+// Stand-in for librccl (csc_comm.hip opens whatever SPORCO_AMD_RCCL_LIB names; tests/conftest.py
+// points it at this library): single-rank communicators, identity collectives -- what runs is the
+// sharded code path of the library around them.
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+struct HostsimNcclId {
+    char internal[128];
+};
+int ncclGetUniqueId(HostsimNcclId *id) {
+    std::memset(id->internal, 0, sizeof id->internal);
+    return 0;
+}
+int ncclCommInitRank(void **comm, int world, HostsimNcclId, int rank) {
+    if (world != 1 || rank != 0) return 5;      // (ncclInvalidArgument)
+    *comm = reinterpret_cast<void *>(0x1);
+    return 0;
+}
+int ncclCommDestroy(void *) { return 0; }
+int ncclAllReduce(const void *in, void *out, size_t count, int dtype, int, void *, hipStream_t) {
+    if (in != out) std::memcpy(out, in, count * (dtype == 7 ? 4 : 8));
+    return 0;
+}
+const char *ncclGetErrorString(int rc) {
+    return rc == 5 ? "the CPU simulator build has single-rank communicators only" : "hostsim nccl stand-in";
+}
+}

@@ -2,9 +2,8 @@
 """The generic ADMM chain (sizes / dtypes the register kernels do not serve; SPORCO_AMD_UNFUSED=1
 forces it at the other sizes): iterations per second in the (Y, U) form (SPORCO_AMD_NO_VFORM=1),
 in the single-array form (V = AX + U in place of Y and U, 13 passes instead of 16), with the
-column pass as one LDS-resident kernel on top of that (the default where the tile fits: 9 passes), and
-with the epilogue fused into the row pass of irfftn (SPORCO_AMD_C2R_POST=1, (Y, U) form).  One JSON
-line per configuration and variant."""
+column pass as one LDS-resident kernel on top of that (the default where the tile fits: 9 passes).
+One JSON line per configuration and variant."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,15 +12,13 @@ CONFIGS = [(512, 512, 64, 8, 'float32', True), (384, 384, 64, 8, 'float32', Fals
            (240, 320, 64, 8, 'float32', False), (128, 128, 64, 8, 'float64', False),
            (320, 480, 32, 8, 'float32', False), (256, 256, 32, 8, 'float64', False)]
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ''           # substring of '<H>x<W> K=<K>'
-VARIANTS = sys.argv[2].split(',') if len(sys.argv) > 2 else ['yu', 'v', 'v_cols_sm', 'yu_c2r_post']
+VARIANTS = sys.argv[2].split(',') if len(sys.argv) > 2 else ['yu', 'v', 'v_cols_sm']
 CONFIGS += [(480, 320, 64, 8, 'float32', False), (256, 256, 64, 8, 'float64', False), (224, 224, 64, 8, 'float32', False)]
 for (H, W, K, N, dt, force) in CONFIGS:
     if ONLY not in '%dx%d K=%d %s' % (H, W, K, dt):
         continue
     for variant in VARIANTS:
-        nofuse = variant != 'yu_c2r_post'
         env = {'SPORCO_AMD_UNFUSED': '1'} if force else {}
-        env['SPORCO_AMD_C2R_POST'] = '0' if nofuse else '1'
         if variant not in ('v', 'v_cols_sm'):
             env['SPORCO_AMD_NO_VFORM'] = '1'
         if variant != 'v_cols_sm':
