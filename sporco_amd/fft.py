@@ -1,8 +1,9 @@
 """Device FFT primitives with the call signatures of ``sporco.fft``.
 
 Mirrors ``rfftn`` / ``irfftn`` / ``rfl2norm2`` of the reference
-(sporco/fft.py:257-314, :449-484) for the case the convolutional solvers use:
-transform axes (0, 1) of an array whose remaining axes form the batch.
+(sporco/fft.py:257-314, :449-484).  The case the convolutional solvers use -- transform axes
+(0, 1) of an array whose remaining axes form the batch -- goes to the device as it is; any other
+pair of axes, or a single axis, after those axes have been moved to the front.
 """
 
 import ctypes
@@ -29,10 +30,32 @@ def _check_axes(axes):
         raise NotImplementedError("sporco_amd.fft transforms axes (0, 1) only")
 
 
+def _norm_axes(axes, nd):
+    """One or two distinct axes, non-negative; None when they are (0, 1) already."""
+    if axes is None:
+        axes = (0, 1)
+    if np.ndim(axes) == 0:
+        axes = (int(axes),)
+    ax = tuple(int(x) + nd if int(x) < 0 else int(x) for x in axes)
+    if len(ax) not in (1, 2) or len(set(ax)) != len(ax) or not all(0 <= x < nd for x in ax):
+        raise NotImplementedError("sporco_amd.fft transforms one or two distinct axes (got %r for "
+                                  "%d dimensions)" % (axes, nd))
+    return None if ax == (0, 1) else ax
+
+
 def rfftn(a, s=None, axes=(0, 1)):
-    """Unnormalised real FFT over axes (0, 1); ``s`` zero-pads (or crops) first."""
-    _check_axes(axes)
+    """Unnormalised real FFT over ``axes`` (one or two axes; the last one listed is the halved
+    one, as in numpy.fft.rfftn); ``s`` zero-pads (or crops) first."""
     a = np.asarray(a)
+    ax = _norm_axes(axes, a.ndim)
+    if ax is not None:
+        # the transform axes to the front (a single axis behind a unit one), transform, and back
+        if len(ax) == 1:
+            m = np.moveaxis(a, ax[0], 0)[np.newaxis]
+            out = rfftn(m, None if s is None else (1, int(s[0])))
+            return np.moveaxis(out[0], 0, ax[0])
+        out = rfftn(np.moveaxis(a, ax, (0, 1)), s)
+        return np.moveaxis(out, (0, 1), ax)
     if a.dtype not in (np.float32, np.float64):
         a = a.astype(np.float64)
     if s is not None and tuple(s) != a.shape[:2]:
@@ -50,8 +73,15 @@ def rfftn(a, s=None, axes=(0, 1)):
 
 
 def irfftn(a, s, axes=(0, 1)):
-    """Inverse of :func:`rfftn`; ``s`` = (H, W) is required (W may be odd)."""
-    _check_axes(axes)
+    """Inverse of :func:`rfftn`; ``s`` (the lengths of the transformed axes) is required: the
+    last one may be odd."""
+    a = np.asarray(a)
+    ax = _norm_axes(axes, a.ndim)
+    if ax is not None:
+        if len(ax) == 1:
+            out = irfftn(np.moveaxis(a, ax[0], 0)[np.newaxis], (1, int(s[0])))
+            return np.moveaxis(out[0], 0, ax[0])
+        return np.moveaxis(irfftn(np.moveaxis(a, ax, (0, 1)), s), (0, 1), ax)
     a = np.ascontiguousarray(a)
     if a.dtype not in (np.complex64, np.complex128):
         a = a.astype(np.complex128)

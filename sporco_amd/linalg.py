@@ -1,8 +1,10 @@
 """Device linear-algebra primitives with the signatures of ``sporco.linalg``.
 
 ``inner`` (sporco/linalg.py:41-88), ``solvedbi_sm`` / ``solvedbi_sm_c``
-(:232-297) and ``rrs`` (:883-910), for 5-D arrays in the internal layout with
-the sum / solve taken along the last (filter) axis.
+(:232-297) and ``rrs`` (:883-910).  Any axis and any pair of operands that broadcast against each
+other, as in the reference; the layout the solvers use -- ``a`` of shape (pixels..., 1, 1, K)
+against ``b`` of shape (pixels..., C, N, K), sum / solve along the last axis -- goes to the device
+as it is, every other case after the axis has been moved last and the operands expanded.
 """
 
 import numpy as np
@@ -33,26 +35,62 @@ def _cplx(a, cdt):
     return np.ascontiguousarray(a, dtype=cdt)
 
 
+def _fast_pattern(ah, b, axis):
+    """(npix, CN, K) when the operands have the solvers' layout and ``axis`` is the last, else None."""
+    ah, b = np.asarray(ah), np.asarray(b)
+    if ah.ndim != b.ndim or ah.ndim < 3 or axis not in (-1, b.ndim - 1):
+        return None
+    try:
+        return _split(ah, b)
+    except (NotImplementedError, ValueError):
+        return None
+
+
+def _moved_last(x, y, axis):
+    """The operands expanded against each other with ``axis`` moved last, as contiguous 2-D
+    (M, K) arrays, and the expanded shape (axis still in place)."""
+    xb, yb = np.broadcast_arrays(x, y)
+    nd = xb.ndim
+    ax = axis + nd if axis < 0 else axis
+    if not 0 <= ax < nd:
+        raise ValueError("axis %d out of range for %d dimensions" % (axis, nd))
+    K = xb.shape[ax]
+    xm = np.ascontiguousarray(np.moveaxis(xb, ax, -1)).reshape(-1, K)
+    ym = np.ascontiguousarray(np.moveaxis(yb, ax, -1)).reshape(-1, K)
+    return xm, ym, xb.shape, ax
+
+
 def inner(x, y, axis=-1):
-    """sum(x * y, axis, keepdims=True) on device (no conjugation)."""
+    """sum(x * y, axis, keepdims=True) on device, no conjugation (sporco/linalg.py:41-88): any
+    axis, operands that broadcast against each other."""
     x = np.asarray(x)
     y = np.asarray(y)
-    if axis not in (-1, y.ndim - 1):
-        raise NotImplementedError("sporco_amd.linalg.inner sums over the last axis")
-    npix, CN, K = _split(x, y)
+    real = not (np.iscomplexobj(x) or np.iscomplexobj(y))
     cdt = np.result_type(x.dtype, y.dtype, np.complex64)
-    out = np.empty(y.shape[:-1] + (1,), dtype=cdt)
-    _lib.check(_lib.lib().sporco_amd_inner(_lib.dtype_code(real_dtype(cdt)), npix, CN, K,
-                                           _lib._ptr(_cplx(x, cdt)), _lib._ptr(_cplx(y, cdt)),
-                                           _lib._ptr(out)))
-    return out
+    pat = _fast_pattern(x, y, axis)
+    if pat is not None:
+        npix, CN, K = pat
+        out = np.empty(y.shape[:-1] + (1,), dtype=cdt)
+        _lib.check(_lib.lib().sporco_amd_inner(_lib.dtype_code(real_dtype(cdt)), npix, CN, K,
+                                               _lib._ptr(_cplx(x, cdt)), _lib._ptr(_cplx(y, cdt)),
+                                               _lib._ptr(out)))
+    else:
+        xm, ym, shp, ax = _moved_last(x, y, axis)
+        M, K = xm.shape
+        o = np.empty((M, 1), dtype=cdt)
+        _lib.check(_lib.lib().sporco_amd_inner(_lib.dtype_code(real_dtype(cdt)), M, 1, K,
+                                               _lib._ptr(_cplx(xm, cdt)), _lib._ptr(_cplx(ym, cdt)),
+                                               _lib._ptr(o)))
+        rest = tuple(n for i, n in enumerate(shp) if i != ax)
+        out = np.moveaxis(o.reshape(rest + (1,)), -1, ax)
+    return out.real.astype(np.result_type(x.dtype, y.dtype, np.float32)) if real else out
 
 
 def solvedbi_sm_c(ah, a, rho, axis=4):
-    """c = ah / (<ah, a> + rho): kept for API parity; the device solve does not
-    need it (the denominator is formed inside the kernel)."""
+    """c = ah / (<ah, a> + rho) (sporco/linalg.py:232-256): the sum on the device.  The device
+    solve itself does not need it (the denominator is formed inside the kernel)."""
     ah = np.asarray(ah)
-    return ah / (np.sum(ah * a, axis=axis, keepdims=True) + rho)
+    return ah / (inner(ah, a, axis=axis) + rho)
 
 
 def solvedbi_sm(ah, rho, b, c=None, axis=4):
@@ -61,15 +99,25 @@ def solvedbi_sm(ah, rho, b, c=None, axis=4):
     ``c`` is accepted for signature compatibility and ignored.
     """
     b = np.asarray(b)
-    if axis not in (-1, b.ndim - 1):
-        raise NotImplementedError("sporco_amd.linalg.solvedbi_sm solves along the last axis")
-    npix, CN, K = _split(ah, b)
-    cdt = np.result_type(np.asarray(ah).dtype, b.dtype, np.complex64)
-    x = np.empty(b.shape, dtype=cdt)
+    ah = np.asarray(ah)
+    cdt = np.result_type(ah.dtype, b.dtype, np.complex64)
+    pat = _fast_pattern(ah, b, axis)
+    if pat is not None:
+        npix, CN, K = pat
+        x = np.empty(b.shape, dtype=cdt)
+        _lib.check(_lib.lib().sporco_amd_solvedbi_sm(
+            _lib.dtype_code(real_dtype(cdt)), npix, CN, K, _lib._ptr(_cplx(ah, cdt)), float(rho),
+            _lib._ptr(_cplx(b, cdt)), _lib._ptr(x)))
+        return x
+    # any other axis / broadcast pattern: one system per row after the axis has been moved last
+    am, bm, shp, ax = _moved_last(ah, b, axis)
+    M, K = bm.shape
+    xm = np.empty((M, K), dtype=cdt)
     _lib.check(_lib.lib().sporco_amd_solvedbi_sm(
-        _lib.dtype_code(real_dtype(cdt)), npix, CN, K, _lib._ptr(_cplx(ah, cdt)), float(rho),
-        _lib._ptr(_cplx(b, cdt)), _lib._ptr(x)))
-    return x
+        _lib.dtype_code(real_dtype(cdt)), M, 1, K, _lib._ptr(_cplx(am, cdt)), float(rho),
+        _lib._ptr(_cplx(bm, cdt)), _lib._ptr(xm)))
+    rest = tuple(n for i, n in enumerate(shp) if i != ax)
+    return np.moveaxis(xm.reshape(rest + (K,)), -1, ax)
 
 
 def rrs(ax, b):

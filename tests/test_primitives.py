@@ -34,8 +34,8 @@ def test_solvedbi_sm_and_inner(backend):
     # float32 inputs stay float32
     x32 = linalg.solvedbi_sm(ah.astype(np.complex64), rho, b.astype(np.complex64))
     assert x32.dtype == np.complex64 and rel_l2(x32, g['sm_x']) < 1e-5
-    with pytest.raises(NotImplementedError):
-        linalg.inner(ah, b, axis=0)
+    # (any other axis: test_inner_and_solvedbi_sm_any_axis)
+    assert rel_l2(linalg.inner(ah, b, axis=0), np.sum(ah * b, axis=0, keepdims=True)) < 1e-12
 
 
 def test_rfftn_irfftn_rfl2norm2(backend):
@@ -97,3 +97,38 @@ def test_rfftn_lengths_with_factors_3_5_7(backend, shape, dt):
     tol = 1e-14 if dt == np.float64 else 2e-6
     assert rel_l2(X, np.fft.rfft2(x.astype(np.float64), axes=(0, 1))) < tol
     assert rel_l2(sf.irfftn(X, shape[:2], (0, 1)), x) < tol
+
+
+def test_inner_and_solvedbi_sm_any_axis(backend):
+    """`linalg.inner` / `solvedbi_sm` / `solvedbi_sm_c` along ANY axis and for any operands that
+    broadcast (sporco/linalg.py:41-88, :232-297; the dictionary update sums over the image axis,
+    sporco/pgm/ccmod.py:303) against NumPy."""
+    from sporco_amd import linalg
+    rng = np.random.RandomState(0)
+    x = rng.randn(6, 5, 3, 2, 4) + 1j * rng.randn(6, 5, 3, 2, 4)
+    y = rng.randn(6, 5, 1, 2, 4) + 1j * rng.randn(6, 5, 1, 2, 4)
+    for ax in (-1, 0, 2, 3, 4, -2):
+        r, e = linalg.inner(x, y, axis=ax), np.sum(x * y, axis=ax, keepdims=True)
+        assert r.shape == e.shape and np.abs(r - e).max() < 1e-12, ax
+    xr, yr = rng.randn(4, 7, 3).astype(np.float32), rng.randn(4, 7, 3).astype(np.float32)
+    r = linalg.inner(xr, yr, axis=1)
+    assert r.dtype == np.float32 and np.allclose(r, np.sum(xr * yr, axis=1, keepdims=True), atol=1e-5)
+    a = rng.randn(6, 5, 1, 4, 1) + 1j * rng.randn(6, 5, 1, 4, 1)
+    b = rng.randn(6, 5, 3, 4, 2) + 1j * rng.randn(6, 5, 3, 4, 2)
+    rho = 0.7
+    xs = linalg.solvedbi_sm(np.conj(a), rho, b, axis=3)
+    assert np.abs(rho * xs + a * np.sum(np.conj(a) * xs, axis=3, keepdims=True) - b).max() < 1e-12
+    c = linalg.solvedbi_sm_c(np.conj(a), a, rho, axis=3)
+    assert np.abs(c - np.conj(a) / (np.sum(np.conj(a) * a, axis=3, keepdims=True) + rho)).max() < 1e-13
+
+
+def test_rfftn_any_axes(backend):
+    """`fft.rfftn` / `irfftn` over any two axes, or one (sporco/fft.py:257-314), against numpy.fft."""
+    from sporco_amd import fft
+    v = np.random.RandomState(1).randn(3, 10, 4, 9)
+    for axes in ((1, 3), (3, 1), (0, 2), (-1,), (1,), (2, 0)):
+        f, e = fft.rfftn(v, axes=axes), np.fft.rfftn(v, axes=axes)
+        assert f.shape == e.shape and np.abs(f - e).max() < 1e-12, axes
+        assert np.abs(fft.irfftn(f, [v.shape[i] for i in axes], axes=axes) - v).max() < 1e-12, axes
+    with pytest.raises(NotImplementedError):
+        fft.rfftn(v, axes=(0, 1, 2))
