@@ -66,13 +66,13 @@ def itstat_dict(b, prefix='it_'):
 
 
 # ---------------------------------------------------------------------------
-def admm_case(name, D, S, lmbda, optd, dimK=None, joint_mu=None):
+def admm_case(name, D, S, lmbda, optd, dimK=None, joint_mu=None, dimN=2):
     if joint_mu is None:
         opt = ref_cbpdn.ConvBPDN.Options(optd)
-        b = ref_cbpdn.ConvBPDN(D, S, lmbda, opt, dimK=dimK)
+        b = ref_cbpdn.ConvBPDN(D, S, lmbda, opt, dimK=dimK, dimN=dimN)
     else:
         opt = ref_cbpdn.ConvBPDNJoint.Options(optd)
-        b = ref_cbpdn.ConvBPDNJoint(D, S, lmbda, joint_mu, opt, dimK=dimK)
+        b = ref_cbpdn.ConvBPDNJoint(D, S, lmbda, joint_mu, opt, dimK=dimK, dimN=dimN)
     b.solve()
     extra = {}
     for key, val in optd.items():
@@ -99,6 +99,25 @@ def gen_admm_cplx():
                'AuxVarObj': True})
     admm_case('admm_cplx_default_f32', D.astype(np.complex64), S.astype(np.complex64), 0.1,
               {'MaxMainIter': 30})
+
+
+def gen_dim1():
+    """dimN = 1: one-dimensional signals (sporco/cnvrep.py:33-198 with dimN=1; the constructor
+    contract of sporco/admm/cbpdn.py:175, pgm/cbpdn.py:100).  A single signal, three signals
+    (dimK = 1), three channels with the joint l2,1 term; FISTA on the three signals."""
+    rng = np.random.RandomState(1001)
+    D = rng.randn(6, 5)
+    admm_case('admm_dim1_single_f64', D, rng.randn(48), 0.1, {'MaxMainIter': 30}, dimN=1)
+    admm_case('admm_dim1_multi_f64', D, rng.randn(45, 3), 0.1, {'MaxMainIter': 30, 'NonNegCoef': True},
+              dimK=1, dimN=1)
+    admm_case('admm_dim1_joint_f64', D, rng.randn(40, 3), 0.05, {'MaxMainIter': 25}, dimK=0, joint_mu=0.02,
+              dimN=1)
+    S = rng.randn(45, 3)
+    opt = ref_pgm_cbpdn.ConvBPDN.Options({'MaxMainIter': 30, 'L': 50.0, 'Backtrack': BacktrackStandard()})
+    b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.1, opt, dimK=1, dimN=1)
+    X = b.solve()
+    save('pgm_dim1_f64', D=D, S=S, lmbda=np.float64(0.1), X=X, k_final=np.int64(b.k), recon=b.reconstruct(),
+         **itstat_dict(b))
 
 
 def gen_admm():
@@ -1403,7 +1422,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
-             'known': gen_known_answer, 'config1': gen_config1,
+             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

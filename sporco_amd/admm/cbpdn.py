@@ -106,6 +106,8 @@ class GenericConvBPDN(admm.ADMMEqual):
     # (linalg.solvemdbi_ism, cbpdn.py:277-279); the variants below that need a different
     # system matrix switch this off
     _multichannel_dict_ok = True
+    # dimN = 1 through a unit first axis: the classes whose regulariser has no spatial structure
+    _dim1_ok = False
 
     def __init__(self, D, S, opt=None, dimK=None, dimN=2, device=0, stream=None,
                  reducer=None, resident=False):
@@ -123,8 +125,20 @@ class GenericConvBPDN(admm.ADMMEqual):
         self._resident = bool(resident)
         if opt is None:
             opt = GenericConvBPDN.Options()
+        # dimN = 1 (signals, sporco/cnvrep.py:33-198): the two-dimensional machinery on arrays with a
+        # unit first axis -- a length-1 transform is the identity, so every sum and transform is
+        # the one-dimensional one; the public arrays (X / Y / U, solve(), getcoef(), reconstruct())
+        # keep the reference's dimN = 1 shapes (the unit axis is dropped / added at the boundary).
+        self._dim1 = False
+        if dimN == 1 and self._dim1_ok and self._S_dev is None:
+            self._dim1 = True
+            D, S, dimN = np.asarray(D)[np.newaxis], np.asarray(S)[np.newaxis], 2
+            for key in ('L1Weight', 'L21Weight', 'Y0', 'U0'):
+                if key in opt and opt[key] is not None and np.ndim(opt[key]) > 0:
+                    opt[key] = np.asarray(opt[key])[np.newaxis]
         if dimN != 2:
-            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, for ConvBPDN / "
+                                      "ConvBPDNJoint, dimN = 1 (signals)")
         if not (np.isrealobj(D) and (self._S_dev is not None or np.isrealobj(S))):
             raise NotImplementedError("sporco_amd handles real-valued D and S")
         self.real_dtype = True
@@ -173,7 +187,8 @@ class GenericConvBPDN(admm.ADMMEqual):
         var = _lib.VAR_X if self.opt['ReturnX'] else _lib.VAR_Y
         if getattr(self, '_resident', False):
             from ..device import DeviceArray
-            return DeviceArray(self.cri.shpX, self.dtype, ptr=self._dev.device_ptr(var), base=self)
+            shp = self.cri.shpX[1:] if getattr(self, '_dim1', False) else self.cri.shpX
+            return DeviceArray(shp, self.dtype, ptr=self._dev.device_ptr(var), base=self)
         return self._fetch(var)
 
     # -- device plumbing --------------------------------------------------------
@@ -198,13 +213,18 @@ class GenericConvBPDN(admm.ADMMEqual):
             a = self._dev.download(var)
             if var == _lib.VAR_U and self._u_scale != 1.0:
                 a *= a.dtype.type(self._u_scale)
+            if getattr(self, '_dim1', False) and a.ndim >= 2 and a.shape[0] == 1:
+                a = a[0]       # (dimN = 1: the unit axis stays inside)
             self._cache[var] = a
         return self._cache[var]
 
     def _store(self, var, value):
         if value is None:      # ADMM.__init__ convention `self.X = None`
             return
-        self._dev.upload(var, np.asarray(value))
+        value = np.asarray(value)
+        if getattr(self, '_dim1', False) and value.ndim == len(self.cri.shpX) - 1:
+            value = value[np.newaxis]
+        self._dev.upload(var, value)
         if var == _lib.VAR_U:
             self._u_scale = 1.0
         self._touch(var)
@@ -251,7 +271,10 @@ class GenericConvBPDN(admm.ADMMEqual):
         """Set the dictionary (internal layout, support (dH, dW) <= (H, W)):
         Df and the Sherman-Morrison denominators are rebuilt on device."""
         if D is not None:
-            self.D = np.asarray(D, dtype=self.dtype)
+            D = np.asarray(D, dtype=self.dtype)
+            if getattr(self, '_dim1', False) and D.ndim == len(self.cri.shpD) - 1:
+                D = D[np.newaxis]
+            self.D = D
         self._dev.set_dict(self.D)
         self._touch(_lib.VAR_DF)
         self.c = None
@@ -553,10 +576,14 @@ class GenericConvBPDN(admm.ADMMEqual):
         if X is None:
             var = _lib.VAR_Y
         else:
-            self._dev.upload(_lib.VAR_AX, np.asarray(X, dtype=self.dtype))
+            X = np.asarray(X, dtype=self.dtype)
+            if getattr(self, '_dim1', False) and X.ndim == len(self.cri.shpX) - 1:
+                X = X[np.newaxis]
+            self._dev.upload(_lib.VAR_AX, X)
             self._touch(_lib.VAR_AX)
             var = _lib.VAR_AX
-        return self._dev.reconstruct(var)[..., 0]
+        r = self._dev.reconstruct(var)[..., 0]
+        return r[0] if getattr(self, '_dim1', False) else r
 
     # -- per-kernel timing ---------------------------------------------------------------------
     def profile(self, enable=True):
@@ -573,6 +600,9 @@ class ConvBPDN(GenericConvBPDN):
     IterationStats fields: ``Iter, ObjFun, DFid, RegL1, PrimalRsdl, DualRsdl,
     EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
     """
+
+    _dim1_ok = True
+
 
     class Options(GenericConvBPDN.Options):
         """Adds ``L1Weight`` (cbpdn.py:494-495)."""
@@ -743,6 +773,9 @@ class ConvBPDNGradReg(ConvBPDN):
     DualRsdl, EpsPrimal, EpsDual, Rho, XSlvRelRes, Time``.
     """
 
+    _dim1_ok = False     # (its gradient term has a spatial structure: dimN = 2 only)
+
+
     _multichannel_dict_ok = True
 
     class Options(ConvBPDN.Options):
@@ -825,6 +858,9 @@ class ConvBPDNMaskDcpl(ConvBPDN):
     EpsDual, Rho, XSlvRelRes, Time``.  Multi-channel dictionaries (``Cd > 1``): block 0 keeps the
     signal's channels and is swapped onto the filter axis for ``Y`` / ``U`` (cbpdn.py:1688-1722).
     """
+
+    _dim1_ok = False
+
 
     _multichannel_dict_ok = True    # (X-step by linalg.solvemdbi_ism with rho = 1, cbpdn.py:1621-1626)
     _fused_base = None

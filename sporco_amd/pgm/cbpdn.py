@@ -30,6 +30,9 @@ class ConvBPDN(pgm.PGMDFT):
     r"""Minimise (1/2)||sum_m d_m * x_m - s||_2^2 + lambda sum_m ||x_m||_1 by
     accelerated proximal gradient."""
 
+    _dim1_ok = True
+
+
     class Options(pgm.PGMDFT.Options):
         """Adds ``NonNegCoef``, ``NoBndryCross``, ``L1Weight``; default ``L`` 500
         (sporco/pgm/cbpdn.py:112-118)."""
@@ -65,8 +68,17 @@ class ConvBPDN(pgm.PGMDFT):
         self._reducer = reducer
         if opt is None:
             opt = ConvBPDN.Options()
+        # dimN = 1 (signals): the two-dimensional machinery on arrays with a unit first axis, the
+        # public arrays in the reference's dimN = 1 shapes (see admm.cbpdn.GenericConvBPDN)
+        self._dim1 = False
+        if dimN == 1 and type(self)._dim1_ok:
+            self._dim1 = True
+            D, S, dimN = np.asarray(D)[np.newaxis], np.asarray(S)[np.newaxis], 2
+            if np.ndim(opt['L1Weight']) > 0:
+                opt['L1Weight'] = np.asarray(opt['L1Weight'])[np.newaxis]
         if dimN != 2:
-            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, for ConvBPDN, "
+                                      "dimN = 1 (signals)")
         if not (np.isrealobj(D) and np.isrealobj(S)):
             raise NotImplementedError("sporco_amd handles real-valued D and S")
         if not hasattr(self, 'cri'):
@@ -102,13 +114,19 @@ class ConvBPDN(pgm.PGMDFT):
 
     def _fetch(self, var):
         if var not in self._cache:
-            self._cache[var] = self.dev.download(var)
+            a = self.dev.download(var)
+            if getattr(self, '_dim1', False) and a.ndim >= 2 and a.shape[0] == 1:
+                a = a[0]
+            self._cache[var] = a
         return self._cache[var]
 
     def _store(self, var, value):
         if value is None:
             return
-        self.dev.upload(var, np.asarray(value))
+        value = np.asarray(value)
+        if getattr(self, '_dim1', False) and value.ndim == 4:
+            value = value[np.newaxis]
+        self.dev.upload(var, value)
         self.invalidate(var)
 
     def _upload_weights(self):
@@ -155,7 +173,10 @@ class ConvBPDN(pgm.PGMDFT):
     # -- dictionary / coefficients ------------------------------------------------------
     def setdict(self, D=None):
         if D is not None:
-            self.D = np.asarray(D, dtype=self.dtype)
+            D = np.asarray(D, dtype=self.dtype)
+            if getattr(self, '_dim1', False) and D.ndim == len(self.cri.shpD) - 1:
+                D = D[np.newaxis]
+            self.D = D
         self.dev.set_dict(self.D)
         self._cache.pop(_lib.VAR_DF, None)
         self._fcache.clear()
@@ -430,9 +451,13 @@ class ConvBPDN(pgm.PGMDFT):
         if X is None:
             var = _lib.VAR_X
         else:
-            self.dev.upload(_lib.VAR_AX, np.asarray(X, dtype=self.dtype))
+            X = np.asarray(X, dtype=self.dtype)
+            if getattr(self, '_dim1', False) and X.ndim == 4:
+                X = X[np.newaxis]
+            self.dev.upload(_lib.VAR_AX, X)
             var = _lib.VAR_AX
-        return self.dev.reconstruct(var)[..., 0]
+        r = self.dev.reconstruct(var)[..., 0]
+        return r[0] if getattr(self, '_dim1', False) else r
 
 
 class ConvBPDNMask(ConvBPDN):
@@ -441,6 +466,9 @@ class ConvBPDNMask(ConvBPDN):
     sporco/pgm/cbpdn.py:387-506).  The gradient takes the residual to the spatial domain,
     weights it by W^2 and brings it back (``sporco_amd_csc_masked_grad``); everything else is
     the unmasked solver."""
+
+    _dim1_ok = False
+
 
     def __init__(self, D, S, lmbda, W=None, opt=None, dimK=None, dimN=2, **backend):
         super(ConvBPDNMask, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN, **backend)

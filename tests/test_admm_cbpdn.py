@@ -436,3 +436,49 @@ def test_complex_input_outside_admm_convbpdn_is_refused(backend):
                  lambda: pc.ConvBPDN(D, S + 1j * S, 0.1)):
         with pytest.raises(NotImplementedError):
             make()
+
+
+@pytest.mark.parametrize('name', ['admm_dim1_single_f64', 'admm_dim1_multi_f64', 'admm_dim1_joint_f64',
+                                  'pgm_dim1_f64'])
+def test_dimN1_signals(backend, name):
+    """dimN = 1 (sporco/cnvrep.py:33-198; constructor contract sporco/admm/cbpdn.py:175,
+    pgm/cbpdn.py:100): one-dimensional signals against runs of the unmodified reference -- a single
+    signal, three signals (dimK = 1, NonNegCoef), three channels with the joint l2,1 term, FISTA
+    with backtracking -- in the reference's own dimN = 1 array shapes."""
+    from sporco_amd.admm import cbpdn
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    g = load_golden(name)
+    if name.startswith('pgm'):
+        opt = pc.ConvBPDN.Options({'MaxMainIter': 30, 'L': 50.0, 'Backtrack': BacktrackStandard()})
+        b = pc.ConvBPDN(g['D'], g['S'], 0.1, opt, dimK=1, dimN=1)
+        X = b.solve()
+        assert X.shape == g['X'].shape and rel_l2(X, g['X']) < 1e-9
+        assert rel_l2(b.reconstruct(), g['recon']) < 1e-9
+        its = b.getitstat()
+        for f in ('ObjFun', 'Rsdl', 'L', 'IterBTrack'):
+            assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-9, f
+        return
+    dimK = None if 'single' in name else (1 if 'multi' in name else 0)
+    if 'joint' in name:
+        b = cbpdn.ConvBPDNJoint(g['D'], g['S'], float(g['lmbda']), float(g['mu']),
+                                cbpdn.ConvBPDNJoint.Options({'MaxMainIter': 25}), dimK=dimK, dimN=1)
+    else:
+        optd = {'MaxMainIter': 30, 'NonNegCoef': 'multi' in name}
+        b = cbpdn.ConvBPDN(g['D'], g['S'], float(g['lmbda']), cbpdn.ConvBPDN.Options(optd), dimK=dimK, dimN=1)
+    Y = b.solve()
+    assert Y.shape == g['Y'].shape and rel_l2(Y, g['Y']) < 1e-9
+    assert rel_l2(b.X, g['X']) < 1e-9 and rel_l2(b.U, g['U']) < 1e-9
+    r = b.reconstruct()
+    assert r.shape == g['recon'].shape and rel_l2(r, g['recon']) < 1e-9
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-9, f
+    # float32 input: the reference's arithmetic for float32 signals, within the float32 bar
+    b32 = type(b)(*([g['D'].astype(np.float32), g['S'].astype(np.float32), float(g['lmbda'])] +
+                    ([float(g['mu'])] if 'joint' in name else [])),
+                  type(b).Options({'MaxMainIter': 25 if 'joint' in name else 30,
+                                   'NonNegCoef': 'multi' in name}), dimK=dimK, dimN=1)
+    assert rel_l2(b32.solve(), g['Y']) < 1e-4
+    with pytest.raises(NotImplementedError):
+        cbpdn.ConvBPDN(np.zeros((3, 3, 3, 2)), np.zeros((8, 8, 8)), 0.1, dimN=3)
