@@ -42,7 +42,8 @@
  *   SPORCO_AMD_MD_GENERIC=1     ConvBPDNMaskDcpl on the generic chain
  *   SPORCO_AMD_CNS_GENERIC=1    consensus dictionary update on the generic chain
  *   SPORCO_AMD_CG_HOST=1        CG dictionary update: the scalars read back every iteration
- *   SPORCO_AMD_PLACEMENT=0      no placement search for concurrently written arrays
+ *   SPORCO_AMD_PLACEMENT=0|force   no placement search for concurrently written arrays / the search
+ *                               (and the striped column output) also for small arrays -- tests
  *                               (sporco_amd_csc_placement_report)
  *   SPORCO_AMD_RCCL_LIB=path    the RCCL library to open (default librccl.so.1, librccl.so)
  * Outside the library: SPORCO_AMD_LIBRARY=path and SPORCO_AMD_SHARE_TORCH_RUNTIME=0 (the Python

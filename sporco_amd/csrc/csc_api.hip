@@ -32,7 +32,7 @@ const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_
 // early-stop tests) and sporco_amd_csc_admm_run reads at its entry.
 struct Switches {
     bool unfused, old_rows, no_pad, no_vform, no_speculation, no_cols_sm, md_generic, cns_generic, cg_host,
-        placement_off;
+        placement_off, placement_force;
     int persist;              // SPORCO_AMD_PERSIST: -1 unset (the hint decides), 0, 1
     int cols_sm_force_slab;   // SPORCO_AMD_COLS_SM_FORCE_SLAB: 0 unset
     static bool set(const char *name) { return std::getenv(name) != nullptr; }
@@ -49,6 +49,7 @@ struct Switches {
         s.cg_host = set("SPORCO_AMD_CG_HOST");
         const char *e = std::getenv("SPORCO_AMD_PLACEMENT");
         s.placement_off = e && e[0] == '0';
+        s.placement_force = e && e[0] == 'f';      // "force": also for small arrays (tests)
         e = std::getenv("SPORCO_AMD_PERSIST");
         s.persist = e ? (e[0] == '1' ? 1 : 0) : -1;
         e = std::getenv("SPORCO_AMD_COLS_SM_FORCE_SLAB");
@@ -372,6 +373,8 @@ template <typename T> struct Csc : CscBase {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(st);
         place_release_spares();
+        big_free(cols_out[0]);
+        big_free(cols_out[1]);
         for (hipEvent_t e : place_ev)
             if (e) (void)hipEventDestroy(e);
         for (auto &v : vars) big_free(v);
@@ -475,6 +478,22 @@ template <typename T> struct Csc : CscBase {
     // the second pair of iterate buffers (the (Y, U) ping-pong, and the two V buffers of the
     // single-array state): each clear of the spectrum buffer it is written together with by the
     // emitting row epilogue (api_placement.inc)
+    // Striped output of the column pass (csc_fused.h FusedColsArgs::out_even / out_odd): two
+    // half-sized spectra in different regions of the device memory, for the fused iteration of large
+    // single-slab problems (the arrays the placement search serves).
+    cx<T> *cols_out[2] = {nullptr, nullptr};
+    bool cols_striped() const { return cols_out[0] != nullptr; }
+    void alloc_cols_out() {
+        if (cols_out[0] || !std::is_same<T, float>::value || !fused || fused_slabs || tail_mode || Ks != K || !rows_ok)
+            return;
+        const size_t plane = sizeof(cx<T>) * (size_t)CN * H * K;
+        const size_t be = plane * (size_t)((Wf + 1) / 2), bo = plane * (size_t)(Wf / 2);
+        if (!placement_on(be)) return;
+        void *p0 = nullptr;
+        big_alloc(&p0, be);
+        cols_out[0] = static_cast<cx<T> *>(p0);
+        cols_out[1] = static_cast<cx<T> *>(place_alloc(bo, {{p0, be}}, "cols_out_odd"));
+    }
     void alloc_alt_pair() {
         if (y_alt) return;
         (void)var_ptr(SPORCO_AMD_VAR_XF);
@@ -487,6 +506,11 @@ template <typename T> struct Csc : CscBase {
         const size_t tb = var_alloc_bytes(SPORCO_AMD_VAR_XF), nb = sizeof(T) * (size_t)E;
         y_alt = static_cast<T *>(place_alloc(nb, {{t, tb}}, "V0"));
         u_alt = static_cast<T *>(place_alloc(nb, {{t, tb}}, "V1"));
+        // (the spectrum buffer could not be moved clear of Y / U -- a long region: they move instead,
+        // to where the search has arrived by now; no-ops when they are clear already)
+        place_var(SPORCO_AMD_VAR_Y, {SPORCO_AMD_VAR_XF}, "Y");
+        place_var(SPORCO_AMD_VAR_U, {SPORCO_AMD_VAR_XF}, "U");
+        alloc_cols_out();      // (after the decisions above: its candidates must not disturb them)
     }
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;

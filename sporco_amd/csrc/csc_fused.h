@@ -65,6 +65,14 @@ template <typename T> struct FusedColsArgs {
     // device-driven solve (csc_kernels.h AdmmCtl): rho is ctl->rho_f, and the launch returns at
     // once when ctl->stop is set
     const AdmmCtl *ctl = nullptr;
+    // Striped output (K <= 64 kernel; both null: the tile is stored where it was loaded).  The
+    // tile (wf, cn) goes to out_even / out_odd by the parity of wf, at tile index (wf >> 1) CN + cn
+    // of that buffer -- two half-sized spectra that the caller has placed in DIFFERENT regions of
+    // the device memory: one array takes streaming stores at ~4.5 TB/s on the MI355X, two in
+    // different regions at ~6.3 TB/s together (profiles/r05_placement_notes.md), and this
+    // kernel's store phases (half of its time) run at the single-region rate when it rewrites
+    // `t` in place.  The reader (csc_rows.h RowsPostArgs::t_odd) takes the planes from the two.
+    cx<T> *out_even = nullptr, *out_odd = nullptr;
     const T *g1t = nullptr;
     T *g1t_out = nullptr;
     const T *ghh = nullptr, *ghw = nullptr, *wg = nullptr;

@@ -73,6 +73,9 @@ template <typename T> struct RowsFwdArgs {
 
 template <typename T> struct RowsPostArgs {
     const cx<T> *t;    // in: tile-major column-inverse-transformed solution, unnormalised
+    const cx<T> *t_odd = nullptr;   // the column pass stored its output striped (csc_fused.h
+                       // FusedColsArgs::out_even / out_odd): t holds the even row-frequency planes,
+                       // t_odd the odd ones, plane wf at index wf >> 1 of its buffer
     const cx<T> *twW;  // exp(-2 pi i t / W), t in [0, W)
     const cx<T> *twA;  // rows_twiddles table (only read when t_next is set)
     cx<T> *t_next;     // optional: also emit rfft_W(Y' - U') tile-major, i.e. the next

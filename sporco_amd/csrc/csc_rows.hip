@@ -195,10 +195,11 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 // Spectral side -> spatial side: the bins f <= W/2 of t[f][cn][h][k..k+1] are loaded,
 // the packed spectrum Z is rebuilt, and v[n1] receives the unnormalised inverse
 // transform at x = NW n1 + w: (re, im) = (filter k, filter k+1).
+// (t_odd: the planes arrive in two buffers, csc_rows.h RowsPostArgs::t_odd)
 template <int NW, bool COH = false>
 __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW, const cf *t, int CN,
                                                     int H, int K, int cn, int k, int h, bool pv, int w,
-                                                    int lane, f2 *L, int &token) {
+                                                    int lane, f2 *L, int &token, const cf *t_odd = nullptr) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
     constexpr int NG = 2;
     constexpr int LPG = J / NG;
@@ -207,14 +208,17 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
     // ---- spectral side: load the bins f <= W/2 of this thread's lines, rebuild Z -------
     const int64_t tline = (int64_t)CN * H * K;
     const cf *Tl = t + (int64_t)cn * H * K + (int64_t)h * K + k;
+    // striped planes: plane f at index f >> 1 of the buffer of its parity (wave-uniform arithmetic)
+    const int64_t odd_delta = t_odd ? t_odd - t : 0;
     auto load_unit = [&](int f) {
         cf2 ab;
         ab.a = zero;
         ab.b = zero;
         if (pv) {
             float q[4];
-            if constexpr (COH) sa_coh_load4(reinterpret_cast<const float *>(Tl + (int64_t)f * tline), q);
-            else sa_stream_load4(reinterpret_cast<const float *>(Tl + (int64_t)f * tline), q);
+            const int64_t poff = t_odd ? (int64_t)(f >> 1) * tline + ((f & 1) ? odd_delta : 0) : (int64_t)f * tline;
+            if constexpr (COH) sa_coh_load4(reinterpret_cast<const float *>(Tl + poff), q);
+            else sa_stream_load4(reinterpret_cast<const float *>(Tl + poff), q);
             ab.a = mk<float>(q[0], q[1]);
             ab.b = mk<float>(q[2], q[3]);
         }
@@ -521,7 +525,8 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     int token = 0;
 
     cf v[N1];
-    spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L, token);
+    spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L, token,
+                                 a->t_odd);
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a->P;

@@ -134,6 +134,46 @@ __global__ void __launch_bounds__(256) copy22_kernel(const float4 *a_, const flo
         __builtin_nontemporal_store(x - y, d + i);
     }
 }
+// Persistent 16-wave workgroups that load a 256 KiB tile (the column kernel's access pattern: wave w,
+// lane k, rows h = 16 h1 + w, 512-byte rows), spend `gap` spins of barrier-locked arithmetic, and
+// store it -- to the same place (out0 == out1 == in), or to out0 / out1 by the parity of the tile.
+typedef __amdgpu_buffer_rsrc_t PBuf;
+typedef float pf2 __attribute__((ext_vector_type(2)));
+typedef decltype(__builtin_amdgcn_raw_buffer_load_b64(PBuf(), 0, 0, 0)) pb64;
+__global__ void __launch_bounds__(1024) tile_copy_kernel(float *in, float *out0, float *out1, int ntiles, int gap,
+                                                         float *sink) {
+    extern __shared__ float lds_dummy[];     // 128 KiB requested: one workgroup per CU, as the real kernel
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float acc[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        PBuf bi = __builtin_amdgcn_make_buffer_rsrc(in + (int64_t)tile * 65536, 0, 262144, 0x00020000);
+        // striped output: even tiles -> out0[tile / 2], odd -> out1[tile / 2]; in place when out0 == in
+        float *ob = out0 == in ? in + (int64_t)tile * 65536
+                               : ((tile & 1) ? out1 : out0) + (int64_t)(out0 == out1 ? tile : tile >> 1) * 65536;
+        PBuf bo = __builtin_amdgcn_make_buffer_rsrc(ob, 0, 262144, 0x00020000);
+        pf2 v[32];
+        const int vo = (w * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            v[i] = __builtin_bit_cast(pf2, __builtin_amdgcn_raw_buffer_load_b64(bi, vo, i * 16 * 512, 2));
+        if (gap) {
+            acc[0] += v[0].x + v[31].y;
+            __syncthreads();
+            for (int i = 0; i < gap; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = acc[j] * 1.0001f + 0.5f;
+            }
+            __syncthreads();
+            v[0].x += acc[1] * 1e-30f;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            v[i].x += 1.0f;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(pb64, v[i]), bo, vo, i * 16 * 512, 2);
+        }
+    }
+    if (acc[0] == 123.456f) sink[0] = acc[0] + acc[7];
+}
 template <typename F> static float time_launch(F &&f, int reps) {
     f();
     CK(hipEventRecord(ev0, st));
@@ -325,6 +365,46 @@ int main(int argc, char **argv) {
                             (double)off / MiB, 2.0 * n16 * 16 / ms * 1e-6);
             }
             CK(hipFree(base));
+        } else if (part == "stripe") {
+            // one write stream into one region, or spread over two?  (the column kernel rewrites the
+            // spectrum in place: its store phases run at the single-region write rate)
+            const int M = std::getenv("PROBE_M") ? std::atoi(std::getenv("PROBE_M")) : 14;
+            std::vector<char *> base(M), al(M);
+            for (int i = 0; i < M; ++i) {
+                CK(hipMalloc((void **)&base[i], TB + 64 * MiB));
+                al[i] = reinterpret_cast<char *>(up(reinterpret_cast<size_t>(base[i]), 64 * MiB));
+            }
+            const int64_t n16 = VB / 16;
+            auto rate = [&](int a, int b) {
+                const float ms = time_launch([&] { launch_place_probe(st, al[a], al[b], n16, n16, 0, 0, false, false); }, reps);
+                return 2.0 * n16 * 16 / ms * 1e-6;
+            };
+            // classify against buffer 0
+            int same = -1, other = -1;
+            double rs = 1e30, ro = 0;
+            for (int j = 1; j < M; ++j) {
+                const double r = rate(0, j);
+                if (r < rs) { rs = r; same = j; }
+                if (r > ro) { ro = r; other = j; }
+            }
+            std::printf("{\"part\": \"stripe\", \"same_region_buffer\": %d, \"rate\": %.0f, \"other_region_buffer\": %d, \"rate_other\": %.0f}\n",
+                        same, rs, other, ro);
+            CK(hipFuncSetAttribute((const void *)&tile_copy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            float *sink;
+            CK(hipMalloc((void **)&sink, 64));
+            const int ntiles = 8224;
+            auto tc = [&](float *in, float *o0, float *o1, int gap) {
+                const float ms = time_launch([&] { hipLaunchKernelGGL(tile_copy_kernel, dim3(256), dim3(1024), 131072, st, in, o0, o1, ntiles, gap, sink); }, reps);
+                return ms;
+            };
+            float *A = reinterpret_cast<float *>(al[0]), *A2 = reinterpret_cast<float *>(al[same]), *B = reinterpret_cast<float *>(al[other]);
+            for (int gap : {0, 300, 600, 900, 1500}) {
+                std::printf("{\"part\": \"stripe\", \"gap\": %d, \"in_place_ms\": %.4f, \"out_same_region_ms\": %.4f, "
+                            "\"out_other_region_ms\": %.4f, \"out_striped_same_plus_other_ms\": %.4f, \"out_striped_same_same_ms\": %.4f}\n",
+                            gap, tc(A, A, A, gap), tc(A, A2, A2, gap), tc(A, B, B, gap), tc(A, A2, B, gap),
+                            tc(A, A2, A2 + (size_t)4112 * 65536, gap));
+            }
+            for (int i = 0; i < M; ++i) CK(hipFree(base[i]));
         } else if (part == "map") {
             // G chunks of 1 GiB in allocation order, each classified by the two-stream fill against
             // chunk 0 (and against the first chunk found to differ from chunk 0): the region map
