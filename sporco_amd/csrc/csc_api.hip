@@ -24,7 +24,8 @@ const char *kProfNames[PS_COUNT] = {"fft_r2c_rows",     "fft_c2c_cols_fwd", "sm_
                                            "pgm_grad_ifft",    "pgm_rows_prox",    "pgm_fft_momentum",
                                            "finalize",         "pgm_elementwise",  "other",
                                            "admm_persist_run",
-                                    "setcoef_rows",     "setcoef_cols",     "ccmod_grad_tiled"};
+                                    "setcoef_rows",     "setcoef_cols",     "ccmod_grad_tiled",
+                                    "fft_c2r_vpost",    "fft_c2r_vpost_emit"};
 
 // Environment switches (include/sporco_amd.h lists them; tests and measurements, none is needed in
 // normal use).  Read ONCE, when a handle is made -- except SPORCO_AMD_HOST_LOOP and
@@ -373,6 +374,8 @@ template <typename T> struct Csc : CscBase {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(st);
         place_release_spares();
+        big_free(gemit);
+        if (part_vpost) (void)hipFree(part_vpost);
         big_free(cols_out[0]);
         big_free(cols_out[1]);
         for (hipEvent_t e : place_ev)

@@ -82,6 +82,8 @@ enum ProfSlot {
     PS_SETCOEF_ROWS,            // dictionary update: row / column transform of the coefficient maps
     PS_SETCOEF_COLS,            // into the tile-major spectrum Zf (ccmod_setcoef)
     PS_CCMOD_GRAD,              // ... and the gradient over tiles (ccmod_grad_tiled + group sum)
+    PS_C2R_VPOST,               // generic chain: c2r row pass + epilogue of the single-array state in one
+    PS_C2R_VPOST_EMIT,          // kernel (fft.h fft_c2r_vpost), ... + the next iteration's row spectrum
     PS_COUNT
 };
 extern const char *kProfNames[PS_COUNT];

@@ -67,6 +67,22 @@ void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64
              int64_t P, int64_t in_outer, int64_t in_line, int64_t out_outer, int64_t out_line,
              T scale, int64_t grp = 0, int64_t grp_stride = 0);
 
+// The same pass fused with the ADMM epilogue of the single-array state (csc_kernels.h PostParams with
+// v_in / v_out; csc_post_elem.h: relax_AX, ystep, ustep and the residual / objective sums of
+// admm.py:877-885, cbpdn.py:614-620, admm.py:434-486; plain l1 term): X of an (n_outer, n, P) array is
+// formed in the workgroup and never stored, V is read and V' written, every workgroup writes 8 partial
+// sums (returns how many; fft_c2r_vpost_blocks: the same number, for sizing `partials`) -- and, when
+// emit_out is set, Y' - U' is transformed forward again and stored there in the layout fft_r2c writes:
+// the next iteration's row spectrum for an unchanged rho.  Four X-sized passes (three without the
+// emission) in place of the c2r pass, the epilogue kernel and the next r2c pass (seven).  P even.
+template <typename T> struct PostParams;
+template <typename T> bool fft_c2r_vpost_supported(int64_t P);
+template <typename T> int64_t fft_c2r_vpost_blocks(const FftPlan &plan, int64_t n_outer, int64_t P);
+template <typename T>
+int64_t fft_c2r_vpost(hipStream_t st, const FftPlan &plan, const cx<T> *in, int64_t n_outer, int64_t P,
+                      int64_t in_outer, int64_t in_line, T scale, const PostParams<T> &post, cx<T> *emit_out,
+                      int64_t emit_outer, int64_t emit_line, double *partials);
+
 // out(H, W/2+1, P) = rfftn(in [- s2*in2], axes=(0,1)) for real in(H, W, P).
 template <typename T>
 void rfft2(hipStream_t st, const FftPlan &planW, const FftPlan &planH, const T *in, const T *in2,

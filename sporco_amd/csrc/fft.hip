@@ -47,6 +47,16 @@ template <typename T> struct LineArgs {
     // lives at (p / grp) * grp_stride + p % grp instead of p.  This is how the row
     // transforms write / read the tile-major layout of csc_fused.h.
     int64_t grp, grp_stride;
+    // C2R fused with the ADMM epilogue in the single-array state (FUSE > 0; fft.h fft_c2r_vpost): the
+    // transform's output is X of element (o, i, p) of an (n_outer, n, P) array and never leaves the
+    // workgroup; post.v_in / post.v_out carry the iterate (vthr / vnonneg below derive Y, U from
+    // it), every workgroup writes 8 partial sums, and with FUSE == 2 the line Y' - U' is transformed
+    // forward again and stored as the next iteration's row spectrum (emit_*).
+    PostParams<T> post;
+    double *partials;
+    int64_t postP;
+    cx<T> *emit_out;
+    int64_t emit_outer, emit_line;
     // R2C only: `in` is the ADMM iterate in its single-array form V = AX + U (csc_rows.h): the line
     // transformed is Y - s2 U with Y = prox_l1(V; vthr) (+ NonNegCoef), U = V - Y, derived per
     // element as the epilogue derived them (csc_post_elem.h admm_post_elem)
@@ -292,7 +302,10 @@ __device__ __forceinline__ void stockham_pass_r(int R, const cx<T> *src, cx<T> *
     }
 }
 
-template <typename T, int MODE, bool PACK>
+// FUSE (MODE_C2R with packed columns only): 0 = plain store; 1 = the ADMM epilogue of the
+// single-array state on every output element instead (csc_post_elem.h; plain l1 term); 2 = ... and
+// the forward transform of Y' - U' after it (the next iteration's fft_r2c for an unchanged rho).
+template <typename T, int MODE, bool PACK, int FUSE = 0>
 __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
     const int n = a.n, cols = a.cols;
     cx<T> *buf0 = dyn_lds<cx<T>>();
@@ -392,6 +405,57 @@ __global__ void __launch_bounds__(1024) fft_lines_kernel(const LineArgs<T> a) {
         Ns *= R;
     }
 
+    if constexpr (FUSE != 0) {
+        static_assert(MODE == MODE_C2R && PACK, "the fused epilogue belongs to the packed c2r pass");
+        double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (valid) {
+            const int64_t P = a.postP;
+            for (int i = lane; i < n; i += lpc) {
+                const cx<T> z = src[i * cols + col];
+                const int64_t idx = (o * n + i) * P + 2 * c;
+                const T x0 = z.re * a.scale, x1 = z.im * a.scale;
+                // (Y, U) of the iterate from V, as admm_post_kernel derives them
+                const cx<T> vv = *reinterpret_cast<const cx<T> *>(a.post.v_in + idx);
+                T y0 = soft(vv.re, a.post.thr_prev), y1 = soft(vv.im, a.post.thr_prev);
+                if ((a.post.flags & F_NONNEG) && y0 < T(0)) y0 = T(0);
+                if ((a.post.flags & F_NONNEG) && y1 < T(0)) y1 = T(0);
+                T u0 = vv.re - y0, u1 = vv.im - y1, vn0, vn1;
+                admm_post_elem<T, false>(a.post, idx, P, x0, y0, u0, acc, &vn0);
+                admm_post_elem<T, false>(a.post, idx + 1, P, x1, y1, u1, acc, &vn1);
+                *reinterpret_cast<cx<T> *>(a.post.v_out + idx) = mk<T>(vn0, vn1);
+                // (the line the next fft_r2c would form from V' with s2 = 1: Y' - U')
+                if (FUSE == 2) src[i * cols + col] = mk<T>(y0 - u0, y1 - u1);
+            }
+        }
+        if constexpr (FUSE == 2) {
+            __syncthreads();
+            for (int t = tid; t < n; t += blockDim.x) tw[t].im = -tw[t].im;     // forward twiddles
+            __syncthreads();
+            Ns = 1;
+            for (int p = 0; p < a.nrad; ++p) {
+                stockham_pass_r<T, false, false>(a.radix[p], src, dst, tw, n, Ns, cols, col, lane, lpc);
+                __syncthreads();
+                cx<T> *t = src;
+                src = dst;
+                dst = t;
+                Ns *= a.radix[p];
+            }
+            if (valid) {
+                for (int f = lane; f < a.nfreq; f += lpc) {
+                    const cx<T> zf = src[f * cols + col];
+                    const cx<T> zn = src[(f == 0 ? 0 : n - f) * cols + col];
+                    cx2<T> ab;
+                    ab.a = mk<T>(T(0.5) * (zf.re + zn.re), T(0.5) * (zf.im - zn.im));
+                    ab.b = mk<T>(T(0.5) * (zf.im + zn.im), T(0.5) * (zn.re - zf.re));
+                    *reinterpret_cast<cx2<T> *>(a.emit_out + o * a.emit_outer + f * a.emit_line + 2 * c) = ab;
+                }
+            }
+        }
+        __syncthreads();      // the transform buffers become the reduction scratch
+        block_sum_store<8>(acc, reinterpret_cast<double *>(buf0),
+                           a.partials + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8);
+        return;
+    }
     // ---------------- store ----------------
     if (!valid) return;
     if (MODE == MODE_C2C) {
@@ -904,11 +968,11 @@ template <typename T> Cfg pick_cfg(int n, int64_t ncols) {
     return c;
 }
 
-template <typename T, int MODE, bool PACK>
+template <typename T, int MODE, bool PACK, int FUSE = 0>
 int64_t launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_t n_outer) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK>),
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_lines_kernel<T, MODE, PACK, FUSE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
     }
     if (a.ncols <= 0 || n_outer <= 0) return 0;
@@ -921,7 +985,7 @@ int64_t launch_lines(hipStream_t st, const FftPlan &plan, LineArgs<T> &a, int64_
     a.tw = plan.tw<T>();
     SA_REQUIRE(n_outer <= 65535, "too many outer slices for one launch");
     const dim3 grid((unsigned)ceil_div(a.ncols, cfg.cols), (unsigned)n_outer, 1);
-    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK>), grid, dim3(cfg.threads), cfg.lds, st, a);
+    hipLaunchKernelGGL((fft_lines_kernel<T, MODE, PACK, FUSE>), grid, dim3(cfg.threads), cfg.lds, st, a);
     SA_HIP(hipGetLastError());
     return (int64_t)grid.x * grid.y;
 }
@@ -1019,6 +1083,41 @@ void fft_c2r(hipStream_t st, const FftPlan &plan, const cx<T> *in, T *out, int64
         a.out_line = out_line;
         launch_lines<T, MODE_C2R, false>(st, plan, a, n_outer);
     }
+}
+
+template <typename T> bool fft_c2r_vpost_supported(int64_t P) { return P % 2 == 0; }
+
+template <typename T>
+int64_t fft_c2r_vpost_blocks(const FftPlan &plan, int64_t n_outer, int64_t P) {
+    return ceil_div(P / 2, pick_cfg<T>(plan.n, P / 2).cols) * n_outer;
+}
+
+template <typename T>
+int64_t fft_c2r_vpost(hipStream_t st, const FftPlan &plan, const cx<T> *in, int64_t n_outer, int64_t P,
+                      int64_t in_outer, int64_t in_line, T scale, const PostParams<T> &post, cx<T> *emit_out,
+                      int64_t emit_outer, int64_t emit_line, double *partials) {
+    SA_REQUIRE(fft_c2r_vpost_supported<T>(P) && in_outer % 2 == 0 && in_line % 2 == 0,
+               "the fused row pass needs an even number of columns");
+    SA_REQUIRE(post.v_in && post.v_out && !(post.flags & (F_JOINT | F_NOBNDRY)) && !post.wl1.ptr && !post.ams.ptr,
+               "the fused row pass serves the single-array state with a plain l1 term");
+    LineArgs<T> a{};
+    a.in = in;
+    a.in2 = nullptr;
+    a.out = nullptr;
+    a.s2 = T(0);
+    a.scale = scale;
+    a.inverse = 1;
+    a.in_outer = in_outer;
+    a.in_line = in_line;
+    a.post = post;
+    a.partials = partials;
+    a.postP = P;
+    a.emit_out = emit_out;
+    a.emit_outer = emit_outer;
+    a.emit_line = emit_line;
+    a.ncols = P / 2;
+    return emit_out ? launch_lines<T, MODE_C2R, true, 2>(st, plan, a, n_outer)
+                    : launch_lines<T, MODE_C2R, true, 1>(st, plan, a, n_outer);
 }
 
 template <typename T>
@@ -1154,6 +1253,10 @@ int64_t fft_cols_sm(hipStream_t st, const FftPlan &plan, cx<T> *xf, const cx<T> 
                              int64_t, int64_t, const VformIn<T> *);                              \
     template void fft_c2r<T>(hipStream_t, const FftPlan &, const cx<T> *, T *, int64_t, int64_t,  \
                              int64_t, int64_t, int64_t, int64_t, T, int64_t, int64_t);           \
+    template bool fft_c2r_vpost_supported<T>(int64_t);                                           \
+    template int64_t fft_c2r_vpost_blocks<T>(const FftPlan &, int64_t, int64_t);                 \
+    template int64_t fft_c2r_vpost<T>(hipStream_t, const FftPlan &, const cx<T> *, int64_t, int64_t, int64_t, \
+                                      int64_t, T, const PostParams<T> &, cx<T> *, int64_t, int64_t, double *); \
     template bool fft_cols_sm_supported<T>(const FftPlan &, int, int);                          \
     template int64_t fft_cols_sm<T>(hipStream_t, const FftPlan &, cx<T> *, const cx<T> *,        \
                                     const cx<T> *, const T *, T, int, int, int, int, bool, double *, int); \

@@ -283,9 +283,17 @@ def test_generic_chain_v_form_is_bit_identical_to_the_yu_form(backend, case):
         if o1['k'] >= 3 * calls:
             assert o1['live'] == [1] * calls, (case, o1['k'])
         assert o0['k'] == o1['k']
+        # Element for element the two forms perform the same operations; since round 5 the sums of the
+        # V form come out of the fused row pass (fft.h fft_c2r_vpost), i.e. the same double-precision
+        # terms added in another order, so rho -- formed from them -- may differ in its last bit and
+        # the iterates with it: equal to rounding of the working precision, not bit for bit.
+        # (float64 only: the float32 chain keeps its three kernels and stays bit for bit)
+        tol = 1e-12 if dt == np.float64 else 0.0
         for f in ('Y', 'U', 'X'):
-            assert np.array_equal(o0[f], o1[f]), f
+            assert np.array_equal(o0[f], o1[f]) or rel_l2(o1[f], o0[f]) < tol, f
+        # (the sums of the fused row pass -- fft.h fft_c2r_vpost, round 5 -- are reduced over other
+        # workgroups than the epilogue kernel's: the same double-precision terms in another order)
         for f in o0['stats']:
-            assert np.array_equal(o0['stats'][f], o1['stats'][f], equal_nan=True), f
+            assert np.allclose(o0['stats'][f], o1['stats'][f], rtol=(1e-10 if dt == np.float64 else 0.0), atol=0.0, equal_nan=True), f
     # reading the iterates takes the handle back to the (Y, U) form
     assert b1._dev.query(_lib.QUERY_VFORM_LIVE) == 0
