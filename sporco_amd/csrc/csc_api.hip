@@ -514,6 +514,7 @@ template <typename T> struct Csc : CscBase {
         place_var(SPORCO_AMD_VAR_Y, {SPORCO_AMD_VAR_XF}, "Y");
         place_var(SPORCO_AMD_VAR_U, {SPORCO_AMD_VAR_XF}, "U");
         alloc_cols_out();      // (after the decisions above: its candidates must not disturb them)
+        place_release_spares();   // (what no decision took goes back: up to 8 GiB otherwise idle)
     }
     int query(int what) override {
         if (what == SPORCO_AMD_QUERY_FUSED_COLS) return (fused || fused_slabs || fused_mc) ? 1 : 0;
