@@ -346,8 +346,12 @@ template <typename T> struct Csc : CscBase {
             if (spare_big[i].second >= bytes && spare_big[i].second <= bytes + bytes / 8) {
                 *p = spare_big[i].first;
                 spare_big.erase(spare_big.begin() + i);
+                spare_vs.erase(spare_vs.begin() + i);
                 return;
             }
+        big_alloc_fresh(p, bytes);
+    }
+    void big_alloc_fresh(void **p, size_t bytes) {
         if (bytes >= ((size_t)64 << 20)) {
             const size_t al = (size_t)kAllocAlignMb << 20;
             void *base = nullptr;
