@@ -764,6 +764,8 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-time-to-tol', action='store_true')
     ap.add_argument('--parity-iters', type=int, default=6)
+    ap.add_argument('--steady-steps', type=int, default=100,
+                    help='iterations of the same solver after the timed ones (`steady_state`)')
     ap.add_argument('--parity-only', action='store_true',
                     help='run the parity gate alone and print its JSON (what the main run spawns)')
     args = ap.parse_args()
@@ -920,7 +922,7 @@ def main():
     # in most of the first 20-30 iterations (which invalidates the speculatively emitted row
     # spectra); what a user sees over the hundreds of iterations to tolerance is the rate after
     # it has settled
-    steady_steps = 100
+    steady_steps = max(args.steady_steps, 1)
     b.opt['MaxMainIter'] = steady_steps
     sync_all(b)
     t0s = time.perf_counter()

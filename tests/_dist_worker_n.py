@@ -54,7 +54,7 @@ def main():
     Df = rng.randn(4, 4, 4).astype(np.float32)
     Df /= np.sqrt(np.sum(Df ** 2, axis=(0, 1), keepdims=True))
     Sf = rng.randn(128, 128, n_img).astype(np.float32)
-    opts = {'MaxMainIter': 30, 'RelStopTol': 6e-2}
+    opts = {'MaxMainIter': 24, 'RelStopTol': 8e-2}
     os.environ['SPORCO_AMD_RUN_LAG'] = '3' if rank % 2 else '0'
     red = TorchReducer()
     be = cbpdn.ConvBPDN(Df, shard_images(Sf, rank, world), 0.05, cbpdn.ConvBPDN.Options(opts), reducer=red)
@@ -78,7 +78,7 @@ def main():
     D0 = rng.randn(4, 4, 6)
     Sd = rng.randn(16, 16, n_img)
     for dm in ('pgm', 'cns'):
-        o = {'MaxMainIter': 3, 'AccurateDFid': True}
+        o = {'MaxMainIter': 2, 'AccurateDFid': True}
         runs = [(shard_images(Sd, rank, world), {'reducer': TorchReducer()})]
         if rank == 0:
             runs.append((Sd, {}))

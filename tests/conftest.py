@@ -31,7 +31,7 @@ def _parallel_cpu_run(config):
             getattr(config.option, 'collectonly', False):
         return
     try:
-        n = int(os.environ.get('SPORCO_AMD_TEST_WORKERS', min(6, os.cpu_count() or 1)))
+        n = int(os.environ.get('SPORCO_AMD_TEST_WORKERS', min(8, os.cpu_count() or 1)))
     except ValueError:
         n = 0
     if n < 2:
