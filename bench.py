@@ -33,6 +33,9 @@ traffic in profiles/hbm_traffic_bytes.json) / its HIP-event duration in this run
 HBM peak; the SURVEY.md 8(d) stage-bytes figure is kept beside it as `algorithmic_frac`.
 `cpu_baseline` times the unmodified reference (staged into the git-ignored oracle/_ref by
 build()) in a subprocess on this box's host cores, and the NumPy port as a second leg.
+`roofline.placement` lists where the library put the arrays the dominant kernel writes at the
+same time (sporco_amd_csc_placement_report); `frac_check` states that no `frac`
+of the line exceeds 1 (check_fracs walks the whole line before it is printed).
 """
 
 import argparse
@@ -831,10 +834,10 @@ def main():
     K, N = args.filters, args.images
 
     # parity gate first, rank 0, on the kernels this workload runs -- in a process
-    # of its own: its solver's buffers, allocated and freed here, would decide where the timed
-    # solver's arrays land in device memory, and the streaming kernels feel that (the emitting row
-    # epilogue: 1.49 / 1.65 / 1.8 ms per launch depending on the allocation history of the process,
-    # profiles/r04zc_alloc_placement.txt)
+    # of its own, so that the timed solver meets the device memory as a fresh process does (round 4
+    # did this because the allocation history decided between three speeds of the dominant kernel;
+    # since round 5 the library places its concurrently written arrays by measurement --
+    # DESIGN.md 4.7, `roofline.placement` below -- and the separation only keeps the runs alike)
     parity = None
     if rank == 0 and not args.no_parity:
         if args.parity_only:
