@@ -120,6 +120,35 @@ def gen_dim1():
          **itstat_dict(b))
 
 
+def gen_dim1_dl():
+    """dimN = 1 dictionary learning and the PGM dictionary update alone (sporco/dictlrn/cbpdndl.py:385,
+    sporco/pgm/ccmod.py:139 with dimN=1): signals of three channels with a single-channel
+    dictionary and zero-mean filters; a two-channel dictionary; the update with a mask."""
+    rng = np.random.RandomState(1002)
+    N, K, M, w = 48, 4, 5, 7
+    for name, xm, S, D0, zm in (('cbpdndl_dim1_admm_f64', 'admm', rng.randn(N, 3, K), rng.randn(w, M), True),
+                                ('cbpdndl_dim1_pgm_f64', 'pgm', rng.randn(N, K), rng.randn(w, M), False),
+                                ('cbpdndl_dim1_mcdict_f64', 'admm', rng.randn(N, 2, K), rng.randn(w, 2, M), False)):
+        opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+            {'MaxMainIter': 10, 'AccurateDFid': True, 'CCMOD': {'ZeroMean': zm}}, xmethod=xm, dmethod='pgm')
+        b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod=xm, dmethod='pgm', dimK=1, dimN=1)
+        D1 = b.solve()
+        save(name, D0=D0, S=S, lmbda=np.float64(0.1), zm=np.bool_(zm), D1=D1, X=b.getcoef(),
+             recon=b.reconstruct(), **itstat_dict(b))
+    S = rng.randn(N, K)
+    Z = rng.randn(N, 1, K, M) * (rng.rand(N, 1, K, M) > 0.6)
+    opt = ref_pgm_ccmod.ConvCnstrMOD.Options({'MaxMainIter': 25, 'L': 60.0, 'ZeroMean': True})
+    c = ref_pgm_ccmod.ConvCnstrMOD(Z, S, (w, M), opt, dimK=1, dimN=1)
+    c.solve()
+    W = (rng.rand(N, 1, K, 1) > 0.3).astype(np.float64)
+    opt = ref_pgm_ccmod.ConvCnstrMODMask.Options({'MaxMainIter': 25, 'L': 60.0})
+    cm = ref_pgm_ccmod.ConvCnstrMODMask(Z, S, W, (w, M), opt, dimK=1, dimN=1)
+    cm.solve()
+    save('pgm_ccmod_dim1_f64', Z=Z, S=S, W=W, dsz=np.array((w, M)), D=c.getdict(), Xfull=c.X,
+         recon=c.reconstruct(), D_mask=cm.getdict(), DFid_mask=np.array(cm.getitstat().DFid),
+         **itstat_dict(c))
+
+
 def gen_admm():
     np.random.seed(12345)
     D = np.random.randn(5, 5, 4)
@@ -1422,7 +1451,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
-             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1,
+             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

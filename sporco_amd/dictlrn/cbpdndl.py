@@ -157,11 +157,25 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
                              'to initialise the Options object')
         self.opt, self.xmethod, self.dmethod = opt, xmethod, dmethod
         dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
-        cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)
-        # normalise the initial dictionary and hand it (zero-padded) to the D-step
-        D0 = cr.Pcn(D0, dsz, cri.Nv, dimN, cri.dimCd, crp=True, zm=opt['CCMOD', 'ZeroMean'])
-        optname = 'X0' if dmethod == 'pgm' else 'Y0'        # (cbpdndl.py:443-445)
-        opt['CCMOD'].update({optname: cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
+        self._dim1 = dimN == 1
+        if self._dim1:
+            # signals: both steps run them as images with a unit first axis (admm/cbpdn.py,
+            # pgm/ccmod.py); the set-up arithmetic below does the same and drops the axis again
+            if dmethod != 'pgm' or xmethod not in ('admm', 'pgm'):
+                raise NotImplementedError("dimN = 1 is offered with xmethod 'admm' / 'pgm' and "
+                                          "dmethod 'pgm'")
+            from ..pgm.ccmod import _dsz_unit_axis
+            cri = cr.CDU_ConvRepIndexing(_dsz_unit_axis(dsz), np.asarray(S)[np.newaxis], dimK, 2)
+            D0 = cr.Pcn(np.asarray(D0)[np.newaxis], _dsz_unit_axis(dsz), cri.Nv, 2, cri.dimCd,
+                        crp=True, zm=opt['CCMOD', 'ZeroMean'])
+            opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, 2), cri.Nv)})
+            D0 = D0[0]
+        else:
+            cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)
+            # normalise the initial dictionary and hand it (zero-padded) to the D-step
+            D0 = cr.Pcn(D0, dsz, cri.Nv, dimN, cri.dimCd, crp=True, zm=opt['CCMOD', 'ZeroMean'])
+            optname = 'X0' if dmethod == 'pgm' else 'Y0'        # (cbpdndl.py:443-445)
+            opt['CCMOD'].update({optname: cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, dimN), cri.Nv)})
         bk = {} if reducer is None else {'reducer': reducer}
         xstep = ConvBPDN(D0, S, lmbda, opt['CBPDN'], method=xmethod, dimK=dimK, dimN=dimN,
                          device=device, stream=stream, **bk)
@@ -215,6 +229,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             x._fcache.clear()
         # keep the host attribute current: a (dH, dW, 1, 1, M) crop, a few KB
         x.D = self.dstep.getdict()
+        if self._dim1:
+            x.D = x.D[np.newaxis]       # (the X-step keeps its arrays with the unit axis)
 
     def getdict(self, crop=True):
         return self.dstep.getdict(crop=crop)
@@ -226,12 +242,17 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         """irfftn(sum_m rfftn(D) rfftn(X)) (cbpdndl.py:486-498)."""
         if D is None and X is None:
             dev = self.xstep._dev if self.xmethod == 'admm' else self.xstep.dev
-            return dev.reconstruct(self._coef_var())      # (5-D, as the reference's inner())
+            r = dev.reconstruct(self._coef_var())         # (5-D, as the reference's inner())
+            return r[0] if self._dim1 else r
         if D is None:
             D = self.getdict(crop=False)
         if X is None:
             X = self.getcoef()
         Nv = self.dstep.cri.Nv
+        if self._dim1:
+            Df = np.fft.rfft(D, Nv[1], axis=0)
+            Xf = np.fft.rfft(X, Nv[1], axis=0)
+            return np.fft.irfft(np.sum(Df * Xf, axis=3, keepdims=True), Nv[1], axis=0)
         Df = np.fft.rfftn(D, Nv, axes=(0, 1))
         Xf = np.fft.rfftn(X, Nv, axes=(0, 1))
         return np.fft.irfftn(np.sum(Df * Xf, axis=4, keepdims=True), Nv, axes=(0, 1))

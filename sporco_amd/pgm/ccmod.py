@@ -24,6 +24,14 @@ from ..admm.cbpdn import _DeviceArray
 __all__ = ['ConvCnstrMOD', 'ConvCnstrMODMask']
 
 
+def _dsz_unit_axis(dsz):
+    """Filter support(s) of a dimN = 1 dictionary with a unit first axis added: (w, [C,] M) ->
+    (1, w, [C,] M), for each scale of a multi-scale specification (cnvrep.py:201-215)."""
+    if isinstance(dsz[0], (list, tuple)):
+        return tuple(_dsz_unit_axis(d) for d in dsz)
+    return (1,) + tuple(dsz)
+
+
 class ConvCnstrMOD(pgm.PGMDFT):
 
     class Options(pgm.PGMDFT.Options):
@@ -50,8 +58,10 @@ class ConvCnstrMOD(pgm.PGMDFT):
     Sf = _DeviceArray(_lib.VAR_SF)
 
     def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None,
-                 reducer=None):
-        """``Z, S, dsz, opt, dimK, dimN`` as in the reference (pgm/ccmod.py:139).
+                 reducer=None, _dim1=False):
+        """``Z, S, dsz, opt, dimK, dimN`` as in the reference (pgm/ccmod.py:139); ``dimN`` 2
+        (images) or 1 (signals: run as images with a unit first axis, which the public arrays
+        -- X, getdict(), reconstruct() -- do not show).
         Backend keyword ``dev``: an existing :class:`sporco_amd._lib.Solver`
         (that of the sparse-coding step) to share, so that coefficient maps and
         dictionary never leave the GPU during dictionary learning.  ``reducer``
@@ -61,9 +71,18 @@ class ConvCnstrMOD(pgm.PGMDFT):
         self._reducer = reducer
         if opt is None:
             opt = ConvCnstrMOD.Options()
+        self._dim1 = bool(_dim1)
+        if dimN == 1:
+            self._dim1 = True
+            S, dsz, dimN = np.asarray(S)[np.newaxis], _dsz_unit_axis(dsz), 2
         if dimN != 2:
-            raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images) and 1 (signals)")
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        if self._dim1 and self.cri.Cd > 1 and opt['ZeroMean']:
+            # the reference's projection passes no dimN to its mean subtraction there
+            # (cnvrep.py:1011 against :1074): with dimN = 1 it takes the mean over samples AND
+            # channels, unlike its own cropped form; neither reading is offered as "the" result
+            raise NotImplementedError("dimN = 1 with a multi-channel dictionary and ZeroMean")
         self.set_dtype(opt, S.dtype)
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
@@ -97,21 +116,27 @@ class ConvCnstrMOD(pgm.PGMDFT):
         from ..dist import global_count
         nimg = global_count(reducer, self.cri.K)
         self.set_attr('L', opt['L'], dval=nimg * 14.0, dtype=self.dtype)
-        self.Pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd,
-                             zm=opt['ZeroMean'])
+        pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd, zm=opt['ZeroMean'])
+        self.Pcn = (lambda x: pcn(np.asarray(x)[np.newaxis])[0]) if self._dim1 else pcn
         if Z is not None:
             self.setcoef(Z)
 
     # -- state ---------------------------------------------------------------------
     def _fetch(self, var):
         if var not in self._cache:
-            self._cache[var] = self.dev.download(var)
+            a = self.dev.download(var)
+            if self._dim1 and a.ndim >= 2 and a.shape[0] == 1:
+                a = a[0]
+            self._cache[var] = a
         return self._cache[var]
 
     def _store(self, var, value):
         if value is None:
             return
-        self.dev.upload(var, np.asarray(value))
+        value = np.asarray(value)
+        if self._dim1 and value.ndim == 4:
+            value = value[np.newaxis]
+        self.dev.upload(var, value)
         self.invalidate(var)
 
     def init_state(self, xshape):
@@ -128,6 +153,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
     def setcoef(self, Z):
         """Set the coefficient maps: Zf = rfftn(Z) (pgm/ccmod.py:264-279)."""
         self.Z = np.asarray(Z, dtype=self.dtype)
+        if self._dim1 and self.Z.ndim == 4:
+            self.Z = self.Z[np.newaxis]
         cri = self.cri
         if cri.Cd > 1 and self.Z.size == cri.N * cri.Cd * cri.K * cri.M:
             # maps that carry the dictionary's channels (the reference's broadcasting makes
@@ -152,7 +179,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
         """Current dictionary, cropped to the filter support by default
         (pgm/ccmod.py:283-291)."""
         if crop:
-            return self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
+            D = self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
+            return D[0] if self._dim1 else D
         return self.X
 
     # -- smooth term -------------------------------------------------------------------
@@ -203,6 +231,10 @@ class ConvCnstrMOD(pgm.PGMDFT):
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Df) (pgm/ccmod.py:374-383); host arithmetic on the
         downloaded spectra (off the iteration path)."""
+        if self._dim1:
+            Df = self.Xf if D is None else np.fft.rfft(np.asarray(D), axis=0)
+            Sf = np.sum(self.Zf * Df, axis=self.cri.axisM - 1)
+            return np.fft.irfft(Sf, self.cri.Nv[1], axis=0).astype(self.dtype)
         Df = self.Xf if D is None else np.fft.rfftn(np.asarray(D), axes=(0, 1))
         Sf = np.sum(self.Zf * Df, axis=self.cri.axisM)
         return np.fft.irfftn(Sf, self.cri.Nv, axes=(0, 1)).astype(self.dtype)
@@ -217,8 +249,15 @@ class ConvCnstrMODMask(ConvCnstrMOD):
     def __init__(self, Z, S, W, dsz, opt=None, dimK=None, dimN=2, **backend):
         if opt is None:
             opt = ConvCnstrMODMask.Options()
-        cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
         W = np.asarray(W)
+        if dimN == 1:
+            # (signals: a unit first axis on every array, see ConvCnstrMOD)
+            S, dsz, dimN = np.asarray(S)[np.newaxis], _dsz_unit_axis(dsz), 2
+            W = W[np.newaxis] if W.ndim > 0 else W
+            if Z is not None and np.ndim(Z) == 4:
+                Z = np.asarray(Z)[np.newaxis]
+            backend['_dim1'] = True
+        cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
         if W.ndim < dimN + 3:
             W = W.reshape(W.shape + (1,) * (dimN + 3 - W.ndim))
         if cri.C > 1 and cri.Cd == 1:

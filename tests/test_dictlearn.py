@@ -349,3 +349,54 @@ def test_generic_dstep_gradient_few_and_many_images(backend, N):
     R1 = np.sum(Zf * np.fft.rfftn(D1, axes=(0, 1)), axis=4, keepdims=True) - Sf
     dfid = 0.5 * np.sum(np.fft.irfftn(R1, (H, W), axes=(0, 1)) ** 2)
     assert abs(c.getitstat().DFid[-1] - dfid) < 1e-11 * dfid
+
+
+@pytest.mark.parametrize('name,xm', [('cbpdndl_dim1_admm_f64', 'admm'), ('cbpdndl_dim1_pgm_f64', 'pgm'),
+                                     ('cbpdndl_dim1_mcdict_f64', 'admm')])
+def test_dictlearn_dimN1_signals(backend, name, xm):
+    """dimN = 1 (cbpdndl.py:385 with one-dimensional signals): both steps run the signals as images
+    with a unit first axis; the arrays the caller sees have the reference's shapes and values."""
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden(name)
+    opt = cbpdndl.ConvBPDNDictLearn.Options(
+        {'MaxMainIter': 10, 'AccurateDFid': True, 'CCMOD': {'ZeroMean': bool(g['zm'])}}, xmethod=xm, dmethod='pgm')
+    b = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], float(g['lmbda']), opt, xmethod=xm, dmethod='pgm',
+                                  dimK=1, dimN=1)
+    D1 = b.solve()
+    assert D1.shape == g['D1'].shape and rel_l2(D1, g['D1']) < 1e-9
+    assert b.getcoef().shape == g['X'].shape and rel_l2(b.getcoef(), g['X']) < 1e-9
+    assert b.reconstruct().shape == g['recon'].shape and rel_l2(b.reconstruct(), g['recon']) < 1e-9
+    assert rel_l2(b.reconstruct(D=b.getdict(crop=False), X=b.getcoef()), g['recon']) < 1e-9
+    errs = trace_errors(b.getitstat(), g)
+    assert {'ObjFun', 'DFid', 'RegL1', 'D_L', 'D_Rsdl'} <= set(errs) and max(errs.values()) < 1e-9, errs
+    assert rel_l2(b.xstep.D[0], D1) == 0.0 and b.getdict(crop=False).shape == (g['S'].shape[0],) + D1.shape[1:]
+    with pytest.raises(NotImplementedError):
+        cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], 0.1, cbpdndl.ConvBPDNDictLearn.Options(
+            {}, xmethod='admm', dmethod='cns'), xmethod='admm', dmethod='cns', dimK=1, dimN=1)
+
+
+def test_pgm_ccmod_dimN1(backend):
+    """The PGM dictionary update on signals (pgm/ccmod.py:139 with dimN = 1), plain and masked."""
+    from sporco_amd.pgm import ccmod
+    g = load_golden('pgm_ccmod_dim1_f64')
+    dsz = tuple(int(v) for v in g['dsz'])
+    c = ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz, ccmod.ConvCnstrMOD.Options(
+        {'MaxMainIter': 25, 'L': 60.0, 'ZeroMean': True}), dimK=1, dimN=1)
+    X = c.solve()
+    assert X.shape == g['Xfull'].shape and rel_l2(X, g['Xfull']) < 1e-9
+    assert c.getdict().shape == g['D'].shape and rel_l2(c.getdict(), g['D']) < 1e-9
+    assert rel_l2(c.X, g['Xfull']) < 1e-9 and rel_l2(c.reconstruct(), g['recon']) < 1e-9
+    assert rel_l2(c.reconstruct(D=c.X), g['recon']) < 1e-9
+    errs = trace_errors(c.getitstat(), g)
+    assert errs and max(errs.values()) < 1e-9, errs
+    assert np.allclose(np.sum(c.X ** 2, axis=0).ravel(), 1.0) and np.all(c.X[dsz[0]:] == 0)
+    assert np.abs(np.sum(c.X, axis=0)).max() < 1e-12
+    assert rel_l2(c.Pcn(c.X), c.X) < 1e-12
+    m = ccmod.ConvCnstrMODMask(g['Z'], g['S'], g['W'], dsz, ccmod.ConvCnstrMODMask.Options(
+        {'MaxMainIter': 25, 'L': 60.0}), dimK=1, dimN=1)
+    m.solve()
+    assert rel_l2(m.getdict(), g['D_mask']) < 1e-9
+    assert rel_l2(np.array(m.getitstat().DFid), g['DFid_mask']) < 1e-9
+    with pytest.raises(NotImplementedError):
+        ccmod.ConvCnstrMOD(None, np.zeros((32, 2, 3)), (5, 2, 4), ccmod.ConvCnstrMOD.Options({'ZeroMean': True}),
+                           dimK=1, dimN=1)
