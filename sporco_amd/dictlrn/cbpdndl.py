@@ -132,6 +132,8 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
                 'CCMOD': ConvCnstrMODOptions(self.defaults['CCMOD'], method=self.dmethod)})
             self.update({} if opt is None else opt)
 
+    _dim1 = False       # (set per object by __init__; classes that share the coupling methods keep it)
+
     def __init__(self, D0, S, lmbda=None, opt=None, xmethod=None, dmethod=None, dimK=1,
                  dimN=2, device=0, stream=None, reducer=None):
         """Arguments as in the reference (cbpdndl.py:385-423).  Backend keywords: ``device``,
