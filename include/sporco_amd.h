@@ -198,6 +198,17 @@ int sporco_amd_csc_placement_report(sporco_amd_csc_t h, char *buf, size_t cap);
  * ends the call with SPORCO_AMD_EHIP after a few seconds; the handle's iterate is then void.
  * The environment variable SPORCO_AMD_PERSIST=1 / 0 overrides the hint. */
 #define SPORCO_AMD_HINT_ONE_LAUNCH 1
+/* COMPLEX_PAIR -- not a hint: it changes what the dictionary-update calls compute.  The handle
+ * (two-channel dictionary, Cd = 2; set before sporco_amd_csc_set_signal) serves complex-valued
+ * signals, coefficient maps and dictionary, whose real and imaginary parts are its two channels:
+ * sporco_amd_csc_dstep_iter / _cns_iter then solve the complex problem of
+ * sporco/admm/ccmod.py:103-907 given complex input (its fftn / ifftn path, :219-231; the
+ * reference's tests/admm/test_ccmod.py:49-140) with the coefficient maps staged per channel
+ * (sporco_amd_csc_ccmod_setcoef(VAR_CX)).  Spectral arrays of such a handle hold A + iB and
+ * A - iB (A, B the half spectra of the two parts) scaled as csrc/csc_kernels.h
+ * launch_pm_butterfly describes; the real arrays (VAR_DX, VAR_DSX, VAR_DSU, VAR_CX, VAR_CU) are
+ * (re, im) channel pairs.  Not with mask decoupling, image shards or the objective at X. */
+#define SPORCO_AMD_MODE_COMPLEX_PAIR 2
 int sporco_amd_csc_set_hint(sporco_amd_csc_t h, int what, int value);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))

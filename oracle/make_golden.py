@@ -836,6 +836,46 @@ def gen_ccmod_eq():
                  X=b.getcoef(), **itstat_dict(b))
 
 
+def gen_ccmod_cplx():
+    """Complex-valued coefficient maps, signals and dictionary in the ADMM dictionary updates
+    (sporco/admm/ccmod.py:219-231: fftn / ifftn in place of rfftn / irfftn; the reference's own
+    tests/admm/test_ccmod.py:49-140): IterSM with the default options (AutoRho) and with
+    LinSolveCheck / ZeroMean / a start dictionary, in complex64 too; CG run to 1e-9; consensus."""
+    rng = np.random.RandomState(97531)
+    N, M, Nd, K = 16, 4, 5, 3
+    cn = lambda *shp: rng.randn(*shp) + 1j * rng.randn(*shp)
+    S = cn(N, N, K)
+    Z = cn(N, N, 1, K, M) * (rng.rand(N, N, 1, K, M) > 0.7)
+    D0 = cn(Nd, Nd, M)
+    Y0 = ref_cnvrep.zpad(ref_cnvrep.stdformD(
+        ref_cnvrep.Pcn(D0, (Nd, Nd, M), (N, N), 2, 0, crp=True), 1, M, 2), (N, N))
+    fixed = {'rho': 2.0, 'AutoRho': {'Enabled': False}}
+    cases = (('ism', 'f64', ref_admm_ccmod.ConvCnstrMOD_IterSM, {'MaxMainIter': 20}),
+             ('ism', 'f32', ref_admm_ccmod.ConvCnstrMOD_IterSM, {'MaxMainIter': 20, 'DataType': np.complex64}),
+             ('ism', 'chk_zm_y0_f64', ref_admm_ccmod.ConvCnstrMOD_IterSM,
+              {'MaxMainIter': 15, 'LinSolveCheck': True, 'ZeroMean': True, 'RelaxParam': 1.5, 'Y0': Y0,
+               'AuxVarObj': True}),
+             ('cg', 'tight_f64', ref_admm_ccmod.ConvCnstrMOD_CG,
+              dict(fixed, MaxMainIter=15, LinSolveCheck=True, CG={'MaxIter': 500, 'StopTol': 1e-9})),
+             ('cg', 'f64', ref_admm_ccmod.ConvCnstrMOD_CG, {'MaxMainIter': 15}),
+             ('cns', 'f64', ref_admm_ccmod.ConvCnstrMOD_Consensus, {'MaxMainIter': 20}),
+             ('cns', 'chk_zm_autorho_f64', ref_admm_ccmod.ConvCnstrMOD_Consensus,
+              {'MaxMainIter': 15, 'LinSolveCheck': True, 'ZeroMean': True, 'AutoRho': {'Enabled': True},
+               'Y0': Y0}))
+    for meth, name, cls, optd in cases:
+        c = cls(Z, S, (Nd, Nd, M), cls.Options(optd))
+        c.solve()
+        save('ccmod_cplx_%s_%s' % (meth, name), Z=Z, S=S, Y0=Y0, dsz=np.array((Nd, Nd, M)), D=c.getdict(),
+             Y=c.Y, X=c.X, U=c.U, rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+    # one image (dimK = 0), odd sizes
+    S1, Z1 = cn(15, 13), cn(15, 13, 1, 1, M) * (rng.rand(15, 13, 1, 1, M) > 0.6)
+    c = ref_admm_ccmod.ConvCnstrMOD_IterSM(Z1, S1, (4, 6, M), ref_admm_ccmod.ConvCnstrMOD_IterSM.Options(
+        {'MaxMainIter': 15}), dimK=0)
+    c.solve()
+    save('ccmod_cplx_ism_odd_single_f64', Z=Z1, S=S1, dsz=np.array((4, 6, M)), D=c.getdict(), Y=c.Y, X=c.X,
+         U=c.U, rho_final=np.float64(c.rho), k_final=np.int64(c.k), **itstat_dict(c))
+
+
 def gen_ccmod_eq_mcdict():
     """The single-copy ADMM dictionary updates with a MULTI-CHANNEL dictionary (Cd = C > 1):
     ConvCnstrMOD_IterSM / _CG (sporco/admm/ccmod.py:433-601: linalg.solvemdbi_ism / _cg with the
@@ -1451,7 +1491,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
-             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl,
+             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'ccmod_cplx': gen_ccmod_cplx,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

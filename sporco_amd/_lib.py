@@ -40,6 +40,7 @@ QUERY_FUSED_COLS, QUERY_FUSED_ROWS, QUERY_FUSED_PGM, QUERY_DEVICE_FILTERS, QUERY
 QUERY_PERSIST_RUNS = 5
 HINT_KEEP_VFORM = 0
 HINT_ONE_LAUNCH = 1
+MODE_COMPLEX_PAIR = 2
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7

@@ -37,6 +37,59 @@ class _DeviceDStep(object):
     hdrtxt_objfn = ('DFid', 'Cnstr')
     hdrval_objfun = {'DFid': 'DFid', 'Cnstr': 'Cnstr'}
 
+    # Complex-valued coefficient maps, signals and dictionary (the reference takes them through
+    # its fftn path, ccmod.py:219-231; tests/admm/test_ccmod.py:49-140): the real and the imaginary
+    # part are the two channels of a real problem with a two-channel dictionary whose coefficient
+    # maps carry the channels -- constraint projection, residuals and dual update of the complex
+    # problem are those of that real problem as they stand (a complex l2 norm is the norm over
+    # the pair) -- and the handle pairs the channels' spectra in its linear solves
+    # (``SPORCO_AMD_MODE_COMPLEX_PAIR``, include/sporco_amd.h).  ``dtype`` stays the real working
+    # type; ``cdtype`` is the complex one of the arrays the caller sees.
+    _cplx = False
+
+    def _complex_setup(self, Z, S, dsz, opt, dimK, dimN, dev, reducer=None):
+        """The arguments of the equivalent real problem when any of ``Z`` / ``S`` is complex
+        (or ``DataType`` asks for it); the complex problem's indexing in ``self.cri_c``."""
+        dt = opt['DataType']
+        if not (np.iscomplexobj(S) or (Z is not None and np.iscomplexobj(Z))
+                or (dt is not None and np.dtype(dt).kind == 'c')):
+            return Z, S, dsz, dimK
+        if dev is not None or reducer is not None:
+            raise NotImplementedError("complex-valued dictionary update: not with a shared device "
+                                      "handle or image shards")
+        if isinstance(dsz[0], (list, tuple)):
+            raise NotImplementedError("complex-valued dictionary update: one filter support")
+        S = np.asarray(S)
+        cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        if cri.C > 1 or cri.Cd > 1:
+            raise NotImplementedError("complex-valued dictionary update: single-channel signals "
+                                      "and dictionary")
+        if opt['fEvalX'] and type(self)._objective_at_y_only:
+            raise NotImplementedError("complex-valued consensus update: objective at Y (AuxVarObj)")
+        cdt = np.result_type(S.dtype if dt is None else np.dtype(dt), np.complex64)
+        self._cplx = True
+        self.cri_c = cri
+        self.cdtype = np.dtype(cdt)
+        self.dtype = np.dtype(np.float32 if cdt == np.complex64 else np.float64)
+        Sc = S.reshape(cri.Nv + (1, cri.K))
+        S2 = np.concatenate([Sc.real, Sc.imag], axis=2).astype(self.dtype)     # (H, W, 2, K)
+        return Z, S2, tuple(dsz[0:dimN]) + (2, cri.M), 1
+
+    def _to_pair(self, a):
+        """Complex array with a unit channel axis (axis 2) -> real array with (re, im) channels."""
+        if a is None or not self._cplx:
+            return a
+        a = np.asarray(a)
+        if a.ndim < 3 or a.shape[2] != 1:
+            raise ValueError("complex-valued array with a unit channel axis expected, got shape %s"
+                             % (a.shape,))
+        return np.concatenate([a.real, a.imag], axis=2).astype(self.dtype)
+
+    def _from_pair(self, a):
+        if not self._cplx:
+            return a
+        return (a[:, :, 0:1] + 1j * a[:, :, 1:2]).astype(self.cdtype)
+
     def _attach_device(self, S, dev, device, stream):
         """``self.S`` in the internal layout (one block per (channel, image): channels fold
         into the image axis for a single-channel dictionary, ccmod.py:695-699, :702-706) and
@@ -51,6 +104,8 @@ class _DeviceDStep(object):
             if dev is None:
                 self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
                                        device=device, stream=stream, Cd=self.cri.Cd)
+                if self._cplx:
+                    self.dev.set_hint(_lib.MODE_COMPLEX_PAIR, 1)
                 self.dev.set_signal(self.S)
             else:
                 if (dev.dims[:2] + (dev.Cs,) + dev.dims[3:]) != (H, W, self.cri.C, self.cri.K,
@@ -82,14 +137,14 @@ class _DeviceDStep(object):
     @property
     def Y(self):
         if _lib.VAR_DX not in self._cache:
-            self._cache[_lib.VAR_DX] = self.dev.download(_lib.VAR_DX)
+            self._cache[_lib.VAR_DX] = self._from_pair(self.dev.download(_lib.VAR_DX))
         return self._cache[_lib.VAR_DX]
 
     @Y.setter
     def Y(self, value):
         if value is None:
             return
-        self.dev.upload(_lib.VAR_DX, np.asarray(value, dtype=self.dtype))
+        self.dev.upload(_lib.VAR_DX, np.asarray(self._to_pair(value), dtype=self.dtype))
         self.dev.fft_var(_lib.VAR_DX, _lib.VAR_DXF)
         self._cache.pop(_lib.VAR_DX, None)
 
@@ -100,6 +155,10 @@ class _DeviceDStep(object):
         """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:311-327, :746-755)."""
         # (multi-channel dictionary: Nb = K and the maps have no channel axis, same reshape)
         Z = np.asarray(Z)
+        if self._cplx:
+            # (the complex maps for reconstruct(); the device gets their (re, im) channel pair)
+            self._Zc = Z.reshape(self.cri.Nv + (1, self.Nb, self.cri.M)).astype(self.cdtype)
+            Z = np.concatenate([self._Zc.real, self._Zc.imag], axis=2)
         self._z_chan = self.cri.Cd > 1 and Z.size == self.cri.N * self.cri.Cd * self.Nb * self.cri.M
         if self._z_chan:
             # ... unless they carry the dictionary's channels: the reference's broadcasting then
@@ -123,8 +182,15 @@ class _DeviceDStep(object):
         """The dictionary, cropped to the filter support by default (ccmod.py:331-339,
         :839-848)."""
         if crop:
-            return self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
+            return self._from_pair(self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1]))
         return self.Y
+
+    def _reconstruct_complex(self, D):
+        """ifftn(sum_m fftn(Z) fftn(D)) (ccmod.py:418-427 / :897-907 on the fftn path)."""
+        D = self.Y if D is None else np.asarray(D)
+        Sf = np.sum(np.fft.fftn(self._Zc, axes=(0, 1)) * np.fft.fftn(D, axes=(0, 1)),
+                    axis=self.cri.axisM)
+        return np.fft.ifftn(Sf, axes=(0, 1)).astype(self.cdtype)
 
     def finish_solve(self):
         self.dev.sync()
@@ -187,6 +253,7 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
     # dictionary sized, i.e. identical on every rank)
     _shard_slots = (_lib.OUT_R2, _lib.OUT_AX2, _lib.OUT_U2, _lib.OUT_DFID)
     _mask_dcpl = False
+    _objective_at_y_only = True      # (of the complex-valued form: _DeviceDStep._complex_setup)
 
     def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None,
                  reducer=None):
@@ -203,6 +270,9 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
             opt = ConvCnstrMOD_Consensus.Options()
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        if self._mask_dcpl and (np.iscomplexobj(S) or (Z is not None and np.iscomplexobj(Z))):
+            raise NotImplementedError("complex-valued dictionary update: not with mask decoupling")
+        Z, S, dsz, dimK = self._complex_setup(Z, S, dsz, opt, dimK, dimN, dev, reducer)
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
         if self.cri.Cd > 1 and reducer is not None:
             raise NotImplementedError("a multi-channel dictionary in the consensus update: not "
@@ -218,8 +288,9 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         if self.dtype not in (np.float32, np.float64):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
         self._attach_device(S, dev, device, stream)     # one consensus block per image
-        self.yshape = self.cri.shpD
-        self.xshape = self.cri.shpD + (self.Nb,)
+        # (the complex form counts complex elements: Nx, Nc and the shapes are its own)
+        self.yshape = self.cri_c.shpD if self._cplx else self.cri.shpD
+        self.xshape = self.yshape + (self.Nb,)
         # (blocks of the whole problem: the residual scalings and tolerances refer to them)
         from ..dist import global_count
         self._nb_all = global_count(reducer, self.Nb)
@@ -236,7 +307,7 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
     def init_state(self, yshape, ushape):
         """Y = Y0 or zeros, U_n = Y0 / rho or zeros (admm.py:262-272 with uinit of
         ccmod.py:734-742), on the device."""
-        self.dev.cns_init(self.opt['Y0'], float(self.rho))
+        self.dev.cns_init(self._to_pair(self.opt['Y0']), float(self.rho))
         if self.opt['U0'] is not None:
             self.U = self.opt['U0']
 
@@ -257,22 +328,22 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
 
     @property
     def X(self):
-        return self._from_blocks(self.dev.download(_lib.VAR_CX))
+        return self._from_pair(self._from_blocks(self.dev.download(_lib.VAR_CX)))
 
     @X.setter
     def X(self, value):
         if value is not None:
-            self.dev.upload(_lib.VAR_CX, self._to_blocks(np.asarray(value, dtype=self.dtype)))
+            self.dev.upload(_lib.VAR_CX, self._to_blocks(np.asarray(self._to_pair(value), dtype=self.dtype)))
 
     @property
     def U(self):
         u = self._from_blocks(self.dev.download(_lib.VAR_CU))
-        return u * u.dtype.type(self._u_scale) if self._u_scale != 1.0 else u
+        return self._from_pair(u * u.dtype.type(self._u_scale) if self._u_scale != 1.0 else u)
 
     @U.setter
     def U(self, value):
         if value is not None:
-            self.dev.upload(_lib.VAR_CU, self._to_blocks(np.asarray(value, dtype=self.dtype)))
+            self.dev.upload(_lib.VAR_CU, self._to_blocks(np.asarray(self._to_pair(value), dtype=self.dtype)))
             self._u_scale = 1.0
 
     # -- iteration --------------------------------------------------------------------------
@@ -333,6 +404,8 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
 
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Df) (ccmod.py:897-907); host arithmetic, off the iteration path."""
+        if self._cplx:
+            return self._reconstruct_complex(D)
         Df = self.dev.download(_lib.VAR_DXF) if D is None else \
             np.fft.rfftn(np.asarray(D), axes=(0, 1))
         Zf = np.fft.rfftn(self.Z, axes=(0, 1)) if getattr(self, '_z_chan', False) else \
@@ -372,12 +445,14 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
                 self['gEvalY'] = value is True
 
     _method = None
+    _objective_at_y_only = False
 
     def __init__(self, Z, S, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
         if opt is None:
             opt = type(self).Options()
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images)")
+        Z, S, dsz, dimK = self._complex_setup(Z, S, dsz, opt, dimK, dimN, dev)
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
         if opt['ReturnX']:
             raise NotImplementedError("the device D-step returns the constrained variable Y "
@@ -387,8 +462,9 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
             raise TypeError("sporco_amd works in float32 or float64, not %s" % self.dtype)
         self.Nb = self.cri.C * self.cri.K
         self._attach_device(S, dev, device, stream)
-        Nx = int(np.prod(self.cri.shpD))
-        admm.ADMM.__init__(self, Nx, self.cri.shpD, self.cri.shpD, S.dtype, opt)
+        shpD = self.cri_c.shpD if self._cplx else self.cri.shpD    # (complex elements counted once)
+        Nx = int(np.prod(shpD))
+        admm.ADMM.__init__(self, Nx, shpD, shpD, S.dtype, opt)
         # (as for the consensus class, the `dval=cri.K` of ccmod.py:264 never takes effect)
         self.xrrs = None
         self.cgit = None
@@ -398,32 +474,34 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
     # -- state ---------------------------------------------------------------------------
     def init_state(self, yshape, ushape):
         """Y = Y0 or zeros, U = Y0 or zeros (uinit, ccmod.py:298-307), Xf = 0."""
-        self.dev.dstep_init(self.opt['Y0'])
+        self.dev.dstep_init(self._to_pair(self.opt['Y0']))
         if self.opt['U0'] is not None:
             self.U = self.opt['U0']
 
     @property
     def X(self):
-        return self.dev.download(_lib.VAR_DSX)
+        return self._from_pair(self.dev.download(_lib.VAR_DSX))
 
     @X.setter
     def X(self, value):
         if value is not None:
-            self.dev.upload(_lib.VAR_DSX, np.asarray(value, dtype=self.dtype))
+            self.dev.upload(_lib.VAR_DSX, np.asarray(self._to_pair(value), dtype=self.dtype))
 
     @property
     def Xf(self):
+        if self._cplx:      # (the device holds the paired spectra: the plain transform of X instead)
+            return np.fft.fftn(self.X, axes=(0, 1))
         return self.dev.download(_lib.VAR_DYF)
 
     @property
     def U(self):
         u = self.dev.download(_lib.VAR_DSU)
-        return u * u.dtype.type(self._u_scale) if self._u_scale != 1.0 else u
+        return self._from_pair(u * u.dtype.type(self._u_scale) if self._u_scale != 1.0 else u)
 
     @U.setter
     def U(self, value):
         if value is not None:
-            self.dev.upload(_lib.VAR_DSU, np.asarray(value, dtype=self.dtype))
+            self.dev.upload(_lib.VAR_DSU, np.asarray(self._to_pair(value), dtype=self.dtype))
             self._u_scale = 1.0
 
     # -- iteration --------------------------------------------------------------------------
@@ -469,6 +547,8 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
 
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Xf) (ccmod.py:418-427); host arithmetic, off the iteration path."""
+        if self._cplx:
+            return self._reconstruct_complex(self.X if D is None else D)
         Df = self.Xf if D is None else np.fft.rfftn(np.asarray(D), axes=(0, 1))
         Zf = self.dev.download(_lib.VAR_ZF)
         return np.fft.irfftn(np.sum(Zf * Df, axis=self.cri.axisM), self.cri.Nv,

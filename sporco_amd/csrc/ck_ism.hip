@@ -536,6 +536,44 @@ void launch_swap_inner(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t row
     SA_HIP(hipGetLastError());
 }
 
+// Complex-valued signals on a real handle (csc_kernels.h launch_pm_butterfly): the channel pair
+// (A, B) = half spectra of the real and the imaginary part, array (npix, mid, 2, inner).
+template <typename T>
+__global__ void __launch_bounds__(kThreads) pm_butterfly_kernel(const cx<T> *src, cx<T> *dst, int64_t npix,
+                                                                int mid, int inner, int Wf, int W,
+                                                                int mode) {
+    const int64_t total = npix * mid * inner;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t grp = t / inner;                 // (pix, j)
+        const int i = (int)(t - grp * inner);
+        const int64_t pix = grp / mid;
+        const int64_t ia = grp * 2 * inner + i, ib = ia + inner;
+        const cx<T> a = src[ia], b = src[ib];
+        // s^2 = half the Parseval weight of the row frequency: 1/2 on the two self-conjugate
+        // columns, which the + and the - array both hold in full, 1 elsewhere
+        const T s = (mode != 0 && parseval_weight((int)(pix % Wf), Wf, W) == 1.0) ? (T)0.70710678118654752440
+                                                                                   : T(1);
+        if (mode != 2) {
+            // (A + iB, A - iB): i times (re, im) = (-im, re)
+            dst[ia] = cscale(mk<T>(a.re - b.im, a.im + b.re), s);
+            dst[ib] = cscale(mk<T>(a.re + b.im, a.im - b.re), s);
+        } else {
+            // A = (P + M) / 2, B = (P - M) / (2i), with the scaling taken out
+            const T h = T(0.5) / s;
+            dst[ia] = cscale(mk<T>(a.re + b.re, a.im + b.im), h);
+            dst[ib] = cscale(mk<T>(a.im - b.im, b.re - a.re), h);
+        }
+    }
+}
+template <typename T>
+void launch_pm_butterfly(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t npix, int mid, int inner,
+                         int W, int mode) {
+    hipLaunchKernelGGL((pm_butterfly_kernel<T>), dim3(grid_for(npix * mid * inner)), dim3(kThreads), 0, st,
+                       src, dst, npix, mid, inner, W / 2 + 1, W, mode);
+    SA_HIP(hipGetLastError());
+}
+
 // dst[(pix, c), n, k] = zch ? src[pix, n, c, k] : src[pix, n, k]: the coefficient spectrum of a
 // multi-channel dictionary update seen as one single-channel update per (frequency, channel)
 // -- the same matrix for every channel of a frequency (linalg.solvemdbi_ism / _cg with a
@@ -936,6 +974,7 @@ template <typename T> int launch_asum(hipStream_t st, const T *v, int64_t n, dou
     template void launch_cns_xrrs_rhs<T>(hipStream_t, const cx<T> *, const cx<T> *, const cx<T> *, T, cx<T> *, int64_t, int, int, int, int); \
     template int launch_cns_xrrs_fin<T>(hipStream_t, const cx<T> *, const cx<T> *, T, const cx<T> *, int64_t, int, int, double *, int, int); \
     template void launch_swap_inner<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int); \
+    template void launch_pm_butterfly<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int, int, int); \
     template void launch_zf_per_channel<T>(hipStream_t, const cx<T> *, cx<T> *, int64_t, int, int, int, int); \
     template void launch_ism_setup<T>(hipStream_t, const cx<T> *, cx<T> *, cx<T> *, cx<T> *, int64_t, int, int, T, const GradTerm<T> *, int); \
     template int launch_ism_solve<T>(hipStream_t, const cx<T> *, cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *, const cx<T> *, T, int64_t, int, int, int, int, bool, bool, double *, const GradTerm<T> *); \

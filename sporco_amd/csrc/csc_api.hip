@@ -476,10 +476,22 @@ template <typename T> struct Csc : CscBase {
     // its Xf buffer to 80 for the ADMM tail kernels: the staged composition serves it).
     bool pgm_fused_ok() const { return rows_ok && cols256 && (fused || (fused_slabs && !tail_mode)); }
     bool hint_vform = false, hint_one_launch = false;
+    // SPORCO_AMD_MODE_COMPLEX_PAIR: the two channels of the handle are the real and the imaginary
+    // part of complex data (dictionary updates only; csc_kernels.h launch_pm_butterfly)
+    bool cplx_pair = false;
     void set_hint(int what, int value) override {
         if (what == SPORCO_AMD_HINT_KEEP_VFORM) hint_vform = value != 0;
         else if (what == SPORCO_AMD_HINT_ONE_LAUNCH) hint_one_launch = value != 0;
-        else throw Error(SPORCO_AMD_EINVAL, "unknown hint");
+        else if (what == SPORCO_AMD_MODE_COMPLEX_PAIR) {
+            SA_REQUIRE(Cd == 2 && Cs == 2, "complex pair mode: a handle with two channels (real, imaginary)");
+            SA_REQUIRE(!have_signal && !zf_ch, "complex pair mode is set before the signal and the coefficient maps");
+            cplx_pair = value != 0;
+        } else throw Error(SPORCO_AMD_EINVAL, "unknown hint");
+    }
+    // (A, B) -> (A + iB, A - iB) and back on an array (npix, mid, 2, inner) of such a handle
+    void pm_pair(const cx<T> *src, cx<T> *dst, int mid, int inner, int mode) {
+        ProfScope ps(prof, PS_OTHER);
+        launch_pm_butterfly<T>(st, src, dst, npix, mid, inner, W, mode);
     }
     std::string placement() override { return placement_report(); }
     // the second pair of iterate buffers (the (Y, U) ping-pong, and the two V buffers of the

@@ -303,6 +303,19 @@ int launch_md_dualres_tiled(hipStream_t st, const cx<T> *t, const cx<T> *dft, co
 template <typename T>
 int launch_resid_stats(hipStream_t st, const cx<T> *a, const cx<T> *b, const cx<T> *c, const cx<T> *d,
                        const T *gramt, int64_t ntiles, int H, int CN, double *partials);
+// Complex-valued maps, signals and dictionary on a handle with Cd = 2 (the real and the imaginary
+// part are the two channels; admm/ccmod.py with complex input, tests/admm/test_ccmod.py:49-140).
+// With A, B the half spectra of the two parts, the full spectrum of a + ib is A + iB at a stored
+// frequency f and conj(A - iB) at -f: in the variables P = A + iB, M = A - iB every per-frequency
+// equation of the dictionary update holds for P and for M separately -- two "channels" again, each
+// with its own coefficient maps, which is a layout the update kernels already take (zch).
+// Array (npix, mid, 2, inner), in place or not.  mode 0: (A, B) -> (P, M); mode 1: the same times
+// s(f) = sqrt(w(f) / 2), w the Parseval weights of the half spectrum, so that UNWEIGHTED sums over
+// the stored half are sums over the full spectrum (the CG dot products and residual norms of the
+// reference's fftn path); mode 2: the inverse of mode 1.
+template <typename T>
+void launch_pm_butterfly(hipStream_t st, const cx<T> *src, cx<T> *dst, int64_t npix, int mid, int inner,
+                         int W, int mode);
 // dst[(pix, c), n, k] = zch ? src[pix, n, c, k] : src[pix, n, k]  (npix Cd "frequencies" of a
 // single-channel dictionary update: api_dstep.inc)
 template <typename T>
