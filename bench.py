@@ -403,6 +403,7 @@ def run_config4(device, backtrack, tiny=False):
 def run_config5(device, tiny=False):
     """dictlrn.cbpdndl.ConvBPDNDictLearn, 256x256, K=64, N=64, admm X-step / pgm D-step
     (BASELINE configs[4]); metric = outer iterations/s."""
+    from sporco_amd import _lib
     from sporco_amd.dictlrn import cbpdndl
     H = W = 128 if tiny else 256
     K, N = 64, (4 if tiny else 64)
@@ -439,7 +440,7 @@ def run_config5(device, tiny=False):
     # enqueues both epilogue variants and lets the unneeded one return at once, and an average
     # over those idle dispatches is not a kernel time)
     prof = profiled_pass(d, dev, 10, host_loop=True)
-    groups = min(8, N, -(-768 // (W // 2 + 1)))      # ccmod_grad's image groups (api_dictupdate.inc)
+    groups = dev.query(_lib.QUERY_CCMOD_GROUPS)      # ccmod_grad's image groups (api_dictupdate.inc)
     moved, alg = byte_model(H, W, 1, N, K, grad_groups=groups)
     # the generic FFT slots of this configuration are the D-step's transforms of the dictionary
     # (H, W, K): dictionary-sized, 1/N of the arrays above

@@ -170,6 +170,9 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
 #define SPORCO_AMD_QUERY_PERSIST_RUNS 5  /* how many sporco_amd_csc_admm_run calls of this handle
                                             ran their iterations as one launch (small problems:
                                             see sporco_amd_csc_admm_run) -- diagnostics */
+#define SPORCO_AMD_QUERY_CCMOD_GROUPS 6  /* image groups per row frequency of the tile-major
+                                          * dictionary-update gradient (their partial gradients
+                                          * are written and summed: bench.py's byte model) */
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out);
 /* Diagnostics, no reference counterpart: where the handle put the X-sized arrays that one kernel
  * writes at the same time (the spectrum buffer T and the iterate buffers of the fused ADMM

@@ -38,6 +38,7 @@ FLAG_AMS = 1 << 11
 FLAG_DMASK = 1 << 12
 QUERY_FUSED_COLS, QUERY_FUSED_ROWS, QUERY_FUSED_PGM, QUERY_DEVICE_FILTERS, QUERY_VFORM_LIVE = 0, 1, 2, 3, 4
 QUERY_PERSIST_RUNS = 5
+QUERY_CCMOD_GROUPS = 6
 HINT_KEEP_VFORM = 0
 HINT_ONE_LAUNCH = 1
 MODE_COMPLEX_PAIR = 2

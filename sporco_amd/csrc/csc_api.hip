@@ -539,6 +539,7 @@ template <typename T> struct Csc : CscBase {
         if (what == SPORCO_AMD_QUERY_DEVICE_FILTERS) return K;
         if (what == SPORCO_AMD_QUERY_VFORM_LIVE) return (v_live || gv_live) ? 1 : 0;
         if (what == SPORCO_AMD_QUERY_PERSIST_RUNS) return pst_runs;
+        if (what == SPORCO_AMD_QUERY_CCMOD_GROUPS) return ccmod_group_count();
         throw Error(SPORCO_AMD_EINVAL, "unknown query");
     }
 

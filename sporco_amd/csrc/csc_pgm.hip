@@ -508,6 +508,102 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
     }
 }
 
+// The same for K = 64 and H = 16 NW <= 256, rebuilt around what bounds the kernel above at those
+// sizes -- bytes in flight: there, a wave has 4 rows of Zf requested while it works on 4 others,
+// 16 waves per CU, 32 KB; a CU needs about twice that to keep its share of the HBM pipe full.
+// Here one workgroup of 16 waves per CU (16 rows per thread instead of 32: half the accumulator
+// registers) keeps a whole tile -- 16 rows per thread, 128 KiB per workgroup -- requested ahead: the
+// four 4-row chunks of image n + 1 are asked for as the chunks of image n are consumed, the signal
+// coefficients with them.  The dictionary column d(., wf, .), which does not change over the images
+// of a workgroup, waits in LDS instead of being re-read from L2 for every image (each thread reads
+// back what it stored: no barrier).  Gradient bits as above (same association per element); the
+// two sums are added in another order.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_ahead_kernel(const CcmodTiledArgs<float> a) {
+    constexpr int N1 = 16, H = N1 * NW, NC = N1 / 4, K = 64;
+    const int tid = threadIdx.x;
+    const int k = tid & 63;
+    const int w = sa_readfirstlane(tid >> 6);
+    const int Wf = a.W / 2 + 1;
+    const int g = blockIdx.x % a.G, wf = blockIdx.x / a.G;
+    const int cng = (a.CN + a.G - 1) / a.G;
+    const int cn0 = g * cng, cn1 = (cn0 + cng < a.CN) ? cn0 + cng : a.CN;
+    const cf zero = mk<float>(0.f, 0.f);
+    cf *dl = dyn_lds<cf>();                                       // [H][K]
+    double *scratch = reinterpret_cast<double *>(dl + H * K);
+    {
+        const BufRsrc Db = make_rsrc(a.d, (uint32_t)((int64_t)H * Wf * K * sizeof(cf)));
+        const int dko = ((w * Wf + wf) * K + k) * (int)sizeof(cf);
+#pragma unroll
+        for (int i = 0; i < N1; ++i)
+            dl[(NW * i + w) * K + k] = buf_load_cf_cached(Db, dko, i * NW * Wf * K * (int)sizeof(cf));
+    }
+    cf acc[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) acc[i] = zero;
+    float s_r2 = 0.f, s_q2 = 0.f;
+    cf zb[NC][4], sb[NC];      // sb[c]: lane l holds the signal coefficient of row 4 c + (l & 3)
+    // (the offsets pass through the register fences below: a request may not be scheduled before
+    // the chunk whose registers it reuses has been consumed, nor the LDS reads of all 16 rows of d
+    // ahead of the first chunk -- either would double the registers of the tile)
+    int ko = (w * K + k) * (int)sizeof(cf);
+    int so = (NW * (k & 3) + w) * (int)sizeof(cf);
+    int dlo = w * K + k;
+    // (live = false: a buffer of no bytes -- the loads return zero without touching memory; the
+    // request after the last image, which keeps the loop free of a branch around the loads)
+    auto request = [&](auto cc, int cn, bool live) {
+        constexpr int c = decltype(cc)::value;
+        const int tile = wf * a.CN + cn;
+        const BufRsrc Zb = make_rsrc(a.zf + (int64_t)tile * H * K, live ? (uint32_t)(H * K * sizeof(cf)) : 0u);
+        const BufRsrc Sb = make_rsrc(a.sft + (int64_t)tile * H, live ? (uint32_t)(H * sizeof(cf)) : 0u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zb[c][e] = buf_load_cf(Zb, ko, NW * (4 * c + e) * K * (int)sizeof(cf));
+        sb[c] = buf_load_cf_cached(Sb, so, NW * 4 * c * (int)sizeof(cf));
+    };
+    static_for<NC>([&](auto cc) { request(cc, cn0 < cn1 ? cn0 : 0, cn0 < cn1); });
+    for (int cn = cn0; cn < cn1; ++cn) {
+        const bool more = cn + 1 < cn1;
+        static_for<NC>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            cf d[4], q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = dl[dlo + NW * (4 * c + e) * K];
+            inner4(d, zb[c], k, q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * c + e;
+                const cf r = q[e] - mk<float>(sa_readlane(sb[c].re, e), sa_readlane(sb[c].im, e));
+                s_r2 += cabs2(r);
+                s_q2 += cabs2(q[e]);
+                acc[i] = acc[i] + cmulc(zb[c][e], r);
+            }
+            {
+                float &dep = acc[4 * c + 3].re;
+                SA_VGPR_FENCE3(dep, ko, so);
+                SA_VGPR_FENCE3(dep, dlo, dlo);
+            }
+            request(cc, more ? cn + 1 : cn, more);
+        });
+    }
+    if (a.gpart) {
+        cf *gp = a.gpart + (int64_t)g * H * Wf * K;
+#pragma unroll
+        for (int i = 0; i < N1; ++i) gp[((int64_t)(NW * i + w) * Wf + wf) * K + k] = acc[i];
+    }
+    const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
+    double accd[4] = {k == 0 ? (double)s_r2 : 0.0, k == 0 ? (double)s_r2 * pw : 0.0,
+                      k == 0 ? (double)s_q2 : 0.0, 0.0};
+    block_sum_store<4>(accd, scratch, a.partials + (int64_t)blockIdx.x * 4);
+}
+template <int NW> static void launch_ccmod_ahead(hipStream_t st, const CcmodTiledArgs<float> &a, unsigned grid) {
+    const size_t lds = sizeof(cf) * 16 * NW * 64 + sizeof(double) * 4 * 16;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first())
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ccmod_grad_tiled_ahead_kernel<NW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((ccmod_grad_tiled_ahead_kernel<NW>), dim3(grid), dim3(NW * 64), lds, st, a);
+}
+
 // K > 64, between the two passes: r = sum_slab qpart - sf per frequency of a tile, and the sums
 // of the one-pass kernel per tile
 __global__ void __launch_bounds__(256) ccmod_resid_sum_kernel(const CcmodTiledArgs<float> a, int NH) {
@@ -723,10 +819,10 @@ template <> int64_t launch_ccmod_grad_tiled<float>(hipStream_t st, const CcmodTi
         return ntiles;
     }
     if (a.H == 128) {
-        if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<4, 64>), dim3(grid), dim3(256), lds, st, a);
+        if (a.K == 64) launch_ccmod_ahead<8>(st, a, grid);
         else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<4, 0>), dim3(grid), dim3(256), lds, st, a);
     } else if (a.H == 256) {
-        if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 64>), dim3(grid), dim3(512), lds, st, a);
+        if (a.K == 64) launch_ccmod_ahead<16>(st, a, grid);
         else hipLaunchKernelGGL((ccmod_grad_tiled_kernel<8, 0>), dim3(grid), dim3(512), lds, st, a);
     } else {
         if (a.K == 64) hipLaunchKernelGGL((ccmod_grad_tiled_kernel<16, 64>), dim3(grid), dim3(1024), lds, st, a);
