@@ -400,3 +400,32 @@ def test_pgm_ccmod_dimN1(backend):
     with pytest.raises(NotImplementedError):
         ccmod.ConvCnstrMOD(None, np.zeros((32, 2, 3)), (5, 2, 4), ccmod.ConvCnstrMOD.Options({'ZeroMean': True}),
                            dimK=1, dimN=1)
+
+
+def test_tiled_gradient_at_256_vs_numpy(backend):
+    """One pgm.ccmod.ConvCnstrMOD iteration at 256 x 256, K = 64 (the dictionary-learning shape of
+    BASELINE configs[4]; N = 2 keeps the CPU simulator to seconds): the tile-major gradient kernel of
+    that shape -- a whole tile requested ahead, 16 rows per thread, csrc/csc_pgm.hip
+    ccmod_grad_tiled_ahead_kernel<16> -- against the NumPy restatement of pgm/ccmod.py:295-323."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd import _lib
+    from sporco_amd.pgm import ccmod
+    H, W, K, N = 256, 256, 64, 2
+    rng = np.random.RandomState(506)
+    Z = (rng.randn(H, W, 1, N, K) * (rng.rand(H, W, 1, N, K) < 0.02)).astype(np.float32)
+    S = rng.randn(H, W, N).astype(np.float32)
+    D0 = orc.pcn(rng.randn(H, W, 1, 1, K), (8, 8, K), (H, W)).astype(np.float32)
+    L = 14.0 * N * 50
+    c = ccmod.ConvCnstrMOD(Z, S, (8, 8, K), ccmod.ConvCnstrMOD.Options({'MaxMainIter': 1, 'L': L, 'X0': D0}))
+    assert c.dev.uses_fused_rows() and 1 <= c.dev.query(_lib.QUERY_CCMOD_GROUPS) <= N
+    c.solve()
+    Zf = np.fft.rfftn(Z.astype(np.float64), axes=(0, 1))
+    Sf = np.fft.rfftn(S.astype(np.float64).reshape(H, W, 1, N, 1), axes=(0, 1))
+    Df = np.fft.rfftn(D0.astype(np.float64), axes=(0, 1))
+    R = np.sum(Zf * Df, axis=4, keepdims=True) - Sf
+    G = np.sum(np.conj(Zf) * R, axis=3, keepdims=True)
+    D1 = orc.pcn(np.fft.irfftn(Df - G / L, (H, W), axes=(0, 1)), (8, 8, K), (H, W))
+    assert rel_l2(c.getdict(crop=False), D1) < 1e-5
+    R1 = np.sum(Zf * np.fft.rfftn(D1, axes=(0, 1)), axis=4, keepdims=True) - Sf
+    dfid = 0.5 * np.sum(np.fft.irfftn(R1, (H, W), axes=(0, 1)) ** 2)
+    assert abs(c.getitstat().DFid[-1] - dfid) < 1e-5 * dfid
