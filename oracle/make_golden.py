@@ -149,6 +149,32 @@ def gen_dim1_dl():
          **itstat_dict(c))
 
 
+def gen_dim1_dstep():
+    """dimN = 1 in the ADMM dictionary updates (sporco/admm/ccmod.py with one-dimensional signals)
+    alone and as the D-step of ConvBPDNDictLearn."""
+    rng = np.random.RandomState(1003)
+    N, K, M, w = 48, 4, 5, 7
+    S = rng.randn(N, K)
+    Z = rng.randn(N, 1, K, M) * (rng.rand(N, 1, K, M) > 0.5)
+    D0 = rng.randn(w, M)
+    for meth, cls in (('ism', ref_admm_ccmod.ConvCnstrMOD_IterSM), ('cg', ref_admm_ccmod.ConvCnstrMOD_CG),
+                      ('cns', ref_admm_ccmod.ConvCnstrMOD_Consensus)):
+        optd = {'MaxMainIter': 15, 'ZeroMean': True, 'LinSolveCheck': True}
+        if meth == 'cg':
+            optd['CG'] = {'MaxIter': 500, 'StopTol': 1e-9}
+        c = cls(Z, S, (w, M), cls.Options(optd), dimK=1, dimN=1)
+        c.solve()
+        optl = {'MaxMainIter': 8, 'AccurateDFid': True, 'CCMOD': {'ZeroMean': True}}
+        if meth == 'cg':
+            optl['CCMOD']['CG'] = {'MaxIter': 500, 'StopTol': 1e-9}
+        b = ref_cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, ref_cbpdndl.ConvBPDNDictLearn.Options(
+            optl, xmethod='admm', dmethod=meth), xmethod='admm', dmethod=meth, dimK=1, dimN=1)
+        D1 = b.solve()
+        save('ccmod_dim1_%s_f64' % meth, Z=Z, S=S, D0=D0, dsz=np.array((w, M)), D=c.getdict(), Y=c.Y, X=c.X,
+             U=c.U, k_final=np.int64(c.k), dl_D1=D1, dl_X=b.getcoef(), dl_ObjFun=np.array(b.getitstat().ObjFun),
+             **itstat_dict(c))
+
+
 def gen_admm():
     np.random.seed(12345)
     D = np.random.randn(5, 5, 4)
@@ -1491,7 +1517,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
-             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'ccmod_cplx': gen_ccmod_cplx,
+             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'dim1_dstep': gen_dim1_dstep, 'ccmod_cplx': gen_ccmod_cplx,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -54,6 +54,8 @@ class ConvCnstrMODMaskDcplBase(ccmod.ConvCnstrMODBase):
                 self['fEvalX'] = value is not True
                 self['gEvalY'] = value is True
 
+    _signals_ok = False
+
     def __init__(self, Z, S, W, dsz, opt=None, dimK=1, dimN=2, device=0, stream=None, dev=None):
         if opt is None:
             opt = type(self).Options()

@@ -163,14 +163,12 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         if self._dim1:
             # signals: both steps run them as images with a unit first axis (admm/cbpdn.py,
             # pgm/ccmod.py); the set-up arithmetic below does the same and drops the axis again
-            if dmethod != 'pgm' or xmethod not in ('admm', 'pgm'):
-                raise NotImplementedError("dimN = 1 is offered with xmethod 'admm' / 'pgm' and "
-                                          "dmethod 'pgm'")
             from ..pgm.ccmod import _dsz_unit_axis
             cri = cr.CDU_ConvRepIndexing(_dsz_unit_axis(dsz), np.asarray(S)[np.newaxis], dimK, 2)
             D0 = cr.Pcn(np.asarray(D0)[np.newaxis], _dsz_unit_axis(dsz), cri.Nv, 2, cri.dimCd,
                         crp=True, zm=opt['CCMOD', 'ZeroMean'])
-            opt['CCMOD'].update({'X0': cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, 2), cri.Nv)})
+            opt['CCMOD'].update({('X0' if dmethod == 'pgm' else 'Y0'):
+                                 cr.zpad(cr.stdformD(D0, cri.Cd, cri.M, 2), cri.Nv)})
             D0 = D0[0]
         else:
             cri = cr.CDU_ConvRepIndexing(dsz, S, dimK, dimN)

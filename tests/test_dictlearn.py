@@ -370,9 +370,6 @@ def test_dictlearn_dimN1_signals(backend, name, xm):
     errs = trace_errors(b.getitstat(), g)
     assert {'ObjFun', 'DFid', 'RegL1', 'D_L', 'D_Rsdl'} <= set(errs) and max(errs.values()) < 1e-9, errs
     assert rel_l2(b.xstep.D[0], D1) == 0.0 and b.getdict(crop=False).shape == (g['S'].shape[0],) + D1.shape[1:]
-    with pytest.raises(NotImplementedError):
-        cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], 0.1, cbpdndl.ConvBPDNDictLearn.Options(
-            {}, xmethod='admm', dmethod='cns'), xmethod='admm', dmethod='cns', dimK=1, dimN=1)
 
 
 def test_pgm_ccmod_dimN1(backend):
@@ -429,3 +426,38 @@ def test_tiled_gradient_at_256_vs_numpy(backend):
     R1 = np.sum(Zf * np.fft.rfftn(D1, axes=(0, 1)), axis=4, keepdims=True) - Sf
     dfid = 0.5 * np.sum(np.fft.irfftn(R1, (H, W), axes=(0, 1)) ** 2)
     assert abs(c.getitstat().DFid[-1] - dfid) < 1e-5 * dfid
+
+
+@pytest.mark.parametrize('meth', ['ism', 'cg', 'cns'])
+def test_admm_dictionary_updates_dimN1(backend, meth):
+    """dimN = 1 in the ADMM dictionary updates (admm/ccmod.py) alone and as the D-step of
+    ConvBPDNDictLearn, against reference runs; CG is run to 1e-9."""
+    from sporco_amd.admm import ccmod
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden('ccmod_dim1_%s_f64' % meth)
+    cls = {'ism': ccmod.ConvCnstrMOD_IterSM, 'cg': ccmod.ConvCnstrMOD_CG, 'cns': ccmod.ConvCnstrMOD_Consensus}[meth]
+    tol = 1e-7 if meth == 'cg' else 1e-9
+    optd = {'MaxMainIter': 15, 'ZeroMean': True, 'LinSolveCheck': True}
+    if meth == 'cg':
+        optd['CG'] = {'MaxIter': 500, 'StopTol': 1e-9}
+    dsz = tuple(int(v) for v in g['dsz'])
+    c = cls(g['Z'], g['S'], dsz, cls.Options(optd), dimK=1, dimN=1)
+    Y = c.solve()
+    assert c.k == int(g['k_final'])
+    for a, name in ((Y, 'Y'), (c.getdict(), 'D'), (c.X, 'X'), (c.U, 'U')):
+        assert a.shape == g[name].shape and rel_l2(a, g[name]) < tol, name
+    errs = trace_errors(c.getitstat(), g)
+    assert {'DFid', 'PrimalRsdl', 'DualRsdl', 'Rho'} <= set(errs) and max(errs[f] for f in ('DFid', 'PrimalRsdl', 'DualRsdl', 'Rho')) < tol, errs
+    if meth != 'cns':
+        assert c.reconstruct().shape == g['S'].shape[0:1] + (1,) + g['S'].shape[1:]
+    # the setters take the reference's shapes
+    c.Y, c.U = c.Y.copy(), c.U.copy()
+    assert rel_l2(c.Y, g['Y']) < tol
+    optl = {'MaxMainIter': 8, 'AccurateDFid': True, 'CCMOD': {'ZeroMean': True}}
+    if meth == 'cg':
+        optl['CCMOD']['CG'] = {'MaxIter': 500, 'StopTol': 1e-9}
+    b = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], 0.1, cbpdndl.ConvBPDNDictLearn.Options(
+        optl, xmethod='admm', dmethod=meth), xmethod='admm', dmethod=meth, dimK=1, dimN=1)
+    D1 = b.solve()
+    assert D1.shape == g['dl_D1'].shape and rel_l2(D1, g['dl_D1']) < tol
+    assert rel_l2(b.getcoef(), g['dl_X']) < tol and rel_l2(b.getitstat().ObjFun, g['dl_ObjFun']) < tol
