@@ -146,6 +146,18 @@ int sporco_amd_csc_create(const sporco_amd_dims *dims, int device, void *stream,
  * sporco_amd_csc_create. */
 int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels, int device,
                              void *stream, sporco_amd_csc_t *out);
+/* Volumes -- three spatial axes, dimN = 3 of sporco/cnvrep.py:33-198 (the constructor contract of
+ * sporco/admm/cbpdn.py:175; the reference's examples/scripts/cdl/cbpdndl_video.py:74 is the use):
+ * arrays (depth, height, W, C, N, K) are handed over as they lie in memory with dims->H =
+ * depth * height, and `depth` tells the handle where the folded axis splits.  Everything per
+ * pixel / frequency / row is unchanged on the folded array; the transform along the folded axis
+ * runs as two passes.  Single-channel dictionary, given zero-padded to the full volume
+ * (sporco_amd_csc_set_dict with dH = dims->H, dW = dims->W).  Such a handle serves the ADMM sparse
+ * coding calls (set_signal, set_dict, set_l1_weight, upload / download, admm_iter / _run and the
+ * staged steps, reconstruct, dhs_absmax, asum) without NoBndryCross / gradient term / AddMaskSim;
+ * every other entry point returns SPORCO_AMD_EINVAL for it.  Generic transform chain. */
+int sporco_amd_csc_create_volume(const sporco_amd_dims *dims, int32_t depth, int device, void *stream,
+                                 sporco_amd_csc_t *out);
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
 int sporco_amd_csc_sync(sporco_amd_csc_t h);
 /* The hipStream_t every launch of this handle goes to (the `stream` given at creation, or the

@@ -175,6 +175,27 @@ def gen_dim1_dstep():
              **itstat_dict(c))
 
 
+def gen_dim3():
+    """dimN = 3: volumes (sporco/cnvrep.py:33-198 with three spatial axes; the reference's
+    examples/scripts/cdl/cbpdndl_video.py:74 is the use).  A single volume, two volumes with
+    NonNegCoef, three channels with the joint l2,1 term and a per-filter L1Weight; FISTA with
+    backtracking on the two volumes."""
+    rng = np.random.RandomState(1004)
+    D = rng.randn(3, 4, 4, 4)
+    admm_case('admm_dim3_single_f64', D, rng.randn(6, 12, 10), 0.1, {'MaxMainIter': 25}, dimN=3)
+    admm_case('admm_dim3_multi_f64', D, rng.randn(6, 12, 10, 2), 0.1, {'MaxMainIter': 25, 'NonNegCoef': True},
+              dimK=1, dimN=3)
+    w = np.abs(rng.randn(1, 1, 1, 1, 1, 4)) + 0.5
+    admm_case('admm_dim3_joint_f64', D, rng.randn(5, 9, 8, 3), 0.05, {'MaxMainIter': 20, 'L1Weight': w},
+              dimK=0, joint_mu=0.02, dimN=3)
+    S = rng.randn(6, 12, 10, 2)
+    opt = ref_pgm_cbpdn.ConvBPDN.Options({'MaxMainIter': 25, 'L': 100.0, 'Backtrack': BacktrackStandard()})
+    b = ref_pgm_cbpdn.ConvBPDN(D, S, 0.1, opt, dimK=1, dimN=3)
+    X = b.solve()
+    save('pgm_dim3_f64', D=D, S=S, lmbda=np.float64(0.1), X=X, k_final=np.int64(b.k), recon=b.reconstruct(),
+         **itstat_dict(b))
+
+
 def gen_admm():
     np.random.seed(12345)
     D = np.random.randn(5, 5, 4)
@@ -1517,7 +1538,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
-             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'dim1_dstep': gen_dim1_dstep, 'ccmod_cplx': gen_ccmod_cplx,
+             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'dim3': gen_dim3, 'dim1_dstep': gen_dim1_dstep, 'ccmod_cplx': gen_ccmod_cplx,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -55,7 +55,7 @@ PGM_F, PGM_DFID, PGM_L1, PGM_HESS, PGM_RSDL, PGM_FY, PGM_LIN, PGM_DXY2 = range(8
 
 EXPORTS = (
     'sporco_amd_version', 'sporco_amd_last_error', 'sporco_amd_device_count',
-    'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc',
+    'sporco_amd_device_info', 'sporco_amd_csc_create', 'sporco_amd_csc_create_mc', 'sporco_amd_csc_create_volume',
     'sporco_amd_csc_destroy',
     'sporco_amd_csc_sync', 'sporco_amd_csc_stream', 'sporco_amd_csc_query', 'sporco_amd_csc_placement_report', 'sporco_amd_csc_set_hint', 'sporco_amd_csc_set_signal', 'sporco_amd_csc_set_dict', 'sporco_amd_csc_set_dict_imag',
     'sporco_amd_csc_set_l1_weight', 'sporco_amd_csc_set_l21_weight',
@@ -218,6 +218,7 @@ def load(path=None):
     lib.sporco_amd_csc_create_mc.argtypes = [ctypes.POINTER(Dims), ctypes.c_int32, ctypes.c_int,
                                              ctypes.c_void_p,
                                              ctypes.POINTER(ctypes.c_void_p)]
+    lib.sporco_amd_csc_create_volume.argtypes = lib.sporco_amd_csc_create_mc.argtypes
     vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
     dptr = ctypes.POINTER(ctypes.c_double)
     pptr = ctypes.POINTER(AdmmParams)
@@ -395,10 +396,13 @@ def _carr(a, dtype):
 class Solver(object):
     """Owner of one device-side ConvBPDN problem (opaque C handle)."""
 
-    def __init__(self, H, W, C, N, K, dtype, device=0, stream=None, Cd=1):
+    def __init__(self, H, W, C, N, K, dtype, device=0, stream=None, Cd=1, depth=1):
         """``C``: channels of the signal.  ``Cd`` > 1 (== C): multi-channel dictionary, the
-        coefficient arrays then have a single channel (cnvrep.py:186-194)."""
+        coefficient arrays then have a single channel (cnvrep.py:186-194).  ``depth`` > 1: a
+        volume handle (dimN = 3), ``H`` = depth * height (include/sporco_amd.h
+        sporco_amd_csc_create_volume)."""
         self.Cd = int(Cd)
+        self.depth = int(depth)
         self.Cs = int(C)
         self.dims = (int(H), int(W), 1 if self.Cd > 1 else int(C), int(N), int(K))
         self.dtype = np.dtype(dtype)
@@ -406,9 +410,13 @@ class Solver(object):
                                else np.complex128)
         d = Dims(int(H), int(W), int(C), int(N), int(K), dtype_code(dtype))
         h = ctypes.c_void_p()
-        check(lib().sporco_amd_csc_create_mc(ctypes.byref(d), self.Cd, int(device),
-                                             ctypes.c_void_p(stream or 0),
-                                             ctypes.byref(h)))
+        if self.depth > 1:
+            check(lib().sporco_amd_csc_create_volume(ctypes.byref(d), self.depth, int(device),
+                                                     ctypes.c_void_p(stream or 0), ctypes.byref(h)))
+        else:
+            check(lib().sporco_amd_csc_create_mc(ctypes.byref(d), self.Cd, int(device),
+                                                 ctypes.c_void_p(stream or 0),
+                                                 ctypes.byref(h)))
         self._h = h
         self._lib = lib()
 

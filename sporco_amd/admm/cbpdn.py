@@ -136,9 +136,24 @@ class GenericConvBPDN(admm.ADMMEqual):
             for key in ('L1Weight', 'L21Weight', 'Y0', 'U0'):
                 if key in opt and opt[key] is not None and np.ndim(opt[key]) > 0:
                     opt[key] = np.asarray(opt[key])[np.newaxis]
+        # dimN = 3 (volumes; the reference's examples/scripts/cdl/cbpdndl_video.py:74 is the use): the
+        # first two axes folded into one -- (depth, height, W, ...) IS (depth * height, W, ...) in
+        # memory -- on a handle that knows where the folded axis splits and runs the transform along
+        # it as two passes (include/sporco_amd.h sporco_amd_csc_create_volume); the dictionary is
+        # handed over zero-padded to the volume.  X / Y / U, solve(), getcoef(), reconstruct() keep
+        # the reference's six-axis shapes; ``D`` is the folded, zero-padded array.
+        self._dim3 = None
+        if dimN == 3 and self._dim1_ok and self._S_dev is None:
+            if opt['NoBndryCross']:
+                raise NotImplementedError("dimN = 3: NoBndryCross is not offered")
+            self._dim3, D, S = cr.volume_problem(D, S, dimK)
+            dimK, dimN = 1, 2
+            for key in ('L1Weight', 'L21Weight', 'Y0', 'U0'):
+                if key in opt and opt[key] is not None and np.ndim(opt[key]) > 0:
+                    opt[key] = self._fold(np.asarray(opt[key]))
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, for ConvBPDN / "
-                                      "ConvBPDNJoint, dimN = 1 (signals)")
+                                      "ConvBPDNJoint, dimN = 1 (signals) and 3 (volumes)")
         if not (np.isrealobj(D) and (self._S_dev is not None or np.isrealobj(S))):
             raise NotImplementedError("sporco_amd handles real-valued D and S")
         self.real_dtype = True
@@ -170,6 +185,14 @@ class GenericConvBPDN(admm.ADMMEqual):
             self._dev.set_signal(self.S)
         self.setdict()
 
+    def _fold(self, a):
+        """(depth, height, ...) -> (depth * height, ...) of a dimN = 3 array; arrays that broadcast
+        along both axes lose one of the two unit axes."""
+        return cr.fold3(a, *self._dim3)
+
+    def _unfold(self, a):
+        return cr.unfold3(a, *self._dim3)
+
     @property
     def S(self):
         """The signal in the internal layout; for a device-resident input, a host copy made
@@ -195,7 +218,8 @@ class GenericConvBPDN(admm.ADMMEqual):
     def _new_handle(self):
         H, W = self.cri.Nv
         self._dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                device=self._device, stream=self._stream, Cd=self.cri.Cd)
+                                device=self._device, stream=self._stream, Cd=self.cri.Cd,
+                                depth=self._dim3[0] if getattr(self, '_dim3', None) else 1)
         self._cache = {}
         self._no_x = getattr(self, '_no_x', False)   # promise that X / Xf will not be read
         self._u_scale = 1.0      # pending `U /= rsf` (admm.py:573), applied lazily
@@ -215,6 +239,8 @@ class GenericConvBPDN(admm.ADMMEqual):
                 a *= a.dtype.type(self._u_scale)
             if getattr(self, '_dim1', False) and a.ndim >= 2 and a.shape[0] == 1:
                 a = a[0]       # (dimN = 1: the unit axis stays inside)
+            if getattr(self, '_dim3', None):
+                a = self._unfold(a)
             self._cache[var] = a
         return self._cache[var]
 
@@ -224,6 +250,8 @@ class GenericConvBPDN(admm.ADMMEqual):
         value = np.asarray(value)
         if getattr(self, '_dim1', False) and value.ndim == len(self.cri.shpX) - 1:
             value = value[np.newaxis]
+        if getattr(self, '_dim3', None) and value.ndim == len(self.cri.shpX) + 1:
+            value = self._fold(value)
         self._dev.upload(var, value)
         if var == _lib.VAR_U:
             self._u_scale = 1.0
@@ -274,6 +302,11 @@ class GenericConvBPDN(admm.ADMMEqual):
             D = np.asarray(D, dtype=self.dtype)
             if getattr(self, '_dim1', False) and D.ndim == len(self.cri.shpD) - 1:
                 D = D[np.newaxis]
+            if getattr(self, '_dim3', None) and D.shape[0] != self.cri.Nv[0]:
+                # (a dictionary in the reference's dimN = 3 shapes: zero-padded to the volume, folded)
+                Dz, Hs = self._dim3
+                D = D.reshape(D.shape[0:3] + (1, 1, D.shape[-1]))
+                D = self._fold(cr.zpad(D, (Dz, Hs, self.cri.Nv[1])))
             self.D = D
         self._dev.set_dict(self.D)
         self._touch(_lib.VAR_DF)
@@ -579,10 +612,14 @@ class GenericConvBPDN(admm.ADMMEqual):
             X = np.asarray(X, dtype=self.dtype)
             if getattr(self, '_dim1', False) and X.ndim == len(self.cri.shpX) - 1:
                 X = X[np.newaxis]
+            if getattr(self, '_dim3', None) and X.ndim == len(self.cri.shpX) + 1:
+                X = self._fold(X)
             self._dev.upload(_lib.VAR_AX, X)
             self._touch(_lib.VAR_AX)
             var = _lib.VAR_AX
         r = self._dev.reconstruct(var)[..., 0]
+        if getattr(self, '_dim3', None):
+            return self._unfold(r)
         return r[0] if getattr(self, '_dim1', False) else r
 
     # -- per-kernel timing ---------------------------------------------------------------------

@@ -167,6 +167,34 @@ def mskWshape(W, cri):
 
 # -- dictionary constraint set -------------------------------------------------
 
+def fold3(a, Dz, Hs):
+    """(depth, height, ...) -> (depth * height, ...): how the dimN = 3 arrays reach the device (the
+    memory layout is the same); arrays that broadcast along both axes lose one of the unit axes."""
+    if a.shape[0:2] == (Dz, Hs):
+        return a.reshape((Dz * Hs,) + a.shape[2:])
+    if a.shape[0:2] == (1, 1):
+        return a[0]
+    raise ValueError("dimN = 3: an array of shape %s neither spans nor broadcasts along the first "
+                     "two axes" % (a.shape,))
+
+
+def unfold3(a, Dz, Hs):
+    return a.reshape((Dz, Hs) + a.shape[1:]) if a.ndim >= 1 and a.shape[0] == Dz * Hs else a
+
+
+def volume_problem(D, S, dimK):
+    """The folded two-dimensional problem of a dimN = 3 one: ((depth, height), folded zero-padded
+    single-channel dictionary (depth * height, W, M), folded signal (depth * height, W, C, K))."""
+    D, S = np.asarray(D), np.asarray(S)
+    c3 = CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=3)
+    if c3.Cd > 1:
+        raise NotImplementedError("dimN = 3: single-channel dictionary")
+    Dz, Hs = int(c3.Nv[0]), int(c3.Nv[1])
+    D2 = fold3(zpad(D.reshape(c3.shpD), c3.Nv), Dz, Hs)[:, :, 0, 0]
+    S2 = fold3(S.reshape(c3.shpS), Dz, Hs)[..., 0]
+    return (Dz, Hs), D2, S2
+
+
 def zpad(v, Nv):
     """Zero-pad the leading axes of ``v`` to ``Nv``."""
     out = np.zeros(tuple(Nv) + v.shape[len(Nv):], dtype=v.dtype)

@@ -58,6 +58,23 @@ int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels,
     SA_API_END
 }
 
+int sporco_amd_csc_create_volume(const sporco_amd_dims *dims, int32_t depth, int device, void *stream,
+                                 sporco_amd_csc_t *out) {
+    SA_API_BEGIN
+    SA_REQUIRE(dims && out, "null argument");
+    SA_REQUIRE(depth >= 1 && dims->H % depth == 0, "depth must divide the folded first axis dims->H");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        throw Error(SPORCO_AMD_EHIP, "no HIP device visible: libsporco_amd needs an AMD GPU");
+    SA_REQUIRE(device >= 0 && device < n, "device index out of range");
+    std::unique_ptr<sporco_amd_csc> h(new sporco_amd_csc);
+    h->device = device;
+    h->depth = depth;
+    h->impl.reset(make_csc(*dims, 1, device, stream, depth));
+    *out = h.release();
+    SA_API_END
+}
+
 int sporco_amd_csc_destroy(sporco_amd_csc_t h) {
     SA_API_BEGIN
     if (h) {
@@ -69,14 +86,14 @@ int sporco_amd_csc_destroy(sporco_amd_csc_t h) {
 
 int sporco_amd_csc_sync(sporco_amd_csc_t h) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->sync();
     SA_API_END
 }
 
 int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(stream, "null argument");
     *stream = h->impl->stream_handle();
     SA_API_END
@@ -84,14 +101,14 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream) {
 
 int sporco_amd_csc_set_hint(sporco_amd_csc_t h, int what, int value) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->set_hint(what, value);
     SA_API_END
 }
 
 int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "null output pointer");
     *out = h->impl->query(what);
     SA_API_END
@@ -99,7 +116,7 @@ int sporco_amd_csc_query(sporco_amd_csc_t h, int what, int *out) {
 
 int sporco_amd_csc_placement_report(sporco_amd_csc_t h, char *buf, size_t cap) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(buf != nullptr && cap > 0, "null or empty report buffer");
     const std::string r = h->impl->placement();
     std::snprintf(buf, cap, "%s", r.c_str());
@@ -108,7 +125,7 @@ int sporco_amd_csc_placement_report(sporco_amd_csc_t h, char *buf, size_t cap) {
 
 int sporco_amd_csc_set_signal(sporco_amd_csc_t h, const void *S) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(S != nullptr, "S is null");
     h->impl->set_signal(S);
     SA_API_END
@@ -116,7 +133,7 @@ int sporco_amd_csc_set_signal(sporco_amd_csc_t h, const void *S) {
 
 int sporco_amd_csc_set_dict(sporco_amd_csc_t h, const void *D, int32_t dH, int32_t dW) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(D != nullptr, "D is null");
     h->impl->set_dict(D, dH, dW);
     SA_API_END
@@ -131,7 +148,7 @@ int sporco_amd_csc_set_dict_imag(sporco_amd_csc_t h, const void *D_imag, int32_t
 
 int sporco_amd_csc_set_l1_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
     h->impl->set_weight(0, w, shape);
     SA_API_END
@@ -139,7 +156,7 @@ int sporco_amd_csc_set_l1_weight(sporco_amd_csc_t h, const void *w, const int64_
 
 int sporco_amd_csc_set_l21_weight(sporco_amd_csc_t h, const void *w, const int64_t shape[5]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(w == nullptr || shape != nullptr, "shape is null");
     h->impl->set_weight(1, w, shape);
     SA_API_END
@@ -170,7 +187,7 @@ int sporco_amd_csc_set_filter_sizes(sporco_amd_csc_t h, const int32_t *fh, const
 
 int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(src != nullptr, "src is null");
     h->impl->upload(var, src);
     SA_API_END
@@ -178,7 +195,7 @@ int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src) {
 
 int sporco_amd_csc_download(sporco_amd_csc_t h, int var, void *dst) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(dst != nullptr, "dst is null");
     h->impl->download(var, dst);
     SA_API_END
@@ -186,7 +203,7 @@ int sporco_amd_csc_download(sporco_amd_csc_t h, int var, void *dst) {
 
 int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(ptr_dev != nullptr, "ptr_dev is null");
     *ptr_dev = h->impl->device_ptr(var);
     SA_API_END
@@ -195,7 +212,7 @@ int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev) {
 int sporco_amd_csc_admm_iter(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
                              double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p && out, "null argument");
     h->impl->admm_iter(*p, h->impl->out_dev_default);
     h->impl->read_out(h->impl->out_dev_default, out);
@@ -207,7 +224,7 @@ int sporco_amd_csc_admm_run(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
                             int32_t *n_done, double *rho_out, double *u_scale_out,
                             sporco_amd_reduce_fn reduce, void *user) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p && c && records && n_done && rho_out && u_scale_out, "null argument");
     const int n = h->impl->admm_run(*p, *c, records, rho_out, u_scale_out, reduce, user);
     if (n < 0) {
@@ -221,7 +238,7 @@ int sporco_amd_csc_admm_run(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
 int sporco_amd_csc_admm_iter_dev(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
                                  double *out_dev) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p && out_dev, "null argument");
     h->impl->admm_iter(*p, out_dev);
     SA_API_END
@@ -230,7 +247,7 @@ int sporco_amd_csc_admm_iter_dev(sporco_amd_csc_t h, const sporco_amd_admm_param
 int sporco_amd_csc_admm_xstep(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
                               double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p && out, "null argument");
     h->impl->admm_xstep(*p, h->impl->out_dev_default);
     h->impl->read_out(h->impl->out_dev_default, out);
@@ -239,14 +256,14 @@ int sporco_amd_csc_admm_xstep(sporco_amd_csc_t h, const sporco_amd_admm_params *
 
 int sporco_amd_csc_admm_relax(sporco_amd_csc_t h, double rlx) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->admm_relax(rlx);
     SA_API_END
 }
 
 int sporco_amd_csc_admm_ystep(sporco_amd_csc_t h, const sporco_amd_admm_params *p) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p, "null argument");
     h->impl->admm_ystep(*p);
     SA_API_END
@@ -254,7 +271,7 @@ int sporco_amd_csc_admm_ystep(sporco_amd_csc_t h, const sporco_amd_admm_params *
 
 int sporco_amd_csc_admm_ustep(sporco_amd_csc_t h, const sporco_amd_admm_params *p) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p, "null argument");
     h->impl->admm_ustep(*p);
     SA_API_END
@@ -263,7 +280,7 @@ int sporco_amd_csc_admm_ustep(sporco_amd_csc_t h, const sporco_amd_admm_params *
 int sporco_amd_csc_admm_stats(sporco_amd_csc_t h, const sporco_amd_admm_params *p,
                               double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p && out, "null argument");
     h->impl->admm_stats(*p, h->impl->out_dev_default);
     h->impl->read_out(h->impl->out_dev_default, out);
@@ -272,14 +289,14 @@ int sporco_amd_csc_admm_stats(sporco_amd_csc_t h, const sporco_amd_admm_params *
 
 int sporco_amd_csc_scale_u(sporco_amd_csc_t h, double s) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->scale_u(s);
     SA_API_END
 }
 
 int sporco_amd_csc_reconstruct(sporco_amd_csc_t h, int var, void *dst) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(dst != nullptr, "dst is null");
     h->impl->reconstruct(var, dst);
     SA_API_END
@@ -287,7 +304,7 @@ int sporco_amd_csc_reconstruct(sporco_amd_csc_t h, int var, void *dst) {
 
 int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     h->impl->dhs_absmax(out);
     SA_API_END
@@ -303,7 +320,7 @@ static double *stats_buf(sporco_amd_csc_t h) {
 
 int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->pgm_grad(var, sb);
@@ -313,7 +330,7 @@ int sporco_amd_csc_pgm_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_O
 
 int sporco_amd_csc_pgm_commit(sporco_amd_csc_t h) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->pgm_commit();
     SA_API_END
 }
@@ -329,7 +346,7 @@ int sporco_amd_csc_pgm_iter(sporco_amd_csc_t h, const sporco_amd_pgm_params *p,
 
 int sporco_amd_csc_pgm_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->pgm_eval(var, sb);
@@ -340,7 +357,7 @@ int sporco_amd_csc_pgm_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_O
 int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uint32_t flags,
                                  int32_t dH, int32_t dW, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(L > 0.0, "L must be positive");
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
@@ -352,7 +369,7 @@ int sporco_amd_csc_pgm_prox_step(sporco_amd_csc_t h, double L, double lmbda, uin
 int sporco_amd_csc_lincomb(sporco_amd_csc_t h, int dst, double a, int va, double b, int vb,
                            double c, int vc) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->lincomb(dst, a, va, b, vb, c, vc);
     SA_API_END
 }
@@ -360,7 +377,7 @@ int sporco_amd_csc_lincomb(sporco_amd_csc_t h, int dst, double a, int va, double
 int sporco_amd_csc_pair_stats(sporco_amd_csc_t h, int va, int vb, int vg,
                               double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->pair_stats(va, vb, vg, sb);
@@ -388,21 +405,21 @@ int sporco_amd_csc_pgm_resid_stats(sporco_amd_csc_t h, int a, int b, int c, int 
 
 int sporco_amd_csc_fft_var(sporco_amd_csc_t h, int real_var, int cplx_var) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->fft_var(real_var, cplx_var, false);
     SA_API_END
 }
 
 int sporco_amd_csc_ifft_var(sporco_amd_csc_t h, int cplx_var, int real_var) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->fft_var(real_var, cplx_var, true);
     SA_API_END
 }
 
 int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->copy(dst_var, src_var);
     SA_API_END
 }
@@ -578,7 +595,7 @@ int sporco_amd_csc_dstep_iter(sporco_amd_csc_t h, const sporco_amd_dstep_params 
 
 int sporco_amd_csc_asum(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->asum(var, sb);
@@ -588,7 +605,7 @@ int sporco_amd_csc_asum(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_C
 
 int sporco_amd_csc_profile(sporco_amd_csc_t h, int enable) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->sync();
     h->impl->prof.drain();
     if (enable) {
@@ -610,7 +627,7 @@ int sporco_amd_profile_slots(void) { return PS_COUNT; }
 int sporco_amd_csc_profile_read(sporco_amd_csc_t h, int slot, const char **name, double *total_ms,
                                 int64_t *launches) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(slot >= 0 && slot < PS_COUNT, "timing slot out of range");
     h->impl->prof.drain();
     if (name) *name = kProfNames[slot];

@@ -119,6 +119,14 @@ template <typename T> struct Csc : CscBase {
     double ism_rho = 0.0, ism_mu = -1.0;   // (ism_mu: mu of the gradient diagonal, -1 = none)
     int64_t P, E, npix, EF;  // P = C*N*K, E = H*W*P, npix = H*Wf, EF = npix*P
     FftPlan planW, planH;
+    // Volumes (dimN = 3, sporco/cnvrep.py:33-198 with three spatial axes): the first two axes
+    // (depth, height) arrive folded into H = depth * Hs -- the memory layout (depth, Hs, W, C, N, K)
+    // IS the layout (H, W, C, N, K) -- and everything per pixel, per frequency or per row works on
+    // the folded array as it stands; only the transform along the folded axis is two passes, Hs
+    // then depth (api_transforms.inc fwd2 / inv2).  Generic chain only, ADMM sparse coding only
+    // (the C ABI refuses the other entry points: csc_impl.h SA_HANDLE).
+    int depth = 1, Hs = 0;
+    FftPlan planD;
     void *vars[SPORCO_AMD_VAR_COUNT] = {nullptr};
     cx<T> *work = nullptr;    // column-pass scratch (EF complex)
     cx<T> *dwork = nullptr;   // column-pass scratch of the D-step (npix*K complex)
@@ -239,7 +247,7 @@ template <typename T> struct Csc : CscBase {
         return (cols && rows_supported<T>(W_, K_ + 1)) ? K_ + 1 : K_;
     }
 
-    Csc(const sporco_amd_dims &d, int dev, void *stream, int cd) : dm(d), device(dev) {
+    Csc(const sporco_amd_dims &d, int dev, void *stream, int cd, int depth_ = 1) : dm(d), device(dev) {
         SA_REQUIRE(d.H >= 1 && d.W >= 1 && d.C >= 1 && d.N >= 1 && d.K >= 1,
                    "all dimensions must be >= 1");
         SA_REQUIRE(cd == 1 || cd == d.C,
@@ -267,8 +275,14 @@ template <typename T> struct Csc : CscBase {
             own_stream = true;
         }
         prof.st = st;
+        depth = depth_;
+        SA_REQUIRE(depth >= 1 && H % depth == 0 && (depth == 1 || cd == 1),
+                   "volume handle: depth divides H, single-channel dictionary");
+        Hs = H / depth;
+        const bool generic_only = sw.unfused || depth > 1;
         planW.init(W);
-        planH.init(H);
+        planH.init(Hs);
+        if (depth > 1) planD.init(depth);
         SA_HIP(hipMalloc((void **)&part_a, sizeof(double) * kMaxPartialBlocks * 8));
         SA_HIP(hipMalloc((void **)&part_b, sizeof(double) * kMaxPartialBlocks * 8));
         SA_HIP(hipMalloc((void **)&out_dev_own, sizeof(double) * kOutSlots));
@@ -279,11 +293,11 @@ template <typename T> struct Csc : CscBase {
         SA_HIP(hipMalloc((void **)&innerb, sizeof(cx<T>) * npix * CNs));
         SA_HIP(hipMalloc((void **)&sreal, sizeof(T) * (int64_t)H * W * CNs));
         fused = Cd == 1 && fused_cols_supported<T>(H, K) && K % 2 == 0 &&
-                !sw.unfused;
+                !generic_only;
         cols256 = H == 128 || H == 256 || H == 512;   // (every column kernel family has the 32 x 4 split)
-        fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !sw.unfused;
+        fused_slabs = Cd == 1 && fused_slabs_supported<T>(H, K) && !generic_only;
         fused_mc = Cd > 1 && fused_mc_supported<T>(H, K, Cd) && K % 2 == 0 &&
-                   !sw.unfused;
+                   !generic_only;
         if (fused_mc) {
             SA_HIP(hipMalloc((void **)&dft_mc, sizeof(cx<T>) * npix * Cd * K));
             SA_HIP(hipMalloc((void **)&sft_mc, sizeof(cx<T>) * npix * CNs));
@@ -410,6 +424,7 @@ template <typename T> struct Csc : CscBase {
         if (ctl_dev) (void)hipFree(ctl_dev);
         planW.destroy();
         planH.destroy();
+        if (depth > 1) planD.destroy();
         if (own_stream) (void)hipStreamDestroy(st);
     }
 
@@ -555,9 +570,9 @@ template <typename T> struct Csc : CscBase {
 #include "api_dstep.inc"
 };
 
-CscBase *make_csc(const sporco_amd_dims &dims, int dict_channels, int device, void *stream) {
-    if (dims.dtype == SPORCO_AMD_F32) return new Csc<float>(dims, device, stream, dict_channels);
-    if (dims.dtype == SPORCO_AMD_F64) return new Csc<double>(dims, device, stream, dict_channels);
+CscBase *make_csc(const sporco_amd_dims &dims, int dict_channels, int device, void *stream, int depth) {
+    if (dims.dtype == SPORCO_AMD_F32) return new Csc<float>(dims, device, stream, dict_channels, depth);
+    if (dims.dtype == SPORCO_AMD_F64) return new Csc<double>(dims, device, stream, dict_channels, depth);
     throw Error(SPORCO_AMD_EINVAL, "dtype must be SPORCO_AMD_F32 or SPORCO_AMD_F64");
 }
 

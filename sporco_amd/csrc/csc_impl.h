@@ -259,7 +259,8 @@ static bool var_is_valid(int var) {
 }
 
 // the one place that instantiates Csc<float> / Csc<double> (csc_api.hip)
-CscBase *make_csc(const sporco_amd_dims &dims, int dict_channels, int device, void *stream);
+CscBase *make_csc(const sporco_amd_dims &dims, int dict_channels, int device, void *stream,
+                  int depth = 1);
 
 }  // namespace sporco_amd
 
@@ -267,6 +268,7 @@ CscBase *make_csc(const sporco_amd_dims &dims, int dict_channels, int device, vo
 struct sporco_amd_csc {
     std::unique_ptr<sporco_amd::CscBase> impl;
     int device;
+    int depth = 1;                // > 1: a volume handle (sporco_amd_csc_create_volume)
     double *stats_dev = nullptr;  // scratch for pgm_stats into a separate buffer
     ~sporco_amd_csc() {
         if (stats_dev) (void)hipFree(stats_dev);
@@ -290,6 +292,11 @@ struct sporco_amd_csc {
     }                                                                                  \
     return SPORCO_AMD_OK;
 
-#define SA_HANDLE(h)                                                                   \
+#define SA_HANDLE_ANY(h)                                                               \
     SA_REQUIRE((h) != nullptr && (h)->impl, "null solver handle");                     \
     SA_HIP(hipSetDevice((h)->device));
+// (every entry point that has not been taught the third transform axis refuses a volume handle)
+#define SA_HANDLE(h)                                                                   \
+    SA_HANDLE_ANY(h)                                                                   \
+    SA_REQUIRE((h)->depth == 1,                                                        \
+               "a volume handle (dimN = 3) serves the ADMM sparse coding calls only");

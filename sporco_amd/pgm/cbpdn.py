@@ -76,9 +76,18 @@ class ConvBPDN(pgm.PGMDFT):
             D, S, dimN = np.asarray(D)[np.newaxis], np.asarray(S)[np.newaxis], 2
             if np.ndim(opt['L1Weight']) > 0:
                 opt['L1Weight'] = np.asarray(opt['L1Weight'])[np.newaxis]
+        # dimN = 3 (volumes): the first two axes folded, on a volume handle (admm.cbpdn.GenericConvBPDN)
+        self._dim3 = None
+        if dimN == 3 and type(self)._dim1_ok:
+            if opt['NoBndryCross'] or reducer is not None:
+                raise NotImplementedError("dimN = 3: no NoBndryCross, no image shards")
+            self._dim3, D, S = cr.volume_problem(D, S, dimK)
+            dimK, dimN = 1, 2
+            if np.ndim(opt['L1Weight']) > 0:
+                opt['L1Weight'] = cr.fold3(np.asarray(opt['L1Weight']), *self._dim3)
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, for ConvBPDN, "
-                                      "dimN = 1 (signals)")
+                                      "dimN = 1 (signals) and 3 (volumes)")
         if not (np.isrealobj(D) and np.isrealobj(S)):
             raise NotImplementedError("sporco_amd handles real-valued D and S")
         if not hasattr(self, 'cri'):
@@ -103,7 +112,8 @@ class ConvBPDN(pgm.PGMDFT):
     def _new_handle(self):
         H, W = self.cri.Nv
         self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                               device=self._device, stream=self._stream, Cd=self.cri.Cd)
+                               device=self._device, stream=self._stream, Cd=self.cri.Cd,
+                               depth=self._dim3[0] if getattr(self, '_dim3', None) else 1)
         if getattr(self, '_reducer', None) is not None:
             from ..dist import ReducingSolver
             self.dev = ReducingSolver(self.dev, self._reducer)
@@ -117,6 +127,8 @@ class ConvBPDN(pgm.PGMDFT):
             a = self.dev.download(var)
             if getattr(self, '_dim1', False) and a.ndim >= 2 and a.shape[0] == 1:
                 a = a[0]
+            if getattr(self, '_dim3', None):
+                a = cr.unfold3(a, *self._dim3)
             self._cache[var] = a
         return self._cache[var]
 
@@ -126,6 +138,8 @@ class ConvBPDN(pgm.PGMDFT):
         value = np.asarray(value)
         if getattr(self, '_dim1', False) and value.ndim == 4:
             value = value[np.newaxis]
+        if getattr(self, '_dim3', None) and value.ndim == 6:
+            value = cr.fold3(value, *self._dim3)
         self.dev.upload(var, value)
         self.invalidate(var)
 
@@ -176,6 +190,10 @@ class ConvBPDN(pgm.PGMDFT):
             D = np.asarray(D, dtype=self.dtype)
             if getattr(self, '_dim1', False) and D.ndim == len(self.cri.shpD) - 1:
                 D = D[np.newaxis]
+            if getattr(self, '_dim3', None) and D.shape[0] != self.cri.Nv[0]:
+                Dz, Hs = self._dim3
+                D = D.reshape(D.shape[0:3] + (1, 1, D.shape[-1]))
+                D = cr.fold3(cr.zpad(D, (Dz, Hs, self.cri.Nv[1])), Dz, Hs)
             self.D = D
         self.dev.set_dict(self.D)
         self._cache.pop(_lib.VAR_DF, None)
@@ -454,9 +472,13 @@ class ConvBPDN(pgm.PGMDFT):
             X = np.asarray(X, dtype=self.dtype)
             if getattr(self, '_dim1', False) and X.ndim == 4:
                 X = X[np.newaxis]
+            if getattr(self, '_dim3', None) and X.ndim == 6:
+                X = cr.fold3(X, *self._dim3)
             self.dev.upload(_lib.VAR_AX, X)
             var = _lib.VAR_AX
         r = self.dev.reconstruct(var)[..., 0]
+        if getattr(self, '_dim3', None):
+            return cr.unfold3(r, *self._dim3)
         return r[0] if getattr(self, '_dim1', False) else r
 
 
