@@ -154,8 +154,11 @@ int sporco_amd_csc_create_mc(const sporco_amd_dims *dims, int32_t dict_channels,
  * runs as two passes.  Single-channel dictionary, given zero-padded to the full volume
  * (sporco_amd_csc_set_dict with dH = dims->H, dW = dims->W).  Such a handle serves the ADMM sparse
  * coding calls (set_signal, set_dict, set_l1_weight, upload / download, admm_iter / _run and the
- * staged steps, reconstruct, dhs_absmax, asum) without NoBndryCross / gradient term / AddMaskSim;
- * every other entry point returns SPORCO_AMD_EINVAL for it.  Generic transform chain. */
+ * staged steps, the staged PGM steps, reconstruct, dhs_absmax, asum) without NoBndryCross /
+ * gradient term / AddMaskSim, and the PGM and consensus dictionary updates (ccmod_setcoef, _grad,
+ * _eval, _prox_step, _cnstr, setdict_from_dstep, cns_init, cns_iter without mask decoupling;
+ * SPORCO_AMD_VOLUME_FILTER_DEPTH below); every other
+ * entry point returns SPORCO_AMD_EINVAL for it.  Generic transform chain. */
 int sporco_amd_csc_create_volume(const sporco_amd_dims *dims, int32_t depth, int device, void *stream,
                                  sporco_amd_csc_t *out);
 int sporco_amd_csc_destroy(sporco_amd_csc_t h);
@@ -224,6 +227,11 @@ int sporco_amd_csc_placement_report(sporco_amd_csc_t h, char *buf, size_t cap);
  * launch_pm_butterfly describes; the real arrays (VAR_DX, VAR_DSX, VAR_DSU, VAR_CX, VAR_CU) are
  * (re, im) channel pairs.  Not with mask decoupling, image shards or the objective at X. */
 #define SPORCO_AMD_MODE_COMPLEX_PAIR 2
+/* VOLUME_FILTER_DEPTH -- a setting, for a volume handle (sporco_amd_csc_create_volume): how many
+ * depth slabs the filter support spans.  The dictionary-update calls that take a support (dH, dW) --
+ * sporco_amd_csc_ccmod_prox_step, _ccmod_cnstr, _cns_iter -- then crop to (value, dH, dW) (cnvrep.bcrop with
+ * dimN = 3, sporco/cnvrep.py:553-606). */
+#define SPORCO_AMD_VOLUME_FILTER_DEPTH 3
 int sporco_amd_csc_set_hint(sporco_amd_csc_t h, int what, int value);
 
 /* S: real (H,W,C,N) in the handle dtype.  Computes Sf = rfftn(S, axes=(0,1))

@@ -196,6 +196,42 @@ def gen_dim3():
          **itstat_dict(b))
 
 
+def gen_dim3_dl():
+    """dimN = 3 dictionary learning: the configuration of the reference's
+    examples/scripts/cdl/cbpdndl_video.py:64-74 (ADMM sparse coding, consensus dictionary update, a
+    single volume, AutoRho in both steps) at a small size, the PGM dictionary update on two volumes,
+    and the two dictionary updates alone."""
+    rng = np.random.RandomState(1005)
+    D0 = rng.randn(3, 3, 2, 4)
+    S1, S2 = rng.randn(8, 10, 6), rng.randn(8, 10, 6, 2)
+    lmbda = 0.1
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options(
+        {'MaxMainIter': 10, 'CBPDN': {'rho': 50.0 * lmbda, 'AutoRho': {'Enabled': True}},
+         'CCMOD': {'rho': 1e2, 'AutoRho': {'Enabled': True}}}, dmethod='cns')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, S1, lmbda, opt, dimK=0, dimN=3)
+    D1 = b.solve()
+    save('cbpdndl_dim3_video_f64', D0=D0, S=S1, lmbda=np.float64(lmbda), D1=D1, X=b.getcoef(),
+         recon=b.reconstruct(), **itstat_dict(b))
+    opt = ref_cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True}, xmethod='admm',
+                                                dmethod='pgm')
+    b = ref_cbpdndl.ConvBPDNDictLearn(D0, S2, lmbda, opt, xmethod='admm', dmethod='pgm', dimK=1, dimN=3)
+    D1 = b.solve()
+    save('cbpdndl_dim3_pgm_f64', D0=D0, S=S2, lmbda=np.float64(lmbda), D1=D1, X=b.getcoef(),
+         recon=b.reconstruct(), **itstat_dict(b))
+    Z = rng.randn(8, 10, 6, 1, 2, 4) * (rng.rand(8, 10, 6, 1, 2, 4) > 0.6)
+    dsz = (3, 3, 2, 4)
+    c = ref_pgm_ccmod.ConvCnstrMOD(Z, S2, dsz, ref_pgm_ccmod.ConvCnstrMOD.Options({'MaxMainIter': 25, 'L': 150.0}),
+                                   dimK=1, dimN=3)
+    c.solve()
+    n = ref_admm_ccmod.ConvCnstrMOD_Consensus(Z, S2, dsz, ref_admm_ccmod.ConvCnstrMOD_Consensus.Options(
+        {'MaxMainIter': 20, 'LinSolveCheck': True, 'rho': 3.0}), dimK=1, dimN=3)
+    n.solve()
+    save('ccmod_dim3_f64', Z=Z, S=S2, dsz=np.array(dsz), pgm_D=c.getdict(), pgm_X=c.X, pgm_recon=c.reconstruct(),
+         pgm_DFid=np.array(c.getitstat().DFid), pgm_Rsdl=np.array(c.getitstat().Rsdl),
+         cns_D=n.getdict(), cns_Y=n.Y, cns_X=n.X, cns_U=n.U, cns_DFid=np.array(n.getitstat().DFid),
+         cns_PrimalRsdl=np.array(n.getitstat().PrimalRsdl), cns_DualRsdl=np.array(n.getitstat().DualRsdl))
+
+
 def gen_admm():
     np.random.seed(12345)
     D = np.random.randn(5, 5, 4)
@@ -1538,7 +1574,7 @@ if __name__ == '__main__':
     which = sys.argv[1:] or ['primitives', 'admm', 'known', 'config1', 'pgm',
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
-             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'dim3': gen_dim3, 'dim1_dstep': gen_dim1_dstep, 'ccmod_cplx': gen_ccmod_cplx,
+             'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'dim3': gen_dim3, 'dim3_dl': gen_dim3_dl, 'dim1_dstep': gen_dim1_dstep, 'ccmod_cplx': gen_ccmod_cplx,
              'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,

@@ -42,6 +42,7 @@ QUERY_CCMOD_GROUPS = 6
 HINT_KEEP_VFORM = 0
 HINT_ONE_LAUNCH = 1
 MODE_COMPLEX_PAIR = 2
+VOLUME_FILTER_DEPTH = 3
 
 OUT_R2, OUT_S2, OUT_AX2, OUT_Y2, OUT_U2 = 0, 1, 2, 3, 4
 OUT_DFID, OUT_L1, OUT_L21 = 5, 6, 7

@@ -63,12 +63,40 @@ class _DeviceDStep(object):
                 opt[key] = np.asarray(opt[key])[np.newaxis]
         return np.asarray(S)[np.newaxis], _dsz_unit_axis(dsz), 2
 
+    # dimN = 3 (volumes; consensus update only): the first two axes folded, on a volume handle whose
+    # projections crop in three axes (admm/cbpdn.py, pgm/ccmod.py)
+    _dim3 = None
+
+    def _volume_setup(self, S, dsz, opt, dimK, dimN, reducer):
+        if dimN != 3:
+            return S, dsz, dimK, dimN
+        if isinstance(dsz[0], (list, tuple)) or reducer is not None or np.iscomplexobj(S):
+            raise NotImplementedError("dimN = 3: one filter support, real data, no image shards")
+        S = np.asarray(S)
+        c3 = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=3)
+        if c3.Cd > 1:
+            raise NotImplementedError("dimN = 3: single-channel dictionary")
+        if opt['ZeroMean']:
+            raise NotImplementedError("dimN = 3 with ZeroMean (see pgm/ccmod.py)")
+        self._dim3 = (int(c3.Nv[0]), int(c3.Nv[1]))
+        self._dsz3, self._cri3 = tuple(int(v) for v in dsz), c3
+        for key in ('Y0', 'U0'):
+            if opt[key] is not None and np.ndim(opt[key]) >= 6:
+                opt[key] = cr.fold3(np.asarray(opt[key]), *self._dim3)
+        S2 = cr.fold3(S.reshape(c3.shpS), *self._dim3)[..., 0]
+        return S2, (self._dim3[0] * self._dim3[1], int(c3.Nv[2]), c3.M), 1, 2
+
     def _drop1(self, a):
+        if self._dim3:
+            return cr.unfold3(a, *self._dim3)
         return a[0] if self._dim1 else a
 
     def _add1(self, a, ndim):
-        """The unit axis back on an array handed in with the reference's dimN = 1 shape."""
+        """The unit axis back on an array handed in with the reference's dimN = 1 shape (dimN = 3:
+        the first two axes folded)."""
         a = np.asarray(a)
+        if self._dim3:
+            return cr.fold3(a, *self._dim3) if a.ndim == ndim + 1 else a
         return a[np.newaxis] if self._dim1 and a.ndim == ndim - 1 else a
 
     def _complex_setup(self, Z, S, dsz, opt, dimK, dimN, dev, reducer=None):
@@ -144,19 +172,24 @@ class _DeviceDStep(object):
             return
         self.Nb = self.cri.C * self.cri.K
         self.S = np.asarray(S.reshape(self.cri.Nv + (1, self.Nb, 1)), dtype=self.dtype)
+        vol = self._dim3[0] if self._dim3 else 1
         if dev is None:
             self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                   device=device, stream=stream)
+                                   device=device, stream=stream, depth=vol)
             self.dev.set_signal(self.S)
         else:
-            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype:
+            if dev.dims != (H, W, self.cri.C, self.cri.K, self.cri.M) or dev.dtype != self.dtype \
+                    or getattr(dev, 'depth', 1) != vol:
                 raise ValueError("shared device solver has different dimensions")
             self.dev = dev
         self._cache = {}
         self._u_scale = 1.0
         self._sums = [0.0] * _lib.OUT_COUNT
-        # (multi-scale dsz: every filter's own support for the projections of this handle)
-        self.dev.set_filter_sizes(self.cri.fsz)
+        if self._dim3:
+            self.dev.set_hint(_lib.VOLUME_FILTER_DEPTH, self._dsz3[0])
+        else:
+            # (multi-scale dsz: every filter's own support for the projections of this handle)
+            self.dev.set_filter_sizes(self.cri.fsz)
 
     @property
     def Y(self):
@@ -179,6 +212,8 @@ class _DeviceDStep(object):
         """Set the coefficient maps: Zf = rfftn(Z) (ccmod.py:311-327, :746-755)."""
         # (multi-channel dictionary: Nb = K and the maps have no channel axis, same reshape)
         Z = np.asarray(Z)
+        if self._dim3 and Z.shape[0:2] == self._dim3:
+            Z = cr.fold3(Z.reshape(self._cri3.shpX), *self._dim3)
         if self._cplx:
             # (the complex maps for reconstruct(); the device gets their (re, im) channel pair)
             self._Zc = Z.reshape(self.cri.Nv + (1, self.Nb, self.cri.M)).astype(self.cdtype)
@@ -205,6 +240,8 @@ class _DeviceDStep(object):
     def getdict(self, crop=True):
         """The dictionary, cropped to the filter support by default (ccmod.py:331-339,
         :839-848)."""
+        if crop and self._dim3:
+            return cr.bcrop(self.Y, self._dsz3, 3)
         if crop:
             return self._drop1(self._from_pair(self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])))
         return self.Y
@@ -294,9 +331,10 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
             opt = ConvCnstrMOD_Consensus.Options()
         if not self._mask_dcpl:
             S, dsz, dimN = self._signal_setup(S, dsz, opt, dimN)
+            S, dsz, dimK, dimN = self._volume_setup(S, dsz, opt, dimK, dimN, reducer)
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, without a mask, "
-                                      "dimN = 1 (signals)")
+                                      "dimN = 1 (signals) and -- the consensus update -- 3 (volumes)")
         if self._mask_dcpl and (np.iscomplexobj(S) or (Z is not None and np.iscomplexobj(Z))):
             raise NotImplementedError("complex-valued dictionary update: not with mask decoupling")
         Z, S, dsz, dimK = self._complex_setup(Z, S, dsz, opt, dimK, dimN, dev, reducer)
@@ -322,7 +360,10 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         self.yshape = self.cri_c.shpD if self._cplx else self.cri.shpD
         if self._dim1:
             self.yshape = self.yshape[1:]
+        if self._dim3:
+            self.yshape = self._cri3.shpD
         self.xshape = self.yshape + (self.Nb,)
+        self._crop = self._dsz3[1:3] if self._dim3 else tuple(self.cri.mxsz[0:2])
         # (blocks of the whole problem: the residual scalings and tolerances refer to them)
         from ..dist import global_count
         self._nb_all = global_count(reducer, self.Nb)
@@ -415,7 +456,7 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
     def _device_iteration(self, flags):
         """One ``sporco_amd_csc_cns_iter`` call -- or, with image shards, its two phases around
         the all-reduce that turns the rank-local mean into the consensus average."""
-        args = (self.rho, self.rlx, self._u_scale, flags, self.cri.mxsz[0], self.cri.mxsz[1],
+        args = (self.rho, self.rlx, self._u_scale, flags, self._crop[0], self._crop[1],
                 self.opt['ZeroMean'])
         if self._reducer is None:
             return self.dev.cns_iter(*args, mask_dcpl=self._mask_dcpl)
@@ -438,6 +479,8 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
 
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Df) (ccmod.py:897-907); host arithmetic, off the iteration path."""
+        if self._dim3:
+            raise NotImplementedError("reconstruct() of the consensus update: dimN <= 2")
         if self._cplx:
             return self._reconstruct_complex(D)
         Df = self.dev.download(_lib.VAR_DXF) if D is None else \

@@ -879,18 +879,23 @@ __global__ void __launch_bounds__(kThreads) pcn_stats_kernel(const T *__restrict
     for (int k = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; k < K; k += nwaves) {
         // (multi-scale dictionary: every filter has its own support, cnvrep.py:634-662, :778-812)
         const int dH = fs.h ? fs.h[k] : dH_, dW = fs.w ? fs.w[k] : dW_;
-        const int np = dH * dW;
+        const int np = fs.dD * dH * dW;
+        // support element i -> row of the (folded) array: slab i / (dH dW), height (i / dW) % dH
+        auto row_of = [&](int i) -> int64_t {
+            const int r = i / dW;
+            return fs.Hs ? (int64_t)(r / dH) * fs.Hs + r % dH : r;
+        };
         T n2 = T(0);
         for (int c = 0; c < Cd; ++c) {
             T mean = T(0);
             if (zm) {
                 T s = T(0);
                 for (int i = lane; i < np; i += kWave)
-                    s += v[(((int64_t)(i / dW) * W + i % dW) * Cd + c) * K + k];
+                    s += v[((row_of(i) * W + i % dW) * Cd + c) * K + k];
                 mean = (T)(wave_sum((double)s) / (double)np);
             }
             for (int i = lane; i < np; i += kWave) {
-                const T e = v[(((int64_t)(i / dW) * W + i % dW) * Cd + c) * K + k] - mean;
+                const T e = v[((row_of(i) * W + i % dW) * Cd + c) * K + k] - mean;
                 n2 += e * e;
             }
             if (lane == 0) stats[2 * (c * K + k)] = mean;
@@ -928,7 +933,8 @@ __global__ void __launch_bounds__(kThreads) pcn_apply_kernel(const T *__restrict
         // v / vn as in cnvrep.normalise (cnvrep.py:696-700): 1/norm is applied by division
         // (filters >= Kvalid are the handle's zero padding: rounding noise must not be
         // normalised up to a unit-norm filter)
-        const T o = (h < dH && x < dW && k < Kvalid) ? (vi - stats[2 * ck]) * stats[2 * k + 1] : T(0);
+        const bool in_rows = fs.Hs ? (h / fs.Hs < fs.dD && h % fs.Hs < dH) : h < dH;
+        const T o = (in_rows && x < dW && k < Kvalid) ? (vi - stats[2 * ck]) * stats[2 * k + 1] : T(0);
         if (out) out[i] = o;
         const double df = (double)(o - vi);
         acc[0] += df * df;

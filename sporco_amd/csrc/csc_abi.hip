@@ -426,14 +426,14 @@ int sporco_amd_csc_copy(sporco_amd_csc_t h, int dst_var, int src_var) {
 
 int sporco_amd_csc_ccmod_setcoef(sporco_amd_csc_t h, int var) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->ccmod_setcoef(var);
     SA_API_END
 }
 
 int sporco_amd_csc_ccmod_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->ccmod_grad(var, true, sb);
@@ -443,7 +443,7 @@ int sporco_amd_csc_ccmod_grad(sporco_amd_csc_t h, int var, double out[SPORCO_AMD
 
 int sporco_amd_csc_ccmod_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->ccmod_grad(var, false, sb);
@@ -454,7 +454,7 @@ int sporco_amd_csc_ccmod_eval(sporco_amd_csc_t h, int var, double out[SPORCO_AMD
 int sporco_amd_csc_ccmod_prox_step(sporco_amd_csc_t h, double L, int32_t dH, int32_t dW,
                                    int32_t zero_mean) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(L > 0.0, "L must be positive");
     h->impl->ccmod_prox_step(L, dH, dW, zero_mean != 0);
     SA_API_END
@@ -463,7 +463,7 @@ int sporco_amd_csc_ccmod_prox_step(sporco_amd_csc_t h, double L, int32_t dH, int
 int sporco_amd_csc_ccmod_cnstr(sporco_amd_csc_t h, int32_t dH, int32_t dW, int32_t zero_mean,
                                double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(out != nullptr, "out is null");
     double *sb = stats_buf(h);
     h->impl->ccmod_cnstr(dH, dW, zero_mean != 0, sb);
@@ -482,7 +482,7 @@ int sporco_amd_csc_ccmod_getdict(sporco_amd_csc_t h, int32_t dH, int32_t dW, voi
 
 int sporco_amd_csc_setdict_from_dstep(sporco_amd_csc_t h, int32_t dH, int32_t dW) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->setdict_from_dstep(dH, dW);
     SA_API_END
 }
@@ -508,7 +508,7 @@ int sporco_amd_csc_masked_grad(sporco_amd_csc_t h, int var, int32_t dstep, int32
 
 int sporco_amd_csc_cns_init(sporco_amd_csc_t h, const void *Y0, double rho) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     h->impl->cns_init(Y0, rho);
     SA_API_END
 }
@@ -531,7 +531,7 @@ int sporco_amd_csc_cns_md_init(sporco_amd_csc_t h, const void *S) {
 int sporco_amd_csc_cns_iter(sporco_amd_csc_t h, const sporco_amd_cns_params *p,
                             double out[SPORCO_AMD_OUT_COUNT]) {
     SA_API_BEGIN
-    SA_HANDLE(h);
+    SA_HANDLE_ANY(h);
     SA_REQUIRE(p && out, "null argument");
     double *dev = stats_buf(h);
     h->impl->cns_iter(*p, dev);

@@ -501,6 +501,10 @@ template <typename T> struct Csc : CscBase {
             SA_REQUIRE(Cd == 2 && Cs == 2, "complex pair mode: a handle with two channels (real, imaginary)");
             SA_REQUIRE(!have_signal && !zf_ch, "complex pair mode is set before the signal and the coefficient maps");
             cplx_pair = value != 0;
+        } else if (what == SPORCO_AMD_VOLUME_FILTER_DEPTH) {
+            SA_REQUIRE(depth > 1 && value >= 1 && value <= depth, "filter depth: a volume handle, 1 <= value <= depth");
+            SA_REQUIRE(!flt_h, "volume handle: one filter support (no multi-scale dictionary)");
+            vol_dD = value;
         } else throw Error(SPORCO_AMD_EINVAL, "unknown hint");
     }
     // (A, B) -> (A + iB, A - iB) and back on an array (npix, mid, 2, inner) of such a handle

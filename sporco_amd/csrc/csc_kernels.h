@@ -204,6 +204,9 @@ int launch_ccmod_grad(hipStream_t st, const cx<T> *zf, const cx<T> *d, const cx<
 // support sizes in device memory (K ints each), or null pointers for the one support (dH, dW).
 struct FilterSizes {
     const int *h = nullptr, *w = nullptr;
+    // a volume handle (csc_api.hip): rows are (depth slab, height) folded, Hs rows per slab, and
+    // the support spans the first dD slabs -- row r lies inside iff r / Hs < dD and r % Hs < dH
+    int Hs = 0, dD = 1;
 };
 template <typename T>
 void launch_pcn_stats(hipStream_t st, const T *v, T *stats, int H, int W, int K, int dH, int dW,

@@ -133,6 +133,7 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
             self.update({} if opt is None else opt)
 
     _dim1 = False       # (set per object by __init__; classes that share the coupling methods keep it)
+    _dim3 = False
 
     def __init__(self, D0, S, lmbda=None, opt=None, xmethod=None, dmethod=None, dimK=1,
                  dimN=2, device=0, stream=None, reducer=None):
@@ -159,6 +160,13 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
                              'to initialise the Options object')
         self.opt, self.xmethod, self.dmethod = opt, xmethod, dmethod
         dsz = D0.shape if opt['DictSize'] is None else opt['DictSize']
+        self._dim3 = dimN == 3
+        if self._dim3:
+            # volumes: the steps fold the first two axes themselves (admm/cbpdn.py, pgm/ccmod.py,
+            # admm/ccmod.py) and share a volume handle; the set-up arithmetic below is dimN-generic
+            if dmethod not in ('pgm', 'cns') or xmethod not in ('admm', 'pgm'):
+                raise NotImplementedError("dimN = 3 is offered with xmethod 'admm' / 'pgm' and "
+                                          "dmethod 'pgm' / 'cns'")
         self._dim1 = dimN == 1
         if self._dim1:
             # signals: both steps run them as images with a unit first axis (admm/cbpdn.py,
@@ -231,6 +239,9 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         x.D = self.dstep.getdict()
         if self._dim1:
             x.D = x.D[np.newaxis]       # (the X-step keeps its arrays with the unit axis)
+        if self._dim3:                  # (... and a volume's dictionary zero-padded and folded)
+            Dz, Hs = x._dim3
+            x.D = cr.fold3(cr.zpad(x.D, (Dz, Hs, x.cri.Nv[1])), Dz, Hs)
 
     def getdict(self, crop=True):
         return self.dstep.getdict(crop=crop)
@@ -243,12 +254,19 @@ class ConvBPDNDictLearn(dictlrn.DictLearn):
         if D is None and X is None:
             dev = self.xstep._dev if self.xmethod == 'admm' else self.xstep.dev
             r = dev.reconstruct(self._coef_var())         # (5-D, as the reference's inner())
+            if self._dim3:
+                return cr.unfold3(r, *self.xstep._dim3)
             return r[0] if self._dim1 else r
         if D is None:
             D = self.getdict(crop=False)
         if X is None:
             X = self.getcoef()
         Nv = self.dstep.cri.Nv
+        if self._dim3:
+            Nv = self.dstep._cri3.Nv
+            Df = np.fft.rfftn(D, Nv, axes=(0, 1, 2))
+            Xf = np.fft.rfftn(X, Nv, axes=(0, 1, 2))
+            return np.fft.irfftn(np.sum(Df * Xf, axis=5, keepdims=True), Nv, axes=(0, 1, 2))
         if self._dim1:
             Df = np.fft.rfft(D, Nv[1], axis=0)
             Xf = np.fft.rfft(X, Nv[1], axis=0)

@@ -46,6 +46,7 @@ class ConvCnstrMOD(pgm.PGMDFT):
     itstat_fields_objfn = ('DFid', 'Cnstr')
     hdrtxt_objfn = ('DFid', 'Cnstr')
     hdrval_objfun = {'DFid': 'DFid', 'Cnstr': 'Cnstr'}
+    _volumes_ok = True      # (dimN = 3; the masked subclass: dimN <= 2)
 
     _v = {'x': _lib.VAR_DXF, 'y': _lib.VAR_DYF, 'xprv': _lib.VAR_DXFPRV,
           'yprv': _lib.VAR_DYFPRV, 'g': _lib.VAR_DGF, 't0': _lib.VAR_DT0,
@@ -75,9 +76,32 @@ class ConvCnstrMOD(pgm.PGMDFT):
         if dimN == 1:
             self._dim1 = True
             S, dsz, dimN = np.asarray(S)[np.newaxis], _dsz_unit_axis(dsz), 2
+        # dimN = 3 (volumes): the first two axes folded, on a volume handle whose projections crop in
+        # three axes (admm.cbpdn.GenericConvBPDN; include/sporco_amd.h sporco_amd_csc_create_volume)
+        self._dim3 = None
+        if dimN == 3 and type(self)._volumes_ok:
+            if isinstance(dsz[0], (list, tuple)) or reducer is not None:
+                raise NotImplementedError("dimN = 3: one filter support, no image shards")
+            S = np.asarray(S)
+            c3 = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=3)
+            if c3.Cd > 1:
+                raise NotImplementedError("dimN = 3: single-channel dictionary")
+            if opt['ZeroMean']:
+                # (the reference's padded projection passes no dimN to its mean subtraction,
+                # cnvrep.py:1011: at dimN = 3 it takes means over the first two axes only, unlike its
+                # own cropped form -- as for dimN = 1 with channels, neither reading is offered)
+                raise NotImplementedError("dimN = 3 with ZeroMean")
+            self._dim3 = (int(c3.Nv[0]), int(c3.Nv[1]))
+            self._dsz3, self._cri3 = tuple(int(v) for v in dsz), c3
+            S = cr.fold3(S.reshape(c3.shpS), *self._dim3)[..., 0]                 # (depth * H, W, C, K)
+            dsz, dimK, dimN = (self._dim3[0] * self._dim3[1], int(c3.Nv[2]), c3.M), 1, 2
         if dimN != 2:
-            raise NotImplementedError("sporco_amd handles dimN = 2 (images) and 1 (signals)")
+            raise NotImplementedError("sporco_amd handles dimN = 2 (images), 1 (signals) and, for the "
+                                      "plain update, 3 (volumes)")
         self.cri = cr.CDU_ConvRepIndexing(dsz, S, dimK=dimK, dimN=dimN)
+        # (support handed to the device's projections: rows x columns -- of one depth slab on a
+        # volume handle, which knows the depth of the support by itself)
+        self._crop = self._dsz3[1:3] if self._dim3 else tuple(self.cri.mxsz[0:2])
         if self._dim1 and self.cri.Cd > 1 and opt['ZeroMean']:
             # the reference's projection passes no dimN to its mean subtraction there
             # (cnvrep.py:1011 against :1074): with dimN = 1 it takes the mean over samples AND
@@ -101,23 +125,31 @@ class ConvCnstrMOD(pgm.PGMDFT):
             self.S = np.asarray(S.reshape(self.cri.shpS), dtype=self.dtype)
         if dev is None:
             self.dev = _lib.Solver(H, W, self.cri.C, self.cri.K, self.cri.M, self.dtype,
-                                   device=device, stream=stream, Cd=self.cri.Cd)
+                                   device=device, stream=stream, Cd=self.cri.Cd,
+                                   depth=self._dim3[0] if self._dim3 else 1)
             self.dev.set_signal(self.S)
         else:
             if (dev.dims[:2] + (dev.Cs,) + dev.dims[3:]) != (H, W, self.cri.C, self.cri.K,
                                                               self.cri.M) \
-                    or dev.Cd != self.cri.Cd or dev.dtype != self.dtype:
+                    or dev.Cd != self.cri.Cd or dev.dtype != self.dtype \
+                    or getattr(dev, 'depth', 1) != (self._dim3[0] if self._dim3 else 1):
                 raise ValueError("shared device solver has different dimensions")
             self.dev = dev
-        # (multi-scale dsz: every filter's own support for the projections of this handle)
-        self.dev.set_filter_sizes(self.cri.fsz)
+        if self._dim3:
+            self.dev.set_hint(_lib.VOLUME_FILTER_DEPTH, self._dsz3[0])
+        else:
+            # (multi-scale dsz: every filter's own support for the projections of this handle)
+            self.dev.set_filter_sizes(self.cri.fsz)
         super(ConvCnstrMOD, self).__init__(self.cri.shpD, self.cri.Nv, self.cri.axisN,
                                            S.dtype, opt)
         from ..dist import global_count
         nimg = global_count(reducer, self.cri.K)
         self.set_attr('L', opt['L'], dval=nimg * 14.0, dtype=self.dtype)
-        pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd, zm=opt['ZeroMean'])
-        self.Pcn = (lambda x: pcn(np.asarray(x)[np.newaxis])[0]) if self._dim1 else pcn
+        if self._dim3:
+            self.Pcn = cr.getPcn(self._dsz3, self._cri3.Nv, 3, self._cri3.dimCd, zm=opt['ZeroMean'])
+        else:
+            pcn = cr.getPcn(dsz, self.cri.Nv, self.cri.dimN, self.cri.dimCd, zm=opt['ZeroMean'])
+            self.Pcn = (lambda x: pcn(np.asarray(x)[np.newaxis])[0]) if self._dim1 else pcn
         if Z is not None:
             self.setcoef(Z)
 
@@ -127,6 +159,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
             a = self.dev.download(var)
             if self._dim1 and a.ndim >= 2 and a.shape[0] == 1:
                 a = a[0]
+            if self._dim3:
+                a = cr.unfold3(a, *self._dim3)
             self._cache[var] = a
         return self._cache[var]
 
@@ -136,6 +170,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
         value = np.asarray(value)
         if self._dim1 and value.ndim == 4:
             value = value[np.newaxis]
+        if self._dim3 and value.ndim == 6:
+            value = cr.fold3(value, *self._dim3)
         self.dev.upload(var, value)
         self.invalidate(var)
 
@@ -155,6 +191,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
         self.Z = np.asarray(Z, dtype=self.dtype)
         if self._dim1 and self.Z.ndim == 4:
             self.Z = self.Z[np.newaxis]
+        if self._dim3 and self.Z.shape[0:2] == self._dim3:
+            self.Z = cr.fold3(self.Z.reshape(self._cri3.shpX), *self._dim3)
         cri = self.cri
         if cri.Cd > 1 and self.Z.size == cri.N * cri.Cd * cri.K * cri.M:
             # maps that carry the dictionary's channels (the reference's broadcasting makes
@@ -178,6 +216,8 @@ class ConvCnstrMOD(pgm.PGMDFT):
     def getdict(self, crop=True):
         """Current dictionary, cropped to the filter support by default
         (pgm/ccmod.py:283-291)."""
+        if crop and self._dim3:
+            return cr.bcrop(self.X, self._dsz3, 3)
         if crop:
             D = self.dev.ccmod_getdict(self.cri.mxsz[0], self.cri.mxsz[1])
             return D[0] if self._dim1 else D
@@ -214,7 +254,7 @@ class ConvCnstrMOD(pgm.PGMDFT):
     def prox_step(self, gradf):
         if gradf != _lib.VAR_DGF:
             self.dev.copy(_lib.VAR_DGF, gradf)
-        self.dev.ccmod_prox_step(self.L, self.cri.mxsz[0], self.cri.mxsz[1], self.opt['ZeroMean'])
+        self.dev.ccmod_prox_step(self.L, self._crop[0], self._crop[1], self.opt['ZeroMean'])
         self.invalidate(_lib.VAR_DX, _lib.VAR_DXF, _lib.VAR_DVF)
 
     # -- objective ------------------------------------------------------------------------
@@ -226,11 +266,16 @@ class ConvCnstrMOD(pgm.PGMDFT):
 
     def obfn_cns(self):
         """||Pcn(X) - X||_2 (pgm/ccmod.py:350-355)."""
-        return self.dev.ccmod_cnstr(self.cri.mxsz[0], self.cri.mxsz[1], self.opt['ZeroMean'])
+        return self.dev.ccmod_cnstr(self._crop[0], self._crop[1], self.opt['ZeroMean'])
 
     def reconstruct(self, D=None):
         """irfftn(sum_m Zf * Df) (pgm/ccmod.py:374-383); host arithmetic on the
         downloaded spectra (off the iteration path)."""
+        if self._dim3:
+            Nv = self._cri3.Nv
+            Df = self.Xf if D is None else np.fft.rfftn(np.asarray(D), Nv, axes=(0, 1, 2))
+            Sf = np.sum(self.Zf * Df, axis=5)
+            return np.fft.irfftn(Sf, Nv, axes=(0, 1, 2)).astype(self.dtype)
         if self._dim1:
             Df = self.Xf if D is None else np.fft.rfft(np.asarray(D), axis=0)
             Sf = np.sum(self.Zf * Df, axis=self.cri.axisM - 1)
@@ -245,6 +290,8 @@ class ConvCnstrMODMask(ConvCnstrMOD):
     (1/2) sum_k ||W (sum_m d_m * x_{k,m} - s_k)||_2^2 over constrained filters (reference
     class: sporco/pgm/ccmod.py:408-604).  ``W`` must be compatible with the *internal* layout
     of ``S``, (H, W, C, K, 1) (single-channel dictionaries: (H, W, 1, C K, 1) works too)."""
+
+    _volumes_ok = False
 
     def __init__(self, Z, S, W, dsz, opt=None, dimK=None, dimN=2, **backend):
         if opt is None:

@@ -537,6 +537,6 @@ def test_dimN3_volumes(backend, name):
         with pytest.raises(NotImplementedError):
             cbpdn.ConvBPDNGradReg(g['D'], g['S'], 0.1, 0.1, dimN=3)
         with pytest.raises(_lib.BackendError):
-            b._dev.ccmod_setcoef(_lib.VAR_Y)
+            b._dev.dstep_init(None)            # (single-copy ADMM dictionary updates: two axes only)
         with pytest.raises(_lib.BackendError):
-            b._dev.cns_init(None, 1.0)
+            b._dev.set_dict_imag(np.zeros((3, 4, 4), dtype=np.float64))

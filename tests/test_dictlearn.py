@@ -461,3 +461,68 @@ def test_admm_dictionary_updates_dimN1(backend, meth):
     D1 = b.solve()
     assert D1.shape == g['dl_D1'].shape and rel_l2(D1, g['dl_D1']) < tol
     assert rel_l2(b.getcoef(), g['dl_X']) < tol and rel_l2(b.getitstat().ObjFun, g['dl_ObjFun']) < tol
+
+
+@pytest.mark.parametrize('name', ['cbpdndl_dim3_video_f64', 'cbpdndl_dim3_pgm_f64'])
+def test_dictlearn_dimN3_volumes(backend, name):
+    """dimN = 3 dictionary learning against reference runs: the configuration of the reference's
+    examples/scripts/cdl/cbpdndl_video.py:64-74 (consensus dictionary update, one volume, AutoRho
+    in both steps) and the PGM dictionary update on two volumes -- both steps on one volume handle."""
+    from sporco_amd.dictlrn import cbpdndl
+    g = load_golden(name)
+    lmbda = float(g['lmbda'])
+    if 'video' in name:
+        opt = cbpdndl.ConvBPDNDictLearn.Options(
+            {'MaxMainIter': 10, 'CBPDN': {'rho': 50.0 * lmbda, 'AutoRho': {'Enabled': True}},
+             'CCMOD': {'rho': 1e2, 'AutoRho': {'Enabled': True}}}, dmethod='cns')
+        b = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], lmbda, opt, dimK=0, dimN=3)
+    else:
+        opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 10, 'AccurateDFid': True}, xmethod='admm',
+                                                dmethod='pgm')
+        b = cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], lmbda, opt, xmethod='admm', dmethod='pgm', dimK=1, dimN=3)
+    D1 = b.solve()
+    assert D1.shape == g['D1'].shape and rel_l2(D1, g['D1']) < 1e-9
+    assert b.getcoef().shape == g['X'].shape and rel_l2(b.getcoef(), g['X']) < 1e-9
+    assert b.reconstruct().shape == g['recon'].shape and rel_l2(b.reconstruct(), g['recon']) < 1e-9
+    assert rel_l2(b.reconstruct(D=b.getdict(crop=False), X=b.getcoef()), g['recon']) < 1e-9
+    errs = trace_errors(b.getitstat(), g)
+    assert {'ObjFun', 'DFid', 'RegL1', 'XPrRsdl', 'XRho'} <= set(errs) and max(errs.values()) < 1e-9, errs
+    with pytest.raises(NotImplementedError):
+        cbpdndl.ConvBPDNDictLearn(g['D0'], g['S'], lmbda, cbpdndl.ConvBPDNDictLearn.Options(
+            {}, xmethod='admm', dmethod='ism'), xmethod='admm', dmethod='ism', dimK=0 if 'video' in name else 1, dimN=3)
+
+
+def test_dictionary_updates_dimN3(backend):
+    """The PGM and the consensus dictionary update alone on volumes (pgm/ccmod.py:139,
+    admm/ccmod.py:653 with dimN = 3): a crop in three axes inside the device's projections."""
+    from sporco_amd.admm import ccmod as accmod
+    from sporco_amd.pgm import ccmod
+    g = load_golden('ccmod_dim3_f64')
+    dsz = tuple(int(v) for v in g['dsz'])
+    c = ccmod.ConvCnstrMOD(g['Z'], g['S'], dsz, ccmod.ConvCnstrMOD.Options({'MaxMainIter': 25, 'L': 150.0}),
+                           dimK=1, dimN=3)
+    X = c.solve()
+    assert X.shape == g['pgm_X'].shape and rel_l2(X, g['pgm_X']) < 1e-9
+    assert c.getdict().shape == g['pgm_D'].shape and rel_l2(c.getdict(), g['pgm_D']) < 1e-9
+    assert rel_l2(c.reconstruct(), g['pgm_recon']) < 1e-9 and rel_l2(c.reconstruct(D=c.X), g['pgm_recon']) < 1e-9
+    its = c.getitstat()
+    assert rel_l2(its.DFid, g['pgm_DFid']) < 1e-9 and rel_l2(its.Rsdl, g['pgm_Rsdl']) < 1e-9
+    assert max(its.Cnstr) < 1e-12
+    assert np.allclose(np.sum(c.X ** 2, axis=(0, 1, 2)).ravel(), 1.0)
+    assert np.all(c.X[dsz[0]:] == 0) and np.all(c.X[:, dsz[1]:] == 0) and np.all(c.X[:, :, dsz[2]:] == 0)
+    assert rel_l2(c.Pcn(c.X), c.X) < 1e-12
+    n = accmod.ConvCnstrMOD_Consensus(g['Z'], g['S'], dsz, accmod.ConvCnstrMOD_Consensus.Options(
+        {'MaxMainIter': 20, 'LinSolveCheck': True, 'rho': 3.0}), dimK=1, dimN=3)
+    Y = n.solve()
+    for a, key in ((Y, 'cns_Y'), (n.getdict(), 'cns_D'), (n.X, 'cns_X'), (n.U, 'cns_U')):
+        assert a.shape == g[key].shape and rel_l2(a, g[key]) < 1e-9, key
+    its = n.getitstat()
+    for f in ('DFid', 'PrimalRsdl', 'DualRsdl'):
+        assert rel_l2(getattr(its, f), g['cns_' + f]) < 1e-9, f
+    n.Y, n.U = n.Y.copy(), n.U.copy()          # (the setters take the reference's shapes)
+    assert rel_l2(n.Y, g['cns_Y']) < 1e-9
+    for cls, kw in ((ccmod.ConvCnstrMOD, {'ZeroMean': True}), (accmod.ConvCnstrMOD_Consensus, {'ZeroMean': True})):
+        with pytest.raises(NotImplementedError):
+            cls(g['Z'], g['S'], dsz, cls.Options(kw), dimK=1, dimN=3)
+    with pytest.raises(NotImplementedError):
+        accmod.ConvCnstrMOD_IterSM(g['Z'], g['S'], dsz, dimK=1, dimN=3)
