@@ -48,6 +48,23 @@ class _DeviceArray(object):
         obj._store(self.var, value)
 
 
+
+def _reshaped_options(opt, keys, reshape, when=None):
+    """The array-valued entries ``keys`` of ``opt`` passed through ``reshape`` -- in a private
+    copy: the caller's Options object is never written to (the reference does not modify it
+    either, and one Options object reused over a lambda sweep is the normal usage), and
+    without an array-valued entry the object itself comes back.  ``when(array)`` restricts the
+    entries that are reshaped (default: every array)."""
+    todo = [k for k in keys if k in opt and opt[k] is not None and np.ndim(opt[k]) > 0 and
+            (when is None or when(np.asarray(opt[k])))]
+    if not todo:
+        return opt
+    opt = copy.deepcopy(opt)
+    for k in todo:
+        opt[k] = reshape(np.asarray(opt[k]))
+    return opt
+
+
 class GenericConvBPDN(admm.ADMMEqual):
     r"""Base class: data fidelity (1/2)||sum_m d_m * x_m - s||^2 plus a
     regulariser supplied by the derived class through ``ystep``/``obfn_reg``."""
@@ -133,9 +150,8 @@ class GenericConvBPDN(admm.ADMMEqual):
         if dimN == 1 and self._dim1_ok and self._S_dev is None:
             self._dim1 = True
             D, S, dimN = np.asarray(D)[np.newaxis], np.asarray(S)[np.newaxis], 2
-            for key in ('L1Weight', 'L21Weight', 'Y0', 'U0'):
-                if key in opt and opt[key] is not None and np.ndim(opt[key]) > 0:
-                    opt[key] = np.asarray(opt[key])[np.newaxis]
+            opt = _reshaped_options(opt, ('L1Weight', 'L21Weight', 'Y0', 'U0'),
+                                    lambda a: a[np.newaxis])
         # dimN = 3 (volumes; the reference's examples/scripts/cdl/cbpdndl_video.py:74 is the use): the
         # first two axes folded into one -- (depth, height, W, ...) IS (depth * height, W, ...) in
         # memory -- on a handle that knows where the folded axis splits and runs the transform along
@@ -148,9 +164,7 @@ class GenericConvBPDN(admm.ADMMEqual):
                 raise NotImplementedError("dimN = 3: NoBndryCross is not offered")
             self._dim3, D, S = cr.volume_problem(D, S, dimK)
             dimK, dimN = 1, 2
-            for key in ('L1Weight', 'L21Weight', 'Y0', 'U0'):
-                if key in opt and opt[key] is not None and np.ndim(opt[key]) > 0:
-                    opt[key] = self._fold(np.asarray(opt[key]))
+            opt = _reshaped_options(opt, ('L1Weight', 'L21Weight', 'Y0', 'U0'), self._fold)
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, for ConvBPDN / "
                                       "ConvBPDNJoint, dimN = 1 (signals) and 3 (volumes)")
@@ -1134,6 +1148,8 @@ class AddMaskSim(object):
     def __init__(self, cbpdnclass, D, S, W, *args, **kwargs):
         dimK = kwargs.get('dimK', None)
         dimN = kwargs.get('dimN', 2)
+        if dimN != 2:
+            raise NotImplementedError("AddMaskSim: the masked kernels know two spatial axes (dimN = 2)")
         self.cri = cr.CSC_ConvRepIndexing(D, S, dimK=dimK, dimN=dimN)
         if not hasattr(cbpdnclass, '_set_ams'):
             raise TypeError("AddMaskSim wraps the solver classes of sporco_amd.admm.cbpdn")

@@ -21,6 +21,7 @@ import numpy as np
 from . import admm
 from .. import _lib
 from .. import cnvrep as cr
+from .cbpdn import _reshaped_options
 
 __all__ = ['ConvCnstrMOD_Consensus', 'ConvCnstrMOD_IterSM', 'ConvCnstrMOD_CG', 'ConvCnstrMOD',
            'ConvCnstrMODOptions']
@@ -53,15 +54,14 @@ class _DeviceDStep(object):
 
     def _signal_setup(self, S, dsz, opt, dimN):
         if dimN != 1:
-            return S, dsz, dimN
+            return S, dsz, opt, dimN
         from ..pgm.ccmod import _dsz_unit_axis
         if np.iscomplexobj(S):
             raise NotImplementedError("complex-valued dictionary update: dimN = 2")
         self._dim1 = True
-        for key in ('Y0', 'U0'):
-            if opt[key] is not None and np.ndim(opt[key]) in (4, 5) and np.shape(opt[key])[0] != 1:
-                opt[key] = np.asarray(opt[key])[np.newaxis]
-        return np.asarray(S)[np.newaxis], _dsz_unit_axis(dsz), 2
+        # (an array in the reference's dimN = 1 shape (N, C, K, M) has four axes, the internal one five)
+        opt = _reshaped_options(opt, ('Y0', 'U0'), lambda a: a[np.newaxis], when=lambda a: a.ndim == 4)
+        return np.asarray(S)[np.newaxis], _dsz_unit_axis(dsz), opt, 2
 
     # dimN = 3 (volumes; consensus update only): the first two axes folded, on a volume handle whose
     # projections crop in three axes (admm/cbpdn.py, pgm/ccmod.py)
@@ -69,7 +69,7 @@ class _DeviceDStep(object):
 
     def _volume_setup(self, S, dsz, opt, dimK, dimN, reducer):
         if dimN != 3:
-            return S, dsz, dimK, dimN
+            return S, dsz, opt, dimK, dimN
         if isinstance(dsz[0], (list, tuple)) or reducer is not None or np.iscomplexobj(S):
             raise NotImplementedError("dimN = 3: one filter support, real data, no image shards")
         S = np.asarray(S)
@@ -80,11 +80,10 @@ class _DeviceDStep(object):
             raise NotImplementedError("dimN = 3 with ZeroMean (see pgm/ccmod.py)")
         self._dim3 = (int(c3.Nv[0]), int(c3.Nv[1]))
         self._dsz3, self._cri3 = tuple(int(v) for v in dsz), c3
-        for key in ('Y0', 'U0'):
-            if opt[key] is not None and np.ndim(opt[key]) >= 6:
-                opt[key] = cr.fold3(np.asarray(opt[key]), *self._dim3)
+        opt = _reshaped_options(opt, ('Y0', 'U0'), lambda a: cr.fold3(a, *self._dim3),
+                                when=lambda a: a.ndim >= 6)
         S2 = cr.fold3(S.reshape(c3.shpS), *self._dim3)[..., 0]
-        return S2, (self._dim3[0] * self._dim3[1], int(c3.Nv[2]), c3.M), 1, 2
+        return S2, (self._dim3[0] * self._dim3[1], int(c3.Nv[2]), c3.M), opt, 1, 2
 
     def _drop1(self, a):
         if self._dim3:
@@ -330,8 +329,8 @@ class ConvCnstrMOD_Consensus(_DeviceDStep, admm.ADMM):
         if opt is None:
             opt = ConvCnstrMOD_Consensus.Options()
         if not self._mask_dcpl:
-            S, dsz, dimN = self._signal_setup(S, dsz, opt, dimN)
-            S, dsz, dimK, dimN = self._volume_setup(S, dsz, opt, dimK, dimN, reducer)
+            S, dsz, opt, dimN = self._signal_setup(S, dsz, opt, dimN)
+            S, dsz, opt, dimK, dimN = self._volume_setup(S, dsz, opt, dimK, dimN, reducer)
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, without a mask, "
                                       "dimN = 1 (signals) and -- the consensus update -- 3 (volumes)")
@@ -529,7 +528,7 @@ class ConvCnstrMODBase(_DeviceDStep, admm.ADMM):
         if opt is None:
             opt = type(self).Options()
         if type(self)._signals_ok:
-            S, dsz, dimN = self._signal_setup(S, dsz, opt, dimN)
+            S, dsz, opt, dimN = self._signal_setup(S, dsz, opt, dimN)
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, without a mask, "
                                       "dimN = 1 (signals)")

@@ -55,13 +55,29 @@ template <typename T> __host__ __device__ __forceinline__ cx<T> operator+(cx<T> 
 template <typename T> __host__ __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) {
     return mk<T>(a.re - b.re, a.im - b.im);
 }
+// a * b + c with ONE rounding, spelled out.  The complex products below name their fused
+// multiply-adds instead of leaving `x * y + z * w` to the compiler's contraction, which picks the
+// product to fuse by the code AROUND the expression: two instantiations of the same transform
+// (the (Y, U) and the V form of an epilogue, the one-launch solve and the launch-per-pass loop)
+// then round differently.  The register-kernel translation units are compiled with
+// -ffp-contract=off on top of this (Makefile), so what is not spelled out is not fused.
+__host__ __device__ __forceinline__ float fma1(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__host__ __device__ __forceinline__ double fma1(double a, double b, double c) { return __builtin_fma(a, b, c); }
 // a * b
 template <typename T> __host__ __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
-    return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re);
+    return mk<T>(fma1(a.re, b.re, -(a.im * b.im)), fma1(a.re, b.im, a.im * b.re));
 }
 // conj(a) * b
 template <typename T> __host__ __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> b) {
-    return mk<T>(a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re);
+    return mk<T>(fma1(a.re, b.re, a.im * b.im), fma1(a.re, b.im, -(a.im * b.re)));
+}
+// u + conj(a) * b and acc + |a|^2, every product fused into the sum it feeds (four / two
+// instructions)
+template <typename T> __host__ __device__ __forceinline__ cx<T> cmulc_add(cx<T> u, cx<T> a, cx<T> b) {
+    return mk<T>(fma1(a.re, b.re, fma1(a.im, b.im, u.re)), fma1(a.re, b.im, fma1(-a.im, b.re, u.im)));
+}
+template <typename T> __host__ __device__ __forceinline__ T cabs2_add(T acc, cx<T> a) {
+    return fma1(a.re, a.re, fma1(a.im, a.im, acc));
 }
 template <typename T> __host__ __device__ __forceinline__ cx<T> cscale(cx<T> a, T s) {
     return mk<T>(a.re * s, a.im * s);
@@ -70,7 +86,7 @@ template <typename T> __host__ __device__ __forceinline__ cx<T> cconj(cx<T> a) {
     return mk<T>(a.re, -a.im);
 }
 template <typename T> __host__ __device__ __forceinline__ T cabs2(cx<T> a) {
-    return a.re * a.re + a.im * a.im;
+    return fma1(a.re, a.re, a.im * a.im);
 }
 // multiply by -i (forward quarter turn) / +i
 template <typename T> __host__ __device__ __forceinline__ cx<T> mul_mi(cx<T> a) {

@@ -339,8 +339,8 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
                 } else {
                     const float inv = sa_rcp(sa_uload(G + fo) + rho);
                     const cf coef = cscale(sv - qq, inv);
-                    obj += cabs2(coef);
-                    u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] + cmulc(d, coef);
+                    obj = cabs2_add(obj, coef);
+                    u[NW * jl + 4 * c + e] = cmulc_add(u[NW * jl + 4 * c + e], d, coef);
                 }
             }
             if constexpr (c == CPL - 1) {
@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                 rg += (gh + gw) * cabs2(xn);
                 ue = xn;
             } else {
-                ue = ue + cmulc(d[e], coef);
+                ue = cmulc_add(ue, d[e], coef);
             }
         }
         if constexpr (c == CPL - 1) {

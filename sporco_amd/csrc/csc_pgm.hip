@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
                 if constexpr (EYIN) r = sv[e];          // the (masked) residual, from memory
                 else r = qq[e] - sv[e];                 // sum_k Df Yf - Sf
                 if constexpr (BT) {
-                    fsum += cabs2(r);
+                    fsum = cabs2_add(fsum, r);
                     if (k == 0) EY[NW * j + N1 * brev(4 * c + e, LBW)] = r;
                 }
                 u[NW * jl + 4 * c + e] = u[NW * jl + 4 * c + e] - cscale(cmulc(dd[e], r), inv_L);
@@ -327,12 +327,12 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const cf ex = qq[e] - sv[e];
-                    fsum += cabs2(ex);
+                    fsum = cabs2_add(fsum, ex);
                     if constexpr (BT) {
                         cf ey;
                         sa_uload2(reinterpret_cast<const float *>(EY + NW * j + N1 * brev(4 * c + e, LBW)),
                                   ey.re, ey.im);
-                        lin += (ex.re - ey.re) * ey.re + (ex.im - ey.im) * ey.im;
+                        lin = fma1(ex.re - ey.re, ey.re, fma1(ex.im - ey.im, ey.im, lin));
                     }
                 }
             }
@@ -340,12 +340,12 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
             for (int e = 0; e < 4; ++e) {
                 const int fo = NW * j + N1 * brev(4 * c + e, LBW);
                 const cf xn = u[NW * jl + 4 * c + e];
-                const cf yn = xn + cscale(xn - xo[e], beta);
+                const cf yn = mk<float>(fma1(xn.re - xo[e].re, beta, xn.re), fma1(xn.im - xo[e].im, beta, xn.im));
                 if (kv) {
                     buf_store_cf(Tb, ko, fo * K * (int)sizeof(cf), xn);
                     if constexpr (!PLAIN) {
                         buf_store_cf(Yn, ko, fo * K * (int)sizeof(cf), yn);
-                        rs += cabs2(xn - yo[e]);
+                        rs = cabs2_add(rs, xn - yo[e]);
                     }
                 }
             }
@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
                     const int i = 4 * c + e;
                     cf r;
                     sa_uload2(reinterpret_cast<const float *>(R + NW * i), r.re, r.im);
-                    acc[i] = acc[i] + cmulc(z[e], r);
+                    acc[i] = cmulc_add(acc[i], z[e], r);
                 }
             } else {
             inner4(d, z, k, q);
@@ -484,9 +484,9 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
                 cf sv;
                 sa_uload2(reinterpret_cast<const float *>(S + NW * i), sv.re, sv.im);
                 const cf r = q[e] - sv;
-                s_r2 += cabs2(r);
-                s_q2 += cabs2(q[e]);
-                acc[i] = acc[i] + cmulc(z[e], r);
+                s_r2 = cabs2_add(s_r2, r);
+                s_q2 = cabs2_add(s_q2, q[e]);
+                acc[i] = cmulc_add(acc[i], z[e], r);
             }
             }
         });
@@ -573,9 +573,9 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_ahead_kernel(const C
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * c + e;
                 const cf r = q[e] - mk<float>(sa_readlane(sb[c].re, e), sa_readlane(sb[c].im, e));
-                s_r2 += cabs2(r);
-                s_q2 += cabs2(q[e]);
-                acc[i] = acc[i] + cmulc(zb[c][e], r);
+                s_r2 = cabs2_add(s_r2, r);
+                s_q2 = cabs2_add(s_q2, q[e]);
+                acc[i] = cmulc_add(acc[i], zb[c][e], r);
             }
             {
                 float &dep = acc[4 * c + 3].re;

@@ -196,10 +196,17 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 // the packed spectrum Z is rebuilt, and v[n1] receives the unnormalised inverse
 // transform at x = NW n1 + w: (re, im) = (filter k, filter k+1).
 // (t_odd: the planes arrive in two buffers, csc_rows.h RowsPostArgs::t_odd)
-template <int NW, bool COH = false>
+// before_last: called when the exchange is over and only the in-register FFT-32 is left -- the
+// point where the spectral-side registers have just died (the parked epilogue requests its first
+// batch of the previous iterate there, under the transform).
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int NW, bool COH = false, typename Hook = NoHook>
 __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW, const cf *t, int CN,
                                                     int H, int K, int cn, int k, int h, bool pv, int w,
-                                                    int lane, f2 *L, int &token, const cf *t_odd = nullptr) {
+                                                    int lane, f2 *L, int &token, const cf *t_odd = nullptr,
+                                                    Hook before_last = Hook()) {
     constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
     constexpr int NG = 2;
     constexpr int LPG = J / NG;
@@ -295,6 +302,7 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
         if (g + 1 < NG) __syncthreads();
     });
     reg_fence<N1>(v, 0, token);
+    before_last();
     dit<N1, true>(v, 0);   // v[n1] = (X_p, X_{p+1}) at x = NW n1 + w, unnormalised
 }
 
@@ -524,9 +532,61 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     double *scratch = reinterpret_cast<double *>(L + 16 * NW * 64);
     int token = 0;
 
+    // pixels per batch (the previous iterate of the next batch is in flight); the emitting variants
+    // keep the tile for the forward transform and have fewer registers to spare
+    // (V form reads one array instead of two: twice the pixels per batch for the same registers)
+#ifndef SA_POST_B_VIN
+#define SA_POST_B_VIN 8
+#endif
+    // PARK (emitting V-form epilogues): the second half of the tile -- x at the pixels n1 >= 16 --
+    // waits in the idle exchange buffer while the first half is worked on, each value in the slot
+    // column its own thread reads and writes in the exchanges (no barrier), and each result takes the
+    // place of the value it came from; the half comes back into registers for the forward transform.
+    // The 32 registers this frees hold the previous iterate of more pixels in flight: the joint
+    // variant had room for ONE pixel per thread (8 KiB per CU requested at a time against the
+    // ~64 KiB that keep a CU's share of the memory pipe full), now SA_POST_B_JOINT_PARK.
+#ifndef SA_PARK_JOINT
+#define SA_PARK_JOINT 1
+#endif
+#ifndef SA_PARK_PLAIN
+#define SA_PARK_PLAIN 0
+#endif
+#ifndef SA_POST_B_JOINT_PARK
+#define SA_POST_B_JOINT_PARK 4
+#endif
+#ifndef SA_POST_B_PLAIN_PARK
+#define SA_POST_B_PLAIN_PARK 8
+#endif
+    constexpr bool PARK = EMIT_T && VIN && (JOINT ? SA_PARK_JOINT != 0 : SA_PARK_PLAIN != 0);
+    constexpr int NP = N1 / 2;      // parked pixels per thread
+    constexpr int B = EMIT_T ? (JOINT ? (PARK ? SA_POST_B_JOINT_PARK : 1)
+                                      : (VIN ? (PARK ? SA_POST_B_PLAIN_PARK : 4) : 2))
+                             : ((VIN && !JOINT) ? SA_POST_B_VIN : 4);
+    cf yb[2][B], ub[2][B];
     cf v[N1];
-    spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L, token,
-                                 a->t_odd);
+    if constexpr (PARK) {
+        // the first batch of the previous iterate is requested under the last in-register transform
+        auto first_fetch = [&]() {
+            const int64_t rowoff0 = (int64_t)h * W * a->P;
+            const BufRsrc Vb0 = make_rsrc(a->v_in + rowoff0, (uint32_t)((int64_t)W * a->P * sizeof(float)));
+            const int voff0 = pv ? (int)(p * (int64_t)sizeof(float)) : (int)0x80000000;
+            const int pixbytes0 = (int)(a->P * (int64_t)sizeof(float));
+#pragma unroll
+            for (int i = 0; i < B; ++i) yb[0][i] = buf_load_cf(Vb0, voff0, (NW * i + w) * pixbytes0);
+        };
+        spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
+                                     token, a->t_odd, first_fetch);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            f2 t;
+            t.x = v[NP + i].re;
+            t.y = v[NP + i].im;
+            L[(i * NW + w) * 64 + lane] = t;
+        }
+    } else {
+        spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
+                                     token, a->t_odd);
+    }
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
     const int64_t rowoff = (int64_t)h * W * a->P;
@@ -573,14 +633,6 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
     const float l21w = lane < 16 ? 1.f : 0.f;  // the l2,1 sum counts each channel group once
     const float emit_y = (EMIT_T && SF == 0 && a->emit_u) ? 0.f : 1.f;
     const float emit_s = (EMIT_T && SF == 0 && a->emit_u) ? -1.f : 1.f;
-    // pixels per batch (Y, U of the next batch are in flight); the emitting variants keep the
-    // tile for the forward transform and have fewer registers to spare
-    // (V form reads one array instead of two: twice the pixels per batch for the same registers)
-#ifndef SA_POST_B_VIN
-#define SA_POST_B_VIN 8
-#endif
-    constexpr int B = EMIT_T ? (JOINT ? 1 : (VIN ? 4 : 2)) : ((VIN && !JOINT) ? SA_POST_B_VIN : 4);
-    cf yb[2][B], ub[2][B];
     auto fetch = [&](int slot, int b) {
 #pragma unroll
         for (int i = 0; i < B; ++i) {
@@ -589,7 +641,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             if constexpr (!VIN) ub[slot][i] = buf_load_cf(Ub, voff, soff);
         }
     };
-    fetch(0, 0);
+    if constexpr (!PARK) fetch(0, 0);
     static_for<N1 / B>([&](auto bc) {
         // (every product rounded: the state forms of csc_rows.h must agree bit for bit, see
         // rows_fwd_tile)
@@ -601,7 +653,14 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             const int n1 = b * B + i;
             const int xw = NW * n1 + w;
             const int soff = xw * pixbytes;
-            const float xs[2] = {v[n1].re * scale, v[n1].im * scale};
+            // (a batch lies in one half of the tile: B divides N1 / 2)
+            constexpr bool parked = PARK && b * B >= NP;
+            cf xraw = v[parked ? 0 : n1];
+            if constexpr (parked) {
+                const f2 t = L[((n1 - NP) * NW + w) * 64 + lane];
+                xraw = mk<float>(t.x, t.y);
+            }
+            const float xs[2] = {xraw.re * scale, xraw.im * scale};
             float yo[2] = {yb[b & 1][i].re, yb[b & 1][i].im};
             float uraw[2];
             // NoBndryCross as a multiplicative mask (a uniform branch here splits the unrolled
@@ -738,11 +797,23 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             if constexpr (EMIT_T && SF == 0) {
                 // (emit_u: the spectrum of U' alone; 1 * y - u rounds as y - u does)
                 v[n1] = mk<float>(emit_y * yn[0] - emit_s * un[0], emit_y * yn[1] - emit_s * un[1]);
+            } else if constexpr (PARK && b * B >= NP) {
+                f2 t;
+                t.x = yn[0] - un[0];
+                t.y = yn[1] - un[1];
+                L[((n1 - NP) * NW + w) * 64 + lane] = t;
             } else if (EMIT_T) {
                 v[n1] = mk<float>(yn[0] - un[0], yn[1] - un[1]);
             }
         }
     });
+    if constexpr (PARK) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const f2 t = L[(i * NW + w) * 64 + lane];
+            v[NP + i] = mk<float>(t.x, t.y);
+        }
+    }
 
     // (pin the six sums here: left alone, the compiler sinks their accumulation below the
     // transform that follows and keeps every per-element term alive until then)

@@ -72,9 +72,10 @@ template <bool INV> __device__ __forceinline__ cf tw64_mul(cf d, int t) {
     if (t == 24)
         return INV ? mk<float>(-h * (d.re + d.im), h * (d.re - d.im))
                    : mk<float>(h * (d.im - d.re), -h * (d.re + d.im));
+    // (fused multiply-adds named, see common.h fma1)
     const float c = (float)cos64(t), s = (float)sin64(t);
-    return INV ? mk<float>(d.re * c - d.im * s, d.im * c + d.re * s)
-               : mk<float>(d.re * c + d.im * s, d.im * c - d.re * s);
+    return INV ? mk<float>(fma1(d.re, c, -(d.im * s)), fma1(d.im, c, d.re * s))
+               : mk<float>(fma1(d.re, c, d.im * s), fma1(d.im, c, -(d.re * s)));
 }
 
 // Decimation in frequency: natural-order input v[off .. off+N), output X[brev(i)] at v[off+i].

@@ -101,6 +101,9 @@ def solvedbi_sm(ah, rho, b, c=None, axis=4):
     b = np.asarray(b)
     ah = np.asarray(ah)
     cdt = np.result_type(ah.dtype, b.dtype, np.complex64)
+    # real operands give a real solution, as the reference's expression does (and as inner() above)
+    real = not (np.iscomplexobj(ah) or np.iscomplexobj(b))
+    rdt = np.result_type(ah.dtype, b.dtype, np.float32)
     pat = _fast_pattern(ah, b, axis)
     if pat is not None:
         npix, CN, K = pat
@@ -108,7 +111,7 @@ def solvedbi_sm(ah, rho, b, c=None, axis=4):
         _lib.check(_lib.lib().sporco_amd_solvedbi_sm(
             _lib.dtype_code(real_dtype(cdt)), npix, CN, K, _lib._ptr(_cplx(ah, cdt)), float(rho),
             _lib._ptr(_cplx(b, cdt)), _lib._ptr(x)))
-        return x
+        return x.real.astype(rdt) if real else x
     # any other axis / broadcast pattern: one system per row after the axis has been moved last
     am, bm, shp, ax = _moved_last(ah, b, axis)
     M, K = bm.shape
@@ -117,7 +120,8 @@ def solvedbi_sm(ah, rho, b, c=None, axis=4):
         _lib.dtype_code(real_dtype(cdt)), M, 1, K, _lib._ptr(_cplx(am, cdt)), float(rho),
         _lib._ptr(_cplx(bm, cdt)), _lib._ptr(xm)))
     rest = tuple(n for i, n in enumerate(shp) if i != ax)
-    return np.moveaxis(xm.reshape(rest + (K,)), -1, ax)
+    x = np.moveaxis(xm.reshape(rest + (K,)), -1, ax)
+    return x.real.astype(rdt) if real else x
 
 
 def rrs(ax, b):

@@ -21,7 +21,7 @@ from .backtrack import BacktrackStandard, BacktrackRobust
 from .stepsize import StepSizePolicyCauchy, StepSizePolicyBB
 from .. import _lib
 from .. import cnvrep as cr
-from ..admm.cbpdn import _DeviceArray, _broadcastable
+from ..admm.cbpdn import _DeviceArray, _broadcastable, _reshaped_options
 
 __all__ = ['ConvBPDN', 'ConvBPDNMask']
 
@@ -74,8 +74,7 @@ class ConvBPDN(pgm.PGMDFT):
         if dimN == 1 and type(self)._dim1_ok:
             self._dim1 = True
             D, S, dimN = np.asarray(D)[np.newaxis], np.asarray(S)[np.newaxis], 2
-            if np.ndim(opt['L1Weight']) > 0:
-                opt['L1Weight'] = np.asarray(opt['L1Weight'])[np.newaxis]
+            opt = _reshaped_options(opt, ('L1Weight',), lambda a: a[np.newaxis])
         # dimN = 3 (volumes): the first two axes folded, on a volume handle (admm.cbpdn.GenericConvBPDN)
         self._dim3 = None
         if dimN == 3 and type(self)._dim1_ok:
@@ -83,8 +82,7 @@ class ConvBPDN(pgm.PGMDFT):
                 raise NotImplementedError("dimN = 3: no NoBndryCross, no image shards")
             self._dim3, D, S = cr.volume_problem(D, S, dimK)
             dimK, dimN = 1, 2
-            if np.ndim(opt['L1Weight']) > 0:
-                opt['L1Weight'] = cr.fold3(np.asarray(opt['L1Weight']), *self._dim3)
+            opt = _reshaped_options(opt, ('L1Weight',), lambda a: cr.fold3(a, *self._dim3))
         if dimN != 2:
             raise NotImplementedError("sporco_amd handles dimN = 2 (images) and, for ConvBPDN, "
                                       "dimN = 1 (signals) and 3 (volumes)")

@@ -540,3 +540,40 @@ def test_dimN3_volumes(backend, name):
             b._dev.dstep_init(None)            # (single-copy ADMM dictionary updates: two axes only)
         with pytest.raises(_lib.BackendError):
             b._dev.set_dict_imag(np.zeros((3, 4, 4), dtype=np.float64))
+
+
+def test_options_object_is_not_written_to(backend):
+    """One Options object reused for several solvers (a lambda sweep) -- the reference never
+    modifies it (sporco/admm/admm.py:234, sporco/admm/cbpdn.py:175-204): the dimN = 1 / dimN = 3
+    set-up reshapes array-valued entries in a private copy, so a second construction from the
+    same object sees what the first one saw."""
+    from sporco_amd.admm import cbpdn, ccmod
+    from sporco_amd.pgm import cbpdn as pc
+    rng = np.random.RandomState(7)
+    # dimN = 1: signals (32,) x 3, dictionary (5, 4); L1Weight and Y0 in the reference's shapes
+    D1, S1 = rng.randn(5, 4), rng.randn(32, 3)
+    w1, y0 = np.abs(rng.randn(32, 1, 3, 4)) + 0.5, rng.randn(32, 1, 3, 4)
+    opt = cbpdn.ConvBPDN.Options({'MaxMainIter': 3, 'L1Weight': w1, 'Y0': y0})
+    ys = [cbpdn.ConvBPDN(D1, S1, lm, opt, dimK=1, dimN=1).solve() for lm in (0.1, 0.1, 0.2)]
+    assert opt['L1Weight'] is w1 and opt['Y0'] is y0 and opt['L1Weight'].shape == (32, 1, 3, 4)
+    assert np.array_equal(ys[0], ys[1]) and not np.array_equal(ys[0], ys[2])
+    optp = pc.ConvBPDN.Options({'MaxMainIter': 3, 'L1Weight': w1, 'L': 50.0})
+    xs = [pc.ConvBPDN(D1, S1, 0.1, optp, dimK=1, dimN=1).solve() for _ in range(2)]
+    assert optp['L1Weight'] is w1 and np.array_equal(xs[0], xs[1])
+    # dimN = 3: one volume (4, 6, 8), dictionary (2, 3, 3, 4)
+    D3, S3 = rng.randn(2, 3, 3, 4), rng.randn(4, 6, 8)
+    w3 = np.abs(rng.randn(4, 6, 8, 1, 1, 4)) + 0.5
+    y3 = rng.randn(4, 6, 8, 1, 1, 4)
+    opt3 = cbpdn.ConvBPDN.Options({'MaxMainIter': 3, 'L1Weight': w3, 'Y0': y3})
+    v = [cbpdn.ConvBPDN(D3, S3, 0.1, opt3, dimN=3).solve() for _ in range(2)]
+    assert opt3['L1Weight'] is w3 and opt3['Y0'] is y3 and np.array_equal(v[0], v[1])
+    # the ADMM dictionary update with a start value in the reference's dimN = 1 shape
+    Z = rng.randn(32, 1, 3, 4)
+    yd = rng.randn(32, 1, 1, 4)
+    optd = ccmod.ConvCnstrMOD_IterSM.Options({'MaxMainIter': 3, 'Y0': yd})
+    d = []
+    for _ in range(2):
+        c = ccmod.ConvCnstrMOD_IterSM(Z, S1, (5, 4), optd, dimK=1, dimN=1)
+        c.solve()
+        d.append(c.getdict())
+    assert optd['Y0'] is yd and np.array_equal(d[0], d[1])

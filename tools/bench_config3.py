@@ -35,8 +35,11 @@ def run(unfused, iters, timed):
 
 
 b, its, perf = run(False, 3, 10)
-print(json.dumps({'config': 'ConvBPDNJoint 512x512x3 K=128 N=%d f32 (config 3, one of 8 shards)' % N,
+print(json.dumps({'library': os.path.basename(os.environ.get('SPORCO_AMD_LIBRARY', 'libsporco_amd.so')),
+                  'config': 'ConvBPDNJoint 512x512x3 K=128 N=%d f32 (config 3, one of 8 shards)' % N,
                   'fused_cols': bool(b._dev.uses_fused_cols()), **perf}))
+if os.environ.get('C3_QUICK'):          # A/B timing of library variants: no generic-chain twin
+    sys.exit(0)
 obj = np.asarray(its.ObjFun, dtype=float)
 # (ObjFun is evaluated at X, the unconstrained X-step solution, with gEvalY = False -- the
 # reference's default, cbpdn.py:127-128 -- so it is not a monotone sequence for ADMM, and with
