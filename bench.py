@@ -30,7 +30,9 @@ on the same kernel instantiations (committed fixtures, tests/golden/ -- oracle/m
 the recipe) and the roofline of its dominant kernel.  `roofline.frac` is bytes really MOVED by
 the dominant kernel (by construction: its inputs and outputs once; equal to the rocprofv3 PMC
 traffic in profiles/hbm_traffic_bytes.json) / its HIP-event duration in this run / the 8 TB/s
-HBM peak; the SURVEY.md 8(d) stage-bytes figure is kept beside it as `algorithmic_frac`.
+HBM peak; the SURVEY.md 8(d) stage-bytes figure is kept beside it as `stage_model_ratio` -- stage
+bytes / time / peak, which is NOT a distance to the peak: the single-array kernels move two thirds
+of the bytes that model credits, so it exceeds 1 where they run near the roofline.
 `cpu_baseline` times the unmodified reference (staged into the git-ignored oracle/_ref by
 build()) in a subprocess on this box's host cores, and the NumPy port as a second leg.
 `roofline.placement` lists where the library put the arrays the dominant kernel writes at the
@@ -138,7 +140,7 @@ def kernel_roofline(prof, moved, alg):
             out[k] = {'avg_ms': round(ms, 4), 'launches': int(v[1]),
                       'moved_bytes': moved[k], 'GBps': round(moved[k] / ms / 1e6, 1),
                       'frac': round(moved[k] / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                      'algorithmic_frac': round(alg[k] / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+                      'stage_model_ratio': round(alg[k] / ms / 1e6 / HBM_PEAK_GBPS, 4)}
     return out
 
 
@@ -149,8 +151,8 @@ def check_fracs(obj, path='line'):
     bad = []
     if isinstance(obj, dict):
         for k, v in obj.items():
-            # (`algorithmic_frac` credits the stage bytes of SURVEY 8(d), of which the single-array
-            # kernels move two thirds: it is documented as not being a distance to the peak)
+            # (`stage_model_ratio` credits the stage bytes of SURVEY 8(d), of which the single-array
+            # kernels move two thirds: it is named as what it is, not as a fraction of the peak)
             if k == 'frac' and isinstance(v, (int, float)) and v > 1.0:
                 bad.append('%s.%s=%.3f' % (path, k, v))
             else:
@@ -172,7 +174,7 @@ def roofline_of(table, extra=None):
     t = table[k]
     r = {'bound': 'hbm', 'kernel': k, 'moved_bytes': t['moved_bytes'], 'avg_kernel_ms': t['avg_ms'],
          'achieved': t['GBps'], 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': t['frac'],
-         'algorithmic_frac': t['algorithmic_frac']}
+         'stage_model_ratio': t['stage_model_ratio']}
     if extra:
         r.update(extra)
     return r
@@ -253,7 +255,7 @@ def iteration_summary(table, prof_steps, ms_per_step, alg_bytes_per_iter):
     mv = sum(t['moved_bytes'] * t['launches'] for t in table.values()) / float(prof_steps)
     return {'moved_bytes_per_iter': mv, 'frac': mv / ms_per_step / 1e6 / HBM_PEAK_GBPS,
             'algorithmic_bytes_per_iter': alg_bytes_per_iter,
-            'algorithmic_frac': alg_bytes_per_iter / ms_per_step / 1e6 / HBM_PEAK_GBPS,
+            'stage_model_ratio': alg_bytes_per_iter / ms_per_step / 1e6 / HBM_PEAK_GBPS,
             'note': 'moved = sum over the profiled kernels of bytes moved by construction, per '
                     'iteration of the profiled pass; ms = the timed region'}
 
@@ -351,6 +353,55 @@ def run_config3(device, n_shard=32, tiny=False):
            'parity': par, 'roofline': roofline_of(tab),
            'iteration': iteration_summary(tab, 6, ms, 40 * E), 'kernels': tab,
            'placement': b._dev.placement_report()}
+    del b
+    return out
+
+
+def run_config3_sharded(device, rank, world, reducer, stream, sync_all, allmax, n_shard=32, tiny=False):
+    """BASELINE configs[2] as the job it is: ConvBPDNJoint 512x512 RGB, K=128, N = 32 images per
+    rank (8 ranks: the N = 256 problem), images sharded, one all-reduce of the 16 sums per
+    iteration inside the device-driven loop.  Every rank runs this; `allmax(x)` is the maximum of a
+    host float over the ranks.  Returns the leg's entry (identical on every rank)."""
+    from sporco_amd.admm import cbpdn
+    H = W = 128 if tiny else 512
+    K, C = (32 if tiny else 128), 3
+    if tiny:
+        n_shard = 1
+    D, _ = make_problem_rgb(H, W, K, 1, 0)              # the dictionary is replicated
+    _, S = make_problem_rgb(H, W, K, n_shard, rank)     # this rank's images
+    b = cbpdn.ConvBPDNJoint(D, S, 0.1, 0.01, cbpdn.ConvBPDNJoint.Options(
+        {'MaxMainIter': 3, 'RelStopTol': 0.0}), device=device, stream=stream, reducer=reducer)
+    b._return_min = False
+    steps, warm = (3, 1) if tiny else (10, 3)
+    b.opt['MaxMainIter'] = warm
+    b.solve()
+    b.opt['MaxMainIter'] = steps
+    gc.collect()
+    gc.disable()
+    try:
+        sync_all(b)
+        t0 = time.perf_counter()
+        b.solve()
+        sync_all(b)
+        own = time.perf_counter() - t0
+    finally:
+        gc.enable()
+    slow, fast = allmax(own), -allmax(-own)
+    its = b.getitstat()
+    E = H * W * C * n_shard * K
+    out = {'workload': 'admm.cbpdn.ConvBPDNJoint %dx%d RGB (C=3), K=%d, lambda=0.1, mu=0.01, default '
+                       'options: N=%d images per rank x %d ranks = N=%d (BASELINE configs[2] at 8 ranks), '
+                       'images sharded, one all-reduce of 16 doubles per iteration'
+                       % (H, W, K, n_shard, world, n_shard * world),
+           'steps': steps, 'warmup': warm, 'ms_per_step': 1e3 * slow / steps,
+           'value': steps / slow * world,
+           'unit': 'shard-iterations/s summed over ranks (N=%d images each): weak scaling' % n_shard,
+           'iterations_per_s_of_the_sharded_problem': steps / slow,
+           'ms_per_step_fastest_rank': 1e3 * fast / steps,
+           'fused_kernels_engaged': bool(b._dev.uses_fused_rows() and b._dev.uses_fused_cols()),
+           'stage_model_ratio_per_gpu': 40 * E * (steps / slow) / 1e9 / HBM_PEAK_GBPS,
+           'final_rho': float(its.Rho[-1]), 'final_primal_rsdl': float(its.PrimalRsdl[-1]),
+           'reducer': type(reducer).__name__}
     del b
     return out
 
@@ -968,6 +1019,41 @@ def main():
     del b2
     del b
 
+    config3_sharded = None
+    if world > 1:
+        dev_t = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+
+        def allmax(x):
+            t = torch.tensor([float(x)], dtype=torch.float64, device=dev_t)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.cpu()[0])
+
+        # the same local problem WITHOUT the reducer on every rank at once: what one GPU does alone
+        # -- the N = 1 figure of this very invocation.  sharded / unsharded is the cost of the
+        # collective and of waiting for the slowest rank; the driver's N = 1 run must agree with
+        # `unsharded` (same code path: a one-rank invocation has no reducer either).
+        bu = ResidentConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(
+            {'MaxMainIter': max(args.warmup, 1), 'RelStopTol': 0.0}), device=local_rank, stream=stream)
+        bu.solve()
+        bu.opt['MaxMainIter'] = args.steps
+        sync_all(bu)
+        t0u = time.perf_counter()
+        bu.solve()
+        bu._dev.sync()
+        own_u = time.perf_counter() - t0u
+        del bu
+        slow_u, fast_u = allmax(own_u), -allmax(-own_u)
+        rank_stats.update({'unsharded_ms_per_step_slowest_rank': 1e3 * slow_u / args.steps,
+                           'unsharded_ms_per_step_fastest_rank': 1e3 * fast_u / args.steps,
+                           'sharded_over_unsharded_time': elapsed / slow_u})
+        if args.configs != 'none' and (args.configs == 'all' or 'config3' in args.configs.split(',')):
+            gc.collect()
+            try:
+                config3_sharded = run_config3_sharded(local_rank, rank, world, reducer, stream, sync_all,
+                                                      allmax, tiny=args.tiny)
+            except Exception as e:      # noqa: BLE001 -- every rank fails alike (same shapes) or none
+                config3_sharded = {'error': '%s: %s' % (type(e).__name__, e)}
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -1039,12 +1125,17 @@ def main():
                      # distance to the HBM peak)
                      'algorithmic_bytes_per_launch': alg[dom],
                      'algorithmic_achieved': alg[dom] / dom_ms / 1e6,
-                     'algorithmic_frac': alg[dom] / dom_ms / 1e6 / HBM_PEAK_GBPS,
+                     'stage_model_ratio': alg[dom] / dom_ms / 1e6 / HBM_PEAK_GBPS,
                      'from_profiles': from_profiles,
+                     # (scalars first: consumers that flatten this object keep them)
+                     'placement_clear_all': bool(all(d.get('clear') for d in placement)) if placement else None,
+                     'placement_compact': ' '.join('%s:%s/%d@%.2f' % (d.get('role'), 'clear' if d.get('clear') else 'SHARED',
+                                                                      d.get('candidates', 0), d.get('chosen_ratio', 0.0))
+                                                   for d in placement) if placement else '',
                      'placement': placement},
         'iteration_roofline': dict(
             iteration_summary(table, prof_steps, ms_per_step, iter_alg_bytes),
-            steady_state_algorithmic_frac=iter_alg_bytes * (steady_steps / elapsed_steady) / 1e9
+            steady_state_stage_model_ratio=iter_alg_bytes * (steady_steps / elapsed_steady) / 1e9
             / HBM_PEAK_GBPS),
         'other_options': {'options': names[not args.fastsolve],
                           'value': args.steps / elapsed2 * world,
@@ -1058,6 +1149,8 @@ def main():
         'kernels_ms_per_iter': {k: round(v[0] / prof_steps, 4) for k, v in prof.items() if v[1] > 0},
         'kernel_roofline': table,
     }
+    if config3_sharded is not None:
+        line['configs'] = {'config3_sharded': config3_sharded}
     if world == 1 and args.configs != 'none':
         line['configs'] = run_other_configs(local_rank, args.configs, tiny=args.tiny)
     if world == 1 and args.configs == 'all':
@@ -1083,6 +1176,26 @@ def main():
                 for v in obj:
                     blank(v)
         blank(line)
+    # the numbers that matter once more, compact, as the LAST key: a consumer that keeps only the
+    # tail of this (long) line still has them
+    cfg = line.get('configs') or {}
+    line['summary'] = {
+        'value': line['value'], 'ms_per_step': ms_per_step, 'steady_state': line['steady_state']['value'],
+        'roofline_kernel': dom, 'roofline_frac': line['roofline']['frac'], 'avg_kernel_ms': dom_ms,
+        'placement_clear_all': line['roofline']['placement_clear_all'],
+        'placement': line['roofline']['placement_compact'],
+        'configs': {k: (round(v['value'], 2) if isinstance(v, dict) and 'value' in v else None)
+                    for k, v in cfg.items()},
+        'config_roofline_frac': {k: v['roofline']['frac'] for k, v in cfg.items()
+                                 if isinstance(v, dict) and isinstance(v.get('roofline'), dict)},
+        'next_rows': {k: (round(v['value'], 1) if isinstance(v, dict) and 'value' in v else None)
+                      for k, v in (line.get('next_rows') or {}).items()},
+        'parity_pass': (parity or {}).get('pass') if isinstance(parity, dict) else None,
+        'cpu_baseline': (line.get('cpu_baseline') or {}).get('value'),
+        'ranks': ({k: rank_stats[k] for k in ('ms_per_step_slowest_rank', 'ms_per_step_fastest_rank',
+                                              'sharded_over_unsharded_time', 'reducer') if k in rank_stats}
+                  if rank_stats else None),
+        'frac_violations': bad}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

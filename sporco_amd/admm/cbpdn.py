@@ -682,6 +682,7 @@ class ConvBPDN(GenericConvBPDN):
             opt = ConvBPDN.Options()
         self.set_dtype(opt, S.dtype)
         super(ConvBPDN, self).__init__(D, S, opt, dimK, dimN, **backend)
+        opt = self.opt     # (dimN = 1 / 3: a private copy with the array-valued entries reshaped)
         rdt = real_dtype(self.dtype).type
         if lmbda is None:
             # 0.1 * max |D^H s|  (cbpdn.py:573-578), evaluated on device
@@ -761,11 +762,12 @@ class ConvBPDNJoint(ConvBPDN):
         if opt is None:
             opt = ConvBPDN.Options()
         self.mu = None
-        self.wl21 = np.asarray(opt['L21Weight'] if 'L21Weight' in opt else 1.0)
+        self.wl21 = np.asarray(1.0)      # (until the options have been through the dimN set-up)
         super(ConvBPDNJoint, self).__init__(D, S, lmbda, opt, dimK=dimK, dimN=dimN,
                                             **backend)
         self.mu = self.dtype.type(mu)
-        self.wl21 = np.asarray(self.wl21, dtype=self.dtype)
+        self.wl21 = np.asarray(self.opt['L21Weight'] if 'L21Weight' in self.opt else 1.0,
+                               dtype=self.dtype)
         self._upload_weights()
 
     def _upload_weights(self):

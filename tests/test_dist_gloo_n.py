@@ -78,7 +78,8 @@ def test_bench_multi_rank_fields_under_gloo(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', '29641', os.path.join(REPO, 'bench.py'),
            '--gpus', '2', '--steps', '3', '--warmup', '1', '--size', '128', '--filters', '8', '--images', '1',
-           '--steady-steps', '4', '--no-cpu-baseline', '--no-parity', '--no-time-to-tol', '--configs', 'none']
+           '--steady-steps', '4', '--no-cpu-baseline', '--no-parity', '--no-time-to-tol', '--configs', 'config3',
+           '--tiny']
     r = subprocess.run(cmd, env=env, timeout=1500, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
@@ -90,3 +91,17 @@ def test_bench_multi_rank_fields_under_gloo(tmp_path):
     assert rk['ms_per_step_slowest_rank'] >= rk['ms_per_step_fastest_rank'] > 0
     assert rk['allreduce_calls_timed'] > 0 and rk['allreduce_ms_max'] >= rk['allreduce_ms_mean_worst_rank'] >= 0
     assert d['frac_check']['violations'] == []
+    # the N = 1 figure of the same invocation (every rank alone, no reducer) beside the sharded one
+    assert rk['unsharded_ms_per_step_slowest_rank'] >= rk['unsharded_ms_per_step_fastest_rank'] > 0
+    assert rk['sharded_over_unsharded_time'] > 0
+    # BASELINE configs[2] under the reducer: ConvBPDNJoint, images sharded over the two ranks
+    c3 = d['configs']['config3_sharded']
+    assert 'error' not in c3, c3
+    assert c3['fused_kernels_engaged'] and c3['value'] > 0 and c3['reducer'] == 'TorchReducer'
+    assert c3['ms_per_step'] >= c3['ms_per_step_fastest_rank'] > 0
+    # the compact summary is the LAST key of the line (a tail of the line keeps it)
+    assert list(d)[-1] == 'summary' and lines[0].rstrip().endswith('}}')
+    sm = d['summary']
+    assert sm['value'] == d['value'] and sm['roofline_frac'] == d['roofline']['frac']
+    assert sm['configs'] == {'config3_sharded': round(c3['value'], 2)}
+    assert not any('algorithmic_frac' in k for k in json.dumps(d).split('"'))
