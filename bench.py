@@ -1006,6 +1006,29 @@ def main():
     sync_all(b)
     prof = b.profile_read()
     b.profile(False)
+    # the emitting epilogue in each of its two ping-pong directions (V buffer A -> B, B -> A): one
+    # iteration per solve() call, HIP events of that launch alone.  Equal times = both iterate
+    # buffers lie clear of the spectrum buffer; one direction ~8 % slower = that buffer shares its
+    # region whatever the placement report says.
+    per_direction = None
+    if world == 1:
+        dirs = [[], []]
+        b.opt['MaxMainIter'] = 1
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+        try:
+            for i in range(8):
+                b.profile(True)
+                b.solve()
+                b._dev.sync()
+                p1 = b.profile_read()
+                b.profile(False)
+                v = p1.get('rows_inv_post_v_emit')
+                if v and v[1] == 1:
+                    dirs[i & 1].append(v[0])
+        finally:
+            os.environ.pop('SPORCO_AMD_HOST_LOOP', None)
+        if dirs[0] and dirs[1]:
+            per_direction = [round(float(np.median(d)), 4) for d in dirs]
     # where the library put the arrays the dominant kernel writes at the same time
     # (sporco_amd_csc_placement_report; profiles/r05_placement_notes.md)
     placement = b._dev.placement_report()
@@ -1128,6 +1151,7 @@ def main():
                      'stage_model_ratio': alg[dom] / dom_ms / 1e6 / HBM_PEAK_GBPS,
                      'from_profiles': from_profiles,
                      # (scalars first: consumers that flatten this object keep them)
+                     'per_direction_ms': per_direction,
                      'placement_clear_all': bool(all(d.get('clear') for d in placement)) if placement else None,
                      'placement_compact': ' '.join('%s:%s/%d@%.2f' % (d.get('role'), 'clear' if d.get('clear') else 'SHARED',
                                                                       d.get('candidates', 0), d.get('chosen_ratio', 0.0))
@@ -1183,7 +1207,7 @@ def main():
         'value': line['value'], 'ms_per_step': ms_per_step, 'steady_state': line['steady_state']['value'],
         'roofline_kernel': dom, 'roofline_frac': line['roofline']['frac'], 'avg_kernel_ms': dom_ms,
         'placement_clear_all': line['roofline']['placement_clear_all'],
-        'placement': line['roofline']['placement_compact'],
+        'placement': line['roofline']['placement_compact'], 'per_direction_ms': per_direction,
         'configs': {k: (round(v['value'], 2) if isinstance(v, dict) and 'value' in v else None)
                     for k, v in cfg.items()},
         'config_roofline_frac': {k: v['roofline']['frac'] for k, v in cfg.items()
