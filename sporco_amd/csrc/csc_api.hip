@@ -113,7 +113,7 @@ template <typename T> struct Csc : CscBase {
     T *gramz_t = nullptr;      // its fused path: sum_k |Zf|^2 per row of the tile-major Zf
     bool gramz_valid = false;
     bool cns_fused() const {
-        return rows_ok && fused && cols256 && !sw.cns_generic;
+        return rows_ok && fused && cols256 && !mr && !sw.cns_generic;
     }
     bool ism_valid = false;
     double ism_rho = 0.0, ism_mu = -1.0;   // (ism_mu: mu of the gradient diagonal, -1 = none)
@@ -165,6 +165,14 @@ template <typename T> struct Csc : CscBase {
     int part_f_rows = 0;   // rows of part_f the last column pass wrote (tiles, or tiles x slabs)
     // fused row passes (csc_rows.h)
     bool rows_ok = false;
+    // Mixed-radix shape (round 6): H or W one of 320 / 384 / 448 / 480 -- the register-resident kernels
+    // exist in the instantiations of plain ConvBPDN only (csc_rows_mr.hip, csc_fused.h); every other
+    // option set, and every other solver family, stays on the generic chain for such a handle.
+    bool mr = false;
+    bool mr_ok(const sporco_amd_admm_params &p) const {
+        return !mr || (Cd == 1 && !wl1.ptr && !wl21.ptr &&
+                       !(p.flags & (F_JOINT | F_NOBNDRY | F_AMS | F_GRADREG | F_XRRS)));
+    }
     cx<T> *twRows = nullptr;
     double *part_rows = nullptr;
     // one-launch solve of small problems (csc_rows.h admm_persist): second set of partial-sum
@@ -303,12 +311,13 @@ template <typename T> struct Csc : CscBase {
             SA_HIP(hipMalloc((void **)&sft_mc, sizeof(cx<T>) * npix * CNs));
             SA_HIP(hipMalloc((void **)&bt_mc, sizeof(T) * npix * 2 * Cd * Cd));
             SA_HIP(hipMalloc((void **)&part_f, sizeof(double) * 2 * (int64_t)Wf * CN));
-            SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * H));
-            SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * H));
-            std::vector<cx<T>> ta(H), tb(H);
+            const int ntw = fused_twiddle_count(H);
+            SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * ntw));
+            SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * ntw));
+            std::vector<cx<T>> ta(ntw), tb(ntw);
             fused_twiddles<T>(H, K, ta.data(), tb.data());
-            SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
-            SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * ntw, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * ntw, hipMemcpyHostToDevice));
         }
         if (fused_slabs)
             SA_HIP(hipMalloc((void **)&qpart, sizeof(cx<T>) * (int64_t)Wf * CN * ((K + 63) / 64) * H));
@@ -319,15 +328,25 @@ template <typename T> struct Csc : CscBase {
             // (two per tile, and per 64-filter slab for the gradient-regularised slab pass)
             SA_HIP(hipMalloc((void **)&part_f,
                              sizeof(double) * 2 * (int64_t)Wf * CN * ((K + 63) / 64)));
-            SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * H));
-            SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * H));
-            std::vector<cx<T>> ta(H), tb(H);
+            const int ntw = fused_twiddle_count(H);
+            SA_HIP(hipMalloc((void **)&twA, sizeof(cx<T>) * ntw));
+            SA_HIP(hipMalloc((void **)&twB, sizeof(cx<T>) * ntw));
+            std::vector<cx<T>> ta(ntw), tb(ntw);
             fused_twiddles<T>(H, K, ta.data(), tb.data());
-            SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
-            SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * H, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(twA, ta.data(), sizeof(cx<T>) * ntw, hipMemcpyHostToDevice));
+            SA_HIP(hipMemcpy(twB, tb.data(), sizeof(cx<T>) * ntw, hipMemcpyHostToDevice));
         }
         rows_ok = (fused || fused_slabs || fused_mc) && rows_supported<T>(W, K) &&
                   !sw.old_rows;
+        mr = std::is_same<T, float>::value && (fused_mr_height(H) || rows_mr_width(W));
+        if (mr && !(fused && rows_ok)) {
+            // (a mixed-radix side needs the register kernels on BOTH sides and K <= 64: otherwise
+            // the whole handle is a generic-chain one)
+            rows_ok = false;
+            if (fused_mr_height(H)) fused = false;
+            mr = false;
+        }
+        if (mr) cols256 = false;      // (FISTA, the tile-major dictionary updates, consensus: generic)
         tail_mode = fused_slabs && K - 64 <= kTailMax;
         Ks = (rows_ok && tail_mode) ? 80 : K;
         EFt = npix * CN * (int64_t)Ks;
@@ -522,7 +541,7 @@ template <typename T> struct Csc : CscBase {
     cx<T> *cols_out[2] = {nullptr, nullptr};
     bool cols_striped() const { return cols_out[0] != nullptr; }
     void alloc_cols_out() {
-        if (cols_out[0] || !std::is_same<T, float>::value || !fused || fused_slabs || tail_mode || Ks != K || !rows_ok)
+        if (cols_out[0] || !std::is_same<T, float>::value || !fused || fused_slabs || tail_mode || Ks != K || !rows_ok || mr)
             return;
         const size_t plane = sizeof(cx<T>) * (size_t)CN * H * K;
         const size_t be = plane * (size_t)((Wf + 1) / 2), bo = plane * (size_t)(Wf / 2);

@@ -146,7 +146,13 @@ void launch_mc_binv(hipStream_t st, const cx<T> *dft, T *bt, int64_t nrows, int 
 // tile-major 2-D spectrum of u0 (fields t, dft, sft, twA, H, W, CN, K, Ks, partials); t is only read.
 template <typename T> int64_t launch_cols_dualres(hipStream_t st, const FusedColsArgs<T> &a);
 
-// Host tables twA, twB (H entries each) for fused_cols_supported shapes.
+// Mixed-radix heights (round 6): H = 320, 384, 448, 480 = 16 waves x 20 / 24 / 28 / 30 rows per thread
+// (regfft.h).  The plain column pass only (K <= 64, no gradient term, per-tile operands or stored
+// multipliers).
+bool fused_mr_height(int H);
+// Host tables twA, twB for fused_cols_supported shapes: fused_twiddle_count(H) entries each
+// (H, except for the mixed-radix heights).
+int fused_twiddle_count(int H);
 template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB);
 // True when the register-resident column kernel handles this shape.
 template <typename T> bool fused_cols_supported(int H, int K);

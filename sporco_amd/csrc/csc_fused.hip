@@ -761,23 +761,37 @@ static FusedSplit fused_split(int H, int K) {
     (void)K;
     if (H == 128) return {32, 4, 4};
     if (H == 256) return {32, 8, 2};
+    if (fused_mr_height(H)) return {H / 16, 16, 1};     // 320 ... 480: 20 ... 30 rows per thread
     return {32, 16, 1};
 }
+static int fused_rev(int N1, int i) {
+    switch (N1) {
+    case 20: return mr_rev<20>(i);
+    case 24: return mr_rev<24>(i);
+    case 28: return mr_rev<28>(i);
+    case 30: return mr_rev<30>(i);
+    default: return brev(i, ilog2(N1));
+    }
+}
+bool fused_mr_height(int H) { return H == 320 || H == 384 || H == 448 || H == 480; }
+int fused_twiddle_count(int H) { return H < 512 && fused_mr_height(H) ? 512 : H; }
 
 template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB) {
     const FusedSplit sp = fused_split(H, K);
     const int N1 = sp.N1, NW = sp.NW;
-    const int LB = ilog2(N1), J = N1 / NW;
+    // (mixed-radix heights: two stage-2 lines per wave, the second one only while w + 16 < N1; the
+    // second table has J NW = 32 entries per wave -- fused_twiddle_count(H) in all)
+    const int J = fused_mr_height(H) ? 2 : N1 / NW;
     const double two_pi = 6.283185307179586476925286766559;
     for (int w = 0; w < NW; ++w) {
         for (int i = 0; i < N1; ++i) {
-            const double ang = -two_pi * (double)(w * brev(i, LB)) / (double)H;
+            const double ang = -two_pi * (double)(w * fused_rev(N1, i)) / (double)H;
             twA[w * N1 + i] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
         }
         for (int j = 0; j < J; ++j)
             for (int h2 = 0; h2 < NW; ++h2) {
                 const double ang = -two_pi * (double)((w + NW * j) * h2) / (double)H;
-                twB[w * N1 + NW * j + h2] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
+                twB[w * (J * NW) + NW * j + h2] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
             }
     }
 }
@@ -785,7 +799,7 @@ template void fused_twiddles<float>(int, int, cx<float> *, cx<float> *);
 template void fused_twiddles<double>(int, int, cx<double> *, cx<double> *);
 
 template <> bool fused_cols_supported<float>(int H, int K) {
-    return (H == 128 || H == 256 || H == 512) && K >= 1 && K <= 64;
+    return (H == 128 || H == 256 || H == 512 || fused_mr_height(H)) && K >= 1 && K <= 64;
 }
 template <> bool fused_cols_supported<double>(int, int) { return false; }
 
@@ -850,7 +864,19 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     // (profiles/r02_fused_cols_notes.md)
     a.stagger_groups = kColsStaggerGroups;
     a.stagger_sleeps = kColsStaggerSleeps;
-    if (sp.NW == 4)
+    if (sp.N1 != 32) {
+        // mixed-radix heights: the plain system only (no gradient term, no per-tile operands, no
+        // multipliers stored) -- the API layer keeps everything else on the generic chain
+        SA_REQUIRE(!a.g1t && !a.per_tile && !a.coef_out && !(a.Kv == 64 && a.K > 64),
+                   "mixed-radix heights: the plain column pass only");
+        const bool k64 = a.K == 64;
+        switch (sp.N1) {
+        case 20: k64 ? launch_fused_inst<20, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<20, 16, 1, 0, false>(st, a, ntiles); break;
+        case 24: k64 ? launch_fused_inst<24, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<24, 16, 1, 0, false>(st, a, ntiles); break;
+        case 28: k64 ? launch_fused_inst<28, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<28, 16, 1, 0, false>(st, a, ntiles); break;
+        default: k64 ? launch_fused_inst<30, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<30, 16, 1, 0, false>(st, a, ntiles); break;
+        }
+    } else if (sp.NW == 4)
         launch_fused_k<32, 4, 4>(st, a, ntiles);
     else if (sp.NW == 8)
         launch_fused_k<32, 8, 2>(st, a, ntiles);

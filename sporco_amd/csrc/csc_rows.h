@@ -150,7 +150,14 @@ template <typename T> int64_t launch_rows_inv_prox_fwd(hipStream_t st, const Row
 template <typename T> bool rows_joint_supported(int W, int C, int K);
 // Shapes the register-resident row kernels handle (float32, W in {128, 256, 512}, K even).
 template <typename T> bool rows_supported(int W, int K);
-// Host table for RowsFwdArgs::twA ((W/32) * 32 entries).
+// Mixed-radix widths (round 6): 320, 384, 448, 480 = 16 waves x 20 / 24 / 28 / 30 points per thread
+// (csc_rows_mr.hip).  Plain ConvBPDN options only: scalar weights, no NoBndryCross / AddMaskSim /
+// Joint; the launchers refuse anything else and the API layer keeps such calls on the generic chain.
+bool rows_mr_width(int W);
+void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a);
+int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a);
+int64_t launch_rows_inv_prox_fwd_mr(hipStream_t st, const RowsProxArgs<float> &a);
+// Host table for RowsFwdArgs::twA (W entries: [wave][point of the in-register transform]).
 template <typename T> void rows_twiddles(int W, cx<T> *twA);
 template <typename T> void launch_rows_fwd(hipStream_t st, const RowsFwdArgs<T> &a);
 // Returns the number of tiles (= rows of `partials` written).

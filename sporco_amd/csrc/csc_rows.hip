@@ -47,9 +47,17 @@ constexpr size_t rows_lds_bytes(int NW) {
 // line k1 held in slot j of spectral-side wave w (see the file header): slots (2 m, 2 m + 1) hold
 // a pair {k1, 32 - k1} (wave 0, m = 0: the self-paired lines 0 and 16).  NW = 4 (W = 128) has
 // eight slots per wave: the four of the other splits, then {4 + w, 28 - w} and {9 + w, 23 - w}.
-template <int NW> __device__ __forceinline__ int line_of(int w, int j) {
+// Mixed-radix lines (round 6): N1 = 20 / 24 / 28 / 30 points per thread with NW = 16 waves (W = 320 /
+// 384 / 448 / 480).  The spatial side is as before (wave w, pixels x = 16 n1 + w, n1 < N1); on the
+// spectral side the N1 lines make N1 / 2 pairs {k1, N1 - k1} (wave 0: the self-paired 0 and N1 / 2),
+// one pair per wave for the first NA = N1 / 2 waves -- the remaining 16 - NA waves idle through the
+// second transform and the spectrum loads / stores (a fifth of a stage that is not what bounds
+// the kernel) and take part in the exchange and its barriers only.
+template <int N1, int NW> constexpr int spectral_waves() { return regfft::mr_length(N1) ? N1 / 2 : NW; }
+template <int N1, int NW> constexpr int spectral_lines() { return regfft::mr_length(N1) ? 2 : N1 / NW; }
+template <int N1, int NW> __device__ __forceinline__ int line_of(int w, int j) {
     if (j == 0) return w;
-    if (j == 1) return w == 0 ? 16 : 32 - w;
+    if (j == 1) return w == 0 ? N1 / 2 : N1 - w;
     if (j == 2) return w == 0 ? 8 : 16 - w;
     if (j == 3) return w == 0 ? 24 : 16 + w;
     if (j == 4) return 4 + w;
@@ -64,18 +72,18 @@ template <int NW> __device__ __forceinline__ int line_of(int w, int j) {
 __host__ __device__ constexpr bool first_half4(int k1) {
     return k1 < 4 || k1 == 8 || (k1 >= 13 && k1 <= 19) || k1 == 24 || k1 > 28;
 }
-__host__ __device__ constexpr int group_of(int NW, int k1) {
+__host__ __device__ constexpr int group_of(int N1, int NW, int k1) {
     if (NW == 4) return first_half4(k1) ? 0 : 1;
-    return NW == 16 ? (k1 >> 4) : ((k1 < 8 || k1 == 16 || k1 > 24) ? 0 : 1);
+    return NW == 16 ? (k1 >= N1 / 2 ? 1 : 0) : ((k1 < 8 || k1 == 16 || k1 > 24) ? 0 : 1);
 }
-__host__ __device__ constexpr int kl_of(int NW, int k1) {
+__host__ __device__ constexpr int kl_of(int N1, int NW, int k1) {
     if (NW == 4) {       // rank of the line among the 16 of its half
         int r = 0;
         for (int o = 0; o < k1; ++o) r += first_half4(o) == first_half4(k1) ? 1 : 0;
         return r;
     }
-    if (NW == 16) return k1 & 15;
-    if (group_of(NW, k1) == 0) return k1 < 8 ? k1 : (k1 == 16 ? 8 : k1 - 16);
+    if (NW == 16) return k1 >= N1 / 2 ? k1 - N1 / 2 : k1;
+    if (group_of(N1, NW, k1) == 0) return k1 < 8 ? k1 : (k1 == 16 ? 8 : k1 - 16);
     return k1 < 16 ? k1 - 8 : k1 - 9;
 }
 
@@ -99,15 +107,16 @@ template <int MODE> __device__ __forceinline__ float soft1_m(float v, float thr)
 // f <= W/2 are stored tile-major at t[f][cn][h][k..k+1].
 // COH (here and below): the spectrum changes hands between workgroups of the same launch
 // (admm_persist_kernel) -- agent-scope accesses instead of the streaming ones.
-template <int NW, bool COH = false>
-__device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA, cf *t, int CN, int H,
+template <int NW, bool COH = false, int N1 = kN1>
+__device__ __forceinline__ void spatial_to_spectral(cf (&v)[N1], const cf *twA, cf *t, int CN, int H,
                                                     int K, int cn, int k, int h, bool pv, int w,
                                                     int lane, f2 *L, int &token) {
-    constexpr int N1 = kN1, J = N1 / NW;
+    constexpr int J = spectral_lines<N1, NW>(), NA = spectral_waves<N1, NW>();
     constexpr int NG = 2;                    // exchange halves
     constexpr int LPG = J / NG;
     constexpr int LBW = ilog2(NW);
-    dif<N1, false>(v, 0);
+    const bool act = NA >= NW || w < NA;     // (wave-uniform; always true for the power-of-two lines)
+    dif1<N1, false>(v, 0);
 #pragma unroll
     for (int i = 1; i < N1; ++i) {
         cf tw;
@@ -117,33 +126,36 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
     reg_fence<N1>(v, 0, token);
 
     // ---- exchange to the spectral side: z[NW j + n2] = C[line_of<NW>(w, j)][n2] ------------
-    cf z[N1];
+    cf z[J * NW];
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1) {
-            if (group_of(NW, k1) != g) continue;
-            const cf x = v[brev(k1, 5)];   // C[k1][n2 = w]
+            if (group_of(N1, NW, k1) != g) continue;
+            const cf x = v[pos1<N1>(k1)];   // C[k1][n2 = w]
             f2 t;
             t.x = x.re;
             t.y = x.im;
-            L[(kl_of(NW, k1) * NW + w) * 64 + lane] = t;
+            L[(kl_of(N1, NW, k1) * NW + w) * 64 + lane] = t;
         }
         __syncthreads();
+        if (act) {
 #pragma unroll
-        for (int jl = 0; jl < LPG; ++jl) {
-            const int j = g * LPG + jl;
-            const int kl = kl_of(NW, line_of<NW>(w, j));
+            for (int jl = 0; jl < LPG; ++jl) {
+                const int j = g * LPG + jl;
+                const int kl = kl_of(N1, NW, line_of<N1, NW>(w, j));
 #pragma unroll
-            for (int n2 = 0; n2 < NW; ++n2) {
-                const f2 t = L[(kl * NW + n2) * 64 + lane];
-                z[NW * j + n2] = mk<float>(t.x, t.y);
+                for (int n2 = 0; n2 < NW; ++n2) {
+                    const f2 t = L[(kl * NW + n2) * 64 + lane];
+                    z[NW * j + n2] = mk<float>(t.x, t.y);
+                }
             }
         }
         if (g + 1 < NG) __syncthreads();
     });
+    if (!act) return;
 
-    // ---- transform over n2: z[NW j + i] = Z[k1 + 32 brev(i)] -----------------------------
+    // ---- transform over n2: z[NW j + i] = Z[k1 + N1 brev(i)] -----------------------------
 #pragma unroll
     for (int j = 0; j < J; ++j) dif<NW, false>(z, NW * j);
 
@@ -164,9 +176,9 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 #pragma unroll
     for (int pr = 0; pr < J / 2; ++pr) {
         const int ja = 2 * pr, jb = 2 * pr + 1;
-        const int k1a = line_of<NW>(w, ja), k1b = line_of<NW>(w, jb);
+        const int k1a = line_of<N1, NW>(w, ja), k1b = line_of<N1, NW>(w, jb);
         if (pr == 0 && w == 0) {
-            // self-paired lines 0 and 16: f and W - f sit in the same line
+            // self-paired lines 0 and N1 / 2: f and W - f sit in the same line
 #pragma unroll
             for (int k2 = 0; k2 <= NW / 2; ++k2) {
                 const cf zf = z[NW * ja + brev(k2 % NW, LBW)];
@@ -180,7 +192,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
                 store_unit(N1 / 2 + N1 * k2, zf, zp);
             }
         } else {
-            // W - (k1a + 32 k2) = k1b + 32 (NW - 1 - k2)
+            // W - (k1a + N1 k2) = k1b + N1 (NW - 1 - k2)
 #pragma unroll
             for (int k2 = 0; k2 < NW / 2; ++k2) {
                 store_unit(k1a + N1 * k2, z[NW * ja + brev(k2, LBW)],
@@ -202,15 +214,16 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[kN1], const cf *twA,
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
-template <int NW, bool COH = false, typename Hook = NoHook>
-__device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW, const cf *t, int CN,
+template <int NW, bool COH = false, int N1 = kN1, typename Hook = NoHook>
+__device__ __forceinline__ void spectral_to_spatial(cf (&v)[N1], const cf *twW, const cf *t, int CN,
                                                     int H, int K, int cn, int k, int h, bool pv, int w,
                                                     int lane, f2 *L, int &token, const cf *t_odd = nullptr,
                                                     Hook before_last = Hook()) {
-    constexpr int N1 = kN1, W = N1 * NW, J = N1 / NW;
+    constexpr int J = spectral_lines<N1, NW>(), NA = spectral_waves<N1, NW>();
     constexpr int NG = 2;
     constexpr int LPG = J / NG;
     constexpr int LBW = ilog2(NW);
+    const bool act = NA >= NW || w < NA;     // (see spatial_to_spectral)
     const cf zero = mk<float>(0.f, 0.f);
     // ---- spectral side: load the bins f <= W/2 of this thread's lines, rebuild Z -------
     const int64_t tline = (int64_t)CN * H * K;
@@ -231,11 +244,12 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
         }
         return ab;
     };
-    cf z[N1];   // z[NW j + i] = Z[line_of<NW>(w, j) + 32 brev(i)]
+    cf z[J * NW];   // z[NW j + i] = Z[line_of<N1, NW>(w, j) + N1 brev(i)]
+    if (act) {
 #pragma unroll
     for (int pr = 0; pr < J / 2; ++pr) {
         const int ja = 2 * pr, jb = 2 * pr + 1;
-        const int k1a = line_of<NW>(w, ja), k1b = line_of<NW>(w, jb);
+        const int k1a = line_of<N1, NW>(w, ja), k1b = line_of<N1, NW>(w, jb);
         if (pr == 0 && w == 0) {
 #pragma unroll
             for (int k2 = 0; k2 <= NW / 2; ++k2) {
@@ -266,24 +280,26 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
             }
         }
     }
-    reg_fence<N1>(z, 0, token);
+    reg_fence<J * NW>(z, 0, token);
+    }
 
     // ---- inverse transform over k2, conj twiddle, exchange to the spatial side --------------
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
+        if (act) {
 #pragma unroll
         for (int jl = 0; jl < LPG; ++jl) {
             const int j = g * LPG + jl;
-            const int k1 = line_of<NW>(w, j);
-            const int kl = kl_of(NW, k1);
+            const int k1 = line_of<N1, NW>(w, j);
+            const int kl = kl_of(N1, NW, k1);
             dit<NW, true>(z, NW * j);
 #pragma unroll
             for (int n2 = 0; n2 < NW; ++n2) {
                 cf x = z[NW * j + n2];
                 if (n2 > 0) {
+                    // (n2 k1 < NW N1 = W: the table index needs no reduction)
                     cf tw;
-                    sa_uload2(reinterpret_cast<const float *>(twW + ((n2 * k1) & (W - 1))), tw.re,
-                              tw.im);
+                    sa_uload2(reinterpret_cast<const float *>(twW + n2 * k1), tw.re, tw.im);
                     x = cmulc(tw, x);
                 }
                 f2 t;
@@ -292,18 +308,19 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
                 L[(kl * NW + n2) * 64 + lane] = t;
             }
         }
+        }
         __syncthreads();
 #pragma unroll
         for (int k1 = 0; k1 < N1; ++k1) {
-            if (group_of(NW, k1) != g) continue;
-            const f2 t = L[(kl_of(NW, k1) * NW + w) * 64 + lane];
-            v[brev(k1, 5)] = mk<float>(t.x, t.y);
+            if (group_of(N1, NW, k1) != g) continue;
+            const f2 t = L[(kl_of(N1, NW, k1) * NW + w) * 64 + lane];
+            v[pos1<N1>(k1)] = mk<float>(t.x, t.y);
         }
         if (g + 1 < NG) __syncthreads();
     });
     reg_fence<N1>(v, 0, token);
     before_last();
-    dit<N1, true>(v, 0);   // v[n1] = (X_p, X_{p+1}) at x = NW n1 + w, unnormalised
+    dit1<N1, true>(v, 0);   // v[n1] = (X_p, X_{p+1}) at x = NW n1 + w, unnormalised
 }
 
 // ---------------------------------------------------------------------------
@@ -316,9 +333,9 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[kN1], const cf *twW,
 // -- one image, 32 filters, all C <= 4 channels, lane = (channel, filter pair).
 // MODE (with VFORM, as rows_inv_post): 1 = L1Weight array (+ NoBndryCross, AddMaskSim), 2 =
 // NoBndryCross and / or AddMaskSim without a weight array -- the derivation of Y repeats them.
-template <int NW, bool BCAST, bool VFORM, bool JOINT, int MODE, bool COH = false, typename AP>
+template <int NW, bool BCAST, bool VFORM, bool JOINT, int MODE, bool COH = false, int N1 = kN1, typename AP>
 __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
-    constexpr int N1 = kN1, W = N1 * NW;
+    constexpr int W = N1 * NW;
     constexpr bool GENERAL = MODE != 0;
     static_assert(!(BCAST && VFORM), "the broadcast form reads a dictionary-sized Y");
     static_assert(!JOINT || VFORM, "only the V form needs the joint tiling");
@@ -453,8 +470,8 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
         }
         reg_fence<N1 / 2>(v, half * (N1 / 2), token);
     }
-    spatial_to_spectral<NW, COH>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
-                            token);
+    spatial_to_spectral<NW, COH, N1>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
+                                     token);
 }
 
 // Tile loop shared by the row kernels: a 1-D grid of G workgroups, workgroup b takes the tiles
@@ -477,14 +494,14 @@ __device__ __forceinline__ void rows_tile_loop(const A &a_in, int tiles_x, int t
     }
 }
 
-template <int NW, bool BCAST, bool VFORM = false, bool JOINT = false, int MODE = 0>
+template <int NW, bool BCAST, bool VFORM = false, bool JOINT = false, int MODE = 0, int N1 = kN1>
 __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<float> a_in) {
     // device-driven solve: nothing to do once the stopping test is met, or when the previous
     // epilogue already left this spectrum behind
     if (a_in.ctl && (a_in.ctl->stop | a_in.ctl->skip_fwd)) return;
     const int tiles_x = JOINT ? a_in.N * (a_in.K >> 5) : (int)((a_in.P + 127) / 128);
     rows_tile_loop(a_in, tiles_x, a_in.H,
-                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM, JOINT, MODE>(a, bx, h); });
+                   [](auto a, int bx, int h) { rows_fwd_tile<NW, BCAST, VFORM, JOINT, MODE, false, N1>(a, bx, h); });
 }
 
 // ---------------------------------------------------------------------------
@@ -493,13 +510,22 @@ __global__ void __launch_bounds__(NW * 64) rows_fwd_kernel(const RowsFwdArgs<flo
 // MODE: 0 = plain epilogue; 1 = L1Weight array (+ NoBndryCross, AddMaskSim); 2 = NoBndryCross
 // and / or AddMaskSim without a weight array (no weight loads).
 // SF (state form, csc_rows.h): 0 = (Y, U) in and out; 1 = (Y, U) in, V' out; 2 = V in, V' out.
-template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT, int SF, bool COH = false, typename AP>
+// largest divisor of n that is <= want (pixels per batch of the epilogue: N1 = 20 ... 30 have other
+// divisors than the powers of two)
+constexpr int batch_of(int n, int want) {
+    int b = 1;
+    for (int d = 1; d <= want; ++d)
+        if (n % d == 0) b = d;
+    return b;
+}
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT, int SF, bool COH = false, int N1 = kN1,
+          typename AP>
 __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tiles_x) {
     constexpr bool GENERAL = MODE != 0;
     constexpr bool VIN = SF == 2, VOUT = SF != 0;
     static_assert(!JOINT || MODE == 0, "the joint epilogue takes scalar weights only");
     static_assert(SF == 0 || !WRITE_X, "V form: no X output");
-    constexpr int N1 = kN1, W = N1 * NW;
+    constexpr int W = N1 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -559,9 +585,9 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 #endif
     constexpr bool PARK = EMIT_T && VIN && (JOINT ? SA_PARK_JOINT != 0 : SA_PARK_PLAIN != 0);
     constexpr int NP = N1 / 2;      // parked pixels per thread
-    constexpr int B = EMIT_T ? (JOINT ? (PARK ? SA_POST_B_JOINT_PARK : 1)
-                                      : (VIN ? (PARK ? SA_POST_B_PLAIN_PARK : 4) : 2))
-                             : ((VIN && !JOINT) ? SA_POST_B_VIN : 4);
+    constexpr int B = batch_of(PARK ? NP : N1, EMIT_T ? (JOINT ? (PARK ? SA_POST_B_JOINT_PARK : 1)
+                                                               : (VIN ? (PARK ? SA_POST_B_PLAIN_PARK : 4) : 2))
+                                                      : ((VIN && !JOINT) ? SA_POST_B_VIN : 4));
     cf yb[2][B], ub[2][B];
     cf v[N1];
     if constexpr (PARK) {
@@ -574,8 +600,8 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 #pragma unroll
             for (int i = 0; i < B; ++i) yb[0][i] = buf_load_cf(Vb0, voff0, (NW * i + w) * pixbytes0);
         };
-        spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
-                                     token, a->t_odd, first_fetch);
+        spectral_to_spatial<NW, COH, N1>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
+                                         token, a->t_odd, first_fetch);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             f2 t;
@@ -584,8 +610,8 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
             L[(i * NW + w) * 64 + lane] = t;
         }
     } else {
-        spectral_to_spatial<NW, COH>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
-                                     token, a->t_odd);
+        spectral_to_spatial<NW, COH, N1>(v, a->twW, a->t, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
+                                         token, a->t_odd);
     }
 
     // ---- ADMM epilogue on the 32 pixels of this thread ---------------------------------------
@@ -824,8 +850,8 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
         // iteration's rows_fwd would compute from these very values, stored over the
         // units this thread consumed (same spectral-side ownership: in place is safe).
         reg_fence<N1>(v, 0, token);
-        spatial_to_spectral<NW, COH>(v, a->twA, a->t_next, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane,
-                                L, token);
+        spatial_to_spectral<NW, COH, N1>(v, a->twA, a->t_next, CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane,
+                                         L, token);
         __syncthreads();   // the reduction scratch below sits next to the exchange buffer
     }
 
@@ -839,7 +865,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 
 // (two 8-wave workgroups share a CU only at <= 128 registers: the joint emitting variants land a
 // register or two above that on their own, so they are told -- second argument = waves per SIMD)
-template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false, int SF = 0>
+template <int NW, bool WRITE_X, int MODE, bool EMIT_T, bool JOINT = false, int SF = 0, int N1 = kN1>
 __global__ void __launch_bounds__(NW * 64, (JOINT && EMIT_T && NW == 8) ? 4 : 1)
 rows_inv_post_kernel(const RowsPostArgs<float> a_in) {
     // device-driven solve: both variants are enqueued every iteration and the one whose EMIT_T
@@ -849,16 +875,16 @@ rows_inv_post_kernel(const RowsPostArgs<float> a_in) {
     if (a_in.ctl && (a_in.ctl->stop | (a_in.ctl->emit != (EMIT_T ? 1 : 0)))) return;
     const int tiles_x = JOINT ? a_in.N * (a_in.K >> 5) : (int)((a_in.P + 127) / 128);
     rows_tile_loop(a_in, tiles_x, a_in.H, [tiles_x](auto a, int bx, int h) {
-        rows_inv_post_tile<NW, WRITE_X, MODE, EMIT_T, JOINT, SF>(a, bx, h, tiles_x);
+        rows_inv_post_tile<NW, WRITE_X, MODE, EMIT_T, JOINT, SF, false, N1>(a, bx, h, tiles_x);
     });
 }
 
 // ---------------------------------------------------------------------------
 // rows_inv_prox_fwd: X = prox_l1(irfft_W(T_in) / (H W)); T_out = rfft_W(X)
 // ---------------------------------------------------------------------------
-template <int NW, bool GENERAL, typename AP>
+template <int NW, bool GENERAL, int N1 = kN1, typename AP>
 __device__ __forceinline__ void rows_inv_prox_fwd_tile(AP ap, int bx, int h, int tiles_x) {
-    constexpr int N1 = kN1, W = N1 * NW;
+    constexpr int W = N1 * NW;
     const auto &a = *ap;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -872,8 +898,8 @@ __device__ __forceinline__ void rows_inv_prox_fwd_tile(AP ap, int bx, int h, int
     int token = 0;
 
     cf v[N1];
-    spectral_to_spatial<NW>(v, a.twW, a.t_in, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
-                            token);
+    spectral_to_spatial<NW, false, N1>(v, a.twW, a.t_in, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
+                                       token);
 
     // ---- proximal step on the 32 pixels of this thread -----------------------------------------
     const int64_t rowoff = (int64_t)h * W * a.P;
@@ -923,15 +949,15 @@ __device__ __forceinline__ void rows_inv_prox_fwd_tile(AP ap, int bx, int h, int
     if (!a.t_out) return;
     reg_fence<N1>(v, 0, token);
 
-    spatial_to_spectral<NW>(v, a.twA, a.t_out, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
-                            token);
+    spatial_to_spectral<NW, false, N1>(v, a.twA, a.t_out, CN, a.H, a.Ks ? a.Ks : a.K, cn, k, h, pv, w, lane, L,
+                                       token);
 }
 
-template <int NW, bool GENERAL>
+template <int NW, bool GENERAL, int N1 = kN1>
 __global__ void __launch_bounds__(NW * 64) rows_inv_prox_fwd_kernel(const RowsProxArgs<float> a_in) {
     const int tiles_x = (int)((a_in.P + 127) / 128);
     rows_tile_loop(a_in, tiles_x, a_in.H, [tiles_x](auto a, int bx, int h) {
-        rows_inv_prox_fwd_tile<NW, GENERAL>(a, bx, h, tiles_x);
+        rows_inv_prox_fwd_tile<NW, GENERAL, N1>(a, bx, h, tiles_x);
     });
 }
 
@@ -1111,26 +1137,42 @@ void set_lds_attr(K kernel) {
 
 }  // namespace
 
+// points per thread of a supported line length: 32 for the powers of two, W / 16 for the
+// mixed-radix lengths 320, 384, 448, 480
+static int rows_n1(int W) { return rows_mr_width(W) ? W / 16 : kN1; }
+static int rows_rev(int N1, int i) {
+    switch (N1) {
+    case 20: return regfft::mr_rev<20>(i);
+    case 24: return regfft::mr_rev<24>(i);
+    case 28: return regfft::mr_rev<28>(i);
+    case 30: return regfft::mr_rev<30>(i);
+    default: return regfft::brev(i, 5);
+    }
+}
+
+#ifndef SA_ROWS_MR_TU
+bool rows_mr_width(int W) { return W == 320 || W == 384 || W == 448 || W == 480; }
 template <> bool rows_supported<float>(int W, int K) {
-    return (W == 128 || W == 256 || W == 512) && K >= 2 && K % 2 == 0;
+    return (W == 128 || W == 256 || W == 512 || rows_mr_width(W)) && K >= 2 && K % 2 == 0;
 }
 template <> bool rows_supported<double>(int, int) { return false; }
 template <> bool rows_joint_supported<float>(int W, int C, int K) {
-    return rows_supported<float>(W, K) && C >= 1 && C <= 4 && K % 32 == 0;
+    return rows_supported<float>(W, K) && !rows_mr_width(W) && C >= 1 && C <= 4 && K % 32 == 0;
 }
 template <> bool rows_joint_supported<double>(int, int, int) { return false; }
 
 template <typename T> void rows_twiddles(int W, cx<T> *twA) {
-    const int NW = W / kN1;
+    const int N1 = rows_n1(W), NW = W / N1;
     const double two_pi = 6.283185307179586476925286766559;
     for (int w = 0; w < NW; ++w)
-        for (int i = 0; i < kN1; ++i) {
-            const double ang = -two_pi * (double)(w * regfft::brev(i, 5)) / (double)W;
-            twA[w * kN1 + i] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
+        for (int i = 0; i < N1; ++i) {
+            const double ang = -two_pi * (double)(w * rows_rev(N1, i)) / (double)W;
+            twA[w * N1 + i] = mk<T>((T)std::cos(ang), (T)std::sin(ang));
         }
 }
 template void rows_twiddles<float>(int, cx<float> *);
 template void rows_twiddles<double>(int, cx<double> *);
+#endif
 
 // Workgroups of a persistent row-kernel launch: what the device holds at once (one 16-wave
 // workgroup per CU, two 8-wave ones).
@@ -1148,6 +1190,7 @@ static dim3 rows_grid(A &a, int NW, int64_t tiles_x, int64_t tiles_y, int want) 
     return dim3((unsigned)(a.persist ? g : n), 1);
 }
 
+#ifndef SA_ROWS_MR_TU
 // ---- the one-launch solve ---------------------------------------------------------------------
 template <> bool admm_persist_supported<float>(int H, int W, int K) {
     return H == W && (W == 128 || W == 256) && K >= 2 && K % 2 == 0 && K <= 64;
@@ -1249,6 +1292,10 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
         set_lds_attr<16>(&rows_fwd_kernel<16, false, true, true>);
     }
     SA_REQUIRE(!(a.v && a.y_bcast), "the broadcast row pass has no V form");
+    if (rows_mr_width(a.W)) {
+        launch_rows_fwd_mr(st, a);
+        return;
+    }
     if (a.v && !(a.flags & F_JOINT) &&
         (a.wl1.ptr || (a.flags & F_NOBNDRY) || a.ams_bits)) {
         // the V form under an L1Weight array / NoBndryCross / AddMaskSim
@@ -1424,6 +1471,7 @@ template <> int64_t launch_rows_inv_post<float>(hipStream_t st, const RowsPostAr
     RowsPostArgs<float> a = a_in;
     SA_REQUIRE(rows_supported<float>(a.W, a.K), "shape not handled by the fused row kernels");
     SA_REQUIRE(a.H <= 65535, "too many rows for one launch");
+    if (rows_mr_width(a.W)) return launch_rows_inv_post_mr(st, a);
     if (a.flags & F_JOINT) {
         SA_REQUIRE(!a.v_in || a.v_out, "a V-form input needs a V-form output");
         SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && !a.wl1.ptr && !a.ams_bits &&
@@ -1487,6 +1535,7 @@ template <> int64_t launch_rows_inv_prox_fwd<float>(hipStream_t st, const RowsPr
     // (the forward half of this kernel is the emitting epilogue's, which gained 8 % from a
     // persistent launch; this one does not -- config 4 244.7-245.8 it/s persistent against
     // 240.7-246.2 per tile, profiles/r03g_config4_prox_persist.jsonl: one tile per workgroup)
+    if (rows_mr_width(a.W)) return launch_rows_inv_prox_fwd_mr(st, a);
     RowsProxArgs<float> ap = a;
     const int64_t tx = ceil_div(a.P, 128);
     const dim3 grid = rows_grid(ap, a.W / kN1, tx, a.H, 0);
@@ -1506,5 +1555,7 @@ template <> int64_t launch_rows_inv_prox_fwd<double>(hipStream_t, const RowsProx
 template <> int64_t launch_rows_inv_post<double>(hipStream_t, const RowsPostArgs<double> &) {
     throw Error(-1, "the fused row kernels are float32 only");
 }
+
+#endif   // SA_ROWS_MR_TU
 
 }  // namespace sporco_amd

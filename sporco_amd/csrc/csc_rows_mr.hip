@@ -1,0 +1,108 @@
+// csc_rows_mr.hip -- the register-resident row passes (csc_rows.h) at the mixed-radix widths
+// W = 320, 384, 448, 480: 16 waves x N1 = 20 / 24 / 28 / 30 points per thread, the in-register
+// transform of N1 points from regfft.h (radices 5.2.2, 3.2.2.2, 7.2.2, 5.3.2).  The kernels are the
+// templates of csc_rows.hip instantiated with that N1 (a translation unit of its own: they compile
+// side by side with the power-of-two ones); only the variants of plain ConvBPDN are built -- scalar
+// weights, no NoBndryCross / AddMaskSim / Joint -- which is what sporco/admm/cbpdn.py:267-311, 614-630
+// runs with default options at image sizes such as the reference's own odd-sized tests
+// (tests/admm/test_cbpdn.py:204-225).
+#define SA_ROWS_MR_TU
+#include "csc_rows.hip"
+
+namespace sporco_amd {
+
+namespace {
+
+template <int N1> void fwd_mr(hipStream_t st, RowsFwdArgs<float> &a) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
+        set_lds_attr<16>(&rows_fwd_kernel<16, false, false, false, 0, N1>);
+        set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 0, N1>);
+    }
+    const dim3 grid = rows_grid(a, 16, ceil_div(a.P, 128), a.H, 0);
+    if (a.v)
+        hipLaunchKernelGGL((rows_fwd_kernel<16, false, true, false, 0, N1>), grid, dim3(16 * 64), rows_lds_bytes(16),
+                           st, a);
+    else
+        hipLaunchKernelGGL((rows_fwd_kernel<16, false, false, false, 0, N1>), grid, dim3(16 * 64), rows_lds_bytes(16),
+                           st, a);
+}
+
+template <int N1, bool EMIT> void post_mr(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
+        set_lds_attr<16>(&rows_inv_post_kernel<16, false, 0, EMIT, false, 0, N1>);
+        set_lds_attr<16>(&rows_inv_post_kernel<16, true, 0, EMIT, false, 0, N1>);
+        set_lds_attr<16>(&rows_inv_post_kernel<16, false, 0, EMIT, false, 1, N1>);
+        set_lds_attr<16>(&rows_inv_post_kernel<16, false, 0, EMIT, false, 2, N1>);
+    }
+    const dim3 block(16 * 64);
+    const size_t lds = rows_lds_bytes(16);
+    if (a.v_out) {
+        SA_REQUIRE(!a.x, "the V form has no X output");
+        if (a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<16, false, 0, EMIT, false, 2, N1>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((rows_inv_post_kernel<16, false, 0, EMIT, false, 1, N1>), grid, block, lds, st, a);
+        return;
+    }
+    SA_REQUIRE(!a.v_in, "a V-form input needs a V-form output");
+    if (a.x) hipLaunchKernelGGL((rows_inv_post_kernel<16, true, 0, EMIT, false, 0, N1>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((rows_inv_post_kernel<16, false, 0, EMIT, false, 0, N1>), grid, block, lds, st, a);
+}
+
+template <int N1> void prox_mr(hipStream_t st, const RowsProxArgs<float> &a, dim3 grid) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) set_lds_attr<16>(&rows_inv_prox_fwd_kernel<16, false, N1>);
+    hipLaunchKernelGGL((rows_inv_prox_fwd_kernel<16, false, N1>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+}
+
+}  // namespace
+
+void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
+    RowsFwdArgs<float> a = a_in;
+    SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
+    SA_REQUIRE(!a.y_bcast && !(a.flags & (F_JOINT | F_NOBNDRY)) && !a.wl1.ptr && !a.ams_bits,
+               "mixed-radix widths: plain ConvBPDN options only");
+    switch (a.W / 16) {
+    case 20: fwd_mr<20>(st, a); break;
+    case 24: fwd_mr<24>(st, a); break;
+    case 28: fwd_mr<28>(st, a); break;
+    default: fwd_mr<30>(st, a); break;
+    }
+    SA_HIP(hipGetLastError());
+}
+
+int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a_in) {
+    RowsPostArgs<float> a = a_in;
+    SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
+    SA_REQUIRE(!(a.flags & (F_JOINT | F_NOBNDRY)) && !a.wl1.ptr && !a.ams_bits && !a.emit_u && !a.t_odd,
+               "mixed-radix widths: plain ConvBPDN options only");
+    const int64_t tx = ceil_div(a.P, 128);
+    const bool emit = a.t_next != nullptr;
+    const dim3 grid = rows_grid(a, 16, tx, a.H, emit);
+    switch (a.W / 16) {
+    case 20: emit ? post_mr<20, true>(st, a, grid) : post_mr<20, false>(st, a, grid); break;
+    case 24: emit ? post_mr<24, true>(st, a, grid) : post_mr<24, false>(st, a, grid); break;
+    case 28: emit ? post_mr<28, true>(st, a, grid) : post_mr<28, false>(st, a, grid); break;
+    default: emit ? post_mr<30, true>(st, a, grid) : post_mr<30, false>(st, a, grid); break;
+    }
+    SA_HIP(hipGetLastError());
+    return tx * a.H;
+}
+
+int64_t launch_rows_inv_prox_fwd_mr(hipStream_t st, const RowsProxArgs<float> &a_in) {
+    RowsProxArgs<float> a = a_in;
+    SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
+    SA_REQUIRE(!a.wl1.ptr && !(a.flags & F_NOBNDRY) && a.thr >= 0.f, "mixed-radix widths: plain options only");
+    const int64_t tx = ceil_div(a.P, 128);
+    const dim3 grid = rows_grid(a, 16, tx, a.H, 0);
+    switch (a.W / 16) {
+    case 20: prox_mr<20>(st, a, grid); break;
+    case 24: prox_mr<24>(st, a, grid); break;
+    case 28: prox_mr<28>(st, a, grid); break;
+    default: prox_mr<30>(st, a, grid); break;
+    }
+    SA_HIP(hipGetLastError());
+    return tx * a.H;
+}
+
+}  // namespace sporco_amd

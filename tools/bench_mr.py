@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Mixed-radix image sizes (H, W in {320, 384, 448, 480}: csc_rows_mr.hip, csc_fused.h) on the
+register-resident kernels against the generic chain (SPORCO_AMD_UNFUSED=1) of the same library:
+iterations/s, per-kernel times, and the agreement of the two after a few iterations.
+One JSON line per shape."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from sporco_amd.admm import cbpdn as ac
+
+SHAPES = [(384, 384, 32, 8), (480, 320, 64, 8), (320, 480, 32, 8), (448, 448, 64, 8), (384, 512, 64, 8),
+          (480, 480, 64, 16)]
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ''
+
+
+class NoDownload(ac.ConvBPDN):
+    def getmin(self):
+        return None
+
+
+def solver(D, S, unfused, iters, cls=ac.ConvBPDN):
+    if unfused:
+        os.environ['SPORCO_AMD_UNFUSED'] = '1'
+    try:
+        return cls(D, S, 0.05, cls.Options({'MaxMainIter': iters, 'RelStopTol': 0.0}))
+    finally:
+        os.environ.pop('SPORCO_AMD_UNFUSED', None)
+
+
+for (H, W, K, N) in SHAPES:
+    if ONLY not in '%dx%d K=%d' % (H, W, K):
+        continue
+    rng = np.random.RandomState(1)
+    D = rng.randn(8, 8, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, N).astype(np.float32)
+    out = {'config': 'admm.cbpdn.ConvBPDN %dx%d K=%d N=%d float32, default options' % (H, W, K, N)}
+    ys = {}
+    for name, unfused in (('register', False), ('generic', True)):
+        b = solver(D, S, unfused, 6)
+        ys[name] = b.solve().astype(np.float64)
+        tr = np.asarray(b.getitstat().ObjFun, float)
+        ys[name + '_obj'] = tr
+        out[name + '_engaged'] = bool(b._dev.uses_fused_rows() and b._dev.uses_fused_cols())
+        del b
+        b = solver(D, S, unfused, 5, NoDownload)
+        b.solve(); b._dev.sync()
+        b.opt['MaxMainIter'] = 60
+        t0 = time.perf_counter(); b.solve(); b._dev.sync()
+        out[name + '_it_per_s'] = 60 / (time.perf_counter() - t0)
+        b._dev.profile(True)
+        os.environ['SPORCO_AMD_HOST_LOOP'] = '1'
+        b.opt['MaxMainIter'] = 20
+        b.solve(); b._dev.sync()
+        os.environ.pop('SPORCO_AMD_HOST_LOOP')
+        out[name + '_kernel_ms'] = {k: round(v[0] / max(v[1], 1), 4) for k, v in b._dev.profile_read().items() if v[1]}
+        b._dev.profile(False)
+        del b
+    out['speedup'] = out['register_it_per_s'] / out['generic_it_per_s']
+    out['rel_l2_Y_register_vs_generic'] = float(np.linalg.norm(ys['register'] - ys['generic']) / np.linalg.norm(ys['generic']))
+    out['ObjFun_max_rel_dev'] = float(np.max(np.abs(ys['register_obj'] - ys['generic_obj']) / np.abs(ys['generic_obj'])))
+    print(json.dumps(out), flush=True)
