@@ -371,6 +371,30 @@ def gen_config2():
              Y_nnz=np.int64(np.count_nonzero(Y)), **itstat_dict(b))
 
 
+def gen_mixed_radix():
+    """Image sizes of the mixed-radix register kernels (round 6: H, W in {320, 384, 448, 480}), the
+    bench's own synthetic inputs (bench.make_problem, rank 0), default options, the float64 reference
+    run of the float32 inputs: traces, a strided subsample of Y and its norms.
+      admm_mr_384x384_k32_n2   the shape of the bench line's next_rows entry, two of its images
+      admm_mr_480x320_k64_n1   ... and of the K = 64 entry (H = 30 x 16, W = 20 x 16)
+      admm_mr_448x384_k8_nonneg_n2   the 28-point transform, NonNegCoef, AutoRho period 2"""
+    sys.path.insert(0, REPO)
+    import bench
+    for name, (H, W, K, N), extra in (
+            ('admm_mr_384x384_k32_n2', (384, 384, 32, 2), {}),
+            ('admm_mr_480x320_k64_n1', (480, 320, 64, 1), {}),
+            ('admm_mr_448x384_k8_nonneg_n2', (448, 384, 8, 2), {'NonNegCoef': True, 'AutoRho': {'Period': 2}})):
+        D, S = bench.make_problem(H, W, K, N, 0)
+        optd = {'MaxMainIter': 10, 'RelStopTol': 0.0, 'DataType': np.float64}
+        optd.update(extra)
+        b = ref_cbpdn.ConvBPDN(D, S, 0.05, ref_cbpdn.ConvBPDN.Options(optd))
+        b.solve()
+        Y = b.Y
+        save(name, lmbda=np.float64(0.05), shape=np.array((H, W, K, N)), Y_sub=Y[::8, ::8].copy(),
+             Y_l2=np.float64(np.linalg.norm(Y)), Y_l1=np.float64(np.abs(Y).sum()),
+             Y_nnz=np.int64(np.count_nonzero(Y)), **itstat_dict(b))
+
+
 def gen_config5():
     """BASELINE config 5 kernels end to end: ConvBPDNDictLearn (xmethod admm, dmethod pgm),
     256x256, K=64 8x8 filters, N=4 images, 4 outer iterations, from the float64 reference run
@@ -1575,7 +1599,7 @@ if __name__ == '__main__':
                              'pcn', 'dictlearn', 'gradreg', 'ams', 'mcdict', 'mcdict_classes', 'cns', 'cns_options', 'cns_mcdict', 'ccmod_eq', 'ccmod_ism_many', 'online', 'shard', 'maskdcpl', 'maskdl', 'ccmodmd', 'ccmodmd_cns', 'shard_cns', 'signal', 'mask', 'mask_mcdict', 'multiscale', 'zchan', 'ccmodmd_cns_mcdict', 'ccmod_eq_mcdict']
     table = {'primitives': gen_primitives, 'admm': gen_admm, 'gradreg': gen_gradreg, 'ams': gen_ams, 'mcdict': gen_mcdict, 'mcdict_classes': gen_mcdict_classes, 'cns': gen_cns, 'cns_options': gen_cns_options, 'cns_mcdict': gen_cns_mcdict, 'ccmod_eq': gen_ccmod_eq, 'ccmod_ism_many': gen_ccmod_ism_many, 'online': gen_online, 'shard': gen_shard, 'maskdcpl': gen_maskdcpl, 'maskdl': gen_maskdl, 'ccmodmd': gen_ccmodmd, 'signal': gen_signal, 'mask': gen_mask, 'mask_mcdict': gen_mask_mcdict, 'multiscale': gen_multiscale, 'zchan': gen_zchan, 'ccmodmd_cns_mcdict': gen_ccmodmd_cns_mcdict,
              'known': gen_known_answer, 'config1': gen_config1, 'dim1': gen_dim1, 'dim1_dl': gen_dim1_dl, 'dim3': gen_dim3, 'dim3_dl': gen_dim3_dl, 'dim1_dstep': gen_dim1_dstep, 'ccmod_cplx': gen_ccmod_cplx,
-             'config2': gen_config2, 'tol': gen_tol, 'config5': gen_config5,
+             'config2': gen_config2, 'mixed_radix': gen_mixed_radix, 'tol': gen_tol, 'config5': gen_config5,
              'config3': gen_config3, 'config4': gen_config4, 'ccmod_eq_mcdict': gen_ccmod_eq_mcdict,
              'ccmodmd_cns': gen_ccmodmd_cns, 'shard_cns': gen_shard_cns,
              'admm_cplx': gen_admm_cplx, 'pgm': gen_pgm, 'pgm_bt256': gen_pgm_bt256, 'pgm_btrobust256': gen_pgm_btrobust256, 'pgm_monotone256': gen_pgm_monotone256, 'pgm_stepsize256': gen_pgm_stepsize256, 'maskdl_cg_default': gen_maskdl_cg_default, 'pcn': gen_pcn, 'dictlearn': gen_dictlearn}

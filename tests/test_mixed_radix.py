@@ -1,0 +1,187 @@
+"""Image sizes 320 / 384 / 448 / 480 on the register-resident kernels (round 6: csc_rows_mr.hip,
+csc_fused.h; in-register transforms of 20 / 24 / 28 / 30 points, regfft.h) -- the sizes the
+reference serves in the same speed class as any other (sporco/fft.py:257-314; its own tests are
+odd-sized: tests/admm/test_cbpdn.py:204-225).
+
+* against runs of the UNMODIFIED reference at the shapes of the bench line (tests/golden/admm_mr_*,
+  written by oracle/make_golden.py mixed_radix), with the kernel counters asserting that the
+  mixed-radix instantiations ran;
+* against the float64 oracle and the generic chain of this library at small filter counts (what the
+  CPU simulator finishes in a minute);
+* the single-array state bit for bit against the (Y, U) form;
+* every option set the mixed-radix kernels do not serve takes the generic chain of the same handle
+  and gives the generic chain's results."""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_l2
+
+TRACES = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'EpsPrimal', 'EpsDual', 'Rho')
+
+
+def problem(H, W, K, N, seed):
+    rng = np.random.RandomState(seed)
+    D = rng.randn(4, 4, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    return D, rng.randn(H, W, N).astype(np.float32)
+
+
+class env(object):
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k in self.kv:
+            os.environ.pop(k, None)
+
+
+def kernel_counts(b):
+    return {k: v[1] for k, v in b._dev.profile_read().items() if v[1] > 0}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['admm_mr_384x384_k32_n2', 'admm_mr_480x320_k64_n1',
+                                  'admm_mr_448x384_k8_nonneg_n2'])
+def test_reference_fixtures_at_mixed_radix_shapes(gpu_backend, name):
+    """float32 on the register kernels against the reference's float64 run of the same inputs:
+    coefficient maps within the BASELINE bar (1e-4; measured ~1e-6), traces 1e-3 (measured ~1e-6);
+    device-driven loop and host-driven loop (whose counters show the kernels that ran)."""
+    import bench
+    from sporco_amd.admm import cbpdn
+    g = load_golden(name)
+    H, W, K, N = [int(v) for v in g['shape']]
+    D, S = bench.make_problem(H, W, K, N, 0)
+    optd = {'MaxMainIter': len(g['it_Iter']), 'RelStopTol': 0.0}
+    if 'nonneg' in name:
+        optd.update({'NonNegCoef': True, 'AutoRho': {'Period': 2}})
+    for host in (False, True):
+        with env(**({'SPORCO_AMD_HOST_LOOP': '1'} if host else {})):
+            b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+            assert b._dev.uses_fused_rows() and b._dev.uses_fused_cols() and b._fused_ok()
+            assert host or b._device_loop_ok()
+            b._dev.profile(True)
+            Y = b.solve()
+            kc = kernel_counts(b)
+        Y = Y.reshape(H, W, 1, N, K)
+        assert rel_l2(Y[::8, ::8], g['Y_sub']) < 1e-4
+        assert abs(np.linalg.norm(Y.astype(np.float64)) / float(g['Y_l2']) - 1.0) < 1e-5
+        its = b.getitstat()
+        for f in TRACES:
+            assert rel_l2(getattr(its, f), g['it_' + f]) < 1e-3, f
+        if host:
+            # the three-launch iteration in the single-array state: no generic-chain kernel ran
+            assert kc.get('fused_cols_sm', 0) == len(g['it_Iter'])
+            assert kc.get('rows_inv_post_v', 0) + kc.get('rows_inv_post_v_emit', 0) >= len(g['it_Iter']) - 2
+            assert not any(k.startswith(('fft_', 'sm_solve', 'admm_post')) for k in kc), kc
+
+
+@pytest.mark.parametrize('H,W,K,N', [(384, 320, 4, 1),
+                                     pytest.param(480, 448, 6, 1, marks=pytest.mark.gpu),
+                                     pytest.param(448, 480, 64, 2, marks=pytest.mark.gpu),
+                                     pytest.param(320, 512, 8, 2, marks=pytest.mark.gpu),
+                                     pytest.param(128, 384, 6, 3, marks=pytest.mark.gpu),
+                                     pytest.param(384, 256, 62, 1, marks=pytest.mark.gpu),
+                                     pytest.param(320, 320, 7, 2, marks=pytest.mark.gpu)])
+def test_mixed_radix_sizes_vs_oracle_and_generic_chain(backend, H, W, K, N):
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    D, S = problem(H, W, K, N, seed=H + W + K)
+    iters = 4 if backend == 'hostsim' else 12
+    optd = {'MaxMainIter': iters, 'RelStopTol': 0.0}
+    b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    assert b._dev.uses_fused_rows() and b._dev.uses_fused_cols() and b._device_loop_ok()
+    Y = b.solve()
+    ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                         maxiter=iters, rel_tol=0.0)
+    assert rel_l2(Y, ref['Y']) < 2e-5 and rel_l2(b.U, ref['U']) < 2e-5
+    its = b.getitstat()
+    for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+        assert rel_l2(getattr(its, f), ref[f]) < 2e-5, f
+    # X never left the registers: rebuilt on demand, and Xf from X
+    assert rel_l2(b.X, ref['X']) < 2e-5
+    assert rel_l2(b.Xf, np.fft.rfftn(ref['X'], axes=(0, 1))) < 2e-5
+    if backend == 'hostsim':
+        return
+    with env(SPORCO_AMD_UNFUSED='1'):
+        b0 = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+    assert not b0._dev.uses_fused_rows()
+    assert rel_l2(Y, b0.solve()) < 2e-5
+    # the solver keeps going from where it stopped (admm.py:331), now under the host-driven loop
+    with env(SPORCO_AMD_HOST_LOOP='1'):
+        b.solve()
+    ref2 = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                          maxiter=2 * iters, rel_tol=0.0)
+    assert rel_l2(b.Y, ref2['Y']) < 5e-5
+
+
+@pytest.mark.parametrize('case', ['default', pytest.param('nonneg_fixed_rho', marks=pytest.mark.gpu)])
+def test_single_array_state_is_bit_identical_at_mixed_radix_sizes(backend, case):
+    from sporco_amd import _lib
+    from sporco_amd.admm import cbpdn
+    H, W, K, N = (320, 384, 4, 1) if backend == 'hostsim' else (480, 384, 16, 2)
+    D, S = problem(H, W, K, N, seed=99)
+    optd = {'MaxMainIter': 5 if backend == 'hostsim' else 9, 'RelStopTol': 0.0}
+    if case != 'default':
+        optd.update({'NonNegCoef': True, 'AutoRho': {'Enabled': False}, 'rho': 3.0})
+    outs = []
+    for vform in (False, True):
+        with env(**({} if vform else {'SPORCO_AMD_NO_VFORM': '1'})):
+            b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+            b._return_min = False
+            b.solve()
+            assert b._dev.query(_lib.QUERY_VFORM_LIVE) == (1 if vform else 0)
+            outs.append((b.Y.copy(), b.U.copy(), b.X.copy(),
+                         {f: np.asarray(getattr(b.getitstat(), f), float) for f in TRACES}))
+    for a, c in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a, c)
+    for f in TRACES:
+        assert np.array_equal(outs[0][3][f], outs[1][3][f]), f
+
+
+def test_other_options_take_the_generic_chain(backend):
+    """L1Weight arrays, NoBndryCross, ConvBPDNJoint, ConvBPDNGradReg, AddMaskSim, FISTA and the
+    staged step methods at a mixed-radix size: served by the generic chain of the handle (the
+    mixed-radix kernels exist for plain ConvBPDN only) -- the results are those of a handle that
+    never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit."""
+    from sporco_amd.admm import cbpdn
+    from sporco_amd.pgm import cbpdn as pc
+    H, W, K, N = (320, 320, 4, 1) if backend == 'hostsim' else (384, 480, 8, 2)
+    D, S = problem(H, W, K, N, seed=7)
+    rng = np.random.RandomState(3)
+    wl1 = (np.abs(rng.randn(H, W, 1, N, K)) + 0.5).astype(np.float32)
+    o = {'MaxMainIter': 3, 'RelStopTol': 0.0}
+
+    class Hooked(cbpdn.ConvBPDN):
+        def ystep(self):
+            super(Hooked, self).ystep()
+
+    cases = [
+        ('L1Weight', lambda: cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(dict(o, L1Weight=wl1)))),
+        ('NoBndryCross', lambda: cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(dict(o, NoBndryCross=True)))),
+        ('GradReg', lambda: cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.1, cbpdn.ConvBPDNGradReg.Options(o))),
+        ('staged', lambda: Hooked(D, S, 0.05, cbpdn.ConvBPDN.Options(o))),
+        ('pgm', lambda: pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(dict(o, L=50.0)))),
+    ]
+    if backend != 'hostsim':
+        S3 = np.stack([S, 0.5 * S, -S], axis=2)
+        cases.append(('Joint', lambda: cbpdn.ConvBPDNJoint(D, S3, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(o))))
+    for name, make in cases:
+        b = make()
+        a = b.solve()
+        with env(SPORCO_AMD_UNFUSED='1'):
+            b0 = make()
+        c = b0.solve()
+        t, t0 = b.getitstat(), b0.getitstat()
+        if name == 'staged':
+            # (an overridden step method: one device call per step -- the X-step alone still runs
+            # on the mixed-radix kernels, rows_fwd / fused_cols / the prox-less inverse row pass)
+            assert rel_l2(a, c) < 2e-5 and rel_l2(t.ObjFun, t0.ObjFun) < 1e-5
+            continue
+        assert np.array_equal(a, c), name
+        assert np.array_equal(np.asarray(t.ObjFun), np.asarray(t0.ObjFun)), name
