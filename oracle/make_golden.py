@@ -377,13 +377,15 @@ def gen_mixed_radix():
     run of the float32 inputs: traces, a strided subsample of Y and its norms.
       admm_mr_384x384_k32_n2   the shape of the bench line's next_rows entry, two of its images
       admm_mr_480x320_k64_n1   ... and of the K = 64 entry (H = 30 x 16, W = 20 x 16)
-      admm_mr_448x384_k8_nonneg_n2   the 28-point transform, NonNegCoef, AutoRho period 2"""
+      admm_mr_448x384_k8_nonneg_n2   the 28-point transform, NonNegCoef, AutoRho period 2
+      admm_mr_240x320_k64_n2   the third next_rows shape: an odd number of points per thread (15)"""
     sys.path.insert(0, REPO)
     import bench
     for name, (H, W, K, N), extra in (
             ('admm_mr_384x384_k32_n2', (384, 384, 32, 2), {}),
             ('admm_mr_480x320_k64_n1', (480, 320, 64, 1), {}),
-            ('admm_mr_448x384_k8_nonneg_n2', (448, 384, 8, 2), {'NonNegCoef': True, 'AutoRho': {'Period': 2}})):
+            ('admm_mr_448x384_k8_nonneg_n2', (448, 384, 8, 2), {'NonNegCoef': True, 'AutoRho': {'Period': 2}}),
+            ('admm_mr_240x320_k64_n2', (240, 320, 64, 2), {})):
         D, S = bench.make_problem(H, W, K, N, 0)
         optd = {'MaxMainIter': 10, 'RelStopTol': 0.0, 'DataType': np.float64}
         optd.update(extra)

@@ -761,27 +761,27 @@ static FusedSplit fused_split(int H, int K) {
     (void)K;
     if (H == 128) return {32, 4, 4};
     if (H == 256) return {32, 8, 2};
-    if (fused_mr_height(H)) return {H / 16, 16, 1};     // 320 ... 480: 20 ... 30 rows per thread
+    if (fused_mr_height(H)) return {H / 16, 16, 1};     // 160 ... 480: 10 ... 30 rows per thread
     return {32, 16, 1};
 }
 static int fused_rev(int N1, int i) {
     switch (N1) {
-    case 20: return mr_rev<20>(i);
-    case 24: return mr_rev<24>(i);
-    case 28: return mr_rev<28>(i);
-    case 30: return mr_rev<30>(i);
+#define SA_MR_CASE(n) case n: return mr_rev<n>(i);
+    SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
     default: return brev(i, ilog2(N1));
     }
 }
-bool fused_mr_height(int H) { return H == 320 || H == 384 || H == 448 || H == 480; }
-int fused_twiddle_count(int H) { return H < 512 && fused_mr_height(H) ? 512 : H; }
+bool fused_mr_height(int H) { return H % 16 == 0 && mr_length(H / 16); }
+// (the second table has (lines per wave) x 16 entries for each of the 16 waves)
+int fused_twiddle_count(int H) { return fused_mr_height(H) ? (H > 256 ? 512 : 256) : H; }
 
 template <typename T> void fused_twiddles(int H, int K, cx<T> *twA, cx<T> *twB) {
     const FusedSplit sp = fused_split(H, K);
     const int N1 = sp.N1, NW = sp.NW;
     // (mixed-radix heights: two stage-2 lines per wave, the second one only while w + 16 < N1; the
     // second table has J NW = 32 entries per wave -- fused_twiddle_count(H) in all)
-    const int J = fused_mr_height(H) ? 2 : N1 / NW;
+    const int J = fused_mr_height(H) ? (N1 > NW ? 2 : 1) : N1 / NW;
     const double two_pi = 6.283185307179586476925286766559;
     for (int w = 0; w < NW; ++w) {
         for (int i = 0; i < N1; ++i) {
@@ -871,10 +871,14 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
                    "mixed-radix heights: the plain column pass only");
         const bool k64 = a.K == 64;
         switch (sp.N1) {
-        case 20: k64 ? launch_fused_inst<20, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<20, 16, 1, 0, false>(st, a, ntiles); break;
-        case 24: k64 ? launch_fused_inst<24, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<24, 16, 1, 0, false>(st, a, ntiles); break;
-        case 28: k64 ? launch_fused_inst<28, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<28, 16, 1, 0, false>(st, a, ntiles); break;
-        default: k64 ? launch_fused_inst<30, 16, 1, 64, false>(st, a, ntiles) : launch_fused_inst<30, 16, 1, 0, false>(st, a, ntiles); break;
+#define SA_MR_CASE(n)                                                            \
+    case n:                                                                      \
+        k64 ? launch_fused_inst<n, 16, 1, 64, false>(st, a, ntiles)             \
+            : launch_fused_inst<n, 16, 1, 0, false>(st, a, ntiles);             \
+        break;
+        SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
+        default: SA_REQUIRE(false, "height not handled by the mixed-radix column kernel");
         }
     } else if (sp.NW == 4)
         launch_fused_k<32, 4, 4>(st, a, ntiles);

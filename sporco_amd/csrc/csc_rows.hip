@@ -47,14 +47,17 @@ constexpr size_t rows_lds_bytes(int NW) {
 // line k1 held in slot j of spectral-side wave w (see the file header): slots (2 m, 2 m + 1) hold
 // a pair {k1, 32 - k1} (wave 0, m = 0: the self-paired lines 0 and 16).  NW = 4 (W = 128) has
 // eight slots per wave: the four of the other splits, then {4 + w, 28 - w} and {9 + w, 23 - w}.
-// Mixed-radix lines (round 6): N1 = 20 / 24 / 28 / 30 points per thread with NW = 16 waves (W = 320 /
-// 384 / 448 / 480).  The spatial side is as before (wave w, pixels x = 16 n1 + w, n1 < N1); on the
-// spectral side the N1 lines make N1 / 2 pairs {k1, N1 - k1} (wave 0: the self-paired 0 and N1 / 2),
-// one pair per wave for the first NA = N1 / 2 waves -- the remaining 16 - NA waves idle through the
-// second transform and the spectrum loads / stores (a fifth of a stage that is not what bounds
-// the kernel) and take part in the exchange and its barriers only.
-template <int N1, int NW> constexpr int spectral_waves() { return regfft::mr_length(N1) ? N1 / 2 : NW; }
+// Mixed-radix lines (round 6): N1 = 10 ... 30 points per thread (regfft.h SA_MR_LENGTHS) with NW = 16
+// waves (W = 16 N1 = 160 ... 480).  The spatial side is as before (wave w, pixels x = 16 n1 + w,
+// n1 < N1); on the spectral side the N1 lines make pairs {k1, N1 - k1} -- wave 0 takes the
+// self-paired lines 0 and (N1 even) N1 / 2, wave w >= 1 the pair {w, N1 - w} -- one pair per wave
+// for the first NA = (N1 + 1) / 2 waves; the remaining 16 - NA waves idle through the second
+// transform and the spectrum loads / stores (a part of a stage that is not what bounds the kernel)
+// and take part in the exchange and its barriers only.
+template <int N1, int NW> constexpr int spectral_waves() { return regfft::mr_length(N1) ? (N1 + 1) / 2 : NW; }
 template <int N1, int NW> constexpr int spectral_lines() { return regfft::mr_length(N1) ? 2 : N1 / NW; }
+// (odd N1: wave 0 has no second line)
+template <int N1> __device__ __forceinline__ bool second_line(int w) { return (N1 & 1) == 0 || w != 0; }
 template <int N1, int NW> __device__ __forceinline__ int line_of(int w, int j) {
     if (j == 0) return w;
     if (j == 1) return w == 0 ? N1 / 2 : N1 - w;
@@ -74,7 +77,7 @@ __host__ __device__ constexpr bool first_half4(int k1) {
 }
 __host__ __device__ constexpr int group_of(int N1, int NW, int k1) {
     if (NW == 4) return first_half4(k1) ? 0 : 1;
-    return NW == 16 ? (k1 >= N1 / 2 ? 1 : 0) : ((k1 < 8 || k1 == 16 || k1 > 24) ? 0 : 1);
+    return NW == 16 ? (k1 >= (N1 + 1) / 2 ? 1 : 0) : ((k1 < 8 || k1 == 16 || k1 > 24) ? 0 : 1);
 }
 __host__ __device__ constexpr int kl_of(int N1, int NW, int k1) {
     if (NW == 4) {       // rank of the line among the 16 of its half
@@ -82,7 +85,7 @@ __host__ __device__ constexpr int kl_of(int N1, int NW, int k1) {
         for (int o = 0; o < k1; ++o) r += first_half4(o) == first_half4(k1) ? 1 : 0;
         return r;
     }
-    if (NW == 16) return k1 >= N1 / 2 ? k1 - N1 / 2 : k1;
+    if (NW == 16) return k1 >= (N1 + 1) / 2 ? k1 - (N1 + 1) / 2 : k1;
     if (group_of(N1, NW, k1) == 0) return k1 < 8 ? k1 : (k1 == 16 ? 8 : k1 - 16);
     return k1 < 16 ? k1 - 8 : k1 - 9;
 }
@@ -139,7 +142,7 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[N1], const cf *twA, 
             L[(kl_of(N1, NW, k1) * NW + w) * 64 + lane] = t;
         }
         __syncthreads();
-        if (act) {
+        if (act && (g == 0 || second_line<N1>(w))) {
 #pragma unroll
             for (int jl = 0; jl < LPG; ++jl) {
                 const int j = g * LPG + jl;
@@ -150,6 +153,9 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[N1], const cf *twA, 
                     z[NW * j + n2] = mk<float>(t.x, t.y);
                 }
             }
+        } else if (act) {
+#pragma unroll
+            for (int i = 0; i < LPG * NW; ++i) z[NW * g * LPG + i] = mk<float>(0.f, 0.f);
         }
         if (g + 1 < NG) __syncthreads();
     });
@@ -185,11 +191,13 @@ __device__ __forceinline__ void spatial_to_spectral(cf (&v)[N1], const cf *twA, 
                 const cf zp = z[NW * ja + brev((NW - k2) % NW, LBW)];
                 store_unit(N1 * k2, zf, zp);
             }
+            if constexpr ((N1 & 1) == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < NW / 2; ++k2) {
                 const cf zf = z[NW * jb + brev(k2, LBW)];
                 const cf zp = z[NW * jb + brev(NW - 1 - k2, LBW)];
                 store_unit(N1 / 2 + N1 * k2, zf, zp);
+            }
             }
         } else {
             // W - (k1a + N1 k2) = k1b + N1 (NW - 1 - k2)
@@ -262,11 +270,16 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[N1], const cf *twW, 
                     z[NW * ja + brev(NW - k2, LBW)] = mk<float>(ab.a.re + ab.b.im, ab.b.re - ab.a.im);
                 }
             }
+            if constexpr ((N1 & 1) == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < NW / 2; ++k2) {
                 const cf2 ab = load_unit(N1 / 2 + N1 * k2);
                 z[NW * jb + brev(k2, LBW)] = mk<float>(ab.a.re - ab.b.im, ab.a.im + ab.b.re);
                 z[NW * jb + brev(NW - 1 - k2, LBW)] = mk<float>(ab.a.re + ab.b.im, ab.b.re - ab.a.im);
+            }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) z[NW * jb + i] = zero;
             }
         } else {
 #pragma unroll
@@ -286,7 +299,7 @@ __device__ __forceinline__ void spectral_to_spatial(cf (&v)[N1], const cf *twW, 
     // ---- inverse transform over k2, conj twiddle, exchange to the spatial side --------------
     static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
-        if (act) {
+        if (act && (g == 0 || second_line<N1>(w))) {
 #pragma unroll
         for (int jl = 0; jl < LPG; ++jl) {
             const int j = g * LPG + jl;
@@ -410,27 +423,31 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
     cf v[N1];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        cf yv[N1 / 2], uv[N1 / 2];
+        // (two halves of (N1 + 1) / 2 and N1 / 2 pixels: HB = the first half's length)
+        constexpr int HB = (N1 + 1) / 2;
+        cf yv[HB], uv[HB];
 #pragma unroll
-        for (int i = 0; i < N1 / 2; ++i) {
-            const int n1 = half * (N1 / 2) + i;
+        for (int i = 0; i < HB; ++i) {
+            if (half * HB + i >= N1) continue;
+            const int n1 = half * HB + i;
             const int soff = (NW * n1 + w) * pixbytes;
             if constexpr (!VFORM) yv[i] = buf_load_cf(Yb, yvoff, (NW * n1 + w) * ypixbytes);
             uv[i] = buf_load_cf(Ub, voff, soff);
         }
         if constexpr (VFORM) {
 #pragma unroll
-            for (int i = 0; i < N1 / 2; ++i) {
+            for (int i = 0; i < HB; ++i) {
                 // (no fused multiply-adds here or in the epilogue: the (Y, U) and the V form of
                 // an iteration must round alike, and which product of a sum the compiler
                 // fuses depends on the code around it)
 #pragma clang fp contract(off)
+                if (half * HB + i >= N1) continue;
                 const cf vv = uv[i];
                 float t0 = thr_p, t1 = thr_p;
                 if constexpr (GENERAL) {
                     float w0 = 1.f, w1 = 1.f;
                     if (MODE == 1) {
-                        const int xw = NW * (half * (N1 / 2) + i) + w;
+                        const int xw = NW * (half * HB + i) + w;
                         const float *wrow = a->wl1.ptr + (int64_t)h * a->wl1.stride[0] +
                                             (int64_t)xw * a->wl1.stride[1];
                         w0 = wrow[wlane];
@@ -453,7 +470,7 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
                 y0 = sa_med3(y0, am_e[0] ? -__builtin_inff() : nn_lo, __builtin_inff());
                 y1 = sa_med3(y1, am_e[1] ? -__builtin_inff() : nn_lo, __builtin_inff());
                 if constexpr (GENERAL) {
-                    const int n1 = half * (N1 / 2) + i;
+                    const int n1 = half * HB + i;
                     const float keep = (hkill || NW * n1 + w >= x0kill) ? 0.f : 1.f;
                     const float mkeep = ((mbits >> n1) & 1u) ? 0.f : 1.f;
                     y0 *= am_e[0] ? mkeep : keep;
@@ -464,11 +481,13 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < N1 / 2; ++i) {
+        for (int i = 0; i < HB; ++i) {
 #pragma clang fp contract(off)
-            v[half * (N1 / 2) + i] = mk<float>(sa_fma(-s2, uv[i].re, yv[i].re), sa_fma(-s2, uv[i].im, yv[i].im));
+            if (half * HB + i >= N1) continue;
+            v[half * HB + i] = mk<float>(sa_fma(-s2, uv[i].re, yv[i].re), sa_fma(-s2, uv[i].im, yv[i].im));
         }
-        reg_fence<N1 / 2>(v, half * (N1 / 2), token);
+        if (half == 0) reg_fence<HB>(v, 0, token);
+        else reg_fence<N1 - HB>(v, HB, token);
     }
     spatial_to_spectral<NW, COH, N1>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,
                                      token);
@@ -1142,16 +1161,15 @@ void set_lds_attr(K kernel) {
 static int rows_n1(int W) { return rows_mr_width(W) ? W / 16 : kN1; }
 static int rows_rev(int N1, int i) {
     switch (N1) {
-    case 20: return regfft::mr_rev<20>(i);
-    case 24: return regfft::mr_rev<24>(i);
-    case 28: return regfft::mr_rev<28>(i);
-    case 30: return regfft::mr_rev<30>(i);
+#define SA_MR_CASE(n) case n: return regfft::mr_rev<n>(i);
+    SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
     default: return regfft::brev(i, 5);
     }
 }
 
 #ifndef SA_ROWS_MR_TU
-bool rows_mr_width(int W) { return W == 320 || W == 384 || W == 448 || W == 480; }
+bool rows_mr_width(int W) { return W % 16 == 0 && regfft::mr_length(W / 16); }
 template <> bool rows_supported<float>(int W, int K) {
     return (W == 128 || W == 256 || W == 512 || rows_mr_width(W)) && K >= 2 && K % 2 == 0;
 }

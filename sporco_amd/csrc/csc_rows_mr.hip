@@ -1,6 +1,6 @@
 // csc_rows_mr.hip -- the register-resident row passes (csc_rows.h) at the mixed-radix widths
-// W = 320, 384, 448, 480: 16 waves x N1 = 20 / 24 / 28 / 30 points per thread, the in-register
-// transform of N1 points from regfft.h (radices 5.2.2, 3.2.2.2, 7.2.2, 5.3.2).  The kernels are the
+// W = 16 N1 = 160, 192, 224, 240, 288, 320, 336, 384, 400, 432, 448, 480: 16 waves x N1 = 10 ... 30
+// points per thread, the in-register transform of N1 points from regfft.h (radices 7, 5, 3 then 2).  The kernels are the
 // templates of csc_rows.hip instantiated with that N1 (a translation unit of its own: they compile
 // side by side with the power-of-two ones); only the variants of plain ConvBPDN are built -- scalar
 // weights, no NoBndryCross / AddMaskSim / Joint -- which is what sporco/admm/cbpdn.py:267-311, 614-630
@@ -63,10 +63,10 @@ void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
     SA_REQUIRE(!a.y_bcast && !(a.flags & (F_JOINT | F_NOBNDRY)) && !a.wl1.ptr && !a.ams_bits,
                "mixed-radix widths: plain ConvBPDN options only");
     switch (a.W / 16) {
-    case 20: fwd_mr<20>(st, a); break;
-    case 24: fwd_mr<24>(st, a); break;
-    case 28: fwd_mr<28>(st, a); break;
-    default: fwd_mr<30>(st, a); break;
+#define SA_MR_CASE(n) case n: fwd_mr<n>(st, a); break;
+    SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
+    default: SA_REQUIRE(false, "width not handled by the mixed-radix row kernels");
     }
     SA_HIP(hipGetLastError());
 }
@@ -80,10 +80,10 @@ int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a_in)
     const bool emit = a.t_next != nullptr;
     const dim3 grid = rows_grid(a, 16, tx, a.H, emit);
     switch (a.W / 16) {
-    case 20: emit ? post_mr<20, true>(st, a, grid) : post_mr<20, false>(st, a, grid); break;
-    case 24: emit ? post_mr<24, true>(st, a, grid) : post_mr<24, false>(st, a, grid); break;
-    case 28: emit ? post_mr<28, true>(st, a, grid) : post_mr<28, false>(st, a, grid); break;
-    default: emit ? post_mr<30, true>(st, a, grid) : post_mr<30, false>(st, a, grid); break;
+#define SA_MR_CASE(n) case n: emit ? post_mr<n, true>(st, a, grid) : post_mr<n, false>(st, a, grid); break;
+    SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
+    default: SA_REQUIRE(false, "width not handled by the mixed-radix row kernels");
     }
     SA_HIP(hipGetLastError());
     return tx * a.H;
@@ -96,10 +96,10 @@ int64_t launch_rows_inv_prox_fwd_mr(hipStream_t st, const RowsProxArgs<float> &a
     const int64_t tx = ceil_div(a.P, 128);
     const dim3 grid = rows_grid(a, 16, tx, a.H, 0);
     switch (a.W / 16) {
-    case 20: prox_mr<20>(st, a, grid); break;
-    case 24: prox_mr<24>(st, a, grid); break;
-    case 28: prox_mr<28>(st, a, grid); break;
-    default: prox_mr<30>(st, a, grid); break;
+#define SA_MR_CASE(n) case n: prox_mr<n>(st, a, grid); break;
+    SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
+    default: SA_REQUIRE(false, "width not handled by the mixed-radix row kernels");
     }
     SA_HIP(hipGetLastError());
     return tx * a.H;

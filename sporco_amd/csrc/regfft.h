@@ -157,13 +157,35 @@ constexpr double mr_cos(int num, int den) {
 }
 constexpr double mr_sin(int num, int den) { return mr_cos(4 * num - den, 4 * den); }
 
-// the radices of a supported length, in the order the forward transform applies them
-template <int N> struct MrPlan;
-template <> struct MrPlan<20> { static constexpr int S = 3; static constexpr int r(int s) { return s == 0 ? 5 : 2; } };
-template <> struct MrPlan<24> { static constexpr int S = 4; static constexpr int r(int s) { return s == 0 ? 3 : 2; } };
-template <> struct MrPlan<28> { static constexpr int S = 3; static constexpr int r(int s) { return s == 0 ? 7 : 2; } };
-template <> struct MrPlan<30> { static constexpr int S = 3; static constexpr int r(int s) { return s == 0 ? 5 : s == 1 ? 3 : 2; } };
-constexpr bool mr_length(int n) { return n == 20 || n == 24 || n == 28 || n == 30; }
+// The supported lengths (one list for the kernels' instantiations, the launchers' switches and the
+// host tables): X(n) for every n.  16 n = 160, 192, 224, 240, 288, 320, 336, 384, 400, 432, 448, 480.
+#define SA_MR_LENGTHS(X) X(10) X(12) X(14) X(15) X(18) X(20) X(21) X(24) X(25) X(27) X(28) X(30)
+constexpr bool mr_length(int n) {
+#define SA_MR_IS(m) if (n == m) return true;
+    SA_MR_LENGTHS(SA_MR_IS)
+#undef SA_MR_IS
+    return false;
+}
+// the radices of a length, in the order the forward transform applies them: odd ones first
+constexpr int mr_radix_at(int n, int s) {
+    const int rs[4] = {7, 5, 3, 2};
+    for (int i = 0; i < 4; ++i)
+        while (n % rs[i] == 0) {
+            if (s == 0) return rs[i];
+            --s;
+            n /= rs[i];
+        }
+    return 1;
+}
+constexpr int mr_stages(int n) {
+    int s = 0;
+    while (mr_radix_at(n, s) != 1) ++s;
+    return s;
+}
+template <int N> struct MrPlan {
+    static constexpr int S = mr_stages(N);
+    static constexpr int r(int s) { return mr_radix_at(N, s); }
+};
 
 // position i of the forward transform's output -> the frequency it holds (digits of i, most
 // significant first, are the output indices p_1, p_2, ... of the stages; k = p_1 + r_1 p_2 + ...)

@@ -1,5 +1,6 @@
-"""Image sizes 320 / 384 / 448 / 480 on the register-resident kernels (round 6: csc_rows_mr.hip,
-csc_fused.h; in-register transforms of 20 / 24 / 28 / 30 points, regfft.h) -- the sizes the
+"""Image sizes 16 x {10, 12, 14, 15, 18, 20, 21, 24, 25, 27, 28, 30} = 160 ... 480 on the register-resident
+kernels (round 6: csc_rows_mr.hip, csc_fused.h; in-register transforms of that many points,
+radices 7 / 5 / 3 / 2, regfft.h) -- the sizes the
 reference serves in the same speed class as any other (sporco/fft.py:257-314; its own tests are
 odd-sized: tests/admm/test_cbpdn.py:204-225).
 
@@ -47,7 +48,7 @@ def kernel_counts(b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', ['admm_mr_384x384_k32_n2', 'admm_mr_480x320_k64_n1',
-                                  'admm_mr_448x384_k8_nonneg_n2'])
+                                  'admm_mr_448x384_k8_nonneg_n2', 'admm_mr_240x320_k64_n2'])
 def test_reference_fixtures_at_mixed_radix_shapes(gpu_backend, name):
     """float32 on the register kernels against the reference's float64 run of the same inputs:
     coefficient maps within the BASELINE bar (1e-4; measured ~1e-6), traces 1e-3 (measured ~1e-6);
@@ -82,6 +83,14 @@ def test_reference_fixtures_at_mixed_radix_shapes(gpu_backend, name):
 
 
 @pytest.mark.parametrize('H,W,K,N', [(384, 320, 4, 1),
+                                     # odd points per thread (15), one exchange group (10 <= 16)
+                                     (240, 160, 4, 1),
+                                     pytest.param(240, 320, 64, 2, marks=pytest.mark.gpu),
+                                     pytest.param(224, 224, 14, 3, marks=pytest.mark.gpu),
+                                     pytest.param(336, 400, 8, 1, marks=pytest.mark.gpu),
+                                     pytest.param(432, 288, 6, 2, marks=pytest.mark.gpu),
+                                     pytest.param(160, 192, 64, 2, marks=pytest.mark.gpu),
+                                     pytest.param(512, 240, 10, 1, marks=pytest.mark.gpu),
                                      pytest.param(480, 448, 6, 1, marks=pytest.mark.gpu),
                                      pytest.param(448, 480, 64, 2, marks=pytest.mark.gpu),
                                      pytest.param(320, 512, 8, 2, marks=pytest.mark.gpu),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Mixed-radix image sizes (H, W in {320, 384, 448, 480}: csc_rows_mr.hip, csc_fused.h) on the
+"""Mixed-radix image sizes (H, W = 16 x {10, 12, 14, 15, 18, 20, 21, 24, 25, 27, 28, 30}: csc_rows_mr.hip, csc_fused.h) on the
 register-resident kernels against the generic chain (SPORCO_AMD_UNFUSED=1) of the same library:
 iterations/s, per-kernel times, and the agreement of the two after a few iterations.
 One JSON line per shape."""
@@ -8,8 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from sporco_amd.admm import cbpdn as ac
 
-SHAPES = [(384, 384, 32, 8), (480, 320, 64, 8), (320, 480, 32, 8), (448, 448, 64, 8), (384, 512, 64, 8),
-          (480, 480, 64, 16)]
+SHAPES = [(384, 384, 32, 8), (480, 320, 64, 8), (240, 320, 64, 8), (320, 480, 32, 8), (448, 448, 64, 8),
+          (384, 512, 64, 8), (480, 480, 64, 16), (224, 224, 64, 8), (160, 192, 64, 16), (336, 400, 32, 8),
+          (432, 288, 64, 8)]
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ''
 
 
