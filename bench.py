@@ -581,11 +581,23 @@ def run_next_rows(device, tiny=False):
             Dg = r2.randn(8, 8, k).astype(dt)
             Sg = r2.randn(h, w, N8).astype(dt)
             b = ac.ConvBPDN(Dg, Sg, 0.05, ac.ConvBPDN.Options(o0), device=device)
-            return {'workload': 'admm.cbpdn.ConvBPDN %dx%d K=%d N=%d %s (outside the register kernels)'
-                                % (h, w, k, N8, np.dtype(dt).name),
-                    'value': rate(b, b._dev), 'unit': 'iterations/s',
-                    'path': 'register-resident kernels' if b._dev.uses_fused_rows() else
-                            'generic chain (single-array state, fused column pass: whole tile in LDS or slabs of filters)'}
+            reg = bool(b._dev.uses_fused_rows() and b._dev.uses_fused_cols())
+            out = {'workload': 'admm.cbpdn.ConvBPDN %dx%d K=%d N=%d %s (sizes other than 128 / 256 / 512, '
+                               'or float64)' % (h, w, k, N8, np.dtype(dt).name),
+                   'value': rate(b, b._dev), 'unit': 'iterations/s',
+                   'path': ('register-resident kernels, mixed-radix lengths (round 6: 16 x {10 ... 30} points, '
+                            'csc_rows_mr.hip)') if reg else
+                           'generic chain (single-array state, fused column pass: whole tile in LDS or slabs of filters)'}
+            if reg:
+                # the same shape on the generic chain of this library (what served it until round 5)
+                del b
+                os.environ['SPORCO_AMD_UNFUSED'] = '1'
+                try:
+                    b = ac.ConvBPDN(Dg, Sg, 0.05, ac.ConvBPDN.Options(o0), device=device)
+                finally:
+                    os.environ.pop('SPORCO_AMD_UNFUSED', None)
+                out['generic_chain_value'] = rate(b, b._dev)
+            return out
         return go
 
     legs = {'maskdcpl': leg_maskdcpl, 'pgm_mask': leg_pgm_mask, 'pgm_backtrack_robust': leg_pgm_robust}
@@ -593,10 +605,13 @@ def run_next_rows(device, tiny=False):
         legs['generic_48x40_k8_f32'] = leg_generic(48, 40, 8, np.float32)
         legs['generic_32x32_k8_f64'] = leg_generic(32, 32, 8, np.float64)
     else:
+        # (the key names of rounds 4 / 5 are kept so that the records compare; the first three run on
+        # the mixed-radix register kernels since round 6 -- `path` says which)
         legs['generic_384x384_k32_f32'] = leg_generic(384, 384, 32, np.float32)
         legs['generic_240x320_k64_f32'] = leg_generic(240, 320, 64, np.float32)
         legs['generic_480x320_k64_f32'] = leg_generic(480, 320, 64, np.float32)
         legs['generic_256x256_k32_f64'] = leg_generic(256, 256, 32, np.float64)
+        legs['generic_360x360_k32_f32'] = leg_generic(360, 360, 32, np.float32)   # (no register path: 360 / 16)
     out = {}
     for name, fn in legs.items():
         try:

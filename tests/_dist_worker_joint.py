@@ -69,7 +69,7 @@ def main():
     Df = rng.randn(4, 4, 32).astype(np.float32)
     Df /= np.sqrt(np.sum(Df ** 2, axis=(0, 1), keepdims=True))
     Sf = rng.randn(128, 128, 3, n_img).astype(np.float32)
-    of = {'MaxMainIter': 6, 'RelStopTol': 0.0}
+    of = {'MaxMainIter': 4, 'RelStopTol': 0.0}
     os.environ['SPORCO_AMD_RUN_LAG'] = '2' if rank % 2 else '0'
     red = TorchReducer()
     bf = cbpdn.ConvBPDNJoint(Df, shard_images(Sf, rank, world), 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(of),

@@ -82,9 +82,9 @@ def test_reference_fixtures_at_mixed_radix_shapes(gpu_backend, name):
             assert not any(k.startswith(('fft_', 'sm_solve', 'admm_post')) for k in kc), kc
 
 
-@pytest.mark.parametrize('H,W,K,N', [(384, 320, 4, 1),
+@pytest.mark.parametrize('H,W,K,N', [pytest.param(384, 320, 4, 1, marks=pytest.mark.gpu),
                                      # odd points per thread (15), one exchange group (10 <= 16)
-                                     (240, 160, 4, 1),
+                                     (240, 160, 4, 1), (160, 336, 4, 1),
                                      pytest.param(240, 320, 64, 2, marks=pytest.mark.gpu),
                                      pytest.param(224, 224, 14, 3, marks=pytest.mark.gpu),
                                      pytest.param(336, 400, 8, 1, marks=pytest.mark.gpu),
@@ -133,7 +133,7 @@ def test_mixed_radix_sizes_vs_oracle_and_generic_chain(backend, H, W, K, N):
 def test_single_array_state_is_bit_identical_at_mixed_radix_sizes(backend, case):
     from sporco_amd import _lib
     from sporco_amd.admm import cbpdn
-    H, W, K, N = (320, 384, 4, 1) if backend == 'hostsim' else (480, 384, 16, 2)
+    H, W, K, N = (192, 240, 4, 1) if backend == 'hostsim' else (480, 384, 16, 2)
     D, S = problem(H, W, K, N, seed=99)
     optd = {'MaxMainIter': 5 if backend == 'hostsim' else 9, 'RelStopTol': 0.0}
     if case != 'default':
@@ -160,7 +160,7 @@ def test_other_options_take_the_generic_chain(backend):
     never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit."""
     from sporco_amd.admm import cbpdn
     from sporco_amd.pgm import cbpdn as pc
-    H, W, K, N = (320, 320, 4, 1) if backend == 'hostsim' else (384, 480, 8, 2)
+    H, W, K, N = (160, 160, 4, 1) if backend == 'hostsim' else (384, 480, 8, 2)
     D, S = problem(H, W, K, N, seed=7)
     rng = np.random.RandomState(3)
     wl1 = (np.abs(rng.randn(H, W, 1, N, K)) + 0.5).astype(np.float32)
