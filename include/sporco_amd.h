@@ -170,7 +170,10 @@ int sporco_amd_csc_sync(sporco_amd_csc_t h);
 int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
 /* Which kernels serve this handle's shape: *out = 1 when the fused path named by
  * `what` is active (float32, H and/or W in {128, 256, 512}, even K <= 64 -- or even
- * 64 < K <= 256, where the column pass runs as cooperating 64-filter slab workgroups), else 0. */
+ * 64 < K <= 256, where the column pass runs as cooperating 64-filter slab workgroups; since
+ * round 6 also H, W in 16 x {10, 12, 14, 15, 18, 20, 21, 24, 25, 27, 28, 30} with K <= 64, for the
+ * ADMM ConvBPDN calls with scalar or array L1Weight / NonNegCoef / NoBndryCross: such a handle
+ * serves every other flag set on its generic chain), else 0. */
 #define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
 #define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
 #define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step               */
@@ -287,7 +290,13 @@ int sporco_amd_csc_set_ams_mask(sporco_amd_csc_t h, const void *w, const int64_t
 /* Host <-> device transfer of one state array in the reference layout. */
 int sporco_amd_csc_upload(sporco_amd_csc_t h, int var, const void *src);
 int sporco_amd_csc_download(sporco_amd_csc_t h, int var, void *dst);
-/* Raw device pointer of a state array (plumbing for torch.distributed / tests). */
+/* Raw device pointer of a state array (plumbing for torch.distributed / tests).
+ * LIFETIME: the pointer is valid until the next call on this handle that iterates or changes state
+ * (sporco_amd_csc_admm_iter / _admm_run / _pgm_iter / the dictionary-update steps, set_dict,
+ * set_signal, upload): the iterates ping-pong between buffers, and the first fused iteration of a
+ * handle may MOVE the variable -- the arrays a kernel writes at the same time are placed by
+ * measurement then (sporco_amd_csc_placement_report) and the old buffer is freed.  Ask again after
+ * such a call; do not cache the value across it. */
 int sporco_amd_csc_device_ptr(sporco_amd_csc_t h, int var, void **ptr_dev);
 
 /* ---- ADMM iteration (sporco/admm/admm.py:331-367 loop body) -------------- */

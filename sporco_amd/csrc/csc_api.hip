@@ -166,12 +166,12 @@ template <typename T> struct Csc : CscBase {
     // fused row passes (csc_rows.h)
     bool rows_ok = false;
     // Mixed-radix shape (round 6): H or W one of 320 / 384 / 448 / 480 -- the register-resident kernels
-    // exist in the instantiations of plain ConvBPDN only (csc_rows_mr.hip, csc_fused.h); every other
-    // option set, and every other solver family, stays on the generic chain for such a handle.
+    // exist in the instantiations of admm.cbpdn.ConvBPDN only (scalar or array L1Weight, NonNegCoef,
+    // NoBndryCross: csc_rows_mr.hip, csc_fused.h); every other option set, and every other solver
+    // family, stays on the generic chain for such a handle.
     bool mr = false;
     bool mr_ok(const sporco_amd_admm_params &p) const {
-        return !mr || (Cd == 1 && !wl1.ptr && !wl21.ptr &&
-                       !(p.flags & (F_JOINT | F_NOBNDRY | F_AMS | F_GRADREG | F_XRRS)));
+        return !mr || (Cd == 1 && !wl21.ptr && !(p.flags & (F_JOINT | F_AMS | F_GRADREG | F_XRRS)));
     }
     cx<T> *twRows = nullptr;
     double *part_rows = nullptr;

@@ -1168,6 +1168,17 @@ static int rows_rev(int N1, int i) {
     }
 }
 
+// a device-resident 1.0f: the weight array of the GENERAL epilogue when none is set
+static const float *device_one() {
+    static float *one = nullptr;
+    if (!one) {
+        const float v = 1.0f;
+        SA_HIP(hipMalloc((void **)&one, sizeof(float)));
+        SA_HIP(hipMemcpy(one, &v, sizeof(float), hipMemcpyHostToDevice));
+    }
+    return one;
+}
+
 #ifndef SA_ROWS_MR_TU
 bool rows_mr_width(int W) { return W % 16 == 0 && regfft::mr_length(W / 16); }
 template <> bool rows_supported<float>(int W, int K) {
@@ -1373,17 +1384,6 @@ template <> void launch_rows_fwd<float>(hipStream_t st, const RowsFwdArgs<float>
 }
 template <> void launch_rows_fwd<double>(hipStream_t, const RowsFwdArgs<double> &) {
     throw Error(-1, "the fused row kernels are float32 only");
-}
-
-// a device-resident 1.0f: the weight array of the GENERAL epilogue when none is set
-static const float *device_one() {
-    static float *one = nullptr;
-    if (!one) {
-        const float v = 1.0f;
-        SA_HIP(hipMalloc((void **)&one, sizeof(float)));
-        SA_HIP(hipMemcpy(one, &v, sizeof(float), hipMemcpyHostToDevice));
-    }
-    return one;
 }
 
 template <int NW, bool EMIT>

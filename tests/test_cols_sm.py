@@ -27,12 +27,14 @@ CASES = {
 }
 
 
-def run(D, S, optd, fused, slab=None):
+def run(D, S, optd, fused, slab=None, generic=False):
     from sporco_amd.admm import cbpdn
     if not fused:
         os.environ['SPORCO_AMD_NO_COLS_SM'] = '1'
     if slab:
         os.environ['SPORCO_AMD_COLS_SM_FORCE_SLAB'] = str(slab)
+    if generic:      # (sizes the mixed-radix register kernels serve since round 6)
+        os.environ['SPORCO_AMD_UNFUSED'] = '1'
     try:
         b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
         b._dev.profile(True)
@@ -41,6 +43,7 @@ def run(D, S, optd, fused, slab=None):
     finally:
         os.environ.pop('SPORCO_AMD_NO_COLS_SM', None)
         os.environ.pop('SPORCO_AMD_COLS_SM_FORCE_SLAB', None)
+        os.environ.pop('SPORCO_AMD_UNFUSED', None)
     return b, prof
 
 
@@ -98,7 +101,8 @@ def test_generic_chain_at_mid_sizes_against_the_oracle(gpu_backend, H, W, K, N, 
     D = rng.randn(8, 8, K)
     D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
     S = rng.randn(H, W, N)
-    b, prof = run(D.astype(dt), S.astype(dt), {'MaxMainIter': 10, 'RelStopTol': 0.0, 'DataType': dt}, True)
+    b, prof = run(D.astype(dt), S.astype(dt), {'MaxMainIter': 10, 'RelStopTol': 0.0, 'DataType': dt}, True,
+                  generic=True)
     assert not b._dev.uses_fused_rows()
     assert prof['fft_c2c_cols_fwd'][1] == 0 and prof['sm_solve'][1] == 10
     ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,

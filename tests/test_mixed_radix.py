@@ -153,17 +153,51 @@ def test_single_array_state_is_bit_identical_at_mixed_radix_sizes(backend, case)
         assert np.array_equal(outs[0][3][f], outs[1][3][f]), f
 
 
+def test_weights_and_boundary_options_on_the_mixed_radix_kernels(backend):
+    """An L1Weight array (incl. a per-filter weight with a zero, the lowpass-filter idiom of the
+    reference's examples), NoBndryCross and both with NonNegCoef: the MODE 1 instantiations of the
+    mixed-radix row kernels (csc_rows_mr.hip) against the float64 oracle and the generic chain."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    H, W, K, N = (160, 192, 4, 1) if backend == 'hostsim' else (384, 480, 8, 2)
+    D, S = problem(H, W, K, N, seed=17)
+    rng = np.random.RandomState(5)
+    wfull = (np.abs(rng.randn(H, W, 1, N, K)) + 0.5).astype(np.float32)
+    wfilt = np.ones((1, 1, 1, 1, K), np.float32)
+    wfilt[..., 0] = 0.0
+    iters = 4 if backend == 'hostsim' else 10
+    cases = [('filter_weight', {'L1Weight': wfilt}, dict(wl1=wfilt.astype(np.float64))),
+             ('nobndry', {'NoBndryCross': True}, dict(nobndry=True))]
+    if backend != 'hostsim':
+        cases += [('full_weight_nonneg', {'L1Weight': wfull, 'NonNegCoef': True},
+                   dict(wl1=wfull.astype(np.float64), nonneg=True)),
+                  ('weight_nobndry', {'L1Weight': wfilt, 'NoBndryCross': True},
+                   dict(wl1=wfilt.astype(np.float64), nobndry=True))]
+    for name, extra, okw in cases:
+        optd = dict({'MaxMainIter': iters, 'RelStopTol': 0.0}, **extra)
+        b = cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(optd))
+        assert b._dev.uses_fused_rows() and b._fused_ok() and b._device_loop_ok(), name
+        b._dev.profile(True)
+        Y = b.solve()
+        kc = kernel_counts(b)
+        assert not any(k.startswith(('fft_', 'sm_solve', 'admm_post')) for k in kc), (name, kc)
+        ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                             maxiter=iters, rel_tol=0.0, **okw)
+        assert rel_l2(Y, ref['Y']) < 2e-5 and rel_l2(b.U, ref['U']) < 2e-5 and rel_l2(b.X, ref['X']) < 2e-5, name
+        its = b.getitstat()
+        for f in ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+            assert rel_l2(getattr(its, f), ref[f]) < 2e-5, (name, f)
+
+
 def test_other_options_take_the_generic_chain(backend):
-    """L1Weight arrays, NoBndryCross, ConvBPDNJoint, ConvBPDNGradReg, AddMaskSim, FISTA and the
-    staged step methods at a mixed-radix size: served by the generic chain of the handle (the
-    mixed-radix kernels exist for plain ConvBPDN only) -- the results are those of a handle that
-    never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit."""
+    """ConvBPDNJoint, ConvBPDNGradReg, FISTA at a mixed-radix size: served by the generic chain of
+    the handle (the mixed-radix kernels exist for admm.cbpdn.ConvBPDN only) -- the results are those
+    of a handle that never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit; the staged
+    step methods run their X-step on the register kernels."""
     from sporco_amd.admm import cbpdn
     from sporco_amd.pgm import cbpdn as pc
     H, W, K, N = (160, 160, 4, 1) if backend == 'hostsim' else (384, 480, 8, 2)
     D, S = problem(H, W, K, N, seed=7)
-    rng = np.random.RandomState(3)
-    wl1 = (np.abs(rng.randn(H, W, 1, N, K)) + 0.5).astype(np.float32)
     o = {'MaxMainIter': 3, 'RelStopTol': 0.0}
 
     class Hooked(cbpdn.ConvBPDN):
@@ -171,8 +205,6 @@ def test_other_options_take_the_generic_chain(backend):
             super(Hooked, self).ystep()
 
     cases = [
-        ('L1Weight', lambda: cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(dict(o, L1Weight=wl1)))),
-        ('NoBndryCross', lambda: cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(dict(o, NoBndryCross=True)))),
         ('GradReg', lambda: cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.1, cbpdn.ConvBPDNGradReg.Options(o))),
         ('staged', lambda: Hooked(D, S, 0.05, cbpdn.ConvBPDN.Options(o))),
         ('pgm', lambda: pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(dict(o, L=50.0)))),

@@ -8,12 +8,12 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
-CONFIGS = [(512, 512, 64, 8, 'float32', True), (384, 384, 64, 8, 'float32', False), (384, 384, 32, 8, 'float32', False),
-           (240, 320, 64, 8, 'float32', False), (128, 128, 64, 8, 'float64', False),
-           (320, 480, 32, 8, 'float32', False), (256, 256, 32, 8, 'float64', False)]
+CONFIGS = [(512, 512, 64, 8, 'float32', True), (384, 384, 64, 8, 'float32', True), (384, 384, 32, 8, 'float32', True),
+           (240, 320, 64, 8, 'float32', True), (128, 128, 64, 8, 'float64', False),
+           (320, 480, 32, 8, 'float32', True), (256, 256, 32, 8, 'float64', False)]
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ''           # substring of '<H>x<W> K=<K>'
 VARIANTS = sys.argv[2].split(',') if len(sys.argv) > 2 else ['yu', 'v', 'v_cols_sm']
-CONFIGS += [(480, 320, 64, 8, 'float32', False), (256, 256, 64, 8, 'float64', False), (224, 224, 64, 8, 'float32', False)]
+CONFIGS += [(480, 320, 64, 8, 'float32', True), (256, 256, 64, 8, 'float64', False), (224, 224, 64, 8, 'float32', True)]
 for (H, W, K, N, dt, force) in CONFIGS:
     if ONLY not in '%dx%d K=%d %s' % (H, W, K, dt):
         continue
