@@ -346,7 +346,7 @@ template <typename T> struct Csc : CscBase {
             if (fused_mr_height(H)) fused = false;
             mr = false;
         }
-        if (mr) cols256 = false;      // (FISTA, the tile-major dictionary updates, consensus: generic)
+        if (mr) cols256 = false;      // (consensus, mask decoupling, the K > 64 families: generic)
         tail_mode = fused_slabs && K - 64 <= kTailMax;
         Ks = (rows_ok && tail_mode) ? 80 : K;
         EFt = npix * CN * (int64_t)Ks;
@@ -508,7 +508,9 @@ template <typename T> struct Csc : CscBase {
     // The fused FISTA iteration: the register-resident kernels of both directions, and -- for
     // K > 64 -- rows of exactly K filters (a handle in tail mode, 64 < K <= 72, pads the rows of
     // its Xf buffer to 80 for the ADMM tail kernels: the staged composition serves it).
-    bool pgm_fused_ok() const { return rows_ok && cols256 && (fused || (fused_slabs && !tail_mode)); }
+    // (a mixed-radix handle: the FISTA and tile-major dictionary-update column kernels exist at its
+    // height too, csc_pgm_mr.hip)
+    bool pgm_fused_ok() const { return rows_ok && (cols256 || mr) && (fused || (fused_slabs && !tail_mode)); }
     bool hint_vform = false, hint_one_launch = false;
     // SPORCO_AMD_MODE_COMPLEX_PAIR: the two channels of the handle are the real and the imaginary
     // part of complex data (dictionary updates only; csc_kernels.h launch_pm_butterfly)

@@ -84,4 +84,11 @@ template <typename T> int64_t launch_pgm_fft_momentum(hipStream_t st, const PgmC
 template <typename T>
 int64_t launch_pgm_stats_slabs(hipStream_t st, const PgmColsArgs<T> &a, double *partials2);
 
+// Mixed-radix heights (csc_fused.h fused_mr_height: H = 16 x {10 ... 30}; csc_pgm_mr.hip): the three
+// column kernels above with that many rows per thread, K <= 64.
+// plain: the forward transform alone (launch_cols_fft).
+int64_t launch_pgm_grad_ifft_mr(hipStream_t st, const PgmColsArgs<float> &a);
+int64_t launch_pgm_fft_momentum_mr(hipStream_t st, const PgmColsArgs<float> &a, bool plain);
+int64_t launch_ccmod_grad_tiled_mr(hipStream_t st, const CcmodTiledArgs<float> &a);
+
 }  // namespace sporco_amd

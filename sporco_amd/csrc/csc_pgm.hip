@@ -10,6 +10,7 @@
 //                     the momentum update and the sums are element-wise.
 #include "csc_pgm.h"
 
+#include "csc_fused.h"
 #include "regfft.h"
 
 namespace sporco_amd {
@@ -49,10 +50,14 @@ __device__ __forceinline__ void inner4(const cf (&d)[4], const cf *x, int lane, 
 // EYIN: the residual per frequency comes from memory (a.ey_in) instead of being formed from
 // Yf -- the masked classes, whose residual passes through the spatial domain for the mask
 // between the inner product and the gradient (pgm/cbpdn.py:454-477); no wave reduction then.
-template <int NW, int LP, int KC, bool BT, bool PERS = false, bool EYIN = false>
+// N1: rows per thread -- 32, or one of the mixed-radix lengths (regfft.h SA_MR_LENGTHS; 16 waves, LP = 1:
+// the exchange groups of csc_fused_body.inc, the last one partly filled)
+template <int NW, int LP, int KC, bool BT, bool PERS = false, bool EYIN = false, int N1 = 32>
 __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArgs<float> a) {
     static_assert(!(BT && EYIN), "a held trial forms its own residual");
-    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr bool MR = mr_length(N1);
+    constexpr int H = N1 * NW, J = MR ? (N1 > NW ? 2 : 1) : N1 / NW;
+    static_assert(!MR || (NW == 16 && LP == 1), "mixed-radix heights: 16 waves, one line per group");
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
     constexpr bool PERSIST = PERS;
@@ -85,13 +90,15 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
     const BufRsrc Db = make_rsrc(ap->dft + (int64_t)wf * H * K, tbytes);
     const cf *S = (EYIN ? ap->ey_in : ap->sft) + (int64_t)tile * H + w;
     cf *EY = BT ? ap->ey + (int64_t)tile * H + w : nullptr;
-    const cf *twB = ap->twB + w * N1;
+    const cf *twB = ap->twB + w * (J * NW);
     const float inv_L = ap->inv_L;
     float fsum = 0.f;
 
     cf v[N1];
     static_for<Q>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
+        const bool lv = !MR || q * FP + w < N1;      // (this wave's line of the group exists)
+        if (lv) {
         // this group's lines of Yf and the matching rows of Df
         cf u[FP];
 #pragma unroll
@@ -151,11 +158,13 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
                 L[((w + NW * jl) * NW + h2) * 64 + k] = t;
             }
         }
+        }   // lv
         __syncthreads();
 #pragma unroll
         for (int fl = 0; fl < FP; ++fl) {
+            if (q * FP + fl >= N1) continue;
             const f2 t = L[(fl * NW + w) * 64 + k];
-            v[brev(q * FP + fl, 5)] = mk<float>(t.x, t.y);
+            v[pos1<N1>(q * FP + fl)] = mk<float>(t.x, t.y);
         }
         if (q + 1 < Q) __syncthreads();
     });
@@ -168,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
     } else if constexpr (PERSIST) {
         __syncthreads();     // the exchange buffer is reused by the next tile
     }
-    dit<N1, true>(v, 0);
+    dit1<N1, true>(v, 0);
     if (kv) {
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1) buf_store_cf(Ob, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
@@ -183,9 +192,11 @@ __global__ void __launch_bounds__(NW * 64) pgm_grad_ifft_kernel(const PgmColsArg
 // ---------------------------------------------------------------------------
 // PLAIN: forward transform only (no momentum, no sums): t <- FFT_H(t)
 // BT: with STATS, also the linear term of the backtracking model from a.ey
-template <int NW, int LP, int KC, bool STATS, bool PLAIN = false, bool BT = false, bool PERS = false>
+template <int NW, int LP, int KC, bool STATS, bool PLAIN = false, bool BT = false, bool PERS = false, int N1 = 32>
 __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmColsArgs<float> a) {
-    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr bool MR = mr_length(N1);
+    constexpr int H = N1 * NW, J = MR ? (N1 > NW ? 2 : 1) : N1 / NW;
+    static_assert(!MR || (NW == 16 && LP == 1), "mixed-radix heights: 16 waves, one line per group");
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
     // (persistent as pgm_grad_ifft: 16 waves, K = 64 -- there is no slab axis then)
@@ -237,7 +248,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
 #pragma unroll
     for (int h1 = 0; h1 < N1; ++h1)
         v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
-    dif<N1, false>(v, 0);
+    dif1<N1, false>(v, 0);
     reg_fence<N1>(v, 0, token);
 #pragma unroll
     for (int i = 1; i < N1; ++i) {
@@ -252,7 +263,8 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
         constexpr int q = decltype(qc)::value;
 #pragma unroll
         for (int fl = 0; fl < FP; ++fl) {
-            const cf x = v[brev(q * FP + fl, 5)];
+            if (q * FP + fl >= N1) continue;
+            const cf x = v[pos1<N1>(q * FP + fl)];
             f2 t;
             t.x = x.re;
             t.y = x.im;
@@ -264,6 +276,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
         constexpr int q = decltype(qc)::value;
         // previous iterates (and Df / Sf for the objective) of chunk g+1 are requested while
         // chunk g is processed; chunk 0's before the barrier
+        const bool lv = !MR || q * FP + w < N1;      // (this wave's line of the group exists)
         cf xn4[4], yn4[4];
         auto prefetch = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
@@ -280,9 +293,10 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                 }
             }
         };
-        prefetch(std::integral_constant<int, 0>{});
+        if (lv) prefetch(std::integral_constant<int, 0>{});
         __syncthreads();
         cf u[FP];
+        if (lv) {
 #pragma unroll
         for (int jl = 0; jl < LP; ++jl) {
 #pragma unroll
@@ -291,6 +305,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                 u[NW * jl + h2] = mk<float>(t.x, t.y);
             }
         }
+        }
         if constexpr (q + 1 < Q) {
             // the next group goes to the exchange buffer as soon as this one has been read:
             // its half of the register tile is then free while this group's chunks -- the
@@ -298,6 +313,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
             __syncthreads();
             write_group(std::integral_constant<int, q + 1>{});
         }
+        if (lv) {
         static_for<NCH>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
@@ -350,6 +366,7 @@ __global__ void __launch_bounds__(NW * 64) pgm_fft_momentum_kernel(const PgmCols
                 }
             }
         });
+        }   // lv
         {
             float &rs_ = rs, &fs_ = fsum;   // (named references: asm operands alone do not capture)
             int &tk_ = token;
@@ -401,9 +418,12 @@ __global__ void __launch_bounds__(256) pgm_stats_slabs_kernel(const PgmColsArgs<
 // MODE 0: everything in one pass (K <= 64).  K > 64, one workgroup per 64-filter slab
 // (blockIdx.y): MODE 1 writes the slab's share of sum_k zf d to a.qpart; MODE 2 forms the
 // gradient from the residual in a.rbuf (ccmod_resid_sum_kernel in between).
-template <int NW, int KC, int MODE = 0>
+// N1: rows per thread (H = N1 NW); a length that is not a multiple of four runs a last chunk whose
+// surplus rows read zeros (buffer range checks) and are not stored (MODE 0 only).
+template <int NW, int KC, int MODE = 0, int N1 = 32>
 __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTiledArgs<float> a) {
-    constexpr int N1 = 32, H = N1 * NW;
+    constexpr int H = N1 * NW, NC = (N1 + 3) / 4, NR = 4 * NC;
+    static_assert(N1 % 4 == 0 || MODE == 0, "ragged heights: the one-pass form only");
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -422,9 +442,9 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
     const int dko = ((w * Wf + wf) * K + slab * 64 + k) * (int)sizeof(cf);
     const int drow = NW * Wf * K * (int)sizeof(cf);   // from row f to row f + NW
     const int ko = (w * K + slab * 64 + k) * (int)sizeof(cf);
-    cf acc[N1];
+    cf acc[NR];
 #pragma unroll
-    for (int i = 0; i < N1; ++i) acc[i] = zero;
+    for (int i = 0; i < NR; ++i) acc[i] = zero;
     float s_r2 = 0.f, s_q2 = 0.f;
     int kov = ko, dkov = dko, token = 0;   // offsets routed through the register fences below
     for (int cn = cn0; cn < cn1; ++cn) {
@@ -445,7 +465,7 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
             }
         };
         prefetch(std::integral_constant<int, 0>{});
-        static_for<N1 / 4>([&](auto cc) {
+        static_for<NC>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             cf z[4], d[4], q[4];
 #pragma unroll
@@ -453,7 +473,7 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
                 z[e] = zn[e];
                 d[e] = dn[e];
             }
-            if constexpr (c + 1 < N1 / 4) {
+            if constexpr (c + 1 < NC) {
                 if constexpr (c > 0) {
                     float &dep = acc[4 * c - 1].re;
                     int &ko_ = kov, &dko_ = dkov;
@@ -481,6 +501,7 @@ __global__ void __launch_bounds__(NW * 64) ccmod_grad_tiled_kernel(const CcmodTi
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = 4 * c + e;
+                if (i >= N1) continue;       // (the surplus rows of a ragged last chunk)
                 cf sv;
                 sa_uload2(reinterpret_cast<const float *>(S + NW * i), sv.re, sv.im);
                 const cf r = q[e] - sv;
@@ -714,7 +735,9 @@ void launch_mom(hipStream_t st, const PgmColsArgs<float> &a_in) {
 
 }  // namespace
 
+#ifndef SA_PGM_MR_TU
 template <> int64_t launch_pgm_grad_ifft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
+    if (fused_mr_height(a.H)) return launch_pgm_grad_ifft_mr(st, a);
     SA_REQUIRE((a.H == 128 || a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 64,
                "shape not handled by the fused PGM kernels");
     if (a.H == 128) {
@@ -743,6 +766,7 @@ template <> int64_t launch_pgm_stats_slabs<double>(hipStream_t, const PgmColsArg
     throw Error(-1, "the fused FISTA kernels are float32 only");
 }
 template <> int64_t launch_pgm_fft_momentum<float>(hipStream_t st, const PgmColsArgs<float> &a) {
+    if (fused_mr_height(a.H)) return launch_pgm_fft_momentum_mr(st, a, false);
     SA_REQUIRE((a.H == 128 || a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
                "shape not handled by the fused PGM kernels");
     SA_REQUIRE(a.K <= 64 || !a.want_stats || a.qpart, "K > 64 with statistics needs qpart");
@@ -771,6 +795,7 @@ template <int NW, int LP, int KC> static void launch_plain(hipStream_t st, const
 }
 
 template <> int64_t launch_cols_fft<float>(hipStream_t st, const PgmColsArgs<float> &a) {
+    if (fused_mr_height(a.H)) return launch_pgm_fft_momentum_mr(st, a, true);
     SA_REQUIRE((a.H == 128 || a.H == 256 || a.H == 512) && a.K >= 1 && a.K <= 256,
                "shape not handled by the fused column kernels");
     if (a.H == 128) {
@@ -791,12 +816,13 @@ template <> int64_t launch_cols_fft<double>(hipStream_t, const PgmColsArgs<doubl
 }
 
 template <> bool ccmod_tiled_supported<float>(int H, int K) {
-    return (H == 128 || H == 256 || H == 512) && K >= 1 && K <= 256;
+    return ((H == 128 || H == 256 || H == 512) && K >= 1 && K <= 256) || (fused_mr_height(H) && K >= 1 && K <= 64);
 }
 template <> bool ccmod_tiled_supported<double>(int, int) { return false; }
 
 template <> int64_t launch_ccmod_grad_tiled<float>(hipStream_t st, const CcmodTiledArgs<float> &a) {
     SA_REQUIRE(ccmod_tiled_supported<float>(a.H, a.K), "shape not handled by the tiled D-step kernel");
+    if (fused_mr_height(a.H)) return launch_ccmod_grad_tiled_mr(st, a);
     const unsigned grid = (unsigned)((a.W / 2 + 1) * a.G);
     const size_t lds = sizeof(double) * 4 * 16;
     if (a.K > 64) {
@@ -853,5 +879,6 @@ template <> int64_t launch_pgm_grad_ifft<double>(hipStream_t, const PgmColsArgs<
 template <> int64_t launch_pgm_fft_momentum<double>(hipStream_t, const PgmColsArgs<double> &) {
     throw Error(-1, "the fused PGM kernels are float32 only");
 }
+#endif   // SA_PGM_MR_TU
 
 }  // namespace sporco_amd

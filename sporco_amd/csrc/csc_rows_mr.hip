@@ -78,10 +78,19 @@ template <int N1, bool EMIT> void post_mr(hipStream_t st, RowsPostArgs<float> &a
     else post_mr_mode<N1, EMIT, 0>(st, a, grid);
 }
 
-template <int N1> void prox_mr(hipStream_t st, const RowsProxArgs<float> &a, dim3 grid) {
+template <int N1> void prox_mr(hipStream_t st, RowsProxArgs<float> &a, dim3 grid) {
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) set_lds_attr<16>(&rows_inv_prox_fwd_kernel<16, false, N1>);
-    hipLaunchKernelGGL((rows_inv_prox_fwd_kernel<16, false, N1>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+    if (attr_set.first()) {
+        set_lds_attr<16>(&rows_inv_prox_fwd_kernel<16, false, N1>);
+        set_lds_attr<16>(&rows_inv_prox_fwd_kernel<16, true, N1>);
+    }
+    // (a weight array, NoBndryCross, or a negative threshold: the variant that makes no assumption)
+    const bool general = a.wl1.ptr != nullptr || (a.flags & F_NOBNDRY) || a.thr < 0.f;
+    if (general && !a.wl1.ptr) a.wl1.ptr = device_one();
+    if (general)
+        hipLaunchKernelGGL((rows_inv_prox_fwd_kernel<16, true, N1>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
+    else
+        hipLaunchKernelGGL((rows_inv_prox_fwd_kernel<16, false, N1>), grid, dim3(16 * 64), rows_lds_bytes(16), st, a);
 }
 
 }  // namespace
@@ -129,7 +138,6 @@ int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a_in)
 int64_t launch_rows_inv_prox_fwd_mr(hipStream_t st, const RowsProxArgs<float> &a_in) {
     RowsProxArgs<float> a = a_in;
     SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
-    SA_REQUIRE(!a.wl1.ptr && !(a.flags & F_NOBNDRY) && a.thr >= 0.f, "mixed-radix widths: plain options only");
     const int64_t tx = ceil_div(a.P, 128);
     const dim3 grid = rows_grid(a, 16, tx, a.H, 0);
     switch (a.W / 16) {

@@ -226,3 +226,54 @@ def test_other_options_take_the_generic_chain(backend):
             continue
         assert np.array_equal(a, c), name
         assert np.array_equal(np.asarray(t.ObjFun), np.asarray(t0.ObjFun)), name
+
+
+@pytest.mark.parametrize('H,W,K,N', [(240, 160, 4, 2),
+                                     pytest.param(320, 192, 4, 1, marks=pytest.mark.gpu),
+                                     pytest.param(480, 384, 64, 2, marks=pytest.mark.gpu),
+                                     pytest.param(336, 448, 10, 2, marks=pytest.mark.gpu)])
+def test_fista_and_dictionary_learning_at_mixed_radix_sizes(backend, H, W, K, N):
+    """pgm.cbpdn.ConvBPDN (fixed L, BacktrackStandard, an L1Weight array) and ConvBPDNDictLearn
+    (ADMM X-step, PGM D-step) on the mixed-radix column kernels of csc_pgm_mr.hip
+    (sporco/pgm/cbpdn.py:263-372, sporco/pgm/ccmod.py:295-323) against the generic chain of the
+    same library -- which the reference fixtures of tests/test_pgm_cbpdn.py / test_dictlearn.py
+    pin -- and the float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    from sporco_amd.dictlrn import cbpdndl
+    D, S = problem(H, W, K, N, seed=H + K)
+    rng = np.random.RandomState(11)
+    wfilt = np.ones((1, 1, 1, 1, K), np.float32)
+    wfilt[..., 0] = 0.0
+    iters = 4 if backend == 'hostsim' else 12
+    cases = [('fixed_L', {'L': 50.0}), ('backtrack', {'L': 5.0, 'Backtrack': BacktrackStandard()})]
+    if backend != 'hostsim':
+        cases.append(('weights', {'L': 50.0, 'L1Weight': wfilt}))
+    for name, extra in cases:
+        runs = []
+        for unfused in (False, True):
+            with env(**({'SPORCO_AMD_UNFUSED': '1'} if unfused else {})):
+                b = pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(dict({'MaxMainIter': iters, 'RelStopTol': 0.0}, **extra)))
+            assert bool(b.dev.uses_fused_pgm()) == (not unfused) and b._fused_ok() == (not unfused), name
+            runs.append((b.solve(), b.getitstat()))
+        assert rel_l2(runs[0][0], runs[1][0]) < 2e-5, name
+        for f in ('ObjFun', 'DFid', 'RegL1', 'Rsdl', 'L'):
+            assert rel_l2(getattr(runs[0][1], f), getattr(runs[1][1], f)) < 2e-5, (name, f)
+        if name == 'fixed_L':
+            ref = orc.pgm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, L=50.0, dtype=np.float64,
+                                maxiter=iters, rel_tol=0.0)
+            assert rel_l2(runs[0][0], ref['X'].reshape(runs[0][0].shape)) < 2e-5
+    D0 = rng.randn(4, 4, K).astype(np.float32)
+    outs = []
+    for unfused in (False, True):
+        with env(**({'SPORCO_AMD_UNFUSED': '1'} if unfused else {})):
+            opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 3, 'AccurateDFid': True, 'CCMOD': {'ZeroMean': True}},
+                                                    xmethod='admm', dmethod='pgm')
+            d = cbpdndl.ConvBPDNDictLearn(D0, S, 0.1, opt, xmethod='admm', dmethod='pgm')
+        assert bool(d.xstep._dev.uses_fused_rows()) == (not unfused)
+        outs.append((d.solve(), d.getcoef(), d.getitstat()))
+    assert rel_l2(outs[0][0], outs[1][0]) < 1e-5 and rel_l2(outs[0][1], outs[1][1]) < 2e-5
+    for f in ('ObjFun', 'DFid', 'RegL1', 'Cnstr'):
+        a, c = np.asarray(getattr(outs[0][2], f), float), np.asarray(getattr(outs[1][2], f), float)
+        assert rel_l2(a, c) < 2e-5 or np.max(np.abs(a - c)) < 1e-6, f

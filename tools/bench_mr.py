@@ -61,3 +61,52 @@ for (H, W, K, N) in SHAPES:
     out['rel_l2_Y_register_vs_generic'] = float(np.linalg.norm(ys['register'] - ys['generic']) / np.linalg.norm(ys['generic']))
     out['ObjFun_max_rel_dev'] = float(np.max(np.abs(ys['register_obj'] - ys['generic_obj']) / np.abs(ys['generic_obj'])))
     print(json.dumps(out), flush=True)
+
+
+# ---- FISTA and dictionary learning at mixed-radix sizes (csc_pgm_mr.hip) --------------------------
+def fista_and_cdl():
+    from sporco_amd.pgm import cbpdn as pc
+    from sporco_amd.pgm.backtrack import BacktrackStandard
+    from sporco_amd.dictlrn import cbpdndl
+    for (H, W, K, N) in [(384, 384, 32, 8), (480, 320, 64, 8), (240, 320, 64, 16)]:
+        if ONLY not in '%dx%d K=%d' % (H, W, K):
+            continue
+        rng = np.random.RandomState(2)
+        D = rng.randn(8, 8, K).astype(np.float32)
+        D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+        S = rng.randn(H, W, N).astype(np.float32)
+        out = {'config': 'pgm.cbpdn.ConvBPDN and ConvBPDNDictLearn(admm, pgm) %dx%d K=%d N=%d float32' % (H, W, K, N)}
+        for name, unfused in (('register', False), ('generic', True)):
+            for tag, extra in (('fista', {}), ('fista_bt', {'Backtrack': BacktrackStandard()})):
+                if unfused:
+                    os.environ['SPORCO_AMD_UNFUSED'] = '1'
+                try:
+                    b = pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(dict({'MaxMainIter': 5, 'RelStopTol': 0.0, 'L': 500.0}, **extra)))
+                finally:
+                    os.environ.pop('SPORCO_AMD_UNFUSED', None)
+                b._return_min = False
+                b.solve(); b.dev.sync()
+                b.opt['MaxMainIter'] = 40
+                t0 = time.perf_counter(); b.solve(); b.dev.sync()
+                out['%s_%s_it_per_s' % (name, tag)] = 40 / (time.perf_counter() - t0)
+                out['%s_%s_objfun' % (name, tag)] = float(b.getitstat().ObjFun[-1])
+                out['%s_%s_fused' % (name, tag)] = bool(b._fused_ok())
+                del b
+            if unfused:
+                os.environ['SPORCO_AMD_UNFUSED'] = '1'
+            try:
+                opt = cbpdndl.ConvBPDNDictLearn.Options({'MaxMainIter': 5}, xmethod='admm', dmethod='pgm')
+                d = cbpdndl.ConvBPDNDictLearn(D, S, 0.1, opt, xmethod='admm', dmethod='pgm')
+            finally:
+                os.environ.pop('SPORCO_AMD_UNFUSED', None)
+            d.solve(); d.xstep._dev.sync()
+            d.opt['MaxMainIter'] = 30
+            t0 = time.perf_counter(); d.solve(); d.xstep._dev.sync()
+            out[name + '_cdl_outer_it_per_s'] = 30 / (time.perf_counter() - t0)
+            out[name + '_cdl_objfun'] = float(d.getitstat().ObjFun[-1])
+            del d
+        print(json.dumps(out), flush=True)
+
+
+if len(sys.argv) > 2 and sys.argv[2] == 'pgm':
+    fista_and_cdl()
