@@ -171,7 +171,7 @@ template <typename T> struct Csc : CscBase {
     // family, stays on the generic chain for such a handle.
     bool mr = false;
     bool mr_ok(const sporco_amd_admm_params &p) const {
-        return !mr || (Cd == 1 && !wl21.ptr && !(p.flags & (F_JOINT | F_AMS | F_GRADREG | F_XRRS)));
+        return !mr || (Cd == 1 && !wl21.ptr && !(p.flags & (F_AMS | F_GRADREG | F_XRRS)));
     }
     cx<T> *twRows = nullptr;
     double *part_rows = nullptr;

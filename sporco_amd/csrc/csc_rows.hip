@@ -602,7 +602,7 @@ __device__ __forceinline__ void rows_inv_post_tile(AP a, int bx, int h, int tile
 #ifndef SA_POST_B_PLAIN_PARK
 #define SA_POST_B_PLAIN_PARK 8
 #endif
-    constexpr bool PARK = EMIT_T && VIN && (JOINT ? SA_PARK_JOINT != 0 : SA_PARK_PLAIN != 0);
+    constexpr bool PARK = EMIT_T && VIN && !regfft::mr_length(N1) && (JOINT ? SA_PARK_JOINT != 0 : SA_PARK_PLAIN != 0);
     constexpr int NP = N1 / 2;      // parked pixels per thread
     constexpr int B = batch_of(PARK ? NP : N1, EMIT_T ? (JOINT ? (PARK ? SA_POST_B_JOINT_PARK : 1)
                                                                : (VIN ? (PARK ? SA_POST_B_PLAIN_PARK : 4) : 2))
@@ -1186,7 +1186,7 @@ template <> bool rows_supported<float>(int W, int K) {
 }
 template <> bool rows_supported<double>(int, int) { return false; }
 template <> bool rows_joint_supported<float>(int W, int C, int K) {
-    return rows_supported<float>(W, K) && !rows_mr_width(W) && C >= 1 && C <= 4 && K % 32 == 0;
+    return rows_supported<float>(W, K) && C >= 1 && C <= 4 && K % 32 == 0;
 }
 template <> bool rows_joint_supported<double>(int, int, int) { return false; }
 

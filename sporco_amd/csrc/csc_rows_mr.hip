@@ -4,8 +4,9 @@
 // The kernels are the templates of csc_rows.hip instantiated with that N1 (translation units of
 // their own -- this file for N1 <= 20, csc_rows_mr2.hip for the rest -- so that they compile side by
 // side with the power-of-two ones).  Built: the variants of admm.cbpdn.ConvBPDN -- scalar or array
-// L1Weight, NonNegCoef, NoBndryCross (sporco/admm/cbpdn.py:267-311, 614-630) -- at image sizes such as
-// the reference's own odd-sized tests (tests/admm/test_cbpdn.py:204-225); no AddMaskSim, no Joint.
+// L1Weight, NonNegCoef, NoBndryCross (sporco/admm/cbpdn.py:267-311, 614-630) -- and of ConvBPDNJoint
+// (:785-807; scalar weights), and the proximal row pass of FISTA, at image sizes such as the
+// reference's own odd-sized tests (tests/admm/test_cbpdn.py:204-225); no AddMaskSim.
 #ifndef SA_MR_PART
 #define SA_MR_PART 0
 #endif
@@ -41,8 +42,20 @@ template <int N1> void fwd_mr(hipStream_t st, RowsFwdArgs<float> &a) {
         set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 0, N1>);
         set_lds_attr<16>(&rows_fwd_kernel<16, false, true, false, 1, N1>);
     }
-    const dim3 grid = rows_grid(a, 16, ceil_div(a.P, 128), a.H, 0), block(16 * 64);
+    const dim3 block(16 * 64);
     const size_t lds = rows_lds_bytes(16);
+    if (a.v && (a.flags & F_JOINT)) {
+        // the V form of ConvBPDNJoint: tiles as the joint epilogue (one image, 32 filters, all channels)
+        static PerDeviceOnce jattr;
+        if (jattr.first()) set_lds_attr<16>(&rows_fwd_kernel<16, false, true, true, 0, N1>);
+        SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && a.C * a.N == a.CN && !a.wl1.ptr &&
+                       !(a.flags & F_NOBNDRY),
+                   "configuration not handled by the joint row pass");
+        const dim3 jgrid = rows_grid(a, 16, (int64_t)a.N * (a.K / 32), a.H, 0);
+        hipLaunchKernelGGL((rows_fwd_kernel<16, false, true, true, 0, N1>), jgrid, block, lds, st, a);
+        return;
+    }
+    const dim3 grid = rows_grid(a, 16, ceil_div(a.P, 128), a.H, 0);
     if (!a.v) {
         hipLaunchKernelGGL((rows_fwd_kernel<16, false, false, false, 0, N1>), grid, block, lds, st, a);
     } else if (general_options(a)) {
@@ -73,8 +86,22 @@ template <int N1, bool EMIT, int MODE> void post_mr_mode(hipStream_t st, const R
     if (a.x) hipLaunchKernelGGL((rows_inv_post_kernel<16, true, MODE, EMIT, false, 0, N1>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((rows_inv_post_kernel<16, false, MODE, EMIT, false, 0, N1>), grid, block, lds, st, a);
 }
+template <int N1, bool EMIT> void post_mr_joint(hipStream_t st, const RowsPostArgs<float> &a, dim3 grid) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
+        set_lds_attr<16>(&rows_inv_post_kernel<16, false, 0, EMIT, true, 0, N1>);
+        set_lds_attr<16>(&rows_inv_post_kernel<16, false, 0, EMIT, true, 1, N1>);
+        set_lds_attr<16>(&rows_inv_post_kernel<16, false, 0, EMIT, true, 2, N1>);
+    }
+    const dim3 block(16 * 64);
+    const size_t lds = rows_lds_bytes(16);
+    if (a.v_out && a.v_in) hipLaunchKernelGGL((rows_inv_post_kernel<16, false, 0, EMIT, true, 2, N1>), grid, block, lds, st, a);
+    else if (a.v_out) hipLaunchKernelGGL((rows_inv_post_kernel<16, false, 0, EMIT, true, 1, N1>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((rows_inv_post_kernel<16, false, 0, EMIT, true, 0, N1>), grid, block, lds, st, a);
+}
 template <int N1, bool EMIT> void post_mr(hipStream_t st, RowsPostArgs<float> &a, dim3 grid) {
-    if (general_options(a)) post_mr_mode<N1, EMIT, 1>(st, a, grid);
+    if (a.flags & F_JOINT) post_mr_joint<N1, EMIT>(st, a, grid);
+    else if (general_options(a)) post_mr_mode<N1, EMIT, 1>(st, a, grid);
     else post_mr_mode<N1, EMIT, 0>(st, a, grid);
 }
 
@@ -108,7 +135,7 @@ void launch_rows_inv_prox_fwd_mr2(hipStream_t st, RowsProxArgs<float> &a, dim3 g
 void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
     RowsFwdArgs<float> a = a_in;
     SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
-    SA_REQUIRE(!a.y_bcast && !(a.flags & F_JOINT) && !a.ams_bits, "mixed-radix widths: ConvBPDN options only");
+    SA_REQUIRE(!a.y_bcast && !a.ams_bits, "mixed-radix widths: no broadcast form, no AddMaskSim");
     switch (a.W / 16) {
 #define SA_MR_CASE(n) case n: fwd_mr<n>(st, a); break;
     SA_MR_PART_LENGTHS(SA_MR_CASE)
@@ -121,8 +148,15 @@ void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
 int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a_in) {
     RowsPostArgs<float> a = a_in;
     SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
-    SA_REQUIRE(!(a.flags & F_JOINT) && !a.ams_bits && !a.emit_u && !a.t_odd, "mixed-radix widths: ConvBPDN options only");
-    const int64_t tx = ceil_div(a.P, 128);
+    SA_REQUIRE(!a.ams_bits && !a.emit_u && !a.t_odd, "mixed-radix widths: no AddMaskSim, no mask decoupling");
+    const bool joint = a.flags & F_JOINT;
+    if (joint) {
+        SA_REQUIRE(!a.v_in || a.v_out, "a V-form input needs a V-form output");
+        SA_REQUIRE(rows_joint_supported<float>(a.W, a.C, a.K) && !a.wl1.ptr && !(a.flags & F_NOBNDRY) && !a.x,
+                   "configuration not handled by the joint row epilogue");
+    }
+    // (ConvBPDNJoint tiles by (image, 32 filters): all channels of a pixel in one wave, csc_rows.h)
+    const int64_t tx = joint ? (int64_t)a.N * (a.K / 32) : ceil_div(a.P, 128);
     const bool emit = a.t_next != nullptr;
     const dim3 grid = rows_grid(a, 16, tx, a.H, emit);
     switch (a.W / 16) {

@@ -143,7 +143,8 @@ def test_slab_form_at_the_sizes_it_is_for(gpu_backend, H, W, K, dt):
     D = rng.randn(8, 8, K)
     D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
     S = rng.randn(H, W, 2)
-    b, prof = run(D.astype(dt), S.astype(dt), {'MaxMainIter': 8, 'RelStopTol': 0.0, 'DataType': dt}, True)
+    b, prof = run(D.astype(dt), S.astype(dt), {'MaxMainIter': 8, 'RelStopTol': 0.0, 'DataType': dt}, True,
+                  generic=True)
     assert prof['fft_c2c_cols_fwd'][1] == 0 and prof['sm_solve'][1] == 8
     ref = orc.admm_cbpdn(D.reshape(8, 8, 1, 1, K), S.reshape(H, W, 1, 2, 1), 0.05, dtype=np.float64,
                          maxiter=8, rel_tol=0.0)

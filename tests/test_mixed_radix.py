@@ -190,10 +190,10 @@ def test_weights_and_boundary_options_on_the_mixed_radix_kernels(backend):
 
 
 def test_other_options_take_the_generic_chain(backend):
-    """ConvBPDNJoint, ConvBPDNGradReg, FISTA at a mixed-radix size: served by the generic chain of
-    the handle (the mixed-radix kernels exist for admm.cbpdn.ConvBPDN only) -- the results are those
-    of a handle that never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit; the staged
-    step methods run their X-step on the register kernels."""
+    """ConvBPDNGradReg (and AddMaskSim, LinSolveCheck, multi-channel dictionaries, K > 64) at a
+    mixed-radix size: served by the generic chain of the handle -- the results are those of a handle
+    that never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit; the staged step methods
+    run their X-step on the register kernels, FISTA its whole iteration (tested above)."""
     from sporco_amd.admm import cbpdn
     from sporco_amd.pgm import cbpdn as pc
     H, W, K, N = (160, 160, 4, 1) if backend == 'hostsim' else (384, 480, 8, 2)
@@ -207,11 +207,8 @@ def test_other_options_take_the_generic_chain(backend):
     cases = [
         ('GradReg', lambda: cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.1, cbpdn.ConvBPDNGradReg.Options(o))),
         ('staged', lambda: Hooked(D, S, 0.05, cbpdn.ConvBPDN.Options(o))),
-        ('pgm', lambda: pc.ConvBPDN(D, S, 0.05, pc.ConvBPDN.Options(dict(o, L=50.0)))),
+        ('LinSolveCheck', lambda: cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(dict(o, LinSolveCheck=True)))),
     ]
-    if backend != 'hostsim':
-        S3 = np.stack([S, 0.5 * S, -S], axis=2)
-        cases.append(('Joint', lambda: cbpdn.ConvBPDNJoint(D, S3, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(o))))
     for name, make in cases:
         b = make()
         a = b.solve()
@@ -277,3 +274,38 @@ def test_fista_and_dictionary_learning_at_mixed_radix_sizes(backend, H, W, K, N)
     for f in ('ObjFun', 'DFid', 'RegL1', 'Cnstr'):
         a, c = np.asarray(getattr(outs[0][2], f), float), np.asarray(getattr(outs[1][2], f), float)
         assert rel_l2(a, c) < 2e-5 or np.max(np.abs(a - c)) < 1e-6, f
+
+
+@pytest.mark.parametrize('H,W,K,N', [(160, 240, 32, 1),
+                                     pytest.param(384, 480, 32, 2, marks=pytest.mark.gpu),
+                                     pytest.param(240, 336, 64, 1, marks=pytest.mark.gpu)])
+def test_joint_at_mixed_radix_sizes(backend, H, W, K, N):
+    """ConvBPDNJoint (l1 + l2,1 over the three channels inside the row epilogue, re-derived from V in
+    rows_fwd: sporco/admm/cbpdn.py:785-807, sporco/prox/_l21.py:51-88) at mixed-radix sizes against
+    the float64 oracle; default AutoRho and a fixed rho (the emitting epilogue from the third
+    iteration on); the V form bit for bit against the (Y, U) form."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(H + K)
+    D = rng.randn(4, 4, K).astype(np.float32)
+    D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+    S = rng.randn(H, W, 3, N).astype(np.float32)
+    iters = 4 if backend == 'hostsim' else 9
+    for extra, okw in (({}, {}), ({'AutoRho': {'Enabled': False}, 'rho': 3.0}, {'rho': 3.0, 'auto_rho': False})):
+        optd = dict({'MaxMainIter': iters, 'RelStopTol': 0.0}, **extra)
+        b = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(optd))
+        assert b._dev.uses_fused_rows() and b._fused_ok() and b._device_loop_ok()
+        Y = b.solve()
+        ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 3, N, 1), 0.05, mu=0.02, dtype=np.float64,
+                             maxiter=iters, rel_tol=0.0, **okw)
+        assert rel_l2(Y, ref['Y']) < 2e-5 and rel_l2(b.U, ref['U']) < 2e-5 and rel_l2(b.X, ref['X']) < 2e-5
+        its = b.getitstat()
+        for f in ('ObjFun', 'DFid', 'RegL1', 'RegL21', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+            assert rel_l2(getattr(its, f), ref[f]) < 2e-5, f
+        if backend == 'hostsim' and extra:
+            continue
+        with env(SPORCO_AMD_NO_VFORM='1'):
+            b0 = cbpdn.ConvBPDNJoint(D, S, 0.05, 0.02, cbpdn.ConvBPDNJoint.Options(optd))
+            Y0 = b0.solve()
+        assert np.array_equal(Y, Y0)
+        assert np.array_equal(np.asarray(its.ObjFun), np.asarray(b0.getitstat().ObjFun))
