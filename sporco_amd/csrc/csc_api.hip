@@ -166,12 +166,13 @@ template <typename T> struct Csc : CscBase {
     // fused row passes (csc_rows.h)
     bool rows_ok = false;
     // Mixed-radix shape (round 6): H or W one of 320 / 384 / 448 / 480 -- the register-resident kernels
-    // exist in the instantiations of admm.cbpdn.ConvBPDN only (scalar or array L1Weight, NonNegCoef,
-    // NoBndryCross: csc_rows_mr.hip, csc_fused.h); every other option set, and every other solver
-    // family, stays on the generic chain for such a handle.
+    // exist for K <= 64 and a single-channel dictionary: ConvBPDN (scalar or array L1Weight, NonNegCoef,
+    // NoBndryCross), ConvBPDNJoint, ConvBPDNGradReg, AddMaskSim, FISTA and the tile-major dictionary
+    // update (csc_rows_mr.hip, csc_pgm_mr.hip, csc_fused.h); LinSolveCheck, mask decoupling, consensus
+    // and the K > 64 families stay on the generic chain for such a handle.
     bool mr = false;
     bool mr_ok(const sporco_amd_admm_params &p) const {
-        return !mr || (Cd == 1 && !wl21.ptr && !(p.flags & (F_AMS | F_GRADREG | F_XRRS)));
+        return !mr || (Cd == 1 && !wl21.ptr && !(p.flags & F_XRRS));
     }
     cx<T> *twRows = nullptr;
     double *part_rows = nullptr;

@@ -867,14 +867,16 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     if (sp.N1 != 32) {
         // mixed-radix heights: the plain system only (no gradient term, no per-tile operands, no
         // multipliers stored) -- the API layer keeps everything else on the generic chain
-        SA_REQUIRE(!a.g1t && !a.per_tile && !a.coef_out && !(a.Kv == 64 && a.K > 64),
-                   "mixed-radix heights: the plain column pass only");
-        const bool k64 = a.K == 64;
+        SA_REQUIRE(!a.per_tile && !a.coef_out && !(a.Kv == 64 && a.K > 64),
+                   "mixed-radix heights: the plain and the gradient-regularised column pass only");
+        const bool k64 = a.K == 64, grad = a.g1t != nullptr;
         switch (sp.N1) {
-#define SA_MR_CASE(n)                                                            \
-    case n:                                                                      \
-        k64 ? launch_fused_inst<n, 16, 1, 64, false>(st, a, ntiles)             \
-            : launch_fused_inst<n, 16, 1, 0, false>(st, a, ntiles);             \
+#define SA_MR_CASE(n)                                                                     \
+    case n:                                                                               \
+        if (grad) k64 ? launch_fused_inst<n, 16, 1, 64, true>(st, a, ntiles)              \
+                      : launch_fused_inst<n, 16, 1, 0, true>(st, a, ntiles);              \
+        else k64 ? launch_fused_inst<n, 16, 1, 64, false>(st, a, ntiles)                  \
+                 : launch_fused_inst<n, 16, 1, 0, false>(st, a, ntiles);                  \
         break;
         SA_MR_LENGTHS(SA_MR_CASE)
 #undef SA_MR_CASE

@@ -1454,7 +1454,7 @@ __global__ void __launch_bounds__(256) ams_pack_kernel(Weight<float> m, uint32_t
 
 template <> void launch_ams_pack<float>(hipStream_t st, const Weight<float> &mask, uint32_t *bits,
                                         int H, int W, int C, int N) {
-    const int NW = W / kN1;
+    const int NW = rows_mr_width(W) ? 16 : W / kN1;     // (waves of the row kernels: one word per wave)
     const int64_t total = (int64_t)H * C * N * NW;
     hipLaunchKernelGGL(ams_pack_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 65535)),
                        dim3(256), 0, st, mask, bits, H, W, C, N, NW);

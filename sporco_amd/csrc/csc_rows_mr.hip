@@ -6,7 +6,7 @@
 // side with the power-of-two ones).  Built: the variants of admm.cbpdn.ConvBPDN -- scalar or array
 // L1Weight, NonNegCoef, NoBndryCross (sporco/admm/cbpdn.py:267-311, 614-630) -- and of ConvBPDNJoint
 // (:785-807; scalar weights), and the proximal row pass of FISTA, at image sizes such as the
-// reference's own odd-sized tests (tests/admm/test_cbpdn.py:204-225); no AddMaskSim.
+// reference's own odd-sized tests (tests/admm/test_cbpdn.py:204-225).
 #ifndef SA_MR_PART
 #define SA_MR_PART 0
 #endif
@@ -24,10 +24,10 @@ namespace sporco_amd {
 
 namespace {
 
-// MODE 1 (csc_rows.hip): weight array and / or NoBndryCross; without an array the kernel reads a
+// MODE 1 (csc_rows.hip): weight array, NoBndryCross and / or the AddMaskSim mask; without an array the kernel reads a
 // device-resident 1.0 through zero strides
 template <typename A> bool general_options(A &a) {
-    const bool g = a.wl1.ptr != nullptr || (a.flags & F_NOBNDRY);
+    const bool g = a.wl1.ptr != nullptr || (a.flags & F_NOBNDRY) || a.ams_bits != nullptr;
     if (g && !a.wl1.ptr) {
         a.wl1 = Weight<float>();
         a.wl1.ptr = device_one();
@@ -135,7 +135,7 @@ void launch_rows_inv_prox_fwd_mr2(hipStream_t st, RowsProxArgs<float> &a, dim3 g
 void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
     RowsFwdArgs<float> a = a_in;
     SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
-    SA_REQUIRE(!a.y_bcast && !a.ams_bits, "mixed-radix widths: no broadcast form, no AddMaskSim");
+    SA_REQUIRE(!a.y_bcast, "mixed-radix widths: no broadcast form");
     switch (a.W / 16) {
 #define SA_MR_CASE(n) case n: fwd_mr<n>(st, a); break;
     SA_MR_PART_LENGTHS(SA_MR_CASE)
@@ -148,7 +148,7 @@ void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
 int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a_in) {
     RowsPostArgs<float> a = a_in;
     SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
-    SA_REQUIRE(!a.ams_bits && !a.emit_u && !a.t_odd, "mixed-radix widths: no AddMaskSim, no mask decoupling");
+    SA_REQUIRE(!a.emit_u && !a.t_odd, "mixed-radix widths: no mask decoupling, no striped spectrum");
     const bool joint = a.flags & F_JOINT;
     if (joint) {
         SA_REQUIRE(!a.v_in || a.v_out, "a V-form input needs a V-form output");

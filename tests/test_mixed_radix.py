@@ -190,7 +190,7 @@ def test_weights_and_boundary_options_on_the_mixed_radix_kernels(backend):
 
 
 def test_other_options_take_the_generic_chain(backend):
-    """ConvBPDNGradReg (and AddMaskSim, LinSolveCheck, multi-channel dictionaries, K > 64) at a
+    """LinSolveCheck (and multi-channel dictionaries, K > 64, mask decoupling, consensus) at a
     mixed-radix size: served by the generic chain of the handle -- the results are those of a handle
     that never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit; the staged step methods
     run their X-step on the register kernels, FISTA its whole iteration (tested above)."""
@@ -205,7 +205,6 @@ def test_other_options_take_the_generic_chain(backend):
             super(Hooked, self).ystep()
 
     cases = [
-        ('GradReg', lambda: cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.1, cbpdn.ConvBPDNGradReg.Options(o))),
         ('staged', lambda: Hooked(D, S, 0.05, cbpdn.ConvBPDN.Options(o))),
         ('LinSolveCheck', lambda: cbpdn.ConvBPDN(D, S, 0.05, cbpdn.ConvBPDN.Options(dict(o, LinSolveCheck=True)))),
     ]
@@ -309,3 +308,66 @@ def test_joint_at_mixed_radix_sizes(backend, H, W, K, N):
             Y0 = b0.solve()
         assert np.array_equal(Y, Y0)
         assert np.array_equal(np.asarray(its.ObjFun), np.asarray(b0.getitstat().ObjFun))
+
+
+@pytest.mark.parametrize('H,W,K,N', [(160, 192, 3, 1),
+                                     pytest.param(384, 240, 5, 2, marks=pytest.mark.gpu),
+                                     pytest.param(480, 320, 63, 1, marks=pytest.mark.gpu)])
+def test_gradreg_and_addmasksim_at_mixed_radix_sizes(backend, H, W, K, N):
+    """ConvBPDNGradReg (the GRAD column kernel: sporco/admm/cbpdn.py:1163-1214) and AddMaskSim around
+    ConvBPDN / ConvBPDNGradReg (:2287-2485; the mask bits packed one word per wave of the 16-wave row
+    kernels) at mixed-radix sizes: against the generic chain, and the float64 oracle where that is
+    quick."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    D, S = problem(H, W, K, N, seed=H + K + 3)
+    rng = np.random.RandomState(3)
+    Wm = (rng.rand(H, W, N) > 0.25).astype(np.float32)
+    iters = 4
+    wg = np.linspace(0.0, 2.0, K).astype(np.float32)
+    small = K * N <= 8
+    fields = ('ObjFun', 'DFid', 'RegL1', 'PrimalRsdl', 'DualRsdl', 'Rho')
+    # --- ConvBPDNGradReg
+    outs = []
+    for unfused in (False, True):
+        with env(**({'SPORCO_AMD_UNFUSED': '1'} if unfused else {})):
+            b = cbpdn.ConvBPDNGradReg(D, S, 0.05, 0.3, cbpdn.ConvBPDNGradReg.Options(
+                {'MaxMainIter': iters, 'RelStopTol': 0.0, 'GradWeight': wg}))
+        assert bool(b._dev.uses_fused_rows()) == (not unfused)
+        outs.append((b.solve(), b.X.copy(), b.getitstat()))
+    assert rel_l2(outs[0][0], outs[1][0]) < 2e-5 and rel_l2(outs[0][1], outs[1][1]) < 2e-5
+    for f in fields + ('RegGrad',):
+        assert rel_l2(getattr(outs[0][2], f), getattr(outs[1][2], f)) < 1e-4, f
+    if small:
+        ref = orc.admm_cbpdn(D.reshape(4, 4, 1, 1, K), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                             maxiter=iters, rel_tol=0.0, grad_mu=0.3, grad_weight=wg.astype(np.float64))
+        assert rel_l2(outs[0][0], ref['Y']) < 1e-4
+        for f in fields + ('RegGrad',):
+            assert rel_l2(getattr(outs[0][2], f), ref[f]) < 1e-3, f
+    # --- AddMaskSim around ConvBPDN and (GPU) around ConvBPDNGradReg
+    for gradreg in ((False,) if backend == 'hostsim' else (False, True)):
+        cls = cbpdn.ConvBPDNGradReg if gradreg else cbpdn.ConvBPDN
+        args = (0.05, 0.3) if gradreg else (0.05,)
+        optd = {'MaxMainIter': iters, 'RelStopTol': 0.0, 'NonNegCoef': True}
+        runs = []
+        for unfused in (False, True):
+            with env(**({'SPORCO_AMD_UNFUSED': '1'} if unfused else {})):
+                b = cbpdn.AddMaskSim(cls, D, S, Wm, *args, opt=cls.Options(optd))
+            b.solve()
+            assert bool(b.cbpdn._dev.uses_fused_rows()) == (not unfused) and b.cbpdn._fused_ok()
+            runs.append(b)
+        b, b0 = runs
+        assert rel_l2(b.cbpdn.Y, b0.cbpdn.Y) < 2e-5 and rel_l2(b.cbpdn.U, b0.cbpdn.U) < 2e-5
+        for f in fields:
+            assert rel_l2(getattr(b.getitstat(), f), getattr(b0.getitstat(), f)) < 1e-4, f
+        Yi = b.cbpdn.Y[..., -1]
+        assert np.all(Yi[Wm.reshape(Yi.shape) != 0] == 0)
+        if small and not gradreg:
+            imp = np.zeros((4, 4, 1), np.float32)
+            imp[0, 0] = 1
+            Di = np.concatenate((D, imp), axis=2)
+            ref = orc.admm_cbpdn(Di.reshape(4, 4, 1, 1, K + 1), S.reshape(H, W, 1, N, 1), 0.05, dtype=np.float64,
+                                 maxiter=iters, rel_tol=0.0, nonneg=True, ams_mask=Wm.reshape(H, W, 1, N, 1))
+            assert rel_l2(b.cbpdn.Y, ref['Y']) < 1e-4
+            for f in fields:
+                assert rel_l2(getattr(b.getitstat(), f), ref[f]) < 1e-3, f
