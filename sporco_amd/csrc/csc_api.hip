@@ -166,10 +166,10 @@ template <typename T> struct Csc : CscBase {
     // fused row passes (csc_rows.h)
     bool rows_ok = false;
     // Mixed-radix shape (round 6): H or W one of 320 / 384 / 448 / 480 -- the register-resident kernels
-    // exist for K <= 64 and a single-channel dictionary: ConvBPDN (scalar or array L1Weight, NonNegCoef,
-    // NoBndryCross), ConvBPDNJoint, ConvBPDNGradReg, AddMaskSim, FISTA and the tile-major dictionary
-    // update (csc_rows_mr.hip, csc_pgm_mr.hip, csc_fused.h); LinSolveCheck, mask decoupling, consensus
-    // and the K > 64 families stay on the generic chain for such a handle.
+    // exist for a single-channel dictionary: ConvBPDN (scalar or array L1Weight, NonNegCoef,
+    // NoBndryCross), ConvBPDNJoint, ConvBPDNGradReg, AddMaskSim with K <= 256; FISTA and the tile-major
+    // dictionary update with K <= 64 (csc_rows_mr.hip, csc_pgm_mr.hip, csc_fused.h); LinSolveCheck,
+    // mask decoupling and consensus stay on the generic chain for such a handle.
     bool mr = false;
     bool mr_ok(const sporco_amd_admm_params &p) const {
         return !mr || (Cd == 1 && !wl21.ptr && !(p.flags & F_XRRS));
@@ -340,15 +340,16 @@ template <typename T> struct Csc : CscBase {
         rows_ok = (fused || fused_slabs || fused_mc) && rows_supported<T>(W, K) &&
                   !sw.old_rows;
         mr = std::is_same<T, float>::value && (fused_mr_height(H) || rows_mr_width(W));
-        if (mr && !(fused && rows_ok)) {
+        if (mr && !((fused || fused_slabs) && rows_ok)) {
             // (a mixed-radix side needs the register kernels on BOTH sides and K <= 64: otherwise
             // the whole handle is a generic-chain one)
             rows_ok = false;
-            if (fused_mr_height(H)) fused = false;
+            if (fused_mr_height(H)) fused = fused_slabs = false;
             mr = false;
         }
         if (mr) cols256 = false;      // (consensus, mask decoupling, the K > 64 families: generic)
-        tail_mode = fused_slabs && K - 64 <= kTailMax;
+        // (a mixed-radix height has no tail form: 64 < K <= 72 runs two slabs there)
+        tail_mode = fused_slabs && K - 64 <= kTailMax && !fused_mr_height(H);
         Ks = (rows_ok && tail_mode) ? 80 : K;
         EFt = npix * CN * (int64_t)Ks;
         if (Ks != K) {   // dft was sized for K-filter rows above
@@ -511,7 +512,9 @@ template <typename T> struct Csc : CscBase {
     // its Xf buffer to 80 for the ADMM tail kernels: the staged composition serves it).
     // (a mixed-radix handle: the FISTA and tile-major dictionary-update column kernels exist at its
     // height too, csc_pgm_mr.hip)
-    bool pgm_fused_ok() const { return rows_ok && (cols256 || mr) && (fused || (fused_slabs && !tail_mode)); }
+    bool pgm_fused_ok() const {
+        return rows_ok && (cols256 || mr) && (fused || (fused_slabs && !tail_mode && !mr));
+    }
     bool hint_vform = false, hint_one_launch = false;
     // SPORCO_AMD_MODE_COMPLEX_PAIR: the two channels of the handle are the real and the imaginary
     // part of complex data (dictionary updates only; csc_kernels.h launch_pm_butterfly)

@@ -410,13 +410,18 @@ __global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedS
 // PGM: the gradient step of the fused FISTA iteration for K > 64 instead (csc_pgm.h pgm_grad_ifft):
 // the input rows are the spectrum Yf itself (no forward transform), the per-row coefficient is
 // -(sum_k Df Yf - Sf) / L, the output goes to a.c.t, and partials[tile] = sum |sum_k Df Yf - Sf|^2.
-template <int NW, int LP, int KS, bool GRAD, bool PGM = false>
+// N1: rows per thread -- 32, or a mixed-radix length (16 waves, LP = 1: the second exchange group partly
+// filled, as in csc_fused_body.inc; not with PGM)
+template <int NW, int LP, int KS, bool GRAD, bool PGM = false, int N1 = 32>
 __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlabArgs<float> aa) {
     static_assert(!(GRAD && PGM), "one or the other");
-    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
+    constexpr bool MR = mr_length(N1);
+    static_assert(!MR || (NW == 16 && LP == 1 && !PGM), "mixed-radix heights: 16 waves, one line per group, ADMM");
+    constexpr int H = N1 * NW, J = MR ? (N1 > NW ? 2 : 1) : N1 / NW;
     constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP, CPL = NW / 4, NCH = LP * CPL;
-    static_assert(Q * FP == N1, "a thread holds N1 spectrum rows");
+    static_assert(MR || Q * FP == N1, "a thread holds N1 spectrum rows");
+    constexpr int NU = Q * FP;          // slots of the spectrum rows of a thread (>= N1)
     const int tid = threadIdx.x;
     const int k = tid & 63;
     const int w = sa_readfirstlane(tid >> 6);
@@ -439,6 +444,8 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     // r = l of slab 0 (+ 2, ...), lane l >= 32 the same row of slab 1 (+ 3, ...)
     const int rl = k & 31;
     const int fo_lane = NW * (rl / NW) + N1 * brev(rl % NW, LBW);
+    // (mixed-radix heights: the line w + NW (rl / NW) may not exist -- its lanes hold zeros)
+    const bool row_ok = !MR || (rl < NU && w + NW * (rl / NW) < N1);
     bool gave_up = false;
 
     for (int slot = pair >> 3;; slot += npairs >> 3) {
@@ -454,7 +461,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     const BufRsrc Tb = make_rsrc(ap->c.t + (int64_t)tile * H * K, tbytes);
     const BufRsrc Db = make_rsrc(ap->c.dft + (int64_t)wf * H * K, tbytes);
     const cf *twA = ap->c.twA + w * N1;
-    const cf *twB = ap->c.twB + w * N1;
+    const cf *twB = ap->c.twB + w * (J * NW);
     const cf *S = ap->c.sft + (int64_t)tile * H + w;
     const float *G = PGM ? nullptr : (GRAD ? ap->c.g1t : ap->c.gramt) + (int64_t)wf * H + w;
     const float *GH = ap->c.ghh + w;
@@ -472,7 +479,11 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     }
 
     // ---- phase 1: FFT along H, this slab's share of sum_k Df yuf ------------------------
-    cf uall[N1];                       // the slab's spectrum rows: group q in [q FP, (q + 1) FP)
+    cf uall[NU];                       // the slab's spectrum rows: group q in [q FP, (q + 1) FP)
+    if constexpr (MR) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) uall[i] = zero;
+    }
     if constexpr (PGM) {
         // the iterate is already a spectrum: rows f = w + NW j + N1 brev(i) of Yf, and the slab's
         // share of sum_k Df Yf
@@ -509,7 +520,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1)
             v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
-        dif<N1, false>(v, 0);
+        dif1<N1, false>(v, 0);
         reg_fence<N1>(v, 0, token);
 #pragma unroll
         for (int i = 1; i < N1; ++i) {
@@ -520,9 +531,11 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
         reg_fence<N1>(v, 0, token);
         static_for<Q>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
+            const bool lv = !MR || q * FP + w < N1;      // (this wave's line of the group exists)
 #pragma unroll
             for (int fl = 0; fl < FP; ++fl) {
-                const cf x = v[brev(q * FP + fl, 5)];
+                if (q * FP + fl >= N1) continue;
+                const cf x = v[pos1<N1>(q * FP + fl)];
                 f2 t;
                 t.x = x.re;
                 t.y = x.im;
@@ -538,8 +551,9 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                     dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
                 }
             };
-            prefetch(std::integral_constant<int, 0>{});
+            if (lv) prefetch(std::integral_constant<int, 0>{});
             __syncthreads();
+            if (lv) {
 #pragma unroll
             for (int jl = 0; jl < LP; ++jl) {
 #pragma unroll
@@ -548,7 +562,9 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                     uall[q * FP + NW * jl + h2] = mk<float>(t.x, t.y);
                 }
             }
+            }
             if (q + 1 < Q) __syncthreads();
+            if (lv) {
             static_for<NCH>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr int jl = g / CPL, c = g % CPL, j = q * LP + jl;
@@ -574,6 +590,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                 constexpr int fo_c = NW * j + N1 * brev(c, LBW - 2);
                 if ((k & 7) == 0) sa_store_agent(pub + 2 * fo_c, tot);
             });
+            }   // lv
         });
     }
     // ---- publish, and wait for the other slabs of this tile ------------------------------
@@ -583,12 +600,15 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     // what phase 2 needs besides the sums, requested before the wait: per row (one row per
     // lane, as the sums below) Sf and the Sherman-Morrison denominator; the first rows of Df
     float s_re, s_im, g_l, gh_l = 0.f;
-    {
+    if (row_ok) {
         const f2 t = *reinterpret_cast<const f2 *>(S + fo_lane);
         s_re = t.x;
         s_im = t.y;
         g_l = PGM ? 0.f : G[fo_lane];
         if constexpr (GRAD) gh_l = GH[fo_lane];
+    } else {
+        s_re = s_im = 0.f;
+        g_l = 1.f;
     }
     cf dn[4];
     auto prefetch_d = [&](auto nc) {
@@ -600,7 +620,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
             dn[e] = kv ? buf_load_cf_cached(Db, ko, fo * K * (int)sizeof(cf)) : zero;
         }
     };
-    prefetch_d(std::integral_constant<int, 0>{});
+    if (!MR || w < N1) prefetch_d(std::integral_constant<int, 0>{});
     if (tid < NH && tid != slab && !gave_up) {
         int polls = 0;
         while (sa_load_agent(flags + tid) != seq) {
@@ -616,7 +636,7 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     float qre = 0.f, qim = 0.f;
     for (int sl = 0; sl < NH; sl += 2) {
         const int mine = sl + (k >> 5);
-        if (mine < NH) {
+        if (mine < NH && row_ok) {
             float a0, b0;
             sa_load_agent2(reinterpret_cast<const float *>(qp + (int64_t)mine * H + fo_lane), a0, b0);
             qre += a0;
@@ -645,10 +665,17 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     static_for<Q * NCH>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
         constexpr int q = n / NCH, g = n % NCH, jl = g / CPL, c = g % CPL, j = q * LP + jl;
+        const bool lv = !MR || q * FP + w < N1;          // (this wave's line of the group exists)
+        // (the operand prefetch runs one chunk ahead: chunk n + 1 is requested when ITS line exists)
+        constexpr int qn = (n + 1) / NCH;
+        const bool lvn = !MR || qn * FP + w < N1;
         cf d[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = dn[e];
-        if constexpr (n + 1 < Q * NCH) prefetch_d(std::integral_constant<int, n + 1>{});
+        if constexpr (n + 1 < Q * NCH) {
+            if (lvn) prefetch_d(std::integral_constant<int, n + 1>{});
+        }
+        if (lv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = NW * j + 4 * c + e;        // the lane that holds this row's values
@@ -672,12 +699,14 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                 uall[q * FP + NW * jl + h2] = cmulc(tw, uall[q * FP + NW * jl + h2]);
             }
         }
+        }   // lv
         if constexpr (g == NCH - 1) {
             {
                 float &rg_ = rg;
                 int &tk_ = token;
                 SA_VGPR_FENCE3(rg_, tk_, tk_);
             }
+            if (lv) {
 #pragma unroll
             for (int jl2 = 0; jl2 < LP; ++jl2) {
 #pragma unroll
@@ -688,10 +717,12 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                     L[((w + NW * jl2) * NW + h2) * 64 + k] = t;
                 }
             }
+            }
             __syncthreads();
-            // (back into the group's own registers: rows h1 = brev(q FP + fl) of the last stage)
+            // (back into the group's own registers: rows h1 = pos(q FP + fl) of the last stage)
 #pragma unroll
             for (int fl = 0; fl < FP; ++fl) {
+                if (q * FP + fl >= N1) continue;
                 const f2 t = L[(fl * NW + w) * 64 + k];
                 uall[q * FP + fl] = mk<float>(t.x, t.y);
             }
@@ -700,9 +731,9 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
     });
     cf v[N1];
 #pragma unroll
-    for (int i = 0; i < N1; ++i) v[brev(i, 5)] = uall[i];
+    for (int i = 0; i < N1; ++i) v[pos1<N1>(i)] = uall[i];
     reg_fence<N1>(v, 0, token);
-    dit<N1, true>(v, 0);
+    dit1<N1, true>(v, 0);
 #pragma unroll
     for (int h1 = 0; h1 < N1; ++h1)
         if (kv) buf_store_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf), v[h1]);
@@ -1033,7 +1064,7 @@ template <> void launch_tail_update<double>(hipStream_t, const FusedColsArgs<dou
 }
 
 template <> bool fused_slabs_supported<float>(int H, int K) {
-    return (H == 128 || H == 256 || H == 512) && K > 64 && K <= 256 && K % 2 == 0;
+    return (H == 128 || H == 256 || H == 512 || fused_mr_height(H)) && K > 64 && K <= 256 && K % 2 == 0;
 }
 template <> bool fused_slabs_supported<double>(int, int) { return false; }
 
@@ -1060,11 +1091,11 @@ static void launch_slabs(hipStream_t st, const FusedSlabArgs<float> &a, bool sec
 // Workgroups of the one-launch form: NH per tile side by side, as many groups as the device
 // holds at once with one workgroup per CU (a multiple of 8 groups: the residue of the row
 // frequencies a group walks stays fixed).
-template <int NW, int LP, int KS, bool GRAD>
+template <int NW, int LP, int KS, bool GRAD, int N1 = 32>
 static void launch_slab_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, GRAD>),
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_slab_coop_kernel<NW, LP, KS, GRAD, false, N1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)fused_lds_bytes(NW, LP)));
     }
@@ -1078,7 +1109,7 @@ static void launch_slab_coop(hipStream_t st, const FusedSlabArgs<float> &a) {
     SA_REQUIRE(groups >= 8, "too few compute units for cooperating slab workgroups");
     const int64_t slots = ceil_div(a.c.W / 2 + 1, 8) * a.c.CN;
     if ((int64_t)(groups >> 3) > slots) groups = (int)slots * 8;
-    hipLaunchKernelGGL((cols_slab_coop_kernel<NW, LP, KS, GRAD>), dim3((unsigned)(groups * NH)),
+    hipLaunchKernelGGL((cols_slab_coop_kernel<NW, LP, KS, GRAD, false, N1>), dim3((unsigned)(groups * NH)),
                        dim3(NW * 64), fused_lds_bytes(NW, LP), st, a);
     SA_HIP(hipGetLastError());
 }
@@ -1089,6 +1120,20 @@ template <> int64_t launch_cols_slab_coop<float>(hipStream_t st, const FusedSlab
     a.c.stagger_groups = kColsStaggerGroups;
     a.c.stagger_sleeps = kColsStaggerSleeps;
     const bool g = a.c.g1t != nullptr;
+    if (fused_mr_height(a.c.H)) {
+        // mixed-radix heights: run-time K, plain and gradient-regularised systems
+        switch (a.c.H / 16) {
+#define SA_MR_CASE(n)                                                                          \
+    case n:                                                                                    \
+        if (g) launch_slab_coop<16, 1, 0, true, n>(st, a);                                     \
+        else launch_slab_coop<16, 1, 0, false, n>(st, a);                                      \
+        break;
+        SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
+        default: SA_REQUIRE(false, "height not handled by the mixed-radix slab kernel");
+        }
+        return (int64_t)(a.c.W / 2 + 1) * a.c.CN;
+    }
     if (a.c.H == 128) {
         if (a.c.K == 128) { if (g) launch_slab_coop<4, 4, 128, true>(st, a); else launch_slab_coop<4, 4, 128, false>(st, a); }
         else { if (g) launch_slab_coop<4, 4, 0, true>(st, a); else launch_slab_coop<4, 4, 0, false>(st, a); }

@@ -85,6 +85,12 @@ def test_reference_fixtures_at_mixed_radix_shapes(gpu_backend, name):
 @pytest.mark.parametrize('H,W,K,N', [pytest.param(384, 320, 4, 1, marks=pytest.mark.gpu),
                                      # odd points per thread (15), one exchange group (10 <= 16)
                                      (240, 160, 4, 1), (160, 336, 4, 1),
+                                     # K > 64: cooperating 64-filter slab workgroups at a mixed-radix height
+                                     (240, 160, 66, 1),
+                                     pytest.param(384, 320, 128, 1, marks=pytest.mark.gpu),
+                                     pytest.param(480, 240, 96, 2, marks=pytest.mark.gpu),
+                                     pytest.param(448, 336, 70, 1, marks=pytest.mark.gpu),
+                                     pytest.param(512, 400, 128, 1, marks=pytest.mark.gpu),
                                      pytest.param(240, 320, 64, 2, marks=pytest.mark.gpu),
                                      pytest.param(224, 224, 14, 3, marks=pytest.mark.gpu),
                                      pytest.param(336, 400, 8, 1, marks=pytest.mark.gpu),
@@ -277,7 +283,8 @@ def test_fista_and_dictionary_learning_at_mixed_radix_sizes(backend, H, W, K, N)
 
 @pytest.mark.parametrize('H,W,K,N', [(160, 240, 32, 1),
                                      pytest.param(384, 480, 32, 2, marks=pytest.mark.gpu),
-                                     pytest.param(240, 336, 64, 1, marks=pytest.mark.gpu)])
+                                     pytest.param(240, 336, 64, 1, marks=pytest.mark.gpu),
+                                     pytest.param(320, 384, 128, 1, marks=pytest.mark.gpu)])
 def test_joint_at_mixed_radix_sizes(backend, H, W, K, N):
     """ConvBPDNJoint (l1 + l2,1 over the three channels inside the row epilogue, re-derived from V in
     rows_fwd: sporco/admm/cbpdn.py:785-807, sporco/prox/_l21.py:51-88) at mixed-radix sizes against
