@@ -452,7 +452,9 @@ int sporco_amd_csc_dhs_absmax(sporco_amd_csc_t h, double *out);
 #define SPORCO_AMD_PGM_DXY2 7    /* sum |Xf - Yf|^2, unweighted (backtrack.py:98-100)       */
 
 /* One whole default-option FISTA iteration on device (float32, H and W in {128, 256, 512},
- * even K <= 64 or 72 < K <= 256; SPORCO_AMD_EINVAL otherwise -- compose the calls below instead):
+ * even K <= 64 or 72 < K <= 256; since round 6 also H, W in 16 x {10, 12, 14, 15, 18, 20, 21, 24, 25,
+ * 27, 28, 30} with even K <= 64 -- SPORCO_AMD_QUERY_FUSED_PGM says which;
+ * SPORCO_AMD_EINVAL otherwise -- compose the calls below instead):
  * on_iteration_start (Xfprv = Xf, Yfprv = Yf, by buffer rotation), PGMDFT.xstep
  * (grad_f at Yf, Vf = Yf - grad/L, X = prox_g(irfftn(Vf)), Xf = rfftn(X);
  * sporco/pgm/pgm.py:779-811) and PGMDFT.ystep with the caller's momentum factor
