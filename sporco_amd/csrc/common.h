@@ -55,6 +55,12 @@ template <typename T> __host__ __device__ __forceinline__ cx<T> operator+(cx<T> 
 template <typename T> __host__ __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) {
     return mk<T>(a.re - b.re, a.im - b.im);
 }
+// occupancy floor of a kernel (waves per SIMD; caps its registers at 512 / n)
+#ifdef SPORCO_AMD_HOSTSIM
+#define SA_MIN_WAVES_PER_SIMD(n)
+#else
+#define SA_MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 // a * b + c with ONE rounding, spelled out.  The complex products below name their fused
 // multiply-adds instead of leaving `x * y + z * w` to the compiler's contraction, which picks the
 // product to fuse by the code AROUND the expression: two instantiations of the same transform

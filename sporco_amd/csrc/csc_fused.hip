@@ -37,7 +37,10 @@ using namespace regfft;
 
 template <int N1, int NW, int LPARAM, int KC, bool GRAD, bool KRT = false, bool PER_TILE = false,
           int DBG = 0>
-__global__ void __launch_bounds__(NW * 64) fused_cols_kernel(const FusedColsArgs<float> a) {
+// (compile-time K: four waves per SIMD, i.e. at most 128 registers -- at 8 waves per workgroup that is
+// the difference between two workgroups on a CU and one, and the GradReg form at H = 256 sat at 130)
+__global__ void __launch_bounds__(NW * 64) SA_MIN_WAVES_PER_SIMD(KC == 64 ? 4 : 1)
+fused_cols_kernel(const FusedColsArgs<float> a) {
     constexpr bool PERSIST = (NW == 16 || N1 == 64) && KC == 64;   // (run-time K: scalar registers are short)
     constexpr int AOFF = 0;
     SA_ARGS_PTR_T(FusedColsArgs<float>) afix = nullptr;
@@ -263,7 +266,9 @@ __global__ void __launch_bounds__(NW * 64) cols_fwd_partial_kernel(const FusedSl
 }
 
 template <int NW, int LP, int KS, bool GRAD>
-__global__ void __launch_bounds__(NW * 64) cols_sm_apply_inv_kernel(const FusedSlabArgs<float> aa) {
+// (K = 128: at most 128 registers, as fused_cols_kernel)
+__global__ void __launch_bounds__(NW * 64) SA_MIN_WAVES_PER_SIMD(KS == 128 ? 4 : 1)
+cols_sm_apply_inv_kernel(const FusedSlabArgs<float> aa) {
     const FusedColsArgs<float> &a = aa.c;
     constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
     constexpr int LBW = ilog2(NW);
@@ -687,7 +692,9 @@ __global__ void __launch_bounds__(NW * 64) cols_slab_coop_kernel(const FusedSlab
                 rg += (gh + gw) * cabs2(xn);
                 ue = xn;
             } else {
-                ue = cmulc_add(ue, d[e], coef);
+                // (product first, then the sum: the four-instruction cmulc_add measured 2 % slower
+                // here -- 7.22 against 7.08 ms at 1024 x 1024, profiles/r06s_config3_ab.txt)
+                ue = ue + cmulc(d[e], coef);
             }
         }
         if constexpr (c == CPL - 1) {

@@ -486,7 +486,10 @@ __device__ __forceinline__ void rows_fwd_tile(AP a, int bx, int h) {
             if (half * HB + i >= N1) continue;
             v[half * HB + i] = mk<float>(sa_fma(-s2, uv[i].re, yv[i].re), sa_fma(-s2, uv[i].im, yv[i].im));
         }
-        if (half == 0) reg_fence<HB>(v, 0, token);
+        // (one call where the halves are alike: a branch on the unrolled loop's counter around the
+        // fence cost the joint V form 13 registers and 52 bytes of scratch)
+        if constexpr ((N1 & 1) == 0) reg_fence<HB>(v, half * HB, token);
+        else if (half == 0) reg_fence<HB>(v, 0, token);
         else reg_fence<N1 - HB>(v, HB, token);
     }
     spatial_to_spectral<NW, COH, N1>(v, a->twA, a->t, a->CN, a->H, a->Ks ? a->Ks : a->K, cn, k, h, pv, w, lane, L,

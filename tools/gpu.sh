@@ -33,7 +33,7 @@ for step in "$@"; do
     env) if [ "${arg#-}" != "$arg" ]; then unset "${arg#-}"; else export "$arg"; fi ;;
     sh) timeout 600 bash -c "$arg" 2>&1 | grep -v amdgpu.ids | tee $O/sh_$n.txt | tail -40 ;;
     tests)
-      timeout 2400 python -m pytest ${arg:-tests} -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -6 | tee $O/pytest_gpu_$n.txt ;;
+      timeout 2400 python -m pytest ${arg:-tests} -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -${PYTEST_TAIL:-6} | tee $O/pytest_gpu_$n.txt ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/smoke.txt ;;
     bench)

@@ -20,15 +20,22 @@ def counters(path, name):
             if len(r) >= 4 and r[1] == name}
 
 
-KERNELS = {      # bench.py's kernel names -> a substring of the dispatch name
-    'rows_fwd': 'rows_fwd_kernel<16, false, false, false>',
-    'rows_fwd_v': 'rows_fwd_kernel<16, false, true, false>',
-    'fused_cols_sm': 'fused_cols_kernel<32, 16, 1, 64, false, false, false, 0>',
-    'rows_inv_post': 'rows_inv_post_kernel<16, false, 0, false, false, 0>',
-    'rows_inv_post_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 0>',
-    'rows_inv_post_v': 'rows_inv_post_kernel<16, false, 0, false, false, 2>',
-    'rows_inv_post_v_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 2>',
+KERNELS = {      # bench.py's kernel names -> the leading template arguments of the dispatch name
+    # (later rounds appended defaulted arguments -- the points per thread, ", 32>" -- so a name
+    # matches when the arguments listed here are followed by ',' or '>')
+    'rows_fwd': 'rows_fwd_kernel<16, false, false, false',
+    'rows_fwd_v': 'rows_fwd_kernel<16, false, true, false',
+    'fused_cols_sm': 'fused_cols_kernel<32, 16, 1, 64, false, false, false, 0',
+    'rows_inv_post': 'rows_inv_post_kernel<16, false, 0, false, false, 0',
+    'rows_inv_post_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 0',
+    'rows_inv_post_v': 'rows_inv_post_kernel<16, false, 0, false, false, 2',
+    'rows_inv_post_v_emit': 'rows_inv_post_kernel<16, false, 0, true, false, 2',
 }
+
+
+def matches(sub, name):
+    i = name.find(sub)
+    return i >= 0 and name[i + len(sub):i + len(sub) + 1] in (',', '>')
 
 
 def main():
@@ -40,8 +47,8 @@ def main():
                        "(MI355X_MICROARCH.md, HBM section; confirmed in round 1 on gram_kernel, which reads "
                        "the 67.4 MB Df once and reports FETCH_SIZE*1024 = 33.7 MB)." % (', ' + tag if tag else '')}
     for key, sub in KERNELS.items():
-        fk = [v for n, v in f.items() if sub in n]
-        wk = [v for n, v in w.items() if sub in n]
+        fk = [v for n, v in f.items() if matches(sub, n)]
+        wk = [v for n, v in w.items() if matches(sub, n)]
         if fk and wk:
             out[key] = (2.0 * fk[0] + wk[0]) * 1024.0
     # optional 5th argument: the kernel statistics of the --kernel-trace --stats run of the same
@@ -54,7 +61,7 @@ def main():
         avg = {}
         for key, sub in KERNELS.items():
             for r in rows[1:]:
-                if len(r) > wi and sub in r[0]:
+                if len(r) > wi and matches(sub, r[0]):
                     avg[key] = float(r[wi]) * 1e-6
         out['_rocprof_avg_ms'] = avg
         out['_rocprof_source'] = 'rocprofv3 --kernel-trace --stats of `python bench.py` (working dispatches)'
