@@ -52,10 +52,14 @@ fused_cols_kernel(const FusedColsArgs<float> a) {
 // pass on the row spectra of u1 -- load the tile, FFT-N1, twiddle, exchange, FFT-NW -- and then, per
 // frequency f, sum_k |conj(Df[f][k]) u0f[f] + u1f[f][k]|^2 instead of a solve; nothing is written
 // back (one read pass over the spectrum).  partials[tile] carries the Parseval weight of wf.
-template <int NW, int LP, int KC>
+// N1: rows per thread -- 32, or a mixed-radix length (16 waves, LP = 1; the second exchange group partly
+// filled, as in csc_fused_body.inc)
+template <int NW, int LP, int KC, int N1 = 32>
 __global__ void __launch_bounds__(NW * 64) cols_dualres_kernel(const FusedColsArgs<float> a) {
-    constexpr int N1 = 32, H = N1 * NW, J = N1 / NW;
-    constexpr int LB1 = ilog2(N1), LBW = ilog2(NW);
+    constexpr bool MR = mr_length(N1);
+    static_assert(!MR || (NW == 16 && LP == 1), "mixed-radix heights: 16 waves, one line per group");
+    constexpr int H = N1 * NW, J = MR ? (N1 > NW ? 2 : 1) : N1 / NW;
+    constexpr int LBW = ilog2(NW);
     constexpr int FP = LP * NW, Q = J / LP;
     static_assert(J % LP == 0, "lines per group must divide the lines per thread");
     const int tid = threadIdx.x;
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(NW * 64) cols_dualres_kernel(const FusedColsAr
 #pragma unroll
         for (int h1 = 0; h1 < N1; ++h1)
             v[h1] = kv ? buf_load_cf(Tb, ko, NW * h1 * K * (int)sizeof(cf)) : zero;
-        dif<N1, false>(v, 0);
+        dif1<N1, false>(v, 0);
         reg_fence<N1>(v, 0, token);
 #pragma unroll
         for (int i = 1; i < N1; ++i) v[i] = cmul(v[i], twA[i]);
@@ -88,15 +92,18 @@ __global__ void __launch_bounds__(NW * 64) cols_dualres_kernel(const FusedColsAr
         float acc = 0.f;
         static_for<Q>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
+            const bool lv = !MR || q * FP + w < N1;      // (this wave's line of the group exists)
 #pragma unroll
             for (int fl = 0; fl < FP; ++fl) {
-                const cf x = v[brev(q * FP + fl, LB1)];
+                if (q * FP + fl >= N1) continue;
+                const cf x = v[pos1<N1>(q * FP + fl)];
                 f2 t;
                 t.x = x.re;
                 t.y = x.im;
                 LA[(fl * NW + w) * 64 + k] = t;
             }
             __syncthreads();
+            if (lv) {
             cf u[FP];
 #pragma unroll
             for (int jl = 0; jl < LP; ++jl) {
@@ -119,6 +126,7 @@ __global__ void __launch_bounds__(NW * 64) cols_dualres_kernel(const FusedColsAr
                     acc += kv ? cabs2(val) : 0.f;
                 }
             }
+            }   // lv
             __syncthreads();     // the exchange buffer is reused by the next group / tile
         });
         const double pw = (wf == 0 || ((a.W & 1) == 0 && wf == Wf - 1)) ? 1.0 : 2.0;
@@ -903,16 +911,18 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     a.stagger_groups = kColsStaggerGroups;
     a.stagger_sleeps = kColsStaggerSleeps;
     if (sp.N1 != 32) {
-        // mixed-radix heights: the plain system only (no gradient term, no per-tile operands, no
-        // multipliers stored) -- the API layer keeps everything else on the generic chain
-        SA_REQUIRE(!a.per_tile && !a.coef_out && !(a.Kv == 64 && a.K > 64),
+        // mixed-radix heights: the plain system, the gradient term, or the multipliers stored (mask
+        // decoupling); no per-tile operands -- the API layer keeps everything else on the generic chain
+        SA_REQUIRE(!a.per_tile && !(a.Kv == 64 && a.K > 64) && !(a.coef_out && a.g1t),
                    "mixed-radix heights: the plain and the gradient-regularised column pass only");
-        const bool k64 = a.K == 64, grad = a.g1t != nullptr;
+        const bool k64 = a.K == 64, grad = a.g1t != nullptr, krt = a.coef_out != nullptr;
         switch (sp.N1) {
 #define SA_MR_CASE(n)                                                                     \
     case n:                                                                               \
         if (grad) k64 ? launch_fused_inst<n, 16, 1, 64, true>(st, a, ntiles)              \
                       : launch_fused_inst<n, 16, 1, 0, true>(st, a, ntiles);              \
+        else if (krt) k64 ? launch_fused_inst<n, 16, 1, 64, false, true>(st, a, ntiles)   \
+                          : launch_fused_inst<n, 16, 1, 0, false, true>(st, a, ntiles);   \
         else k64 ? launch_fused_inst<n, 16, 1, 64, false>(st, a, ntiles)                  \
                  : launch_fused_inst<n, 16, 1, 0, false>(st, a, ntiles);                  \
         break;
@@ -929,24 +939,33 @@ template <> int64_t launch_fused_cols<float>(hipStream_t st, const FusedColsArgs
     SA_HIP(hipGetLastError());
     return ntiles;
 }
-template <int NW, int LP, int KC> static void launch_dualres_inst(hipStream_t st, const FusedColsArgs<float> &a) {
+template <int NW, int LP, int KC, int N1 = 32>
+static void launch_dualres_inst(hipStream_t st, const FusedColsArgs<float> &a) {
     static PerDeviceOnce attr_set;
     if (attr_set.first()) {
-        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_dualres_kernel<NW, LP, KC>),
+        SA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cols_dualres_kernel<NW, LP, KC, N1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_lds_bytes(NW, LP)));
     }
     const int64_t ntiles = (int64_t)(a.W / 2 + 1) * a.CN;
     const int64_t cus = current_device_cus();
     // (one 16-wave workgroup fills a CU; two 8-wave, four 4-wave ones share it)
     const int64_t grid = std::min<int64_t>(ntiles, cus * (16 / NW));
-    hipLaunchKernelGGL((cols_dualres_kernel<NW, LP, KC>), dim3((unsigned)grid), dim3(NW * 64),
+    hipLaunchKernelGGL((cols_dualres_kernel<NW, LP, KC, N1>), dim3((unsigned)grid), dim3(NW * 64),
                        fused_lds_bytes(NW, LP), st, a);
 }
 template <> int64_t launch_cols_dualres<float>(hipStream_t st, const FusedColsArgs<float> &a) {
     SA_REQUIRE(fused_cols_supported<float>(a.H, a.K), "shape not handled by the fused column kernel");
     const FusedSplit sp = fused_split(a.H, a.K);
     const bool k64 = a.K == 64 && (a.Ks == 0 || a.Ks == 64);
-    if (sp.NW == 4) k64 ? launch_dualres_inst<4, 4, 64>(st, a) : launch_dualres_inst<4, 4, 0>(st, a);
+    if (sp.N1 != 32) {
+        switch (sp.N1) {
+#define SA_MR_CASE(n) \
+    case n: k64 ? launch_dualres_inst<16, 1, 64, n>(st, a) : launch_dualres_inst<16, 1, 0, n>(st, a); break;
+        SA_MR_LENGTHS(SA_MR_CASE)
+#undef SA_MR_CASE
+        default: SA_REQUIRE(false, "height not handled by the mixed-radix column kernel");
+        }
+    } else if (sp.NW == 4) k64 ? launch_dualres_inst<4, 4, 64>(st, a) : launch_dualres_inst<4, 4, 0>(st, a);
     else if (sp.NW == 8) k64 ? launch_dualres_inst<8, 2, 64>(st, a) : launch_dualres_inst<8, 2, 0>(st, a);
     else k64 ? launch_dualres_inst<16, 1, 64>(st, a) : launch_dualres_inst<16, 1, 0>(st, a);
     SA_HIP(hipGetLastError());

@@ -148,7 +148,7 @@ void launch_rows_fwd_mr(hipStream_t st, const RowsFwdArgs<float> &a_in) {
 int64_t launch_rows_inv_post_mr(hipStream_t st, const RowsPostArgs<float> &a_in) {
     RowsPostArgs<float> a = a_in;
     SA_REQUIRE(rows_mr_width(a.W) && a.K % 2 == 0 && a.H <= 65535, "shape not handled by the mixed-radix row kernels");
-    SA_REQUIRE(!a.emit_u && !a.t_odd, "mixed-radix widths: no mask decoupling, no striped spectrum");
+    SA_REQUIRE(!a.t_odd, "mixed-radix widths: no striped spectrum");
     const bool joint = a.flags & F_JOINT;
     if (joint) {
         SA_REQUIRE(!a.v_in || a.v_out, "a V-form input needs a V-form output");

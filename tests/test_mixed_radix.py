@@ -197,7 +197,7 @@ def test_weights_and_boundary_options_on_the_mixed_radix_kernels(backend):
 
 
 def test_other_options_take_the_generic_chain(backend):
-    """LinSolveCheck (and multi-channel dictionaries, K > 64, mask decoupling, consensus) at a
+    """LinSolveCheck (and multi-channel dictionaries, the consensus dictionary update) at a
     mixed-radix size: served by the generic chain of the handle -- the results are those of a handle
     that never had the register kernels (SPORCO_AMD_UNFUSED=1), bit for bit; the staged step methods
     run their X-step on the register kernels, FISTA its whole iteration (tested above)."""
@@ -380,3 +380,54 @@ def test_gradreg_and_addmasksim_at_mixed_radix_sizes(backend, H, W, K, N):
             assert rel_l2(b.cbpdn.Y, ref['Y']) < 1e-4
             for f in fields:
                 assert rel_l2(getattr(b.getitstat(), f), ref[f]) < 1e-3, f
+
+
+MD_OPTS = {'default': {}, 'options': {'NonNegCoef': True, 'NoBndryCross': True, 'AuxVarObj': True, 'RelaxParam': 1.5,
+                                      'AutoRho': {'Enabled': True, 'Period': 2}}}
+
+
+@pytest.mark.parametrize('H,W,K,N,case', [(160, 192, 4, 1, 'default'),
+                                          pytest.param(400, 240, 6, 2, 'default', marks=pytest.mark.gpu),
+                                          pytest.param(400, 240, 6, 2, 'options', marks=pytest.mark.gpu),
+                                          pytest.param(320, 224, 30, 1, 'default', marks=pytest.mark.gpu),
+                                          pytest.param(384, 480, 64, 2, 'options', marks=pytest.mark.gpu)])
+def test_mask_decoupling_at_mixed_radix_sizes(backend, H, W, K, N, case):
+    """ConvBPDNMaskDcpl (sporco/admm/cbpdn.py:1927-2175) at mixed-radix sizes: the X-step with the
+    block-0 spectrum in the signal's place and its multipliers stored (fused_cols), the block-1
+    epilogue that also emits the row spectra of the new dual variable, and the dual residual's
+    read-only column pass (cols_dualres) -- against the generic chain of the same library (pinned
+    by the reference's fixtures, tests/test_maskdcpl.py) and, where the host finishes it, the
+    float64 oracle."""
+    from oracle import cbpdn_oracle as orc
+    from sporco_amd.admm import cbpdn
+    rng = np.random.RandomState(H + K)
+    D = rng.randn(4, 4, K).astype(np.float32)
+    S = rng.randn(H, W, N).astype(np.float32)
+    M = (rng.rand(H, W, N) > 0.3).astype(np.float32)
+    cls = cbpdn.ConvBPDNMaskDcpl
+    iters = 4 if backend == 'hostsim' else 6
+    optd = dict(MD_OPTS[case], MaxMainIter=iters)
+
+    def run(generic):
+        with env(**({'SPORCO_AMD_MD_GENERIC': '1'} if generic else {})):
+            b = cls(D, S, 0.1, M, cls.Options(optd))
+            b._dev.profile(True)
+            Y1 = b.solve()
+        return b, Y1, set(kernel_counts(b))
+
+    bf, Yf, pf = run(False)
+    bg, Yg, pg = run(True)
+    assert {'rows_fwd', 'fused_cols_sm', 'rows_inv_post', 'setcoef_cols'} <= pf and 'sm_solve' not in pf
+    assert 'sm_solve' in pg and 'fused_cols_sm' not in pg
+    assert rel_l2(Yf, Yg) < 1e-4 and rel_l2(bf.X, bg.X) < 1e-4 and rel_l2(bf.U, bg.U) < 1e-4
+    assert rel_l2(bf.var_y0(), bg.var_y0()) < 1e-3
+    assert rel_l2(bf.reconstruct(), bg.reconstruct()) < 1e-4
+    for f in TRACES:
+        assert rel_l2(getattr(bf.getitstat(), f), getattr(bg.getitstat(), f)) < 1e-4, f
+    if case == 'default' and H * W * K * N <= 2.5e6:
+        r = orc.admm_cbpdn_maskdcpl(D.reshape(4, 4, 1, 1, K).astype(np.float64),
+                                    S.reshape(H, W, 1, N, 1).astype(np.float64), 0.1,
+                                    M.reshape(H, W, 1, N, 1).astype(np.float64), maxiter=iters)
+        assert rel_l2(Yf, r['Y1']) < 1e-4
+        for f in ('ObjFun', 'PrimalRsdl', 'DualRsdl', 'Rho'):
+            assert rel_l2(getattr(bf.getitstat(), f), r[f]) < 1e-4, f
