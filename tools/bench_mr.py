@@ -29,6 +29,8 @@ def solver(D, S, unfused, iters, cls=ac.ConvBPDN):
 
 
 for (H, W, K, N) in SHAPES:
+    if ONLY == "none":
+        break
     if ONLY not in '%dx%d K=%d' % (H, W, K):
         continue
     rng = np.random.RandomState(1)
@@ -110,3 +112,42 @@ def fista_and_cdl():
 
 if len(sys.argv) > 2 and sys.argv[2] == 'pgm':
     fista_and_cdl()
+
+
+# ---- mask decoupling at mixed-radix sizes (api_maskdcpl.inc on csc_rows_mr / csc_fused) ----------
+def mask_decoupling():
+    for (H, W, K, N) in [(480, 320, 64, 8), (384, 384, 32, 8), (240, 320, 64, 8)]:
+        rng = np.random.RandomState(2)
+        D = rng.randn(8, 8, K).astype(np.float32)
+        D /= np.sqrt(np.sum(D ** 2, axis=(0, 1), keepdims=True))
+        S = rng.randn(H, W, N).astype(np.float32)
+        M = (rng.rand(H, W, N) > 0.3).astype(np.float32)
+        out = {'config': 'admm.cbpdn.ConvBPDNMaskDcpl %dx%d K=%d N=%d float32, default options' % (H, W, K, N)}
+        ys = {}
+        for name, generic in (('register', False), ('generic', True)):
+            if generic:
+                os.environ['SPORCO_AMD_MD_GENERIC'] = '1'
+            try:
+                cls = ac.ConvBPDNMaskDcpl
+                b = cls(D, S, 0.05, M, cls.Options({'MaxMainIter': 5, 'RelStopTol': 0.0}))
+                b._return_min = False
+                b.solve(); b._dev.sync()
+                ys[name] = np.asarray(b.Y, np.float64)
+                b.opt['MaxMainIter'] = 40
+                t0 = time.perf_counter(); b.solve(); b._dev.sync()
+                out[name + '_it_per_s'] = 40 / (time.perf_counter() - t0)
+                b._dev.profile(True)
+                b.opt['MaxMainIter'] = 10
+                b.solve(); b._dev.sync()
+                out[name + '_kernel_ms'] = {k: round(v[0] / max(v[1], 1), 4) for k, v in b._dev.profile_read().items() if v[1]}
+                b._dev.profile(False)
+                del b
+            finally:
+                os.environ.pop('SPORCO_AMD_MD_GENERIC', None)
+        out['speedup'] = out['register_it_per_s'] / out['generic_it_per_s']
+        out['rel_l2_Y_register_vs_generic'] = float(np.linalg.norm(ys['register'] - ys['generic']) / np.linalg.norm(ys['generic']))
+        print(json.dumps(out), flush=True)
+
+
+if len(sys.argv) > 2 and sys.argv[2] == 'md':
+    mask_decoupling()
