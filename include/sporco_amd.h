@@ -171,9 +171,10 @@ int sporco_amd_csc_stream(sporco_amd_csc_t h, void **stream);
 /* Which kernels serve this handle's shape: *out = 1 when the fused path named by
  * `what` is active (float32, H and/or W in {128, 256, 512}, even K <= 64 -- or even
  * 64 < K <= 256, where the column pass runs as cooperating 64-filter slab workgroups; since
- * round 6 also H, W in 16 x {10, 12, 14, 15, 18, 20, 21, 24, 25, 27, 28, 30} with K <= 64, for the
- * ADMM ConvBPDN calls with scalar or array L1Weight / NonNegCoef / NoBndryCross: such a handle
- * serves every other flag set on its generic chain), else 0. */
+ * round 6 also H, W in 16 x {10, 12, 14, 15, 18, 20, 21, 24, 25, 27, 28, 30}, K <= 256, for the
+ * ADMM ConvBPDN / Joint / GradReg / AddMaskSim / mask-decoupling calls, the fused PGM iteration and
+ * the tile-major dictionary-update gradient with K <= 64: such a handle serves LinSolveCheck,
+ * multi-channel dictionaries and the consensus update on its generic chain), else 0. */
 #define SPORCO_AMD_QUERY_FUSED_COLS 0  /* register-resident column FFT + Sherman-Morrison */
 #define SPORCO_AMD_QUERY_FUSED_ROWS 1  /* three-launch ADMM iteration                      */
 #define SPORCO_AMD_QUERY_FUSED_PGM 2   /* fused PGM iteration / tile-major D-step               */

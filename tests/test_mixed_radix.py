@@ -390,6 +390,9 @@ MD_OPTS = {'default': {}, 'options': {'NonNegCoef': True, 'NoBndryCross': True, 
                                           pytest.param(400, 240, 6, 2, 'default', marks=pytest.mark.gpu),
                                           pytest.param(400, 240, 6, 2, 'options', marks=pytest.mark.gpu),
                                           pytest.param(320, 224, 30, 1, 'default', marks=pytest.mark.gpu),
+                                          # (the remaining points-per-thread counts: 18, 21 and 27, 28)
+                                          pytest.param(288, 336, 8, 1, 'default', marks=pytest.mark.gpu),
+                                          pytest.param(432, 448, 8, 1, 'options', marks=pytest.mark.gpu),
                                           pytest.param(384, 480, 64, 2, 'options', marks=pytest.mark.gpu)])
 def test_mask_decoupling_at_mixed_radix_sizes(backend, H, W, K, N, case):
     """ConvBPDNMaskDcpl (sporco/admm/cbpdn.py:1927-2175) at mixed-radix sizes: the X-step with the
