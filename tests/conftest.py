@@ -89,6 +89,10 @@ HOSTSIM_LIB = os.path.join(HOSTSIM_DIR, 'libsporco_amd_hostsim.so')
 
 
 def build_hostsim():
+    # (SPORCO_AMD_HOSTSIM_LIB: a prebuilt simulator library to use instead -- the AddressSanitizer
+    # build of tests/hostsim/Makefile's `asan` target)
+    if os.environ.get('SPORCO_AMD_HOSTSIM_LIB'):
+        return os.path.abspath(os.environ['SPORCO_AMD_HOSTSIM_LIB'])
     import subprocess
     subprocess.check_call(['make', '-s', '-C', HOSTSIM_DIR, '-j8'])
     return HOSTSIM_LIB
