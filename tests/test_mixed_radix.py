@@ -102,7 +102,11 @@ def test_reference_fixtures_at_mixed_radix_shapes(gpu_backend, name):
                                      pytest.param(320, 512, 8, 2, marks=pytest.mark.gpu),
                                      pytest.param(128, 384, 6, 3, marks=pytest.mark.gpu),
                                      pytest.param(384, 256, 62, 1, marks=pytest.mark.gpu),
-                                     pytest.param(320, 320, 7, 2, marks=pytest.mark.gpu)])
+                                     pytest.param(320, 320, 7, 2, marks=pytest.mark.gpu),
+                                     # three and four cooperating slabs (K = 192, 256), the minimal K
+                                     pytest.param(320, 240, 192, 1, marks=pytest.mark.gpu),
+                                     pytest.param(240, 400, 256, 1, marks=pytest.mark.gpu),
+                                     pytest.param(160, 480, 2, 1, marks=pytest.mark.gpu)])
 def test_mixed_radix_sizes_vs_oracle_and_generic_chain(backend, H, W, K, N):
     from oracle import cbpdn_oracle as orc
     from sporco_amd.admm import cbpdn
