@@ -560,6 +560,27 @@ def run_next_rows(device, tiny=False):
                 'value': rate(b, b._dev), 'unit': 'iterations/s',
                 'path': 'register-resident kernels' if b._dev.uses_fused_rows() else 'generic chain'}
 
+    def leg_maskdcpl_mr():
+        # mask decoupling at a mixed-radix shape (round 6), and the generic chain of the same library
+        h, w = (48, 40) if tiny else (480, 320)
+        r2 = np.random.RandomState(2)
+        Sg = r2.randn(h, w, N8).astype(np.float32)
+        Wg = (r2.rand(h, w, N8) > 0.3).astype(np.float32)
+        b = ac.ConvBPDNMaskDcpl(D, Sg, 0.05, Wg, ac.ConvBPDNMaskDcpl.Options(o0), device=device)
+        reg = bool(b._dev.uses_fused_rows() and b._dev.uses_fused_cols())
+        out = {'workload': 'admm.cbpdn.ConvBPDNMaskDcpl %dx%d K=%d N=%d f32' % (h, w, K, N8),
+               'value': rate(b, b._dev), 'unit': 'iterations/s',
+               'path': 'register-resident kernels, mixed-radix lengths' if reg else 'generic chain'}
+        if reg:
+            del b
+            os.environ['SPORCO_AMD_MD_GENERIC'] = '1'
+            try:
+                b = ac.ConvBPDNMaskDcpl(D, Sg, 0.05, Wg, ac.ConvBPDNMaskDcpl.Options(o0), device=device)
+                out['generic_chain_value'] = rate(b, b._dev)
+            finally:
+                os.environ.pop('SPORCO_AMD_MD_GENERIC', None)
+        return out
+
     def leg_pgm_mask():
         b = pc.ConvBPDNMask(D, S, 0.05, Wm, pc.ConvBPDNMask.Options(dict(o0, L=500.0)), device=device)
         return {'workload': 'pgm.cbpdn.ConvBPDNMask %dx%d K=%d N=%d f32' % (H, H, K, N8),
@@ -600,7 +621,8 @@ def run_next_rows(device, tiny=False):
             return out
         return go
 
-    legs = {'maskdcpl': leg_maskdcpl, 'pgm_mask': leg_pgm_mask, 'pgm_backtrack_robust': leg_pgm_robust}
+    legs = {'maskdcpl': leg_maskdcpl, 'maskdcpl_480x320_k64_f32': leg_maskdcpl_mr, 'pgm_mask': leg_pgm_mask,
+            'pgm_backtrack_robust': leg_pgm_robust}
     if tiny:
         legs['generic_48x40_k8_f32'] = leg_generic(48, 40, 8, np.float32)
         legs['generic_32x32_k8_f64'] = leg_generic(32, 32, 8, np.float64)
