@@ -504,7 +504,8 @@ def run_config5(device, tiny=False):
                        'options (BASELINE configs[4])' % (H, W, K, N),
            'steps': steps, 'warmup': warm, 'ms_per_step': ms, 'value': steps / el,
            'unit': 'outer iterations/s', 'parity': par, 'roofline': roofline_of(tab),
-           'iteration': iteration_summary(tab, 10, ms, 56 * H * W * N * K), 'kernels': tab}
+           'iteration': iteration_summary(tab, 10, ms, 56 * H * W * N * K), 'kernels': tab,
+           'placement': dev.placement_report()}
     del d
     return out
 
