@@ -24,7 +24,7 @@ for tag in "$@"; do
     SPORCO_AMD_LIBRARY=$lib python bench.py $Q 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-out = {'lib': '$tag', 'value': round(d['value'], 1), 'steady': round(d['steady_state']['value'], 1)}
+out = {'lib': '$tag', 'value': round(d['value'], 1), 'steady': round(d['steady_state']['value'], 1), 'epilogue_ms': d['roofline']['avg_kernel_ms'], 'placement': d['roofline']['placement_compact']}
 for k, v in d['configs'].items():
     out[k] = round(v['value'], 2)
     out[k + '_kern'] = {n: x['avg_ms'] for n, x in v['kernels'].items() if x['avg_ms'] > 0.2}
