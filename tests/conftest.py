@@ -27,8 +27,10 @@ def _parallel_cpu_run(config):
         return
     if (config.option.markexpr or '').strip() != 'not gpu':
         return
-    if getattr(config.option, 'numprocesses', None) is not None or \
-            getattr(config.option, 'collectonly', False):
+    if getattr(config.option, 'collectonly', False):
+        return
+    if getattr(config.option, 'numprocesses', None) is not None:
+        build_hostsim()      # (an explicit -n: the workers must still not race for the build)
         return
     try:
         n = int(os.environ.get('SPORCO_AMD_TEST_WORKERS', min(8, os.cpu_count() or 1)))
